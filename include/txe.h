@@ -1,0 +1,121 @@
+/* libtxe -- C ABI of the MI355X (gfx950) kernels behind TaxoExpan's propagation / readout / match path.
+ *
+ * The reference has no FFI of its own: the path sits behind Python classes in model/model_zoo.py that call DGL 0.4
+ * and torch.  Each entry point below names the reference lines it replaces; taxoexpan_amd/model_zoo.py binds them
+ * with ctypes (see INTEGRATION.md for the stub a reference maintainer would add).
+ *
+ * Conventions
+ *   - every pointer is a BORROWED DEVICE pointer (fp32 / int32, contiguous unless a row stride `ld_*` is given, in
+ *     elements); nothing is allocated, freed or synchronised inside; all work is enqueued on `stream`
+ *     (a hipStream_t passed as void*);  workspaces are supplied by the caller (size from the *_ws_bytes functions)
+ *   - return value: 0 = TXE_OK, <0 = error (TXE_ERR_ARG -1, TXE_ERR_LAUNCH -2, TXE_ERR_WORKSPACE -3); never throws
+ *   - re-entrant, no global state
+ *   - graph structure: destination-sorted CSR  (rowptr_in[N+1], col_src[E])  and source-sorted CSR
+ *     (rowptr_out[N+1], col_dst[E], pos_out[E] = index of that edge in the destination-sorted order); per-edge
+ *     arrays (alpha, dz) live in destination-sorted order
+ *   - dropout: counter based, keep(seed, index) = splitmix64 hash (taxoexpan_amd/csrc/txe_common.h, restated for
+ *     tests in taxoexpan_amd/rng.py); index = row*cols+col for features, csr_position*H+head for attention
+ */
+#ifndef TXE_H
+#define TXE_H
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TXE_OK 0
+#define TXE_ERR_ARG -1
+#define TXE_ERR_LAUNCH -2
+#define TXE_ERR_WORKSPACE -3
+
+/* ---- GATLayer dense part: model_zoo.py:82-85 (feat_drop, fc, a1, a2) with the PGAT concat of :214-215 -------------
+ * h [N][Kh] (row stride ld_h), pos [N] in [0,vocab), P [vocab][Pd] (Pd = 0 -> plain GAT, :186), W [H*D][Kh+Pd],
+ * attn_l/attn_r [H*D].  Writes ft [N][H*D] and a_ext [N][2H] = [a1 | a2].  ws >= 2H*(Kh+Pd) floats. */
+size_t txe_gat_project_ws_bytes(int n_nodes, int Kh, int Pd, int H, int D, int vocab);
+int txe_gat_project_fwd(const float* h, long long ld_h, int n_nodes, int Kh, const int* pos, const float* P, int Pd,
+                        const float* W, const float* attn_l, const float* attn_r, int H, int D, float feat_drop_p,
+                        unsigned long long seed, float* ft, float* a_ext, void* ws, size_t ws_bytes, void* stream);
+/* backward of the above given d_ft [N][H*D], d_a_ext [N][2H].  Writes dW, d_attn_l, d_attn_r, dP [vocab][Pd] and, if
+ * d_h != NULL, d_h [N][Kh] (x leaky'(act_src) when act_src != NULL: backward of the F.leaky_relu of model_zoo.py:216
+ * that produced h).  ws >= txe_gat_project_ws_bytes. */
+int txe_gat_project_bwd(const float* h, long long ld_h, int n_nodes, int Kh, const int* pos, const float* P, int Pd, int vocab,
+                        const float* W, const float* attn_l, const float* attn_r, int H, int D, float feat_drop_p,
+                        unsigned long long seed, const float* d_ft, const float* d_a_ext, float* d_h, long long ld_dh,
+                        const float* act_src, long long ld_act, float act_slope, float* dW, float* d_attn_l, float* d_attn_r,
+                        float* dP, void* ws, size_t ws_bytes, void* stream);
+
+/* ---- GATLayer message/reduce: model_zoo.py:90-95,106-114 (edge_attention, edge_softmax, attn_drop, update_all) -----
+ * out_mode 0: out = aggregated features; 1: out = leaky_relu(aggregated, act_slope) (model_zoo.py:216 fused).
+ * alpha [E][H] (post-softmax, pre-dropout; NULL in inference). */
+int txe_gat_aggregate_fwd(const int* rowptr_in, const int* col_src, int n_nodes, const float* ft, long long ld_ft,
+                          const float* a_src, const float* a_dst, int ld_a, int H, int D, float attn_slope, float attn_drop_p,
+                          unsigned long long seed, int out_mode, float act_slope, float* out, long long ld_out, float* alpha,
+                          void* stream);
+/* d_pre = gradient w.r.t. the PRE-activation aggregated output.  Writes d_ft [N][H*D], d_a_src/d_a_dst [N][H]
+ * (row stride ld_da).  dz_ws: E*H floats of scratch. */
+int txe_gat_aggregate_bwd(const int* rowptr_in, const int* col_src, const int* rowptr_out, const int* col_dst,
+                          const int* pos_out, int n_nodes, const float* ft, long long ld_ft, const float* a_src,
+                          const float* a_dst, int ld_a, int H, int D, float attn_slope, float attn_drop_p,
+                          unsigned long long seed, const float* alpha, const float* d_pre, long long ld_dpre, float* d_ft,
+                          long long ld_dft, float* d_a_src, float* d_a_dst, int ld_da, float* dz_ws, void* stream);
+int txe_leaky_relu_bwd(const float* d_out, const float* out_act, float slope, long long n, float* d_pre, void* stream);
+/* `.mean(1)` over heads of the output layer, model_zoo.py:219 */
+int txe_head_mean_fwd(const float* x, int H, int D, long long n_rows, float* y, void* stream);
+int txe_head_mean_bwd(const float* dy, int H, int D, long long n_rows, float* dx, void* stream);
+
+/* ---- GCNLayer: model_zoo.py:34-50 and the norm of :157-161 ------------------------------------------------------ */
+size_t txe_gcn_project_ws_bytes(int n_nodes, int Kh, int Pd, int Fo, int vocab);
+int txe_gcn_project_fwd(const float* h, long long ld_h, int n_nodes, int Kh, const int* pos, const float* P, int Pd,
+                        const float* W, int Fo, float drop_p, unsigned long long seed, float* hw, void* stream);
+int txe_gcn_project_bwd(const float* h, long long ld_h, int n_nodes, int Kh, const int* pos, const float* P, int Pd, int vocab,
+                        const float* W, int Fo, float drop_p, unsigned long long seed, const float* d_hw, float* d_h,
+                        long long ld_dh, const float* act_src, long long ld_act, float act_slope, float* dW, float* dP,
+                        void* ws, size_t ws_bytes, void* stream);
+int txe_gcn_norm(const int* rowptr_in, int n_nodes, float* norm, void* stream);
+int txe_gcn_aggregate_fwd(const int* rowptr_in, const int* col_src, int n_nodes, const float* hw, long long ld_hw,
+                          const float* norm, const float* bias, int has_act, float act_slope, int F, float* out, long long ld_out,
+                          void* stream);
+size_t txe_gcn_aggregate_bwd_ws_bytes(int n_nodes, int F);
+int txe_gcn_aggregate_bwd(const int* rowptr_out, const int* col_dst, int n_nodes, const float* d_pre, long long ld_dpre,
+                          const float* norm, int F, float* d_hw, long long ld_dhw, float* d_bias, void* ws, size_t ws_bytes,
+                          void* stream);
+
+/* ---- readouts: MeanReadout model_zoo.py:231-232 (pw = NULL), WeightedMeanReadout :240-242 ------------------------- */
+int txe_readout_fwd(const int* graph_off, int G, const float* h, long long ld_h, const int* pos, const float* pw, int D,
+                    float* hg, float* wsum, void* stream);
+int txe_readout_bwd(const int* graph_off, int G, const float* h, long long ld_h, const int* pos, const float* pw, int vocab,
+                    int D, const float* hg, const float* wsum, const float* d_hg, float* d_h, long long ld_dh, float* d_pw,
+                    float* dpw_ws, void* stream);
+
+/* ---- matchers: BIM model_zoo.py:313, LBM :328 (apply_exp) ------------------------------------------------------- */
+int txe_bilinear_project(const float* e1, long long ld_e1, int G, int l, const float* W, int r, float* U, void* stream);
+int txe_bilinear_pair_fwd(const float* e1, long long ld_e1, const float* e2, long long ld_e2, int G, int l, int r,
+                          const float* W, int apply_exp, float* U, float* s, void* stream);
+size_t txe_bilinear_pair_bwd_ws_bytes(int G, int l, int r);
+int txe_bilinear_pair_bwd(const float* e1, long long ld_e1, const float* e2, long long ld_e2, int G, int l, int r,
+                          const float* W, int apply_exp, const float* U, const float* s, const float* ds, float* d_e1,
+                          long long ld_de1, float* d_e2, long long ld_de2, float* dW, void* ws, size_t ws_bytes, void* stream);
+/* ---- all-candidate scoring loop: test_fast.py:116-123 / infer.py:95-99.  U = txe_bilinear_project(hg, W) once, then
+ * per query block S[q][g] = match(hg[g], Q[q]) for every candidate g. */
+int txe_score_block(const float* Q, long long ld_q, int nq, const float* U, int G, int r, int apply_exp, float* S,
+                    long long ld_s, void* stream);
+
+/* ---- rank extraction of the scoring loop: test_fast.py:16-22 + model/metric.py:7-31 (strict inequalities, the
+ * query's other positives excluded).  pos_off [nq+1], pos_idx: candidate columns of each query's true parents. */
+int txe_rank_block(const float* S, long long ld_s, int nq, int G, const int* pos_off, const int* pos_idx, int* ranks,
+                   int larger_is_better, void* ws_unused, void* stream);
+
+/* ---- graph structure: the batched-egonet COO of dgl.batch (data_loaders.py:25; edge order dataset.py:431-435) to the
+ * two CSR views the kernels read (stable: in-edges stay in edge-id order). */
+size_t txe_build_csr_ws_bytes(int n_nodes, int n_edges);
+int txe_build_csr(const int* src, const int* dst, int n_nodes, int n_edges, int* rowptr_in, int* col_src, int* eid_in,
+                  int* rowptr_out, int* col_dst, int* pos_out, void* ws, size_t ws_bytes, void* stream);
+
+/* host-side evaluation of the counter-based dropout hash the kernels inline (uniform in [0,1)); keep = u >= p */
+float txe_dropout_uniform_host(unsigned long long seed, unsigned long long idx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TXE_H */

@@ -1,0 +1,84 @@
+"""ctypes binding of libtxe.so (include/txe.h).  There is NO fallback: if the HIP library cannot be loaded the
+first compute call raises -- a GPU box must never silently run something else."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libtxe.so")
+
+P, I, L, F, U64, SZ = C.c_void_p, C.c_int, C.c_longlong, C.c_float, C.c_ulonglong, C.c_size_t
+
+# name -> (restype, argtypes); mirrors include/txe.h one to one (tests/test_cabi.py checks the header against this)
+SIGNATURES = {
+    "txe_gat_project_ws_bytes": (SZ, [I, I, I, I, I, I]),
+    "txe_gat_project_fwd": (I, [P, L, I, I, P, P, I, P, P, P, I, I, F, U64, P, P, P, SZ, P]),
+    "txe_gat_project_bwd": (I, [P, L, I, I, P, P, I, I, P, P, P, I, I, F, U64, P, P, P, L, P, L, F, P, P, P, P, P, SZ, P]),
+    "txe_gat_aggregate_fwd": (I, [P, P, I, P, L, P, P, I, I, I, F, F, U64, I, F, P, L, P, P]),
+    "txe_gat_aggregate_bwd": (I, [P, P, P, P, P, I, P, L, P, P, I, I, I, F, F, U64, P, P, L, P, L, P, P, I, P, P]),
+    "txe_leaky_relu_bwd": (I, [P, P, F, L, P, P]),
+    "txe_head_mean_fwd": (I, [P, I, I, L, P, P]),
+    "txe_head_mean_bwd": (I, [P, I, I, L, P, P]),
+    "txe_gcn_project_ws_bytes": (SZ, [I, I, I, I, I]),
+    "txe_gcn_project_fwd": (I, [P, L, I, I, P, P, I, P, I, F, U64, P, P]),
+    "txe_gcn_project_bwd": (I, [P, L, I, I, P, P, I, I, P, I, F, U64, P, P, L, P, L, F, P, P, P, SZ, P]),
+    "txe_gcn_norm": (I, [P, I, P, P]),
+    "txe_gcn_aggregate_fwd": (I, [P, P, I, P, L, P, P, I, F, I, P, L, P]),
+    "txe_gcn_aggregate_bwd_ws_bytes": (SZ, [I, I]),
+    "txe_gcn_aggregate_bwd": (I, [P, P, I, P, L, P, I, P, L, P, P, SZ, P]),
+    "txe_readout_fwd": (I, [P, I, P, L, P, P, I, P, P, P]),
+    "txe_readout_bwd": (I, [P, I, P, L, P, P, I, I, P, P, P, P, L, P, P, P]),
+    "txe_bilinear_project": (I, [P, L, I, I, P, I, P, P]),
+    "txe_bilinear_pair_fwd": (I, [P, L, P, L, I, I, I, P, I, P, P, P]),
+    "txe_bilinear_pair_bwd_ws_bytes": (SZ, [I, I, I]),
+    "txe_bilinear_pair_bwd": (I, [P, L, P, L, I, I, I, P, I, P, P, P, P, L, P, L, P, P, SZ, P]),
+    "txe_score_block": (I, [P, L, I, P, I, I, I, P, L, P]),
+    "txe_build_csr_ws_bytes": (SZ, [I, I]),
+    "txe_build_csr": (I, [P, P, I, I, P, P, P, P, P, P, P, SZ, P]),
+    "txe_rank_block": (I, [P, L, I, I, P, P, P, I, P, P]),
+    "txe_dropout_uniform_host": (F, [U64, U64]),
+}
+
+_ERR = {-1: "TXE_ERR_ARG", -2: "TXE_ERR_LAUNCH", -3: "TXE_ERR_WORKSPACE"}
+
+_lib = None
+
+
+class TxeError(RuntimeError):
+    pass
+
+
+def load():
+    """dlopen libtxe.so and declare prototypes.  Raises if the library is absent (build it with
+    `python taxoexpan_amd/csrc/build.py` or `python -c 'import __graft_entry__ as g; g.build()'`)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise TxeError(f"HIP extension missing: {LIB_PATH} not built -- run taxoexpan_amd/csrc/build.py "
+                       "(there is no CPU fallback)")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the .so does not export a declared symbol
+        fn.restype, fn.argtypes = res, args
+    _lib = lib
+    return lib
+
+
+def call(name, *args):
+    fn = getattr(load(), name)
+    rc = fn(*args)
+    if SIGNATURES[name][0] is I and rc != 0:
+        raise TxeError(f"{name} failed: {_ERR.get(rc, rc)}")
+    return rc
+
+
+def ptr(t):
+    """device pointer of a (contiguous) tensor, or None"""
+    if t is None:
+        return None
+    return t.data_ptr()
+
+
+def stream_ptr():
+    import torch
+    return torch.cuda.current_stream().cuda_stream

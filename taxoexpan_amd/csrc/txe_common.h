@@ -1,0 +1,65 @@
+// Shared device/host helpers for the TaxoExpan MI355X (gfx950) kernels.
+// Wavefront = 64 lanes everywhere in this library.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define TXE_OK 0
+#define TXE_ERR_ARG -1
+#define TXE_ERR_LAUNCH -2
+#define TXE_ERR_WORKSPACE -3
+
+#define TXE_WAVE 64
+#define TXE_NUM_XCD 8
+
+#define TXE_CHECK_LAUNCH()                                  \
+    do {                                                    \
+        hipError_t e__ = hipGetLastError();                 \
+        if (e__ != hipSuccess) return TXE_ERR_LAUNCH;       \
+    } while (0)
+
+namespace txe {
+
+// MI355X dispatches workgroup b to XCD (b % 8); each XCD has a private 4 MiB L2.  Remap the
+// hardware block id so that every XCD works on ONE contiguous range of logical blocks: neighbouring
+// logical blocks (nodes of the same egonet, tiles that share an operand panel) then share an L2.
+// Bijective for every nblocks (MI355X_MICROARCH.md "XCD swizzle must be bijective").
+__device__ __forceinline__ int xcd_remap(int bid, int nblocks) {
+    const int q = nblocks / TXE_NUM_XCD, r = nblocks % TXE_NUM_XCD;
+    const int xcd = bid % TXE_NUM_XCD, idx = bid / TXE_NUM_XCD;
+    const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + idx;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// Counter-based dropout: keep(seed, idx) is a pure function, so forward, backward and the host-side
+// test restatement (taxoexpan_amd/rng.py) regenerate the same mask without storing it.
+// splitmix64 finaliser; the top 24 bits give a uniform in [0,1).
+__host__ __device__ __forceinline__ uint64_t mix64(uint64_t z) {
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+__host__ __device__ __forceinline__ float uniform01(uint64_t seed, uint64_t idx) {
+    const uint64_t h = mix64(seed ^ mix64(idx));
+    return (float)(h >> 40) * (1.0f / 16777216.0f);
+}
+// returns the multiplicative factor: 0 (dropped) or 1/(1-p) (kept); p == 0 -> 1.
+__host__ __device__ __forceinline__ float drop_factor(uint64_t seed, uint64_t idx, float p, float scale) {
+    return (uniform01(seed, idx) >= p) ? scale : 0.0f;
+}
+
+__device__ __forceinline__ float leaky(float x, float slope) { return x > 0.f ? x : x * slope; }
+
+}  // namespace txe

@@ -1,0 +1,329 @@
+// GAT message/reduce for batched egonets on gfx950: the fused replacement of
+//   apply_edges(edge_attention)      model_zoo.py:90,106-109   e = leaky_relu_0.2(a1[src] + a2[dst])
+//   edge_softmax over in-edges        model_zoo.py:111-112
+//   attn_drop                         model_zoo.py:114
+//   update_all(src_mul_edge, sum)     model_zoo.py:95           out[v] = sum_e a_drop[e] * ft[src_e]
+// (+ the inter-layer F.leaky_relu of model_zoo.py:216 as an epilogue) and of its backward.
+//
+// Mapping: ONE 64-lane wavefront per destination node.  Neighbour lists come from a destination-sorted
+// CSR (coalesced int32 reads).  The per-destination softmax is a wavefront segmented max / sum: lane p
+// owns in-edge p, __shfl_xor butterflies reduce over the segment, per head.  The normalised (and
+// dropped) attention of a 64-edge chunk is parked in LDS, then all 64 lanes sweep the H*D-wide feature
+// row of every neighbour with 16-byte loads (lane = feature column block) and accumulate in registers;
+// nothing but `out` (and alpha, kept for backward) is written.  HBM-bound: per node it reads deg rows
+// and writes one row of H*D floats.  Workgroups are remapped so that one XCD (one L2) owns a contiguous
+// range of destination nodes -- the nodes of an egonet share their source rows.
+#include "txe_gather.h"
+
+namespace txe {
+
+// ------------------------------------------------------------------------------------------------
+// forward
+// ------------------------------------------------------------------------------------------------
+template <int VEC>
+__global__ __launch_bounds__(GAT_WAVES * 64) void gat_aggregate_fwd_kernel(
+    const int* __restrict__ rowptr, const int* __restrict__ col, const int n_nodes, const float* __restrict__ ft,
+    const long long ld_ft, const float* __restrict__ a_src, const float* __restrict__ a_dst, const int ld_a, const int H,
+    const int D, const float slope, const float drop_p, const float drop_scale, const unsigned long long seed,
+    const int out_mode, const float act_slope, float* __restrict__ out, const long long ld_out, float* __restrict__ alpha) {
+    __shared__ float s_w[GAT_WAVES][GAT_MAXH * 64];
+    __shared__ int s_idx[GAT_WAVES][64];
+    __shared__ float s_stat[GAT_WAVES][2 * GAT_MAXH];
+
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    const int v = xcd_remap(blockIdx.x, gridDim.x) * GAT_WAVES + w;
+    if (v >= n_nodes) return;
+    const int beg = rowptr[v], end = rowptr[v + 1];
+
+    // wavefront segmented max / sum of the attention logits of v's in-edges, per head
+    for (int h = 0; h < H; ++h) {
+        const float ad = a_dst[(long long)v * ld_a + h];
+        float m = -INFINITY;
+        for (int p = beg + l; p < end; p += 64) m = fmaxf(m, leaky(a_src[(long long)col[p] * ld_a + h] + ad, slope));
+        m = wave_max(m);
+        float s = 0.f;
+        for (int p = beg + l; p < end; p += 64) s += __expf(leaky(a_src[(long long)col[p] * ld_a + h] + ad, slope) - m);
+        s = wave_sum(s);
+        if (l == 0) { s_stat[w][2 * h] = m; s_stat[w][2 * h + 1] = 1.f / s; }
+    }
+    __builtin_amdgcn_wave_barrier();
+
+    const int F = H * D, nvec = F / VEC;
+    for (int t0 = 0; t0 < nvec; t0 += 64 * GAT_MAXI) {
+        int hidx[GAT_MAXI];
+        float acc[GAT_MAXI][VEC];
+#pragma unroll
+        for (int i = 0; i < GAT_MAXI; ++i) {
+            const int j = t0 + l + 64 * i;
+            hidx[i] = (j < nvec) ? (j * VEC) / D : 0;
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) acc[i][k] = 0.f;
+        }
+        for (int cb = beg; cb < end; cb += 64) {
+            const int p = cb + l;
+            if (p < end) {
+                const int u = col[p];
+                s_idx[w][l] = u;
+                for (int h = 0; h < H; ++h) {
+                    const float e = leaky(a_src[(long long)u * ld_a + h] + a_dst[(long long)v * ld_a + h], slope);
+                    const float al = __expf(e - s_stat[w][2 * h]) * s_stat[w][2 * h + 1];
+                    if (alpha != nullptr && t0 == 0) alpha[(long long)p * H + h] = al;
+                    float f = 1.f;
+                    if (drop_p > 0.f) f = drop_factor(seed, (unsigned long long)p * H + h, drop_p, drop_scale);
+                    s_w[w][h * 64 + l] = al * f;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            gather_accumulate<VEC>(ft, ld_ft, s_idx[w], s_w[w], min(64, end - cb), t0, nvec, hidx, acc);
+            __builtin_amdgcn_wave_barrier();
+        }
+#pragma unroll
+        for (int i = 0; i < GAT_MAXI; ++i) {
+            const int j = t0 + l + 64 * i;
+            if (j < nvec) {
+                if (out_mode == 1) {
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k) acc[i][k] = leaky(acc[i][k], act_slope);
+                }
+                vstore<VEC>(out + (long long)v * ld_out + (long long)j * VEC, acc[i]);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward, destination side: d alpha (dot products), softmax + leaky-relu backward -> dz[E,H],
+// d a_dst[N,H].  d_pre = gradient w.r.t. the aggregated (pre-activation) output.
+// ------------------------------------------------------------------------------------------------
+template <int VEC>
+__global__ __launch_bounds__(GAT_WAVES * 64) void gat_bwd_edge_kernel(
+    const int* __restrict__ rowptr, const int* __restrict__ col, const int n_nodes, const float* __restrict__ ft,
+    const long long ld_ft, const float* __restrict__ a_src, const float* __restrict__ a_dst, const int ld_a, const int H,
+    const int D, const float slope, const float drop_p, const float drop_scale, const unsigned long long seed,
+    const float* __restrict__ alpha, const float* __restrict__ d_pre, const long long ld_dpre, float* __restrict__ dz,
+    float* __restrict__ d_a_dst, const int ld_da) {
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    const int v = xcd_remap(blockIdx.x, gridDim.x) * GAT_WAVES + w;
+    if (v >= n_nodes) return;
+    const int beg = rowptr[v], end = rowptr[v + 1];
+    const int dvec = D / VEC;
+    for (int h = 0; h < H; ++h) {
+        const float* drow = d_pre + (long long)v * ld_dpre + (long long)h * D;
+        float sacc = 0.f;
+        for (int p = beg; p < end; ++p) {
+            const float* frow = ft + (long long)col[p] * ld_ft + (long long)h * D;
+            float part = 0.f;
+            for (int j = l; j < dvec; j += 64) {
+                float a[VEC], b[VEC];
+                vload<VEC>(drow + (long long)j * VEC, a);
+                vload<VEC>(frow + (long long)j * VEC, b);
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) part = fmaf(a[k], b[k], part);
+            }
+            const float tot = wave_sum(part);
+            if (l == ((p - beg) & 63)) {
+                float f = 1.f;
+                if (drop_p > 0.f) f = drop_factor(seed, (unsigned long long)p * H + h, drop_p, drop_scale);
+                const float dal = tot * f;
+                dz[(long long)p * H + h] = dal;              // parked; the same lane re-reads it below
+                sacc = fmaf(alpha[(long long)p * H + h], dal, sacc);
+            }
+        }
+        const float S = wave_sum(sacc);
+        const float ad = a_dst[(long long)v * ld_a + h];
+        float dacc = 0.f;
+        for (int p = beg + l; p < end; p += 64) {
+            const float dal = dz[(long long)p * H + h];
+            const float de = alpha[(long long)p * H + h] * (dal - S);
+            const float z = a_src[(long long)col[p] * ld_a + h] + ad;
+            const float g = de * (z > 0.f ? 1.f : slope);
+            dz[(long long)p * H + h] = g;
+            dacc += g;
+        }
+        dacc = wave_sum(dacc);
+        if (l == 0) d_a_dst[(long long)v * ld_da + h] = dacc;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward, source side (source-sorted CSR, atomic free):
+//   d_ft[u] = sum_{e=(u->v)} a_drop[e] * d_pre[v]        d_a_src[u,h] = sum_{e=(u->v)} dz[e,h]
+// pos_out[j] = position of out-edge j in the destination-sorted order (where alpha / dz live).
+// ------------------------------------------------------------------------------------------------
+template <int VEC>
+__global__ __launch_bounds__(GAT_WAVES * 64) void gat_bwd_node_kernel(
+    const int* __restrict__ rowptr_out, const int* __restrict__ col_dst, const int* __restrict__ pos_out, const int n_nodes,
+    const float* __restrict__ alpha, const float* __restrict__ dz, const int H, const int D, const float drop_p,
+    const float drop_scale, const unsigned long long seed, const float* __restrict__ d_pre, const long long ld_dpre,
+    float* __restrict__ d_ft, const long long ld_dft, float* __restrict__ d_a_src, const int ld_da) {
+    __shared__ float s_w[GAT_WAVES][GAT_MAXH * 64];
+    __shared__ int s_idx[GAT_WAVES][64];
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    const int u = xcd_remap(blockIdx.x, gridDim.x) * GAT_WAVES + w;
+    if (u >= n_nodes) return;
+    const int beg = rowptr_out[u], end = rowptr_out[u + 1];
+
+    for (int h = 0; h < H; ++h) {
+        float acc = 0.f;
+        for (int j = beg + l; j < end; j += 64) acc += dz[(long long)pos_out[j] * H + h];
+        acc = wave_sum(acc);
+        if (l == 0) d_a_src[(long long)u * ld_da + h] = acc;
+    }
+
+    const int F = H * D, nvec = F / VEC;
+    for (int t0 = 0; t0 < nvec; t0 += 64 * GAT_MAXI) {
+        int hidx[GAT_MAXI];
+        float acc[GAT_MAXI][VEC];
+#pragma unroll
+        for (int i = 0; i < GAT_MAXI; ++i) {
+            const int j = t0 + l + 64 * i;
+            hidx[i] = (j < nvec) ? (j * VEC) / D : 0;
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) acc[i][k] = 0.f;
+        }
+        for (int cb = beg; cb < end; cb += 64) {
+            const int j = cb + l;
+            if (j < end) {
+                const int q = pos_out[j];
+                s_idx[w][l] = col_dst[j];
+                for (int h = 0; h < H; ++h) {
+                    float f = 1.f;
+                    if (drop_p > 0.f) f = drop_factor(seed, (unsigned long long)q * H + h, drop_p, drop_scale);
+                    s_w[w][h * 64 + l] = alpha[(long long)q * H + h] * f;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            gather_accumulate<VEC>(d_pre, ld_dpre, s_idx[w], s_w[w], min(64, end - cb), t0, nvec, hidx, acc);
+            __builtin_amdgcn_wave_barrier();
+        }
+#pragma unroll
+        for (int i = 0; i < GAT_MAXI; ++i) {
+            const int j = t0 + l + 64 * i;
+            if (j < nvec) vstore<VEC>(d_ft + (long long)u * ld_dft + (long long)j * VEC, acc[i]);
+        }
+    }
+}
+
+// d_pre = d_out * leaky'(out_act)   (out_act = leaky(out): same sign as out)
+__global__ void leaky_bwd_kernel(const float* __restrict__ d_out, const float* __restrict__ out_act, float slope,
+                                 long long n, float* __restrict__ d_pre) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        d_pre[i] = d_out[i] * (out_act[i] > 0.f ? 1.f : slope);
+}
+
+// mean over heads: y[n,d] = (1/H) sum_h x[n,h,d]  (model_zoo.py:219 `.mean(1)`), and its backward.
+__global__ void head_mean_kernel(const float* __restrict__ x, int H, int D, long long n_rows, float* __restrict__ y) {
+    const long long total = n_rows * D;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long r = i / D;
+        const int d = (int)(i % D);
+        float s = 0.f;
+        for (int h = 0; h < H; ++h) s += x[(r * H + h) * D + d];
+        y[i] = s / (float)H;
+    }
+}
+__global__ void head_mean_bwd_kernel(const float* __restrict__ dy, int H, int D, long long n_rows, float* __restrict__ dx) {
+    const long long total = n_rows * H * D;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long r = i / ((long long)H * D);
+        const int d = (int)(i % D);
+        dx[i] = dy[r * D + d] / (float)H;
+    }
+}
+
+static inline int pick_vec(int D, long long ld1, long long ld2, const void* p1, const void* p2) {
+    auto al = [](const void* p, int bytes) { return ((uintptr_t)p % bytes) == 0; };
+    if (D % 4 == 0 && ld1 % 4 == 0 && ld2 % 4 == 0 && al(p1, 16) && al(p2, 16)) return 4;
+    if (D % 2 == 0 && ld1 % 2 == 0 && ld2 % 2 == 0 && al(p1, 8) && al(p2, 8)) return 2;
+    return 1;
+}
+
+}  // namespace txe
+
+using namespace txe;
+
+extern "C" {
+
+int txe_gat_aggregate_fwd(const int* rowptr_in, const int* col_src, int n_nodes, const float* ft, long long ld_ft,
+                          const float* a_src, const float* a_dst, int ld_a, int H, int D, float attn_slope, float attn_drop_p,
+                          unsigned long long seed, int out_mode, float act_slope, float* out, long long ld_out, float* alpha,
+                          void* stream) {
+    if (n_nodes < 0 || H < 1 || H > GAT_MAXH || D < 1 || !rowptr_in || !ft || !a_src || !a_dst || !out) return TXE_ERR_ARG;
+    if (out_mode != 0 && out_mode != 1) return TXE_ERR_ARG;
+    if (attn_drop_p < 0.f || attn_drop_p >= 1.f) return TXE_ERR_ARG;
+    if (n_nodes == 0) return TXE_OK;
+    const float scale = 1.f / (1.f - attn_drop_p);
+    const int nb = (n_nodes + GAT_WAVES - 1) / GAT_WAVES;
+    hipStream_t s = (hipStream_t)stream;
+    const int vec = pick_vec(D, ld_ft, ld_out, ft, out);
+#define TXE_L(V)                                                                                                         \
+    hipLaunchKernelGGL((gat_aggregate_fwd_kernel<V>), dim3(nb), dim3(GAT_WAVES * 64), 0, s, rowptr_in, col_src, n_nodes, \
+                       ft, ld_ft, a_src, a_dst, ld_a, H, D, attn_slope, attn_drop_p, scale, seed, out_mode, act_slope,   \
+                       out, ld_out, alpha)
+    if (vec == 4) TXE_L(4); else if (vec == 2) TXE_L(2); else TXE_L(1);
+#undef TXE_L
+    TXE_CHECK_LAUNCH();
+    return TXE_OK;
+}
+
+int txe_gat_aggregate_bwd(const int* rowptr_in, const int* col_src, const int* rowptr_out, const int* col_dst,
+                          const int* pos_out, int n_nodes, const float* ft, long long ld_ft, const float* a_src,
+                          const float* a_dst, int ld_a, int H, int D, float attn_slope, float attn_drop_p,
+                          unsigned long long seed, const float* alpha, const float* d_pre, long long ld_dpre, float* d_ft,
+                          long long ld_dft, float* d_a_src, float* d_a_dst, int ld_da, float* dz_ws, void* stream) {
+    if (n_nodes < 0 || H < 1 || H > GAT_MAXH || D < 1) return TXE_ERR_ARG;
+    if (!rowptr_in || !rowptr_out || !ft || !alpha || !d_pre || !d_ft || !d_a_src || !d_a_dst || !dz_ws) return TXE_ERR_ARG;
+    if (attn_drop_p < 0.f || attn_drop_p >= 1.f) return TXE_ERR_ARG;
+    if (n_nodes == 0) return TXE_OK;
+    const float scale = 1.f / (1.f - attn_drop_p);
+    const int nb = (n_nodes + GAT_WAVES - 1) / GAT_WAVES;
+    hipStream_t s = (hipStream_t)stream;
+    const int v1 = pick_vec(D, ld_ft, ld_dpre, ft, d_pre);
+#define TXE_L(V)                                                                                                          \
+    hipLaunchKernelGGL((gat_bwd_edge_kernel<V>), dim3(nb), dim3(GAT_WAVES * 64), 0, s, rowptr_in, col_src, n_nodes, ft,   \
+                       ld_ft, a_src, a_dst, ld_a, H, D, attn_slope, attn_drop_p, scale, seed, alpha, d_pre, ld_dpre,      \
+                       dz_ws, d_a_dst, ld_da)
+    if (v1 == 4) TXE_L(4); else if (v1 == 2) TXE_L(2); else TXE_L(1);
+#undef TXE_L
+    TXE_CHECK_LAUNCH();
+    const int v2 = pick_vec(D, ld_dpre, ld_dft, d_pre, d_ft);
+#define TXE_L(V)                                                                                                          \
+    hipLaunchKernelGGL((gat_bwd_node_kernel<V>), dim3(nb), dim3(GAT_WAVES * 64), 0, s, rowptr_out, col_dst, pos_out,      \
+                       n_nodes, alpha, (const float*)dz_ws, H, D, attn_drop_p, scale, seed, d_pre, ld_dpre, d_ft, ld_dft, \
+                       d_a_src, ld_da)
+    if (v2 == 4) TXE_L(4); else if (v2 == 2) TXE_L(2); else TXE_L(1);
+#undef TXE_L
+    TXE_CHECK_LAUNCH();
+    return TXE_OK;
+}
+
+int txe_leaky_relu_bwd(const float* d_out, const float* out_act, float slope, long long n, float* d_pre, void* stream) {
+    if (n < 0 || (n > 0 && (!d_out || !out_act || !d_pre))) return TXE_ERR_ARG;
+    if (n == 0) return TXE_OK;
+    const int nb = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+    hipLaunchKernelGGL(leaky_bwd_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, d_out, out_act, slope, n, d_pre);
+    TXE_CHECK_LAUNCH();
+    return TXE_OK;
+}
+
+int txe_head_mean_fwd(const float* x, int H, int D, long long n_rows, float* y, void* stream) {
+    if (H < 1 || D < 1 || n_rows < 0) return TXE_ERR_ARG;
+    if (n_rows == 0) return TXE_OK;
+    const long long total = n_rows * D;
+    const int nb = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+    hipLaunchKernelGGL(head_mean_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, x, H, D, n_rows, y);
+    TXE_CHECK_LAUNCH();
+    return TXE_OK;
+}
+
+int txe_head_mean_bwd(const float* dy, int H, int D, long long n_rows, float* dx, void* stream) {
+    if (H < 1 || D < 1 || n_rows < 0) return TXE_ERR_ARG;
+    if (n_rows == 0) return TXE_OK;
+    const long long total = n_rows * H * D;
+    const int nb = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+    hipLaunchKernelGGL(head_mean_bwd_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, dy, H, D, n_rows, dx);
+    TXE_CHECK_LAUNCH();
+    return TXE_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,51 @@
+// Wave-per-node weighted row gather shared by the GAT and GCN message/reduce kernels (gfx950).
+#pragma once
+#include "txe_common.h"
+
+namespace txe {
+
+constexpr int GAT_MAXH = 16;     // heads supported by the LDS staging
+constexpr int GAT_MAXI = 8;      // feature vectors per lane kept in registers per feature tile
+constexpr int GAT_WAVES = 4;     // waves (= destination nodes) per workgroup
+
+template <int VEC> struct vec_t;
+template <> struct vec_t<4> { typedef float4 type; };
+template <> struct vec_t<2> { typedef float2 type; };
+template <> struct vec_t<1> { typedef float type; };
+
+template <int VEC>
+__device__ __forceinline__ void vload(const float* p, float* v) {
+    if constexpr (VEC == 4) { const float4 t = *reinterpret_cast<const float4*>(p); v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
+    else if constexpr (VEC == 2) { const float2 t = *reinterpret_cast<const float2*>(p); v[0] = t.x; v[1] = t.y; }
+    else { v[0] = *p; }
+}
+template <int VEC>
+__device__ __forceinline__ void vstore(float* p, const float* v) {
+    if constexpr (VEC == 4) { *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]); }
+    else if constexpr (VEC == 2) { *reinterpret_cast<float2*>(p) = make_float2(v[0], v[1]); }
+    else { *p = v[0]; }
+}
+
+// acc[i] += sum_{e<cnt} w[head(i)][e] * rows[idx[e]][(t0 + lane + 64 i) * VEC ...]
+template <int VEC>
+__device__ __forceinline__ void gather_accumulate(const float* __restrict__ base, long long ld, const int* s_idx,
+                                                  const float* s_w, int cnt, int t0, int nvec, const int* hidx,
+                                                  float (&acc)[GAT_MAXI][VEC]) {
+    const int l = threadIdx.x & 63;
+    for (int e = 0; e < cnt; ++e) {
+        const float* row = base + (long long)s_idx[e] * ld;
+#pragma unroll
+        for (int i = 0; i < GAT_MAXI; ++i) {
+            const int j = t0 + l + 64 * i;
+            if (j < nvec) {
+                float v[VEC];
+                vload<VEC>(row + (long long)j * VEC, v);
+                const float a = s_w[hidx[i] * 64 + e];
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) acc[i][k] = fmaf(a, v[k], acc[i][k]);
+            }
+        }
+    }
+}
+
+}  // namespace txe

@@ -1,0 +1,159 @@
+// GCN message/reduce (the PGCN / GCN variant), model_zoo.py:38-49 and :157-161:
+//     norm = in_degree^-1/2 (inf -> 0);  out = act( norm[v] * sum_{e=(u->v)} norm[u] * hw[u]  + bias )
+// Same wave-per-destination row gather as the GAT kernel (txe_gather.h) with per-source weights norm[u].
+#include "txe_gather.h"
+
+namespace txe {
+
+__global__ void gcn_norm_kernel(const int* __restrict__ rowptr, int n, float* __restrict__ norm) {
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= n) return;
+    const int deg = rowptr[v + 1] - rowptr[v];
+    norm[v] = deg > 0 ? 1.0f / sqrtf((float)deg) : 0.f;
+}
+
+// mode 0: out[v] = act(norm[v] * sum_u norm[u] x[u] + bias)      (forward; rowptr/col = destination CSR)
+// mode 1: out[u] = norm[u] * sum_v norm[v] x[v]                   (backward; rowptr/col = source CSR)
+template <int VEC>
+__global__ __launch_bounds__(GAT_WAVES * 64) void gcn_aggregate_kernel(const int* __restrict__ rowptr, const int* __restrict__ col,
+                                                                       const int n_nodes, const float* __restrict__ x,
+                                                                       const long long ld_x, const float* __restrict__ norm,
+                                                                       const float* __restrict__ bias, const int has_act,
+                                                                       const float act_slope, const int F, float* __restrict__ out,
+                                                                       const long long ld_out) {
+    __shared__ float s_w[GAT_WAVES][64];
+    __shared__ int s_idx[GAT_WAVES][64];
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    const int v = xcd_remap(blockIdx.x, gridDim.x) * GAT_WAVES + w;
+    if (v >= n_nodes) return;
+    const int beg = rowptr[v], end = rowptr[v + 1];
+    const float nv = norm[v];
+    const int nvec = F / VEC;
+    for (int t0 = 0; t0 < nvec; t0 += 64 * GAT_MAXI) {
+        int hidx[GAT_MAXI];
+        float acc[GAT_MAXI][VEC];
+#pragma unroll
+        for (int i = 0; i < GAT_MAXI; ++i) {
+            hidx[i] = 0;
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) acc[i][k] = 0.f;
+        }
+        for (int cb = beg; cb < end; cb += 64) {
+            const int p = cb + l;
+            if (p < end) {
+                const int u = col[p];
+                s_idx[w][l] = u;
+                s_w[w][l] = norm[u];
+            }
+            __builtin_amdgcn_wave_barrier();
+            gather_accumulate<VEC>(x, ld_x, s_idx[w], s_w[w], min(64, end - cb), t0, nvec, hidx, acc);
+            __builtin_amdgcn_wave_barrier();
+        }
+#pragma unroll
+        for (int i = 0; i < GAT_MAXI; ++i) {
+            const int j = t0 + l + 64 * i;
+            if (j < nvec) {
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) {
+                    float r = acc[i][k] * nv;
+                    if (bias) r += bias[j * VEC + k];
+                    if (has_act) r = leaky(r, act_slope);
+                    acc[i][k] = r;
+                }
+                vstore<VEC>(out + (long long)v * ld_out + (long long)j * VEC, acc[i]);
+            }
+        }
+    }
+}
+
+// two-stage deterministic column sum: part[b][j] = sum_{m in block b} x[m][j] * (act_src ? leaky'(act_src[m][j]) : 1)
+__global__ void colsum_stage1(const float* __restrict__ x, long long ldx, int n_rows, int cols, int rows_per_block,
+                              float* __restrict__ part) {
+    const int r0 = blockIdx.x * rows_per_block, r1 = min(n_rows, r0 + rows_per_block);
+    for (int j = threadIdx.x; j < cols; j += blockDim.x) {
+        float acc = 0.f;
+        for (int m = r0; m < r1; ++m) acc += x[(long long)m * ldx + j];
+        part[(long long)blockIdx.x * cols + j] = acc;
+    }
+}
+__global__ void colsum_stage2(const float* __restrict__ part, int nb, int cols, float* __restrict__ out) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= cols) return;
+    float acc = 0.f;
+    for (int b = 0; b < nb; ++b) acc += part[(long long)b * cols + j];
+    out[j] = acc;
+}
+
+static inline int gcn_pick_vec(int F, long long ld1, long long ld2, const void* p1, const void* p2) {
+    auto al = [](const void* p, int bytes) { return ((uintptr_t)p % bytes) == 0; };
+    if (F % 4 == 0 && ld1 % 4 == 0 && ld2 % 4 == 0 && al(p1, 16) && al(p2, 16)) return 4;
+    if (F % 2 == 0 && ld1 % 2 == 0 && ld2 % 2 == 0 && al(p1, 8) && al(p2, 8)) return 2;
+    return 1;
+}
+
+static int gcn_launch(const int* rowptr, const int* col, int n, const float* x, long long ld_x, const float* norm,
+                      const float* bias, int has_act, float slope, int F, float* out, long long ld_out, hipStream_t s) {
+    const int nb = (n + GAT_WAVES - 1) / GAT_WAVES;
+    int vec = gcn_pick_vec(F, ld_x, ld_out, x, out);
+#define TXE_L(V)                                                                                                           \
+    hipLaunchKernelGGL((gcn_aggregate_kernel<V>), dim3(nb), dim3(GAT_WAVES * 64), 0, s, rowptr, col, n, x, ld_x, norm, bias, \
+                       has_act, slope, F, out, ld_out)
+    if (vec == 4) TXE_L(4); else if (vec == 2) TXE_L(2); else TXE_L(1);
+#undef TXE_L
+    TXE_CHECK_LAUNCH();
+    return TXE_OK;
+}
+
+}  // namespace txe
+
+using namespace txe;
+
+extern "C" {
+
+int txe_gcn_norm(const int* rowptr_in, int n_nodes, float* norm, void* stream) {
+    if (n_nodes < 0 || !rowptr_in || !norm) return TXE_ERR_ARG;
+    if (n_nodes == 0) return TXE_OK;
+    hipLaunchKernelGGL(gcn_norm_kernel, dim3((n_nodes + 255) / 256), dim3(256), 0, (hipStream_t)stream, rowptr_in, n_nodes, norm);
+    TXE_CHECK_LAUNCH();
+    return TXE_OK;
+}
+
+// out = act(norm[v] * sum_{u->v} norm[u] hw[u] + bias); has_act = 0 -> identity (last layer, model_zoo.py:152)
+int txe_gcn_aggregate_fwd(const int* rowptr_in, const int* col_src, int n_nodes, const float* hw, long long ld_hw,
+                          const float* norm, const float* bias, int has_act, float act_slope, int F, float* out, long long ld_out,
+                          void* stream) {
+    if (n_nodes < 0 || F < 1 || !rowptr_in || !hw || !norm || !out) return TXE_ERR_ARG;
+    if (n_nodes == 0) return TXE_OK;
+    return gcn_launch(rowptr_in, col_src, n_nodes, hw, ld_hw, norm, bias, has_act, act_slope, F, out, ld_out, (hipStream_t)stream);
+}
+
+size_t txe_gcn_aggregate_bwd_ws_bytes(int n_nodes, int F) {
+    const int nb = (n_nodes + 255) / 256 > 0 ? (n_nodes + 255) / 256 : 1;
+    return (size_t)nb * F * 4;
+}
+
+// d_pre: gradient w.r.t. the pre-activation output (caller applies leaky' first, e.g. txe_leaky_relu_bwd).
+// d_hw[u] = norm[u] * sum_{u->v} norm[v] d_pre[v];  d_bias = column sum of d_pre (may be NULL).
+int txe_gcn_aggregate_bwd(const int* rowptr_out, const int* col_dst, int n_nodes, const float* d_pre, long long ld_dpre,
+                          const float* norm, int F, float* d_hw, long long ld_dhw, float* d_bias, void* ws, size_t ws_bytes,
+                          void* stream) {
+    if (n_nodes < 0 || F < 1 || !rowptr_out || !d_pre || !norm || !d_hw) return TXE_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    if (n_nodes > 0) {
+        int rc = gcn_launch(rowptr_out, col_dst, n_nodes, d_pre, ld_dpre, norm, nullptr, 0, 1.f, F, d_hw, ld_dhw, s);
+        if (rc) return rc;
+    }
+    if (d_bias) {
+        if (!ws || ws_bytes < txe_gcn_aggregate_bwd_ws_bytes(n_nodes, F)) return TXE_ERR_WORKSPACE;
+        const int nb = (n_nodes + 255) / 256;
+        if (nb > 0) {
+            hipLaunchKernelGGL(colsum_stage1, dim3(nb), dim3(128), 0, s, d_pre, ld_dpre, n_nodes, F, 256, (float*)ws);
+            TXE_CHECK_LAUNCH();
+        }
+        hipLaunchKernelGGL(colsum_stage2, dim3((F + 127) / 128), dim3(128), 0, s, (const float*)ws, nb, F, d_bias);
+        TXE_CHECK_LAUNCH();
+    }
+    return TXE_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,66 @@
+// Rank extraction for the all-candidate scoring loop, on device.
+// Reference: test_fast.py:16-22 (rearrange) + model/metric.py:7-31:
+//     rank(p) = 1 + #{ g not in positives(q) : score[q][g]  >  score[q][p] }      (similarity, info_nce)
+//     rank(p) = 1 + #{ g not in positives(q) : score[q][g]  <  score[q][p] }      (distance)
+// i.e. positives never count against each other and ties do not count (strict inequality).
+// One workgroup per query streams the G scores of its row once (coalesced), compares against the query's
+// few positives held in LDS, and reduces integer counts -- exact, no floating point accumulation.
+#include "txe_common.h"
+
+namespace txe {
+
+constexpr int RANK_MAXP = 64;   // positives handled per pass
+
+__global__ __launch_bounds__(256) void rank_kernel(const float* __restrict__ S, long long ld_s, int G,
+                                                   const int* __restrict__ pos_off, const int* __restrict__ pos_idx,
+                                                   int larger_is_better, int* __restrict__ ranks) {
+    __shared__ float s_sp[RANK_MAXP];
+    __shared__ int s_cnt[RANK_MAXP];
+    const int q = blockIdx.x;
+    const float* row = S + (long long)q * ld_s;
+    const int pb = pos_off[q], pe = pos_off[q + 1];
+    for (int c0 = pb; c0 < pe; c0 += RANK_MAXP) {
+        const int np = min(RANK_MAXP, pe - c0);
+        if (threadIdx.x < np) { s_sp[threadIdx.x] = row[pos_idx[c0 + threadIdx.x]]; s_cnt[threadIdx.x] = 0; }
+        __syncthreads();
+        for (int k = 0; k < np; ++k) {
+            const float sp = s_sp[k];
+            int cnt = 0;
+            for (int g = threadIdx.x; g < G; g += blockDim.x) {
+                const float v = row[g];
+                cnt += larger_is_better ? (v > sp) : (v < sp);
+            }
+            // positives of this query are excluded from the comparison set
+            for (int j = pb + threadIdx.x; j < pe; j += blockDim.x) {
+                const float v = row[pos_idx[j]];
+                cnt -= larger_is_better ? (v > sp) : (v < sp);
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
+            if ((threadIdx.x & 63) == 0) atomicAdd(&s_cnt[k], cnt);   // integer: order independent
+        }
+        __syncthreads();
+        if (threadIdx.x < np) ranks[c0 + threadIdx.x] = s_cnt[threadIdx.x] + 1;
+        __syncthreads();
+    }
+}
+
+}  // namespace txe
+
+using namespace txe;
+
+extern "C" {
+
+// S [nq][G] (row stride ld_s); pos_off [nq+1], pos_idx [pos_off[nq]] = candidate columns of each query's true
+// parents (duplicates not allowed); ranks [pos_off[nq]] int32 out.
+int txe_rank_block(const float* S, long long ld_s, int nq, int G, const int* pos_off, const int* pos_idx, int* ranks,
+                   int larger_is_better, void* ws_unused, void* stream) {
+    (void)ws_unused;
+    if (nq < 0 || G < 0 || !S || !pos_off || !pos_idx || !ranks) return TXE_ERR_ARG;
+    if (nq == 0) return TXE_OK;
+    hipLaunchKernelGGL(rank_kernel, dim3(nq), dim3(256), 0, (hipStream_t)stream, S, ld_s, G, pos_off, pos_idx, larger_is_better, ranks);
+    TXE_CHECK_LAUNCH();
+    return TXE_OK;
+}
+
+}  // extern "C"

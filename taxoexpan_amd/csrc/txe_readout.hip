@@ -1,0 +1,193 @@
+// Graph readouts of the batched egonets (model_zoo.py:227-242):
+//   MeanReadout          hg[g] = mean_v h[v]                                  (dgl.mean_nodes, :232)
+//   WeightedMeanReadout  w_v = softplus(position_weights[pos_v]);             (:241)
+//                        hg[g] = sum_v w_v h[v] / sum_v w_v                   (:242)
+// One wavefront per egonet: lanes span the feature row with 16-byte loads, the (few) nodes of the egonet
+// are walked serially; HBM-bound, every h row is read exactly once.  Backward is atomic free: the three
+// position-weight gradients are reduced per egonet, then over egonets in a second tiny kernel.
+#include "txe_common.h"
+
+namespace txe {
+
+constexpr int RO_WAVES = 4;
+constexpr int RO_MAXI = 8;
+constexpr int RO_MAX_VOCAB = 8;
+
+__device__ __forceinline__ float softplus_t(float x) { return x > 20.f ? x : log1pf(__expf(x)); }   // F.softplus, threshold 20
+__device__ __forceinline__ float sigmoid_t(float x) { return x > 20.f ? 1.f : 1.f / (1.f + __expf(-x)); }
+
+template <int VEC>
+__device__ __forceinline__ void ro_vload(const float* p, float* v) {
+    if constexpr (VEC == 4) { const float4 t = *reinterpret_cast<const float4*>(p); v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
+    else if constexpr (VEC == 2) { const float2 t = *reinterpret_cast<const float2*>(p); v[0] = t.x; v[1] = t.y; }
+    else { v[0] = *p; }
+}
+template <int VEC>
+__device__ __forceinline__ void ro_vstore(float* p, const float* v) {
+    if constexpr (VEC == 4) { *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]); }
+    else if constexpr (VEC == 2) { *reinterpret_cast<float2*>(p) = make_float2(v[0], v[1]); }
+    else { *p = v[0]; }
+}
+
+template <int VEC>
+__global__ __launch_bounds__(RO_WAVES * 64) void readout_fwd_kernel(const int* __restrict__ goff, const int G,
+                                                                    const float* __restrict__ h, const long long ld_h,
+                                                                    const int* __restrict__ pos, const float* __restrict__ pw,
+                                                                    const int D, float* __restrict__ hg, float* __restrict__ wsum) {
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    const int g = xcd_remap(blockIdx.x, gridDim.x) * RO_WAVES + w;
+    if (g >= G) return;
+    const int beg = goff[g], end = goff[g + 1];
+    float S = 0.f;
+    for (int v = beg + l; v < end; v += 64) S += pw ? softplus_t(pw[pos[v]]) : 1.f;
+    S = wave_sum(S);
+    if (l == 0 && wsum) wsum[g] = S;
+    const float inv = 1.f / S;
+    const int nvec = D / VEC;
+    for (int t0 = 0; t0 < nvec; t0 += 64 * RO_MAXI) {
+        float acc[RO_MAXI][VEC];
+#pragma unroll
+        for (int i = 0; i < RO_MAXI; ++i)
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) acc[i][k] = 0.f;
+        for (int v = beg; v < end; ++v) {
+            const float wv = pw ? softplus_t(pw[pos[v]]) : 1.f;
+            const float* row = h + (long long)v * ld_h;
+#pragma unroll
+            for (int i = 0; i < RO_MAXI; ++i) {
+                const int j = t0 + l + 64 * i;
+                if (j < nvec) {
+                    float x[VEC];
+                    ro_vload<VEC>(row + (long long)j * VEC, x);
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k) acc[i][k] = fmaf(wv, x[k], acc[i][k]);
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < RO_MAXI; ++i) {
+            const int j = t0 + l + 64 * i;
+            if (j < nvec) {
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) acc[i][k] *= inv;
+                ro_vstore<VEC>(hg + (long long)g * D + (long long)j * VEC, acc[i]);
+            }
+        }
+    }
+}
+
+// d_h[v] = (w_v / S_g) d_hg[g];   d_w_v = <d_hg[g], h[v] - hg[g]> / S_g;   d_pw[c] += d_w_v * sigmoid(pw[c]) for pos_v == c
+template <int VEC>
+__global__ __launch_bounds__(RO_WAVES * 64) void readout_bwd_kernel(const int* __restrict__ goff, const int G,
+                                                                    const float* __restrict__ h, const long long ld_h,
+                                                                    const int* __restrict__ pos, const float* __restrict__ pw,
+                                                                    const int vocab, const int D, const float* __restrict__ hg,
+                                                                    const float* __restrict__ wsum, const float* __restrict__ d_hg,
+                                                                    float* __restrict__ d_h, const long long ld_dh,
+                                                                    float* __restrict__ dpw_part /*[G][vocab]*/) {
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    const int g = xcd_remap(blockIdx.x, gridDim.x) * RO_WAVES + w;
+    if (g >= G) return;
+    const int beg = goff[g], end = goff[g + 1];
+    const float inv = 1.f / wsum[g];
+    const int nvec = D / VEC;
+    float dpw[RO_MAX_VOCAB];
+#pragma unroll
+    for (int c = 0; c < RO_MAX_VOCAB; ++c) dpw[c] = 0.f;
+    for (int v = beg; v < end; ++v) {
+        const int pc = pw ? pos[v] : 0;
+        const float wv = pw ? softplus_t(pw[pc]) : 1.f;
+        const float sc = wv * inv;
+        float part = 0.f;
+        for (int j = l; j < nvec; j += 64) {
+            float dg[VEC], x[VEC], m[VEC], o[VEC];
+            ro_vload<VEC>(d_hg + (long long)g * D + (long long)j * VEC, dg);
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) o[k] = sc * dg[k];
+            ro_vstore<VEC>(d_h + (long long)v * ld_dh + (long long)j * VEC, o);
+            if (pw) {
+                ro_vload<VEC>(h + (long long)v * ld_h + (long long)j * VEC, x);
+                ro_vload<VEC>(hg + (long long)g * D + (long long)j * VEC, m);
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) part = fmaf(dg[k], x[k] - m[k], part);
+            }
+        }
+        if (pw) {
+            part = wave_sum(part) * inv * sigmoid_t(pw[pc]);
+#pragma unroll
+            for (int c = 0; c < RO_MAX_VOCAB; ++c) dpw[c] += (pc == c) ? part : 0.f;
+        }
+    }
+    if (pw && l == 0) {
+#pragma unroll
+        for (int c = 0; c < RO_MAX_VOCAB; ++c)
+            if (c < vocab) dpw_part[(long long)g * vocab + c] = dpw[c];
+    }
+}
+
+__global__ void readout_dpw_reduce_kernel(const float* __restrict__ part, int G, int vocab, float* __restrict__ d_pw) {
+    __shared__ float red[4];
+    const int c = blockIdx.x;
+    float acc = 0.f;
+    for (int g = threadIdx.x; g < G; g += blockDim.x) acc += part[(long long)g * vocab + c];
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) d_pw[c] = red[0] + red[1] + red[2] + red[3];
+}
+
+static inline int ro_pick_vec(int D, long long ld1, long long ld2, const void* a, const void* b, const void* c) {
+    auto al = [](const void* p, int bytes) { return p == nullptr || ((uintptr_t)p % bytes) == 0; };
+    if (D % 4 == 0 && ld1 % 4 == 0 && ld2 % 4 == 0 && al(a, 16) && al(b, 16) && al(c, 16)) return 4;
+    if (D % 2 == 0 && ld1 % 2 == 0 && ld2 % 2 == 0 && al(a, 8) && al(b, 8) && al(c, 8)) return 2;
+    return 1;
+}
+
+}  // namespace txe
+
+using namespace txe;
+
+extern "C" {
+
+// pw == NULL -> MeanReadout; else WeightedMeanReadout with softplus(pw[pos]).  wsum[G] (may be NULL in
+// inference) receives sum_v w_v, needed by backward.
+int txe_readout_fwd(const int* graph_off, int G, const float* h, long long ld_h, const int* pos, const float* pw, int D,
+                    float* hg, float* wsum, void* stream) {
+    if (G < 0 || D < 1 || !graph_off || !h || !hg || (pw && !pos)) return TXE_ERR_ARG;
+    if (G == 0) return TXE_OK;
+    const int nb = (G + RO_WAVES - 1) / RO_WAVES;
+    const int vec = ro_pick_vec(D, ld_h, D, h, hg, nullptr);
+    hipStream_t s = (hipStream_t)stream;
+#define TXE_L(V) hipLaunchKernelGGL((readout_fwd_kernel<V>), dim3(nb), dim3(RO_WAVES * 64), 0, s, graph_off, G, h, ld_h, pos, pw, D, hg, wsum)
+    if (vec == 4) TXE_L(4); else if (vec == 2) TXE_L(2); else TXE_L(1);
+#undef TXE_L
+    TXE_CHECK_LAUNCH();
+    return TXE_OK;
+}
+
+// dpw_ws: G*vocab floats of scratch (only when pw != NULL).
+int txe_readout_bwd(const int* graph_off, int G, const float* h, long long ld_h, const int* pos, const float* pw, int vocab,
+                    int D, const float* hg, const float* wsum, const float* d_hg, float* d_h, long long ld_dh, float* d_pw,
+                    float* dpw_ws, void* stream) {
+    if (G < 0 || D < 1 || !graph_off || !h || !hg || !wsum || !d_hg || !d_h) return TXE_ERR_ARG;
+    if (pw && (!pos || !d_pw || !dpw_ws || vocab < 1 || vocab > RO_MAX_VOCAB)) return TXE_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    if (G > 0) {
+        const int nb = (G + RO_WAVES - 1) / RO_WAVES;
+        int vec = ro_pick_vec(D, ld_h, ld_dh, h, d_h, hg);
+        if (vec > 1 && ((uintptr_t)d_hg % (vec * 4)) != 0) vec = 1;
+#define TXE_L(V)                                                                                                          \
+    hipLaunchKernelGGL((readout_bwd_kernel<V>), dim3(nb), dim3(RO_WAVES * 64), 0, s, graph_off, G, h, ld_h, pos, pw, vocab, \
+                       D, hg, wsum, d_hg, d_h, ld_dh, dpw_ws)
+        if (vec == 4) TXE_L(4); else if (vec == 2) TXE_L(2); else TXE_L(1);
+#undef TXE_L
+        TXE_CHECK_LAUNCH();
+    }
+    if (pw) {
+        hipLaunchKernelGGL(readout_dpw_reduce_kernel, dim3(vocab), dim3(256), 0, s, (const float*)dpw_ws, G, vocab, d_pw);
+        TXE_CHECK_LAUNCH();
+    }
+    return TXE_OK;
+}
+
+}  // extern "C"

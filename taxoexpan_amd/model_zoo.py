@@ -1,0 +1,311 @@
+"""Drop-in `model_zoo` for MI355X: same class names, constructor / forward signatures, parameter names and shapes
+(state-dict compatible) as /root/reference/model/model_zoo.py -- the arithmetic runs in the HIP kernels of
+libtxe (include/txe.h) instead of DGL + torch.
+
+    reference class                      here
+    GCNLayer   model_zoo.py:13-50        GCNLayer   -> txe_gcn_project_* + txe_gcn_aggregate_*
+    GATLayer   model_zoo.py:52-114       GATLayer   -> txe_gat_project_* + txe_gat_aggregate_*
+    GCN/PGCN   model_zoo.py:116-167      GCN/PGCN   -> one fused GCNStackFunction over all layers
+    GAT/PGAT   model_zoo.py:169-220      GAT/PGAT   -> one fused GATStackFunction over all layers
+    MeanReadout/WeightedMeanReadout      model_zoo.py:227-242 -> txe_readout_*
+    BIM/LBM    model_zoo.py:301-328      BIM/LBM    -> txe_bilinear_pair_*  (+ score_all for the eval loop)
+Graph argument: a taxoexpan_amd.graph.(Batched)DGLGraph -- the DGL-0.4 surface of the reference's loaders.
+Side effects the callers rely on are kept: PGAT/PGCN pop g.ndata['pos'] (model_zoo.py:163,212); WeightedMeanReadout
+writes g.ndata['a'] (:241).
+"""
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+
+
+def _fused_slope(activation):
+    """slope of the activation if it is the leaky_relu the reference passes (model.py:25-41), else None"""
+    if activation is F.leaky_relu:
+        return ops.LEAKY_SLOPE
+    if isinstance(activation, nn.LeakyReLU):
+        return float(activation.negative_slope)
+    return None
+
+
+def _p(dropout_module_or_zero, training):
+    """effective dropout probability of an nn.Dropout-or-falsy attribute"""
+    if isinstance(dropout_module_or_zero, nn.Dropout) and training:
+        return float(dropout_module_or_zero.p)
+    return 0.0
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Graph propagation
+# ---------------------------------------------------------------------------------------------------------------
+class GCNLayer(nn.Module):
+    def __init__(self, in_feats, out_feats, activation, dropout, bias=True):
+        super(GCNLayer, self).__init__()
+        self.weight = nn.Parameter(torch.Tensor(in_feats, out_feats))
+        if bias:
+            self.bias = nn.Parameter(torch.Tensor(out_feats))
+        else:
+            self.bias = None
+        self.activation = activation
+        if dropout:
+            self.dropout = nn.Dropout(p=dropout)
+        else:
+            self.dropout = 0.
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        stdv = 1. / math.sqrt(self.weight.size(1))
+        self.weight.data.uniform_(-stdv, stdv)
+        if self.bias is not None:
+            self.bias.data.uniform_(-stdv, stdv)
+
+    def forward(self, g, h):
+        """model_zoo.py:34-50 (the norm comes from in-degrees; g.ndata['norm'] is not needed)."""
+        slope = _fused_slope(self.activation)
+        cfg = ops.GCNConfig([self.weight.shape[1]], 0, [slope], [_p(self.dropout, self.training)], ops.new_seed())
+        out = ops.GCNStackFunction.apply(g.csr(h.device), cfg, h, None, self.weight, self.bias, None)
+        if self.activation and slope is None:
+            out = self.activation(out)
+        return out
+
+
+class GATLayer(nn.Module):
+    def __init__(self, in_dim, out_dim, num_heads=1, feat_drop=0.5, attn_drop=0.5, leaky_relu_alpha=0.2, residual=False):
+        super(GATLayer, self).__init__()
+        self.num_heads = num_heads
+        self.fc = nn.Linear(in_dim, num_heads * out_dim, bias=False)
+        if feat_drop:
+            self.feat_drop = nn.Dropout(feat_drop)
+        else:
+            self.feat_drop = lambda x: x
+        if attn_drop:
+            self.attn_drop = nn.Dropout(attn_drop)
+        else:
+            self.attn_drop = lambda x: x
+        self.attn_l = nn.Parameter(torch.Tensor(size=(1, num_heads, out_dim)))
+        self.attn_r = nn.Parameter(torch.Tensor(size=(1, num_heads, out_dim)))
+        nn.init.xavier_normal_(self.fc.weight.data, gain=1.414)
+        nn.init.xavier_normal_(self.attn_l.data, gain=1.414)
+        nn.init.xavier_normal_(self.attn_r.data, gain=1.414)
+        self.leaky_relu = nn.LeakyReLU(leaky_relu_alpha)
+        self.residual = residual
+        if residual:
+            if in_dim != out_dim:
+                self.res_fc = nn.Linear(in_dim, num_heads * out_dim, bias=False)
+                nn.init.xavier_normal_(self.res_fc.weight.data, gain=1.414)
+            else:
+                self.res_fc = None
+
+    @property
+    def out_dim(self):
+        return self.attn_l.shape[2]
+
+    def forward(self, g, feature):
+        """model_zoo.py:80-104 -> N x H x D'."""
+        cfg = ops.GATConfig([self.num_heads], [self.out_dim], [0], 0, self.leaky_relu.negative_slope, None,
+                            _p(self.feat_drop, self.training), _p(self.attn_drop, self.training), "none", ops.new_seed())
+        ret = ops.GATStackFunction.apply(g.csr(feature.device), cfg, feature, None, self.fc.weight, self.attn_l, self.attn_r, None)
+        if self.residual:                               # model_zoo.py:98-103 (never enabled by model.py)
+            if self.res_fc is not None:
+                resval = self.res_fc(feature).reshape((feature.shape[0], self.num_heads, -1))
+            else:
+                resval = torch.unsqueeze(feature, 1)
+            ret = resval + ret
+        return ret
+
+
+def _gat_stack(layers, embeddings, g, h, pos, activation, training):
+    """shared forward of GAT / PGAT: one fused autograd node when the activation is the reference's leaky_relu."""
+    first = layers[0]
+    slope = _fused_slope(activation)
+    if slope is None or any(l.residual for l in layers):
+        return None
+    cfg = ops.GATConfig([l.num_heads for l in layers], [l.out_dim for l in layers],
+                        [0 if embeddings is None else e.weight.shape[1] for e in (embeddings or layers)],
+                        0 if embeddings is None else embeddings[0].weight.shape[0],
+                        first.leaky_relu.negative_slope, slope, _p(first.feat_drop, training), _p(first.attn_drop, training),
+                        "mean", ops.new_seed())
+    params = []
+    for i, l in enumerate(layers):
+        params += [l.fc.weight, l.attn_l, l.attn_r, None if embeddings is None else embeddings[i].weight]
+    return ops.GATStackFunction.apply(g.csr(h.device), cfg, h, pos, *params)
+
+
+class GCN(nn.Module):
+    def __init__(self, in_dim, hidden_dim, out_dim, num_layers, activation, in_dropout=0.1, hidden_dropout=0.1, output_dropout=0.0):
+        super(GCN, self).__init__()
+        self.layers = nn.ModuleList()
+        self.layers.append(GCNLayer(in_dim, hidden_dim, activation, in_dropout))
+        for l in range(num_layers - 1):
+            self.layers.append(GCNLayer(hidden_dim, hidden_dim, activation, hidden_dropout))
+        self.layers.append(GCNLayer(hidden_dim, out_dim, None, output_dropout))
+
+    def forward(self, g, features):
+        """model_zoo.py:128-137"""
+        return _gcn_stack(self.layers, None, g, features, None, self.training)
+
+
+class PGCN(nn.Module):
+    def __init__(self, in_dim, hidden_dim, out_dim, pos_dim, num_layers, activation, in_dropout=0.1, hidden_dropout=0.1,
+                 output_dropout=0.0, position_vocab_size=3):
+        super(PGCN, self).__init__()
+        self.layers = nn.ModuleList()
+        self.prop_position_embeddings = nn.ModuleList()
+        self.layers.append(GCNLayer(in_dim + pos_dim, hidden_dim, activation, in_dropout))
+        self.prop_position_embeddings.append(nn.Embedding(position_vocab_size, pos_dim))
+        for l in range(num_layers - 1):
+            self.layers.append(GCNLayer(hidden_dim + pos_dim, hidden_dim, activation, hidden_dropout))
+            self.prop_position_embeddings.append(nn.Embedding(position_vocab_size, pos_dim))
+        self.layers.append(GCNLayer(hidden_dim + pos_dim, out_dim, None, output_dropout))
+        self.prop_position_embeddings.append(nn.Embedding(position_vocab_size, pos_dim))
+
+    def forward(self, g, features):
+        """model_zoo.py:155-167 (pops g.ndata['pos'], :163)"""
+        positions = g.ndata.pop('pos').to(features.device)
+        return _gcn_stack(self.layers, self.prop_position_embeddings, g, features, positions, self.training)
+
+
+def _gcn_stack(layers, embeddings, g, h, pos, training):
+    slopes = []
+    for l in layers:
+        s = _fused_slope(l.activation)
+        if l.activation and s is None:
+            raise NotImplementedError("GCN/PGCN: only leaky_relu (what model.py passes) or no activation is supported "
+                                      "by the fused MI355X path; use GCNLayer directly for other activations")
+        slopes.append(s)
+    vocab = 0 if embeddings is None else embeddings[0].weight.shape[0]
+    cfg = ops.GCNConfig([l.weight.shape[1] for l in layers], vocab, slopes, [_p(l.dropout, training) for l in layers],
+                        ops.new_seed())
+    params = []
+    for i, l in enumerate(layers):
+        params += [l.weight, l.bias, None if embeddings is None else embeddings[i].weight]
+    return ops.GCNStackFunction.apply(g.csr(h.device), cfg, h, pos, *params)
+
+
+class GAT(nn.Module):
+    def __init__(self, in_dim, hidden_dim, out_dim, num_layers, heads, activation, feat_drop=0.5, attn_drop=0.5,
+                 leaky_relu_alpha=0.2, residual=False):
+        super(GAT, self).__init__()
+        self.num_layers = num_layers
+        self.gat_layers = nn.ModuleList()
+        self.activation = activation
+        self.gat_layers.append(GATLayer(in_dim, hidden_dim, heads[0], feat_drop, attn_drop, leaky_relu_alpha, False))
+        for l in range(1, num_layers):
+            self.gat_layers.append(GATLayer(hidden_dim * heads[l - 1], hidden_dim, heads[l], feat_drop, attn_drop, leaky_relu_alpha, residual))
+        self.gat_layers.append(GATLayer(hidden_dim * heads[-2], out_dim, heads[-1], feat_drop, attn_drop, leaky_relu_alpha, residual))
+
+    def forward(self, g, features):
+        """model_zoo.py:183-190"""
+        out = _gat_stack(self.gat_layers, None, g, features, None, self.activation, self.training)
+        if out is not None:
+            return out
+        h = features
+        for l in range(self.num_layers):
+            h = self.gat_layers[l](g, h).flatten(1)
+            h = self.activation(h)
+        return self.gat_layers[-1](g, h).mean(1)
+
+
+class PGAT(nn.Module):
+    def __init__(self, in_dim, hidden_dim, out_dim, pos_dim, num_layers, heads, activation, feat_drop=0.5, attn_drop=0.5,
+                 leaky_relu_alpha=0.2, residual=False, position_vocab_size=3):
+        super(PGAT, self).__init__()
+        self.num_layers = num_layers
+        self.gat_layers = nn.ModuleList()
+        self.prop_position_embeddings = nn.ModuleList()
+        self.activation = activation
+        self.gat_layers.append(GATLayer(in_dim + pos_dim, hidden_dim, heads[0], feat_drop, attn_drop, leaky_relu_alpha, False))
+        self.prop_position_embeddings.append(nn.Embedding(position_vocab_size, pos_dim))
+        for l in range(1, num_layers):
+            self.gat_layers.append(GATLayer(hidden_dim * heads[l - 1] + pos_dim, hidden_dim, heads[l], feat_drop, attn_drop, leaky_relu_alpha, residual))
+            self.prop_position_embeddings.append(nn.Embedding(position_vocab_size, pos_dim))
+        self.gat_layers.append(GATLayer(hidden_dim * heads[-2] + pos_dim, out_dim, heads[-1], feat_drop, attn_drop, leaky_relu_alpha, residual))
+        self.prop_position_embeddings.append(nn.Embedding(position_vocab_size, pos_dim))
+
+    def forward(self, g, features):
+        """model_zoo.py:210-220 (pops g.ndata['pos'], :212)"""
+        positions = g.ndata.pop('pos').to(features.device)
+        out = _gat_stack(self.gat_layers, self.prop_position_embeddings, g, features, positions, self.activation, self.training)
+        if out is not None:
+            return out
+        h = features                       # generic activation / residual: layer by layer, concat materialised
+        for l in range(self.num_layers):
+            p = self.prop_position_embeddings[l](positions)
+            h = self.gat_layers[l](g, torch.cat((h, p), 1)).flatten(1)
+            h = self.activation(h)
+        p = self.prop_position_embeddings[-1](positions)
+        return self.gat_layers[-1](g, torch.cat((h, p), 1)).mean(1)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Readouts
+# ---------------------------------------------------------------------------------------------------------------
+class MeanReadout(nn.Module):
+    def __init__(self):
+        super(MeanReadout, self).__init__()
+
+    def forward(self, g, pos=None):
+        """model_zoo.py:231-232"""
+        h = g.ndata['h']
+        return ops.ReadoutFunction.apply(g.csr(h.device), h, None, None)
+
+
+class WeightedMeanReadout(nn.Module):
+    def __init__(self):
+        super(WeightedMeanReadout, self).__init__()
+        self.position_weights = nn.Embedding(3, 1)
+        self.nonlinear = F.softplus
+
+    def forward(self, g, pos):
+        """model_zoo.py:240-242"""
+        h = g.ndata['h']
+        g.ndata['a'] = _LazyPositionWeight(self.position_weights.weight, pos)
+        return ops.ReadoutFunction.apply(g.csr(h.device), h, pos, self.position_weights.weight)
+
+
+class _LazyPositionWeight:
+    """g.ndata['a'] of model_zoo.py:241 (softplus(Emb[pos])) -- nobody on the hot path reads it, so it is only
+    materialised if a caller asks (`.tensor()`)."""
+
+    def __init__(self, weight, pos):
+        self._w, self._pos = weight, pos
+
+    def tensor(self):
+        return F.softplus(self._w.detach()[self._pos.long()])
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Matchers
+# ---------------------------------------------------------------------------------------------------------------
+class _Bilinear(nn.Module):
+    apply_exp = False
+
+    def __init__(self, l_dim, r_dim):
+        super(_Bilinear, self).__init__()
+        self.W = nn.Bilinear(l_dim, r_dim, 1, bias=False)      # parameter container: same name/shape/init as the reference
+
+    def forward(self, e1, e2):
+        """e1 (*, l_dim), e2 (*, r_dim) -> (*, 1)"""
+        if e2.dim() == 2 and e2.stride(0) == 0 and e2.shape[0] == e1.shape[0] and not torch.is_grad_enabled():
+            # the eval loop's `nf.expand(n_position, -1)` (test_fast.py:122-123): one query against all candidates
+            U = ops.bilinear_project(e1, self.W.weight)
+            return ops.score_block(e2[:1], U, self.apply_exp).reshape(-1, 1)
+        return ops.BilinearPairFunction.apply(e1, e2, self.W.weight, self.apply_exp)
+
+    def score_all(self, hg, queries, block=1024, out=None):
+        """The whole scoring loop at once: S[q][g] = match(hg[g], queries[q]) (test_fast.py:116-123)."""
+        from .scoring import score_all
+        return score_all(self, hg, queries, block=block, out=out)
+
+
+class BIM(_Bilinear):
+    """model_zoo.py:301-313"""
+    apply_exp = False
+
+
+class LBM(_Bilinear):
+    """model_zoo.py:316-328: exp of the bilinear form"""
+    apply_exp = True

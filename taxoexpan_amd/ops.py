@@ -1,0 +1,381 @@
+"""torch.autograd bindings of the libtxe kernels (include/txe.h).
+
+torch is plumbing here: it owns device memory (caching allocator), the current HIP stream and autograd's tape;
+every number is produced by the hand-written HIP kernels.  There is no CPU path -- host tensors raise.
+"""
+import torch
+
+from . import _lib
+from ._lib import call, ptr
+
+LEAKY_SLOPE = 0.01  # F.leaky_relu default, the only activation model.py:25-41 passes
+
+
+def _need_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("taxoexpan_amd: tensors must live on the MI355X (no CPU fallback exists); "
+                               "got a host tensor")
+
+
+def _f32(t):
+    if t is None:
+        return None
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _rows(t):
+    """2-D fp32 tensor with unit column stride; returns (tensor, ld)."""
+    if t.dtype != torch.float32:
+        t = t.float()
+    if t.dim() != 2 or t.stride(1) != 1 or t.stride(0) < t.shape[1]:
+        t = t.contiguous()
+    return t, t.stride(0)
+
+
+def _i32(t, device):
+    if t is None:
+        return None
+    if t.dtype != torch.int32 or t.device != device:
+        t = t.to(device=device, dtype=torch.int32)
+    return t.contiguous()
+
+
+def _empty(shape, ref, dtype=torch.float32):
+    return torch.empty(shape, dtype=dtype, device=ref.device)
+
+
+def _ws(nbytes, ref):
+    return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=ref.device)
+
+
+def new_seed():
+    """64-bit dropout seed drawn from torch's CPU generator (so torch.manual_seed makes runs repeatable)."""
+    return int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
+
+
+# ================================================================================================================
+# GAT stack (PGAT / GAT / a single GATLayer)
+# ================================================================================================================
+class GATConfig:
+    """static description of a stack of GATLayers (model_zoo.py:52-114,169-220)"""
+
+    def __init__(self, heads, out_dims, pos_dims, vocab, attn_slope, act_slope, feat_p, attn_p, final, seed):
+        self.heads, self.out_dims, self.pos_dims, self.vocab = list(heads), list(out_dims), list(pos_dims), vocab
+        self.attn_slope, self.act_slope = float(attn_slope), act_slope
+        self.feat_p, self.attn_p = float(feat_p), float(attn_p)
+        self.final = final          # 'mean' (PGAT/GAT: .mean(1) over heads of the last layer) | 'none' (GATLayer: N x H x D)
+        self.seed = int(seed)
+        self.n_layers = len(self.heads)
+
+
+def _gat_layer_fwd(csr, h, ld_h, pos, P, W, al, ar, H, D, feat_p, attn_p, seed, attn_slope, out_mode, act_slope, save):
+    N, Kh = h.shape
+    Pd = 0 if P is None else P.shape[1]
+    F = H * D
+    ft, a_ext = _empty((N, F), h), _empty((N, 2 * H), h)
+    wsb = 2 * H * (Kh + Pd) * 4
+    ws = _ws(wsb, h)
+    st = _lib.stream_ptr()
+    call("txe_gat_project_fwd", ptr(h), ld_h, N, Kh, ptr(pos), ptr(P), Pd, ptr(W), ptr(al), ptr(ar), H, D, feat_p, seed,
+         ptr(ft), ptr(a_ext), ptr(ws), wsb, st)
+    out = _empty((N, F), h)
+    alpha = _empty((max(csr.n_edges, 1), H), h) if save else None
+    call("txe_gat_aggregate_fwd", ptr(csr.rowptr_in), ptr(csr.col_src), N, ptr(ft), F, ptr(a_ext), ptr(a_ext) + 4 * H, 2 * H,
+         H, D, attn_slope, attn_p, seed + 1, out_mode, act_slope, ptr(out), F, ptr(alpha), st)
+    return out, ft, a_ext, alpha
+
+
+def _gat_layer_bwd(csr, h, ld_h, pos, P, vocab, W, al, ar, H, D, feat_p, attn_p, seed, attn_slope, ft, a_ext, alpha,
+                   d_pre, ld_dpre, need_dh, act_src, act_slope):
+    N, Kh = h.shape
+    Pd = 0 if P is None else P.shape[1]
+    F = H * D
+    st = _lib.stream_ptr()
+    d_ft, d_a = _empty((N, F), h), _empty((N, 2 * H), h)
+    dz = _empty((max(csr.n_edges, 1) * H,), h)
+    call("txe_gat_aggregate_bwd", ptr(csr.rowptr_in), ptr(csr.col_src), ptr(csr.rowptr_out), ptr(csr.col_dst), ptr(csr.pos_out),
+         N, ptr(ft), F, ptr(a_ext), ptr(a_ext) + 4 * H, 2 * H, H, D, attn_slope, attn_p, seed + 1, ptr(alpha), ptr(d_pre),
+         ld_dpre, ptr(d_ft), F, ptr(d_a), ptr(d_a) + 4 * H, 2 * H, ptr(dz), st)
+    dW, dal, dar = torch.empty_like(W), torch.empty_like(al), torch.empty_like(ar)
+    dP = torch.empty_like(P) if P is not None else None
+    d_h = _empty((N, Kh), h) if need_dh else None
+    wsb = call("txe_gat_project_ws_bytes", N, Kh, Pd, H, D, vocab)
+    ws = _ws(wsb, h)
+    call("txe_gat_project_bwd", ptr(h), ld_h, N, Kh, ptr(pos), ptr(P), Pd, vocab, ptr(W), ptr(al), ptr(ar), H, D, feat_p, seed,
+         ptr(d_ft), ptr(d_a), ptr(d_h), Kh, ptr(act_src), (ld_h if act_src is not None else 0), act_slope if act_slope else 1.0,
+         ptr(dW), ptr(dal), ptr(dar), ptr(dP), ptr(ws), wsb, st)
+    return d_h, dW, dal, dar, dP
+
+
+class GATStackFunction(torch.autograd.Function):
+    """params per layer: (W [H*D, Kin], attn_l [1,H,D], attn_r [1,H,D], P [vocab, Pd] or None)."""
+
+    @staticmethod
+    def forward(ctx, csr, cfg, h, pos, *params):
+        _need_cuda(h, *[p for p in params if p is not None])
+        h, ld_h = _rows(h)
+        pos = _i32(pos, h.device)
+        L = cfg.n_layers
+        need = torch.is_grad_enabled() and (h.requires_grad or any(p is not None and p.requires_grad for p in params))
+        saved = []
+        x, ldx = h, ld_h
+        with torch.cuda.device(h.device):
+            for l in range(L):
+                W, al, ar, P = (_f32(p) for p in params[4 * l:4 * l + 4])
+                H, D = cfg.heads[l], cfg.out_dims[l]
+                last = (l == L - 1)
+                out_mode = 0 if (last or cfg.act_slope is None) else 1
+                out, ft, a_ext, alpha = _gat_layer_fwd(csr, x, ldx, pos if P is not None else None, P, W, al, ar, H, D,
+                                                       cfg.feat_p, cfg.attn_p, cfg.seed + 16 * l, cfg.attn_slope, out_mode,
+                                                       cfg.act_slope or 1.0, need)
+                saved.append((x, ldx, W, al, ar, P, ft, a_ext, alpha))
+                x, ldx = out, out.stride(0)
+            H, D = cfg.heads[-1], cfg.out_dims[-1]
+            if cfg.final == "mean":
+                if H == 1:
+                    res = x.view(x.shape[0], D)
+                else:
+                    res = _empty((x.shape[0], D), x)
+                    call("txe_head_mean_fwd", ptr(x), H, D, x.shape[0], ptr(res), _lib.stream_ptr())
+            else:
+                res = x.view(x.shape[0], H, D)
+        ctx.csr, ctx.cfg, ctx.pos, ctx.saved = csr, cfg, pos, (saved if need else None)
+        ctx.h_req = h.requires_grad
+        return res
+
+    @staticmethod
+    def backward(ctx, d_res):
+        csr, cfg, pos, saved = ctx.csr, ctx.cfg, ctx.pos, ctx.saved
+        L = cfg.n_layers
+        H, D = cfg.heads[-1], cfg.out_dims[-1]
+        d_res = _f32(d_res)
+        grads = [None] * (4 * L)
+        with torch.cuda.device(d_res.device):
+            if cfg.final == "mean" and H > 1:
+                d_pre = _empty((d_res.shape[0], H * D), d_res)
+                call("txe_head_mean_bwd", ptr(d_res), H, D, d_res.shape[0], ptr(d_pre), _lib.stream_ptr())
+            else:
+                d_pre = d_res.reshape(d_res.shape[0], H * D)
+            d_h = None
+            for l in range(L - 1, -1, -1):
+                x, ldx, W, al, ar, P, ft, a_ext, alpha = saved[l]
+                need_dh = (l > 0) or ctx.h_req
+                # the input of layer l>0 is leaky_relu(out_{l-1}) (fused epilogue): fold its derivative into dX
+                act_src = x if (l > 0 and cfg.act_slope is not None) else None
+                d_h, dW, dal, dar, dP = _gat_layer_bwd(csr, x, ldx, pos if P is not None else None, P, cfg.vocab, W, al, ar,
+                                                       cfg.heads[l], cfg.out_dims[l], cfg.feat_p, cfg.attn_p, cfg.seed + 16 * l,
+                                                       cfg.attn_slope, ft, a_ext, alpha, d_pre, d_pre.stride(0), need_dh, act_src,
+                                                       cfg.act_slope)
+                grads[4 * l:4 * l + 4] = [dW, dal, dar, dP]
+                d_pre = d_h
+        return (None, None, d_h if ctx.h_req else None, None, *grads)
+
+
+# ================================================================================================================
+# GCN stack (PGCN / GCN / a single GCNLayer)
+# ================================================================================================================
+class GCNConfig:
+    def __init__(self, out_dims, vocab, act_slopes, drop_ps, seed):
+        self.out_dims, self.vocab = list(out_dims), vocab
+        self.act_slopes = list(act_slopes)      # per layer: slope of the fused leaky_relu or None
+        self.drop_ps = [float(p) for p in drop_ps]
+        self.seed = int(seed)
+        self.n_layers = len(self.out_dims)
+
+
+def gcn_norm(csr, ref):
+    norm = _empty((csr.n_nodes,), ref)
+    call("txe_gcn_norm", ptr(csr.rowptr_in), csr.n_nodes, ptr(norm), _lib.stream_ptr())
+    return norm
+
+
+class GCNStackFunction(torch.autograd.Function):
+    """params per layer: (W [Kin, Fo], bias [Fo] or None, P [vocab, Pd] or None)."""
+
+    @staticmethod
+    def forward(ctx, csr, cfg, h, pos, *params):
+        _need_cuda(h, *[p for p in params if p is not None])
+        h, ld_h = _rows(h)
+        pos = _i32(pos, h.device)
+        L = cfg.n_layers
+        need = torch.is_grad_enabled() and (h.requires_grad or any(p is not None and p.requires_grad for p in params))
+        saved = []
+        x, ldx = h, ld_h
+        with torch.cuda.device(h.device):
+            st = _lib.stream_ptr()
+            norm = gcn_norm(csr, h)
+            for l in range(L):
+                W, b, P = (_f32(p) for p in params[3 * l:3 * l + 3])
+                N, Kh = x.shape
+                Pd = 0 if P is None else P.shape[1]
+                Fo = cfg.out_dims[l]
+                hw = _empty((N, Fo), x)
+                call("txe_gcn_project_fwd", ptr(x), ldx, N, Kh, ptr(pos if P is not None else None), ptr(P), Pd, ptr(W), Fo,
+                     cfg.drop_ps[l], cfg.seed + 16 * l, ptr(hw), st)
+                out = _empty((N, Fo), x)
+                slope = cfg.act_slopes[l]
+                call("txe_gcn_aggregate_fwd", ptr(csr.rowptr_in), ptr(csr.col_src), N, ptr(hw), Fo, ptr(norm), ptr(b),
+                     0 if slope is None else 1, slope or 1.0, Fo, ptr(out), Fo, st)
+                saved.append((x, ldx, W, b, P))
+                x, ldx = out, Fo
+        ctx.csr, ctx.cfg, ctx.pos, ctx.norm = csr, cfg, pos, norm
+        ctx.saved = saved if need else None
+        ctx.h_req = h.requires_grad
+        ctx.out = x if need else None
+        return x
+
+    @staticmethod
+    def backward(ctx, d_out):
+        csr, cfg, pos, norm, saved = ctx.csr, ctx.cfg, ctx.pos, ctx.norm, ctx.saved
+        L = cfg.n_layers
+        d_out = _f32(d_out)
+        grads = [None] * (3 * L)
+        with torch.cuda.device(d_out.device):
+            st = _lib.stream_ptr()
+            N = d_out.shape[0]
+            if cfg.act_slopes[-1] is not None:   # a standalone activated layer: undo the fused activation explicitly
+                d_pre = torch.empty_like(d_out)
+                call("txe_leaky_relu_bwd", ptr(d_out), ptr(ctx.out), cfg.act_slopes[-1], d_out.numel(), ptr(d_pre), st)
+            else:
+                d_pre = d_out
+            d_h = None
+            for l in range(L - 1, -1, -1):
+                x, ldx, W, b, P = saved[l]
+                Kh = x.shape[1]
+                Pd = 0 if P is None else P.shape[1]
+                Fo = cfg.out_dims[l]
+                d_hw = _empty((N, Fo), d_out)
+                d_b = torch.empty_like(b) if b is not None else None
+                wsb = call("txe_gcn_aggregate_bwd_ws_bytes", N, Fo)
+                ws = _ws(wsb, d_out)
+                call("txe_gcn_aggregate_bwd", ptr(csr.rowptr_out), ptr(csr.col_dst), N, ptr(d_pre), d_pre.stride(0), ptr(norm), Fo,
+                     ptr(d_hw), Fo, ptr(d_b), ptr(ws), wsb, st)
+                need_dh = (l > 0) or ctx.h_req
+                act_src = x if (l > 0 and cfg.act_slopes[l - 1] is not None) else None
+                d_h = _empty((N, Kh), d_out) if need_dh else None
+                dW = torch.empty_like(W)
+                dP = torch.empty_like(P) if P is not None else None
+                wsb2 = call("txe_gcn_project_ws_bytes", N, Kh, Pd, Fo, cfg.vocab)
+                ws2 = _ws(wsb2, d_out)
+                call("txe_gcn_project_bwd", ptr(x), ldx, N, Kh, ptr(pos if P is not None else None), ptr(P), Pd, cfg.vocab, ptr(W), Fo,
+                     cfg.drop_ps[l], cfg.seed + 16 * l, ptr(d_hw), ptr(d_h), Kh, ptr(act_src), (ldx if act_src is not None else 0),
+                     (cfg.act_slopes[l - 1] if act_src is not None else 1.0), ptr(dW), ptr(dP), ptr(ws2), wsb2, st)
+                grads[3 * l:3 * l + 3] = [dW, d_b, dP]
+                d_pre = d_h
+        return (None, None, d_h if ctx.h_req else None, None, *grads)
+
+
+# ================================================================================================================
+# Readout (MeanReadout / WeightedMeanReadout)
+# ================================================================================================================
+class ReadoutFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, csr, h, pos, pw):
+        _need_cuda(h, pw)
+        h, ld_h = _rows(h)
+        G, D = csr.n_graphs, h.shape[1]
+        pos = _i32(pos, h.device) if pw is not None else None
+        pwf = _f32(pw.reshape(-1)) if pw is not None else None
+        hg, wsum = _empty((G, D), h), _empty((max(G, 1),), h)
+        with torch.cuda.device(h.device):
+            call("txe_readout_fwd", ptr(csr.graph_off), G, ptr(h), ld_h, ptr(pos), ptr(pwf), D, ptr(hg), ptr(wsum),
+                 _lib.stream_ptr())
+        ctx.csr, ctx.pos, ctx.misc = csr, pos, (h, ld_h, pwf, hg, wsum)
+        ctx.pw_shape = None if pw is None else pw.shape
+        return hg
+
+    @staticmethod
+    def backward(ctx, d_hg):
+        csr, pos = ctx.csr, ctx.pos
+        h, ld_h, pwf, hg, wsum = ctx.misc
+        G, D = csr.n_graphs, h.shape[1]
+        d_hg = _f32(d_hg)
+        d_h = _empty((h.shape[0], D), h)
+        vocab = 0 if pwf is None else pwf.numel()
+        d_pw = torch.empty_like(pwf) if pwf is not None else None
+        ws = _empty((max(G, 1) * max(vocab, 1),), h) if pwf is not None else None
+        with torch.cuda.device(h.device):
+            call("txe_readout_bwd", ptr(csr.graph_off), G, ptr(h), ld_h, ptr(pos), ptr(pwf), vocab, D, ptr(hg), ptr(wsum), ptr(d_hg),
+                 ptr(d_h), D, ptr(d_pw), ptr(ws), _lib.stream_ptr())
+        return None, d_h, None, (d_pw.reshape(ctx.pw_shape) if d_pw is not None else None)
+
+
+# ================================================================================================================
+# Bilinear match (BIM / LBM) -- pairwise form of training, model.py:86
+# ================================================================================================================
+class BilinearPairFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, e1, e2, W, apply_exp):
+        _need_cuda(e1, e2, W)
+        e1, ld1 = _rows(e1)
+        e2, ld2 = _rows(e2)
+        Wf = _f32(W).reshape(W.shape[-2], W.shape[-1])
+        G, l = e1.shape
+        r = e2.shape[1]
+        U, s = _empty((max(G, 1), r), e1), _empty((G,), e1)
+        with torch.cuda.device(e1.device):
+            call("txe_bilinear_pair_fwd", ptr(e1), ld1, ptr(e2), ld2, G, l, r, ptr(Wf), int(apply_exp), ptr(U), ptr(s),
+                 _lib.stream_ptr())
+        ctx.misc = (e1, ld1, e2, ld2, Wf, U, s, int(apply_exp), W.shape)
+        ctx.e2_req = e2.requires_grad
+        return s.unsqueeze(1)
+
+    @staticmethod
+    def backward(ctx, ds):
+        e1, ld1, e2, ld2, Wf, U, s, apply_exp, wshape = ctx.misc
+        G, l = e1.shape
+        r = e2.shape[1]
+        ds = _f32(ds.reshape(-1))
+        d_e1 = _empty((G, l), e1)
+        d_e2 = _empty((G, r), e1) if ctx.e2_req else None
+        dW = torch.empty_like(Wf)
+        with torch.cuda.device(e1.device):
+            wsb = call("txe_bilinear_pair_bwd_ws_bytes", G, l, r)
+            ws = _ws(wsb, e1)
+            call("txe_bilinear_pair_bwd", ptr(e1), ld1, ptr(e2), ld2, G, l, r, ptr(Wf), apply_exp, ptr(U), ptr(s), ptr(ds), ptr(d_e1),
+                 l, ptr(d_e2), r, ptr(dW), ptr(ws), wsb, _lib.stream_ptr())
+        return d_e1, d_e2, dW.reshape(wshape), None
+
+
+# ================================================================================================================
+# inference-side helpers (no autograd)
+# ================================================================================================================
+def bilinear_project(hg, W):
+    """U = hg @ W[0]  (G x r): the factored half of the bilinear form, computed once per candidate set."""
+    _need_cuda(hg, W)
+    hg, ld = _rows(hg)
+    Wf = _f32(W).reshape(W.shape[-2], W.shape[-1])
+    G, l = hg.shape
+    r = Wf.shape[1]
+    U = _empty((G, r), hg)
+    with torch.cuda.device(hg.device):
+        call("txe_bilinear_project", ptr(hg), ld, G, l, ptr(Wf), r, ptr(U), _lib.stream_ptr())
+    return U
+
+
+def score_block(Q, U, apply_exp, out=None):
+    """S[q][g] = match(hg[g], Q[q]) for a block of queries against every candidate (test_fast.py:116-123)."""
+    _need_cuda(Q, U)
+    Q, ldq = _rows(Q)
+    nq, r = Q.shape
+    G = U.shape[0]
+    S = out if out is not None else _empty((nq, G), Q)
+    with torch.cuda.device(Q.device):
+        call("txe_score_block", ptr(Q), ldq, nq, ptr(U), G, r, int(apply_exp), ptr(S), S.stride(0), _lib.stream_ptr())
+    return S
+
+
+def rank_block(S, pos_off, pos_idx, larger_is_better=True):
+    """ranks of each query's true parents among the candidates (metric.py:7-31 semantics), int32 on device."""
+    _need_cuda(S)
+    nq, G = S.shape
+    pos_off = _i32(pos_off, S.device)
+    pos_idx = _i32(pos_idx, S.device)
+    ranks = torch.empty(max(int(pos_idx.numel()), 1), dtype=torch.int32, device=S.device)
+    with torch.cuda.device(S.device):
+        call("txe_rank_block", ptr(S), S.stride(0), nq, G, ptr(pos_off), ptr(pos_idx), ptr(ranks), int(larger_is_better), None,
+             _lib.stream_ptr())
+    return ranks[:pos_idx.numel()]

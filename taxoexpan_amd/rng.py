@@ -1,0 +1,31 @@
+"""Host restatement of the counter-based dropout hash of csrc/txe_common.h (mix64 / uniform01 / drop_factor).
+
+The kernels never store a dropout mask: keep(seed, index) is a pure function that forward and backward both
+re-evaluate.  This numpy version produces the identical mask so that tests can hand the very same mask to the
+oracle (whose dropout is an explicit keep-mask multiply, model_zoo.py:82,114).
+"""
+import numpy as np
+
+_M = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+
+def _mix64(z):
+    z = (z + np.uint64(0x9E3779B97F4A7C15)) & _M
+    z = ((z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)) & _M
+    z = ((z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)) & _M
+    return z ^ (z >> np.uint64(31))
+
+
+def uniform01(seed, idx):
+    """idx: integer array.  Returns float32 uniforms in [0,1) exactly as the device computes them."""
+    with np.errstate(over="ignore"):
+        idx = np.asarray(idx).astype(np.uint64)
+        h = _mix64(np.uint64(seed) ^ _mix64(idx))
+    return (h >> np.uint64(40)).astype(np.float32) * np.float32(1.0 / 16777216.0)
+
+
+def keep_mask(seed, shape, p):
+    """0/1 float32 keep mask of `shape` (row-major linear index), for dropout probability p."""
+    n = int(np.prod(shape))
+    u = uniform01(seed, np.arange(n, dtype=np.uint64))
+    return (u >= np.float32(p)).astype(np.float32).reshape(shape)

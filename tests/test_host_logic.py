@@ -1,0 +1,123 @@
+"""CPU: host-side logic -- the DGL-0.4 graph surface, CSR construction, synthetic taxonomies / egonet batching,
+module/state-dict compatibility with the reference (names + shapes from the golden specs)."""
+import numpy as np
+import pytest
+import torch
+
+import golden_cases as gc
+import txe_oracle as orc
+
+
+def test_dgl_surface_and_batch_match_reference_layout():
+    from taxoexpan_amd import graph as G
+    shapes = gc.EDGE_SHAPES
+    graphs = []
+    for (k, m) in shapes:      # dataset.py:429-435 call sequence
+        n = k + 1 + m
+        g = G.DGLGraph()
+        g.add_nodes(n, {"x": torch.randn(n, 4), "_id": torch.arange(n), "pos": torch.tensor([0] * k + [1] + [2] * m)})
+        g.add_edges(list(range(k)), k)
+        g.add_edges(k, list(range(k + 1, n)))
+        g.add_edges(g.nodes(), g.nodes())
+        assert g.number_of_nodes() == n and g.number_of_edges() == 2 * n - 1
+        graphs.append(g)
+    bg = G.batch(graphs)
+    ref = orc.batch_egonets(shapes)
+    assert bg.batch_size == len(shapes)
+    assert bg.batch_num_nodes == [k + 1 + m for k, m in shapes]
+    assert np.array_equal(bg._src, ref["src"].numpy()) and np.array_equal(bg._dst, ref["dst"].numpy())
+    assert torch.equal(bg.ndata["pos"], ref["pos"])
+    assert torch.equal(bg.in_degrees(), torch.bincount(ref["dst"], minlength=ref["num_nodes"]))
+    x = bg.ndata.pop("x")
+    assert x.shape[0] == bg.number_of_nodes() and "x" not in bg.ndata
+    # vectorised constructor == per-egonet construction + dgl.batch
+    vg = G.BatchedDGLGraph.from_egonet_shapes([s[0] for s in shapes], [s[1] for s in shapes])
+    assert np.array_equal(vg._src, bg._src) and np.array_equal(vg._dst, bg._dst)
+    assert torch.equal(vg.ndata["pos"], bg.ndata["pos"]) and vg.batch_num_edges == bg.batch_num_edges
+
+
+def test_host_csr_views():
+    from taxoexpan_amd import graph as G
+    rs = np.random.RandomState(0)
+    n, e = 50, 400
+    src, dst = rs.randint(0, n, e), rs.randint(0, n, e)
+    g = G.DGLGraph()
+    g.add_nodes(n)
+    g.add_edges(src, dst)
+    c = g.csr("cpu")
+    rp, col, eid = c.rowptr_in.numpy(), c.col_src.numpy(), c.eid_in.numpy()
+    for v in range(n):
+        seg = eid[rp[v]:rp[v + 1]]
+        assert np.all(dst[seg] == v) and np.all(np.diff(seg) > 0)          # stable: edge-id order inside a segment
+        assert np.array_equal(col[rp[v]:rp[v + 1]], src[seg])
+    rpo, cd, po = c.rowptr_out.numpy(), c.col_dst.numpy(), c.pos_out.numpy()
+    for u in range(n):
+        for j in range(rpo[u], rpo[u + 1]):
+            p = po[j]
+            assert col[p] == u and dst[eid[p]] == cd[j]
+    assert c.graph_off.tolist() == [0, n]
+    with pytest.raises(ValueError):
+        g.add_edges([0], [n])
+
+
+def test_synthetic_taxonomy_and_egonets():
+    from taxoexpan_amd import synthetic as syn
+    tax = syn.make_taxonomy(3000, 4700, 16, seed=1)
+    assert tax.par_ptr[-1] == tax.n_edges and tax.chd_ptr[-1] == tax.n_edges
+    # DAG in topological order, distinct parents
+    for v in range(1, 3000, 97):
+        ps = tax.par_idx[tax.par_ptr[v]:tax.par_ptr[v + 1]]
+        assert len(ps) >= 1 and np.all(ps < v) and len(set(ps.tolist())) == len(ps)
+    leaf_frac = len(tax.leaves()) / tax.n_nodes
+    assert 0.6 < leaf_frac < 0.95
+    np.testing.assert_allclose(tax.features.norm(dim=1).numpy(), 1.0, rtol=1e-5)
+    cand, val, test = syn.split_candidates(tax)
+    assert len(val) == len(test) and len(cand) + len(val) + len(test) == tax.n_nodes
+    g = syn.egonet_batch(tax, cand[:200], expand_factor=5, seed=3)
+    n = np.asarray(g.batch_num_nodes)
+    off = np.concatenate([[0], np.cumsum(n)])
+    ids, pos = g.ndata["_id"].numpy(), g.ndata["pos"].numpy()
+    for i, a in enumerate(cand[:200]):
+        p = pos[off[i]:off[i + 1]]
+        k, m = int((p == 0).sum()), int((p == 2).sum())
+        assert ids[off[i] + k] == a and m <= 5
+        assert sorted(ids[off[i]:off[i] + k].tolist()) == sorted(tax.par_idx[tax.par_ptr[a]:tax.par_ptr[a + 1]].tolist())
+        assert set(ids[off[i] + k + 1:off[i + 1]].tolist()) <= set(tax.chd_idx[tax.chd_ptr[a]:tax.chd_ptr[a + 1]].tolist())
+    assert torch.equal(g.ndata["x"], tax.features[g.ndata["_id"]])
+    gb, qf, lab = syn.training_batch(tax, 8, 3, seed=2)
+    assert gb.batch_size == 32 and qf.shape == (32, 16) and lab.reshape(8, 4)[:, 0].tolist() == [1] * 8
+    # the positive egonet never contains its own query among the siblings (instance_mode 1, dataset.py:421-424)
+    assert gb.number_of_edges() == 2 * gb.number_of_nodes() - gb.batch_size
+
+
+@pytest.mark.parametrize("name", [n for n, s in gc.CASES.items() if s["match"] != "MLP" and s["readout"] != "CR"])
+def test_state_dict_names_and_shapes_match_reference(name):
+    """strict load of the reference-keyed parameter set (keys/shapes were pinned by load_state_dict(strict=True) on the
+    reference's own TaxoExpan in oracle/gen_golden.py)"""
+    from taxoexpan_amd import TaxoExpan
+    spec = gc.CASES[name]
+    params = gc.make_params(spec)
+    model = TaxoExpan(spec["prop"], spec["readout"], spec["match"], in_dim=spec["in_dim"], hidden_dim=spec["hidden_dim"],
+                      out_dim=spec["out_dim"], pos_dim=spec["pos_dim"], num_layers=spec["num_layers"], heads=spec["heads"],
+                      feat_drop=0.1, attn_drop=0.1, hidden_drop=0.1, out_drop=0.1)
+    sd = model.state_dict()
+    assert list(sd.keys()) == list(params.keys())
+    for k, v in params.items():
+        assert tuple(sd[k].shape) == v.shape, k
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()}, strict=True)
+    assert hasattr(model, "graph_propagate") and hasattr(model, "readout") and hasattr(model, "match")
+
+
+def test_unknown_method_strings_fall_through_silently():
+    from taxoexpan_amd import TaxoExpan
+    m = TaxoExpan("nope", "MR", "BIM", in_dim=4, hidden_dim=4, out_dim=4, pos_dim=2, num_layers=1, heads=[1, 1],
+                  feat_drop=0.1, attn_drop=0.1, hidden_drop=0.1, out_drop=0.1)
+    assert not hasattr(m, "graph_propagate")       # model/model.py:43 `assert "<str>"` never fires
+
+
+def test_generic_dgl_message_passing_raises_loudly():
+    from taxoexpan_amd import graph as G
+    g = G.DGLGraph()
+    g.add_nodes(2)
+    with pytest.raises(NotImplementedError):
+        g.update_all(None, None)

@@ -119,7 +119,7 @@ class GATStackFunction(torch.autograd.Function):
         h, ld_h = _rows(h)
         pos = _i32(pos, h.device)
         L = cfg.n_layers
-        need = torch.is_grad_enabled() and (h.requires_grad or any(p is not None and p.requires_grad for p in params))
+        need = any(ctx.needs_input_grad)       # (grad mode itself is off inside Function.forward)
         saved = []
         x, ldx = h, ld_h
         with torch.cuda.device(h.device):
@@ -143,7 +143,7 @@ class GATStackFunction(torch.autograd.Function):
             else:
                 res = x.view(x.shape[0], H, D)
         ctx.csr, ctx.cfg, ctx.pos, ctx.saved = csr, cfg, pos, (saved if need else None)
-        ctx.h_req = h.requires_grad
+        ctx.h_req = ctx.needs_input_grad[2]
         return res
 
     @staticmethod
@@ -201,7 +201,7 @@ class GCNStackFunction(torch.autograd.Function):
         h, ld_h = _rows(h)
         pos = _i32(pos, h.device)
         L = cfg.n_layers
-        need = torch.is_grad_enabled() and (h.requires_grad or any(p is not None and p.requires_grad for p in params))
+        need = any(ctx.needs_input_grad)       # (grad mode itself is off inside Function.forward)
         saved = []
         x, ldx = h, ld_h
         with torch.cuda.device(h.device):
@@ -223,7 +223,7 @@ class GCNStackFunction(torch.autograd.Function):
                 x, ldx = out, Fo
         ctx.csr, ctx.cfg, ctx.pos, ctx.norm = csr, cfg, pos, norm
         ctx.saved = saved if need else None
-        ctx.h_req = h.requires_grad
+        ctx.h_req = ctx.needs_input_grad[2]
         ctx.out = x if need else None
         return x
 
@@ -320,7 +320,7 @@ class BilinearPairFunction(torch.autograd.Function):
             call("txe_bilinear_pair_fwd", ptr(e1), ld1, ptr(e2), ld2, G, l, r, ptr(Wf), int(apply_exp), ptr(U), ptr(s),
                  _lib.stream_ptr())
         ctx.misc = (e1, ld1, e2, ld2, Wf, U, s, int(apply_exp), W.shape)
-        ctx.e2_req = e2.requires_grad
+        ctx.e2_req = ctx.needs_input_grad[1]
         return s.unsqueeze(1)
 
     @staticmethod

@@ -1,0 +1,296 @@
+#!/usr/bin/env python3
+"""bench.py -- egonet-edges/s of the PGAT training step (BASELINE.json metric, configs[1]) on N MI355X of one node.
+
+A "step" = one pass of the hot path over one batch: 128 queries x (1 positive + 31 negative) = 4,096 egonets of the
+MAG-CS-shaped synthetic taxonomy per GPU (config_files/config.mag.json:28-30): PGAT (250+50 -> 4x500 -> 500) +
+WeightedMeanReadout + LBM, InfoNCE, backward, Adam(amsgrad) -- exactly trainer/trainer.py:45-61 -- in training mode
+(dropout 0.1 as the config says).  Inputs (CSR, features, queries) are resident in HBM before the timed region.
+N > 1: one process per GPU (torch.distributed / RCCL), each rank its own batch (weak scaling), one flat gradient
+all-reduce per step.
+
+Prints ONE JSON line (rank 0) with value = total egonet-edges/s over all ranks, plus
+  roofline      -- the dominant kernel by time in an instrumented pass (HIP events on the launch stream, per launch)
+  roofline_all  -- the same for every kernel class (the message/reduce kernels are HBM-bound, the projections MFMA-bound)
+  cpu_baseline  -- the CPU oracle (torch fp32, explicit COO; a restatement of the reference's DGL-CPU path, which
+                   cannot run: DGL 0.4 is not installable) timed on the host cores on a bounded sample of the same batch
+  extra         -- forward-only edges/s and candidates-scored/s of the eval loop (MAG-CS: 24.7k candidates x 2,450 queries)
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.nn.functional as F
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+MAG = dict(in_dim=250, hidden_dim=500, out_dim=500, pos_dim=50, num_layers=1, heads=[4, 1], feat_drop=0.1, attn_drop=0.1,
+           hidden_drop=0.1, out_drop=0.1)
+N_QUERIES, NEG = 128, 31
+PEAK_MFMA_F32 = 157.3e12      # MI355X_MICROARCH.md: fp32 MFMA = fp32 vector peak, no TF32 on gfx950
+PEAK_HBM = 8.0e12             # spec; ~6.3e12 achievable
+
+
+def build_batches(tax, n_batches, seed0, device):
+    from taxoexpan_amd import synthetic as syn
+    out = []
+    for b in range(n_batches):
+        g, qf, labels = syn.training_batch(tax, N_QUERIES, NEG, seed=seed0 + b)
+        x = g.ndata.pop("x").to(device)
+        pos = g.ndata["pos"].to(device)
+        g.csr(device)                    # CSR views resident in HBM
+        out.append(dict(g=g, x=x, pos=pos, qf=qf.to(device), n_nodes=g.number_of_nodes(), n_edges=g.number_of_edges()))
+    return out
+
+
+def train_step(model, opt, batch, target, world):
+    from taxoexpan_amd.scoring import allreduce_gradients
+    g = batch["g"]
+    g.ndata["pos"] = batch["pos"]
+    opt.zero_grad(set_to_none=True)
+    pred = model(g, batch["x"], batch["qf"])                       # trainer.py:51
+    loss = F.cross_entropy(pred.reshape(N_QUERIES, -1), target, reduction="sum")   # trainer.py:52-56, loss.py:57
+    loss.backward()                                                  # trainer.py:60
+    if world > 1:
+        allreduce_gradients(list(model.parameters()))
+    opt.step()                                                       # trainer.py:61
+    return loss
+
+
+def profile_step(model, opt, batch, target):
+    """one instrumented step: per-kernel durations from HIP events on the launch stream (libtxe profiling facility)"""
+    from taxoexpan_amd import _lib
+    lib = _lib.load()
+    lib.txe_profile_reset()
+    lib.txe_profile_enable(1)
+    train_step(model, opt, batch, target, 1)
+    torch.cuda.synchronize()
+    lib.txe_profile_enable(0)
+    recs = []
+    buf = ctypes.create_string_buffer(64)
+    ms, work, kind = ctypes.c_float(), ctypes.c_double(), ctypes.c_int()
+    for i in range(lib.txe_profile_count()):
+        lib.txe_profile_get(i, buf, 64, ctypes.byref(ms), ctypes.byref(work), ctypes.byref(kind))
+        recs.append((buf.value.decode(), ms.value * 1e-3, work.value, kind.value))
+    lib.txe_profile_reset()
+    return recs
+
+
+def summarize_profile(all_recs, n_edges_by_launch):
+    """aggregate records by kernel name: launches, avg duration, algorithmic work per launch, roofline fraction"""
+    agg = {}
+    for recs, e in zip(all_recs, n_edges_by_launch):
+        for name, sec, work, kind in recs:
+            if kind == 1 and name.startswith("gat_"):       # add the E-proportional compulsory bytes (alpha/dz + CSR col)
+                H = 4 if work > 4.0 * 2 * 1000 * 1000 else 1   # layer-0 (H=4, F=2000) vs layer-1 (H=1, F=500) rows
+                work += 4.0 * e * (H + 1)
+            a = agg.setdefault(name, dict(launches=0, sec=0.0, work=0.0, kind=kind))
+            a["launches"] += 1
+            a["sec"] += sec
+            a["work"] += work
+    out = []
+    for name, a in agg.items():
+        peak = PEAK_HBM if a["kind"] == 1 else PEAK_MFMA_F32
+        ach = a["work"] / a["sec"] if a["sec"] > 0 else 0.0
+        out.append(dict(kernel=name, bound="hbm" if a["kind"] == 1 else "mfma", launches=a["launches"],
+                        avg_us=1e6 * a["sec"] / a["launches"], total_us=1e6 * a["sec"],
+                        achieved=(ach / 1e9 if a["kind"] == 1 else ach / 1e12), peak=(peak / 1e9 if a["kind"] == 1 else peak / 1e12),
+                        unit="GB/s" if a["kind"] == 1 else "TFLOP/s", frac=ach / peak, work_per_launch=a["work"] / a["launches"]))
+    out.sort(key=lambda r: -r["total_us"])
+    return out
+
+
+def cpu_baseline(batch, state_dict, n_sample_queries=16, iters=2):
+    """The oracle's training step (forward + InfoNCE + backward, torch CPU fp32, all host threads) on the first
+    n_sample_queries x 32 egonets of the same batch."""
+    sys.path.insert(0, os.path.join(REPO, "oracle"))
+    import txe_oracle as orc
+    g = batch["g"]
+    n_g = n_sample_queries * (1 + NEG)
+    n_nodes = int(np.sum(g.batch_num_nodes[:n_g]))
+    n_edges = int(np.sum(g.batch_num_edges[:n_g]))
+    pos = batch["pos"].cpu().long()[:n_nodes]
+    goff = torch.from_numpy(np.concatenate([[0], np.cumsum(g.batch_num_nodes[:n_g])])).long()
+    graph = dict(src=torch.from_numpy(g._src[:n_edges]), dst=torch.from_numpy(g._dst[:n_edges]), pos=pos, graph_off=goff,
+                 num_nodes=n_nodes)
+    x = batch["x"][:n_nodes].cpu()
+    q = batch["qf"][:n_g].cpu()
+    P = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in state_dict.items()}
+    rs = np.random.RandomState(0)
+    masks = []
+    for l, (kt, H) in enumerate(((300, 4), (2050, 1))):      # dropout as explicit masks (same work as nn.Dropout)
+        masks.append(dict(feat_keep=torch.from_numpy((rs.uniform(size=(n_nodes, kt)) >= 0.1).astype(np.float32)), feat_scale=1 / 0.9,
+                          attn_keep=torch.from_numpy((rs.uniform(size=(n_edges, H, 1)) >= 0.1).astype(np.float32)), attn_scale=1 / 0.9))
+
+    def step():
+        for p in P.values():
+            p.grad = None
+        s, _, _ = orc.taxoexpan_forward(P, graph, x, q, "PGAT", "WMR", "LBM", [4, 1], 1, masks)
+        orc.info_nce_loss(s, n_sample_queries).backward()
+    step()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        step()
+    dt = (time.perf_counter() - t0) / iters
+    return dict(value=n_edges / dt, unit="egonet-edges/s", cores=torch.get_num_threads(), kind="port",
+                sample=f"{n_g} of the 4096 egonets of batch 0 ({n_nodes} nodes, {n_edges} edges), fwd+InfoNCE+bwd, "
+                       f"{iters} timed iterations after 1 warm-up, {dt:.3f} s/iter; oracle/txe_oracle.py (torch CPU fp32)")
+
+
+def extra_metrics(model, tax, device, batches, target):
+    """forward-only throughput and the eval scoring loop (candidates scored / s) on one GPU"""
+    from taxoexpan_amd import ops, synthetic as syn
+    from taxoexpan_amd.scoring import encode_candidates, score_all
+    out = {}
+    model.eval()
+    with torch.no_grad():
+        for _ in range(2):
+            for b in batches:
+                b["g"].ndata["pos"] = b["pos"]
+                model(b["g"], b["x"], b["qf"])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        reps = 5
+        for _ in range(reps):
+            for b in batches:
+                b["g"].ndata["pos"] = b["pos"]
+                model(b["g"], b["x"], b["qf"])
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        out["pgat_fwd_eval_edges_per_s"] = reps * sum(b["n_edges"] for b in batches) / dt
+        # all-candidate inference (test_fast.py small mode): encode every candidate egonet, score every test query
+        cand, val, test = syn.split_candidates(tax)
+        g = syn.egonet_batch(tax, cand, seed=7)
+        g.ndata["x"] = g.ndata["x"].to(device)
+        g.csr(device)
+        queries = tax.features[torch.from_numpy(test)].to(device)
+        hg = encode_candidates(model, g)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        hg = encode_candidates(model, g)
+        torch.cuda.synchronize()
+        t_enc = time.perf_counter() - t0
+        S = score_all(model.match, hg, queries)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        S = score_all(model.match, hg, queries, out=S)
+        torch.cuda.synchronize()
+        t_sc = time.perf_counter() - t0
+        # ranks of each query's true parents on device
+        cand_index = np.full(tax.n_nodes, -1, dtype=np.int64)
+        cand_index[cand] = np.arange(len(cand))
+        pos_lists = [cand_index[tax.par_idx[tax.par_ptr[q]:tax.par_ptr[q + 1]]] for q in test]
+        pos_lists = [p[p >= 0] for p in pos_lists]
+        off = torch.tensor(np.concatenate([[0], np.cumsum([len(p) for p in pos_lists])]), dtype=torch.int32)
+        idx = torch.tensor(np.concatenate(pos_lists) if len(pos_lists) else np.zeros(0), dtype=torch.int32)
+        t0 = time.perf_counter()
+        ranks = ops.rank_block(S, off, idx, True)
+        torch.cuda.synchronize()
+        t_rk = time.perf_counter() - t0
+        out.update(infer_candidates=int(len(cand)), infer_queries=int(len(test)), infer_encode_s=t_enc,
+                   infer_encode_edges_per_s=g.number_of_edges() / t_enc, infer_score_s=t_sc,
+                   candidates_scored_per_s=len(cand) * len(test) / t_sc,
+                   candidates_scored_per_s_incl_encode_and_rank=len(cand) * len(test) / (t_enc + t_sc + t_rk),
+                   infer_rank_s=t_rk, mean_rank=float(ranks.float().mean().item()) if ranks.numel() else None)
+    model.train()
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    from taxoexpan_amd import TaxoExpan, synthetic as syn
+    tax = syn.make_named_taxonomy("mag_cs", seed=47)
+    torch.manual_seed(47)
+    model = TaxoExpan("PGAT", "WMR", "LBM", **MAG).to(device).train()
+    if world > 1:                                   # identical replicas
+        for p in model.parameters():
+            dist.broadcast(p.data, src=0)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=0, amsgrad=True)   # config.mag.json:66-73
+    batches = build_batches(tax, 4, seed0=1000 * (rank + 1), device=device)
+    target = torch.zeros(N_QUERIES, dtype=torch.long, device=device)
+
+    for i in range(args.warmup):
+        train_step(model, opt, batches[i % len(batches)], target, world)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    edges = 0
+    for i in range(args.steps):
+        b = batches[i % len(batches)]
+        train_step(model, opt, b, target, world)
+        edges += b["n_edges"]
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        e = torch.tensor([edges], dtype=torch.float64, device=device)
+        dist.all_reduce(e, op=dist.ReduceOp.SUM)
+        edges = float(e.item())
+
+    roof_all, cpu, extra = None, None, None
+    if rank == 0:
+        recs = [profile_step(model, opt, b, target) for b in batches]
+        roof_all = summarize_profile(recs, [b["n_edges"] for b in batches])
+    if rank == 0 and world == 1:
+        if not args.no_cpu_baseline:
+            cpu = cpu_baseline(batches[0], model.state_dict())
+        if not args.no_extra:
+            extra = extra_metrics(model, tax, device, batches, target)
+    if world > 1:
+        dist.barrier()
+
+    if rank == 0:
+        dom = roof_all[0]
+        line = {
+            "metric": "egonet_edges_per_sec_pgat_fwd_bwd", "value": edges / elapsed, "unit": "egonet-edges/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "MAG-CS synthetic taxonomy (29,654 nodes, d=250), PGAT+WMR+LBM fp32 dims 250/50/500/500 heads [4,1], "
+                                   "128 queries x 32 = 4096 egonets per GPU per step, fwd + InfoNCE + bwd + Adam(amsgrad), dropout 0.1",
+                       "egonets_per_step_per_gpu": N_QUERIES * (1 + NEG), "avg_edges_per_step_per_gpu": edges / args.steps / world,
+                       "parallelism": f"dp{world}"},
+            "roofline": {"bound": dom["bound"], "achieved": dom["achieved"], "peak": dom["peak"], "unit": dom["unit"],
+                         "frac": dom["frac"], "traffic": None, "kernel": dom["kernel"], "avg_us": dom["avg_us"],
+                         "launches_per_4_steps": dom["launches"], "work_per_launch": dom["work_per_launch"]},
+            "roofline_all": roof_all,
+            "cpu_baseline": cpu,
+            "extra": extra,
+        }
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -13,8 +13,9 @@
  *   - graph structure: destination-sorted CSR  (rowptr_in[N+1], col_src[E])  and source-sorted CSR
  *     (rowptr_out[N+1], col_dst[E], pos_out[E] = index of that edge in the destination-sorted order); per-edge
  *     arrays (alpha, dz) live in destination-sorted order
- *   - dropout: counter based, keep(seed, index) = splitmix64 hash (taxoexpan_amd/csrc/txe_common.h, restated for
- *     tests in taxoexpan_amd/rng.py); index = row*cols+col for features, csr_position*H+head for attention
+ *   - dropout: counter based splitmix64 hash (taxoexpan_amd/csrc/txe_common.h, restated for tests in
+ *     taxoexpan_amd/rng.py): features use a precomputed keep-bit mask (txe_dropout_mask), attention coefficients
+ *     hash (seed, csr_position*H+head) inline
  */
 #ifndef TXE_H
 #define TXE_H
@@ -29,19 +30,25 @@ extern "C" {
 #define TXE_ERR_LAUNCH -2
 #define TXE_ERR_WORKSPACE -3
 
+/* ---- feature dropout (nn.Dropout of model_zoo.py:36,82) as a keep-bit mask over an [n_rows][n_cols] operand: 32 columns per
+ * word, ceil(n_cols/32) words per row.  Generated once per layer per step; forward, dX and dW all read the same mask.
+ * Pass mask = NULL (or p = 0) to the projections for "no dropout" (eval mode). */
+size_t txe_dropout_mask_bytes(long long n_rows, int n_cols);
+int txe_dropout_mask(long long n_rows, int n_cols, float p, unsigned long long seed, unsigned* mask, void* stream);
+
 /* ---- GATLayer dense part: model_zoo.py:82-85 (feat_drop, fc, a1, a2) with the PGAT concat of :214-215 -------------
  * h [N][Kh] (row stride ld_h), pos [N] in [0,vocab), P [vocab][Pd] (Pd = 0 -> plain GAT, :186), W [H*D][Kh+Pd],
  * attn_l/attn_r [H*D].  Writes ft [N][H*D] and a_ext [N][2H] = [a1 | a2].  ws >= 2H*(Kh+Pd) floats. */
 size_t txe_gat_project_ws_bytes(int n_nodes, int Kh, int Pd, int H, int D, int vocab);
 int txe_gat_project_fwd(const float* h, long long ld_h, int n_nodes, int Kh, const int* pos, const float* P, int Pd,
                         const float* W, const float* attn_l, const float* attn_r, int H, int D, float feat_drop_p,
-                        unsigned long long seed, float* ft, float* a_ext, void* ws, size_t ws_bytes, void* stream);
+                        const unsigned* mask, float* ft, float* a_ext, void* ws, size_t ws_bytes, void* stream);
 /* backward of the above given d_ft [N][H*D], d_a_ext [N][2H].  Writes dW, d_attn_l, d_attn_r, dP [vocab][Pd] and, if
  * d_h != NULL, d_h [N][Kh] (x leaky'(act_src) when act_src != NULL: backward of the F.leaky_relu of model_zoo.py:216
  * that produced h).  ws >= txe_gat_project_ws_bytes. */
 int txe_gat_project_bwd(const float* h, long long ld_h, int n_nodes, int Kh, const int* pos, const float* P, int Pd, int vocab,
                         const float* W, const float* attn_l, const float* attn_r, int H, int D, float feat_drop_p,
-                        unsigned long long seed, const float* d_ft, const float* d_a_ext, float* d_h, long long ld_dh,
+                        const unsigned* mask, const float* d_ft, const float* d_a_ext, float* d_h, long long ld_dh,
                         const float* act_src, long long ld_act, float act_slope, float* dW, float* d_attn_l, float* d_attn_r,
                         float* dP, void* ws, size_t ws_bytes, void* stream);
 
@@ -67,9 +74,9 @@ int txe_head_mean_bwd(const float* dy, int H, int D, long long n_rows, float* dx
 /* ---- GCNLayer: model_zoo.py:34-50 and the norm of :157-161 ------------------------------------------------------ */
 size_t txe_gcn_project_ws_bytes(int n_nodes, int Kh, int Pd, int Fo, int vocab);
 int txe_gcn_project_fwd(const float* h, long long ld_h, int n_nodes, int Kh, const int* pos, const float* P, int Pd,
-                        const float* W, int Fo, float drop_p, unsigned long long seed, float* hw, void* stream);
+                        const float* W, int Fo, float drop_p, const unsigned* mask, float* hw, void* stream);
 int txe_gcn_project_bwd(const float* h, long long ld_h, int n_nodes, int Kh, const int* pos, const float* P, int Pd, int vocab,
-                        const float* W, int Fo, float drop_p, unsigned long long seed, const float* d_hw, float* d_h,
+                        const float* W, int Fo, float drop_p, const unsigned* mask, const float* d_hw, float* d_h,
                         long long ld_dh, const float* act_src, long long ld_act, float act_slope, float* dW, float* dP,
                         void* ws, size_t ws_bytes, void* stream);
 int txe_gcn_norm(const int* rowptr_in, int n_nodes, float* norm, void* stream);
@@ -112,8 +119,17 @@ size_t txe_build_csr_ws_bytes(int n_nodes, int n_edges);
 int txe_build_csr(const int* src, const int* dst, int n_nodes, int n_edges, int* rowptr_in, int* col_src, int* eid_in,
                   int* rowptr_out, int* col_dst, int* pos_out, void* ws, size_t ws_bytes, void* stream);
 
+/* ---- optional per-kernel timing (debug / bench): HIP events on the launch stream around every kernel launch, with the
+ * algorithmic work (flops or compulsory bytes) its launcher attributes to it.  The library's only global state; off by
+ * default.  txe_profile_get synchronises on record i's events. */
+int txe_profile_enable(int on);
+int txe_profile_reset(void);
+int txe_profile_count(void);
+int txe_profile_get(int i, char* name_buf, int buf_len, float* ms, double* work, int* kind);
+
 /* host-side evaluation of the counter-based dropout hash the kernels inline (uniform in [0,1)); keep = u >= p */
 float txe_dropout_uniform_host(unsigned long long seed, unsigned long long idx);
+unsigned txe_dropout_mask_word_host(unsigned long long seed, unsigned long long word_index, float p);
 
 #ifdef __cplusplus
 }

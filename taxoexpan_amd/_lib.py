@@ -10,17 +10,19 @@ P, I, L, F, U64, SZ = C.c_void_p, C.c_int, C.c_longlong, C.c_float, C.c_ulonglon
 
 # name -> (restype, argtypes); mirrors include/txe.h one to one (tests/test_cabi.py checks the header against this)
 SIGNATURES = {
+    "txe_dropout_mask_bytes": (SZ, [L, I]),
+    "txe_dropout_mask": (I, [L, I, F, U64, P, P]),
     "txe_gat_project_ws_bytes": (SZ, [I, I, I, I, I, I]),
-    "txe_gat_project_fwd": (I, [P, L, I, I, P, P, I, P, P, P, I, I, F, U64, P, P, P, SZ, P]),
-    "txe_gat_project_bwd": (I, [P, L, I, I, P, P, I, I, P, P, P, I, I, F, U64, P, P, P, L, P, L, F, P, P, P, P, P, SZ, P]),
+    "txe_gat_project_fwd": (I, [P, L, I, I, P, P, I, P, P, P, I, I, F, P, P, P, P, SZ, P]),
+    "txe_gat_project_bwd": (I, [P, L, I, I, P, P, I, I, P, P, P, I, I, F, P, P, P, P, L, P, L, F, P, P, P, P, P, SZ, P]),
     "txe_gat_aggregate_fwd": (I, [P, P, I, P, L, P, P, I, I, I, F, F, U64, I, F, P, L, P, P]),
     "txe_gat_aggregate_bwd": (I, [P, P, P, P, P, I, P, L, P, P, I, I, I, F, F, U64, P, P, L, P, L, P, P, I, P, P]),
     "txe_leaky_relu_bwd": (I, [P, P, F, L, P, P]),
     "txe_head_mean_fwd": (I, [P, I, I, L, P, P]),
     "txe_head_mean_bwd": (I, [P, I, I, L, P, P]),
     "txe_gcn_project_ws_bytes": (SZ, [I, I, I, I, I]),
-    "txe_gcn_project_fwd": (I, [P, L, I, I, P, P, I, P, I, F, U64, P, P]),
-    "txe_gcn_project_bwd": (I, [P, L, I, I, P, P, I, I, P, I, F, U64, P, P, L, P, L, F, P, P, P, SZ, P]),
+    "txe_gcn_project_fwd": (I, [P, L, I, I, P, P, I, P, I, F, P, P, P]),
+    "txe_gcn_project_bwd": (I, [P, L, I, I, P, P, I, I, P, I, F, P, P, P, L, P, L, F, P, P, P, SZ, P]),
     "txe_gcn_norm": (I, [P, I, P, P]),
     "txe_gcn_aggregate_fwd": (I, [P, P, I, P, L, P, P, I, F, I, P, L, P]),
     "txe_gcn_aggregate_bwd_ws_bytes": (SZ, [I, I]),
@@ -36,6 +38,11 @@ SIGNATURES = {
     "txe_build_csr": (I, [P, P, I, I, P, P, P, P, P, P, P, SZ, P]),
     "txe_rank_block": (I, [P, L, I, I, P, P, P, I, P, P]),
     "txe_dropout_uniform_host": (F, [U64, U64]),
+    "txe_dropout_mask_word_host": (C.c_uint, [U64, U64, F]),
+    "txe_profile_enable": (I, [I]),
+    "txe_profile_reset": (I, []),
+    "txe_profile_count": (I, []),
+    "txe_profile_get": (I, [I, P, I, P, P, P]),
 }
 
 _ERR = {-1: "TXE_ERR_ARG", -2: "TXE_ERR_LAUNCH", -3: "TXE_ERR_WORKSPACE"}

@@ -60,6 +60,32 @@ __host__ __device__ __forceinline__ float drop_factor(uint64_t seed, uint64_t id
     return (uniform01(seed, idx) >= p) ? scale : 0.0f;
 }
 
+// Feature-dropout bit mask (1 = keep), 32 columns per word, words_per_row = ceil(cols/32).  Word w of the whole mask is
+// built from 8 hashes x 4 16-bit chunks: bit (4j+c) = chunk c of mix64(seed ^ mix64(8w+j)) >= thr16, thr16 = round(p*65536).
+__host__ __device__ __forceinline__ unsigned drop_mask_word(uint64_t seed, uint64_t word_index, unsigned thr16) {
+    unsigned bits = 0;
+    for (int j = 0; j < 8; ++j) {
+        const uint64_t h = mix64(seed ^ mix64(word_index * 8 + j));
+        for (int c = 0; c < 4; ++c) bits |= ((unsigned)((h >> (16 * c)) & 0xFFFFu) >= thr16 ? 1u : 0u) << (4 * j + c);
+    }
+    return bits;
+}
+
 __device__ __forceinline__ float leaky(float x, float slope) { return x > 0.f ? x : x * slope; }
+
+// ---- optional per-launch timing (txe_profile.hip); a no-op unless txe_profile_enable(1) was called ----
+bool prof_enabled();
+int prof_begin(const char* name, hipStream_t s, double work, int kind);
+void prof_end(int id, hipStream_t s);
+struct ProfScope {
+    int id;
+    hipStream_t s;
+    ProfScope(const char* name, hipStream_t st, double work, int kind) : id(-1), s(st) {
+        if (prof_enabled()) id = prof_begin(name, st, work, kind);
+    }
+    ~ProfScope() {
+        if (id >= 0) prof_end(id, s);
+    }
+};
 
 }  // namespace txe

@@ -10,11 +10,14 @@
 //   gfx950).  Block tile 128x128x32, 4 waves (2x2), each wave 2x2 MFMA tiles of 32x32 -> 64 accumulator
 //   VGPRs.  Operands are staged global -> registers -> LDS (double buffered, one barrier per k-tile).
 // * operands are *virtual* row-major matrices (VMat): the concat of node features with the position
-//   embedding row (model_zoo.py:215), the feature dropout (model_zoo.py:82), row/column extensions that
-//   carry the folded attention projections, per-row scales ... are synthesised by the loader, so none of
-//   those tensors is ever materialised in HBM.
+//   embedding row (model_zoo.py:215), the feature dropout (model_zoo.py:82, as a precomputed bit mask), row /
+//   column extensions that carry the folded attention projections, per-row scales ... are synthesised by the
+//   loader, so none of those tensors is ever materialised in HBM.
 // * either operand may be read "k-contiguous" (A[m][kk], kk fastest) or "row-contiguous"
 //   (A(m,kk) = Mat[kk][m]); that covers NT / NN / TN products without transposing in HBM.
+// * the loaders are BRANCH-FREE per element (clamped addresses + selects): hipcc waits vmcnt(0) behind every
+//   load that sits under a divergent branch, which serialises the whole staging stream (measured: 25 TF/s).
+//   The only branch is block-uniform: "does this k-tile lie entirely in the plain region of the operand".
 #pragma once
 #include "txe_common.h"
 
@@ -25,7 +28,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // Logical row-major matrix [rows][cols] assembled from up to three arrays:
 //   cols [0, cols_main)      : p  (rows < rows_main)  or p3 (rows >= rows_main, row r-rows_main)
 //   cols [cols_main, cols)   : p2[er*ld2 + c-cols_main], er = pos ? pos[r] : r      (table / 2nd matrix)
-// then optionally * rowscale[r] and * dropout factor(seed, r*drop_ld + c).
+// then optionally * (mask bit(r,c) ? drop_scale : 0)  (mask: 32 columns per word, mask_ld words/row).
 struct VMat {
     const float* p;
     long long ld;
@@ -37,10 +40,10 @@ struct VMat {
     int rows_main;
     const float* p3;
     long long ld3;
-    const float* rowscale;
-    float drop_p, drop_scale;
-    unsigned long long seed;
-    long long drop_ld;
+    const unsigned* mask;      // ALWAYS a readable address (the operand itself when there is no dropout): the loader
+    long long mask_ld;         // fetches one word per vector unconditionally, `mask_on` decides whether it is applied
+    int mask_on;
+    float drop_scale;
 };
 
 static inline VMat vmat_plain(const float* p, long long ld, int rows, int cols) {
@@ -48,14 +51,17 @@ static inline VMat vmat_plain(const float* p, long long ld, int rows, int cols) 
     m.p = p; m.ld = ld; m.rows = rows; m.cols = cols; m.cols_main = cols;
     m.p2 = nullptr; m.ld2 = 0; m.pos = nullptr;
     m.rows_main = rows; m.p3 = nullptr; m.ld3 = 0;
-    m.rowscale = nullptr; m.drop_p = 0.f; m.drop_scale = 1.f; m.seed = 0; m.drop_ld = cols;
+    m.mask = reinterpret_cast<const unsigned*>(p); m.mask_ld = 0; m.mask_on = 0; m.drop_scale = 1.f;
     return m;
+}
+static inline void vmat_set_mask(VMat& m, const unsigned* mask, float drop_p) {
+    if (mask && drop_p > 0.f) { m.mask = mask; m.mask_ld = (m.cols + 31) / 32; m.mask_on = 1; m.drop_scale = 1.f / (1.f - drop_p); }
 }
 
 // Output side.  Logical C [rows][cols]:
 //   n <  cols_main : c [m*ldc  + n]
 //   n >= cols_main : c2[m*ldc2 + n - cols_main]
-// value = acc (* rowscale[m]) (* dropout factor(seed, m*drop_ld + n)) (* leaky'(act_src[m][n]) for n<cols_main)
+// value = acc (* (mask bit(m, n+mask_col0) ? drop_scale : 0)) (* leaky'(act_src[m][n]) for n<cols_main)
 //         (exp() if apply_exp).  Split-K: block z writes at c + z*split_stride (no extras expected).
 struct Epi {
     float* c;
@@ -63,14 +69,15 @@ struct Epi {
     int cols_main;
     float* c2;
     long long ldc2;
-    const float* act_src;
+    const float* act_src;      // act_src / mask: always readable addresses; act_on / mask_on say whether they apply
     long long ld_act;
     float act_slope;
-    float drop_p, drop_scale;
-    unsigned long long seed;
-    long long drop_ld;
-    int drop_col0;             // dropout index column = n + drop_col0
-    const float* rowscale;
+    int act_on;
+    const unsigned* mask;
+    long long mask_ld;
+    int mask_col0;
+    int mask_on;
+    float drop_scale;
     int apply_exp;
     long long split_stride;
 };
@@ -78,19 +85,30 @@ struct Epi {
 static inline Epi epi_plain(float* c, long long ldc, int cols) {
     Epi e;
     e.c = c; e.ldc = ldc; e.cols_main = cols; e.c2 = nullptr; e.ldc2 = 0;
-    e.act_src = nullptr; e.ld_act = 0; e.act_slope = 1.f;
-    e.drop_p = 0.f; e.drop_scale = 1.f; e.seed = 0; e.drop_ld = 0; e.drop_col0 = 0;
-    e.rowscale = nullptr; e.apply_exp = 0; e.split_stride = 0;
+    e.act_src = c; e.ld_act = 0; e.act_slope = 1.f; e.act_on = 0;
+    e.mask = reinterpret_cast<const unsigned*>(c); e.mask_ld = 0; e.mask_col0 = 0; e.mask_on = 0; e.drop_scale = 1.f;
+    e.apply_exp = 0; e.split_stride = 0;
     return e;
 }
+static inline void epi_set_mask(Epi& e, const unsigned* mask, int total_cols, int col0, float drop_p) {
+    if (mask && drop_p > 0.f) { e.mask = mask; e.mask_ld = (total_cols + 31) / 32; e.mask_col0 = col0; e.mask_on = 1; e.drop_scale = 1.f / (1.f - drop_p); }
+}
+static inline void epi_set_act(Epi& e, const float* act_src, long long ld_act, float slope) {
+    if (act_src) { e.act_src = act_src; e.ld_act = ld_act; e.act_slope = slope; e.act_on = 1; }
+}
 
-template <int V>
-__device__ __forceinline__ void vmat_load(const VMat& M, int r, int c, float* v) {
-#pragma unroll
-    for (int e = 0; e < V; ++e) v[e] = 0.f;
-    if (r >= M.rows || c >= M.cols) return;
-    const float* row = (r < M.rows_main) ? (M.p + (long long)r * M.ld) : (M.p3 + (long long)(r - M.rows_main) * M.ld3);
-    if (c + V <= M.cols_main) {
+// Staging is split in two phases so that NO consumer of a load sits between the loads of one k-tile:
+//   issue  : address math + global loads only (data, and the dropout mask word of each vector)
+//   finish : bounds selects + dropout factor, executed after the MFMAs of the current tile, right before the LDS store.
+// hipcc places s_waitcnt vmcnt(0) in front of the first use of a loaded value and schedules only inside basic blocks;
+// a select right behind each load serialised the stream at one HBM round trip per vector (25 TF/s measured).
+// FAST: the whole tile lies inside the plain column range (c + V <= cols_main); only rows can be out of range.
+// Otherwise the element path: per element ONE load from a selected (always valid) address.
+template <int V, bool FAST>
+__device__ __forceinline__ void vmat_issue(const VMat& M, int r, int c, long long er, float* v, unsigned& mw) {
+    const int rr = (r < M.rows) ? r : 0;
+    const float* row = (rr < M.rows_main) ? (M.p + (long long)rr * M.ld) : (M.p3 + (long long)(rr - M.rows_main) * M.ld3);
+    if constexpr (FAST) {
         if constexpr (V == 4) {
             const float4 t = *reinterpret_cast<const float4*>(row + c);
             v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
@@ -101,49 +119,89 @@ __device__ __forceinline__ void vmat_load(const VMat& M, int r, int c, float* v)
             v[0] = row[c];
         }
     } else {
-        const long long er = M.pos ? (long long)M.pos[r] : (long long)r;
+        const float* ext = M.p2 ? (M.p2 + er * M.ld2) : row;          // block-uniform
 #pragma unroll
         for (int e = 0; e < V; ++e) {
             const int cc = c + e;
-            if (cc < M.cols_main) v[e] = row[cc];
-            else if (cc < M.cols) v[e] = M.p2[er * M.ld2 + (cc - M.cols_main)];
+            const bool in_main = cc < M.cols_main;
+            const bool in_ext = (!in_main) & (cc < M.cols) & (M.p2 != nullptr);
+            const float* a = in_main ? (row + cc) : (in_ext ? (ext + (cc - M.cols_main)) : row);
+            v[e] = *a;
         }
     }
-    if (M.rowscale) {
-        const float s = M.rowscale[r];
+    mw = M.mask[(long long)rr * M.mask_ld + (M.mask_on ? ((c < M.cols ? c : 0) >> 5) : 0)];
+}
+
+template <int V, bool FAST>
+__device__ __forceinline__ void vmat_finish(const VMat& M, int r, int c, float* v, unsigned mw) {
+    const bool rok = r < M.rows;
 #pragma unroll
-        for (int e = 0; e < V; ++e) v[e] *= s;
-    }
-    if (M.drop_p > 0.f) {
-        const unsigned long long base = (unsigned long long)r * (unsigned long long)M.drop_ld + (unsigned long long)c;
-#pragma unroll
-        for (int e = 0; e < V; ++e) v[e] *= drop_factor(M.seed, base + e, M.drop_p, M.drop_scale);
+    for (int e = 0; e < V; ++e) {
+        const int cc = c + e;
+        bool ok = rok;
+        if constexpr (!FAST) ok = rok & ((cc < M.cols_main) | ((cc < M.cols) & (M.p2 != nullptr)));
+        const unsigned keep = ((mw >> (cc & 31)) & 1u) | (M.mask_on ? 0u : 1u);      // bitwise: no short-circuit branches
+        v[e] = (ok & (keep != 0u)) ? v[e] * M.drop_scale : 0.f;
     }
 }
 
 constexpr int GEMM_BM = 128, GEMM_BN = 128, GEMM_BK = 32, GEMM_THREADS = 256;
 constexpr int GEMM_KPAD = GEMM_BK + 4;  // k-contiguous LDS row stride (floats): conflict-free ds_read_b128
 
+template <bool KC, int V> struct StageGeom {
+    static constexpr int VPR = (KC ? GEMM_BK : GEMM_BM) / V;     // vectors per tile line (k-row or m-row)
+    static constexpr int LPP = GEMM_THREADS / VPR;               // lines per pass
+    static constexpr int PASSES = (KC ? GEMM_BM : GEMM_BK) / LPP;
+};
+
 // KC = true : operand tile is [R=128 rows][BK] read along k   (LDS [row][BK+4])
 // KC = false: operand tile is [BK][R=128]      read along rows (LDS [k][128])
+// (r, c) of pass p in the operand's own coordinates:
 template <bool KC, int V>
-__device__ __forceinline__ void stage_load(const VMat& M, int row0, int k0, float* regs) {
+__device__ __forceinline__ void stage_coord(int row0, int k0, int p, int& r, int& c) {
+    using G = StageGeom<KC, V>;
     const int t = threadIdx.x;
-    if constexpr (KC) {
-        constexpr int VPR = GEMM_BK / V;             // vectors per tile row
-        constexpr int RPP = GEMM_THREADS / VPR;      // rows per pass
-        constexpr int PASSES = GEMM_BM / RPP;
-        const int kq = t % VPR, r = t / VPR;
+    const int q = t % G::VPR, line = t / G::VPR + p * G::LPP;
+    if constexpr (KC) { r = row0 + line; c = k0 + q * V; }
+    else { r = k0 + line; c = row0 + q * V; }
+}
+
+template <bool KC, int V, bool FAST>
+__device__ __forceinline__ void stage_issue(const VMat& M, int row0, int k0, float* regs, unsigned* mws) {
+    using G = StageGeom<KC, V>;
+    long long er[G::PASSES];
 #pragma unroll
-        for (int p = 0; p < PASSES; ++p) vmat_load<V>(M, row0 + r + p * RPP, k0 + kq * V, regs + p * V);
-    } else {
-        constexpr int VPR = GEMM_BM / V;             // vectors per k-row
-        constexpr int KPP = GEMM_THREADS / VPR;      // k-rows per pass
-        constexpr int PASSES = GEMM_BK / KPP;
-        const int mq = t % VPR, kr = t / VPR;
-#pragma unroll
-        for (int p = 0; p < PASSES; ++p) vmat_load<V>(M, k0 + kr + p * KPP, row0 + mq * V, regs + p * V);
+    for (int p = 0; p < G::PASSES; ++p) {
+        int r, c;
+        stage_coord<KC, V>(row0, k0, p, r, c);
+        const int rr = (r < M.rows) ? r : 0;
+        er[p] = rr;
+        if constexpr (!FAST) { if (M.pos) er[p] = M.pos[rr]; }      // all position loads first, one wait
     }
+#pragma unroll
+    for (int p = 0; p < G::PASSES; ++p) {
+        int r, c;
+        stage_coord<KC, V>(row0, k0, p, r, c);
+        vmat_issue<V, FAST>(M, r, c, er[p], regs + p * V, mws[p]);
+    }
+}
+
+template <bool KC, int V, bool FAST>
+__device__ __forceinline__ void stage_finish(const VMat& M, int row0, int k0, float* regs, const unsigned* mws) {
+    using G = StageGeom<KC, V>;
+#pragma unroll
+    for (int p = 0; p < G::PASSES; ++p) {
+        int r, c;
+        stage_coord<KC, V>(row0, k0, p, r, c);
+        vmat_finish<V, FAST>(M, r, c, regs + p * V, mws[p]);
+    }
+}
+
+// block-uniform: is the [row0, row0+128) x [k0, k0+BK) tile entirely inside the plain column range of M?
+template <bool KC>
+__device__ __forceinline__ bool tile_is_plain(const VMat& M, int row0, int k0) {
+    if constexpr (KC) return k0 + GEMM_BK <= M.cols_main;
+    else return row0 + GEMM_BM <= M.cols_main;
 }
 
 template <bool KC, int V>
@@ -221,68 +279,117 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_kernel(VMat A, VMat B, c
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
     float ra[16], rb[16];
+    unsigned ma[StageGeom<AK, V>::PASSES], mb[StageGeom<BKC, V>::PASSES];
     const int nk = (kend - kbeg + GEMM_BK - 1) / GEMM_BK;
+    // leading k-tiles that are plain for BOTH operands.  The pipelined loop is split by the kind of the tile being
+    // ISSUED (fast prefix, then generic tail) so that no branch sits between a load and its first use.
+    int nkf;
+    {
+        const int fa_ = AK ? max(0, (A.cols_main - kbeg) / GEMM_BK) : ((m0 + GEMM_BM <= A.cols_main) ? nk : 0);
+        const int fb_ = BKC ? max(0, (B.cols_main - kbeg) / GEMM_BK) : ((n0 + GEMM_BN <= B.cols_main) ? nk : 0);
+        nkf = min(nk, min(fa_, fb_));
+    }
+
+#define TXE_COMPUTE_TILE(cur_)                                                                                       \
+    {                                                                                                                \
+        const float* a_l = As + (cur_) * ASZ;                                                                        \
+        const float* b_l = Bs + (cur_) * BSZ;                                                                        \
+        _Pragma("unroll") for (int kb = 0; kb < GEMM_BK / 8; ++kb) {                                                 \
+            float fa[2][4], fb[2][4];                                                                                \
+            _Pragma("unroll") for (int i = 0; i < 2; ++i) frag_load<AK>(a_l, wr * 64 + i * 32, kb, fa[i]);           \
+            _Pragma("unroll") for (int j = 0; j < 2; ++j) frag_load<BKC>(b_l, wc * 64 + j * 32, kb, fb[j]);          \
+            _Pragma("unroll") for (int s = 0; s < 4; ++s)                                                            \
+                _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                        \
+                    _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                    \
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][s], fb[j][s], acc[i][j], 0, 0, 0);    \
+        }                                                                                                            \
+    }
+
     if (nk > 0) {
-        stage_load<AK, V>(A, m0, kbeg, ra);
-        stage_load<BKC, V>(B, n0, kbeg, rb);
+        if (nkf > 0) {
+            stage_issue<AK, V, true>(A, m0, kbeg, ra, ma);
+            stage_issue<BKC, V, true>(B, n0, kbeg, rb, mb);
+            stage_finish<AK, V, true>(A, m0, kbeg, ra, ma);
+            stage_finish<BKC, V, true>(B, n0, kbeg, rb, mb);
+        } else {
+            stage_issue<AK, V, false>(A, m0, kbeg, ra, ma);
+            stage_issue<BKC, V, false>(B, n0, kbeg, rb, mb);
+            stage_finish<AK, V, false>(A, m0, kbeg, ra, ma);
+            stage_finish<BKC, V, false>(B, n0, kbeg, rb, mb);
+        }
         stage_store<AK, V>(As, ra);
         stage_store<BKC, V>(Bs, rb);
     }
     __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        const bool more = (kt + 1 < nk);
-        if (more) {
-            stage_load<AK, V>(A, m0, kbeg + (kt + 1) * GEMM_BK, ra);
-            stage_load<BKC, V>(B, n0, kbeg + (kt + 1) * GEMM_BK, rb);
-        }
-        const float* a_l = As + cur * ASZ;
-        const float* b_l = Bs + cur * BSZ;
-#pragma unroll
-        for (int kb = 0; kb < GEMM_BK / 8; ++kb) {
-            float fa[2][4], fb[2][4];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) frag_load<AK>(a_l, wr * 64 + i * 32, kb, fa[i]);
-#pragma unroll
-            for (int j = 0; j < 2; ++j) frag_load<BKC>(b_l, wc * 64 + j * 32, kb, fb[j]);
-#pragma unroll
-            for (int s = 0; s < 4; ++s)
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][s], fb[j][s], acc[i][j], 0, 0, 0);
-        }
-        if (more) {
-            stage_store<AK, V>(As + (cur ^ 1) * ASZ, ra);
-            stage_store<BKC, V>(Bs + (cur ^ 1) * BSZ, rb);
-        }
+    int t = 1;
+    for (; t < nkf; ++t) {                      // tile t (plain) is fetched while tile t-1 is multiplied
+        const int k0 = kbeg + t * GEMM_BK;
+        stage_issue<AK, V, true>(A, m0, k0, ra, ma);
+        stage_issue<BKC, V, true>(B, n0, k0, rb, mb);
+        __builtin_amdgcn_sched_barrier(0);          // loads first: the whole MFMA block then covers their latency
+        TXE_COMPUTE_TILE((t - 1) & 1)
+        __builtin_amdgcn_sched_barrier(0);
+        stage_finish<AK, V, true>(A, m0, k0, ra, ma);
+        stage_finish<BKC, V, true>(B, n0, k0, rb, mb);
+        stage_store<AK, V>(As + (t & 1) * ASZ, ra);
+        stage_store<BKC, V>(Bs + (t & 1) * BSZ, rb);
         __syncthreads();
     }
+    for (; t < nk; ++t) {                       // generic tiles (extension columns / ragged edges)
+        const int k0 = kbeg + t * GEMM_BK;
+        stage_issue<AK, V, false>(A, m0, k0, ra, ma);
+        stage_issue<BKC, V, false>(B, n0, k0, rb, mb);
+        __builtin_amdgcn_sched_barrier(0);
+        TXE_COMPUTE_TILE((t - 1) & 1)
+        __builtin_amdgcn_sched_barrier(0);
+        stage_finish<AK, V, false>(A, m0, k0, ra, ma);
+        stage_finish<BKC, V, false>(B, n0, k0, rb, mb);
+        stage_store<AK, V>(As + (t & 1) * ASZ, ra);
+        stage_store<BKC, V>(Bs + (t & 1) * BSZ, rb);
+        __syncthreads();
+    }
+    if (nk > 0) TXE_COMPUTE_TILE((nk - 1) & 1)
+#undef TXE_COMPUTE_TILE
 
-    // epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+    // epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
+    // Extras (mask word, activation source, row scale) are fetched for all 16 rows of a sub-tile with clamped,
+    // unconditional loads first, then applied -- no load sits under a divergent branch.
     float* cbase = E.c + (long long)blockIdx.y * E.split_stride;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int n = n0 + wc * 64 + j * 32 + (l & 31);
-            if (n >= N) continue;
+            const bool nok = n < N;
+            const bool main_col = n < E.cols_main;
+            const int nc = nok ? n : 0;
+            const int mbase = m0 + wr * 64 + i * 32 + 4 * (l >> 5);
+            const int cm = nc + E.mask_col0;
+            float av[16];
+            unsigned wd[16];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {          // all extra loads first (always valid addresses), no branches
+                const int m = mbase + (e & 3) + 8 * (e >> 2);
+                const int mc = (m < M) ? m : 0;
+                wd[e] = E.mask[E.mask_on ? ((long long)mc * E.mask_ld + (cm >> 5)) : 0];
+                av[e] = E.act_src[((E.act_on != 0) & main_col) ? ((long long)mc * E.ld_act + nc) : 0];
+            }
+            float val[16];
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const int m = m0 + wr * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (l >> 5);
-                if (m >= M) continue;
-                float v = acc[i][j][e];
-                if (E.rowscale) v *= E.rowscale[m];
-                if (E.drop_p > 0.f)
-                    v *= drop_factor(E.seed, (unsigned long long)m * (unsigned long long)E.drop_ld + (unsigned long long)(n + E.drop_col0),
-                                     E.drop_p, E.drop_scale);
-                if (n < E.cols_main) {
-                    if (E.act_src) v *= (E.act_src[(long long)m * E.ld_act + n] > 0.f) ? 1.f : E.act_slope;
-                    if (E.apply_exp) v = __expf(v);
-                    cbase[(long long)m * E.ldc + n] = v;
-                } else {
-                    E.c2[(long long)m * E.ldc2 + (n - E.cols_main)] = v;
+                const unsigned keep = ((wd[e] >> (cm & 31)) & 1u) | (E.mask_on ? 0u : 1u);
+                float g = keep ? E.drop_scale : 0.f;
+                g *= ((E.act_on != 0) & main_col & !(av[e] > 0.f)) ? E.act_slope : 1.f;
+                float x = acc[i][j][e] * g;
+                val[e] = E.apply_exp ? __expf(x) : x;
+            }
+            if (nok) {
+                float* dst = main_col ? (cbase + n) : (E.c2 + (n - E.cols_main));
+                const long long ldd = main_col ? E.ldc : E.ldc2;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int m = mbase + (e & 3) + 8 * (e >> 2);
+                    if (m < M) dst[(long long)m * ldd] = val[e];
                 }
             }
         }
@@ -304,9 +411,15 @@ static inline int vmat_vec(const VMat& m) {
 
 // Launch C = A*B.  splits > 1 => split-K over gridDim.y, block z stores at E.c + z*E.split_stride.
 template <bool AK, bool BKC>
-static inline int gemm_launch_layout(const VMat& A, const VMat& B, const Epi& E, int M, int N, int K, int splits,
+static inline int gemm_launch_layout(const VMat& A, const VMat& B, const Epi& E_in, int M, int N, int K, int splits,
                                      hipStream_t stream) {
     if (M <= 0 || N <= 0) return TXE_OK;
+    Epi E = E_in;
+    {   // the epilogue loads its extras unconditionally: give the unused ones a readable dummy address
+        const void* valid = E.c ? (const void*)E.c : (const void*)E.c2;
+        if (!E.act_on) E.act_src = (const float*)valid;
+        if (!E.mask_on) E.mask = (const unsigned*)valid;
+    }
     int v = vmat_vec(A);
     const int vb = vmat_vec(B);
     if (vb < v) v = vb;
@@ -316,6 +429,10 @@ static inline int gemm_launch_layout(const VMat& A, const VMat& B, const Epi& E,
     ksplit = ((ksplit + GEMM_BK - 1) / GEMM_BK) * GEMM_BK;
     if (ksplit == 0) ksplit = GEMM_BK;
     dim3 grid(nbm * nbn, splits), block(GEMM_THREADS);
+    static const char* const kNames[3][3] = {{"gemm_tn_v1", "gemm_tn_v2", "gemm_tn_v4"},
+                                             {"gemm_nn_v1", "gemm_nn_v2", "gemm_nn_v4"},
+                                             {"gemm_nt_v1", "gemm_nt_v2", "gemm_nt_v4"}};
+    ProfScope prof(kNames[(AK ? 1 : 0) + (BKC ? 1 : 0)][v == 4 ? 2 : (v == 2 ? 1 : 0)], stream, 2.0 * M * (double)N * K, 0);
     if (v == 4) hipLaunchKernelGGL((gemm_kernel<AK, BKC, 4>), grid, block, 0, stream, A, B, E, M, N, K, ksplit);
     else if (v == 2) hipLaunchKernelGGL((gemm_kernel<AK, BKC, 2>), grid, block, 0, stream, A, B, E, M, N, K, ksplit);
     else hipLaunchKernelGGL((gemm_kernel<AK, BKC, 1>), grid, block, 0, stream, A, B, E, M, N, K, ksplit);

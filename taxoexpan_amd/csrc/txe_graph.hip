@@ -64,6 +64,9 @@ extern "C" {
 // host evaluation of the dropout hash (uniform in [0,1) for (seed, index)); lets tests pin taxoexpan_amd/rng.py to the
 // very function the kernels inline.
 float txe_dropout_uniform_host(unsigned long long seed, unsigned long long idx) { return txe::uniform01(seed, idx); }
+unsigned txe_dropout_mask_word_host(unsigned long long seed, unsigned long long word_index, float p) {
+    return txe::drop_mask_word(seed, word_index, (unsigned)(p * 65536.0f + 0.5f));
+}
 
 size_t txe_build_csr_ws_bytes(int n_nodes, int n_edges) {
     (void)n_nodes;

@@ -26,6 +26,17 @@ __global__ void dsl_kernel(const float* __restrict__ ds, const float* __restrict
     if (i < G) dsl[i] = apply_exp ? ds[i] * s[i] : ds[i];
 }
 
+// dU[i][k] = dsl[i] * e2[i][k]      (gradient of U = E1 W, the only consumer of e2 in s_i = <U_i, e2_i>)
+__global__ void du_kernel(const float* __restrict__ dsl, const float* __restrict__ e2, long long ld_e2, int G, int r,
+                          float* __restrict__ dU) {
+    const long long n = (long long)G * r;
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (long long)gridDim.x * blockDim.x) {
+        const long long i = t / r;
+        const int k = (int)(t % r);
+        dU[t] = dsl[i] * e2[i * ld_e2 + k];
+    }
+}
+
 // d_e2[i][k] = dsl[i] * U[i][k]
 __global__ void de2_kernel(const float* __restrict__ dsl, const float* __restrict__ U, int G, int r, float* __restrict__ d_e2,
                            long long ld) {
@@ -87,7 +98,8 @@ int txe_bilinear_pair_fwd(const float* e1, long long ld_e1, const float* e2, lon
 }
 
 size_t txe_bilinear_pair_bwd_ws_bytes(int G, int l, int r) {
-    return mt_align((size_t)(G > 0 ? G : 1) * 4) + mt_align((size_t)mt_splits(l, r, G) * l * r * 4);
+    return mt_align((size_t)(G > 0 ? G : 1) * 4) + mt_align((size_t)(G > 0 ? G : 1) * r * 4) +
+           mt_align((size_t)mt_splits(l, r, G) * l * r * 4);
 }
 
 // ds: gradient of the returned scores.  d_e1 [G][l] and dW [l][r] are always written; d_e2 may be NULL.
@@ -98,14 +110,17 @@ int txe_bilinear_pair_bwd(const float* e1, long long ld_e1, const float* e2, lon
     if (ws_bytes < txe_bilinear_pair_bwd_ws_bytes(G, l, r)) return TXE_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     float* dsl = (float*)ws;
-    float* part = (float*)((char*)ws + mt_align((size_t)(G > 0 ? G : 1) * 4));
+    float* dU = (float*)((char*)ws + mt_align((size_t)(G > 0 ? G : 1) * 4));
+    float* part = (float*)((char*)dU + mt_align((size_t)(G > 0 ? G : 1) * r * 4));
     int rc;
     if (G > 0) {
         hipLaunchKernelGGL(dsl_kernel, dim3((G + 255) / 256), dim3(256), 0, st, ds, s, apply_exp, G, dsl);
+        const long long nu = (long long)G * r;
+        hipLaunchKernelGGL(du_kernel, dim3((int)((nu + 255) / 256 < 2048 ? (nu + 255) / 256 : 2048)), dim3(256), 0, st,
+                           (const float*)dsl, e2, ld_e2, G, r, dU);
         TXE_CHECK_LAUNCH();
-        // d_e1[i][j] = sum_k (dsl[i] e2[i][k]) W[j][k]
-        VMat A = vmat_plain(e2, ld_e2, G, r);
-        A.rowscale = dsl;
+        // d_e1[i][j] = sum_k dU[i][k] W[j][k]
+        VMat A = vmat_plain(dU, r, G, r);
         VMat B = vmat_plain(W, r, l, r);
         Epi E = epi_plain(d_e1, ld_de1, l);
         rc = gemm_nt(A, B, E, G, l, r, 1, st);
@@ -117,11 +132,10 @@ int txe_bilinear_pair_bwd(const float* e1, long long ld_e1, const float* e2, lon
             TXE_CHECK_LAUNCH();
         }
     }
-    // dW[j][k] = sum_i e1[i][j] * dsl[i] e2[i][k]
+    // dW[j][k] = sum_i e1[i][j] * dU[i][k]
     const int S = mt_splits(l, r, G);
     VMat A = vmat_plain(e1, ld_e1, G, l);
-    VMat B = vmat_plain(e2, ld_e2, G, r);
-    B.rowscale = dsl;
+    VMat B = vmat_plain(dU, r, G, r);
     Epi E = epi_plain(part, r, r);
     E.split_stride = (long long)l * r;
     rc = gemm_tn(A, B, E, l, r, G, S, st);

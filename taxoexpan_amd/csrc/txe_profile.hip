@@ -1,0 +1,76 @@
+// Optional per-kernel timing with HIP events on the launch stream (OFF by default).
+// bench.py switches it on for one instrumented pass to obtain each kernel's live launch duration together with the
+// algorithmic work (flops or bytes) the launcher attributes to that launch -- the `roofline` numbers of the bench line.
+// This is the library's only process-global state; with profiling off the launch path does not touch it.
+#include <string.h>
+
+#include <vector>
+
+#include "txe_common.h"
+
+namespace txe {
+
+struct ProfRec {
+    const char* name;
+    hipEvent_t a, b;
+    double work;
+    int kind;  // 0 = flops, 1 = bytes
+};
+
+static bool g_on = false;
+static std::vector<ProfRec> g_recs;
+static std::vector<hipEvent_t> g_pool;
+
+bool prof_enabled() { return g_on; }
+
+static hipEvent_t take_event() {
+    if (!g_pool.empty()) { hipEvent_t e = g_pool.back(); g_pool.pop_back(); return e; }
+    hipEvent_t e;
+    (void)hipEventCreate(&e);
+    return e;
+}
+
+int prof_begin(const char* name, hipStream_t s, double work, int kind) {
+    ProfRec r;
+    r.name = name; r.work = work; r.kind = kind;
+    r.a = take_event(); r.b = take_event();
+    (void)hipEventRecord(r.a, s);
+    g_recs.push_back(r);
+    return (int)g_recs.size() - 1;
+}
+void prof_end(int id, hipStream_t s) { (void)hipEventRecord(g_recs[id].b, s); }
+
+}  // namespace txe
+
+using namespace txe;
+
+extern "C" {
+
+int txe_profile_enable(int on) {
+    g_on = (on != 0);
+    return TXE_OK;
+}
+
+int txe_profile_reset(void) {
+    for (auto& r : g_recs) { g_pool.push_back(r.a); g_pool.push_back(r.b); }
+    g_recs.clear();
+    return TXE_OK;
+}
+
+int txe_profile_count(void) { return (int)g_recs.size(); }
+
+// record i: kernel name (copied into name_buf), elapsed ms between its two events (synchronises on them), the
+// algorithmic work of the launch and its kind (0 flops / 1 bytes).
+int txe_profile_get(int i, char* name_buf, int buf_len, float* ms, double* work, int* kind) {
+    if (i < 0 || i >= (int)g_recs.size() || !name_buf || buf_len < 2 || !ms || !work || !kind) return TXE_ERR_ARG;
+    const ProfRec& r = g_recs[i];
+    if (hipEventSynchronize(r.b) != hipSuccess) return TXE_ERR_LAUNCH;
+    if (hipEventElapsedTime(ms, r.a, r.b) != hipSuccess) return TXE_ERR_LAUNCH;
+    strncpy(name_buf, r.name, buf_len - 1);
+    name_buf[buf_len - 1] = 0;
+    *work = r.work;
+    *kind = r.kind;
+    return TXE_OK;
+}
+
+}  // extern "C"

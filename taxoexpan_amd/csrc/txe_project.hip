@@ -124,12 +124,17 @@ static inline int choose_splits(int M, int N, int K) {
 }
 
 static VMat make_xcat(const float* h, long long ld_h, int n, int Kh, const int* pos, const float* P, int Pd, float drop_p,
-                      unsigned long long seed) {
+                      const unsigned* mask) {
     VMat m = vmat_plain(h, ld_h, n, Kh + Pd);
     m.cols_main = Kh;
     m.p2 = P; m.ld2 = Pd; m.pos = pos;
-    m.drop_p = drop_p; m.drop_scale = 1.f / (1.f - drop_p); m.seed = seed; m.drop_ld = Kh + Pd;
+    vmat_set_mask(m, mask, drop_p);
     return m;
+}
+
+__global__ void dropout_mask_kernel(long long n_words, unsigned long long seed, unsigned thr16, unsigned* __restrict__ mask) {
+    for (long long w = (long long)blockIdx.x * blockDim.x + threadIdx.x; w < n_words; w += (long long)gridDim.x * blockDim.x)
+        mask[w] = drop_mask_word(seed, (unsigned long long)w, thr16);
 }
 
 struct ProjectWs {
@@ -166,13 +171,28 @@ using namespace txe;
 
 extern "C" {
 
+// Feature-dropout keep mask for an [n_rows][n_cols] operand: bit (r, c) = word[r*ceil(n_cols/32) + c/32] >> (c%32) & 1.
+// nn.Dropout(p) of model_zoo.py:36,82 -- generated once per layer per step, reused by forward, dX and dW.
+size_t txe_dropout_mask_bytes(long long n_rows, int n_cols) { return (size_t)n_rows * ((n_cols + 31) / 32) * 4; }
+
+int txe_dropout_mask(long long n_rows, int n_cols, float p, unsigned long long seed, unsigned* mask, void* stream) {
+    if (n_rows < 0 || n_cols < 1 || p < 0.f || p >= 1.f || !mask) return TXE_ERR_ARG;
+    const long long n_words = n_rows * ((n_cols + 31) / 32);
+    if (n_words == 0) return TXE_OK;
+    const unsigned thr16 = (unsigned)(p * 65536.0f + 0.5f);
+    const int nb = (int)((n_words + 255) / 256 < 4096 ? (n_words + 255) / 256 : 4096);
+    hipLaunchKernelGGL(dropout_mask_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, n_words, seed, thr16, mask);
+    TXE_CHECK_LAUNCH();
+    return TXE_OK;
+}
+
 size_t txe_gat_project_ws_bytes(int n_nodes, int Kh, int Pd, int H, int D, int vocab) {
     return plan_ws(nullptr, n_nodes, H * D, 2 * H, Kh + Pd, Pd, vocab).total;
 }
 
 int txe_gat_project_fwd(const float* h, long long ld_h, int n_nodes, int Kh, const int* pos, const float* P, int Pd,
                         const float* W, const float* attn_l, const float* attn_r, int H, int D, float feat_drop_p,
-                        unsigned long long seed, float* ft, float* a_ext, void* ws, size_t ws_bytes, void* stream) {
+                        const unsigned* mask, float* ft, float* a_ext, void* ws, size_t ws_bytes, void* stream) {
     if (n_nodes < 0 || Kh < 1 || Pd < 0 || H < 1 || D < 1 || !h || !W || !attn_l || !attn_r || !ft || !a_ext || !ws)
         return TXE_ERR_ARG;
     if (Pd > 0 && (!pos || !P)) return TXE_ERR_ARG;
@@ -184,7 +204,7 @@ int txe_gat_project_fwd(const float* h, long long ld_h, int n_nodes, int Kh, con
     float* wa = (float*)ws;
     hipLaunchKernelGGL(fold_attn_kernel, dim3((Kt + 127) / 128, H2), dim3(128), 0, s, W, (long long)Kt, Kt, attn_l, attn_r, H, D, wa);
     TXE_CHECK_LAUNCH();
-    VMat A = make_xcat(h, ld_h, n_nodes, Kh, pos, P, Pd, feat_drop_p, seed);
+    VMat A = make_xcat(h, ld_h, n_nodes, Kh, pos, P, Pd, feat_drop_p, mask);
     VMat B = vmat_plain(W, Kt, F + H2, Kt);
     B.rows_main = F; B.p3 = wa; B.ld3 = Kt;
     Epi E = epi_plain(ft, F, F);
@@ -196,7 +216,7 @@ int txe_gat_project_fwd(const float* h, long long ld_h, int n_nodes, int Kh, con
 // the result is multiplied by leaky'(act_src[m][k]) -- the backward of the inter-layer activation that produced h.
 int txe_gat_project_bwd(const float* h, long long ld_h, int n_nodes, int Kh, const int* pos, const float* P, int Pd, int vocab,
                         const float* W, const float* attn_l, const float* attn_r, int H, int D, float feat_drop_p,
-                        unsigned long long seed, const float* d_ft, const float* d_a_ext, float* d_h, long long ld_dh,
+                        const unsigned* mask, const float* d_ft, const float* d_a_ext, float* d_h, long long ld_dh,
                         const float* act_src, long long ld_act, float act_slope, float* dW, float* d_attn_l, float* d_attn_r,
                         float* dP, void* ws, size_t ws_bytes, void* stream) {
     if (n_nodes < 0 || Kh < 1 || Pd < 0 || H < 1 || D < 1 || !h || !W || !attn_l || !attn_r || !d_ft || !d_a_ext || !dW ||
@@ -214,7 +234,6 @@ int txe_gat_project_bwd(const float* h, long long ld_h, int n_nodes, int Kh, con
 
     VMat G = vmat_plain(d_ft, F, n_nodes, F + H2);          // [d_ft | d_a_ext]
     G.cols_main = F; G.p2 = d_a_ext; G.ld2 = H2;
-    const float drop_scale = 1.f / (1.f - feat_drop_p);
 
     // ---- dX = G * Wext, only the columns somebody needs: [c0, Kt) ----
     const int c0 = d_h ? 0 : Kh;
@@ -223,8 +242,8 @@ int txe_gat_project_bwd(const float* h, long long ld_h, int n_nodes, int Kh, con
         B.rows_main = F; B.p3 = p.wa + c0; B.ld3 = Kt;
         Epi E = epi_plain(d_h, ld_dh, Kh - c0);
         E.c2 = p.dxp; E.ldc2 = Pd;
-        E.drop_p = feat_drop_p; E.drop_scale = drop_scale; E.seed = seed; E.drop_ld = Kt; E.drop_col0 = c0;
-        if (d_h && act_src) { E.act_src = act_src; E.ld_act = ld_act; E.act_slope = act_slope; }
+        epi_set_mask(E, mask, Kt, c0, feat_drop_p);
+        if (d_h) epi_set_act(E, act_src, ld_act, act_slope);
         rc = gemm_nn(G, B, E, n_nodes, Kt - c0, F + H2, 1, s);
         if (rc) return rc;
     }
@@ -241,7 +260,7 @@ int txe_gat_project_bwd(const float* h, long long ld_h, int n_nodes, int Kh, con
     }
     // ---- dWext = G^T * Xcat  (split-K over the node dimension) ----
     {
-        VMat X = make_xcat(h, ld_h, n_nodes, Kh, pos, P, Pd, feat_drop_p, seed);
+        VMat X = make_xcat(h, ld_h, n_nodes, Kh, pos, P, Pd, feat_drop_p, mask);
         Epi E = epi_plain(p.part, Kt, Kt);
         E.split_stride = (long long)(F + H2) * Kt;
         rc = gemm_tn(G, X, E, F + H2, Kt, n_nodes, p.splits, s);
@@ -265,20 +284,20 @@ size_t txe_gcn_project_ws_bytes(int n_nodes, int Kh, int Pd, int Fo, int vocab) 
 }
 
 int txe_gcn_project_fwd(const float* h, long long ld_h, int n_nodes, int Kh, const int* pos, const float* P, int Pd,
-                        const float* W, int Fo, float drop_p, unsigned long long seed, float* hw, void* stream) {
+                        const float* W, int Fo, float drop_p, const unsigned* mask, float* hw, void* stream) {
     if (n_nodes < 0 || Kh < 1 || Pd < 0 || Fo < 1 || !h || !W || !hw) return TXE_ERR_ARG;
     if (Pd > 0 && (!pos || !P)) return TXE_ERR_ARG;
     if (drop_p < 0.f || drop_p >= 1.f) return TXE_ERR_ARG;
     if (n_nodes == 0) return TXE_OK;
     const int Kt = Kh + Pd;
-    VMat A = make_xcat(h, ld_h, n_nodes, Kh, pos, P, Pd, drop_p, seed);
+    VMat A = make_xcat(h, ld_h, n_nodes, Kh, pos, P, Pd, drop_p, mask);
     VMat B = vmat_plain(W, Fo, Kt, Fo);
     Epi E = epi_plain(hw, Fo, Fo);
     return gemm_nn(A, B, E, n_nodes, Fo, Kt, 1, (hipStream_t)stream);
 }
 
 int txe_gcn_project_bwd(const float* h, long long ld_h, int n_nodes, int Kh, const int* pos, const float* P, int Pd, int vocab,
-                        const float* W, int Fo, float drop_p, unsigned long long seed, const float* d_hw, float* d_h,
+                        const float* W, int Fo, float drop_p, const unsigned* mask, const float* d_hw, float* d_h,
                         long long ld_dh, const float* act_src, long long ld_act, float act_slope, float* dW, float* dP,
                         void* ws, size_t ws_bytes, void* stream) {
     if (n_nodes < 0 || Kh < 1 || Pd < 0 || Fo < 1 || !h || !W || !d_hw || !dW || !ws) return TXE_ERR_ARG;
@@ -289,7 +308,6 @@ int txe_gcn_project_bwd(const float* h, long long ld_h, int n_nodes, int Kh, con
     if (ws_bytes < p.total) return TXE_ERR_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
     int rc;
-    const float drop_scale = 1.f / (1.f - drop_p);
     VMat G = vmat_plain(d_hw, Fo, n_nodes, Fo);
     // dXcat[m][c] = sum_fo d_hw[m][fo] * W[c][fo]   (NT), columns [c0, Kt)
     const int c0 = d_h ? 0 : Kh;
@@ -297,8 +315,8 @@ int txe_gcn_project_bwd(const float* h, long long ld_h, int n_nodes, int Kh, con
         VMat B = vmat_plain(W + (long long)c0 * Fo, Fo, Kt - c0, Fo);
         Epi E = epi_plain(d_h, ld_dh, Kh - c0);
         E.c2 = p.dxp; E.ldc2 = Pd;
-        E.drop_p = drop_p; E.drop_scale = drop_scale; E.seed = seed; E.drop_ld = Kt; E.drop_col0 = c0;
-        if (d_h && act_src) { E.act_src = act_src; E.ld_act = ld_act; E.act_slope = act_slope; }
+        epi_set_mask(E, mask, Kt, c0, drop_p);
+        if (d_h) epi_set_act(E, act_src, ld_act, act_slope);
         rc = gemm_nt(G, B, E, n_nodes, Kt - c0, Fo, 1, s);
         if (rc) return rc;
     }
@@ -314,7 +332,7 @@ int txe_gcn_project_bwd(const float* h, long long ld_h, int n_nodes, int Kh, con
     }
     // dW[kt][fo] = sum_m Xcat[m][kt] * d_hw[m][fo]   (TN, split-K over nodes)
     {
-        VMat X = make_xcat(h, ld_h, n_nodes, Kh, pos, P, Pd, drop_p, seed);
+        VMat X = make_xcat(h, ld_h, n_nodes, Kh, pos, P, Pd, drop_p, mask);
         Epi E = epi_plain(p.part, Fo, Fo);
         E.split_stride = (long long)Kt * Fo;
         rc = gemm_tn(X, G, E, Kt, Fo, n_nodes, p.splits, s);

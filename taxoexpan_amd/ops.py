@@ -71,6 +71,15 @@ class GATConfig:
         self.n_layers = len(self.heads)
 
 
+def dropout_mask(n_rows, n_cols, p, seed, ref):
+    """keep-bit mask (int32 words [n_rows, ceil(n_cols/32)]) of nn.Dropout(p) over an [n_rows, n_cols] operand, or None"""
+    if p <= 0.0:
+        return None
+    mask = torch.empty((n_rows, (n_cols + 31) // 32), dtype=torch.int32, device=ref.device)
+    call("txe_dropout_mask", n_rows, n_cols, p, seed, ptr(mask), _lib.stream_ptr())
+    return mask
+
+
 def _gat_layer_fwd(csr, h, ld_h, pos, P, W, al, ar, H, D, feat_p, attn_p, seed, attn_slope, out_mode, act_slope, save):
     N, Kh = h.shape
     Pd = 0 if P is None else P.shape[1]
@@ -79,16 +88,17 @@ def _gat_layer_fwd(csr, h, ld_h, pos, P, W, al, ar, H, D, feat_p, attn_p, seed, 
     wsb = 2 * H * (Kh + Pd) * 4
     ws = _ws(wsb, h)
     st = _lib.stream_ptr()
-    call("txe_gat_project_fwd", ptr(h), ld_h, N, Kh, ptr(pos), ptr(P), Pd, ptr(W), ptr(al), ptr(ar), H, D, feat_p, seed,
+    mask = dropout_mask(N, Kh + Pd, feat_p, seed, h)
+    call("txe_gat_project_fwd", ptr(h), ld_h, N, Kh, ptr(pos), ptr(P), Pd, ptr(W), ptr(al), ptr(ar), H, D, feat_p, ptr(mask),
          ptr(ft), ptr(a_ext), ptr(ws), wsb, st)
     out = _empty((N, F), h)
     alpha = _empty((max(csr.n_edges, 1), H), h) if save else None
     call("txe_gat_aggregate_fwd", ptr(csr.rowptr_in), ptr(csr.col_src), N, ptr(ft), F, ptr(a_ext), ptr(a_ext) + 4 * H, 2 * H,
          H, D, attn_slope, attn_p, seed + 1, out_mode, act_slope, ptr(out), F, ptr(alpha), st)
-    return out, ft, a_ext, alpha
+    return out, ft, a_ext, alpha, mask
 
 
-def _gat_layer_bwd(csr, h, ld_h, pos, P, vocab, W, al, ar, H, D, feat_p, attn_p, seed, attn_slope, ft, a_ext, alpha,
+def _gat_layer_bwd(csr, h, ld_h, pos, P, vocab, W, al, ar, H, D, feat_p, attn_p, seed, attn_slope, ft, a_ext, alpha, mask,
                    d_pre, ld_dpre, need_dh, act_src, act_slope):
     N, Kh = h.shape
     Pd = 0 if P is None else P.shape[1]
@@ -104,7 +114,7 @@ def _gat_layer_bwd(csr, h, ld_h, pos, P, vocab, W, al, ar, H, D, feat_p, attn_p,
     d_h = _empty((N, Kh), h) if need_dh else None
     wsb = call("txe_gat_project_ws_bytes", N, Kh, Pd, H, D, vocab)
     ws = _ws(wsb, h)
-    call("txe_gat_project_bwd", ptr(h), ld_h, N, Kh, ptr(pos), ptr(P), Pd, vocab, ptr(W), ptr(al), ptr(ar), H, D, feat_p, seed,
+    call("txe_gat_project_bwd", ptr(h), ld_h, N, Kh, ptr(pos), ptr(P), Pd, vocab, ptr(W), ptr(al), ptr(ar), H, D, feat_p, ptr(mask),
          ptr(d_ft), ptr(d_a), ptr(d_h), Kh, ptr(act_src), (ld_h if act_src is not None else 0), act_slope if act_slope else 1.0,
          ptr(dW), ptr(dal), ptr(dar), ptr(dP), ptr(ws), wsb, st)
     return d_h, dW, dal, dar, dP
@@ -128,10 +138,10 @@ class GATStackFunction(torch.autograd.Function):
                 H, D = cfg.heads[l], cfg.out_dims[l]
                 last = (l == L - 1)
                 out_mode = 0 if (last or cfg.act_slope is None) else 1
-                out, ft, a_ext, alpha = _gat_layer_fwd(csr, x, ldx, pos if P is not None else None, P, W, al, ar, H, D,
+                out, ft, a_ext, alpha, mask = _gat_layer_fwd(csr, x, ldx, pos if P is not None else None, P, W, al, ar, H, D,
                                                        cfg.feat_p, cfg.attn_p, cfg.seed + 16 * l, cfg.attn_slope, out_mode,
                                                        cfg.act_slope or 1.0, need)
-                saved.append((x, ldx, W, al, ar, P, ft, a_ext, alpha))
+                saved.append((x, ldx, W, al, ar, P, ft, a_ext, alpha, mask))
                 x, ldx = out, out.stride(0)
             H, D = cfg.heads[-1], cfg.out_dims[-1]
             if cfg.final == "mean":
@@ -161,13 +171,13 @@ class GATStackFunction(torch.autograd.Function):
                 d_pre = d_res.reshape(d_res.shape[0], H * D)
             d_h = None
             for l in range(L - 1, -1, -1):
-                x, ldx, W, al, ar, P, ft, a_ext, alpha = saved[l]
+                x, ldx, W, al, ar, P, ft, a_ext, alpha, mask = saved[l]
                 need_dh = (l > 0) or ctx.h_req
                 # the input of layer l>0 is leaky_relu(out_{l-1}) (fused epilogue): fold its derivative into dX
                 act_src = x if (l > 0 and cfg.act_slope is not None) else None
                 d_h, dW, dal, dar, dP = _gat_layer_bwd(csr, x, ldx, pos if P is not None else None, P, cfg.vocab, W, al, ar,
                                                        cfg.heads[l], cfg.out_dims[l], cfg.feat_p, cfg.attn_p, cfg.seed + 16 * l,
-                                                       cfg.attn_slope, ft, a_ext, alpha, d_pre, d_pre.stride(0), need_dh, act_src,
+                                                       cfg.attn_slope, ft, a_ext, alpha, mask, d_pre, d_pre.stride(0), need_dh, act_src,
                                                        cfg.act_slope)
                 grads[4 * l:4 * l + 4] = [dW, dal, dar, dP]
                 d_pre = d_h
@@ -213,13 +223,14 @@ class GCNStackFunction(torch.autograd.Function):
                 Pd = 0 if P is None else P.shape[1]
                 Fo = cfg.out_dims[l]
                 hw = _empty((N, Fo), x)
+                mask = dropout_mask(N, Kh + Pd, cfg.drop_ps[l], cfg.seed + 16 * l, x)
                 call("txe_gcn_project_fwd", ptr(x), ldx, N, Kh, ptr(pos if P is not None else None), ptr(P), Pd, ptr(W), Fo,
-                     cfg.drop_ps[l], cfg.seed + 16 * l, ptr(hw), st)
+                     cfg.drop_ps[l], ptr(mask), ptr(hw), st)
                 out = _empty((N, Fo), x)
                 slope = cfg.act_slopes[l]
                 call("txe_gcn_aggregate_fwd", ptr(csr.rowptr_in), ptr(csr.col_src), N, ptr(hw), Fo, ptr(norm), ptr(b),
                      0 if slope is None else 1, slope or 1.0, Fo, ptr(out), Fo, st)
-                saved.append((x, ldx, W, b, P))
+                saved.append((x, ldx, W, b, P, mask))
                 x, ldx = out, Fo
         ctx.csr, ctx.cfg, ctx.pos, ctx.norm = csr, cfg, pos, norm
         ctx.saved = saved if need else None
@@ -243,7 +254,7 @@ class GCNStackFunction(torch.autograd.Function):
                 d_pre = d_out
             d_h = None
             for l in range(L - 1, -1, -1):
-                x, ldx, W, b, P = saved[l]
+                x, ldx, W, b, P, mask = saved[l]
                 Kh = x.shape[1]
                 Pd = 0 if P is None else P.shape[1]
                 Fo = cfg.out_dims[l]
@@ -261,7 +272,7 @@ class GCNStackFunction(torch.autograd.Function):
                 wsb2 = call("txe_gcn_project_ws_bytes", N, Kh, Pd, Fo, cfg.vocab)
                 ws2 = _ws(wsb2, d_out)
                 call("txe_gcn_project_bwd", ptr(x), ldx, N, Kh, ptr(pos if P is not None else None), ptr(P), Pd, cfg.vocab, ptr(W), Fo,
-                     cfg.drop_ps[l], cfg.seed + 16 * l, ptr(d_hw), ptr(d_h), Kh, ptr(act_src), (ldx if act_src is not None else 0),
+                     cfg.drop_ps[l], ptr(mask), ptr(d_hw), ptr(d_h), Kh, ptr(act_src), (ldx if act_src is not None else 0),
                      (cfg.act_slopes[l - 1] if act_src is not None else 1.0), ptr(dW), ptr(dP), ptr(ws2), wsb2, st)
                 grads[3 * l:3 * l + 3] = [dW, d_b, dP]
                 d_pre = d_h

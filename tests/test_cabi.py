@@ -13,8 +13,8 @@ def _header_decls():
     text = open(os.path.join(REPO, "include", "txe.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     decls = {}
-    for m in re.finditer(r"\b(int|size_t|float)\s+(txe_\w+)\s*\(([^;]*?)\)\s*;", text, flags=re.S):
-        args = [a.strip() for a in m.group(3).replace("\n", " ").split(",") if a.strip()]
+    for m in re.finditer(r"\b(int|size_t|float|unsigned)\s+(txe_\w+)\s*\(([^;]*?)\)\s*;", text, flags=re.S):
+        args = [a.strip() for a in m.group(3).replace("\n", " ").split(",") if a.strip() and a.strip() != "void"]
         decls[m.group(2)] = (m.group(1), args)
     return decls
 
@@ -34,7 +34,7 @@ def test_ctypes_table_mirrors_header():
     decls = _header_decls()
     assert set(decls) == set(_lib.SIGNATURES), set(decls) ^ set(_lib.SIGNATURES)
     cmap = {"int": ctypes.c_int, "long long": ctypes.c_longlong, "float": ctypes.c_float, "size_t": ctypes.c_size_t,
-            "unsigned long long": ctypes.c_ulonglong}
+            "unsigned long long": ctypes.c_ulonglong, "unsigned": ctypes.c_uint}
     for name, (ret, args) in decls.items():
         res, argtypes = _lib.SIGNATURES[name]
         assert res is cmap[ret], name
@@ -67,6 +67,18 @@ def test_host_rng_restatement_matches_library():
         assert np.array_equal(got, want)
     m = rng.keep_mask(42, (1000, 37), 0.3)
     assert abs(m.mean() - 0.7) < 0.01
+    # bit-mask form used for feature dropout: words from the library (host evaluation) == rng.keep_mask_bits
+    for seed, rows, cols, p in ((7, 5, 70, 0.1), (2 ** 40 + 3, 3, 32, 0.3), (11, 4, 17, 0.5)):
+        wpr = (cols + 31) // 32
+        bits = rng.keep_mask_bits(seed, rows, cols, p)
+        for r in range(rows):
+            for w in range(wpr):
+                word = lib.txe_dropout_mask_word_host(seed, r * wpr + w, p)
+                for b in range(32):
+                    c = w * 32 + b
+                    if c < cols:
+                        assert bits[r, c] == ((word >> b) & 1), (seed, r, c)
+    assert abs(rng.keep_mask_bits(5, 500, 300, 0.1).mean() - 0.9) < 0.005
 
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):

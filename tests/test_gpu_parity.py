@@ -68,7 +68,7 @@ def _hash_masks(spec, params, graph, seed, csr_eid_in):
         if is_gat:
             kt = params[f"graph_propagate.gat_layers.{l}.fc.weight"].shape[1]
             H = spec["heads"][l]
-            d = dict(feat_keep=torch.from_numpy(rng.keep_mask(seed + 16 * l, (N, kt), pf)), feat_scale=1.0 / (1.0 - pf))
+            d = dict(feat_keep=torch.from_numpy(rng.keep_mask_bits(seed + 16 * l, N, kt, pf)), feat_scale=1.0 / (1.0 - pf))
             if pa > 0:
                 m_csr = rng.keep_mask(seed + 16 * l + 1, (E, H), pa)       # destination-CSR order
                 m_eid = np.empty_like(m_csr)
@@ -77,7 +77,7 @@ def _hash_masks(spec, params, graph, seed, csr_eid_in):
             out.append(d)
         else:
             kt = params[f"graph_propagate.layers.{l}.weight"].shape[0]
-            out.append(dict(keep=torch.from_numpy(rng.keep_mask(seed + 16 * l, (N, kt), pf)), keep_scale=1.0 / (1.0 - pf)))
+            out.append(dict(keep=torch.from_numpy(rng.keep_mask_bits(seed + 16 * l, N, kt, pf)), keep_scale=1.0 / (1.0 - pf)))
     return out
 
 

@@ -19,16 +19,30 @@ constexpr int MAX_VOCAB = 8;
 
 // wa[h][k]   = sum_d attn_l[h*D+d] * W[(h*D+d)*ldw + k]
 // wa[H+h][k] = sum_d attn_r[h*D+d] * W[(h*D+d)*ldw + k]            (k < Kt)
-__global__ void fold_attn_kernel(const float* __restrict__ W, long long ldw, int Kt, const float* __restrict__ attn_l,
-                                 const float* __restrict__ attn_r, int H, int D, float* __restrict__ wa) {
+// One workgroup per (row r, 64-column chunk): 64 columns x 16 d-groups, LDS tree over the d-groups.
+constexpr int FOLD_DG = 16;
+__global__ __launch_bounds__(64 * FOLD_DG) void fold_attn_kernel(const float* __restrict__ W, long long ldw, int Kt,
+                                                                 const float* __restrict__ attn_l, const float* __restrict__ attn_r,
+                                                                 int H, int D, float* __restrict__ wa) {
+    __shared__ float red[FOLD_DG][64];
     const int r = blockIdx.y;                     // 0 .. 2H-1
     const int h = r % H;
-    const float* attn = (r < H) ? attn_l : attn_r;
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= Kt) return;
+    const float* attn = ((r < H) ? attn_l : attn_r) + (long long)h * D;
+    const float* Wh = W + (long long)h * D * ldw;
+    const int kl = threadIdx.x & 63, dg = threadIdx.x >> 6;
+    const int k = blockIdx.x * 64 + kl;
+    const int kc = (k < Kt) ? k : 0;
     float acc = 0.f;
-    for (int d = 0; d < D; ++d) acc = fmaf(attn[h * D + d], W[(long long)(h * D + d) * ldw + k], acc);
-    wa[(long long)r * Kt + k] = acc;
+#pragma unroll 4
+    for (int d = dg; d < D; d += FOLD_DG) acc = fmaf(attn[d], Wh[(long long)d * ldw + kc], acc);
+    red[dg][kl] = acc;
+    __syncthreads();
+    if (dg == 0 && k < Kt) {
+        float s = 0.f;
+#pragma unroll
+        for (int g = 0; g < FOLD_DG; ++g) s += red[g][kl];
+        wa[(long long)r * Kt + k] = s;
+    }
 }
 
 // dwa[r][k] = sum_s part[s][F + r][k]     r < 2H
@@ -86,29 +100,48 @@ __global__ void reduce_splits_kernel(const float* __restrict__ part, int S, long
 }
 
 // Deterministic two-stage "sum rows by position class":  dP[c][j] = sum_{m : pos[m]==c} x[m][j]
-// stage 1: block b owns rows [b*rows_per_block, ...), thread j-strided over columns.
-__global__ void pos_segsum_stage1(const float* __restrict__ x, long long ldx, const int* __restrict__ pos, int n_rows, int cols,
-                                  int vocab, int rows_per_block, float* __restrict__ part /*[nb][vocab][cols]*/) {
+// stage 1: block b owns rows [b*rows_per_block, ...): 64 column lanes x 4 row groups, fixed-order LDS combine.
+__global__ __launch_bounds__(256) void pos_segsum_stage1(const float* __restrict__ x, long long ldx, const int* __restrict__ pos,
+                                                         int n_rows, int cols, int vocab, int rows_per_block,
+                                                         float* __restrict__ part /*[nb][vocab][cols]*/) {
+    __shared__ float red[4][MAX_VOCAB][64];
     const int r0 = blockIdx.x * rows_per_block, r1 = min(n_rows, r0 + rows_per_block);
-    for (int j = threadIdx.x; j < cols; j += blockDim.x) {
+    const int jl = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    for (int j0 = 0; j0 < cols; j0 += 64) {
+        const int j = j0 + jl;
+        const int jc = (j < cols) ? j : 0;
         float acc[MAX_VOCAB];
 #pragma unroll
         for (int c = 0; c < MAX_VOCAB; ++c) acc[c] = 0.f;
-        for (int m = r0; m < r1; ++m) {
+#pragma unroll 4
+        for (int m = r0 + rg; m < r1; m += 4) {
             const int pc = pos[m];
-            const float v = x[(long long)m * ldx + j];
+            const float v = x[(long long)m * ldx + jc];
 #pragma unroll
             for (int c = 0; c < MAX_VOCAB; ++c) acc[c] += (pc == c) ? v : 0.f;
         }
-        for (int c = 0; c < vocab; ++c) part[((long long)blockIdx.x * vocab + c) * cols + j] = acc[c];
+#pragma unroll
+        for (int c = 0; c < MAX_VOCAB; ++c) red[rg][c][jl] = acc[c];
+        __syncthreads();
+        if (rg == 0 && j < cols)
+            for (int c = 0; c < vocab; ++c)
+                part[((long long)blockIdx.x * vocab + c) * cols + j] = red[0][c][jl] + red[1][c][jl] + red[2][c][jl] + red[3][c][jl];
+        __syncthreads();
     }
 }
-__global__ void pos_segsum_stage2(const float* __restrict__ part, int nb, int vocab, int cols, float* __restrict__ out) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= vocab * cols) return;
+__global__ __launch_bounds__(256) void pos_segsum_stage2(const float* __restrict__ part, int nb, int vocab, int cols,
+                                                         float* __restrict__ out) {
+    __shared__ float red[4][64];
+    const int il = threadIdx.x & 63, bg = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + il;
+    const int n = vocab * cols;
+    const int ic = (i < n) ? i : 0;
     float acc = 0.f;
-    for (int b = 0; b < nb; ++b) acc += part[(long long)b * vocab * cols + i];
-    out[i] = acc;
+#pragma unroll 4
+    for (int b = bg; b < nb; b += 4) acc += part[(long long)b * n + ic];
+    red[bg][il] = acc;
+    __syncthreads();
+    if (bg == 0 && i < n) out[i] = red[0][il] + red[1][il] + red[2][il] + red[3][il];
 }
 
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
@@ -155,7 +188,7 @@ static ProjectWs plan_ws(void* ws, int n, int F, int H2, int Kt, int Pd, int voc
     p.wa = take((size_t)H2 * Kt * 4);
     p.dwa = take((size_t)H2 * Kt * 4);
     p.dxp = take((size_t)n * (Pd > 0 ? Pd : 1) * 4);
-    p.seg_rows = 256;
+    p.seg_rows = 64;
     p.seg_blocks = (n + p.seg_rows - 1) / p.seg_rows;
     if (p.seg_blocks < 1) p.seg_blocks = 1;
     p.ppart = take((size_t)p.seg_blocks * (vocab > 0 ? vocab : 1) * (Pd > 0 ? Pd : 1) * 4);
@@ -202,7 +235,7 @@ int txe_gat_project_fwd(const float* h, long long ld_h, int n_nodes, int Kh, con
     if (n_nodes == 0) return TXE_OK;
     hipStream_t s = (hipStream_t)stream;
     float* wa = (float*)ws;
-    hipLaunchKernelGGL(fold_attn_kernel, dim3((Kt + 127) / 128, H2), dim3(128), 0, s, W, (long long)Kt, Kt, attn_l, attn_r, H, D, wa);
+    hipLaunchKernelGGL(fold_attn_kernel, dim3((Kt + 63) / 64, H2), dim3(64 * FOLD_DG), 0, s, W, (long long)Kt, Kt, attn_l, attn_r, H, D, wa);
     TXE_CHECK_LAUNCH();
     VMat A = make_xcat(h, ld_h, n_nodes, Kh, pos, P, Pd, feat_drop_p, mask);
     VMat B = vmat_plain(W, Kt, F + H2, Kt);
@@ -229,7 +262,7 @@ int txe_gat_project_bwd(const float* h, long long ld_h, int n_nodes, int Kh, con
     if (ws_bytes < p.total) return TXE_ERR_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
     int rc;
-    hipLaunchKernelGGL(fold_attn_kernel, dim3((Kt + 127) / 128, H2), dim3(128), 0, s, W, (long long)Kt, Kt, attn_l, attn_r, H, D, p.wa);
+    hipLaunchKernelGGL(fold_attn_kernel, dim3((Kt + 63) / 64, H2), dim3(64 * FOLD_DG), 0, s, W, (long long)Kt, Kt, attn_l, attn_r, H, D, p.wa);
     TXE_CHECK_LAUNCH();
 
     VMat G = vmat_plain(d_ft, F, n_nodes, F + H2);          // [d_ft | d_a_ext]
@@ -250,11 +283,11 @@ int txe_gat_project_bwd(const float* h, long long ld_h, int n_nodes, int Kh, con
     // ---- dP[c][j] = sum_{pos[m]==c} dXcat[m][Kh+j] ----
     if (Pd > 0) {
         if (n_nodes > 0) {
-            hipLaunchKernelGGL(pos_segsum_stage1, dim3(p.seg_blocks), dim3(64), 0, s, (const float*)p.dxp, (long long)Pd, pos,
+            hipLaunchKernelGGL(pos_segsum_stage1, dim3(p.seg_blocks), dim3(256), 0, s, (const float*)p.dxp, (long long)Pd, pos,
                                n_nodes, Pd, vocab, p.seg_rows, p.ppart);
             TXE_CHECK_LAUNCH();
         }
-        hipLaunchKernelGGL(pos_segsum_stage2, dim3((vocab * Pd + 127) / 128), dim3(128), 0, s, (const float*)p.ppart,
+        hipLaunchKernelGGL(pos_segsum_stage2, dim3((vocab * Pd + 63) / 64), dim3(256), 0, s, (const float*)p.ppart,
                            n_nodes > 0 ? p.seg_blocks : 0, vocab, Pd, dP);
         TXE_CHECK_LAUNCH();
     }
@@ -322,11 +355,11 @@ int txe_gcn_project_bwd(const float* h, long long ld_h, int n_nodes, int Kh, con
     }
     if (Pd > 0) {
         if (n_nodes > 0) {
-            hipLaunchKernelGGL(pos_segsum_stage1, dim3(p.seg_blocks), dim3(64), 0, s, (const float*)p.dxp, (long long)Pd, pos,
+            hipLaunchKernelGGL(pos_segsum_stage1, dim3(p.seg_blocks), dim3(256), 0, s, (const float*)p.dxp, (long long)Pd, pos,
                                n_nodes, Pd, vocab, p.seg_rows, p.ppart);
             TXE_CHECK_LAUNCH();
         }
-        hipLaunchKernelGGL(pos_segsum_stage2, dim3((vocab * Pd + 127) / 128), dim3(128), 0, s, (const float*)p.ppart,
+        hipLaunchKernelGGL(pos_segsum_stage2, dim3((vocab * Pd + 63) / 64), dim3(256), 0, s, (const float*)p.ppart,
                            n_nodes > 0 ? p.seg_blocks : 0, vocab, Pd, dP);
         TXE_CHECK_LAUNCH();
     }

@@ -29,20 +29,22 @@ __device__ __forceinline__ void ro_vstore(float* p, const float* v) {
     else { *p = v[0]; }
 }
 
+// per-node weights of a <=64-node chunk, one node per lane: w = softplus(pw[pos]) (or 1), parked in LDS for the row sweep
+__device__ __forceinline__ float node_weight(const int* __restrict__ pos, const float* __restrict__ pw, int v, bool valid) {
+    if (!valid) return 0.f;
+    return pw ? softplus_t(pw[pos[v]]) : 1.f;
+}
+
 template <int VEC>
 __global__ __launch_bounds__(RO_WAVES * 64) void readout_fwd_kernel(const int* __restrict__ goff, const int G,
                                                                     const float* __restrict__ h, const long long ld_h,
                                                                     const int* __restrict__ pos, const float* __restrict__ pw,
                                                                     const int D, float* __restrict__ hg, float* __restrict__ wsum) {
+    __shared__ float s_w[RO_WAVES][64];
     const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
     const int g = xcd_remap(blockIdx.x, gridDim.x) * RO_WAVES + w;
     if (g >= G) return;
     const int beg = goff[g], end = goff[g + 1];
-    float S = 0.f;
-    for (int v = beg + l; v < end; v += 64) S += pw ? softplus_t(pw[pos[v]]) : 1.f;
-    S = wave_sum(S);
-    if (l == 0 && wsum) wsum[g] = S;
-    const float inv = 1.f / S;
     const int nvec = D / VEC;
     for (int t0 = 0; t0 < nvec; t0 += 64 * RO_MAXI) {
         float acc[RO_MAXI][VEC];
@@ -50,20 +52,33 @@ __global__ __launch_bounds__(RO_WAVES * 64) void readout_fwd_kernel(const int* _
         for (int i = 0; i < RO_MAXI; ++i)
 #pragma unroll
             for (int k = 0; k < VEC; ++k) acc[i][k] = 0.f;
-        for (int v = beg; v < end; ++v) {
-            const float wv = pw ? softplus_t(pw[pos[v]]) : 1.f;
-            const float* row = h + (long long)v * ld_h;
+        float S = 0.f;
+        for (int cb = beg; cb < end; cb += 64) {
+            const float wl = node_weight(pos, pw, cb + l, cb + l < end);
+            S += wl;
+            s_w[w][l] = wl;
+            __builtin_amdgcn_wave_barrier();
+            const int cnt = min(64, end - cb);
+#pragma unroll 2
+            for (int e = 0; e < cnt; ++e) {
+                const float wv = s_w[w][e];
+                const float* row = h + (long long)(cb + e) * ld_h;
 #pragma unroll
-            for (int i = 0; i < RO_MAXI; ++i) {
-                const int j = t0 + l + 64 * i;
-                if (j < nvec) {
-                    float x[VEC];
-                    ro_vload<VEC>(row + (long long)j * VEC, x);
+                for (int i = 0; i < RO_MAXI; ++i) {
+                    const int j = t0 + l + 64 * i;
+                    if (j < nvec) {
+                        float x[VEC];
+                        ro_vload<VEC>(row + (long long)j * VEC, x);
 #pragma unroll
-                    for (int k = 0; k < VEC; ++k) acc[i][k] = fmaf(wv, x[k], acc[i][k]);
+                        for (int k = 0; k < VEC; ++k) acc[i][k] = fmaf(wv, x[k], acc[i][k]);
+                    }
                 }
             }
+            __builtin_amdgcn_wave_barrier();
         }
+        S = wave_sum(S);
+        if (l == 0 && wsum && t0 == 0) wsum[g] = S;
+        const float inv = 1.f / S;
 #pragma unroll
         for (int i = 0; i < RO_MAXI; ++i) {
             const int j = t0 + l + 64 * i;
@@ -85,6 +100,9 @@ __global__ __launch_bounds__(RO_WAVES * 64) void readout_bwd_kernel(const int* _
                                                                     const float* __restrict__ wsum, const float* __restrict__ d_hg,
                                                                     float* __restrict__ d_h, const long long ld_dh,
                                                                     float* __restrict__ dpw_part /*[G][vocab]*/) {
+    __shared__ float s_sc[RO_WAVES][64];      // w_v / S
+    __shared__ float s_sg[RO_WAVES][64];      // sigmoid(pw[pos_v]) / S
+    __shared__ int s_pc[RO_WAVES][64];
     const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
     const int g = xcd_remap(blockIdx.x, gridDim.x) * RO_WAVES + w;
     if (g >= G) return;
@@ -94,29 +112,43 @@ __global__ __launch_bounds__(RO_WAVES * 64) void readout_bwd_kernel(const int* _
     float dpw[RO_MAX_VOCAB];
 #pragma unroll
     for (int c = 0; c < RO_MAX_VOCAB; ++c) dpw[c] = 0.f;
-    for (int v = beg; v < end; ++v) {
-        const int pc = pw ? pos[v] : 0;
-        const float wv = pw ? softplus_t(pw[pc]) : 1.f;
-        const float sc = wv * inv;
-        float part = 0.f;
-        for (int j = l; j < nvec; j += 64) {
-            float dg[VEC], x[VEC], m[VEC], o[VEC];
-            ro_vload<VEC>(d_hg + (long long)g * D + (long long)j * VEC, dg);
+    for (int cb = beg; cb < end; cb += 64) {
+        {
+            const int v = cb + l;
+            const bool valid = v < end;
+            const int pc = (valid && pw) ? pos[v] : 0;
+            const float x = pw ? pw[pc] : 0.f;
+            s_pc[w][l] = pc;
+            s_sc[w][l] = valid ? (pw ? softplus_t(x) : 1.f) * inv : 0.f;
+            s_sg[w][l] = pw ? sigmoid_t(x) * inv : 0.f;
+        }
+        __builtin_amdgcn_wave_barrier();
+        const int cnt = min(64, end - cb);
+        for (int e = 0; e < cnt; ++e) {
+            const int v = cb + e;
+            const float sc = s_sc[w][e];
+            float part = 0.f;
+            for (int j = l; j < nvec; j += 64) {
+                float dg[VEC], x[VEC], m[VEC], o[VEC];
+                ro_vload<VEC>(d_hg + (long long)g * D + (long long)j * VEC, dg);
 #pragma unroll
-            for (int k = 0; k < VEC; ++k) o[k] = sc * dg[k];
-            ro_vstore<VEC>(d_h + (long long)v * ld_dh + (long long)j * VEC, o);
+                for (int k = 0; k < VEC; ++k) o[k] = sc * dg[k];
+                ro_vstore<VEC>(d_h + (long long)v * ld_dh + (long long)j * VEC, o);
+                if (pw) {
+                    ro_vload<VEC>(h + (long long)v * ld_h + (long long)j * VEC, x);
+                    ro_vload<VEC>(hg + (long long)g * D + (long long)j * VEC, m);
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k) part = fmaf(dg[k], x[k] - m[k], part);
+                }
+            }
             if (pw) {
-                ro_vload<VEC>(h + (long long)v * ld_h + (long long)j * VEC, x);
-                ro_vload<VEC>(hg + (long long)g * D + (long long)j * VEC, m);
+                part = wave_sum(part) * s_sg[w][e];
+                const int pc = s_pc[w][e];
 #pragma unroll
-                for (int k = 0; k < VEC; ++k) part = fmaf(dg[k], x[k] - m[k], part);
+                for (int c = 0; c < RO_MAX_VOCAB; ++c) dpw[c] += (pc == c) ? part : 0.f;
             }
         }
-        if (pw) {
-            part = wave_sum(part) * inv * sigmoid_t(pw[pc]);
-#pragma unroll
-            for (int c = 0; c < RO_MAX_VOCAB; ++c) dpw[c] += (pc == c) ? part : 0.f;
-        }
+        __builtin_amdgcn_wave_barrier();
     }
     if (pw && l == 0) {
 #pragma unroll

@@ -10,7 +10,7 @@ import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SOURCES = ["txe_gemm.hip", "txe_gat.hip", "txe_gcn.hip", "txe_project.hip", "txe_readout.hip", "txe_match.hip",
+SOURCES = ["txe_gemm_nt.hip", "txe_gemm_nn.hip", "txe_gemm_tn.hip", "txe_gat.hip", "txe_gcn.hip", "txe_project.hip", "txe_readout.hip", "txe_match.hip",
            "txe_graph.hip", "txe_rank.hip", "txe_profile.hip"]
 HEADERS = ["txe_common.h", "txe_gemm.h", "txe_gather.h"]
 LIB = os.path.join(HERE, "libtxe.so")

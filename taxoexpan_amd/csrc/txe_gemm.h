@@ -7,17 +7,20 @@
 //     C[m][n] = sum_kk  A(m,kk) * B(kk,n)          m < M, n < N, kk in [k0,k1)
 //
 // * math: v_mfma_f32_32x32x2_f32 (exact fp32, 157 TFLOP/s peak on MI355X -- there is no TF32/xf32 on
-//   gfx950).  Block tile 128x128x32, 4 waves (2x2), each wave 2x2 MFMA tiles of 32x32 -> 64 accumulator
-//   VGPRs.  Operands are staged global -> registers -> LDS (double buffered, one barrier per k-tile).
+//   gfx950).  Block tile 128 x BN x 32 (BN = 128: 2x2 waves of 64x64; BN = 64: 4x1 waves of 32x64 -- more,
+//   smaller workgroups for narrow outputs and to soften wave quantisation on 256 CUs).  Operands are staged
+//   global -> registers -> LDS (double buffered, one barrier per k-tile).
 // * operands are *virtual* row-major matrices (VMat): the concat of node features with the position
 //   embedding row (model_zoo.py:215), the feature dropout (model_zoo.py:82, as a precomputed bit mask), row /
-//   column extensions that carry the folded attention projections, per-row scales ... are synthesised by the
-//   loader, so none of those tensors is ever materialised in HBM.
+//   column extensions that carry the folded attention projections ... are synthesised by the loader, so none
+//   of those tensors is ever materialised in HBM.
 // * either operand may be read "k-contiguous" (A[m][kk], kk fastest) or "row-contiguous"
 //   (A(m,kk) = Mat[kk][m]); that covers NT / NN / TN products without transposing in HBM.
-// * the loaders are BRANCH-FREE per element (clamped addresses + selects): hipcc waits vmcnt(0) behind every
-//   load that sits under a divergent branch, which serialises the whole staging stream (measured: 25 TF/s).
-//   The only branch is block-uniform: "does this k-tile lie entirely in the plain region of the operand".
+// * NO branch between a load and its first use: hipcc waits vmcnt(0) at control-flow merges behind pending loads
+//   and schedules only inside basic blocks, which serialised the staging stream at one HBM round trip per vector
+//   (measured 25 TF/s).  Hence: two-phase staging (issue = loads only / finish = selects + dropout, after the MFMA
+//   block), clamped always-valid addresses instead of guards, dummy-but-readable pointers for absent extras, and a
+//   k-loop split by the kind of tile being fetched (plain prefix, generic tail) instead of a per-tile branch.
 #pragma once
 #include "txe_common.h"
 
@@ -61,8 +64,8 @@ static inline void vmat_set_mask(VMat& m, const unsigned* mask, float drop_p) {
 // Output side.  Logical C [rows][cols]:
 //   n <  cols_main : c [m*ldc  + n]
 //   n >= cols_main : c2[m*ldc2 + n - cols_main]
-// value = acc (* (mask bit(m, n+mask_col0) ? drop_scale : 0)) (* leaky'(act_src[m][n]) for n<cols_main)
-//         (exp() if apply_exp).  Split-K: block z writes at c + z*split_stride (no extras expected).
+// value = acc (* (mask bit(m, n+mask_col0) ? drop_scale : 0)) (* leaky'(act_src[m][n]) for n<cols_main) (exp() if apply_exp).
+// Split-K: block z writes at c + z*split_stride (no extras expected).
 struct Epi {
     float* c;
     long long ldc;
@@ -97,11 +100,7 @@ static inline void epi_set_act(Epi& e, const float* act_src, long long ld_act, f
     if (act_src) { e.act_src = act_src; e.ld_act = ld_act; e.act_slope = slope; e.act_on = 1; }
 }
 
-// Staging is split in two phases so that NO consumer of a load sits between the loads of one k-tile:
-//   issue  : address math + global loads only (data, and the dropout mask word of each vector)
-//   finish : bounds selects + dropout factor, executed after the MFMAs of the current tile, right before the LDS store.
-// hipcc places s_waitcnt vmcnt(0) in front of the first use of a loaded value and schedules only inside basic blocks;
-// a select right behind each load serialised the stream at one HBM round trip per vector (25 TF/s measured).
+// ---- staging, phase 1: loads only ----------------------------------------------------------------------------
 // FAST: the whole tile lies inside the plain column range (c + V <= cols_main); only rows can be out of range.
 // Otherwise the element path: per element ONE load from a selected (always valid) address.
 template <int V, bool FAST>
@@ -119,7 +118,7 @@ __device__ __forceinline__ void vmat_issue(const VMat& M, int r, int c, long lon
             v[0] = row[c];
         }
     } else {
-        const float* ext = M.p2 ? (M.p2 + er * M.ld2) : row;          // block-uniform
+        const float* ext = M.p2 ? (M.p2 + er * M.ld2) : row;          // block-uniform select
 #pragma unroll
         for (int e = 0; e < V; ++e) {
             const int cc = c + e;
@@ -132,6 +131,7 @@ __device__ __forceinline__ void vmat_issue(const VMat& M, int r, int c, long lon
     mw = M.mask[(long long)rr * M.mask_ld + (M.mask_on ? ((c < M.cols ? c : 0) >> 5) : 0)];
 }
 
+// ---- staging, phase 2: bounds selects + dropout factor (runs after the MFMA block) ---------------------------
 template <int V, bool FAST>
 __device__ __forceinline__ void vmat_finish(const VMat& M, int r, int c, float* v, unsigned mw) {
     const bool rok = r < M.rows;
@@ -145,35 +145,37 @@ __device__ __forceinline__ void vmat_finish(const VMat& M, int r, int c, float* 
     }
 }
 
-constexpr int GEMM_BM = 128, GEMM_BN = 128, GEMM_BK = 32, GEMM_THREADS = 256;
+constexpr int GEMM_BM = 128, GEMM_BK = 32, GEMM_THREADS = 256;
 constexpr int GEMM_KPAD = GEMM_BK + 4;  // k-contiguous LDS row stride (floats): conflict-free ds_read_b128
 
-template <bool KC, int V> struct StageGeom {
-    static constexpr int VPR = (KC ? GEMM_BK : GEMM_BM) / V;     // vectors per tile line (k-row or m-row)
+// An operand tile has ROWS (128 or 64) rows of the GEMM's m/n dimension and BK k-values.
+// KC = true : tile is [ROWS][BK] read along k        (LDS [row][BK+4])
+// KC = false: tile is [BK][ROWS] read along the rows (LDS [k][ROWS])
+template <bool KC, int V, int ROWS> struct StageGeom {
+    static constexpr int VPR = (KC ? GEMM_BK : ROWS) / V;        // vectors per tile line
     static constexpr int LPP = GEMM_THREADS / VPR;               // lines per pass
-    static constexpr int PASSES = (KC ? GEMM_BM : GEMM_BK) / LPP;
+    static constexpr int PASSES = (KC ? ROWS : GEMM_BK) / LPP;
+    static constexpr int NREG = PASSES * V;
+    static constexpr int LDS = KC ? ROWS * GEMM_KPAD : GEMM_BK * ROWS;
 };
 
-// KC = true : operand tile is [R=128 rows][BK] read along k   (LDS [row][BK+4])
-// KC = false: operand tile is [BK][R=128]      read along rows (LDS [k][128])
-// (r, c) of pass p in the operand's own coordinates:
-template <bool KC, int V>
+template <bool KC, int V, int ROWS>
 __device__ __forceinline__ void stage_coord(int row0, int k0, int p, int& r, int& c) {
-    using G = StageGeom<KC, V>;
+    using G = StageGeom<KC, V, ROWS>;
     const int t = threadIdx.x;
     const int q = t % G::VPR, line = t / G::VPR + p * G::LPP;
     if constexpr (KC) { r = row0 + line; c = k0 + q * V; }
     else { r = k0 + line; c = row0 + q * V; }
 }
 
-template <bool KC, int V, bool FAST>
+template <bool KC, int V, int ROWS, bool FAST>
 __device__ __forceinline__ void stage_issue(const VMat& M, int row0, int k0, float* regs, unsigned* mws) {
-    using G = StageGeom<KC, V>;
+    using G = StageGeom<KC, V, ROWS>;
     long long er[G::PASSES];
 #pragma unroll
     for (int p = 0; p < G::PASSES; ++p) {
         int r, c;
-        stage_coord<KC, V>(row0, k0, p, r, c);
+        stage_coord<KC, V, ROWS>(row0, k0, p, r, c);
         const int rr = (r < M.rows) ? r : 0;
         er[p] = rr;
         if constexpr (!FAST) { if (M.pos) er[p] = M.pos[rr]; }      // all position loads first, one wait
@@ -181,57 +183,40 @@ __device__ __forceinline__ void stage_issue(const VMat& M, int row0, int k0, flo
 #pragma unroll
     for (int p = 0; p < G::PASSES; ++p) {
         int r, c;
-        stage_coord<KC, V>(row0, k0, p, r, c);
+        stage_coord<KC, V, ROWS>(row0, k0, p, r, c);
         vmat_issue<V, FAST>(M, r, c, er[p], regs + p * V, mws[p]);
     }
 }
 
-template <bool KC, int V, bool FAST>
+template <bool KC, int V, int ROWS, bool FAST>
 __device__ __forceinline__ void stage_finish(const VMat& M, int row0, int k0, float* regs, const unsigned* mws) {
-    using G = StageGeom<KC, V>;
+    using G = StageGeom<KC, V, ROWS>;
 #pragma unroll
     for (int p = 0; p < G::PASSES; ++p) {
         int r, c;
-        stage_coord<KC, V>(row0, k0, p, r, c);
+        stage_coord<KC, V, ROWS>(row0, k0, p, r, c);
         vmat_finish<V, FAST>(M, r, c, regs + p * V, mws[p]);
     }
 }
 
-// block-uniform: is the [row0, row0+128) x [k0, k0+BK) tile entirely inside the plain column range of M?
-template <bool KC>
-__device__ __forceinline__ bool tile_is_plain(const VMat& M, int row0, int k0) {
-    if constexpr (KC) return k0 + GEMM_BK <= M.cols_main;
-    else return row0 + GEMM_BM <= M.cols_main;
-}
-
-template <bool KC, int V>
+template <bool KC, int V, int ROWS>
 __device__ __forceinline__ void stage_store(float* lds, const float* regs) {
+    using G = StageGeom<KC, V, ROWS>;
     const int t = threadIdx.x;
-    if constexpr (KC) {
-        constexpr int VPR = GEMM_BK / V, RPP = GEMM_THREADS / VPR, PASSES = GEMM_BM / RPP;
-        const int kq = t % VPR, r = t / VPR;
+    const int q = t % G::VPR, line0 = t / G::VPR;
 #pragma unroll
-        for (int p = 0; p < PASSES; ++p) {
-            float* d = lds + (r + p * RPP) * GEMM_KPAD + kq * V;
+    for (int p = 0; p < G::PASSES; ++p) {
+        const int line = line0 + p * G::LPP;
+        float* d = KC ? (lds + line * GEMM_KPAD + q * V) : (lds + line * ROWS + q * V);
 #pragma unroll
-            for (int e = 0; e < V; ++e) d[e] = regs[p * V + e];
-        }
-    } else {
-        constexpr int VPR = GEMM_BM / V, KPP = GEMM_THREADS / VPR, PASSES = GEMM_BK / KPP;
-        const int mq = t % VPR, kr = t / VPR;
-#pragma unroll
-        for (int p = 0; p < PASSES; ++p) {
-            float* d = lds + (kr + p * KPP) * GEMM_BM + mq * V;
-#pragma unroll
-            for (int e = 0; e < V; ++e) d[e] = regs[p * V + e];
-        }
+        for (int e = 0; e < V; ++e) d[e] = regs[p * V + e];
     }
 }
 
 // MFMA operand fragment for the 32-row sub-tile starting at row r0, k-group kb (8 k values):
 // lane l supplies row (l&31) and k = kb*8 + (l>>5)*4 + s for step s = 0..3.  A and B use the same
 // (lane-half, step) -> k map, so the products line up whatever the storage mode.
-template <bool KC>
+template <bool KC, int ROWS>
 __device__ __forceinline__ void frag_load(const float* lds, int r0, int kb, float* f) {
     const int l = threadIdx.x & 63;
     const int row = r0 + (l & 31), kk = kb * 8 + (l >> 5) * 4;
@@ -240,24 +225,27 @@ __device__ __forceinline__ void frag_load(const float* lds, int r0, int kb, floa
         f[0] = t.x; f[1] = t.y; f[2] = t.z; f[3] = t.w;
     } else {
 #pragma unroll
-        for (int s = 0; s < 4; ++s) f[s] = lds[(kk + s) * GEMM_BM + row];
+        for (int s = 0; s < 4; ++s) f[s] = lds[(kk + s) * ROWS + row];
     }
 }
 
-template <bool AK, bool BKC, int V>
+template <bool AK, bool BKC, int VA, int VB, int BN>
 __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_kernel(VMat A, VMat B, const Epi E, const int M, const int N,
                                                                 const int K, const int ksplit) {
-    constexpr int ASZ = AK ? GEMM_BM * GEMM_KPAD : GEMM_BK * GEMM_BM;
-    constexpr int BSZ = BKC ? GEMM_BN * GEMM_KPAD : GEMM_BK * GEMM_BN;
+    using GA = StageGeom<AK, VA, GEMM_BM>;
+    using GB = StageGeom<BKC, VB, BN>;
+    constexpr int ASZ = GA::LDS, BSZ = GB::LDS;
+    constexpr int MI = (BN == 128) ? 2 : 1;          // 32-row MFMA tiles per wave along m
+    constexpr int NJ = 2;                            // along n
     __shared__ __attribute__((aligned(16))) float smem[2 * (ASZ + BSZ)];
     float* As = smem;
     float* Bs = smem + 2 * ASZ;
 
-    const int nbn = (N + GEMM_BN - 1) / GEMM_BN;
+    const int nbn = (N + BN - 1) / BN;
     const int ntiles = gridDim.x;
     const int lb = xcd_remap(blockIdx.x, ntiles);   // XCD-contiguous tile order: row panels stay in one L2
     const int tm = lb / nbn, tn = lb % nbn;
-    const int m0 = tm * GEMM_BM, n0 = tn * GEMM_BN;
+    const int m0 = tm * GEMM_BM, n0 = tn * BN;
     const int kbeg = blockIdx.y * ksplit;
     const int kend = min(K, kbeg + ksplit);
 
@@ -268,25 +256,26 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_kernel(VMat A, VMat B, c
     else     { B.rows = min(B.rows, kend); }
 
     const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
-    const int wr = w >> 1, wc = w & 1;
+    const int wr = (BN == 128) ? (w >> 1) : w, wc = (BN == 128) ? (w & 1) : 0;
+    const int wm0 = wr * (MI * 32), wn0 = wc * 64;
 
-    f32x16 acc[2][2];
+    f32x16 acc[MI][NJ];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    float ra[16], rb[16];
-    unsigned ma[StageGeom<AK, V>::PASSES], mb[StageGeom<BKC, V>::PASSES];
+    float ra[GA::NREG], rb[GB::NREG];
+    unsigned ma[GA::PASSES], mb[GB::PASSES];
     const int nk = (kend - kbeg + GEMM_BK - 1) / GEMM_BK;
     // leading k-tiles that are plain for BOTH operands.  The pipelined loop is split by the kind of the tile being
     // ISSUED (fast prefix, then generic tail) so that no branch sits between a load and its first use.
     int nkf;
     {
         const int fa_ = AK ? max(0, (A.cols_main - kbeg) / GEMM_BK) : ((m0 + GEMM_BM <= A.cols_main) ? nk : 0);
-        const int fb_ = BKC ? max(0, (B.cols_main - kbeg) / GEMM_BK) : ((n0 + GEMM_BN <= B.cols_main) ? nk : 0);
+        const int fb_ = BKC ? max(0, (B.cols_main - kbeg) / GEMM_BK) : ((n0 + BN <= B.cols_main) ? nk : 0);
         nkf = min(nk, min(fa_, fb_));
     }
 
@@ -295,80 +284,66 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_kernel(VMat A, VMat B, c
         const float* a_l = As + (cur_) * ASZ;                                                                        \
         const float* b_l = Bs + (cur_) * BSZ;                                                                        \
         _Pragma("unroll") for (int kb = 0; kb < GEMM_BK / 8; ++kb) {                                                 \
-            float fa[2][4], fb[2][4];                                                                                \
-            _Pragma("unroll") for (int i = 0; i < 2; ++i) frag_load<AK>(a_l, wr * 64 + i * 32, kb, fa[i]);           \
-            _Pragma("unroll") for (int j = 0; j < 2; ++j) frag_load<BKC>(b_l, wc * 64 + j * 32, kb, fb[j]);          \
+            float fa[MI][4], fb[NJ][4];                                                                              \
+            _Pragma("unroll") for (int i = 0; i < MI; ++i) frag_load<AK, GEMM_BM>(a_l, wm0 + i * 32, kb, fa[i]);     \
+            _Pragma("unroll") for (int j = 0; j < NJ; ++j) frag_load<BKC, BN>(b_l, wn0 + j * 32, kb, fb[j]);         \
             _Pragma("unroll") for (int s = 0; s < 4; ++s)                                                            \
-                _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                        \
-                    _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                    \
+                _Pragma("unroll") for (int i = 0; i < MI; ++i)                                                       \
+                    _Pragma("unroll") for (int j = 0; j < NJ; ++j)                                                   \
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][s], fb[j][s], acc[i][j], 0, 0, 0);    \
         }                                                                                                            \
     }
+#define TXE_NOTHING
+#define TXE_STAGE(FAST_, k0_, buf_, COMPUTE_)                                                                        \
+    {                                                                                                                \
+        stage_issue<AK, VA, GEMM_BM, FAST_>(A, m0, (k0_), ra, ma);                                                   \
+        stage_issue<BKC, VB, BN, FAST_>(B, n0, (k0_), rb, mb);                                                       \
+        __builtin_amdgcn_sched_barrier(0); /* loads first: the whole MFMA block then covers their latency */        \
+        COMPUTE_                                                                                                     \
+        __builtin_amdgcn_sched_barrier(0);                                                                           \
+        stage_finish<AK, VA, GEMM_BM, FAST_>(A, m0, (k0_), ra, ma);                                                  \
+        stage_finish<BKC, VB, BN, FAST_>(B, n0, (k0_), rb, mb);                                                      \
+        stage_store<AK, VA, GEMM_BM>(As + (buf_) * ASZ, ra);                                                         \
+        stage_store<BKC, VB, BN>(Bs + (buf_) * BSZ, rb);                                                             \
+    }
 
     if (nk > 0) {
-        if (nkf > 0) {
-            stage_issue<AK, V, true>(A, m0, kbeg, ra, ma);
-            stage_issue<BKC, V, true>(B, n0, kbeg, rb, mb);
-            stage_finish<AK, V, true>(A, m0, kbeg, ra, ma);
-            stage_finish<BKC, V, true>(B, n0, kbeg, rb, mb);
-        } else {
-            stage_issue<AK, V, false>(A, m0, kbeg, ra, ma);
-            stage_issue<BKC, V, false>(B, n0, kbeg, rb, mb);
-            stage_finish<AK, V, false>(A, m0, kbeg, ra, ma);
-            stage_finish<BKC, V, false>(B, n0, kbeg, rb, mb);
-        }
-        stage_store<AK, V>(As, ra);
-        stage_store<BKC, V>(Bs, rb);
+        if (nkf > 0) TXE_STAGE(true, kbeg, 0, TXE_NOTHING)
+        else TXE_STAGE(false, kbeg, 0, TXE_NOTHING)
     }
     __syncthreads();
     int t = 1;
     for (; t < nkf; ++t) {                      // tile t (plain) is fetched while tile t-1 is multiplied
-        const int k0 = kbeg + t * GEMM_BK;
-        stage_issue<AK, V, true>(A, m0, k0, ra, ma);
-        stage_issue<BKC, V, true>(B, n0, k0, rb, mb);
-        __builtin_amdgcn_sched_barrier(0);          // loads first: the whole MFMA block then covers their latency
-        TXE_COMPUTE_TILE((t - 1) & 1)
-        __builtin_amdgcn_sched_barrier(0);
-        stage_finish<AK, V, true>(A, m0, k0, ra, ma);
-        stage_finish<BKC, V, true>(B, n0, k0, rb, mb);
-        stage_store<AK, V>(As + (t & 1) * ASZ, ra);
-        stage_store<BKC, V>(Bs + (t & 1) * BSZ, rb);
+        TXE_STAGE(true, kbeg + t * GEMM_BK, t & 1, TXE_COMPUTE_TILE((t - 1) & 1))
         __syncthreads();
     }
     for (; t < nk; ++t) {                       // generic tiles (extension columns / ragged edges)
-        const int k0 = kbeg + t * GEMM_BK;
-        stage_issue<AK, V, false>(A, m0, k0, ra, ma);
-        stage_issue<BKC, V, false>(B, n0, k0, rb, mb);
-        __builtin_amdgcn_sched_barrier(0);
-        TXE_COMPUTE_TILE((t - 1) & 1)
-        __builtin_amdgcn_sched_barrier(0);
-        stage_finish<AK, V, false>(A, m0, k0, ra, ma);
-        stage_finish<BKC, V, false>(B, n0, k0, rb, mb);
-        stage_store<AK, V>(As + (t & 1) * ASZ, ra);
-        stage_store<BKC, V>(Bs + (t & 1) * BSZ, rb);
+        TXE_STAGE(false, kbeg + t * GEMM_BK, t & 1, TXE_COMPUTE_TILE((t - 1) & 1))
         __syncthreads();
     }
     if (nk > 0) TXE_COMPUTE_TILE((nk - 1) & 1)
+#undef TXE_STAGE
+#undef TXE_NOTHING
 #undef TXE_COMPUTE_TILE
 
     // epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
-    // Extras (mask word, activation source, row scale) are fetched for all 16 rows of a sub-tile with clamped,
-    // unconditional loads first, then applied -- no load sits under a divergent branch.
+    // Extras (mask word, activation source) are fetched for all 16 rows of a sub-tile with clamped, unconditional
+    // loads first, then applied -- no load sits under a branch.
     float* cbase = E.c + (long long)blockIdx.y * E.split_stride;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < MI; ++i) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int n = n0 + wc * 64 + j * 32 + (l & 31);
+        for (int j = 0; j < NJ; ++j) {
+            const int n = n0 + wn0 + j * 32 + (l & 31);
             const bool nok = n < N;
             const bool main_col = n < E.cols_main;
             const int nc = nok ? n : 0;
-            const int mbase = m0 + wr * 64 + i * 32 + 4 * (l >> 5);
+            const int mbase = m0 + wm0 + i * 32 + 4 * (l >> 5);
             const int cm = nc + E.mask_col0;
             float av[16];
             unsigned wd[16];
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {          // all extra loads first (always valid addresses), no branches
+            for (int e = 0; e < 16; ++e) {
                 const int m = mbase + (e & 3) + 8 * (e >> 2);
                 const int mc = (m < M) ? m : 0;
                 wd[e] = E.mask[E.mask_on ? ((long long)mc * E.mask_ld + (cm >> 5)) : 0];
@@ -380,7 +355,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_kernel(VMat A, VMat B, c
                 const unsigned keep = ((wd[e] >> (cm & 31)) & 1u) | (E.mask_on ? 0u : 1u);
                 float g = keep ? E.drop_scale : 0.f;
                 g *= ((E.act_on != 0) & main_col & !(av[e] > 0.f)) ? E.act_slope : 1.f;
-                float x = acc[i][j][e] * g;
+                const float x = acc[i][j][e] * g;
                 val[e] = E.apply_exp ? __expf(x) : x;
             }
             if (nok) {
@@ -409,7 +384,31 @@ static inline int vmat_vec(const VMat& m) {
     return v;
 }
 
+int device_cu_count();     // txe_profile.hip (cached hipDeviceAttributeMultiprocessorCount of the current device)
+
+// 128 x BN tile choice: the narrower tile when it wastes fewer MFMA columns or needs fewer (fractional) rounds of
+// workgroups over the CUs (2 co-resident workgroups per CU).
+static inline int choose_bn(int M, int N, int splits) {
+    if (N <= 64) return 64;
+    const int slots = 2 * device_cu_count();
+    auto cost = [&](int bn) {
+        const long long blocks = (long long)((M + GEMM_BM - 1) / GEMM_BM) * ((N + bn - 1) / bn) * splits;
+        const long long rounds = (blocks + slots - 1) / slots;
+        return (double)rounds * bn * (bn == 64 ? 1.25 : 1.0);     // narrower tile: measured ~20% less efficient per flop
+    };
+    return cost(64) < cost(128) ? 64 : 128;
+}
+
+template <bool AK, bool BKC, int VA, int VB>
+static inline void gemm_launch_v(int bn, dim3 grid, hipStream_t stream, const VMat& A, const VMat& B, const Epi& E, int M, int N,
+                                 int K, int ksplit) {
+    if (bn == 128) hipLaunchKernelGGL((gemm_kernel<AK, BKC, VA, VB, 128>), grid, dim3(GEMM_THREADS), 0, stream, A, B, E, M, N, K, ksplit);
+    else hipLaunchKernelGGL((gemm_kernel<AK, BKC, VA, VB, 64>), grid, dim3(GEMM_THREADS), 0, stream, A, B, E, M, N, K, ksplit);
+}
+
 // Launch C = A*B.  splits > 1 => split-K over gridDim.y, block z stores at E.c + z*E.split_stride.
+// Vector widths: 16-byte loads for an operand whose rows are 16-byte aligned, else 8-byte; a 4-byte-only operand
+// drops both to scalar loads (odd leading dimensions: correctness path, not a fast one).
 template <bool AK, bool BKC>
 static inline int gemm_launch_layout(const VMat& A, const VMat& B, const Epi& E_in, int M, int N, int K, int splits,
                                      hipStream_t stream) {
@@ -420,27 +419,44 @@ static inline int gemm_launch_layout(const VMat& A, const VMat& B, const Epi& E_
         if (!E.act_on) E.act_src = (const float*)valid;
         if (!E.mask_on) E.mask = (const unsigned*)valid;
     }
-    int v = vmat_vec(A);
-    const int vb = vmat_vec(B);
-    if (vb < v) v = vb;
-    const int nbm = (M + GEMM_BM - 1) / GEMM_BM, nbn = (N + GEMM_BN - 1) / GEMM_BN;
+    int va = vmat_vec(A), vb = vmat_vec(B);
+    if (va == 1 || vb == 1) va = vb = 1;
     if (splits < 1) splits = 1;
+    const int bn = choose_bn(M, N, splits);
+    const int nbm = (M + GEMM_BM - 1) / GEMM_BM, nbn = (N + bn - 1) / bn;
     int ksplit = (K + splits - 1) / splits;
     ksplit = ((ksplit + GEMM_BK - 1) / GEMM_BK) * GEMM_BK;
     if (ksplit == 0) ksplit = GEMM_BK;
-    dim3 grid(nbm * nbn, splits), block(GEMM_THREADS);
-    static const char* const kNames[3][3] = {{"gemm_tn_v1", "gemm_tn_v2", "gemm_tn_v4"},
-                                             {"gemm_nn_v1", "gemm_nn_v2", "gemm_nn_v4"},
-                                             {"gemm_nt_v1", "gemm_nt_v2", "gemm_nt_v4"}};
-    ProfScope prof(kNames[(AK ? 1 : 0) + (BKC ? 1 : 0)][v == 4 ? 2 : (v == 2 ? 1 : 0)], stream, 2.0 * M * (double)N * K, 0);
-    if (v == 4) hipLaunchKernelGGL((gemm_kernel<AK, BKC, 4>), grid, block, 0, stream, A, B, E, M, N, K, ksplit);
-    else if (v == 2) hipLaunchKernelGGL((gemm_kernel<AK, BKC, 2>), grid, block, 0, stream, A, B, E, M, N, K, ksplit);
-    else hipLaunchKernelGGL((gemm_kernel<AK, BKC, 1>), grid, block, 0, stream, A, B, E, M, N, K, ksplit);
+    dim3 grid(nbm * nbn, splits);
+    static const char* const kNames[3] = {"gemm_tn", "gemm_nn", "gemm_nt"};
+    ProfScope prof(kNames[(AK ? 1 : 0) + (BKC ? 1 : 0)], stream, 2.0 * M * (double)N * K, 0);
+    if (va == 4 && vb == 4) gemm_launch_v<AK, BKC, 4, 4>(bn, grid, stream, A, B, E, M, N, K, ksplit);
+    else if (va == 4 && vb == 2) gemm_launch_v<AK, BKC, 4, 2>(bn, grid, stream, A, B, E, M, N, K, ksplit);
+    else if (va == 2 && vb == 4) gemm_launch_v<AK, BKC, 2, 4>(bn, grid, stream, A, B, E, M, N, K, ksplit);
+    else if (va == 2 && vb == 2) gemm_launch_v<AK, BKC, 2, 2>(bn, grid, stream, A, B, E, M, N, K, ksplit);
+    else gemm_launch_v<AK, BKC, 1, 1>(bn, grid, stream, A, B, E, M, N, K, ksplit);
     TXE_CHECK_LAUNCH();
     return TXE_OK;
 }
 
-// defined in txe_gemm.hip (one translation unit instantiates the kernels)
+// number of split-K slices for a product with `tiles` output tiles and reduction length K: fill whole rounds of
+// 2 workgroups per CU, keep >= 8 k-tiles per slice.
+static inline int choose_splits(int M, int N, int K) {
+    const int tiles = ((M + GEMM_BM - 1) / GEMM_BM) * ((N + 127) / 128);
+    const int slots = 2 * device_cu_count();
+    const int max_by_k = (K + 255) / 256 > 0 ? (K + 255) / 256 : 1;
+    int best = 1;
+    double best_cost = 1e30;
+    for (int s = 1; s <= 64 && s <= max_by_k; ++s) {
+        const long long blocks = (long long)tiles * s;
+        const long long rounds = (blocks + slots - 1) / slots;
+        const double cost = (double)rounds / s + 0.002 * s;      // time ~ rounds x (K/s); small penalty for partial traffic
+        if (cost < best_cost) { best_cost = cost; best = s; }
+    }
+    return best;
+}
+
+// each defined in its own translation unit (txe_gemm_nt.hip / _nn / _tn) so that the 30 kernel variants compile in parallel
 int gemm_nt(const VMat& A, const VMat& B, const Epi& E, int M, int N, int K, int splits, hipStream_t s);  // A[m][k], B[n][k]
 int gemm_nn(const VMat& A, const VMat& B, const Epi& E, int M, int N, int K, int splits, hipStream_t s);  // A[m][k], B[k][n]
 int gemm_tn(const VMat& A, const VMat& B, const Epi& E, int M, int N, int K, int splits, hipStream_t s);  // A[k][m], B[k][n]

@@ -1,0 +1,10 @@
+// Instantiates the fp32 MFMA GEMM kernels (txe_gemm.h) for the "nn" operand layout.
+#include "txe_gemm.h"
+
+namespace txe {
+
+int gemm_nn(const VMat& A, const VMat& B, const Epi& E, int M, int N, int K, int splits, hipStream_t s) {
+    return gemm_launch_layout<true, false>(A, B, E, M, N, K, splits, s);
+}
+
+}  // namespace txe

@@ -58,15 +58,7 @@ __global__ void reduce_splits_kernel2(const float* __restrict__ part, int S, lon
 
 static inline size_t mt_align(size_t x) { return (x + 255) / 256 * 256; }
 
-static inline int mt_splits(int M, int N, int K) {
-    const int tiles = ((M + GEMM_BM - 1) / GEMM_BM) * ((N + GEMM_BN - 1) / GEMM_BN);
-    int s = (512 + tiles - 1) / tiles;
-    const int max_by_k = (K + 255) / 256;
-    if (s > max_by_k) s = max_by_k;
-    if (s > 64) s = 64;
-    if (s < 1) s = 1;
-    return s;
-}
+static inline int mt_splits(int M, int N, int K) { return choose_splits(M, N, K); }
 
 }  // namespace txe
 

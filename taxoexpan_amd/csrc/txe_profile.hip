@@ -23,6 +23,19 @@ static std::vector<hipEvent_t> g_pool;
 
 bool prof_enabled() { return g_on; }
 
+// compute-unit count of the current device (256 on MI355X), cached per process; 256 if no device is visible (CPU-only
+// build hosts only ever size workspaces with it).
+int device_cu_count() {
+    static int cached = 0;
+    if (cached > 0) return cached;
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0)
+        cached = n;
+    else
+        return 256;
+    return cached;
+}
+
 static hipEvent_t take_event() {
     if (!g_pool.empty()) { hipEvent_t e = g_pool.back(); g_pool.pop_back(); return e; }
     hipEvent_t e;

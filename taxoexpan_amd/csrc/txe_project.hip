@@ -146,16 +146,6 @@ __global__ __launch_bounds__(256) void pos_segsum_stage2(const float* __restrict
 
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
-static inline int choose_splits(int M, int N, int K) {
-    const int tiles = ((M + GEMM_BM - 1) / GEMM_BM) * ((N + GEMM_BN - 1) / GEMM_BN);
-    int s = (768 + tiles - 1) / tiles;            // aim at ~3 workgroups per CU
-    const int max_by_k = (K + 255) / 256;         // keep >= 8 k-tiles per split
-    if (s > max_by_k) s = max_by_k;
-    if (s > 64) s = 64;
-    if (s < 1) s = 1;
-    return s;
-}
-
 static VMat make_xcat(const float* h, long long ld_h, int n, int Kh, const int* pos, const float* P, int Pd, float drop_p,
                       const unsigned* mask) {
     VMat m = vmat_plain(h, ld_h, n, Kh + Pd);

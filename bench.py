@@ -82,8 +82,27 @@ def profile_step(model, opt, batch, target):
     return recs
 
 
+def load_traffic():
+    """HBM-side bytes per launch of each kernel from the committed rocprofv3 PMC passes (profiles/*_traffic.json, made by
+    tools/summarize_profiles.py from separate --pmc FETCH_SIZE / --pmc WRITE_SIZE runs of the same workload, FETCH_SIZE
+    corrected x2 as calibrated on a 1 GiB copy -- MI355X_MICROARCH.md HBM section).  PMC collection cannot run inside the
+    timed process, so bench.py reports the latest committed measurement."""
+    import glob
+    files = sorted(glob.glob(os.path.join(REPO, "profiles", "*_traffic.json")))
+    if not files:
+        return {}, None
+    d = json.load(open(files[-1]))
+    out = {}
+    for kind in ("fetch", "write"):
+        for k, v in d.get(kind, {}).get("kernels", {}).items():
+            out.setdefault(k, 0.0)
+            out[k] += v["avg_corrected_bytes"]
+    return out, os.path.basename(files[-1])
+
+
 def summarize_profile(all_recs, n_edges_by_launch):
     """aggregate records by kernel name: launches, avg duration, algorithmic work per launch, roofline fraction"""
+    traffic, traffic_src = load_traffic()
     agg = {}
     for recs, e in zip(all_recs, n_edges_by_launch):
         for name, sec, work, kind in recs:
@@ -101,7 +120,8 @@ def summarize_profile(all_recs, n_edges_by_launch):
         out.append(dict(kernel=name, bound="hbm" if a["kind"] == 1 else "mfma", launches=a["launches"],
                         avg_us=1e6 * a["sec"] / a["launches"], total_us=1e6 * a["sec"],
                         achieved=(ach / 1e9 if a["kind"] == 1 else ach / 1e12), peak=(peak / 1e9 if a["kind"] == 1 else peak / 1e12),
-                        unit="GB/s" if a["kind"] == 1 else "TFLOP/s", frac=ach / peak, work_per_launch=a["work"] / a["launches"]))
+                        unit="GB/s" if a["kind"] == 1 else "TFLOP/s", frac=ach / peak, work_per_launch=a["work"] / a["launches"],
+                        traffic=traffic.get(name), traffic_source=traffic_src if name in traffic else None))
     out.sort(key=lambda r: -r["total_us"])
     return out
 
@@ -281,7 +301,8 @@ def main():
                        "egonets_per_step_per_gpu": N_QUERIES * (1 + NEG), "avg_edges_per_step_per_gpu": edges / args.steps / world,
                        "parallelism": f"dp{world}"},
             "roofline": {"bound": dom["bound"], "achieved": dom["achieved"], "peak": dom["peak"], "unit": dom["unit"],
-                         "frac": dom["frac"], "traffic": None, "kernel": dom["kernel"], "avg_us": dom["avg_us"],
+                         "frac": dom["frac"], "traffic": dom["traffic"], "traffic_source": dom["traffic_source"],
+                         "kernel": dom["kernel"], "avg_us": dom["avg_us"],
                          "launches_per_4_steps": dom["launches"], "work_per_launch": dom["work_per_launch"]},
             "roofline_all": roof_all,
             "cpu_baseline": cpu,

@@ -258,7 +258,7 @@ int txe_gat_aggregate_fwd(const int* rowptr_in, const int* col_src, int n_nodes,
     const int vec = pick_vec(D, ld_ft, ld_out, ft, out);
     // algorithmic (compulsory) bytes, SURVEY 8d: read ft + write out + a_src/a_dst + CSR (+ alpha when kept for backward);
     // the edge count is not known here (device rowptr), the E-proportional terms are added by the caller-side model
-    ProfScope prof("gat_aggregate_fwd", s, 4.0 * (2.0 * n_nodes * (double)H * D + 2.0 * n_nodes * H + n_nodes + 1), 1);
+    ProfScope prof(vec == 4 ? "gat_aggregate_fwd_kernel<4>" : (vec == 2 ? "gat_aggregate_fwd_kernel<2>" : "gat_aggregate_fwd_kernel<1>"), s, 4.0 * (2.0 * n_nodes * (double)H * D + 2.0 * n_nodes * H + n_nodes + 1), 1);
 #define TXE_L(V)                                                                                                         \
     hipLaunchKernelGGL((gat_aggregate_fwd_kernel<V>), dim3(nb), dim3(GAT_WAVES * 64), 0, s, rowptr_in, col_src, n_nodes, \
                        ft, ld_ft, a_src, a_dst, ld_a, H, D, attn_slope, attn_drop_p, scale, seed, out_mode, act_slope,   \
@@ -283,7 +283,7 @@ int txe_gat_aggregate_bwd(const int* rowptr_in, const int* col_src, const int* r
     hipStream_t s = (hipStream_t)stream;
     const int v1 = pick_vec(D, ld_ft, ld_dpre, ft, d_pre);
     {
-    ProfScope prof("gat_bwd_edge", s, 4.0 * (2.0 * n_nodes * (double)H * D + 3.0 * n_nodes * H), 1);   // read ft + d_pre
+    ProfScope prof(v1 == 4 ? "gat_bwd_edge_kernel<4>" : (v1 == 2 ? "gat_bwd_edge_kernel<2>" : "gat_bwd_edge_kernel<1>"), s, 4.0 * (2.0 * n_nodes * (double)H * D + 3.0 * n_nodes * H), 1);   // read ft + d_pre
 #define TXE_L(V)                                                                                                          \
     hipLaunchKernelGGL((gat_bwd_edge_kernel<V>), dim3(nb), dim3(GAT_WAVES * 64), 0, s, rowptr_in, col_src, n_nodes, ft,   \
                        ld_ft, a_src, a_dst, ld_a, H, D, attn_slope, attn_drop_p, scale, seed, alpha, d_pre, ld_dpre,      \
@@ -293,7 +293,7 @@ int txe_gat_aggregate_bwd(const int* rowptr_in, const int* col_src, const int* r
     }
     TXE_CHECK_LAUNCH();
     const int v2 = pick_vec(D, ld_dpre, ld_dft, d_pre, d_ft);
-    ProfScope prof2("gat_bwd_node", s, 4.0 * (2.0 * n_nodes * (double)H * D + n_nodes * H), 1);          // read d_pre + write d_ft
+    ProfScope prof2(v2 == 4 ? "gat_bwd_node_kernel<4>" : (v2 == 2 ? "gat_bwd_node_kernel<2>" : "gat_bwd_node_kernel<1>"), s, 4.0 * (2.0 * n_nodes * (double)H * D + n_nodes * H), 1);          // read d_pre + write d_ft
 #define TXE_L(V)                                                                                                          \
     hipLaunchKernelGGL((gat_bwd_node_kernel<V>), dim3(nb), dim3(GAT_WAVES * 64), 0, s, rowptr_out, col_dst, pos_out,      \
                        n_nodes, alpha, (const float*)dz_ws, H, D, attn_drop_p, scale, seed, d_pre, ld_dpre, d_ft, ld_dft, \

@@ -95,7 +95,7 @@ static int gcn_launch(const int* rowptr, const int* col, int n, const float* x, 
                       const float* bias, int has_act, float slope, int F, float* out, long long ld_out, hipStream_t s) {
     const int nb = (n + GAT_WAVES - 1) / GAT_WAVES;
     int vec = gcn_pick_vec(F, ld_x, ld_out, x, out);
-    ProfScope prof("gcn_aggregate", s, 4.0 * (2.0 * n * (double)F + 2.0 * n + 1), 1);
+    ProfScope prof(vec == 4 ? "gcn_aggregate_kernel<4>" : (vec == 2 ? "gcn_aggregate_kernel<2>" : "gcn_aggregate_kernel<1>"), s, 4.0 * (2.0 * n * (double)F + 2.0 * n + 1), 1);
 #define TXE_L(V)                                                                                                           \
     hipLaunchKernelGGL((gcn_aggregate_kernel<V>), dim3(nb), dim3(GAT_WAVES * 64), 0, s, rowptr, col, n, x, ld_x, norm, bias, \
                        has_act, slope, F, out, ld_out)

@@ -190,7 +190,7 @@ int txe_readout_fwd(const int* graph_off, int G, const float* h, long long ld_h,
     const int nb = (G + RO_WAVES - 1) / RO_WAVES;
     const int vec = ro_pick_vec(D, ld_h, D, h, hg, nullptr);
     hipStream_t s = (hipStream_t)stream;
-    ProfScope prof("readout_fwd", s, 4.0 * (double)G * D, 1);   // output bytes; the caller adds the N*D input rows
+    ProfScope prof(vec == 4 ? "readout_fwd_kernel<4>" : (vec == 2 ? "readout_fwd_kernel<2>" : "readout_fwd_kernel<1>"), s, 4.0 * (double)G * D, 1);   // output bytes; the caller adds the N*D input rows
 #define TXE_L(V) hipLaunchKernelGGL((readout_fwd_kernel<V>), dim3(nb), dim3(RO_WAVES * 64), 0, s, graph_off, G, h, ld_h, pos, pw, D, hg, wsum)
     if (vec == 4) TXE_L(4); else if (vec == 2) TXE_L(2); else TXE_L(1);
 #undef TXE_L

@@ -1,0 +1,34 @@
+#!/usr/bin/env python3
+"""Plain-operand GEMM micro-benchmark of libtxe's fp32 MFMA kernel against torch.mm (hipBLASLt), on one MI355X."""
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from taxoexpan_amd import ops  # noqa: E402
+
+dev = torch.device("cuda:0")
+
+
+def bench(fn, flops, n=10):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    for _ in range(n):
+        fn()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t) / n
+    return dt * 1e6, flops / dt / 1e12
+
+
+for (M, N, K) in [(4096, 4096, 4096), (8192, 8192, 1024), (16384, 2048, 2048), (18000, 2008, 300), (18000, 508, 2050), (18000, 2050, 508)]:
+    A = torch.randn(M, K, device=dev)
+    B = torch.randn(K, N, device=dev)
+    Bt = B.t().contiguous()
+    us, tf = bench(lambda: ops.bilinear_project(A, B.unsqueeze(0)), 2.0 * M * N * K)
+    us2, tf2 = bench(lambda: ops.score_block(A, Bt, False), 2.0 * M * N * K)
+    us3, tf3 = bench(lambda: torch.mm(A, B), 2.0 * M * N * K)
+    print(f"M={M} N={N} K={K}: NN {us:.0f}us {tf:.1f}TF | NT {us2:.0f}us {tf2:.1f}TF | torch.mm {us3:.0f}us {tf3:.1f}TF")

@@ -1,0 +1,70 @@
+#!/usr/bin/env python3
+"""Summarise rocprofv3 outputs (kernel stats CSV + FETCH_SIZE / WRITE_SIZE counter CSVs) into profiles/<tag>_*.{md,json}.
+
+    python tools/summarize_profiles.py <dir with kt_kernel_stats.csv, fetch_counter_collection.csv, write_counter_collection.csv> <tag>
+"""
+import collections
+import csv
+import json
+import os
+import sys
+
+src, tag = sys.argv[1], sys.argv[2]
+out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
+os.makedirs(out_dir, exist_ok=True)
+CALIB_BYTES = 256 * 1024 * 1024 * 4
+
+
+def short(name):
+    name = name.replace("void ", "").replace("txe::", "")
+    return name.split("(")[0][:70]
+
+
+lines = [f"# rocprofv3 summary `{tag}`", ""]
+ks = os.path.join(src, "kt_kernel_stats.csv")
+if os.path.exists(ks):
+    rows = list(csv.DictReader(open(ks)))
+    lines += ["## kernel-trace --stats (python bench.py --steps 20 --warmup 5 --no-extra --no-cpu-baseline)", "",
+              "| kernel | calls | total ms | avg us | % |", "|---|---|---|---|---|"]
+    for r in rows[:28]:
+        lines.append(f"| `{short(r['Name'])}` | {r['Calls']} | {float(r['TotalDurationNs'])/1e6:.2f} | {float(r['AverageNs'])/1e3:.1f} | {float(r['Percentage']):.2f} |")
+    lines.append("")
+
+traffic = {}
+for kind, cname in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
+    f = os.path.join(src, f"{kind}_counter_collection.csv")
+    if not os.path.exists(f):
+        continue
+    per = collections.defaultdict(float)
+    names = {}
+    for r in csv.DictReader(open(f)):
+        if r["Counter_Name"] != cname:
+            continue
+        per[r["Dispatch_Id"]] += float(r["Counter_Value"])
+        names[r["Dispatch_Id"]] = r["Kernel_Name"]
+    # calibration: the single big elementwise copy
+    calib = [(v, d) for d, v in per.items() if "elementwise" in names[d] or "copy" in names[d].lower()]
+    cv, cd = max(calib) if calib else (0.0, None)
+    factor = CALIB_BYTES / (cv * 1024.0) if cv > 0 else 1.0
+    agg = collections.defaultdict(lambda: [0, 0.0])
+    for d, v in per.items():
+        if d == cd:
+            continue
+        a = agg[short(names[d])]
+        a[0] += 1
+        a[1] += v * 1024.0
+    traffic[kind] = dict(raw_unit_bytes=1024, calibration_kernel=short(names[cd]) if cd else None, calibration_counter=cv,
+                         correction_factor=factor,
+                         kernels={k: dict(launches=n, avg_raw_bytes=b / n, avg_corrected_bytes=b / n * factor) for k, (n, b) in agg.items()})
+    lines += [f"## --pmc {cname} (tools/profile_workload.py)", "",
+              f"calibration: 1 GiB device copy reported {cv:.0f} x 1 KiB -> correction factor x{factor:.3f}", "",
+              "| kernel | launches | avg raw MB | avg corrected MB |", "|---|---|---|---|"]
+    for k, (n, b) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+        if "txe" in k or "gemm" in k or "gat" in k or "readout" in k:
+            lines.append(f"| `{k}` | {n} | {b/n/1e6:.2f} | {b/n*factor/1e6:.2f} |")
+    lines.append("")
+
+open(os.path.join(out_dir, f"{tag}_summary.md"), "w").write("\n".join(lines) + "\n")
+if traffic:
+    json.dump(traffic, open(os.path.join(out_dir, f"{tag}_traffic.json"), "w"), indent=1)
+print("\n".join(lines[:60]))

@@ -126,7 +126,7 @@ def summarize_profile(all_recs, n_edges_by_launch):
     return out
 
 
-def cpu_baseline(batch, state_dict, n_sample_queries=16, iters=2):
+def cpu_baseline(batch, state_dict, n_sample_queries=128, iters=4):
     """The oracle's training step (forward + InfoNCE + backward, torch CPU fp32, all host threads) on the first
     n_sample_queries x 32 egonets of the same batch."""
     sys.path.insert(0, os.path.join(REPO, "oracle"))

@@ -108,6 +108,11 @@ int txe_bilinear_pair_bwd(const float* e1, long long ld_e1, const float* e2, lon
 int txe_score_block(const float* Q, long long ld_q, int nq, const float* U, int G, int r, int apply_exp, float* S,
                     long long ld_s, void* stream);
 
+/* plain dense product on the fp32 MFMA GEMM (tests / micro-benchmarks).  layout 0: C = A[M][K] B[N][K]^T; 1: C = A[M][K] B[K][N];
+ * 2: C = A[K][M]^T B[K][N].  splits > 1: `splits` partial products at C + z*M*ldc. */
+int txe_gemm_plain(int layout, const float* A, long long lda, const float* B, long long ldb, float* C, long long ldc, int M, int N,
+                   int K, int splits, void* stream);
+
 /* ---- rank extraction of the scoring loop: test_fast.py:16-22 + model/metric.py:7-31 (strict inequalities, the
  * query's other positives excluded).  pos_off [nq+1], pos_idx: candidate columns of each query's true parents. */
 int txe_rank_block(const float* S, long long ld_s, int nq, int G, const int* pos_off, const int* pos_idx, int* ranks,

@@ -34,6 +34,7 @@ SIGNATURES = {
     "txe_bilinear_pair_bwd_ws_bytes": (SZ, [I, I, I]),
     "txe_bilinear_pair_bwd": (I, [P, L, P, L, I, I, I, P, I, P, P, P, P, L, P, L, P, P, SZ, P]),
     "txe_score_block": (I, [P, L, I, P, I, I, I, P, L, P]),
+    "txe_gemm_plain": (I, [I, P, L, P, L, P, L, I, I, I, I, P]),
     "txe_build_csr_ws_bytes": (SZ, [I, I]),
     "txe_build_csr": (I, [P, P, I, I, P, P, P, P, P, P, P, SZ, P]),
     "txe_rank_block": (I, [P, L, I, I, P, P, P, I, P, P]),

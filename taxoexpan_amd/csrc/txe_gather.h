@@ -48,4 +48,49 @@ __device__ __forceinline__ void gather_accumulate(const float* __restrict__ base
     }
 }
 
+// Same accumulation for a SLICE of the feature row owned by one wave of a workgroup that shares a node among its
+// 4 waves (skewed degree lists, e.g. an egonet anchor with 50 out-edges): lane l owns vectors j0 + l + 64 i, i < NI.
+// Edges are unrolled by EU so that NI*EU independent 16-byte loads are in flight per lane.
+template <int VEC, int NI, int EU>
+__device__ __forceinline__ void gather_accumulate_slice(const float* __restrict__ base, long long ld, const int* s_idx,
+                                                        const float* s_w, int cnt, int j0, int j1, const int* hidx,
+                                                        float (&acc)[NI][VEC]) {
+    const int l = threadIdx.x & 63;
+    int e = 0;
+    for (; e + EU <= cnt; e += EU) {
+        float v[EU][NI][VEC];
+#pragma unroll
+        for (int u = 0; u < EU; ++u) {
+            const float* row = base + (long long)s_idx[e + u] * ld;
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                const int j = j0 + l + 64 * i;
+                const int jc = (j < j1) ? j : j0;               // clamped: loads stay unconditional
+                vload<VEC>(row + (long long)jc * VEC, v[u][i]);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < EU; ++u)
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                const float a = s_w[hidx[i] * 64 + e + u];
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) acc[i][k] = fmaf(a, v[u][i][k], acc[i][k]);
+            }
+    }
+    for (; e < cnt; ++e) {
+        const float* row = base + (long long)s_idx[e] * ld;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int j = j0 + l + 64 * i;
+            const int jc = (j < j1) ? j : j0;
+            float v[VEC];
+            vload<VEC>(row + (long long)jc * VEC, v);
+            const float a = s_w[hidx[i] * 64 + e];
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) acc[i][k] = fmaf(a, v[k], acc[i][k]);
+        }
+    }
+}
+
 }  // namespace txe

@@ -245,10 +245,14 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_kernel(VMat A, VMat B, c
 
     const int nbn = (N + BN - 1) / BN;
     const int ntiles = gridDim.x;
-    const int lb = xcd_remap(blockIdx.x, ntiles);   // XCD-contiguous tile order: row panels stay in one L2
+    // XCD-contiguous order over (k-slice, tile): workgroup b runs on XCD b % 8; after the remap each XCD owns one
+    // contiguous range of (slice, row panel, column) triples, so a k-slice of both operands (split-K) / a row panel of A
+    // and all of B (no split) is pulled into ONE L2 instead of all eight.
+    const int vb = xcd_remap(blockIdx.x + ntiles * blockIdx.y, ntiles * gridDim.y);
+    const int zslice = vb / ntiles, lb = vb % ntiles;
     const int tm = lb / nbn, tn = lb % nbn;
     const int m0 = tm * GEMM_BM, n0 = tn * BN;
-    const int kbeg = blockIdx.y * ksplit;
+    const int kbeg = zslice * ksplit;
     const int kend = min(K, kbeg + ksplit);
 
     // clip the reduction range into the operands' own bounds (split-K and K tails read zeros)
@@ -331,7 +335,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_kernel(VMat A, VMat B, c
     // epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
     // Extras (mask word, activation source) are fetched for all 16 rows of a sub-tile with clamped, unconditional
     // loads first, then applied -- no load sits under a branch.
-    float* cbase = E.c + (long long)blockIdx.y * E.split_stride;
+    float* cbase = E.c + (long long)zslice * E.split_stride;
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
 #pragma unroll

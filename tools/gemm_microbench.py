@@ -24,6 +24,15 @@ def bench(fn, flops, n=10):
     return dt * 1e6, flops / dt / 1e12
 
 
+def plain(layout, A, B, M, N, K, splits=1):
+    from taxoexpan_amd import _lib
+    C = torch.empty((splits, M, N), device=dev)
+    def f():
+        _lib.call("txe_gemm_plain", layout, A.data_ptr(), A.stride(0), B.data_ptr(), B.stride(0), C.data_ptr(), N, M, N, K, splits,
+                  _lib.stream_ptr())
+    return f
+
+
 for (M, N, K) in [(4096, 4096, 4096), (8192, 8192, 1024), (16384, 2048, 2048), (18000, 2008, 300), (18000, 508, 2050), (18000, 2050, 508)]:
     A = torch.randn(M, K, device=dev)
     B = torch.randn(K, N, device=dev)
@@ -31,4 +40,12 @@ for (M, N, K) in [(4096, 4096, 4096), (8192, 8192, 1024), (16384, 2048, 2048), (
     us, tf = bench(lambda: ops.bilinear_project(A, B.unsqueeze(0)), 2.0 * M * N * K)
     us2, tf2 = bench(lambda: ops.score_block(A, Bt, False), 2.0 * M * N * K)
     us3, tf3 = bench(lambda: torch.mm(A, B), 2.0 * M * N * K)
-    print(f"M={M} N={N} K={K}: NN {us:.0f}us {tf:.1f}TF | NT {us2:.0f}us {tf2:.1f}TF | torch.mm {us3:.0f}us {tf3:.1f}TF")
+    At = A.t().contiguous()
+    us4, tf4 = bench(plain(2, At, B, M, N, K), 2.0 * M * N * K)
+    print(f"M={M} N={N} K={K}: NN {us:.0f}us {tf:.1f}TF | NT {us2:.0f}us {tf2:.1f}TF | TN {us4:.0f}us {tf4:.1f}TF | torch.mm {us3:.0f}us {tf3:.1f}TF")
+for (M, N, K, S) in [(508, 2050, 18000, 15), (2008, 300, 18000, 21), (512, 2048, 16384, 15)]:
+    A = torch.randn(K, M, device=dev)
+    B = torch.randn(K, N, device=dev)
+    us, tf = bench(plain(2, A, B, M, N, K, S), 2.0 * M * N * K)
+    us3, tf3 = bench(lambda: torch.mm(A.t(), B), 2.0 * M * N * K)
+    print(f"TN split-K M={M} N={N} K={K} S={S}: {us:.0f}us {tf:.1f}TF | torch.mm(A.t(),B) {us3:.0f}us {tf3:.1f}TF")

@@ -201,6 +201,83 @@ __device__ __forceinline__ void stage_finish(const VMat& M, int row0, int k0, fl
     }
 }
 
+// ---- plain-tile fast path with HOISTED addressing -------------------------------------------------------------------
+// PMC on the 4096^3 product showed 278 VALU instructions per k-tile per wave -- mostly 64-bit address arithmetic, clamps
+// and selects -- sitting between the MFMA blocks of both co-resident waves at the same time (~27 % idle matrix pipe).
+// For a workgroup whose 128 (64) rows are all valid and from one source array, and for k-tiles inside the plain range, the
+// address of pass p of a thread is  base + p * pass_stride,  and base moves by a uniform stride per tile: one 64-bit
+// pointer per operand lives in registers, no clamps, no selects, and nothing to do in the finish phase unless the
+// operand carries a dropout mask.
+template <bool KC, int ROWS>
+__device__ __forceinline__ bool block_is_plain(const VMat& M, int row0) {
+    if constexpr (KC) {       // rows = the GEMM's m/n range of this workgroup: all valid, all from p or all from p3
+        return (row0 + ROWS <= M.rows) && ((row0 + ROWS <= M.rows_main) || (row0 >= M.rows_main));
+    } else {                  // columns = the m/n range: all inside the plain column range
+        return row0 + ROWS <= M.cols_main;
+    }
+}
+
+template <bool KC, int V, int ROWS> struct FastPtr {
+    const float* base;         // address of pass 0 for the current tile
+    const unsigned* mbase;     // mask word of pass 0 for the current tile (only meaningful when mask_on)
+    long long pstride, adv;    // elements between passes / per k-tile (block-uniform)
+    long long mpstride, madv;  // mask words between passes / per k-tile
+};
+
+template <bool KC, int V, int ROWS>
+__device__ __forceinline__ void fast_init(const VMat& M, int row0, int kbeg, FastPtr<KC, V, ROWS>& f) {
+    using G = StageGeom<KC, V, ROWS>;
+    int r, c;
+    stage_coord<KC, V, ROWS>(row0, kbeg, 0, r, c);
+    const int rr = (r < M.rows) ? r : 0;                 // only dereferenced when the block/tile is plain (then r is valid)
+    const float* row = (rr < M.rows_main) ? (M.p + (long long)rr * M.ld) : (M.p3 + (long long)(rr - M.rows_main) * M.ld3);
+    const long long ld = (rr < M.rows_main) ? M.ld : M.ld3;
+    f.base = row + c;
+    f.pstride = (long long)G::LPP * ld;
+    f.adv = KC ? (long long)GEMM_BK : (long long)GEMM_BK * ld;
+    f.mbase = M.mask + (long long)rr * M.mask_ld + (c >> 5);
+    f.mpstride = (long long)G::LPP * M.mask_ld;
+    f.madv = KC ? 1 : (long long)GEMM_BK * M.mask_ld;
+}
+
+template <bool KC, int V, int ROWS>
+__device__ __forceinline__ void fast_issue(const VMat& M, FastPtr<KC, V, ROWS>& f, float* regs, unsigned* mws) {
+    using G = StageGeom<KC, V, ROWS>;
+#pragma unroll
+    for (int p = 0; p < G::PASSES; ++p) {
+        const float* a = f.base + p * f.pstride;
+        float* v = regs + p * V;
+        if constexpr (V == 4) {
+            const float4 t = *reinterpret_cast<const float4*>(a);
+            v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+        } else if constexpr (V == 2) {
+            const float2 t = *reinterpret_cast<const float2*>(a);
+            v[0] = t.x; v[1] = t.y;
+        } else {
+            v[0] = *a;
+        }
+    }
+    f.base += f.adv;
+    if (M.mask_on) {                                    // block-uniform; only dropout operands pay the extra word loads
+#pragma unroll
+        for (int p = 0; p < G::PASSES; ++p) mws[p] = f.mbase[p * f.mpstride];
+        f.mbase += f.madv;
+    }
+}
+
+template <bool KC, int V, int ROWS>
+__device__ __forceinline__ void fast_finish(const VMat& M, float* regs, const unsigned* mws) {
+    using G = StageGeom<KC, V, ROWS>;
+    if (M.mask_on) {
+        const int bit0 = ((threadIdx.x % G::VPR) * V) & 31;      // column of element 0 inside its mask word (tile starts are x32)
+#pragma unroll
+        for (int p = 0; p < G::PASSES; ++p)
+#pragma unroll
+            for (int e = 0; e < V; ++e)
+                regs[p * V + e] = ((mws[p] >> (bit0 + e)) & 1u) ? regs[p * V + e] * M.drop_scale : 0.f;
+    }
+}
+
 template <bool KC, int V, int ROWS>
 __device__ __forceinline__ void stage_store(float* lds, const float* regs) {
     using G = StageGeom<KC, V, ROWS>;
@@ -278,12 +355,17 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_kernel(VMat A, VMat B, c
     const int nk = (kend - kbeg + GEMM_BK - 1) / GEMM_BK;
     // leading k-tiles that are plain for BOTH operands.  The pipelined loop is split by the kind of the tile being
     // ISSUED (fast prefix, then generic tail) so that no branch sits between a load and its first use.
-    int nkf;
-    {
-        const int fa_ = AK ? max(0, (A.cols_main - kbeg) / GEMM_BK) : ((m0 + GEMM_BM <= A.cols_main) ? nk : 0);
-        const int fb_ = BKC ? max(0, (B.cols_main - kbeg) / GEMM_BK) : ((n0 + BN <= B.cols_main) ? nk : 0);
+    int nkf = 0;
+    if (block_is_plain<AK, GEMM_BM>(A, m0) && block_is_plain<BKC, BN>(B, n0)) {
+        const int full = (kend - kbeg) / GEMM_BK;     // complete k-tiles (a ragged last tile takes the generic path)
+        const int fa_ = AK ? max(0, (A.cols_main - kbeg) / GEMM_BK) : min(full, max(0, (min(A.rows, A.rows_main) - kbeg) / GEMM_BK));
+        const int fb_ = BKC ? max(0, (B.cols_main - kbeg) / GEMM_BK) : min(full, max(0, (min(B.rows, B.rows_main) - kbeg) / GEMM_BK));
         nkf = min(nk, min(fa_, fb_));
     }
+    FastPtr<AK, VA, GEMM_BM> fpa;
+    FastPtr<BKC, VB, BN> fpb;
+    fast_init<AK, VA, GEMM_BM>(A, m0, kbeg, fpa);
+    fast_init<BKC, VB, BN>(B, n0, kbeg, fpb);
 
 #define TXE_COMPUTE_TILE(cur_)                                                                                       \
     {                                                                                                                \
@@ -300,35 +382,48 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_kernel(VMat A, VMat B, c
         }                                                                                                            \
     }
 #define TXE_NOTHING
-#define TXE_STAGE(FAST_, k0_, buf_, COMPUTE_)                                                                        \
+#define TXE_STAGE_GENERIC(k0_, buf_, COMPUTE_)                                                                       \
     {                                                                                                                \
-        stage_issue<AK, VA, GEMM_BM, FAST_>(A, m0, (k0_), ra, ma);                                                   \
-        stage_issue<BKC, VB, BN, FAST_>(B, n0, (k0_), rb, mb);                                                       \
+        stage_issue<AK, VA, GEMM_BM, false>(A, m0, (k0_), ra, ma);                                                   \
+        stage_issue<BKC, VB, BN, false>(B, n0, (k0_), rb, mb);                                                       \
         __builtin_amdgcn_sched_barrier(0); /* loads first: the whole MFMA block then covers their latency */        \
         COMPUTE_                                                                                                     \
         __builtin_amdgcn_sched_barrier(0);                                                                           \
-        stage_finish<AK, VA, GEMM_BM, FAST_>(A, m0, (k0_), ra, ma);                                                  \
-        stage_finish<BKC, VB, BN, FAST_>(B, n0, (k0_), rb, mb);                                                      \
+        stage_finish<AK, VA, GEMM_BM, false>(A, m0, (k0_), ra, ma);                                                  \
+        stage_finish<BKC, VB, BN, false>(B, n0, (k0_), rb, mb);                                                      \
+        stage_store<AK, VA, GEMM_BM>(As + (buf_) * ASZ, ra);                                                         \
+        stage_store<BKC, VB, BN>(Bs + (buf_) * BSZ, rb);                                                             \
+    }
+#define TXE_STAGE_FAST(k0_, buf_, COMPUTE_)                                                                          \
+    {                                                                                                                \
+        fast_issue<AK, VA, GEMM_BM>(A, fpa, ra, ma);                                                                 \
+        fast_issue<BKC, VB, BN>(B, fpb, rb, mb);                                                                     \
+        __builtin_amdgcn_sched_barrier(0);                                                                           \
+        COMPUTE_                                                                                                     \
+        __builtin_amdgcn_sched_barrier(0);                                                                           \
+        fast_finish<AK, VA, GEMM_BM>(A, ra, ma);                                                                     \
+        fast_finish<BKC, VB, BN>(B, rb, mb);                                                                         \
         stage_store<AK, VA, GEMM_BM>(As + (buf_) * ASZ, ra);                                                         \
         stage_store<BKC, VB, BN>(Bs + (buf_) * BSZ, rb);                                                             \
     }
 
     if (nk > 0) {
-        if (nkf > 0) TXE_STAGE(true, kbeg, 0, TXE_NOTHING)
-        else TXE_STAGE(false, kbeg, 0, TXE_NOTHING)
+        if (nkf > 0) TXE_STAGE_FAST(kbeg, 0, TXE_NOTHING)
+        else TXE_STAGE_GENERIC(kbeg, 0, TXE_NOTHING)
     }
     __syncthreads();
     int t = 1;
     for (; t < nkf; ++t) {                      // tile t (plain) is fetched while tile t-1 is multiplied
-        TXE_STAGE(true, kbeg + t * GEMM_BK, t & 1, TXE_COMPUTE_TILE((t - 1) & 1))
+        TXE_STAGE_FAST(kbeg + t * GEMM_BK, t & 1, TXE_COMPUTE_TILE((t - 1) & 1))
         __syncthreads();
     }
     for (; t < nk; ++t) {                       // generic tiles (extension columns / ragged edges)
-        TXE_STAGE(false, kbeg + t * GEMM_BK, t & 1, TXE_COMPUTE_TILE((t - 1) & 1))
+        TXE_STAGE_GENERIC(kbeg + t * GEMM_BK, t & 1, TXE_COMPUTE_TILE((t - 1) & 1))
         __syncthreads();
     }
     if (nk > 0) TXE_COMPUTE_TILE((nk - 1) & 1)
-#undef TXE_STAGE
+#undef TXE_STAGE_FAST
+#undef TXE_STAGE_GENERIC
 #undef TXE_NOTHING
 #undef TXE_COMPUTE_TILE
 
@@ -400,7 +495,7 @@ static inline int choose_bn(int M, int N, int splits) {
     auto cost = [&](int bn) {
         const long long blocks = (long long)((M + GEMM_BM - 1) / GEMM_BM) * ((N + bn - 1) / bn) * splits;
         const long long rounds = (blocks + slots - 1) / slots;
-        return (double)rounds * bn * (bn == 64 ? 1.25 : 1.0);     // narrower tile: measured ~20% less efficient per flop
+        return (double)rounds * bn * (bn == 64 ? 1.6 : 1.0);     // the narrow tile is markedly less efficient per flop (measured)
     };
     return cost(64) < cost(128) ? 64 : 128;
 }

@@ -38,8 +38,10 @@ int txe_dropout_mask(long long n_rows, int n_cols, float p, unsigned long long s
 
 /* ---- GATLayer dense part: model_zoo.py:82-85 (feat_drop, fc, a1, a2) with the PGAT concat of :214-215 -------------
  * h [N][Kh] (row stride ld_h), pos [N] in [0,vocab), P [vocab][Pd] (Pd = 0 -> plain GAT, :186), W [H*D][Kh+Pd],
- * attn_l/attn_r [H*D].  Writes ft [N][H*D] and a_ext [N][2H] = [a1 | a2].  ws >= 2H*(Kh+Pd) floats. */
-size_t txe_gat_project_ws_bytes(int n_nodes, int Kh, int Pd, int H, int D, int vocab);
+ * attn_l/attn_r [H*D].  Writes ft [N][H*D] and a_ext [N][2H] = [a1 | a2].  ws: txe_gat_project_fwd_ws_bytes (minimum
+ * 2H*(Kh+Pd) floats; the rest lets the GEMM split the leftover tiles of its last, partial round of workgroups). */
+size_t txe_gat_project_ws_bytes(int n_nodes, int Kh, int Pd, int H, int D, int vocab);   /* backward */
+size_t txe_gat_project_fwd_ws_bytes(int Kh, int Pd, int H);                                 /* forward  */
 int txe_gat_project_fwd(const float* h, long long ld_h, int n_nodes, int Kh, const int* pos, const float* P, int Pd,
                         const float* W, const float* attn_l, const float* attn_r, int H, int D, float feat_drop_p,
                         const unsigned* mask, float* ft, float* a_ext, void* ws, size_t ws_bytes, void* stream);
@@ -109,9 +111,11 @@ int txe_score_block(const float* Q, long long ld_q, int nq, const float* U, int 
                     long long ld_s, void* stream);
 
 /* plain dense product on the fp32 MFMA GEMM (tests / micro-benchmarks).  layout 0: C = A[M][K] B[N][K]^T; 1: C = A[M][K] B[K][N];
- * 2: C = A[K][M]^T B[K][N].  splits > 1: `splits` partial products at C + z*M*ldc. */
+ * 2: C = A[K][M]^T B[K][N].  splits > 1: `splits` partial products at C + z*M*ldc.  ws/ws_bytes (optional, txe_gemm_tail_ws_bytes):
+ * scratch that lets the last, partial round of workgroups be split along k ("tail splitting"). */
+size_t txe_gemm_tail_ws_bytes(void);
 int txe_gemm_plain(int layout, const float* A, long long lda, const float* B, long long ldb, float* C, long long ldc, int M, int N,
-                   int K, int splits, void* stream);
+                   int K, int splits, void* ws, size_t ws_bytes, void* stream);
 
 /* ---- rank extraction of the scoring loop: test_fast.py:16-22 + model/metric.py:7-31 (strict inequalities, the
  * query's other positives excluded).  pos_off [nq+1], pos_idx: candidate columns of each query's true parents. */

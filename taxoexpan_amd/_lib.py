@@ -13,6 +13,7 @@ SIGNATURES = {
     "txe_dropout_mask_bytes": (SZ, [L, I]),
     "txe_dropout_mask": (I, [L, I, F, U64, P, P]),
     "txe_gat_project_ws_bytes": (SZ, [I, I, I, I, I, I]),
+    "txe_gat_project_fwd_ws_bytes": (SZ, [I, I, I]),
     "txe_gat_project_fwd": (I, [P, L, I, I, P, P, I, P, P, P, I, I, F, P, P, P, P, SZ, P]),
     "txe_gat_project_bwd": (I, [P, L, I, I, P, P, I, I, P, P, P, I, I, F, P, P, P, P, L, P, L, F, P, P, P, P, P, SZ, P]),
     "txe_gat_aggregate_fwd": (I, [P, P, I, P, L, P, P, I, I, I, F, F, U64, I, F, P, L, P, P]),
@@ -34,7 +35,8 @@ SIGNATURES = {
     "txe_bilinear_pair_bwd_ws_bytes": (SZ, [I, I, I]),
     "txe_bilinear_pair_bwd": (I, [P, L, P, L, I, I, I, P, I, P, P, P, P, L, P, L, P, P, SZ, P]),
     "txe_score_block": (I, [P, L, I, P, I, I, I, P, L, P]),
-    "txe_gemm_plain": (I, [I, P, L, P, L, P, L, I, I, I, I, P]),
+    "txe_gemm_tail_ws_bytes": (SZ, []),
+    "txe_gemm_plain": (I, [I, P, L, P, L, P, L, I, I, I, I, P, SZ, P]),
     "txe_build_csr_ws_bytes": (SZ, [I, I]),
     "txe_build_csr": (I, [P, P, I, I, P, P, P, P, P, P, P, SZ, P]),
     "txe_rank_block": (I, [P, L, I, I, P, P, P, I, P, P]),

@@ -308,9 +308,51 @@ __device__ __forceinline__ void frag_load(const float* lds, int r0, int kb, floa
     }
 }
 
+// ---- tail splitting ----------------------------------------------------------------------------------------------------
+// With T output tiles and `slots` co-resident workgroups (2 per CU), T = q*slots + r leaves a last round of only r
+// workgroups (MAG layer-1 forward: 564 tiles on 512 slots -> the second round runs at 10 % occupancy and doubles the
+// kernel time).  The first q*slots workgroups compute whole tiles; each of the r leftover tiles is cut into S = slots/r
+// k-slices that all run concurrently in the last round and park raw partial tiles in a workspace; a tiny fix-up kernel
+// adds the S slices in fixed order (deterministic) and applies the real epilogue.
+struct Tail {
+    int nfull;       // workgroups [0, nfull) own whole tiles; S == 0 -> no tail splitting
+    int S;           // k-slices per leftover tile
+    int ksplit;      // k-range of one slice (multiple of BK)
+    float* ws;       // [r*S][GEMM_BM*BN] raw partial tiles
+};
+
+__device__ __forceinline__ void epi_store_one(const Epi& E, int m, int n, float acc, float* cbase) {
+    const bool main_col = n < E.cols_main;
+    const int cm = n + E.mask_col0;
+    const unsigned wd = E.mask[E.mask_on ? ((long long)m * E.mask_ld + (cm >> 5)) : 0];
+    const float av = E.act_src[((E.act_on != 0) & main_col) ? ((long long)m * E.ld_act + n) : 0];
+    const unsigned keep = ((wd >> (cm & 31)) & 1u) | (E.mask_on ? 0u : 1u);
+    float g = keep ? E.drop_scale : 0.f;
+    g *= ((E.act_on != 0) & main_col & !(av > 0.f)) ? E.act_slope : 1.f;
+    const float x = acc * g;
+    const float val = E.apply_exp ? __expf(x) : x;
+    if (main_col) cbase[(long long)m * E.ldc + n] = val;
+    else E.c2[(long long)m * E.ldc2 + (n - E.cols_main)] = val;
+}
+
+template <int BN>
+__global__ __launch_bounds__(256) void gemm_tail_fixup_kernel(const Epi E, const Tail T, const int M, const int N) {
+    const int nbn = (N + BN - 1) / BN;
+    const int tile = T.nfull + blockIdx.x;
+    const int m0 = (tile / nbn) * GEMM_BM, n0 = (tile % nbn) * BN;
+    const float* part = T.ws + (long long)blockIdx.x * T.S * (GEMM_BM * BN);
+    constexpr int CH = GEMM_BM * BN / 16;            // 16 workgroups per leftover tile (blockIdx.y)
+    for (int idx = blockIdx.y * CH + threadIdx.x; idx < (blockIdx.y + 1) * CH; idx += 256) {
+        const int m = m0 + idx / BN, n = n0 + idx % BN;
+        float acc = 0.f;
+        for (int z = 0; z < T.S; ++z) acc += part[(long long)z * (GEMM_BM * BN) + idx];
+        if (m < M && n < N) epi_store_one(E, m, n, acc, E.c);
+    }
+}
+
 template <bool AK, bool BKC, int VA, int VB, int BN>
 __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_kernel(VMat A, VMat B, const Epi E, const int M, const int N,
-                                                                const int K, const int ksplit) {
+                                                                const int K, const int ksplit, const Tail T) {
     using GA = StageGeom<AK, VA, GEMM_BM>;
     using GB = StageGeom<BKC, VB, BN>;
     constexpr int ASZ = GA::LDS, BSZ = GB::LDS;
@@ -321,16 +363,30 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_kernel(VMat A, VMat B, c
     float* Bs = smem + 2 * ASZ;
 
     const int nbn = (N + BN - 1) / BN;
-    const int ntiles = gridDim.x;
     // XCD-contiguous order over (k-slice, tile): workgroup b runs on XCD b % 8; after the remap each XCD owns one
     // contiguous range of (slice, row panel, column) triples, so a k-slice of both operands (split-K) / a row panel of A
     // and all of B (no split) is pulled into ONE L2 instead of all eight.
-    const int vb = xcd_remap(blockIdx.x + ntiles * blockIdx.y, ntiles * gridDim.y);
-    const int zslice = vb / ntiles, lb = vb % ntiles;
+    int zslice, lb, kbeg, kend, tail_slot = -1;
+    if (T.S > 0) {                                   // tail splitting (never combined with regular split-K)
+        const int bid = blockIdx.x;
+        if (bid < T.nfull) {
+            lb = xcd_remap(bid, T.nfull); zslice = 0; kbeg = 0; kend = K;
+        } else {
+            tail_slot = bid - T.nfull;
+            lb = T.nfull + tail_slot / T.S;
+            zslice = 0;
+            kbeg = (tail_slot % T.S) * T.ksplit;
+            kend = min(K, kbeg + T.ksplit);
+        }
+    } else {
+        const int ntiles = gridDim.x;
+        const int vb = xcd_remap(blockIdx.x + ntiles * blockIdx.y, ntiles * gridDim.y);
+        zslice = vb / ntiles; lb = vb % ntiles;
+        kbeg = zslice * ksplit;
+        kend = min(K, kbeg + ksplit);
+    }
     const int tm = lb / nbn, tn = lb % nbn;
     const int m0 = tm * GEMM_BM, n0 = tn * BN;
-    const int kbeg = zslice * ksplit;
-    const int kend = min(K, kbeg + ksplit);
 
     // clip the reduction range into the operands' own bounds (split-K and K tails read zeros)
     if (AK) { A.cols = min(A.cols, kend); A.cols_main = min(A.cols_main, kend); }
@@ -430,6 +486,19 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_kernel(VMat A, VMat B, c
     // epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
     // Extras (mask word, activation source) are fetched for all 16 rows of a sub-tile with clamped, unconditional
     // loads first, then applied -- no load sits under a branch.
+    if (tail_slot >= 0) {                            // leftover-tile slice: park the raw partial tile, fix-up kernel finishes
+        float* part = T.ws + (long long)tail_slot * (GEMM_BM * BN);
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int row = wm0 + i * 32 + 4 * (l >> 5) + (e & 3) + 8 * (e >> 2);
+                    part[row * BN + wn0 + j * 32 + (l & 31)] = acc[i][j][e];
+                }
+        return;
+    }
     float* cbase = E.c + (long long)zslice * E.split_stride;
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
@@ -502,7 +571,7 @@ static inline int choose_bn(int M, int N, int splits) {
 
 template <bool AK, bool BKC, int VA, int VB>
 static inline void gemm_launch_v(int bn, dim3 grid, hipStream_t stream, const VMat& A, const VMat& B, const Epi& E, int M, int N,
-                                 int K, int ksplit) {
+                                 int K, int ksplit, const Tail& T) {
     // profiler record named exactly like rocprofv3 prints the kernel (minus "void txe::"), so that bench.py can join its
     // HIP-event timings with the committed rocprof summaries under profiles/
     char* name = nullptr;
@@ -516,16 +585,19 @@ static inline void gemm_launch_v(int bn, dim3 grid, hipStream_t stream, const VM
     }
     name = names[bn == 128 ? 0 : 1];
     ProfScope prof(name, stream, 2.0 * M * (double)N * K, 0);
-    if (bn == 128) hipLaunchKernelGGL((gemm_kernel<AK, BKC, VA, VB, 128>), grid, dim3(GEMM_THREADS), 0, stream, A, B, E, M, N, K, ksplit);
-    else hipLaunchKernelGGL((gemm_kernel<AK, BKC, VA, VB, 64>), grid, dim3(GEMM_THREADS), 0, stream, A, B, E, M, N, K, ksplit);
+    if (bn == 128) hipLaunchKernelGGL((gemm_kernel<AK, BKC, VA, VB, 128>), grid, dim3(GEMM_THREADS), 0, stream, A, B, E, M, N, K, ksplit, T);
+    else hipLaunchKernelGGL((gemm_kernel<AK, BKC, VA, VB, 64>), grid, dim3(GEMM_THREADS), 0, stream, A, B, E, M, N, K, ksplit, T);
 }
 
 // Launch C = A*B.  splits > 1 => split-K over gridDim.y, block z stores at E.c + z*E.split_stride.
 // Vector widths: 16-byte loads for an operand whose rows are 16-byte aligned, else 8-byte; a 4-byte-only operand
 // drops both to scalar loads (odd leading dimensions: correctness path, not a fast one).
+// bytes of tail-splitting workspace that always suffice (r*S <= slots partial tiles of 128x128 floats)
+static inline size_t gemm_tail_ws_bytes() { return (size_t)2 * device_cu_count() * GEMM_BM * 128 * sizeof(float); }
+
 template <bool AK, bool BKC>
 static inline int gemm_launch_layout(const VMat& A, const VMat& B, const Epi& E_in, int M, int N, int K, int splits,
-                                     hipStream_t stream) {
+                                     hipStream_t stream, void* tail_ws = nullptr, size_t tail_ws_bytes = 0) {
     if (M <= 0 || N <= 0) return TXE_OK;
     Epi E = E_in;
     {   // the epilogue loads its extras unconditionally: give the unused ones a readable dummy address
@@ -542,12 +614,34 @@ static inline int gemm_launch_layout(const VMat& A, const VMat& B, const Epi& E_
     ksplit = ((ksplit + GEMM_BK - 1) / GEMM_BK) * GEMM_BK;
     if (ksplit == 0) ksplit = GEMM_BK;
     dim3 grid(nbm * nbn, splits);
-    if (va == 4 && vb == 4) gemm_launch_v<AK, BKC, 4, 4>(bn, grid, stream, A, B, E, M, N, K, ksplit);
-    else if (va == 4 && vb == 2) gemm_launch_v<AK, BKC, 4, 2>(bn, grid, stream, A, B, E, M, N, K, ksplit);
-    else if (va == 2 && vb == 4) gemm_launch_v<AK, BKC, 2, 4>(bn, grid, stream, A, B, E, M, N, K, ksplit);
-    else if (va == 2 && vb == 2) gemm_launch_v<AK, BKC, 2, 2>(bn, grid, stream, A, B, E, M, N, K, ksplit);
-    else gemm_launch_v<AK, BKC, 1, 1>(bn, grid, stream, A, B, E, M, N, K, ksplit);
+    Tail T;
+    T.nfull = 0; T.S = 0; T.ksplit = 0; T.ws = (float*)tail_ws;
+    if (splits == 1 && tail_ws != nullptr) {
+        const int slots = 2 * device_cu_count();
+        const int tiles = nbm * nbn, r = tiles % slots;
+        const int nkt = (K + GEMM_BK - 1) / GEMM_BK;
+        int S = (r > 0) ? slots / r : 0;
+        if (S > nkt / 4) S = nkt / 4;                 // >= 4 k-tiles per slice
+        if (S > 16) S = 16;
+        if (S >= 2 && (size_t)r * S * GEMM_BM * bn * sizeof(float) <= tail_ws_bytes) {
+            T.nfull = tiles - r; T.S = S;
+            T.ksplit = ((nkt + S - 1) / S) * GEMM_BK;
+            grid = dim3(T.nfull + r * S, 1);
+        }
+    }
+    if (va == 4 && vb == 4) gemm_launch_v<AK, BKC, 4, 4>(bn, grid, stream, A, B, E, M, N, K, ksplit, T);
+    else if (va == 4 && vb == 2) gemm_launch_v<AK, BKC, 4, 2>(bn, grid, stream, A, B, E, M, N, K, ksplit, T);
+    else if (va == 2 && vb == 4) gemm_launch_v<AK, BKC, 2, 4>(bn, grid, stream, A, B, E, M, N, K, ksplit, T);
+    else if (va == 2 && vb == 2) gemm_launch_v<AK, BKC, 2, 2>(bn, grid, stream, A, B, E, M, N, K, ksplit, T);
+    else gemm_launch_v<AK, BKC, 1, 1>(bn, grid, stream, A, B, E, M, N, K, ksplit, T);
     TXE_CHECK_LAUNCH();
+    if (T.S > 0) {
+        const int r = nbm * nbn - T.nfull;
+        ProfScope prof("gemm_tail_fixup_kernel", stream, 0.0, 0);
+        if (bn == 128) hipLaunchKernelGGL((gemm_tail_fixup_kernel<128>), dim3(r, 16), dim3(256), 0, stream, E, T, M, N);
+        else hipLaunchKernelGGL((gemm_tail_fixup_kernel<64>), dim3(r, 16), dim3(256), 0, stream, E, T, M, N);
+        TXE_CHECK_LAUNCH();
+    }
     return TXE_OK;
 }
 
@@ -569,8 +663,9 @@ static inline int choose_splits(int M, int N, int K) {
 }
 
 // each defined in its own translation unit (txe_gemm_nt.hip / _nn / _tn) so that the 30 kernel variants compile in parallel
-int gemm_nt(const VMat& A, const VMat& B, const Epi& E, int M, int N, int K, int splits, hipStream_t s);  // A[m][k], B[n][k]
-int gemm_nn(const VMat& A, const VMat& B, const Epi& E, int M, int N, int K, int splits, hipStream_t s);  // A[m][k], B[k][n]
-int gemm_tn(const VMat& A, const VMat& B, const Epi& E, int M, int N, int K, int splits, hipStream_t s);  // A[k][m], B[k][n]
+// tail_ws (optional, >= gemm_tail_ws_bytes()) enables tail splitting when splits == 1.
+int gemm_nt(const VMat& A, const VMat& B, const Epi& E, int M, int N, int K, int splits, hipStream_t s, void* tail_ws = nullptr, size_t tail_ws_bytes = 0);  // A[m][k], B[n][k]
+int gemm_nn(const VMat& A, const VMat& B, const Epi& E, int M, int N, int K, int splits, hipStream_t s, void* tail_ws = nullptr, size_t tail_ws_bytes = 0);  // A[m][k], B[k][n]
+int gemm_tn(const VMat& A, const VMat& B, const Epi& E, int M, int N, int K, int splits, hipStream_t s, void* tail_ws = nullptr, size_t tail_ws_bytes = 0);  // A[k][m], B[k][n]
 
 }  // namespace txe

@@ -3,8 +3,8 @@
 
 namespace txe {
 
-int gemm_nn(const VMat& A, const VMat& B, const Epi& E, int M, int N, int K, int splits, hipStream_t s) {
-    return gemm_launch_layout<true, false>(A, B, E, M, N, K, splits, s);
+int gemm_nn(const VMat& A, const VMat& B, const Epi& E, int M, int N, int K, int splits, hipStream_t s, void* tail_ws, size_t tail_ws_bytes) {
+    return gemm_launch_layout<true, false>(A, B, E, M, N, K, splits, s, tail_ws, tail_ws_bytes);
 }
 
 }  // namespace txe

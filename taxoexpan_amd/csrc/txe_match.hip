@@ -142,15 +142,17 @@ int txe_bilinear_pair_bwd(const float* e1, long long ld_e1, const float* e2, lon
 // Plain dense product on the library's fp32 MFMA GEMM (tests / micro-benchmarks; the model paths above use the same kernels
 // through their fused entry points).  layout 0: C = A[M][K] * B[N][K]^T;  1: C = A[M][K] * B[K][N];  2: C = A[K][M]^T * B[K][N].
 // splits > 1 writes `splits` partial products at C + z*M*N (the caller reduces them).
+size_t txe_gemm_tail_ws_bytes(void) { return gemm_tail_ws_bytes(); }
+
 int txe_gemm_plain(int layout, const float* A, long long lda, const float* B, long long ldb, float* C, long long ldc, int M, int N,
-                   int K, int splits, void* stream) {
+                   int K, int splits, void* ws, size_t ws_bytes, void* stream) {
     if (layout < 0 || layout > 2 || M < 0 || N < 0 || K < 0 || !A || !B || !C) return TXE_ERR_ARG;
     Epi E = epi_plain(C, ldc, N);
     if (splits > 1) E.split_stride = (long long)M * ldc;
     hipStream_t s = (hipStream_t)stream;
-    if (layout == 0) return gemm_nt(vmat_plain(A, lda, M, K), vmat_plain(B, ldb, N, K), E, M, N, K, splits, s);
-    if (layout == 1) return gemm_nn(vmat_plain(A, lda, M, K), vmat_plain(B, ldb, K, N), E, M, N, K, splits, s);
-    return gemm_tn(vmat_plain(A, lda, K, M), vmat_plain(B, ldb, K, N), E, M, N, K, splits, s);
+    if (layout == 0) return gemm_nt(vmat_plain(A, lda, M, K), vmat_plain(B, ldb, N, K), E, M, N, K, splits, s, ws, ws_bytes);
+    if (layout == 1) return gemm_nn(vmat_plain(A, lda, M, K), vmat_plain(B, ldb, K, N), E, M, N, K, splits, s, ws, ws_bytes);
+    return gemm_tn(vmat_plain(A, lda, K, M), vmat_plain(B, ldb, K, N), E, M, N, K, splits, s, ws, ws_bytes);
 }
 
 // One block of the scoring loop: S[q][g] = <Q[q], U[g]> (exp optionally), q < nq, g < G.  S row stride ld_s.

@@ -166,6 +166,8 @@ struct ProjectWs {
     float* dxp;     // [N][Pd]
     float* ppart;   // [nb][vocab][Pd]
     float* part;    // [S][(F+2H)][Kt]
+    void* tail;     // GEMM tail-splitting workspace
+    size_t tail_bytes;
     int splits, seg_blocks, seg_rows;
     size_t total;
 };
@@ -184,6 +186,8 @@ static ProjectWs plan_ws(void* ws, int n, int F, int H2, int Kt, int Pd, int voc
     p.ppart = take((size_t)p.seg_blocks * (vocab > 0 ? vocab : 1) * (Pd > 0 ? Pd : 1) * 4);
     p.splits = choose_splits(F + H2, Kt, n);
     p.part = take((size_t)p.splits * (F + H2) * Kt * 4);
+    p.tail_bytes = gemm_tail_ws_bytes();
+    p.tail = take(p.tail_bytes);
     p.total = off;
     return p;
 }
@@ -209,6 +213,12 @@ int txe_dropout_mask(long long n_rows, int n_cols, float p, unsigned long long s
     return TXE_OK;
 }
 
+// forward workspace: the folded attention rows wa [2H][Kh+Pd] (+ the GEMM tail-splitting scratch, optional: with less than
+// this the projection still runs, without tail splitting)
+size_t txe_gat_project_fwd_ws_bytes(int Kh, int Pd, int H) {
+    return align_up((size_t)2 * H * (Kh + Pd) * 4, 256) + gemm_tail_ws_bytes();
+}
+
 size_t txe_gat_project_ws_bytes(int n_nodes, int Kh, int Pd, int H, int D, int vocab) {
     return plan_ws(nullptr, n_nodes, H * D, 2 * H, Kh + Pd, Pd, vocab).total;
 }
@@ -232,7 +242,9 @@ int txe_gat_project_fwd(const float* h, long long ld_h, int n_nodes, int Kh, con
     B.rows_main = F; B.p3 = wa; B.ld3 = Kt;
     Epi E = epi_plain(ft, F, F);
     E.c2 = a_ext; E.ldc2 = H2;
-    return gemm_nt(A, B, E, n_nodes, F + H2, Kt, 1, s);
+    const size_t wa_bytes = align_up((size_t)H2 * Kt * 4, 256);
+    void* tail = (ws_bytes >= wa_bytes + gemm_tail_ws_bytes()) ? (void*)((char*)ws + wa_bytes) : nullptr;
+    return gemm_nt(A, B, E, n_nodes, F + H2, Kt, 1, s, tail, tail ? ws_bytes - wa_bytes : 0);
 }
 
 // d_h may be NULL (first layer: the input features carry no gradient).  When d_h is written and act_src is non-NULL
@@ -267,7 +279,7 @@ int txe_gat_project_bwd(const float* h, long long ld_h, int n_nodes, int Kh, con
         E.c2 = p.dxp; E.ldc2 = Pd;
         epi_set_mask(E, mask, Kt, c0, feat_drop_p);
         if (d_h) epi_set_act(E, act_src, ld_act, act_slope);
-        rc = gemm_nn(G, B, E, n_nodes, Kt - c0, F + H2, 1, s);
+        rc = gemm_nn(G, B, E, n_nodes, Kt - c0, F + H2, 1, s, p.tail, p.tail_bytes);
         if (rc) return rc;
     }
     // ---- dP[c][j] = sum_{pos[m]==c} dXcat[m][Kh+j] ----
@@ -340,7 +352,7 @@ int txe_gcn_project_bwd(const float* h, long long ld_h, int n_nodes, int Kh, con
         E.c2 = p.dxp; E.ldc2 = Pd;
         epi_set_mask(E, mask, Kt, c0, drop_p);
         if (d_h) epi_set_act(E, act_src, ld_act, act_slope);
-        rc = gemm_nt(G, B, E, n_nodes, Kt - c0, Fo, 1, s);
+        rc = gemm_nt(G, B, E, n_nodes, Kt - c0, Fo, 1, s, p.tail, p.tail_bytes);
         if (rc) return rc;
     }
     if (Pd > 0) {

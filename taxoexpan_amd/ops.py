@@ -85,7 +85,7 @@ def _gat_layer_fwd(csr, h, ld_h, pos, P, W, al, ar, H, D, feat_p, attn_p, seed, 
     Pd = 0 if P is None else P.shape[1]
     F = H * D
     ft, a_ext = _empty((N, F), h), _empty((N, 2 * H), h)
-    wsb = 2 * H * (Kh + Pd) * 4
+    wsb = call("txe_gat_project_fwd_ws_bytes", Kh, Pd, H)
     ws = _ws(wsb, h)
     st = _lib.stream_ptr()
     mask = dropout_mask(N, Kh + Pd, feat_p, seed, h)

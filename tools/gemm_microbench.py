@@ -24,12 +24,15 @@ def bench(fn, flops, n=10):
     return dt * 1e6, flops / dt / 1e12
 
 
-def plain(layout, A, B, M, N, K, splits=1):
+def plain(layout, A, B, M, N, K, splits=1, tail=False):
     from taxoexpan_amd import _lib
     C = torch.empty((splits, M, N), device=dev)
+    wsb = _lib.call("txe_gemm_tail_ws_bytes") if tail else 0
+    ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=dev)
     def f():
         _lib.call("txe_gemm_plain", layout, A.data_ptr(), A.stride(0), B.data_ptr(), B.stride(0), C.data_ptr(), N, M, N, K, splits,
-                  _lib.stream_ptr())
+                  ws.data_ptr() if tail else None, wsb, _lib.stream_ptr())
+    f.C = C
     return f
 
 
@@ -42,6 +45,10 @@ for (M, N, K) in [(4096, 4096, 4096), (8192, 8192, 1024), (16384, 2048, 2048), (
     us3, tf3 = bench(lambda: torch.mm(A, B), 2.0 * M * N * K)
     At = A.t().contiguous()
     us4, tf4 = bench(plain(2, At, B, M, N, K), 2.0 * M * N * K)
+    ft = plain(0, A, Bt, M, N, K, tail=True)
+    us5, tf5 = bench(ft, 2.0 * M * N * K)
+    err = (ft.C[0] - torch.mm(A, B)).abs().max().item()
+    print(f"   NT with tail splitting: {us5:.0f}us {tf5:.1f}TF  max|err| vs torch.mm {err:.2e}")
     print(f"M={M} N={N} K={K}: NN {us:.0f}us {tf:.1f}TF | NT {us2:.0f}us {tf2:.1f}TF | TN {us4:.0f}us {tf4:.1f}TF | torch.mm {us3:.0f}us {tf3:.1f}TF")
 for (M, N, K, S) in [(508, 2050, 18000, 15), (2008, 300, 18000, 21), (512, 2048, 16384, 15)]:
     A = torch.randn(K, M, device=dev)

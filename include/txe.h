@@ -36,23 +36,29 @@ extern "C" {
 size_t txe_dropout_mask_bytes(long long n_rows, int n_cols);
 int txe_dropout_mask(long long n_rows, int n_cols, float p, unsigned long long seed, unsigned* mask, void* stream);
 
-/* ---- GATLayer dense part: model_zoo.py:82-85 (feat_drop, fc, a1, a2) with the PGAT concat of :214-215 -------------
- * h [N][Kh] (row stride ld_h), pos [N] in [0,vocab), P [vocab][Pd] (Pd = 0 -> plain GAT, :186), W [H*D][Kh+Pd],
- * attn_l/attn_r [H*D].  Writes ft [N][H*D] and a_ext [N][2H] = [a1 | a2].  ws: txe_gat_project_fwd_ws_bytes (minimum
- * 2H*(Kh+Pd) floats; the rest lets the GEMM split the leftover tiles of its last, partial round of workgroups). */
-size_t txe_gat_project_ws_bytes(int n_nodes, int Kh, int Pd, int H, int D, int vocab);   /* backward */
-size_t txe_gat_project_fwd_ws_bytes(int Kh, int Pd, int H);                                 /* forward  */
-int txe_gat_project_fwd(const float* h, long long ld_h, int n_nodes, int Kh, const int* pos, const float* P, int Pd,
-                        const float* W, const float* attn_l, const float* attn_r, int H, int D, float feat_drop_p,
-                        const unsigned* mask, float* ft, float* a_ext, void* ws, size_t ws_bytes, void* stream);
-/* backward of the above given d_ft [N][H*D], d_a_ext [N][2H].  Writes dW, d_attn_l, d_attn_r, dP [vocab][Pd] and, if
- * d_h != NULL, d_h [N][Kh] (x leaky'(act_src) when act_src != NULL: backward of the F.leaky_relu of model_zoo.py:216
- * that produced h).  ws >= txe_gat_project_ws_bytes. */
-int txe_gat_project_bwd(const float* h, long long ld_h, int n_nodes, int Kh, const int* pos, const float* P, int Pd, int vocab,
-                        const float* W, const float* attn_l, const float* attn_r, int H, int D, float feat_drop_p,
-                        const unsigned* mask, const float* d_ft, const float* d_a_ext, float* d_h, long long ld_dh,
-                        const float* act_src, long long ld_act, float act_slope, float* dW, float* d_attn_l, float* d_attn_r,
-                        float* dP, void* ws, size_t ws_bytes, void* stream);
+/* ---- GATLayer dense part: model_zoo.py:82-85 (feat_drop, fc, a1, a2) with the PGAT concat of :214-215, on PADDED operands -------
+ *   X  [N][Kp]  layer input [h (Kh) | Emb[pos] (Pd) | 0..], Kp = txe_gat_padded_k = roundup(Kh+Pd, 32).  txe_gat_build_x writes it
+ *               (h == NULL: the feature part is already in place -- the previous layer's aggregation wrote it -- only the
+ *               position-embedding and padding columns are filled).
+ *   Wp [Fp][Kp] txe_gat_pack_weights: rows < H*D = fc.weight [H*D][Kh+Pd], rows H*D..H*D+2H = attention projections folded into
+ *               the weights (a1 = h (W^T attn_l)), rest 0;  Fp = txe_gat_padded_f = roundup(H*D+2H, 128).
+ *   Y  [N][Fp]  = dropout(X) Wp^T = [ft (H*D) | a1 (H) | a2 (H) | unused].
+ * txe_gat_dense_bwd: d_Y [N][Fp] in the same layout with ZERO padding columns (txe_zero_cols) -> d_X columns [c0, Kh+Pd)
+ * (c0 = 0 if need_dh, else the 32-aligned start of the position columns; columns < Kh x leaky'(X) if act_on -- the backward of
+ * the F.leaky_relu of model_zoo.py:216 that produced h -- and all x the dropout factor), dW [H*D][Kh+Pd], d_attn_l/r [H*D],
+ * dP [vocab][Pd].  ws: txe_gat_dense_ws_bytes (forward needs only txe_gemm_tail_ws_bytes, or NULL). */
+int txe_gat_padded_k(int Kh, int Pd);
+int txe_gat_padded_f(int H, int D);
+int txe_gat_pack_weights(const float* W, const float* attn_l, const float* attn_r, int H, int D, int Kt, float* Wp, void* stream);
+int txe_gat_build_x(const float* h, long long ld_h, int n_nodes, int Kh, const int* pos, const float* P, int Pd, float* X, void* stream);
+size_t txe_gat_dense_ws_bytes(int n_nodes, int Kh, int Pd, int H, int D, int vocab);
+int txe_gat_dense_fwd(const float* X, int n_nodes, int Kh, int Pd, const float* Wp, int H, int D, float feat_drop_p,
+                      const unsigned* mask, float* Y, void* ws, size_t ws_bytes, void* stream);
+int txe_gat_dense_bwd(const float* X, int n_nodes, int Kh, int Pd, const int* pos, int vocab, const float* Wp, const float* W,
+                      const float* attn_l, const float* attn_r, int H, int D, float feat_drop_p, const unsigned* mask, const float* d_Y,
+                      int need_dh, int act_on, float act_slope, float* d_X, float* dW, float* d_attn_l, float* d_attn_r, float* dP,
+                      void* ws, size_t ws_bytes, void* stream);
+int txe_zero_cols(float* x, long long ld, int n_rows, int c0, int c1, void* stream);
 
 /* ---- GATLayer message/reduce: model_zoo.py:90-95,106-114 (edge_attention, edge_softmax, attn_drop, update_all) -----
  * out_mode 0: out = aggregated features; 1: out = leaky_relu(aggregated, act_slope) (model_zoo.py:216 fused).

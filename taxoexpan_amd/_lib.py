@@ -12,10 +12,14 @@ P, I, L, F, U64, SZ = C.c_void_p, C.c_int, C.c_longlong, C.c_float, C.c_ulonglon
 SIGNATURES = {
     "txe_dropout_mask_bytes": (SZ, [L, I]),
     "txe_dropout_mask": (I, [L, I, F, U64, P, P]),
-    "txe_gat_project_ws_bytes": (SZ, [I, I, I, I, I, I]),
-    "txe_gat_project_fwd_ws_bytes": (SZ, [I, I, I]),
-    "txe_gat_project_fwd": (I, [P, L, I, I, P, P, I, P, P, P, I, I, F, P, P, P, P, SZ, P]),
-    "txe_gat_project_bwd": (I, [P, L, I, I, P, P, I, I, P, P, P, I, I, F, P, P, P, P, L, P, L, F, P, P, P, P, P, SZ, P]),
+    "txe_gat_padded_k": (I, [I, I]),
+    "txe_gat_padded_f": (I, [I, I]),
+    "txe_gat_pack_weights": (I, [P, P, P, I, I, I, P, P]),
+    "txe_gat_build_x": (I, [P, L, I, I, P, P, I, P, P]),
+    "txe_gat_dense_ws_bytes": (SZ, [I, I, I, I, I, I]),
+    "txe_gat_dense_fwd": (I, [P, I, I, I, P, I, I, F, P, P, P, SZ, P]),
+    "txe_gat_dense_bwd": (I, [P, I, I, I, P, I, P, P, P, P, I, I, F, P, P, I, I, F, P, P, P, P, P, P, SZ, P]),
+    "txe_zero_cols": (I, [P, L, I, I, I, P]),
     "txe_gat_aggregate_fwd": (I, [P, P, I, P, L, P, P, I, I, I, F, F, U64, I, F, P, L, P, P]),
     "txe_gat_aggregate_bwd": (I, [P, P, P, P, P, I, P, L, P, P, I, I, I, F, F, U64, P, P, L, P, L, P, P, I, P, P]),
     "txe_leaky_relu_bwd": (I, [P, P, F, L, P, P]),
@@ -49,6 +53,7 @@ SIGNATURES = {
 }
 
 _ERR = {-1: "TXE_ERR_ARG", -2: "TXE_ERR_LAUNCH", -3: "TXE_ERR_WORKSPACE"}
+VALUE_RETURNING = {"txe_gat_padded_k", "txe_gat_padded_f", "txe_profile_count"}   # int results that are not status codes
 
 _lib = None
 
@@ -77,7 +82,7 @@ def load():
 def call(name, *args):
     fn = getattr(load(), name)
     rc = fn(*args)
-    if SIGNATURES[name][0] is I and rc != 0:
+    if SIGNATURES[name][0] is I and rc != 0 and name not in VALUE_RETURNING:
         raise TxeError(f"{name} failed: {_ERR.get(rc, rc)}")
     return rc
 

@@ -212,8 +212,9 @@ template <bool KC, int ROWS>
 __device__ __forceinline__ bool block_is_plain(const VMat& M, int row0) {
     if constexpr (KC) {       // rows = the GEMM's m/n range of this workgroup: all valid, all from p or all from p3
         return (row0 + ROWS <= M.rows) && ((row0 + ROWS <= M.rows_main) || (row0 >= M.rows_main));
-    } else {                  // columns = the m/n range: all inside the plain column range
-        return row0 + ROWS <= M.cols_main;
+    } else {                  // columns = the m/n range: inside the plain column range; for an operand without an extension a
+                              // ragged last tile is fine too (out-of-range column vectors are clamped and zeroed)
+        return (M.cols_main == M.cols) ? (row0 < M.cols) : (row0 + ROWS <= M.cols_main);
     }
 }
 
@@ -222,6 +223,7 @@ template <bool KC, int V, int ROWS> struct FastPtr {
     const unsigned* mbase;     // mask word of pass 0 for the current tile (only meaningful when mask_on)
     long long pstride, adv;    // elements between passes / per k-tile (block-uniform)
     long long mpstride, madv;  // mask words between passes / per k-tile
+    bool cvalid;               // row-contiguous operands: this thread's column vector lies inside the matrix
 };
 
 template <bool KC, int V, int ROWS>
@@ -229,6 +231,8 @@ __device__ __forceinline__ void fast_init(const VMat& M, int row0, int kbeg, Fas
     using G = StageGeom<KC, V, ROWS>;
     int r, c;
     stage_coord<KC, V, ROWS>(row0, kbeg, 0, r, c);
+    f.cvalid = KC ? true : (c + V <= M.cols);
+    if (!f.cvalid) c = 0;                                // clamped (always readable) column, zeroed in fast_finish
     const int rr = (r < M.rows) ? r : 0;                 // only dereferenced when the block/tile is plain (then r is valid)
     const float* row = (rr < M.rows_main) ? (M.p + (long long)rr * M.ld) : (M.p3 + (long long)(rr - M.rows_main) * M.ld3);
     const long long ld = (rr < M.rows_main) ? M.ld : M.ld3;
@@ -266,8 +270,12 @@ __device__ __forceinline__ void fast_issue(const VMat& M, FastPtr<KC, V, ROWS>& 
 }
 
 template <bool KC, int V, int ROWS>
-__device__ __forceinline__ void fast_finish(const VMat& M, float* regs, const unsigned* mws) {
+__device__ __forceinline__ void fast_finish(const VMat& M, const FastPtr<KC, V, ROWS>& f, float* regs, const unsigned* mws) {
     using G = StageGeom<KC, V, ROWS>;
+    if constexpr (!KC) {
+#pragma unroll
+        for (int i = 0; i < G::NREG; ++i) regs[i] = f.cvalid ? regs[i] : 0.f;
+    }
     if (M.mask_on) {
         const int bit0 = ((threadIdx.x % G::VPR) * V) & 31;      // column of element 0 inside its mask word (tile starts are x32)
 #pragma unroll
@@ -457,8 +465,8 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_kernel(VMat A, VMat B, c
         __builtin_amdgcn_sched_barrier(0);                                                                           \
         COMPUTE_                                                                                                     \
         __builtin_amdgcn_sched_barrier(0);                                                                           \
-        fast_finish<AK, VA, GEMM_BM>(A, ra, ma);                                                                     \
-        fast_finish<BKC, VB, BN>(B, rb, mb);                                                                         \
+        fast_finish<AK, VA, GEMM_BM>(A, fpa, ra, ma);                                                                     \
+        fast_finish<BKC, VB, BN>(B, fpb, rb, mb);                                                                         \
         stage_store<AK, VA, GEMM_BM>(As + (buf_) * ASZ, ra);                                                         \
         stage_store<BKC, VB, BN>(Bs + (buf_) * BSZ, rb);                                                             \
     }

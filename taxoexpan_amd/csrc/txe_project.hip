@@ -23,7 +23,7 @@ constexpr int MAX_VOCAB = 8;
 constexpr int FOLD_DG = 16;
 __global__ __launch_bounds__(64 * FOLD_DG) void fold_attn_kernel(const float* __restrict__ W, long long ldw, int Kt,
                                                                  const float* __restrict__ attn_l, const float* __restrict__ attn_r,
-                                                                 int H, int D, float* __restrict__ wa) {
+                                                                 int H, int D, float* __restrict__ wa, long long ld_wa) {
     __shared__ float red[FOLD_DG][64];
     const int r = blockIdx.y;                     // 0 .. 2H-1
     const int h = r % H;
@@ -41,19 +41,19 @@ __global__ __launch_bounds__(64 * FOLD_DG) void fold_attn_kernel(const float* __
         float s = 0.f;
 #pragma unroll
         for (int g = 0; g < FOLD_DG; ++g) s += red[g][kl];
-        wa[(long long)r * Kt + k] = s;
+        wa[(long long)r * ld_wa + k] = s;
     }
 }
 
 // dwa[r][k] = sum_s part[s][F + r][k]     r < 2H
-__global__ void reduce_ext_rows_kernel(const float* __restrict__ part, int S, long long split_stride, int F, int H2, int Kt,
+__global__ void reduce_ext_rows_kernel(const float* __restrict__ part, int S, long long split_stride, int F, int H2, int ldp,
                                        float* __restrict__ dwa) {
     const int r = blockIdx.y;
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= Kt) return;
+    if (k >= ldp) return;
     float acc = 0.f;
-    for (int s = 0; s < S; ++s) acc += part[(long long)s * split_stride + (long long)(F + r) * Kt + k];
-    dwa[(long long)r * Kt + k] = acc;
+    for (int s = 0; s < S; ++s) acc += part[(long long)s * split_stride + (long long)(F + r) * ldp + k];
+    dwa[(long long)r * ldp + k] = acc;
 }
 
 // One workgroup per weight row f = h*D + d:
@@ -61,7 +61,7 @@ __global__ void reduce_ext_rows_kernel(const float* __restrict__ part, int S, lo
 //   d_attn_l[f] = sum_k dwa[h][k]   * W[f][k]
 //   d_attn_r[f] = sum_k dwa[H+h][k] * W[f][k]
 __global__ __launch_bounds__(256) void gat_unfold_kernel(const float* __restrict__ part, int S, long long split_stride,
-                                                         const float* __restrict__ dwa, const float* __restrict__ W,
+                                                         const float* __restrict__ dwa, long long ldp, const float* __restrict__ W,
                                                          long long ldw, const float* __restrict__ attn_l,
                                                          const float* __restrict__ attn_r, int H, int D, int Kt,
                                                          float* __restrict__ dW, long long ld_dw,
@@ -72,8 +72,8 @@ __global__ __launch_bounds__(256) void gat_unfold_kernel(const float* __restrict
     float dl = 0.f, dr = 0.f;
     for (int k = threadIdx.x; k < Kt; k += blockDim.x) {
         float acc = 0.f;
-        for (int s = 0; s < S; ++s) acc += part[(long long)s * split_stride + (long long)f * Kt + k];
-        const float gl = dwa[(long long)h * Kt + k], gr = dwa[(long long)(H + h) * Kt + k];
+        for (int s = 0; s < S; ++s) acc += part[(long long)s * split_stride + (long long)f * ldp + k];
+        const float gl = dwa[(long long)h * ldp + k], gr = dwa[(long long)(H + h) * ldp + k];
         dW[(long long)f * ld_dw + k] = acc + al * gl + ar * gr;
         const float wv = W[(long long)f * ldw + k];
         dl = fmaf(gl, wv, dl);
@@ -213,103 +213,209 @@ int txe_dropout_mask(long long n_rows, int n_cols, float p, unsigned long long s
     return TXE_OK;
 }
 
-// forward workspace: the folded attention rows wa [2H][Kh+Pd] (+ the GEMM tail-splitting scratch, optional: with less than
-// this the projection still runs, without tail splitting)
-size_t txe_gat_project_fwd_ws_bytes(int Kh, int Pd, int H) {
-    return align_up((size_t)2 * H * (Kh + Pd) * 4, 256) + gemm_tail_ws_bytes();
+}  // extern "C"
+
+namespace txe {
+
+// ---------------------------------------------------------------------------------------------
+// GATLayer dense part on PADDED operands.
+//   X  [N][Kp]   layer input:  [h (Kh) | Emb[pos] (Pd) | 0 ...],  Kp = roundup(Kh+Pd, 32).  The producer of h (the previous
+//                layer's aggregation kernel, or txe_gat_build_x for the raw features) writes straight into it.
+//   Wp [Fp][Kp]  packed weights: rows < F = fc.weight, rows F..F+2H = folded attention rows, rest 0; Fp = roundup(F+2H,128)
+//   Y  [N][Fp]   projection output: [ft (F) | a1 (H) | a2 (H) | unused];  d_Y has the same layout with ZERO padding.
+// Every GEMM operand is then a plain, 16-byte aligned, tile-padded matrix (all tiles take the hoisted fast path); the only
+// loader-side extra left is the dropout bit mask on X.
+// ---------------------------------------------------------------------------------------------
+static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+
+// Wp[f][k] = W[f][k] (f < F, k < Kt) else 0   (rows F..Fe are written by fold_attn_kernel)
+__global__ void pack_w_kernel(const float* __restrict__ W, int F, int Fe, int Fp, int Kt, int Kp, float* __restrict__ Wp) {
+    const long long n = (long long)Fp * Kp;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int f = (int)(i / Kp), k = (int)(i % Kp);
+        if (f >= F && f < Fe && k < Kt) continue;              // folded rows: other kernel
+        Wp[i] = (f < F && k < Kt) ? W[(long long)f * Kt + k] : 0.f;
+    }
 }
 
-size_t txe_gat_project_ws_bytes(int n_nodes, int Kh, int Pd, int H, int D, int vocab) {
-    return plan_ws(nullptr, n_nodes, H * D, 2 * H, Kh + Pd, Pd, vocab).total;
+// X[r][c] = h[r][c] (c < Kh, only when h != NULL) | P[pos[r]][c-Kh] (Kh <= c < Kt) | 0 (Kt <= c < Kp)
+__global__ void build_x_kernel(const float* __restrict__ h, long long ld_h, const int* __restrict__ pos, const float* __restrict__ P,
+                               int n_rows, int Kh, int Pd, int Kp, float* __restrict__ X) {
+    const int c0 = h ? 0 : Kh;
+    const int wdt = Kp - c0;
+    const long long n = (long long)n_rows * wdt;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const long long r = i / wdt;
+        const int c = c0 + (int)(i % wdt);
+        float v = 0.f;
+        if (c < Kh) v = h[r * ld_h + c];
+        else if (c < Kh + Pd) v = P[(long long)pos[r] * Pd + (c - Kh)];
+        X[r * Kp + c] = v;
+    }
 }
 
-int txe_gat_project_fwd(const float* h, long long ld_h, int n_nodes, int Kh, const int* pos, const float* P, int Pd,
-                        const float* W, const float* attn_l, const float* attn_r, int H, int D, float feat_drop_p,
-                        const unsigned* mask, float* ft, float* a_ext, void* ws, size_t ws_bytes, void* stream) {
-    if (n_nodes < 0 || Kh < 1 || Pd < 0 || H < 1 || D < 1 || !h || !W || !attn_l || !attn_r || !ft || !a_ext || !ws)
-        return TXE_ERR_ARG;
-    if (Pd > 0 && (!pos || !P)) return TXE_ERR_ARG;
-    if (feat_drop_p < 0.f || feat_drop_p >= 1.f) return TXE_ERR_ARG;
-    const int F = H * D, H2 = 2 * H, Kt = Kh + Pd;
-    if (ws_bytes < (size_t)H2 * Kt * 4) return TXE_ERR_WORKSPACE;
-    if (n_nodes == 0) return TXE_OK;
+// zero columns [c0, c1) of a row-major [n_rows][ld] matrix
+__global__ void zero_cols_kernel(float* __restrict__ x, long long ld, int n_rows, int c0, int c1) {
+    const int wdt = c1 - c0;
+    const long long n = (long long)n_rows * wdt;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        x[(i / wdt) * ld + c0 + (i % wdt)] = 0.f;
+}
+
+struct DenseWs {
+    float* dwa;     // [2H][Kp]
+    float* ppart;   // [nb][vocab][Pd]
+    float* part;    // [S][Fp][Kp]
+    void* tail;
+    size_t tail_bytes;
+    int splits, seg_blocks, seg_rows;
+    size_t total;
+};
+
+static DenseWs plan_dense_ws(void* ws, int n, int Fp, int H2, int Kp, int Pd, int vocab) {
+    DenseWs p;
+    char* b = (char*)ws;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { float* r = (float*)(b + off); off += align_up(bytes, 256); return r; };
+    p.dwa = take((size_t)H2 * Kp * 4);
+    p.seg_rows = 64;
+    p.seg_blocks = (n + p.seg_rows - 1) / p.seg_rows;
+    if (p.seg_blocks < 1) p.seg_blocks = 1;
+    p.ppart = take((size_t)p.seg_blocks * (vocab > 0 ? vocab : 1) * (Pd > 0 ? Pd : 1) * 4);
+    p.splits = choose_splits(Fp, Kp, n);
+    p.part = take((size_t)p.splits * Fp * Kp * 4);
+    p.tail_bytes = gemm_tail_ws_bytes();
+    p.tail = take(p.tail_bytes);
+    p.total = off;
+    return p;
+}
+
+}  // namespace txe
+using namespace txe;
+extern "C" {
+
+int txe_gat_padded_k(int Kh, int Pd) { return round_up(Kh + Pd, 32); }
+int txe_gat_padded_f(int H, int D) { return round_up(H * D + 2 * H, 128); }
+
+// Wp [Fp][Kp] from fc.weight W [H*D][Kt], attn_l / attn_r [H*D]   (model_zoo.py:56,65-66)
+int txe_gat_pack_weights(const float* W, const float* attn_l, const float* attn_r, int H, int D, int Kt, float* Wp, void* stream) {
+    if (!W || !attn_l || !attn_r || !Wp || H < 1 || D < 1 || Kt < 1) return TXE_ERR_ARG;
+    const int F = H * D, Fe = F + 2 * H, Fp = round_up(Fe, 128), Kp = round_up(Kt, 32);
     hipStream_t s = (hipStream_t)stream;
-    float* wa = (float*)ws;
-    hipLaunchKernelGGL(fold_attn_kernel, dim3((Kt + 63) / 64, H2), dim3(64 * FOLD_DG), 0, s, W, (long long)Kt, Kt, attn_l, attn_r, H, D, wa);
+    const long long n = (long long)Fp * Kp;
+    hipLaunchKernelGGL(pack_w_kernel, dim3((int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048)), dim3(256), 0, s, W, F, Fe, Fp, Kt, Kp, Wp);
+    hipLaunchKernelGGL(fold_attn_kernel, dim3((Kt + 63) / 64, 2 * H), dim3(64 * FOLD_DG), 0, s, W, (long long)Kt, Kt, attn_l, attn_r, H, D,
+                       Wp + (long long)F * Kp, (long long)Kp);
     TXE_CHECK_LAUNCH();
-    VMat A = make_xcat(h, ld_h, n_nodes, Kh, pos, P, Pd, feat_drop_p, mask);
-    VMat B = vmat_plain(W, Kt, F + H2, Kt);
-    B.rows_main = F; B.p3 = wa; B.ld3 = Kt;
-    Epi E = epi_plain(ft, F, F);
-    E.c2 = a_ext; E.ldc2 = H2;
-    const size_t wa_bytes = align_up((size_t)H2 * Kt * 4, 256);
-    void* tail = (ws_bytes >= wa_bytes + gemm_tail_ws_bytes()) ? (void*)((char*)ws + wa_bytes) : nullptr;
-    return gemm_nt(A, B, E, n_nodes, F + H2, Kt, 1, s, tail, tail ? ws_bytes - wa_bytes : 0);
+    return TXE_OK;
 }
 
-// d_h may be NULL (first layer: the input features carry no gradient).  When d_h is written and act_src is non-NULL
-// the result is multiplied by leaky'(act_src[m][k]) -- the backward of the inter-layer activation that produced h.
-int txe_gat_project_bwd(const float* h, long long ld_h, int n_nodes, int Kh, const int* pos, const float* P, int Pd, int vocab,
-                        const float* W, const float* attn_l, const float* attn_r, int H, int D, float feat_drop_p,
-                        const unsigned* mask, const float* d_ft, const float* d_a_ext, float* d_h, long long ld_dh,
-                        const float* act_src, long long ld_act, float act_slope, float* dW, float* d_attn_l, float* d_attn_r,
-                        float* dP, void* ws, size_t ws_bytes, void* stream) {
-    if (n_nodes < 0 || Kh < 1 || Pd < 0 || H < 1 || D < 1 || !h || !W || !attn_l || !attn_r || !d_ft || !d_a_ext || !dW ||
-        !d_attn_l || !d_attn_r || !ws)
-        return TXE_ERR_ARG;
-    if (Pd > 0 && (!pos || !P || !dP || vocab < 1 || vocab > MAX_VOCAB)) return TXE_ERR_ARG;
+// Layer input in padded layout (model_zoo.py:214-215 `cat(h, Emb[pos])`).  h == NULL: the feature part [0, Kh) is already in
+// place (written by the previous layer's aggregation), only the position-embedding and padding columns are filled.
+int txe_gat_build_x(const float* h, long long ld_h, int n_nodes, int Kh, const int* pos, const float* P, int Pd, float* X, void* stream) {
+    if (n_nodes < 0 || Kh < 1 || Pd < 0 || !X || (Pd > 0 && (!pos || !P))) return TXE_ERR_ARG;
+    if (n_nodes == 0) return TXE_OK;
+    const int Kp = round_up(Kh + Pd, 32);
+    const long long n = (long long)n_nodes * (Kp - (h ? 0 : Kh));
+    if (n == 0) return TXE_OK;
+    hipLaunchKernelGGL(build_x_kernel, dim3((int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096)), dim3(256), 0, (hipStream_t)stream, h,
+                       ld_h, pos, P, n_nodes, Kh, Pd, Kp, X);
+    TXE_CHECK_LAUNCH();
+    return TXE_OK;
+}
+
+size_t txe_gat_dense_ws_bytes(int n_nodes, int Kh, int Pd, int H, int D, int vocab) {
+    return plan_dense_ws(nullptr, n_nodes, round_up(H * D + 2 * H, 128), 2 * H, round_up(Kh + Pd, 32), Pd, vocab).total;
+}
+
+// Y [N][Fp] = dropout(X) [N][Kp] * Wp^T      (model_zoo.py:82-85: feat_drop, fc, a1, a2 in one product)
+int txe_gat_dense_fwd(const float* X, int n_nodes, int Kh, int Pd, const float* Wp, int H, int D, float feat_drop_p,
+                      const unsigned* mask, float* Y, void* ws, size_t ws_bytes, void* stream) {
+    if (n_nodes < 0 || Kh < 1 || Pd < 0 || H < 1 || D < 1 || !X || !Wp || !Y) return TXE_ERR_ARG;
     if (feat_drop_p < 0.f || feat_drop_p >= 1.f) return TXE_ERR_ARG;
-    const int F = H * D, H2 = 2 * H, Kt = Kh + Pd;
-    ProjectWs p = plan_ws(ws, n_nodes, F, H2, Kt, Pd, vocab);
+    if (n_nodes == 0) return TXE_OK;
+    const int Fe = H * D + 2 * H, Fp = round_up(Fe, 128), Kp = round_up(Kh + Pd, 32);
+    VMat A = vmat_plain(X, Kp, n_nodes, Kp);
+    vmat_set_mask(A, mask, feat_drop_p);
+    VMat B = vmat_plain(Wp, Kp, Fp, Kp);
+    Epi E = epi_plain(Y, Fp, Fe);
+    const bool tail_ok = ws && ws_bytes >= gemm_tail_ws_bytes();
+    return gemm_nt(A, B, E, n_nodes, Fe, Kp, 1, (hipStream_t)stream, tail_ok ? ws : nullptr, tail_ok ? ws_bytes : 0);
+}
+
+// Backward of txe_gat_dense_fwd.  d_Y [N][Fp] must have ZERO padding columns [F+2H, Fp).
+//   d_X [N][Kp]: columns [c0, Kt) are written, c0 = 0 if need_dh else the 32-aligned start of the position columns;
+//                columns < Kh are multiplied by leaky'(X) when act_slope_on (X[:, :Kh] is then the activated output of the
+//                previous layer), all by the dropout factor.
+//   dW [F][Kt], d_attn_l / d_attn_r [F], dP [vocab][Pd].
+int txe_gat_dense_bwd(const float* X, int n_nodes, int Kh, int Pd, const int* pos, int vocab, const float* Wp, const float* W,
+                      const float* attn_l, const float* attn_r, int H, int D, float feat_drop_p, const unsigned* mask, const float* d_Y,
+                      int need_dh, int act_on, float act_slope, float* d_X, float* dW, float* d_attn_l, float* d_attn_r, float* dP,
+                      void* ws, size_t ws_bytes, void* stream) {
+    if (n_nodes < 0 || Kh < 1 || Pd < 0 || H < 1 || D < 1 || !X || !Wp || !W || !attn_l || !attn_r || !d_Y || !dW || !d_attn_l || !d_attn_r || !ws)
+        return TXE_ERR_ARG;
+    if ((need_dh || Pd > 0) && !d_X) return TXE_ERR_ARG;
+    if (Pd > 0 && (!pos || !dP || vocab < 1 || vocab > MAX_VOCAB)) return TXE_ERR_ARG;
+    if (feat_drop_p < 0.f || feat_drop_p >= 1.f) return TXE_ERR_ARG;
+    const int F = H * D, H2 = 2 * H, Fe = F + H2, Fp = round_up(Fe, 128), Kt = Kh + Pd, Kp = round_up(Kt, 32);
+    DenseWs p = plan_dense_ws(ws, n_nodes, Fp, H2, Kp, Pd, vocab);
     if (ws_bytes < p.total) return TXE_ERR_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
     int rc;
-    hipLaunchKernelGGL(fold_attn_kernel, dim3((Kt + 63) / 64, H2), dim3(64 * FOLD_DG), 0, s, W, (long long)Kt, Kt, attn_l, attn_r, H, D, p.wa);
-    TXE_CHECK_LAUNCH();
-
-    VMat G = vmat_plain(d_ft, F, n_nodes, F + H2);          // [d_ft | d_a_ext]
-    G.cols_main = F; G.p2 = d_a_ext; G.ld2 = H2;
-
-    // ---- dX = G * Wext, only the columns somebody needs: [c0, Kt) ----
-    const int c0 = d_h ? 0 : Kh;
-    if (Kt - c0 > 0 && n_nodes > 0) {
-        VMat B = vmat_plain(W + c0, Kt, F + H2, Kt - c0);
-        B.rows_main = F; B.p3 = p.wa + c0; B.ld3 = Kt;
-        Epi E = epi_plain(d_h, ld_dh, Kh - c0);
-        E.c2 = p.dxp; E.ldc2 = Pd;
+    // ---- d_X[:, c0:Kt] = d_Y * Wp[:, c0:Kt] ----
+    const int c0 = need_dh ? 0 : (Kh / 32) * 32;
+    if (Kt - c0 > 0 && n_nodes > 0 && (need_dh || Pd > 0)) {
+        VMat A = vmat_plain(d_Y, Fp, n_nodes, Fp);
+        VMat B = vmat_plain(Wp + c0, Kp, Fp, Kp - c0);
+        Epi E = epi_plain(d_X + c0, Kp, Kh > c0 ? Kh - c0 : 0);
+        E.c2 = d_X + c0 + E.cols_main; E.ldc2 = Kp;                 // same buffer: the split only scopes the activation factor
         epi_set_mask(E, mask, Kt, c0, feat_drop_p);
-        if (d_h) epi_set_act(E, act_src, ld_act, act_slope);
-        rc = gemm_nn(G, B, E, n_nodes, Kt - c0, F + H2, 1, s, p.tail, p.tail_bytes);
+        if (act_on && need_dh) epi_set_act(E, X + c0, Kp, act_slope);
+        rc = gemm_nn(A, B, E, n_nodes, Kt - c0, Fp, 1, s, p.tail, p.tail_bytes);
         if (rc) return rc;
     }
-    // ---- dP[c][j] = sum_{pos[m]==c} dXcat[m][Kh+j] ----
+    // ---- dP[c][j] = sum_{pos[m]==c} d_X[m][Kh+j] ----
     if (Pd > 0) {
         if (n_nodes > 0) {
-            hipLaunchKernelGGL(pos_segsum_stage1, dim3(p.seg_blocks), dim3(256), 0, s, (const float*)p.dxp, (long long)Pd, pos,
-                               n_nodes, Pd, vocab, p.seg_rows, p.ppart);
+            hipLaunchKernelGGL(pos_segsum_stage1, dim3(p.seg_blocks), dim3(256), 0, s, (const float*)(d_X + Kh), (long long)Kp, pos, n_nodes,
+                               Pd, vocab, p.seg_rows, p.ppart);
             TXE_CHECK_LAUNCH();
         }
         hipLaunchKernelGGL(pos_segsum_stage2, dim3((vocab * Pd + 63) / 64), dim3(256), 0, s, (const float*)p.ppart,
                            n_nodes > 0 ? p.seg_blocks : 0, vocab, Pd, dP);
         TXE_CHECK_LAUNCH();
     }
-    // ---- dWext = G^T * Xcat  (split-K over the node dimension) ----
+    // ---- dWp = d_Y^T * dropout(X)  (split-K over the node dimension) ----
     {
-        VMat X = make_xcat(h, ld_h, n_nodes, Kh, pos, P, Pd, feat_drop_p, mask);
-        Epi E = epi_plain(p.part, Kt, Kt);
-        E.split_stride = (long long)(F + H2) * Kt;
-        rc = gemm_tn(G, X, E, F + H2, Kt, n_nodes, p.splits, s);
+        VMat A = vmat_plain(d_Y, Fp, n_nodes, Fp);
+        VMat B = vmat_plain(X, Kp, n_nodes, Kp);
+        vmat_set_mask(B, mask, feat_drop_p);
+        Epi E = epi_plain(p.part, Kp, Kp);
+        E.split_stride = (long long)Fp * Kp;
+        rc = gemm_tn(A, B, E, Fp, Kp, n_nodes, p.splits, s);
         if (rc) return rc;
         const int S = n_nodes > 0 ? p.splits : 0;
-        hipLaunchKernelGGL(reduce_ext_rows_kernel, dim3((Kt + 127) / 128, H2), dim3(128), 0, s, (const float*)p.part, S,
-                           E.split_stride, F, H2, Kt, p.dwa);
+        hipLaunchKernelGGL(reduce_ext_rows_kernel, dim3((Kp + 127) / 128, H2), dim3(128), 0, s, (const float*)p.part, S, E.split_stride, F,
+                           H2, Kp, p.dwa);
         TXE_CHECK_LAUNCH();
-        hipLaunchKernelGGL(gat_unfold_kernel, dim3(F), dim3(256), 0, s, (const float*)p.part, S, E.split_stride,
-                           (const float*)p.dwa, W, (long long)Kt, attn_l, attn_r, H, D, Kt, dW, (long long)Kt, d_attn_l, d_attn_r);
+        hipLaunchKernelGGL(gat_unfold_kernel, dim3(F), dim3(256), 0, s, (const float*)p.part, S, E.split_stride, (const float*)p.dwa,
+                           (long long)Kp, W, (long long)Kt, attn_l, attn_r, H, D, Kt, dW, (long long)Kt, d_attn_l, d_attn_r);
         TXE_CHECK_LAUNCH();
     }
     return TXE_OK;
 }
+
+// zero columns [c0, c1) of a row-major fp32 matrix (padding columns of d_Y)
+int txe_zero_cols(float* x, long long ld, int n_rows, int c0, int c1, void* stream) {
+    if (!x || n_rows < 0 || c0 < 0 || c1 < c0) return TXE_ERR_ARG;
+    const long long n = (long long)n_rows * (c1 - c0);
+    if (n == 0) return TXE_OK;
+    hipLaunchKernelGGL(zero_cols_kernel, dim3((int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048)), dim3(256), 0, (hipStream_t)stream, x, ld,
+                       n_rows, c0, c1);
+    TXE_CHECK_LAUNCH();
+    return TXE_OK;
+}
+
 
 // ---------------------------------------------------------------------------------------------
 // GCN projection (model_zoo.py:35-37):  hw = dropout(cat(x, P[pos])) @ W,  W is [Kt][Fo] row-major.

@@ -80,44 +80,61 @@ def dropout_mask(n_rows, n_cols, p, seed, ref):
     return mask
 
 
-def _gat_layer_fwd(csr, h, ld_h, pos, P, W, al, ar, H, D, feat_p, attn_p, seed, attn_slope, out_mode, act_slope, save):
-    N, Kh = h.shape
-    Pd = 0 if P is None else P.shape[1]
-    F = H * D
-    ft, a_ext = _empty((N, F), h), _empty((N, 2 * H), h)
-    wsb = call("txe_gat_project_fwd_ws_bytes", Kh, Pd, H)
-    ws = _ws(wsb, h)
-    st = _lib.stream_ptr()
-    mask = dropout_mask(N, Kh + Pd, feat_p, seed, h)
-    call("txe_gat_project_fwd", ptr(h), ld_h, N, Kh, ptr(pos), ptr(P), Pd, ptr(W), ptr(al), ptr(ar), H, D, feat_p, ptr(mask),
-         ptr(ft), ptr(a_ext), ptr(ws), wsb, st)
-    out = _empty((N, F), h)
-    alpha = _empty((max(csr.n_edges, 1), H), h) if save else None
-    call("txe_gat_aggregate_fwd", ptr(csr.rowptr_in), ptr(csr.col_src), N, ptr(ft), F, ptr(a_ext), ptr(a_ext) + 4 * H, 2 * H,
-         H, D, attn_slope, attn_p, seed + 1, out_mode, act_slope, ptr(out), F, ptr(alpha), st)
-    return out, ft, a_ext, alpha, mask
+_tail_ws_cache = {}
 
 
-def _gat_layer_bwd(csr, h, ld_h, pos, P, vocab, W, al, ar, H, D, feat_p, attn_p, seed, attn_slope, ft, a_ext, alpha, mask,
-                   d_pre, ld_dpre, need_dh, act_src, act_slope):
-    N, Kh = h.shape
-    Pd = 0 if P is None else P.shape[1]
+def _tail_ws(ref):
+    """persistent GEMM tail-splitting scratch per device (stream-ordered reuse; contents never outlive one GEMM)"""
+    key = ref.device.index
+    t = _tail_ws_cache.get(key)
+    if t is None:
+        t = torch.empty(call("txe_gemm_tail_ws_bytes"), dtype=torch.uint8, device=ref.device)
+        _tail_ws_cache[key] = t
+    return t
+
+
+class _GatLayerState:
+    __slots__ = ("X", "Wp", "mask", "Y", "alpha", "W", "al", "ar", "P", "Kh", "Pd", "Kp", "Fp", "H", "D", "seed")
+
+
+def _gat_layer_fwd(csr, st, h, ld_h, pos, out, ld_out, feat_p, attn_p, attn_slope, out_mode, act_slope, save):
+    """st.X is pre-allocated [N, Kp]; h != None copies the raw features in, h == None means the producer already wrote them."""
+    N = st.X.shape[0]
+    H, D, Kh, Pd, Kp, Fp = st.H, st.D, st.Kh, st.Pd, st.Kp, st.Fp
     F = H * D
-    st = _lib.stream_ptr()
-    d_ft, d_a = _empty((N, F), h), _empty((N, 2 * H), h)
-    dz = _empty((max(csr.n_edges, 1) * H,), h)
+    s = _lib.stream_ptr()
+    call("txe_gat_build_x", ptr(h), ld_h, N, Kh, ptr(pos), ptr(st.P), Pd, ptr(st.X), s)
+    st.Wp = _empty((Fp, Kp), st.X)
+    call("txe_gat_pack_weights", ptr(st.W), ptr(st.al), ptr(st.ar), H, D, Kh + Pd, ptr(st.Wp), s)
+    st.mask = dropout_mask(N, Kh + Pd, feat_p, st.seed, st.X)
+    st.Y = _empty((N, Fp), st.X)
+    tws = _tail_ws(st.X)
+    call("txe_gat_dense_fwd", ptr(st.X), N, Kh, Pd, ptr(st.Wp), H, D, feat_p, ptr(st.mask), ptr(st.Y), ptr(tws), tws.numel(), s)
+    st.alpha = _empty((max(csr.n_edges, 1), H), st.X) if save else None
+    call("txe_gat_aggregate_fwd", ptr(csr.rowptr_in), ptr(csr.col_src), N, ptr(st.Y), Fp, ptr(st.Y) + 4 * F, ptr(st.Y) + 4 * (F + H), Fp,
+         H, D, attn_slope, attn_p, st.seed + 1, out_mode, act_slope, ptr(out), ld_out, ptr(st.alpha), s)
+
+
+def _gat_layer_bwd(csr, st, pos, vocab, feat_p, attn_p, attn_slope, d_pre, ld_dpre, need_dh, act_on, act_slope):
+    N = st.X.shape[0]
+    H, D, Kh, Pd, Kp, Fp = st.H, st.D, st.Kh, st.Pd, st.Kp, st.Fp
+    F, Fe = H * D, H * D + 2 * H
+    s = _lib.stream_ptr()
+    d_Y = _empty((N, Fp), st.X)
+    call("txe_zero_cols", ptr(d_Y), Fp, N, Fe, Fp, s)
+    dz = _empty((max(csr.n_edges, 1) * H,), st.X)
     call("txe_gat_aggregate_bwd", ptr(csr.rowptr_in), ptr(csr.col_src), ptr(csr.rowptr_out), ptr(csr.col_dst), ptr(csr.pos_out),
-         N, ptr(ft), F, ptr(a_ext), ptr(a_ext) + 4 * H, 2 * H, H, D, attn_slope, attn_p, seed + 1, ptr(alpha), ptr(d_pre),
-         ld_dpre, ptr(d_ft), F, ptr(d_a), ptr(d_a) + 4 * H, 2 * H, ptr(dz), st)
-    dW, dal, dar = torch.empty_like(W), torch.empty_like(al), torch.empty_like(ar)
-    dP = torch.empty_like(P) if P is not None else None
-    d_h = _empty((N, Kh), h) if need_dh else None
-    wsb = call("txe_gat_project_ws_bytes", N, Kh, Pd, H, D, vocab)
-    ws = _ws(wsb, h)
-    call("txe_gat_project_bwd", ptr(h), ld_h, N, Kh, ptr(pos), ptr(P), Pd, vocab, ptr(W), ptr(al), ptr(ar), H, D, feat_p, ptr(mask),
-         ptr(d_ft), ptr(d_a), ptr(d_h), Kh, ptr(act_src), (ld_h if act_src is not None else 0), act_slope if act_slope else 1.0,
-         ptr(dW), ptr(dal), ptr(dar), ptr(dP), ptr(ws), wsb, st)
-    return d_h, dW, dal, dar, dP
+         N, ptr(st.Y), Fp, ptr(st.Y) + 4 * F, ptr(st.Y) + 4 * (F + H), Fp, H, D, attn_slope, attn_p, st.seed + 1, ptr(st.alpha),
+         ptr(d_pre), ld_dpre, ptr(d_Y), Fp, ptr(d_Y) + 4 * F, ptr(d_Y) + 4 * (F + H), Fp, ptr(dz), s)
+    dW, dal, dar = torch.empty_like(st.W), torch.empty_like(st.al), torch.empty_like(st.ar)
+    dP = torch.empty_like(st.P) if st.P is not None else None
+    d_X = _empty((N, Kp), st.X) if (need_dh or Pd > 0) else None
+    wsb = call("txe_gat_dense_ws_bytes", N, Kh, Pd, H, D, vocab)
+    ws = _ws(wsb, st.X)
+    call("txe_gat_dense_bwd", ptr(st.X), N, Kh, Pd, ptr(pos), vocab, ptr(st.Wp), ptr(st.W), ptr(st.al), ptr(st.ar), H, D, feat_p,
+         ptr(st.mask), ptr(d_Y), int(need_dh), int(act_on), act_slope if act_slope else 1.0, ptr(d_X), ptr(dW), ptr(dal), ptr(dar),
+         ptr(dP), ptr(ws), wsb, s)
+    return d_X, dW, dal, dar, dP
 
 
 class GATStackFunction(torch.autograd.Function):
@@ -130,58 +147,79 @@ class GATStackFunction(torch.autograd.Function):
         pos = _i32(pos, h.device)
         L = cfg.n_layers
         need = any(ctx.needs_input_grad)       # (grad mode itself is off inside Function.forward)
-        saved = []
-        x, ldx = h, ld_h
+        N = h.shape[0]
+        states = []
         with torch.cuda.device(h.device):
+            kh = h.shape[1]
             for l in range(L):
-                W, al, ar, P = (_f32(p) for p in params[4 * l:4 * l + 4])
-                H, D = cfg.heads[l], cfg.out_dims[l]
+                st = _GatLayerState()
+                st.W, st.al, st.ar, st.P = (_f32(p) for p in params[4 * l:4 * l + 4])
+                st.H, st.D, st.Kh = cfg.heads[l], cfg.out_dims[l], kh
+                st.Pd = 0 if st.P is None else st.P.shape[1]
+                st.Kp = call("txe_gat_padded_k", st.Kh, st.Pd)
+                st.Fp = call("txe_gat_padded_f", st.H, st.D)
+                st.seed = cfg.seed + 16 * l
+                st.X = None
+                states.append(st)
+                kh = st.H * st.D
+            states[0].X = _empty((N, states[0].Kp), h)
+            for l, st in enumerate(states):
                 last = (l == L - 1)
+                F = st.H * st.D
+                if last:
+                    out, ld_out = _empty((N, F), h), F
+                else:                                  # the aggregation writes straight into the next layer's padded input
+                    states[l + 1].X = _empty((N, states[l + 1].Kp), h)
+                    out, ld_out = states[l + 1].X, states[l + 1].Kp
                 out_mode = 0 if (last or cfg.act_slope is None) else 1
-                out, ft, a_ext, alpha, mask = _gat_layer_fwd(csr, x, ldx, pos if P is not None else None, P, W, al, ar, H, D,
-                                                       cfg.feat_p, cfg.attn_p, cfg.seed + 16 * l, cfg.attn_slope, out_mode,
-                                                       cfg.act_slope or 1.0, need)
-                saved.append((x, ldx, W, al, ar, P, ft, a_ext, alpha, mask))
-                x, ldx = out, out.stride(0)
+                _gat_layer_fwd(csr, st, h if l == 0 else None, ld_h if l == 0 else 0, pos if st.P is not None else None, out, ld_out,
+                               cfg.feat_p, cfg.attn_p, cfg.attn_slope, out_mode, cfg.act_slope or 1.0, need)
+                if not need:
+                    st.Y = st.mask = st.Wp = None
+                    if l > 0:
+                        st.X = None
             H, D = cfg.heads[-1], cfg.out_dims[-1]
             if cfg.final == "mean":
                 if H == 1:
-                    res = x.view(x.shape[0], D)
+                    res = out.view(N, D)
                 else:
-                    res = _empty((x.shape[0], D), x)
-                    call("txe_head_mean_fwd", ptr(x), H, D, x.shape[0], ptr(res), _lib.stream_ptr())
+                    res = _empty((N, D), h)
+                    call("txe_head_mean_fwd", ptr(out), H, D, N, ptr(res), _lib.stream_ptr())
             else:
-                res = x.view(x.shape[0], H, D)
-        ctx.csr, ctx.cfg, ctx.pos, ctx.saved = csr, cfg, pos, (saved if need else None)
+                res = out.view(N, H, D)
+        ctx.csr, ctx.cfg, ctx.pos, ctx.states = csr, cfg, pos, (states if need else None)
         ctx.h_req = ctx.needs_input_grad[2]
         return res
 
     @staticmethod
     def backward(ctx, d_res):
-        csr, cfg, pos, saved = ctx.csr, ctx.cfg, ctx.pos, ctx.saved
+        csr, cfg, pos, states = ctx.csr, ctx.cfg, ctx.pos, ctx.states
         L = cfg.n_layers
         H, D = cfg.heads[-1], cfg.out_dims[-1]
         d_res = _f32(d_res)
+        N = d_res.shape[0]
         grads = [None] * (4 * L)
         with torch.cuda.device(d_res.device):
             if cfg.final == "mean" and H > 1:
-                d_pre = _empty((d_res.shape[0], H * D), d_res)
-                call("txe_head_mean_bwd", ptr(d_res), H, D, d_res.shape[0], ptr(d_pre), _lib.stream_ptr())
+                d_pre = _empty((N, H * D), d_res)
+                call("txe_head_mean_bwd", ptr(d_res), H, D, N, ptr(d_pre), _lib.stream_ptr())
             else:
-                d_pre = d_res.reshape(d_res.shape[0], H * D)
-            d_h = None
+                d_pre = d_res.reshape(N, H * D)
+            ld_dpre = d_pre.stride(0)
+            d_X = None
             for l in range(L - 1, -1, -1):
-                x, ldx, W, al, ar, P, ft, a_ext, alpha, mask = saved[l]
+                st = states[l]
                 need_dh = (l > 0) or ctx.h_req
                 # the input of layer l>0 is leaky_relu(out_{l-1}) (fused epilogue): fold its derivative into dX
-                act_src = x if (l > 0 and cfg.act_slope is not None) else None
-                d_h, dW, dal, dar, dP = _gat_layer_bwd(csr, x, ldx, pos if P is not None else None, P, cfg.vocab, W, al, ar,
-                                                       cfg.heads[l], cfg.out_dims[l], cfg.feat_p, cfg.attn_p, cfg.seed + 16 * l,
-                                                       cfg.attn_slope, ft, a_ext, alpha, mask, d_pre, d_pre.stride(0), need_dh, act_src,
-                                                       cfg.act_slope)
+                act_on = (l > 0 and cfg.act_slope is not None)
+                d_X, dW, dal, dar, dP = _gat_layer_bwd(csr, st, pos if st.P is not None else None, cfg.vocab, cfg.feat_p, cfg.attn_p,
+                                                       cfg.attn_slope, d_pre, ld_dpre, need_dh, act_on, cfg.act_slope)
                 grads[4 * l:4 * l + 4] = [dW, dal, dar, dP]
-                d_pre = d_h
-        return (None, None, d_h if ctx.h_req else None, None, *grads)
+                if l > 0:
+                    d_pre, ld_dpre = d_X, st.Kp            # its first H*D(l-1) columns are d(pre-activation out_{l-1})
+            d_h = d_X[:, :states[0].Kh].contiguous() if ctx.h_req else None
+        ctx.states = None
+        return (None, None, d_h, None, *grads)
 
 
 # ================================================================================================================

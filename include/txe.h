@@ -44,7 +44,7 @@ int txe_dropout_mask(long long n_rows, int n_cols, float p, unsigned long long s
  *               the weights (a1 = h (W^T attn_l)), rest 0;  Fp = txe_gat_padded_f = roundup(H*D+2H, 128).
  *   Y  [N][Fp]  = dropout(X) Wp^T = [ft (H*D) | a1 (H) | a2 (H) | unused].
  * txe_gat_dense_bwd: d_Y [N][Fp] in the same layout with ZERO padding columns (txe_zero_cols) -> d_X columns [c0, Kh+Pd)
- * (c0 = 0 if need_dh, else the 32-aligned start of the position columns; columns < Kh x leaky'(X) if act_on -- the backward of
+ * (c0 = 0 if need_dh, else the 4-aligned start of the position columns; columns < Kh x leaky'(X) if act_on -- the backward of
  * the F.leaky_relu of model_zoo.py:216 that produced h -- and all x the dropout factor), dW [H*D][Kh+Pd], d_attn_l/r [H*D],
  * dP [vocab][Pd].  ws: txe_gat_dense_ws_bytes (forward needs only txe_gemm_tail_ws_bytes, or NULL). */
 int txe_gat_padded_k(int Kh, int Pd);

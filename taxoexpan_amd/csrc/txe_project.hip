@@ -363,7 +363,7 @@ int txe_gat_dense_bwd(const float* X, int n_nodes, int Kh, int Pd, const int* po
     hipStream_t s = (hipStream_t)stream;
     int rc;
     // ---- d_X[:, c0:Kt] = d_Y * Wp[:, c0:Kt] ----
-    const int c0 = need_dh ? 0 : (Kh / 32) * 32;
+    const int c0 = need_dh ? 0 : (Kh / 4) * 4;      // 16-byte aligned start of the position columns
     if (Kt - c0 > 0 && n_nodes > 0 && (need_dh || Pd > 0)) {
         VMat A = vmat_plain(d_Y, Fp, n_nodes, Fp);
         VMat B = vmat_plain(Wp + c0, Kp, Fp, Kp - c0);

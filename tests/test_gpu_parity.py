@@ -316,3 +316,35 @@ def test_full_size_properties_mag_cs_batch():
     out_ab, _ = agg(2.0 * ft + ft_b)
     np.testing.assert_allclose(out_ab.cpu().numpy(), (2.0 * out1 + out_b).cpu().numpy(), rtol=1e-4, atol=1e-4)   # linear in ft
     assert E == 2 * N - g.batch_size                                               # E = 2n-1 per egonet
+
+
+def test_sharded_scoring_single_rank_rccl():
+    """the candidate-sharded scoring path with its real (HIP) local scorer and an RCCL all-gather, world size 1 (the only
+    size a 1-GPU box offers; world size 2 is covered on CPU/gloo in tests/test_distributed_cpu.py)"""
+    import os
+    import torch.distributed as dist
+    from taxoexpan_amd.model_zoo import LBM
+    from taxoexpan_amd.scoring import allreduce_gradients, score_all, score_all_sharded, shard_bounds
+    z = dict(np.load(f"{GOLDEN_DIR}/scoring.npz"))
+    hg, qs, W, positives = gc.make_scoring_inputs()
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    created = False
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=_dev())
+        created = True
+    try:
+        mod = LBM(hg.shape[1], qs.shape[1])
+        mod.load_state_dict({"W.weight": torch.from_numpy(W)})
+        mod = mod.to(_dev())
+        lo, hi = shard_bounds(hg.shape[0], 1, 0)
+        S = score_all_sharded(mod, torch.from_numpy(hg[lo:hi]).to(_dev()), hg.shape[0], torch.from_numpy(qs).to(_dev()), block=7)
+        np.testing.assert_allclose(S.cpu().numpy(), z["S_lbm"], rtol=RT, atol=AT)
+        assert torch.equal(S, score_all(mod, torch.from_numpy(hg).to(_dev()), torch.from_numpy(qs).to(_dev()), block=7))
+        p = torch.nn.Parameter(torch.ones(5, device=_dev()))
+        p.grad = torch.arange(5.0, device=_dev())
+        allreduce_gradients([p])
+        assert torch.equal(p.grad.cpu(), torch.arange(5.0))
+    finally:
+        if created:
+            dist.destroy_process_group()

@@ -229,6 +229,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
+    ap.add_argument("--workload", default="pgat", choices=["pgat", "pgcn"],
+                    help="pgat = BASELINE configs[1] (default, the metric's workload); pgcn = configs[4] (PGCN+MR+BIM, same batches)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -245,7 +247,10 @@ def main():
     from taxoexpan_amd import TaxoExpan, synthetic as syn
     tax = syn.make_named_taxonomy("mag_cs", seed=47)
     torch.manual_seed(47)
-    model = TaxoExpan("PGAT", "WMR", "LBM", **MAG).to(device).train()
+    if args.workload == "pgat":
+        model = TaxoExpan("PGAT", "WMR", "LBM", **MAG).to(device).train()
+    else:
+        model = TaxoExpan("PGCN", "MR", "BIM", **MAG).to(device).train()
     if world > 1:                                   # identical replicas
         for p in model.parameters():
             dist.broadcast(p.data, src=0)
@@ -282,7 +287,7 @@ def main():
     if rank == 0:
         recs = [profile_step(model, opt, b, target) for b in batches]
         roof_all = summarize_profile(recs, [b["n_edges"] for b in batches])
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and args.workload == "pgat":
         if not args.no_cpu_baseline:
             cpu = cpu_baseline(batches[0], model.state_dict())
         if not args.no_extra:
@@ -293,7 +298,7 @@ def main():
     if rank == 0:
         dom = roof_all[0]
         line = {
-            "metric": "egonet_edges_per_sec_pgat_fwd_bwd", "value": edges / elapsed, "unit": "egonet-edges/s",
+            "metric": "egonet_edges_per_sec_%s_fwd_bwd" % args.workload, "value": edges / elapsed, "unit": "egonet-edges/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "MAG-CS synthetic taxonomy (29,654 nodes, d=250), PGAT+WMR+LBM fp32 dims 250/50/500/500 heads [4,1], "

@@ -237,11 +237,17 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
+    if os.environ.get("TXE_BENCH_BACKEND", "nccl") != "nccl":
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        backend = os.environ.get("TXE_BENCH_BACKEND", "nccl")     # "nccl" = RCCL over xGMI; "gloo" only to exercise the N>1
+        if backend == "nccl":                                       # logic on a single-GPU box (both ranks on cuda:0)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     from taxoexpan_amd import TaxoExpan, synthetic as syn

@@ -1,0 +1,88 @@
+#!/usr/bin/env python3
+"""All-candidate inference (test_fast.py:99-225) on a synthetic taxonomy of a named shape, one MI355X:
+encode every candidate egonet (one batch, and in `-b` chunks like the reference), then score every test query against
+every candidate in query blocks with the ranks taken on device.  Prints one JSON line."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402
+from taxoexpan_amd import TaxoExpan, ops, synthetic as syn  # noqa: E402
+from taxoexpan_amd.scoring import encode_candidates  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--shape", default="mag_full", choices=list(syn.SHAPES))
+ap.add_argument("--chunk", type=int, default=-1, help="-b of test_fast.py: egonets per encoder batch (-1 = one batch)")
+ap.add_argument("--qblock", type=int, default=1024)
+ap.add_argument("--max-queries", type=int, default=0)
+args = ap.parse_args()
+
+dev = torch.device("cuda:0")
+t0 = time.perf_counter()
+tax = syn.make_named_taxonomy(args.shape, seed=47)
+cand, val, test = syn.split_candidates(tax)
+if args.max_queries:
+    test = test[:args.max_queries]
+t_tax = time.perf_counter() - t0
+torch.manual_seed(47)
+model = TaxoExpan("PGAT", "WMR", "LBM", **bench.MAG).to(dev).eval()
+
+t0 = time.perf_counter()
+chunks = [cand] if args.chunk <= 0 else [cand[i:i + args.chunk] for i in range(0, len(cand), args.chunk)]
+graphs = []
+for c in chunks:
+    g = syn.egonet_batch(tax, c, seed=7)
+    g.ndata["x"] = g.ndata["x"].to(dev)
+    g.csr(dev)
+    graphs.append(g)
+torch.cuda.synchronize()
+t_build = time.perf_counter() - t0
+n_nodes = sum(g.number_of_nodes() for g in graphs)
+n_edges = sum(g.number_of_edges() for g in graphs)
+
+hg = encode_candidates(model, graphs)          # warm-up (allocator, code objects)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+hg = encode_candidates(model, graphs)
+torch.cuda.synchronize()
+t_enc = time.perf_counter() - t0
+
+queries = tax.features[torch.from_numpy(test)].to(dev)
+cand_index = np.full(tax.n_nodes, -1, dtype=np.int64)
+cand_index[cand] = np.arange(len(cand))
+pos_lists = [cand_index[tax.par_idx[tax.par_ptr[q]:tax.par_ptr[q + 1]]] for q in test]
+pos_lists = [p[p >= 0] for p in pos_lists]
+U = ops.bilinear_project(hg, model.match.W.weight)
+S = torch.empty((args.qblock, len(cand)), dtype=torch.float32, device=dev)
+
+
+def run_scoring():
+    all_ranks = []
+    for q0 in range(0, len(test), args.qblock):
+        qb = queries[q0:q0 + args.qblock]
+        Sb = ops.score_block(qb, U, True, out=S[:qb.shape[0]])
+        pl = pos_lists[q0:q0 + qb.shape[0]]
+        off = torch.tensor(np.concatenate([[0], np.cumsum([len(p) for p in pl])]), dtype=torch.int32)
+        idx = torch.tensor(np.concatenate(pl) if pl else np.zeros(0), dtype=torch.int32)
+        all_ranks.append(ops.rank_block(Sb, off, idx, True))
+    return torch.cat(all_ranks)
+
+
+run_scoring()
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+ranks = run_scoring()
+torch.cuda.synchronize()
+t_score = time.perf_counter() - t0
+pairs = float(len(cand)) * len(test)
+print(json.dumps(dict(shape=args.shape, candidates=int(len(cand)), queries=int(len(test)), nodes=n_nodes, edges=n_edges,
+                      encoder_batches=len(graphs), host_taxonomy_s=t_tax, host_egonet_build_and_upload_s=t_build,
+                      encode_s=t_enc, encode_edges_per_s=n_edges / t_enc, score_and_rank_s=t_score,
+                      candidates_scored_per_s=pairs / t_score, candidates_scored_per_s_incl_encode=pairs / (t_score + t_enc),
+                      mean_rank=float(ranks.float().mean()), hbm_gb=torch.cuda.max_memory_allocated() / 1e9)))

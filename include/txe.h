@@ -103,6 +103,12 @@ int txe_readout_bwd(const int* graph_off, int G, const float* h, long long ld_h,
                     int D, const float* hg, const float* wsum, const float* d_hg, float* d_h, long long ld_dh, float* d_pw,
                     float* dpw_ws, void* stream);
 
+/* SumReadout (mode 1), MaxReadout (mode 2), ConcatReadout (mode 3: [G][3D]) -- model_zoo.py:244-276 */
+int txe_readout_multi_fwd(const int* graph_off, int G, const float* h, long long ld_h, const int* pos, int D, int mode, float* hg,
+                          int* argmax, void* stream);
+int txe_readout_multi_bwd(const int* graph_off, int G, const int* pos, int D, int mode, const float* d_hg, const int* argmax,
+                          float* d_h, long long ld_dh, void* stream);
+
 /* ---- matchers: BIM model_zoo.py:313, LBM :328 (apply_exp) ------------------------------------------------------- */
 int txe_bilinear_project(const float* e1, long long ld_e1, int G, int l, const float* W, int r, float* U, void* stream);
 int txe_bilinear_pair_fwd(const float* e1, long long ld_e1, const float* e2, long long ld_e2, int G, int l, int r,
@@ -111,6 +117,13 @@ size_t txe_bilinear_pair_bwd_ws_bytes(int G, int l, int r);
 int txe_bilinear_pair_bwd(const float* e1, long long ld_e1, const float* e2, long long ld_e2, int G, int l, int r,
                           const float* W, int apply_exp, const float* U, const float* s, const float* ds, float* d_e1,
                           long long ld_de1, float* d_e2, long long ld_de2, float* dW, void* ws, size_t ws_bytes, void* stream);
+/* nn.Linear over the (virtual) concat of two inputs + activation (0 none / 1 relu / 2 tanh): the MLP matcher, model_zoo.py:285-298 */
+int txe_linear_fwd(const float* x1, long long ld1, int l, const float* x2, long long ld2, int r, int G, const float* W, const float* b,
+                   int O, int act, float* y, void* stream);
+size_t txe_linear_bwd_ws_bytes(int G, int l, int r, int O);
+int txe_linear_bwd(const float* x1, long long ld1, int l, const float* x2, long long ld2, int r, int G, const float* W, int O, int act,
+                   const float* y, const float* dy, float* dx1, long long ld_dx1, float* dx2, long long ld_dx2, float* dW, float* db,
+                   void* ws, size_t ws_bytes, void* stream);
 /* ---- all-candidate scoring loop: test_fast.py:116-123 / infer.py:95-99.  U = txe_bilinear_project(hg, W) once, then
  * per query block S[q][g] = match(hg[g], Q[q]) for every candidate g. */
 int txe_score_block(const float* Q, long long ld_q, int nq, const float* U, int G, int r, int apply_exp, float* S,

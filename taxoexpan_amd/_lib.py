@@ -34,6 +34,11 @@ SIGNATURES = {
     "txe_gcn_aggregate_bwd": (I, [P, P, I, P, L, P, I, P, L, P, P, SZ, P]),
     "txe_readout_fwd": (I, [P, I, P, L, P, P, I, P, P, P]),
     "txe_readout_bwd": (I, [P, I, P, L, P, P, I, I, P, P, P, P, L, P, P, P]),
+    "txe_readout_multi_fwd": (I, [P, I, P, L, P, I, I, P, P, P]),
+    "txe_readout_multi_bwd": (I, [P, I, P, I, I, P, P, P, L, P]),
+    "txe_linear_fwd": (I, [P, L, I, P, L, I, I, P, P, I, I, P, P]),
+    "txe_linear_bwd_ws_bytes": (SZ, [I, I, I, I]),
+    "txe_linear_bwd": (I, [P, L, I, P, L, I, I, P, I, I, P, P, P, L, P, L, P, P, P, SZ, P]),
     "txe_bilinear_project": (I, [P, L, I, I, P, I, P, P]),
     "txe_bilinear_pair_fwd": (I, [P, L, P, L, I, I, I, P, I, P, P, P]),
     "txe_bilinear_pair_bwd_ws_bytes": (SZ, [I, I, I]),

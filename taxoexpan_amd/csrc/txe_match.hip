@@ -56,6 +56,40 @@ __global__ void reduce_splits_kernel2(const float* __restrict__ part, int S, lon
     }
 }
 
+// y[i][o] = act(y[i][o] + b[o])      act: 0 none, 1 relu, 2 tanh
+__global__ void bias_act_kernel(float* __restrict__ y, const float* __restrict__ b, long long n_rows, int O, int act) {
+    const long long n = n_rows * O;
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (long long)gridDim.x * blockDim.x) {
+        float v = y[t] + (b ? b[t % O] : 0.f);
+        if (act == 1) v = v > 0.f ? v : 0.f;
+        else if (act == 2) v = tanhf(v);
+        y[t] = v;
+    }
+}
+// dz = dy * act'(y)  (in terms of the activated output y), colsum partial for the bias gradient done by the caller
+__global__ void act_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y, long long n, int act, float* __restrict__ dz) {
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (long long)gridDim.x * blockDim.x) {
+        const float yv = y[t];
+        float g = 1.f;
+        if (act == 1) g = yv > 0.f ? 1.f : 0.f;
+        else if (act == 2) g = 1.f - yv * yv;
+        dz[t] = dy[t] * g;
+    }
+}
+__global__ void colsum_small_kernel(const float* __restrict__ x, long long n_rows, int O, float* __restrict__ out) {
+    __shared__ float red[256];
+    const int o = blockIdx.x;
+    float a = 0.f;
+    for (long long r = threadIdx.x; r < n_rows; r += blockDim.x) a += x[r * O + o];
+    red[threadIdx.x] = a;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[o] = red[0];
+}
+
 static inline size_t mt_align(size_t x) { return (x + 255) / 256 * 256; }
 
 static inline int mt_splits(int M, int N, int K) { return choose_splits(M, N, K); }
@@ -153,6 +187,75 @@ int txe_gemm_plain(int layout, const float* A, long long lda, const float* B, lo
     if (layout == 0) return gemm_nt(vmat_plain(A, lda, M, K), vmat_plain(B, ldb, N, K), E, M, N, K, splits, s, ws, ws_bytes);
     if (layout == 1) return gemm_nn(vmat_plain(A, lda, M, K), vmat_plain(B, ldb, K, N), E, M, N, K, splits, s, ws, ws_bytes);
     return gemm_tn(vmat_plain(A, lda, K, M), vmat_plain(B, ldb, K, N), E, M, N, K, splits, s, ws, ws_bytes);
+}
+
+// nn.Linear on the concatenation of up to two inputs, with activation (the MLP matcher, model_zoo.py:285-298):
+//   y[G][O] = act([x1 | x2] W^T + b),  W [O][l+r], x2/b optional, act 0 none / 1 relu / 2 tanh.  The concat is virtual (VMat).
+int txe_linear_fwd(const float* x1, long long ld1, int l, const float* x2, long long ld2, int r, int G, const float* W, const float* b,
+                   int O, int act, float* y, void* stream) {
+    if (G < 0 || l < 1 || r < 0 || O < 1 || !x1 || !W || !y || (r > 0 && !x2)) return TXE_ERR_ARG;
+    if (G == 0) return TXE_OK;
+    hipStream_t s = (hipStream_t)stream;
+    VMat A = vmat_plain(x1, ld1, G, l + r);
+    A.cols_main = l; A.p2 = x2; A.ld2 = ld2;
+    VMat B = vmat_plain(W, l + r, O, l + r);
+    Epi E = epi_plain(y, O, O);
+    int rc = gemm_nt(A, B, E, G, O, l + r, 1, s);
+    if (rc) return rc;
+    if (b || act) {
+        const long long n = (long long)G * O;
+        hipLaunchKernelGGL(bias_act_kernel, dim3((int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048)), dim3(256), 0, s, y, b, (long long)G, O, act);
+        TXE_CHECK_LAUNCH();
+    }
+    return TXE_OK;
+}
+
+size_t txe_linear_bwd_ws_bytes(int G, int l, int r, int O) {
+    return mt_align((size_t)(G > 0 ? G : 1) * O * 4) + mt_align((size_t)choose_splits(O, l + r, G) * O * (l + r) * 4);
+}
+
+// backward of txe_linear_fwd given dy and the activated output y: dx1 [G][l], dx2 [G][r] (NULL to skip), dW [O][l+r], db [O] (NULL ok)
+int txe_linear_bwd(const float* x1, long long ld1, int l, const float* x2, long long ld2, int r, int G, const float* W, int O, int act,
+                   const float* y, const float* dy, float* dx1, long long ld_dx1, float* dx2, long long ld_dx2, float* dW, float* db,
+                   void* ws, size_t ws_bytes, void* stream) {
+    if (G < 0 || l < 1 || r < 0 || O < 1 || !x1 || !W || !y || !dy || !dW || !ws || (r > 0 && !x2)) return TXE_ERR_ARG;
+    if (ws_bytes < txe_linear_bwd_ws_bytes(G, l, r, O)) return TXE_ERR_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    float* dz = (float*)ws;
+    float* part = (float*)((char*)ws + mt_align((size_t)(G > 0 ? G : 1) * O * 4));
+    const int K = l + r;
+    int rc;
+    if (G > 0) {
+        const long long n = (long long)G * O;
+        hipLaunchKernelGGL(act_bwd_kernel, dim3((int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048)), dim3(256), 0, s, dy, y, n, act, dz);
+        TXE_CHECK_LAUNCH();
+        if (db) {
+            hipLaunchKernelGGL(colsum_small_kernel, dim3(O), dim3(256), 0, s, (const float*)dz, (long long)G, O, db);
+            TXE_CHECK_LAUNCH();
+        }
+        if (dx1) {   // dx = dz W  -> split into the two inputs by the epilogue
+            VMat A = vmat_plain(dz, O, G, O);
+            VMat B = vmat_plain(W, K, O, K);
+            Epi E = epi_plain(dx1, ld_dx1, dx2 ? l : K);
+            if (dx2) { E.c2 = dx2; E.ldc2 = ld_dx2; }
+            rc = gemm_nn(A, B, E, G, dx2 ? K : l, O, 1, s);
+            if (rc) return rc;
+        }
+    }
+    const int S = choose_splits(O, K, G);
+    VMat A = vmat_plain(dz, O, G, O);
+    VMat B = vmat_plain(x1, ld1, G, K);
+    B.cols_main = l; B.p2 = x2; B.ld2 = ld2;
+    Epi E = epi_plain(part, K, K);
+    E.split_stride = (long long)O * K;
+    rc = gemm_tn(A, B, E, O, K, G, S, s);
+    if (rc) return rc;
+    const long long n = (long long)O * K;
+    hipLaunchKernelGGL(reduce_splits_kernel2, dim3((int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048)), dim3(256), 0, s, (const float*)part,
+                       G > 0 ? S : 0, E.split_stride, n, dW);
+    TXE_CHECK_LAUNCH();
+    if (db && G == 0) hipMemsetAsync(db, 0, (size_t)O * 4, s);
+    return TXE_OK;
 }
 
 // One block of the scoring loop: S[q][g] = <Q[q], U[g]> (exp optionally), q < nq, g < G.  S row stride ld_s.

@@ -168,6 +168,81 @@ __global__ void readout_dpw_reduce_kernel(const float* __restrict__ part, int G,
     if (threadIdx.x == 0) d_pw[c] = red[0] + red[1] + red[2] + red[3];
 }
 
+// ---- SumReadout / MaxReadout / ConcatReadout (model_zoo.py:244-276) ---------------------------------------------------
+// mode 1 SUM   : hg[g][d]       = sum_v h[v][d]
+// mode 2 MAX   : hg[g][d]       = max_v h[v][d]            (argmax[g][d] = first maximiser, for backward)
+// mode 3 CONCAT: hg[g][c*D + d] = sum_{v: pos_v == c} h[v][d] * s_c,  s_0 = s_2 = 1/n_g,  s_1 = 1/#{pos == 1}   (c < 3)
+// One wavefront per egonet, lane = feature column (scalar loads: these variants are API completeness, not the hot path).
+__global__ __launch_bounds__(RO_WAVES * 64) void readout_multi_fwd_kernel(const int* __restrict__ goff, const int G,
+                                                                          const float* __restrict__ h, const long long ld_h,
+                                                                          const int* __restrict__ pos, const int D, const int mode,
+                                                                          float* __restrict__ hg, int* __restrict__ argmax) {
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    const int g = blockIdx.x * RO_WAVES + w;
+    if (g >= G) return;
+    const int beg = goff[g], end = goff[g + 1];
+    float cnt1 = 0.f;
+    if (mode == 3) {
+        for (int v = beg + l; v < end; v += 64) cnt1 += (pos[v] == 1) ? 1.f : 0.f;
+        cnt1 = wave_sum(cnt1);
+    }
+    const float inv_n = 1.f / (float)(end - beg), inv_1 = 1.f / cnt1;
+    for (int d = l; d < D; d += 64) {
+        if (mode == 1) {
+            float a = 0.f;
+            for (int v = beg; v < end; ++v) a += h[(long long)v * ld_h + d];
+            hg[(long long)g * D + d] = a;
+        } else if (mode == 2) {
+            float a = -INFINITY;
+            int am = beg;
+            for (int v = beg; v < end; ++v) {
+                const float x = h[(long long)v * ld_h + d];
+                if (x > a) { a = x; am = v; }
+            }
+            hg[(long long)g * D + d] = a;
+            if (argmax) argmax[(long long)g * D + d] = am;
+        } else {
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+            for (int v = beg; v < end; ++v) {
+                const float x = h[(long long)v * ld_h + d];
+                const int pc = pos[v];
+                a0 += (pc == 0) ? x : 0.f;
+                a1 += (pc == 1) ? x : 0.f;
+                a2 += (pc == 2) ? x : 0.f;
+            }
+            hg[(long long)g * 3 * D + d] = a0 * inv_n;
+            hg[(long long)g * 3 * D + D + d] = a1 * inv_1;
+            hg[(long long)g * 3 * D + 2 * D + d] = a2 * inv_n;
+        }
+    }
+}
+
+__global__ __launch_bounds__(RO_WAVES * 64) void readout_multi_bwd_kernel(const int* __restrict__ goff, const int G,
+                                                                          const int* __restrict__ pos, const int D, const int mode,
+                                                                          const float* __restrict__ d_hg, const int* __restrict__ argmax,
+                                                                          float* __restrict__ d_h, const long long ld_dh) {
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    const int g = blockIdx.x * RO_WAVES + w;
+    if (g >= G) return;
+    const int beg = goff[g], end = goff[g + 1];
+    float cnt1 = 0.f;
+    if (mode == 3) {
+        for (int v = beg + l; v < end; v += 64) cnt1 += (pos[v] == 1) ? 1.f : 0.f;
+        cnt1 = wave_sum(cnt1);
+    }
+    const float inv_n = 1.f / (float)(end - beg), inv_1 = 1.f / cnt1;
+    for (int v = beg; v < end; ++v) {
+        const int pc = (mode == 3) ? pos[v] : 0;
+        for (int d = l; d < D; d += 64) {
+            float r;
+            if (mode == 1) r = d_hg[(long long)g * D + d];
+            else if (mode == 2) r = (argmax[(long long)g * D + d] == v) ? d_hg[(long long)g * D + d] : 0.f;
+            else r = (pc >= 0 && pc < 3) ? d_hg[(long long)g * 3 * D + (long long)pc * D + d] * (pc == 1 ? inv_1 : inv_n) : 0.f;
+            d_h[(long long)v * ld_dh + d] = r;
+        }
+    }
+}
+
 static inline int ro_pick_vec(int D, long long ld1, long long ld2, const void* a, const void* b, const void* c) {
     auto al = [](const void* p, int bytes) { return p == nullptr || ((uintptr_t)p % bytes) == 0; };
     if (D % 4 == 0 && ld1 % 4 == 0 && ld2 % 4 == 0 && al(a, 16) && al(b, 16) && al(c, 16)) return 4;
@@ -220,6 +295,29 @@ int txe_readout_bwd(const int* graph_off, int G, const float* h, long long ld_h,
         hipLaunchKernelGGL(readout_dpw_reduce_kernel, dim3(vocab), dim3(256), 0, s, (const float*)dpw_ws, G, vocab, d_pw);
         TXE_CHECK_LAUNCH();
     }
+    return TXE_OK;
+}
+
+// SumReadout (mode 1), MaxReadout (mode 2), ConcatReadout (mode 3) -- model_zoo.py:244-276.  hg is [G][D] ([G][3D] for mode 3);
+// argmax [G][D] int32 is written in mode 2 (may be NULL in inference) and read by the backward.
+int txe_readout_multi_fwd(const int* graph_off, int G, const float* h, long long ld_h, const int* pos, int D, int mode, float* hg,
+                          int* argmax, void* stream) {
+    if (G < 0 || D < 1 || mode < 1 || mode > 3 || !graph_off || !h || !hg || (mode == 3 && !pos)) return TXE_ERR_ARG;
+    if (G == 0) return TXE_OK;
+    hipLaunchKernelGGL(readout_multi_fwd_kernel, dim3((G + RO_WAVES - 1) / RO_WAVES), dim3(RO_WAVES * 64), 0, (hipStream_t)stream,
+                       graph_off, G, h, ld_h, pos, D, mode, hg, argmax);
+    TXE_CHECK_LAUNCH();
+    return TXE_OK;
+}
+
+int txe_readout_multi_bwd(const int* graph_off, int G, const int* pos, int D, int mode, const float* d_hg, const int* argmax,
+                          float* d_h, long long ld_dh, void* stream) {
+    if (G < 0 || D < 1 || mode < 1 || mode > 3 || !graph_off || !d_hg || !d_h || (mode == 3 && !pos) || (mode == 2 && !argmax))
+        return TXE_ERR_ARG;
+    if (G == 0) return TXE_OK;
+    hipLaunchKernelGGL(readout_multi_bwd_kernel, dim3((G + RO_WAVES - 1) / RO_WAVES), dim3(RO_WAVES * 64), 0, (hipStream_t)stream,
+                       graph_off, G, pos, D, mode, d_hg, argmax, d_h, ld_dh);
+    TXE_CHECK_LAUNCH();
     return TXE_OK;
 }
 

@@ -5,7 +5,7 @@ like the reference's `assert "<string>"` (model/model.py:43,58,67)."""
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .model_zoo import BIM, GAT, GCN, LBM, PGAT, PGCN, MeanReadout, WeightedMeanReadout
+from .model_zoo import BIM, GAT, GCN, LBM, MLP, PGAT, PGCN, ConcatReadout, MeanReadout, WeightedMeanReadout
 
 
 class TaxoExpan(nn.Module):
@@ -38,8 +38,13 @@ class TaxoExpan(nn.Module):
         elif readout_method == "WMR":
             self.readout = WeightedMeanReadout()
             l_dim, r_dim = o["out_dim"], o["in_dim"]
+        elif readout_method == "CR":
+            self.readout = ConcatReadout()
+            l_dim, r_dim = o["out_dim"] * 3, o["in_dim"]
 
-        if matching_method == "LBM":
+        if matching_method == "MLP":
+            self.match = MLP(l_dim, r_dim, o["hidden_dim"])
+        elif matching_method == "LBM":
             self.match = LBM(l_dim, r_dim)
         elif matching_method == "BIM":
             self.match = BIM(l_dim, r_dim)

@@ -8,6 +8,8 @@ libtxe (include/txe.h) instead of DGL + torch.
     GCN/PGCN   model_zoo.py:116-167      GCN/PGCN   -> one fused GCNStackFunction over all layers
     GAT/PGAT   model_zoo.py:169-220      GAT/PGAT   -> one fused GATStackFunction over all layers
     MeanReadout/WeightedMeanReadout      model_zoo.py:227-242 -> txe_readout_*
+    ConcatReadout/SumReadout/MaxReadout  model_zoo.py:244-276 -> txe_readout_multi_*
+    MLP        model_zoo.py:281-298      MLP        -> txe_linear_*  (NTN :331-346 is not reachable from model.py and not provided)
     BIM/LBM    model_zoo.py:301-328      BIM/LBM    -> txe_bilinear_pair_*  (+ score_all for the eval loop)
 Graph argument: a taxoexpan_amd.graph.(Batched)DGLGraph -- the DGL-0.4 surface of the reference's loaders.
 Side effects the callers rely on are kept: PGAT/PGCN pop g.ndata['pos'] (model_zoo.py:163,212); WeightedMeanReadout
@@ -266,6 +268,36 @@ class WeightedMeanReadout(nn.Module):
         return ops.ReadoutFunction.apply(g.csr(h.device), h, pos, self.position_weights.weight)
 
 
+class ConcatReadout(nn.Module):
+    def __init__(self):
+        super(ConcatReadout, self).__init__()
+
+    def forward(self, g, pos):
+        """model_zoo.py:248-258: [sum_{pos=0} h / n, mean_{pos=1} h, sum_{pos=2} h / n]"""
+        h = g.ndata['h']
+        return ops.ReadoutMultiFunction.apply(g.csr(h.device), h, pos, 3)
+
+
+class SumReadout(nn.Module):
+    def __init__(self):
+        super(SumReadout, self).__init__()
+
+    def forward(self, g):
+        """model_zoo.py:265-267"""
+        h = g.ndata['h']
+        return ops.ReadoutMultiFunction.apply(g.csr(h.device), h, None, 1)
+
+
+class MaxReadout(nn.Module):
+    def __init__(self):
+        super(MaxReadout, self).__init__()
+
+    def forward(self, g):
+        """model_zoo.py:274-276"""
+        h = g.ndata['h']
+        return ops.ReadoutMultiFunction.apply(g.csr(h.device), h, None, 2)
+
+
 class _LazyPositionWeight:
     """g.ndata['a'] of model_zoo.py:241 (softplus(Emb[pos])) -- nobody on the hot path reads it, so it is only
     materialised if a caller asks (`.tensor()`)."""
@@ -280,6 +312,22 @@ class _LazyPositionWeight:
 # ---------------------------------------------------------------------------------------------------------------
 # Matchers
 # ---------------------------------------------------------------------------------------------------------------
+class MLP(nn.Module):
+    def __init__(self, l_dim, r_dim, hidden_dim):
+        super(MLP, self).__init__()
+        activation = nn.ReLU()
+        self.ffn = nn.Sequential(          # parameter container: same names / shapes / init as the reference (model_zoo.py:285-289)
+            nn.Linear(l_dim + r_dim, hidden_dim),
+            activation,
+            nn.Linear(hidden_dim, 1)
+        )
+
+    def forward(self, e1, e2):
+        """model_zoo.py:291-298: ffn(cat(e1, e2)); the concat is synthesised by the GEMM's operand loader"""
+        hid = ops.LinearFunction.apply(e1, e2, self.ffn[0].weight, self.ffn[0].bias, 1)
+        return ops.LinearFunction.apply(hid, None, self.ffn[2].weight, self.ffn[2].bias, 0)
+
+
 class _Bilinear(nn.Module):
     apply_exp = False
 

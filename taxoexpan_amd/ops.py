@@ -352,6 +352,73 @@ class ReadoutFunction(torch.autograd.Function):
         return None, d_h, None, (d_pw.reshape(ctx.pw_shape) if d_pw is not None else None)
 
 
+class ReadoutMultiFunction(torch.autograd.Function):
+    """mode 1 SumReadout, 2 MaxReadout, 3 ConcatReadout (model_zoo.py:244-276)"""
+
+    @staticmethod
+    def forward(ctx, csr, h, pos, mode):
+        _need_cuda(h)
+        h, ld_h = _rows(h)
+        G, D = csr.n_graphs, h.shape[1]
+        pos = _i32(pos, h.device) if mode == 3 else None
+        hg = _empty((G, 3 * D if mode == 3 else D), h)
+        argmax = torch.empty((max(G, 1), D), dtype=torch.int32, device=h.device) if mode == 2 else None
+        with torch.cuda.device(h.device):
+            call("txe_readout_multi_fwd", ptr(csr.graph_off), G, ptr(h), ld_h, ptr(pos), D, mode, ptr(hg), ptr(argmax), _lib.stream_ptr())
+        ctx.misc = (csr, pos, mode, argmax, h.shape[0], D)
+        return hg
+
+    @staticmethod
+    def backward(ctx, d_hg):
+        csr, pos, mode, argmax, N, D = ctx.misc
+        d_hg = _f32(d_hg)
+        d_h = _empty((N, D), d_hg)
+        with torch.cuda.device(d_hg.device):
+            call("txe_readout_multi_bwd", ptr(csr.graph_off), csr.n_graphs, ptr(pos), D, mode, ptr(d_hg), ptr(argmax), ptr(d_h), D,
+                 _lib.stream_ptr())
+        return None, d_h, None, None
+
+
+class LinearFunction(torch.autograd.Function):
+    """y = act([x1 | x2] W^T + b): nn.Linear over a virtual concat (the MLP matcher, model_zoo.py:285-298); act 0/1 relu/2 tanh"""
+
+    @staticmethod
+    def forward(ctx, x1, x2, W, b, act):
+        _need_cuda(x1, x2, W, b)
+        x1, ld1 = _rows(x1)
+        l = x1.shape[1]
+        if x2 is not None:
+            x2, ld2 = _rows(x2)
+            r = x2.shape[1]
+        else:
+            ld2, r = 0, 0
+        Wf, bf = _f32(W), _f32(b)
+        G, O = x1.shape[0], Wf.shape[0]
+        y = _empty((G, O), x1)
+        with torch.cuda.device(x1.device):
+            call("txe_linear_fwd", ptr(x1), ld1, l, ptr(x2), ld2, r, G, ptr(Wf), ptr(bf), O, int(act), ptr(y), _lib.stream_ptr())
+        ctx.misc = (x1, ld1, l, x2, ld2, r, Wf, bf is not None, int(act), y)
+        ctx.req = (ctx.needs_input_grad[0], ctx.needs_input_grad[1])
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x1, ld1, l, x2, ld2, r, Wf, has_b, act, y = ctx.misc
+        dy = _f32(dy)
+        G, O = y.shape
+        need1, need2 = ctx.req
+        dx1 = _empty((G, l), y) if (need1 or need2) else None
+        dx2 = _empty((G, r), y) if (need2 and x2 is not None) else None
+        dW = torch.empty_like(Wf)
+        db = _empty((O,), y) if has_b else None
+        with torch.cuda.device(y.device):
+            wsb = call("txe_linear_bwd_ws_bytes", G, l, r, O)
+            ws = _ws(wsb, y)
+            call("txe_linear_bwd", ptr(x1), ld1, l, ptr(x2), ld2, r, G, ptr(Wf), O, act, ptr(y), ptr(dy), ptr(dx1), l, ptr(dx2), r, ptr(dW),
+                 ptr(db), ptr(ws), wsb, _lib.stream_ptr())
+        return (dx1 if need1 else None), (dx2 if need2 else None), dW, db, None
+
+
 # ================================================================================================================
 # Bilinear match (BIM / LBM) -- pairwise form of training, model.py:86
 # ================================================================================================================

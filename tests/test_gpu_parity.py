@@ -35,7 +35,7 @@ def _graph(shapes):
     return BatchedDGLGraph.from_egonet_shapes([s[0] for s in shapes], [s[1] for s in shapes])
 
 
-NODROP = [n for n, s in gc.CASES.items() if s["match"] != "MLP" and not s.get("dropout")]
+NODROP = [n for n, s in gc.CASES.items() if not s.get("dropout")]       # includes the ConcatReadout + MLP case
 
 
 @pytest.mark.parametrize("name", NODROP)
@@ -348,3 +348,25 @@ def test_sharded_scoring_single_rank_rccl():
     finally:
         if created:
             dist.destroy_process_group()
+
+
+def test_sum_max_readouts_against_oracle():
+    from taxoexpan_amd.graph import BatchedDGLGraph
+    from taxoexpan_amd.model_zoo import MaxReadout, SumReadout
+    rs = np.random.RandomState(11)
+    shapes = [(0, 0), (2, 3), (1, 50), (3, 0), (0, 7)] * 3
+    g = BatchedDGLGraph.from_egonet_shapes([s[0] for s in shapes], [s[1] for s in shapes])
+    graph = orc.batch_egonets(shapes)
+    N, D = g.number_of_nodes(), 37
+    h = torch.from_numpy(rs.standard_normal((N, D)).astype(np.float32))
+    w = torch.from_numpy(rs.standard_normal((len(shapes), D)).astype(np.float32))
+    for mod, ref_fn in ((SumReadout(), orc.sum_readout), (MaxReadout(), orc.max_readout)):
+        hd = h.to(_dev()).requires_grad_(True)
+        g.ndata["h"] = hd
+        out = mod(g)
+        (out * w.to(_dev())).sum().backward()
+        hc = h.clone().requires_grad_(True)
+        ref = ref_fn(graph["graph_off"], hc)
+        (ref * w).sum().backward()
+        np.testing.assert_allclose(out.detach().cpu().numpy(), ref.detach().numpy(), rtol=RT, atol=AT)
+        np.testing.assert_allclose(hd.grad.cpu().numpy(), hc.grad.numpy(), rtol=1e-4, atol=1e-6)

@@ -80,13 +80,17 @@ int txe_head_mean_fwd(const float* x, int H, int D, long long n_rows, float* y, 
 int txe_head_mean_bwd(const float* dy, int H, int D, long long n_rows, float* dx, void* stream);
 
 /* ---- GCNLayer: model_zoo.py:34-50 and the norm of :157-161 ------------------------------------------------------ */
-size_t txe_gcn_project_ws_bytes(int n_nodes, int Kh, int Pd, int Fo, int vocab);
-int txe_gcn_project_fwd(const float* h, long long ld_h, int n_nodes, int Kh, const int* pos, const float* P, int Pd,
-                        const float* W, int Fo, float drop_p, const unsigned* mask, float* hw, void* stream);
-int txe_gcn_project_bwd(const float* h, long long ld_h, int n_nodes, int Kh, const int* pos, const float* P, int Pd, int vocab,
-                        const float* W, int Fo, float drop_p, const unsigned* mask, const float* d_hw, float* d_h,
-                        long long ld_dh, const float* act_src, long long ld_act, float act_slope, float* dW, float* dP,
-                        void* ws, size_t ws_bytes, void* stream);
+/* dense part on padded operands (as for GAT): Wp [roundup(Kp,128)][Fop] = weight [Kt][Fo] zero padded, Fop = roundup(Fo,32) =
+ * txe_gcn_padded_f; hw / d_hw [N][Fop] (d_hw with zero padding columns).  txe_gcn_dense_bwd writes d_X [N][Kp] columns [c0,Kt)
+ * exactly like txe_gat_dense_bwd, dW [Kt][Fo] and dP [vocab][Pd]. */
+int txe_gcn_padded_f(int Fo);
+int txe_gcn_pack_weights(const float* W, int Kt, int Fo, float* Wp, void* stream);
+size_t txe_gcn_dense_ws_bytes(int n_nodes, int Kh, int Pd, int Fo, int vocab);
+int txe_gcn_dense_fwd(const float* X, int n_nodes, int Kh, int Pd, const float* Wp, int Fo, float drop_p, const unsigned* mask,
+                      float* hw, void* ws, size_t ws_bytes, void* stream);
+int txe_gcn_dense_bwd(const float* X, int n_nodes, int Kh, int Pd, const int* pos, int vocab, const float* Wp, int Fo, float drop_p,
+                      const unsigned* mask, const float* d_hw, int need_dh, int act_on, float act_slope, float* d_X, float* dW,
+                      float* dP, void* ws, size_t ws_bytes, void* stream);
 int txe_gcn_norm(const int* rowptr_in, int n_nodes, float* norm, void* stream);
 int txe_gcn_aggregate_fwd(const int* rowptr_in, const int* col_src, int n_nodes, const float* hw, long long ld_hw,
                           const float* norm, const float* bias, int has_act, float act_slope, int F, float* out, long long ld_out,

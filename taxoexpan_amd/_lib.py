@@ -25,9 +25,11 @@ SIGNATURES = {
     "txe_leaky_relu_bwd": (I, [P, P, F, L, P, P]),
     "txe_head_mean_fwd": (I, [P, I, I, L, P, P]),
     "txe_head_mean_bwd": (I, [P, I, I, L, P, P]),
-    "txe_gcn_project_ws_bytes": (SZ, [I, I, I, I, I]),
-    "txe_gcn_project_fwd": (I, [P, L, I, I, P, P, I, P, I, F, P, P, P]),
-    "txe_gcn_project_bwd": (I, [P, L, I, I, P, P, I, I, P, I, F, P, P, P, L, P, L, F, P, P, P, SZ, P]),
+    "txe_gcn_padded_f": (I, [I]),
+    "txe_gcn_pack_weights": (I, [P, I, I, P, P]),
+    "txe_gcn_dense_ws_bytes": (SZ, [I, I, I, I, I]),
+    "txe_gcn_dense_fwd": (I, [P, I, I, I, P, I, F, P, P, P, SZ, P]),
+    "txe_gcn_dense_bwd": (I, [P, I, I, I, P, I, P, I, F, P, P, I, I, F, P, P, P, P, SZ, P]),
     "txe_gcn_norm": (I, [P, I, P, P]),
     "txe_gcn_aggregate_fwd": (I, [P, P, I, P, L, P, P, I, F, I, P, L, P]),
     "txe_gcn_aggregate_bwd_ws_bytes": (SZ, [I, I]),
@@ -58,7 +60,7 @@ SIGNATURES = {
 }
 
 _ERR = {-1: "TXE_ERR_ARG", -2: "TXE_ERR_LAUNCH", -3: "TXE_ERR_WORKSPACE"}
-VALUE_RETURNING = {"txe_gat_padded_k", "txe_gat_padded_f", "txe_profile_count"}   # int results that are not status codes
+VALUE_RETURNING = {"txe_gat_padded_k", "txe_gat_padded_f", "txe_gcn_padded_f", "txe_profile_count"}   # int results that are not status codes
 
 _lib = None
 

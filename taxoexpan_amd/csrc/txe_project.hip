@@ -146,50 +146,9 @@ __global__ __launch_bounds__(256) void pos_segsum_stage2(const float* __restrict
 
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
-static VMat make_xcat(const float* h, long long ld_h, int n, int Kh, const int* pos, const float* P, int Pd, float drop_p,
-                      const unsigned* mask) {
-    VMat m = vmat_plain(h, ld_h, n, Kh + Pd);
-    m.cols_main = Kh;
-    m.p2 = P; m.ld2 = Pd; m.pos = pos;
-    vmat_set_mask(m, mask, drop_p);
-    return m;
-}
-
 __global__ void dropout_mask_kernel(long long n_words, unsigned long long seed, unsigned thr16, unsigned* __restrict__ mask) {
     for (long long w = (long long)blockIdx.x * blockDim.x + threadIdx.x; w < n_words; w += (long long)gridDim.x * blockDim.x)
         mask[w] = drop_mask_word(seed, (unsigned long long)w, thr16);
-}
-
-struct ProjectWs {
-    float* wa;      // [2H][Kt]
-    float* dwa;     // [2H][Kt]
-    float* dxp;     // [N][Pd]
-    float* ppart;   // [nb][vocab][Pd]
-    float* part;    // [S][(F+2H)][Kt]
-    void* tail;     // GEMM tail-splitting workspace
-    size_t tail_bytes;
-    int splits, seg_blocks, seg_rows;
-    size_t total;
-};
-
-static ProjectWs plan_ws(void* ws, int n, int F, int H2, int Kt, int Pd, int vocab) {
-    ProjectWs p;
-    char* b = (char*)ws;
-    size_t off = 0;
-    auto take = [&](size_t bytes) { float* r = (float*)(b + off); off += align_up(bytes, 256); return r; };
-    p.wa = take((size_t)H2 * Kt * 4);
-    p.dwa = take((size_t)H2 * Kt * 4);
-    p.dxp = take((size_t)n * (Pd > 0 ? Pd : 1) * 4);
-    p.seg_rows = 64;
-    p.seg_blocks = (n + p.seg_rows - 1) / p.seg_rows;
-    if (p.seg_blocks < 1) p.seg_blocks = 1;
-    p.ppart = take((size_t)p.seg_blocks * (vocab > 0 ? vocab : 1) * (Pd > 0 ? Pd : 1) * 4);
-    p.splits = choose_splits(F + H2, Kt, n);
-    p.part = take((size_t)p.splits * (F + H2) * Kt * 4);
-    p.tail_bytes = gemm_tail_ws_bytes();
-    p.tail = take(p.tail_bytes);
-    p.total = off;
-    return p;
 }
 
 }  // namespace txe
@@ -418,70 +377,101 @@ int txe_zero_cols(float* x, long long ld, int n_rows, int c0, int c1, void* stre
 
 
 // ---------------------------------------------------------------------------------------------
-// GCN projection (model_zoo.py:35-37):  hw = dropout(cat(x, P[pos])) @ W,  W is [Kt][Fo] row-major.
+// GCNLayer dense part (model_zoo.py:35-37) on padded operands:  hw = dropout(X) Wp,
+//   X  [N][Kp]       as for GAT (txe_gat_build_x),
+//   Wp [Kp128][Fop]  = weight [Kt][Fo] zero-padded, Kp128 = roundup(Kp,128), Fop = roundup(Fo,32),
+//   hw / d_hw [N][Fop]  (d_hw with ZERO padding columns).
 // ---------------------------------------------------------------------------------------------
-size_t txe_gcn_project_ws_bytes(int n_nodes, int Kh, int Pd, int Fo, int vocab) {
-    return plan_ws(nullptr, n_nodes, Kh + Pd, 0, Fo, Pd, vocab).total;
+int txe_gcn_padded_f(int Fo) { return round_up(Fo, 32); }
+
+int txe_gcn_pack_weights(const float* W, int Kt, int Fo, float* Wp, void* stream) {
+    if (!W || !Wp || Kt < 1 || Fo < 1) return TXE_ERR_ARG;
+    const int Kp128 = round_up(round_up(Kt, 32), 128), Fop = round_up(Fo, 32);
+    const long long n = (long long)Kp128 * Fop;
+    // pack_w_kernel(W, F=rows, Fe=rows, Fp=padded rows, Kt=cols, Kp=padded cols)
+    hipLaunchKernelGGL(pack_w_kernel, dim3((int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048)), dim3(256), 0, (hipStream_t)stream, W, Kt,
+                       Kt, Kp128, Fo, Fop, Wp);
+    TXE_CHECK_LAUNCH();
+    return TXE_OK;
 }
 
-int txe_gcn_project_fwd(const float* h, long long ld_h, int n_nodes, int Kh, const int* pos, const float* P, int Pd,
-                        const float* W, int Fo, float drop_p, const unsigned* mask, float* hw, void* stream) {
-    if (n_nodes < 0 || Kh < 1 || Pd < 0 || Fo < 1 || !h || !W || !hw) return TXE_ERR_ARG;
-    if (Pd > 0 && (!pos || !P)) return TXE_ERR_ARG;
+size_t txe_gcn_dense_ws_bytes(int n_nodes, int Kh, int Pd, int Fo, int vocab) {
+    return plan_dense_ws(nullptr, n_nodes, round_up(Kh + Pd, 32), 0, round_up(Fo, 32), Pd, vocab).total;
+}
+
+int txe_gcn_dense_fwd(const float* X, int n_nodes, int Kh, int Pd, const float* Wp, int Fo, float drop_p, const unsigned* mask,
+                      float* hw, void* ws, size_t ws_bytes, void* stream) {
+    if (n_nodes < 0 || Kh < 1 || Pd < 0 || Fo < 1 || !X || !Wp || !hw) return TXE_ERR_ARG;
     if (drop_p < 0.f || drop_p >= 1.f) return TXE_ERR_ARG;
     if (n_nodes == 0) return TXE_OK;
-    const int Kt = Kh + Pd;
-    VMat A = make_xcat(h, ld_h, n_nodes, Kh, pos, P, Pd, drop_p, mask);
-    VMat B = vmat_plain(W, Fo, Kt, Fo);
-    Epi E = epi_plain(hw, Fo, Fo);
-    return gemm_nn(A, B, E, n_nodes, Fo, Kt, 1, (hipStream_t)stream);
+    const int Kp = round_up(Kh + Pd, 32), Fop = round_up(Fo, 32);
+    VMat A = vmat_plain(X, Kp, n_nodes, Kp);
+    vmat_set_mask(A, mask, drop_p);
+    VMat B = vmat_plain(Wp, Fop, Kp, Fop);
+    Epi E = epi_plain(hw, Fop, Fo);
+    const bool tail_ok = ws && ws_bytes >= gemm_tail_ws_bytes();
+    return gemm_nn(A, B, E, n_nodes, Fo, Kp, 1, (hipStream_t)stream, tail_ok ? ws : nullptr, tail_ok ? ws_bytes : 0);
 }
 
-int txe_gcn_project_bwd(const float* h, long long ld_h, int n_nodes, int Kh, const int* pos, const float* P, int Pd, int vocab,
-                        const float* W, int Fo, float drop_p, const unsigned* mask, const float* d_hw, float* d_h,
-                        long long ld_dh, const float* act_src, long long ld_act, float act_slope, float* dW, float* dP,
-                        void* ws, size_t ws_bytes, void* stream) {
-    if (n_nodes < 0 || Kh < 1 || Pd < 0 || Fo < 1 || !h || !W || !d_hw || !dW || !ws) return TXE_ERR_ARG;
-    if (Pd > 0 && (!pos || !P || !dP || vocab < 1 || vocab > MAX_VOCAB)) return TXE_ERR_ARG;
+// dW[k][f] = sum_s part[s][k][f]  (k < Kt, f < Fo; part rows have stride ldp)
+__global__ void reduce_splits_sub_kernel(const float* __restrict__ part, int S, long long stride, int rows, int cols, int ldp,
+                                         float* __restrict__ out) {
+    const long long n = (long long)rows * cols;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const long long r = i / cols;
+        const int c = (int)(i % cols);
+        float acc = 0.f;
+        for (int s = 0; s < S; ++s) acc += part[(long long)s * stride + r * ldp + c];
+        out[i] = acc;
+    }
+}
+
+// d_hw [N][Fop] with zero padding columns.  Writes d_X columns [c0, Kt) (as txe_gat_dense_bwd), dW [Kt][Fo], dP.
+int txe_gcn_dense_bwd(const float* X, int n_nodes, int Kh, int Pd, const int* pos, int vocab, const float* Wp, int Fo, float drop_p,
+                      const unsigned* mask, const float* d_hw, int need_dh, int act_on, float act_slope, float* d_X, float* dW,
+                      float* dP, void* ws, size_t ws_bytes, void* stream) {
+    if (n_nodes < 0 || Kh < 1 || Pd < 0 || Fo < 1 || !X || !Wp || !d_hw || !dW || !ws) return TXE_ERR_ARG;
+    if ((need_dh || Pd > 0) && !d_X) return TXE_ERR_ARG;
+    if (Pd > 0 && (!pos || !dP || vocab < 1 || vocab > MAX_VOCAB)) return TXE_ERR_ARG;
     if (drop_p < 0.f || drop_p >= 1.f) return TXE_ERR_ARG;
-    const int Kt = Kh + Pd;
-    ProjectWs p = plan_ws(ws, n_nodes, Kt, 0, Fo, Pd, vocab);   // part: [S][Kt][Fo]
+    const int Kt = Kh + Pd, Kp = round_up(Kt, 32), Fop = round_up(Fo, 32);
+    DenseWs p = plan_dense_ws(ws, n_nodes, Kp, 0, Fop, Pd, vocab);          // part: [S][Kp][Fop]
     if (ws_bytes < p.total) return TXE_ERR_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
     int rc;
-    VMat G = vmat_plain(d_hw, Fo, n_nodes, Fo);
-    // dXcat[m][c] = sum_fo d_hw[m][fo] * W[c][fo]   (NT), columns [c0, Kt)
-    const int c0 = d_h ? 0 : Kh;
-    if (Kt - c0 > 0 && n_nodes > 0) {
-        VMat B = vmat_plain(W + (long long)c0 * Fo, Fo, Kt - c0, Fo);
-        Epi E = epi_plain(d_h, ld_dh, Kh - c0);
-        E.c2 = p.dxp; E.ldc2 = Pd;
+    const int c0 = need_dh ? 0 : (Kh / 4) * 4;
+    if (Kt - c0 > 0 && n_nodes > 0 && (need_dh || Pd > 0)) {
+        // d_X[m][c] = sum_f d_hw[m][f] * Wp[c][f]     (NT; Wp rows are padded to a multiple of 128, so every tile is plain)
+        VMat A = vmat_plain(d_hw, Fop, n_nodes, Fop);
+        VMat B = vmat_plain(Wp + (long long)c0 * Fop, Fop, round_up(Kp, 128) - c0, Fop);
+        Epi E = epi_plain(d_X + c0, Kp, Kh > c0 ? Kh - c0 : 0);
+        E.c2 = d_X + c0 + E.cols_main; E.ldc2 = Kp;
         epi_set_mask(E, mask, Kt, c0, drop_p);
-        if (d_h) epi_set_act(E, act_src, ld_act, act_slope);
-        rc = gemm_nt(G, B, E, n_nodes, Kt - c0, Fo, 1, s, p.tail, p.tail_bytes);
+        if (act_on && need_dh) epi_set_act(E, X + c0, Kp, act_slope);
+        rc = gemm_nt(A, B, E, n_nodes, Kt - c0, Fop, 1, s, p.tail, p.tail_bytes);
         if (rc) return rc;
     }
     if (Pd > 0) {
         if (n_nodes > 0) {
-            hipLaunchKernelGGL(pos_segsum_stage1, dim3(p.seg_blocks), dim3(256), 0, s, (const float*)p.dxp, (long long)Pd, pos,
-                               n_nodes, Pd, vocab, p.seg_rows, p.ppart);
+            hipLaunchKernelGGL(pos_segsum_stage1, dim3(p.seg_blocks), dim3(256), 0, s, (const float*)(d_X + Kh), (long long)Kp, pos, n_nodes,
+                               Pd, vocab, p.seg_rows, p.ppart);
             TXE_CHECK_LAUNCH();
         }
         hipLaunchKernelGGL(pos_segsum_stage2, dim3((vocab * Pd + 63) / 64), dim3(256), 0, s, (const float*)p.ppart,
                            n_nodes > 0 ? p.seg_blocks : 0, vocab, Pd, dP);
         TXE_CHECK_LAUNCH();
     }
-    // dW[kt][fo] = sum_m Xcat[m][kt] * d_hw[m][fo]   (TN, split-K over nodes)
-    {
-        VMat X = make_xcat(h, ld_h, n_nodes, Kh, pos, P, Pd, drop_p, mask);
-        Epi E = epi_plain(p.part, Fo, Fo);
-        E.split_stride = (long long)Kt * Fo;
-        rc = gemm_tn(X, G, E, Kt, Fo, n_nodes, p.splits, s);
+    {   // dWp[k][f] = sum_m dropout(X)[m][k] * d_hw[m][f]
+        VMat A = vmat_plain(X, Kp, n_nodes, Kp);
+        vmat_set_mask(A, mask, drop_p);
+        VMat B = vmat_plain(d_hw, Fop, n_nodes, Fop);
+        Epi E = epi_plain(p.part, Fop, Fop);
+        E.split_stride = (long long)Kp * Fop;
+        rc = gemm_tn(A, B, E, Kp, Fop, n_nodes, p.splits, s);
         if (rc) return rc;
         const long long n = (long long)Kt * Fo;
-        const int nb = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
-        hipLaunchKernelGGL(reduce_splits_kernel, dim3(nb), dim3(256), 0, s, (const float*)p.part, n_nodes > 0 ? p.splits : 0,
-                           E.split_stride, n, dW);
+        hipLaunchKernelGGL(reduce_splits_sub_kernel, dim3((int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048)), dim3(256), 0, s,
+                           (const float*)p.part, n_nodes > 0 ? p.splits : 0, E.split_stride, Kt, Fo, Fop, dW);
         TXE_CHECK_LAUNCH();
     }
     return TXE_OK;

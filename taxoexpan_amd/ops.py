@@ -240,6 +240,10 @@ def gcn_norm(csr, ref):
     return norm
 
 
+class _GcnLayerState:
+    __slots__ = ("X", "Wp", "mask", "W", "b", "P", "Kh", "Pd", "Kp", "Fo", "Fop", "seed")
+
+
 class GCNStackFunction(torch.autograd.Function):
     """params per layer: (W [Kin, Fo], bias [Fo] or None, P [vocab, Pd] or None)."""
 
@@ -250,71 +254,95 @@ class GCNStackFunction(torch.autograd.Function):
         pos = _i32(pos, h.device)
         L = cfg.n_layers
         need = any(ctx.needs_input_grad)       # (grad mode itself is off inside Function.forward)
-        saved = []
-        x, ldx = h, ld_h
+        N = h.shape[0]
+        states = []
         with torch.cuda.device(h.device):
-            st = _lib.stream_ptr()
+            st_ = _lib.stream_ptr()
             norm = gcn_norm(csr, h)
+            kh = h.shape[1]
             for l in range(L):
-                W, b, P = (_f32(p) for p in params[3 * l:3 * l + 3])
-                N, Kh = x.shape
-                Pd = 0 if P is None else P.shape[1]
-                Fo = cfg.out_dims[l]
-                hw = _empty((N, Fo), x)
-                mask = dropout_mask(N, Kh + Pd, cfg.drop_ps[l], cfg.seed + 16 * l, x)
-                call("txe_gcn_project_fwd", ptr(x), ldx, N, Kh, ptr(pos if P is not None else None), ptr(P), Pd, ptr(W), Fo,
-                     cfg.drop_ps[l], ptr(mask), ptr(hw), st)
-                out = _empty((N, Fo), x)
+                st = _GcnLayerState()
+                st.W, st.b, st.P = (_f32(p) for p in params[3 * l:3 * l + 3])
+                st.Kh, st.Fo = kh, cfg.out_dims[l]
+                st.Pd = 0 if st.P is None else st.P.shape[1]
+                st.Kp = call("txe_gat_padded_k", st.Kh, st.Pd)
+                st.Fop = call("txe_gcn_padded_f", st.Fo)
+                st.seed = cfg.seed + 16 * l
+                st.X = None
+                states.append(st)
+                kh = st.Fo
+            states[0].X = _empty((N, states[0].Kp), h)
+            tws = _tail_ws(h)
+            for l, st in enumerate(states):
+                last = (l == L - 1)
+                call("txe_gat_build_x", ptr(h if l == 0 else None), ld_h if l == 0 else 0, N, st.Kh, ptr(pos if st.P is not None else None),
+                     ptr(st.P), st.Pd, ptr(st.X), st_)
+                kp128 = (st.Kp + 127) // 128 * 128
+                st.Wp = _empty((kp128, st.Fop), h)
+                call("txe_gcn_pack_weights", ptr(st.W), st.Kh + st.Pd, st.Fo, ptr(st.Wp), st_)
+                st.mask = dropout_mask(N, st.Kh + st.Pd, cfg.drop_ps[l], st.seed, h)
+                hw = _empty((N, st.Fop), h)
+                call("txe_gcn_dense_fwd", ptr(st.X), N, st.Kh, st.Pd, ptr(st.Wp), st.Fo, cfg.drop_ps[l], ptr(st.mask), ptr(hw), ptr(tws),
+                     tws.numel(), st_)
+                if last:
+                    out, ld_out = _empty((N, st.Fo), h), st.Fo
+                else:
+                    states[l + 1].X = _empty((N, states[l + 1].Kp), h)
+                    out, ld_out = states[l + 1].X, states[l + 1].Kp
                 slope = cfg.act_slopes[l]
-                call("txe_gcn_aggregate_fwd", ptr(csr.rowptr_in), ptr(csr.col_src), N, ptr(hw), Fo, ptr(norm), ptr(b),
-                     0 if slope is None else 1, slope or 1.0, Fo, ptr(out), Fo, st)
-                saved.append((x, ldx, W, b, P, mask))
-                x, ldx = out, Fo
+                call("txe_gcn_aggregate_fwd", ptr(csr.rowptr_in), ptr(csr.col_src), N, ptr(hw), st.Fop, ptr(norm), ptr(st.b),
+                     0 if slope is None else 1, slope or 1.0, st.Fo, ptr(out), ld_out, st_)
+                if not need:
+                    st.mask = st.Wp = None
+                    if l > 0:
+                        st.X = None
         ctx.csr, ctx.cfg, ctx.pos, ctx.norm = csr, cfg, pos, norm
-        ctx.saved = saved if need else None
+        ctx.states = states if need else None
         ctx.h_req = ctx.needs_input_grad[2]
-        ctx.out = x if need else None
-        return x
+        ctx.out = out if need else None
+        return out
 
     @staticmethod
     def backward(ctx, d_out):
-        csr, cfg, pos, norm, saved = ctx.csr, ctx.cfg, ctx.pos, ctx.norm, ctx.saved
+        csr, cfg, pos, norm, states = ctx.csr, ctx.cfg, ctx.pos, ctx.norm, ctx.states
         L = cfg.n_layers
         d_out = _f32(d_out)
         grads = [None] * (3 * L)
         with torch.cuda.device(d_out.device):
-            st = _lib.stream_ptr()
+            st_ = _lib.stream_ptr()
             N = d_out.shape[0]
             if cfg.act_slopes[-1] is not None:   # a standalone activated layer: undo the fused activation explicitly
                 d_pre = torch.empty_like(d_out)
-                call("txe_leaky_relu_bwd", ptr(d_out), ptr(ctx.out), cfg.act_slopes[-1], d_out.numel(), ptr(d_pre), st)
+                call("txe_leaky_relu_bwd", ptr(d_out), ptr(ctx.out), cfg.act_slopes[-1], d_out.numel(), ptr(d_pre), st_)
             else:
                 d_pre = d_out
-            d_h = None
+            ld_dpre = d_pre.stride(0)
+            d_X = None
             for l in range(L - 1, -1, -1):
-                x, ldx, W, b, P, mask = saved[l]
-                Kh = x.shape[1]
-                Pd = 0 if P is None else P.shape[1]
-                Fo = cfg.out_dims[l]
-                d_hw = _empty((N, Fo), d_out)
-                d_b = torch.empty_like(b) if b is not None else None
-                wsb = call("txe_gcn_aggregate_bwd_ws_bytes", N, Fo)
+                st = states[l]
+                d_hw = _empty((N, st.Fop), d_out)
+                call("txe_zero_cols", ptr(d_hw), st.Fop, N, st.Fo, st.Fop, st_)
+                d_b = torch.empty_like(st.b) if st.b is not None else None
+                wsb = call("txe_gcn_aggregate_bwd_ws_bytes", N, st.Fo)
                 ws = _ws(wsb, d_out)
-                call("txe_gcn_aggregate_bwd", ptr(csr.rowptr_out), ptr(csr.col_dst), N, ptr(d_pre), d_pre.stride(0), ptr(norm), Fo,
-                     ptr(d_hw), Fo, ptr(d_b), ptr(ws), wsb, st)
+                call("txe_gcn_aggregate_bwd", ptr(csr.rowptr_out), ptr(csr.col_dst), N, ptr(d_pre), ld_dpre, ptr(norm), st.Fo, ptr(d_hw),
+                     st.Fop, ptr(d_b), ptr(ws), wsb, st_)
                 need_dh = (l > 0) or ctx.h_req
-                act_src = x if (l > 0 and cfg.act_slopes[l - 1] is not None) else None
-                d_h = _empty((N, Kh), d_out) if need_dh else None
-                dW = torch.empty_like(W)
-                dP = torch.empty_like(P) if P is not None else None
-                wsb2 = call("txe_gcn_project_ws_bytes", N, Kh, Pd, Fo, cfg.vocab)
+                act_on = l > 0 and cfg.act_slopes[l - 1] is not None
+                d_X = _empty((N, st.Kp), d_out) if (need_dh or st.Pd > 0) else None
+                dW = torch.empty_like(st.W)
+                dP = torch.empty_like(st.P) if st.P is not None else None
+                wsb2 = call("txe_gcn_dense_ws_bytes", N, st.Kh, st.Pd, st.Fo, cfg.vocab)
                 ws2 = _ws(wsb2, d_out)
-                call("txe_gcn_project_bwd", ptr(x), ldx, N, Kh, ptr(pos if P is not None else None), ptr(P), Pd, cfg.vocab, ptr(W), Fo,
-                     cfg.drop_ps[l], ptr(mask), ptr(d_hw), ptr(d_h), Kh, ptr(act_src), (ldx if act_src is not None else 0),
-                     (cfg.act_slopes[l - 1] if act_src is not None else 1.0), ptr(dW), ptr(dP), ptr(ws2), wsb2, st)
+                call("txe_gcn_dense_bwd", ptr(st.X), N, st.Kh, st.Pd, ptr(pos if st.P is not None else None), cfg.vocab, ptr(st.Wp), st.Fo,
+                     cfg.drop_ps[l], ptr(st.mask), ptr(d_hw), int(need_dh), int(act_on), (cfg.act_slopes[l - 1] if act_on else 1.0),
+                     ptr(d_X), ptr(dW), ptr(dP), ptr(ws2), wsb2, st_)
                 grads[3 * l:3 * l + 3] = [dW, d_b, dP]
-                d_pre = d_h
-        return (None, None, d_h if ctx.h_req else None, None, *grads)
+                if l > 0:
+                    d_pre, ld_dpre = d_X, st.Kp
+            d_h = d_X[:, :states[0].Kh].contiguous() if ctx.h_req else None
+        ctx.states = None
+        return (None, None, d_h, None, *grads)
 
 
 # ================================================================================================================

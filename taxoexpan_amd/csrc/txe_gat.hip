@@ -17,6 +17,8 @@
 
 namespace txe {
 
+constexpr int SLICE_NI = 2;      // feature vectors per lane of a wave that owns a quarter of a row
+
 // ------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------
@@ -35,6 +37,37 @@ __global__ __launch_bounds__(GAT_WAVES * 64) void gat_aggregate_fwd_kernel(
     if (v >= n_nodes) return;
     const int beg = rowptr[v], end = rowptr[v + 1];
 
+    // Common case (every egonet: in-degree <= 51, H <= 4): one edge per lane, the logits of all heads stay in registers, the
+    // H max / sum butterflies run interleaved, alpha goes straight to LDS -- one dependent-load chain instead of three.
+    const bool single = (end - beg <= 64) && (H <= 4);
+    if (single) {
+        const int p = beg + l;
+        const bool valid = p < end;
+        const int u = valid ? col[p] : 0;
+        float e[4], ex[4], m[4], sm[4];
+#pragma unroll
+        for (int h = 0; h < 4; ++h)
+            e[h] = (valid && h < H) ? leaky(a_src[(long long)u * ld_a + h] + a_dst[(long long)v * ld_a + h], slope) : -INFINITY;
+#pragma unroll
+        for (int h = 0; h < 4; ++h) m[h] = wave_max(e[h]);
+#pragma unroll
+        for (int h = 0; h < 4; ++h) ex[h] = (valid && h < H) ? __expf(e[h] - m[h]) : 0.f;
+#pragma unroll
+        for (int h = 0; h < 4; ++h) sm[h] = wave_sum(ex[h]);
+        if (valid) {
+            s_idx[w][l] = u;
+#pragma unroll
+            for (int h = 0; h < 4; ++h) {
+                if (h < H) {
+                    const float al = ex[h] / sm[h];
+                    if (alpha != nullptr) alpha[(long long)p * H + h] = al;
+                    float f = 1.f;
+                    if (drop_p > 0.f) f = drop_factor(seed, (unsigned long long)p * H + h, drop_p, drop_scale);
+                    s_w[w][h * 64 + l] = al * f;
+                }
+            }
+        }
+    } else {
     // wavefront segmented max / sum of the attention logits of v's in-edges, per head
     for (int h = 0; h < H; ++h) {
         const float ad = a_dst[(long long)v * ld_a + h];
@@ -45,6 +78,7 @@ __global__ __launch_bounds__(GAT_WAVES * 64) void gat_aggregate_fwd_kernel(
         for (int p = beg + l; p < end; p += 64) s += __expf(leaky(a_src[(long long)col[p] * ld_a + h] + ad, slope) - m);
         s = wave_sum(s);
         if (l == 0) { s_stat[w][2 * h] = m; s_stat[w][2 * h + 1] = 1.f / s; }
+    }
     }
     __builtin_amdgcn_wave_barrier();
 
@@ -61,7 +95,7 @@ __global__ __launch_bounds__(GAT_WAVES * 64) void gat_aggregate_fwd_kernel(
         }
         for (int cb = beg; cb < end; cb += 64) {
             const int p = cb + l;
-            if (p < end) {
+            if (!single && p < end) {
                 const int u = col[p];
                 s_idx[w][l] = u;
                 for (int h = 0; h < H; ++h) {
@@ -208,7 +242,6 @@ __global__ __launch_bounds__(GAT_WAVES * 64) void gat_bwd_node_kernel(
 // owning a quarter of the H*D row.  A node with many out-edges (the anchor of an egonet feeds up to 50 siblings) then
 // costs each wave a quarter of the row per edge instead of serialising one wave on the whole row (measured 2.4x on the
 // MAG layer-0 backward).  Requires nvec = H*D/VEC <= 4*64*SLICE_NI.
-constexpr int SLICE_NI = 2;
 template <int VEC>
 __global__ __launch_bounds__(GAT_WAVES * 64) void gat_bwd_node_split_kernel(
     const int* __restrict__ rowptr_out, const int* __restrict__ col_dst, const int* __restrict__ pos_out, const int n_nodes,
@@ -322,7 +355,10 @@ int txe_gat_aggregate_fwd(const int* rowptr_in, const int* col_src, int n_nodes,
     const int vec = pick_vec(D, ld_ft, ld_out, ft, out);
     // algorithmic (compulsory) bytes, SURVEY 8d: read ft + write out + a_src/a_dst + CSR (+ alpha when kept for backward);
     // the edge count is not known here (device rowptr), the E-proportional terms are added by the caller-side model
-    ProfScope prof(vec == 4 ? "gat_aggregate_fwd_kernel<4>" : (vec == 2 ? "gat_aggregate_fwd_kernel<2>" : "gat_aggregate_fwd_kernel<1>"), s, 4.0 * (2.0 * n_nodes * (double)H * D + 2.0 * n_nodes * H + n_nodes + 1), 1);
+    // algorithmic (compulsory) bytes, SURVEY 8d: read ft + write out + a_src/a_dst + CSR (+ alpha when kept for backward);
+    // the edge count is not known here (device rowptr), the E-proportional terms are added by the caller-side model
+    ProfScope prof(vec == 4 ? "gat_aggregate_fwd_kernel<4>" : (vec == 2 ? "gat_aggregate_fwd_kernel<2>" : "gat_aggregate_fwd_kernel<1>"), s,
+                   4.0 * (2.0 * n_nodes * (double)H * D + 2.0 * n_nodes * H + n_nodes + 1), 1);
 #define TXE_L(V)                                                                                                         \
     hipLaunchKernelGGL((gat_aggregate_fwd_kernel<V>), dim3(nb), dim3(GAT_WAVES * 64), 0, s, rowptr_in, col_src, n_nodes, \
                        ft, ld_ft, a_src, a_dst, ld_a, H, D, attn_slope, attn_drop_p, scale, seed, out_mode, act_slope,   \

@@ -51,6 +51,9 @@ SIGNATURES = {
     "txe_build_csr_ws_bytes": (SZ, [I, I]),
     "txe_build_csr": (I, [P, P, I, I, P, P, P, P, P, P, P, SZ, P]),
     "txe_rank_block": (I, [P, L, I, I, P, P, P, I, P, P]),
+    "txe_egonet_ws_bytes": (SZ, [I]),
+    "txe_egonet_offsets": (I, [P, P, P, P, P, I, I, U64, P, P, SZ, P]),
+    "txe_egonet_fill": (I, [P, P, P, P, P, P, I, I, U64, P, P, P, P, P, P, P, P, P, P]),
     "txe_dropout_uniform_host": (F, [U64, U64]),
     "txe_dropout_mask_word_host": (C.c_uint, [U64, U64, F]),
     "txe_profile_enable": (I, [I]),

@@ -230,3 +230,117 @@ def build_csr_device(src, dst, n_nodes):
                   _lib.ptr(eid_in), _lib.ptr(rowptr_out), _lib.ptr(col_dst), _lib.ptr(pos_out), _lib.ptr(ws), wsb,
                   _lib.stream_ptr())
     return rowptr_in, col_src[:e], eid_in[:e], rowptr_out, col_dst[:e], pos_out[:e]
+
+
+class DeviceBatchedGraph(BatchedDGLGraph):
+    """A batch of egonets whose node table and CSR views were built ON DEVICE (txe_egonet_*), never as host objects.
+    Same surface as BatchedDGLGraph; the host COO (`_src/_dst`, edges(), in_degrees()) is materialised lazily on demand."""
+
+    def __init__(self, csr, node_off, ids, pos):
+        DGLGraph.__init__(self)
+        self._n = csr.n_nodes
+        self._csr_dev = csr
+        self._csr_cache[str(csr.rowptr_in.device)] = csr
+        self._node_off = node_off
+        self._host_ready = False
+        self.ndata["_id"] = ids
+        self.ndata["pos"] = pos
+
+    def _materialise_host(self):
+        if self._host_ready:
+            return
+        c = self._csr_dev
+        e = c.n_edges
+        eid = c.eid_in[:e].cpu().numpy().astype(np.int64)
+        src = np.empty(e, dtype=np.int64)
+        dst = np.empty(e, dtype=np.int64)
+        src[eid] = c.col_src[:e].cpu().numpy()
+        rp = c.rowptr_in.cpu().numpy().astype(np.int64)
+        dst[eid] = np.repeat(np.arange(c.n_nodes), np.diff(rp))
+        self.__dict__["_src_host"], self.__dict__["_dst_host"] = src, dst
+        off = self._node_off.cpu().numpy().astype(np.int64)
+        self._batch_num_nodes = np.diff(off).tolist()
+        self._batch_num_edges = (2 * np.diff(off) - 1).tolist()
+        self._host_ready = True
+
+    @property
+    def _src(self):
+        self._materialise_host()
+        return self.__dict__["_src_host"]
+
+    @_src.setter
+    def _src(self, v):
+        pass
+
+    @property
+    def _dst(self):
+        self._materialise_host()
+        return self.__dict__["_dst_host"]
+
+    @_dst.setter
+    def _dst(self, v):
+        pass
+
+    @property
+    def batch_size(self):
+        return self._csr_dev.n_graphs
+
+    @property
+    def batch_num_nodes(self):
+        self._materialise_host()
+        return self._batch_num_nodes
+
+    @property
+    def batch_num_edges(self):
+        self._materialise_host()
+        return self._batch_num_edges
+
+    def number_of_edges(self):
+        return self._csr_dev.n_edges
+
+    def csr(self, device, method="auto"):
+        device = torch.device(device)
+        if device == self._csr_dev.rowptr_in.device:
+            return self._csr_dev
+        return super().csr(device, method)
+
+
+class DeviceTaxonomy:
+    """parent / child CSR (int32) and the node feature table of a taxonomy, resident on one GPU"""
+
+    def __init__(self, par_ptr, par_idx, chd_ptr, chd_idx, features, device):
+        i32 = lambda a: torch.as_tensor(np.asarray(a), dtype=torch.int32).to(device)
+        self.par_ptr, self.par_idx, self.chd_ptr, self.chd_idx = i32(par_ptr), i32(par_idx), i32(chd_ptr), i32(chd_idx)
+        self.features = features.to(device) if features is not None else None
+        self.device = torch.device(device)
+
+
+def device_egonet_batch(dtax, anchors, exclude=None, expand_factor=50, seed=0, with_features=True):
+    """Batched egonets of `anchors` built on the GPU (dataset.py:404-437 + dgl.batch).  anchors / exclude: int arrays or
+    int32 device tensors.  Returns a DeviceBatchedGraph with ndata '_id', 'pos' (int32, device) and 'x' (features gathered)."""
+    dev = dtax.device
+    to_dev = lambda a: None if a is None else (a.to(device=dev, dtype=torch.int32) if torch.is_tensor(a)
+                                               else torch.as_tensor(np.asarray(a), dtype=torch.int32).to(dev))
+    anchors, exclude = to_dev(anchors), to_dev(exclude)
+    G = int(anchors.numel())
+    i32 = lambda k: torch.empty(max(k, 1), dtype=torch.int32, device=dev)
+    node_off = i32(G + 1)
+    with torch.cuda.device(dev):
+        st = _lib.stream_ptr()
+        wsb = _lib.call("txe_egonet_ws_bytes", G)
+        ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=dev)
+        _lib.call("txe_egonet_offsets", _lib.ptr(dtax.par_ptr), _lib.ptr(dtax.chd_ptr), _lib.ptr(dtax.chd_idx), _lib.ptr(anchors),
+                  _lib.ptr(exclude), G, expand_factor, seed, _lib.ptr(node_off), _lib.ptr(ws), wsb, st)
+        N = int(node_off[G].item())                  # the one host sync of batch construction: sizes of the output arrays
+        E = 2 * N - G
+        ids, pos = i32(N), i32(N)
+        rowptr_in, rowptr_out = i32(N + 1), i32(N + 1)
+        col_src, eid_in, col_dst, pos_out = i32(E), i32(E), i32(E), i32(E)
+        _lib.call("txe_egonet_fill", _lib.ptr(dtax.par_ptr), _lib.ptr(dtax.par_idx), _lib.ptr(dtax.chd_ptr), _lib.ptr(dtax.chd_idx),
+                  _lib.ptr(anchors), _lib.ptr(exclude), G, expand_factor, seed, _lib.ptr(node_off), _lib.ptr(ids), _lib.ptr(pos),
+                  _lib.ptr(rowptr_in), _lib.ptr(col_src), _lib.ptr(eid_in), _lib.ptr(rowptr_out), _lib.ptr(col_dst), _lib.ptr(pos_out), st)
+    csr = CSR(N, E, G, rowptr_in[:N + 1], col_src[:E], eid_in[:E], rowptr_out[:N + 1], col_dst[:E], pos_out[:E], node_off[:G + 1])
+    g = DeviceBatchedGraph(csr, node_off[:G + 1], ids[:N], pos[:N])
+    if with_features and dtax.features is not None:
+        g.ndata["x"] = dtax.features.index_select(0, ids[:N].long())
+    return g

@@ -370,3 +370,56 @@ def test_sum_max_readouts_against_oracle():
         (ref * w).sum().backward()
         np.testing.assert_allclose(out.detach().cpu().numpy(), ref.detach().numpy(), rtol=RT, atol=AT)
         np.testing.assert_allclose(hd.grad.cpu().numpy(), hc.grad.numpy(), rtol=1e-4, atol=1e-6)
+
+
+def test_device_egonet_builder_equals_host_builder():
+    """txe_egonet_* (dataset.py:404-437 + dgl.batch on device) against the host builder: bit-exact node table and both CSR
+    views when no anchor exceeds expand_factor; with sampling, every property the reference's construction guarantees."""
+    from taxoexpan_amd import graph as G
+    from taxoexpan_amd import synthetic as syn
+    dev = _dev()
+    tax = syn.make_taxonomy(6000, 9500, 12, seed=5)
+    dtax = G.DeviceTaxonomy(tax.par_ptr, tax.par_idx, tax.chd_ptr, tax.chd_idx, tax.features, dev)
+    rs = np.random.RandomState(1)
+    anchors = rs.randint(0, tax.n_nodes, 777)
+    anchors[:3] = [0, tax.n_nodes - 1, int(np.argmax(np.diff(tax.chd_ptr)))]       # root (k=0), a leaf (m=0), the widest node
+    exclude = np.full(anchors.size, -1, dtype=np.int64)
+    for i, a in enumerate(anchors):                                                # every third egonet drops one of its children
+        ch = tax.chd_idx[tax.chd_ptr[a]:tax.chd_ptr[a + 1]]
+        if i % 3 == 0 and ch.size:
+            exclude[i] = ch[rs.randint(ch.size)]
+    big = 10 ** 6
+    for ex in (None, exclude):
+        hg = syn.egonet_batch(tax, anchors, expand_factor=big, exclude_child=ex)
+        dg = G.device_egonet_batch(dtax, anchors, exclude=ex, expand_factor=big)
+        hc, dc = hg.csr("cpu", "host"), dg.csr(dev)
+        assert (dc.n_nodes, dc.n_edges, dc.n_graphs) == (hc.n_nodes, hc.n_edges, hc.n_graphs)
+        assert torch.equal(dg.ndata["_id"].cpu().long(), hg.ndata["_id"]) and torch.equal(dg.ndata["pos"].cpu().long(), hg.ndata["pos"].long())
+        for f in ("rowptr_in", "col_src", "eid_in", "rowptr_out", "col_dst", "pos_out", "graph_off"):
+            assert torch.equal(getattr(dc, f).cpu(), getattr(hc, f)), f
+        assert torch.equal(dg.ndata["x"].cpu(), hg.ndata["x"])
+        assert dg.batch_num_nodes == hg.batch_num_nodes and np.array_equal(dg._src, hg._src) and np.array_equal(dg._dst, hg._dst)
+    # sampling with replacement (dataset.py:419): exactly expand_factor draws from the anchor's children, minus the excluded
+    dg = G.device_egonet_batch(dtax, anchors, exclude=exclude, expand_factor=4, seed=11)
+    dg2 = G.device_egonet_batch(dtax, anchors, exclude=exclude, expand_factor=4, seed=11)
+    assert torch.equal(dg.ndata["_id"], dg2.ndata["_id"])                           # counter-based: reproducible
+    ids, pos, off = dg.ndata["_id"].cpu().numpy(), dg.ndata["pos"].cpu().numpy(), dg.csr(dev).graph_off.cpu().numpy()
+    for i, a in enumerate(anchors):
+        p, d = pos[off[i]:off[i + 1]], ids[off[i]:off[i + 1]]
+        k, m = int((p == 0).sum()), int((p == 2).sum())
+        ch = tax.chd_idx[tax.chd_ptr[a]:tax.chd_ptr[a + 1]]
+        assert d[k] == a and p[k] == 1 and np.array_equal(d[:k], tax.par_idx[tax.par_ptr[a]:tax.par_ptr[a + 1]])
+        assert set(d[k + 1:].tolist()) <= set(ch.tolist()) and exclude[i] not in d[k + 1:]
+        if ch.size <= 4:
+            assert m == ch.size - int(exclude[i] >= 0)
+        else:
+            assert m <= 4 and (exclude[i] >= 0 or m == 4)
+    # the device-built batch drives the encoder to the same result as the host-built one
+    spec = gc.CASES["mag_pgat_wmr_lbm"] if "mag_pgat_wmr_lbm" in gc.CASES else gc.CASES[NODROP[0]]
+    tax2 = syn.make_taxonomy(3000, 4700, spec["in_dim"], seed=2)
+    dtax2 = G.DeviceTaxonomy(tax2.par_ptr, tax2.par_idx, tax2.chd_ptr, tax2.chd_idx, tax2.features, dev)
+    model = _build_model(spec, gc.make_params(spec)).eval()
+    an = np.arange(0, 3000, 7)
+    hg, dg = syn.egonet_batch(tax2, an, expand_factor=big), G.device_egonet_batch(dtax2, an, expand_factor=big)
+    from taxoexpan_amd.scoring import encode_candidates
+    assert torch.equal(encode_candidates(model, hg), encode_candidates(model, dg))

@@ -229,8 +229,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
-    ap.add_argument("--workload", default="pgat", choices=["pgat", "pgcn"],
-                    help="pgat = BASELINE configs[1] (default, the metric's workload); pgcn = configs[4] (PGCN+MR+BIM, same batches)")
+    ap.add_argument("--workload", default="pgat", choices=["pgat", "pgcn", "pgat2"],
+                    help="pgat = BASELINE configs[1] (default, the metric's workload); pgcn = configs[4] (PGCN+MR+BIM, same batches); "
+                         "pgat2 = configs[3] (MAG-Full-shaped taxonomy, PGAT num_layers=2 heads [4,4,1])")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -251,10 +252,12 @@ def main():
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     from taxoexpan_amd import TaxoExpan, synthetic as syn
-    tax = syn.make_named_taxonomy("mag_cs", seed=47)
+    tax = syn.make_named_taxonomy("mag_full" if args.workload == "pgat2" else "mag_cs", seed=47)
     torch.manual_seed(47)
     if args.workload == "pgat":
         model = TaxoExpan("PGAT", "WMR", "LBM", **MAG).to(device).train()
+    elif args.workload == "pgat2":
+        model = TaxoExpan("PGAT", "WMR", "LBM", **dict(MAG, num_layers=2, heads=[4, 4, 1])).to(device).train()
     else:
         model = TaxoExpan("PGCN", "MR", "BIM", **MAG).to(device).train()
     if world > 1:                                   # identical replicas
@@ -307,7 +310,10 @@ def main():
             "metric": "egonet_edges_per_sec_%s_fwd_bwd" % args.workload, "value": edges / elapsed, "unit": "egonet-edges/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "MAG-CS synthetic taxonomy (29,654 nodes, d=250), PGAT+WMR+LBM fp32 dims 250/50/500/500 heads [4,1], "
+            "config": {"workload": {"pgat": "MAG-CS synthetic taxonomy (29,654 nodes, d=250), PGAT+WMR+LBM fp32 dims 250/50/500/500 heads [4,1], ",
+                                    "pgat2": "MAG-Full synthetic taxonomy (431,416 nodes, d=250), PGAT num_layers=2 +WMR+LBM fp32 dims 250/50/500/500 "
+                                             "heads [4,4,1], ",
+                                    "pgcn": "MAG-CS synthetic taxonomy (29,654 nodes, d=250), PGCN+MR+BIM fp32 dims 250/50/500/500, "}[args.workload] +
                                    "128 queries x 32 = 4096 egonets per GPU per step, fwd + InfoNCE + bwd + Adam(amsgrad), dropout 0.1",
                        "egonets_per_step_per_gpu": N_QUERIES * (1 + NEG), "avg_edges_per_step_per_gpu": edges / args.steps / world,
                        "parallelism": f"dp{world}"},

@@ -20,6 +20,7 @@ dependency.  Restated primitives and the reference call sites that use them:
                                       mean_nodes(g,f,w) = segsum(w*f)/segsum(w)
   batch(list)                        data_loaders.py:25   concatenate, offset ids
   DGLGraph().add_nodes/add_edges     dataset.py:429-435
+  g.to_networkx()                    dataset.py:225       DiGraph, nodes 0..n-1, edges in edge-id order
 """
 import torch
 
@@ -81,6 +82,15 @@ class DGLGraph:
 
     def in_degrees(self):
         return torch.bincount(self._dst, minlength=self._n)
+
+    def to_networkx(self):
+        """dataset.py:225 -- DGL 0.4: nx.DiGraph, nodes 0..n-1, edges added in edge-id order (attribute 'id')"""
+        import networkx as nx
+        g = nx.DiGraph()
+        g.add_nodes_from(range(self._n))
+        for eid, (u, v) in enumerate(zip(self._src.tolist(), self._dst.tolist())):
+            g.add_edge(u, v, id=eid)
+        return g
 
     # -- message passing --------------------------------------------------------
     def apply_edges(self, udf):

@@ -174,8 +174,59 @@ def run_scoring():
     print("scoring: S", save["S_lbm"].shape)
 
 
+def run_extras():
+    """modules of model_zoo.py that model/model.py never instantiates: the NTN matcher (:331-346) and GATLayer's residual
+    branch (:98-103, with res_fc and with the broadcast identity), forward + gradients of sum(out * coef)."""
+    rs = np.random.RandomState(77)
+    f32 = lambda *shape: (rs.randn(*shape) * 0.5).astype(np.float32)
+    save = {}
+    # --- NTN
+    ntn = ref_zoo.NTN(12, 7, k=4)
+    P = {"u_R.weight": f32(1, 4), "W.weight": f32(4, 12, 7), "W.bias": f32(4), "V.weight": f32(4, 19)}
+    ntn.load_state_dict({k: torch.from_numpy(v) for k, v in P.items()}, strict=True)
+    e1, e2, coef = f32(9, 12), f32(9, 7), f32(9, 1)
+    t1, t2 = torch.from_numpy(e1).requires_grad_(), torch.from_numpy(e2).requires_grad_()
+    out = ntn(t1, t2)
+    (out * torch.from_numpy(coef)).sum().backward()
+    save.update({"ntn.e1": e1, "ntn.e2": e2, "ntn.coef": coef, "ntn.out": out.detach().numpy(), "ntn.d_e1": t1.grad.numpy(),
+                 "ntn.d_e2": t2.grad.numpy()})
+    for k, v in P.items():
+        save["ntn.p." + k] = v
+    for k, v in ntn.named_parameters():
+        save["ntn.g." + k] = v.grad.numpy()
+    # --- residual GATLayer on the EDGE_SHAPES batch
+    shapes = gc.EDGE_SHAPES
+    n = sum(k + 1 + m for k, m in shapes)
+    for tag, (din, dout, H) in {"res_fc": (10, 6, 3), "res_id": (6, 6, 2)}.items():
+        layer = ref_zoo.GATLayer(din, dout, H, feat_drop=0.0, attn_drop=0.0, residual=True)
+        P = {"fc.weight": f32(H * dout, din), "attn_l": f32(1, H, dout), "attn_r": f32(1, H, dout)}
+        if din != dout:
+            P["res_fc.weight"] = f32(H * dout, din)
+        layer.load_state_dict({k: torch.from_numpy(v) for k, v in P.items()}, strict=True)
+        x, coef = f32(n, din), f32(n, H, dout)
+        tx = torch.from_numpy(x).requires_grad_()
+        off, graphs = 0, []
+        for (k, m) in shapes:
+            graphs.append(build_egonet(k, m, tx[off:off + k + 1 + m]))
+            off += k + 1 + m
+        bg = dgl.batch(graphs)
+        out = layer(bg, tx)
+        (out * torch.from_numpy(coef)).sum().backward()
+        save.update({f"{tag}.x": x, f"{tag}.coef": coef, f"{tag}.out": out.detach().numpy(), f"{tag}.d_x": tx.grad.numpy()})
+        for k, v in P.items():
+            save[f"{tag}.p.{k}"] = v
+        for k, v in layer.named_parameters():
+            save[f"{tag}.g.{k}"] = v.grad.numpy()
+    np.savez_compressed(os.path.join(OUT, "extras.npz"), **save)
+    print("extras:", len(save), "arrays")
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
+    if "--extras-only" in sys.argv:
+        run_extras()
+        sys.exit(0)
     for name, spec in gc.CASES.items():
         run_case(name, spec)
     run_scoring()
+    run_extras()

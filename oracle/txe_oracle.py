@@ -93,8 +93,9 @@ def segment_sum(graph_off, x):
 # GAT  (model_zoo.py:52-114, 169-220)
 # ----------------------------------------------------------------------------------------
 def gat_layer(src, dst, n, feature, fc_w, attn_l, attn_r, slope=0.2, feat_keep=None, attn_keep=None,
-              feat_scale=1.0, attn_scale=1.0, return_parts=False):
-    """GATLayer.forward, model_zoo.py:80-104 (residual branch :98-103 is dead for PGAT).
+              feat_scale=1.0, attn_scale=1.0, return_parts=False, residual=False, res_w=None):
+    """GATLayer.forward, model_zoo.py:80-104 (residual branch :98-103 is dead for PGAT: `residual=True` adds
+    res_fc(h) -- or h itself broadcast over heads when res_w is None, i.e. in_dim == out_dim).
 
     feature N x K; fc_w (H*D) x K; attn_l/attn_r 1 x H x D.  Dropout is expressed through explicit
     keep masks (feat_keep N x K, attn_keep E x H x 1, values 0/1) and their 1/(1-p) scales.
@@ -109,6 +110,8 @@ def gat_layer(src, dst, n, feature, fc_w, attn_l, attn_r, slope=0.2, feat_keep=N
     alpha = edge_softmax(dst, n, e)                                                  # :111-112
     a_drop = alpha if attn_keep is None else alpha * attn_keep * attn_scale          # :114
     out = scatter_sum(dst, n, ft[src] * a_drop)                                      # :95
+    if residual:                                                                     # :98-103
+        out = out + ((h @ res_w.t()).reshape(h.shape[0], H, -1) if res_w is not None else h.unsqueeze(1))
     if return_parts:
         return out, dict(ft=ft, a1=a1, a2=a2, e=e, alpha=alpha)
     return out
@@ -235,6 +238,12 @@ def bilinear_match(e1, e2, W, apply_exp):
 def mlp_match(e1, e2, w0, b0, w1, b1):
     """MLP (:285-298)."""
     return F.linear(F.relu(F.linear(torch.cat((e1, e2), 1), w0, b0)), w1, b1)
+
+
+def ntn_match(e1, e2, u_w, W_w, W_b, V_w, non_linear=torch.tanh):
+    """NTN (:331-346): u_R(f(Bilinear_k(e1, e2) + bias + V(cat(e1, e2))))."""
+    bil = torch.einsum("gl,klr,gr->gk", e1, W_w, e2) + W_b
+    return non_linear(bil + torch.cat((e1, e2), 1) @ V_w.t()) @ u_w.t()
 
 
 # ----------------------------------------------------------------------------------------

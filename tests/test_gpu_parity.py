@@ -423,3 +423,65 @@ def test_device_egonet_builder_equals_host_builder():
     hg, dg = syn.egonet_batch(tax2, an, expand_factor=big), G.device_egonet_batch(dtax2, an, expand_factor=big)
     from taxoexpan_amd.scoring import encode_candidates
     assert torch.equal(encode_candidates(model, hg), encode_candidates(model, dg))
+
+
+def test_device_egonets_from_raw_dataset_files():
+    """raw .terms/.taxo/.embed -> MaskedGraphDataset -> device egonet builder == the dataset's own `_get_subgraph(-1, a, 0)`
+    (the all-candidate construction of test_fast.py:93-97), and the encoder gives identical candidate embeddings"""
+    import os
+    import shutil
+    import tempfile
+    from taxoexpan_amd import graph as G
+    from taxoexpan_amd.dataset import MAGDataset, MaskedGraphDataset
+    from taxoexpan_amd.graph import batch
+    from taxoexpan_amd.scoring import encode_candidates
+    dev = _dev()
+    d = tempfile.mkdtemp(dir=os.environ.get("TMPDIR", None))
+    try:
+        for fn in os.listdir(os.path.join(GOLDEN_DIR, "toy_taxo")):
+            shutil.copy(os.path.join(GOLDEN_DIR, "toy_taxo", fn), d)
+        ds = MaskedGraphDataset(MAGDataset("toy", d, raw=True), mode="test", sampling_mode=0, expand_factor=50, normalize_embed=True)
+    finally:
+        shutil.rmtree(d)
+    anchors = list(ds.graph.nodes)
+    host = batch([ds._get_subgraph(-1, a, 0) for a in anchors])
+    dg = G.device_egonet_batch(ds.device_taxonomy(dev), anchors, expand_factor=50)
+    assert torch.equal(dg.ndata["_id"].cpu().long(), host.ndata["_id"]) and torch.equal(dg.ndata["pos"].cpu().long(), host.ndata["pos"])
+    assert np.array_equal(dg._src, host._src) and np.array_equal(dg._dst, host._dst)
+    torch.manual_seed(0)
+    from taxoexpan_amd import TaxoExpan
+    model = TaxoExpan("PGAT", "WMR", "LBM", in_dim=8, hidden_dim=16, out_dim=12, pos_dim=4, num_layers=1, heads=[2, 1], feat_drop=0.1,
+                      attn_drop=0.1, hidden_drop=0.1, out_drop=0.1).to(dev).eval()
+    assert torch.equal(encode_candidates(model, host), encode_candidates(model, dg))
+
+
+def test_ntn_and_residual_gat_against_reference_goldens():
+    """NTN matcher (model_zoo.py:331-346) and GATLayer(residual=True) (:98-103) through the HIP ops vs the reference goldens"""
+    import os
+    from taxoexpan_amd import model_zoo as mz
+    dev = _dev()
+    z = np.load(os.path.join(GOLDEN_DIR, "extras.npz"))
+    t = lambda k: torch.from_numpy(z[k]).to(dev)
+    ntn = mz.NTN(12, 7, k=4)
+    ntn.load_state_dict({k: torch.from_numpy(z["ntn.p." + k]) for k in ("u_R.weight", "W.weight", "W.bias", "V.weight")}, strict=True)
+    ntn = ntn.to(dev)
+    e1, e2 = t("ntn.e1").requires_grad_(), t("ntn.e2").requires_grad_()
+    out = ntn(e1, e2)
+    (out * t("ntn.coef")).sum().backward()
+    np.testing.assert_allclose(out.detach().cpu().numpy(), z["ntn.out"], rtol=RT, atol=AT)
+    np.testing.assert_allclose(e1.grad.cpu().numpy(), z["ntn.d_e1"], rtol=2e-3, atol=2e-5)
+    np.testing.assert_allclose(e2.grad.cpu().numpy(), z["ntn.d_e2"], rtol=2e-3, atol=2e-5)
+    for k, p in ntn.named_parameters():
+        np.testing.assert_allclose(p.grad.cpu().numpy(), z["ntn.g." + k], rtol=2e-3, atol=2e-5, err_msg=k)
+    for tag, (din, dout, H) in {"res_fc": (10, 6, 3), "res_id": (6, 6, 2)}.items():
+        layer = mz.GATLayer(din, dout, H, feat_drop=0.0, attn_drop=0.0, residual=True)
+        keys = ["fc.weight", "attn_l", "attn_r"] + (["res_fc.weight"] if tag == "res_fc" else [])
+        layer.load_state_dict({k: torch.from_numpy(z[f"{tag}.p.{k}"]) for k in keys}, strict=True)
+        layer = layer.to(dev)
+        x = t(tag + ".x").requires_grad_()
+        out = layer(_graph(gc.EDGE_SHAPES), x)
+        (out * t(tag + ".coef")).sum().backward()
+        np.testing.assert_allclose(out.detach().cpu().numpy(), z[tag + ".out"], rtol=RT, atol=AT)
+        np.testing.assert_allclose(x.grad.cpu().numpy(), z[tag + ".d_x"], rtol=2e-3, atol=2e-5)
+        for k, p in layer.named_parameters():
+            np.testing.assert_allclose(p.grad.cpu().numpy(), z[f"{tag}.g.{k}"], rtol=2e-3, atol=2e-5, err_msg=k)

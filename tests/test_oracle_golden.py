@@ -76,3 +76,36 @@ def test_egonet_layout():
     assert p == [0, 0, 1, 2, 2, 2]
     n, s, d, p = orc.egonet_edges(0, 0)
     assert (n, s, d, p) == (1, [0], [0], [1])
+
+
+def _extras():
+    import os
+    return np.load(os.path.join(GOLDEN_DIR, "extras.npz"))
+
+
+def test_oracle_ntn_and_residual_gat_against_reference_goldens():
+    """modules model/model.py never instantiates (NTN :331-346, GATLayer residual :98-103), pinned by oracle/gen_golden.py"""
+    z = _extras()
+    t = lambda k: torch.from_numpy(z[k]).clone().requires_grad_(True)
+    e1, e2 = t("ntn.e1"), t("ntn.e2")
+    P = {k: t("ntn.p." + k) for k in ("u_R.weight", "W.weight", "W.bias", "V.weight")}
+    out = orc.ntn_match(e1, e2, P["u_R.weight"], P["W.weight"], P["W.bias"], P["V.weight"])
+    (out * torch.from_numpy(z["ntn.coef"])).sum().backward()
+    np.testing.assert_allclose(out.detach().numpy(), z["ntn.out"], rtol=RT, atol=AT)
+    np.testing.assert_allclose(e1.grad.numpy(), z["ntn.d_e1"], rtol=2e-4, atol=2e-6)
+    np.testing.assert_allclose(e2.grad.numpy(), z["ntn.d_e2"], rtol=2e-4, atol=2e-6)
+    for k, p in P.items():
+        np.testing.assert_allclose(p.grad.numpy(), z["ntn.g." + k], rtol=2e-4, atol=2e-6)
+    graph = orc.batch_egonets(gc.EDGE_SHAPES)
+    for tag in ("res_fc", "res_id"):
+        x = t(tag + ".x")
+        P = {k: t(f"{tag}.p.{k}") for k in ("fc.weight", "attn_l", "attn_r")}
+        rw = t(tag + ".p.res_fc.weight") if tag == "res_fc" else None
+        out = orc.gat_layer(graph["src"], graph["dst"], graph["num_nodes"], x, P["fc.weight"], P["attn_l"], P["attn_r"], residual=True, res_w=rw)
+        (out * torch.from_numpy(z[tag + ".coef"])).sum().backward()
+        np.testing.assert_allclose(out.detach().numpy(), z[tag + ".out"], rtol=RT, atol=AT)
+        np.testing.assert_allclose(x.grad.numpy(), z[tag + ".d_x"], rtol=2e-4, atol=2e-6)
+        for k, p in P.items():
+            np.testing.assert_allclose(p.grad.numpy(), z[f"{tag}.g.{k}"], rtol=2e-4, atol=2e-6)
+        if rw is not None:
+            np.testing.assert_allclose(rw.grad.numpy(), z[tag + ".g.res_fc.weight"], rtol=2e-4, atol=2e-6)

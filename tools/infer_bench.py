@@ -21,6 +21,7 @@ ap.add_argument("--shape", default="mag_full", choices=list(syn.SHAPES))
 ap.add_argument("--chunk", type=int, default=-1, help="-b of test_fast.py: egonets per encoder batch (-1 = one batch)")
 ap.add_argument("--qblock", type=int, default=1024)
 ap.add_argument("--max-queries", type=int, default=0)
+ap.add_argument("--profile", action="store_true", help="per-kernel HIP-event timing of one encode pass (stderr)")
 args = ap.parse_args()
 
 dev = torch.device("cuda:0")
@@ -63,6 +64,27 @@ t0 = time.perf_counter()
 hg = encode_candidates(model, graphs)
 torch.cuda.synchronize()
 t_enc = time.perf_counter() - t0
+
+if args.profile:
+    import ctypes
+    from taxoexpan_amd import _lib
+    lib = _lib.load()
+    lib.txe_profile_reset()
+    lib.txe_profile_enable(1)
+    encode_candidates(model, graphs)
+    torch.cuda.synchronize()
+    lib.txe_profile_enable(0)
+    buf = ctypes.create_string_buffer(64)
+    ms, work, kind = ctypes.c_float(), ctypes.c_double(), ctypes.c_int()
+    tot = 0.0
+    for i in range(lib.txe_profile_count()):
+        lib.txe_profile_get(i, buf, 64, ctypes.byref(ms), ctypes.byref(work), ctypes.byref(kind))
+        tot += ms.value
+        rate = work.value / (ms.value * 1e-3)
+        print(f"  {buf.value.decode():44s} {ms.value * 1e3:10.1f} us  " + (f"{rate / 1e12:7.1f} TF/s" if kind.value == 0 else f"{rate / 1e9:7.0f} GB/s"),
+              file=sys.stderr)
+    print(f"  kernel total {tot:.3f} ms", file=sys.stderr)
+    lib.txe_profile_reset()
 
 queries = tax.features[torch.from_numpy(test)].to(dev)
 cand_index = np.full(tax.n_nodes, -1, dtype=np.int64)

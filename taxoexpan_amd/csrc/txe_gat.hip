@@ -22,7 +22,7 @@ constexpr int SLICE_NI = 2;      // feature vectors per lane of a wave that owns
 // ------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------
-template <int VEC>
+template <int VEC, int NI>
 __global__ __launch_bounds__(GAT_WAVES * 64) void gat_aggregate_fwd_kernel(
     const int* __restrict__ rowptr, const int* __restrict__ col, const int n_nodes, const float* __restrict__ ft,
     const long long ld_ft, const float* __restrict__ a_src, const float* __restrict__ a_dst, const int ld_a, const int H,
@@ -83,11 +83,12 @@ __global__ __launch_bounds__(GAT_WAVES * 64) void gat_aggregate_fwd_kernel(
     __builtin_amdgcn_wave_barrier();
 
     const int F = H * D, nvec = F / VEC;
-    for (int t0 = 0; t0 < nvec; t0 += 64 * GAT_MAXI) {
-        int hidx[GAT_MAXI];
-        float acc[GAT_MAXI][VEC];
+    constexpr int EU = NI >= 8 ? 1 : 2;
+    for (int t0 = 0; t0 < nvec; t0 += 64 * NI) {
+        int hidx[NI];
+        float acc[NI][VEC];
 #pragma unroll
-        for (int i = 0; i < GAT_MAXI; ++i) {
+        for (int i = 0; i < NI; ++i) {
             const int j = t0 + l + 64 * i;
             hidx[i] = (j < nvec) ? (j * VEC) / D : 0;
 #pragma unroll
@@ -108,11 +109,11 @@ __global__ __launch_bounds__(GAT_WAVES * 64) void gat_aggregate_fwd_kernel(
                 }
             }
             __builtin_amdgcn_wave_barrier();
-            gather_accumulate<VEC>(ft, ld_ft, s_idx[w], s_w[w], min(64, end - cb), t0, nvec, hidx, acc);
+            gather_rows<VEC, NI, EU>(ft, ld_ft, s_idx[w], s_w[w], min(64, end - cb), t0, nvec, hidx, acc);
             __builtin_amdgcn_wave_barrier();
         }
 #pragma unroll
-        for (int i = 0; i < GAT_MAXI; ++i) {
+        for (int i = 0; i < NI; ++i) {
             const int j = t0 + l + 64 * i;
             if (j < nvec) {
                 if (out_mode == 1) {
@@ -129,8 +130,9 @@ __global__ __launch_bounds__(GAT_WAVES * 64) void gat_aggregate_fwd_kernel(
 // backward, destination side: d alpha (dot products), softmax + leaky-relu backward -> dz[E,H],
 // d a_dst[N,H].  d_pre = gradient w.r.t. the aggregated (pre-activation) output.
 // ------------------------------------------------------------------------------------------------
+// Generic shape (more than 4 heads, or rows wider than one 64*NI-vector tile): one head and one edge at a time.
 template <int VEC>
-__global__ __launch_bounds__(GAT_WAVES * 64) void gat_bwd_edge_kernel(
+__global__ __launch_bounds__(GAT_WAVES * 64) void gat_bwd_edge_generic_kernel(
     const int* __restrict__ rowptr, const int* __restrict__ col, const int n_nodes, const float* __restrict__ ft,
     const long long ld_ft, const float* __restrict__ a_src, const float* __restrict__ a_dst, const int ld_a, const int H,
     const int D, const float slope, const float drop_p, const float drop_scale, const unsigned long long seed,
@@ -179,12 +181,139 @@ __global__ __launch_bounds__(GAT_WAVES * 64) void gat_bwd_edge_kernel(
     }
 }
 
+// Shipped shapes (H <= 4, the whole H*D row in one 64*NI-vector tile).  The d_pre row of v is parked in LDS once; lane l
+// owns in-edge beg + l of the current 64-edge chunk (source id, alpha, pre-activation logit fetched up front); every edge
+// costs ONE sweep of NI independent 16-byte loads of ft[u], folded into per-head partial sums, reduced across the wave and
+// left in lane e's register; the softmax / leaky-relu backward then runs out of registers.  Dependent chain:
+// rowptr -> {col, alpha, d_pre} -> a_src -> one row sweep per edge.  Nodes with more than 64 in-edges park dz in memory.
+template <int VEC, int NI>
+__global__ __launch_bounds__(GAT_WAVES * 64) void gat_bwd_edge_kernel(
+    const int* __restrict__ rowptr, const int* __restrict__ col, const int n_nodes, const float* __restrict__ ft,
+    const long long ld_ft, const float* __restrict__ a_src, const float* __restrict__ a_dst, const int ld_a, const int H,
+    const int D, const float slope, const float drop_p, const float drop_scale, const unsigned long long seed,
+    const float* __restrict__ alpha, const float* __restrict__ d_pre, const long long ld_dpre, float* __restrict__ dz,
+    float* __restrict__ d_a_dst, const int ld_da) {
+    __shared__ float s_d[GAT_WAVES][64 * NI * VEC];
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    const int v = xcd_remap(blockIdx.x, gridDim.x) * GAT_WAVES + w;
+    if (v >= n_nodes) return;
+    const int beg = rowptr[v], end = rowptr[v + 1];
+    if (beg == end) {                                                // no in-edge (never for egonets: self loops)
+        if (l < H) d_a_dst[(long long)v * ld_da + l] = 0.f;
+        return;
+    }
+    const int dvec = D / VEC, nvec = H * dvec;
+    int off[NI];                                                     // clamped float offset of this lane's vector i
+    unsigned qpack = 0;                                              // 2 bits per vector: its head; vectors past the row: weight 0
+    float live[NI];
+    {
+        const float* drow = d_pre + (long long)v * ld_dpre;
+        float t[NI][VEC];
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int j = l + 64 * i;
+            const int jc = (j < nvec) ? j : 0;
+            off[i] = jc * VEC;
+            qpack |= (unsigned)(jc / dvec) << (2 * i);
+            live[i] = (j < nvec) ? 1.f : 0.f;
+            vload<VEC>(drow + off[i], t[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) t[i][k] *= live[i];         // dead vectors contribute exactly 0 to every dot product
+            vstore<VEC>(&s_d[w][(l + 64 * i) * VEC], t[i]);
+        }
+    }
+    const bool one_chunk = (end - beg) <= 64;
+    float sacc[4] = {0.f, 0.f, 0.f, 0.f};
+    float al[4], zz[4], dal[4];
+    for (int cb = beg; cb < end; cb += 64) {
+        const int pl = min(cb + l, end - 1);
+        const int colv = col[pl];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int h = min(t, H - 1);                             // clamped: loads stay unconditional
+            al[t] = alpha[(long long)pl * H + h];
+            zz[t] = a_src[(long long)colv * ld_a + h] + a_dst[(long long)v * ld_a + h];
+            dal[t] = 0.f;
+        }
+        const int cnt = min(64, end - cb);
+        for (int e = 0; e < cnt; ++e) {
+            const float* frow = ft + (long long)__builtin_amdgcn_readlane(colv, e) * ld_ft;
+            float b[NI][VEC];
+#pragma unroll
+            for (int i = 0; i < NI; ++i) vload<VEC>(frow + off[i], b[i]);
+            float part[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                float a[VEC];
+                vload<VEC>(&s_d[w][(l + 64 * i) * VEC], a);
+                float d = 0.f;
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) d = fmaf(a[k], b[i][k], d);
+                const unsigned qi = (qpack >> (2 * i)) & 3u;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) part[t] += (qi == (unsigned)t) ? d : 0.f;
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                if (t < H) {                                          // wave-uniform
+                    const float tot = wave_sum(part[t]);
+                    if (l == e) {
+                        float f = 1.f;
+                        if (drop_p > 0.f) f = drop_factor(seed, (unsigned long long)(cb + e) * H + t, drop_p, drop_scale);
+                        dal[t] = tot * f;
+                    }
+                }
+            }
+        }
+        const bool lvalid = cb + l < end;
+        if (one_chunk) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                if (t < H) {
+                    const float S = wave_sum(lvalid ? al[t] * dal[t] : 0.f);
+                    const float g = lvalid ? al[t] * (dal[t] - S) * (zz[t] > 0.f ? 1.f : slope) : 0.f;
+                    if (lvalid) dz[(long long)(cb + l) * H + t] = g;
+                    const float dacc = wave_sum(g);
+                    if (l == 0) d_a_dst[(long long)v * ld_da + t] = dacc;
+                }
+            }
+        } else if (lvalid) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                if (t < H) {
+                    dz[(long long)(cb + l) * H + t] = dal[t];          // parked; the same lane re-reads it below
+                    sacc[t] = fmaf(al[t], dal[t], sacc[t]);
+                }
+            }
+        }
+    }
+    if (!one_chunk) {
+        for (int t = 0; t < H; ++t) {
+            const float S = wave_sum(sacc[t]);
+            const float ad = a_dst[(long long)v * ld_a + t];
+            float dacc = 0.f;
+            for (int p = beg + l; p < end; p += 64) {
+                const float de = alpha[(long long)p * H + t] * (dz[(long long)p * H + t] - S);
+                const float z = a_src[(long long)col[p] * ld_a + t] + ad;
+                const float g = de * (z > 0.f ? 1.f : slope);
+                dz[(long long)p * H + t] = g;
+                dacc += g;
+            }
+            dacc = wave_sum(dacc);
+            if (l == 0) d_a_dst[(long long)v * ld_da + t] = dacc;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // backward, source side (source-sorted CSR, atomic free):
 //   d_ft[u] = sum_{e=(u->v)} a_drop[e] * d_pre[v]        d_a_src[u,h] = sum_{e=(u->v)} dz[e,h]
 // pos_out[j] = position of out-edge j in the destination-sorted order (where alpha / dz live).
 // ------------------------------------------------------------------------------------------------
-template <int VEC>
+template <int VEC, int NI>
 __global__ __launch_bounds__(GAT_WAVES * 64) void gat_bwd_node_kernel(
     const int* __restrict__ rowptr_out, const int* __restrict__ col_dst, const int* __restrict__ pos_out, const int n_nodes,
     const float* __restrict__ alpha, const float* __restrict__ dz, const int H, const int D, const float drop_p,
@@ -205,11 +334,11 @@ __global__ __launch_bounds__(GAT_WAVES * 64) void gat_bwd_node_kernel(
     }
 
     const int F = H * D, nvec = F / VEC;
-    for (int t0 = 0; t0 < nvec; t0 += 64 * GAT_MAXI) {
-        int hidx[GAT_MAXI];
-        float acc[GAT_MAXI][VEC];
+    for (int t0 = 0; t0 < nvec; t0 += 64 * NI) {
+        int hidx[NI];
+        float acc[NI][VEC];
 #pragma unroll
-        for (int i = 0; i < GAT_MAXI; ++i) {
+        for (int i = 0; i < NI; ++i) {
             const int j = t0 + l + 64 * i;
             hidx[i] = (j < nvec) ? (j * VEC) / D : 0;
 #pragma unroll
@@ -227,11 +356,11 @@ __global__ __launch_bounds__(GAT_WAVES * 64) void gat_bwd_node_kernel(
                 }
             }
             __builtin_amdgcn_wave_barrier();
-            gather_accumulate<VEC>(d_pre, ld_dpre, s_idx[w], s_w[w], min(64, end - cb), t0, nvec, hidx, acc);
+            gather_rows<VEC, NI, (NI >= 8 ? 1 : 2)>(d_pre, ld_dpre, s_idx[w], s_w[w], min(64, end - cb), t0, nvec, hidx, acc);
             __builtin_amdgcn_wave_barrier();
         }
 #pragma unroll
-        for (int i = 0; i < GAT_MAXI; ++i) {
+        for (int i = 0; i < NI; ++i) {
             const int j = t0 + l + 64 * i;
             if (j < nvec) vstore<VEC>(d_ft + (long long)u * ld_dft + (long long)j * VEC, acc[i]);
         }
@@ -261,11 +390,52 @@ __global__ __launch_bounds__(GAT_WAVES * 64) void gat_bwd_node_split_kernel(
         const int j = j0 + l + 64 * i;
         hidx[i] = (j < j1) ? (j * VEC) / D : 0;
     }
+    // The out-edge lists of all 4 nodes are fetched up front (first 64 edges each, H <= 4): rowptr -> {pos_out, col_dst} ->
+    // {alpha, dz} is paid once per workgroup instead of once per node, and the 4 gathers then run back to back.
+    const int n_edges = rowptr_out[n_nodes];
+    const bool pre = (H <= 4) && (n_edges > 0);
+    int nbeg[GAT_WAVES], nend[GAT_WAVES], pidx[GAT_WAVES], pq[GAT_WAVES];
+    float pw[GAT_WAVES][4];
+#pragma unroll
+    for (int t = 0; t < GAT_WAVES; ++t) {
+        const int u = min(node0 + t, n_nodes - 1);
+        nbeg[t] = rowptr_out[u];
+        nend[t] = (node0 + t < n_nodes) ? rowptr_out[u + 1] : nbeg[t];
+    }
+    if (pre) {
+#pragma unroll
+        for (int t = 0; t < GAT_WAVES; ++t) {
+            const int j = min(nbeg[t] + l, n_edges - 1);                // clamped: loads stay unconditional
+            pq[t] = pos_out[j];
+            pidx[t] = col_dst[j];
+        }
+#pragma unroll
+        for (int t = 0; t < GAT_WAVES; ++t)
+#pragma unroll
+            for (int h = 0; h < 4; ++h) pw[t][h] = alpha[(long long)pq[t] * H + min(h, H - 1)];
+        // d_a_src of node node0 + w: this wave's own reduction, from the same prefetch
+        int qw = pq[0], bw = nbeg[0], ew = nend[0];
+#pragma unroll
+        for (int t = 1; t < GAT_WAVES; ++t) {
+            qw = (w == t) ? pq[t] : qw;
+            bw = (w == t) ? nbeg[t] : bw;
+            ew = (w == t) ? nend[t] : ew;
+        }
+        if (node0 + w < n_nodes) {
+            for (int h = 0; h < H; ++h) {
+                float a = (bw + l < ew) ? dz[(long long)qw * H + h] : 0.f;
+                for (int j = bw + 64 + l; j < ew; j += 64) a += dz[(long long)pos_out[j] * H + h];
+                a = wave_sum(a);
+                if (l == 0) d_a_src[(long long)(node0 + w) * ld_da + h] = a;
+            }
+        }
+    }
+#pragma unroll
     for (int t = 0; t < GAT_WAVES; ++t) {
         const int u = node0 + t;
         if (u >= n_nodes) break;                                   // workgroup-uniform
-        const int beg = rowptr_out[u], end = rowptr_out[u + 1];
-        if (w == t) {                                              // one wave per node does the tiny d_a_src reduction
+        const int beg = nbeg[t], end = nend[t];
+        if (!pre && w == t) {                                      // one wave per node does the tiny d_a_src reduction
             for (int h = 0; h < H; ++h) {
                 float a = 0.f;
                 for (int j = beg + l; j < end; j += 64) a += dz[(long long)pos_out[j] * H + h];
@@ -281,16 +451,28 @@ __global__ __launch_bounds__(GAT_WAVES * 64) void gat_bwd_node_split_kernel(
         for (int cb = beg; cb < end; cb += 64) {
             const int j = cb + l;
             if (j < end) {
-                const int qd = pos_out[j];
-                s_idx[w][l] = col_dst[j];
-                for (int h = 0; h < H; ++h) {
-                    float f = 1.f;
-                    if (drop_p > 0.f) f = drop_factor(seed, (unsigned long long)qd * H + h, drop_p, drop_scale);
-                    s_w[w][h * 64 + l] = alpha[(long long)qd * H + h] * f;
+                if (pre && cb == beg) {
+                    s_idx[w][l] = pidx[t];
+#pragma unroll
+                    for (int h = 0; h < 4; ++h) {
+                        if (h < H) {
+                            float f = 1.f;
+                            if (drop_p > 0.f) f = drop_factor(seed, (unsigned long long)pq[t] * H + h, drop_p, drop_scale);
+                            s_w[w][h * 64 + l] = pw[t][h] * f;
+                        }
+                    }
+                } else {
+                    const int qd = pos_out[j];
+                    s_idx[w][l] = col_dst[j];
+                    for (int h = 0; h < H; ++h) {
+                        float f = 1.f;
+                        if (drop_p > 0.f) f = drop_factor(seed, (unsigned long long)qd * H + h, drop_p, drop_scale);
+                        s_w[w][h * 64 + l] = alpha[(long long)qd * H + h] * f;
+                    }
                 }
             }
             __builtin_amdgcn_wave_barrier();
-            gather_accumulate_slice<VEC, SLICE_NI, 4>(d_pre, ld_dpre, s_idx[w], s_w[w], min(64, end - cb), j0, j1, hidx, acc);
+            gather_rows<VEC, SLICE_NI, 4>(d_pre, ld_dpre, s_idx[w], s_w[w], min(64, end - cb), j0, j1, hidx, acc);
             __builtin_amdgcn_wave_barrier();
         }
 #pragma unroll
@@ -328,6 +510,20 @@ __global__ void head_mean_bwd_kernel(const float* __restrict__ dy, int H, int D,
     }
 }
 
+// name as rocprofv3 prints it, e.g. "gat_aggregate_fwd_kernel<4, 8>"
+struct KName {
+    char s[64];
+    KName(const char* base, int a, int b) { snprintf(s, sizeof(s), "%s<%d, %d>", base, a, b); }
+    KName(const char* base, int a) { snprintf(s, sizeof(s), "%s<%d>", base, a); }
+};
+
+#define TXE_DISPATCH_VEC_NI(vec, ni, LAUNCH)                                     \
+    do {                                                                         \
+        if (vec == 4) { if (ni == 8) LAUNCH(4, 8); else if (ni == 4) LAUNCH(4, 4); else LAUNCH(4, 2); } \
+        else if (vec == 2) { if (ni == 8) LAUNCH(2, 8); else if (ni == 4) LAUNCH(2, 4); else LAUNCH(2, 2); } \
+        else { if (ni == 8) LAUNCH(1, 8); else if (ni == 4) LAUNCH(1, 4); else LAUNCH(1, 2); } \
+    } while (0)
+
 static inline int pick_vec(int D, long long ld1, long long ld2, const void* p1, const void* p2) {
     auto al = [](const void* p, int bytes) { return ((uintptr_t)p % bytes) == 0; };
     if (D % 4 == 0 && ld1 % 4 == 0 && ld2 % 4 == 0 && al(p1, 16) && al(p2, 16)) return 4;
@@ -357,13 +553,14 @@ int txe_gat_aggregate_fwd(const int* rowptr_in, const int* col_src, int n_nodes,
     // the edge count is not known here (device rowptr), the E-proportional terms are added by the caller-side model
     // algorithmic (compulsory) bytes, SURVEY 8d: read ft + write out + a_src/a_dst + CSR (+ alpha when kept for backward);
     // the edge count is not known here (device rowptr), the E-proportional terms are added by the caller-side model
-    ProfScope prof(vec == 4 ? "gat_aggregate_fwd_kernel<4>" : (vec == 2 ? "gat_aggregate_fwd_kernel<2>" : "gat_aggregate_fwd_kernel<1>"), s,
-                   4.0 * (2.0 * n_nodes * (double)H * D + 2.0 * n_nodes * H + n_nodes + 1), 1);
-#define TXE_L(V)                                                                                                         \
-    hipLaunchKernelGGL((gat_aggregate_fwd_kernel<V>), dim3(nb), dim3(GAT_WAVES * 64), 0, s, rowptr_in, col_src, n_nodes, \
-                       ft, ld_ft, a_src, a_dst, ld_a, H, D, attn_slope, attn_drop_p, scale, seed, out_mode, act_slope,   \
+    const int ni = pick_ni(H * D / vec);
+    const KName kn("gat_aggregate_fwd_kernel", vec, ni);
+    ProfScope prof(kn.s, s, 4.0 * (2.0 * n_nodes * (double)H * D + 2.0 * n_nodes * H + n_nodes + 1), 1);
+#define TXE_L(V, I)                                                                                                        \
+    hipLaunchKernelGGL((gat_aggregate_fwd_kernel<V, I>), dim3(nb), dim3(GAT_WAVES * 64), 0, s, rowptr_in, col_src, n_nodes, \
+                       ft, ld_ft, a_src, a_dst, ld_a, H, D, attn_slope, attn_drop_p, scale, seed, out_mode, act_slope,     \
                        out, ld_out, alpha)
-    if (vec == 4) TXE_L(4); else if (vec == 2) TXE_L(2); else TXE_L(1);
+    TXE_DISPATCH_VEC_NI(vec, ni, TXE_L);
 #undef TXE_L
     TXE_CHECK_LAUNCH();
     return TXE_OK;
@@ -382,11 +579,23 @@ int txe_gat_aggregate_bwd(const int* rowptr_in, const int* col_src, const int* r
     const int nb = (n_nodes + GAT_WAVES - 1) / GAT_WAVES;
     hipStream_t s = (hipStream_t)stream;
     const int v1 = pick_vec(D, ld_ft, ld_dpre, ft, d_pre);
-    {
-    ProfScope prof(v1 == 4 ? "gat_bwd_edge_kernel<4>" : (v1 == 2 ? "gat_bwd_edge_kernel<2>" : "gat_bwd_edge_kernel<1>"), s, 4.0 * (2.0 * n_nodes * (double)H * D + 3.0 * n_nodes * H), 1);   // read ft + d_pre
-#define TXE_L(V)                                                                                                          \
-    hipLaunchKernelGGL((gat_bwd_edge_kernel<V>), dim3(nb), dim3(GAT_WAVES * 64), 0, s, rowptr_in, col_src, n_nodes, ft,   \
-                       ld_ft, a_src, a_dst, ld_a, H, D, attn_slope, attn_drop_p, scale, seed, alpha, d_pre, ld_dpre,      \
+    const int nvec1 = H * D / v1;
+    if (H <= 4 && nvec1 <= 512) {
+    const int ni1 = pick_ni(nvec1);
+    const KName kn("gat_bwd_edge_kernel", v1, ni1);
+    ProfScope prof(kn.s, s, 4.0 * (2.0 * n_nodes * (double)H * D + 3.0 * n_nodes * H), 1);   // read ft + d_pre
+#define TXE_L(V, I)                                                                                                        \
+    hipLaunchKernelGGL((gat_bwd_edge_kernel<V, I>), dim3(nb), dim3(GAT_WAVES * 64), 0, s, rowptr_in, col_src, n_nodes, ft, \
+                       ld_ft, a_src, a_dst, ld_a, H, D, attn_slope, attn_drop_p, scale, seed, alpha, d_pre, ld_dpre,       \
+                       dz_ws, d_a_dst, ld_da)
+    TXE_DISPATCH_VEC_NI(v1, ni1, TXE_L);
+#undef TXE_L
+    } else {
+    const KName kn("gat_bwd_edge_generic_kernel", v1);
+    ProfScope prof(kn.s, s, 4.0 * (2.0 * n_nodes * (double)H * D + 3.0 * n_nodes * H), 1);
+#define TXE_L(V)                                                                                                           \
+    hipLaunchKernelGGL((gat_bwd_edge_generic_kernel<V>), dim3(nb), dim3(GAT_WAVES * 64), 0, s, rowptr_in, col_src, n_nodes, \
+                       ft, ld_ft, a_src, a_dst, ld_a, H, D, attn_slope, attn_drop_p, scale, seed, alpha, d_pre, ld_dpre,    \
                        dz_ws, d_a_dst, ld_da)
     if (v1 == 4) TXE_L(4); else if (v1 == 2) TXE_L(2); else TXE_L(1);
 #undef TXE_L
@@ -404,13 +613,14 @@ int txe_gat_aggregate_bwd(const int* rowptr_in, const int* col_src, const int* r
         if (v2 == 4) TXE_L(4); else if (v2 == 2) TXE_L(2); else TXE_L(1);
 #undef TXE_L
     } else {
-        ProfScope prof2(v2 == 4 ? "gat_bwd_node_kernel<4>" : (v2 == 2 ? "gat_bwd_node_kernel<2>" : "gat_bwd_node_kernel<1>"), s,
-                        4.0 * (2.0 * n_nodes * (double)H * D + n_nodes * H), 1);          // read d_pre + write d_ft
-#define TXE_L(V)                                                                                                          \
-    hipLaunchKernelGGL((gat_bwd_node_kernel<V>), dim3(nb), dim3(GAT_WAVES * 64), 0, s, rowptr_out, col_dst, pos_out,      \
-                       n_nodes, alpha, (const float*)dz_ws, H, D, attn_drop_p, scale, seed, d_pre, ld_dpre, d_ft, ld_dft, \
+        const int ni2 = pick_ni(nvec2);
+        const KName kn("gat_bwd_node_kernel", v2, ni2);
+        ProfScope prof2(kn.s, s, 4.0 * (2.0 * n_nodes * (double)H * D + n_nodes * H), 1);          // read d_pre + write d_ft
+#define TXE_L(V, I)                                                                                                        \
+    hipLaunchKernelGGL((gat_bwd_node_kernel<V, I>), dim3(nb), dim3(GAT_WAVES * 64), 0, s, rowptr_out, col_dst, pos_out,    \
+                       n_nodes, alpha, (const float*)dz_ws, H, D, attn_drop_p, scale, seed, d_pre, ld_dpre, d_ft, ld_dft,  \
                        d_a_src, ld_da)
-        if (v2 == 4) TXE_L(4); else if (v2 == 2) TXE_L(2); else TXE_L(1);
+        TXE_DISPATCH_VEC_NI(v2, ni2, TXE_L);
 #undef TXE_L
     }
     TXE_CHECK_LAUNCH();

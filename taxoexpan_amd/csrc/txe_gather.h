@@ -5,7 +5,6 @@
 namespace txe {
 
 constexpr int GAT_MAXH = 16;     // heads supported by the LDS staging
-constexpr int GAT_MAXI = 8;      // feature vectors per lane kept in registers per feature tile
 constexpr int GAT_WAVES = 4;     // waves (= destination nodes) per workgroup
 
 template <int VEC> struct vec_t;
@@ -26,33 +25,15 @@ __device__ __forceinline__ void vstore(float* p, const float* v) {
     else { *p = v[0]; }
 }
 
-// acc[i] += sum_{e<cnt} w[head(i)][e] * rows[idx[e]][(t0 + lane + 64 i) * VEC ...]
-template <int VEC>
-__device__ __forceinline__ void gather_accumulate(const float* __restrict__ base, long long ld, const int* s_idx,
-                                                  const float* s_w, int cnt, int t0, int nvec, const int* hidx,
-                                                  float (&acc)[GAT_MAXI][VEC]) {
-    const int l = threadIdx.x & 63;
-    for (int e = 0; e < cnt; ++e) {
-        const float* row = base + (long long)s_idx[e] * ld;
-#pragma unroll
-        for (int i = 0; i < GAT_MAXI; ++i) {
-            const int j = t0 + l + 64 * i;
-            if (j < nvec) {
-                float v[VEC];
-                vload<VEC>(row + (long long)j * VEC, v);
-                const float a = s_w[hidx[i] * 64 + e];
-#pragma unroll
-                for (int k = 0; k < VEC; ++k) acc[i][k] = fmaf(a, v[k], acc[i][k]);
-            }
-        }
-    }
-}
-
-// Same accumulation for a SLICE of the feature row owned by one wave of a workgroup that shares a node among its
-// 4 waves (skewed degree lists, e.g. an egonet anchor with 50 out-edges): lane l owns vectors j0 + l + 64 i, i < NI.
-// Edges are unrolled by EU so that NI*EU independent 16-byte loads are in flight per lane.
+// acc[i] += sum_{e<cnt} w[head(i)][e] * rows[idx[e]][(j0 + lane + 64 i) * VEC ...]      for the vectors j0 <= j < j1 of the row
+//
+// Lane l owns vectors j0 + l + 64 i, i < NI.  Every load is UNCONDITIONAL (out-of-range lanes re-read vector j0 and their
+// accumulators are never stored) and all NI*EU loads of a step are issued before the first use: hipcc puts an
+// `s_waitcnt vmcnt(0)` behind every predicated load, which left ONE 16-byte load in flight per wave (measured 2.5 TB/s);
+// NI*EU independent loads per lane is what fills the HBM pipe.  Used by one wave for a whole row (j0 = tile start, j1 = row
+// end) and by the workgroup-cooperative kernels for a quarter row per wave.
 template <int VEC, int NI, int EU>
-__device__ __forceinline__ void gather_accumulate_slice(const float* __restrict__ base, long long ld, const int* s_idx,
+__device__ __forceinline__ void gather_rows(const float* __restrict__ base, long long ld, const int* s_idx,
                                                         const float* s_w, int cnt, int j0, int j1, const int* hidx,
                                                         float (&acc)[NI][VEC]) {
     const int l = threadIdx.x & 63;
@@ -92,5 +73,8 @@ __device__ __forceinline__ void gather_accumulate_slice(const float* __restrict_
         }
     }
 }
+
+// vectors-per-lane template choice for a row of nvec vectors: 2 / 4 / 8 (wider rows loop over 512-vector tiles)
+static inline int pick_ni(int nvec) { return nvec <= 128 ? 2 : (nvec <= 256 ? 4 : 8); }
 
 }  // namespace txe

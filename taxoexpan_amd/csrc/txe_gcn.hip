@@ -14,7 +14,7 @@ __global__ void gcn_norm_kernel(const int* __restrict__ rowptr, int n, float* __
 
 // mode 0: out[v] = act(norm[v] * sum_u norm[u] x[u] + bias)      (forward; rowptr/col = destination CSR)
 // mode 1: out[u] = norm[u] * sum_v norm[v] x[v]                   (backward; rowptr/col = source CSR)
-template <int VEC>
+template <int VEC, int NI>
 __global__ __launch_bounds__(GAT_WAVES * 64) void gcn_aggregate_kernel(const int* __restrict__ rowptr, const int* __restrict__ col,
                                                                        const int n_nodes, const float* __restrict__ x,
                                                                        const long long ld_x, const float* __restrict__ norm,
@@ -29,11 +29,11 @@ __global__ __launch_bounds__(GAT_WAVES * 64) void gcn_aggregate_kernel(const int
     const int beg = rowptr[v], end = rowptr[v + 1];
     const float nv = norm[v];
     const int nvec = F / VEC;
-    for (int t0 = 0; t0 < nvec; t0 += 64 * GAT_MAXI) {
-        int hidx[GAT_MAXI];
-        float acc[GAT_MAXI][VEC];
+    for (int t0 = 0; t0 < nvec; t0 += 64 * NI) {
+        int hidx[NI];
+        float acc[NI][VEC];
 #pragma unroll
-        for (int i = 0; i < GAT_MAXI; ++i) {
+        for (int i = 0; i < NI; ++i) {
             hidx[i] = 0;
 #pragma unroll
             for (int k = 0; k < VEC; ++k) acc[i][k] = 0.f;
@@ -46,11 +46,11 @@ __global__ __launch_bounds__(GAT_WAVES * 64) void gcn_aggregate_kernel(const int
                 s_w[w][l] = norm[u];
             }
             __builtin_amdgcn_wave_barrier();
-            gather_accumulate<VEC>(x, ld_x, s_idx[w], s_w[w], min(64, end - cb), t0, nvec, hidx, acc);
+            gather_rows<VEC, NI, (NI >= 8 ? 1 : 2)>(x, ld_x, s_idx[w], s_w[w], min(64, end - cb), t0, nvec, hidx, acc);
             __builtin_amdgcn_wave_barrier();
         }
 #pragma unroll
-        for (int i = 0; i < GAT_MAXI; ++i) {
+        for (int i = 0; i < NI; ++i) {
             const int j = t0 + l + 64 * i;
             if (j < nvec) {
 #pragma unroll
@@ -95,11 +95,16 @@ static int gcn_launch(const int* rowptr, const int* col, int n, const float* x, 
                       const float* bias, int has_act, float slope, int F, float* out, long long ld_out, hipStream_t s) {
     const int nb = (n + GAT_WAVES - 1) / GAT_WAVES;
     int vec = gcn_pick_vec(F, ld_x, ld_out, x, out);
-    ProfScope prof(vec == 4 ? "gcn_aggregate_kernel<4>" : (vec == 2 ? "gcn_aggregate_kernel<2>" : "gcn_aggregate_kernel<1>"), s, 4.0 * (2.0 * n * (double)F + 2.0 * n + 1), 1);
-#define TXE_L(V)                                                                                                           \
-    hipLaunchKernelGGL((gcn_aggregate_kernel<V>), dim3(nb), dim3(GAT_WAVES * 64), 0, s, rowptr, col, n, x, ld_x, norm, bias, \
+    const int ni = pick_ni(F / vec);
+    char kn[64];
+    snprintf(kn, sizeof(kn), "gcn_aggregate_kernel<%d, %d>", vec, ni);
+    ProfScope prof(kn, s, 4.0 * (2.0 * n * (double)F + 2.0 * n + 1), 1);
+#define TXE_L(V, I)                                                                                                           \
+    hipLaunchKernelGGL((gcn_aggregate_kernel<V, I>), dim3(nb), dim3(GAT_WAVES * 64), 0, s, rowptr, col, n, x, ld_x, norm, bias, \
                        has_act, slope, F, out, ld_out)
-    if (vec == 4) TXE_L(4); else if (vec == 2) TXE_L(2); else TXE_L(1);
+    if (vec == 4) { if (ni == 8) TXE_L(4, 8); else if (ni == 4) TXE_L(4, 4); else TXE_L(4, 2); }
+    else if (vec == 2) { if (ni == 8) TXE_L(2, 8); else if (ni == 4) TXE_L(2, 4); else TXE_L(2, 2); }
+    else { if (ni == 8) TXE_L(1, 8); else if (ni == 4) TXE_L(1, 4); else TXE_L(1, 2); }
 #undef TXE_L
     TXE_CHECK_LAUNCH();
     return TXE_OK;

@@ -11,7 +11,7 @@
 namespace txe {
 
 struct ProfRec {
-    const char* name;
+    char name[64];
     hipEvent_t a, b;
     double work;
     int kind;  // 0 = flops, 1 = bytes
@@ -45,7 +45,7 @@ static hipEvent_t take_event() {
 
 int prof_begin(const char* name, hipStream_t s, double work, int kind) {
     ProfRec r;
-    r.name = name; r.work = work; r.kind = kind;
+    strncpy(r.name, name, sizeof(r.name) - 1); r.name[sizeof(r.name) - 1] = 0; r.work = work; r.kind = kind;
     r.a = take_event(); r.b = take_event();
     (void)hipEventRecord(r.a, s);
     g_recs.push_back(r);

@@ -117,7 +117,7 @@ def _random_graph(n, e, seed, zero_in=True):
     return src.astype(np.int64), dst.astype(np.int64)
 
 
-@pytest.mark.parametrize("H,D,K", [(3, 5, 7), (4, 8, 12), (1, 500, 64), (2, 66, 10)])
+@pytest.mark.parametrize("H,D,K", [(3, 5, 7), (4, 8, 12), (1, 500, 64), (2, 66, 10), (6, 12, 9), (4, 600, 20), (2, 1100, 8)])
 def test_gat_layer_generic_graph_fwd_bwd(H, D, K):
     """GATLayer on an arbitrary CSR (degree >> 64, zero in-degree, odd / even / x4 widths) vs the oracle."""
     from taxoexpan_amd.graph import DGLGraph

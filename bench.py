@@ -100,12 +100,16 @@ def load_traffic():
     return out, os.path.basename(files[-1])
 
 
-def summarize_profile(all_recs, n_edges_by_launch):
+def summarize_profile(all_recs, n_edges_by_launch, n_nodes_by_launch=None):
     """aggregate records by kernel name: launches, avg duration, algorithmic work per launch, roofline fraction"""
     traffic, traffic_src = load_traffic()
     agg = {}
-    for recs, e in zip(all_recs, n_edges_by_launch):
+    n_graphs = N_QUERIES * (1 + NEG)
+    for idx, (recs, e) in enumerate(zip(all_recs, n_edges_by_launch)):
+        n = n_nodes_by_launch[idx] if n_nodes_by_launch else 0
         for name, sec, work, kind in recs:
+            if name.startswith("readout_"):                 # the launcher knows G*D only: add the N*D rows read (+ written in bwd)
+                work += (work / n_graphs) * n * (2 if "bwd" in name else 1)
             if kind == 1 and name.startswith("gat_"):       # add the E-proportional compulsory bytes (alpha/dz + CSR col)
                 H = 4 if work > 4.0 * 2 * 1000 * 1000 else 1   # layer-0 (H=4, F=2000) vs layer-1 (H=1, F=500) rows
                 work += 4.0 * e * (H + 1)
@@ -295,7 +299,7 @@ def main():
     roof_all, cpu, extra = None, None, None
     if rank == 0:
         recs = [profile_step(model, opt, b, target) for b in batches]
-        roof_all = summarize_profile(recs, [b["n_edges"] for b in batches])
+        roof_all = summarize_profile(recs, [b["n_edges"] for b in batches], [b["n_nodes"] for b in batches])
     if rank == 0 and world == 1 and args.workload == "pgat":
         if not args.no_cpu_baseline:
             cpu = cpu_baseline(batches[0], model.state_dict())

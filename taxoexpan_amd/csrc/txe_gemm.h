@@ -366,7 +366,9 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_kernel(VMat A, VMat B, c
     constexpr int ASZ = GA::LDS, BSZ = GB::LDS;
     constexpr int MI = (BN == 128) ? 2 : 1;          // 32-row MFMA tiles per wave along m
     constexpr int NJ = 2;                            // along n
-    __shared__ __attribute__((aligned(16))) float smem[2 * (ASZ + BSZ)];
+    constexpr int CLD = BN + 4;                       // row stride of the C tile staged for the epilogue
+    constexpr int SMEM = (2 * (ASZ + BSZ) > GEMM_BM * CLD) ? 2 * (ASZ + BSZ) : GEMM_BM * CLD;
+    __shared__ __attribute__((aligned(16))) float smem[SMEM];
     float* As = smem;
     float* Bs = smem + 2 * ASZ;
 
@@ -491,59 +493,97 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_kernel(VMat A, VMat B, c
 #undef TXE_NOTHING
 #undef TXE_COMPUTE_TILE
 
-    // epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
-    // Extras (mask word, activation source) are fetched for all 16 rows of a sub-tile with clamped, unconditional
-    // loads first, then applied -- no load sits under a branch.
+    // epilogue.  C/D layout of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) -- a lane's registers
+    // walk DOWN a column, so storing them directly issues 64 scattered dword stores per thread (store-issue bound: ~10 us of
+    // a 60 us K=320 round).  The tile is transposed through the (now idle) operand stages instead: every thread then owns
+    // 4 consecutive columns of a row -> one 16-byte load per extra (activation source), one or two mask words, one 16-byte
+    // store, rows written as full 512-byte lines.
+    float* Cs = smem;
+    __syncthreads();                                 // every wave is done reading the operand stages
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = wm0 + i * 32 + 4 * (l >> 5) + (e & 3) + 8 * (e >> 2);
+                Cs[row * CLD + wn0 + j * 32 + (l & 31)] = acc[i][j][e];
+            }
+    __syncthreads();
+    constexpr int C4 = BN / 4;                       // 16-byte chunks per tile row
     if (tail_slot >= 0) {                            // leftover-tile slice: park the raw partial tile, fix-up kernel finishes
         float* part = T.ws + (long long)tail_slot * (GEMM_BM * BN);
-#pragma unroll
-        for (int i = 0; i < MI; ++i)
-#pragma unroll
-            for (int j = 0; j < NJ; ++j)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int row = wm0 + i * 32 + 4 * (l >> 5) + (e & 3) + 8 * (e >> 2);
-                    part[row * BN + wn0 + j * 32 + (l & 31)] = acc[i][j][e];
-                }
+        for (int idx = threadIdx.x; idx < GEMM_BM * C4; idx += GEMM_THREADS) {
+            const int row = idx / C4, c4 = idx % C4;
+            *reinterpret_cast<float4*>(part + row * BN + c4 * 4) = *reinterpret_cast<const float4*>(Cs + row * CLD + c4 * 4);
+        }
         return;
     }
     float* cbase = E.c + (long long)zslice * E.split_stride;
+    const bool vec_main = ((E.ldc & 3) == 0) && ((reinterpret_cast<uintptr_t>(cbase) & 15) == 0);
+    const bool vec_c2 = ((E.ldc2 & 3) == 0) && ((reinterpret_cast<uintptr_t>(E.c2) & 15) == 0) && ((E.cols_main & 3) == 0);
+    const bool vec_act = (E.act_on == 0) || (((E.ld_act & 3) == 0) && ((reinterpret_cast<uintptr_t>(E.act_src) & 15) == 0));
+    constexpr int NCH = GEMM_BM * C4 / GEMM_THREADS;  // chunks per thread (16 / 8)
+    constexpr int UB = NCH;                           // all of a thread's chunks: their extras are fetched together (independent loads in flight)
+    static_assert(NCH % UB == 0, "chunk batches");
+    const int w1max = E.mask_on ? E.mask_ld - 1 : 0;
+    for (int cb = 0; cb < NCH; cb += UB) {
+        float v[UB][4], av[UB][4];
+        unsigned mw0[UB], mw1[UB];
+        bool fast[UB];
 #pragma unroll
-    for (int i = 0; i < MI; ++i) {
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-            const int n = n0 + wn0 + j * 32 + (l & 31);
-            const bool nok = n < N;
-            const bool main_col = n < E.cols_main;
-            const int nc = nok ? n : 0;
-            const int mbase = m0 + wm0 + i * 32 + 4 * (l >> 5);
-            const int cm = nc + E.mask_col0;
-            float av[16];
-            unsigned wd[16];
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int m = mbase + (e & 3) + 8 * (e >> 2);
-                const int mc = (m < M) ? m : 0;
-                wd[e] = E.mask[E.mask_on ? ((long long)mc * E.mask_ld + (cm >> 5)) : 0];
-                av[e] = E.act_src[((E.act_on != 0) & main_col) ? ((long long)mc * E.ld_act + nc) : 0];
+        for (int u = 0; u < UB; ++u) {
+            const int idx = threadIdx.x + (cb + u) * GEMM_THREADS;
+            const int row = idx / C4, c4 = idx % C4;
+            const int m = m0 + row, n = n0 + c4 * 4;
+            const bool all_main = n + 3 < E.cols_main, all_c2 = n >= E.cols_main;
+            fast[u] = (m < M) && (n + 3 < N) && ((all_main && vec_main && vec_act) || (all_c2 && vec_c2));
+            const float4 t = *reinterpret_cast<const float4*>(Cs + row * CLD + c4 * 4);
+            v[u][0] = t.x; v[u][1] = t.y; v[u][2] = t.z; v[u][3] = t.w;
+            const int mm = fast[u] ? m : 0, nn = fast[u] ? n : 0;          // clamped: the extras' loads stay unconditional
+            if (E.mask_on) {                                               // kernel-uniform
+                const int cm = nn + E.mask_col0;
+                mw0[u] = E.mask[(long long)mm * E.mask_ld + (cm >> 5)];
+                mw1[u] = E.mask[(long long)mm * E.mask_ld + min((cm + 3) >> 5, w1max)];
             }
-            float val[16];
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const unsigned keep = ((wd[e] >> (cm & 31)) & 1u) | (E.mask_on ? 0u : 1u);
-                float g = keep ? E.drop_scale : 0.f;
-                g *= ((E.act_on != 0) & main_col & !(av[e] > 0.f)) ? E.act_slope : 1.f;
-                const float x = acc[i][j][e] * g;
-                val[e] = E.apply_exp ? __expf(x) : x;
+            if (E.act_on != 0 && vec_act) {
+                const float4 a4 = *reinterpret_cast<const float4*>(E.act_src + (long long)mm * E.ld_act + (all_main ? nn : 0));
+                av[u][0] = a4.x; av[u][1] = a4.y; av[u][2] = a4.z; av[u][3] = a4.w;
             }
-            if (nok) {
-                float* dst = main_col ? (cbase + n) : (E.c2 + (n - E.cols_main));
-                const long long ldd = main_col ? E.ldc : E.ldc2;
+        }
 #pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int m = mbase + (e & 3) + 8 * (e >> 2);
-                    if (m < M) dst[(long long)m * ldd] = val[e];
+        for (int u = 0; u < UB; ++u) {
+            const int idx = threadIdx.x + (cb + u) * GEMM_THREADS;
+            const int row = idx / C4, c4 = idx % C4;
+            const int m = m0 + row, n = n0 + c4 * 4;
+            if (fast[u]) {
+                const bool all_main = n + 3 < E.cols_main;
+                float g[4] = {E.drop_scale, E.drop_scale, E.drop_scale, E.drop_scale};
+                if (E.mask_on) {
+                    const int cm = n + E.mask_col0;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int c = cm + q;
+                        const unsigned wd = ((c >> 5) == (cm >> 5)) ? mw0[u] : mw1[u];
+                        g[q] = ((wd >> (c & 31)) & 1u) ? E.drop_scale : 0.f;
+                    }
                 }
+                if (E.act_on != 0 && all_main) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) g[q] *= (av[u][q] > 0.f) ? 1.f : E.act_slope;
+                }
+                float o[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float x = v[u][q] * g[q];
+                    o[q] = E.apply_exp ? __expf(x) : x;
+                }
+                float* dst = all_main ? (cbase + (long long)m * E.ldc + n) : (E.c2 + (long long)m * E.ldc2 + (n - E.cols_main));
+                *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+            } else if (m < M) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (n + q < N) epi_store_one(E, m, n + q, v[u][q], cbase);
             }
         }
     }

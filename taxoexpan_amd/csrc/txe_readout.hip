@@ -35,23 +35,33 @@ __device__ __forceinline__ float node_weight(const int* __restrict__ pos, const 
     return pw ? softplus_t(pw[pos[v]]) : 1.f;
 }
 
-template <int VEC>
+// Lane l owns vectors t0 + l + 64 i (i < NI) of the row; EU nodes are swept together so that NI*EU independent 16-byte loads
+// are in flight per lane (all loads unconditional: out-of-range vectors / nodes are clamped and weighted 0).
+template <int NI> struct ro_eu { static constexpr int value = NI >= 8 ? 1 : (NI == 4 ? 2 : 4); };
+
+template <int VEC, int NI>
 __global__ __launch_bounds__(RO_WAVES * 64) void readout_fwd_kernel(const int* __restrict__ goff, const int G,
                                                                     const float* __restrict__ h, const long long ld_h,
                                                                     const int* __restrict__ pos, const float* __restrict__ pw,
                                                                     const int D, float* __restrict__ hg, float* __restrict__ wsum) {
-    __shared__ float s_w[RO_WAVES][64];
+    constexpr int EU = ro_eu<NI>::value;
+    __shared__ float s_w[RO_WAVES][64 + EU];
     const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
     const int g = xcd_remap(blockIdx.x, gridDim.x) * RO_WAVES + w;
     if (g >= G) return;
     const int beg = goff[g], end = goff[g + 1];
     const int nvec = D / VEC;
-    for (int t0 = 0; t0 < nvec; t0 += 64 * RO_MAXI) {
-        float acc[RO_MAXI][VEC];
+    if (l < EU) s_w[w][64 + l] = 0.f;                       // the unrolled sweep may look EU - 1 nodes past a full chunk
+    for (int t0 = 0; t0 < nvec; t0 += 64 * NI) {
+        int off[NI];
+        float acc[NI][VEC];
 #pragma unroll
-        for (int i = 0; i < RO_MAXI; ++i)
+        for (int i = 0; i < NI; ++i) {
+            const int j = t0 + l + 64 * i;
+            off[i] = ((j < nvec) ? j : t0) * VEC;
 #pragma unroll
             for (int k = 0; k < VEC; ++k) acc[i][k] = 0.f;
+        }
         float S = 0.f;
         for (int cb = beg; cb < end; cb += 64) {
             const float wl = node_weight(pos, pw, cb + l, cb + l < end);
@@ -59,19 +69,21 @@ __global__ __launch_bounds__(RO_WAVES * 64) void readout_fwd_kernel(const int* _
             s_w[w][l] = wl;
             __builtin_amdgcn_wave_barrier();
             const int cnt = min(64, end - cb);
-#pragma unroll 2
-            for (int e = 0; e < cnt; ++e) {
-                const float wv = s_w[w][e];
-                const float* row = h + (long long)(cb + e) * ld_h;
+            for (int e = 0; e < cnt; e += EU) {
+                float x[EU][NI][VEC];
 #pragma unroll
-                for (int i = 0; i < RO_MAXI; ++i) {
-                    const int j = t0 + l + 64 * i;
-                    if (j < nvec) {
-                        float x[VEC];
-                        ro_vload<VEC>(row + (long long)j * VEC, x);
+                for (int u = 0; u < EU; ++u) {
+                    const float* row = h + (long long)min(cb + e + u, end - 1) * ld_h;
 #pragma unroll
-                        for (int k = 0; k < VEC; ++k) acc[i][k] = fmaf(wv, x[k], acc[i][k]);
-                    }
+                    for (int i = 0; i < NI; ++i) ro_vload<VEC>(row + off[i], x[u][i]);
+                }
+#pragma unroll
+                for (int u = 0; u < EU; ++u) {
+                    const float wv = s_w[w][e + u];             // 0 for nodes past the end of the egonet
+#pragma unroll
+                    for (int i = 0; i < NI; ++i)
+#pragma unroll
+                        for (int k = 0; k < VEC; ++k) acc[i][k] = fmaf(wv, x[u][i][k], acc[i][k]);
                 }
             }
             __builtin_amdgcn_wave_barrier();
@@ -80,7 +92,7 @@ __global__ __launch_bounds__(RO_WAVES * 64) void readout_fwd_kernel(const int* _
         if (l == 0 && wsum && t0 == 0) wsum[g] = S;
         const float inv = 1.f / S;
 #pragma unroll
-        for (int i = 0; i < RO_MAXI; ++i) {
+        for (int i = 0; i < NI; ++i) {
             const int j = t0 + l + 64 * i;
             if (j < nvec) {
 #pragma unroll
@@ -92,7 +104,7 @@ __global__ __launch_bounds__(RO_WAVES * 64) void readout_fwd_kernel(const int* _
 }
 
 // d_h[v] = (w_v / S_g) d_hg[g];   d_w_v = <d_hg[g], h[v] - hg[g]> / S_g;   d_pw[c] += d_w_v * sigmoid(pw[c]) for pos_v == c
-template <int VEC>
+template <int VEC, int NI>
 __global__ __launch_bounds__(RO_WAVES * 64) void readout_bwd_kernel(const int* __restrict__ goff, const int G,
                                                                     const float* __restrict__ h, const long long ld_h,
                                                                     const int* __restrict__ pos, const float* __restrict__ pw,
@@ -100,18 +112,22 @@ __global__ __launch_bounds__(RO_WAVES * 64) void readout_bwd_kernel(const int* _
                                                                     const float* __restrict__ wsum, const float* __restrict__ d_hg,
                                                                     float* __restrict__ d_h, const long long ld_dh,
                                                                     float* __restrict__ dpw_part /*[G][vocab]*/) {
-    __shared__ float s_sc[RO_WAVES][64];      // w_v / S
-    __shared__ float s_sg[RO_WAVES][64];      // sigmoid(pw[pos_v]) / S
-    __shared__ int s_pc[RO_WAVES][64];
+    constexpr int EU = ro_eu<NI>::value;
+    __shared__ float s_sc[RO_WAVES][64 + EU];      // w_v / S
+    __shared__ float s_sg[RO_WAVES][64 + EU];      // sigmoid(pw[pos_v]) / S
+    __shared__ int s_pc[RO_WAVES][64 + EU];
     const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
     const int g = xcd_remap(blockIdx.x, gridDim.x) * RO_WAVES + w;
     if (g >= G) return;
     const int beg = goff[g], end = goff[g + 1];
     const float inv = 1.f / wsum[g];
     const int nvec = D / VEC;
+    if (l < EU) { s_sc[w][64 + l] = 0.f; s_sg[w][64 + l] = 0.f; s_pc[w][64 + l] = 0; }
     float dpw[RO_MAX_VOCAB];
 #pragma unroll
     for (int c = 0; c < RO_MAX_VOCAB; ++c) dpw[c] = 0.f;
+    const float* dgrow = d_hg + (long long)g * D;
+    const float* mrow = hg + (long long)g * D;
     for (int cb = beg; cb < end; cb += 64) {
         {
             const int v = cb + l;
@@ -120,32 +136,62 @@ __global__ __launch_bounds__(RO_WAVES * 64) void readout_bwd_kernel(const int* _
             const float x = pw ? pw[pc] : 0.f;
             s_pc[w][l] = pc;
             s_sc[w][l] = valid ? (pw ? softplus_t(x) : 1.f) * inv : 0.f;
-            s_sg[w][l] = pw ? sigmoid_t(x) * inv : 0.f;
+            s_sg[w][l] = (valid && pw) ? sigmoid_t(x) * inv : 0.f;
         }
         __builtin_amdgcn_wave_barrier();
         const int cnt = min(64, end - cb);
-        for (int e = 0; e < cnt; ++e) {
-            const int v = cb + e;
-            const float sc = s_sc[w][e];
-            float part = 0.f;
-            for (int j = l; j < nvec; j += 64) {
-                float dg[VEC], x[VEC], m[VEC], o[VEC];
-                ro_vload<VEC>(d_hg + (long long)g * D + (long long)j * VEC, dg);
+        for (int e = 0; e < cnt; e += EU) {
+            float part[EU];
 #pragma unroll
-                for (int k = 0; k < VEC; ++k) o[k] = sc * dg[k];
-                ro_vstore<VEC>(d_h + (long long)v * ld_dh + (long long)j * VEC, o);
+            for (int u = 0; u < EU; ++u) part[u] = 0.f;
+            for (int t0 = 0; t0 < nvec; t0 += 64 * NI) {
+                int off[NI];
+                float dg[NI][VEC], m[NI][VEC], x[EU][NI][VEC];
+#pragma unroll
+                for (int i = 0; i < NI; ++i) {
+                    const int j = t0 + l + 64 * i;
+                    off[i] = ((j < nvec) ? j : t0) * VEC;
+                    ro_vload<VEC>(dgrow + off[i], dg[i]);
+                    if (pw) ro_vload<VEC>(mrow + off[i], m[i]);
+                }
                 if (pw) {
-                    ro_vload<VEC>(h + (long long)v * ld_h + (long long)j * VEC, x);
-                    ro_vload<VEC>(hg + (long long)g * D + (long long)j * VEC, m);
 #pragma unroll
-                    for (int k = 0; k < VEC; ++k) part = fmaf(dg[k], x[k] - m[k], part);
+                    for (int u = 0; u < EU; ++u) {
+                        const float* row = h + (long long)min(cb + e + u, end - 1) * ld_h;
+#pragma unroll
+                        for (int i = 0; i < NI; ++i) ro_vload<VEC>(row + off[i], x[u][i]);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < EU; ++u) {
+                    const int v = cb + e + u;
+                    const float sc = s_sc[w][e + u];
+#pragma unroll
+                    for (int i = 0; i < NI; ++i) {
+                        const bool live = (t0 + l + 64 * i) < nvec;
+                        if (live && v < end) {
+                            float o[VEC];
+#pragma unroll
+                            for (int k = 0; k < VEC; ++k) o[k] = sc * dg[i][k];
+                            ro_vstore<VEC>(d_h + (long long)v * ld_dh + off[i], o);
+                        }
+                        if (pw) {
+                            float d = 0.f;
+#pragma unroll
+                            for (int k = 0; k < VEC; ++k) d = fmaf(dg[i][k], x[u][i][k] - m[i][k], d);
+                            part[u] += live ? d : 0.f;
+                        }
+                    }
                 }
             }
             if (pw) {
-                part = wave_sum(part) * s_sg[w][e];
-                const int pc = s_pc[w][e];
 #pragma unroll
-                for (int c = 0; c < RO_MAX_VOCAB; ++c) dpw[c] += (pc == c) ? part : 0.f;
+                for (int u = 0; u < EU; ++u) {
+                    const float pt = wave_sum(part[u]) * s_sg[w][e + u];      // 0 past the end of the egonet
+                    const int pc = s_pc[w][e + u];
+#pragma unroll
+                    for (int c = 0; c < RO_MAX_VOCAB; ++c) dpw[c] += (pc == c) ? pt : 0.f;
+                }
             }
         }
         __builtin_amdgcn_wave_barrier();
@@ -265,9 +311,14 @@ int txe_readout_fwd(const int* graph_off, int G, const float* h, long long ld_h,
     const int nb = (G + RO_WAVES - 1) / RO_WAVES;
     const int vec = ro_pick_vec(D, ld_h, D, h, hg, nullptr);
     hipStream_t s = (hipStream_t)stream;
-    ProfScope prof(vec == 4 ? "readout_fwd_kernel<4>" : (vec == 2 ? "readout_fwd_kernel<2>" : "readout_fwd_kernel<1>"), s, 4.0 * (double)G * D, 1);   // output bytes; the caller adds the N*D input rows
-#define TXE_L(V) hipLaunchKernelGGL((readout_fwd_kernel<V>), dim3(nb), dim3(RO_WAVES * 64), 0, s, graph_off, G, h, ld_h, pos, pw, D, hg, wsum)
-    if (vec == 4) TXE_L(4); else if (vec == 2) TXE_L(2); else TXE_L(1);
+    const int ni = D / vec <= 128 ? 2 : (D / vec <= 256 ? 4 : 8);
+    char kn[64];
+    snprintf(kn, sizeof(kn), "readout_fwd_kernel<%d, %d>", vec, ni);
+    ProfScope prof(kn, s, 4.0 * (double)G * D, 1);   // output bytes; the caller adds the N*D input rows
+#define TXE_L(V, I) hipLaunchKernelGGL((readout_fwd_kernel<V, I>), dim3(nb), dim3(RO_WAVES * 64), 0, s, graph_off, G, h, ld_h, pos, pw, D, hg, wsum)
+    if (vec == 4) { if (ni == 8) TXE_L(4, 8); else if (ni == 4) TXE_L(4, 4); else TXE_L(4, 2); }
+    else if (vec == 2) { if (ni == 8) TXE_L(2, 8); else if (ni == 4) TXE_L(2, 4); else TXE_L(2, 2); }
+    else { if (ni == 8) TXE_L(1, 8); else if (ni == 4) TXE_L(1, 4); else TXE_L(1, 2); }
 #undef TXE_L
     TXE_CHECK_LAUNCH();
     return TXE_OK;
@@ -284,10 +335,16 @@ int txe_readout_bwd(const int* graph_off, int G, const float* h, long long ld_h,
         const int nb = (G + RO_WAVES - 1) / RO_WAVES;
         int vec = ro_pick_vec(D, ld_h, ld_dh, h, d_h, hg);
         if (vec > 1 && ((uintptr_t)d_hg % (vec * 4)) != 0) vec = 1;
-#define TXE_L(V)                                                                                                          \
-    hipLaunchKernelGGL((readout_bwd_kernel<V>), dim3(nb), dim3(RO_WAVES * 64), 0, s, graph_off, G, h, ld_h, pos, pw, vocab, \
+        const int ni = D / vec <= 128 ? 2 : (D / vec <= 256 ? 4 : 8);
+        char kn[64];
+        snprintf(kn, sizeof(kn), "readout_bwd_kernel<%d, %d>", vec, ni);
+        ProfScope prof(kn, s, 4.0 * (double)G * D, 1);   // d_hg rows; the caller adds the N*D rows read (h) and written (d_h)
+#define TXE_L(V, I)                                                                                                          \
+    hipLaunchKernelGGL((readout_bwd_kernel<V, I>), dim3(nb), dim3(RO_WAVES * 64), 0, s, graph_off, G, h, ld_h, pos, pw, vocab, \
                        D, hg, wsum, d_hg, d_h, ld_dh, dpw_ws)
-        if (vec == 4) TXE_L(4); else if (vec == 2) TXE_L(2); else TXE_L(1);
+        if (vec == 4) { if (ni == 8) TXE_L(4, 8); else if (ni == 4) TXE_L(4, 4); else TXE_L(4, 2); }
+        else if (vec == 2) { if (ni == 8) TXE_L(2, 8); else if (ni == 4) TXE_L(2, 4); else TXE_L(2, 2); }
+        else { if (ni == 8) TXE_L(1, 8); else if (ni == 4) TXE_L(1, 4); else TXE_L(1, 2); }
 #undef TXE_L
         TXE_CHECK_LAUNCH();
     }

@@ -114,7 +114,8 @@ int txe_readout_multi_bwd(const int* graph_off, int G, const int* pos, int D, in
                           float* d_h, long long ld_dh, void* stream);
 
 /* ---- matchers: BIM model_zoo.py:313, LBM :328 (apply_exp) ------------------------------------------------------- */
-int txe_bilinear_project(const float* e1, long long ld_e1, int G, int l, const float* W, int r, float* U, void* stream);
+int txe_bilinear_project(const float* e1, long long ld_e1, int G, int l, const float* W, int r, float* U, long long ld_u,
+                         void* stream);
 int txe_bilinear_pair_fwd(const float* e1, long long ld_e1, const float* e2, long long ld_e2, int G, int l, int r,
                           const float* W, int apply_exp, float* U, float* s, void* stream);
 size_t txe_bilinear_pair_bwd_ws_bytes(int G, int l, int r);
@@ -130,7 +131,7 @@ int txe_linear_bwd(const float* x1, long long ld1, int l, const float* x2, long 
                    void* ws, size_t ws_bytes, void* stream);
 /* ---- all-candidate scoring loop: test_fast.py:116-123 / infer.py:95-99.  U = txe_bilinear_project(hg, W) once, then
  * per query block S[q][g] = match(hg[g], Q[q]) for every candidate g. */
-int txe_score_block(const float* Q, long long ld_q, int nq, const float* U, int G, int r, int apply_exp, float* S,
+int txe_score_block(const float* Q, long long ld_q, int nq, const float* U, long long ld_u, int G, int r, int apply_exp, float* S,
                     long long ld_s, void* stream);
 
 /* plain dense product on the fp32 MFMA GEMM (tests / micro-benchmarks).  layout 0: C = A[M][K] B[N][K]^T; 1: C = A[M][K] B[K][N];

@@ -100,12 +100,13 @@ using namespace txe;
 
 extern "C" {
 
-// U[G][r] = E1[G][l] * W[l][r]
-int txe_bilinear_project(const float* e1, long long ld_e1, int G, int l, const float* W, int r, float* U, void* stream) {
-    if (G < 0 || l < 1 || r < 1 || !e1 || !W || !U) return TXE_ERR_ARG;
+// U[G][r] = E1[G][l] * W[l][r]   (row stride ld_u >= r: a multiple of 4 lets the scoring GEMM read U with 16-byte loads)
+int txe_bilinear_project(const float* e1, long long ld_e1, int G, int l, const float* W, int r, float* U, long long ld_u,
+                         void* stream) {
+    if (G < 0 || l < 1 || r < 1 || ld_u < r || !e1 || !W || !U) return TXE_ERR_ARG;
     VMat A = vmat_plain(e1, ld_e1, G, l);
     VMat B = vmat_plain(W, r, l, r);
-    Epi E = epi_plain(U, r, r);
+    Epi E = epi_plain(U, ld_u, r);
     return gemm_nn(A, B, E, G, r, l, 1, (hipStream_t)stream);
 }
 
@@ -114,7 +115,7 @@ int txe_bilinear_project(const float* e1, long long ld_e1, int G, int l, const f
 int txe_bilinear_pair_fwd(const float* e1, long long ld_e1, const float* e2, long long ld_e2, int G, int l, int r,
                           const float* W, int apply_exp, float* U, float* s, void* stream) {
     if (G < 0 || !e2 || !s) return TXE_ERR_ARG;
-    int rc = txe_bilinear_project(e1, ld_e1, G, l, W, r, U, stream);
+    int rc = txe_bilinear_project(e1, ld_e1, G, l, W, r, U, r, stream);
     if (rc) return rc;
     if (G == 0) return TXE_OK;
     hipLaunchKernelGGL(rowdot_kernel, dim3((G + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const float*)U, e2, ld_e2, G, r,
@@ -259,11 +260,11 @@ int txe_linear_bwd(const float* x1, long long ld1, int l, const float* x2, long 
 }
 
 // One block of the scoring loop: S[q][g] = <Q[q], U[g]> (exp optionally), q < nq, g < G.  S row stride ld_s.
-int txe_score_block(const float* Q, long long ld_q, int nq, const float* U, int G, int r, int apply_exp, float* S,
+int txe_score_block(const float* Q, long long ld_q, int nq, const float* U, long long ld_u, int G, int r, int apply_exp, float* S,
                     long long ld_s, void* stream) {
-    if (nq < 0 || G < 0 || r < 1 || !Q || !U || !S) return TXE_ERR_ARG;
+    if (nq < 0 || G < 0 || r < 1 || ld_u < r || !Q || !U || !S) return TXE_ERR_ARG;
     VMat A = vmat_plain(Q, ld_q, nq, r);
-    VMat B = vmat_plain(U, r, G, r);
+    VMat B = vmat_plain(U, ld_u, G, r);
     Epi E = epi_plain(S, ld_s, G);
     E.apply_exp = apply_exp;
     return gemm_nt(A, B, E, nq, G, r, 1, (hipStream_t)stream);

@@ -19,6 +19,58 @@ __global__ __launch_bounds__(256) void rank_kernel(const float* __restrict__ S, 
     const int q = blockIdx.x;
     const float* row = S + (long long)q * ld_s;
     const int pb = pos_off[q], pe = pos_off[q + 1];
+    // Rows on a 16-byte pitch (every caller in this repo): the thresholds of four positives sit in registers and ONE sweep of
+    // the row with 16-byte loads, four in flight per thread, counts against all of them -- the row is read once per four
+    // positives instead of once per positive with dword loads.
+    if ((ld_s & 3) == 0 && (reinterpret_cast<uintptr_t>(S) & 15) == 0) {
+        const float4* row4 = reinterpret_cast<const float4*>(row);
+        const int g4n = G >> 2;
+        for (int c0 = pb; c0 < pe; c0 += 4) {
+            const int np = min(4, pe - c0);
+            float sp[4];
+            int cnt[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) sp[k] = row[pos_idx[c0 + min(k, np - 1)]];
+            for (int g0 = 0; g0 < g4n; g0 += 4 * 256) {
+                float4 v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v[u] = row4[min(g0 + u * 256 + (int)threadIdx.x, g4n - 1)];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const bool ok = g0 + u * 256 + (int)threadIdx.x < g4n;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int c = larger_is_better ? ((v[u].x > sp[k]) + (v[u].y > sp[k]) + (v[u].z > sp[k]) + (v[u].w > sp[k]))
+                                                       : ((v[u].x < sp[k]) + (v[u].y < sp[k]) + (v[u].z < sp[k]) + (v[u].w < sp[k]));
+                        cnt[k] += ok ? c : 0;
+                    }
+                }
+            }
+            for (int g = (g4n << 2) + threadIdx.x; g < G; g += 256) {      // ragged end of the row
+                const float x = row[g];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) cnt[k] += larger_is_better ? (x > sp[k]) : (x < sp[k]);
+            }
+            for (int j = pb + threadIdx.x; j < pe; j += 256) {             // positives never count against each other
+                const float x = row[pos_idx[j]];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) cnt[k] -= larger_is_better ? (x > sp[k]) : (x < sp[k]);
+            }
+            if (threadIdx.x < 4) s_cnt[threadIdx.x] = 0;
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                int c = cnt[k];
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+                if ((threadIdx.x & 63) == 0) atomicAdd(&s_cnt[k], c);       // integer: order independent
+            }
+            __syncthreads();
+            if ((int)threadIdx.x < np) ranks[c0 + threadIdx.x] = s_cnt[threadIdx.x] + 1;
+            __syncthreads();
+        }
+        return;
+    }
     for (int c0 = pb; c0 < pe; c0 += RANK_MAXP) {
         const int np = min(RANK_MAXP, pe - c0);
         if (threadIdx.x < np) { s_sp[threadIdx.x] = row[pos_idx[c0 + threadIdx.x]]; s_cnt[threadIdx.x] = 0; }

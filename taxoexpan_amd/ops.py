@@ -494,9 +494,10 @@ def bilinear_project(hg, W):
     Wf = _f32(W).reshape(W.shape[-2], W.shape[-1])
     G, l = hg.shape
     r = Wf.shape[1]
-    U = _empty((G, r), hg)
+    rp = (r + 3) // 4 * 4                               # rows padded to 16 bytes: the scoring GEMM then loads U with dwordx4
+    U = _empty((G, rp), hg)[:, :r]
     with torch.cuda.device(hg.device):
-        call("txe_bilinear_project", ptr(hg), ld, G, l, ptr(Wf), r, ptr(U), _lib.stream_ptr())
+        call("txe_bilinear_project", ptr(hg), ld, G, l, ptr(Wf), r, ptr(U), rp, _lib.stream_ptr())
     return U
 
 
@@ -504,11 +505,16 @@ def score_block(Q, U, apply_exp, out=None):
     """S[q][g] = match(hg[g], Q[q]) for a block of queries against every candidate (test_fast.py:116-123)."""
     _need_cuda(Q, U)
     Q, ldq = _rows(Q)
+    U, ldu = _rows(U)
     nq, r = Q.shape
+    if ldq % 4 != 0 and nq > 0:                         # query rows re-laid out on a 16-byte pitch (a few hundred KB per block)
+        Qp = _empty((nq, (r + 3) // 4 * 4), Q)[:, :r]
+        Qp.copy_(Q)
+        Q, ldq = Qp, Qp.stride(0)
     G = U.shape[0]
-    S = out if out is not None else _empty((nq, G), Q)
+    S = out if out is not None else _empty((nq, (G + 3) // 4 * 4), Q)[:, :G]     # 16-byte row pitch: vector stores / rank sweeps
     with torch.cuda.device(Q.device):
-        call("txe_score_block", ptr(Q), ldq, nq, ptr(U), G, r, int(apply_exp), ptr(S), S.stride(0), _lib.stream_ptr())
+        call("txe_score_block", ptr(Q), ldq, nq, ptr(U), ldu, G, r, int(apply_exp), ptr(S), S.stride(0), _lib.stream_ptr())
     return S
 
 

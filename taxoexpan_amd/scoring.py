@@ -19,7 +19,8 @@ def score_all(match, hg, queries, block=1024, out=None):
     """S[q][g] = match(hg[g], queries[q]) for all pairs; match is a BIM / LBM module."""
     U = ops.bilinear_project(hg, match.W.weight)
     Q = queries.shape[0]
-    S = out if out is not None else torch.empty((Q, hg.shape[0]), dtype=torch.float32, device=hg.device)
+    G = hg.shape[0]
+    S = out if out is not None else torch.empty((Q, (G + 3) // 4 * 4), dtype=torch.float32, device=hg.device)[:, :G]
     for q0 in range(0, Q, block):
         ops.score_block(queries[q0:q0 + block], U, match.apply_exp, out=S[q0:q0 + block])
     return S
@@ -98,11 +99,8 @@ def allreduce_gradients(params, group=None):
         return
     flat = torch.cat([g.reshape(-1) for g in grads])
     dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
-    off = 0
-    for g in grads:
-        n = g.numel()
-        g.copy_(flat[off:off + n].view_as(g))
-        off += n
+    parts = flat.split([g.numel() for g in grads])
+    torch._foreach_copy_(grads, [q.view_as(g) for q, g in zip(parts, grads)])      # one multi-tensor kernel
 
 
 def topk_parents(S, candidate_ids, k=5, larger_is_better=True):

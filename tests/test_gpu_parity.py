@@ -485,3 +485,27 @@ def test_ntn_and_residual_gat_against_reference_goldens():
         np.testing.assert_allclose(x.grad.cpu().numpy(), z[tag + ".d_x"], rtol=2e-3, atol=2e-5)
         for k, p in layer.named_parameters():
             np.testing.assert_allclose(p.grad.cpu().numpy(), z[f"{tag}.g.{k}"], rtol=2e-3, atol=2e-5, err_msg=k)
+
+
+@pytest.mark.parametrize("G,pitch,larger", [(1000, 1000, True), (1003, 1003, True), (1003, 1004, False), (5000, 5000, False), (37, 40, True)])
+def test_rank_kernel_against_metric_definition(G, pitch, larger):
+    """txe_rank_block on both row layouts (16-byte pitch -> single-sweep path, odd pitch -> scalar path), 1..9 positives per
+    query, heavy ties: rank(p) = 1 + #{g not a positive : S[g] strictly better than S[p]}  (model/metric.py:7-31)"""
+    from taxoexpan_amd import ops
+    rs = np.random.RandomState(G + pitch)
+    nq = 23
+    S = np.round(rs.randn(nq, G) * 3).astype(np.float32) / 2            # many exact ties
+    npos = rs.randint(1, 10, size=nq)
+    pos_idx = np.concatenate([rs.choice(G, size=k, replace=False) for k in npos]).astype(np.int32)
+    pos_off = np.concatenate([[0], np.cumsum(npos)]).astype(np.int32)
+    want = []
+    for q in range(nq):
+        P = pos_idx[pos_off[q]:pos_off[q + 1]]
+        neg = np.ones(G, dtype=bool)
+        neg[P] = False
+        for p in P:
+            want.append(1 + int(((S[q][neg] > S[q][p]) if larger else (S[q][neg] < S[q][p])).sum()))
+    Sd = torch.empty((nq, pitch), device=_dev())[:, :G]
+    Sd.copy_(torch.from_numpy(S))
+    got = ops.rank_block(Sd, torch.from_numpy(pos_off), torch.from_numpy(pos_idx), larger)
+    assert got.cpu().numpy().tolist() == want

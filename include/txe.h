@@ -152,6 +152,25 @@ size_t txe_build_csr_ws_bytes(int n_nodes, int n_edges);
 int txe_build_csr(const int* src, const int* dst, int n_nodes, int n_edges, int* rowptr_in, int* col_src, int* eid_in,
                   int* rowptr_out, int* col_dst, int* pos_out, void* ws, size_t ws_bytes, void* stream);
 
+/* ---- output GATLayer (ONE head) folded behind MeanReadout / WeightedMeanReadout: model_zoo.py:80-104,219,227-242.
+ * hg[g] = (sum_{u in g} c_u Xd[u]) W^T with c_u = sum_{v: u->v} w_v alpha'_uv / S_g -- the same arithmetic as projection ->
+ * edge-softmax aggregation -> weighted mean, re-associated so that the projection and its dX / dW products run on G graph rows
+ * instead of N node rows.  X [N][Kp] / Wp [Fp][Kp] / mask as for txe_gat_dense_*; pw == NULL: MeanReadout.  Forward keeps
+ * a12 [N][2], alpha [E], coef [N], wsum [G], gid [N], Z [G][Kp] for backward; d_X has the layout txe_gat_dense_bwd produces. */
+size_t txe_gat_collapse_ws_bytes(int n_nodes, int n_edges, int G, int Kh, int Pd, int D, int vocab);
+int txe_gat_collapse_fwd(const int* rowptr_in, const int* col_src, const int* rowptr_out, const int* col_dst, const int* pos_out,
+                         const int* graph_off, int n_nodes, int n_edges, int G, const float* X, int Kh, int Pd, const float* Wp, int D,
+                         float feat_drop_p, const unsigned* mask, float attn_slope, float attn_drop_p, unsigned long long seed,
+                         const int* pos, const float* pw, float* a12, float* alpha, float* coef, float* wsum, int* gid, float* Z,
+                         float* hg, long long ld_hg, void* ws, size_t ws_bytes, void* stream);
+int txe_gat_collapse_bwd(const int* rowptr_in, const int* col_src, const int* rowptr_out, const int* col_dst, const int* pos_out,
+                         const int* graph_off, int n_nodes, int n_edges, int G, const float* X, int Kh, int Pd, const int* pos, int vocab,
+                         const float* Wp, const float* W, const float* attn_l, const float* attn_r, int D, float feat_drop_p,
+                         const unsigned* mask, float attn_slope, float attn_drop_p, unsigned long long seed, const float* pw,
+                         const float* a12, const float* alpha, const float* coef, const float* wsum, const int* gid, const float* Z,
+                         const float* d_hg, long long ld_dhg, int act_on, float act_slope, float* d_X, float* dW, float* d_attn_l,
+                         float* d_attn_r, float* dP, float* d_pw, void* ws, size_t ws_bytes, void* stream);
+
 /* ---- egonet construction + batching on device: data_loader/dataset.py:404-437 (_get_subgraph) + dgl.batch (data_loaders.py:25).
  * Taxonomy as parent CSR (par_ptr/par_idx) and child CSR (chd_ptr/chd_idx); anchors [G]; exclude [G] or NULL (query node removed
  * from each egonet's siblings, -1 = none: the positive example of dataset.py:421-424); children beyond `expand` are drawn with

@@ -51,6 +51,10 @@ SIGNATURES = {
     "txe_build_csr_ws_bytes": (SZ, [I, I]),
     "txe_build_csr": (I, [P, P, I, I, P, P, P, P, P, P, P, SZ, P]),
     "txe_rank_block": (I, [P, L, I, I, P, P, P, I, P, P]),
+    "txe_gat_collapse_ws_bytes": (SZ, [I, I, I, I, I, I, I]),
+    "txe_gat_collapse_fwd": (I, [P, P, P, P, P, P, I, I, I, P, I, I, P, I, F, P, F, F, U64, P, P, P, P, P, P, P, P, P, L, P, SZ, P]),
+    "txe_gat_collapse_bwd": (I, [P, P, P, P, P, P, I, I, I, P, I, I, P, I, P, P, P, P, I, F, P, F, F, U64, P, P, P, P, P, P, P, P, L, I, F,
+                                 P, P, P, P, P, P, P, SZ, P]),
     "txe_egonet_ws_bytes": (SZ, [I]),
     "txe_egonet_offsets": (I, [P, P, P, P, P, I, I, U64, P, P, SZ, P]),
     "txe_egonet_fill": (I, [P, P, P, P, P, P, I, I, U64, P, P, P, P, P, P, P, P, P, P]),

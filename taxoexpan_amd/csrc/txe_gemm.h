@@ -606,13 +606,20 @@ int device_cu_count();     // txe_profile.hip (cached hipDeviceAttributeMultipro
 
 // 128 x BN tile choice: the narrower tile when it wastes fewer MFMA columns or needs fewer (fractional) rounds of
 // workgroups over the CUs (2 co-resident workgroups per CU).
-static inline int choose_bn(int M, int N, int splits) {
+static inline int choose_bn(int M, int N, int splits, bool tail_split = false, int K = 0) {
     if (N <= 64) return 64;
     const int slots = 2 * device_cu_count();
     auto cost = [&](int bn) {
         const long long blocks = (long long)((M + GEMM_BM - 1) / GEMM_BM) * ((N + bn - 1) / bn) * splits;
         const long long rounds = (blocks + slots - 1) / slots;
-        return (double)rounds * bn * (bn == 64 ? 1.6 : 1.0);     // the narrow tile is markedly less efficient per flop (measured)
+        double r = (double)rounds;
+        // with tail splitting a partial last round is cut along k: its time shrinks to its share of the slots (down to 4 k-tiles)
+        if (tail_split && splits == 1 && blocks % slots != 0) {
+            const double frac = (double)(blocks % slots) / slots;
+            const double kfloor = K > 0 ? 4.0 * GEMM_BK / K : 0.25;
+            r = (double)(blocks / slots) + (frac > kfloor ? frac : kfloor) + 0.1;      // + fix-up kernel
+        }
+        return r * bn * (bn == 64 ? 1.6 : 1.0);                  // the narrow tile is markedly less efficient per flop (measured)
     };
     return cost(64) < cost(128) ? 64 : 128;
 }
@@ -656,7 +663,7 @@ static inline int gemm_launch_layout(const VMat& A, const VMat& B, const Epi& E_
     int va = vmat_vec(A), vb = vmat_vec(B);
     if (va == 1 || vb == 1) va = vb = 1;
     if (splits < 1) splits = 1;
-    const int bn = choose_bn(M, N, splits);
+    const int bn = choose_bn(M, N, splits, tail_ws != nullptr, K);
     const int nbm = (M + GEMM_BM - 1) / GEMM_BM, nbn = (N + bn - 1) / bn;
     int ksplit = (K + splits - 1) / splits;
     ksplit = ((ksplit + GEMM_BK - 1) / GEMM_BK) * GEMM_BK;

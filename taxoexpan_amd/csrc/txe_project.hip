@@ -12,6 +12,7 @@
 //    d a1, d a2 ride as 2H extra columns of the incoming gradient through the dX and dW GEMMs and are
 //    unfolded on the (tiny) weight side:  dW += attn (x) d wa,  d attn = <d wa, W>.
 #include "txe_gemm.h"
+#include "txe_gather.h"
 
 namespace txe {
 
@@ -474,6 +475,513 @@ int txe_gcn_dense_bwd(const float* X, int n_nodes, int Kh, int Pd, const int* po
                            (const float*)p.part, n_nodes > 0 ? p.splits : 0, E.split_stride, Kt, Fo, Fop, dW);
         TXE_CHECK_LAUNCH();
     }
+    return TXE_OK;
+}
+
+}  // extern "C"
+
+// =====================================================================================================================
+// Last GATLayer folded behind a linear readout (PGAT / GAT output layer with ONE head + MeanReadout / WeightedMeanReadout;
+// model_zoo.py:80-104,219,227-242).  The output layer has no activation, its head mean is the identity, and the readout is
+// a weighted mean, so   hg[g] = sum_v w_v/S_g * sum_u alpha'_uv * (Xd[u] W^T)  =  ( sum_{u in g} c_u Xd[u] ) W^T,
+//     c_u = sum_{v : u->v} w_v alpha'_uv / S_g,   Xd = feat-dropped layer input,  alpha' = attention-dropped softmax,
+// and the attention logits need only two columns:  a1 = Xd wa1, a2 = Xd wa2 (the folded rows F, F+1 of Wp).
+// Same arithmetic, different association: the projection (and its dX / dW products) shrink from N node rows to G graph
+// rows (4.4x fewer flops on the MAG batch); everything else is two HBM sweeps over X in forward and two in backward.
+//   forward : logits (sweep 1) -> alpha [E] -> c~ [N] -> Z[g] = sum c~_u Xd[u] / S_g (sweep 2) -> hg = Z W^T (GEMM, G rows)
+//   backward: dZ = d_hg W, dW = d_hg^T Z (GEMMs, G rows) -> dc~_u = <dZ[g], Xd[u]>/S_g, dS_g (sweep 3) -> edge-level softmax /
+//             readout-weight backward -> d_X[u] = keep*s*(c_u dZ[g] + da1_u wa1 + da2_u wa2) * leaky'(X), d_wa (sweep 4) -> unfold.
+// =====================================================================================================================
+namespace txe {
+
+constexpr int CL_NI = 4;                      // 16-byte vectors per lane per column tile (256 vectors = 1024 columns per tile)
+
+__device__ __forceinline__ float cl_softplus(float x) { return x > 20.f ? x : log1pf(__expf(x)); }
+__device__ __forceinline__ float cl_sigmoid(float x) { return x > 20.f ? 1.f : 1.f / (1.f + __expf(-x)); }
+
+// keep factors (0 / 1) of the 4 columns of vector j from the row's mask words (mask == nullptr: all kept)
+__device__ __forceinline__ void cl_keep4(const unsigned* __restrict__ mrow, int mask_ld, int j, float* k4) {
+    if (mrow == nullptr) { k4[0] = k4[1] = k4[2] = k4[3] = 1.f; return; }
+    const int c = j * 4;
+    const unsigned wd = mrow[min(c >> 5, mask_ld - 1)];
+    const unsigned b = (c >> 5) < mask_ld ? (wd >> (c & 31)) : 0u;
+    k4[0] = (b & 1u) ? 1.f : 0.f; k4[1] = (b & 2u) ? 1.f : 0.f; k4[2] = (b & 4u) ? 1.f : 0.f; k4[3] = (b & 8u) ? 1.f : 0.f;
+}
+
+// sweep 1 -- one wave per node (persistent waves keep the two folded rows in registers per column tile):
+//   a12[u][0] = <Xd[u], wa1>,  a12[u][1] = <Xd[u], wa2>
+__global__ __launch_bounds__(256) void cl_logits_kernel(const float* __restrict__ X, int Kp, int n_nodes, const unsigned* __restrict__ mask,
+                                                        int mask_ld, float scale, const float* __restrict__ wa /*[2][Kp]*/,
+                                                        float* __restrict__ a12) {
+    const int l = threadIdx.x & 63;
+    const int wave = (blockIdx.x * 256 + threadIdx.x) >> 6, nwaves = (gridDim.x * 256) >> 6;
+    const int nvec = Kp >> 2;
+    for (int u = wave; u < n_nodes; u += nwaves) {
+        const float* row = X + (long long)u * Kp;
+        const unsigned* mrow = mask ? mask + (long long)u * mask_ld : nullptr;
+        float s1 = 0.f, s2 = 0.f;
+        for (int t0 = 0; t0 < nvec; t0 += 64 * CL_NI) {
+            float x[CL_NI][4], w1[CL_NI][4], w2[CL_NI][4], k4[CL_NI][4];
+#pragma unroll
+            for (int i = 0; i < CL_NI; ++i) {
+                const int j = t0 + l + 64 * i;
+                const int jc = (j < nvec) ? j : t0;
+                vload<4>(row + jc * 4, x[i]);
+                vload<4>(wa + jc * 4, w1[i]);
+                vload<4>(wa + Kp + jc * 4, w2[i]);
+                cl_keep4(mrow, mask_ld, jc, k4[i]);
+                if (j >= nvec) k4[i][0] = k4[i][1] = k4[i][2] = k4[i][3] = 0.f;
+            }
+#pragma unroll
+            for (int i = 0; i < CL_NI; ++i)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float xd = x[i][k] * k4[i][k];
+                    s1 = fmaf(xd, w1[i][k], s1);
+                    s2 = fmaf(xd, w2[i][k], s2);
+                }
+        }
+        s1 = wave_sum(s1) * scale;
+        s2 = wave_sum(s2) * scale;
+        if (l == 0) { a12[2 * (long long)u] = s1; a12[2 * (long long)u + 1] = s2; }
+    }
+}
+
+// one wave per destination: alpha[p] = softmax over the in-edges of v of leaky(a1[u] + a2[v])      (model_zoo.py:106-114)
+__global__ __launch_bounds__(256) void cl_alpha_kernel(const int* __restrict__ rowptr, const int* __restrict__ col, int n_nodes,
+                                                       const float* __restrict__ a12, float slope, float* __restrict__ alpha) {
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    const int v = blockIdx.x * 4 + w;
+    if (v >= n_nodes) return;
+    const int beg = rowptr[v], end = rowptr[v + 1];
+    const float a2v = a12[2 * (long long)v + 1];
+    float m = -INFINITY;
+    for (int p = beg + l; p < end; p += 64) m = fmaxf(m, leaky(a12[2 * (long long)col[p]] + a2v, slope));
+    m = wave_max(m);
+    float s = 0.f;
+    for (int p = beg + l; p < end; p += 64) s += __expf(leaky(a12[2 * (long long)col[p]] + a2v, slope) - m);
+    s = wave_sum(s);
+    const float inv = 1.f / s;
+    for (int p = beg + l; p < end; p += 64) alpha[p] = __expf(leaky(a12[2 * (long long)col[p]] + a2v, slope) - m) * inv;
+}
+
+// one thread per source: c~_u = sum_{j in out(u)} w_{dst(j)} * alpha'[pos_out[j]]
+__global__ void cl_coef_kernel(const int* __restrict__ rowptr_out, const int* __restrict__ col_dst, const int* __restrict__ pos_out,
+                               int n_nodes, const float* __restrict__ alpha, float drop_p, float drop_scale, unsigned long long seed,
+                               const int* __restrict__ pos, const float* __restrict__ pw, float* __restrict__ coef) {
+    const int u = blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= n_nodes) return;
+    float c = 0.f;
+    for (int j = rowptr_out[u]; j < rowptr_out[u + 1]; ++j) {
+        const int p = pos_out[j], v = col_dst[j];
+        float f = 1.f;
+        if (drop_p > 0.f) f = drop_factor(seed, (unsigned long long)p, drop_p, drop_scale);
+        const float wv = pw ? cl_softplus(pw[pos[v]]) : 1.f;
+        c = fmaf(wv * f, alpha[p], c);
+    }
+    coef[u] = c;
+}
+
+// per graph: S_g = sum_v w_v -> wsum[g];  gid[v] = g for its nodes
+__global__ __launch_bounds__(256) void cl_wsum_kernel(const int* __restrict__ goff, int G, const int* __restrict__ pos,
+                                                      const float* __restrict__ pw, float* __restrict__ wsum, int* __restrict__ gid) {
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    const int g = blockIdx.x * 4 + w;
+    if (g >= G) return;
+    const int beg = goff[g], end = goff[g + 1];
+    float S = 0.f;
+    for (int v = beg + l; v < end; v += 64) {
+        S += pw ? cl_softplus(pw[pos[v]]) : 1.f;
+        gid[v] = g;
+    }
+    S = wave_sum(S);
+    if (l == 0) wsum[g] = S;
+}
+
+// sweep 2 -- one wave per (graph, 256-column tile):  Z[g][tile] = (scale / S_g) sum_{u in g} c~_u (X[u] * keep)[tile]
+__global__ __launch_bounds__(256) void cl_zsum_kernel(const int* __restrict__ goff, int G, int ntile, const float* __restrict__ X, int Kp,
+                                                      const unsigned* __restrict__ mask, int mask_ld, float scale,
+                                                      const float* __restrict__ coef, const float* __restrict__ wsum,
+                                                      float* __restrict__ Z) {
+    const int l = threadIdx.x & 63;
+    const long long wid = ((long long)blockIdx.x * 256 + threadIdx.x) >> 6;
+    const int g = (int)(wid / ntile), t = (int)(wid % ntile);
+    if (g >= G) return;
+    const int beg = goff[g], end = goff[g + 1];
+    const int nvec = Kp >> 2;
+    const int j = t * 64 + l;
+    const int jc = (j < nvec) ? j : t * 64;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int u0 = beg; u0 < end; u0 += 4) {                          // four nodes per step: independent loads in flight
+        float x[4][4], k4[4][4], cu[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int u = min(u0 + e, end - 1);
+            cu[e] = (u0 + e < end) ? coef[u] : 0.f;
+            vload<4>(X + (long long)u * Kp + jc * 4, x[e]);
+            cl_keep4(mask ? mask + (long long)u * mask_ld : nullptr, mask_ld, jc, k4[e]);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) acc[k] = fmaf(cu[e] * k4[e][k], x[e][k], acc[k]);
+    }
+    if (j < nvec) {
+        const float S = wsum[g];
+        const float zs = S > 0.f ? scale / S : 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc[k] *= zs;
+        vstore<4>(Z + (long long)g * Kp + j * 4, acc);
+    }
+}
+
+// per graph: dS[g] = -<dZ[g], Z[g]> / S_g
+__global__ __launch_bounds__(256) void cl_bwd_ds_kernel(int G, int Kp, const float* __restrict__ dZ, const float* __restrict__ Z,
+                                                        const float* __restrict__ wsum, float* __restrict__ dS) {
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    const int g = blockIdx.x * 4 + w;
+    if (g >= G) return;
+    const int nvec = Kp >> 2;
+    float s = 0.f;
+    for (int j = l; j < nvec; j += 64) {
+        float d[4], z[4];
+        vload<4>(dZ + (long long)g * Kp + j * 4, d);
+        vload<4>(Z + (long long)g * Kp + j * 4, z);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) s = fmaf(d[k], z[k], s);
+    }
+    s = wave_sum(s);
+    if (l == 0) dS[g] = wsum[g] > 0.f ? -s / wsum[g] : 0.f;
+}
+
+// sweep 3 -- one wave per node:  dc~_u = (scale / S_g) <dZ[g], X[u] * keep>
+__global__ __launch_bounds__(256) void cl_bwd_dot_kernel(int n_nodes, const int* __restrict__ gid, const float* __restrict__ X, int Kp,
+                                                         const unsigned* __restrict__ mask, int mask_ld, float scale,
+                                                         const float* __restrict__ dZ, const float* __restrict__ wsum,
+                                                         float* __restrict__ dc) {
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    const int u = blockIdx.x * 4 + w;
+    if (u >= n_nodes) return;
+    const int g = gid[u];
+    const int nvec = Kp >> 2;
+    const float* row = X + (long long)u * Kp;
+    const float* dzrow = dZ + (long long)g * Kp;
+    const unsigned* mrow = mask ? mask + (long long)u * mask_ld : nullptr;
+    float part = 0.f;
+    for (int t0 = 0; t0 < nvec; t0 += 64 * CL_NI) {
+        float x[CL_NI][4], d[CL_NI][4], k4[CL_NI][4];
+#pragma unroll
+        for (int i = 0; i < CL_NI; ++i) {
+            const int j = t0 + l + 64 * i;
+            const int jc = (j < nvec) ? j : t0;
+            vload<4>(row + jc * 4, x[i]);
+            vload<4>(dzrow + jc * 4, d[i]);
+            cl_keep4(mrow, mask_ld, jc, k4[i]);
+            if (j >= nvec) k4[i][0] = k4[i][1] = k4[i][2] = k4[i][3] = 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < CL_NI; ++i)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) part = fmaf(d[i][k] * k4[i][k], x[i][k], part);
+    }
+    part = wave_sum(part);
+    if (l == 0) dc[u] = wsum[g] > 0.f ? part * scale / wsum[g] : 0.f;
+}
+
+// one wave per destination v: readout-weight and softmax backward of the edge coefficients
+//   d_w_v = dS_g(v) + sum_p alpha_p f_p dc~_{u_p};  dalpha_p = w_v f_p dc~_{u_p};  dz_p = alpha_p (dalpha_p - sum alpha dalpha) leaky'(z_p)
+//   outputs: dz[p], da2[v] = sum_p dz_p, dwv[v] = d_w_v * sigmoid(pw[pos_v])  (0 without position weights)
+__global__ __launch_bounds__(256) void cl_bwd_edge_kernel(const int* __restrict__ rowptr, const int* __restrict__ col, int n_nodes,
+                                                          const float* __restrict__ a12, float slope, const float* __restrict__ alpha,
+                                                          float drop_p, float drop_scale, unsigned long long seed,
+                                                          const int* __restrict__ pos, const float* __restrict__ pw,
+                                                          const float* __restrict__ dc, const float* __restrict__ dS,
+                                                          const int* __restrict__ gid, float* __restrict__ dz, float* __restrict__ da2,
+                                                          float* __restrict__ dwv) {
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    const int v = blockIdx.x * 4 + w;
+    if (v >= n_nodes) return;
+    const int beg = rowptr[v], end = rowptr[v + 1];
+    const float pwv = pw ? pw[pos[v]] : 0.f;
+    const float wv = pw ? cl_softplus(pwv) : 1.f;
+    const float a2v = a12[2 * (long long)v + 1];
+    float T = 0.f, dw = 0.f;
+    for (int p = beg + l; p < end; p += 64) {
+        float f = 1.f;
+        if (drop_p > 0.f) f = drop_factor(seed, (unsigned long long)p, drop_p, drop_scale);
+        const float g = alpha[p] * f * dc[col[p]];
+        dw += g;                       // alpha f dc
+        T = fmaf(alpha[p], wv * f * dc[col[p]], T);
+    }
+    T = wave_sum(T);
+    dw = wave_sum(dw);
+    float s2 = 0.f;
+    for (int p = beg + l; p < end; p += 64) {
+        float f = 1.f;
+        if (drop_p > 0.f) f = drop_factor(seed, (unsigned long long)p, drop_p, drop_scale);
+        const float da = wv * f * dc[col[p]];
+        const float de = alpha[p] * (da - T);
+        const float z = a12[2 * (long long)col[p]] + a2v;
+        const float gz = de * (z > 0.f ? 1.f : slope);
+        dz[p] = gz;
+        s2 += gz;
+    }
+    s2 = wave_sum(s2);
+    if (l == 0) {
+        da2[v] = s2;
+        dwv[v] = pw ? (dS[gid[v]] + dw) * cl_sigmoid(pwv) : 0.f;
+    }
+}
+
+// one thread per source: da1[u] = sum_{j in out(u)} dz[pos_out[j]]
+__global__ void cl_bwd_src_kernel(const int* __restrict__ rowptr_out, const int* __restrict__ pos_out, int n_nodes,
+                                  const float* __restrict__ dz, float* __restrict__ da1) {
+    const int u = blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= n_nodes) return;
+    float a = 0.f;
+    for (int j = rowptr_out[u]; j < rowptr_out[u + 1]; ++j) a += dz[pos_out[j]];
+    da1[u] = a;
+}
+
+// sweep 4 -- one wave per (chunk of CL_CHUNK nodes, 256-column tile):
+//   d_X[u][j] = keep * scale * (c~_u / S_g * dZ[g][j] + da1[u] wa1[j] + da2[u] wa2[j]) * (act_on && j < Kh ? leaky'(X[u][j]) : 1)
+//   dwa_part[chunk][0/1][j] = sum over the chunk's nodes of da1/da2[u] * scale * keep * X[u][j]     (fixed order: deterministic)
+constexpr int CL_CHUNK = 32;
+__global__ __launch_bounds__(256) void cl_bwd_dx_kernel(int n_nodes, int ntile, const int* __restrict__ gid, const float* __restrict__ X, int Kp,
+                                                        int Kh, const unsigned* __restrict__ mask, int mask_ld, float scale,
+                                                        const float* __restrict__ dZ, const float* __restrict__ coef,
+                                                        const float* __restrict__ wsum, const float* __restrict__ da1,
+                                                        const float* __restrict__ da2, const float* __restrict__ wa, int act_on,
+                                                        float act_slope, float* __restrict__ d_X, float* __restrict__ dwa_part) {
+    const int l = threadIdx.x & 63;
+    const long long wid = ((long long)blockIdx.x * 256 + threadIdx.x) >> 6;
+    const int chunk = (int)(wid / ntile), t = (int)(wid % ntile);
+    const int u_beg = chunk * CL_CHUNK;
+    if (u_beg >= n_nodes) return;
+    const int u_end = min(n_nodes, u_beg + CL_CHUNK);
+    const int nvec = Kp >> 2;
+    const int j = t * 64 + l;
+    const int jc = (j < nvec) ? j : t * 64;
+    float w1[4], w2[4], s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+    vload<4>(wa + jc * 4, w1);
+    vload<4>(wa + Kp + jc * 4, w2);
+    for (int u0 = u_beg; u0 < u_end; u0 += 4) {                      // four nodes per step: independent loads in flight
+        float x[4][4], d[4][4], k4[4][4], cu[4], g1[4], g2[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int u = min(u0 + e, u_end - 1);
+            const bool ok = u0 + e < u_end;
+            const int g = gid[u];
+            const float S = wsum[g];
+            cu[e] = (ok && S > 0.f) ? coef[u] / S : 0.f;
+            g1[e] = ok ? da1[u] : 0.f;
+            g2[e] = ok ? da2[u] : 0.f;
+            vload<4>(X + (long long)u * Kp + jc * 4, x[e]);
+            vload<4>(dZ + (long long)g * Kp + jc * 4, d[e]);
+            cl_keep4(mask ? mask + (long long)u * mask_ld : nullptr, mask_ld, jc, k4[e]);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (u0 + e < u_end && j < nvec) {
+                float o[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    float v = k4[e][k] * scale * (cu[e] * d[e][k] + g1[e] * w1[k] + g2[e] * w2[k]);
+                    if (act_on && (j * 4 + k) < Kh) v *= (x[e][k] > 0.f) ? 1.f : act_slope;
+                    o[k] = v;
+                }
+                vstore<4>(d_X + (long long)(u0 + e) * Kp + j * 4, o);
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float xd = x[e][k] * k4[e][k] * scale;
+                s1[k] = fmaf(g1[e], xd, s1[k]);
+                s2[k] = fmaf(g2[e], xd, s2[k]);
+            }
+        }
+    }
+    if (j < nvec) {
+        vstore<4>(dwa_part + ((long long)chunk * 2 + 0) * Kp + j * 4, s1);
+        vstore<4>(dwa_part + ((long long)chunk * 2 + 1) * Kp + j * 4, s2);
+    }
+}
+
+struct CollapseWs {
+    float *dZ, *part, *dwa_part, *dwa, *dc, *dS, *dz, *da1, *da2, *dwv, *ppart, *ppart2;
+    void* tail;
+    size_t tail_bytes, total;
+    int splits, seg_blocks, seg_rows, chunks;
+};
+
+static CollapseWs plan_collapse_ws(void* ws, int n, int e, int G, int Kp, int D, int Pd, int vocab) {
+    CollapseWs p;
+    char* b = (char*)ws;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { float* r = (float*)(b + off); off += align_up(bytes > 0 ? bytes : 4, 256); return r; };
+    const int n1 = n > 0 ? n : 1, v1 = vocab > 0 ? vocab : 1;
+    p.dZ = take((size_t)(G > 0 ? G : 1) * Kp * 4);
+    p.splits = choose_splits(D, Kp, G);
+    p.part = take((size_t)p.splits * D * Kp * 4);
+    p.chunks = (n + CL_CHUNK - 1) / CL_CHUNK;
+    p.dwa_part = take((size_t)(p.chunks > 0 ? p.chunks : 1) * 2 * Kp * 4);
+    p.dwa = take((size_t)2 * Kp * 4);
+    p.dc = take((size_t)n1 * 4);
+    p.dS = take((size_t)(G > 0 ? G : 1) * 4);
+    p.dz = take((size_t)(e > 0 ? e : 1) * 4);
+    p.da1 = take((size_t)n1 * 4);
+    p.da2 = take((size_t)n1 * 4);
+    p.dwv = take((size_t)n1 * 4);
+    p.seg_rows = 64;
+    p.seg_blocks = (n + p.seg_rows - 1) / p.seg_rows;
+    if (p.seg_blocks < 1) p.seg_blocks = 1;
+    p.ppart = take((size_t)p.seg_blocks * v1 * (Pd > 0 ? Pd : 1) * 4);
+    p.ppart2 = take((size_t)p.seg_blocks * v1 * 4);
+    p.tail_bytes = gemm_tail_ws_bytes();
+    p.tail = take(p.tail_bytes);
+    p.total = off;
+    return p;
+}
+
+}  // namespace txe
+using namespace txe;
+extern "C" {
+
+size_t txe_gat_collapse_ws_bytes(int n_nodes, int n_edges, int G, int Kh, int Pd, int D, int vocab) {
+    return plan_collapse_ws(nullptr, n_nodes, n_edges, G, round_up(Kh + Pd, 32), D, Pd, vocab).total;
+}
+
+// X [N][Kp], Wp [Fp][Kp] (rows < D the weight, rows D / D+1 the folded attention rows), mask: feature-dropout keep bits of X
+// or NULL.  pos / pw: WeightedMeanReadout (pw == NULL: MeanReadout).  Saved for backward: a12 [N][2], alpha [E], coef [N],
+// wsum [G], gid [N] (graph of each node), Z [G][Kp].  hg [G][D] (row stride ld_hg).
+int txe_gat_collapse_fwd(const int* rowptr_in, const int* col_src, const int* rowptr_out, const int* col_dst, const int* pos_out,
+                         const int* graph_off, int n_nodes, int n_edges, int G, const float* X, int Kh, int Pd, const float* Wp, int D,
+                         float feat_drop_p, const unsigned* mask, float attn_slope, float attn_drop_p, unsigned long long seed,
+                         const int* pos, const float* pw, float* a12, float* alpha, float* coef, float* wsum, int* gid, float* Z,
+                         float* hg, long long ld_hg, void* ws, size_t ws_bytes, void* stream) {
+    if (n_nodes < 0 || n_edges < 0 || G < 0 || Kh < 1 || Pd < 0 || D < 1 || !rowptr_in || !rowptr_out || !graph_off || !X || !Wp || !a12 ||
+        !alpha || !coef || !wsum || !gid || !Z || !hg || !ws || (pw && !pos))
+        return TXE_ERR_ARG;
+    if (feat_drop_p < 0.f || feat_drop_p >= 1.f || attn_drop_p < 0.f || attn_drop_p >= 1.f) return TXE_ERR_ARG;
+    const int Kt = Kh + Pd, Kp = round_up(Kt, 32);
+    CollapseWs p = plan_collapse_ws(ws, n_nodes, n_edges, G, Kp, D, Pd, 0);
+    if (ws_bytes < p.total) return TXE_ERR_WORKSPACE;
+    if (G == 0) return TXE_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const unsigned* mk = (mask && feat_drop_p > 0.f) ? mask : nullptr;
+    const int mask_ld = (Kt + 31) / 32;
+    const float fs = mk ? 1.f / (1.f - feat_drop_p) : 1.f, as = 1.f / (1.f - attn_drop_p);
+    const float* wa = Wp + (long long)D * Kp;
+    if (n_nodes > 0) {
+        const int nb = (n_nodes + 3) / 4;
+        {
+            ProfScope prof("cl_logits_kernel", s, 4.0 * n_nodes * (double)Kp, 1);
+            hipLaunchKernelGGL(cl_logits_kernel, dim3(nb < 2048 ? nb : 2048), dim3(256), 0, s, X, Kp, n_nodes, mk, mask_ld, fs, wa, a12);
+        }
+        hipLaunchKernelGGL(cl_alpha_kernel, dim3(nb), dim3(256), 0, s, rowptr_in, col_src, n_nodes, (const float*)a12, attn_slope, alpha);
+        hipLaunchKernelGGL(cl_coef_kernel, dim3((n_nodes + 255) / 256), dim3(256), 0, s, rowptr_out, col_dst, pos_out, n_nodes,
+                           (const float*)alpha, attn_drop_p, as, seed, pos, pw, coef);
+        TXE_CHECK_LAUNCH();
+    }
+    hipLaunchKernelGGL(cl_wsum_kernel, dim3((G + 3) / 4), dim3(256), 0, s, graph_off, G, pos, pw, wsum, gid);
+    {
+        const int ntile = (Kp / 4 + 63) / 64;
+        const long long nwaves = (long long)G * ntile;
+        ProfScope prof("cl_zsum_kernel", s, 4.0 * (n_nodes + (double)G) * Kp, 1);
+        hipLaunchKernelGGL(cl_zsum_kernel, dim3((unsigned)((nwaves + 3) / 4)), dim3(256), 0, s, graph_off, G, ntile, X, Kp, mk, mask_ld, fs,
+                           (const float*)coef, (const float*)wsum, Z);
+    }
+    TXE_CHECK_LAUNCH();
+    VMat A = vmat_plain(Z, Kp, G, Kp);
+    VMat B = vmat_plain(Wp, Kp, D, Kp);
+    Epi E = epi_plain(hg, ld_hg, D);
+    return gemm_nt(A, B, E, G, D, Kp, 1, s, p.tail, p.tail_bytes);
+}
+
+// d_hg [G][D] -> d_X [N][Kp] (first Kh columns through leaky' of X when act_on: they are d(pre-activation) of the previous
+// layer), dW [D][Kt], d_attn_l / d_attn_r [D], dP [vocab][Pd] (Pd > 0), d_pw [vocab] (pw != NULL).
+int txe_gat_collapse_bwd(const int* rowptr_in, const int* col_src, const int* rowptr_out, const int* col_dst, const int* pos_out,
+                         const int* graph_off, int n_nodes, int n_edges, int G, const float* X, int Kh, int Pd, const int* pos, int vocab,
+                         const float* Wp, const float* W, const float* attn_l, const float* attn_r, int D, float feat_drop_p,
+                         const unsigned* mask, float attn_slope, float attn_drop_p, unsigned long long seed, const float* pw,
+                         const float* a12, const float* alpha, const float* coef, const float* wsum, const int* gid, const float* Z,
+                         const float* d_hg, long long ld_dhg, int act_on, float act_slope, float* d_X, float* dW, float* d_attn_l,
+                         float* d_attn_r, float* dP, float* d_pw, void* ws, size_t ws_bytes, void* stream) {
+    if (n_nodes < 0 || n_edges < 0 || G < 0 || Kh < 1 || Pd < 0 || D < 1 || !rowptr_in || !rowptr_out || !graph_off || !X || !Wp || !W ||
+        !attn_l || !attn_r || !a12 || !alpha || !coef || !wsum || !gid || !Z || !d_hg || !d_X || !dW || !d_attn_l || !d_attn_r || !ws)
+        return TXE_ERR_ARG;
+    if ((Pd > 0 || pw) && (!pos || vocab < 1 || vocab > MAX_VOCAB)) return TXE_ERR_ARG;
+    if ((Pd > 0 && !dP) || (pw && !d_pw)) return TXE_ERR_ARG;
+    if (feat_drop_p < 0.f || feat_drop_p >= 1.f || attn_drop_p < 0.f || attn_drop_p >= 1.f) return TXE_ERR_ARG;
+    const int Kt = Kh + Pd, Kp = round_up(Kt, 32);
+    CollapseWs p = plan_collapse_ws(ws, n_nodes, n_edges, G, Kp, D, Pd, vocab);
+    if (ws_bytes < p.total) return TXE_ERR_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    const unsigned* mk = (mask && feat_drop_p > 0.f) ? mask : nullptr;
+    const int mask_ld = (Kt + 31) / 32;
+    const float fs = mk ? 1.f / (1.f - feat_drop_p) : 1.f, as = 1.f / (1.f - attn_drop_p);
+    const float* wa = Wp + (long long)D * Kp;
+    int rc;
+    // ---- dZ = d_hg W ;  dW (main part, split-K partial slices) = d_hg^T Z ----
+    {
+        VMat A = vmat_plain(d_hg, ld_dhg, G, D);
+        VMat B = vmat_plain(Wp, Kp, D, Kp);
+        Epi E = epi_plain(p.dZ, Kp, Kp);
+        rc = gemm_nn(A, B, E, G, Kp, D, 1, s, p.tail, p.tail_bytes);
+        if (rc) return rc;
+    }
+    const long long split_stride = (long long)D * Kp;
+    {
+        VMat A = vmat_plain(d_hg, ld_dhg, G, D);
+        VMat B = vmat_plain(Z, Kp, G, Kp);
+        Epi E = epi_plain(p.part, Kp, Kp);
+        E.split_stride = split_stride;
+        rc = gemm_tn(A, B, E, D, Kp, G, p.splits, s);
+        if (rc) return rc;
+    }
+    const int S = G > 0 ? p.splits : 0;
+    const int nblk = (G > 0 && n_nodes > 0) ? p.chunks : 0;
+    if (G > 0 && n_nodes > 0) {
+        const int nb = (n_nodes + 3) / 4;
+        const int ntile = (Kp / 4 + 63) / 64;
+        hipLaunchKernelGGL(cl_bwd_ds_kernel, dim3((G + 3) / 4), dim3(256), 0, s, G, Kp, (const float*)p.dZ, Z, wsum, p.dS);
+        {
+            ProfScope prof("cl_bwd_dot_kernel", s, 4.0 * (n_nodes + (double)G) * Kp, 1);
+            hipLaunchKernelGGL(cl_bwd_dot_kernel, dim3(nb), dim3(256), 0, s, n_nodes, gid, X, Kp, mk, mask_ld, fs, (const float*)p.dZ, wsum, p.dc);
+        }
+        hipLaunchKernelGGL(cl_bwd_edge_kernel, dim3(nb), dim3(256), 0, s, rowptr_in, col_src, n_nodes, a12, attn_slope, alpha, attn_drop_p, as,
+                           seed, pos, pw, (const float*)p.dc, (const float*)p.dS, gid, p.dz, p.da2, p.dwv);
+        hipLaunchKernelGGL(cl_bwd_src_kernel, dim3((n_nodes + 255) / 256), dim3(256), 0, s, rowptr_out, pos_out, n_nodes, (const float*)p.dz,
+                           p.da1);
+        {
+            const long long nwaves = (long long)p.chunks * ntile;
+            ProfScope prof("cl_bwd_dx_kernel", s, 4.0 * (2.0 * n_nodes + G) * Kp, 1);
+            hipLaunchKernelGGL(cl_bwd_dx_kernel, dim3((unsigned)((nwaves + 3) / 4)), dim3(256), 0, s, n_nodes, ntile, gid, X, Kp, Kh, mk, mask_ld, fs,
+                               (const float*)p.dZ, coef, wsum, (const float*)p.da1, (const float*)p.da2, wa, act_on, act_slope, d_X,
+                               p.dwa_part);
+        }
+        TXE_CHECK_LAUNCH();
+    }
+    // ---- d_wa = sum of the per-block partials;  position embedding / readout position-weight gradients ----
+    hipLaunchKernelGGL(reduce_splits_kernel, dim3((2 * Kp + 255) / 256), dim3(256), 0, s, (const float*)p.dwa_part, nblk, (long long)2 * Kp,
+                       (long long)2 * Kp, p.dwa);
+    if (Pd > 0) {
+        if (n_nodes > 0)
+            hipLaunchKernelGGL(pos_segsum_stage1, dim3(p.seg_blocks), dim3(256), 0, s, (const float*)(d_X + Kh), (long long)Kp, pos, n_nodes, Pd,
+                               vocab, p.seg_rows, p.ppart);
+        hipLaunchKernelGGL(pos_segsum_stage2, dim3((vocab * Pd + 63) / 64), dim3(256), 0, s, (const float*)p.ppart,
+                           n_nodes > 0 ? p.seg_blocks : 0, vocab, Pd, dP);
+    }
+    if (pw) {
+        if (n_nodes > 0)
+            hipLaunchKernelGGL(pos_segsum_stage1, dim3(p.seg_blocks), dim3(256), 0, s, (const float*)p.dwv, (long long)1, pos, n_nodes, 1, vocab,
+                               p.seg_rows, p.ppart2);
+        hipLaunchKernelGGL(pos_segsum_stage2, dim3((vocab + 63) / 64), dim3(256), 0, s, (const float*)p.ppart2, n_nodes > 0 ? p.seg_blocks : 0,
+                           vocab, 1, d_pw);
+    }
+    // ---- dW = main + attn (x) d_wa ;  d_attn = <d_wa, W> ----
+    hipLaunchKernelGGL(gat_unfold_kernel, dim3(D), dim3(256), 0, s, (const float*)p.part, S, split_stride, (const float*)p.dwa, (long long)Kp, W,
+                       (long long)Kt, attn_l, attn_r, 1, D, Kt, dW, (long long)Kt, d_attn_l, d_attn_r);
+    TXE_CHECK_LAUNCH();
     return TXE_OK;
 }
 

@@ -113,7 +113,7 @@ class GATLayer(nn.Module):
             feature, p_feat = F.dropout(feature, p_feat, True), 0.0
         cfg = ops.GATConfig([self.num_heads], [self.out_dim], [0], 0, self.leaky_relu.negative_slope, None,
                             p_feat, _p(self.attn_drop, self.training), "none", ops.new_seed())
-        ret = ops.GATStackFunction.apply(g.csr(feature.device), cfg, feature, None, self.fc.weight, self.attn_l, self.attn_r, None)
+        ret = ops.GATStackFunction.apply(g.csr(feature.device), cfg, feature, None, None, None, self.fc.weight, self.attn_l, self.attn_r, None)
         if self.residual:                               # model_zoo.py:98-103 (never enabled by model.py)
             if self.res_fc is not None:
                 resval = ops.LinearFunction.apply(feature, None, self.res_fc.weight, None, 0).reshape((feature.shape[0], self.num_heads, -1))
@@ -137,7 +137,55 @@ def _gat_stack(layers, embeddings, g, h, pos, activation, training):
     params = []
     for i, l in enumerate(layers):
         params += [l.fc.weight, l.attn_l, l.attn_r, None if embeddings is None else embeddings[i].weight]
-    return ops.GATStackFunction.apply(g.csr(h.device), cfg, h, pos, *params)
+    if layers[-1].num_heads == 1:
+        # one-head output layer: a weighted-mean readout can fold it (ops 'collapse'); anything else materialises N x D
+        return DeferredNodeOutput(g.csr(h.device), cfg, h, pos, params)
+    return ops.GATStackFunction.apply(g.csr(h.device), cfg, h, pos, None, None, *params)
+
+
+class DeferredNodeOutput:
+    """What PGAT / GAT.forward return when the output layer has one head: the N x out_dim node features, not yet computed.
+    MeanReadout / WeightedMeanReadout consume it through `.readout(...)` -- the output layer is then evaluated on G graph
+    rows instead of N node rows (ops.GATStackFunction 'collapse'; same arithmetic, re-associated).  Every other use (attribute
+    access, torch functions, other readouts) materialises the ordinary tensor once, with the same dropout seeds."""
+
+    def __init__(self, csr, cfg, h, pos, params):
+        self._args = (csr, cfg, h, pos, params)
+        self._tensor = None
+
+    def readout(self, rpos, pw):
+        import copy
+        csr, cfg, h, pos, params = self._args
+        c = copy.copy(cfg)
+        c.final = "collapse"
+        return ops.GATStackFunction.apply(csr, c, h, pos, rpos, pw, *params)
+
+    def tensor(self):
+        if self._tensor is None:
+            csr, cfg, h, pos, params = self._args
+            self._tensor = ops.GATStackFunction.apply(csr, cfg, h, pos, None, None, *params)
+        return self._tensor
+
+    def __getattr__(self, name):                    # .shape, .device, .detach(), .cpu(), ... of the node features
+        if name.startswith("_"):
+            raise AttributeError(name)
+        return getattr(self.tensor(), name)
+
+    def __getitem__(self, idx):
+        return self.tensor()[idx]
+
+    def __len__(self):
+        return len(self.tensor())
+
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        un = lambda a: a.tensor() if isinstance(a, DeferredNodeOutput) else a
+        return func(*[un(a) for a in args], **{k: un(v) for k, v in (kwargs or {}).items()})
+
+
+def _node_features(g):
+    h = g.ndata['h']
+    return h.tensor() if isinstance(h, DeferredNodeOutput) else h
 
 
 class GCN(nn.Module):
@@ -256,6 +304,8 @@ class MeanReadout(nn.Module):
     def forward(self, g, pos=None):
         """model_zoo.py:231-232"""
         h = g.ndata['h']
+        if isinstance(h, DeferredNodeOutput):
+            return h.readout(None, None)
         return ops.ReadoutFunction.apply(g.csr(h.device), h, None, None)
 
 
@@ -269,6 +319,8 @@ class WeightedMeanReadout(nn.Module):
         """model_zoo.py:240-242"""
         h = g.ndata['h']
         g.ndata['a'] = _LazyPositionWeight(self.position_weights.weight, pos)
+        if isinstance(h, DeferredNodeOutput):
+            return h.readout(pos, self.position_weights.weight)
         return ops.ReadoutFunction.apply(g.csr(h.device), h, pos, self.position_weights.weight)
 
 
@@ -278,7 +330,7 @@ class ConcatReadout(nn.Module):
 
     def forward(self, g, pos):
         """model_zoo.py:248-258: [sum_{pos=0} h / n, mean_{pos=1} h, sum_{pos=2} h / n]"""
-        h = g.ndata['h']
+        h = _node_features(g)
         return ops.ReadoutMultiFunction.apply(g.csr(h.device), h, pos, 3)
 
 
@@ -288,7 +340,7 @@ class SumReadout(nn.Module):
 
     def forward(self, g):
         """model_zoo.py:265-267"""
-        h = g.ndata['h']
+        h = _node_features(g)
         return ops.ReadoutMultiFunction.apply(g.csr(h.device), h, None, 1)
 
 
@@ -298,7 +350,7 @@ class MaxReadout(nn.Module):
 
     def forward(self, g):
         """model_zoo.py:274-276"""
-        h = g.ndata['h']
+        h = _node_features(g)
         return ops.ReadoutMultiFunction.apply(g.csr(h.device), h, None, 2)
 
 

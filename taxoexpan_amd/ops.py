@@ -94,7 +94,53 @@ def _tail_ws(ref):
 
 
 class _GatLayerState:
-    __slots__ = ("X", "Wp", "mask", "Y", "alpha", "W", "al", "ar", "P", "Kh", "Pd", "Kp", "Fp", "H", "D", "seed")
+    __slots__ = ("X", "Wp", "mask", "Y", "alpha", "W", "al", "ar", "P", "Kh", "Pd", "Kp", "Fp", "H", "D", "seed", "cl")
+
+
+def _gat_layer_prepare(st, h, ld_h, pos, feat_p):
+    """layer input X = [h | Emb[pos] | 0] (h == None: the producer already wrote the feature columns), packed weights, keep mask"""
+    N = st.X.shape[0]
+    s = _lib.stream_ptr()
+    call("txe_gat_build_x", ptr(h), ld_h, N, st.Kh, ptr(pos), ptr(st.P), st.Pd, ptr(st.X), s)
+    st.Wp = _empty((st.Fp, st.Kp), st.X)
+    call("txe_gat_pack_weights", ptr(st.W), ptr(st.al), ptr(st.ar), st.H, st.D, st.Kh + st.Pd, ptr(st.Wp), s)
+    st.mask = dropout_mask(N, st.Kh + st.Pd, feat_p, st.seed, st.X)
+
+
+def _gat_collapse_fwd(csr, st, h, ld_h, pos, rpos, pw, feat_p, attn_p, attn_slope):
+    """output layer (one head) folded behind the weighted-mean readout: hg [G, D] (txe_gat_collapse_fwd)"""
+    N, G, E = st.X.shape[0], csr.n_graphs, csr.n_edges
+    _gat_layer_prepare(st, h, ld_h, pos, feat_p)
+    a12, alpha, coef = _empty((max(N, 1), 2), st.X), _empty((max(E, 1),), st.X), _empty((max(N, 1),), st.X)
+    wsum, Z, hg = _empty((max(G, 1),), st.X), _empty((max(G, 1), st.Kp), st.X), _empty((G, st.D), st.X)
+    gid = torch.empty(max(N, 1), dtype=torch.int32, device=st.X.device)
+    wsb = call("txe_gat_collapse_ws_bytes", N, E, G, st.Kh, st.Pd, st.D, 8)
+    ws = _ws(wsb, st.X)
+    call("txe_gat_collapse_fwd", ptr(csr.rowptr_in), ptr(csr.col_src), ptr(csr.rowptr_out), ptr(csr.col_dst), ptr(csr.pos_out),
+         ptr(csr.graph_off), N, E, G, ptr(st.X), st.Kh, st.Pd, ptr(st.Wp), st.D, feat_p, ptr(st.mask), attn_slope, attn_p, st.seed + 1,
+         ptr(rpos), ptr(pw), ptr(a12), ptr(alpha), ptr(coef), ptr(wsum), ptr(gid), ptr(Z), ptr(hg), st.D, ptr(ws), wsb,
+         _lib.stream_ptr())
+    st.cl = (a12, alpha, coef, wsum, gid, Z)
+    return hg
+
+
+def _gat_collapse_bwd(csr, st, pos, rpos, pw, vocab, feat_p, attn_p, attn_slope, d_hg, act_on, act_slope):
+    N, G, E = st.X.shape[0], csr.n_graphs, csr.n_edges
+    a12, alpha, coef, wsum, gid, Z = st.cl
+    d_hg, ld = _rows(d_hg)
+    dW, dal, dar = torch.empty_like(st.W), torch.empty_like(st.al), torch.empty_like(st.ar)
+    dP = torch.empty_like(st.P) if st.P is not None else None
+    d_pw = torch.empty_like(pw) if pw is not None else None
+    d_X = _empty((N, st.Kp), st.X)
+    v = max(vocab, pw.numel() if pw is not None else 0)
+    wsb = call("txe_gat_collapse_ws_bytes", N, E, G, st.Kh, st.Pd, st.D, 8)
+    ws = _ws(wsb, st.X)
+    call("txe_gat_collapse_bwd", ptr(csr.rowptr_in), ptr(csr.col_src), ptr(csr.rowptr_out), ptr(csr.col_dst), ptr(csr.pos_out),
+         ptr(csr.graph_off), N, E, G, ptr(st.X), st.Kh, st.Pd, ptr(pos if pos is not None else rpos), v, ptr(st.Wp), ptr(st.W),
+         ptr(st.al), ptr(st.ar), st.D, feat_p, ptr(st.mask), attn_slope, attn_p, st.seed + 1, ptr(pw), ptr(a12), ptr(alpha), ptr(coef),
+         ptr(wsum), ptr(gid), ptr(Z), ptr(d_hg), ld, int(act_on), act_slope if act_slope else 1.0, ptr(d_X), ptr(dW), ptr(dal), ptr(dar), ptr(dP),
+         ptr(d_pw), ptr(ws), wsb, _lib.stream_ptr())
+    return d_X, dW, dal, dar, dP, d_pw
 
 
 def _gat_layer_fwd(csr, st, h, ld_h, pos, out, ld_out, feat_p, attn_p, attn_slope, out_mode, act_slope, save):
@@ -103,10 +149,7 @@ def _gat_layer_fwd(csr, st, h, ld_h, pos, out, ld_out, feat_p, attn_p, attn_slop
     H, D, Kh, Pd, Kp, Fp = st.H, st.D, st.Kh, st.Pd, st.Kp, st.Fp
     F = H * D
     s = _lib.stream_ptr()
-    call("txe_gat_build_x", ptr(h), ld_h, N, Kh, ptr(pos), ptr(st.P), Pd, ptr(st.X), s)
-    st.Wp = _empty((Fp, Kp), st.X)
-    call("txe_gat_pack_weights", ptr(st.W), ptr(st.al), ptr(st.ar), H, D, Kh + Pd, ptr(st.Wp), s)
-    st.mask = dropout_mask(N, Kh + Pd, feat_p, st.seed, st.X)
+    _gat_layer_prepare(st, h, ld_h, pos, feat_p)
     st.Y = _empty((N, Fp), st.X)
     tws = _tail_ws(st.X)
     call("txe_gat_dense_fwd", ptr(st.X), N, Kh, Pd, ptr(st.Wp), H, D, feat_p, ptr(st.mask), ptr(st.Y), ptr(tws), tws.numel(), s)
@@ -138,13 +181,18 @@ def _gat_layer_bwd(csr, st, pos, vocab, feat_p, attn_p, attn_slope, d_pre, ld_dp
 
 
 class GATStackFunction(torch.autograd.Function):
-    """params per layer: (W [H*D, Kin], attn_l [1,H,D], attn_r [1,H,D], P [vocab, Pd] or None)."""
+    """params per layer: (W [H*D, Kin], attn_l [1,H,D], attn_r [1,H,D], P [vocab, Pd] or None).
+    cfg.final: 'mean' -> N x D (PGAT / GAT), 'none' -> N x H x D (GATLayer), 'collapse' -> G x D: the one-head output layer folded
+    behind MeanReadout (pw None) / WeightedMeanReadout (pw = position_weights.weight, rpos = node positions)."""
 
     @staticmethod
-    def forward(ctx, csr, cfg, h, pos, *params):
+    def forward(ctx, csr, cfg, h, pos, rpos, pw, *params):
         _need_cuda(h, *[p for p in params if p is not None])
         h, ld_h = _rows(h)
         pos = _i32(pos, h.device)
+        collapse = (cfg.final == "collapse")
+        rpos = _i32(rpos, h.device) if (collapse and pw is not None) else None
+        pwf = _f32(pw.reshape(-1)) if (collapse and pw is not None) else None
         L = cfg.n_layers
         need = any(ctx.needs_input_grad)       # (grad mode itself is off inside Function.forward)
         N = h.shape[0]
@@ -166,6 +214,12 @@ class GATStackFunction(torch.autograd.Function):
             for l, st in enumerate(states):
                 last = (l == L - 1)
                 F = st.H * st.D
+                if last and collapse:
+                    res = _gat_collapse_fwd(csr, st, h if l == 0 else None, ld_h if l == 0 else 0, pos if st.P is not None else None,
+                                            rpos, pwf, cfg.feat_p, cfg.attn_p, cfg.attn_slope)
+                    if not need:
+                        st.cl = st.mask = st.Wp = st.X = None
+                    break
                 if last:
                     out, ld_out = _empty((N, F), h), F
                 else:                                  # the aggregation writes straight into the next layer's padded input
@@ -179,7 +233,9 @@ class GATStackFunction(torch.autograd.Function):
                     if l > 0:
                         st.X = None
             H, D = cfg.heads[-1], cfg.out_dims[-1]
-            if cfg.final == "mean":
+            if collapse:
+                pass
+            elif cfg.final == "mean":
                 if H == 1:
                     res = out.view(N, D)
                 else:
@@ -188,6 +244,7 @@ class GATStackFunction(torch.autograd.Function):
             else:
                 res = out.view(N, H, D)
         ctx.csr, ctx.cfg, ctx.pos, ctx.states = csr, cfg, pos, (states if need else None)
+        ctx.rpos, ctx.pwf, ctx.pw_shape = rpos, pwf, (pw.shape if pwf is not None else None)
         ctx.h_req = ctx.needs_input_grad[2]
         return res
 
@@ -197,29 +254,40 @@ class GATStackFunction(torch.autograd.Function):
         L = cfg.n_layers
         H, D = cfg.heads[-1], cfg.out_dims[-1]
         d_res = _f32(d_res)
-        N = d_res.shape[0]
+        collapse = (cfg.final == "collapse")
+        N = states[0].X.shape[0]
         grads = [None] * (4 * L)
+        d_pw = None
         with torch.cuda.device(d_res.device):
-            if cfg.final == "mean" and H > 1:
+            if collapse:
+                d_pre, ld_dpre = None, 0
+            elif cfg.final == "mean" and H > 1:
                 d_pre = _empty((N, H * D), d_res)
                 call("txe_head_mean_bwd", ptr(d_res), H, D, N, ptr(d_pre), _lib.stream_ptr())
             else:
                 d_pre = d_res.reshape(N, H * D)
-            ld_dpre = d_pre.stride(0)
+            if d_pre is not None:
+                ld_dpre = d_pre.stride(0)
             d_X = None
             for l in range(L - 1, -1, -1):
                 st = states[l]
                 need_dh = (l > 0) or ctx.h_req
                 # the input of layer l>0 is leaky_relu(out_{l-1}) (fused epilogue): fold its derivative into dX
                 act_on = (l > 0 and cfg.act_slope is not None)
-                d_X, dW, dal, dar, dP = _gat_layer_bwd(csr, st, pos if st.P is not None else None, cfg.vocab, cfg.feat_p, cfg.attn_p,
-                                                       cfg.attn_slope, d_pre, ld_dpre, need_dh, act_on, cfg.act_slope)
+                if collapse and l == L - 1:
+                    d_X, dW, dal, dar, dP, d_pw = _gat_collapse_bwd(csr, st, pos if st.P is not None else None, ctx.rpos, ctx.pwf, cfg.vocab,
+                                                                    cfg.feat_p, cfg.attn_p, cfg.attn_slope, d_res, act_on, cfg.act_slope)
+                else:
+                    d_X, dW, dal, dar, dP = _gat_layer_bwd(csr, st, pos if st.P is not None else None, cfg.vocab, cfg.feat_p, cfg.attn_p,
+                                                           cfg.attn_slope, d_pre, ld_dpre, need_dh, act_on, cfg.act_slope)
                 grads[4 * l:4 * l + 4] = [dW, dal, dar, dP]
                 if l > 0:
                     d_pre, ld_dpre = d_X, st.Kp            # its first H*D(l-1) columns are d(pre-activation out_{l-1})
             d_h = d_X[:, :states[0].Kh].contiguous() if ctx.h_req else None
         ctx.states = None
-        return (None, None, d_h, None, *grads)
+        if d_pw is not None:
+            d_pw = d_pw.reshape(ctx.pw_shape)
+        return (None, None, d_h, None, None, d_pw, *grads)
 
 
 # ================================================================================================================

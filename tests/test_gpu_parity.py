@@ -509,3 +509,28 @@ def test_rank_kernel_against_metric_definition(G, pitch, larger):
     Sd.copy_(torch.from_numpy(S))
     got = ops.rank_block(Sd, torch.from_numpy(pos_off), torch.from_numpy(pos_idx), larger)
     assert got.cpu().numpy().tolist() == want
+
+
+def test_bench_contract_line():
+    """bench.py prints ONE JSON line with the driver's keys plus `roofline` and `cpu_baseline` objects (short run)"""
+    import json
+    import os
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--steps", "3", "--warmup", "1", "--no-extra"], cwd=repo,
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["higher_is_better"] is True and d["scaling"] == "weak"
+    assert d["dtype"] == "f32" and d["data"] == "synthetic" and d["vs_baseline"] is None and "workload" in d["config"]
+    assert abs(d["value"] - d["config"]["avg_edges_per_step_per_gpu"] / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
+    r = d["roofline"]
+    assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == d["unit"] and "sample" in c

@@ -565,21 +565,25 @@ __global__ __launch_bounds__(256) void cl_alpha_kernel(const int* __restrict__ r
     for (int p = beg + l; p < end; p += 64) alpha[p] = __expf(leaky(a12[2 * (long long)col[p]] + a2v, slope) - m) * inv;
 }
 
-// one thread per source: c~_u = sum_{j in out(u)} w_{dst(j)} * alpha'[pos_out[j]]
-__global__ void cl_coef_kernel(const int* __restrict__ rowptr_out, const int* __restrict__ col_dst, const int* __restrict__ pos_out,
-                               int n_nodes, const float* __restrict__ alpha, float drop_p, float drop_scale, unsigned long long seed,
-                               const int* __restrict__ pos, const float* __restrict__ pw, float* __restrict__ coef) {
-    const int u = blockIdx.x * blockDim.x + threadIdx.x;
+// one wave per source: c~_u = sum_{j in out(u)} w_{dst(j)} * alpha'[pos_out[j]]     (lanes over the out-edges)
+__global__ __launch_bounds__(256) void cl_coef_kernel(const int* __restrict__ rowptr_out, const int* __restrict__ col_dst,
+                                                      const int* __restrict__ pos_out, int n_nodes, const float* __restrict__ alpha,
+                                                      float drop_p, float drop_scale, unsigned long long seed, const int* __restrict__ pos,
+                                                      const float* __restrict__ pw, float* __restrict__ coef) {
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    const int u = blockIdx.x * 4 + w;
     if (u >= n_nodes) return;
+    const int beg = rowptr_out[u], end = rowptr_out[u + 1];
     float c = 0.f;
-    for (int j = rowptr_out[u]; j < rowptr_out[u + 1]; ++j) {
+    for (int j = beg + l; j < end; j += 64) {
         const int p = pos_out[j], v = col_dst[j];
         float f = 1.f;
         if (drop_p > 0.f) f = drop_factor(seed, (unsigned long long)p, drop_p, drop_scale);
         const float wv = pw ? cl_softplus(pw[pos[v]]) : 1.f;
         c = fmaf(wv * f, alpha[p], c);
     }
-    coef[u] = c;
+    c = wave_sum(c);
+    if (l == 0) coef[u] = c;
 }
 
 // per graph: S_g = sum_v w_v -> wsum[g];  gid[v] = g for its nodes
@@ -733,14 +737,16 @@ __global__ __launch_bounds__(256) void cl_bwd_edge_kernel(const int* __restrict_
     }
 }
 
-// one thread per source: da1[u] = sum_{j in out(u)} dz[pos_out[j]]
-__global__ void cl_bwd_src_kernel(const int* __restrict__ rowptr_out, const int* __restrict__ pos_out, int n_nodes,
-                                  const float* __restrict__ dz, float* __restrict__ da1) {
-    const int u = blockIdx.x * blockDim.x + threadIdx.x;
+// one wave per source: da1[u] = sum_{j in out(u)} dz[pos_out[j]]
+__global__ __launch_bounds__(256) void cl_bwd_src_kernel(const int* __restrict__ rowptr_out, const int* __restrict__ pos_out, int n_nodes,
+                                                         const float* __restrict__ dz, float* __restrict__ da1) {
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    const int u = blockIdx.x * 4 + w;
     if (u >= n_nodes) return;
     float a = 0.f;
-    for (int j = rowptr_out[u]; j < rowptr_out[u + 1]; ++j) a += dz[pos_out[j]];
-    da1[u] = a;
+    for (int j = rowptr_out[u] + l; j < rowptr_out[u + 1]; j += 64) a += dz[pos_out[j]];
+    a = wave_sum(a);
+    if (l == 0) da1[u] = a;
 }
 
 // sweep 4 -- one wave per (chunk of CL_CHUNK nodes, 256-column tile):
@@ -878,7 +884,7 @@ int txe_gat_collapse_fwd(const int* rowptr_in, const int* col_src, const int* ro
             hipLaunchKernelGGL(cl_logits_kernel, dim3(nb < 2048 ? nb : 2048), dim3(256), 0, s, X, Kp, n_nodes, mk, mask_ld, fs, wa, a12);
         }
         hipLaunchKernelGGL(cl_alpha_kernel, dim3(nb), dim3(256), 0, s, rowptr_in, col_src, n_nodes, (const float*)a12, attn_slope, alpha);
-        hipLaunchKernelGGL(cl_coef_kernel, dim3((n_nodes + 255) / 256), dim3(256), 0, s, rowptr_out, col_dst, pos_out, n_nodes,
+        hipLaunchKernelGGL(cl_coef_kernel, dim3(nb), dim3(256), 0, s, rowptr_out, col_dst, pos_out, n_nodes,
                            (const float*)alpha, attn_drop_p, as, seed, pos, pw, coef);
         TXE_CHECK_LAUNCH();
     }
@@ -950,8 +956,7 @@ int txe_gat_collapse_bwd(const int* rowptr_in, const int* col_src, const int* ro
         }
         hipLaunchKernelGGL(cl_bwd_edge_kernel, dim3(nb), dim3(256), 0, s, rowptr_in, col_src, n_nodes, a12, attn_slope, alpha, attn_drop_p, as,
                            seed, pos, pw, (const float*)p.dc, (const float*)p.dS, gid, p.dz, p.da2, p.dwv);
-        hipLaunchKernelGGL(cl_bwd_src_kernel, dim3((n_nodes + 255) / 256), dim3(256), 0, s, rowptr_out, pos_out, n_nodes, (const float*)p.dz,
-                           p.da1);
+        hipLaunchKernelGGL(cl_bwd_src_kernel, dim3(nb), dim3(256), 0, s, rowptr_out, pos_out, n_nodes, (const float*)p.dz, p.da1);
         {
             const long long nwaves = (long long)p.chunks * ntile;
             ProfScope prof("cl_bwd_dx_kernel", s, 4.0 * (2.0 * n_nodes + G) * Kp, 1);
@@ -962,8 +967,7 @@ int txe_gat_collapse_bwd(const int* rowptr_in, const int* col_src, const int* ro
         TXE_CHECK_LAUNCH();
     }
     // ---- d_wa = sum of the per-block partials;  position embedding / readout position-weight gradients ----
-    hipLaunchKernelGGL(reduce_splits_kernel, dim3((2 * Kp + 255) / 256), dim3(256), 0, s, (const float*)p.dwa_part, nblk, (long long)2 * Kp,
-                       (long long)2 * Kp, p.dwa);
+    hipLaunchKernelGGL(pos_segsum_stage2, dim3((2 * Kp + 63) / 64), dim3(256), 0, s, (const float*)p.dwa_part, nblk, 2, Kp, p.dwa);
     if (Pd > 0) {
         if (n_nodes > 0)
             hipLaunchKernelGGL(pos_segsum_stage1, dim3(p.seg_blocks), dim3(256), 0, s, (const float*)(d_X + Kh), (long long)Kp, pos, n_nodes, Pd,

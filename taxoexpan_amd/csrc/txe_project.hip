@@ -898,7 +898,7 @@ int txe_gat_collapse_fwd(const int* rowptr_in, const int* col_src, const int* ro
     }
     TXE_CHECK_LAUNCH();
     VMat A = vmat_plain(Z, Kp, G, Kp);
-    VMat B = vmat_plain(Wp, Kp, D, Kp);
+    VMat B = vmat_plain(Wp, Kp, round_up(D + 2, 128), Kp);       // all Fp packed rows are readable: every tile stays on the plain loader
     Epi E = epi_plain(hg, ld_hg, D);
     return gemm_nt(A, B, E, G, D, Kp, 1, s, p.tail, p.tail_bytes);
 }

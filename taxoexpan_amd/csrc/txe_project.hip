@@ -771,10 +771,11 @@ __global__ __launch_bounds__(256) void cl_bwd_dx_kernel(int n_nodes, int ntile, 
     float w1[4], w2[4], s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
     vload<4>(wa + jc * 4, w1);
     vload<4>(wa + Kp + jc * 4, w2);
-    for (int u0 = u_beg; u0 < u_end; u0 += 4) {                      // four nodes per step: independent loads in flight
-        float x[4][4], d[4][4], k4[4][4], cu[4], g1[4], g2[4];
+    constexpr int NU = 8;                                            // nodes per step: 2*NU independent 16-byte loads in flight
+    for (int u0 = u_beg; u0 < u_end; u0 += NU) {
+        float x[NU][4], d[NU][4], k4[NU][4], cu[NU], g1[NU], g2[NU];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
+        for (int e = 0; e < NU; ++e) {
             const int u = min(u0 + e, u_end - 1);
             const bool ok = u0 + e < u_end;
             const int g = gid[u];
@@ -787,7 +788,7 @@ __global__ __launch_bounds__(256) void cl_bwd_dx_kernel(int n_nodes, int ntile, 
             cl_keep4(mask ? mask + (long long)u * mask_ld : nullptr, mask_ld, jc, k4[e]);
         }
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
+        for (int e = 0; e < NU; ++e) {
             if (u0 + e < u_end && j < nvec) {
                 float o[4];
 #pragma unroll

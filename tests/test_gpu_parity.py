@@ -534,3 +534,53 @@ def test_bench_contract_line():
     assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == d["unit"] and "sample" in c
+
+
+@pytest.mark.parametrize("readout,drop", [("WMR", 0.0), ("MR", 0.0), ("WMR", 0.2)])
+def test_collapsed_output_layer_equals_unfused_path(readout, drop):
+    """PGAT + (weighted) mean readout: the folded output layer (txe_gat_collapse_*, G graph rows) against the ordinary
+    projection -> aggregation -> readout path (N node rows) of the SAME modules, same dropout seeds -- on generic batched graphs
+    (degree > 64 hub, graphs of 1..40 nodes), forward and every gradient."""
+    from taxoexpan_amd import model_zoo as mz, ops
+    from taxoexpan_amd.graph import DGLGraph, batch
+    dev = _dev()
+    rs = np.random.RandomState(3)
+    graphs = []
+    for i, n in enumerate([1, 2, 40, 7, 3, 90, 5]):
+        g = DGLGraph()
+        g.add_nodes(n)
+        if n > 1:
+            e = 3 * n
+            g.add_edges(rs.randint(0, n, e), rs.randint(0, n, e))
+        if n == 90:
+            g.add_edges(rs.randint(0, n, 100), np.full(100, 11))        # hub: in-degree > 64
+        g.add_edges(g.nodes(), g.nodes())
+        graphs.append(g)
+    bg = batch(graphs)
+    N = bg.number_of_nodes()
+    pos = torch.from_numpy(rs.randint(0, 3, N)).to(dev)
+    x = torch.randn(N, 10, generator=torch.Generator().manual_seed(0)).to(dev)
+    coef = torch.randn(len(graphs), 6, generator=torch.Generator().manual_seed(1)).to(dev)
+    torch.manual_seed(5)
+    prop = mz.PGAT(10, 8, 6, 4, num_layers=1, heads=[3, 1], activation=torch.nn.functional.leaky_relu, feat_drop=drop, attn_drop=drop).to(dev)
+    ro = (mz.WeightedMeanReadout() if readout == "WMR" else mz.MeanReadout()).to(dev)
+    prop.train(drop > 0)
+    xg = x.clone().requires_grad_(True)
+    bg.ndata["pos"] = pos
+    h = prop(bg, xg)                                                     # one forward: both paths share its dropout seeds
+    assert isinstance(h, mz.DeferredNodeOutput)
+    results = []
+    for fused in (True, False):
+        for p in list(prop.parameters()) + list(ro.parameters()):
+            p.grad = None
+        xg.grad = None
+        bg.ndata["h"] = h if fused else h.tensor()
+        hg = ro(bg, pos)
+        (hg * coef).sum().backward()
+        results.append((hg.detach().cpu().numpy(), xg.grad.cpu().numpy(),
+                        {k: p.grad.cpu().numpy() for k, p in list(prop.named_parameters()) + list(ro.named_parameters())}))
+    (a, dxa, ga), (b, dxb, gb) = results
+    np.testing.assert_allclose(a, b, rtol=RT, atol=AT)
+    np.testing.assert_allclose(dxa, dxb, rtol=2e-3, atol=2e-5)
+    for k in ga:
+        np.testing.assert_allclose(ga[k], gb[k], rtol=2e-3, atol=2e-5, err_msg=k)

@@ -619,7 +619,9 @@ static inline int choose_bn(int M, int N, int splits, bool tail_split = false, i
             const double kfloor = K > 0 ? 4.0 * GEMM_BK / K : 0.25;
             r = (double)(blocks / slots) + (frac > kfloor ? frac : kfloor) + 0.1;      // + fix-up kernel
         }
-        return r * bn * (bn == 64 ? 1.6 : 1.0);                  // the narrow tile is markedly less efficient per flop (measured)
+        // per-flop cost of the narrow tile, measured: x1.6 on the forward / dX shapes (short k-loops, epilogue extras), x1.1 on the
+        // long split-K reductions of the weight gradients (2.5 vs 4.7 us per k-tile and round)
+        return r * bn * (bn == 64 ? (splits > 1 ? 1.1 : 1.6) : 1.0);
     };
     return cost(64) < cost(128) ? 64 : 128;
 }
@@ -703,16 +705,22 @@ static inline int gemm_launch_layout(const VMat& A, const VMat& B, const Epi& E_
 // number of split-K slices for a product with `tiles` output tiles and reduction length K: fill whole rounds of
 // 2 workgroups per CU, keep >= 8 k-tiles per slice.
 static inline int choose_splits(int M, int N, int K) {
-    const int tiles = ((M + GEMM_BM - 1) / GEMM_BM) * ((N + 127) / 128);
     const int slots = 2 * device_cu_count();
     const int max_by_k = (K + 255) / 256 > 0 ? (K + 255) / 256 : 1;
+    const int nkt = (K + GEMM_BK - 1) / GEMM_BK;
     int best = 1;
     double best_cost = 1e30;
-    for (int s = 1; s <= 64 && s <= max_by_k; ++s) {
-        const long long blocks = (long long)tiles * s;
-        const long long rounds = (blocks + slots - 1) / slots;
-        const double cost = (double)rounds / s + 0.002 * s;      // time ~ rounds x (K/s); small penalty for partial traffic
-        if (cost < best_cost) { best_cost = cost; best = s; }
+    for (int bn = 64; bn <= 128; bn += 64) {                      // the launcher's choose_bn() applies the same per-tile costs
+        if (bn == 64 && N <= 64) continue;
+        const int tiles = ((M + GEMM_BM - 1) / GEMM_BM) * ((N + bn - 1) / bn);
+        for (int s = 1; s <= 64 && s <= max_by_k; ++s) {
+            const long long blocks = (long long)tiles * s;
+            const long long rounds = (blocks + slots - 1) / slots;
+            const double kt = (double)((nkt + s - 1) / s);
+            // time ~ rounds x k-tiles per slice x per-k-tile cost of the tile width; small penalty for the partial traffic
+            const double cost = (double)rounds * (kt + 2.0) * (bn == 64 ? 0.55 : 1.0) + 0.004 * nkt * s * (bn / 128.0);
+            if (cost < best_cost) { best_cost = cost; best = s; }
+        }
     }
     return best;
 }

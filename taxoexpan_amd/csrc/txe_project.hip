@@ -500,8 +500,9 @@ __device__ __forceinline__ float cl_softplus(float x) { return x > 20.f ? x : lo
 __device__ __forceinline__ float cl_sigmoid(float x) { return x > 20.f ? 1.f : 1.f / (1.f + __expf(-x)); }
 
 // keep factors (0 / 1) of the 4 columns of vector j from the row's mask words (mask == nullptr: all kept)
+template <bool MASK>
 __device__ __forceinline__ void cl_keep4(const unsigned* __restrict__ mrow, int mask_ld, int j, float* k4) {
-    if (mrow == nullptr) { k4[0] = k4[1] = k4[2] = k4[3] = 1.f; return; }
+    if constexpr (!MASK) { k4[0] = k4[1] = k4[2] = k4[3] = 1.f; return; }
     const int c = j * 4;
     const unsigned wd = mrow[min(c >> 5, mask_ld - 1)];
     const unsigned b = (c >> 5) < mask_ld ? (wd >> (c & 31)) : 0u;
@@ -510,6 +511,7 @@ __device__ __forceinline__ void cl_keep4(const unsigned* __restrict__ mrow, int 
 
 // sweep 1 -- one wave per node (persistent waves keep the two folded rows in registers per column tile):
 //   a12[u][0] = <Xd[u], wa1>,  a12[u][1] = <Xd[u], wa2>
+template <bool MASK>
 __global__ __launch_bounds__(256) void cl_logits_kernel(const float* __restrict__ X, int Kp, int n_nodes, const unsigned* __restrict__ mask,
                                                         int mask_ld, float scale, const float* __restrict__ wa /*[2][Kp]*/,
                                                         float* __restrict__ a12) {
@@ -518,7 +520,7 @@ __global__ __launch_bounds__(256) void cl_logits_kernel(const float* __restrict_
     const int nvec = Kp >> 2;
     for (int u = wave; u < n_nodes; u += nwaves) {
         const float* row = X + (long long)u * Kp;
-        const unsigned* mrow = mask ? mask + (long long)u * mask_ld : nullptr;
+        const unsigned* mrow = mask + (MASK ? (long long)u * mask_ld : 0);
         float s1 = 0.f, s2 = 0.f;
         for (int t0 = 0; t0 < nvec; t0 += 64 * CL_NI) {
             float x[CL_NI][4], w1[CL_NI][4], w2[CL_NI][4], k4[CL_NI][4];
@@ -529,8 +531,10 @@ __global__ __launch_bounds__(256) void cl_logits_kernel(const float* __restrict_
                 vload<4>(row + jc * 4, x[i]);
                 vload<4>(wa + jc * 4, w1[i]);
                 vload<4>(wa + Kp + jc * 4, w2[i]);
-                cl_keep4(mrow, mask_ld, jc, k4[i]);
-                if (j >= nvec) k4[i][0] = k4[i][1] = k4[i][2] = k4[i][3] = 0.f;
+                cl_keep4<MASK>(mrow, mask_ld, jc, k4[i]);
+                const float live = (j < nvec) ? 1.f : 0.f;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) k4[i][k] *= live;
             }
 #pragma unroll
             for (int i = 0; i < CL_NI; ++i)
@@ -603,6 +607,7 @@ __global__ __launch_bounds__(256) void cl_wsum_kernel(const int* __restrict__ go
 }
 
 // sweep 2 -- one wave per (graph, 256-column tile):  Z[g][tile] = (scale / S_g) sum_{u in g} c~_u (X[u] * keep)[tile]
+template <bool MASK>
 __global__ __launch_bounds__(256) void cl_zsum_kernel(const int* __restrict__ goff, int G, int ntile, const float* __restrict__ X, int Kp,
                                                       const unsigned* __restrict__ mask, int mask_ld, float scale,
                                                       const float* __restrict__ coef, const float* __restrict__ wsum,
@@ -621,9 +626,9 @@ __global__ __launch_bounds__(256) void cl_zsum_kernel(const int* __restrict__ go
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int u = min(u0 + e, end - 1);
-            cu[e] = (u0 + e < end) ? coef[u] : 0.f;
+            cu[e] = coef[u] * ((u0 + e < end) ? 1.f : 0.f);
             vload<4>(X + (long long)u * Kp + jc * 4, x[e]);
-            cl_keep4(mask ? mask + (long long)u * mask_ld : nullptr, mask_ld, jc, k4[e]);
+            cl_keep4<MASK>(mask + (MASK ? (long long)u * mask_ld : 0), mask_ld, jc, k4[e]);
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e)
@@ -659,10 +664,11 @@ __global__ __launch_bounds__(256) void cl_bwd_ds_kernel(int G, int Kp, const flo
 }
 
 // sweep 3 -- one wave per node:  dc~_u = (scale / S_g) <dZ[g], X[u] * keep>
+template <bool MASK>
 __global__ __launch_bounds__(256) void cl_bwd_dot_kernel(int n_nodes, const int* __restrict__ gid, const float* __restrict__ X, int Kp,
                                                          const unsigned* __restrict__ mask, int mask_ld, float scale,
                                                          const float* __restrict__ dZ, const float* __restrict__ wsum,
-                                                         float* __restrict__ dc) {
+                                                         const float* __restrict__ coef, float* __restrict__ dc, float* __restrict__ cn) {
     const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
     const int u = blockIdx.x * 4 + w;
     if (u >= n_nodes) return;
@@ -670,7 +676,7 @@ __global__ __launch_bounds__(256) void cl_bwd_dot_kernel(int n_nodes, const int*
     const int nvec = Kp >> 2;
     const float* row = X + (long long)u * Kp;
     const float* dzrow = dZ + (long long)g * Kp;
-    const unsigned* mrow = mask ? mask + (long long)u * mask_ld : nullptr;
+    const unsigned* mrow = mask + (MASK ? (long long)u * mask_ld : 0);
     float part = 0.f;
     for (int t0 = 0; t0 < nvec; t0 += 64 * CL_NI) {
         float x[CL_NI][4], d[CL_NI][4], k4[CL_NI][4];
@@ -680,8 +686,10 @@ __global__ __launch_bounds__(256) void cl_bwd_dot_kernel(int n_nodes, const int*
             const int jc = (j < nvec) ? j : t0;
             vload<4>(row + jc * 4, x[i]);
             vload<4>(dzrow + jc * 4, d[i]);
-            cl_keep4(mrow, mask_ld, jc, k4[i]);
-            if (j >= nvec) k4[i][0] = k4[i][1] = k4[i][2] = k4[i][3] = 0.f;
+            cl_keep4<MASK>(mrow, mask_ld, jc, k4[i]);
+            const float live = (j < nvec) ? 1.f : 0.f;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) k4[i][k] *= live;
         }
 #pragma unroll
         for (int i = 0; i < CL_NI; ++i)
@@ -689,7 +697,12 @@ __global__ __launch_bounds__(256) void cl_bwd_dot_kernel(int n_nodes, const int*
             for (int k = 0; k < 4; ++k) part = fmaf(d[i][k] * k4[i][k], x[i][k], part);
     }
     part = wave_sum(part);
-    if (l == 0) dc[u] = wsum[g] > 0.f ? part * scale / wsum[g] : 0.f;
+    if (l == 0) {
+        const float S = wsum[g];
+        const float inv = S > 0.f ? 1.f / S : 0.f;
+        dc[u] = part * scale * inv;
+        cn[u] = coef[u] * inv;                        // normalised coefficient for the d_X sweep
+    }
 }
 
 // one wave per destination v: readout-weight and softmax backward of the edge coefficients
@@ -753,12 +766,13 @@ __global__ __launch_bounds__(256) void cl_bwd_src_kernel(const int* __restrict__
 //   d_X[u][j] = keep * scale * (c~_u / S_g * dZ[g][j] + da1[u] wa1[j] + da2[u] wa2[j]) * (act_on && j < Kh ? leaky'(X[u][j]) : 1)
 //   dwa_part[chunk][0/1][j] = sum over the chunk's nodes of da1/da2[u] * scale * keep * X[u][j]     (fixed order: deterministic)
 constexpr int CL_CHUNK = 32;
+template <bool MASK>
 __global__ __launch_bounds__(256) void cl_bwd_dx_kernel(int n_nodes, int ntile, const int* __restrict__ gid, const float* __restrict__ X, int Kp,
                                                         int Kh, const unsigned* __restrict__ mask, int mask_ld, float scale,
-                                                        const float* __restrict__ dZ, const float* __restrict__ coef,
-                                                        const float* __restrict__ wsum, const float* __restrict__ da1,
-                                                        const float* __restrict__ da2, const float* __restrict__ wa, int act_on,
-                                                        float act_slope, float* __restrict__ d_X, float* __restrict__ dwa_part) {
+                                                        const float* __restrict__ dZ, const float* __restrict__ cn,
+                                                        const float* __restrict__ da1, const float* __restrict__ da2,
+                                                        const float* __restrict__ wa, int act_on, float act_slope,
+                                                        float* __restrict__ d_X, float* __restrict__ dwa_part) {
     const int l = threadIdx.x & 63;
     const long long wid = ((long long)blockIdx.x * 256 + threadIdx.x) >> 6;
     const int chunk = (int)(wid / ntile), t = (int)(wid % ntile);
@@ -767,54 +781,52 @@ __global__ __launch_bounds__(256) void cl_bwd_dx_kernel(int n_nodes, int ntile, 
     const int u_end = min(n_nodes, u_beg + CL_CHUNK);
     const int nvec = Kp >> 2;
     const int j = t * 64 + l;
-    const int jc = (j < nvec) ? j : t * 64;
+    const bool jok = j < nvec;
+    const int jc = jok ? j : t * 64;
+    // leaky' applies to the first Kh columns (the previous layer's activated output); slope 1 elsewhere / when off
+    float sl[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) sl[k] = (act_on && (jc * 4 + k) < Kh) ? act_slope : 1.f;
     float w1[4], w2[4], s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
     vload<4>(wa + jc * 4, w1);
     vload<4>(wa + Kp + jc * 4, w2);
-    constexpr int NU = 8;                                            // nodes per step: 2*NU independent 16-byte loads in flight
+    constexpr int NU = 8;                            // nodes per step: all their loads are unconditional and issued together
     for (int u0 = u_beg; u0 < u_end; u0 += NU) {
         float x[NU][4], d[NU][4], k4[NU][4], cu[NU], g1[NU], g2[NU];
 #pragma unroll
         for (int e = 0; e < NU; ++e) {
             const int u = min(u0 + e, u_end - 1);
-            const bool ok = u0 + e < u_end;
+            const float ok = (u0 + e < u_end) ? 1.f : 0.f;
             const int g = gid[u];
-            const float S = wsum[g];
-            cu[e] = (ok && S > 0.f) ? coef[u] / S : 0.f;
-            g1[e] = ok ? da1[u] : 0.f;
-            g2[e] = ok ? da2[u] : 0.f;
+            cu[e] = cn[u] * ok;
+            g1[e] = da1[u] * ok;
+            g2[e] = da2[u] * ok;
             vload<4>(X + (long long)u * Kp + jc * 4, x[e]);
             vload<4>(dZ + (long long)g * Kp + jc * 4, d[e]);
-            cl_keep4(mask ? mask + (long long)u * mask_ld : nullptr, mask_ld, jc, k4[e]);
+            cl_keep4<MASK>(mask + (MASK ? (long long)u * mask_ld : 0), mask_ld, jc, k4[e]);
         }
 #pragma unroll
         for (int e = 0; e < NU; ++e) {
-            if (u0 + e < u_end && j < nvec) {
-                float o[4];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    float v = k4[e][k] * scale * (cu[e] * d[e][k] + g1[e] * w1[k] + g2[e] * w2[k]);
-                    if (act_on && (j * 4 + k) < Kh) v *= (x[e][k] > 0.f) ? 1.f : act_slope;
-                    o[k] = v;
-                }
-                vstore<4>(d_X + (long long)(u0 + e) * Kp + j * 4, o);
-            }
+            float o[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                const float xd = x[e][k] * k4[e][k] * scale;
+                const float ks = k4[e][k] * scale;
+                o[k] = ks * (cu[e] * d[e][k] + g1[e] * w1[k] + g2[e] * w2[k]) * ((x[e][k] > 0.f) ? 1.f : sl[k]);
+                const float xd = x[e][k] * ks;
                 s1[k] = fmaf(g1[e], xd, s1[k]);
                 s2[k] = fmaf(g2[e], xd, s2[k]);
             }
+            if (jok && u0 + e < u_end) vstore<4>(d_X + (long long)(u0 + e) * Kp + j * 4, o);
         }
     }
-    if (j < nvec) {
+    if (jok) {
         vstore<4>(dwa_part + ((long long)chunk * 2 + 0) * Kp + j * 4, s1);
         vstore<4>(dwa_part + ((long long)chunk * 2 + 1) * Kp + j * 4, s2);
     }
 }
 
 struct CollapseWs {
-    float *dZ, *part, *dwa_part, *dwa, *dc, *dS, *dz, *da1, *da2, *dwv, *ppart, *ppart2;
+    float *dZ, *part, *dwa_part, *dwa, *dc, *cn, *dS, *dz, *da1, *da2, *dwv, *ppart, *ppart2;
     void* tail;
     size_t tail_bytes, total;
     int splits, seg_blocks, seg_rows, chunks;
@@ -833,6 +845,7 @@ static CollapseWs plan_collapse_ws(void* ws, int n, int e, int G, int Kp, int D,
     p.dwa_part = take((size_t)(p.chunks > 0 ? p.chunks : 1) * 2 * Kp * 4);
     p.dwa = take((size_t)2 * Kp * 4);
     p.dc = take((size_t)n1 * 4);
+    p.cn = take((size_t)n1 * 4);
     p.dS = take((size_t)(G > 0 ? G : 1) * 4);
     p.dz = take((size_t)(e > 0 ? e : 1) * 4);
     p.da1 = take((size_t)n1 * 4);
@@ -878,11 +891,13 @@ int txe_gat_collapse_fwd(const int* rowptr_in, const int* col_src, const int* ro
     const int mask_ld = (Kt + 31) / 32;
     const float fs = mk ? 1.f / (1.f - feat_drop_p) : 1.f, as = 1.f / (1.f - attn_drop_p);
     const float* wa = Wp + (long long)D * Kp;
+    const unsigned* dummy_mask = reinterpret_cast<const unsigned*>(X);     // never dereferenced by the <false> instantiations
     if (n_nodes > 0) {
         const int nb = (n_nodes + 3) / 4;
         {
             ProfScope prof("cl_logits_kernel", s, 4.0 * n_nodes * (double)Kp, 1);
-            hipLaunchKernelGGL(cl_logits_kernel, dim3(nb < 2048 ? nb : 2048), dim3(256), 0, s, X, Kp, n_nodes, mk, mask_ld, fs, wa, a12);
+            if (mk) hipLaunchKernelGGL(cl_logits_kernel<true>, dim3(nb < 2048 ? nb : 2048), dim3(256), 0, s, X, Kp, n_nodes, mk, mask_ld, fs, wa, a12);
+            else hipLaunchKernelGGL(cl_logits_kernel<false>, dim3(nb < 2048 ? nb : 2048), dim3(256), 0, s, X, Kp, n_nodes, dummy_mask, mask_ld, fs, wa, a12);
         }
         hipLaunchKernelGGL(cl_alpha_kernel, dim3(nb), dim3(256), 0, s, rowptr_in, col_src, n_nodes, (const float*)a12, attn_slope, alpha);
         hipLaunchKernelGGL(cl_coef_kernel, dim3(nb), dim3(256), 0, s, rowptr_out, col_dst, pos_out, n_nodes,
@@ -894,8 +909,10 @@ int txe_gat_collapse_fwd(const int* rowptr_in, const int* col_src, const int* ro
         const int ntile = (Kp / 4 + 63) / 64;
         const long long nwaves = (long long)G * ntile;
         ProfScope prof("cl_zsum_kernel", s, 4.0 * (n_nodes + (double)G) * Kp, 1);
-        hipLaunchKernelGGL(cl_zsum_kernel, dim3((unsigned)((nwaves + 3) / 4)), dim3(256), 0, s, graph_off, G, ntile, X, Kp, mk, mask_ld, fs,
-                           (const float*)coef, (const float*)wsum, Z);
+        if (mk) hipLaunchKernelGGL(cl_zsum_kernel<true>, dim3((unsigned)((nwaves + 3) / 4)), dim3(256), 0, s, graph_off, G, ntile, X, Kp, mk, mask_ld, fs,
+                                   (const float*)coef, (const float*)wsum, Z);
+        else hipLaunchKernelGGL(cl_zsum_kernel<false>, dim3((unsigned)((nwaves + 3) / 4)), dim3(256), 0, s, graph_off, G, ntile, X, Kp, dummy_mask,
+                                mask_ld, fs, (const float*)coef, (const float*)wsum, Z);
     }
     TXE_CHECK_LAUNCH();
     VMat A = vmat_plain(Z, Kp, G, Kp);
@@ -927,6 +944,7 @@ int txe_gat_collapse_bwd(const int* rowptr_in, const int* col_src, const int* ro
     const int mask_ld = (Kt + 31) / 32;
     const float fs = mk ? 1.f / (1.f - feat_drop_p) : 1.f, as = 1.f / (1.f - attn_drop_p);
     const float* wa = Wp + (long long)D * Kp;
+    const unsigned* dummy_mask = reinterpret_cast<const unsigned*>(X);
     int rc;
     // ---- dZ = d_hg W ;  dW (main part, split-K partial slices) = d_hg^T Z ----
     {
@@ -953,7 +971,10 @@ int txe_gat_collapse_bwd(const int* rowptr_in, const int* col_src, const int* ro
         hipLaunchKernelGGL(cl_bwd_ds_kernel, dim3((G + 3) / 4), dim3(256), 0, s, G, Kp, (const float*)p.dZ, Z, wsum, p.dS);
         {
             ProfScope prof("cl_bwd_dot_kernel", s, 4.0 * (n_nodes + (double)G) * Kp, 1);
-            hipLaunchKernelGGL(cl_bwd_dot_kernel, dim3(nb), dim3(256), 0, s, n_nodes, gid, X, Kp, mk, mask_ld, fs, (const float*)p.dZ, wsum, p.dc);
+            if (mk) hipLaunchKernelGGL(cl_bwd_dot_kernel<true>, dim3(nb), dim3(256), 0, s, n_nodes, gid, X, Kp, mk, mask_ld, fs, (const float*)p.dZ, wsum,
+                                       coef, p.dc, p.cn);
+            else hipLaunchKernelGGL(cl_bwd_dot_kernel<false>, dim3(nb), dim3(256), 0, s, n_nodes, gid, X, Kp, dummy_mask, mask_ld, fs,
+                                    (const float*)p.dZ, wsum, coef, p.dc, p.cn);
         }
         hipLaunchKernelGGL(cl_bwd_edge_kernel, dim3(nb), dim3(256), 0, s, rowptr_in, col_src, n_nodes, a12, attn_slope, alpha, attn_drop_p, as,
                            seed, pos, pw, (const float*)p.dc, (const float*)p.dS, gid, p.dz, p.da2, p.dwv);
@@ -961,9 +982,12 @@ int txe_gat_collapse_bwd(const int* rowptr_in, const int* col_src, const int* ro
         {
             const long long nwaves = (long long)p.chunks * ntile;
             ProfScope prof("cl_bwd_dx_kernel", s, 4.0 * (2.0 * n_nodes + G) * Kp, 1);
-            hipLaunchKernelGGL(cl_bwd_dx_kernel, dim3((unsigned)((nwaves + 3) / 4)), dim3(256), 0, s, n_nodes, ntile, gid, X, Kp, Kh, mk, mask_ld, fs,
-                               (const float*)p.dZ, coef, wsum, (const float*)p.da1, (const float*)p.da2, wa, act_on, act_slope, d_X,
-                               p.dwa_part);
+            if (mk) hipLaunchKernelGGL(cl_bwd_dx_kernel<true>, dim3((unsigned)((nwaves + 3) / 4)), dim3(256), 0, s, n_nodes, ntile, gid, X, Kp, Kh, mk,
+                                       mask_ld, fs, (const float*)p.dZ, (const float*)p.cn, (const float*)p.da1, (const float*)p.da2, wa, act_on,
+                                       act_slope, d_X, p.dwa_part);
+            else hipLaunchKernelGGL(cl_bwd_dx_kernel<false>, dim3((unsigned)((nwaves + 3) / 4)), dim3(256), 0, s, n_nodes, ntile, gid, X, Kp, Kh,
+                                    dummy_mask, mask_ld, fs, (const float*)p.dZ, (const float*)p.cn, (const float*)p.da1, (const float*)p.da2, wa,
+                                    act_on, act_slope, d_X, p.dwa_part);
         }
         TXE_CHECK_LAUNCH();
     }

@@ -694,7 +694,8 @@ static inline int gemm_launch_layout(const VMat& A, const VMat& B, const Epi& E_
     TXE_CHECK_LAUNCH();
     if (T.S > 0) {
         const int r = nbm * nbn - T.nfull;
-        ProfScope prof("gemm_tail_fixup_kernel", stream, 0.0, 0);
+        ProfScope prof(bn == 128 ? "gemm_tail_fixup_kernel<128>" : "gemm_tail_fixup_kernel<64>", stream,
+                       4.0 * r * GEMM_BM * bn * (T.S + 1.0), 1);      // reads S partial tiles, writes one
         if (bn == 128) hipLaunchKernelGGL((gemm_tail_fixup_kernel<128>), dim3(r, 16), dim3(256), 0, stream, E, T, M, N);
         else hipLaunchKernelGGL((gemm_tail_fixup_kernel<64>), dim3(r, 16), dim3(256), 0, stream, E, T, M, N);
         TXE_CHECK_LAUNCH();

@@ -895,7 +895,7 @@ int txe_gat_collapse_fwd(const int* rowptr_in, const int* col_src, const int* ro
     if (n_nodes > 0) {
         const int nb = (n_nodes + 3) / 4;
         {
-            ProfScope prof("cl_logits_kernel", s, 4.0 * n_nodes * (double)Kp, 1);
+            ProfScope prof(mk ? "cl_logits_kernel<true>" : "cl_logits_kernel<false>", s, 4.0 * n_nodes * (double)Kp, 1);
             if (mk) hipLaunchKernelGGL(cl_logits_kernel<true>, dim3(nb < 2048 ? nb : 2048), dim3(256), 0, s, X, Kp, n_nodes, mk, mask_ld, fs, wa, a12);
             else hipLaunchKernelGGL(cl_logits_kernel<false>, dim3(nb < 2048 ? nb : 2048), dim3(256), 0, s, X, Kp, n_nodes, dummy_mask, mask_ld, fs, wa, a12);
         }
@@ -908,7 +908,7 @@ int txe_gat_collapse_fwd(const int* rowptr_in, const int* col_src, const int* ro
     {
         const int ntile = (Kp / 4 + 63) / 64;
         const long long nwaves = (long long)G * ntile;
-        ProfScope prof("cl_zsum_kernel", s, 4.0 * (n_nodes + (double)G) * Kp, 1);
+        ProfScope prof(mk ? "cl_zsum_kernel<true>" : "cl_zsum_kernel<false>", s, 4.0 * (n_nodes + (double)G) * Kp, 1);
         if (mk) hipLaunchKernelGGL(cl_zsum_kernel<true>, dim3((unsigned)((nwaves + 3) / 4)), dim3(256), 0, s, graph_off, G, ntile, X, Kp, mk, mask_ld, fs,
                                    (const float*)coef, (const float*)wsum, Z);
         else hipLaunchKernelGGL(cl_zsum_kernel<false>, dim3((unsigned)((nwaves + 3) / 4)), dim3(256), 0, s, graph_off, G, ntile, X, Kp, dummy_mask,
@@ -970,7 +970,7 @@ int txe_gat_collapse_bwd(const int* rowptr_in, const int* col_src, const int* ro
         const int ntile = (Kp / 4 + 63) / 64;
         hipLaunchKernelGGL(cl_bwd_ds_kernel, dim3((G + 3) / 4), dim3(256), 0, s, G, Kp, (const float*)p.dZ, Z, wsum, p.dS);
         {
-            ProfScope prof("cl_bwd_dot_kernel", s, 4.0 * (n_nodes + (double)G) * Kp, 1);
+            ProfScope prof(mk ? "cl_bwd_dot_kernel<true>" : "cl_bwd_dot_kernel<false>", s, 4.0 * (n_nodes + (double)G) * Kp, 1);
             if (mk) hipLaunchKernelGGL(cl_bwd_dot_kernel<true>, dim3(nb), dim3(256), 0, s, n_nodes, gid, X, Kp, mk, mask_ld, fs, (const float*)p.dZ, wsum,
                                        coef, p.dc, p.cn);
             else hipLaunchKernelGGL(cl_bwd_dot_kernel<false>, dim3(nb), dim3(256), 0, s, n_nodes, gid, X, Kp, dummy_mask, mask_ld, fs,
@@ -981,7 +981,7 @@ int txe_gat_collapse_bwd(const int* rowptr_in, const int* col_src, const int* ro
         hipLaunchKernelGGL(cl_bwd_src_kernel, dim3(nb), dim3(256), 0, s, rowptr_out, pos_out, n_nodes, (const float*)p.dz, p.da1);
         {
             const long long nwaves = (long long)p.chunks * ntile;
-            ProfScope prof("cl_bwd_dx_kernel", s, 4.0 * (2.0 * n_nodes + G) * Kp, 1);
+            ProfScope prof(mk ? "cl_bwd_dx_kernel<true>" : "cl_bwd_dx_kernel<false>", s, 4.0 * (2.0 * n_nodes + G) * Kp, 1);
             if (mk) hipLaunchKernelGGL(cl_bwd_dx_kernel<true>, dim3((unsigned)((nwaves + 3) / 4)), dim3(256), 0, s, n_nodes, ntile, gid, X, Kp, Kh, mk,
                                        mask_ld, fs, (const float*)p.dZ, (const float*)p.cn, (const float*)p.da1, (const float*)p.da2, wa, act_on,
                                        act_slope, d_X, p.dwa_part);

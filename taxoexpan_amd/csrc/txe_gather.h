@@ -33,45 +33,40 @@ __device__ __forceinline__ void vstore(float* p, const float* v) {
 // NI*EU independent loads per lane is what fills the HBM pipe.  Used by one wave for a whole row (j0 = tile start, j1 = row
 // end) and by the workgroup-cooperative kernels for a quarter row per wave.
 template <int VEC, int NI, int EU>
-__device__ __forceinline__ void gather_rows(const float* __restrict__ base, long long ld, const int* s_idx,
-                                                        const float* s_w, int cnt, int j0, int j1, const int* hidx,
-                                                        float (&acc)[NI][VEC]) {
+__device__ __forceinline__ void gather_step(const float* __restrict__ base, long long ld, const int* s_idx, const float* s_w, int e,
+                                            int j0, int j1, const int* hidx, float (&acc)[NI][VEC]) {
     const int l = threadIdx.x & 63;
-    int e = 0;
-    for (; e + EU <= cnt; e += EU) {
-        float v[EU][NI][VEC];
+    float v[EU][NI][VEC];
 #pragma unroll
-        for (int u = 0; u < EU; ++u) {
-            const float* row = base + (long long)s_idx[e + u] * ld;
-#pragma unroll
-            for (int i = 0; i < NI; ++i) {
-                const int j = j0 + l + 64 * i;
-                const int jc = (j < j1) ? j : j0;               // clamped: loads stay unconditional
-                vload<VEC>(row + (long long)jc * VEC, v[u][i]);
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < EU; ++u)
-#pragma unroll
-            for (int i = 0; i < NI; ++i) {
-                const float a = s_w[hidx[i] * 64 + e + u];
-#pragma unroll
-                for (int k = 0; k < VEC; ++k) acc[i][k] = fmaf(a, v[u][i][k], acc[i][k]);
-            }
-    }
-    for (; e < cnt; ++e) {
-        const float* row = base + (long long)s_idx[e] * ld;
+    for (int u = 0; u < EU; ++u) {
+        const float* row = base + (long long)s_idx[e + u] * ld;
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
             const int j = j0 + l + 64 * i;
-            const int jc = (j < j1) ? j : j0;
-            float v[VEC];
-            vload<VEC>(row + (long long)jc * VEC, v);
-            const float a = s_w[hidx[i] * 64 + e];
-#pragma unroll
-            for (int k = 0; k < VEC; ++k) acc[i][k] = fmaf(a, v[k], acc[i][k]);
+            const int jc = (j < j1) ? j : j0;                   // clamped: loads stay unconditional
+            vload<VEC>(row + (long long)jc * VEC, v[u][i]);
         }
     }
+#pragma unroll
+    for (int u = 0; u < EU; ++u)
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const float a = s_w[hidx[i] * 64 + e + u];
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) acc[i][k] = fmaf(a, v[u][i][k], acc[i][k]);
+        }
+}
+
+template <int VEC, int NI, int EU>
+__device__ __forceinline__ void gather_rows(const float* __restrict__ base, long long ld, const int* s_idx,
+                                            const float* s_w, int cnt, int j0, int j1, const int* hidx,
+                                            float (&acc)[NI][VEC]) {
+    int e = 0;
+    for (; e + EU <= cnt; e += EU) gather_step<VEC, NI, EU>(base, ld, s_idx, s_w, e, j0, j1, hidx, acc);
+    if constexpr (EU >= 4) {                                    // remainder in halves: 2 edges still go out together
+        if (e + 2 <= cnt) { gather_step<VEC, NI, 2>(base, ld, s_idx, s_w, e, j0, j1, hidx, acc); e += 2; }
+    }
+    for (; e < cnt; ++e) gather_step<VEC, NI, 1>(base, ld, s_idx, s_w, e, j0, j1, hidx, acc);
 }
 
 // vectors-per-lane template choice for a row of nvec vectors: 2 / 4 / 8 (wider rows loop over 512-vector tiles)

@@ -171,6 +171,20 @@ int txe_gat_collapse_bwd(const int* rowptr_in, const int* col_src, const int* ro
                          const float* d_hg, long long ld_dhg, int act_on, float act_slope, float* d_X, float* dW, float* d_attn_l,
                          float* d_attn_r, float* dP, float* d_pw, void* ws, size_t ws_bytes, void* stream);
 
+/* ---- output GCNLayer folded behind MeanReadout / WeightedMeanReadout: model_zoo.py:35-47,139-167,227-242.
+ * hg[g] = (sum_{u in g} c_u Xd[u]) W + b with c_u = norm_u sum_{v: u->v} w_v norm_v / S_g (graph constants).  X / Wp / mask as for
+ * txe_gcn_dense_*; norm from txe_gcn_norm; forward keeps coef [N], wsum [G], gid [N], Z [G][Kp]. */
+size_t txe_gcn_collapse_ws_bytes(int n_nodes, int G, int Kh, int Pd, int Fo, int vocab);
+int txe_gcn_collapse_fwd(const int* rowptr_out, const int* col_dst, const int* graph_off, int n_nodes, int G, const float* X, int Kh, int Pd,
+                         const float* Wp, int Fo, const float* bias, float drop_p, const unsigned* mask, const float* norm, const int* pos,
+                         const float* pw, float* coef, float* wsum, int* gid, float* Z, float* hg, long long ld_hg, void* ws,
+                         size_t ws_bytes, void* stream);
+int txe_gcn_collapse_bwd(const int* rowptr_in, const int* col_src, const int* graph_off, int n_nodes, int G, const float* X, int Kh, int Pd,
+                         const int* pos, int vocab, const float* Wp, int Fo, float drop_p, const unsigned* mask, const float* norm,
+                         const float* pw, const float* coef, const float* wsum, const int* gid, const float* Z, const float* d_hg,
+                         long long ld_dhg, int act_on, float act_slope, float* d_X, float* dW, float* d_b, float* dP, float* d_pw, void* ws,
+                         size_t ws_bytes, void* stream);
+
 /* ---- egonet construction + batching on device: data_loader/dataset.py:404-437 (_get_subgraph) + dgl.batch (data_loaders.py:25).
  * Taxonomy as parent CSR (par_ptr/par_idx) and child CSR (chd_ptr/chd_idx); anchors [G]; exclude [G] or NULL (query node removed
  * from each egonet's siblings, -1 = none: the positive example of dataset.py:421-424); children beyond `expand` are drawn with

@@ -55,6 +55,9 @@ SIGNATURES = {
     "txe_gat_collapse_fwd": (I, [P, P, P, P, P, P, I, I, I, P, I, I, P, I, F, P, F, F, U64, P, P, P, P, P, P, P, P, P, L, P, SZ, P]),
     "txe_gat_collapse_bwd": (I, [P, P, P, P, P, P, I, I, I, P, I, I, P, I, P, P, P, P, I, F, P, F, F, U64, P, P, P, P, P, P, P, P, L, I, F,
                                  P, P, P, P, P, P, P, SZ, P]),
+    "txe_gcn_collapse_ws_bytes": (SZ, [I, I, I, I, I, I]),
+    "txe_gcn_collapse_fwd": (I, [P, P, P, I, I, P, I, I, P, I, P, F, P, P, P, P, P, P, P, P, P, L, P, SZ, P]),
+    "txe_gcn_collapse_bwd": (I, [P, P, P, I, I, P, I, I, P, I, P, I, F, P, P, P, P, P, P, P, P, L, I, F, P, P, P, P, P, P, SZ, P]),
     "txe_egonet_ws_bytes": (SZ, [I]),
     "txe_egonet_offsets": (I, [P, P, P, P, P, I, I, U64, P, P, SZ, P]),
     "txe_egonet_fill": (I, [P, P, P, P, P, P, I, I, U64, P, P, P, P, P, P, P, P, P, P]),

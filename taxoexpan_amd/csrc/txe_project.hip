@@ -766,7 +766,7 @@ __global__ __launch_bounds__(256) void cl_bwd_src_kernel(const int* __restrict__
 //   d_X[u][j] = keep * scale * (c~_u / S_g * dZ[g][j] + da1[u] wa1[j] + da2[u] wa2[j]) * (act_on && j < Kh ? leaky'(X[u][j]) : 1)
 //   dwa_part[chunk][0/1][j] = sum over the chunk's nodes of da1/da2[u] * scale * keep * X[u][j]     (fixed order: deterministic)
 constexpr int CL_CHUNK = 32;
-template <bool MASK>
+template <bool MASK, bool ATT>
 __global__ __launch_bounds__(256) void cl_bwd_dx_kernel(int n_nodes, int ntile, const int* __restrict__ gid, const float* __restrict__ X, int Kp,
                                                         int Kh, const unsigned* __restrict__ mask, int mask_ld, float scale,
                                                         const float* __restrict__ dZ, const float* __restrict__ cn,
@@ -787,9 +787,11 @@ __global__ __launch_bounds__(256) void cl_bwd_dx_kernel(int n_nodes, int ntile, 
     float sl[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) sl[k] = (act_on && (jc * 4 + k) < Kh) ? act_slope : 1.f;
-    float w1[4], w2[4], s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
-    vload<4>(wa + jc * 4, w1);
-    vload<4>(wa + Kp + jc * 4, w2);
+    float w1[4] = {0.f, 0.f, 0.f, 0.f}, w2[4] = {0.f, 0.f, 0.f, 0.f}, s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (ATT) {
+        vload<4>(wa + jc * 4, w1);
+        vload<4>(wa + Kp + jc * 4, w2);
+    }
     constexpr int NU = 8;                            // nodes per step: all their loads are unconditional and issued together
     for (int u0 = u_beg; u0 < u_end; u0 += NU) {
         float x[NU][4], d[NU][4], k4[NU][4], cu[NU], g1[NU], g2[NU];
@@ -799,8 +801,8 @@ __global__ __launch_bounds__(256) void cl_bwd_dx_kernel(int n_nodes, int ntile, 
             const float ok = (u0 + e < u_end) ? 1.f : 0.f;
             const int g = gid[u];
             cu[e] = cn[u] * ok;
-            g1[e] = da1[u] * ok;
-            g2[e] = da2[u] * ok;
+            g1[e] = ATT ? da1[u] * ok : 0.f;
+            g2[e] = ATT ? da2[u] * ok : 0.f;
             vload<4>(X + (long long)u * Kp + jc * 4, x[e]);
             vload<4>(dZ + (long long)g * Kp + jc * 4, d[e]);
             cl_keep4<MASK>(mask + (MASK ? (long long)u * mask_ld : 0), mask_ld, jc, k4[e]);
@@ -819,7 +821,7 @@ __global__ __launch_bounds__(256) void cl_bwd_dx_kernel(int n_nodes, int ntile, 
             if (jok && u0 + e < u_end) vstore<4>(d_X + (long long)(u0 + e) * Kp + j * 4, o);
         }
     }
-    if (jok) {
+    if (ATT && jok) {
         vstore<4>(dwa_part + ((long long)chunk * 2 + 0) * Kp + j * 4, s1);
         vstore<4>(dwa_part + ((long long)chunk * 2 + 1) * Kp + j * 4, s2);
     }
@@ -981,11 +983,11 @@ int txe_gat_collapse_bwd(const int* rowptr_in, const int* col_src, const int* ro
         hipLaunchKernelGGL(cl_bwd_src_kernel, dim3(nb), dim3(256), 0, s, rowptr_out, pos_out, n_nodes, (const float*)p.dz, p.da1);
         {
             const long long nwaves = (long long)p.chunks * ntile;
-            ProfScope prof(mk ? "cl_bwd_dx_kernel<true>" : "cl_bwd_dx_kernel<false>", s, 4.0 * (2.0 * n_nodes + G) * Kp, 1);
-            if (mk) hipLaunchKernelGGL(cl_bwd_dx_kernel<true>, dim3((unsigned)((nwaves + 3) / 4)), dim3(256), 0, s, n_nodes, ntile, gid, X, Kp, Kh, mk,
+            ProfScope prof(mk ? "cl_bwd_dx_kernel<true, true>" : "cl_bwd_dx_kernel<false, true>", s, 4.0 * (2.0 * n_nodes + G) * Kp, 1);
+            if (mk) hipLaunchKernelGGL((cl_bwd_dx_kernel<true, true>), dim3((unsigned)((nwaves + 3) / 4)), dim3(256), 0, s, n_nodes, ntile, gid, X, Kp, Kh, mk,
                                        mask_ld, fs, (const float*)p.dZ, (const float*)p.cn, (const float*)p.da1, (const float*)p.da2, wa, act_on,
                                        act_slope, d_X, p.dwa_part);
-            else hipLaunchKernelGGL(cl_bwd_dx_kernel<false>, dim3((unsigned)((nwaves + 3) / 4)), dim3(256), 0, s, n_nodes, ntile, gid, X, Kp, Kh,
+            else hipLaunchKernelGGL((cl_bwd_dx_kernel<false, true>), dim3((unsigned)((nwaves + 3) / 4)), dim3(256), 0, s, n_nodes, ntile, gid, X, Kp, Kh,
                                     dummy_mask, mask_ld, fs, (const float*)p.dZ, (const float*)p.cn, (const float*)p.da1, (const float*)p.da2, wa,
                                     act_on, act_slope, d_X, p.dwa_part);
         }
@@ -1015,3 +1017,250 @@ int txe_gat_collapse_bwd(const int* rowptr_in, const int* col_src, const int* ro
 }
 
 }  // extern "C"
+
+// =====================================================================================================================
+// Last GCNLayer folded behind MeanReadout / WeightedMeanReadout (PGCN / GCN output layer: no activation; model_zoo.py:35-47,
+// 139-167, 227-242):  hg[g] = sum_v w_v/S_g (norm_v sum_{u->v} norm_u Xd[u] W + b) = (sum_{u in g} c_u Xd[u]) W + b,
+//     c_u = norm_u sum_{v : u->v} w_v norm_v / S_g      -- graph constants (no attention): one sweep forward, one backward
+// (two with learnable readout weights).  Reuses the sweep kernels of the GAT fold above.
+// =====================================================================================================================
+namespace txe {
+
+// one wave per source: c~_u = norm_u * sum_{j in out(u)} w_{dst(j)} norm_{dst(j)}
+__global__ __launch_bounds__(256) void gcl_coef_kernel(const int* __restrict__ rowptr_out, const int* __restrict__ col_dst, int n_nodes,
+                                                       const float* __restrict__ norm, const int* __restrict__ pos,
+                                                       const float* __restrict__ pw, float* __restrict__ coef) {
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    const int u = blockIdx.x * 4 + w;
+    if (u >= n_nodes) return;
+    float c = 0.f;
+    for (int j = rowptr_out[u] + l; j < rowptr_out[u + 1]; j += 64) {
+        const int v = col_dst[j];
+        c = fmaf(pw ? cl_softplus(pw[pos[v]]) : 1.f, norm[v], c);
+    }
+    c = wave_sum(c);
+    if (l == 0) coef[u] = c * norm[u];
+}
+
+// one wave per destination: dwv[v] = (dS_g(v) + norm_v sum_{p in in(v)} norm_u dc~_u) * sigmoid(pw[pos_v])
+__global__ __launch_bounds__(256) void gcl_bwd_w_kernel(const int* __restrict__ rowptr, const int* __restrict__ col, int n_nodes,
+                                                        const float* __restrict__ norm, const int* __restrict__ pos,
+                                                        const float* __restrict__ pw, const float* __restrict__ dc,
+                                                        const float* __restrict__ dS, const int* __restrict__ gid,
+                                                        float* __restrict__ dwv) {
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    const int v = blockIdx.x * 4 + w;
+    if (v >= n_nodes) return;
+    float a = 0.f;
+    for (int p = rowptr[v] + l; p < rowptr[v + 1]; p += 64) a = fmaf(norm[col[p]], dc[col[p]], a);
+    a = wave_sum(a);
+    if (l == 0) dwv[v] = (dS[gid[v]] + norm[v] * a) * cl_sigmoid(pw[pos[v]]);
+}
+
+// y[g][f] += b[f]
+__global__ void gcl_add_bias_kernel(float* __restrict__ y, long long ld, int rows, int cols, const float* __restrict__ b) {
+    const long long n = (long long)rows * cols;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        y[(i / cols) * ld + (i % cols)] += b[i % cols];
+}
+
+// out[f] = sum_g x[g][f]     (one block per 64 columns, fixed order)
+__global__ __launch_bounds__(256) void gcl_colsum_kernel(const float* __restrict__ x, long long ld, int rows, int cols, float* __restrict__ out) {
+    __shared__ float red[4][64];
+    const int jl = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int j = blockIdx.x * 64 + jl;
+    const int jc = j < cols ? j : 0;
+    float acc = 0.f;
+    for (int r = rg; r < rows; r += 4) acc += x[(long long)r * ld + jc];
+    red[rg][jl] = acc;
+    __syncthreads();
+    if (rg == 0 && j < cols) out[j] = red[0][jl] + red[1][jl] + red[2][jl] + red[3][jl];
+}
+
+struct GclWs {
+    float *dZ, *part, *dc, *cn, *dS, *dwv, *ppart, *ppart2;
+    void* tail;
+    size_t tail_bytes, total;
+    int splits, seg_blocks, seg_rows;
+};
+
+static GclWs plan_gcl_ws(void* ws, int n, int G, int Kp, int Fop, int Pd, int vocab) {
+    GclWs p;
+    char* b = (char*)ws;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { float* r = (float*)(b + off); off += align_up(bytes > 0 ? bytes : 4, 256); return r; };
+    const int n1 = n > 0 ? n : 1, g1 = G > 0 ? G : 1, v1 = vocab > 0 ? vocab : 1;
+    p.dZ = take((size_t)g1 * Kp * 4);
+    p.splits = choose_splits(Kp, Fop, G);
+    p.part = take((size_t)p.splits * Kp * Fop * 4);
+    p.dc = take((size_t)n1 * 4);
+    p.cn = take((size_t)n1 * 4);
+    p.dS = take((size_t)g1 * 4);
+    p.dwv = take((size_t)n1 * 4);
+    p.seg_rows = 64;
+    p.seg_blocks = (n + p.seg_rows - 1) / p.seg_rows;
+    if (p.seg_blocks < 1) p.seg_blocks = 1;
+    p.ppart = take((size_t)p.seg_blocks * v1 * (Pd > 0 ? Pd : 1) * 4);
+    p.ppart2 = take((size_t)p.seg_blocks * v1 * 4);
+    p.tail_bytes = gemm_tail_ws_bytes();
+    p.tail = take(p.tail_bytes);
+    p.total = off;
+    return p;
+}
+
+// cn[u] = coef[u] / S_g(u)   (MeanReadout path: no dot sweep to piggy-back on)
+__global__ void gcl_cn_kernel(int n_nodes, const int* __restrict__ gid, const float* __restrict__ coef, const float* __restrict__ wsum,
+                              float* __restrict__ cn) {
+    const int u = blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= n_nodes) return;
+    const float S = wsum[gid[u]];
+    cn[u] = S > 0.f ? coef[u] / S : 0.f;
+}
+
+}  // namespace txe
+using namespace txe;
+extern "C" {
+
+size_t txe_gcn_collapse_ws_bytes(int n_nodes, int G, int Kh, int Pd, int Fo, int vocab) {
+    return plan_gcl_ws(nullptr, n_nodes, G, round_up(Kh + Pd, 32), round_up(Fo, 32), Pd, vocab).total;
+}
+
+// X [N][Kp], Wp [Kp128][Fop], mask as for txe_gcn_dense_*; norm [N] (txe_gcn_norm); bias [Fo] or NULL; pw == NULL: MeanReadout.
+// Saved for backward: coef [N], wsum [G], gid [N], Z [G][Kp].  hg [G][Fo] (row stride ld_hg).
+int txe_gcn_collapse_fwd(const int* rowptr_out, const int* col_dst, const int* graph_off, int n_nodes, int G, const float* X, int Kh, int Pd,
+                         const float* Wp, int Fo, const float* bias, float drop_p, const unsigned* mask, const float* norm, const int* pos,
+                         const float* pw, float* coef, float* wsum, int* gid, float* Z, float* hg, long long ld_hg, void* ws,
+                         size_t ws_bytes, void* stream) {
+    if (n_nodes < 0 || G < 0 || Kh < 1 || Pd < 0 || Fo < 1 || !rowptr_out || !graph_off || !X || !Wp || !norm || !coef || !wsum || !gid || !Z ||
+        !hg || !ws || (pw && !pos))
+        return TXE_ERR_ARG;
+    if (drop_p < 0.f || drop_p >= 1.f) return TXE_ERR_ARG;
+    const int Kt = Kh + Pd, Kp = round_up(Kt, 32), Fop = round_up(Fo, 32);
+    GclWs p = plan_gcl_ws(ws, n_nodes, G, Kp, Fop, Pd, 0);
+    if (ws_bytes < p.total) return TXE_ERR_WORKSPACE;
+    if (G == 0) return TXE_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const unsigned* mk = (mask && drop_p > 0.f) ? mask : nullptr;
+    const unsigned* dummy_mask = reinterpret_cast<const unsigned*>(X);
+    const int mask_ld = (Kt + 31) / 32;
+    const float fs = mk ? 1.f / (1.f - drop_p) : 1.f;
+    if (n_nodes > 0)
+        hipLaunchKernelGGL(gcl_coef_kernel, dim3((n_nodes + 3) / 4), dim3(256), 0, s, rowptr_out, col_dst, n_nodes, norm, pos, pw, coef);
+    hipLaunchKernelGGL(cl_wsum_kernel, dim3((G + 3) / 4), dim3(256), 0, s, graph_off, G, pos, pw, wsum, gid);
+    {
+        const int ntile = (Kp / 4 + 63) / 64;
+        const long long nwaves = (long long)G * ntile;
+        ProfScope prof(mk ? "cl_zsum_kernel<true>" : "cl_zsum_kernel<false>", s, 4.0 * (n_nodes + (double)G) * Kp, 1);
+        if (mk) hipLaunchKernelGGL(cl_zsum_kernel<true>, dim3((unsigned)((nwaves + 3) / 4)), dim3(256), 0, s, graph_off, G, ntile, X, Kp, mk, mask_ld, fs,
+                                   (const float*)coef, (const float*)wsum, Z);
+        else hipLaunchKernelGGL(cl_zsum_kernel<false>, dim3((unsigned)((nwaves + 3) / 4)), dim3(256), 0, s, graph_off, G, ntile, X, Kp, dummy_mask,
+                                mask_ld, fs, (const float*)coef, (const float*)wsum, Z);
+    }
+    TXE_CHECK_LAUNCH();
+    VMat A = vmat_plain(Z, Kp, G, Kp);
+    VMat B = vmat_plain(Wp, Fop, Kp, Fop);
+    Epi E = epi_plain(hg, ld_hg, Fo);
+    int rc = gemm_nn(A, B, E, G, Fo, Kp, 1, s, p.tail, p.tail_bytes);
+    if (rc) return rc;
+    if (bias) {
+        const long long n = (long long)G * Fo;
+        hipLaunchKernelGGL(gcl_add_bias_kernel, dim3((int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048)), dim3(256), 0, s, hg, ld_hg, G, Fo,
+                           bias);
+        TXE_CHECK_LAUNCH();
+    }
+    return TXE_OK;
+}
+
+// d_hg [G][Fo] -> d_X [N][Kp] (layout of txe_gcn_dense_bwd), dW [Kt][Fo], d_b [Fo] (or NULL), dP, d_pw.
+int txe_gcn_collapse_bwd(const int* rowptr_in, const int* col_src, const int* graph_off, int n_nodes, int G, const float* X, int Kh, int Pd,
+                         const int* pos, int vocab, const float* Wp, int Fo, float drop_p, const unsigned* mask, const float* norm,
+                         const float* pw, const float* coef, const float* wsum, const int* gid, const float* Z, const float* d_hg,
+                         long long ld_dhg, int act_on, float act_slope, float* d_X, float* dW, float* d_b, float* dP, float* d_pw, void* ws,
+                         size_t ws_bytes, void* stream) {
+    if (n_nodes < 0 || G < 0 || Kh < 1 || Pd < 0 || Fo < 1 || !rowptr_in || !graph_off || !X || !Wp || !norm || !coef || !wsum || !gid || !Z ||
+        !d_hg || !d_X || !dW || !ws)
+        return TXE_ERR_ARG;
+    if ((Pd > 0 || pw) && (!pos || vocab < 1 || vocab > MAX_VOCAB)) return TXE_ERR_ARG;
+    if ((Pd > 0 && !dP) || (pw && !d_pw)) return TXE_ERR_ARG;
+    if (drop_p < 0.f || drop_p >= 1.f) return TXE_ERR_ARG;
+    const int Kt = Kh + Pd, Kp = round_up(Kt, 32), Fop = round_up(Fo, 32);
+    GclWs p = plan_gcl_ws(ws, n_nodes, G, Kp, Fop, Pd, vocab);
+    if (ws_bytes < p.total) return TXE_ERR_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    const unsigned* mk = (mask && drop_p > 0.f) ? mask : nullptr;
+    const unsigned* dummy_mask = reinterpret_cast<const unsigned*>(X);
+    const int mask_ld = (Kt + 31) / 32;
+    const float fs = mk ? 1.f / (1.f - drop_p) : 1.f;
+    int rc;
+    {   // dZ[g][k] = sum_f d_hg[g][f] Wp[k][f]
+        VMat A = vmat_plain(d_hg, ld_dhg, G, Fo);
+        VMat B = vmat_plain(Wp, Fop, round_up(Kp, 128), Fop);
+        Epi E = epi_plain(p.dZ, Kp, Kp);
+        rc = gemm_nt(A, B, E, G, Kp, Fo, 1, s, p.tail, p.tail_bytes);
+        if (rc) return rc;
+    }
+    {   // dW[k][f] = sum_g Z[g][k] d_hg[g][f]
+        VMat A = vmat_plain(Z, Kp, G, Kp);
+        VMat B = vmat_plain(d_hg, ld_dhg, G, Fo);
+        Epi E = epi_plain(p.part, Fop, Fo);
+        E.split_stride = (long long)Kp * Fop;
+        rc = gemm_tn(A, B, E, Kp, Fo, G, p.splits, s);
+        if (rc) return rc;
+        const long long n = (long long)Kt * Fo;
+        hipLaunchKernelGGL(reduce_splits_sub_kernel, dim3((int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048)), dim3(256), 0, s,
+                           (const float*)p.part, G > 0 ? p.splits : 0, E.split_stride, Kt, Fo, Fop, dW);
+        TXE_CHECK_LAUNCH();
+    }
+    if (d_b) {
+        hipLaunchKernelGGL(gcl_colsum_kernel, dim3((Fo + 63) / 64), dim3(256), 0, s, d_hg, ld_dhg, G, Fo, d_b);
+        TXE_CHECK_LAUNCH();
+    }
+    if (G > 0 && n_nodes > 0) {
+        const int nb = (n_nodes + 3) / 4;
+        const int ntile = (Kp / 4 + 63) / 64;
+        if (pw) {
+            hipLaunchKernelGGL(cl_bwd_ds_kernel, dim3((G + 3) / 4), dim3(256), 0, s, G, Kp, (const float*)p.dZ, Z, wsum, p.dS);
+            {
+                ProfScope prof(mk ? "cl_bwd_dot_kernel<true>" : "cl_bwd_dot_kernel<false>", s, 4.0 * (n_nodes + (double)G) * Kp, 1);
+                if (mk) hipLaunchKernelGGL(cl_bwd_dot_kernel<true>, dim3(nb), dim3(256), 0, s, n_nodes, gid, X, Kp, mk, mask_ld, fs, (const float*)p.dZ,
+                                           wsum, coef, p.dc, p.cn);
+                else hipLaunchKernelGGL(cl_bwd_dot_kernel<false>, dim3(nb), dim3(256), 0, s, n_nodes, gid, X, Kp, dummy_mask, mask_ld, fs,
+                                        (const float*)p.dZ, wsum, coef, p.dc, p.cn);
+            }
+            hipLaunchKernelGGL(gcl_bwd_w_kernel, dim3(nb), dim3(256), 0, s, rowptr_in, col_src, n_nodes, norm, pos, pw, (const float*)p.dc,
+                               (const float*)p.dS, gid, p.dwv);
+        } else {
+            hipLaunchKernelGGL(gcl_cn_kernel, dim3((n_nodes + 255) / 256), dim3(256), 0, s, n_nodes, gid, coef, wsum, p.cn);
+        }
+        {
+            const long long nwaves = (long long)((n_nodes + CL_CHUNK - 1) / CL_CHUNK) * ntile;
+            ProfScope prof(mk ? "cl_bwd_dx_kernel<true, false>" : "cl_bwd_dx_kernel<false, false>", s, 4.0 * (2.0 * n_nodes + G) * Kp, 1);
+            if (mk) hipLaunchKernelGGL((cl_bwd_dx_kernel<true, false>), dim3((unsigned)((nwaves + 3) / 4)), dim3(256), 0, s, n_nodes, ntile, gid, X, Kp,
+                                       Kh, mk, mask_ld, fs, (const float*)p.dZ, (const float*)p.cn, (const float*)nullptr,
+                                       (const float*)nullptr, (const float*)nullptr, act_on, act_slope, d_X, (float*)nullptr);
+            else hipLaunchKernelGGL((cl_bwd_dx_kernel<false, false>), dim3((unsigned)((nwaves + 3) / 4)), dim3(256), 0, s, n_nodes, ntile, gid, X,
+                                    Kp, Kh, dummy_mask, mask_ld, fs, (const float*)p.dZ, (const float*)p.cn, (const float*)nullptr,
+                                    (const float*)nullptr, (const float*)nullptr, act_on, act_slope, d_X, (float*)nullptr);
+        }
+        TXE_CHECK_LAUNCH();
+    }
+    if (Pd > 0) {
+        if (n_nodes > 0)
+            hipLaunchKernelGGL(pos_segsum_stage1, dim3(p.seg_blocks), dim3(256), 0, s, (const float*)(d_X + Kh), (long long)Kp, pos, n_nodes, Pd,
+                               vocab, p.seg_rows, p.ppart);
+        hipLaunchKernelGGL(pos_segsum_stage2, dim3((vocab * Pd + 63) / 64), dim3(256), 0, s, (const float*)p.ppart,
+                           n_nodes > 0 ? p.seg_blocks : 0, vocab, Pd, dP);
+    }
+    if (pw) {
+        if (n_nodes > 0)
+            hipLaunchKernelGGL(pos_segsum_stage1, dim3(p.seg_blocks), dim3(256), 0, s, (const float*)p.dwv, (long long)1, pos, n_nodes, 1, vocab,
+                               p.seg_rows, p.ppart2);
+        hipLaunchKernelGGL(pos_segsum_stage2, dim3((vocab + 63) / 64), dim3(256), 0, s, (const float*)p.ppart2, n_nodes > 0 ? p.seg_blocks : 0,
+                           vocab, 1, d_pw);
+    }
+    TXE_CHECK_LAUNCH();
+    return TXE_OK;
+}
+
+}  // extern "C"
+

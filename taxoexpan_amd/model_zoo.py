@@ -69,7 +69,7 @@ class GCNLayer(nn.Module):
         """model_zoo.py:34-50 (the norm comes from in-degrees; g.ndata['norm'] is not needed)."""
         slope = _fused_slope(self.activation)
         cfg = ops.GCNConfig([self.weight.shape[1]], 0, [slope], [_p(self.dropout, self.training)], ops.new_seed())
-        out = ops.GCNStackFunction.apply(g.csr(h.device), cfg, h, None, self.weight, self.bias, None)
+        out = ops.GCNStackFunction.apply(g.csr(h.device), cfg, h, None, None, None, self.weight, self.bias, None)
         if self.activation and slope is None:
             out = self.activation(out)
         return out
@@ -139,18 +139,19 @@ def _gat_stack(layers, embeddings, g, h, pos, activation, training):
         params += [l.fc.weight, l.attn_l, l.attn_r, None if embeddings is None else embeddings[i].weight]
     if layers[-1].num_heads == 1:
         # one-head output layer: a weighted-mean readout can fold it (ops 'collapse'); anything else materialises N x D
-        return DeferredNodeOutput(g.csr(h.device), cfg, h, pos, params)
+        return DeferredNodeOutput(g.csr(h.device), cfg, h, pos, params, ops.GATStackFunction)
     return ops.GATStackFunction.apply(g.csr(h.device), cfg, h, pos, None, None, *params)
 
 
 class DeferredNodeOutput:
-    """What PGAT / GAT.forward return when the output layer has one head: the N x out_dim node features, not yet computed.
-    MeanReadout / WeightedMeanReadout consume it through `.readout(...)` -- the output layer is then evaluated on G graph
-    rows instead of N node rows (ops.GATStackFunction 'collapse'; same arithmetic, re-associated).  Every other use (attribute
-    access, torch functions, other readouts) materialises the ordinary tensor once, with the same dropout seeds."""
+    """What PGAT / GAT (one-head output layer) and PGCN / GCN (activation-free output layer) .forward return: the N x out_dim
+    node features, not yet computed.  MeanReadout / WeightedMeanReadout consume it through `.readout(...)` -- the output layer
+    is then evaluated on G graph rows instead of N node rows (ops 'collapse'; same arithmetic, re-associated).  Every other
+    use (attribute access, torch functions, other readouts) materialises the ordinary tensor once, with the same dropout seeds."""
 
-    def __init__(self, csr, cfg, h, pos, params):
+    def __init__(self, csr, cfg, h, pos, params, fn):
         self._args = (csr, cfg, h, pos, params)
+        self._fn = fn
         self._tensor = None
 
     def readout(self, rpos, pw):
@@ -158,12 +159,12 @@ class DeferredNodeOutput:
         csr, cfg, h, pos, params = self._args
         c = copy.copy(cfg)
         c.final = "collapse"
-        return ops.GATStackFunction.apply(csr, c, h, pos, rpos, pw, *params)
+        return self._fn.apply(csr, c, h, pos, rpos, pw, *params)
 
     def tensor(self):
         if self._tensor is None:
             csr, cfg, h, pos, params = self._args
-            self._tensor = ops.GATStackFunction.apply(csr, cfg, h, pos, None, None, *params)
+            self._tensor = self._fn.apply(csr, cfg, h, pos, None, None, *params)
         return self._tensor
 
     def __getattr__(self, name):                    # .shape, .device, .detach(), .cpu(), ... of the node features
@@ -236,7 +237,10 @@ def _gcn_stack(layers, embeddings, g, h, pos, training):
     params = []
     for i, l in enumerate(layers):
         params += [l.weight, l.bias, None if embeddings is None else embeddings[i].weight]
-    return ops.GCNStackFunction.apply(g.csr(h.device), cfg, h, pos, *params)
+    if slopes[-1] is None:
+        # activation-free output layer: a weighted-mean readout can fold it (ops 'collapse'); anything else materialises N x out
+        return DeferredNodeOutput(g.csr(h.device), cfg, h, pos, params, ops.GCNStackFunction)
+    return ops.GCNStackFunction.apply(g.csr(h.device), cfg, h, pos, None, None, *params)
 
 
 class GAT(nn.Module):

@@ -309,17 +309,22 @@ def gcn_norm(csr, ref):
 
 
 class _GcnLayerState:
-    __slots__ = ("X", "Wp", "mask", "W", "b", "P", "Kh", "Pd", "Kp", "Fo", "Fop", "seed")
+    __slots__ = ("X", "Wp", "mask", "W", "b", "P", "Kh", "Pd", "Kp", "Fo", "Fop", "seed", "cl")
 
 
 class GCNStackFunction(torch.autograd.Function):
-    """params per layer: (W [Kin, Fo], bias [Fo] or None, P [vocab, Pd] or None)."""
+    """params per layer: (W [Kin, Fo], bias [Fo] or None, P [vocab, Pd] or None).
+    cfg.final == 'collapse': G x Fo -- the (activation-free) output layer folded behind MeanReadout (pw None) /
+    WeightedMeanReadout (txe_gcn_collapse_*)."""
 
     @staticmethod
-    def forward(ctx, csr, cfg, h, pos, *params):
+    def forward(ctx, csr, cfg, h, pos, rpos, pw, *params):
         _need_cuda(h, *[p for p in params if p is not None])
         h, ld_h = _rows(h)
         pos = _i32(pos, h.device)
+        collapse = (getattr(cfg, "final", None) == "collapse")
+        rpos = _i32(rpos, h.device) if (collapse and pw is not None) else None
+        pwf = _f32(pw.reshape(-1)) if (collapse and pw is not None) else None
         L = cfg.n_layers
         need = any(ctx.needs_input_grad)       # (grad mode itself is off inside Function.forward)
         N = h.shape[0]
@@ -349,6 +354,20 @@ class GCNStackFunction(torch.autograd.Function):
                 st.Wp = _empty((kp128, st.Fop), h)
                 call("txe_gcn_pack_weights", ptr(st.W), st.Kh + st.Pd, st.Fo, ptr(st.Wp), st_)
                 st.mask = dropout_mask(N, st.Kh + st.Pd, cfg.drop_ps[l], st.seed, h)
+                if last and collapse:
+                    G = csr.n_graphs
+                    coef, wsum = _empty((max(N, 1),), h), _empty((max(G, 1),), h)
+                    gid = torch.empty(max(N, 1), dtype=torch.int32, device=h.device)
+                    Z, out = _empty((max(G, 1), st.Kp), h), _empty((G, st.Fo), h)
+                    wsb = call("txe_gcn_collapse_ws_bytes", N, G, st.Kh, st.Pd, st.Fo, 8)
+                    ws = _ws(wsb, h)
+                    call("txe_gcn_collapse_fwd", ptr(csr.rowptr_out), ptr(csr.col_dst), ptr(csr.graph_off), N, G, ptr(st.X), st.Kh, st.Pd,
+                         ptr(st.Wp), st.Fo, ptr(st.b), cfg.drop_ps[l], ptr(st.mask), ptr(norm), ptr(rpos), ptr(pwf), ptr(coef), ptr(wsum),
+                         ptr(gid), ptr(Z), ptr(out), st.Fo, ptr(ws), wsb, st_)
+                    st.cl = (coef, wsum, gid, Z)
+                    if not need:
+                        st.cl = st.mask = st.Wp = st.X = None
+                    break
                 hw = _empty((N, st.Fop), h)
                 call("txe_gcn_dense_fwd", ptr(st.X), N, st.Kh, st.Pd, ptr(st.Wp), st.Fo, cfg.drop_ps[l], ptr(st.mask), ptr(hw), ptr(tws),
                      tws.numel(), st_)
@@ -368,6 +387,7 @@ class GCNStackFunction(torch.autograd.Function):
         ctx.states = states if need else None
         ctx.h_req = ctx.needs_input_grad[2]
         ctx.out = out if need else None
+        ctx.rpos, ctx.pwf, ctx.pw_shape = rpos, pwf, (pw.shape if pwf is not None else None)
         return out
 
     @staticmethod
@@ -376,18 +396,43 @@ class GCNStackFunction(torch.autograd.Function):
         L = cfg.n_layers
         d_out = _f32(d_out)
         grads = [None] * (3 * L)
+        collapse = (getattr(cfg, "final", None) == "collapse")
+        d_pw = None
         with torch.cuda.device(d_out.device):
             st_ = _lib.stream_ptr()
-            N = d_out.shape[0]
-            if cfg.act_slopes[-1] is not None:   # a standalone activated layer: undo the fused activation explicitly
+            N = states[0].X.shape[0]
+            if collapse:
+                d_pre = None
+            elif cfg.act_slopes[-1] is not None:   # a standalone activated layer: undo the fused activation explicitly
                 d_pre = torch.empty_like(d_out)
                 call("txe_leaky_relu_bwd", ptr(d_out), ptr(ctx.out), cfg.act_slopes[-1], d_out.numel(), ptr(d_pre), st_)
             else:
                 d_pre = d_out
-            ld_dpre = d_pre.stride(0)
+            ld_dpre = d_pre.stride(0) if d_pre is not None else 0
             d_X = None
             for l in range(L - 1, -1, -1):
                 st = states[l]
+                if collapse and l == L - 1:
+                    coef, wsum, gid, Z = st.cl
+                    G = csr.n_graphs
+                    dh, ld = _rows(d_out)
+                    act_on = l > 0 and cfg.act_slopes[l - 1] is not None
+                    d_X = _empty((N, st.Kp), d_out)
+                    dW = torch.empty_like(st.W)
+                    d_b = torch.empty_like(st.b) if st.b is not None else None
+                    dP = torch.empty_like(st.P) if st.P is not None else None
+                    d_pw = torch.empty_like(ctx.pwf) if ctx.pwf is not None else None
+                    v = max(cfg.vocab, ctx.pwf.numel() if ctx.pwf is not None else 0)
+                    wsb = call("txe_gcn_collapse_ws_bytes", N, G, st.Kh, st.Pd, st.Fo, 8)
+                    ws = _ws(wsb, d_out)
+                    call("txe_gcn_collapse_bwd", ptr(csr.rowptr_in), ptr(csr.col_src), ptr(csr.graph_off), N, G, ptr(st.X), st.Kh, st.Pd,
+                         ptr(pos if st.P is not None else ctx.rpos), v, ptr(st.Wp), st.Fo, cfg.drop_ps[l], ptr(st.mask), ptr(norm),
+                         ptr(ctx.pwf), ptr(coef), ptr(wsum), ptr(gid), ptr(Z), ptr(dh), ld, int(act_on),
+                         (cfg.act_slopes[l - 1] if act_on else 1.0), ptr(d_X), ptr(dW), ptr(d_b), ptr(dP), ptr(d_pw), ptr(ws), wsb, st_)
+                    grads[3 * l:3 * l + 3] = [dW, d_b, dP]
+                    if l > 0:
+                        d_pre, ld_dpre = d_X, st.Kp
+                    continue
                 d_hw = _empty((N, st.Fop), d_out)
                 call("txe_zero_cols", ptr(d_hw), st.Fop, N, st.Fo, st.Fop, st_)
                 d_b = torch.empty_like(st.b) if st.b is not None else None
@@ -410,7 +455,9 @@ class GCNStackFunction(torch.autograd.Function):
                     d_pre, ld_dpre = d_X, st.Kp
             d_h = d_X[:, :states[0].Kh].contiguous() if ctx.h_req else None
         ctx.states = None
-        return (None, None, d_h, None, *grads)
+        if d_pw is not None:
+            d_pw = d_pw.reshape(ctx.pw_shape)
+        return (None, None, d_h, None, None, d_pw, *grads)
 
 
 # ================================================================================================================

@@ -536,9 +536,10 @@ def test_bench_contract_line():
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == d["unit"] and "sample" in c
 
 
-@pytest.mark.parametrize("readout,drop", [("WMR", 0.0), ("MR", 0.0), ("WMR", 0.2)])
-def test_collapsed_output_layer_equals_unfused_path(readout, drop):
-    """PGAT + (weighted) mean readout: the folded output layer (txe_gat_collapse_*, G graph rows) against the ordinary
+@pytest.mark.parametrize("kind,readout,drop", [("PGAT", "WMR", 0.0), ("PGAT", "MR", 0.0), ("PGAT", "WMR", 0.2), ("PGCN", "MR", 0.0),
+                                               ("PGCN", "WMR", 0.0), ("PGCN", "WMR", 0.2)])
+def test_collapsed_output_layer_equals_unfused_path(kind, readout, drop):
+    """PGAT / PGCN + (weighted) mean readout: the folded output layer (txe_gat_collapse_* / txe_gcn_collapse_*, G graph rows) against the ordinary
     projection -> aggregation -> readout path (N node rows) of the SAME modules, same dropout seeds -- on generic batched graphs
     (degree > 64 hub, graphs of 1..40 nodes), forward and every gradient."""
     from taxoexpan_amd import model_zoo as mz, ops
@@ -562,7 +563,12 @@ def test_collapsed_output_layer_equals_unfused_path(readout, drop):
     x = torch.randn(N, 10, generator=torch.Generator().manual_seed(0)).to(dev)
     coef = torch.randn(len(graphs), 6, generator=torch.Generator().manual_seed(1)).to(dev)
     torch.manual_seed(5)
-    prop = mz.PGAT(10, 8, 6, 4, num_layers=1, heads=[3, 1], activation=torch.nn.functional.leaky_relu, feat_drop=drop, attn_drop=drop).to(dev)
+    if kind == "PGAT":
+        prop = mz.PGAT(10, 8, 6, 4, num_layers=1, heads=[3, 1], activation=torch.nn.functional.leaky_relu, feat_drop=drop, attn_drop=drop)
+    else:
+        prop = mz.PGCN(10, 8, 6, 4, num_layers=1, activation=torch.nn.functional.leaky_relu, in_dropout=drop, hidden_dropout=drop,
+                       output_dropout=drop)
+    prop = prop.to(dev)
     ro = (mz.WeightedMeanReadout() if readout == "WMR" else mz.MeanReadout()).to(dev)
     prop.train(drop > 0)
     xg = x.clone().requires_grad_(True)

@@ -255,7 +255,7 @@ int txe_linear_bwd(const float* x1, long long ld1, int l, const float* x2, long 
     hipLaunchKernelGGL(reduce_splits_kernel2, dim3((int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048)), dim3(256), 0, s, (const float*)part,
                        G > 0 ? S : 0, E.split_stride, n, dW);
     TXE_CHECK_LAUNCH();
-    if (db && G == 0) hipMemsetAsync(db, 0, (size_t)O * 4, s);
+    if (db && G == 0) (void)hipMemsetAsync(db, 0, (size_t)O * 4, s);
     return TXE_OK;
 }
 

@@ -10,7 +10,6 @@
 namespace txe {
 
 constexpr int RO_WAVES = 4;
-constexpr int RO_MAXI = 8;
 constexpr int RO_MAX_VOCAB = 8;
 
 __device__ __forceinline__ float softplus_t(float x) { return x > 20.f ? x : log1pf(__expf(x)); }   // F.softplus, threshold 20

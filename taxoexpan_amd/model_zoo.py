@@ -180,8 +180,22 @@ class DeferredNodeOutput:
 
     @classmethod
     def __torch_function__(cls, func, types, args=(), kwargs=None):
+        from torch.utils._pytree import tree_map
         un = lambda a: a.tensor() if isinstance(a, DeferredNodeOutput) else a
-        return func(*[un(a) for a in args], **{k: un(v) for k, v in (kwargs or {}).items()})
+        return func(*tree_map(un, tuple(args)), **tree_map(un, dict(kwargs or {})))
+
+
+def _delegate(name):
+    def op(self, *args):
+        return getattr(self.tensor(), name)(*[a.tensor() if isinstance(a, DeferredNodeOutput) else a for a in args])
+    op.__name__ = name
+    return op
+
+
+for _n in ("__add__", "__radd__", "__sub__", "__rsub__", "__mul__", "__rmul__", "__truediv__", "__rtruediv__", "__matmul__", "__rmatmul__",
+           "__neg__", "__pow__", "__eq__", "__ne__", "__lt__", "__le__", "__gt__", "__ge__", "__iter__", "__repr__", "__bool__"):
+    setattr(DeferredNodeOutput, _n, _delegate(_n))
+DeferredNodeOutput.__hash__ = object.__hash__
 
 
 def _node_features(g):

@@ -134,6 +134,14 @@ int txe_linear_bwd(const float* x1, long long ld1, int l, const float* x2, long 
 int txe_score_block(const float* Q, long long ld_q, int nq, const float* U, long long ld_u, int G, int r, int apply_exp, float* S,
                     long long ld_s, void* stream);
 
+/* fused scoring + ranking: the score tile is compared in the GEMM epilogue and never stored.  counts [pos_off[nq]] int32
+ * (zeroed by the caller; shards of candidates add) += #{g : score(q, g) strictly better than thr[j]}; thr[j] = score of query q's j-th
+ * true parent as computed by txe_score_block (bit-identical k-order).  txe_rank_finalize: ranks[j] = 1 + counts[j] - (the query's
+ * other positives that beat j) -- metric.py:7-31. */
+int txe_score_count_block(const float* Q, long long ld_q, int nq, const float* U, long long ld_u, int G, int r, int apply_exp,
+                          const int* pos_off, const float* thr, int larger_is_better, int* counts, void* stream);
+int txe_rank_finalize(const int* pos_off, int nq, const float* thr, const int* counts, int larger_is_better, int* ranks, void* stream);
+
 /* plain dense product on the fp32 MFMA GEMM (tests / micro-benchmarks).  layout 0: C = A[M][K] B[N][K]^T; 1: C = A[M][K] B[K][N];
  * 2: C = A[K][M]^T B[K][N].  splits > 1: `splits` partial products at C + z*M*ldc.  ws/ws_bytes (optional, txe_gemm_tail_ws_bytes):
  * scratch that lets the last, partial round of workgroups be split along k ("tail splitting"). */

@@ -85,6 +85,12 @@ struct Epi {
     float drop_scale;
     int apply_exp;
     long long split_stride;
+    // count mode (fused ranking of the scoring loop): nothing is stored; for row m and each p in [cnt_off[m], cnt_off[m+1]):
+    //   cnt_out[p] += #{ n < N : value(m, n) > cnt_thr[p] }  (cnt_mode 1)  /  < cnt_thr[p]  (cnt_mode 2)    -- int32 atomics, exact
+    int cnt_mode;
+    const int* cnt_off;
+    const float* cnt_thr;
+    int* cnt_out;
 };
 
 static inline Epi epi_plain(float* c, long long ldc, int cols) {
@@ -93,6 +99,7 @@ static inline Epi epi_plain(float* c, long long ldc, int cols) {
     e.act_src = c; e.ld_act = 0; e.act_slope = 1.f; e.act_on = 0;
     e.mask = reinterpret_cast<const unsigned*>(c); e.mask_ld = 0; e.mask_col0 = 0; e.mask_on = 0; e.drop_scale = 1.f;
     e.apply_exp = 0; e.split_stride = 0;
+    e.cnt_mode = 0; e.cnt_off = nullptr; e.cnt_thr = nullptr; e.cnt_out = nullptr;
     return e;
 }
 static inline void epi_set_mask(Epi& e, const unsigned* mask, int total_cols, int col0, float drop_p) {
@@ -327,6 +334,7 @@ struct Tail {
     int S;           // k-slices per leftover tile
     int ksplit;      // k-range of one slice (multiple of BK)
     float* ws;       // [r*S][GEMM_BM*BN] raw partial tiles
+    int row_fast;    // 1: consecutive workgroups walk DOWN a column of tiles (few row panels, many column tiles: the scoring GEMM)
 };
 
 __device__ __forceinline__ void epi_store_one(const Epi& E, int m, int n, float acc, float* cbase) {
@@ -347,7 +355,8 @@ template <int BN>
 __global__ __launch_bounds__(256) void gemm_tail_fixup_kernel(const Epi E, const Tail T, const int M, const int N) {
     const int nbn = (N + BN - 1) / BN;
     const int tile = T.nfull + blockIdx.x;
-    const int m0 = (tile / nbn) * GEMM_BM, n0 = (tile % nbn) * BN;
+    const int nbm = (M + GEMM_BM - 1) / GEMM_BM;
+    const int m0 = (T.row_fast ? tile % nbm : tile / nbn) * GEMM_BM, n0 = (T.row_fast ? tile / nbm : tile % nbn) * BN;
     const float* part = T.ws + (long long)blockIdx.x * T.S * (GEMM_BM * BN);
     constexpr int CH = GEMM_BM * BN / 16;            // 16 workgroups per leftover tile (blockIdx.y)
     for (int idx = blockIdx.y * CH + threadIdx.x; idx < (blockIdx.y + 1) * CH; idx += 256) {
@@ -395,7 +404,11 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_kernel(VMat A, VMat B, c
         kbeg = zslice * ksplit;
         kend = min(K, kbeg + ksplit);
     }
-    const int tm = lb / nbn, tn = lb % nbn;
+    // tile order: consecutive workgroups (same XCD, same L2) share the operand panel of the SHORTER grid dimension's neighbour:
+    // column tiles fastest when there are more row panels than column tiles, else row panels fastest -- the long operand is then
+    // streamed from HBM once instead of once per tile of the short dimension (scoring: U read 1x instead of 8x per query block)
+    const int nbm = (M + GEMM_BM - 1) / GEMM_BM;
+    const int tm = T.row_fast ? lb % nbm : lb / nbn, tn = T.row_fast ? lb / nbm : lb % nbn;
     const int m0 = tm * GEMM_BM, n0 = tn * BN;
 
     // clip the reduction range into the operands' own bounds (split-K and K tails read zeros)
@@ -519,12 +532,69 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_kernel(VMat A, VMat B, c
         }
         return;
     }
+    if (E.cnt_mode != 0) {
+        // fused ranking: every thread owns 4 consecutive columns of a row; the C4 lanes of a row reduce their counts by butterfly.
+        // The rows' positive ranges and (up to PS) thresholds are staged once per tile in the LDS left over behind the C tile.
+        constexpr int FREE = SMEM - GEMM_BM * CLD;
+        constexpr int PS = (FREE - 2 * GEMM_BM) / GEMM_BM >= 8 ? 8 : ((FREE - 2 * GEMM_BM) / GEMM_BM > 0 ? (FREE - 2 * GEMM_BM) / GEMM_BM : 0);
+        float* s_thr = smem + GEMM_BM * CLD;
+        int* s_pb = reinterpret_cast<int*>(s_thr + GEMM_BM * PS);
+        int* s_np = s_pb + GEMM_BM;
+        if constexpr (PS > 0) {
+            if (threadIdx.x < GEMM_BM) {
+                const int m = m0 + threadIdx.x;
+                const int pb = (m < M) ? E.cnt_off[m] : 0;
+                const int np = (m < M) ? E.cnt_off[m + 1] - pb : 0;
+                s_pb[threadIdx.x] = pb;
+                s_np[threadIdx.x] = np;
+                for (int k = 0; k < np && k < PS; ++k) s_thr[threadIdx.x * PS + k] = E.cnt_thr[pb + k];
+            }
+            __syncthreads();
+        }
+        // two threads per row: each keeps its half row (BN/2 values) in registers and sweeps it once per positive of the row
+        {
+            static_assert(GEMM_THREADS == 2 * GEMM_BM, "two threads per tile row");
+            constexpr int HW = BN / 2;
+            const int row = threadIdx.x >> 1, half = threadIdx.x & 1;
+            const int m = m0 + row, nb = n0 + half * HW;
+            float v[HW];
+#pragma unroll
+            for (int j = 0; j < HW / 4; ++j) {
+                const float4 t4 = *reinterpret_cast<const float4*>(Cs + row * CLD + half * HW + 4 * j);
+                v[4 * j] = t4.x; v[4 * j + 1] = t4.y; v[4 * j + 2] = t4.z; v[4 * j + 3] = t4.w;
+            }
+            // columns past N never count: push them to the losing side of every comparison
+            const float lose = (E.cnt_mode == 1) ? -INFINITY : INFINITY;
+#pragma unroll
+            for (int i = 0; i < HW; ++i) {
+                const float x = E.apply_exp ? __expf(v[i]) : v[i];
+                v[i] = (nb + i < N) ? x : lose;
+            }
+            int pb, np;
+            if constexpr (PS > 0) { pb = s_pb[row]; np = s_np[row]; }
+            else { pb = (m < M) ? E.cnt_off[m] : 0; np = (m < M) ? E.cnt_off[m + 1] - pb : 0; }
+            for (int k = 0; k < np; ++k) {                       // the two threads of a row share the trip count
+                const float th = (k < PS) ? s_thr[row * PS + k] : E.cnt_thr[pb + k];
+                int c = 0;
+                if (E.cnt_mode == 1) {
+#pragma unroll
+                    for (int i = 0; i < HW; ++i) c += (v[i] > th) ? 1 : 0;
+                } else {
+#pragma unroll
+                    for (int i = 0; i < HW; ++i) c += (v[i] < th) ? 1 : 0;
+                }
+                c += __shfl_xor(c, 1, 64);
+                if (half == 0 && c != 0) atomicAdd(E.cnt_out + pb + k, c);
+            }
+        }
+        return;
+    }
     float* cbase = E.c + (long long)zslice * E.split_stride;
     const bool vec_main = ((E.ldc & 3) == 0) && ((reinterpret_cast<uintptr_t>(cbase) & 15) == 0);
     const bool vec_c2 = ((E.ldc2 & 3) == 0) && ((reinterpret_cast<uintptr_t>(E.c2) & 15) == 0) && ((E.cols_main & 3) == 0);
     const bool vec_act = (E.act_on == 0) || (((E.ld_act & 3) == 0) && ((reinterpret_cast<uintptr_t>(E.act_src) & 15) == 0));
     constexpr int NCH = GEMM_BM * C4 / GEMM_THREADS;  // chunks per thread (16 / 8)
-    constexpr int UB = NCH;                           // all of a thread's chunks: their extras are fetched together (independent loads in flight)
+    constexpr int UB = 8;                             // chunks whose extras are fetched together (independent loads in flight)
     static_assert(NCH % UB == 0, "chunk batches");
     const int w1max = E.mask_on ? E.mask_ld - 1 : 0;
     for (int cb = 0; cb < NCH; cb += UB) {
@@ -673,6 +743,7 @@ static inline int gemm_launch_layout(const VMat& A, const VMat& B, const Epi& E_
     dim3 grid(nbm * nbn, splits);
     Tail T;
     T.nfull = 0; T.S = 0; T.ksplit = 0; T.ws = (float*)tail_ws;
+    T.row_fast = (nbn > nbm) ? 1 : 0;
     if (splits == 1 && tail_ws != nullptr) {
         const int slots = 2 * device_cu_count();
         const int tiles = nbm * nbn, r = tiles % slots;

@@ -270,4 +270,22 @@ int txe_score_block(const float* Q, long long ld_q, int nq, const float* U, long
     return gemm_nt(A, B, E, nq, G, r, 1, (hipStream_t)stream);
 }
 
+// Fused scoring + ranking of one block of the loop: the score tile never leaves the workgroup.
+//   counts[j] += #{ g < G : match(Q[q], U[g]) strictly better than thr[j] }   for j in [pos_off[q], pos_off[q+1])
+// thr[j] = the score of query q's j-th true parent, computed by THIS library's score kernel (txe_score_block on the gathered
+// rows: identical k-order, hence bit-identical values); counts are int32, zeroed by the caller, accumulated with atomics --
+// exact and order independent.  Candidates may be a shard: counts of shards add.  txe_rank_finalize turns them into ranks.
+int txe_score_count_block(const float* Q, long long ld_q, int nq, const float* U, long long ld_u, int G, int r, int apply_exp,
+                          const int* pos_off, const float* thr, int larger_is_better, int* counts, void* stream) {
+    if (nq < 0 || G < 0 || r < 1 || ld_u < r || !Q || !U || !pos_off || !thr || !counts) return TXE_ERR_ARG;
+    if (nq == 0 || G == 0) return TXE_OK;
+    VMat A = vmat_plain(Q, ld_q, nq, r);
+    VMat B = vmat_plain(U, ld_u, G, r);
+    Epi E = epi_plain(reinterpret_cast<float*>(counts), 0, G);     // c is never written in count mode
+    E.apply_exp = apply_exp;
+    E.cnt_mode = larger_is_better ? 1 : 2;
+    E.cnt_off = pos_off; E.cnt_thr = thr; E.cnt_out = counts;
+    return gemm_nt(A, B, E, nq, G, r, 1, (hipStream_t)stream);
+}
+
 }  // extern "C"

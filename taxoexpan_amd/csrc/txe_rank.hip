@@ -97,6 +97,20 @@ __global__ __launch_bounds__(256) void rank_kernel(const float* __restrict__ S, 
     }
 }
 
+// ranks[j] = 1 + counts[j] - #{ j' of the same query : thr[j'] strictly better than thr[j] }   (positives never count against
+// each other, metric.py:7-31)
+__global__ void rank_finalize_kernel(const int* __restrict__ pos_off, int nq, const float* __restrict__ thr, const int* __restrict__ counts,
+                                     int larger_is_better, int* __restrict__ ranks) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= nq) return;
+    const int pb = pos_off[q], pe = pos_off[q + 1];
+    for (int j = pb; j < pe; ++j) {
+        int c = counts[j];
+        for (int k = pb; k < pe; ++k) c -= larger_is_better ? (thr[k] > thr[j]) : (thr[k] < thr[j]);
+        ranks[j] = c + 1;
+    }
+}
+
 }  // namespace txe
 
 using namespace txe;
@@ -111,6 +125,15 @@ int txe_rank_block(const float* S, long long ld_s, int nq, int G, const int* pos
     if (nq < 0 || G < 0 || !S || !pos_off || !pos_idx || !ranks) return TXE_ERR_ARG;
     if (nq == 0) return TXE_OK;
     hipLaunchKernelGGL(rank_kernel, dim3(nq), dim3(256), 0, (hipStream_t)stream, S, ld_s, G, pos_off, pos_idx, larger_is_better, ranks);
+    TXE_CHECK_LAUNCH();
+    return TXE_OK;
+}
+
+int txe_rank_finalize(const int* pos_off, int nq, const float* thr, const int* counts, int larger_is_better, int* ranks, void* stream) {
+    if (nq < 0 || !pos_off || !thr || !counts || !ranks) return TXE_ERR_ARG;
+    if (nq == 0) return TXE_OK;
+    hipLaunchKernelGGL(rank_finalize_kernel, dim3((nq + 255) / 256), dim3(256), 0, (hipStream_t)stream, pos_off, nq, thr, counts,
+                       larger_is_better, ranks);
     TXE_CHECK_LAUNCH();
     return TXE_OK;
 }

@@ -3,6 +3,8 @@
 torch is plumbing here: it owns device memory (caching allocator), the current HIP stream and autograd's tape;
 every number is produced by the hand-written HIP kernels.  There is no CPU path -- host tensors raise.
 """
+import weakref
+
 import torch
 
 from . import _lib
@@ -609,11 +611,37 @@ def bilinear_project(hg, W):
     Wf = _f32(W).reshape(W.shape[-2], W.shape[-1])
     G, l = hg.shape
     r = Wf.shape[1]
-    rp = (r + 3) // 4 * 4                               # rows padded to 16 bytes: the scoring GEMM then loads U with dwordx4
-    U = _empty((G, rp), hg)[:, :r]
+    # rows zero-padded to a whole number of 32-column k-tiles: the scoring GEMM then runs every k-tile on the plain 16-byte
+    # loader (r = 250 would leave a ragged last tile on the generic one); zeros add exactly nothing to the products
+    rp = (r + 31) // 32 * 32
+    Ufull = torch.zeros((max(G, 1), rp), dtype=torch.float32, device=hg.device) if rp != r else _empty((max(G, 1), rp), hg)
+    U = Ufull[:G, :r]
     with torch.cuda.device(hg.device):
         call("txe_bilinear_project", ptr(hg), ld, G, l, ptr(Wf), r, ptr(U), rp, _lib.stream_ptr())
+    _ZERO_PADDED[U.data_ptr()] = (rp, weakref.ref(Ufull))
     return U
+
+
+_ZERO_PADDED = {}      # data_ptr of a U made by bilinear_project -> (zero-padded row width, weak reference to its storage)
+
+
+def _padded_width(U, r):
+    """row width up to which U's columns beyond r are known zeros (bilinear_project output), else r"""
+    ent = _ZERO_PADDED.get(U.data_ptr())
+    if ent is None:
+        return r
+    rp, ref = ent
+    if ref() is None:                                   # the buffer died; the address may have been reused
+        del _ZERO_PADDED[U.data_ptr()]
+        return r
+    return rp if (U.stride(0) == rp and U.shape[1] == r) else r
+
+
+def _pad_queries(Q, r, rp):
+    """queries on the same zero-padded pitch as U"""
+    Qp = torch.zeros((Q.shape[0], rp), dtype=torch.float32, device=Q.device)
+    Qp[:, :r].copy_(Q)
+    return Qp
 
 
 def score_block(Q, U, apply_exp, out=None):
@@ -622,7 +650,11 @@ def score_block(Q, U, apply_exp, out=None):
     Q, ldq = _rows(Q)
     U, ldu = _rows(U)
     nq, r = Q.shape
-    if ldq % 4 != 0 and nq > 0:                         # query rows re-laid out on a 16-byte pitch (a few hundred KB per block)
+    rp = _padded_width(U, r)
+    if rp != r and nq > 0:                              # both operands zero-padded to whole k-tiles: K = rp
+        Q = _pad_queries(Q, r, rp)
+        ldq, r = rp, rp
+    elif ldq % 4 != 0 and nq > 0:                       # query rows re-laid out on a 16-byte pitch (a few hundred KB per block)
         Qp = _empty((nq, (r + 3) // 4 * 4), Q)[:, :r]
         Qp.copy_(Q)
         Q, ldq = Qp, Qp.stride(0)
@@ -631,6 +663,63 @@ def score_block(Q, U, apply_exp, out=None):
     with torch.cuda.device(Q.device):
         call("txe_score_block", ptr(Q), ldq, nq, ptr(U), ldu, G, r, int(apply_exp), ptr(S), S.stride(0), _lib.stream_ptr())
     return S
+
+
+def positive_scores(Q, U, apply_exp, pos_off, pos_idx):
+    """thr[j] = match(hg[pos_idx[j]], Q[q(j)]) for each query's true parents, through the SAME score kernel as the full block
+    (bit-identical values: the fused ranking compares against them).  pos_idx rows of U that are out of range (< 0: a positive that
+    lives in another candidate shard) give 0."""
+    _need_cuda(Q, U)
+    dev = Q.device
+    pos_off = _i32(pos_off, dev)
+    pos_idx = _i32(pos_idx, dev)
+    n_pos = int(pos_idx.numel())
+    if n_pos == 0:
+        return torch.zeros(0, dtype=torch.float32, device=dev)
+    counts = (pos_off[1:] - pos_off[:-1]).long()
+    qid = torch.repeat_interleave(torch.arange(Q.shape[0], device=dev), counts)
+    local = pos_idx >= 0
+    Ug = U[pos_idx.clamp(min=0).long()]
+    Sp = score_block(Q, Ug, apply_exp)
+    thr = Sp[qid, torch.arange(n_pos, device=dev)]
+    return torch.where(local, thr, torch.zeros_like(thr)).contiguous()
+
+
+def score_count_block(Q, U, apply_exp, pos_off, thr, larger_is_better=True, counts=None):
+    """fused scoring + ranking of one query block against a candidate (shard) matrix U: int32 counts [n_pos] of candidates that beat
+    each positive's score thr[j] (txe_score_count_block; no [nq x G] score block is materialised)."""
+    _need_cuda(Q, U)
+    Q, ldq = _rows(Q)
+    U, ldu = _rows(U)
+    nq, r = Q.shape
+    rp = _padded_width(U, r)
+    if rp != r and nq > 0:
+        Q = _pad_queries(Q, r, rp)
+        ldq, r = rp, rp
+    elif ldq % 4 != 0 and nq > 0:
+        Qp = _empty((nq, (r + 3) // 4 * 4), Q)[:, :r]
+        Qp.copy_(Q)
+        Q, ldq = Qp, Qp.stride(0)
+    pos_off = _i32(pos_off, Q.device)
+    thr = _f32(thr)
+    if counts is None:
+        counts = torch.zeros(max(int(thr.numel()), 1), dtype=torch.int32, device=Q.device)
+    with torch.cuda.device(Q.device):
+        call("txe_score_count_block", ptr(Q), ldq, nq, ptr(U), ldu, U.shape[0], r, int(apply_exp), ptr(pos_off), ptr(thr),
+             int(larger_is_better), ptr(counts), _lib.stream_ptr())
+    return counts
+
+
+def rank_finalize(pos_off, thr, counts, larger_is_better=True):
+    """ranks (int32) from the fused counts: positives never count against each other (metric.py:7-31)"""
+    _need_cuda(thr)
+    pos_off = _i32(pos_off, thr.device)
+    n_pos = int(thr.numel())
+    ranks = torch.empty(max(n_pos, 1), dtype=torch.int32, device=thr.device)
+    with torch.cuda.device(thr.device):
+        call("txe_rank_finalize", ptr(pos_off), int(pos_off.numel()) - 1, ptr(_f32(thr)), ptr(counts), int(larger_is_better), ptr(ranks),
+             _lib.stream_ptr())
+    return ranks[:n_pos]
 
 
 def rank_block(S, pos_off, pos_idx, larger_is_better=True):

@@ -91,6 +91,64 @@ def score_all_sharded(match, hg_local, n_total, queries, block=1024, group=None,
     return None if on_block is not None else torch.cat(collected, 0)
 
 
+def rank_all_fused(match, hg, queries, pos_off, pos_idx, block=1024, larger_is_better=True, group=None, shard_lo=0, local_fns=None):
+    """Ranks of every query's true parents among ALL candidates without materialising the score matrix.
+    hg: this rank's candidate representations (rows [shard_lo, shard_lo + len) of the global candidate list; the whole list when
+    not distributed).  pos_off [Q+1] / pos_idx: GLOBAL candidate columns of each query's true parents.
+    Per query block: thresholds = scores of the positives (each computed by the rank that owns the candidate, summed over ranks),
+    counts = fused score-and-compare over the local shard (summed over ranks), ranks = 1 + counts - own positives that beat it.
+    The only collectives are two all-reduces of [n_positives] vectors per block -- instead of the [queries x candidates] all-gather.
+    local_fns = (positive_scores, score_count) is injectable so that the collective logic is testable without a GPU."""
+    dev = hg.device
+    distributed = dist.is_available() and dist.is_initialized() and (group is not None or dist.get_world_size() > 1)
+    if local_fns is None:
+        U = ops.bilinear_project(hg, match.W.weight) if hg.shape[0] > 0 else None
+        exp = match.apply_exp
+
+        def f_thr(qb, off, idx_local):
+            return ops.positive_scores(qb, U, exp, off, idx_local) if U is not None else torch.zeros(idx_local.numel(), device=dev)
+
+        def f_cnt(qb, off, thr):
+            if U is None:
+                return torch.zeros(max(int(thr.numel()), 1), dtype=torch.int32, device=dev)
+            return ops.score_count_block(qb, U, exp, off, thr, larger_is_better)
+    else:
+        f_thr, f_cnt = local_fns
+    pos_off_h = torch.as_tensor(pos_off).to(torch.int64).cpu()            # block boundaries are host integers
+    pos_off_d = pos_off_h.to(dev)                                          # one upload for the whole loop
+    idx_all = torch.as_tensor(pos_idx).to(torch.int64).to(dev) - shard_lo
+    n_local = hg.shape[0]
+    idx_all = torch.where((idx_all >= 0) & (idx_all < n_local), idx_all, torch.full_like(idx_all, -1)).to(torch.int32)
+    out = []
+    for q0 in range(0, queries.shape[0], block):
+        q1 = min(q0 + block, queries.shape[0])
+        lo, hi = int(pos_off_h[q0]), int(pos_off_h[q1])
+        off = (pos_off_d[q0:q1 + 1] - lo).to(torch.int32)
+        idx_local = idx_all[lo:hi]
+        qb = queries[q0:q1]
+        thr = f_thr(qb, off, idx_local)
+        if distributed:
+            dist.all_reduce(thr, op=dist.ReduceOp.SUM, group=group)          # each positive lives in exactly one shard
+        counts = f_cnt(qb, off, thr)[:hi - lo]
+        if distributed:
+            dist.all_reduce(counts, op=dist.ReduceOp.SUM, group=group)
+        if local_fns is None:
+            out.append(ops.rank_finalize(off, thr, counts, larger_is_better))
+        else:
+            out.append(_rank_finalize_host(off, thr, counts, larger_is_better))
+    return torch.cat(out) if out else torch.zeros(0, dtype=torch.int32, device=dev)
+
+
+def _rank_finalize_host(off, thr, counts, larger_is_better):
+    off, thr, counts = off.cpu().tolist(), thr.cpu(), counts.cpu().to(torch.int64)
+    ranks = torch.empty(len(thr), dtype=torch.int32)
+    for q in range(len(off) - 1):
+        for j in range(off[q], off[q + 1]):
+            t = thr[off[q]:off[q + 1]]
+            ranks[j] = 1 + int(counts[j]) - int(((t > thr[j]) if larger_is_better else (t < thr[j])).sum())
+    return ranks
+
+
 def allreduce_gradients(params, group=None):
     """Data-parallel training: the InfoNCE loss is a SUM over queries (loss.py:57) and queries are sharded over ranks,
     so gradients simply add: one flat bucket (1.76 M fp32 = 7 MB for the MAG config), one RCCL all-reduce."""

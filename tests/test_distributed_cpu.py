@@ -72,3 +72,61 @@ def test_shard_bounds_cover_exactly():
             assert all(spans[i][1] == spans[i + 1][0] for i in range(w - 1))
             c = -(-n // w) if n else 0
             assert all(hi - lo <= c for lo, hi in spans)
+
+
+def _fused_rank_worker(rank, world, port, q):
+    import os
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from taxoexpan_amd import scoring
+    rs = np.random.RandomState(0)
+    G, nq, r = 203, 37, 6
+    U = torch.from_numpy(np.round(rs.randn(G, r) * 2).astype(np.float32))       # integer-valued: exact scores, many ties
+    Qm = torch.from_numpy(np.round(rs.randn(nq, r) * 2).astype(np.float32))
+    npos = rs.randint(1, 4, size=nq)
+    pos_idx = np.concatenate([rs.choice(G, size=k, replace=False) for k in npos]).astype(np.int64)
+    pos_off = np.concatenate([[0], np.cumsum(npos)]).astype(np.int64)
+    lo, hi = scoring.shard_bounds(G, world, rank)
+    Ul = U[lo:hi]
+
+    def f_thr(qb, off, idx_local):
+        cnt = (off[1:] - off[:-1]).long()
+        qid = torch.repeat_interleave(torch.arange(qb.shape[0]), cnt)
+        ok = idx_local >= 0
+        s = (qb[qid] * Ul[idx_local.clamp(min=0).long()]).sum(1)
+        return torch.where(ok, s, torch.zeros_like(s))
+
+    def f_cnt(qb, off, thr):
+        S = qb @ Ul.t()
+        cnt = (off[1:] - off[:-1]).long()
+        qid = torch.repeat_interleave(torch.arange(qb.shape[0]), cnt)
+        return (S[qid] > thr[:, None]).sum(1).to(torch.int32)
+
+    got = scoring.rank_all_fused(None, Ul, Qm, pos_off, pos_idx, block=16, shard_lo=lo, local_fns=(f_thr, f_cnt))
+    S = (Qm @ U.t()).numpy()
+    want = []
+    for i in range(nq):
+        P = pos_idx[pos_off[i]:pos_off[i + 1]]
+        neg = np.ones(G, dtype=bool)
+        neg[P] = False
+        want += [1 + int((S[i][neg] > S[i][p]).sum()) for p in P]
+    q.put((rank, got.tolist() == want))
+    dist.destroy_process_group()
+
+
+def test_fused_rank_counts_all_reduce_world2():
+    """candidate-sharded fused ranking: thresholds and counts all-reduced over 2 gloo ranks == single-process metric ranks"""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29650
+    procs = [ctx.Process(target=_fused_rank_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert all(ok for _, ok in res)

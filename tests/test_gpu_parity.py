@@ -605,3 +605,34 @@ def test_deferred_node_output_behaves_like_the_tensor():
         assert tuple(h.shape) == tuple(t.shape) and h.device == t.device and len(h) == t.shape[0]
         assert torch.equal(h + 1.0, t + 1.0) and torch.equal(2.0 * h, 2.0 * t) and torch.equal(torch.relu(h), torch.relu(t))
         assert torch.equal(h[3], t[3]) and torch.equal(h.cpu(), t.cpu()) and torch.equal(torch.cat((h, h), 0), torch.cat((t, t), 0))
+
+
+@pytest.mark.parametrize("G,r,larger,exp", [(5000, 250, True, True), (1003, 64, False, False), (37, 10, True, False)])
+def test_fused_score_and_rank_equals_materialised_path(G, r, larger, exp):
+    """txe_score_count_block + txe_rank_finalize (no score matrix) == txe_score_block + txe_rank_block, integer-exact, incl. ties"""
+    from taxoexpan_amd import ops, scoring
+    dev = _dev()
+    gen = torch.Generator().manual_seed(G)
+    nq = 300
+    U = (torch.randn(G, r, generator=gen) * (0.05 if exp else 1.0)).to(dev)
+    U[G // 2] = U[G // 3]                                    # exact score ties between two candidates
+    Q = torch.randn(nq, r, generator=gen).to(dev)
+    rs = np.random.RandomState(1)
+    npos = rs.randint(1, 6, size=nq)
+    pos_idx = np.concatenate([rs.choice(G, size=k, replace=False) for k in npos]).astype(np.int64)
+    pos_idx[0] = G // 2
+    pos_off = np.concatenate([[0], np.cumsum(npos)]).astype(np.int64)
+    S = ops.score_block(Q, U, exp)
+    want = ops.rank_block(S, torch.from_numpy(pos_off), torch.from_numpy(pos_idx), larger).cpu().tolist()
+    thr = ops.positive_scores(Q, U, exp, torch.from_numpy(pos_off), torch.from_numpy(pos_idx))
+    assert torch.equal(thr, S[torch.repeat_interleave(torch.arange(nq), torch.from_numpy(npos)).to(dev), torch.from_numpy(pos_idx).to(dev)])
+    counts = ops.score_count_block(Q, U, exp, torch.from_numpy(pos_off), thr, larger)
+    got = ops.rank_finalize(torch.from_numpy(pos_off), thr, counts, larger).cpu().tolist()
+    assert got == want
+
+    class M:                                                  # the loop over query blocks, with a bilinear matcher
+        apply_exp = exp
+        W = type("W", (), {})()
+    M.W.weight = torch.eye(r, device=dev).reshape(1, r, r)   # identity bilinear: U = hg
+    got2 = scoring.rank_all_fused(M, U, Q, pos_off, pos_idx, block=128, larger_is_better=larger).cpu().tolist()
+    assert got2 == want

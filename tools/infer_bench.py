@@ -113,9 +113,20 @@ t0 = time.perf_counter()
 ranks = run_scoring()
 torch.cuda.synchronize()
 t_score = time.perf_counter() - t0
+# fused scoring + ranking: no [queries x candidates] block is ever stored
+from taxoexpan_amd.scoring import rank_all_fused  # noqa: E402
+pos_off_all = np.concatenate([[0], np.cumsum([len(p) for p in pos_lists])])
+pos_idx_all = np.concatenate(pos_lists) if pos_lists else np.zeros(0, dtype=np.int64)
+ranks_f = rank_all_fused(model.match, hg, queries, pos_off_all, pos_idx_all, block=args.qblock)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+ranks_f = rank_all_fused(model.match, hg, queries, pos_off_all, pos_idx_all, block=args.qblock)
+torch.cuda.synchronize()
+t_fused = time.perf_counter() - t0
+assert torch.equal(ranks_f.cpu(), ranks.cpu()), "fused ranks differ from the materialised path"
 pairs = float(len(cand)) * len(test)
 print(json.dumps(dict(shape=args.shape, candidates=int(len(cand)), queries=int(len(test)), nodes=n_nodes, edges=n_edges,
                       encoder_batches=len(graphs), host_taxonomy_s=t_tax, host_egonet_build_and_upload_s=t_build, device_egonet_build_s=t_dbuild,
                       encode_s=t_enc, encode_edges_per_s=n_edges / t_enc, score_and_rank_s=t_score,
-                      candidates_scored_per_s=pairs / t_score, candidates_scored_per_s_incl_encode=pairs / (t_score + t_enc),
+                      candidates_scored_per_s=pairs / t_score, fused_score_and_rank_s=t_fused, candidates_scored_per_s_fused=pairs / t_fused, candidates_scored_per_s_incl_encode=pairs / (t_score + t_enc),
                       mean_rank=float(ranks.float().mean()), hbm_gb=torch.cuda.max_memory_allocated() / 1e9)))

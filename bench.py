@@ -217,6 +217,16 @@ def extra_metrics(model, tax, device, batches, target):
         ranks = ops.rank_block(S, off, idx, True)
         torch.cuda.synchronize()
         t_rk = time.perf_counter() - t0
+        # fused scoring + ranking (no score matrix): must give the same ranks
+        from taxoexpan_amd.scoring import rank_all_fused
+        rank_all_fused(model.match, hg, queries, off, idx)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ranks_f = rank_all_fused(model.match, hg, queries, off, idx)
+        torch.cuda.synchronize()
+        t_fused = time.perf_counter() - t0
+        out["fused_rank_equals_materialised"] = bool(torch.equal(ranks_f.cpu(), ranks.cpu()))
+        out["infer_fused_score_rank_s"] = t_fused
         out.update(infer_candidates=int(len(cand)), infer_queries=int(len(test)), infer_encode_s=t_enc,
                    infer_encode_edges_per_s=g.number_of_edges() / t_enc, infer_score_s=t_sc,
                    candidates_scored_per_s=len(cand) * len(test) / t_sc,

@@ -411,6 +411,17 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_kernel(VMat A, VMat B, c
     const int tm = T.row_fast ? lb % nbm : lb / nbn, tn = T.row_fast ? lb / nbm : lb % nbn;
     const int m0 = tm * GEMM_BM, n0 = tn * BN;
 
+    // count mode: this tile's rows' positive ranges and first thresholds are fetched NOW (two dependent loads), so that their
+    // latency hides under the whole k-loop instead of sitting in the epilogue
+    int cnt_pb = 0, cnt_np = 0;
+    float cnt_th[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (E.cnt_mode != 0 && threadIdx.x < GEMM_BM && m0 + (int)threadIdx.x < M) {
+        cnt_pb = E.cnt_off[m0 + threadIdx.x];
+        cnt_np = E.cnt_off[m0 + threadIdx.x + 1] - cnt_pb;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) cnt_th[k] = E.cnt_thr[(k < cnt_np) ? cnt_pb + k : 0];
+    }
+
     // clip the reduction range into the operands' own bounds (split-K and K tails read zeros)
     if (AK) { A.cols = min(A.cols, kend); A.cols_main = min(A.cols_main, kend); }
     else    { A.rows = min(A.rows, kend); }
@@ -542,12 +553,10 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_kernel(VMat A, VMat B, c
         int* s_np = s_pb + GEMM_BM;
         if constexpr (PS > 0) {
             if (threadIdx.x < GEMM_BM) {
-                const int m = m0 + threadIdx.x;
-                const int pb = (m < M) ? E.cnt_off[m] : 0;
-                const int np = (m < M) ? E.cnt_off[m + 1] - pb : 0;
-                s_pb[threadIdx.x] = pb;
-                s_np[threadIdx.x] = np;
-                for (int k = 0; k < np && k < PS; ++k) s_thr[threadIdx.x * PS + k] = E.cnt_thr[pb + k];
+                s_pb[threadIdx.x] = cnt_pb;
+                s_np[threadIdx.x] = cnt_np;
+#pragma unroll
+                for (int k = 0; k < PS; ++k) s_thr[threadIdx.x * PS + k] = cnt_th[k];
             }
             __syncthreads();
         }

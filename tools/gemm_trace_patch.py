@@ -9,13 +9,13 @@ def rep(a, b):
     global s
     assert a in s, a[:60]
     s = s.replace(a, b)
-rep('''    float* ws;       // [r*S][GEMM_BM*BN] raw partial tiles
-};''', '''    float* ws;       // [r*S][GEMM_BM*BN] raw partial tiles
+rep('''    int row_fast;    // 1: consecutive workgroups walk DOWN a column of tiles (few row panels, many column tiles: the scoring GEMM)
+};''', '''    int row_fast;    // 1: consecutive workgroups walk DOWN a column of tiles (few row panels, many column tiles: the scoring GEMM)
     long long* trace;
 };''')
 rep('''    const int nbn = (N + BN - 1) / BN;
     // XCD-contiguous order over (k-slice, tile)''', '''    long long tr[40]; int trn = 0;
-    const bool tracing = T.trace != nullptr && (blockIdx.x % 37 == 5) && blockIdx.y == 0;
+    const bool tracing = T.trace != nullptr && (blockIdx.x % 37 == 5) && blockIdx.y == 0 && blockIdx.x / 37 < 60;
     tr[trn++] = __builtin_readcyclecounter();
     const int nbn = (N + BN - 1) / BN;
     // XCD-contiguous order over (k-slice, tile)''')

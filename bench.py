@@ -272,10 +272,26 @@ def extra_metrics_sharded(model, device, world, rank, n_queries=8192, qblock=102
             run()
             torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
             timings[name] = time.perf_counter() - t0
-        t = torch.tensor([t_enc, timings["local"], timings["allgather"]], dtype=torch.float64, device=device)
+        # fused ranking: thresholds and counts all-reduced ([n_positives] vectors) instead of gathering the score blocks
+        from taxoexpan_amd.scoring import rank_all_fused
+        cand_index = np.full(tax.n_nodes, -1, dtype=np.int64)
+        cand_index[cand] = np.arange(len(cand))
+        pos_lists = [cand_index[tax.par_idx[tax.par_ptr[qn]:tax.par_ptr[qn + 1]]] for qn in test]
+        pos_lists = [p[p >= 0] for p in pos_lists]
+        pos_off = np.concatenate([[0], np.cumsum([len(p) for p in pos_lists])])
+        pos_idx = np.concatenate(pos_lists) if pos_lists else np.zeros(0, dtype=np.int64)
+        rank_all_fused(model.match, hg, queries, pos_off, pos_idx, block=qblock, shard_lo=lo)
+        torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ranks = rank_all_fused(model.match, hg, queries, pos_off, pos_idx, block=qblock, shard_lo=lo)
+        torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+        t_fr = time.perf_counter() - t0
+        t = torch.tensor([t_enc, timings["local"], timings["allgather"], t_fr], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        t_enc, t_loc, t_ag = (float(x) for x in t.tolist())
+        t_enc, t_loc, t_ag, t_fr = (float(x) for x in t.tolist())
         pairs = float(len(cand)) * len(test)
+        out.update(infer_fused_rank_allreduce_s=t_fr, candidates_scored_per_s_fused_allreduce=pairs / t_fr,
+                   mean_rank=float(ranks.float().mean().item()) if ranks.numel() else None)
         out.update(shape="mag_full", infer_candidates=int(len(cand)), infer_queries=int(len(test)), candidates_per_rank=int(hi - lo),
                    infer_encode_s=t_enc, infer_score_local_s=t_loc, infer_score_allgather_s=t_ag,
                    candidates_scored_per_s_local=pairs / t_loc, candidates_scored_per_s_allgather=pairs / t_ag,

@@ -154,9 +154,14 @@ class DeferredNodeOutput:
         self._fn = fn
         self._tensor = None
 
+    def _out_dim(self):
+        return self._args[1].out_dims[-1]
+
     def readout(self, rpos, pw):
         import copy
         csr, cfg, h, pos, params = self._args
+        if csr.n_nodes == 0 or csr.n_graphs == 0:       # empty batch: nothing to launch
+            return h.new_zeros((csr.n_graphs, self._out_dim()), dtype=torch.float32)
         c = copy.copy(cfg)
         c.final = "collapse"
         return self._fn.apply(csr, c, h, pos, rpos, pw, *params)
@@ -164,7 +169,10 @@ class DeferredNodeOutput:
     def tensor(self):
         if self._tensor is None:
             csr, cfg, h, pos, params = self._args
-            self._tensor = self._fn.apply(csr, cfg, h, pos, None, None, *params)
+            if csr.n_nodes == 0:
+                self._tensor = h.new_zeros((0, self._out_dim()), dtype=torch.float32)
+            else:
+                self._tensor = self._fn.apply(csr, cfg, h, pos, None, None, *params)
         return self._tensor
 
     def __getattr__(self, name):                    # .shape, .device, .detach(), .cpu(), ... of the node features
@@ -398,6 +406,8 @@ class MLP(nn.Module):
 
     def forward(self, e1, e2):
         """model_zoo.py:291-298: ffn(cat(e1, e2)); the concat is synthesised by the GEMM's operand loader"""
+        if e1.shape[0] == 0:
+            return e1.new_zeros((0, 1), dtype=torch.float32)
         hid = ops.LinearFunction.apply(e1, e2, self.ffn[0].weight, self.ffn[0].bias, 1)
         return ops.LinearFunction.apply(hid, None, self.ffn[2].weight, self.ffn[2].bias, 0)
 
@@ -411,6 +421,8 @@ class _Bilinear(nn.Module):
 
     def forward(self, e1, e2):
         """e1 (*, l_dim), e2 (*, r_dim) -> (*, 1)"""
+        if e1.shape[0] == 0:                               # empty batch
+            return e1.new_zeros((0, 1), dtype=torch.float32)
         if e2.dim() == 2 and e2.stride(0) == 0 and e2.shape[0] == e1.shape[0] and not torch.is_grad_enabled():
             # the eval loop's `nf.expand(n_position, -1)` (test_fast.py:122-123): one query against all candidates
             U = ops.bilinear_project(e1, self.W.weight)

@@ -636,3 +636,36 @@ def test_fused_score_and_rank_equals_materialised_path(G, r, larger, exp):
     M.W.weight = torch.eye(r, device=dev).reshape(1, r, r)   # identity bilinear: U = hg
     got2 = scoring.rank_all_fused(M, U, Q, pos_off, pos_idx, block=128, larger_is_better=larger).cpu().tolist()
     assert got2 == want
+
+
+@pytest.mark.parametrize("prop", ["PGAT", "PGCN"])
+def test_empty_and_single_node_batches(prop):
+    """edge cases of the batched input: no egonet at all, and egonets that are a lone anchor (k = m = 0: one self loop)"""
+    from taxoexpan_amd import TaxoExpan
+    from taxoexpan_amd.graph import BatchedDGLGraph
+    dev = _dev()
+    torch.manual_seed(3)
+    model = TaxoExpan(prop, "WMR", "LBM", in_dim=6, hidden_dim=8, out_dim=5, pos_dim=3, num_layers=1, heads=[2, 1], feat_drop=0.0,
+                      attn_drop=0.0, hidden_drop=0.0, out_drop=0.0).to(dev)
+    # empty batch: shapes flow through, gradients are zeros
+    g0 = BatchedDGLGraph.from_egonet_shapes([], [])
+    s0 = model(g0, torch.zeros(0, 6, device=dev), torch.zeros(0, 6, device=dev))
+    assert tuple(s0.shape) == (0, 1)
+    if s0.requires_grad:
+        s0.sum().backward()
+    assert all(p.grad is None or torch.all(p.grad == 0) for p in model.parameters())
+    # lone anchors: softmax over one edge is 1, the readout of one node is the node
+    model.zero_grad()
+    g1 = BatchedDGLGraph.from_egonet_shapes([0, 0, 0], [0, 0, 0])
+    x = torch.randn(3, 6, device=dev)
+    q = torch.randn(3, 6, device=dev)
+    s1 = model(g1, x, q)
+    assert tuple(s1.shape) == (3, 1) and torch.isfinite(s1).all()
+    s1.sum().backward()
+    P = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in model.state_dict().items()}
+    graph = orc.batch_egonets([(0, 0)] * 3)
+    ref, _, _ = orc.taxoexpan_forward(P, graph, x.cpu(), q.cpu(), prop, "WMR", "LBM", [2, 1], 1, None)
+    ref.sum().backward()
+    np.testing.assert_allclose(s1.detach().cpu().numpy(), ref.detach().numpy(), rtol=RT, atol=AT)
+    for k, p in model.named_parameters():
+        np.testing.assert_allclose(p.grad.cpu().numpy(), P[k].grad.numpy(), rtol=2e-3, atol=2e-5, err_msg=k)

@@ -409,6 +409,8 @@ def main():
                                              "heads [4,4,1], ",
                                     "pgcn": "MAG-CS synthetic taxonomy (29,654 nodes, d=250), PGCN+MR+BIM fp32 dims 250/50/500/500, "}[args.workload] +
                                    "128 queries x 32 = 4096 egonets per GPU per step, fwd + InfoNCE + bwd + Adam(amsgrad), dropout 0.1",
+                       "output_layer": ("unfolded (TXE_NO_FOLD=1)" if os.environ.get("TXE_NO_FOLD", "0") == "1" else
+                                        "folded behind the weighted-mean readout (exact re-association, DESIGN 4.1): G graph rows instead of N node rows"),
                        "egonets_per_step_per_gpu": N_QUERIES * (1 + NEG), "avg_edges_per_step_per_gpu": edges / args.steps / world,
                        "parallelism": f"dp{world}"},
             "roofline": {"bound": dom["bound"], "achieved": dom["achieved"], "peak": dom["peak"], "unit": dom["unit"],

@@ -17,6 +17,7 @@ Side effects the callers rely on are kept: PGAT/PGCN pop g.ndata['pos'] (model_z
 writes g.ndata['a'] (:241).
 """
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -137,10 +138,14 @@ def _gat_stack(layers, embeddings, g, h, pos, activation, training):
     params = []
     for i, l in enumerate(layers):
         params += [l.fc.weight, l.attn_l, l.attn_r, None if embeddings is None else embeddings[i].weight]
-    if layers[-1].num_heads == 1:
+    if layers[-1].num_heads == 1 and not _NO_FOLD:
         # one-head output layer: a weighted-mean readout can fold it (ops 'collapse'); anything else materialises N x D
         return DeferredNodeOutput(g.csr(h.device), cfg, h, pos, params, ops.GATStackFunction)
     return ops.GATStackFunction.apply(g.csr(h.device), cfg, h, pos, None, None, *params)
+
+
+# TXE_NO_FOLD=1 switches the folded output layer off (A/B measurements, debugging): graph_propagate then returns the N x out tensor
+_NO_FOLD = bool(int(os.environ.get("TXE_NO_FOLD", "0")))
 
 
 class DeferredNodeOutput:
@@ -259,7 +264,7 @@ def _gcn_stack(layers, embeddings, g, h, pos, training):
     params = []
     for i, l in enumerate(layers):
         params += [l.weight, l.bias, None if embeddings is None else embeddings[i].weight]
-    if slopes[-1] is None:
+    if slopes[-1] is None and not _NO_FOLD:
         # activation-free output layer: a weighted-mean readout can fold it (ops 'collapse'); anything else materialises N x out
         return DeferredNodeOutput(g.csr(h.device), cfg, h, pos, params, ops.GCNStackFunction)
     return ops.GCNStackFunction.apply(g.csr(h.device), cfg, h, pos, None, None, *params)

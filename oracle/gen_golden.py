@@ -221,12 +221,32 @@ def run_extras():
     print("extras:", len(save), "arrays")
 
 
+def run_metrics():
+    """model/metric.py:62-96 (numpy only) on a fixed heavy-tailed rank set -> tests/golden/metrics.json"""
+    import json
+    rs = np.random.RandomState(9)
+    npos = rs.randint(1, 5, size=200)
+    ranks = np.concatenate([np.floor(np.abs(rs.standard_cauchy(k)) * 7).astype(np.int64) + 1 for k in npos])
+    off = np.concatenate([[0], np.cumsum(npos)])
+    all_ranks = [ranks[off[i]:off[i + 1]].tolist() for i in range(len(npos))]
+    out = dict(ranks=ranks.tolist(), pos_off=off.tolist())
+    for name in ("macro_mr", "micro_mr", "hit_at_1", "hit_at_3", "hit_at_5", "mrr_scaled_10", "combined_metrics"):
+        out[name] = float(getattr(ref_metric, name)(all_ranks))
+    with open(os.path.join(OUT, "metrics.json"), "w") as f:
+        json.dump(out, f)
+    print("metrics:", {k: v for k, v in out.items() if k not in ("ranks", "pos_off")})
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     if "--extras-only" in sys.argv:
         run_extras()
         sys.exit(0)
+    if "--metrics-only" in sys.argv:
+        run_metrics()
+        sys.exit(0)
     for name, spec in gc.CASES.items():
         run_case(name, spec)
     run_scoring()
     run_extras()
+    run_metrics()

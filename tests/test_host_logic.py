@@ -121,3 +121,18 @@ def test_generic_dgl_message_passing_raises_loudly():
     g.add_nodes(2)
     with pytest.raises(NotImplementedError):
         g.update_all(None, None)
+
+
+def test_metrics_match_reference_metric_py():
+    """taxoexpan_amd.metric on the flat (ranks, pos_off) layout == the reference's model/metric.py on its nested lists
+    (tests/golden/metrics.json: oracle/gen_golden.py --metrics-only, which imports the unmodified metric.py)"""
+    import json
+    import os
+    from golden_util import GOLDEN_DIR
+    from taxoexpan_amd import metric
+    z = json.load(open(os.path.join(GOLDEN_DIR, "metrics.json")))
+    ranks, off = torch.tensor(z["ranks"], dtype=torch.int32), torch.tensor(z["pos_off"])
+    for name in ("macro_mr", "micro_mr", "hit_at_1", "hit_at_3", "hit_at_5", "mrr_scaled_10", "combined_metrics"):
+        assert abs(getattr(metric, name)(ranks, off) - z[name]) <= 1e-12 * max(1.0, abs(z[name])), name
+    lists = metric.as_rank_lists(ranks, off)
+    assert len(lists) == len(z["pos_off"]) - 1 and sum(len(r) for r in lists) == len(z["ranks"])

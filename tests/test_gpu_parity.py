@@ -669,3 +669,50 @@ def test_empty_and_single_node_batches(prop):
     np.testing.assert_allclose(s1.detach().cpu().numpy(), ref.detach().numpy(), rtol=RT, atol=AT)
     for k, p in model.named_parameters():
         np.testing.assert_allclose(p.grad.cpu().numpy(), P[k].grad.numpy(), rtol=2e-3, atol=2e-5, err_msg=k)
+
+
+def test_end_to_end_evaluation_on_raw_files_against_oracle():
+    """raw .terms/.taxo/.embed -> MaskedGraphDataset(test) -> device egonets -> encode -> fused ranking -> test_fast.py metrics,
+    against the same flow done literally on the host with the oracle (test_fast.py:93-133 + metric.py)"""
+    import os
+    import shutil
+    import tempfile
+    from taxoexpan_amd import TaxoExpan
+    from taxoexpan_amd.dataset import MAGDataset, MaskedGraphDataset
+    from taxoexpan_amd.evaluate import evaluate
+    d = tempfile.mkdtemp(dir=os.environ.get("TMPDIR", None))
+    try:
+        for fn in os.listdir(os.path.join(GOLDEN_DIR, "toy_taxo")):
+            shutil.copy(os.path.join(GOLDEN_DIR, "toy_taxo", fn), d)
+        ds = MaskedGraphDataset(MAGDataset("toy", d, raw=True), mode="test", sampling_mode=0, expand_factor=100, normalize_embed=True)
+    finally:
+        shutil.rmtree(d)
+    torch.manual_seed(11)
+    heads = [2, 1]
+    model = TaxoExpan("PGAT", "WMR", "LBM", in_dim=8, hidden_dim=6, out_dim=5, pos_dim=3, num_layers=1, heads=heads, feat_drop=0.1,
+                      attn_drop=0.1, hidden_drop=0.1, out_drop=0.1).to(_dev())
+    metrics, ranks, pos_off, queries = evaluate(model, ds, _dev())
+    # host: the reference's loop with the oracle model
+    P = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    cand = sorted(ds.all_positions)
+    shapes, ids = [], []
+    for a in cand:
+        nodes, k = ds._build_egonet(-1, a, 0)
+        shapes.append((k, len(nodes) - k - 1))
+        ids += nodes
+    graph = orc.batch_egonets(shapes)
+    x = ds.node_features[torch.tensor(ids)]
+    hn = orc.pgat_forward(P, graph, x, heads, 1, prefix="graph_propagate.")
+    hg = orc.weighted_mean_readout(graph["graph_off"], hn, graph["pos"], P["readout.position_weights.weight"])
+    index = {a: i for i, a in enumerate(cand)}
+    want_ranks, per_q = [], []
+    for q in queries:
+        s = orc.bilinear_match(hg, ds.node_features[q].expand(len(cand), -1), P["match.W.weight"], True).squeeze(1).numpy()
+        pos = [index[a] for a in ds.node2parents[q] if a in index]
+        r = orc.ranks_of_positives(s, pos, True)
+        want_ranks += r
+        per_q.append(r)
+    assert ranks.cpu().tolist() == want_ranks
+    np.testing.assert_allclose(metrics["macro_mr"], np.mean([np.mean(r) for r in per_q]), rtol=1e-12)
+    np.testing.assert_allclose(metrics["hit_at_3"], np.mean([np.mean(np.asarray(r) <= 3) for r in per_q]), rtol=1e-12)
+    np.testing.assert_allclose(metrics["mrr_scaled_10"], np.mean([np.mean(1.0 / np.ceil(np.asarray(r) / 10)) for r in per_q]), rtol=1e-12)

@@ -384,6 +384,31 @@ class MaskedGraphDataset(torch.utils.data.Dataset):
         i64 = lambda a: np.asarray(a, dtype=np.int64)
         return dict(query=i64(query), label=i64(label), k=i64(k), m=i64(m), ids=i64(ids))
 
+    def sample_anchors(self, indices):
+        """instances `indices` as (query [B], anchor [B], label [B], exclude [B]) int64 arrays for graph.device_egonet_batch:
+        the positive / negative anchors of `sample()` without building host egonets (siblings beyond expand_factor are then drawn
+        on device).  exclude = the query for positive pairs (it must not appear among its parent's children, dataset.py:421-424)."""
+        query, anchor, label = [], [], []
+        for idx in indices:
+            q = self.node_list[idx]
+            if self.sampling_mode == 0:
+                pos = list(self.node2parents[q])
+            else:
+                ptr = self.node2positive_pointer[q]
+                pos = [self.node2parents[q][ptr]]
+                self.node2positive_pointer[q] = (ptr + 1) % len(self.node2parents[q])
+            if self.mode in ("train", "validation"):
+                neg = self._get_negative_anchors(q, self.negative_size)
+            else:
+                neg = [a for a in self.all_positions if a not in self.node2masks[q]]
+            for a in pos:
+                query.append(q); anchor.append(a); label.append(1)
+            for a in neg:
+                query.append(q); anchor.append(a); label.append(0)
+        i64 = lambda a: np.asarray(a, dtype=np.int64)
+        query, anchor, label = i64(query), i64(anchor), i64(label)
+        return query, anchor, label, np.where(label == 1, query, -1)
+
     def device_taxonomy(self, device):
         """the masked taxonomy (held-out in-edges removed) + features as device CSR arrays for graph.device_egonet_batch:
         all-candidate inference builds `_get_subgraph(-1, anchor, 0)` for every anchor (test_fast.py:93-97, infer.py:80-82)"""

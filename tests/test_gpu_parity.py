@@ -716,3 +716,57 @@ def test_end_to_end_evaluation_on_raw_files_against_oracle():
     np.testing.assert_allclose(metrics["macro_mr"], np.mean([np.mean(r) for r in per_q]), rtol=1e-12)
     np.testing.assert_allclose(metrics["hit_at_3"], np.mean([np.mean(np.asarray(r) <= 3) for r in per_q]), rtol=1e-12)
     np.testing.assert_allclose(metrics["mrr_scaled_10"], np.mean([np.mean(1.0 / np.ceil(np.asarray(r) / 10)) for r in per_q]), rtol=1e-12)
+
+
+def test_training_on_raw_files_with_device_batches_converges():
+    """a short training run on the toy raw dataset, batches built on device (sample_anchors -> device_egonet_batch with the
+    positive's query excluded), InfoNCE like trainer.py:52-56: the loss goes down (the toy embeddings are random, so only the
+    training loss can be expected to move) and evaluation still runs on the trained model"""
+    import os
+    import random
+    import shutil
+    import tempfile
+    import torch.nn.functional as F
+    from taxoexpan_amd import TaxoExpan
+    from taxoexpan_amd import graph as G
+    from taxoexpan_amd.dataset import MAGDataset, MaskedGraphDataset
+    from taxoexpan_amd.evaluate import evaluate
+    dev = _dev()
+    d = tempfile.mkdtemp(dir=os.environ.get("TMPDIR", None))
+    try:
+        for fn in os.listdir(os.path.join(GOLDEN_DIR, "toy_taxo")):
+            shutil.copy(os.path.join(GOLDEN_DIR, "toy_taxo", fn), d)
+        raw = MAGDataset("toy", d, raw=True)
+        train = MaskedGraphDataset(raw, mode="train", sampling_mode=1, negative_size=7, expand_factor=20, normalize_embed=True)
+        test = MaskedGraphDataset(raw, mode="test", sampling_mode=0, expand_factor=20, normalize_embed=True)
+    finally:
+        shutil.rmtree(d)
+    random.seed(0)
+    torch.manual_seed(0)
+    model = TaxoExpan("PGAT", "WMR", "LBM", in_dim=8, hidden_dim=16, out_dim=16, pos_dim=4, num_layers=1, heads=[2, 1], feat_drop=0.1,
+                      attn_drop=0.1, hidden_drop=0.1, out_drop=0.1).to(dev)
+    before, *_ = evaluate(model, test, dev)
+    dtax = train.device_taxonomy(dev)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-2)
+    feats = train.node_features.to(dev)
+    losses = []
+    order = list(range(len(train)))
+    for step in range(150):
+        idx = [order[(step * 16 + i) % len(order)] for i in range(16)]
+        query, anchor, label, exclude = train.sample_anchors(idx)
+        assert label.reshape(16, 8)[:, 0].tolist() == [1] * 16
+        g = G.device_egonet_batch(dtax, anchor, exclude=exclude, expand_factor=train.expand_factor, seed=step)
+        ids = g.ndata["_id"].cpu().numpy()
+        off = g.csr(dev).graph_off.cpu().numpy()
+        for i in range(0, len(anchor), 8):                       # the positive egonet never contains its own query
+            assert query[i] not in ids[off[i]:off[i + 1]]
+        model.train()
+        opt.zero_grad()
+        pred = model(g, g.ndata.pop("x"), feats[torch.from_numpy(query).to(dev)])
+        loss = F.cross_entropy(pred.reshape(16, 8), torch.zeros(16, dtype=torch.long, device=dev), reduction="sum")
+        loss.backward()
+        opt.step()
+        losses.append(float(loss))
+    after, *_ = evaluate(model, test, dev)
+    assert np.median(losses[-20:]) < 0.92 * np.median(losses[:20])
+    assert np.isfinite(after["macro_mr"]) and after["n_queries"] == before["n_queries"] > 0

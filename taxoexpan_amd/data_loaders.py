@@ -3,28 +3,33 @@ outputs) and MaskedGraphDataLoader (same constructor arguments).  `data_path` is
 `<name>.terms/.taxo/.terms.embed` or the `<name>.txe.npz` cache written by taxoexpan_amd.dataset.MAGDataset; the
 reference's DGL pickles cannot be read without DGL (dataset.py says so when handed one)."""
 import os
-from itertools import chain
+import itertools
 
 import torch
-from torch.utils.data import DataLoader
+import torch.utils.data
 
-from .dataset import MAGDataset, MaskedGraphDataset
+from . import dataset as _ds
 from .graph import batch
 
-BATCH_GRAPH_NODE_LIMIT = 100000
+BATCH_GRAPH_NODE_LIMIT = 100000      # data_loaders.py:7: nodes per batched graph in large-batch mode
+
+
+def _flatten(samples):
+    """instances (tuples of [egonet, query feature, label] triplets) -> three parallel lists"""
+    triplets = list(itertools.chain.from_iterable(samples))
+    return [t[0] for t in triplets], [t[1] for t in triplets], [t[2] for t in triplets]
 
 
 def collate_graph_and_node_small_batch(samples):
-    """data_loaders.py:9-28: list of instances (each a tuple of [egonet, query feature, label]) -> (batched graph,
-    [B, d] query features, [B] labels)"""
-    graphs, node_features, labels = map(list, zip(*chain(*samples)))
+    """data_loaders.py:9-28: list of instances -> (batched graph, [B, d] query features, [B] labels)"""
+    graphs, node_features, labels = _flatten(samples)
     return batch(graphs), torch.stack(node_features), torch.tensor(labels)
 
 
 def collate_graph_and_node_large_batch(samples):
     """data_loaders.py:31-72: as above but cut into several batched graphs once a running node count passes
     BATCH_GRAPH_NODE_LIMIT (the egonet that crosses the limit stays in the batch it closes)"""
-    graphs, node_features, labels = map(list, zip(*chain(*samples)))
+    graphs, node_features, labels = _flatten(samples)
     out_g, out_f, out_l = [], [], []
     start, nodes = 0, 0
     for i, g in enumerate(graphs):
@@ -46,24 +51,30 @@ def _open_dataset(data_path):
         names = [f[:-len(".terms")] for f in os.listdir(data_path) if f.endswith(".terms")]
         if len(names) != 1:
             raise ValueError(f"{data_path}: expected exactly one <name>.terms file, found {sorted(names)}")
-        return MAGDataset(name=names[0], path=data_path, raw=True)
-    return MAGDataset(name="", path=data_path, raw=False)
+        return _ds.MAGDataset(name=names[0], path=data_path, raw=True)
+    return _ds.MAGDataset(name="", path=data_path, raw=False)
 
 
-class MaskedGraphDataLoader(DataLoader):
-    """data_loaders.py:75-117"""
+_COLLATE = {"small_batch": collate_graph_and_node_small_batch, "large_batch": collate_graph_and_node_large_batch}
+
+
+class MaskedGraphDataLoader(torch.utils.data.DataLoader):
+    """data_loaders.py:75-117 (same constructor arguments; `data_path` is a raw directory or a .txe.npz cache)"""
 
     def __init__(self, mode, data_path, sampling_mode=1, batch_size=10, batch_type="small_batch", negative_size=20, expand_factor=50,
                  shuffle=True, num_workers=8, cache_refresh_time=64, normalize_embed=False, test_topk=-1):
-        assert batch_type in ["small_batch", "large_batch"], "batch_type arg must be either small_batch or large_batch"
-        assert mode in ["train", "validation", "test"], "mode must be one of train, validation, and test"
+        if batch_type not in _COLLATE:
+            raise AssertionError("batch_type arg must be either small_batch or large_batch")
+        if mode not in ("train", "validation", "test"):
+            raise AssertionError("mode must be one of train, validation, and test")
         self.mode, self.sampling_mode, self.batch_size_, self.batch_type = mode, sampling_mode, batch_size, batch_type
         self.negative_size, self.expand_factor, self.shuffle = negative_size, expand_factor, shuffle
         self.cache_refresh_time, self.normalize_embed = cache_refresh_time, normalize_embed
-        self.dataset_ = MaskedGraphDataset(_open_dataset(data_path), mode=mode, sampling_mode=sampling_mode, negative_size=negative_size,
-                                           expand_factor=expand_factor, cache_refresh_time=cache_refresh_time,
-                                           normalize_embed=normalize_embed, test_topk=test_topk)
-        collate = collate_graph_and_node_small_batch if batch_type == "small_batch" else collate_graph_and_node_large_batch
+        self.dataset_ = _ds.MaskedGraphDataset(_open_dataset(data_path), mode=mode, sampling_mode=sampling_mode,
+                                               negative_size=negative_size, expand_factor=expand_factor,
+                                               cache_refresh_time=cache_refresh_time, normalize_embed=normalize_embed,
+                                               test_topk=test_topk)
+        collate = _COLLATE[batch_type]
         super().__init__(dataset=self.dataset_, batch_size=batch_size, shuffle=shuffle, collate_fn=collate, num_workers=num_workers,
                          pin_memory=torch.cuda.is_available())
         self.n_samples = len(self.dataset_)

@@ -45,26 +45,33 @@ def _p(dropout_module_or_zero, training):
 # ---------------------------------------------------------------------------------------------------------------
 # Graph propagation
 # ---------------------------------------------------------------------------------------------------------------
+def _maybe_dropout(p):
+    """nn.Dropout for a truthy rate, else the falsy placeholder the reference keeps (0. / identity): only its rate is read here"""
+    return nn.Dropout(p) if p else None
+
+
+def _xavier_(*tensors, gain=1.414):
+    for t in tensors:
+        nn.init.xavier_normal_(t, gain=gain)
+
+
 class GCNLayer(nn.Module):
+    """parameters `weight` [in, out], `bias` [out] (model_zoo.py:14-32: both uniform in +-1/sqrt(out))"""
+
     def __init__(self, in_feats, out_feats, activation, dropout, bias=True):
-        super(GCNLayer, self).__init__()
-        self.weight = nn.Parameter(torch.Tensor(in_feats, out_feats))
-        if bias:
-            self.bias = nn.Parameter(torch.Tensor(out_feats))
-        else:
-            self.bias = None
+        super().__init__()
         self.activation = activation
-        if dropout:
-            self.dropout = nn.Dropout(p=dropout)
-        else:
-            self.dropout = 0.
+        self.dropout = _maybe_dropout(dropout) or 0.
+        self.weight = nn.Parameter(torch.empty(in_feats, out_feats))
+        self.bias = nn.Parameter(torch.empty(out_feats)) if bias else None
         self.reset_parameters()
 
     def reset_parameters(self):
-        stdv = 1. / math.sqrt(self.weight.size(1))
-        self.weight.data.uniform_(-stdv, stdv)
-        if self.bias is not None:
-            self.bias.data.uniform_(-stdv, stdv)
+        bound = self.weight.shape[1] ** -0.5
+        with torch.no_grad():
+            for t in (self.weight, self.bias):
+                if t is not None:
+                    t.uniform_(-bound, bound)
 
     def forward(self, g, h):
         """model_zoo.py:34-50 (the norm comes from in-degrees; g.ndata['norm'] is not needed)."""
@@ -77,31 +84,22 @@ class GCNLayer(nn.Module):
 
 
 class GATLayer(nn.Module):
+    """parameters `fc.weight` [H*D, in], `attn_l` / `attn_r` [1, H, D], optional `res_fc.weight` (model_zoo.py:53-78: Xavier normal,
+    gain 1.414)"""
+
     def __init__(self, in_dim, out_dim, num_heads=1, feat_drop=0.5, attn_drop=0.5, leaky_relu_alpha=0.2, residual=False):
-        super(GATLayer, self).__init__()
-        self.num_heads = num_heads
-        self.fc = nn.Linear(in_dim, num_heads * out_dim, bias=False)
-        if feat_drop:
-            self.feat_drop = nn.Dropout(feat_drop)
-        else:
-            self.feat_drop = lambda x: x
-        if attn_drop:
-            self.attn_drop = nn.Dropout(attn_drop)
-        else:
-            self.attn_drop = lambda x: x
-        self.attn_l = nn.Parameter(torch.Tensor(size=(1, num_heads, out_dim)))
-        self.attn_r = nn.Parameter(torch.Tensor(size=(1, num_heads, out_dim)))
-        nn.init.xavier_normal_(self.fc.weight.data, gain=1.414)
-        nn.init.xavier_normal_(self.attn_l.data, gain=1.414)
-        nn.init.xavier_normal_(self.attn_r.data, gain=1.414)
+        super().__init__()
+        width = num_heads * out_dim
+        self.num_heads, self.residual = num_heads, residual
+        self.fc = nn.Linear(in_dim, width, bias=False)
+        self.attn_l, self.attn_r = (nn.Parameter(torch.empty(1, num_heads, out_dim)) for _ in range(2))
+        self.feat_drop, self.attn_drop = (_maybe_dropout(p) or (lambda x: x) for p in (feat_drop, attn_drop))
         self.leaky_relu = nn.LeakyReLU(leaky_relu_alpha)
-        self.residual = residual
-        if residual:
-            if in_dim != out_dim:
-                self.res_fc = nn.Linear(in_dim, num_heads * out_dim, bias=False)
-                nn.init.xavier_normal_(self.res_fc.weight.data, gain=1.414)
-            else:
-                self.res_fc = None
+        _xavier_(self.fc.weight.data, self.attn_l.data, self.attn_r.data)
+        if residual:                                     # res_fc only when the widths differ, else the identity is added
+            self.res_fc = nn.Linear(in_dim, width, bias=False) if in_dim != out_dim else None
+            if self.res_fc is not None:
+                _xavier_(self.res_fc.weight.data)
 
     @property
     def out_dim(self):
@@ -216,14 +214,24 @@ def _node_features(g):
     return h.tensor() if isinstance(h, DeferredNodeOutput) else h
 
 
+def _gcn_layers(in_dim, hidden_dim, out_dim, extra, num_layers, activation, rates):
+    """the num_layers + 1 GCNLayers of GCN / PGCN (model_zoo.py:117-126,140-153): in -> hidden -> ... -> hidden -> out, activation on
+    all but the last, rates = (input, hidden, output) dropout; `extra` = width of the position embedding appended to every input"""
+    widths = [in_dim] + [hidden_dim] * num_layers
+    outs = [hidden_dim] * num_layers + [out_dim]
+    acts = [activation] * num_layers + [None]
+    drops = [rates[0]] + [rates[1]] * (num_layers - 1) + [rates[2]]
+    return nn.ModuleList(GCNLayer(w + extra, o, a, r) for w, o, a, r in zip(widths, outs, acts, drops))
+
+
+def _position_tables(n, vocab, dim):
+    return nn.ModuleList(nn.Embedding(vocab, dim) for _ in range(n))
+
+
 class GCN(nn.Module):
     def __init__(self, in_dim, hidden_dim, out_dim, num_layers, activation, in_dropout=0.1, hidden_dropout=0.1, output_dropout=0.0):
-        super(GCN, self).__init__()
-        self.layers = nn.ModuleList()
-        self.layers.append(GCNLayer(in_dim, hidden_dim, activation, in_dropout))
-        for l in range(num_layers - 1):
-            self.layers.append(GCNLayer(hidden_dim, hidden_dim, activation, hidden_dropout))
-        self.layers.append(GCNLayer(hidden_dim, out_dim, None, output_dropout))
+        super().__init__()
+        self.layers = _gcn_layers(in_dim, hidden_dim, out_dim, 0, num_layers, activation, (in_dropout, hidden_dropout, output_dropout))
 
     def forward(self, g, features):
         """model_zoo.py:128-137"""
@@ -233,16 +241,10 @@ class GCN(nn.Module):
 class PGCN(nn.Module):
     def __init__(self, in_dim, hidden_dim, out_dim, pos_dim, num_layers, activation, in_dropout=0.1, hidden_dropout=0.1,
                  output_dropout=0.0, position_vocab_size=3):
-        super(PGCN, self).__init__()
-        self.layers = nn.ModuleList()
-        self.prop_position_embeddings = nn.ModuleList()
-        self.layers.append(GCNLayer(in_dim + pos_dim, hidden_dim, activation, in_dropout))
-        self.prop_position_embeddings.append(nn.Embedding(position_vocab_size, pos_dim))
-        for l in range(num_layers - 1):
-            self.layers.append(GCNLayer(hidden_dim + pos_dim, hidden_dim, activation, hidden_dropout))
-            self.prop_position_embeddings.append(nn.Embedding(position_vocab_size, pos_dim))
-        self.layers.append(GCNLayer(hidden_dim + pos_dim, out_dim, None, output_dropout))
-        self.prop_position_embeddings.append(nn.Embedding(position_vocab_size, pos_dim))
+        super().__init__()
+        self.layers = _gcn_layers(in_dim, hidden_dim, out_dim, pos_dim, num_layers, activation,
+                                  (in_dropout, hidden_dropout, output_dropout))
+        self.prop_position_embeddings = _position_tables(num_layers + 1, position_vocab_size, pos_dim)
 
     def forward(self, g, features):
         """model_zoo.py:155-167 (pops g.ndata['pos'], :163)"""
@@ -270,17 +272,22 @@ def _gcn_stack(layers, embeddings, g, h, pos, training):
     return ops.GCNStackFunction.apply(g.csr(h.device), cfg, h, pos, None, None, *params)
 
 
+def _gat_layers(in_dim, hidden_dim, out_dim, extra, num_layers, heads, feat_drop, attn_drop, alpha, residual):
+    """the num_layers + 1 GATLayers of GAT / PGAT (model_zoo.py:170-181,193-208): hidden layers concatenate their heads, so layer l
+    reads hidden_dim * heads[l-1] (+ extra) columns; the output layer has heads[-1] heads; the first layer never has a residual"""
+    ins = [in_dim] + [hidden_dim * heads[l - 1] for l in range(1, num_layers)] + [hidden_dim * heads[-2]]
+    outs = [hidden_dim] * num_layers + [out_dim]
+    hs = list(heads[:num_layers]) + [heads[-1]]
+    res = [False] + [residual] * num_layers
+    return nn.ModuleList(GATLayer(i + extra, o, h, feat_drop, attn_drop, alpha, r) for i, o, h, r in zip(ins, outs, hs, res))
+
+
 class GAT(nn.Module):
     def __init__(self, in_dim, hidden_dim, out_dim, num_layers, heads, activation, feat_drop=0.5, attn_drop=0.5,
                  leaky_relu_alpha=0.2, residual=False):
-        super(GAT, self).__init__()
-        self.num_layers = num_layers
-        self.gat_layers = nn.ModuleList()
-        self.activation = activation
-        self.gat_layers.append(GATLayer(in_dim, hidden_dim, heads[0], feat_drop, attn_drop, leaky_relu_alpha, False))
-        for l in range(1, num_layers):
-            self.gat_layers.append(GATLayer(hidden_dim * heads[l - 1], hidden_dim, heads[l], feat_drop, attn_drop, leaky_relu_alpha, residual))
-        self.gat_layers.append(GATLayer(hidden_dim * heads[-2], out_dim, heads[-1], feat_drop, attn_drop, leaky_relu_alpha, residual))
+        super().__init__()
+        self.num_layers, self.activation = num_layers, activation
+        self.gat_layers = _gat_layers(in_dim, hidden_dim, out_dim, 0, num_layers, heads, feat_drop, attn_drop, leaky_relu_alpha, residual)
 
     def forward(self, g, features):
         """model_zoo.py:183-190"""
@@ -297,18 +304,11 @@ class GAT(nn.Module):
 class PGAT(nn.Module):
     def __init__(self, in_dim, hidden_dim, out_dim, pos_dim, num_layers, heads, activation, feat_drop=0.5, attn_drop=0.5,
                  leaky_relu_alpha=0.2, residual=False, position_vocab_size=3):
-        super(PGAT, self).__init__()
-        self.num_layers = num_layers
-        self.gat_layers = nn.ModuleList()
-        self.prop_position_embeddings = nn.ModuleList()
-        self.activation = activation
-        self.gat_layers.append(GATLayer(in_dim + pos_dim, hidden_dim, heads[0], feat_drop, attn_drop, leaky_relu_alpha, False))
-        self.prop_position_embeddings.append(nn.Embedding(position_vocab_size, pos_dim))
-        for l in range(1, num_layers):
-            self.gat_layers.append(GATLayer(hidden_dim * heads[l - 1] + pos_dim, hidden_dim, heads[l], feat_drop, attn_drop, leaky_relu_alpha, residual))
-            self.prop_position_embeddings.append(nn.Embedding(position_vocab_size, pos_dim))
-        self.gat_layers.append(GATLayer(hidden_dim * heads[-2] + pos_dim, out_dim, heads[-1], feat_drop, attn_drop, leaky_relu_alpha, residual))
-        self.prop_position_embeddings.append(nn.Embedding(position_vocab_size, pos_dim))
+        super().__init__()
+        self.num_layers, self.activation = num_layers, activation
+        self.gat_layers = _gat_layers(in_dim, hidden_dim, out_dim, pos_dim, num_layers, heads, feat_drop, attn_drop, leaky_relu_alpha,
+                                      residual)
+        self.prop_position_embeddings = _position_tables(num_layers + 1, position_vocab_size, pos_dim)
 
     def forward(self, g, features):
         """model_zoo.py:210-220 (pops g.ndata['pos'], :212)"""

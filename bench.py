@@ -351,7 +351,8 @@ def main():
     if world > 1:                                   # identical replicas
         for p in model.parameters():
             dist.broadcast(p.data, src=0)
-    opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=0, amsgrad=True, fused=True)   # config.mag.json:66-73
+    from taxoexpan_amd.optim import Adam          # torch.optim.Adam's update (config.mag.json:66-73) as one HIP launch
+    opt = Adam(model.parameters(), lr=1e-3, weight_decay=0, amsgrad=True)
     batches = build_batches(tax, 4, seed0=1000 * (rank + 1), device=device)
     target = torch.zeros(N_QUERIES, dtype=torch.long, device=device)
 

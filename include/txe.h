@@ -213,6 +213,15 @@ int txe_profile_reset(void);
 int txe_profile_count(void);
 int txe_profile_get(int i, char* name_buf, int buf_len, float* ms, double* work, int* kind);
 
+/* trainer.py:61 `self.optimizer.step()` for torch.optim.Adam (config.mag.json:66-73: lr 1e-3, weight_decay 0, amsgrad true): the whole
+ * parameter set in one launch.  params / grads / exp_avg / exp_avg_sq / max_exp_avg_sq are HOST arrays of n_tensors DEVICE pointers
+ * (dense fp32, numel[t] elements); max_exp_avg_sq == NULL selects plain Adam; `step` >= 1 is the count of this update.
+ *   g' = g + weight_decay p;  m = lerp(m, g', 1-beta1);  v = beta2 v + (1-beta2) g'^2;  vmax = max(vmax, v)
+ *   p -= lr / (1-beta1^step) * m / (sqrt(vmax) / sqrt(1-beta2^step) + eps) */
+int txe_adam_step(int n_tensors, float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
+                  float* const* max_exp_avg_sq, const long long* numel, double lr, double beta1, double beta2, double eps,
+                  double weight_decay, long long step, void* stream);
+
 /* host-side evaluation of the counter-based dropout hash the kernels inline (uniform in [0,1)); keep = u >= p */
 float txe_dropout_uniform_host(unsigned long long seed, unsigned long long idx);
 unsigned txe_dropout_mask_word_host(unsigned long long seed, unsigned long long word_index, float p);

@@ -6,7 +6,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libtxe.so")
 
-P, I, L, F, U64, SZ = C.c_void_p, C.c_int, C.c_longlong, C.c_float, C.c_ulonglong, C.c_size_t
+P, I, L, F, D, U64, SZ = C.c_void_p, C.c_int, C.c_longlong, C.c_float, C.c_double, C.c_ulonglong, C.c_size_t
 
 # name -> (restype, argtypes); mirrors include/txe.h one to one (tests/test_cabi.py checks the header against this)
 SIGNATURES = {
@@ -63,6 +63,7 @@ SIGNATURES = {
     "txe_egonet_ws_bytes": (SZ, [I]),
     "txe_egonet_offsets": (I, [P, P, P, P, P, I, I, U64, P, P, SZ, P]),
     "txe_egonet_fill": (I, [P, P, P, P, P, P, I, I, U64, P, P, P, P, P, P, P, P, P, P]),
+    "txe_adam_step": (I, [I, P, P, P, P, P, P, D, D, D, D, D, L, P]),
     "txe_dropout_uniform_host": (F, [U64, U64]),
     "txe_dropout_mask_word_host": (C.c_uint, [U64, U64, F]),
     "txe_profile_enable": (I, [I]),

@@ -51,7 +51,13 @@ __global__ void de2_kernel(const float* __restrict__ dsl, const float* __restric
 __global__ void reduce_splits_kernel2(const float* __restrict__ part, int S, long long stride, long long n, float* __restrict__ out) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
         float acc = 0.f;
-        for (int s = 0; s < S; ++s) acc += part[(long long)s * stride + i];
+        for (int s0 = 0; s0 < S; s0 += 4) {          // slice order kept; four clamped loads in flight
+            float v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = part[(long long)min(s0 + j, S - 1) * stride + i];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc += (s0 + j < S) ? v[j] : 0.f;
+        }
         out[i] = acc;
     }
 }

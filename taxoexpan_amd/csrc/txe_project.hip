@@ -72,11 +72,19 @@ __global__ __launch_bounds__(256) void gat_unfold_kernel(const float* __restrict
     const float al = attn_l[f], ar = attn_r[f];
     float dl = 0.f, dr = 0.f;
     for (int k = threadIdx.x; k < Kt; k += blockDim.x) {
-        float acc = 0.f;
-        for (int s = 0; s < S; ++s) acc += part[(long long)s * split_stride + (long long)f * ldp + k];
+        // the split-K partials are summed in slice order, four (unconditional, clamped) loads in flight at a time
+        const float* pp = part + (long long)f * ldp + k;
         const float gl = dwa[(long long)h * ldp + k], gr = dwa[(long long)(H + h) * ldp + k];
-        dW[(long long)f * ld_dw + k] = acc + al * gl + ar * gr;
         const float wv = W[(long long)f * ldw + k];
+        float acc = 0.f;
+        for (int s0 = 0; s0 < S; s0 += 4) {
+            float v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = pp[(long long)min(s0 + j, S - 1) * split_stride];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc += (s0 + j < S) ? v[j] : 0.f;
+        }
+        dW[(long long)f * ld_dw + k] = acc + al * gl + ar * gr;
         dl = fmaf(gl, wv, dl);
         dr = fmaf(gr, wv, dr);
     }

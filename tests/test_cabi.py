@@ -34,7 +34,7 @@ def test_ctypes_table_mirrors_header():
     decls = _header_decls()
     assert set(decls) == set(_lib.SIGNATURES), set(decls) ^ set(_lib.SIGNATURES)
     cmap = {"int": ctypes.c_int, "long long": ctypes.c_longlong, "float": ctypes.c_float, "size_t": ctypes.c_size_t,
-            "unsigned long long": ctypes.c_ulonglong, "unsigned": ctypes.c_uint}
+            "unsigned long long": ctypes.c_ulonglong, "unsigned": ctypes.c_uint, "double": ctypes.c_double}
     for name, (ret, args) in decls.items():
         res, argtypes = _lib.SIGNATURES[name]
         assert res is cmap[ret], name

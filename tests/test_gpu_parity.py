@@ -770,3 +770,36 @@ def test_training_on_raw_files_with_device_batches_converges():
     after, *_ = evaluate(model, test, dev)
     assert np.median(losses[-20:]) < 0.92 * np.median(losses[:20])
     assert np.isfinite(after["macro_mr"]) and after["n_queries"] == before["n_queries"] > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("amsgrad,wd", [(True, 0.0), (False, 0.0), (True, 0.01)])
+def test_adam_step_equals_torch_adam(amsgrad, wd):
+    """txe_adam_step against torch.optim.Adam (the optimizer of config.mag.json:66-73) over several steps: odd sizes, a parameter
+    without gradient in some steps (its step count lags), state_dict round trip into the torch class"""
+    from taxoexpan_amd.optim import Adam
+    dev = torch.device("cuda:0")
+    torch.manual_seed(5)
+    shapes = [(3, 1), (3, 50), (1, 4, 500), (2000, 300), (1001,), (1, 500, 250), (7, 9, 11)]
+    mine = [torch.randn(s, device=dev).requires_grad_(True) for s in shapes]
+    ref = [p.detach().clone().requires_grad_(True) for p in mine]
+    o1 = Adam(mine, lr=1e-2, betas=(0.9, 0.999), eps=1e-8, weight_decay=wd, amsgrad=amsgrad)
+    o2 = torch.optim.Adam(ref, lr=1e-2, betas=(0.9, 0.999), eps=1e-8, weight_decay=wd, amsgrad=amsgrad)
+    for it in range(6):
+        for a, b in zip(mine, ref):
+            g = torch.randn_like(a) * (10.0 ** (it % 3 - 1))
+            a.grad, b.grad = g.clone(), g.clone()
+        if it in (2, 3):                       # parameter 4 skips two updates
+            mine[4].grad = None
+            ref[4].grad = None
+        o1.step()
+        o2.step()
+        for a, b in zip(mine, ref):
+            torch.testing.assert_close(a, b, rtol=2e-6, atol=1e-7)
+    assert int(o1.state[mine[4]]["step"]) == 4 and int(o1.state[mine[0]]["step"]) == 6
+    sd = o1.state_dict()
+    o3 = torch.optim.Adam([p.detach().clone().requires_grad_(True) for p in mine], lr=1e-2, weight_decay=wd, amsgrad=amsgrad)
+    o3.load_state_dict(sd)                     # same layout as torch's
+    for k in ("exp_avg", "exp_avg_sq") + (("max_exp_avg_sq",) if amsgrad else ()):
+        for i in range(len(shapes)):
+            torch.testing.assert_close(o3.state[o3.param_groups[0]["params"][i]][k], o2.state[ref[i]][k], rtol=2e-6, atol=1e-7)   # moments near zero cancel

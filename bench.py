@@ -50,12 +50,13 @@ def build_batches(tax, n_batches, seed0, device):
 
 
 def train_step(model, opt, batch, target, world):
+    from taxoexpan_amd.loss import info_nce_loss
     from taxoexpan_amd.scoring import allreduce_gradients
     g = batch["g"]
     g.ndata["pos"] = batch["pos"]
     opt.zero_grad(set_to_none=True)
     pred = model(g, batch["x"], batch["qf"])                       # trainer.py:51
-    loss = F.cross_entropy(pred.reshape(N_QUERIES, -1), target, reduction="sum")   # trainer.py:52-56, loss.py:57
+    loss = info_nce_loss(pred.reshape(N_QUERIES, -1), target)     # trainer.py:52-56, loss.py:52-57 (one launch, gradient included)
     loss.backward()                                                  # trainer.py:60
     if world > 1:
         allreduce_gradients(list(model.parameters()))

@@ -213,6 +213,12 @@ int txe_profile_reset(void);
 int txe_profile_count(void);
 int txe_profile_get(int i, char* name_buf, int buf_len, float* ms, double* work, int* kind);
 
+/* model/loss.py:52-57 info_nce_loss = F.cross_entropy(output [B][C], target [B], reduction="sum") on the [queries][1 + negatives]
+ * regrouping of trainer.py:52-56, together with its gradient:  loss[0] = sum_b (logsumexp(x_b) - x_b[target_b]),
+ * d_x[b][c] = softmax(x_b)[c] - [c == target_b].  target NULL = all zeros (what trainer.py:53 passes). */
+int txe_info_nce(const float* x, long long ld_x, int B, int Cc, const long long* target, float* loss, float* d_x, long long ld_dx,
+                 void* stream);
+
 /* trainer.py:61 `self.optimizer.step()` for torch.optim.Adam (config.mag.json:66-73: lr 1e-3, weight_decay 0, amsgrad true): the whole
  * parameter set in one launch.  params / grads / exp_avg / exp_avg_sq / max_exp_avg_sq are HOST arrays of n_tensors DEVICE pointers
  * (dense fp32, numel[t] elements); max_exp_avg_sq == NULL selects plain Adam; `step` >= 1 is the count of this update.

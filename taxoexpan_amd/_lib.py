@@ -63,6 +63,7 @@ SIGNATURES = {
     "txe_egonet_ws_bytes": (SZ, [I]),
     "txe_egonet_offsets": (I, [P, P, P, P, P, I, I, U64, P, P, SZ, P]),
     "txe_egonet_fill": (I, [P, P, P, P, P, P, I, I, U64, P, P, P, P, P, P, P, P, P, P]),
+    "txe_info_nce": (I, [P, L, I, I, P, P, P, L, P]),
     "txe_adam_step": (I, [I, P, P, P, P, P, P, D, D, D, D, D, L, P]),
     "txe_dropout_uniform_host": (F, [U64, U64]),
     "txe_dropout_mask_word_host": (C.c_uint, [U64, U64, F]),

@@ -37,12 +37,26 @@ def _rows(t):
     return t, t.stride(0)
 
 
+_I32_MEMO = {}       # id(source tensor) -> (weakref, version, device, int32 copy): `pos` is converted once per batch, not once per module
+
+
 def _i32(t, device):
     if t is None:
         return None
-    if t.dtype != torch.int32 or t.device != device:
-        t = t.to(device=device, dtype=torch.int32)
-    return t.contiguous()
+    if t.dtype == torch.int32 and t.device == device:
+        return t.contiguous()
+    key = id(t)
+    hit = _I32_MEMO.get(key)
+    if hit is not None and hit[0]() is t and hit[1] == t._version and hit[2] == device:
+        return hit[3]
+    out = t.to(device=device, dtype=torch.int32).contiguous()
+    if len(_I32_MEMO) > 64:
+        for k in [k for k, v in _I32_MEMO.items() if v[0]() is None]:
+            del _I32_MEMO[k]
+        if len(_I32_MEMO) > 64:
+            _I32_MEMO.clear()
+    _I32_MEMO[key] = (weakref.ref(t), t._version, device, out)
+    return out
 
 
 def _empty(shape, ref, dtype=torch.float32):

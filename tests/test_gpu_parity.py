@@ -5,6 +5,7 @@ summation order differs from MKL's) with a small absolute floor."""
 import numpy as np
 import pytest
 import torch
+import torch.nn.functional as F
 
 import golden_cases as gc
 import txe_oracle as orc
@@ -803,3 +804,23 @@ def test_adam_step_equals_torch_adam(amsgrad, wd):
     for k in ("exp_avg", "exp_avg_sq") + (("max_exp_avg_sq",) if amsgrad else ()):
         for i in range(len(shapes)):
             torch.testing.assert_close(o3.state[o3.param_groups[0]["params"][i]][k], o2.state[ref[i]][k], rtol=2e-6, atol=1e-7)   # moments near zero cancel
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,C,zero_target", [(128, 32, True), (8, 257, False), (1, 1, True), (37, 64, False), (0, 5, True)])
+def test_info_nce_loss_equals_torch_cross_entropy(B, C, zero_target):
+    """txe_info_nce against model/loss.py:52-57 (F.cross_entropy, reduction sum): value, gradient, upstream gradient scaling,
+    non-contiguous rows (the LBM scores are a column of a [G, 1] tensor reshaped)"""
+    from taxoexpan_amd.loss import info_nce_loss
+    dev = torch.device("cuda:0")
+    torch.manual_seed(B * 131 + C)
+    base = (torch.randn(B, C + 3, device=dev) * 4.0)
+    x1 = base[:, :C].detach().requires_grad_(True)          # row stride C + 3
+    x2 = base[:, :C].detach().clone().requires_grad_(True)
+    tgt = torch.zeros(B, dtype=torch.long, device=dev) if zero_target else torch.randint(0, C, (B,), device=dev)
+    l1 = info_nce_loss(x1, None if zero_target and B % 2 == 0 else tgt)
+    l2 = F.cross_entropy(x2, tgt, reduction="sum")
+    torch.testing.assert_close(l1, l2, rtol=1e-5, atol=1e-5)
+    (l1 * 0.5).backward()
+    (l2 * 0.5).backward()
+    torch.testing.assert_close(x1.grad, x2.grad, rtol=1e-5, atol=1e-6)

@@ -51,6 +51,12 @@ int txe_gat_padded_k(int Kh, int Pd);
 int txe_gat_padded_f(int H, int D);
 int txe_gat_pack_weights(const float* W, const float* attn_l, const float* attn_r, int H, int D, int Kt, float* Wp, void* stream);
 int txe_gat_build_x(const float* h, long long ld_h, int n_nodes, int Kh, const int* pos, const float* P, int Pd, float* X, void* stream);
+
+/* build_x + pack_weights + dropout_mask of one GATLayer (model_zoo.py:80-85) as ONE launch; same outputs as the three calls.
+ * mask [n_nodes][ceil((Kh+Pd)/32)] may be NULL when feat_drop_p == 0. */
+int txe_gat_layer_prepare(const float* h, long long ld_h, int n_nodes, int Kh, const int* pos, const float* P, int Pd, float* X,
+                          const float* W, const float* attn_l, const float* attn_r, int H, int D, float* Wp, float feat_drop_p,
+                          unsigned long long seed, unsigned* mask, void* stream);
 size_t txe_gat_dense_ws_bytes(int n_nodes, int Kh, int Pd, int H, int D, int vocab);
 int txe_gat_dense_fwd(const float* X, int n_nodes, int Kh, int Pd, const float* Wp, int H, int D, float feat_drop_p,
                       const unsigned* mask, float* Y, void* ws, size_t ws_bytes, void* stream);

@@ -11,6 +11,8 @@
 //    N x H x D passes of model_zoo.py:84-85 in forward AND their two passes in backward: the gradients
 //    d a1, d a2 ride as 2H extra columns of the incoming gradient through the dX and dW GEMMs and are
 //    unfolded on the (tiny) weight side:  dW += attn (x) d wa,  d attn = <d wa, W>.
+#include <string.h>
+
 #include "txe_gemm.h"
 #include "txe_gather.h"
 
@@ -22,16 +24,15 @@ constexpr int MAX_VOCAB = 8;
 // wa[H+h][k] = sum_d attn_r[h*D+d] * W[(h*D+d)*ldw + k]            (k < Kt)
 // One workgroup per (row r, 64-column chunk): 64 columns x 16 d-groups, LDS tree over the d-groups.
 constexpr int FOLD_DG = 16;
-__global__ __launch_bounds__(64 * FOLD_DG) void fold_attn_kernel(const float* __restrict__ W, long long ldw, int Kt,
-                                                                 const float* __restrict__ attn_l, const float* __restrict__ attn_r,
-                                                                 int H, int D, float* __restrict__ wa, long long ld_wa) {
+__device__ __forceinline__ void fold_attn_job(const int bx, const int r /* 0 .. 2H-1 */, const float* __restrict__ W, long long ldw, int Kt,
+                                              const float* __restrict__ attn_l, const float* __restrict__ attn_r, int H, int D,
+                                              float* __restrict__ wa, long long ld_wa) {
     __shared__ float red[FOLD_DG][64];
-    const int r = blockIdx.y;                     // 0 .. 2H-1
     const int h = r % H;
     const float* attn = ((r < H) ? attn_l : attn_r) + (long long)h * D;
     const float* Wh = W + (long long)h * D * ldw;
     const int kl = threadIdx.x & 63, dg = threadIdx.x >> 6;
-    const int k = blockIdx.x * 64 + kl;
+    const int k = bx * 64 + kl;
     const int kc = (k < Kt) ? k : 0;
     float acc = 0.f;
 #pragma unroll 4
@@ -45,46 +46,52 @@ __global__ __launch_bounds__(64 * FOLD_DG) void fold_attn_kernel(const float* __
         wa[(long long)r * ld_wa + k] = s;
     }
 }
+__global__ __launch_bounds__(64 * FOLD_DG) void fold_attn_kernel(const float* __restrict__ W, long long ldw, int Kt,
+                                                                 const float* __restrict__ attn_l, const float* __restrict__ attn_r,
+                                                                 int H, int D, float* __restrict__ wa, long long ld_wa) {
+    fold_attn_job(blockIdx.x, blockIdx.y, W, ldw, Kt, attn_l, attn_r, H, D, wa, ld_wa);
+}
 
 // dwa[r][k] = sum_s part[s][F + r][k]     r < 2H
-__global__ void reduce_ext_rows_kernel(const float* __restrict__ part, int S, long long split_stride, int F, int H2, int ldp,
-                                       float* __restrict__ dwa) {
-    const int r = blockIdx.y;
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void ext_rows_job(const int r, const int k, const float* __restrict__ part, int S, long long split_stride, int F,
+                                             int ldp, float* __restrict__ dwa) {
     if (k >= ldp) return;
     float acc = 0.f;
     for (int s = 0; s < S; ++s) acc += part[(long long)s * split_stride + (long long)(F + r) * ldp + k];
     dwa[(long long)r * ldp + k] = acc;
+}
+__global__ void reduce_ext_rows_kernel(const float* __restrict__ part, int S, long long split_stride, int F, int H2, int ldp,
+                                       float* __restrict__ dwa) {
+    ext_rows_job(blockIdx.y, blockIdx.x * blockDim.x + threadIdx.x, part, S, split_stride, F, ldp, dwa);
 }
 
 // One workgroup per weight row f = h*D + d:
 //   dW[f][k]    = sum_s part[s][f][k] + attn_l[f] * dwa[h][k] + attn_r[f] * dwa[H+h][k]
 //   d_attn_l[f] = sum_k dwa[h][k]   * W[f][k]
 //   d_attn_r[f] = sum_k dwa[H+h][k] * W[f][k]
-__global__ __launch_bounds__(256) void gat_unfold_kernel(const float* __restrict__ part, int S, long long split_stride,
-                                                         const float* __restrict__ dwa, long long ldp, const float* __restrict__ W,
-                                                         long long ldw, const float* __restrict__ attn_l,
-                                                         const float* __restrict__ attn_r, int H, int D, int Kt,
-                                                         float* __restrict__ dW, long long ld_dw,
-                                                         float* __restrict__ d_attn_l, float* __restrict__ d_attn_r) {
+struct UnfoldArgs {
+    const float* part; int S; long long split_stride; const float* dwa; long long ldp; const float* W; long long ldw;
+    const float *attn_l, *attn_r; int H, D, Kt; float* dW; long long ld_dw; float *d_attn_l, *d_attn_r;
+};
+__device__ __forceinline__ void unfold_job(const int f, const UnfoldArgs& a) {
     __shared__ float red[2][4];
-    const int f = blockIdx.x, h = f / D;
-    const float al = attn_l[f], ar = attn_r[f];
+    const int h = f / a.D;
+    const float al = a.attn_l[f], ar = a.attn_r[f];
     float dl = 0.f, dr = 0.f;
-    for (int k = threadIdx.x; k < Kt; k += blockDim.x) {
+    for (int k = threadIdx.x; k < a.Kt; k += blockDim.x) {
         // the split-K partials are summed in slice order, four (unconditional, clamped) loads in flight at a time
-        const float* pp = part + (long long)f * ldp + k;
-        const float gl = dwa[(long long)h * ldp + k], gr = dwa[(long long)(H + h) * ldp + k];
-        const float wv = W[(long long)f * ldw + k];
+        const float* pp = a.part + (long long)f * a.ldp + k;
+        const float gl = a.dwa[(long long)h * a.ldp + k], gr = a.dwa[(long long)(a.H + h) * a.ldp + k];
+        const float wv = a.W[(long long)f * a.ldw + k];
         float acc = 0.f;
-        for (int s0 = 0; s0 < S; s0 += 4) {
+        for (int s0 = 0; s0 < a.S; s0 += 4) {
             float v[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = pp[(long long)min(s0 + j, S - 1) * split_stride];
+            for (int j = 0; j < 4; ++j) v[j] = pp[(long long)min(s0 + j, a.S - 1) * a.split_stride];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc += (s0 + j < S) ? v[j] : 0.f;
+            for (int j = 0; j < 4; ++j) acc += (s0 + j < a.S) ? v[j] : 0.f;
         }
-        dW[(long long)f * ld_dw + k] = acc + al * gl + ar * gr;
+        a.dW[(long long)f * a.ld_dw + k] = acc + al * gl + ar * gr;
         dl = fmaf(gl, wv, dl);
         dr = fmaf(gr, wv, dr);
     }
@@ -94,8 +101,8 @@ __global__ __launch_bounds__(256) void gat_unfold_kernel(const float* __restrict
     if ((threadIdx.x & 63) == 0) { red[0][w] = dl; red[1][w] = dr; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        d_attn_l[f] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
-        d_attn_r[f] = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+        a.d_attn_l[f] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+        a.d_attn_r[f] = red[1][0] + red[1][1] + red[1][2] + red[1][3];
     }
 }
 
@@ -110,54 +117,101 @@ __global__ void reduce_splits_kernel(const float* __restrict__ part, int S, long
 
 // Deterministic two-stage "sum rows by position class":  dP[c][j] = sum_{m : pos[m]==c} x[m][j]
 // stage 1: block b owns rows [b*rows_per_block, ...): 64 column lanes x 4 row groups, fixed-order LDS combine.
-__global__ __launch_bounds__(256) void pos_segsum_stage1(const float* __restrict__ x, long long ldx, const int* __restrict__ pos,
-                                                         int n_rows, int cols, int vocab, int rows_per_block,
-                                                         float* __restrict__ part /*[nb][vocab][cols]*/) {
+struct Seg1Args { const float* x; long long ldx; int cols; float* part; };
+__device__ __forceinline__ void segsum1_job(const int bid, const Seg1Args& a, const int* __restrict__ pos, int n_rows, int vocab,
+                                            int rows_per_block) {
     __shared__ float red[4][MAX_VOCAB][64];
-    const int r0 = blockIdx.x * rows_per_block, r1 = min(n_rows, r0 + rows_per_block);
+    const int r0 = bid * rows_per_block, r1 = min(n_rows, r0 + rows_per_block);
     const int jl = threadIdx.x & 63, rg = threadIdx.x >> 6;
-    for (int j0 = 0; j0 < cols; j0 += 64) {
+    for (int j0 = 0; j0 < a.cols; j0 += 64) {
         const int j = j0 + jl;
-        const int jc = (j < cols) ? j : 0;
+        const int jc = (j < a.cols) ? j : 0;
         float acc[MAX_VOCAB];
 #pragma unroll
         for (int c = 0; c < MAX_VOCAB; ++c) acc[c] = 0.f;
 #pragma unroll 4
         for (int m = r0 + rg; m < r1; m += 4) {
             const int pc = pos[m];
-            const float v = x[(long long)m * ldx + jc];
+            const float v = a.x[(long long)m * a.ldx + jc];
 #pragma unroll
             for (int c = 0; c < MAX_VOCAB; ++c) acc[c] += (pc == c) ? v : 0.f;
         }
 #pragma unroll
         for (int c = 0; c < MAX_VOCAB; ++c) red[rg][c][jl] = acc[c];
         __syncthreads();
-        if (rg == 0 && j < cols)
+        if (rg == 0 && j < a.cols)
             for (int c = 0; c < vocab; ++c)
-                part[((long long)blockIdx.x * vocab + c) * cols + j] = red[0][c][jl] + red[1][c][jl] + red[2][c][jl] + red[3][c][jl];
+                a.part[((long long)bid * vocab + c) * a.cols + j] = red[0][c][jl] + red[1][c][jl] + red[2][c][jl] + red[3][c][jl];
         __syncthreads();
     }
 }
-__global__ __launch_bounds__(256) void pos_segsum_stage2(const float* __restrict__ part, int nb, int vocab, int cols,
-                                                         float* __restrict__ out) {
+__global__ __launch_bounds__(256) void pos_segsum_stage1(const float* __restrict__ x, long long ldx, const int* __restrict__ pos,
+                                                         int n_rows, int cols, int vocab, int rows_per_block,
+                                                         float* __restrict__ part /*[nb][vocab][cols]*/) {
+    Seg1Args a{x, ldx, cols, part};
+    segsum1_job(blockIdx.x, a, pos, n_rows, vocab, rows_per_block);
+}
+struct Seg2Args { const float* part; int nb; int n /* vocab * cols */; float* out; };
+__device__ __forceinline__ void segsum2_job(const int bid, const Seg2Args& a) {
     __shared__ float red[4][64];
     const int il = threadIdx.x & 63, bg = threadIdx.x >> 6;
-    const int i = blockIdx.x * 64 + il;
-    const int n = vocab * cols;
-    const int ic = (i < n) ? i : 0;
+    const int i = bid * 64 + il;
+    const int ic = (i < a.n) ? i : 0;
     float acc = 0.f;
 #pragma unroll 4
-    for (int b = bg; b < nb; b += 4) acc += part[(long long)b * n + ic];
+    for (int b = bg; b < a.nb; b += 4) acc += a.part[(long long)b * a.n + ic];
     red[bg][il] = acc;
     __syncthreads();
-    if (bg == 0 && i < n) out[i] = red[0][il] + red[1][il] + red[2][il] + red[3][il];
+    if (bg == 0 && i < a.n) a.out[i] = red[0][il] + red[1][il] + red[2][il] + red[3][il];
+}
+__global__ __launch_bounds__(256) void pos_segsum_stage2(const float* __restrict__ part, int nb, int vocab, int cols,
+                                                         float* __restrict__ out) {
+    Seg2Args a{part, nb, vocab * cols, out};
+    segsum2_job(blockIdx.x, a);
+}
+
+// The reductions that end a GATLayer's backward, as TWO launches of independent jobs on disjoint workgroup ranges:
+//   phase A: per-block partial position sums (embedding gradient; readout position-weight gradient) and the folded attention rows'
+//            gradient d_wa (split-K slices of the extension rows, or the per-block partials of the folded output layer);
+//   phase B: dW / d_attn from d_wa (unfold) and the second stage of the position sums.
+struct TailA {
+    int nb_s1a, nb_s1b, nb_r, r_kind;           // r_kind 1: extension rows of the split-K weight gradient, 2: stage 2 over dwa_part
+    Seg1Args s1a, s1b;
+    const int* pos; int n_rows, vocab, rows_per_block;
+    const float* rpart; int S; long long split_stride; int F, ldp, nbx; float* dwa;
+    Seg2Args r2;
+};
+__global__ __launch_bounds__(256) void gat_bwd_reduce_a_kernel(const TailA a) {
+    int b = blockIdx.x;
+    if (b < a.nb_s1a) { segsum1_job(b, a.s1a, a.pos, a.n_rows, a.vocab, a.rows_per_block); return; }
+    b -= a.nb_s1a;
+    if (b < a.nb_s1b) { segsum1_job(b, a.s1b, a.pos, a.n_rows, a.vocab, a.rows_per_block); return; }
+    b -= a.nb_s1b;
+    if (a.r_kind == 1) ext_rows_job(b / a.nbx, (b % a.nbx) * 256 + threadIdx.x, a.rpart, a.S, a.split_stride, a.F, a.ldp, a.dwa);
+    else segsum2_job(b, a.r2);
+}
+struct TailB {
+    int nb_u, nb_2a, nb_2b;
+    UnfoldArgs u;
+    Seg2Args s2a, s2b;
+};
+__global__ __launch_bounds__(256) void gat_bwd_reduce_b_kernel(const TailB a) {
+    int b = blockIdx.x;
+    if (b < a.nb_u) { unfold_job(b, a.u); return; }
+    b -= a.nb_u;
+    if (b < a.nb_2a) { segsum2_job(b, a.s2a); return; }
+    segsum2_job(b - a.nb_2a, a.s2b);
 }
 
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
-__global__ void dropout_mask_kernel(long long n_words, unsigned long long seed, unsigned thr16, unsigned* __restrict__ mask) {
-    for (long long w = (long long)blockIdx.x * blockDim.x + threadIdx.x; w < n_words; w += (long long)gridDim.x * blockDim.x)
+__device__ __forceinline__ void dropout_mask_job(const int bid, const int nb, long long n_words, unsigned long long seed, unsigned thr16,
+                                                 unsigned* __restrict__ mask) {
+    for (long long w = (long long)bid * blockDim.x + threadIdx.x; w < n_words; w += (long long)nb * blockDim.x)
         mask[w] = drop_mask_word(seed, (unsigned long long)w, thr16);
+}
+__global__ void dropout_mask_kernel(long long n_words, unsigned long long seed, unsigned thr16, unsigned* __restrict__ mask) {
+    dropout_mask_job(blockIdx.x, gridDim.x, n_words, seed, thr16, mask);
 }
 
 }  // namespace txe
@@ -197,22 +251,26 @@ namespace txe {
 static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 
 // Wp[f][k] = W[f][k] (f < F, k < Kt) else 0   (rows F..Fe are written by fold_attn_kernel)
-__global__ void pack_w_kernel(const float* __restrict__ W, int F, int Fe, int Fp, int Kt, int Kp, float* __restrict__ Wp) {
+__device__ __forceinline__ void pack_w_job(const int bid, const int nb, const float* __restrict__ W, int F, int Fe, int Fp, int Kt, int Kp,
+                                           float* __restrict__ Wp) {
     const long long n = (long long)Fp * Kp;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    for (long long i = (long long)bid * blockDim.x + threadIdx.x; i < n; i += (long long)nb * blockDim.x) {
         const int f = (int)(i / Kp), k = (int)(i % Kp);
-        if (f >= F && f < Fe && k < Kt) continue;              // folded rows: other kernel
+        if (f >= F && f < Fe && k < Kt) continue;              // folded rows: other job
         Wp[i] = (f < F && k < Kt) ? W[(long long)f * Kt + k] : 0.f;
     }
 }
+__global__ void pack_w_kernel(const float* __restrict__ W, int F, int Fe, int Fp, int Kt, int Kp, float* __restrict__ Wp) {
+    pack_w_job(blockIdx.x, gridDim.x, W, F, Fe, Fp, Kt, Kp, Wp);
+}
 
 // X[r][c] = h[r][c] (c < Kh, only when h != NULL) | P[pos[r]][c-Kh] (Kh <= c < Kt) | 0 (Kt <= c < Kp)
-__global__ void build_x_kernel(const float* __restrict__ h, long long ld_h, const int* __restrict__ pos, const float* __restrict__ P,
-                               int n_rows, int Kh, int Pd, int Kp, float* __restrict__ X) {
+__device__ __forceinline__ void build_x_job(const int bid, const int nb, const float* __restrict__ h, long long ld_h, const int* __restrict__ pos,
+                                            const float* __restrict__ P, int n_rows, int Kh, int Pd, int Kp, float* __restrict__ X) {
     const int c0 = h ? 0 : Kh;
     const int wdt = Kp - c0;
     const long long n = (long long)n_rows * wdt;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    for (long long i = (long long)bid * blockDim.x + threadIdx.x; i < n; i += (long long)nb * blockDim.x) {
         const long long r = i / wdt;
         const int c = c0 + (int)(i % wdt);
         float v = 0.f;
@@ -220,6 +278,30 @@ __global__ void build_x_kernel(const float* __restrict__ h, long long ld_h, cons
         else if (c < Kh + Pd) v = P[(long long)pos[r] * Pd + (c - Kh)];
         X[r * Kp + c] = v;
     }
+}
+__global__ void build_x_kernel(const float* __restrict__ h, long long ld_h, const int* __restrict__ pos, const float* __restrict__ P,
+                               int n_rows, int Kh, int Pd, int Kp, float* __restrict__ X) {
+    build_x_job(blockIdx.x, gridDim.x, h, ld_h, pos, P, n_rows, Kh, Pd, Kp, X);
+}
+
+// Everything a GATLayer needs before its projection GEMM, in ONE launch (four independent jobs on disjoint ranges of workgroups):
+// layer input X (build_x), packed weights Wp (pack_w), folded attention rows (fold_attn), feature-dropout keep mask.
+struct PrepArgs {
+    int nb_x, nb_w, nb_f, nb_m, fold_bx;
+    const float* h; long long ld_h; const int* pos; const float* P; int n_rows, Kh, Pd, Kp; float* X;
+    const float *W, *attn_l, *attn_r; int H, D, F, Fe, Fp, Kt; float* Wp;
+    long long n_words; unsigned long long seed; unsigned thr16; unsigned* mask;
+};
+__global__ __launch_bounds__(64 * FOLD_DG) void gat_prepare_kernel(const PrepArgs a) {
+    int b = blockIdx.x;
+    if (b < a.nb_x) { build_x_job(b, a.nb_x, a.h, a.ld_h, a.pos, a.P, a.n_rows, a.Kh, a.Pd, a.Kp, a.X); return; }
+    b -= a.nb_x;
+    if (b < a.nb_m) { dropout_mask_job(b, a.nb_m, a.n_words, a.seed, a.thr16, a.mask); return; }
+    b -= a.nb_m;
+    if (b < a.nb_w) { pack_w_job(b, a.nb_w, a.W, a.F, a.Fe, a.Fp, a.Kt, a.Kp, a.Wp); return; }
+    b -= a.nb_w;
+    fold_attn_job(b % a.fold_bx, b / a.fold_bx, a.W, (long long)a.Kt, a.Kt, a.attn_l, a.attn_r, a.H, a.D, a.Wp + (long long)a.F * a.Kp,
+                  (long long)a.Kp);
 }
 
 // zero columns [c0, c1) of a row-major [n_rows][ld] matrix
@@ -292,6 +374,34 @@ int txe_gat_build_x(const float* h, long long ld_h, int n_nodes, int Kh, const i
     return TXE_OK;
 }
 
+// txe_gat_build_x + txe_gat_pack_weights + txe_dropout_mask (over the [n_nodes][Kh+Pd] layer input; feat_drop_p == 0: mask may be NULL)
+// as ONE launch -- the per-layer preparation of GATLayer.forward (model_zoo.py:80-85) costs one dispatch instead of four.
+int txe_gat_layer_prepare(const float* h, long long ld_h, int n_nodes, int Kh, const int* pos, const float* P, int Pd, float* X,
+                          const float* W, const float* attn_l, const float* attn_r, int H, int D, float* Wp, float feat_drop_p,
+                          unsigned long long seed, unsigned* mask, void* stream) {
+    if (n_nodes < 0 || Kh < 1 || Pd < 0 || !X || (Pd > 0 && (!pos || !P)) || !W || !attn_l || !attn_r || !Wp || H < 1 || D < 1)
+        return TXE_ERR_ARG;
+    if (feat_drop_p < 0.f || feat_drop_p >= 1.f || (feat_drop_p > 0.f && !mask)) return TXE_ERR_ARG;
+    const int T = 64 * FOLD_DG;
+    PrepArgs a;
+    a.Kt = Kh + Pd; a.Kp = round_up(a.Kt, 32);
+    a.F = H * D; a.Fe = a.F + 2 * H; a.Fp = round_up(a.Fe, 128);
+    auto blocks = [&](long long n, int cap) { const long long b = (n + T - 1) / T; return (int)(b < cap ? b : cap); };
+    const long long nx = (long long)n_nodes * (a.Kp - (h ? 0 : Kh));
+    a.nb_x = blocks(nx, 2048);
+    a.n_words = (feat_drop_p > 0.f) ? (long long)n_nodes * ((a.Kt + 31) / 32) : 0;
+    a.nb_m = blocks(a.n_words, 1024);
+    a.nb_w = blocks((long long)a.Fp * a.Kp, 512);
+    a.fold_bx = (a.Kt + 63) / 64;
+    a.nb_f = a.fold_bx * 2 * H;
+    a.h = h; a.ld_h = ld_h; a.pos = pos; a.P = P; a.n_rows = n_nodes; a.Kh = Kh; a.Pd = Pd; a.X = X;
+    a.W = W; a.attn_l = attn_l; a.attn_r = attn_r; a.H = H; a.D = D; a.Wp = Wp;
+    a.seed = seed; a.thr16 = (unsigned)(feat_drop_p * 65536.0f + 0.5f); a.mask = mask;
+    hipLaunchKernelGGL(gat_prepare_kernel, dim3(a.nb_x + a.nb_m + a.nb_w + a.nb_f), dim3(T), 0, (hipStream_t)stream, a);
+    TXE_CHECK_LAUNCH();
+    return TXE_OK;
+}
+
 size_t txe_gat_dense_ws_bytes(int n_nodes, int Kh, int Pd, int H, int D, int vocab) {
     return plan_dense_ws(nullptr, n_nodes, round_up(H * D + 2 * H, 128), 2 * H, round_up(Kh + Pd, 32), Pd, vocab).total;
 }
@@ -342,34 +452,35 @@ int txe_gat_dense_bwd(const float* X, int n_nodes, int Kh, int Pd, const int* po
         rc = gemm_nn(A, B, E, n_nodes, Kt - c0, Fp, 1, s, p.tail, p.tail_bytes);
         if (rc) return rc;
     }
-    // ---- dP[c][j] = sum_{pos[m]==c} d_X[m][Kh+j] ----
-    if (Pd > 0) {
-        if (n_nodes > 0) {
-            hipLaunchKernelGGL(pos_segsum_stage1, dim3(p.seg_blocks), dim3(256), 0, s, (const float*)(d_X + Kh), (long long)Kp, pos, n_nodes,
-                               Pd, vocab, p.seg_rows, p.ppart);
-            TXE_CHECK_LAUNCH();
-        }
-        hipLaunchKernelGGL(pos_segsum_stage2, dim3((vocab * Pd + 63) / 64), dim3(256), 0, s, (const float*)p.ppart,
-                           n_nodes > 0 ? p.seg_blocks : 0, vocab, Pd, dP);
-        TXE_CHECK_LAUNCH();
-    }
     // ---- dWp = d_Y^T * dropout(X)  (split-K over the node dimension) ----
-    {
-        VMat A = vmat_plain(d_Y, Fp, n_nodes, Fp);
-        VMat B = vmat_plain(X, Kp, n_nodes, Kp);
-        vmat_set_mask(B, mask, feat_drop_p);
-        Epi E = epi_plain(p.part, Kp, Kp);
-        E.split_stride = (long long)Fp * Kp;
-        rc = gemm_tn(A, B, E, Fp, Kp, n_nodes, p.splits, s);
-        if (rc) return rc;
-        const int S = n_nodes > 0 ? p.splits : 0;
-        hipLaunchKernelGGL(reduce_ext_rows_kernel, dim3((Kp + 127) / 128, H2), dim3(128), 0, s, (const float*)p.part, S, E.split_stride, F,
-                           H2, Kp, p.dwa);
-        TXE_CHECK_LAUNCH();
-        hipLaunchKernelGGL(gat_unfold_kernel, dim3(F), dim3(256), 0, s, (const float*)p.part, S, E.split_stride, (const float*)p.dwa,
-                           (long long)Kp, W, (long long)Kt, attn_l, attn_r, H, D, Kt, dW, (long long)Kt, d_attn_l, d_attn_r);
-        TXE_CHECK_LAUNCH();
-    }
+    VMat A = vmat_plain(d_Y, Fp, n_nodes, Fp);
+    VMat B = vmat_plain(X, Kp, n_nodes, Kp);
+    vmat_set_mask(B, mask, feat_drop_p);
+    Epi E = epi_plain(p.part, Kp, Kp);
+    E.split_stride = (long long)Fp * Kp;
+    rc = gemm_tn(A, B, E, Fp, Kp, n_nodes, p.splits, s);
+    if (rc) return rc;
+    const int S = n_nodes > 0 ? p.splits : 0;
+    // ---- phase A: dP partials (dP[c][j] = sum_{pos[m]==c} d_X[m][Kh+j]) and d_wa = the extension rows of dWp ----
+    const int nseg = (Pd > 0 && n_nodes > 0) ? p.seg_blocks : 0;
+    TailA ta;
+    memset(&ta, 0, sizeof(ta));
+    ta.nb_s1a = nseg; ta.s1a = Seg1Args{d_X ? d_X + Kh : nullptr, (long long)Kp, Pd, p.ppart};
+    ta.pos = pos; ta.n_rows = n_nodes; ta.vocab = vocab; ta.rows_per_block = p.seg_rows;
+    ta.r_kind = 1; ta.nbx = (Kp + 255) / 256; ta.nb_r = ta.nbx * H2;
+    ta.rpart = p.part; ta.S = S; ta.split_stride = E.split_stride; ta.F = F; ta.ldp = Kp; ta.dwa = p.dwa;
+    hipLaunchKernelGGL(gat_bwd_reduce_a_kernel, dim3(ta.nb_s1a + ta.nb_r), dim3(256), 0, s, ta);
+    TXE_CHECK_LAUNCH();
+    // ---- phase B: dW / d_attn (unfold) and dP ----
+    TailB tb;
+    memset(&tb, 0, sizeof(tb));
+    tb.nb_u = F;
+    tb.u = UnfoldArgs{p.part, S, E.split_stride, p.dwa, (long long)Kp, W, (long long)Kt, attn_l, attn_r, H, D, Kt, dW, (long long)Kt,
+                      d_attn_l, d_attn_r};
+    tb.nb_2a = Pd > 0 ? (vocab * Pd + 63) / 64 : 0;
+    tb.s2a = Seg2Args{p.ppart, nseg, vocab * Pd, dP};
+    hipLaunchKernelGGL(gat_bwd_reduce_b_kernel, dim3(tb.nb_u + tb.nb_2a), dim3(256), 0, s, tb);
+    TXE_CHECK_LAUNCH();
     return TXE_OK;
 }
 
@@ -1001,25 +1112,27 @@ int txe_gat_collapse_bwd(const int* rowptr_in, const int* col_src, const int* ro
         }
         TXE_CHECK_LAUNCH();
     }
-    // ---- d_wa = sum of the per-block partials;  position embedding / readout position-weight gradients ----
-    hipLaunchKernelGGL(pos_segsum_stage2, dim3((2 * Kp + 63) / 64), dim3(256), 0, s, (const float*)p.dwa_part, nblk, 2, Kp, p.dwa);
-    if (Pd > 0) {
-        if (n_nodes > 0)
-            hipLaunchKernelGGL(pos_segsum_stage1, dim3(p.seg_blocks), dim3(256), 0, s, (const float*)(d_X + Kh), (long long)Kp, pos, n_nodes, Pd,
-                               vocab, p.seg_rows, p.ppart);
-        hipLaunchKernelGGL(pos_segsum_stage2, dim3((vocab * Pd + 63) / 64), dim3(256), 0, s, (const float*)p.ppart,
-                           n_nodes > 0 ? p.seg_blocks : 0, vocab, Pd, dP);
-    }
-    if (pw) {
-        if (n_nodes > 0)
-            hipLaunchKernelGGL(pos_segsum_stage1, dim3(p.seg_blocks), dim3(256), 0, s, (const float*)p.dwv, (long long)1, pos, n_nodes, 1, vocab,
-                               p.seg_rows, p.ppart2);
-        hipLaunchKernelGGL(pos_segsum_stage2, dim3((vocab + 63) / 64), dim3(256), 0, s, (const float*)p.ppart2, n_nodes > 0 ? p.seg_blocks : 0,
-                           vocab, 1, d_pw);
-    }
-    // ---- dW = main + attn (x) d_wa ;  d_attn = <d_wa, W> ----
-    hipLaunchKernelGGL(gat_unfold_kernel, dim3(D), dim3(256), 0, s, (const float*)p.part, S, split_stride, (const float*)p.dwa, (long long)Kp, W,
-                       (long long)Kt, attn_l, attn_r, 1, D, Kt, dW, (long long)Kt, d_attn_l, d_attn_r);
+    // ---- phase A: d_wa = sum of the per-block partials; partial position sums (embedding / readout position-weight gradients) ----
+    const int nseg = n_nodes > 0 ? p.seg_blocks : 0;
+    TailA ta;
+    memset(&ta, 0, sizeof(ta));
+    ta.nb_s1a = Pd > 0 ? nseg : 0; ta.s1a = Seg1Args{d_X + Kh, (long long)Kp, Pd, p.ppart};
+    ta.nb_s1b = pw ? nseg : 0; ta.s1b = Seg1Args{p.dwv, 1, 1, p.ppart2};
+    ta.pos = pos; ta.n_rows = n_nodes; ta.vocab = vocab; ta.rows_per_block = p.seg_rows;
+    ta.r_kind = 2; ta.nb_r = (2 * Kp + 63) / 64; ta.r2 = Seg2Args{p.dwa_part, nblk, 2 * Kp, p.dwa};
+    hipLaunchKernelGGL(gat_bwd_reduce_a_kernel, dim3(ta.nb_s1a + ta.nb_s1b + ta.nb_r), dim3(256), 0, s, ta);
+    TXE_CHECK_LAUNCH();
+    // ---- phase B: dW = main + attn (x) d_wa, d_attn = <d_wa, W> (unfold);  dP, d_pw ----
+    TailB tb;
+    memset(&tb, 0, sizeof(tb));
+    tb.nb_u = D;
+    tb.u = UnfoldArgs{p.part, S, split_stride, p.dwa, (long long)Kp, W, (long long)Kt, attn_l, attn_r, 1, D, Kt, dW, (long long)Kt, d_attn_l,
+                      d_attn_r};
+    tb.nb_2a = Pd > 0 ? (vocab * Pd + 63) / 64 : 0;
+    tb.s2a = Seg2Args{p.ppart, nseg, vocab * Pd, dP};
+    tb.nb_2b = pw ? (vocab + 63) / 64 : 0;
+    tb.s2b = Seg2Args{p.ppart2, nseg, vocab, d_pw};
+    hipLaunchKernelGGL(gat_bwd_reduce_b_kernel, dim3(tb.nb_u + tb.nb_2a + tb.nb_2b), dim3(256), 0, s, tb);
     TXE_CHECK_LAUNCH();
     return TXE_OK;
 }

@@ -117,10 +117,10 @@ def _gat_layer_prepare(st, h, ld_h, pos, feat_p):
     """layer input X = [h | Emb[pos] | 0] (h == None: the producer already wrote the feature columns), packed weights, keep mask"""
     N = st.X.shape[0]
     s = _lib.stream_ptr()
-    call("txe_gat_build_x", ptr(h), ld_h, N, st.Kh, ptr(pos), ptr(st.P), st.Pd, ptr(st.X), s)
     st.Wp = _empty((st.Fp, st.Kp), st.X)
-    call("txe_gat_pack_weights", ptr(st.W), ptr(st.al), ptr(st.ar), st.H, st.D, st.Kh + st.Pd, ptr(st.Wp), s)
-    st.mask = dropout_mask(N, st.Kh + st.Pd, feat_p, st.seed, st.X)
+    st.mask = torch.empty((N, (st.Kh + st.Pd + 31) // 32), dtype=torch.int32, device=st.X.device) if feat_p > 0.0 else None
+    call("txe_gat_layer_prepare", ptr(h), ld_h, N, st.Kh, ptr(pos), ptr(st.P), st.Pd, ptr(st.X), ptr(st.W), ptr(st.al), ptr(st.ar),
+         st.H, st.D, ptr(st.Wp), feat_p, st.seed, ptr(st.mask), s)
 
 
 def _gat_collapse_fwd(csr, st, h, ld_h, pos, rpos, pw, feat_p, attn_p, attn_slope):

@@ -74,12 +74,13 @@ int txe_gat_aggregate_fwd(const int* rowptr_in, const int* col_src, int n_nodes,
                           unsigned long long seed, int out_mode, float act_slope, float* out, long long ld_out, float* alpha,
                           void* stream);
 /* d_pre = gradient w.r.t. the PRE-activation aggregated output.  Writes d_ft [N][H*D], d_a_src/d_a_dst [N][H]
- * (row stride ld_da).  dz_ws: E*H floats of scratch. */
+ * (row stride ld_da).  dz_ws: E*H floats of scratch.  n_pad: floats following d_a_dst[v][H-1] in every row that are cleared as
+ * well (the zero padding columns of txe_gat_dense_bwd's d_Y operand when d_ft | d_a_src | d_a_dst share one padded row); 0 = none. */
 int txe_gat_aggregate_bwd(const int* rowptr_in, const int* col_src, const int* rowptr_out, const int* col_dst,
                           const int* pos_out, int n_nodes, const float* ft, long long ld_ft, const float* a_src,
                           const float* a_dst, int ld_a, int H, int D, float attn_slope, float attn_drop_p,
                           unsigned long long seed, const float* alpha, const float* d_pre, long long ld_dpre, float* d_ft,
-                          long long ld_dft, float* d_a_src, float* d_a_dst, int ld_da, float* dz_ws, void* stream);
+                          long long ld_dft, float* d_a_src, float* d_a_dst, int ld_da, float* dz_ws, int n_pad, void* stream);
 int txe_leaky_relu_bwd(const float* d_out, const float* out_act, float slope, long long n, float* d_pre, void* stream);
 /* `.mean(1)` over heads of the output layer, model_zoo.py:219 */
 int txe_head_mean_fwd(const float* x, int H, int D, long long n_rows, float* y, void* stream);
@@ -182,7 +183,7 @@ int txe_gat_collapse_bwd(const int* rowptr_in, const int* col_src, const int* ro
                          const float* Wp, const float* W, const float* attn_l, const float* attn_r, int D, float feat_drop_p,
                          const unsigned* mask, float attn_slope, float attn_drop_p, unsigned long long seed, const float* pw,
                          const float* a12, const float* alpha, const float* coef, const float* wsum, const int* gid, const float* Z,
-                         const float* d_hg, long long ld_dhg, int act_on, float act_slope, float* d_X, float* dW, float* d_attn_l,
+                         const float* hg, long long ld_hg, const float* d_hg, long long ld_dhg, int act_on, float act_slope, float* d_X, float* dW, float* d_attn_l,
                          float* d_attn_r, float* dP, float* d_pw, void* ws, size_t ws_bytes, void* stream);
 
 /* ---- output GCNLayer folded behind MeanReadout / WeightedMeanReadout: model_zoo.py:35-47,139-167,227-242.

@@ -137,10 +137,11 @@ __global__ __launch_bounds__(GAT_WAVES * 64) void gat_bwd_edge_generic_kernel(
     const long long ld_ft, const float* __restrict__ a_src, const float* __restrict__ a_dst, const int ld_a, const int H,
     const int D, const float slope, const float drop_p, const float drop_scale, const unsigned long long seed,
     const float* __restrict__ alpha, const float* __restrict__ d_pre, const long long ld_dpre, float* __restrict__ dz,
-    float* __restrict__ d_a_dst, const int ld_da) {
+    float* __restrict__ d_a_dst, const int ld_da, const int n_pad) {
     const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
     const int v = xcd_remap(blockIdx.x, gridDim.x) * GAT_WAVES + w;
     if (v >= n_nodes) return;
+    for (int c = l; c < n_pad; c += 64) d_a_dst[(long long)v * ld_da + H + c] = 0.f;      // padding columns of the row
     const int beg = rowptr[v], end = rowptr[v + 1];
     const int dvec = D / VEC;
     for (int h = 0; h < H; ++h) {
@@ -192,11 +193,12 @@ __global__ __launch_bounds__(GAT_WAVES * 64) void gat_bwd_edge_kernel(
     const long long ld_ft, const float* __restrict__ a_src, const float* __restrict__ a_dst, const int ld_a, const int H,
     const int D, const float slope, const float drop_p, const float drop_scale, const unsigned long long seed,
     const float* __restrict__ alpha, const float* __restrict__ d_pre, const long long ld_dpre, float* __restrict__ dz,
-    float* __restrict__ d_a_dst, const int ld_da) {
+    float* __restrict__ d_a_dst, const int ld_da, const int n_pad) {
     __shared__ float s_d[GAT_WAVES][64 * NI * VEC];
     const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
     const int v = xcd_remap(blockIdx.x, gridDim.x) * GAT_WAVES + w;
     if (v >= n_nodes) return;
+    for (int c = l; c < n_pad; c += 64) d_a_dst[(long long)v * ld_da + H + c] = 0.f;      // padding columns of the row
     const int beg = rowptr[v], end = rowptr[v + 1];
     if (beg == end) {                                                // no in-edge (never for egonets: self loops)
         if (l < H) d_a_dst[(long long)v * ld_da + l] = 0.f;
@@ -570,8 +572,8 @@ int txe_gat_aggregate_bwd(const int* rowptr_in, const int* col_src, const int* r
                           const int* pos_out, int n_nodes, const float* ft, long long ld_ft, const float* a_src,
                           const float* a_dst, int ld_a, int H, int D, float attn_slope, float attn_drop_p,
                           unsigned long long seed, const float* alpha, const float* d_pre, long long ld_dpre, float* d_ft,
-                          long long ld_dft, float* d_a_src, float* d_a_dst, int ld_da, float* dz_ws, void* stream) {
-    if (n_nodes < 0 || H < 1 || H > GAT_MAXH || D < 1) return TXE_ERR_ARG;
+                          long long ld_dft, float* d_a_src, float* d_a_dst, int ld_da, float* dz_ws, int n_pad, void* stream) {
+    if (n_nodes < 0 || H < 1 || H > GAT_MAXH || D < 1 || n_pad < 0) return TXE_ERR_ARG;
     if (!rowptr_in || !rowptr_out || !ft || !alpha || !d_pre || !d_ft || !d_a_src || !d_a_dst || !dz_ws) return TXE_ERR_ARG;
     if (attn_drop_p < 0.f || attn_drop_p >= 1.f) return TXE_ERR_ARG;
     if (n_nodes == 0) return TXE_OK;
@@ -587,7 +589,7 @@ int txe_gat_aggregate_bwd(const int* rowptr_in, const int* col_src, const int* r
 #define TXE_L(V, I)                                                                                                        \
     hipLaunchKernelGGL((gat_bwd_edge_kernel<V, I>), dim3(nb), dim3(GAT_WAVES * 64), 0, s, rowptr_in, col_src, n_nodes, ft, \
                        ld_ft, a_src, a_dst, ld_a, H, D, attn_slope, attn_drop_p, scale, seed, alpha, d_pre, ld_dpre,       \
-                       dz_ws, d_a_dst, ld_da)
+                       dz_ws, d_a_dst, ld_da, n_pad)
     TXE_DISPATCH_VEC_NI(v1, ni1, TXE_L);
 #undef TXE_L
     } else {
@@ -596,7 +598,7 @@ int txe_gat_aggregate_bwd(const int* rowptr_in, const int* col_src, const int* r
 #define TXE_L(V)                                                                                                           \
     hipLaunchKernelGGL((gat_bwd_edge_generic_kernel<V>), dim3(nb), dim3(GAT_WAVES * 64), 0, s, rowptr_in, col_src, n_nodes, \
                        ft, ld_ft, a_src, a_dst, ld_a, H, D, attn_slope, attn_drop_p, scale, seed, alpha, d_pre, ld_dpre,    \
-                       dz_ws, d_a_dst, ld_da)
+                       dz_ws, d_a_dst, ld_da, n_pad)
     if (v1 == 4) TXE_L(4); else if (v1 == 2) TXE_L(2); else TXE_L(1);
 #undef TXE_L
     }

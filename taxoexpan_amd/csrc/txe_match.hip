@@ -20,31 +20,28 @@ __global__ __launch_bounds__(256) void rowdot_kernel(const float* __restrict__ U
     if (l == 0) s[i] = apply_exp ? __expf(acc) : acc;
 }
 
-// dsl[i] = ds[i] * (apply_exp ? s[i] : 1)
-__global__ void dsl_kernel(const float* __restrict__ ds, const float* __restrict__ s, int apply_exp, int G, float* __restrict__ dsl) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < G) dsl[i] = apply_exp ? ds[i] * s[i] : ds[i];
-}
-
+// dsl[i] = ds[i] * (apply_exp ? s[i] : 1): gradient at the bilinear form (LBM returns exp of it, model_zoo.py:325-328)
 // dU[i][k] = dsl[i] * e2[i][k]      (gradient of U = E1 W, the only consumer of e2 in s_i = <U_i, e2_i>)
-__global__ void du_kernel(const float* __restrict__ dsl, const float* __restrict__ e2, long long ld_e2, int G, int r,
-                          float* __restrict__ dU) {
+__global__ void du_kernel(const float* __restrict__ ds, const float* __restrict__ s, int apply_exp, const float* __restrict__ e2,
+                          long long ld_e2, int G, int r, float* __restrict__ dU) {
     const long long n = (long long)G * r;
     for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (long long)gridDim.x * blockDim.x) {
         const long long i = t / r;
         const int k = (int)(t % r);
-        dU[t] = dsl[i] * e2[i * ld_e2 + k];
+        const float dsl = apply_exp ? ds[i] * s[i] : ds[i];
+        dU[t] = dsl * e2[i * ld_e2 + k];
     }
 }
 
 // d_e2[i][k] = dsl[i] * U[i][k]
-__global__ void de2_kernel(const float* __restrict__ dsl, const float* __restrict__ U, int G, int r, float* __restrict__ d_e2,
-                           long long ld) {
+__global__ void de2_kernel(const float* __restrict__ ds, const float* __restrict__ s, int apply_exp, const float* __restrict__ U, int G,
+                           int r, float* __restrict__ d_e2, long long ld) {
     const long long n = (long long)G * r;
     for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (long long)gridDim.x * blockDim.x) {
         const long long i = t / r;
         const int k = (int)(t % r);
-        d_e2[i * ld + k] = dsl[i] * U[t];
+        const float dsl = apply_exp ? ds[i] * s[i] : ds[i];
+        d_e2[i * ld + k] = dsl * U[t];
     }
 }
 
@@ -142,15 +139,13 @@ int txe_bilinear_pair_bwd(const float* e1, long long ld_e1, const float* e2, lon
     if (G < 0 || l < 1 || r < 1 || !e1 || !e2 || !W || !U || !s || !ds || !d_e1 || !dW || !ws) return TXE_ERR_ARG;
     if (ws_bytes < txe_bilinear_pair_bwd_ws_bytes(G, l, r)) return TXE_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
-    float* dsl = (float*)ws;
     float* dU = (float*)((char*)ws + mt_align((size_t)(G > 0 ? G : 1) * 4));
     float* part = (float*)((char*)dU + mt_align((size_t)(G > 0 ? G : 1) * r * 4));
     int rc;
     if (G > 0) {
-        hipLaunchKernelGGL(dsl_kernel, dim3((G + 255) / 256), dim3(256), 0, st, ds, s, apply_exp, G, dsl);
         const long long nu = (long long)G * r;
-        hipLaunchKernelGGL(du_kernel, dim3((int)((nu + 255) / 256 < 2048 ? (nu + 255) / 256 : 2048)), dim3(256), 0, st,
-                           (const float*)dsl, e2, ld_e2, G, r, dU);
+        hipLaunchKernelGGL(du_kernel, dim3((int)((nu + 255) / 256 < 2048 ? (nu + 255) / 256 : 2048)), dim3(256), 0, st, ds, s, apply_exp,
+                           e2, ld_e2, G, r, dU);
         TXE_CHECK_LAUNCH();
         // d_e1[i][j] = sum_k dU[i][k] W[j][k]
         VMat A = vmat_plain(dU, r, G, r);
@@ -161,7 +156,7 @@ int txe_bilinear_pair_bwd(const float* e1, long long ld_e1, const float* e2, lon
         if (d_e2) {
             const long long n = (long long)G * r;
             const int nb = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
-            hipLaunchKernelGGL(de2_kernel, dim3(nb), dim3(256), 0, st, (const float*)dsl, U, G, r, d_e2, ld_de2);
+            hipLaunchKernelGGL(de2_kernel, dim3(nb), dim3(256), 0, st, ds, s, apply_exp, U, G, r, d_e2, ld_de2);
             TXE_CHECK_LAUNCH();
         }
     }

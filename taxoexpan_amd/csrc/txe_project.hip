@@ -293,15 +293,19 @@ struct PrepArgs {
     long long n_words; unsigned long long seed; unsigned thr16; unsigned* mask;
 };
 __global__ __launch_bounds__(64 * FOLD_DG) void gat_prepare_kernel(const PrepArgs a) {
+    // the latency-bound job (a strided reduction per folded row) is dispatched first, the streaming jobs fill in behind it
     int b = blockIdx.x;
-    if (b < a.nb_x) { build_x_job(b, a.nb_x, a.h, a.ld_h, a.pos, a.P, a.n_rows, a.Kh, a.Pd, a.Kp, a.X); return; }
-    b -= a.nb_x;
-    if (b < a.nb_m) { dropout_mask_job(b, a.nb_m, a.n_words, a.seed, a.thr16, a.mask); return; }
-    b -= a.nb_m;
+    if (b < a.nb_f) {
+        fold_attn_job(b % a.fold_bx, b / a.fold_bx, a.W, (long long)a.Kt, a.Kt, a.attn_l, a.attn_r, a.H, a.D, a.Wp + (long long)a.F * a.Kp,
+                      (long long)a.Kp);
+        return;
+    }
+    b -= a.nb_f;
     if (b < a.nb_w) { pack_w_job(b, a.nb_w, a.W, a.F, a.Fe, a.Fp, a.Kt, a.Kp, a.Wp); return; }
     b -= a.nb_w;
-    fold_attn_job(b % a.fold_bx, b / a.fold_bx, a.W, (long long)a.Kt, a.Kt, a.attn_l, a.attn_r, a.H, a.D, a.Wp + (long long)a.F * a.Kp,
-                  (long long)a.Kp);
+    if (b < a.nb_m) { dropout_mask_job(b, a.nb_m, a.n_words, a.seed, a.thr16, a.mask); return; }
+    b -= a.nb_m;
+    build_x_job(b, a.nb_x, a.h, a.ld_h, a.pos, a.P, a.n_rows, a.Kh, a.Pd, a.Kp, a.X);
 }
 
 // zero columns [c0, c1) of a row-major [n_rows][ld] matrix
@@ -671,10 +675,10 @@ __global__ __launch_bounds__(256) void cl_logits_kernel(const float* __restrict_
 }
 
 // one wave per destination: alpha[p] = softmax over the in-edges of v of leaky(a1[u] + a2[v])      (model_zoo.py:106-114)
-__global__ __launch_bounds__(256) void cl_alpha_kernel(const int* __restrict__ rowptr, const int* __restrict__ col, int n_nodes,
-                                                       const float* __restrict__ a12, float slope, float* __restrict__ alpha) {
+__device__ __forceinline__ void cl_alpha_job(const int bid, const int* __restrict__ rowptr, const int* __restrict__ col, int n_nodes,
+                                             const float* __restrict__ a12, float slope, float* __restrict__ alpha) {
     const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
-    const int v = blockIdx.x * 4 + w;
+    const int v = bid * 4 + w;
     if (v >= n_nodes) return;
     const int beg = rowptr[v], end = rowptr[v + 1];
     const float a2v = a12[2 * (long long)v + 1];
@@ -710,10 +714,10 @@ __global__ __launch_bounds__(256) void cl_coef_kernel(const int* __restrict__ ro
 }
 
 // per graph: S_g = sum_v w_v -> wsum[g];  gid[v] = g for its nodes
-__global__ __launch_bounds__(256) void cl_wsum_kernel(const int* __restrict__ goff, int G, const int* __restrict__ pos,
-                                                      const float* __restrict__ pw, float* __restrict__ wsum, int* __restrict__ gid) {
+__device__ __forceinline__ void cl_wsum_job(const int bid, const int* __restrict__ goff, int G, const int* __restrict__ pos,
+                                            const float* __restrict__ pw, float* __restrict__ wsum, int* __restrict__ gid) {
     const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
-    const int g = blockIdx.x * 4 + w;
+    const int g = bid * 4 + w;
     if (g >= G) return;
     const int beg = goff[g], end = goff[g + 1];
     float S = 0.f;
@@ -723,6 +727,19 @@ __global__ __launch_bounds__(256) void cl_wsum_kernel(const int* __restrict__ go
     }
     S = wave_sum(S);
     if (l == 0) wsum[g] = S;
+}
+__global__ __launch_bounds__(256) void cl_wsum_kernel(const int* __restrict__ goff, int G, const int* __restrict__ pos,
+                                                      const float* __restrict__ pw, float* __restrict__ wsum, int* __restrict__ gid) {
+    cl_wsum_job(blockIdx.x, goff, G, pos, pw, wsum, gid);
+}
+// the attention softmax (workgroups [0, nb_alpha)) and the graph weight sums (the rest): independent, one launch
+__global__ __launch_bounds__(256) void cl_alpha_wsum_kernel(int nb_alpha, const int* __restrict__ rowptr, const int* __restrict__ col,
+                                                            int n_nodes, const float* __restrict__ a12, float slope,
+                                                            float* __restrict__ alpha, const int* __restrict__ goff, int G,
+                                                            const int* __restrict__ pos, const float* __restrict__ pw,
+                                                            float* __restrict__ wsum, int* __restrict__ gid) {
+    if ((int)blockIdx.x < nb_alpha) cl_alpha_job(blockIdx.x, rowptr, col, n_nodes, a12, slope, alpha);
+    else cl_wsum_job(blockIdx.x - nb_alpha, goff, G, pos, pw, wsum, gid);
 }
 
 // sweep 2 -- one wave per (graph, 256-column tile):  Z[g][tile] = (scale / S_g) sum_{u in g} c~_u (X[u] * keep)[tile]
@@ -787,9 +804,23 @@ template <bool MASK>
 __global__ __launch_bounds__(256) void cl_bwd_dot_kernel(int n_nodes, const int* __restrict__ gid, const float* __restrict__ X, int Kp,
                                                          const unsigned* __restrict__ mask, int mask_ld, float scale,
                                                          const float* __restrict__ dZ, const float* __restrict__ wsum,
-                                                         const float* __restrict__ coef, float* __restrict__ dc, float* __restrict__ cn) {
+                                                         const float* __restrict__ coef, float* __restrict__ dc, float* __restrict__ cn,
+                                                         const int nb_ds, const int G, const int D, const float* __restrict__ d_hg,
+                                                         const long long ld_dhg, const float* __restrict__ hg, const long long ld_hg,
+                                                         float* __restrict__ dS) {
     const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
-    const int u = blockIdx.x * 4 + w;
+    if ((int)blockIdx.x < nb_ds) {
+        // independent job on the first workgroups, one wave per graph: dS[g] = -<dZ[g], Z[g]> / S_g, and since dZ = d_hg W and
+        // hg = Z W^T the product is <d_hg[g], hg[g]> -- D columns instead of Kp, and no dependence on the dZ GEMM
+        const int g = blockIdx.x * 4 + w;
+        if (g >= G) return;
+        float s = 0.f;
+        for (int j = l; j < D; j += 64) s = fmaf(d_hg[(long long)g * ld_dhg + j], hg[(long long)g * ld_hg + j], s);
+        s = wave_sum(s);
+        if (l == 0) dS[g] = wsum[g] > 0.f ? -s / wsum[g] : 0.f;
+        return;
+    }
+    const int u = ((int)blockIdx.x - nb_ds) * 4 + w;
     if (u >= n_nodes) return;
     const int g = gid[u];
     const int nvec = Kp >> 2;
@@ -1020,12 +1051,14 @@ int txe_gat_collapse_fwd(const int* rowptr_in, const int* col_src, const int* ro
             if (mk) hipLaunchKernelGGL(cl_logits_kernel<true>, dim3(nb < 2048 ? nb : 2048), dim3(256), 0, s, X, Kp, n_nodes, mk, mask_ld, fs, wa, a12);
             else hipLaunchKernelGGL(cl_logits_kernel<false>, dim3(nb < 2048 ? nb : 2048), dim3(256), 0, s, X, Kp, n_nodes, dummy_mask, mask_ld, fs, wa, a12);
         }
-        hipLaunchKernelGGL(cl_alpha_kernel, dim3(nb), dim3(256), 0, s, rowptr_in, col_src, n_nodes, (const float*)a12, attn_slope, alpha);
+        hipLaunchKernelGGL(cl_alpha_wsum_kernel, dim3(nb + (G + 3) / 4), dim3(256), 0, s, nb, rowptr_in, col_src, n_nodes, (const float*)a12,
+                           attn_slope, alpha, graph_off, G, pos, pw, wsum, gid);
         hipLaunchKernelGGL(cl_coef_kernel, dim3(nb), dim3(256), 0, s, rowptr_out, col_dst, pos_out, n_nodes,
                            (const float*)alpha, attn_drop_p, as, seed, pos, pw, coef);
         TXE_CHECK_LAUNCH();
+    } else if (G > 0) {
+        hipLaunchKernelGGL(cl_wsum_kernel, dim3((G + 3) / 4), dim3(256), 0, s, graph_off, G, pos, pw, wsum, gid);
     }
-    hipLaunchKernelGGL(cl_wsum_kernel, dim3((G + 3) / 4), dim3(256), 0, s, graph_off, G, pos, pw, wsum, gid);
     {
         const int ntile = (Kp / 4 + 63) / 64;
         const long long nwaves = (long long)G * ntile;
@@ -1049,10 +1082,10 @@ int txe_gat_collapse_bwd(const int* rowptr_in, const int* col_src, const int* ro
                          const float* Wp, const float* W, const float* attn_l, const float* attn_r, int D, float feat_drop_p,
                          const unsigned* mask, float attn_slope, float attn_drop_p, unsigned long long seed, const float* pw,
                          const float* a12, const float* alpha, const float* coef, const float* wsum, const int* gid, const float* Z,
-                         const float* d_hg, long long ld_dhg, int act_on, float act_slope, float* d_X, float* dW, float* d_attn_l,
+                         const float* hg, long long ld_hg, const float* d_hg, long long ld_dhg, int act_on, float act_slope, float* d_X, float* dW, float* d_attn_l,
                          float* d_attn_r, float* dP, float* d_pw, void* ws, size_t ws_bytes, void* stream) {
     if (n_nodes < 0 || n_edges < 0 || G < 0 || Kh < 1 || Pd < 0 || D < 1 || !rowptr_in || !rowptr_out || !graph_off || !X || !Wp || !W ||
-        !attn_l || !attn_r || !a12 || !alpha || !coef || !wsum || !gid || !Z || !d_hg || !d_X || !dW || !d_attn_l || !d_attn_r || !ws)
+        !attn_l || !attn_r || !a12 || !alpha || !coef || !wsum || !gid || !Z || !hg || !d_hg || !d_X || !dW || !d_attn_l || !d_attn_r || !ws)
         return TXE_ERR_ARG;
     if ((Pd > 0 || pw) && (!pos || vocab < 1 || vocab > MAX_VOCAB)) return TXE_ERR_ARG;
     if ((Pd > 0 && !dP) || (pw && !d_pw)) return TXE_ERR_ARG;
@@ -1089,13 +1122,13 @@ int txe_gat_collapse_bwd(const int* rowptr_in, const int* col_src, const int* ro
     if (G > 0 && n_nodes > 0) {
         const int nb = (n_nodes + 3) / 4;
         const int ntile = (Kp / 4 + 63) / 64;
-        hipLaunchKernelGGL(cl_bwd_ds_kernel, dim3((G + 3) / 4), dim3(256), 0, s, G, Kp, (const float*)p.dZ, Z, wsum, p.dS);
         {
-            ProfScope prof(mk ? "cl_bwd_dot_kernel<true>" : "cl_bwd_dot_kernel<false>", s, 4.0 * (n_nodes + (double)G) * Kp, 1);
-            if (mk) hipLaunchKernelGGL(cl_bwd_dot_kernel<true>, dim3(nb), dim3(256), 0, s, n_nodes, gid, X, Kp, mk, mask_ld, fs, (const float*)p.dZ, wsum,
-                                       coef, p.dc, p.cn);
-            else hipLaunchKernelGGL(cl_bwd_dot_kernel<false>, dim3(nb), dim3(256), 0, s, n_nodes, gid, X, Kp, dummy_mask, mask_ld, fs,
-                                    (const float*)p.dZ, wsum, coef, p.dc, p.cn);
+            const int nb_ds = (G + 3) / 4;
+            ProfScope prof(mk ? "cl_bwd_dot_kernel<true>" : "cl_bwd_dot_kernel<false>", s, 4.0 * ((n_nodes + (double)G) * Kp + 2.0 * G * D), 1);
+            if (mk) hipLaunchKernelGGL(cl_bwd_dot_kernel<true>, dim3(nb_ds + nb), dim3(256), 0, s, n_nodes, gid, X, Kp, mk, mask_ld, fs,
+                                       (const float*)p.dZ, wsum, coef, p.dc, p.cn, nb_ds, G, D, d_hg, ld_dhg, hg, ld_hg, p.dS);
+            else hipLaunchKernelGGL(cl_bwd_dot_kernel<false>, dim3(nb_ds + nb), dim3(256), 0, s, n_nodes, gid, X, Kp, dummy_mask, mask_ld, fs,
+                                    (const float*)p.dZ, wsum, coef, p.dc, p.cn, nb_ds, G, D, d_hg, ld_dhg, hg, ld_hg, p.dS);
         }
         hipLaunchKernelGGL(cl_bwd_edge_kernel, dim3(nb), dim3(256), 0, s, rowptr_in, col_src, n_nodes, a12, attn_slope, alpha, attn_drop_p, as,
                            seed, pos, pw, (const float*)p.dc, (const float*)p.dS, gid, p.dz, p.da2, p.dwv);
@@ -1343,10 +1376,12 @@ int txe_gcn_collapse_bwd(const int* rowptr_in, const int* col_src, const int* gr
             hipLaunchKernelGGL(cl_bwd_ds_kernel, dim3((G + 3) / 4), dim3(256), 0, s, G, Kp, (const float*)p.dZ, Z, wsum, p.dS);
             {
                 ProfScope prof(mk ? "cl_bwd_dot_kernel<true>" : "cl_bwd_dot_kernel<false>", s, 4.0 * (n_nodes + (double)G) * Kp, 1);
+                // (the bias makes hg != Z W here, so dS keeps its own kernel: no leading dS workgroups)
                 if (mk) hipLaunchKernelGGL(cl_bwd_dot_kernel<true>, dim3(nb), dim3(256), 0, s, n_nodes, gid, X, Kp, mk, mask_ld, fs, (const float*)p.dZ,
-                                           wsum, coef, p.dc, p.cn);
+                                           wsum, coef, p.dc, p.cn, 0, 0, 0, (const float*)nullptr, 0LL, (const float*)nullptr, 0LL, (float*)nullptr);
                 else hipLaunchKernelGGL(cl_bwd_dot_kernel<false>, dim3(nb), dim3(256), 0, s, n_nodes, gid, X, Kp, dummy_mask, mask_ld, fs,
-                                        (const float*)p.dZ, wsum, coef, p.dc, p.cn);
+                                        (const float*)p.dZ, wsum, coef, p.dc, p.cn, 0, 0, 0, (const float*)nullptr, 0LL, (const float*)nullptr, 0LL,
+                                        (float*)nullptr);
             }
             hipLaunchKernelGGL(gcl_bwd_w_kernel, dim3(nb), dim3(256), 0, s, rowptr_in, col_src, n_nodes, norm, pos, pw, (const float*)p.dc,
                                (const float*)p.dS, gid, p.dwv);

@@ -136,13 +136,13 @@ def _gat_collapse_fwd(csr, st, h, ld_h, pos, rpos, pw, feat_p, attn_p, attn_slop
          ptr(csr.graph_off), N, E, G, ptr(st.X), st.Kh, st.Pd, ptr(st.Wp), st.D, feat_p, ptr(st.mask), attn_slope, attn_p, st.seed + 1,
          ptr(rpos), ptr(pw), ptr(a12), ptr(alpha), ptr(coef), ptr(wsum), ptr(gid), ptr(Z), ptr(hg), st.D, ptr(ws), wsb,
          _lib.stream_ptr())
-    st.cl = (a12, alpha, coef, wsum, gid, Z)
+    st.cl = (a12, alpha, coef, wsum, gid, Z, hg)
     return hg
 
 
 def _gat_collapse_bwd(csr, st, pos, rpos, pw, vocab, feat_p, attn_p, attn_slope, d_hg, act_on, act_slope):
     N, G, E = st.X.shape[0], csr.n_graphs, csr.n_edges
-    a12, alpha, coef, wsum, gid, Z = st.cl
+    a12, alpha, coef, wsum, gid, Z, hg = st.cl
     d_hg, ld = _rows(d_hg)
     dW, dal, dar = torch.empty_like(st.W), torch.empty_like(st.al), torch.empty_like(st.ar)
     dP = torch.empty_like(st.P) if st.P is not None else None
@@ -154,7 +154,7 @@ def _gat_collapse_bwd(csr, st, pos, rpos, pw, vocab, feat_p, attn_p, attn_slope,
     call("txe_gat_collapse_bwd", ptr(csr.rowptr_in), ptr(csr.col_src), ptr(csr.rowptr_out), ptr(csr.col_dst), ptr(csr.pos_out),
          ptr(csr.graph_off), N, E, G, ptr(st.X), st.Kh, st.Pd, ptr(pos if pos is not None else rpos), v, ptr(st.Wp), ptr(st.W),
          ptr(st.al), ptr(st.ar), st.D, feat_p, ptr(st.mask), attn_slope, attn_p, st.seed + 1, ptr(pw), ptr(a12), ptr(alpha), ptr(coef),
-         ptr(wsum), ptr(gid), ptr(Z), ptr(d_hg), ld, int(act_on), act_slope if act_slope else 1.0, ptr(d_X), ptr(dW), ptr(dal), ptr(dar), ptr(dP),
+         ptr(wsum), ptr(gid), ptr(Z), ptr(hg), st.D, ptr(d_hg), ld, int(act_on), act_slope if act_slope else 1.0, ptr(d_X), ptr(dW), ptr(dal), ptr(dar), ptr(dP),
          ptr(d_pw), ptr(ws), wsb, _lib.stream_ptr())
     return d_X, dW, dal, dar, dP, d_pw
 
@@ -180,11 +180,10 @@ def _gat_layer_bwd(csr, st, pos, vocab, feat_p, attn_p, attn_slope, d_pre, ld_dp
     F, Fe = H * D, H * D + 2 * H
     s = _lib.stream_ptr()
     d_Y = _empty((N, Fp), st.X)
-    call("txe_zero_cols", ptr(d_Y), Fp, N, Fe, Fp, s)
     dz = _empty((max(csr.n_edges, 1) * H,), st.X)
     call("txe_gat_aggregate_bwd", ptr(csr.rowptr_in), ptr(csr.col_src), ptr(csr.rowptr_out), ptr(csr.col_dst), ptr(csr.pos_out),
          N, ptr(st.Y), Fp, ptr(st.Y) + 4 * F, ptr(st.Y) + 4 * (F + H), Fp, H, D, attn_slope, attn_p, st.seed + 1, ptr(st.alpha),
-         ptr(d_pre), ld_dpre, ptr(d_Y), Fp, ptr(d_Y) + 4 * F, ptr(d_Y) + 4 * (F + H), Fp, ptr(dz), s)
+         ptr(d_pre), ld_dpre, ptr(d_Y), Fp, ptr(d_Y) + 4 * F, ptr(d_Y) + 4 * (F + H), Fp, ptr(dz), Fp - Fe, s)   # clears d_Y's padding too
     dW, dal, dar = torch.empty_like(st.W), torch.empty_like(st.al), torch.empty_like(st.ar)
     dP = torch.empty_like(st.P) if st.P is not None else None
     d_X = _empty((N, Kp), st.X) if (need_dh or Pd > 0) else None

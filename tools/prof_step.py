@@ -6,7 +6,8 @@ dev = torch.device("cuda:0")
 tax = syn.make_named_taxonomy("mag_cs", seed=47)
 torch.manual_seed(47)
 model = TaxoExpan("PGAT", "WMR", "LBM", **bench.MAG).to(dev).train()
-opt = torch.optim.Adam(model.parameters(), lr=1e-3, amsgrad=True)
+from taxoexpan_amd.optim import Adam  # noqa: E402
+opt = Adam(model.parameters(), lr=1e-3, amsgrad=True)
 batches = bench.build_batches(tax, 2, 1000, dev)
 target = torch.zeros(bench.N_QUERIES, dtype=torch.long, device=dev)
 for i in range(3): bench.train_step(model, opt, batches[i % 2], target, 1)

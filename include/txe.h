@@ -68,11 +68,15 @@ int txe_zero_cols(float* x, long long ld, int n_rows, int c0, int c1, void* stre
 
 /* ---- GATLayer message/reduce: model_zoo.py:90-95,106-114 (edge_attention, edge_softmax, attn_drop, update_all) -----
  * out_mode 0: out = aggregated features; 1: out = leaky_relu(aggregated, act_slope) (model_zoo.py:216 fused).
- * alpha [E][H] (post-softmax, pre-dropout; NULL in inference). */
+ * alpha [E][H] (post-softmax, pre-dropout; NULL in inference).
+ * nx_a12 != NULL (optional fused epilogue, needs 16-byte aligned rows): `out` is the padded input X' [N][nx_kp] of the NEXT, one-head
+ * GATLayer (ld_out == nx_kp, its position / padding columns already in place, nx_mask = its feature keep bits or NULL), and the
+ * folded attention logits of that layer are formed on the way out: nx_a12[v][r] = <dropout(X'[v]), nx_wa[r]> (nx_wa [2][nx_kp] =
+ * rows D, D+1 of its packed weights) -- txe_gat_collapse_fwd then runs with a12_ready = 1. */
 int txe_gat_aggregate_fwd(const int* rowptr_in, const int* col_src, int n_nodes, const float* ft, long long ld_ft,
                           const float* a_src, const float* a_dst, int ld_a, int H, int D, float attn_slope, float attn_drop_p,
                           unsigned long long seed, int out_mode, float act_slope, float* out, long long ld_out, float* alpha,
-                          void* stream);
+                          const float* nx_wa, int nx_kp, const unsigned* nx_mask, float nx_feat_drop_p, float* nx_a12, void* stream);
 /* d_pre = gradient w.r.t. the PRE-activation aggregated output.  Writes d_ft [N][H*D], d_a_src/d_a_dst [N][H]
  * (row stride ld_da).  dz_ws: E*H floats of scratch.  n_pad: floats following d_a_dst[v][H-1] in every row that are cleared as
  * well (the zero padding columns of txe_gat_dense_bwd's d_Y operand when d_ft | d_a_src | d_a_dst share one padded row); 0 = none. */
@@ -176,7 +180,7 @@ size_t txe_gat_collapse_ws_bytes(int n_nodes, int n_edges, int G, int Kh, int Pd
 int txe_gat_collapse_fwd(const int* rowptr_in, const int* col_src, const int* rowptr_out, const int* col_dst, const int* pos_out,
                          const int* graph_off, int n_nodes, int n_edges, int G, const float* X, int Kh, int Pd, const float* Wp, int D,
                          float feat_drop_p, const unsigned* mask, float attn_slope, float attn_drop_p, unsigned long long seed,
-                         const int* pos, const float* pw, float* a12, float* alpha, float* coef, float* wsum, int* gid, float* Z,
+                         const int* pos, const float* pw, float* a12, int a12_ready, float* alpha, float* coef, float* wsum, int* gid, float* Z,
                          float* hg, long long ld_hg, void* ws, size_t ws_bytes, void* stream);
 int txe_gat_collapse_bwd(const int* rowptr_in, const int* col_src, const int* rowptr_out, const int* col_dst, const int* pos_out,
                          const int* graph_off, int n_nodes, int n_edges, int G, const float* X, int Kh, int Pd, const int* pos, int vocab,

@@ -21,7 +21,7 @@ SIGNATURES = {
     "txe_gat_dense_fwd": (I, [P, I, I, I, P, I, I, F, P, P, P, SZ, P]),
     "txe_gat_dense_bwd": (I, [P, I, I, I, P, I, P, P, P, P, I, I, F, P, P, I, I, F, P, P, P, P, P, P, SZ, P]),
     "txe_zero_cols": (I, [P, L, I, I, I, P]),
-    "txe_gat_aggregate_fwd": (I, [P, P, I, P, L, P, P, I, I, I, F, F, U64, I, F, P, L, P, P]),
+    "txe_gat_aggregate_fwd": (I, [P, P, I, P, L, P, P, I, I, I, F, F, U64, I, F, P, L, P, P, I, P, F, P, P]),
     "txe_gat_aggregate_bwd": (I, [P, P, P, P, P, I, P, L, P, P, I, I, I, F, F, U64, P, P, L, P, L, P, P, I, P, I, P]),
     "txe_leaky_relu_bwd": (I, [P, P, F, L, P, P]),
     "txe_head_mean_fwd": (I, [P, I, I, L, P, P]),
@@ -55,7 +55,7 @@ SIGNATURES = {
     "txe_build_csr": (I, [P, P, I, I, P, P, P, P, P, P, P, SZ, P]),
     "txe_rank_block": (I, [P, L, I, I, P, P, P, I, P, P]),
     "txe_gat_collapse_ws_bytes": (SZ, [I, I, I, I, I, I, I]),
-    "txe_gat_collapse_fwd": (I, [P, P, P, P, P, P, I, I, I, P, I, I, P, I, F, P, F, F, U64, P, P, P, P, P, P, P, P, P, L, P, SZ, P]),
+    "txe_gat_collapse_fwd": (I, [P, P, P, P, P, P, I, I, I, P, I, I, P, I, F, P, F, F, U64, P, P, P, I, P, P, P, P, P, P, L, P, SZ, P]),
     "txe_gat_collapse_bwd": (I, [P, P, P, P, P, P, I, I, I, P, I, I, P, I, P, P, P, P, I, F, P, F, F, U64, P, P, P, P, P, P, P, P, L, P, L, I, F,
                                  P, P, P, P, P, P, P, SZ, P]),
     "txe_gcn_collapse_ws_bytes": (SZ, [I, I, I, I, I, I]),

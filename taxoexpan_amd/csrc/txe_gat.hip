@@ -22,17 +22,35 @@ constexpr int SLICE_NI = 2;      // feature vectors per lane of a wave that owns
 // ------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------
-template <int VEC, int NI>
+// NX: the epilogue also forms the attention logits of the NEXT GATLayer in folded form (one head): the row this wave has just
+// produced is the feature part of that layer's input X' = [out | position columns | 0] (out IS X', ld_out = nx_kp), so
+//   nx_a12[v][r] = nx_scale * < X'[v] * keep(nx_mask), nx_wa[r] >,  r = 0, 1
+// costs two FMAs per element here instead of a second sweep over X' (txe_gat_collapse_fwd's logits kernel).
+struct NextLogits {
+    const float* wa;          // [2][kp] folded attention rows of the next layer
+    const unsigned* mask;     // its feature-dropout keep bits [N][mask_ld] or NULL
+    float* a12;               // [N][2]
+    float scale;
+    int kp, mask_ld;
+};
+template <int VEC, int NI, bool NX>
 __global__ __launch_bounds__(GAT_WAVES * 64) void gat_aggregate_fwd_kernel(
     const int* __restrict__ rowptr, const int* __restrict__ col, const int n_nodes, const float* __restrict__ ft,
     const long long ld_ft, const float* __restrict__ a_src, const float* __restrict__ a_dst, const int ld_a, const int H,
     const int D, const float slope, const float drop_p, const float drop_scale, const unsigned long long seed,
-    const int out_mode, const float act_slope, float* __restrict__ out, const long long ld_out, float* __restrict__ alpha) {
+    const int out_mode, const float act_slope, float* __restrict__ out, const long long ld_out, float* __restrict__ alpha,
+    const NextLogits nx) {
     __shared__ float s_w[GAT_WAVES][GAT_MAXH * 64];
     __shared__ int s_idx[GAT_WAVES][64];
     __shared__ float s_stat[GAT_WAVES][2 * GAT_MAXH];
 
     const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    extern __shared__ float s_wa[];                    // NX: the two folded rows [2][kp], shared by the workgroup's 4 nodes
+    if constexpr (NX) {
+        for (int i = threadIdx.x * 4; i < 2 * nx.kp; i += GAT_WAVES * 64 * 4)
+            *reinterpret_cast<float4*>(s_wa + i) = *reinterpret_cast<const float4*>(nx.wa + i);
+        __syncthreads();                               // before any wave leaves
+    }
     const int v = xcd_remap(blockIdx.x, gridDim.x) * GAT_WAVES + w;
     if (v >= n_nodes) return;
     const int beg = rowptr[v], end = rowptr[v + 1];
@@ -84,9 +102,31 @@ __global__ __launch_bounds__(GAT_WAVES * 64) void gat_aggregate_fwd_kernel(
 
     const int F = H * D, nvec = F / VEC;
     constexpr int EU = NI >= 8 ? 1 : 2;
+    float nx1 = 0.f, nx2 = 0.f;
+    float tx[2];                                       // NX: the (at most 128) columns behind the feature part -- position embedding and
+    unsigned tk[2];                                    // zero padding, written by the next layer's preparation -- fetched ahead of the gather
+    if constexpr (NX) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int c = F + l + 64 * i, cc = min(c, nx.kp - 1);
+            tx[i] = out[(long long)v * ld_out + cc];
+            const unsigned wd = nx.mask ? nx.mask[(long long)v * nx.mask_ld + (cc >> 5)] : 0xFFFFFFFFu;
+            tk[i] = (c < nx.kp) ? ((wd >> (cc & 31)) & 1u) : 0u;
+        }
+    }
     for (int t0 = 0; t0 < nvec; t0 += 64 * NI) {
         int hidx[NI];
         float acc[NI][VEC];
+        unsigned kb[NI];                               // NX: keep bits of this lane's vectors, fetched ahead of the gather
+        if constexpr (NX) {
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                const int j = t0 + l + 64 * i;
+                const int c = ((j < nvec) ? j : 0) * VEC;
+                kb[i] = nx.mask ? (nx.mask[(long long)v * nx.mask_ld + (c >> 5)] >> (c & 31)) : 0xFFFFFFFFu;
+                kb[i] = (j < nvec) ? kb[i] : 0u;
+            }
+        }
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
             const int j = t0 + l + 64 * i;
@@ -123,6 +163,35 @@ __global__ __launch_bounds__(GAT_WAVES * 64) void gat_aggregate_fwd_kernel(
                 vstore<VEC>(out + (long long)v * ld_out + (long long)j * VEC, acc[i]);
             }
         }
+        if constexpr (NX) {
+            // VEC divides 32: the VEC keep bits of a vector sit in one mask word (kb, above); the folded rows come from LDS
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                const int j = t0 + l + 64 * i;
+                const int c = ((j < nvec) ? j : 0) * VEC;
+                float w1[VEC], w2[VEC];
+                vload<VEC>(s_wa + c, w1);
+                vload<VEC>(s_wa + nx.kp + c, w2);
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) {
+                    const float xd = ((kb[i] >> k) & 1u) ? acc[i][k] : 0.f;
+                    nx1 = fmaf(xd, w1[k], nx1);
+                    nx2 = fmaf(xd, w2[k], nx2);
+                }
+            }
+        }
+    }
+    if constexpr (NX) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int cc = min(F + l + 64 * i, nx.kp - 1);
+            const float xd = tk[i] ? tx[i] : 0.f;
+            nx1 = fmaf(xd, s_wa[cc], nx1);
+            nx2 = fmaf(xd, s_wa[nx.kp + cc], nx2);
+        }
+        nx1 = wave_sum(nx1) * nx.scale;
+        nx2 = wave_sum(nx2) * nx.scale;
+        if (l == 0) { nx.a12[2 * (long long)v] = nx1; nx.a12[2 * (long long)v + 1] = nx2; }
     }
 }
 
@@ -517,6 +586,7 @@ struct KName {
     char s[64];
     KName(const char* base, int a, int b) { snprintf(s, sizeof(s), "%s<%d, %d>", base, a, b); }
     KName(const char* base, int a) { snprintf(s, sizeof(s), "%s<%d>", base, a); }
+    KName(const char* base, int a, int b, bool c) { snprintf(s, sizeof(s), "%s<%d, %d, %s>", base, a, b, c ? "true" : "false"); }
 };
 
 #define TXE_DISPATCH_VEC_NI(vec, ni, LAUNCH)                                     \
@@ -542,27 +612,38 @@ extern "C" {
 int txe_gat_aggregate_fwd(const int* rowptr_in, const int* col_src, int n_nodes, const float* ft, long long ld_ft,
                           const float* a_src, const float* a_dst, int ld_a, int H, int D, float attn_slope, float attn_drop_p,
                           unsigned long long seed, int out_mode, float act_slope, float* out, long long ld_out, float* alpha,
-                          void* stream) {
+                          const float* nx_wa, int nx_kp, const unsigned* nx_mask, float nx_feat_drop_p, float* nx_a12, void* stream) {
     if (n_nodes < 0 || H < 1 || H > GAT_MAXH || D < 1 || !rowptr_in || !ft || !a_src || !a_dst || !out) return TXE_ERR_ARG;
     if (out_mode != 0 && out_mode != 1) return TXE_ERR_ARG;
     if (attn_drop_p < 0.f || attn_drop_p >= 1.f) return TXE_ERR_ARG;
+    if (nx_a12 && (!nx_wa || nx_kp < H * D || nx_kp - H * D > 128 || (nx_kp & 31) || ld_out != nx_kp || nx_feat_drop_p < 0.f || nx_feat_drop_p >= 1.f ||
+                   (nx_feat_drop_p > 0.f && !nx_mask)))
+        return TXE_ERR_ARG;
     if (n_nodes == 0) return TXE_OK;
     const float scale = 1.f / (1.f - attn_drop_p);
     const int nb = (n_nodes + GAT_WAVES - 1) / GAT_WAVES;
     hipStream_t s = (hipStream_t)stream;
     const int vec = pick_vec(D, ld_ft, ld_out, ft, out);
-    // algorithmic (compulsory) bytes, SURVEY 8d: read ft + write out + a_src/a_dst + CSR (+ alpha when kept for backward);
-    // the edge count is not known here (device rowptr), the E-proportional terms are added by the caller-side model
+    if (nx_a12 && (vec != 4 || ((uintptr_t)nx_wa & 15) || nx_kp > 4096)) return TXE_ERR_ARG;   // 16-byte layout; rows fit 32 KB of LDS
+    NextLogits nx;
+    nx.wa = nx_wa; nx.mask = (nx_feat_drop_p > 0.f) ? nx_mask : nullptr; nx.a12 = nx_a12;
+    nx.scale = 1.f / (1.f - (nx_a12 ? nx_feat_drop_p : 0.f)); nx.kp = nx_kp; nx.mask_ld = nx_kp / 32;
     // algorithmic (compulsory) bytes, SURVEY 8d: read ft + write out + a_src/a_dst + CSR (+ alpha when kept for backward);
     // the edge count is not known here (device rowptr), the E-proportional terms are added by the caller-side model
     const int ni = pick_ni(H * D / vec);
-    const KName kn("gat_aggregate_fwd_kernel", vec, ni);
+    const KName kn("gat_aggregate_fwd_kernel", vec, ni, nx_a12 != nullptr);
     ProfScope prof(kn.s, s, 4.0 * (2.0 * n_nodes * (double)H * D + 2.0 * n_nodes * H + n_nodes + 1), 1);
-#define TXE_L(V, I)                                                                                                        \
-    hipLaunchKernelGGL((gat_aggregate_fwd_kernel<V, I>), dim3(nb), dim3(GAT_WAVES * 64), 0, s, rowptr_in, col_src, n_nodes, \
-                       ft, ld_ft, a_src, a_dst, ld_a, H, D, attn_slope, attn_drop_p, scale, seed, out_mode, act_slope,     \
-                       out, ld_out, alpha)
-    TXE_DISPATCH_VEC_NI(vec, ni, TXE_L);
+#define TXE_L(V, I)                                                                                                               \
+    hipLaunchKernelGGL((gat_aggregate_fwd_kernel<V, I, false>), dim3(nb), dim3(GAT_WAVES * 64), 0, s, rowptr_in, col_src, n_nodes, \
+                       ft, ld_ft, a_src, a_dst, ld_a, H, D, attn_slope, attn_drop_p, scale, seed, out_mode, act_slope,            \
+                       out, ld_out, alpha, nx)
+#define TXE_LX(I)                                                                                                                 \
+    hipLaunchKernelGGL((gat_aggregate_fwd_kernel<4, I, true>), dim3(nb), dim3(GAT_WAVES * 64), (size_t)2 * nx_kp * sizeof(float), s, rowptr_in, col_src, n_nodes,  \
+                       ft, ld_ft, a_src, a_dst, ld_a, H, D, attn_slope, attn_drop_p, scale, seed, out_mode, act_slope,            \
+                       out, ld_out, alpha, nx)
+    if (nx_a12) { if (ni == 8) TXE_LX(8); else if (ni == 4) TXE_LX(4); else TXE_LX(2); }
+    else TXE_DISPATCH_VEC_NI(vec, ni, TXE_L);
+#undef TXE_LX
 #undef TXE_L
     TXE_CHECK_LAUNCH();
     return TXE_OK;

@@ -1028,8 +1028,8 @@ size_t txe_gat_collapse_ws_bytes(int n_nodes, int n_edges, int G, int Kh, int Pd
 int txe_gat_collapse_fwd(const int* rowptr_in, const int* col_src, const int* rowptr_out, const int* col_dst, const int* pos_out,
                          const int* graph_off, int n_nodes, int n_edges, int G, const float* X, int Kh, int Pd, const float* Wp, int D,
                          float feat_drop_p, const unsigned* mask, float attn_slope, float attn_drop_p, unsigned long long seed,
-                         const int* pos, const float* pw, float* a12, float* alpha, float* coef, float* wsum, int* gid, float* Z,
-                         float* hg, long long ld_hg, void* ws, size_t ws_bytes, void* stream) {
+                         const int* pos, const float* pw, float* a12, int a12_ready, float* alpha, float* coef, float* wsum, int* gid,
+                         float* Z, float* hg, long long ld_hg, void* ws, size_t ws_bytes, void* stream) {
     if (n_nodes < 0 || n_edges < 0 || G < 0 || Kh < 1 || Pd < 0 || D < 1 || !rowptr_in || !rowptr_out || !graph_off || !X || !Wp || !a12 ||
         !alpha || !coef || !wsum || !gid || !Z || !hg || !ws || (pw && !pos))
         return TXE_ERR_ARG;
@@ -1046,7 +1046,7 @@ int txe_gat_collapse_fwd(const int* rowptr_in, const int* col_src, const int* ro
     const unsigned* dummy_mask = reinterpret_cast<const unsigned*>(X);     // never dereferenced by the <false> instantiations
     if (n_nodes > 0) {
         const int nb = (n_nodes + 3) / 4;
-        {
+        if (!a12_ready) {          // (the producer of X may already have formed them: txe_gat_aggregate_fwd's fused epilogue)
             ProfScope prof(mk ? "cl_logits_kernel<true>" : "cl_logits_kernel<false>", s, 4.0 * n_nodes * (double)Kp, 1);
             if (mk) hipLaunchKernelGGL(cl_logits_kernel<true>, dim3(nb < 2048 ? nb : 2048), dim3(256), 0, s, X, Kp, n_nodes, mk, mask_ld, fs, wa, a12);
             else hipLaunchKernelGGL(cl_logits_kernel<false>, dim3(nb < 2048 ? nb : 2048), dim3(256), 0, s, X, Kp, n_nodes, dummy_mask, mask_ld, fs, wa, a12);

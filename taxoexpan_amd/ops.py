@@ -3,6 +3,7 @@
 torch is plumbing here: it owns device memory (caching allocator), the current HIP stream and autograd's tape;
 every number is produced by the hand-written HIP kernels.  There is no CPU path -- host tensors raise.
 """
+import os
 import weakref
 
 import torch
@@ -37,6 +38,7 @@ def _rows(t):
     return t, t.stride(0)
 
 
+_NO_FUSED_LOGITS = os.environ.get("TXE_NO_FUSED_LOGITS", "0") == "1"     # A/B switch (tests compare both paths)
 _I32_MEMO = {}       # id(source tensor) -> (weakref, version, device, int32 copy): `pos` is converted once per batch, not once per module
 
 
@@ -123,18 +125,22 @@ def _gat_layer_prepare(st, h, ld_h, pos, feat_p):
          st.H, st.D, ptr(st.Wp), feat_p, st.seed, ptr(st.mask), s)
 
 
-def _gat_collapse_fwd(csr, st, h, ld_h, pos, rpos, pw, feat_p, attn_p, attn_slope):
-    """output layer (one head) folded behind the weighted-mean readout: hg [G, D] (txe_gat_collapse_fwd)"""
+def _gat_collapse_fwd(csr, st, h, ld_h, pos, rpos, pw, feat_p, attn_p, attn_slope, a12=None):
+    """output layer (one head) folded behind the weighted-mean readout: hg [G, D] (txe_gat_collapse_fwd).
+    a12 given: the layer is already prepared and the previous layer's aggregation has formed its attention logits."""
     N, G, E = st.X.shape[0], csr.n_graphs, csr.n_edges
-    _gat_layer_prepare(st, h, ld_h, pos, feat_p)
-    a12, alpha, coef = _empty((max(N, 1), 2), st.X), _empty((max(E, 1),), st.X), _empty((max(N, 1),), st.X)
+    ready = a12 is not None
+    if not ready:
+        _gat_layer_prepare(st, h, ld_h, pos, feat_p)
+        a12 = _empty((max(N, 1), 2), st.X)
+    alpha, coef = _empty((max(E, 1),), st.X), _empty((max(N, 1),), st.X)
     wsum, Z, hg = _empty((max(G, 1),), st.X), _empty((max(G, 1), st.Kp), st.X), _empty((G, st.D), st.X)
     gid = torch.empty(max(N, 1), dtype=torch.int32, device=st.X.device)
     wsb = call("txe_gat_collapse_ws_bytes", N, E, G, st.Kh, st.Pd, st.D, 8)
     ws = _ws(wsb, st.X)
     call("txe_gat_collapse_fwd", ptr(csr.rowptr_in), ptr(csr.col_src), ptr(csr.rowptr_out), ptr(csr.col_dst), ptr(csr.pos_out),
          ptr(csr.graph_off), N, E, G, ptr(st.X), st.Kh, st.Pd, ptr(st.Wp), st.D, feat_p, ptr(st.mask), attn_slope, attn_p, st.seed + 1,
-         ptr(rpos), ptr(pw), ptr(a12), ptr(alpha), ptr(coef), ptr(wsum), ptr(gid), ptr(Z), ptr(hg), st.D, ptr(ws), wsb,
+         ptr(rpos), ptr(pw), ptr(a12), int(ready), ptr(alpha), ptr(coef), ptr(wsum), ptr(gid), ptr(Z), ptr(hg), st.D, ptr(ws), wsb,
          _lib.stream_ptr())
     st.cl = (a12, alpha, coef, wsum, gid, Z, hg)
     return hg
@@ -159,8 +165,9 @@ def _gat_collapse_bwd(csr, st, pos, rpos, pw, vocab, feat_p, attn_p, attn_slope,
     return d_X, dW, dal, dar, dP, d_pw
 
 
-def _gat_layer_fwd(csr, st, h, ld_h, pos, out, ld_out, feat_p, attn_p, attn_slope, out_mode, act_slope, save):
-    """st.X is pre-allocated [N, Kp]; h != None copies the raw features in, h == None means the producer already wrote them."""
+def _gat_layer_fwd(csr, st, h, ld_h, pos, out, ld_out, feat_p, attn_p, attn_slope, out_mode, act_slope, save, nxt=None):
+    """st.X is pre-allocated [N, Kp]; h != None copies the raw features in, h == None means the producer already wrote them.
+    nxt = (prepared state of the next, folded one-head layer, a12 buffer): its attention logits ride in the aggregation's epilogue."""
     N = st.X.shape[0]
     H, D, Kh, Pd, Kp, Fp = st.H, st.D, st.Kh, st.Pd, st.Kp, st.Fp
     F = H * D
@@ -171,7 +178,9 @@ def _gat_layer_fwd(csr, st, h, ld_h, pos, out, ld_out, feat_p, attn_p, attn_slop
     call("txe_gat_dense_fwd", ptr(st.X), N, Kh, Pd, ptr(st.Wp), H, D, feat_p, ptr(st.mask), ptr(st.Y), ptr(tws), tws.numel(), s)
     st.alpha = _empty((max(csr.n_edges, 1), H), st.X) if save else None
     call("txe_gat_aggregate_fwd", ptr(csr.rowptr_in), ptr(csr.col_src), N, ptr(st.Y), Fp, ptr(st.Y) + 4 * F, ptr(st.Y) + 4 * (F + H), Fp,
-         H, D, attn_slope, attn_p, st.seed + 1, out_mode, act_slope, ptr(out), ld_out, ptr(st.alpha), s)
+         H, D, attn_slope, attn_p, st.seed + 1, out_mode, act_slope, ptr(out), ld_out, ptr(st.alpha),
+         *((ptr(nxt[0].Wp) + 4 * nxt[0].D * nxt[0].Kp, nxt[0].Kp, ptr(nxt[0].mask), feat_p, ptr(nxt[1])) if nxt is not None
+           else (None, 0, None, 0.0, None)), s)
 
 
 def _gat_layer_bwd(csr, st, pos, vocab, feat_p, attn_p, attn_slope, d_pre, ld_dpre, need_dh, act_on, act_slope):
@@ -226,12 +235,13 @@ class GATStackFunction(torch.autograd.Function):
                 states.append(st)
                 kh = st.H * st.D
             states[0].X = _empty((N, states[0].Kp), h)
+            fused_a12 = None
             for l, st in enumerate(states):
                 last = (l == L - 1)
                 F = st.H * st.D
                 if last and collapse:
                     res = _gat_collapse_fwd(csr, st, h if l == 0 else None, ld_h if l == 0 else 0, pos if st.P is not None else None,
-                                            rpos, pwf, cfg.feat_p, cfg.attn_p, cfg.attn_slope)
+                                            rpos, pwf, cfg.feat_p, cfg.attn_p, cfg.attn_slope, a12=fused_a12)
                     if not need:
                         st.cl = st.mask = st.Wp = st.X = None
                     break
@@ -241,8 +251,16 @@ class GATStackFunction(torch.autograd.Function):
                     states[l + 1].X = _empty((N, states[l + 1].Kp), h)
                     out, ld_out = states[l + 1].X, states[l + 1].Kp
                 out_mode = 0 if (last or cfg.act_slope is None) else 1
+                nxt = None
+                if (collapse and l + 1 == L - 1 and N > 0 and st.D % 4 == 0 and states[l + 1].Kp - st.H * st.D <= 128 and states[l + 1].Kp <= 4096
+                        and not _NO_FUSED_LOGITS):
+                    # the folded output layer is prepared first: its keep mask and folded attention rows feed this layer's epilogue
+                    sn = states[l + 1]
+                    _gat_layer_prepare(sn, None, 0, pos if sn.P is not None else None, cfg.feat_p)
+                    fused_a12 = _empty((N, 2), h)
+                    nxt = (sn, fused_a12)
                 _gat_layer_fwd(csr, st, h if l == 0 else None, ld_h if l == 0 else 0, pos if st.P is not None else None, out, ld_out,
-                               cfg.feat_p, cfg.attn_p, cfg.attn_slope, out_mode, cfg.act_slope or 1.0, need)
+                               cfg.feat_p, cfg.attn_p, cfg.attn_slope, out_mode, cfg.act_slope or 1.0, need, nxt)
                 if not need:
                     st.Y = st.mask = st.Wp = None
                     if l > 0:

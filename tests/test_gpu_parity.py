@@ -305,7 +305,8 @@ def test_full_size_properties_mag_cs_batch():
     def agg(ft_):
         out, alpha = _empty((N, H * D), ft_), _empty((E, H), ft_)
         _lib.call("txe_gat_aggregate_fwd", csr.rowptr_in.data_ptr(), csr.col_src.data_ptr(), N, ft_.data_ptr(), H * D, a.data_ptr(),
-                  a.data_ptr() + 4 * H, 2 * H, H, D, 0.2, 0.0, 0, 0, 1.0, out.data_ptr(), H * D, alpha.data_ptr(), _lib.stream_ptr())
+                  a.data_ptr() + 4 * H, 2 * H, H, D, 0.2, 0.0, 0, 0, 1.0, out.data_ptr(), H * D, alpha.data_ptr(), None, 0, None, 0.0, None,
+                  _lib.stream_ptr())
         return out, alpha
     out1, alpha1 = agg(ft)
     out2, alpha2 = agg(ft)
@@ -824,3 +825,37 @@ def test_info_nce_loss_equals_torch_cross_entropy(B, C, zero_target):
     (l1 * 0.5).backward()
     (l2 * 0.5).backward()
     torch.testing.assert_close(x1.grad, x2.grad, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("drop", [0.0, 0.3])
+def test_attention_logits_fused_into_the_previous_aggregation(drop, monkeypatch):
+    """the folded output layer's logits formed in layer 0's aggregation epilogue (txe_gat_aggregate_fwd nx_*) against the separate
+    sweep (txe_gat_collapse_fwd a12_ready = 0): same model, same dropout seeds, forward and gradients"""
+    from taxoexpan_amd import TaxoExpan, ops
+    from taxoexpan_amd.graph import BatchedDGLGraph
+    dev = _dev()
+    rs = np.random.RandomState(11)
+    ks = rs.randint(1, 4, 40).tolist() + [1, 3]
+    ms = rs.randint(0, 9, 40).tolist() + [0, 60]
+    g = BatchedDGLGraph.from_egonet_shapes(ks, ms)
+    N = g.number_of_nodes()
+    x = torch.randn(N, 12, generator=torch.Generator().manual_seed(2)).to(dev)
+    q = torch.randn(len(ks), 12, generator=torch.Generator().manual_seed(3)).to(dev)
+    torch.manual_seed(9)
+    model = TaxoExpan("PGAT", "WMR", "LBM", in_dim=12, hidden_dim=20, out_dim=16, pos_dim=6, num_layers=1, heads=[4, 1], feat_drop=drop,
+                      attn_drop=drop).to(dev).train(drop > 0)
+    pos = g.ndata["pos"].clone()
+    outs = []
+    for no_fuse in (False, True):
+        monkeypatch.setattr(ops, "_NO_FUSED_LOGITS", no_fuse)
+        model.zero_grad(set_to_none=True)
+        g.ndata["pos"] = pos.clone()
+        torch.manual_seed(77)                                   # same dropout seeds in both passes
+        s = model(g, x, q)
+        (s * torch.linspace(0.5, 1.5, s.numel(), device=dev).reshape(s.shape)).sum().backward()
+        outs.append((s.detach().cpu().numpy(), {k: p.grad.cpu().numpy() for k, p in model.named_parameters()}))
+    (a, ga), (b, gb) = outs
+    np.testing.assert_allclose(a, b, rtol=1e-5, atol=1e-6)
+    for k in ga:
+        np.testing.assert_allclose(ga[k], gb[k], rtol=1e-3, atol=1e-5, err_msg=k)        # fp32 summation order of the logits differs

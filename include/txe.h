@@ -57,6 +57,12 @@ int txe_gat_build_x(const float* h, long long ld_h, int n_nodes, int Kh, const i
 int txe_gat_layer_prepare(const float* h, long long ld_h, int n_nodes, int Kh, const int* pos, const float* P, int Pd, float* X,
                           const float* W, const float* attn_l, const float* attn_r, int H, int D, float* Wp, float feat_drop_p,
                           unsigned long long seed, unsigned* mask, void* stream);
+
+/* Eval-mode layer-0 projection of a batch whose node features are rows of a taxonomy feature table (SURVEY 8f-2 "dedup by _id"):
+ * the projection T = table W^T is formed once per DISTINCT taxonomy node (txe_gemm_plain), T2 = the position rows' projections, and
+ * every batch node v gets Y[v] = T[row[v]] + T2[row2[v]].  n_cols % 4 == 0, 16-byte aligned rows; T2 / row2 may be NULL. */
+int txe_gather_add_rows(const float* T, long long ld_t, const int* row, const float* T2, long long ld_t2, const int* row2, long long n_rows,
+                        int n_cols, float* Y, long long ld_y, void* stream);
 size_t txe_gat_dense_ws_bytes(int n_nodes, int Kh, int Pd, int H, int D, int vocab);
 int txe_gat_dense_fwd(const float* X, int n_nodes, int Kh, int Pd, const float* Wp, int H, int D, float feat_drop_p,
                       const unsigned* mask, float* Y, void* ws, size_t ws_bytes, void* stream);

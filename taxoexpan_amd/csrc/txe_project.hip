@@ -316,6 +316,24 @@ __global__ void zero_cols_kernel(float* __restrict__ x, long long ld, int n_rows
         x[(i / wdt) * ld + c0 + (i % wdt)] = 0.f;
 }
 
+// Y[v][c] = T[row[v]][c] + T2[row2[v]][c]   (16-byte columns): the layer-0 projection of a batch whose node features are rows of a
+// taxonomy table -- T = table W^T computed once per DISTINCT taxonomy node, T2 = the 3 position-embedding rows' projections.
+__global__ __launch_bounds__(256) void gather_add_rows_kernel(const float* __restrict__ T, long long ld_t, const int* __restrict__ row,
+                                                              const float* __restrict__ T2, long long ld_t2, const int* __restrict__ row2,
+                                                              long long n_rows, int nvec, float* __restrict__ Y, long long ld_y) {
+    const long long total = n_rows * nvec;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long v = i / nvec;
+        const int j = (int)(i % nvec);
+        float4 a = *reinterpret_cast<const float4*>(T + (long long)row[v] * ld_t + 4 * j);
+        if (T2) {
+            const float4 b = *reinterpret_cast<const float4*>(T2 + (long long)row2[v] * ld_t2 + 4 * j);
+            a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+        }
+        *reinterpret_cast<float4*>(Y + v * ld_y + 4 * j) = a;
+    }
+}
+
 struct DenseWs {
     float* dwa;     // [2H][Kp]
     float* ppart;   // [nb][vocab][Pd]
@@ -402,6 +420,23 @@ int txe_gat_layer_prepare(const float* h, long long ld_h, int n_nodes, int Kh, c
     a.W = W; a.attn_l = attn_l; a.attn_r = attn_r; a.H = H; a.D = D; a.Wp = Wp;
     a.seed = seed; a.thr16 = (unsigned)(feat_drop_p * 65536.0f + 0.5f); a.mask = mask;
     hipLaunchKernelGGL(gat_prepare_kernel, dim3(a.nb_x + a.nb_m + a.nb_w + a.nb_f), dim3(T), 0, (hipStream_t)stream, a);
+    TXE_CHECK_LAUNCH();
+    return TXE_OK;
+}
+
+// Eval-mode layer-0 projection of a batch drawn from a feature table (SURVEY 8f-2 "dedup by _id"): Y[v] = T[row[v]] + T2[row2[v]],
+// n_cols a multiple of 4, 16-byte aligned rows.  T2 / row2 may be NULL.
+int txe_gather_add_rows(const float* T, long long ld_t, const int* row, const float* T2, long long ld_t2, const int* row2, long long n_rows,
+                        int n_cols, float* Y, long long ld_y, void* stream) {
+    if (n_rows < 0 || n_cols < 4 || (n_cols & 3) || !T || !row || !Y || (T2 && !row2) || (ld_t & 3) || (ld_y & 3) || (T2 && (ld_t2 & 3)))
+        return TXE_ERR_ARG;
+    if ((((uintptr_t)T | (uintptr_t)Y | (uintptr_t)T2) & 15) != 0) return TXE_ERR_ARG;
+    if (n_rows == 0) return TXE_OK;
+    const int nvec = n_cols / 4;
+    const long long total = n_rows * nvec;
+    const int nb = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+    ProfScope prof("gather_add_rows_kernel", (hipStream_t)stream, 4.0 * 2.0 * n_rows * (double)n_cols, 1);     // read a row, write a row
+    hipLaunchKernelGGL(gather_add_rows_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, T, ld_t, row, T2, ld_t2, row2, n_rows, nvec, Y, ld_y);
     TXE_CHECK_LAUNCH();
     return TXE_OK;
 }

@@ -25,7 +25,8 @@ def evaluate(model, dataset, device, larger_is_better=True, qblock=1024, seed=0)
     cand = sorted(dataset.all_positions)                                    # test_fast.py:93
     index = {a: i for i, a in enumerate(cand)}
     dtax = dataset.device_taxonomy(device)
-    g = device_egonet_batch(dtax, np.asarray(cand, dtype=np.int64), expand_factor=dataset.expand_factor, seed=seed)
+    g = device_egonet_batch(dtax, np.asarray(cand, dtype=np.int64), expand_factor=dataset.expand_factor, seed=seed,
+                            with_features="lazy")                           # x = features[_id]: the encoder projects the table once
     was_training = model.training
     model.eval()
     hg = encode_candidates(model, g)                                        # test_fast.py:99-108

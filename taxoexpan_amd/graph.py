@@ -317,7 +317,8 @@ class DeviceTaxonomy:
 
 def device_egonet_batch(dtax, anchors, exclude=None, expand_factor=50, seed=0, with_features=True):
     """Batched egonets of `anchors` built on the GPU (dataset.py:404-437 + dgl.batch).  anchors / exclude: int arrays or
-    int32 device tensors.  Returns a DeviceBatchedGraph with ndata '_id', 'pos' (int32, device) and 'x' (features gathered)."""
+    int32 device tensors.  Returns a DeviceBatchedGraph with ndata '_id', 'pos' (int32, device) and 'x' (features gathered;
+    with_features="lazy": an ops.GatheredRows over the taxonomy's feature table)."""
     dev = dtax.device
     to_dev = lambda a: None if a is None else (a.to(device=dev, dtype=torch.int32) if torch.is_tensor(a)
                                                else torch.as_tensor(np.asarray(a), dtype=torch.int32).to(dev))
@@ -342,5 +343,9 @@ def device_egonet_batch(dtax, anchors, exclude=None, expand_factor=50, seed=0, w
     csr = CSR(N, E, G, rowptr_in[:N + 1], col_src[:E], eid_in[:E], rowptr_out[:N + 1], col_dst[:E], pos_out[:E], node_off[:G + 1])
     g = DeviceBatchedGraph(csr, node_off[:G + 1], ids[:N], pos[:N])
     if with_features and dtax.features is not None:
-        g.ndata["x"] = dtax.features.index_select(0, ids[:N].long())
+        if with_features == "lazy":          # x = features[_id] kept symbolic: eval-mode encoders project the table once (ops.GatheredRows)
+            from .ops import GatheredRows
+            g.ndata["x"] = GatheredRows(dtax.features, ids[:N])
+        else:
+            g.ndata["x"] = dtax.features.index_select(0, ids[:N].long())
     return g

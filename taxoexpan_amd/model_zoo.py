@@ -77,7 +77,7 @@ class GCNLayer(nn.Module):
         """model_zoo.py:34-50 (the norm comes from in-degrees; g.ndata['norm'] is not needed)."""
         slope = _fused_slope(self.activation)
         cfg = ops.GCNConfig([self.weight.shape[1]], 0, [slope], [_p(self.dropout, self.training)], ops.new_seed())
-        out = ops.GCNStackFunction.apply(g.csr(h.device), cfg, h, None, None, None, self.weight, self.bias, None)
+        out = ops.apply_stack(ops.GCNStackFunction, g.csr(h.device), cfg, h, None, None, None, self.weight, self.bias, None)
         if self.activation and slope is None:
             out = self.activation(out)
         return out
@@ -112,7 +112,7 @@ class GATLayer(nn.Module):
             feature, p_feat = F.dropout(feature, p_feat, True), 0.0
         cfg = ops.GATConfig([self.num_heads], [self.out_dim], [0], 0, self.leaky_relu.negative_slope, None,
                             p_feat, _p(self.attn_drop, self.training), "none", ops.new_seed())
-        ret = ops.GATStackFunction.apply(g.csr(feature.device), cfg, feature, None, None, None, self.fc.weight, self.attn_l, self.attn_r, None)
+        ret = ops.apply_stack(ops.GATStackFunction, g.csr(feature.device), cfg, feature, None, None, None, self.fc.weight, self.attn_l, self.attn_r, None)
         if self.residual:                               # model_zoo.py:98-103 (never enabled by model.py)
             if self.res_fc is not None:
                 resval = ops.LinearFunction.apply(feature, None, self.res_fc.weight, None, 0).reshape((feature.shape[0], self.num_heads, -1))
@@ -139,7 +139,7 @@ def _gat_stack(layers, embeddings, g, h, pos, activation, training):
     if layers[-1].num_heads == 1 and not _NO_FOLD:
         # one-head output layer: a weighted-mean readout can fold it (ops 'collapse'); anything else materialises N x D
         return DeferredNodeOutput(g.csr(h.device), cfg, h, pos, params, ops.GATStackFunction)
-    return ops.GATStackFunction.apply(g.csr(h.device), cfg, h, pos, None, None, *params)
+    return ops.apply_stack(ops.GATStackFunction, g.csr(h.device), cfg, h, pos, None, None, *params)
 
 
 # TXE_NO_FOLD=1 switches the folded output layer off (A/B measurements, debugging): graph_propagate then returns the N x out tensor
@@ -167,7 +167,7 @@ class DeferredNodeOutput:
             return h.new_zeros((csr.n_graphs, self._out_dim()), dtype=torch.float32)
         c = copy.copy(cfg)
         c.final = "collapse"
-        return self._fn.apply(csr, c, h, pos, rpos, pw, *params)
+        return ops.apply_stack(self._fn, csr, c, h, pos, rpos, pw, *params)
 
     def tensor(self):
         if self._tensor is None:
@@ -175,7 +175,7 @@ class DeferredNodeOutput:
             if csr.n_nodes == 0:
                 self._tensor = h.new_zeros((0, self._out_dim()), dtype=torch.float32)
             else:
-                self._tensor = self._fn.apply(csr, cfg, h, pos, None, None, *params)
+                self._tensor = ops.apply_stack(self._fn, csr, cfg, h, pos, None, None, *params)
         return self._tensor
 
     def __getattr__(self, name):                    # .shape, .device, .detach(), .cpu(), ... of the node features
@@ -269,7 +269,7 @@ def _gcn_stack(layers, embeddings, g, h, pos, training):
     if slopes[-1] is None and not _NO_FOLD:
         # activation-free output layer: a weighted-mean readout can fold it (ops 'collapse'); anything else materialises N x out
         return DeferredNodeOutput(g.csr(h.device), cfg, h, pos, params, ops.GCNStackFunction)
-    return ops.GCNStackFunction.apply(g.csr(h.device), cfg, h, pos, None, None, *params)
+    return ops.apply_stack(ops.GCNStackFunction, g.csr(h.device), cfg, h, pos, None, None, *params)
 
 
 def _gat_layers(in_dim, hidden_dim, out_dim, extra, num_layers, heads, feat_drop, attn_drop, alpha, residual):

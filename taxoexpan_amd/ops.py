@@ -74,6 +74,137 @@ def new_seed():
     return int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
 
 
+def apply_stack(fn, csr, cfg, *args):
+    """fn.apply with the caller's grad mode recorded in cfg: inside Function.forward grad mode is always off and needs_input_grad
+    only mirrors requires_grad, so this is how a no_grad pass (evaluation) avoids keeping the backward state -- and may take the
+    table-projection path of GatheredRows."""
+    cfg.grad_enabled = torch.is_grad_enabled()
+    return fn.apply(csr, cfg, *args)
+
+
+# ================================================================================================================
+# Node features that are rows of a taxonomy feature table (SURVEY 8f-2 "dedup by _id")
+# ================================================================================================================
+class GatheredRows:
+    """x[v] = table[index[v]], kept symbolic.  The batched egonets of an evaluation repeat every taxonomy node many times (MAG-Full:
+    1.1 M batch nodes over 431 k taxonomy nodes); without dropout the first layer's projection depends only on (taxonomy node,
+    position), so PGAT / PGCN in eval mode project the TABLE once (`projection_cache()` keeps it across the chunks of one evaluation)
+    and gather.  Every other consumer sees the ordinary [N, d] tensor (materialised on first use)."""
+
+    def __init__(self, table, index):
+        self.table, self.index = table, index
+        self._tensor = None
+
+    shape = property(lambda self: torch.Size((self.index.shape[0], self.table.shape[1])))
+    device = property(lambda self: self.table.device)
+    dtype = property(lambda self: self.table.dtype)
+    is_cuda = property(lambda self: self.table.is_cuda)
+    requires_grad = False
+
+    def dim(self):
+        return 2
+
+    def size(self, d=None):
+        return self.shape if d is None else self.shape[d]
+
+    def to(self, *args, **kwargs):
+        t = self.table.to(*args, **kwargs)
+        return self if t is self.table else GatheredRows(t, self.index.to(t.device))
+
+    def tensor(self):
+        if self._tensor is None:
+            self._tensor = self.table.index_select(0, self.index.long())
+        return self._tensor
+
+    def __getattr__(self, name):
+        if name.startswith("_"):
+            raise AttributeError(name)
+        return getattr(self.tensor(), name)
+
+    def __getitem__(self, idx):
+        return self.tensor()[idx]
+
+    def __len__(self):
+        return int(self.index.shape[0])
+
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        from torch.utils._pytree import tree_map
+        owner = getattr(func, "__self__", None)
+        if isinstance(owner, type) and issubclass(owner, torch.autograd.Function) and getattr(owner, "accepts_gathered_rows", False):
+            with torch._C.DisableTorchFunctionSubclass():       # our own encoders take the symbolic form as it is
+                return func(*args, **(kwargs or {}))
+        un = lambda a: a.tensor() if isinstance(a, GatheredRows) else a
+        return func(*tree_map(un, tuple(args)), **tree_map(un, dict(kwargs or {})))
+
+    def __add__(self, other):
+        return self.tensor() + other
+
+    __radd__ = __add__
+
+    def __mul__(self, other):
+        return self.tensor() * other
+
+    __rmul__ = __mul__
+
+    def __repr__(self):
+        return f"GatheredRows(table={tuple(self.table.shape)}, rows={int(self.index.shape[0])})"
+
+
+_NO_DEDUP = os.environ.get("TXE_NO_DEDUP", "0") == "1"        # A/B switch: always materialise GatheredRows
+_PROJ_CACHE = None
+
+
+class projection_cache:
+    """`with projection_cache():` -- table projections (first-layer W applied to a whole feature table) are reused by every
+    forward inside the block.  Only for a scope in which the weights do not change (one evaluation pass)."""
+
+    def __enter__(self):
+        global _PROJ_CACHE
+        self._prev, _PROJ_CACHE = _PROJ_CACHE, ({} if _PROJ_CACHE is None else _PROJ_CACHE)
+        return self
+
+    def __exit__(self, *exc):
+        global _PROJ_CACHE
+        _PROJ_CACHE = self._prev
+        return False
+
+
+def _use_table(h, need, feat_p):
+    """project the table instead of the batch?  only without gradients / dropout, and when it is less work (or already cached)"""
+    return (isinstance(h, GatheredRows) and not need and feat_p == 0.0 and not _NO_DEDUP and h.table.is_cuda and h.table.dim() == 2
+            and h.table.dtype == torch.float32 and h.table.is_contiguous()
+            and (_PROJ_CACHE is not None or h.table.shape[0] <= h.index.shape[0]))
+
+
+def _gat_table_projection(st, src):
+    """(T [n_table, Fp], T2 [vocab, Fp] or None): the packed first-layer weights applied to every row of the feature table and to the
+    position-embedding rows -- features, a1 and a2 columns alike (they are all linear in the input)."""
+    key = ("gat", src.table.data_ptr(), tuple(src.table.shape), st.W.data_ptr(), st.al.data_ptr(), None if st.P is None else st.P.data_ptr())
+    if _PROJ_CACHE is not None and key in _PROJ_CACHE:
+        return _PROJ_CACHE[key]
+    tab = src.table
+    n_tab, Kh, Kp, Fp = tab.shape[0], st.Kh, st.Kp, st.Fp
+    s = _lib.stream_ptr()
+    Kt = call("txe_gat_padded_k", Kh, 0)
+    Xt = _empty((n_tab, Kt), tab)
+    call("txe_gat_build_x", ptr(tab), tab.stride(0), n_tab, Kh, None, None, 0, ptr(Xt), s)
+    Wp = _empty((Fp, Kp), tab)
+    call("txe_gat_pack_weights", ptr(st.W), ptr(st.al), ptr(st.ar), st.H, st.D, Kh + st.Pd, ptr(Wp), s)
+    tws = _tail_ws(tab)
+    T = _empty((n_tab, Fp), tab)
+    # the padding columns [Kh, Kt) of Xt are zero, so whatever Wp holds there (position columns) does not contribute
+    call("txe_gemm_plain", 0, ptr(Xt), Kt, ptr(Wp), Kp, ptr(T), Fp, n_tab, Fp, min(Kt, Kp), 1, ptr(tws), tws.numel(), s)
+    T2 = None
+    if st.Pd > 0:
+        T2 = _empty((st.P.shape[0], Fp), tab)
+        call("txe_gemm_plain", 0, ptr(st.P), st.Pd, ptr(Wp) + 4 * Kh, Kp, ptr(T2), Fp, st.P.shape[0], Fp, st.Pd, 1, None, 0, s)
+    if _PROJ_CACHE is not None:
+        _PROJ_CACHE[key] = (T, T2, Wp, src.table, st.W)          # (operands kept alive: the key holds their addresses)
+        return _PROJ_CACHE[key]
+    return T, T2
+
+
 # ================================================================================================================
 # GAT stack (PGAT / GAT / a single GATLayer)
 # ================================================================================================================
@@ -168,15 +299,22 @@ def _gat_collapse_bwd(csr, st, pos, rpos, pw, vocab, feat_p, attn_p, attn_slope,
 def _gat_layer_fwd(csr, st, h, ld_h, pos, out, ld_out, feat_p, attn_p, attn_slope, out_mode, act_slope, save, nxt=None):
     """st.X is pre-allocated [N, Kp]; h != None copies the raw features in, h == None means the producer already wrote them.
     nxt = (prepared state of the next, folded one-head layer, a12 buffer): its attention logits ride in the aggregation's epilogue."""
-    N = st.X.shape[0]
     H, D, Kh, Pd, Kp, Fp = st.H, st.D, st.Kh, st.Pd, st.Kp, st.Fp
     F = H * D
     s = _lib.stream_ptr()
-    _gat_layer_prepare(st, h, ld_h, pos, feat_p)
-    st.Y = _empty((N, Fp), st.X)
-    tws = _tail_ws(st.X)
-    call("txe_gat_dense_fwd", ptr(st.X), N, Kh, Pd, ptr(st.Wp), H, D, feat_p, ptr(st.mask), ptr(st.Y), ptr(tws), tws.numel(), s)
-    st.alpha = _empty((max(csr.n_edges, 1), H), st.X) if save else None
+    if isinstance(h, GatheredRows):            # eval-mode first layer on table rows: project the table, gather (SURVEY 8f-2)
+        N = h.index.shape[0]
+        T, T2 = _gat_table_projection(st, h)[:2]
+        st.Y = _empty((N, Fp), T)
+        call("txe_gather_add_rows", ptr(T), Fp, ptr(_i32(h.index, T.device)), ptr(T2), Fp, ptr(pos) if T2 is not None else None, N, Fp,
+             ptr(st.Y), Fp, s)
+    else:
+        N = st.X.shape[0]
+        _gat_layer_prepare(st, h, ld_h, pos, feat_p)
+        st.Y = _empty((N, Fp), st.X)
+        tws = _tail_ws(st.X)
+        call("txe_gat_dense_fwd", ptr(st.X), N, Kh, Pd, ptr(st.Wp), H, D, feat_p, ptr(st.mask), ptr(st.Y), ptr(tws), tws.numel(), s)
+    st.alpha = _empty((max(csr.n_edges, 1), H), st.Y) if save else None
     call("txe_gat_aggregate_fwd", ptr(csr.rowptr_in), ptr(csr.col_src), N, ptr(st.Y), Fp, ptr(st.Y) + 4 * F, ptr(st.Y) + 4 * (F + H), Fp,
          H, D, attn_slope, attn_p, st.seed + 1, out_mode, act_slope, ptr(out), ld_out, ptr(st.alpha),
          *((ptr(nxt[0].Wp) + 4 * nxt[0].D * nxt[0].Kp, nxt[0].Kp, ptr(nxt[0].mask), feat_p, ptr(nxt[1])) if nxt is not None
@@ -208,21 +346,31 @@ class GATStackFunction(torch.autograd.Function):
     """params per layer: (W [H*D, Kin], attn_l [1,H,D], attn_r [1,H,D], P [vocab, Pd] or None).
     cfg.final: 'mean' -> N x D (PGAT / GAT), 'none' -> N x H x D (GATLayer), 'collapse' -> G x D: the one-head output layer folded
     behind MeanReadout (pw None) / WeightedMeanReadout (pw = position_weights.weight, rpos = node positions)."""
+    accepts_gathered_rows = True
 
     @staticmethod
     def forward(ctx, csr, cfg, h, pos, rpos, pw, *params):
-        _need_cuda(h, *[p for p in params if p is not None])
-        h, ld_h = _rows(h)
-        pos = _i32(pos, h.device)
+        need = getattr(cfg, "grad_enabled", True) and any(ctx.needs_input_grad)     # (see apply_stack)
         collapse = (cfg.final == "collapse")
+        table = _use_table(h, need, cfg.feat_p) and not (collapse and cfg.n_layers == 1)
+        if isinstance(h, GatheredRows) and not table:
+            h = h.tensor()
+        if table:
+            _need_cuda(h.table, *[p for p in params if p is not None])
+            src, ld_h = h, 0
+        else:
+            _need_cuda(h, *[p for p in params if p is not None])
+            h, ld_h = _rows(h)
+            src = h
+        pos = _i32(pos, h.device)
         rpos = _i32(rpos, h.device) if (collapse and pw is not None) else None
         pwf = _f32(pw.reshape(-1)) if (collapse and pw is not None) else None
         L = cfg.n_layers
-        need = any(ctx.needs_input_grad)       # (grad mode itself is off inside Function.forward)
         N = h.shape[0]
         states = []
         with torch.cuda.device(h.device):
             kh = h.shape[1]
+            ref = h.table if table else h
             for l in range(L):
                 st = _GatLayerState()
                 st.W, st.al, st.ar, st.P = (_f32(p) for p in params[4 * l:4 * l + 4])
@@ -234,13 +382,14 @@ class GATStackFunction(torch.autograd.Function):
                 st.X = None
                 states.append(st)
                 kh = st.H * st.D
-            states[0].X = _empty((N, states[0].Kp), h)
+            h = ref                                  # (allocation reference from here on; the features travel as `src`)
+            states[0].X = None if table else _empty((N, states[0].Kp), h)
             fused_a12 = None
             for l, st in enumerate(states):
                 last = (l == L - 1)
                 F = st.H * st.D
                 if last and collapse:
-                    res = _gat_collapse_fwd(csr, st, h if l == 0 else None, ld_h if l == 0 else 0, pos if st.P is not None else None,
+                    res = _gat_collapse_fwd(csr, st, src if l == 0 else None, ld_h if l == 0 else 0, pos if st.P is not None else None,
                                             rpos, pwf, cfg.feat_p, cfg.attn_p, cfg.attn_slope, a12=fused_a12)
                     if not need:
                         st.cl = st.mask = st.Wp = st.X = None
@@ -259,7 +408,7 @@ class GATStackFunction(torch.autograd.Function):
                     _gat_layer_prepare(sn, None, 0, pos if sn.P is not None else None, cfg.feat_p)
                     fused_a12 = _empty((N, 2), h)
                     nxt = (sn, fused_a12)
-                _gat_layer_fwd(csr, st, h if l == 0 else None, ld_h if l == 0 else 0, pos if st.P is not None else None, out, ld_out,
+                _gat_layer_fwd(csr, st, src if l == 0 else None, ld_h if l == 0 else 0, pos if st.P is not None else None, out, ld_out,
                                cfg.feat_p, cfg.attn_p, cfg.attn_slope, out_mode, cfg.act_slope or 1.0, need, nxt)
                 if not need:
                     st.Y = st.mask = st.Wp = None
@@ -359,7 +508,7 @@ class GCNStackFunction(torch.autograd.Function):
         rpos = _i32(rpos, h.device) if (collapse and pw is not None) else None
         pwf = _f32(pw.reshape(-1)) if (collapse and pw is not None) else None
         L = cfg.n_layers
-        need = any(ctx.needs_input_grad)       # (grad mode itself is off inside Function.forward)
+        need = getattr(cfg, "grad_enabled", True) and any(ctx.needs_input_grad)     # (see apply_stack)
         N = h.shape[0]
         states = []
         with torch.cuda.device(h.device):

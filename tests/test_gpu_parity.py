@@ -859,3 +859,48 @@ def test_attention_logits_fused_into_the_previous_aggregation(drop, monkeypatch)
     np.testing.assert_allclose(a, b, rtol=1e-5, atol=1e-6)
     for k in ga:
         np.testing.assert_allclose(ga[k], gb[k], rtol=1e-3, atol=1e-5, err_msg=k)        # fp32 summation order of the logits differs
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("prop", ["PGAT", "GAT"])
+def test_eval_encode_on_table_rows_equals_materialised_features(prop, monkeypatch):
+    """SURVEY 8f-2 'dedup by _id': device-built egonets whose features stay rows of the taxonomy table (ops.GatheredRows) -- the
+    eval-mode layer-0 projection is formed once per taxonomy node and gathered -- against the same batch with gathered features;
+    chunked with the projection cache; training mode and TXE_NO_DEDUP fall back to the ordinary path"""
+    from taxoexpan_amd import TaxoExpan, ops, synthetic as syn, graph as G
+    from taxoexpan_amd.scoring import encode_candidates
+    dev = _dev()
+    tax = syn.make_taxonomy(600, 900, 12, seed=4)
+    dtax = G.DeviceTaxonomy(tax.par_ptr, tax.par_idx, tax.chd_ptr, tax.chd_idx, tax.features, dev)
+    torch.manual_seed(3)
+    kw = dict(in_dim=12, hidden_dim=20, out_dim=16, num_layers=1, heads=[4, 1], feat_drop=0.2, attn_drop=0.2)
+    if prop == "PGAT":
+        kw["pos_dim"] = 6
+    model = TaxoExpan(prop, "WMR" if prop == "PGAT" else "MR", "LBM", **kw).to(dev).eval()
+    cand = np.arange(600, dtype=np.int64)                       # every node twice: more batch nodes than table rows
+    chunks = [np.concatenate([cand, cand])[i:i + 500] for i in range(0, 1200, 500)]
+    lazy = [G.device_egonet_batch(dtax, c, seed=5, with_features="lazy") for c in chunks]
+    full = [G.device_egonet_batch(dtax, c, seed=5) for c in chunks]
+    assert isinstance(lazy[0].ndata["x"], ops.GatheredRows)
+    calls = []
+    orig = ops._gat_table_projection
+    monkeypatch.setattr(ops, "_gat_table_projection", lambda st, src: (calls.append(1), orig(st, src))[1])
+    hg_l = encode_candidates(model, lazy)
+    hg_f = encode_candidates(model, full)
+    assert len(calls) == len(chunks)                            # the table path ran (its projection is cached after the first chunk)
+    np.testing.assert_allclose(hg_l.cpu().numpy(), hg_f.cpu().numpy(), rtol=1e-4, atol=1e-5)
+    # the lazy features are an ordinary tensor for every other consumer
+    x = lazy[0].ndata["x"]
+    assert tuple(x.shape) == tuple(full[0].ndata["x"].shape) and torch.equal(x + 0, full[0].ndata["x"])
+    # training mode (dropout) and the A/B switch use the materialised path, same results as gathered features given the seed
+    calls.clear()
+    model.train()
+    outs = []
+    for g in (lazy[0], full[0]):
+        pos = g.ndata["pos"]
+        torch.manual_seed(1)
+        g.ndata["h"] = model.graph_propagate(g, g.ndata["x"])
+        outs.append(model.readout(g, pos).detach().cpu().numpy())
+        g.ndata["pos"] = pos
+    assert not calls
+    np.testing.assert_allclose(outs[0], outs[1], rtol=1e-5, atol=1e-6)

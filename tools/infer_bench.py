@@ -65,6 +65,21 @@ hg = encode_candidates(model, graphs)
 torch.cuda.synchronize()
 t_enc = time.perf_counter() - t0
 
+# the same candidates as device-built batches whose features stay rows of the taxonomy table: the eval-mode layer-0 projection runs
+# once per taxonomy node and is gathered (SURVEY 8f-2 "dedup by _id")
+lgraphs = [G.device_egonet_batch(dtax, c, seed=7, with_features="lazy") for c in chunks]
+hg_l = encode_candidates(model, lgraphs)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+hg_l = encode_candidates(model, lgraphs)
+torch.cuda.synchronize()
+t_enc_dedup = time.perf_counter() - t0
+mgraphs = [G.device_egonet_batch(dtax, c, seed=7) for c in chunks]
+hg_m = encode_candidates(model, mgraphs)
+dedup_err = float((hg_l - hg_m).abs().max() / hg_m.abs().max())
+n_edges_dev = sum(g.number_of_edges() for g in lgraphs)
+del mgraphs, hg_m
+
 if args.profile:
     import ctypes
     from taxoexpan_amd import _lib
@@ -127,6 +142,7 @@ assert torch.equal(ranks_f.cpu(), ranks.cpu()), "fused ranks differ from the mat
 pairs = float(len(cand)) * len(test)
 print(json.dumps(dict(shape=args.shape, candidates=int(len(cand)), queries=int(len(test)), nodes=n_nodes, edges=n_edges,
                       encoder_batches=len(graphs), host_taxonomy_s=t_tax, host_egonet_build_and_upload_s=t_build, device_egonet_build_s=t_dbuild,
-                      encode_s=t_enc, encode_edges_per_s=n_edges / t_enc, score_and_rank_s=t_score,
+                      encode_s=t_enc, encode_edges_per_s=n_edges / t_enc, encode_dedup_s=t_enc_dedup,
+                      encode_dedup_edges_per_s=n_edges_dev / t_enc_dedup, dedup_max_rel_err=dedup_err, score_and_rank_s=t_score,
                       candidates_scored_per_s=pairs / t_score, fused_score_and_rank_s=t_fused, candidates_scored_per_s_fused=pairs / t_fused, candidates_scored_per_s_incl_encode=pairs / (t_score + t_enc),
                       mean_rank=float(ranks.float().mean()), hbm_gb=torch.cuda.max_memory_allocated() / 1e9)))

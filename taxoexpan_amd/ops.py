@@ -205,6 +205,33 @@ def _gat_table_projection(st, src):
     return T, T2
 
 
+def _gcn_table_projection(st, src):
+    """(T [n_table, Fop], T2 [vocab, Fop] or None): the first GCNLayer's weight applied to every table row / position-embedding row"""
+    key = ("gcn", src.table.data_ptr(), tuple(src.table.shape), st.W.data_ptr(), None if st.P is None else st.P.data_ptr())
+    if _PROJ_CACHE is not None and key in _PROJ_CACHE:
+        return _PROJ_CACHE[key]
+    tab = src.table
+    n_tab, Kh, Fop = tab.shape[0], st.Kh, st.Fop
+    s = _lib.stream_ptr()
+    Kt = call("txe_gat_padded_k", Kh, 0)
+    Xt = _empty((n_tab, Kt), tab)
+    call("txe_gat_build_x", ptr(tab), tab.stride(0), n_tab, Kh, None, None, 0, ptr(Xt), s)
+    kp128 = (st.Kp + 127) // 128 * 128
+    Wp = _empty((kp128, Fop), tab)                 # [Kh + Pd (padded)][Fop]: feature rows first, then the position rows
+    call("txe_gcn_pack_weights", ptr(st.W), Kh + st.Pd, st.Fo, ptr(Wp), s)
+    tws = _tail_ws(tab)
+    T = _empty((n_tab, Fop), tab)
+    call("txe_gemm_plain", 1, ptr(Xt), Kt, ptr(Wp), Fop, ptr(T), Fop, n_tab, Fop, min(Kt, kp128), 1, ptr(tws), tws.numel(), s)
+    T2 = None
+    if st.Pd > 0:
+        T2 = _empty((st.P.shape[0], Fop), tab)
+        call("txe_gemm_plain", 1, ptr(st.P), st.Pd, ptr(Wp) + 4 * Kh * Fop, Fop, ptr(T2), Fop, st.P.shape[0], Fop, st.Pd, 1, None, 0, s)
+    if _PROJ_CACHE is not None:
+        _PROJ_CACHE[key] = (T, T2, Wp, src.table, st.W)
+        return _PROJ_CACHE[key]
+    return T, T2
+
+
 # ================================================================================================================
 # GAT stack (PGAT / GAT / a single GATLayer)
 # ================================================================================================================
@@ -499,22 +526,32 @@ class GCNStackFunction(torch.autograd.Function):
     cfg.final == 'collapse': G x Fo -- the (activation-free) output layer folded behind MeanReadout (pw None) /
     WeightedMeanReadout (txe_gcn_collapse_*)."""
 
+    accepts_gathered_rows = True
+
     @staticmethod
     def forward(ctx, csr, cfg, h, pos, rpos, pw, *params):
-        _need_cuda(h, *[p for p in params if p is not None])
-        h, ld_h = _rows(h)
-        pos = _i32(pos, h.device)
         collapse = (getattr(cfg, "final", None) == "collapse")
-        rpos = _i32(rpos, h.device) if (collapse and pw is not None) else None
-        pwf = _f32(pw.reshape(-1)) if (collapse and pw is not None) else None
         L = cfg.n_layers
         need = getattr(cfg, "grad_enabled", True) and any(ctx.needs_input_grad)     # (see apply_stack)
-        N = h.shape[0]
+        table = _use_table(h, need, cfg.drop_ps[0]) and not (collapse and L == 1)
+        if isinstance(h, GatheredRows) and not table:
+            h = h.tensor()
+        src = h if table else None                 # features as rows of a table: layer 0 projects the table (SURVEY 8f-2)
+        if table:
+            _need_cuda(h.table, *[p for p in params if p is not None])
+            N, kh0, ld_h, h = h.index.shape[0], h.table.shape[1], 0, h.table       # h: allocation reference from here on
+        else:
+            _need_cuda(h, *[p for p in params if p is not None])
+            h, ld_h = _rows(h)
+            N, kh0 = h.shape
+        pos = _i32(pos, h.device)
+        rpos = _i32(rpos, h.device) if (collapse and pw is not None) else None
+        pwf = _f32(pw.reshape(-1)) if (collapse and pw is not None) else None
         states = []
         with torch.cuda.device(h.device):
             st_ = _lib.stream_ptr()
             norm = gcn_norm(csr, h)
-            kh = h.shape[1]
+            kh = kh0
             for l in range(L):
                 st = _GcnLayerState()
                 st.W, st.b, st.P = (_f32(p) for p in params[3 * l:3 * l + 3])
@@ -526,16 +563,17 @@ class GCNStackFunction(torch.autograd.Function):
                 st.X = None
                 states.append(st)
                 kh = st.Fo
-            states[0].X = _empty((N, states[0].Kp), h)
+            states[0].X = None if table else _empty((N, states[0].Kp), h)
             tws = _tail_ws(h)
             for l, st in enumerate(states):
                 last = (l == L - 1)
-                call("txe_gat_build_x", ptr(h if l == 0 else None), ld_h if l == 0 else 0, N, st.Kh, ptr(pos if st.P is not None else None),
-                     ptr(st.P), st.Pd, ptr(st.X), st_)
-                kp128 = (st.Kp + 127) // 128 * 128
-                st.Wp = _empty((kp128, st.Fop), h)
-                call("txe_gcn_pack_weights", ptr(st.W), st.Kh + st.Pd, st.Fo, ptr(st.Wp), st_)
-                st.mask = dropout_mask(N, st.Kh + st.Pd, cfg.drop_ps[l], st.seed, h)
+                if not (table and l == 0):
+                    call("txe_gat_build_x", ptr(h if l == 0 else None), ld_h if l == 0 else 0, N, st.Kh,
+                         ptr(pos if st.P is not None else None), ptr(st.P), st.Pd, ptr(st.X), st_)
+                    kp128 = (st.Kp + 127) // 128 * 128
+                    st.Wp = _empty((kp128, st.Fop), h)
+                    call("txe_gcn_pack_weights", ptr(st.W), st.Kh + st.Pd, st.Fo, ptr(st.Wp), st_)
+                    st.mask = dropout_mask(N, st.Kh + st.Pd, cfg.drop_ps[l], st.seed, h)
                 if last and collapse:
                     G = csr.n_graphs
                     coef, wsum = _empty((max(N, 1),), h), _empty((max(G, 1),), h)
@@ -551,8 +589,14 @@ class GCNStackFunction(torch.autograd.Function):
                         st.cl = st.mask = st.Wp = st.X = None
                     break
                 hw = _empty((N, st.Fop), h)
-                call("txe_gcn_dense_fwd", ptr(st.X), N, st.Kh, st.Pd, ptr(st.Wp), st.Fo, cfg.drop_ps[l], ptr(st.mask), ptr(hw), ptr(tws),
-                     tws.numel(), st_)
+                if table and l == 0:
+                    T, T2 = _gcn_table_projection(st, src)[:2]
+                    call("txe_gather_add_rows", ptr(T), st.Fop, ptr(_i32(src.index, h.device)), ptr(T2), st.Fop,
+                         ptr(pos) if T2 is not None else None, N, st.Fop, ptr(hw), st.Fop, st_)
+                    st.mask = st.Wp = None
+                else:
+                    call("txe_gcn_dense_fwd", ptr(st.X), N, st.Kh, st.Pd, ptr(st.Wp), st.Fo, cfg.drop_ps[l], ptr(st.mask), ptr(hw), ptr(tws),
+                         tws.numel(), st_)
                 if last:
                     out, ld_out = _empty((N, st.Fo), h), st.Fo
                 else:

@@ -862,7 +862,7 @@ def test_attention_logits_fused_into_the_previous_aggregation(drop, monkeypatch)
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("prop", ["PGAT", "GAT"])
+@pytest.mark.parametrize("prop", ["PGAT", "GAT", "PGCN"])
 def test_eval_encode_on_table_rows_equals_materialised_features(prop, monkeypatch):
     """SURVEY 8f-2 'dedup by _id': device-built egonets whose features stay rows of the taxonomy table (ops.GatheredRows) -- the
     eval-mode layer-0 projection is formed once per taxonomy node and gathered -- against the same batch with gathered features;
@@ -873,8 +873,8 @@ def test_eval_encode_on_table_rows_equals_materialised_features(prop, monkeypatc
     tax = syn.make_taxonomy(600, 900, 12, seed=4)
     dtax = G.DeviceTaxonomy(tax.par_ptr, tax.par_idx, tax.chd_ptr, tax.chd_idx, tax.features, dev)
     torch.manual_seed(3)
-    kw = dict(in_dim=12, hidden_dim=20, out_dim=16, num_layers=1, heads=[4, 1], feat_drop=0.2, attn_drop=0.2)
-    if prop == "PGAT":
+    kw = dict(in_dim=12, hidden_dim=20, out_dim=16, num_layers=1, heads=[4, 1], feat_drop=0.2, attn_drop=0.2, hidden_drop=0.2, out_drop=0.0)
+    if prop != "GAT":
         kw["pos_dim"] = 6
     model = TaxoExpan(prop, "WMR" if prop == "PGAT" else "MR", "LBM", **kw).to(dev).eval()
     cand = np.arange(600, dtype=np.int64)                       # every node twice: more batch nodes than table rows
@@ -883,8 +883,9 @@ def test_eval_encode_on_table_rows_equals_materialised_features(prop, monkeypatc
     full = [G.device_egonet_batch(dtax, c, seed=5) for c in chunks]
     assert isinstance(lazy[0].ndata["x"], ops.GatheredRows)
     calls = []
-    orig = ops._gat_table_projection
-    monkeypatch.setattr(ops, "_gat_table_projection", lambda st, src: (calls.append(1), orig(st, src))[1])
+    name = "_gcn_table_projection" if prop == "PGCN" else "_gat_table_projection"
+    orig = getattr(ops, name)
+    monkeypatch.setattr(ops, name, lambda st, src: (calls.append(1), orig(st, src))[1])
     hg_l = encode_candidates(model, lazy)
     hg_f = encode_candidates(model, full)
     assert len(calls) == len(chunks)                            # the table path ran (its projection is cached after the first chunk)

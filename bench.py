@@ -201,6 +201,20 @@ def extra_metrics(model, tax, device, batches, target):
         hg = encode_candidates(model, g)
         torch.cuda.synchronize()
         t_enc = time.perf_counter() - t0
+        # the same candidates as device-built egonets whose features stay rows of the taxonomy table (evaluate.py's path): the
+        # layer-0 projection runs once per taxonomy node
+        from taxoexpan_amd import graph as G
+        dtax = G.DeviceTaxonomy(tax.par_ptr, tax.par_idx, tax.chd_ptr, tax.chd_idx, tax.features, device)
+        gl = G.device_egonet_batch(dtax, cand, seed=7, with_features="lazy")
+        hg_l = encode_candidates(model, gl)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        hg_l = encode_candidates(model, gl)
+        torch.cuda.synchronize()
+        t_enc_l = time.perf_counter() - t0
+        out["infer_encode_dedup_s"] = t_enc_l
+        out["infer_encode_dedup_edges_per_s"] = gl.number_of_edges() / t_enc_l
+        del hg_l, gl
         S = score_all(model.match, hg, queries)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -251,7 +265,7 @@ def extra_metrics_sharded(model, device, world, rank, n_queries=8192, qblock=102
         test = test[:n_queries]
         lo, hi = shard_bounds(len(cand), world, rank)
         dtax = G.DeviceTaxonomy(tax.par_ptr, tax.par_idx, tax.chd_ptr, tax.chd_idx, tax.features, device)
-        g = G.device_egonet_batch(dtax, cand[lo:hi], seed=7)
+        g = G.device_egonet_batch(dtax, cand[lo:hi], seed=7, with_features="lazy")    # (a shard smaller than the table gathers as usual)
         queries = tax.features[torch.from_numpy(test)].to(device)
         hg = encode_candidates(model, g)                                   # warm-up
         torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()

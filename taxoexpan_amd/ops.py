@@ -156,12 +156,18 @@ _PROJ_CACHE = None
 
 
 class projection_cache:
-    """`with projection_cache():` -- table projections (first-layer W applied to a whole feature table) are reused by every
-    forward inside the block.  Only for a scope in which the weights do not change (one evaluation pass)."""
+    """`with projection_cache(expected_rows):` -- table projections (first-layer W applied to a whole feature table) are reused by
+    every forward inside the block.  Only for a scope in which the weights do not change (one evaluation pass).  expected_rows =
+    how many batch nodes the pass will encode in total: the table is projected only if it has fewer rows than that (or than the
+    batch at hand)."""
+
+    def __init__(self, expected_rows=0):
+        self.expected_rows = int(expected_rows)
 
     def __enter__(self):
         global _PROJ_CACHE
         self._prev, _PROJ_CACHE = _PROJ_CACHE, ({} if _PROJ_CACHE is None else _PROJ_CACHE)
+        _PROJ_CACHE["expected_rows"] = max(_PROJ_CACHE.get("expected_rows", 0), self.expected_rows)
         return self
 
     def __exit__(self, *exc):
@@ -174,7 +180,7 @@ def _use_table(h, need, feat_p):
     """project the table instead of the batch?  only without gradients / dropout, and when it is less work (or already cached)"""
     return (isinstance(h, GatheredRows) and not need and feat_p == 0.0 and not _NO_DEDUP and h.table.is_cuda and h.table.dim() == 2
             and h.table.dtype == torch.float32 and h.table.is_contiguous()
-            and (_PROJ_CACHE is not None or h.table.shape[0] <= h.index.shape[0]))
+            and h.table.shape[0] <= max(h.index.shape[0], 0 if _PROJ_CACHE is None else _PROJ_CACHE.get("expected_rows", 0)))
 
 
 def _gat_table_projection(st, src):

@@ -32,7 +32,8 @@ def encode_candidates(model, graph, chunk=None, device=None):
     graphs = graph if isinstance(graph, (list, tuple)) else [graph]
     device = device or next(model.parameters()).device
     outs = []
-    with torch.no_grad(), ops.projection_cache():       # weights are fixed for the pass: table projections are shared by the chunks
+    total = sum(int(bg.number_of_nodes()) for bg in graphs)
+    with torch.no_grad(), ops.projection_cache(total):   # weights are fixed for the pass: table projections are shared by the chunks
         for bg in graphs:
             h = bg.ndata['x'].to(device, non_blocking=True)
             pos = bg.ndata['pos'].to(device)

@@ -86,7 +86,7 @@ if args.profile:
     lib = _lib.load()
     lib.txe_profile_reset()
     lib.txe_profile_enable(1)
-    encode_candidates(model, graphs)
+    encode_candidates(model, lgraphs if os.environ.get("TXE_PROFILE_DEDUP", "0") == "1" else graphs)
     torch.cuda.synchronize()
     lib.txe_profile_enable(0)
     buf = ctypes.create_string_buffer(64)

@@ -1,4 +1,4 @@
-"""`torch.optim.Adam` as the reference configures it (train.py:88 `config.initialize('optimizer', torch.optim, ...)`,
+"""`torch.optim.Adam` as the reference configures it (train.py:36 `config.initialize('optimizer', torch.optim, ...)`,
 config.mag.json:66-73: Adam, lr 1e-3, weight_decay 0, amsgrad true), stepped by ONE HIP launch over all parameter tensors
 (txe_adam_step).  Same constructor arguments, same `state_dict()` layout (step / exp_avg / exp_avg_sq / max_exp_avg_sq per
 parameter), so optimizer checkpoints written by base_trainer.py:104-121 load into either class.  There is no CPU path."""

@@ -905,3 +905,23 @@ def test_eval_encode_on_table_rows_equals_materialised_features(prop, monkeypatc
         g.ndata["pos"] = pos
     assert not calls
     np.testing.assert_allclose(outs[0], outs[1], rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.gpu
+def test_adam_step_many_tensors_and_empty_ones():
+    """more tensors than one launch's argument table holds (24), zero-element parameters, a single element"""
+    from taxoexpan_amd.optim import Adam
+    dev = torch.device("cuda:0")
+    torch.manual_seed(8)
+    shapes = [(i % 7 + 1, (i * 13) % 11) for i in range(40)] + [(1,), (0,), (1025,)]
+    mine = [torch.randn(s, device=dev).requires_grad_(True) for s in shapes]
+    ref = [p.detach().clone().requires_grad_(True) for p in mine]
+    o1, o2 = Adam(mine, lr=3e-3, amsgrad=True), torch.optim.Adam(ref, lr=3e-3, amsgrad=True)
+    for _ in range(3):
+        for a, b in zip(mine, ref):
+            g = torch.randn_like(a)
+            a.grad, b.grad = g.clone(), g.clone()
+        o1.step()
+        o2.step()
+    for a, b in zip(mine, ref):
+        torch.testing.assert_close(a, b, rtol=2e-6, atol=1e-7)

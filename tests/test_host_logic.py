@@ -136,3 +136,50 @@ def test_metrics_match_reference_metric_py():
         assert abs(getattr(metric, name)(ranks, off) - z[name]) <= 1e-12 * max(1.0, abs(z[name])), name
     lists = metric.as_rank_lists(ranks, off)
     assert len(lists) == len(z["pos_off"]) - 1 and sum(len(r) for r in lists) == len(z["ranks"])
+
+
+def test_gathered_rows_is_an_ordinary_tensor_to_everyone_else():
+    """ops.GatheredRows (node features kept as rows of the taxonomy table): shape / device / arithmetic / torch
+    functions / indexing see table[index]; the projection cache nests and remembers the largest expected row count"""
+    import torch
+    from taxoexpan_amd import ops
+    table = torch.arange(15, dtype=torch.float32).reshape(5, 3)
+    idx = torch.tensor([4, 0, 0, 2], dtype=torch.int32)
+    x = ops.GatheredRows(table, idx)
+    want = table[idx.long()]
+    assert tuple(x.shape) == (4, 3) and x.dim() == 2 and len(x) == 4 and x.device == table.device and x.dtype == torch.float32
+    assert torch.equal(x.tensor(), want) and torch.equal(x + 1, want + 1) and torch.equal(2 * x, 2 * want)
+    assert torch.equal(torch.cat([x, x], 0), torch.cat([want, want], 0)) and torch.equal(x[1], want[1]) and torch.equal(x.sum(1), want.sum(1))
+    assert x.to(table.device) is x and "GatheredRows" in repr(x)
+    assert ops._PROJ_CACHE is None
+    with ops.projection_cache(10):
+        assert ops._PROJ_CACHE["expected_rows"] == 10
+        with ops.projection_cache(3):
+            assert ops._PROJ_CACHE["expected_rows"] == 10
+        assert ops._PROJ_CACHE is not None
+    assert ops._PROJ_CACHE is None
+    # the table path needs a GPU, no gradients and no dropout: on the host it is never chosen
+    assert not ops._use_table(x, False, 0.0) and not ops._use_table(want, False, 0.0)
+
+
+def test_loss_and_optimizer_have_no_cpu_path():
+    """taxoexpan_amd.loss / optim mirror model/loss.py:52-57 and torch.optim.Adam's constructor, and fail loudly off the GPU"""
+    import pytest
+    import torch
+    from taxoexpan_amd.loss import info_nce_loss
+    from taxoexpan_amd.optim import Adam
+    with pytest.raises(RuntimeError):
+        info_nce_loss(torch.zeros(4, 3), torch.zeros(4, dtype=torch.long))
+    with pytest.raises(ValueError):
+        info_nce_loss(torch.zeros(4), None)
+    p = torch.nn.Parameter(torch.zeros(3))
+    with pytest.raises(ValueError):
+        Adam([p], lr=-1.0)
+    with pytest.raises(ValueError):
+        Adam([p], betas=(0.9, 1.0))
+    opt = Adam([p], lr=1e-3, amsgrad=True)
+    assert opt.defaults == dict(lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, amsgrad=True)
+    opt.step()                                   # no gradient yet: nothing to do, nothing launched
+    p.grad = torch.ones(3)
+    with pytest.raises(RuntimeError):
+        opt.step()

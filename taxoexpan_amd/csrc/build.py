@@ -16,7 +16,7 @@ HEADERS = ["txe_common.h", "txe_gemm.h", "txe_gather.h"]
 LIB = os.path.join(HERE, "libtxe.so")
 OBJ_DIR = os.path.join(HERE, "build")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"] + os.environ.get("TXE_HIPCC_FLAGS", "").split()
 
 
 def _newer(a, b):

@@ -18,6 +18,11 @@
 namespace txe {
 
 constexpr int SLICE_NI = 2;      // feature vectors per lane of a wave that owns a quarter of a row
+#ifndef TXE_SPLIT_LIGHT_DEG
+#define TXE_SPLIT_LIGHT_DEG 16
+#endif
+constexpr bool SPLIT_HYBRID = TXE_SPLIT_LIGHT_DEG > 0;
+constexpr int SPLIT_LIGHT_DEG = TXE_SPLIT_LIGHT_DEG;   // largest out-degree a workgroup's nodes may have for the wave-per-node path
 
 // ------------------------------------------------------------------------------------------------
 // forward
@@ -384,17 +389,13 @@ __global__ __launch_bounds__(GAT_WAVES * 64) void gat_bwd_edge_kernel(
 //   d_ft[u] = sum_{e=(u->v)} a_drop[e] * d_pre[v]        d_a_src[u,h] = sum_{e=(u->v)} dz[e,h]
 // pos_out[j] = position of out-edge j in the destination-sorted order (where alpha / dz live).
 // ------------------------------------------------------------------------------------------------
+// one wave, one source node u, the whole H*D row
 template <int VEC, int NI>
-__global__ __launch_bounds__(GAT_WAVES * 64) void gat_bwd_node_kernel(
-    const int* __restrict__ rowptr_out, const int* __restrict__ col_dst, const int* __restrict__ pos_out, const int n_nodes,
+__device__ __forceinline__ void bwd_node_wave(const int u, const int l, float* __restrict__ s_w, int* __restrict__ s_idx,
+    const int* __restrict__ rowptr_out, const int* __restrict__ col_dst, const int* __restrict__ pos_out,
     const float* __restrict__ alpha, const float* __restrict__ dz, const int H, const int D, const float drop_p,
     const float drop_scale, const unsigned long long seed, const float* __restrict__ d_pre, const long long ld_dpre,
     float* __restrict__ d_ft, const long long ld_dft, float* __restrict__ d_a_src, const int ld_da) {
-    __shared__ float s_w[GAT_WAVES][GAT_MAXH * 64];
-    __shared__ int s_idx[GAT_WAVES][64];
-    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
-    const int u = xcd_remap(blockIdx.x, gridDim.x) * GAT_WAVES + w;
-    if (u >= n_nodes) return;
     const int beg = rowptr_out[u], end = rowptr_out[u + 1];
 
     for (int h = 0; h < H; ++h) {
@@ -419,15 +420,15 @@ __global__ __launch_bounds__(GAT_WAVES * 64) void gat_bwd_node_kernel(
             const int j = cb + l;
             if (j < end) {
                 const int q = pos_out[j];
-                s_idx[w][l] = col_dst[j];
+                s_idx[l] = col_dst[j];
                 for (int h = 0; h < H; ++h) {
                     float f = 1.f;
                     if (drop_p > 0.f) f = drop_factor(seed, (unsigned long long)q * H + h, drop_p, drop_scale);
-                    s_w[w][h * 64 + l] = alpha[(long long)q * H + h] * f;
+                    s_w[h * 64 + l] = alpha[(long long)q * H + h] * f;
                 }
             }
             __builtin_amdgcn_wave_barrier();
-            gather_rows<VEC, NI, (NI >= 8 ? 1 : 2)>(d_pre, ld_dpre, s_idx[w], s_w[w], min(64, end - cb), t0, nvec, hidx, acc);
+            gather_rows<VEC, NI, (NI >= 8 ? 1 : 2)>(d_pre, ld_dpre, s_idx, s_w, min(64, end - cb), t0, nvec, hidx, acc);
             __builtin_amdgcn_wave_barrier();
         }
 #pragma unroll
@@ -436,6 +437,22 @@ __global__ __launch_bounds__(GAT_WAVES * 64) void gat_bwd_node_kernel(
             if (j < nvec) vstore<VEC>(d_ft + (long long)u * ld_dft + (long long)j * VEC, acc[i]);
         }
     }
+}
+
+
+template <int VEC, int NI>
+__global__ __launch_bounds__(GAT_WAVES * 64) void gat_bwd_node_kernel(
+    const int* __restrict__ rowptr_out, const int* __restrict__ col_dst, const int* __restrict__ pos_out, const int n_nodes,
+    const float* __restrict__ alpha, const float* __restrict__ dz, const int H, const int D, const float drop_p,
+    const float drop_scale, const unsigned long long seed, const float* __restrict__ d_pre, const long long ld_dpre,
+    float* __restrict__ d_ft, const long long ld_dft, float* __restrict__ d_a_src, const int ld_da) {
+    __shared__ float s_w[GAT_WAVES][GAT_MAXH * 64];
+    __shared__ int s_idx[GAT_WAVES][64];
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    const int u = xcd_remap(blockIdx.x, gridDim.x) * GAT_WAVES + w;
+    if (u >= n_nodes) return;
+    bwd_node_wave<VEC, NI>(u, l, s_w[w], s_idx[w], rowptr_out, col_dst, pos_out, alpha, dz, H, D, drop_p, drop_scale, seed, d_pre, ld_dpre,
+                           d_ft, ld_dft, d_a_src, ld_da);
 }
 
 // Workgroup-cooperative variant for wide rows: the 4 waves of a workgroup share each of its 4 source nodes, every wave
@@ -472,6 +489,20 @@ __global__ __launch_bounds__(GAT_WAVES * 64) void gat_bwd_node_split_kernel(
         const int u = min(node0 + t, n_nodes - 1);
         nbeg[t] = rowptr_out[u];
         nend[t] = (node0 + t < n_nodes) ? rowptr_out[u + 1] : nbeg[t];
+    }
+    // Light workgroup (the usual one: an egonet's parents and siblings have 1-2 out-edges, its anchor a handful): one wave per
+    // node sweeps its whole row with 8 independent 16-byte loads per edge -- the cooperative path below has two loads in flight
+    // per lane and edge and walks its four nodes one after the other, which only pays when a node feeds many destinations.
+    if (SPLIT_HYBRID) {
+        int maxdeg = 0;
+#pragma unroll
+        for (int t = 0; t < GAT_WAVES; ++t) maxdeg = max(maxdeg, nend[t] - nbeg[t]);
+        if (maxdeg <= SPLIT_LIGHT_DEG && nvec <= 512) {                  // workgroup-uniform
+            if (node0 + w < n_nodes)
+                bwd_node_wave<VEC, 8>(node0 + w, l, s_w[w], s_idx[w], rowptr_out, col_dst, pos_out, alpha, dz, H, D, drop_p, drop_scale, seed,
+                                      d_pre, ld_dpre, d_ft, ld_dft, d_a_src, ld_da);
+            return;
+        }
     }
     if (pre) {
 #pragma unroll

@@ -100,11 +100,11 @@ int txe_adam_step(int n_tensors, float* const* params, const float* const* grads
     c.step_size = (float)(lr / bc1);
     c.bc2_sqrt = (float)sqrt(bc2);
     const bool ams = max_exp_avg_sq != nullptr;
-    for (int t0 = 0; t0 < n_tensors; t0 += ADAM_MAX_T) {
+    for (int t = 0; t < n_tensors;) {                  // one launch per ADAM_MAX_T non-empty tensors
         AdamTable T;
         T.count = 0;
         long long chunks = 0, elems = 0;
-        for (int t = t0; t < n_tensors && T.count < ADAM_MAX_T; ++t) {
+        for (; t < n_tensors && T.count < ADAM_MAX_T; ++t) {
             if (numel[t] < 0) return TXE_ERR_ARG;
             if (numel[t] == 0) continue;
             if (!params[t] || !grads[t] || !exp_avg[t] || !exp_avg_sq[t] || (ams && !max_exp_avg_sq[t])) return TXE_ERR_ARG;

@@ -253,11 +253,15 @@ static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 // Wp[f][k] = W[f][k] (f < F, k < Kt) else 0   (rows F..Fe are written by fold_attn_kernel)
 __device__ __forceinline__ void pack_w_job(const int bid, const int nb, const float* __restrict__ W, int F, int Fe, int Fp, int Kt, int Kp,
                                            float* __restrict__ Wp) {
-    const long long n = (long long)Fp * Kp;
-    for (long long i = (long long)bid * blockDim.x + threadIdx.x; i < n; i += (long long)nb * blockDim.x) {
-        const int f = (int)(i / Kp), k = (int)(i % Kp);
-        if (f >= F && f < Fe && k < Kt) continue;              // folded rows: other job
-        Wp[i] = (f < F && k < Kt) ? W[(long long)f * Kt + k] : 0.f;
+    // one wave per packed row (32-bit index math only): W rows are Kt floats apart, Wp rows Kp
+    const int wpb = blockDim.x >> 6, wv = threadIdx.x >> 6, l = threadIdx.x & 63;
+    for (int f = bid * wpb + wv; f < Fp; f += nb * wpb) {
+        if (f >= F && f < Fe) {                                  // folded rows: other job writes [0, Kt); zero the padding here
+            for (int k = Kt + l; k < Kp; k += 64) Wp[(long long)f * Kp + k] = 0.f;
+            continue;
+        }
+        const float* src = W + (long long)(f < F ? f : 0) * Kt;
+        for (int k = l; k < Kp; k += 64) Wp[(long long)f * Kp + k] = (f < F && k < Kt) ? src[k] : 0.f;
     }
 }
 __global__ void pack_w_kernel(const float* __restrict__ W, int F, int Fe, int Fp, int Kt, int Kp, float* __restrict__ Wp) {
@@ -267,16 +271,19 @@ __global__ void pack_w_kernel(const float* __restrict__ W, int F, int Fe, int Fp
 // X[r][c] = h[r][c] (c < Kh, only when h != NULL) | P[pos[r]][c-Kh] (Kh <= c < Kt) | 0 (Kt <= c < Kp)
 __device__ __forceinline__ void build_x_job(const int bid, const int nb, const float* __restrict__ h, long long ld_h, const int* __restrict__ pos,
                                             const float* __restrict__ P, int n_rows, int Kh, int Pd, int Kp, float* __restrict__ X) {
+    // one wave per row, lanes along the columns: no per-element division, coalesced reads of h / P and writes of X
+    const int wpb = blockDim.x >> 6, wv = threadIdx.x >> 6, l = threadIdx.x & 63;
     const int c0 = h ? 0 : Kh;
-    const int wdt = Kp - c0;
-    const long long n = (long long)n_rows * wdt;
-    for (long long i = (long long)bid * blockDim.x + threadIdx.x; i < n; i += (long long)nb * blockDim.x) {
-        const long long r = i / wdt;
-        const int c = c0 + (int)(i % wdt);
-        float v = 0.f;
-        if (c < Kh) v = h[r * ld_h + c];
-        else if (c < Kh + Pd) v = P[(long long)pos[r] * Pd + (c - Kh)];
-        X[r * Kp + c] = v;
+    for (int r = bid * wpb + wv; r < n_rows; r += nb * wpb) {
+        const float* hrow = h ? h + (long long)r * ld_h : nullptr;
+        const float* prow = (Pd > 0) ? P + (long long)pos[r] * Pd : nullptr;
+        float* xrow = X + (long long)r * Kp;
+        for (int c = c0 + l; c < Kp; c += 64) {
+            float v = 0.f;
+            if (c < Kh) v = hrow[c];
+            else if (c < Kh + Pd) v = prow[c - Kh];
+            xrow[c] = v;
+        }
     }
 }
 __global__ void build_x_kernel(const float* __restrict__ h, long long ld_h, const int* __restrict__ pos, const float* __restrict__ P,
@@ -410,10 +417,10 @@ int txe_gat_layer_prepare(const float* h, long long ld_h, int n_nodes, int Kh, c
     a.F = H * D; a.Fe = a.F + 2 * H; a.Fp = round_up(a.Fe, 128);
     auto blocks = [&](long long n, int cap) { const long long b = (n + T - 1) / T; return (int)(b < cap ? b : cap); };
     const long long nx = (long long)n_nodes * (a.Kp - (h ? 0 : Kh));
-    a.nb_x = blocks(nx, 2048);
+    a.nb_x = nx > 0 ? blocks((long long)n_nodes * 64, 2048) : 0;          // one wave per row
     a.n_words = (feat_drop_p > 0.f) ? (long long)n_nodes * ((a.Kt + 31) / 32) : 0;
     a.nb_m = blocks(a.n_words, 1024);
-    a.nb_w = blocks((long long)a.Fp * a.Kp, 512);
+    a.nb_w = blocks((long long)a.Fp * 64, 512);                            // one wave per packed row
     a.fold_bx = (a.Kt + 63) / 64;
     a.nb_f = a.fold_bx * 2 * H;
     a.h = h; a.ld_h = ld_h; a.pos = pos; a.P = P; a.n_rows = n_nodes; a.Kh = Kh; a.Pd = Pd; a.X = X;

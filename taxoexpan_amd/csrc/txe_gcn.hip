@@ -2,6 +2,7 @@
 //     norm = in_degree^-1/2 (inf -> 0);  out = act( norm[v] * sum_{e=(u->v)} norm[u] * hw[u]  + bias )
 // Same wave-per-destination row gather as the GAT kernel (txe_gather.h) with per-source weights norm[u].
 #include "txe_gather.h"
+#include "txe_colsum.h"
 
 namespace txe {
 
@@ -66,24 +67,6 @@ __global__ __launch_bounds__(GAT_WAVES * 64) void gcn_aggregate_kernel(const int
     }
 }
 
-// two-stage deterministic column sum: part[b][j] = sum_{m in block b} x[m][j] * (act_src ? leaky'(act_src[m][j]) : 1)
-__global__ void colsum_stage1(const float* __restrict__ x, long long ldx, int n_rows, int cols, int rows_per_block,
-                              float* __restrict__ part) {
-    const int r0 = blockIdx.x * rows_per_block, r1 = min(n_rows, r0 + rows_per_block);
-    for (int j = threadIdx.x; j < cols; j += blockDim.x) {
-        float acc = 0.f;
-        for (int m = r0; m < r1; ++m) acc += x[(long long)m * ldx + j];
-        part[(long long)blockIdx.x * cols + j] = acc;
-    }
-}
-__global__ void colsum_stage2(const float* __restrict__ part, int nb, int cols, float* __restrict__ out) {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= cols) return;
-    float acc = 0.f;
-    for (int b = 0; b < nb; ++b) acc += part[(long long)b * cols + j];
-    out[j] = acc;
-}
-
 static inline int gcn_pick_vec(int F, long long ld1, long long ld2, const void* p1, const void* p2) {
     auto al = [](const void* p, int bytes) { return ((uintptr_t)p % bytes) == 0; };
     if (F % 4 == 0 && ld1 % 4 == 0 && ld2 % 4 == 0 && al(p1, 16) && al(p2, 16)) return 4;
@@ -133,10 +116,7 @@ int txe_gcn_aggregate_fwd(const int* rowptr_in, const int* col_src, int n_nodes,
     return gcn_launch(rowptr_in, col_src, n_nodes, hw, ld_hw, norm, bias, has_act, act_slope, F, out, ld_out, (hipStream_t)stream);
 }
 
-size_t txe_gcn_aggregate_bwd_ws_bytes(int n_nodes, int F) {
-    const int nb = (n_nodes + 255) / 256 > 0 ? (n_nodes + 255) / 256 : 1;
-    return (size_t)nb * F * 4;
-}
+size_t txe_gcn_aggregate_bwd_ws_bytes(int n_nodes, int F) { return colsum_ws_bytes(n_nodes, F); }
 
 // d_pre: gradient w.r.t. the pre-activation output (caller applies leaky' first, e.g. txe_leaky_relu_bwd).
 // d_hw[u] = norm[u] * sum_{u->v} norm[v] d_pre[v];  d_bias = column sum of d_pre (may be NULL).
@@ -151,13 +131,8 @@ int txe_gcn_aggregate_bwd(const int* rowptr_out, const int* col_dst, int n_nodes
     }
     if (d_bias) {
         if (!ws || ws_bytes < txe_gcn_aggregate_bwd_ws_bytes(n_nodes, F)) return TXE_ERR_WORKSPACE;
-        const int nb = (n_nodes + 255) / 256;
-        if (nb > 0) {
-            hipLaunchKernelGGL(colsum_stage1, dim3(nb), dim3(128), 0, s, d_pre, ld_dpre, n_nodes, F, 256, (float*)ws);
-            TXE_CHECK_LAUNCH();
-        }
-        hipLaunchKernelGGL(colsum_stage2, dim3((F + 127) / 128), dim3(128), 0, s, (const float*)ws, nb, F, d_bias);
-        TXE_CHECK_LAUNCH();
+        const int rc = colsum_launch(d_pre, ld_dpre, n_nodes, F, (float*)ws, d_bias, s);
+        if (rc) return rc;
     }
     return TXE_OK;
 }

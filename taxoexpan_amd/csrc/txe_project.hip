@@ -15,6 +15,7 @@
 
 #include "txe_gemm.h"
 #include "txe_gather.h"
+#include "txe_colsum.h"
 
 namespace txe {
 
@@ -1260,21 +1261,8 @@ __global__ void gcl_add_bias_kernel(float* __restrict__ y, long long ld, int row
         y[(i / cols) * ld + (i % cols)] += b[i % cols];
 }
 
-// out[f] = sum_g x[g][f]     (one block per 64 columns, fixed order)
-__global__ __launch_bounds__(256) void gcl_colsum_kernel(const float* __restrict__ x, long long ld, int rows, int cols, float* __restrict__ out) {
-    __shared__ float red[4][64];
-    const int jl = threadIdx.x & 63, rg = threadIdx.x >> 6;
-    const int j = blockIdx.x * 64 + jl;
-    const int jc = j < cols ? j : 0;
-    float acc = 0.f;
-    for (int r = rg; r < rows; r += 4) acc += x[(long long)r * ld + jc];
-    red[rg][jl] = acc;
-    __syncthreads();
-    if (rg == 0 && j < cols) out[j] = red[0][jl] + red[1][jl] + red[2][jl] + red[3][jl];
-}
-
 struct GclWs {
-    float *dZ, *part, *dc, *cn, *dS, *dwv, *ppart, *ppart2;
+    float *dZ, *part, *dc, *cn, *dS, *dwv, *ppart, *ppart2, *cpart;
     void* tail;
     size_t tail_bytes, total;
     int splits, seg_blocks, seg_rows;
@@ -1298,6 +1286,7 @@ static GclWs plan_gcl_ws(void* ws, int n, int G, int Kp, int Fop, int Pd, int vo
     if (p.seg_blocks < 1) p.seg_blocks = 1;
     p.ppart = take((size_t)p.seg_blocks * v1 * (Pd > 0 ? Pd : 1) * 4);
     p.ppart2 = take((size_t)p.seg_blocks * v1 * 4);
+    p.cpart = take(colsum_ws_bytes(G, Fop));
     p.tail_bytes = gemm_tail_ws_bytes();
     p.tail = take(p.tail_bytes);
     p.total = off;
@@ -1408,8 +1397,8 @@ int txe_gcn_collapse_bwd(const int* rowptr_in, const int* col_src, const int* gr
         TXE_CHECK_LAUNCH();
     }
     if (d_b) {
-        hipLaunchKernelGGL(gcl_colsum_kernel, dim3((Fo + 63) / 64), dim3(256), 0, s, d_hg, ld_dhg, G, Fo, d_b);
-        TXE_CHECK_LAUNCH();
+        rc = colsum_launch(d_hg, ld_dhg, G, Fo, p.cpart, d_b, s);
+        if (rc) return rc;
     }
     if (G > 0 && n_nodes > 0) {
         const int nb = (n_nodes + 3) / 4;

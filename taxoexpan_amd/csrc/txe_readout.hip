@@ -217,10 +217,13 @@ __global__ void readout_dpw_reduce_kernel(const float* __restrict__ part, int G,
 // mode 1 SUM   : hg[g][d]       = sum_v h[v][d]
 // mode 2 MAX   : hg[g][d]       = max_v h[v][d]            (argmax[g][d] = first maximiser, for backward)
 // mode 3 CONCAT: hg[g][c*D + d] = sum_{v: pos_v == c} h[v][d] * s_c,  s_0 = s_2 = 1/n_g,  s_1 = 1/#{pos == 1}   (c < 3)
-// One wavefront per egonet, lane = feature column (scalar loads: these variants are API completeness, not the hot path).
+// One wavefront per egonet; a lane owns RM_NB columns 64 apart, so every node costs RM_NB independent loads (first version: one
+// column at a time, one load in flight -- 126 us for the MAG batch; these variants are API completeness, not the hot path).
+constexpr int RM_NB = 8;
+template <int mode>
 __global__ __launch_bounds__(RO_WAVES * 64) void readout_multi_fwd_kernel(const int* __restrict__ goff, const int G,
                                                                           const float* __restrict__ h, const long long ld_h,
-                                                                          const int* __restrict__ pos, const int D, const int mode,
+                                                                          const int* __restrict__ pos, const int D,
                                                                           float* __restrict__ hg, int* __restrict__ argmax) {
     const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
     const int g = blockIdx.x * RO_WAVES + w;
@@ -232,38 +235,48 @@ __global__ __launch_bounds__(RO_WAVES * 64) void readout_multi_fwd_kernel(const 
         cnt1 = wave_sum(cnt1);
     }
     const float inv_n = 1.f / (float)(end - beg), inv_1 = 1.f / cnt1;
-    for (int d = l; d < D; d += 64) {
-        if (mode == 1) {
-            float a = 0.f;
-            for (int v = beg; v < end; ++v) a += h[(long long)v * ld_h + d];
-            hg[(long long)g * D + d] = a;
-        } else if (mode == 2) {
-            float a = -INFINITY;
-            int am = beg;
-            for (int v = beg; v < end; ++v) {
-                const float x = h[(long long)v * ld_h + d];
-                if (x > a) { a = x; am = v; }
+    for (int d0 = 0; d0 < D; d0 += 64 * RM_NB) {
+        int dc[RM_NB];
+        float a0[RM_NB], a1[RM_NB], a2[RM_NB];
+        int am[RM_NB];
+#pragma unroll
+        for (int i = 0; i < RM_NB; ++i) {
+            const int d = d0 + l + 64 * i;
+            dc[i] = (d < D) ? d : 0;                            // clamped: loads stay unconditional, results of dead slots are dropped
+            a0[i] = (mode == 2) ? -INFINITY : 0.f;
+            a1[i] = 0.f; a2[i] = 0.f; am[i] = beg;
+        }
+        for (int v = beg; v < end; ++v) {
+            const int pc = (mode == 3) ? pos[v] : 0;
+            float x[RM_NB];
+#pragma unroll
+            for (int i = 0; i < RM_NB; ++i) x[i] = h[(long long)v * ld_h + dc[i]];
+#pragma unroll
+            for (int i = 0; i < RM_NB; ++i) {
+                if (mode == 1) a0[i] += x[i];
+                else if (mode == 2) { if (x[i] > a0[i]) { a0[i] = x[i]; am[i] = v; } }
+                else { a0[i] += (pc == 0) ? x[i] : 0.f; a1[i] += (pc == 1) ? x[i] : 0.f; a2[i] += (pc == 2) ? x[i] : 0.f; }
             }
-            hg[(long long)g * D + d] = a;
-            if (argmax) argmax[(long long)g * D + d] = am;
-        } else {
-            float a0 = 0.f, a1 = 0.f, a2 = 0.f;
-            for (int v = beg; v < end; ++v) {
-                const float x = h[(long long)v * ld_h + d];
-                const int pc = pos[v];
-                a0 += (pc == 0) ? x : 0.f;
-                a1 += (pc == 1) ? x : 0.f;
-                a2 += (pc == 2) ? x : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < RM_NB; ++i) {
+            const int d = d0 + l + 64 * i;
+            if (d >= D) continue;
+            if (mode == 3) {
+                hg[(long long)g * 3 * D + d] = a0[i] * inv_n;
+                hg[(long long)g * 3 * D + D + d] = a1[i] * inv_1;
+                hg[(long long)g * 3 * D + 2 * D + d] = a2[i] * inv_n;
+            } else {
+                hg[(long long)g * D + d] = a0[i];
+                if (mode == 2 && argmax) argmax[(long long)g * D + d] = am[i];
             }
-            hg[(long long)g * 3 * D + d] = a0 * inv_n;
-            hg[(long long)g * 3 * D + D + d] = a1 * inv_1;
-            hg[(long long)g * 3 * D + 2 * D + d] = a2 * inv_n;
         }
     }
 }
 
+template <int mode>
 __global__ __launch_bounds__(RO_WAVES * 64) void readout_multi_bwd_kernel(const int* __restrict__ goff, const int G,
-                                                                          const int* __restrict__ pos, const int D, const int mode,
+                                                                          const int* __restrict__ pos, const int D,
                                                                           const float* __restrict__ d_hg, const int* __restrict__ argmax,
                                                                           float* __restrict__ d_h, const long long ld_dh) {
     const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
@@ -276,14 +289,37 @@ __global__ __launch_bounds__(RO_WAVES * 64) void readout_multi_bwd_kernel(const 
         cnt1 = wave_sum(cnt1);
     }
     const float inv_n = 1.f / (float)(end - beg), inv_1 = 1.f / cnt1;
-    for (int v = beg; v < end; ++v) {
-        const int pc = (mode == 3) ? pos[v] : 0;
-        for (int d = l; d < D; d += 64) {
-            float r;
-            if (mode == 1) r = d_hg[(long long)g * D + d];
-            else if (mode == 2) r = (argmax[(long long)g * D + d] == v) ? d_hg[(long long)g * D + d] : 0.f;
-            else r = (pc >= 0 && pc < 3) ? d_hg[(long long)g * 3 * D + (long long)pc * D + d] * (pc == 1 ? inv_1 : inv_n) : 0.f;
-            d_h[(long long)v * ld_dh + d] = r;
+    for (int d0 = 0; d0 < D; d0 += 64 * RM_NB) {
+        // the graph's gradient row(s) are fetched once per column slot, then every node's row is a pure store
+        float r0[RM_NB], r1[RM_NB], r2[RM_NB];
+        int am[RM_NB];
+#pragma unroll
+        for (int i = 0; i < RM_NB; ++i) {
+            const int d = d0 + l + 64 * i;
+            const int dcl = (d < D) ? d : 0;
+            if (mode == 3) {
+                r0[i] = d_hg[(long long)g * 3 * D + dcl] * inv_n;
+                r1[i] = d_hg[(long long)g * 3 * D + D + dcl] * inv_1;
+                r2[i] = d_hg[(long long)g * 3 * D + 2 * D + dcl] * inv_n;
+                am[i] = 0;
+            } else {
+                r0[i] = d_hg[(long long)g * D + dcl];
+                r1[i] = 0.f; r2[i] = 0.f;
+                am[i] = (mode == 2) ? argmax[(long long)g * D + dcl] : 0;
+            }
+        }
+        for (int v = beg; v < end; ++v) {
+            const int pc = (mode == 3) ? pos[v] : 0;
+#pragma unroll
+            for (int i = 0; i < RM_NB; ++i) {
+                const int d = d0 + l + 64 * i;
+                if (d >= D) continue;
+                float r;
+                if (mode == 1) r = r0[i];
+                else if (mode == 2) r = (am[i] == v) ? r0[i] : 0.f;
+                else r = (pc == 0) ? r0[i] : ((pc == 1) ? r1[i] : ((pc == 2) ? r2[i] : 0.f));
+                d_h[(long long)v * ld_dh + d] = r;
+            }
         }
     }
 }
@@ -360,8 +396,11 @@ int txe_readout_multi_fwd(const int* graph_off, int G, const float* h, long long
                           int* argmax, void* stream) {
     if (G < 0 || D < 1 || mode < 1 || mode > 3 || !graph_off || !h || !hg || (mode == 3 && !pos)) return TXE_ERR_ARG;
     if (G == 0) return TXE_OK;
-    hipLaunchKernelGGL(readout_multi_fwd_kernel, dim3((G + RO_WAVES - 1) / RO_WAVES), dim3(RO_WAVES * 64), 0, (hipStream_t)stream,
-                       graph_off, G, h, ld_h, pos, D, mode, hg, argmax);
+    const dim3 grid((G + RO_WAVES - 1) / RO_WAVES), block(RO_WAVES * 64);
+    hipStream_t s = (hipStream_t)stream;
+    if (mode == 1) hipLaunchKernelGGL(readout_multi_fwd_kernel<1>, grid, block, 0, s, graph_off, G, h, ld_h, pos, D, hg, argmax);
+    else if (mode == 2) hipLaunchKernelGGL(readout_multi_fwd_kernel<2>, grid, block, 0, s, graph_off, G, h, ld_h, pos, D, hg, argmax);
+    else hipLaunchKernelGGL(readout_multi_fwd_kernel<3>, grid, block, 0, s, graph_off, G, h, ld_h, pos, D, hg, argmax);
     TXE_CHECK_LAUNCH();
     return TXE_OK;
 }
@@ -371,8 +410,11 @@ int txe_readout_multi_bwd(const int* graph_off, int G, const int* pos, int D, in
     if (G < 0 || D < 1 || mode < 1 || mode > 3 || !graph_off || !d_hg || !d_h || (mode == 3 && !pos) || (mode == 2 && !argmax))
         return TXE_ERR_ARG;
     if (G == 0) return TXE_OK;
-    hipLaunchKernelGGL(readout_multi_bwd_kernel, dim3((G + RO_WAVES - 1) / RO_WAVES), dim3(RO_WAVES * 64), 0, (hipStream_t)stream,
-                       graph_off, G, pos, D, mode, d_hg, argmax, d_h, ld_dh);
+    const dim3 grid((G + RO_WAVES - 1) / RO_WAVES), block(RO_WAVES * 64);
+    hipStream_t s = (hipStream_t)stream;
+    if (mode == 1) hipLaunchKernelGGL(readout_multi_bwd_kernel<1>, grid, block, 0, s, graph_off, G, pos, D, d_hg, argmax, d_h, ld_dh);
+    else if (mode == 2) hipLaunchKernelGGL(readout_multi_bwd_kernel<2>, grid, block, 0, s, graph_off, G, pos, D, d_hg, argmax, d_h, ld_dh);
+    else hipLaunchKernelGGL(readout_multi_bwd_kernel<3>, grid, block, 0, s, graph_off, G, pos, D, d_hg, argmax, d_h, ld_dh);
     TXE_CHECK_LAUNCH();
     return TXE_OK;
 }

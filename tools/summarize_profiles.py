@@ -64,6 +64,27 @@ for kind, cname in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
             lines.append(f"| `{k}` | {n} | {b/n/1e6:.2f} | {b/n*factor/1e6:.2f} |")
     lines.append("")
 
+# MFMA pipe utilisation from counters: SQ_VALU_MFMA_BUSY_CYCLES (64 cycles per v_mfma_f32_32x32x2_f32, summed over the chip's
+# 1,024 SIMDs) against GRBM_GUI_ACTIVE (busy cycles, summed over the 8 XCDs), collected in their own pass
+f = os.path.join(src, "mfma_counter_collection.csv")
+if os.path.exists(f):
+    per = collections.defaultdict(lambda: collections.defaultdict(float))
+    cnt = collections.Counter()
+    for r in csv.DictReader(open(f)):
+        k = short(r["Kernel_Name"])
+        per[k][r["Counter_Name"]] += float(r["Counter_Value"])
+        if r["Counter_Name"] == "GRBM_GUI_ACTIVE":
+            cnt[k] += 1
+    lines += ["## --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE (tools/profile_workload.py)", "",
+              "utilisation = MFMA busy cycles / (GUI-active cycles per XCD x 1,024 SIMDs); the fp32 MFMA count is busy / 64", "",
+              "| kernel | launches | MFMAs per launch (M) | GUI-active cycles per XCD (k) | MFMA pipe utilisation |", "|---|---|---|---|---|"]
+    for k, c in sorted(per.items(), key=lambda kv: -kv[1].get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0)):
+        mf, gu, n = c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0), c.get("GRBM_GUI_ACTIVE", 0.0), cnt[k]
+        if mf <= 0 or gu <= 0 or n == 0:
+            continue
+        lines.append(f"| `{k}` | {n} | {mf / 64 / n / 1e6:.3f} | {gu / 8 / n / 1e3:.1f} | {mf / (gu / 8 * 1024):.3f} |")
+    lines.append("")
+
 open(os.path.join(out_dir, f"{tag}_summary.md"), "w").write("\n".join(lines) + "\n")
 if traffic:
     json.dump(traffic, open(os.path.join(out_dir, f"{tag}_traffic.json"), "w"), indent=1)

@@ -58,6 +58,10 @@ int txe_gat_layer_prepare(const float* h, long long ld_h, int n_nodes, int Kh, c
                           const float* W, const float* attn_l, const float* attn_r, int H, int D, float* Wp, float feat_drop_p,
                           unsigned long long seed, unsigned* mask, void* stream);
 
+/* the same for a GCNLayer (model_zoo.py:35-37): txe_gat_build_x + txe_gcn_pack_weights + txe_dropout_mask as ONE launch */
+int txe_gcn_layer_prepare(const float* h, long long ld_h, int n_nodes, int Kh, const int* pos, const float* P, int Pd, float* X,
+                          const float* W, int Fo, float* Wp, float drop_p, unsigned long long seed, unsigned* mask, void* stream);
+
 /* Eval-mode layer-0 projection of a batch whose node features are rows of a taxonomy feature table (SURVEY 8f-2 "dedup by _id"):
  * the projection T = table W^T is formed once per DISTINCT taxonomy node (txe_gemm_plain), T2 = the position rows' projections, and
  * every batch node v gets Y[v] = T[row[v]] + T2[row2[v]].  n_cols % 4 == 0, 16-byte aligned rows; T2 / row2 may be NULL. */

@@ -298,6 +298,7 @@ struct PrepArgs {
     int nb_x, nb_w, nb_f, nb_m, fold_bx;
     const float* h; long long ld_h; const int* pos; const float* P; int n_rows, Kh, Pd, Kp; float* X;
     const float *W, *attn_l, *attn_r; int H, D, F, Fe, Fp, Kt; float* Wp;
+    int pk_rows, pk_ext, pk_prows, pk_cols, pk_pcols;       // packing job: W [pk_rows][pk_cols] -> Wp [pk_prows][pk_pcols], rows [pk_rows, pk_ext) left to fold
     long long n_words; unsigned long long seed; unsigned thr16; unsigned* mask;
 };
 __global__ __launch_bounds__(64 * FOLD_DG) void gat_prepare_kernel(const PrepArgs a) {
@@ -309,7 +310,7 @@ __global__ __launch_bounds__(64 * FOLD_DG) void gat_prepare_kernel(const PrepArg
         return;
     }
     b -= a.nb_f;
-    if (b < a.nb_w) { pack_w_job(b, a.nb_w, a.W, a.F, a.Fe, a.Fp, a.Kt, a.Kp, a.Wp); return; }
+    if (b < a.nb_w) { pack_w_job(b, a.nb_w, a.W, a.pk_rows, a.pk_ext, a.pk_prows, a.pk_cols, a.pk_pcols, a.Wp); return; }
     b -= a.nb_w;
     if (b < a.nb_m) { dropout_mask_job(b, a.nb_m, a.n_words, a.seed, a.thr16, a.mask); return; }
     b -= a.nb_m;
@@ -426,8 +427,35 @@ int txe_gat_layer_prepare(const float* h, long long ld_h, int n_nodes, int Kh, c
     a.nb_f = a.fold_bx * 2 * H;
     a.h = h; a.ld_h = ld_h; a.pos = pos; a.P = P; a.n_rows = n_nodes; a.Kh = Kh; a.Pd = Pd; a.X = X;
     a.W = W; a.attn_l = attn_l; a.attn_r = attn_r; a.H = H; a.D = D; a.Wp = Wp;
+    a.pk_rows = a.F; a.pk_ext = a.Fe; a.pk_prows = a.Fp; a.pk_cols = a.Kt; a.pk_pcols = a.Kp;
     a.seed = seed; a.thr16 = (unsigned)(feat_drop_p * 65536.0f + 0.5f); a.mask = mask;
     hipLaunchKernelGGL(gat_prepare_kernel, dim3(a.nb_x + a.nb_m + a.nb_w + a.nb_f), dim3(T), 0, (hipStream_t)stream, a);
+    TXE_CHECK_LAUNCH();
+    return TXE_OK;
+}
+
+// The same for a GCNLayer (model_zoo.py:35-37): txe_gat_build_x + txe_gcn_pack_weights + txe_dropout_mask in one launch.
+// W [Kh+Pd][Fo] -> Wp [roundup(roundup(Kh+Pd,32),128)][roundup(Fo,32)]; mask may be NULL when drop_p == 0.
+int txe_gcn_layer_prepare(const float* h, long long ld_h, int n_nodes, int Kh, const int* pos, const float* P, int Pd, float* X,
+                          const float* W, int Fo, float* Wp, float drop_p, unsigned long long seed, unsigned* mask, void* stream) {
+    if (n_nodes < 0 || Kh < 1 || Pd < 0 || !X || (Pd > 0 && (!pos || !P)) || !W || !Wp || Fo < 1) return TXE_ERR_ARG;
+    if (drop_p < 0.f || drop_p >= 1.f || (drop_p > 0.f && !mask)) return TXE_ERR_ARG;
+    const int T = 64 * FOLD_DG;
+    PrepArgs a;
+    memset(&a, 0, sizeof(a));
+    a.Kt = Kh + Pd; a.Kp = round_up(a.Kt, 32);
+    auto blocks = [&](long long n, int cap) { const long long b = (n + T - 1) / T; return (int)(b < cap ? b : cap); };
+    const long long nx = (long long)n_nodes * (a.Kp - (h ? 0 : Kh));
+    a.nb_x = nx > 0 ? blocks((long long)n_nodes * 64, 2048) : 0;
+    a.n_words = (drop_p > 0.f) ? (long long)n_nodes * ((a.Kt + 31) / 32) : 0;
+    a.nb_m = blocks(a.n_words, 1024);
+    a.pk_rows = a.Kt; a.pk_ext = a.Kt; a.pk_prows = round_up(a.Kp, 128); a.pk_cols = Fo; a.pk_pcols = round_up(Fo, 32);
+    a.nb_w = blocks((long long)a.pk_prows * 64, 512);
+    a.nb_f = 0; a.fold_bx = 1;
+    a.h = h; a.ld_h = ld_h; a.pos = pos; a.P = P; a.n_rows = n_nodes; a.Kh = Kh; a.Pd = Pd; a.X = X;
+    a.W = W; a.Wp = Wp;
+    a.seed = seed; a.thr16 = (unsigned)(drop_p * 65536.0f + 0.5f); a.mask = mask;
+    hipLaunchKernelGGL(gat_prepare_kernel, dim3(a.nb_x + a.nb_m + a.nb_w), dim3(T), 0, (hipStream_t)stream, a);
     TXE_CHECK_LAUNCH();
     return TXE_OK;
 }

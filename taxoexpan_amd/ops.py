@@ -573,13 +573,14 @@ class GCNStackFunction(torch.autograd.Function):
             tws = _tail_ws(h)
             for l, st in enumerate(states):
                 last = (l == L - 1)
-                if not (table and l == 0):
-                    call("txe_gat_build_x", ptr(h if l == 0 else None), ld_h if l == 0 else 0, N, st.Kh,
-                         ptr(pos if st.P is not None else None), ptr(st.P), st.Pd, ptr(st.X), st_)
+                if not (table and l == 0):          # layer input, packed weights and keep mask: one launch
                     kp128 = (st.Kp + 127) // 128 * 128
                     st.Wp = _empty((kp128, st.Fop), h)
-                    call("txe_gcn_pack_weights", ptr(st.W), st.Kh + st.Pd, st.Fo, ptr(st.Wp), st_)
-                    st.mask = dropout_mask(N, st.Kh + st.Pd, cfg.drop_ps[l], st.seed, h)
+                    st.mask = (torch.empty((N, (st.Kh + st.Pd + 31) // 32), dtype=torch.int32, device=h.device)
+                               if cfg.drop_ps[l] > 0.0 else None)
+                    call("txe_gcn_layer_prepare", ptr(h if l == 0 else None), ld_h if l == 0 else 0, N, st.Kh,
+                         ptr(pos if st.P is not None else None), ptr(st.P), st.Pd, ptr(st.X), ptr(st.W), st.Fo, ptr(st.Wp),
+                         cfg.drop_ps[l], st.seed, ptr(st.mask), st_)
                 if last and collapse:
                     G = csr.n_graphs
                     coef, wsum = _empty((max(N, 1),), h), _empty((max(G, 1),), h)

@@ -195,7 +195,8 @@ def extra_metrics(model, tax, device, batches, target):
         g.ndata["x"] = g.ndata["x"].to(device)
         g.csr(device)
         queries = tax.features[torch.from_numpy(test)].to(device)
-        hg = encode_candidates(model, g)
+        for _ in range(2):                                  # warm-up (allocator growth, code objects)
+            hg = encode_candidates(model, g)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         hg = encode_candidates(model, g)
@@ -206,7 +207,8 @@ def extra_metrics(model, tax, device, batches, target):
         from taxoexpan_amd import graph as G
         dtax = G.DeviceTaxonomy(tax.par_ptr, tax.par_idx, tax.chd_ptr, tax.chd_idx, tax.features, device)
         gl = G.device_egonet_batch(dtax, cand, seed=7, with_features="lazy")
-        hg_l = encode_candidates(model, gl)
+        for _ in range(2):
+            hg_l = encode_candidates(model, gl)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         hg_l = encode_candidates(model, gl)

@@ -362,7 +362,13 @@ __global__ __launch_bounds__(256) void gemm_tail_fixup_kernel(const Epi E, const
     for (int idx = blockIdx.y * CH + threadIdx.x; idx < (blockIdx.y + 1) * CH; idx += 256) {
         const int m = m0 + idx / BN, n = n0 + idx % BN;
         float acc = 0.f;
-        for (int z = 0; z < T.S; ++z) acc += part[(long long)z * (GEMM_BM * BN) + idx];
+        for (int z0 = 0; z0 < T.S; z0 += 4) {        // slice order kept; four clamped loads in flight
+            float v[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = part[(long long)min(z0 + q, T.S - 1) * (GEMM_BM * BN) + idx];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc += (z0 + q < T.S) ? v[q] : 0.f;
+        }
         if (m < M && n < N) epi_store_one(E, m, n, acc, E.c);
     }
 }

@@ -9,11 +9,18 @@ N > 1: one process per GPU (torch.distributed / RCCL), each rank its own batch (
 all-reduce per step.
 
 Prints ONE JSON line (rank 0) with value = total egonet-edges/s over all ranks, plus
-  roofline      -- the dominant kernel by time in an instrumented pass (HIP events on the launch stream, per launch)
+  roofline      -- the dominant kernel by time in an instrumented pass (HIP events on the launch stream, per launch); flops are
+                   ALGORITHMIC (unpadded operand sizes)
   roofline_all  -- the same for every kernel class (the message/reduce kernels are HBM-bound, the projections MFMA-bound)
-  cpu_baseline  -- the CPU oracle (torch fp32, explicit COO; a restatement of the reference's DGL-CPU path, which
-                   cannot run: DGL 0.4 is not installable) timed on the host cores on a bounded sample of the same batch
-  extra         -- forward-only edges/s and candidates-scored/s of the eval loop (MAG-CS: 24.7k candidates x 2,450 queries)
+  cpu_baseline  -- the CPU oracle (torch fp32, explicit COO; a restatement of the reference's DGL-CPU path, which cannot run: DGL 0.4
+                   is not installable) timed on the host cores with BASELINE.md 2.3's protocol (3 warm-up + 10 timed, median) on
+                   bounded samples: `step` (= the top-level value: fwd + InfoNCE + bwd), `fwd` (PGAT forward on a MAG-Full-shaped
+                   egonet batch, the north star's >=10x target) and `scoring` (the literal per-query bilinear loop of
+                   test_fast.py:121-123, and its factored form)
+  extra         -- every secondary number as a median of >= 5 repetitions: forward-only edges/s (training batches and MAG-Full-shaped
+                   batches, with the GPU/CPU ratio), the eval scoring loop on the MAG-CS and MAG-Full shapes (candidates scored / s),
+                   and the training step of BASELINE configs[4] (PGCN+MR+BIM) and configs[3] (PGAT 2-layer on the MAG-Full taxonomy)
+                   with their dominant kernel's roofline
 """
 import argparse
 import ctypes
@@ -35,6 +42,37 @@ MAG = dict(in_dim=250, hidden_dim=500, out_dim=500, pos_dim=50, num_layers=1, he
 N_QUERIES, NEG = 128, 31
 PEAK_MFMA_F32 = 157.3e12      # MI355X_MICROARCH.md: fp32 MFMA = fp32 vector peak, no TF32 on gfx950
 PEAK_HBM = 8.0e12             # spec; ~6.3e12 achievable
+
+
+def median_time(fn, reps=5, inner=1, warm=1):
+    """median wall time of `inner` calls of fn over `reps` repetitions (device synchronised around each repetition)"""
+    for _ in range(warm):
+        fn()
+    ts = []
+    for _ in range(reps):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(inner):
+            fn()
+        torch.cuda.synchronize()
+        ts.append((time.perf_counter() - t0) / inner)
+    return float(np.median(ts))
+
+
+def cpu_median(fn, budget_s=8.0):
+    """3 warm-up + 10 timed iterations, median -- cut to 1 + 5 (and said so) when that would not fit the budget"""
+    t0 = time.perf_counter()
+    fn()
+    first = time.perf_counter() - t0
+    warm, iters = (3, 10) if first * 13 <= budget_s else (1, 5)
+    for _ in range(warm - 1):
+        fn()
+    ts = []
+    for _ in range(iters):
+        t0 = time.perf_counter()
+        fn()
+        ts.append(time.perf_counter() - t0)
+    return float(np.median(ts)), f"{warm} warm-up + {iters} timed iterations, median"
 
 
 def build_batches(tax, n_batches, seed0, device):
@@ -83,13 +121,16 @@ def profile_step(model, opt, batch, target):
     return recs
 
 
-def load_traffic():
+def load_traffic(workload="pgat"):
     """HBM-side bytes per launch of each kernel from the committed rocprofv3 PMC passes (profiles/*_traffic.json, made by
     tools/summarize_profiles.py from separate --pmc FETCH_SIZE / --pmc WRITE_SIZE runs of the same workload, FETCH_SIZE
     corrected x2 as calibrated on a 1 GiB copy -- MI355X_MICROARCH.md HBM section).  PMC collection cannot run inside the
     timed process, so bench.py reports the latest committed measurement."""
     import glob
-    files = sorted(glob.glob(os.path.join(REPO, "profiles", "*_traffic.json")))
+    files = sorted(glob.glob(os.path.join(REPO, "profiles", f"*_{workload}_traffic.json")))
+    if not files and workload == "pgat":
+        files = sorted(f for f in glob.glob(os.path.join(REPO, "profiles", "*_traffic.json"))
+                       if not any(t in os.path.basename(f) for t in ("_pgcn_", "_pgat2_", "_infer_")))
     if not files:
         return {}, None
     d = json.load(open(files[-1]))
@@ -101,9 +142,9 @@ def load_traffic():
     return out, os.path.basename(files[-1])
 
 
-def summarize_profile(all_recs, n_edges_by_launch, n_nodes_by_launch=None):
+def summarize_profile(all_recs, n_edges_by_launch, n_nodes_by_launch=None, workload="pgat"):
     """aggregate records by kernel name: launches, avg duration, algorithmic work per launch, roofline fraction"""
-    traffic, traffic_src = load_traffic()
+    traffic, traffic_src = load_traffic(workload)
     agg = {}
     n_graphs = N_QUERIES * (1 + NEG)
     for idx, (recs, e) in enumerate(zip(all_recs, n_edges_by_launch)):
@@ -131,22 +172,29 @@ def summarize_profile(all_recs, n_edges_by_launch, n_nodes_by_launch=None):
     return out
 
 
-def cpu_baseline(batch, state_dict, n_sample_queries=128, iters=4):
-    """The oracle's training step (forward + InfoNCE + backward, torch CPU fp32, all host threads) on the first
-    n_sample_queries x 32 egonets of the same batch."""
-    sys.path.insert(0, os.path.join(REPO, "oracle"))
-    import txe_oracle as orc
-    g = batch["g"]
-    n_g = n_sample_queries * (1 + NEG)
+def _oracle_graph(g, pos, n_g):
+    """the first n_g egonets of a batch as the oracle's COO dict"""
     n_nodes = int(np.sum(g.batch_num_nodes[:n_g]))
     n_edges = int(np.sum(g.batch_num_edges[:n_g]))
-    pos = batch["pos"].cpu().long()[:n_nodes]
     goff = torch.from_numpy(np.concatenate([[0], np.cumsum(g.batch_num_nodes[:n_g])])).long()
-    graph = dict(src=torch.from_numpy(g._src[:n_edges]), dst=torch.from_numpy(g._dst[:n_edges]), pos=pos, graph_off=goff,
-                 num_nodes=n_nodes)
-    x = batch["x"][:n_nodes].cpu()
-    q = batch["qf"][:n_g].cpu()
+    return dict(src=torch.from_numpy(g._src[:n_edges]), dst=torch.from_numpy(g._dst[:n_edges]), pos=pos.cpu().long()[:n_nodes], graph_off=goff,
+                num_nodes=n_nodes), n_nodes, n_edges
+
+
+def cpu_baseline(batch, state_dict, full_batch=None, hg=None, queries=None, n_sample_queries=32):
+    """The CPU oracle (oracle/txe_oracle.py: torch fp32 on explicit COO, all host threads; kind "port") on bounded samples.
+    step:    forward + InfoNCE + backward on the first n_sample_queries x 32 egonets of training batch 0 (dropout as explicit masks);
+    fwd:     PGAT+WMR+LBM forward (eval) on the first n_sample_queries x 32 egonets of a MAG-Full-shaped batch (`full_batch`);
+    scoring: per query, the literal `match(hg, q.expand(G, -1))` of test_fast.py:121-123 over all G candidates (hg: the candidate
+             vectors, encoded beforehand -- input data here), and the factored form S = Q (hg W)^T on a 64-query block."""
+    sys.path.insert(0, os.path.join(REPO, "oracle"))
+    import txe_oracle as orc
+    out = {}
+    n_g = n_sample_queries * (1 + NEG)
     P = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in state_dict.items()}
+    # ---- step ----
+    graph, n_nodes, n_edges = _oracle_graph(batch["g"], batch["pos"], n_g)
+    x, q = batch["x"][:n_nodes].cpu(), batch["qf"][:n_g].cpu()
     rs = np.random.RandomState(0)
     masks = []
     for l, (kt, H) in enumerate(((300, 4), (2050, 1))):      # dropout as explicit masks (same work as nn.Dropout)
@@ -158,154 +206,191 @@ def cpu_baseline(batch, state_dict, n_sample_queries=128, iters=4):
             p.grad = None
         s, _, _ = orc.taxoexpan_forward(P, graph, x, q, "PGAT", "WMR", "LBM", [4, 1], 1, masks)
         orc.info_nce_loss(s, n_sample_queries).backward()
-    step()
-    t0 = time.perf_counter()
-    for _ in range(iters):
-        step()
-    dt = (time.perf_counter() - t0) / iters
-    return dict(value=n_edges / dt, unit="egonet-edges/s", cores=torch.get_num_threads(), kind="port",
-                sample=f"{n_g} of the 4096 egonets of batch 0 ({n_nodes} nodes, {n_edges} edges), fwd+InfoNCE+bwd, "
-                       f"{iters} timed iterations after 1 warm-up, {dt:.3f} s/iter; oracle/txe_oracle.py (torch CPU fp32)")
+    dt, proto = cpu_median(step)
+    out["step"] = dict(value=n_edges / dt, unit="egonet-edges/s", s_per_iter=dt,
+                       sample=f"{n_g} of the 4096 egonets of training batch 0 ({n_nodes} nodes, {n_edges} edges), fwd+InfoNCE+bwd, {proto}")
+    # ---- forward only, MAG-Full-shaped egonets ----
+    if full_batch is not None:
+        graph_f, nn_f, ne_f = _oracle_graph(full_batch["g"], full_batch["pos"], n_g)
+        xf, qf_ = full_batch["x"][:nn_f].cpu(), full_batch["qf"][:n_g].cpu()
+        Pd = {k: v.detach() for k, v in P.items()}
+
+        def fwd():
+            with torch.no_grad():
+                orc.taxoexpan_forward(Pd, graph_f, xf, qf_, "PGAT", "WMR", "LBM", [4, 1], 1, None)
+        dt, proto = cpu_median(fwd)
+        out["fwd"] = dict(value=ne_f / dt, unit="egonet-edges/s", s_per_iter=dt,
+                          sample=f"{n_g} egonets of a MAG-Full-shaped (431,416-node taxonomy) batch ({nn_f} nodes, {ne_f} edges), "
+                                 f"PGAT+WMR+LBM eval forward, {proto}")
+    # ---- scoring loop ----
+    if hg is not None:
+        hg_c, W = hg.detach().cpu(), P["match.W.weight"].detach()
+        G = hg_c.shape[0]
+        qs = queries.cpu()
+        it = iter(range(10 ** 9))
+
+        def literal():                                          # one query of test_fast.py:121-123
+            qv = qs[next(it) % qs.shape[0]]
+            with torch.no_grad():
+                orc.bilinear_match(hg_c, qv.expand(G, -1), W, True)
+        dt, proto = cpu_median(literal, budget_s=4.0)
+        qb = qs[:64]
+
+        def factored():
+            with torch.no_grad():
+                torch.exp(qb @ (hg_c @ W[0]).t())
+        dt2, proto2 = cpu_median(factored, budget_s=4.0)
+        out["scoring"] = dict(value=G / dt, unit="candidates scored/s", s_per_query=dt, factored_value=G * qb.shape[0] / dt2,
+                              sample=f"{G} MAG-CS candidates: literal per-query loop (one query per iteration, {proto}); factored form on a "
+                                     f"{qb.shape[0]}-query block incl. U = hg W ({proto2})")
+    top = dict(out["step"])
+    top.update(cores=torch.get_num_threads(), kind="port", implementation="oracle/txe_oracle.py (torch CPU fp32)", **{k: v for k, v in out.items()})
+    return top
 
 
-def extra_metrics(model, tax, device, batches, target):
-    """forward-only throughput and the eval scoring loop (candidates scored / s) on one GPU"""
-    from taxoexpan_amd import ops, synthetic as syn
-    from taxoexpan_amd.scoring import encode_candidates, score_all
-    out = {}
+def _positives(tax, cand, test):
+    cand_index = np.full(tax.n_nodes, -1, dtype=np.int64)
+    cand_index[cand] = np.arange(len(cand))
+    pos_lists = [cand_index[tax.par_idx[tax.par_ptr[q]:tax.par_ptr[q + 1]]] for q in test]
+    pos_lists = [p[p >= 0] for p in pos_lists]
+    off = np.concatenate([[0], np.cumsum([len(p) for p in pos_lists])])
+    idx = np.concatenate(pos_lists) if len(pos_lists) else np.zeros(0, dtype=np.int64)
+    return off, idx
+
+
+def extra_metrics(model, tax, device, batches, full_batches):
+    """forward-only throughput and the eval scoring loop (candidates scored / s) on one GPU; every time a median of 5 repetitions.
+    Returns (metrics, hg of the MAG-CS candidates, their test queries) -- the latter two feed cpu_baseline's scoring leg."""
+    from taxoexpan_amd import graph as G, ops, synthetic as syn
+    from taxoexpan_amd.scoring import encode_candidates, rank_all_fused, score_all
+    out = {"timing": "median of 5 repetitions each (device synchronised around every repetition)"}
     model.eval()
     with torch.no_grad():
-        for _ in range(2):
-            for b in batches:
+        def fwd_all(bs):
+            for b in bs:
                 b["g"].ndata["pos"] = b["pos"]
                 model(b["g"], b["x"], b["qf"])
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        reps = 5
-        for _ in range(reps):
-            for b in batches:
-                b["g"].ndata["pos"] = b["pos"]
-                model(b["g"], b["x"], b["qf"])
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-        out["pgat_fwd_eval_edges_per_s"] = reps * sum(b["n_edges"] for b in batches) / dt
+        dt = median_time(lambda: fwd_all(batches), reps=5, inner=2, warm=2)
+        out["pgat_fwd_eval_edges_per_s"] = sum(b["n_edges"] for b in batches) / dt
+        if full_batches:
+            dt = median_time(lambda: fwd_all(full_batches), reps=5, inner=2, warm=2)
+            out["pgat_fwd_eval_mag_full_batches_edges_per_s"] = sum(b["n_edges"] for b in full_batches) / dt
         # all-candidate inference (test_fast.py small mode): encode every candidate egonet, score every test query
-        cand, val, test = syn.split_candidates(tax)
+        cand, _val, test = syn.split_candidates(tax)
         g = syn.egonet_batch(tax, cand, seed=7)
         g.ndata["x"] = g.ndata["x"].to(device)
         g.csr(device)
         queries = tax.features[torch.from_numpy(test)].to(device)
-        for _ in range(2):                                  # warm-up (allocator growth, code objects)
-            hg = encode_candidates(model, g)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
+        t_enc = median_time(lambda: encode_candidates(model, g), warm=2)
         hg = encode_candidates(model, g)
-        torch.cuda.synchronize()
-        t_enc = time.perf_counter() - t0
         # the same candidates as device-built egonets whose features stay rows of the taxonomy table (evaluate.py's path): the
         # layer-0 projection runs once per taxonomy node (SURVEY 8f-2)
-        from taxoexpan_amd import graph as G
         dtax = G.DeviceTaxonomy(tax.par_ptr, tax.par_idx, tax.chd_ptr, tax.chd_idx, tax.features, device)
         gl = G.device_egonet_batch(dtax, cand, seed=7, with_features="lazy")
-        for _ in range(2):
-            hg_l = encode_candidates(model, gl)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        hg_l = encode_candidates(model, gl)
-        torch.cuda.synchronize()
-        t_enc_l = time.perf_counter() - t0
+        t_enc_l = median_time(lambda: encode_candidates(model, gl), warm=2)
         out["infer_encode_dedup_s"] = t_enc_l
         out["infer_encode_dedup_edges_per_s"] = gl.number_of_edges() / t_enc_l
-        del hg_l, gl
+        del gl
         S = score_all(model.match, hg, queries)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        S = score_all(model.match, hg, queries, out=S)
-        torch.cuda.synchronize()
-        t_sc = time.perf_counter() - t0
-        # ranks of each query's true parents on device
-        cand_index = np.full(tax.n_nodes, -1, dtype=np.int64)
-        cand_index[cand] = np.arange(len(cand))
-        pos_lists = [cand_index[tax.par_idx[tax.par_ptr[q]:tax.par_ptr[q + 1]]] for q in test]
-        pos_lists = [p[p >= 0] for p in pos_lists]
-        off = torch.tensor(np.concatenate([[0], np.cumsum([len(p) for p in pos_lists])]), dtype=torch.int32)
-        idx = torch.tensor(np.concatenate(pos_lists) if len(pos_lists) else np.zeros(0), dtype=torch.int32)
-        t0 = time.perf_counter()
+        t_sc = median_time(lambda: score_all(model.match, hg, queries, out=S))
+        off_np, idx_np = _positives(tax, cand, test)
+        off, idx = torch.tensor(off_np, dtype=torch.int32), torch.tensor(idx_np, dtype=torch.int32)
+        t_rk = median_time(lambda: ops.rank_block(S, off, idx, True))
         ranks = ops.rank_block(S, off, idx, True)
-        torch.cuda.synchronize()
-        t_rk = time.perf_counter() - t0
         # fused scoring + ranking (no score matrix): must give the same ranks
-        from taxoexpan_amd.scoring import rank_all_fused
-        rank_all_fused(model.match, hg, queries, off, idx)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
+        t_fused = median_time(lambda: rank_all_fused(model.match, hg, queries, off, idx))
         ranks_f = rank_all_fused(model.match, hg, queries, off, idx)
-        torch.cuda.synchronize()
-        t_fused = time.perf_counter() - t0
+        pairs = float(len(cand)) * len(test)
         out["fused_rank_equals_materialised"] = bool(torch.equal(ranks_f.cpu(), ranks.cpu()))
-        out["infer_fused_score_rank_s"] = t_fused
         out.update(infer_candidates=int(len(cand)), infer_queries=int(len(test)), infer_encode_s=t_enc,
-                   infer_encode_edges_per_s=g.number_of_edges() / t_enc, infer_score_s=t_sc,
-                   candidates_scored_per_s=len(cand) * len(test) / t_sc,
-                   candidates_scored_per_s_incl_encode_and_rank=len(cand) * len(test) / (t_enc + t_sc + t_rk),
-                   infer_rank_s=t_rk, mean_rank=float(ranks.float().mean().item()) if ranks.numel() else None)
+                   infer_encode_edges_per_s=g.number_of_edges() / t_enc, infer_score_s=t_sc, infer_rank_s=t_rk,
+                   infer_fused_score_rank_s=t_fused, candidates_scored_per_s=pairs / t_sc,
+                   candidates_scored_per_s_incl_encode_and_rank=pairs / (t_enc + t_sc + t_rk),
+                   candidates_scored_per_s_fused_rank_incl_dedup_encode=pairs / (t_enc_l + t_fused),
+                   score_gemm_tflops=2.0 * 250 * pairs / t_sc / 1e12, score_gemm_frac_of_mfma_peak=2.0 * 250 * pairs / t_sc / PEAK_MFMA_F32,
+                   mean_rank=float(ranks.float().mean().item()) if ranks.numel() else None)
     model.train()
-    return out
+    return out, hg, queries[:256]
 
 
-def extra_metrics_mag_full(model, device, n_queries=8192, qblock=1024):
+def extra_metrics_mag_full(model, device, tax, n_queries=8192, qblock=1024):
     """N = 1: the all-candidate inference loop on the MAG-Full shape (356 k candidate egonets built on device, features as rows of
-    the taxonomy table; 8,192 of the test queries): encode once, then score + rank every (query, candidate) pair -- the
-    `candidates scored / s` half of BASELINE.json's metric at the size it is quoted on."""
+    the taxonomy table; 8,192 of the test queries): encode in one batch and in test_fast.py's `-b 30000` chunks, then score + rank
+    every (query, candidate) pair -- the `candidates scored / s` half of BASELINE.json's metric at the size it is quoted on."""
     from taxoexpan_amd import graph as G, synthetic as syn
+    from taxoexpan_amd.evaluate import candidate_graphs
     from taxoexpan_amd.scoring import encode_candidates, rank_all_fused
     out = {}
     model.eval()
     with torch.no_grad():
-        tax = syn.make_named_taxonomy("mag_full", seed=47)
         cand, _val, test = syn.split_candidates(tax)
         test = test[:n_queries]
         dtax = G.DeviceTaxonomy(tax.par_ptr, tax.par_idx, tax.chd_ptr, tax.chd_idx, tax.features, device)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
+        t_build = median_time(lambda: G.device_egonet_batch(dtax, cand, seed=7, with_features="lazy"))
         g = G.device_egonet_batch(dtax, cand, seed=7, with_features="lazy")
-        torch.cuda.synchronize()
-        t_build = time.perf_counter() - t0
         queries = tax.features[torch.from_numpy(test)].to(device)
-        for _ in range(2):                                                 # warm-up: the caching allocator grows by ~30 GB, twice
-            hg = encode_candidates(model, g)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
+        t_enc = median_time(lambda: encode_candidates(model, g), warm=2)          # (warm-up: the caching allocator grows by ~30 GB)
         hg = encode_candidates(model, g)
-        torch.cuda.synchronize()
-        t_enc = time.perf_counter() - t0
-        _score_local_only(model, hg, queries, qblock)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        _score_local_only(model, hg, queries, qblock)
-        torch.cuda.synchronize()
-        t_sc = time.perf_counter() - t0
-        cand_index = np.full(tax.n_nodes, -1, dtype=np.int64)
-        cand_index[cand] = np.arange(len(cand))
-        pos_lists = [cand_index[tax.par_idx[tax.par_ptr[qn]:tax.par_ptr[qn + 1]]] for qn in test]
-        pos_lists = [p[p >= 0] for p in pos_lists]
-        pos_off = np.concatenate([[0], np.cumsum([len(p) for p in pos_lists])])
-        pos_idx = np.concatenate(pos_lists) if pos_lists else np.zeros(0, dtype=np.int64)
-        rank_all_fused(model.match, hg, queries, pos_off, pos_idx, block=qblock)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
+        n_nodes, n_edges = int(g.number_of_nodes()), int(g.number_of_edges())
+        del g
+        chunks = candidate_graphs(dtax, cand, 50, 7, batch_size=30000)            # BASELINE configs[2]: batch_size=30000
+        t_enc_c = median_time(lambda: encode_candidates(model, chunks), warm=2)
+        n_chunks = len(chunks)
+        del chunks
+        t_sc = median_time(lambda: _score_local_only(model, hg, queries, qblock))
+        pos_off, pos_idx = _positives(tax, cand, test)
+        t_fr = median_time(lambda: rank_all_fused(model.match, hg, queries, pos_off, pos_idx, block=qblock))
         ranks = rank_all_fused(model.match, hg, queries, pos_off, pos_idx, block=qblock)
-        torch.cuda.synchronize()
-        t_fr = time.perf_counter() - t0
         pairs = float(len(cand)) * len(test)
-        out.update(shape="mag_full", candidates=int(len(cand)), queries=int(len(test)), egonet_nodes=int(g.number_of_nodes()),
-                   egonet_edges=int(g.number_of_edges()), device_egonet_build_s=t_build, encode_s=t_enc,
-                   encode_edges_per_s=g.number_of_edges() / t_enc, score_s=t_sc, candidates_scored_per_s=pairs / t_sc,
+        out.update(shape="mag_full", candidates=int(len(cand)), queries=int(len(test)), egonet_nodes=n_nodes, egonet_edges=n_edges,
+                   device_egonet_build_s=t_build, encode_s=t_enc, encode_edges_per_s=n_edges / t_enc,
+                   encode_30000_chunks_s=t_enc_c, encode_30000_chunks_edges_per_s=n_edges / t_enc_c, encode_chunks=n_chunks,
+                   score_s=t_sc, candidates_scored_per_s=pairs / t_sc,
+                   score_gemm_tflops=2.0 * 250 * pairs / t_sc / 1e12, score_gemm_frac_of_mfma_peak=2.0 * 250 * pairs / t_sc / PEAK_MFMA_F32,
                    fused_score_rank_s=t_fr, candidates_scored_per_s_fused_rank=pairs / t_fr,
                    candidates_scored_per_s_fused_rank_incl_encode=pairs / (t_fr + t_enc),
                    mean_rank=float(ranks.float().mean().item()) if ranks.numel() else None)
     model.train()
     return out
+
+
+def make_model(workload, device):
+    from taxoexpan_amd import TaxoExpan
+    if workload == "pgat":
+        return TaxoExpan("PGAT", "WMR", "LBM", **MAG).to(device).train()
+    if workload == "pgat2":
+        return TaxoExpan("PGAT", "WMR", "LBM", **dict(MAG, num_layers=2, heads=[4, 4, 1])).to(device).train()
+    return TaxoExpan("PGCN", "MR", "BIM", **MAG).to(device).train()
+
+
+WORKLOAD_TEXT = {"pgat": "MAG-CS synthetic taxonomy (29,654 nodes, d=250), PGAT+WMR+LBM fp32 dims 250/50/500/500 heads [4,1], ",
+                 "pgat2": "MAG-Full synthetic taxonomy (431,416 nodes, d=250), PGAT num_layers=2 +WMR+LBM fp32 dims 250/50/500/500 heads [4,4,1], ",
+                 "pgcn": "MAG-CS synthetic taxonomy (29,654 nodes, d=250), PGCN+MR+BIM fp32 dims 250/50/500/500, "}
+STEP_TEXT = "128 queries x 32 = 4096 egonets per GPU per step, fwd + InfoNCE + bwd + Adam(amsgrad), dropout 0.1"
+
+
+def variant_step(workload, tax, device, steps=10, reps=5):
+    """the training step of another BASELINE config in the same process (configs[4] `pgcn`, configs[3]'s model `pgat2`): median ms per
+    step over `reps` groups of `steps` steps, and the roofline of its dominant kernel from one instrumented step per batch"""
+    from taxoexpan_amd.optim import Adam
+    torch.manual_seed(47)
+    model = make_model(workload, device)
+    opt = Adam(model.parameters(), lr=1e-3, weight_decay=0, amsgrad=True)
+    batches = build_batches(tax, 2, seed0=1000, device=device)
+    target = torch.zeros(N_QUERIES, dtype=torch.long, device=device)
+    it = iter(range(10 ** 9))
+
+    def one():
+        train_step(model, opt, batches[next(it) % 2], target, 1)
+    dt = median_time(one, reps=reps, inner=steps, warm=5)
+    edges = float(np.mean([b["n_edges"] for b in batches]))
+    recs = [profile_step(model, opt, b, target) for b in batches]
+    roof = summarize_profile(recs, [b["n_edges"] for b in batches], [b["n_nodes"] for b in batches], workload=workload)
+    dom = roof[0]
+    return dict(workload=WORKLOAD_TEXT[workload] + STEP_TEXT, ms_per_step=1e3 * dt, egonet_edges_per_s=edges / dt,
+                timing=f"median of {reps} x {steps} steps",
+                roofline={k: dom[k] for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "avg_us", "work_per_launch")},
+                roofline_top5=[{k: r[k] for k in ("kernel", "bound", "frac", "avg_us", "launches", "total_us")} for r in roof[:5]])
 
 
 def extra_metrics_sharded(model, device, world, rank, n_queries=8192, qblock=1024):
@@ -412,15 +497,10 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
-    from taxoexpan_amd import TaxoExpan, synthetic as syn
+    from taxoexpan_amd import synthetic as syn
     tax = syn.make_named_taxonomy("mag_full" if args.workload == "pgat2" else "mag_cs", seed=47)
     torch.manual_seed(47)
-    if args.workload == "pgat":
-        model = TaxoExpan("PGAT", "WMR", "LBM", **MAG).to(device).train()
-    elif args.workload == "pgat2":
-        model = TaxoExpan("PGAT", "WMR", "LBM", **dict(MAG, num_layers=2, heads=[4, 4, 1])).to(device).train()
-    else:
-        model = TaxoExpan("PGCN", "MR", "BIM", **MAG).to(device).train()
+    model = make_model(args.workload, device)
     if world > 1:                                   # identical replicas
         for p in model.parameters():
             dist.broadcast(p.data, src=0)
@@ -457,16 +537,29 @@ def main():
     roof_all, cpu, extra = None, None, None
     if rank == 0:
         recs = [profile_step(model, opt, b, target) for b in batches]
-        roof_all = summarize_profile(recs, [b["n_edges"] for b in batches], [b["n_nodes"] for b in batches])
+        roof_all = summarize_profile(recs, [b["n_edges"] for b in batches], [b["n_nodes"] for b in batches], workload=args.workload)
     if rank == 0 and world == 1 and args.workload == "pgat":
-        if not args.no_cpu_baseline:
-            cpu = cpu_baseline(batches[0], model.state_dict())
+        tax_full, full_batches, hg_cs, q_cs = None, None, None, None
+        if not (args.no_extra and args.no_cpu_baseline):
+            tax_full = syn.make_named_taxonomy("mag_full", seed=47)
+            full_batches = build_batches(tax_full, 2, seed0=7000, device=device)        # MAG-Full-shaped egonet batches (4,096 each)
         if not args.no_extra:
-            extra = extra_metrics(model, tax, device, batches, target)
-            try:                                     # never let a secondary metric take the bench line down
-                extra["mag_full"] = extra_metrics_mag_full(model, device)
-            except Exception as exc:                 # noqa: BLE001
-                extra["mag_full"] = {"error": repr(exc)[:300]}
+            extra, hg_cs, q_cs = extra_metrics(model, tax, device, batches, full_batches)
+            for name, fn in (("mag_full", lambda: extra_metrics_mag_full(model, device, tax_full)),
+                             ("step_pgcn", lambda: variant_step("pgcn", tax, device)),
+                             ("step_pgat2", lambda: variant_step("pgat2", tax_full, device))):
+                try:                                     # never let a secondary metric take the bench line down
+                    extra[name] = fn()
+                except Exception as exc:                 # noqa: BLE001
+                    extra[name] = {"error": repr(exc)[:300]}
+        if not args.no_cpu_baseline:
+            cpu = cpu_baseline(batches[0], model.state_dict(), full_batches[0] if full_batches else None, hg_cs, q_cs)
+            if extra is not None:                        # the north star's ratios, same process, same batches
+                if "fwd" in cpu and "pgat_fwd_eval_mag_full_batches_edges_per_s" in extra:
+                    extra["gpu_over_cpu_pgat_fwd_mag_full_batches"] = extra["pgat_fwd_eval_mag_full_batches_edges_per_s"] / cpu["fwd"]["value"]
+                if "scoring" in cpu:
+                    extra["gpu_over_cpu_candidates_scored_literal_loop"] = extra["candidates_scored_per_s"] / cpu["scoring"]["value"]
+                    extra["gpu_over_cpu_candidates_scored_factored"] = extra["candidates_scored_per_s"] / cpu["scoring"]["factored_value"]
     if world > 1:
         dist.barrier()
         if args.workload == "pgat" and not args.no_extra:
@@ -478,23 +571,22 @@ def main():
 
     if rank == 0:
         dom = roof_all[0]
+        hbm = [r for r in roof_all if r["bound"] == "hbm"]
         line = {
             "metric": "egonet_edges_per_sec_%s_fwd_bwd" % args.workload, "value": edges / elapsed, "unit": "egonet-edges/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": {"pgat": "MAG-CS synthetic taxonomy (29,654 nodes, d=250), PGAT+WMR+LBM fp32 dims 250/50/500/500 heads [4,1], ",
-                                    "pgat2": "MAG-Full synthetic taxonomy (431,416 nodes, d=250), PGAT num_layers=2 +WMR+LBM fp32 dims 250/50/500/500 "
-                                             "heads [4,4,1], ",
-                                    "pgcn": "MAG-CS synthetic taxonomy (29,654 nodes, d=250), PGCN+MR+BIM fp32 dims 250/50/500/500, "}[args.workload] +
-                                   "128 queries x 32 = 4096 egonets per GPU per step, fwd + InfoNCE + bwd + Adam(amsgrad), dropout 0.1",
+            "config": {"workload": WORKLOAD_TEXT[args.workload] + STEP_TEXT,
                        "output_layer": ("unfolded (TXE_NO_FOLD=1)" if os.environ.get("TXE_NO_FOLD", "0") == "1" else
                                         "folded behind the weighted-mean readout (exact re-association, DESIGN 4.1): G graph rows instead of N node rows"),
                        "egonets_per_step_per_gpu": N_QUERIES * (1 + NEG), "avg_edges_per_step_per_gpu": edges / args.steps / world,
                        "parallelism": f"dp{world}"},
             "roofline": {"bound": dom["bound"], "achieved": dom["achieved"], "peak": dom["peak"], "unit": dom["unit"],
                          "frac": dom["frac"], "traffic": dom["traffic"], "traffic_source": dom["traffic_source"],
-                         "kernel": dom["kernel"], "avg_us": dom["avg_us"],
-                         "launches_per_4_steps": dom["launches"], "work_per_launch": dom["work_per_launch"]},
+                         "kernel": dom["kernel"], "avg_us": dom["avg_us"], "flops": "algorithmic (unpadded operands)",
+                         "launches_per_4_steps": dom["launches"], "work_per_launch": dom["work_per_launch"],
+                         "dominant_hbm_kernel": ({k: hbm[0][k] for k in ("kernel", "achieved", "peak", "unit", "frac", "avg_us", "traffic")}
+                                                 if hbm else None)},
             "roofline_all": roof_all,
             "cpu_baseline": cpu,
             "extra": extra,

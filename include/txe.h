@@ -217,13 +217,14 @@ int txe_gcn_collapse_bwd(const int* rowptr_in, const int* col_src, const int* gr
 /* ---- egonet construction + batching on device: data_loader/dataset.py:404-437 (_get_subgraph) + dgl.batch (data_loaders.py:25).
  * Taxonomy as parent CSR (par_ptr/par_idx) and child CSR (chd_ptr/chd_idx); anchors [G]; exclude [G] or NULL (query node removed
  * from each egonet's siblings, -1 = none: the positive example of dataset.py:421-424); children beyond `expand` are drawn with
- * replacement from a counter-based hash of (seed, egonet, draw).  Step 1 gives node_off [G+1] (node_off[G] = N; E = 2N - G), step 2
+ * replacement from a counter-based hash of (seed, index_base + egonet, draw) -- index_base = position of the batch's first egonet in the
+ * caller's whole list, so that a list cut into `-b` chunks (test_fast.py:149-179) draws what the single batch draws.  Step 1 gives node_off [G+1] (node_off[G] = N; E = 2N - G), step 2
  * the node table (ids, pos [N]) and both CSR views in closed form (no sort). */
 size_t txe_egonet_ws_bytes(int G);
 int txe_egonet_offsets(const int* par_ptr, const int* chd_ptr, const int* chd_idx, const int* anchors, const int* exclude, int G,
-                       int expand, unsigned long long seed, int* node_off, void* ws, size_t ws_bytes, void* stream);
+                       int expand, unsigned long long seed, int index_base, int* node_off, void* ws, size_t ws_bytes, void* stream);
 int txe_egonet_fill(const int* par_ptr, const int* par_idx, const int* chd_ptr, const int* chd_idx, const int* anchors,
-                    const int* exclude, int G, int expand, unsigned long long seed, const int* node_off, int* ids, int* pos,
+                    const int* exclude, int G, int expand, unsigned long long seed, int index_base, const int* node_off, int* ids, int* pos,
                     int* rowptr_in, int* col_src, int* eid_in, int* rowptr_out, int* col_dst, int* pos_out, void* stream);
 
 /* ---- optional per-kernel timing (debug / bench): HIP events on the launch stream around every kernel launch, with the

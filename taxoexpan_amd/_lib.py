@@ -64,8 +64,8 @@ SIGNATURES = {
     "txe_gcn_collapse_fwd": (I, [P, P, P, I, I, P, I, I, P, I, P, F, P, P, P, P, P, P, P, P, P, L, P, SZ, P]),
     "txe_gcn_collapse_bwd": (I, [P, P, P, I, I, P, I, I, P, I, P, I, F, P, P, P, P, P, P, P, P, L, I, F, P, P, P, P, P, P, SZ, P]),
     "txe_egonet_ws_bytes": (SZ, [I]),
-    "txe_egonet_offsets": (I, [P, P, P, P, P, I, I, U64, P, P, SZ, P]),
-    "txe_egonet_fill": (I, [P, P, P, P, P, P, I, I, U64, P, P, P, P, P, P, P, P, P, P]),
+    "txe_egonet_offsets": (I, [P, P, P, P, P, I, I, U64, I, P, P, SZ, P]),
+    "txe_egonet_fill": (I, [P, P, P, P, P, P, I, I, U64, I, P, P, P, P, P, P, P, P, P, P]),
     "txe_info_nce": (I, [P, L, I, I, P, P, P, L, P]),
     "txe_adam_step": (I, [I, P, P, P, P, P, P, D, D, D, D, D, L, P]),
     "txe_dropout_uniform_host": (F, [U64, U64]),

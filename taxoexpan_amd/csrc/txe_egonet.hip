@@ -22,7 +22,7 @@ __device__ __forceinline__ int draw_child(unsigned long long seed, int i, int t,
 // sizes: n[i] = k + 1 + m
 __global__ void egonet_sizes_kernel(const int* __restrict__ par_ptr, const int* __restrict__ chd_ptr, const int* __restrict__ chd_idx,
                                     const int* __restrict__ anchors, const int* __restrict__ exclude, int G, int expand,
-                                    unsigned long long seed, int* __restrict__ n_nodes) {
+                                    unsigned long long seed, int index_base, int* __restrict__ n_nodes) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= G) return;
     const int a = anchors[i];
@@ -35,7 +35,7 @@ __global__ void egonet_sizes_kernel(const int* __restrict__ par_ptr, const int* 
         if (ex >= 0)
             for (int t = 0; t < deg; ++t) m -= (chd_idx[cb + t] == ex) ? 1 : 0;
     } else {
-        for (int t = 0; t < expand; ++t) m += (chd_idx[cb + draw_child(seed, i, t, deg)] != ex) ? 1 : 0;
+        for (int t = 0; t < expand; ++t) m += (chd_idx[cb + draw_child(seed, index_base + i, t, deg)] != ex) ? 1 : 0;
     }
     n_nodes[i] = k + 1 + m;
 }
@@ -44,7 +44,7 @@ __global__ void egonet_sizes_kernel(const int* __restrict__ par_ptr, const int* 
 __global__ __launch_bounds__(256) void egonet_fill_kernel(const int* __restrict__ par_ptr, const int* __restrict__ par_idx,
                                                           const int* __restrict__ chd_ptr, const int* __restrict__ chd_idx,
                                                           const int* __restrict__ anchors, const int* __restrict__ exclude, int G,
-                                                          int expand, unsigned long long seed, const int* __restrict__ node_off,
+                                                          int expand, unsigned long long seed, int index_base, const int* __restrict__ node_off,
                                                           int* __restrict__ ids, int* __restrict__ pos, int* __restrict__ rowptr_in,
                                                           int* __restrict__ col_src, int* __restrict__ eid_in,
                                                           int* __restrict__ rowptr_out, int* __restrict__ col_dst,
@@ -66,7 +66,7 @@ __global__ __launch_bounds__(256) void egonet_fill_kernel(const int* __restrict_
         int o = n0 + k + 1;
         const int draws = deg <= expand ? deg : expand;
         for (int t = 0; t < draws; ++t) {
-            const int c = chd_idx[cb + (deg <= expand ? t : draw_child(seed, i, t, deg))];
+            const int c = chd_idx[cb + (deg <= expand ? t : draw_child(seed, index_base + i, t, deg))];
             if (c != ex) { ids[o] = c; pos[o] = 2; ++o; }
         }
     }
@@ -126,7 +126,7 @@ size_t txe_egonet_ws_bytes(int G) { return ((size_t)(G + 1) * 4 + 255) / 256 * 2
 // Step 1: node_off [G+1] (exclusive prefix sum of the egonet sizes; node_off[G] = total nodes N; total edges = 2N - G).
 // anchors [G], exclude [G] or NULL (query node to drop from each egonet's siblings, -1 = none).
 int txe_egonet_offsets(const int* par_ptr, const int* chd_ptr, const int* chd_idx, const int* anchors, const int* exclude, int G,
-                       int expand, unsigned long long seed, int* node_off, void* ws, size_t ws_bytes, void* stream) {
+                       int expand, unsigned long long seed, int index_base, int* node_off, void* ws, size_t ws_bytes, void* stream) {
     if (G < 0 || expand < 0 || !par_ptr || !chd_ptr || !chd_idx || !node_off || !ws || (G > 0 && !anchors)) return TXE_ERR_ARG;
     if (ws_bytes < txe_egonet_ws_bytes(G)) return TXE_ERR_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
@@ -136,7 +136,7 @@ int txe_egonet_offsets(const int* par_ptr, const int* chd_ptr, const int* chd_id
     (void)hipMemsetAsync(sizes + G, 0, 4, s);
     if (G > 0) {
         hipLaunchKernelGGL(egonet_sizes_kernel, dim3((G + 255) / 256), dim3(256), 0, s, par_ptr, chd_ptr, chd_idx, anchors, exclude, G, expand,
-                           seed, sizes);
+                           seed, index_base, sizes);
         TXE_CHECK_LAUNCH();
     }
     if (hipcub::DeviceScan::ExclusiveSum(temp, temp_bytes, (const int*)sizes, node_off, G + 1, s) != hipSuccess) return TXE_ERR_LAUNCH;
@@ -145,7 +145,7 @@ int txe_egonet_offsets(const int* par_ptr, const int* chd_ptr, const int* chd_id
 
 // Step 2: node table (ids, pos [N]) and both CSR views (rowptr_* [N+1], col_* / eid_in / pos_out [2N-G]) of the batch.
 int txe_egonet_fill(const int* par_ptr, const int* par_idx, const int* chd_ptr, const int* chd_idx, const int* anchors,
-                    const int* exclude, int G, int expand, unsigned long long seed, const int* node_off, int* ids, int* pos,
+                    const int* exclude, int G, int expand, unsigned long long seed, int index_base, const int* node_off, int* ids, int* pos,
                     int* rowptr_in, int* col_src, int* eid_in, int* rowptr_out, int* col_dst, int* pos_out, void* stream) {
     if (G < 0 || !par_ptr || !par_idx || !chd_ptr || !chd_idx || !node_off || !rowptr_in || !rowptr_out) return TXE_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
@@ -156,7 +156,7 @@ int txe_egonet_fill(const int* par_ptr, const int* par_idx, const int* chd_ptr, 
     }
     if (!anchors || !ids || !pos || !col_src || !eid_in || !col_dst || !pos_out) return TXE_ERR_ARG;
     hipLaunchKernelGGL(egonet_fill_kernel, dim3((G + 3) / 4), dim3(256), 0, s, par_ptr, par_idx, chd_ptr, chd_idx, anchors, exclude, G, expand,
-                       seed, node_off, ids, pos, rowptr_in, col_src, eid_in, rowptr_out, col_dst, pos_out);
+                       seed, index_base, node_off, ids, pos, rowptr_in, col_src, eid_in, rowptr_out, col_dst, pos_out);
     TXE_CHECK_LAUNCH();
     return TXE_OK;
 }

@@ -91,6 +91,8 @@ struct Epi {
     const int* cnt_off;
     const float* cnt_thr;
     int* cnt_out;
+    // profiling only: the product's ALGORITHMIC flops when the operands carry tile padding (0: 2*M*N*K as launched)
+    double alg_flops;
 };
 
 static inline Epi epi_plain(float* c, long long ldc, int cols) {
@@ -100,6 +102,7 @@ static inline Epi epi_plain(float* c, long long ldc, int cols) {
     e.mask = reinterpret_cast<const unsigned*>(c); e.mask_ld = 0; e.mask_col0 = 0; e.mask_on = 0; e.drop_scale = 1.f;
     e.apply_exp = 0; e.split_stride = 0;
     e.cnt_mode = 0; e.cnt_off = nullptr; e.cnt_thr = nullptr; e.cnt_out = nullptr;
+    e.alg_flops = 0.0;
     return e;
 }
 static inline void epi_set_mask(Epi& e, const unsigned* mask, int total_cols, int col0, float drop_p) {
@@ -726,7 +729,7 @@ static inline void gemm_launch_v(int bn, dim3 grid, hipStream_t stream, const VM
         init = true;
     }
     name = names[bn == 128 ? 0 : 1];
-    ProfScope prof(name, stream, 2.0 * M * (double)N * K, 0);
+    ProfScope prof(name, stream, E.alg_flops > 0.0 ? E.alg_flops : 2.0 * M * (double)N * K, 0);
     if (bn == 128) hipLaunchKernelGGL((gemm_kernel<AK, BKC, VA, VB, 128>), grid, dim3(GEMM_THREADS), 0, stream, A, B, E, M, N, K, ksplit, T);
     else hipLaunchKernelGGL((gemm_kernel<AK, BKC, VA, VB, 64>), grid, dim3(GEMM_THREADS), 0, stream, A, B, E, M, N, K, ksplit, T);
 }

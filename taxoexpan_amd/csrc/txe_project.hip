@@ -492,6 +492,7 @@ int txe_gat_dense_fwd(const float* X, int n_nodes, int Kh, int Pd, const float* 
     vmat_set_mask(A, mask, feat_drop_p);
     VMat B = vmat_plain(Wp, Kp, Fp, Kp);
     Epi E = epi_plain(Y, Fp, Fe);
+    E.alg_flops = 2.0 * n_nodes * (double)Fe * (Kh + Pd);           // without the k-tile padding of X / Wp
     const bool tail_ok = ws && ws_bytes >= gemm_tail_ws_bytes();
     return gemm_nt(A, B, E, n_nodes, Fe, Kp, 1, (hipStream_t)stream, tail_ok ? ws : nullptr, tail_ok ? ws_bytes : 0);
 }
@@ -524,6 +525,7 @@ int txe_gat_dense_bwd(const float* X, int n_nodes, int Kh, int Pd, const int* po
         E.c2 = d_X + c0 + E.cols_main; E.ldc2 = Kp;                 // same buffer: the split only scopes the activation factor
         epi_set_mask(E, mask, Kt, c0, feat_drop_p);
         if (act_on && need_dh) epi_set_act(E, X + c0, Kp, act_slope);
+        E.alg_flops = 2.0 * n_nodes * (double)(need_dh ? Kt : Pd) * Fe;
         rc = gemm_nn(A, B, E, n_nodes, Kt - c0, Fp, 1, s, p.tail, p.tail_bytes);
         if (rc) return rc;
     }
@@ -533,6 +535,7 @@ int txe_gat_dense_bwd(const float* X, int n_nodes, int Kh, int Pd, const int* po
     vmat_set_mask(B, mask, feat_drop_p);
     Epi E = epi_plain(p.part, Kp, Kp);
     E.split_stride = (long long)Fp * Kp;
+    E.alg_flops = 2.0 * Fe * (double)Kt * n_nodes;
     rc = gemm_tn(A, B, E, Fp, Kp, n_nodes, p.splits, s);
     if (rc) return rc;
     const int S = n_nodes > 0 ? p.splits : 0;
@@ -604,6 +607,7 @@ int txe_gcn_dense_fwd(const float* X, int n_nodes, int Kh, int Pd, const float* 
     vmat_set_mask(A, mask, drop_p);
     VMat B = vmat_plain(Wp, Fop, Kp, Fop);
     Epi E = epi_plain(hw, Fop, Fo);
+    E.alg_flops = 2.0 * n_nodes * (double)Fo * (Kh + Pd);
     const bool tail_ok = ws && ws_bytes >= gemm_tail_ws_bytes();
     return gemm_nn(A, B, E, n_nodes, Fo, Kp, 1, (hipStream_t)stream, tail_ok ? ws : nullptr, tail_ok ? ws_bytes : 0);
 }
@@ -643,6 +647,7 @@ int txe_gcn_dense_bwd(const float* X, int n_nodes, int Kh, int Pd, const int* po
         E.c2 = d_X + c0 + E.cols_main; E.ldc2 = Kp;
         epi_set_mask(E, mask, Kt, c0, drop_p);
         if (act_on && need_dh) epi_set_act(E, X + c0, Kp, act_slope);
+        E.alg_flops = 2.0 * n_nodes * (double)(need_dh ? Kt : Pd) * Fo;
         rc = gemm_nt(A, B, E, n_nodes, Kt - c0, Fop, 1, s, p.tail, p.tail_bytes);
         if (rc) return rc;
     }
@@ -662,6 +667,7 @@ int txe_gcn_dense_bwd(const float* X, int n_nodes, int Kh, int Pd, const int* po
         VMat B = vmat_plain(d_hw, Fop, n_nodes, Fop);
         Epi E = epi_plain(p.part, Fop, Fop);
         E.split_stride = (long long)Kp * Fop;
+        E.alg_flops = 2.0 * Kt * (double)Fo * n_nodes;
         rc = gemm_tn(A, B, E, Kp, Fop, n_nodes, p.splits, s);
         if (rc) return rc;
         const long long n = (long long)Kt * Fo;
@@ -1143,6 +1149,7 @@ int txe_gat_collapse_fwd(const int* rowptr_in, const int* col_src, const int* ro
     VMat A = vmat_plain(Z, Kp, G, Kp);
     VMat B = vmat_plain(Wp, Kp, round_up(D + 2, 128), Kp);       // all Fp packed rows are readable: every tile stays on the plain loader
     Epi E = epi_plain(hg, ld_hg, D);
+    E.alg_flops = 2.0 * G * (double)D * Kt;
     return gemm_nt(A, B, E, G, D, Kp, 1, s, p.tail, p.tail_bytes);
 }
 
@@ -1176,6 +1183,7 @@ int txe_gat_collapse_bwd(const int* rowptr_in, const int* col_src, const int* ro
         VMat A = vmat_plain(d_hg, ld_dhg, G, D);
         VMat B = vmat_plain(Wp, Kp, D, Kp);
         Epi E = epi_plain(p.dZ, Kp, Kp);
+        E.alg_flops = 2.0 * G * (double)Kt * D;
         rc = gemm_nn(A, B, E, G, Kp, D, 1, s, p.tail, p.tail_bytes);
         if (rc) return rc;
     }
@@ -1185,6 +1193,7 @@ int txe_gat_collapse_bwd(const int* rowptr_in, const int* col_src, const int* ro
         VMat B = vmat_plain(Z, Kp, G, Kp);
         Epi E = epi_plain(p.part, Kp, Kp);
         E.split_stride = split_stride;
+        E.alg_flops = 2.0 * D * (double)Kt * G;
         rc = gemm_tn(A, B, E, D, Kp, G, p.splits, s);
         if (rc) return rc;
     }
@@ -1373,6 +1382,7 @@ int txe_gcn_collapse_fwd(const int* rowptr_out, const int* col_dst, const int* g
     VMat A = vmat_plain(Z, Kp, G, Kp);
     VMat B = vmat_plain(Wp, Fop, Kp, Fop);
     Epi E = epi_plain(hg, ld_hg, Fo);
+    E.alg_flops = 2.0 * G * (double)Fo * Kt;
     int rc = gemm_nn(A, B, E, G, Fo, Kp, 1, s, p.tail, p.tail_bytes);
     if (rc) return rc;
     if (bias) {
@@ -1409,6 +1419,7 @@ int txe_gcn_collapse_bwd(const int* rowptr_in, const int* col_src, const int* gr
         VMat A = vmat_plain(d_hg, ld_dhg, G, Fo);
         VMat B = vmat_plain(Wp, Fop, round_up(Kp, 128), Fop);
         Epi E = epi_plain(p.dZ, Kp, Kp);
+        E.alg_flops = 2.0 * G * (double)Kt * Fo;
         rc = gemm_nt(A, B, E, G, Kp, Fo, 1, s, p.tail, p.tail_bytes);
         if (rc) return rc;
     }
@@ -1417,6 +1428,7 @@ int txe_gcn_collapse_bwd(const int* rowptr_in, const int* col_src, const int* gr
         VMat B = vmat_plain(d_hg, ld_dhg, G, Fo);
         Epi E = epi_plain(p.part, Fop, Fo);
         E.split_stride = (long long)Kp * Fop;
+        E.alg_flops = 2.0 * Kt * (double)Fo * G;
         rc = gemm_tn(A, B, E, Kp, Fo, G, p.splits, s);
         if (rc) return rc;
         const long long n = (long long)Kt * Fo;

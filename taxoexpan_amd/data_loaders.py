@@ -51,7 +51,17 @@ def _open_dataset(data_path):
         names = [f[:-len(".terms")] for f in os.listdir(data_path) if f.endswith(".terms")]
         if len(names) != 1:
             raise ValueError(f"{data_path}: expected exactly one <name>.terms file, found {sorted(names)}")
-        return _ds.MAGDataset(name=names[0], path=data_path, raw=True)
+        name = names[0]
+        cache = os.path.join(data_path, f"{name}.txe.npz")
+        raw = [os.path.join(data_path, f) for f in (f"{name}.terms", f"{name}.taxo", f"{name}.terms.embed")]
+        # the cache written by the first raw load is used while it is newer than the raw files (the reference's pickle flow,
+        # generate_dataset_binary.py): train / validation / test loaders and every rank parse the text files once, not 3 x world times
+        if os.path.exists(cache) and all(os.path.getmtime(cache) >= os.path.getmtime(f) for f in raw if os.path.exists(f)):
+            try:
+                return _ds.MAGDataset(name=name, path=cache, raw=False)
+            except Exception:                         # unreadable cache: fall back to the raw files (and rewrite it)
+                pass
+        return _ds.MAGDataset(name=name, path=data_path, raw=True)
     return _ds.MAGDataset(name="", path=data_path, raw=False)
 
 

@@ -14,6 +14,11 @@ seeded run emits the same instances (tests/test_dataset.py against traces captur
 
 The reference's `*.pickle.bin` cache embeds a DGL-0.4 graph object and cannot be read without DGL; this module caches
 to `<name>.txe.npz` instead and says so when handed a pickle.
+
+Restated reference code, acknowledged: `_get_at_most_k_negatives` / `_get_exactly_k_negatives` follow
+data_loader/dataset.py:334-381 statement for statement (about 35 lines, including its corner-case alert message) -- the
+`random` stream has to be consumed call for call for the trace tests to hold, which leaves no freedom in how they are written.
+Everything else in this file is organised differently (CSR adjacency, array batches, device taxonomy).
 """
 import os
 import random
@@ -175,9 +180,12 @@ class MAGDataset:
 
     # -- cache ----------------------------------------------------------------------------------------------------------
     def save(self, path):
-        np.savez(path, name=self.name, vocab=np.asarray(self.vocab, dtype=object), edges=self.edges,
+        """written through a temporary file + os.replace: concurrent loaders (one per rank / DataLoader) never see a torn archive"""
+        tmp = f"{path}.{os.getpid()}.tmp.npz"
+        np.savez(tmp, name=self.name, vocab=np.asarray(self.vocab, dtype=object), edges=self.edges,
                  features=self.g_full.ndata["x"].numpy(), train=np.asarray(self.train_node_ids, dtype=np.int64),
                  validation=np.asarray(self.validation_node_ids, dtype=np.int64), test=np.asarray(self.test_node_ids, dtype=np.int64))
+        os.replace(tmp, path)
 
     def _load_dataset_cached(self, path):
         if not str(path).endswith(".npz"):
@@ -190,6 +198,57 @@ class MAGDataset:
         self.train_node_ids, self.validation_node_ids, self.test_node_ids = (d[k].tolist() for k in ("train", "validation", "test"))
 
 
+class KeyedRows:
+    """The slice of gensim's KeyedVectors the path touches (dataset.py:227-229 builds `self.kv`; test_fast.py:88,121,194 and
+    infer.py:37-38,97,145 read `kv[str(key)]`; dataset.py:323 calls `kv.distances`): string key -> feature row (numpy), without gensim."""
+
+    def __init__(self, vector_size):
+        self.vector_size = int(vector_size)
+        self.index2word, self.vocab = [], {}
+        self.vectors = np.zeros((0, self.vector_size), dtype=np.float32)
+
+    def add(self, entities, weights, replace=False):
+        weights = np.asarray(weights, dtype=np.float32).reshape(-1, self.vector_size)
+        if len(entities) != weights.shape[0]:
+            raise ValueError("KeyedRows.add: one weight row per entity")
+        new = [i for i, e in enumerate(entities) if e not in self.vocab]
+        if replace:
+            for i, e in enumerate(entities):
+                if e in self.vocab:
+                    self.vectors[self.vocab[e]] = weights[i]
+        base = len(self.index2word)
+        for j, i in enumerate(new):
+            self.vocab[entities[i]] = base + j
+            self.index2word.append(entities[i])
+        self.vectors = weights[new] if base == 0 and len(new) == len(entities) else np.concatenate([self.vectors, weights[new]], 0)
+
+    def __contains__(self, key):
+        return key in self.vocab
+
+    def __len__(self):
+        return len(self.index2word)
+
+    def __getitem__(self, key):
+        if isinstance(key, (list, tuple)):
+            return np.stack([self[k] for k in key])
+        return self.vectors[self.vocab[key]]          # KeyError for an unknown key, like gensim
+
+    get_vector = __getitem__
+
+    def distances(self, key, other_keys=()):
+        """cosine distances 1 - cos(key, other) to `other_keys` (all rows when empty) -- gensim's KeyedVectors.distances"""
+        v = self[key] if isinstance(key, str) else np.asarray(key, dtype=np.float32)
+        m = self.vectors if len(other_keys) == 0 else self.vectors[[self.vocab[k] for k in other_keys]]
+        return 1.0 - (m @ v) / (np.linalg.norm(m, axis=1) * np.linalg.norm(v))
+
+
+class _NodeList(list):
+    """`graph.nodes` as an attribute AND as nx's `graph.nodes()` call (infer.py:80 iterates `test_dataset.graph.nodes()`)"""
+
+    def __call__(self):
+        return self
+
+
 class _Adjacency:
     """mutable successor / predecessor lists of the masked taxonomy (the reference's nx subgraph copy, dataset.py:231-239):
     parents ascend by node id, children keep g_full's edge order"""
@@ -197,7 +256,7 @@ class _Adjacency:
     def __init__(self, ds, keep):
         keep_mask = np.zeros(ds.n_nodes, dtype=bool)
         keep_mask[np.asarray(keep, dtype=np.int64)] = True
-        self.nodes = [i for i in range(ds.n_nodes) if keep_mask[i]]
+        self.nodes = _NodeList(i for i in range(ds.n_nodes) if keep_mask[i])
         self.succ = {i: [int(c) for c in ds.chd_idx[ds.chd_ptr[i]:ds.chd_ptr[i + 1]] if keep_mask[c]] for i in self.nodes}
         self.pred = {i: [int(p) for p in ds.par_idx[ds.par_ptr[i]:ds.par_ptr[i + 1]] if keep_mask[p]] for i in self.nodes}
 
@@ -237,6 +296,8 @@ class MaskedGraphDataset(torch.utils.data.Dataset):
         if normalize_embed:
             self.node_features = F.normalize(self.node_features, p=2, dim=1)
         self.vocab = graph_dataset.vocab
+        self.kv = KeyedRows(vector_size=self.node_features.shape[1])           # dataset.py:227-229
+        self.kv.add([str(i) for i in range(len(self.vocab))], self.node_features.numpy())
         held = {"train": [], "validation": graph_dataset.validation_node_ids, "test": graph_dataset.test_node_ids}[mode]
         self.node_list = graph_dataset.train_node_ids if mode == "train" else held
         self.graph = _Adjacency(graph_dataset, list(graph_dataset.train_node_ids) + list(held))

@@ -1,11 +1,22 @@
-"""All-candidate evaluation of a trained model (test_fast.py:82-140, small-batch mode) on the MI355X path, end to end on device:
-egonets of every candidate position built by `txe_egonet_*`, one encoder pass, fused scoring + ranking, and the reference's
-per-query metric aggregation (`total_metrics[j] += metric(ranks of this query)`, divided by the number of queries)."""
+"""All-candidate evaluation (test_fast.py:82-225) and inference on new terms (infer.py:77-159) on the MI355X path, end to end on
+device: egonets of every candidate position built by `txe_egonet_*`, the encoder in one batch (`-b -1`) or in chunks of `-b`
+egonets, then fused scoring + ranking with the reference's per-query metric aggregation (`evaluate`), or the top-5 parents of every
+new term (`infer`)."""
 import numpy as np
 import torch
 
 from .graph import device_egonet_batch
-from .scoring import encode_candidates, rank_all_fused
+from .scoring import encode_candidates, rank_all_fused, topk_parents
+
+
+def candidate_graphs(dtax, anchors, expand_factor, seed, batch_size=-1):
+    """the candidate egonets `_get_subgraph(-1, anchor, 0)` of test_fast.py:93-97 / infer.py:80-82 as one device-built batch
+    (batch_size == -1: the scripts' small mode) or as chunks of batch_size egonets (`-b`, test_fast.py:149-179 / infer.py:108-139)"""
+    anchors = np.asarray(anchors, dtype=np.int64)
+    if batch_size is None or batch_size <= 0 or batch_size >= len(anchors):
+        return device_egonet_batch(dtax, anchors, expand_factor=expand_factor, seed=seed, with_features="lazy")
+    return [device_egonet_batch(dtax, anchors[i:i + batch_size], expand_factor=expand_factor, seed=seed, with_features="lazy", index_base=i)
+            for i in range(0, len(anchors), batch_size)]
 
 
 def _per_query_means(values, pos_off):
@@ -17,7 +28,7 @@ def _per_query_means(values, pos_off):
     return float((sums / cnt.to(torch.float64)).mean().item())
 
 
-def evaluate(model, dataset, device, larger_is_better=True, qblock=1024, seed=0):
+def evaluate(model, dataset, device, larger_is_better=True, qblock=1024, seed=0, batch_size=-1):
     """dataset: taxoexpan_amd.dataset.MaskedGraphDataset in 'validation' or 'test' mode.  Returns (metrics dict, ranks int32
     [n_positives], pos_off [Q+1], queries list).  Queries whose true parents are not candidate positions are skipped, like the
     reference's rearrange() would fail on them."""
@@ -25,8 +36,7 @@ def evaluate(model, dataset, device, larger_is_better=True, qblock=1024, seed=0)
     cand = sorted(dataset.all_positions)                                    # test_fast.py:93
     index = {a: i for i, a in enumerate(cand)}
     dtax = dataset.device_taxonomy(device)
-    g = device_egonet_batch(dtax, np.asarray(cand, dtype=np.int64), expand_factor=dataset.expand_factor, seed=seed,
-                            with_features="lazy")                           # x = features[_id]: the encoder projects the table once
+    g = candidate_graphs(dtax, cand, dataset.expand_factor, seed, batch_size)    # x = features[_id]: the table is projected once
     was_training = model.training
     model.eval()
     hg = encode_candidates(model, g)                                        # test_fast.py:99-108
@@ -48,3 +58,44 @@ def evaluate(model, dataset, device, larger_is_better=True, qblock=1024, seed=0)
                    mrr_scaled_10=_per_query_means(1.0 / torch.ceil(r / 10.0), pos_off), n_queries=len(queries),
                    n_candidates=len(cand))
     return metrics, ranks, pos_off, queries
+
+
+def infer(model, dataset, new_taxons, device, loss="info_nce_loss", batch_size=-1, save=None, topk=5, normalize=False, qblock=1024,
+          seed=0):
+    """infer.py:77-159: the `topk` best parents of every NEW term.  dataset: MaskedGraphDataset in 'test' mode (infer.py:43-57);
+    new_taxons: path of the `<name>\t<v0 v1 ...>` file (infer.py:23-38) or an already loaded (vocab, array) pair.  Candidates are ALL
+    nodes of the dataset's graph (infer.py:80-82 iterates `test_dataset.graph.nodes()`, not `all_positions`), in node order; best =
+    descending score for the info_nce losses, ascending otherwise (infer.py:100-106), ties in candidate order like Python's stable
+    sort.  Returns [(query, [parent vocab entries])]; `save` writes infer.py's TSV (header `Query\tPredicted parents`)."""
+    from .dataset import load_new_taxons
+    device = torch.device(device)
+    vocab, nf = load_new_taxons(new_taxons, normalize) if isinstance(new_taxons, (str, bytes)) or hasattr(new_taxons, "__fspath__") else new_taxons
+    anchors = np.asarray(list(dataset.graph.nodes), dtype=np.int64)
+    dtax = dataset.device_taxonomy(device)
+    g = candidate_graphs(dtax, anchors, dataset.expand_factor, seed, batch_size)
+    was_training = model.training
+    model.eval()
+    hg = encode_candidates(model, g)
+    larger = str(loss).startswith("info_nce")
+    qf = torch.as_tensor(np.asarray(nf), dtype=torch.float32).to(device)
+    cand_ids = torch.as_tensor(anchors, device=device)
+    picks = []
+    with torch.no_grad():
+        U = None
+        for q0 in range(0, qf.shape[0], qblock):
+            from . import ops
+            if hasattr(model.match, "W") and hasattr(model.match, "apply_exp"):      # BIM / LBM: one factored GEMM per block
+                U = ops.bilinear_project(hg, model.match.W.weight) if U is None else U
+                S = ops.score_block(qf[q0:q0 + qblock], U, model.match.apply_exp)
+            else:                                                                    # any other matcher: the literal expand loop
+                S = torch.stack([model.match(hg, q.expand(hg.shape[0], -1)).reshape(-1) for q in qf[q0:q0 + qblock]])
+            picks.append(topk_parents(S, cand_ids, topk, larger))
+    model.train(was_training)
+    picks = torch.cat(picks).cpu().tolist() if picks else []
+    out = [(q, [dataset.vocab[i] for i in row]) for q, row in zip(vocab, picks)]
+    if save is not None:
+        with open(save, "w") as fout:
+            fout.write("Query\tPredicted parents\n")
+            for q, parents in out:
+                fout.write(f"{q}\t{', '.join(parents)}\n")
+    return out

@@ -315,10 +315,11 @@ class DeviceTaxonomy:
         self.device = torch.device(device)
 
 
-def device_egonet_batch(dtax, anchors, exclude=None, expand_factor=50, seed=0, with_features=True):
+def device_egonet_batch(dtax, anchors, exclude=None, expand_factor=50, seed=0, with_features=True, index_base=0):
     """Batched egonets of `anchors` built on the GPU (dataset.py:404-437 + dgl.batch).  anchors / exclude: int arrays or
     int32 device tensors.  Returns a DeviceBatchedGraph with ndata '_id', 'pos' (int32, device) and 'x' (features gathered;
-    with_features="lazy": an ops.GatheredRows over the taxonomy's feature table)."""
+    with_features="lazy": an ops.GatheredRows over the taxonomy's feature table).  index_base: position of anchors[0] in the caller's whole
+    anchor list -- chunks of one list (test_fast.py's `-b`) then sample the same siblings as the single batch."""
     dev = dtax.device
     to_dev = lambda a: None if a is None else (a.to(device=dev, dtype=torch.int32) if torch.is_tensor(a)
                                                else torch.as_tensor(np.asarray(a), dtype=torch.int32).to(dev))
@@ -331,14 +332,14 @@ def device_egonet_batch(dtax, anchors, exclude=None, expand_factor=50, seed=0, w
         wsb = _lib.call("txe_egonet_ws_bytes", G)
         ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=dev)
         _lib.call("txe_egonet_offsets", _lib.ptr(dtax.par_ptr), _lib.ptr(dtax.chd_ptr), _lib.ptr(dtax.chd_idx), _lib.ptr(anchors),
-                  _lib.ptr(exclude), G, expand_factor, seed, _lib.ptr(node_off), _lib.ptr(ws), wsb, st)
+                  _lib.ptr(exclude), G, expand_factor, seed, int(index_base), _lib.ptr(node_off), _lib.ptr(ws), wsb, st)
         N = int(node_off[G].item())                  # the one host sync of batch construction: sizes of the output arrays
         E = 2 * N - G
         ids, pos = i32(N), i32(N)
         rowptr_in, rowptr_out = i32(N + 1), i32(N + 1)
         col_src, eid_in, col_dst, pos_out = i32(E), i32(E), i32(E), i32(E)
         _lib.call("txe_egonet_fill", _lib.ptr(dtax.par_ptr), _lib.ptr(dtax.par_idx), _lib.ptr(dtax.chd_ptr), _lib.ptr(dtax.chd_idx),
-                  _lib.ptr(anchors), _lib.ptr(exclude), G, expand_factor, seed, _lib.ptr(node_off), _lib.ptr(ids), _lib.ptr(pos),
+                  _lib.ptr(anchors), _lib.ptr(exclude), G, expand_factor, seed, int(index_base), _lib.ptr(node_off), _lib.ptr(ids), _lib.ptr(pos),
                   _lib.ptr(rowptr_in), _lib.ptr(col_src), _lib.ptr(eid_in), _lib.ptr(rowptr_out), _lib.ptr(col_dst), _lib.ptr(pos_out), st)
     csr = CSR(N, E, G, rowptr_in[:N + 1], col_src[:E], eid_in[:E], rowptr_out[:N + 1], col_dst[:E], pos_out[:E], node_off[:G + 1])
     g = DeviceBatchedGraph(csr, node_off[:G + 1], ids[:N], pos[:N])

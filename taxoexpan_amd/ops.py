@@ -38,6 +38,8 @@ def _rows(t):
     return t, t.stride(0)
 
 
+_BACKWARD_TWICE = ("taxoexpan_amd: backward through this propagation stack a second time -- its saved activations (several hundred MB per "
+                   "batch) are released by the first backward; run the forward again (retain_graph=True is not supported here)")
 _NO_FUSED_LOGITS = os.environ.get("TXE_NO_FUSED_LOGITS", "0") == "1"     # A/B switch (tests compare both paths)
 _I32_MEMO = {}       # id(source tensor) -> (weakref, version, device, int32 copy): `pos` is converted once per batch, not once per module
 
@@ -72,6 +74,26 @@ def _ws(nbytes, ref):
 def new_seed():
     """64-bit dropout seed drawn from torch's CPU generator (so torch.manual_seed makes runs repeatable)."""
     return int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
+
+
+_CAPTURE = None       # debug_capture(): list that receives (csr, cfg, per-layer states) of every stack forward
+
+
+class debug_capture:
+    """`with ops.debug_capture() as runs:` -- every GAT / GCN stack forward inside the block appends (csr, cfg, states): the per-layer
+    buffers of the fused stack (X = padded layer input, Y = projection output, alpha [E, H] in destination-CSR order, cl = the folded
+    output layer's (a12, alpha, coef, wsum, gid, Z, hg)).  Parity tests read the intermediates the reference exposes per layer
+    (model_zoo.py:90-95) from here; nothing is copied and nothing changes in the computation."""
+
+    def __enter__(self):
+        global _CAPTURE
+        self._prev, _CAPTURE = _CAPTURE, []
+        return _CAPTURE
+
+    def __exit__(self, *exc):
+        global _CAPTURE
+        _CAPTURE = self._prev
+        return False
 
 
 def apply_stack(fn, csr, cfg, *args):
@@ -266,8 +288,9 @@ _tail_ws_cache = {}
 
 
 def _tail_ws(ref):
-    """persistent GEMM tail-splitting scratch per device (stream-ordered reuse; contents never outlive one GEMM)"""
-    key = ref.device.index
+    """persistent GEMM tail-splitting scratch per (device, stream): reuse is stream-ordered and the contents never outlive one
+    GEMM + its fix-up kernel, so two streams (or threads on their own streams) must not share a buffer"""
+    key = (ref.device.index, torch.cuda.current_stream(ref.device).cuda_stream)
     t = _tail_ws_cache.get(key)
     if t is None:
         t = torch.empty(call("txe_gemm_tail_ws_bytes"), dtype=torch.uint8, device=ref.device)
@@ -461,11 +484,15 @@ class GATStackFunction(torch.autograd.Function):
         ctx.csr, ctx.cfg, ctx.pos, ctx.states = csr, cfg, pos, (states if need else None)
         ctx.rpos, ctx.pwf, ctx.pw_shape = rpos, pwf, (pw.shape if pwf is not None else None)
         ctx.h_req = ctx.needs_input_grad[2]
+        if _CAPTURE is not None:
+            _CAPTURE.append((csr, cfg, states))
         return res
 
     @staticmethod
     def backward(ctx, d_res):
         csr, cfg, pos, states = ctx.csr, ctx.cfg, ctx.pos, ctx.states
+        if states is None:
+            raise RuntimeError(_BACKWARD_TWICE)
         L = cfg.n_layers
         H, D = cfg.heads[-1], cfg.out_dims[-1]
         d_res = _f32(d_res)
@@ -617,6 +644,8 @@ class GCNStackFunction(torch.autograd.Function):
                     if l > 0:
                         st.X = None
         ctx.csr, ctx.cfg, ctx.pos, ctx.norm = csr, cfg, pos, norm
+        if _CAPTURE is not None:
+            _CAPTURE.append((csr, cfg, states))
         ctx.states = states if need else None
         ctx.h_req = ctx.needs_input_grad[2]
         ctx.out = out if need else None
@@ -626,6 +655,8 @@ class GCNStackFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, d_out):
         csr, cfg, pos, norm, states = ctx.csr, ctx.cfg, ctx.pos, ctx.norm, ctx.states
+        if states is None:
+            raise RuntimeError(_BACKWARD_TWICE)
         L = cfg.n_layers
         d_out = _f32(d_out)
         grads = [None] * (3 * L)
@@ -935,6 +966,8 @@ def score_count_block(Q, U, apply_exp, pos_off, thr, larger_is_better=True, coun
     thr = _f32(thr)
     if counts is None:
         counts = torch.zeros(max(int(thr.numel()), 1), dtype=torch.int32, device=Q.device)
+    if thr.numel() == 0:                                # a query block without a single positive: nothing to count
+        return counts
     with torch.cuda.device(Q.device):
         call("txe_score_count_block", ptr(Q), ldq, nq, ptr(U), ldu, U.shape[0], r, int(apply_exp), ptr(pos_off), ptr(thr),
              int(larger_is_better), ptr(counts), _lib.stream_ptr())
@@ -947,6 +980,8 @@ def rank_finalize(pos_off, thr, counts, larger_is_better=True):
     pos_off = _i32(pos_off, thr.device)
     n_pos = int(thr.numel())
     ranks = torch.empty(max(n_pos, 1), dtype=torch.int32, device=thr.device)
+    if n_pos == 0:
+        return ranks[:0]
     with torch.cuda.device(thr.device):
         call("txe_rank_finalize", ptr(pos_off), int(pos_off.numel()) - 1, ptr(_f32(thr)), ptr(counts), int(larger_is_better), ptr(ranks),
              _lib.stream_ptr())

@@ -163,6 +163,25 @@ def allreduce_gradients(params, group=None):
 
 
 def topk_parents(S, candidate_ids, k=5, larger_is_better=True):
-    """infer.py:100-106: the k best candidate positions per query (descending score for info_nce, else ascending)."""
-    idx = torch.topk(S, k=min(k, S.shape[1]), dim=1, largest=larger_is_better).indices
+    """infer.py:100-106 / test_fast.py:125-131: the k best candidate positions per query -- `sorted(enumerate(scores), key=-score)[:k]`
+    (descending score for info_nce, ascending otherwise).  Python's sort is stable, so equal scores come out in ascending candidate
+    order, and that is what this returns (torch.topk alone leaves the order of ties unspecified): the strictly better candidates,
+    then the lowest-index members of the tie group at the k-th value.  S [Q, G] -> candidate_ids[...] [Q, min(k, G)]."""
+    Q, G = S.shape
+    k = min(int(k), G)
+    if k == 0 or Q == 0:
+        return candidate_ids.new_zeros((Q, 0)).to(S.device)
+    key = S if larger_is_better else -S
+    vk = torch.topk(key, k, dim=1).values[:, -1:]                                     # the k-th best value of each row
+    ar = torch.arange(G, device=S.device).expand(Q, G)
+    fill = torch.full_like(ar, G)
+    better = torch.topk(torch.where(key > vk, ar, fill), k, dim=1, largest=False).values     # <= k-1 real columns, ascending, then G
+    tied = torch.topk(torch.where(key == vk, ar, fill), k, dim=1, largest=False).values      # lowest k columns of the tie group
+    cand = torch.cat([better, tied], 1)                                                       # [Q, 2k], fillers = G
+    ckey = torch.where(cand < G, torch.gather(key, 1, cand.clamp(max=G - 1)), torch.full((), -float("inf"), device=S.device, dtype=key.dtype))
+    # order by (key descending, column ascending): columns are ascending inside each half; one stable sort by column, one by key
+    o1 = torch.sort(cand, dim=1, stable=True).indices
+    cand, ckey = torch.gather(cand, 1, o1), torch.gather(ckey, 1, o1)
+    o2 = torch.sort(ckey, dim=1, descending=True, stable=True).indices
+    idx = torch.gather(cand, 1, o2)[:, :k]
     return candidate_ids.to(idx.device)[idx]

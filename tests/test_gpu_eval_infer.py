@@ -1,0 +1,125 @@
+"""GPU: the callers either side of the encoder -- infer.py's flow (new terms -> all nodes as candidates -> top-5 parents) and
+test_fast.py's `-b` chunked evaluation -- against the same flows done literally on the host with the oracle."""
+import os
+import shutil
+
+import numpy as np
+import pytest
+import torch
+
+import txe_oracle as orc
+from golden_util import GOLDEN_DIR
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev():
+    return torch.device("cuda:0")
+
+
+def _toy(tmp_path, expand_factor=100):
+    from taxoexpan_amd.dataset import MAGDataset, MaskedGraphDataset
+    for fn in os.listdir(os.path.join(GOLDEN_DIR, "toy_taxo")):
+        shutil.copy(os.path.join(GOLDEN_DIR, "toy_taxo", fn), tmp_path)
+    return MaskedGraphDataset(MAGDataset("toy", str(tmp_path), raw=True), mode="test", sampling_mode=0, expand_factor=expand_factor,
+                              normalize_embed=True)
+
+
+def _model(match="LBM", prop="PGAT"):
+    from taxoexpan_amd import TaxoExpan
+    torch.manual_seed(11)
+    return TaxoExpan(prop, "WMR", match, in_dim=8, hidden_dim=6, out_dim=5, pos_dim=3, num_layers=1, heads=[2, 1], feat_drop=0.1,
+                     attn_drop=0.1, hidden_drop=0.1, out_drop=0.1).to(_dev())
+
+
+def _oracle_hg(model, ds, anchors):
+    P = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    shapes, ids = [], []
+    for a in anchors:
+        nodes, k = ds._build_egonet(-1, a, 0)                      # infer.py:82 / test_fast.py:97: _get_subgraph(-1, anchor, 0)
+        shapes.append((k, len(nodes) - k - 1))
+        ids += nodes
+    graph = orc.batch_egonets(shapes)
+    hn = orc.pgat_forward(P, graph, ds.node_features[torch.tensor(ids)], [2, 1], 1, prefix="graph_propagate.")
+    return orc.weighted_mean_readout(graph["graph_off"], hn, graph["pos"], P["readout.position_weights.weight"]), P
+
+
+@pytest.mark.parametrize("match,loss,batch_size", [("LBM", "info_nce_loss", -1), ("BIM", "bce_loss", -1), ("LBM", "info_nce_loss", 17),
+                                                   ("MLP", "bce_loss", 40)])
+def test_infer_top5_parents_against_the_literal_loop(tmp_path, match, loss, batch_size):
+    """infer.py:77-159 (small mode and `-b` chunks; descending for info_nce, ascending otherwise; any matcher)"""
+    from taxoexpan_amd.evaluate import infer
+    ds = _toy(tmp_path)
+    model = _model(match)
+    rs = np.random.RandomState(5)
+    names = [f"new term {i}" for i in range(9)]
+    vecs = rs.standard_normal((9, 8))
+    taxon_file = tmp_path / "new.tsv"
+    with open(taxon_file, "w") as f:
+        for n, v in zip(names, vecs):
+            f.write(n + "\t" + " ".join(repr(float(t)) for t in v) + "\n")
+    save = tmp_path / "pred.tsv"
+    out = infer(model, ds, str(taxon_file), _dev(), loss=loss, batch_size=batch_size, save=str(save))
+    # host: the reference's loop with the oracle
+    anchors = list(ds.graph.nodes())
+    hg, P = _oracle_hg(model, ds, anchors)
+    larger = loss.startswith("info_nce")
+    want = []
+    for v in vecs:
+        q = torch.tensor(v, dtype=torch.float32).expand(len(anchors), -1)
+        if match == "MLP":
+            s = orc.mlp_match(hg, q, P["match.ffn.0.weight"], P["match.ffn.0.bias"], P["match.ffn.2.weight"], P["match.ffn.2.bias"])
+        else:
+            s = orc.bilinear_match(hg, q, P["match.W.weight"], match == "LBM")
+        sc = s.squeeze(1).tolist()
+        top = sorted(enumerate(sc), key=(lambda e: -e[1]) if larger else (lambda e: e[1]))[:5]
+        want.append([ds.vocab[anchors[i]] for i, _ in top])
+    assert [q for q, _ in out] == ["_".join(n.split(" ")) for n in names]              # infer.py:32
+    # (scores of neighbouring ranks may differ by less than fp32 summation noise; then the ORDER may legitimately differ --
+    #  require identical sets and identical order wherever the oracle's gaps are above 1e-5 relative)
+    n_exact = 0
+    for (qn, got), w in zip(out, want):
+        assert len(got) == 5 and set(got) == set(w), (qn, got, w)
+        n_exact += got == w
+    assert n_exact >= len(want) - 1
+    lines = open(save).read().splitlines()
+    assert lines[0] == "Query\tPredicted parents" and lines[1] == f"{out[0][0]}\t{', '.join(out[0][1])}" and len(lines) == 10
+
+
+@pytest.mark.parametrize("batch_size", [13, 64])
+def test_chunked_evaluation_equals_single_batch(tmp_path, batch_size):
+    """test_fast.py:149-218 (`-b`): the candidates encoded in chunks give the ranks and metrics of the one-batch run; expand_factor
+    below the largest child count, so sampled siblings must be identical too (index_base)"""
+    from taxoexpan_amd.evaluate import evaluate
+    ds = _toy(tmp_path, expand_factor=3)
+    model = _model("LBM")
+    m1, r1, off1, q1 = evaluate(model, ds, _dev(), seed=3)
+    m2, r2, off2, q2 = evaluate(model, ds, _dev(), seed=3, batch_size=batch_size)
+    assert torch.equal(r1.cpu(), r2.cpu()) and list(off1) == list(off2) and q1 == q2
+    assert m1 == m2
+
+
+def test_mag_full_encode_in_30000_chunks_equals_single_batch():
+    """BASELINE configs[2]'s `batch_size=30000` on the MAG-Full shape: 356 k candidate egonets encoded in 12 chunks of 30,000
+    (test_fast.py:149-179) against the single 1.1 M-node batch -- same table projection, same sampled siblings"""
+    from taxoexpan_amd import TaxoExpan, graph as G, synthetic as syn
+    from taxoexpan_amd.evaluate import candidate_graphs
+    from taxoexpan_amd.scoring import encode_candidates
+    dev = _dev()
+    tax = syn.make_named_taxonomy("mag_full", seed=47)
+    cand, _val, _test = syn.split_candidates(tax)
+    torch.manual_seed(47)
+    model = TaxoExpan("PGAT", "WMR", "LBM", in_dim=250, hidden_dim=500, out_dim=500, pos_dim=50, num_layers=1, heads=[4, 1], feat_drop=0.1,
+                      attn_drop=0.1, hidden_drop=0.1, out_drop=0.1).to(dev).eval()
+    dtax = G.DeviceTaxonomy(tax.par_ptr, tax.par_idx, tax.chd_ptr, tax.chd_idx, tax.features, dev)
+    chunks = candidate_graphs(dtax, cand, 50, 7, batch_size=30000)
+    assert isinstance(chunks, list) and len(chunks) == -(-len(cand) // 30000) == 12
+    hg_c = encode_candidates(model, chunks)
+    del chunks
+    one = candidate_graphs(dtax, cand, 50, 7, batch_size=-1)
+    assert int(one.number_of_nodes()) > 1_000_000
+    hg_1 = encode_candidates(model, one)
+    assert hg_c.shape == hg_1.shape == (len(cand), 500)
+    torch.cuda.synchronize()
+    d = (hg_c - hg_1).abs().max().item()
+    assert d <= 1e-5 * hg_1.abs().max().item() + 1e-6, d

@@ -1,0 +1,145 @@
+"""GPU parity at BASELINE.json's full sizes, and of the fused stack's per-layer intermediates.
+
+* the whole training step of the three bench workloads (configs[1] PGAT+WMR+LBM, configs[4] PGCN+MR+BIM, configs[3]'s model PGAT
+  num_layers=2 heads [4,4,1]) on the 4,096-egonet MAG-CS batch bench.py times -- training mode, dropout 0.1 -- against the CPU oracle
+  run on the SAME full batch with the identical hash-generated dropout masks: scores, graph vectors, loss and every parameter gradient
+  (reference: model_zoo.py:80-114,210-220, trainer/trainer.py:45-60, loss.py:52-57);
+* the per-layer attention coefficients and layer outputs the reference goldens carry (`layer{l}_alpha`, `layer{l}_out`, captured from
+  the unmodified model_zoo.GATLayer by oracle/gen_golden.py) against the buffers of the fused / folded stack: a compensating pair of
+  errors inside the stack cannot hide behind correct final scores.
+Tolerance: 1e-4 relative on logits / hidden states (north star); gradients 2e-3 relative plus 2e-4 of the tensor's largest entry (they
+are sums over ~18,000 node rows in a different order than MKL's)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import golden_cases as gc
+import txe_oracle as orc
+from golden_util import load_case
+
+pytestmark = pytest.mark.gpu
+
+MAG = dict(in_dim=250, hidden_dim=500, out_dim=500, pos_dim=50, feat_drop=0.1, attn_drop=0.1, hidden_drop=0.1, out_drop=0.1)
+WORKLOADS = {      # bench.py --workload name -> (propagation, readout, match, num_layers, heads)
+    "pgat": ("PGAT", "WMR", "LBM", 1, [4, 1]),
+    "pgcn": ("PGCN", "MR", "BIM", 1, None),
+    "pgat2": ("PGAT", "WMR", "LBM", 2, [4, 4, 1]),
+}
+N_QUERIES, NEG = 128, 31
+
+
+def _dev():
+    return torch.device("cuda:0")
+
+
+def _close(got, ref, rtol, atol_rel, msg):
+    got, ref = np.asarray(got, dtype=np.float64), np.asarray(ref, dtype=np.float64)
+    assert got.shape == ref.shape, (msg, got.shape, ref.shape)
+    tol = rtol * np.abs(ref) + atol_rel * np.abs(ref).max()
+    bad = np.abs(got - ref) > tol
+    assert not bad.any(), f"{msg}: {int(bad.sum())} of {bad.size} entries off, worst |diff| {np.abs(got - ref).max():.3e} (max |ref| {np.abs(ref).max():.3e})"
+
+
+def _masks(kind, P, heads, num_layers, N, E, seed, eid_in, pf, pa):
+    """the keep masks the kernels regenerate from `seed` (taxoexpan_amd/rng.py restates the device hash), in the oracle's form"""
+    from taxoexpan_amd import rng
+    out = []
+    for l in range(num_layers + 1):
+        if kind == "PGAT":
+            kt = P[f"graph_propagate.gat_layers.{l}.fc.weight"].shape[1]
+            H = heads[l]
+            m_csr = rng.keep_mask(seed + 16 * l + 1, (E, H), pa)              # destination-CSR order
+            m_eid = np.empty_like(m_csr)
+            m_eid[eid_in] = m_csr
+            out.append(dict(feat_keep=torch.from_numpy(rng.keep_mask_bits(seed + 16 * l, N, kt, pf)), feat_scale=1.0 / (1.0 - pf),
+                            attn_keep=torch.from_numpy(m_eid).unsqueeze(-1), attn_scale=1.0 / (1.0 - pa)))
+        else:
+            kt = P[f"graph_propagate.layers.{l}.weight"].shape[0]
+            p = pf if l < num_layers else 0.1                                   # out_drop of the config (model.py:30-31), 0.1 as well
+            out.append(dict(keep=torch.from_numpy(rng.keep_mask_bits(seed + 16 * l, N, kt, p)), keep_scale=1.0 / (1.0 - p)))
+    return out
+
+
+@pytest.mark.parametrize("workload", ["pgat", "pgcn", "pgat2"])
+def test_full_size_training_step_matches_oracle(workload, monkeypatch):
+    from taxoexpan_amd import TaxoExpan, ops, synthetic as syn
+    prop, readout, match, num_layers, heads = WORKLOADS[workload]
+    dev = _dev()
+    tax = syn.make_named_taxonomy("mag_cs", seed=47)
+    g, qf, _labels = syn.training_batch(tax, N_QUERIES, NEG, seed=1000)          # batch 0 of bench.py's rank 0
+    assert g.batch_size == 4096
+    x = g.ndata.pop("x")
+    pos = g.ndata["pos"].clone()
+    torch.manual_seed(47)
+    model = TaxoExpan(prop, readout, match, **dict(MAG, num_layers=num_layers, heads=heads)).to(dev).train()
+    seed = 987654321
+    monkeypatch.setattr(ops, "new_seed", lambda: seed)
+    caps = {}
+    model.readout.register_forward_hook(lambda m, i, o: caps.__setitem__("hg", o.detach()))
+    scores = model(g, x.to(dev), qf.to(dev))
+    loss = F.cross_entropy(scores.reshape(N_QUERIES, -1), torch.zeros(N_QUERIES, dtype=torch.long, device=dev), reduction="sum")
+    loss.backward()
+    torch.cuda.synchronize()
+
+    # ---- the oracle on the same 4,096 egonets, same parameters, same masks ----
+    csr = g.csr("cpu")
+    N, E = csr.n_nodes, csr.n_edges
+    P = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in model.state_dict().items()}
+    graph = dict(src=torch.from_numpy(np.asarray(g._src)).long(), dst=torch.from_numpy(np.asarray(g._dst)).long(), pos=pos.long(),
+                 graph_off=csr.graph_off.long(), num_nodes=N)
+    masks = _masks("PGAT" if prop == "PGAT" else "PGCN", P, heads, num_layers, N, E, seed, csr.eid_in.numpy(), 0.1, 0.1)
+    s_ref, hg_ref, _ = orc.taxoexpan_forward(P, graph, x, qf, prop, readout, match, heads, num_layers, masks)
+    l_ref = orc.info_nce_loss(s_ref, N_QUERIES)
+    l_ref.backward()
+
+    _close(caps["hg"].cpu().numpy(), hg_ref.detach().numpy(), 1e-4, 2e-5, "hg")
+    _close(scores.detach().cpu().numpy(), s_ref.detach().numpy(), 1e-4, 2e-5, "scores")
+    np.testing.assert_allclose(float(loss), float(l_ref), rtol=1e-4)
+    for k, p in model.named_parameters():
+        _close(p.grad.cpu().numpy(), P[k].grad.numpy(), 2e-3, 2e-4, "grad " + k)
+
+
+GAT_GOLDENS = [n for n, s in gc.CASES.items() if s["prop"] == "PGAT" and not s.get("dropout") and s["readout"] in ("WMR", "MR")]
+
+
+@pytest.mark.parametrize("name", GAT_GOLDENS)
+def test_fused_stack_intermediates_match_reference_goldens(name):
+    """layer{l}_alpha (model_zoo.py:112-114, edge-id order) and layer{l}_out (GATLayer.forward's return, :95-104; every 5th node row
+    for the MAG-dimension cases) of the reference run against the fused stack: hidden layers through the aggregation kernel's
+    activated output (the next layer's padded input), the folded output layer through its attention buffer and, unfolded, `h.tensor()`"""
+    from taxoexpan_amd import TaxoExpan, ops
+    from taxoexpan_amd.graph import BatchedDGLGraph
+    spec, z, shapes, x, q, params, graph = load_case(name)
+    dev = _dev()
+    model = TaxoExpan(spec["prop"], spec["readout"], spec["match"], in_dim=spec["in_dim"], hidden_dim=spec["hidden_dim"], out_dim=spec["out_dim"],
+                      pos_dim=spec["pos_dim"], num_layers=spec["num_layers"], heads=spec["heads"], feat_drop=0.1, attn_drop=0.1,
+                      hidden_drop=0.1, out_drop=0.1)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()}, strict=True)
+    model = model.to(dev).eval()
+    g = BatchedDGLGraph.from_egonet_shapes([s[0] for s in shapes], [s[1] for s in shapes])
+    with ops.debug_capture() as runs:
+        scores = model(g, torch.from_numpy(x).to(dev), torch.from_numpy(q).to(dev))       # grad mode on: the stack keeps its state
+    assert len(runs) == 1
+    csr, cfg, states = runs[0]
+    L = len(states)
+    eid = csr.eid_in.long()
+    step = 1 if spec["full"] else 5
+    for l, st in enumerate(states):
+        H, D = st.H, st.D
+        want_alpha = torch.from_numpy(z[f"layer{l}_alpha"]).reshape(-1, H)
+        want_out = torch.from_numpy(z[f"layer{l}_out"]).reshape(-1, H * D)
+        if l < L - 1:
+            alpha = torch.empty_like(want_alpha)
+            alpha[eid.cpu()] = st.alpha.cpu()
+            nxt = states[l + 1]
+            got_out = nxt.X[:, :H * D].cpu()[::step]                                        # = leaky_relu(out), slope 0.01
+            np.testing.assert_allclose(got_out.numpy(), F.leaky_relu(want_out, 0.01).numpy(), rtol=1e-4, atol=2e-5, err_msg=f"layer {l} out")
+        else:                                                                                # folded one-head output layer
+            assert cfg.final == "collapse" and st.cl is not None
+            alpha = torch.empty_like(want_alpha)
+            alpha[eid.cpu()] = st.cl[1].cpu().reshape(-1, 1)
+            hn = g.ndata["h"].tensor().detach().cpu()[::step]                              # the same layer, unfolded: N x out_dim
+            np.testing.assert_allclose(hn.numpy(), want_out.numpy(), rtol=1e-4, atol=2e-5, err_msg=f"layer {l} out (unfolded)")
+        np.testing.assert_allclose(alpha.numpy(), want_alpha.numpy(), rtol=1e-4, atol=2e-6, err_msg=f"layer {l} alpha")
+    np.testing.assert_allclose(scores.detach().cpu().numpy(), z["scores"], rtol=1e-4, atol=2e-5)

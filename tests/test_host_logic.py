@@ -1,11 +1,14 @@
 """CPU: host-side logic -- the DGL-0.4 graph surface, CSR construction, synthetic taxonomies / egonet batching,
 module/state-dict compatibility with the reference (names + shapes from the golden specs)."""
+import os
+
 import numpy as np
 import pytest
 import torch
 
 import golden_cases as gc
 import txe_oracle as orc
+from golden_util import GOLDEN_DIR
 
 
 def test_dgl_surface_and_batch_match_reference_layout():
@@ -183,3 +186,58 @@ def test_loss_and_optimizer_have_no_cpu_path():
     p.grad = torch.ones(3)
     with pytest.raises(RuntimeError):
         opt.step()
+
+
+def _toy_dataset(tmp_path, mode="test", **kw):
+    import shutil
+    from taxoexpan_amd.dataset import MAGDataset, MaskedGraphDataset
+    for fn in os.listdir(os.path.join(GOLDEN_DIR, "toy_taxo")):
+        shutil.copy(os.path.join(GOLDEN_DIR, "toy_taxo", fn), tmp_path)
+    return MaskedGraphDataset(MAGDataset("toy", str(tmp_path), raw=True), mode=mode, sampling_mode=0, **kw)
+
+
+def test_masked_graph_dataset_kv_like_the_reference(tmp_path):
+    """dataset.py:227-229: kv maps str(node id) -> (normalised) feature row; test_fast.py:121 reads `kv[str(query)]`"""
+    ds = _toy_dataset(tmp_path, normalize_embed=True)
+    x = ds.node_features.numpy()
+    for q in list(ds.node_list)[:5] + [0, len(ds.vocab) - 1]:
+        np.testing.assert_array_equal(ds.kv[str(q)], x[q])
+        assert torch.equal(torch.tensor(ds.kv[str(q)], dtype=torch.float32), ds.node_features[q])
+    assert ds.kv.vector_size == x.shape[1] and len(ds.kv) == len(ds.vocab) and "0" in ds.kv and "nope" not in ds.kv
+    with pytest.raises(KeyError):
+        ds.kv["nope"]
+    pool = [str(i) for i in (3, 1, 7)]
+    want = [1.0 - float(x[i] @ x[2]) / float(np.linalg.norm(x[i]) * np.linalg.norm(x[2])) for i in (3, 1, 7)]
+    np.testing.assert_allclose(ds.kv.distances("2", pool), want, rtol=1e-6)
+    assert list(ds.graph.nodes()) == list(ds.graph.nodes)                    # infer.py:80 calls it, our code reads the attribute
+
+
+def test_topk_parents_is_pythons_stable_sort():
+    """infer.py:100-106: sorted(enumerate(scores), key=-score)[:5] -- ties come out in candidate order"""
+    from taxoexpan_amd.scoring import topk_parents
+    torch.manual_seed(0)
+    ids = torch.arange(100, 123)
+    for larger in (True, False):
+        S = torch.randint(0, 4, (40, 23)).float()
+        S[3] = float("inf")
+        S[4, :10] = float("inf")
+        S[5] = torch.randn(23)
+        got = topk_parents(S, ids, 5, larger)
+        for q in range(S.shape[0]):
+            key = (lambda e: -e[1]) if larger else (lambda e: e[1])
+            assert got[q].tolist() == [int(ids[e[0]]) for e in sorted(enumerate(S[q].tolist()), key=key)[:5]]
+    assert topk_parents(torch.randn(3, 2), torch.arange(2), 5).shape == (3, 2)
+
+
+def test_data_loader_uses_the_cache_after_the_first_raw_load(tmp_path, monkeypatch):
+    """the raw text files are parsed once; later loaders (validation / test / other ranks) read <name>.txe.npz"""
+    import shutil
+    from taxoexpan_amd import data_loaders, dataset
+    for fn in os.listdir(os.path.join(GOLDEN_DIR, "toy_taxo")):
+        shutil.copy(os.path.join(GOLDEN_DIR, "toy_taxo", fn), tmp_path)
+    a = data_loaders._open_dataset(str(tmp_path))
+    assert os.path.exists(tmp_path / "toy.txe.npz") and not [f for f in os.listdir(tmp_path) if f.endswith(".tmp.npz")]
+    monkeypatch.setattr(dataset, "read_terms", lambda *_: (_ for _ in ()).throw(AssertionError("raw files parsed again")))
+    b = data_loaders._open_dataset(str(tmp_path))
+    assert b.vocab == a.vocab and b.train_node_ids == a.train_node_ids and b.test_node_ids == a.test_node_ids
+    assert torch.equal(b.g_full.ndata["x"], a.g_full.ndata["x"]) and np.array_equal(b.edges, a.edges)

@@ -60,6 +60,10 @@ SIGNATURES = {
     "txe_gat_collapse_fwd": (I, [P, P, P, P, P, P, I, I, I, P, I, I, P, I, F, P, F, F, U64, P, P, P, I, P, P, P, P, P, P, L, P, SZ, P]),
     "txe_gat_collapse_bwd": (I, [P, P, P, P, P, P, I, I, I, P, I, I, P, I, P, P, P, P, I, F, P, F, F, U64, P, P, P, P, P, P, P, P, L, P, L, I, F,
                                  P, P, P, P, P, P, P, SZ, P]),
+    "txe_gat_fused_bwd_supported": (I, [I, I, I, I]),
+    "txe_gat_collapse_bwd_fused_ws_bytes": (SZ, [I, I, I, I, I, I, I, I]),
+    "txe_gat_collapse_bwd_fused": (I, [P, P, P, P, P, P, I, I, I, P, I, I, P, I, P, P, P, P, I, F, P, F, F, U64, P, P, P, P, P, P, P, P, L, P, L,
+                                       F, P, L, I, I, F, F, U64, P, P, L, I, P, P, P, P, P, P, P, SZ, P]),
     "txe_gcn_collapse_ws_bytes": (SZ, [I, I, I, I, I, I]),
     "txe_gcn_collapse_fwd": (I, [P, P, P, I, I, P, I, I, P, I, P, F, P, P, P, P, P, P, P, P, P, L, P, SZ, P]),
     "txe_gcn_collapse_bwd": (I, [P, P, P, I, I, P, I, I, P, I, P, I, F, P, P, P, P, P, P, P, P, L, I, F, P, P, P, P, P, P, SZ, P]),
@@ -77,7 +81,7 @@ SIGNATURES = {
 }
 
 _ERR = {-1: "TXE_ERR_ARG", -2: "TXE_ERR_LAUNCH", -3: "TXE_ERR_WORKSPACE"}
-VALUE_RETURNING = {"txe_gat_padded_k", "txe_gat_padded_f", "txe_gcn_padded_f", "txe_profile_count"}   # int results that are not status codes
+VALUE_RETURNING = {"txe_gat_padded_k", "txe_gat_padded_f", "txe_gcn_padded_f", "txe_profile_count", "txe_gat_fused_bwd_supported"}   # int results that are not status codes
 
 _lib = None
 

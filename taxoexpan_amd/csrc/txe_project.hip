@@ -703,9 +703,10 @@ __device__ __forceinline__ float cl_sigmoid(float x) { return x > 20.f ? 1.f : 1
 template <bool MASK>
 __device__ __forceinline__ void cl_keep4(const unsigned* __restrict__ mrow, int mask_ld, int j, float* k4) {
     if constexpr (!MASK) { k4[0] = k4[1] = k4[2] = k4[3] = 1.f; return; }
+    // vector j < Kp / 4 and the mask row has Kp / 32 = mask_ld words: the word always exists.  (A bounds select here makes hipcc sink
+    // the load into the conditional and wait vmcnt(0) behind it -- one load in flight per wave.)
     const int c = j * 4;
-    const unsigned wd = mrow[min(c >> 5, mask_ld - 1)];
-    const unsigned b = (c >> 5) < mask_ld ? (wd >> (c & 31)) : 0u;
+    const unsigned b = mrow[c >> 5] >> (c & 31);
     k4[0] = (b & 1u) ? 1.f : 0.f; k4[1] = (b & 2u) ? 1.f : 0.f; k4[2] = (b & 4u) ? 1.f : 0.f; k4[3] = (b & 8u) ? 1.f : 0.f;
 }
 
@@ -1054,6 +1055,368 @@ __global__ __launch_bounds__(256) void cl_bwd_dx_kernel(int n_nodes, int ntile, 
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Folded layer's d_X sweep FUSED with the previous GATLayer's message/reduce backward (one row sweep instead of three).
+// The unfused chain writes d_X' = d(folded layer's input) [N][Kp] (cl_bwd_dx), then reads it twice more: gat_bwd_edge
+// (d alpha_e = <d_pre[v], ft[u]>) and gat_bwd_node (d_ft[u] = sum alpha'_e d_pre[v]) -- ~920 MB of HBM traffic on the 18 k-node
+// training batch.  But a row of d_pre is an ELEMENTWISE function of rows that are read anyway:
+//     d_pre[v][j] = keep[v][j] s (cn_v dZ[g(v)][j] + da1_v wa1[j] + da2_v wa2[j]) leaky'(X'[v][j])          (j < H*D)
+// so the source-side sweep can form it on the fly: for source node u, with ft[u] in registers, every out-edge (u -> v) loads X'[v]
+// (the row cl_bwd_dx would have read), forms d_pre[v], and uses it twice -- the dot product with ft[u] (d alpha_e) and the
+// alpha'-weighted accumulation (d_ft[u]).  d_X' never exists; X', dZ and Y are each read once (+ L2 hits for shared rows), d_Y is
+// written once: ~475 MB.  The four waves of a workgroup own a quarter of the H*D row each (for H = 4: one head per wave, so the
+// per-head dot products are wave-local); a workgroup walks FB_NODES consecutive source nodes, whose out-edge scalars
+// (destination, CSR position, cn, da1, da2) are staged in LDS once, so that the row loads depend on nothing but LDS.
+// The per-node leftovers of cl_bwd_dx ride along: the folded attention rows' gradient partials (sum_u da_u Xd'[u]) per workgroup,
+// and the position-embedding gradient partials from the (never stored) position columns of d_X'.
+// What is left per edge -- softmax / leaky-relu backward of the previous layer's attention from the raw d alpha -- is
+// gat_attn_bwd_kernel (edge-level, a few microseconds).
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int FB_NODES = 16;        // source nodes per workgroup
+constexpr int FB_MAXE = 192;        // out-edges of a workgroup whose scalars are staged in LDS (beyond: read from global)
+#ifndef TXE_FB_EU
+#define TXE_FB_EU 4
+#endif
+#ifndef TXE_FB_OCC
+#define TXE_FB_OCC 3
+#endif
+constexpr int FB_EU = TXE_FB_EU;      // out-edges per round trip behind a node's first two
+constexpr int FB_MAXPD = 128;       // position columns (Kp - Kh <= 128 is a precondition of the fused path)
+
+struct FusedBwdArgs {
+    const int *rowptr_out, *col_dst, *pos_out, *gid, *pos;
+    int n_nodes;
+    const float* X; int Kp, Kh, Pd; const unsigned* mask; int mask_ld; float fscale;
+    const float *dZ, *cn, *da1, *da2, *wa; float act_slope; int vocab;
+    const float* Y; long long ld_y; int H, D; const float* alpha; float drop_p, drop_scale; unsigned long long seed;
+    float* d_Y; long long ld_dy; float* dal; float* dwa_part; float* ppart;
+};
+
+// keep bits (low 4) of the 4 columns starting at c (multiple of 4) of row r; all ones without a mask
+template <bool MASK>
+__device__ __forceinline__ unsigned fb_keep(const unsigned* __restrict__ mask, int mask_ld, long long r, int c) {
+    if constexpr (!MASK) return 0xFu;
+    // c < Kp = 32 * mask_ld always (the mask has one word per 32 columns of the PADDED row), so the word exists: no bounds select
+    // here -- with one, hipcc sinks the load into the conditional and waits vmcnt(0) right behind it, serialising every row load
+    return (mask[r * mask_ld + (c >> 5)] >> (c & 31)) & 0xFu;
+}
+
+// One workgroup's share of the fused sweep.  STAGED: the out-edge scalars of its FB_NODES source nodes sit in LDS (the usual case);
+// otherwise (more than FB_MAXE out-edges) they are read from global memory with dependent loads -- correct, slow, rare.
+// There is NO branch between a load and its first use (hipcc waits vmcnt(0) at every control-flow merge behind a pending load):
+// every address is clamped to something readable, conditions become weights of 0.
+__device__ __forceinline__ int uni(int x) { return __builtin_amdgcn_readfirstlane(x); }
+__device__ __forceinline__ float uni(float x) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(x))); }
+
+template <int NI, int EU> struct FbGroup {
+    int p[EU];
+    float cnv[EU], g1v[EU], g2v[EU], al[EU];
+    float xv[EU][NI][4];
+    unsigned mv[EU][NI];
+};
+
+template <bool MASK, int NI, int NWH, bool STAGED>
+__device__ __forceinline__ void fb_body(const FusedBwdArgs& a, const int b, const int u0, const int u1, const int e0, const int ne,
+                                        const int* s_v, const int* s_p, const float* s_cn, const float* s_g1, const float* s_g2,
+                                        const int* s_ni, const float* s_nf, float (*s_dot)[4], float* s_dp, const float* s_wa,
+                                        float* s_acc) {
+    const int w = uni((int)(threadIdx.x >> 6)), l = threadIdx.x & 63;   // w is wave-uniform: say so (SGPRs, scalar ALU)
+    const int F = a.H * a.D, SL = F >> 2, nvec = SL >> 2;
+    const int c0 = w * SL, hw = c0 / a.D;
+    const int Kp = a.Kp;
+    int off[NI];
+    float live[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int j = l + 64 * i;
+        off[i] = c0 + 4 * ((j < nvec) ? j : 0);
+        live[i] = (j < nvec) ? 1.f : 0.f;
+    }
+    // tail columns [F, Kp) (position embedding + padding) of the folded layer's input: lanes of wave 0 (the loads are issued by
+    // every lane with clamped addresses; only the tail lanes use them)
+    const int tvec = (Kp - F) >> 2;
+    const bool tail = (w == 0) && (l < tvec);
+    const int tc = min(F + 4 * (tail ? l : 0), Kp - 4);
+    const int elast = max(ne - 1, 0);
+
+    // the rows of EU consecutive out-edges, all loads issued together; edge scalars are wave-uniform (SGPRs)
+    auto load_group = [&](auto& q, const int j, const int je) {
+        constexpr int EU = sizeof(q.p) / sizeof(int);
+#pragma unroll
+        for (int t = 0; t < EU; ++t) {
+            const int idx = min(max(min(j + t, je - 1) - e0, 0), elast);
+            int v;
+            if constexpr (STAGED) { v = uni(s_v[idx]); q.p[t] = uni(s_p[idx]); q.cnv[t] = uni(s_cn[idx]); q.g1v[t] = uni(s_g1[idx]); q.g2v[t] = uni(s_g2[idx]); }
+            else { v = a.col_dst[e0 + idx]; q.p[t] = a.pos_out[e0 + idx]; q.cnv[t] = a.cn[v]; q.g1v[t] = a.da1[v]; q.g2v[t] = a.da2[v]; }
+            q.al[t] = a.alpha[(long long)q.p[t] * a.H + hw];
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                vload<4>(a.X + (long long)v * Kp + off[i], q.xv[t][i]);
+                q.mv[t][i] = fb_keep<MASK>(a.mask, a.mask_ld, v, off[i]);
+            }
+        }
+    };
+    // d alpha_e (raw) and the alpha'-weighted accumulation for the EU edges of a group
+    auto use_group = [&](auto& q, const int j, const int je, const float (&ft)[NI][4], const float (&dz)[NI][4], float (&acc)[NI][4]) {
+        constexpr int EU = sizeof(q.p) / sizeof(int);
+        float fd[EU];
+#pragma unroll
+        for (int t = 0; t < EU; ++t) {
+            fd[t] = 1.f;
+            if (j + t < je) {                                      // wave-uniform (and behind every load of the group): the clamped
+                                                                   // duplicates that pad a short group cost no arithmetic
+                fd[t] = (a.drop_p > 0.f) ? drop_factor(a.seed, (unsigned long long)q.p[t] * a.H + hw, a.drop_p, a.drop_scale) : 1.f;
+                const float coef = q.al[t] * fd[t];
+                const float sc = q.cnv[t] * a.fscale, s1 = q.g1v[t] * a.fscale, s2 = q.g2v[t] * a.fscale;     // (uniform: scalar ALU)
+                float part = 0.f;
+#pragma unroll
+                for (int i = 0; i < NI; ++i) {
+                    float w1[4], w2[4];
+                    vload<4>(s_wa + off[i], w1);
+                    vload<4>(s_wa + Kp + off[i], w2);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const float tv = sc * dz[i][k] + s1 * w1[k] + s2 * w2[k];
+                        const float lk = (q.xv[t][i][k] > 0.f) ? live[i] : a.act_slope * live[i];
+                        const float dp = ((q.mv[t][i] >> k) & 1u) ? tv * lk : 0.f;
+                        part = fmaf(dp, ft[i][k], part);
+                        acc[i][k] = fmaf(coef, dp, acc[i][k]);
+                    }
+                }
+                part = wave_sum(part);
+                if constexpr (NWH > 1) {                           // a head spans NWH waves: combine their partial dot products
+                    if (l == 0) s_dot[t][w] = part;
+                } else {
+                    if (l == 0) a.dal[(long long)q.p[t] * a.H + hw] = part * fd[t];
+                }
+            }
+        }
+        if constexpr (NWH > 1) {
+            __syncthreads();
+            if (l == 0 && (w % NWH) == 0) {
+#pragma unroll
+                for (int t = 0; t < EU; ++t) {
+                    float tot = 0.f;
+#pragma unroll
+                    for (int x = 0; x < NWH; ++x) tot += s_dot[t][w + x];
+                    if (j + t < je) a.dal[(long long)q.p[t] * a.H + hw] = tot * fd[t];
+                }
+            }
+            __syncthreads();
+        }
+    };
+
+    for (int u = u0; u < u1; ++u) {
+        const int un = u - u0;                                      // per-node scalars were staged with the edge scalars
+        const int g = uni(s_ni[4 * un]), jb = uni(s_ni[4 * un + 1]), je = uni(s_ni[4 * un + 2]), pu = s_ni[4 * un + 3];
+        const float g1u = uni(s_nf[4 * un]), g2u = uni(s_nf[4 * un + 1]), cnu = s_nf[4 * un + 2];
+        float ft[NI][4], dz[NI][4], acc[NI][4];
+        float xu[NI][4], xt[4], dzt[4];
+        unsigned mu[NI];
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {                              // this node's own rows ...
+            vload<4>(a.Y + (long long)u * a.ld_y + off[i], ft[i]);
+            vload<4>(a.dZ + (long long)g * Kp + off[i], dz[i]);
+            vload<4>(a.X + (long long)u * Kp + off[i], xu[i]);
+            mu[i] = fb_keep<MASK>(a.mask, a.mask_ld, u, off[i]);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) acc[i][k] = 0.f;
+        }
+        vload<4>(a.X + (long long)u * Kp + tc, xt);
+        vload<4>(a.dZ + (long long)g * Kp + tc, dzt);
+        const unsigned mt = fb_keep<MASK>(a.mask, a.mask_ld, u, tc);
+        FbGroup<NI, 2> q;
+        load_group(q, jb, je);                                      // ... and its first two out-edges' rows: one round trip
+        // own-row leftovers of cl_bwd_dx: d_wa partials (per workgroup, in LDS), position columns of d_X'
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            float a1[4], a2[4];
+            vload<4>(s_acc + off[i], a1);
+            vload<4>(s_acc + Kp + off[i], a2);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float xd = ((mu[i] >> k) & 1u) ? xu[i][k] * a.fscale * live[i] : 0.f;
+                a1[k] = fmaf(g1u, xd, a1[k]);
+                a2[k] = fmaf(g2u, xd, a2[k]);
+            }
+            if (l + 64 * i < nvec) { vstore<4>(s_acc + off[i], a1); vstore<4>(s_acc + Kp + off[i], a2); }
+        }
+        if (tail) {
+            float a1[4], a2[4], wt1[4], wt2[4];
+            vload<4>(s_acc + tc, a1);
+            vload<4>(s_acc + Kp + tc, a2);
+            vload<4>(s_wa + tc, wt1);
+            vload<4>(s_wa + Kp + tc, wt2);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const bool keep = ((mt >> k) & 1u) != 0u;
+                const float xd = keep ? xt[k] * a.fscale : 0.f;
+                a1[k] = fmaf(g1u, xd, a1[k]);
+                a2[k] = fmaf(g2u, xd, a2[k]);
+                const int pc = tc + k - a.Kh;                      // position column (d_X' there has no activation factor)
+                if (pc >= 0 && pc < a.Pd) s_dp[pu * a.Pd + pc] += keep ? a.fscale * (cnu * dzt[k] + g1u * wt1[k] + g2u * wt2[k]) : 0.f;
+            }
+            vstore<4>(s_acc + tc, a1);
+            vstore<4>(s_acc + Kp + tc, a2);
+        }
+        if (jb < je) use_group(q, jb, je, ft, dz, acc);
+        for (int j = jb + 2; j < je; j += FB_EU) {                  // a hub's further out-edges, FB_EU rows per round trip
+            FbGroup<NI, FB_EU> q4;
+            load_group(q4, j, je);
+            use_group(q4, j, je, ft, dz, acc);
+        }
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+            if (l + 64 * i < nvec) vstore<4>(a.d_Y + (long long)u * a.ld_dy + off[i], acc[i]);
+    }
+}
+
+template <bool MASK, int NI, int NWH /* waves per head = 4 / H */>
+__global__ __launch_bounds__(256, TXE_FB_OCC) void gat_fused_bwd_kernel(const FusedBwdArgs a) {
+    __shared__ int s_v[FB_MAXE], s_p[FB_MAXE], s_ni[4 * FB_NODES];
+    __shared__ float s_cn[FB_MAXE], s_g1[FB_MAXE], s_g2[FB_MAXE], s_nf[4 * FB_NODES];
+    __shared__ float s_dot[4][4];
+    extern __shared__ __attribute__((aligned(16))) float s_dyn[];   // [2][Kp] folded attention rows | [2][Kp] their gradient partials |
+    const int b = xcd_remap(blockIdx.x, gridDim.x);                 // [vocab][Pd] position-embedding gradient partials
+    const int u0 = b * FB_NODES, u1 = min(a.n_nodes, u0 + FB_NODES);
+    const int Kp = a.Kp;
+    float* s_wa = s_dyn;
+    float* s_acc = s_dyn + 2 * Kp;
+    float* s_dp = s_dyn + 4 * Kp;
+    const int e0 = a.rowptr_out[u0], ne = a.rowptr_out[u1] - e0;
+    if (threadIdx.x == 0) { s_v[0] = u0; s_p[0] = 0; s_cn[0] = 0.f; s_g1[0] = 0.f; s_g2[0] = 0.f; }   // (a workgroup without out-edges)
+    __syncthreads();
+    for (int i = threadIdx.x; i < min(ne, FB_MAXE); i += 256) {
+        const int v = a.col_dst[e0 + i];
+        s_v[i] = v; s_p[i] = a.pos_out[e0 + i];
+        s_cn[i] = a.cn[v]; s_g1[i] = a.da1[v]; s_g2[i] = a.da2[v];
+    }
+    if (threadIdx.x < u1 - u0) {
+        const int u = u0 + threadIdx.x;
+        s_ni[4 * threadIdx.x] = a.gid[u]; s_ni[4 * threadIdx.x + 1] = a.rowptr_out[u]; s_ni[4 * threadIdx.x + 2] = a.rowptr_out[u + 1];
+        s_ni[4 * threadIdx.x + 3] = a.pos[u];                       // (a readable dummy when there are no position columns)
+        s_nf[4 * threadIdx.x] = a.da1[u]; s_nf[4 * threadIdx.x + 1] = a.da2[u]; s_nf[4 * threadIdx.x + 2] = a.cn[u];
+    }
+    for (int i = threadIdx.x; i < a.vocab * a.Pd; i += 256) s_dp[i] = 0.f;
+    for (int i = threadIdx.x * 4; i < 2 * Kp; i += 1024) {
+        *reinterpret_cast<float4*>(s_wa + i) = *reinterpret_cast<const float4*>(a.wa + i);
+        *reinterpret_cast<float4*>(s_acc + i) = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    __syncthreads();
+    if (ne <= FB_MAXE) fb_body<MASK, NI, NWH, true>(a, b, u0, u1, e0, ne, s_v, s_p, s_cn, s_g1, s_g2, s_ni, s_nf, s_dot, s_dp, s_wa, s_acc);
+    else fb_body<MASK, NI, NWH, false>(a, b, u0, u1, e0, ne, s_v, s_p, s_cn, s_g1, s_g2, s_ni, s_nf, s_dot, s_dp, s_wa, s_acc);
+    // per-workgroup partials: folded attention rows' gradient [2][Kp], position-embedding gradient [vocab][Pd]
+    __syncthreads();
+    float* dw = a.dwa_part + (long long)b * 2 * Kp;
+    for (int i = threadIdx.x * 4; i < 2 * Kp; i += 1024) *reinterpret_cast<float4*>(dw + i) = *reinterpret_cast<const float4*>(s_acc + i);
+    for (int i = threadIdx.x; i < a.vocab * a.Pd; i += 256) a.ppart[(long long)b * a.vocab * a.Pd + i] = s_dp[i];
+}
+
+// Softmax + leaky-relu backward of a GATLayer's attention from the raw d alpha of the fused sweep, edge level:
+//   dz_p = alpha_p (dal_p - sum_q alpha_q dal_q) leaky'(a_src[u_p] + a_dst[v]);  d a_dst[v] = sum_in dz;  d a_src[u] = sum_out dz
+// written into the a1 / a2 columns of d_Y (and zeros into its padding columns).  A workgroup owns FA_GRAPHS consecutive graphs:
+// the edges of a batched graph stay inside it, so the destination-side and source-side halves only need a workgroup barrier.
+constexpr int FA_GRAPHS = 8;
+constexpr int FA_LIGHT = 8;         // degrees up to this are walked by one thread per (node, head); heavier nodes by a whole wave
+__global__ __launch_bounds__(256) void gat_attn_bwd_kernel(const int* __restrict__ rowptr_in, const int* __restrict__ col_src,
+                                                           const int* __restrict__ rowptr_out, const int* __restrict__ pos_out,
+                                                           const int* __restrict__ graph_off, const int G, const float* __restrict__ Y,
+                                                           const long long ld_y, const int H, const int F, const float slope,
+                                                           const float* __restrict__ alpha, const float* __restrict__ dal,
+                                                           float* __restrict__ dz, float* __restrict__ d_Y, const long long ld_dy,
+                                                           const int n_pad) {
+    __shared__ int s_heavy[2][256], s_nh[2];                        // heavy destinations / sources found by the light passes
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    const int g0 = blockIdx.x * FA_GRAPHS, g1 = min(G, g0 + FA_GRAPHS);
+    const int n0 = graph_off[g0], n1 = graph_off[g1];
+    const int nn = n1 - n0;
+    if (threadIdx.x < 2) s_nh[threadIdx.x] = 0;
+    __syncthreads();
+    // ---- destination side ----
+    for (int t = threadIdx.x; t < nn * H; t += 256) {               // light nodes: one thread per (node, head)
+        const int v = n0 + t / H, h = t % H;
+        const int beg = rowptr_in[v], end = rowptr_in[v + 1];
+        if (end - beg > FA_LIGHT) {
+            if (h == 0) { const int k = atomicAdd(&s_nh[0], 1); if (k < 256) s_heavy[0][k] = v; }
+            continue;
+        }
+        const float ad = Y[(long long)v * ld_y + F + H + h];
+        float al[FA_LIGHT], dl[FA_LIGHT], zs[FA_LIGHT];
+#pragma unroll
+        for (int i = 0; i < FA_LIGHT; ++i) {                        // clamped, unconditional: all loads of the node go out together
+            const int p = min(beg + i, max(end - 1, beg));
+            const bool ok = beg + i < end;
+            al[i] = ok ? alpha[(long long)p * H + h] : 0.f;
+            dl[i] = ok ? dal[(long long)p * H + h] : 0.f;
+            zs[i] = ok ? Y[(long long)col_src[p] * ld_y + F + h] : 0.f;
+        }
+        float S = 0.f, accv = 0.f;
+#pragma unroll
+        for (int i = 0; i < FA_LIGHT; ++i) S = fmaf(al[i], dl[i], S);
+#pragma unroll
+        for (int i = 0; i < FA_LIGHT; ++i) {
+            const float gz = al[i] * (dl[i] - S) * ((zs[i] + ad > 0.f) ? 1.f : slope);
+            if (beg + i < end) dz[(long long)(beg + i) * H + h] = gz;
+            accv += (beg + i < end) ? gz : 0.f;
+        }
+        d_Y[(long long)v * ld_dy + F + H + h] = accv;
+    }
+    for (int t = threadIdx.x; t < nn * n_pad; t += 256) d_Y[(long long)(n0 + t / n_pad) * ld_dy + F + 2 * H + t % n_pad] = 0.f;
+    __syncthreads();
+    const bool list_a = s_nh[0] <= 256;                             // (more heavy nodes than the list holds: scan the node range)
+    for (int i = w; i < (list_a ? s_nh[0] : nn); i += 4) {          // heavy nodes: one wave each, lanes over the in-edges
+        const int v = list_a ? s_heavy[0][i] : n0 + i;
+        const int beg = rowptr_in[v], end = rowptr_in[v + 1];
+        if (end - beg <= FA_LIGHT) continue;                        // (wave-uniform)
+        for (int h = 0; h < H; ++h) {
+            const float ad = Y[(long long)v * ld_y + F + H + h];
+            float S = 0.f;
+            for (int p = beg + l; p < end; p += 64) S = fmaf(alpha[(long long)p * H + h], dal[(long long)p * H + h], S);
+            S = wave_sum(S);
+            float accv = 0.f;
+            for (int p = beg + l; p < end; p += 64) {
+                const float de = alpha[(long long)p * H + h] * (dal[(long long)p * H + h] - S);
+                const float z = Y[(long long)col_src[p] * ld_y + F + h] + ad;
+                const float gz = de * (z > 0.f ? 1.f : slope);
+                dz[(long long)p * H + h] = gz;
+                accv += gz;
+            }
+            accv = wave_sum(accv);
+            if (l == 0) d_Y[(long long)v * ld_dy + F + H + h] = accv;
+        }
+    }
+    __syncthreads();                                               // dz of this workgroup's edges is complete (first touched below)
+    // ---- source side ----
+    for (int t = threadIdx.x; t < nn * H; t += 256) {
+        const int u = n0 + t / H, h = t % H;
+        const int beg = rowptr_out[u], end = rowptr_out[u + 1];
+        if (end - beg > FA_LIGHT) {
+            if (h == 0) { const int k = atomicAdd(&s_nh[1], 1); if (k < 256) s_heavy[1][k] = u; }
+            continue;
+        }
+        float accu = 0.f;
+#pragma unroll
+        for (int i = 0; i < FA_LIGHT; ++i) {
+            const int j = min(beg + i, max(end - 1, beg));
+            accu += (beg + i < end) ? dz[(long long)pos_out[j] * H + h] : 0.f;
+        }
+        d_Y[(long long)u * ld_dy + F + h] = accu;
+    }
+    __syncthreads();
+    const bool list_b = s_nh[1] <= 256;
+    for (int i = w; i < (list_b ? s_nh[1] : nn); i += 4) {
+        const int u = list_b ? s_heavy[1][i] : n0 + i;
+        const int beg = rowptr_out[u], end = rowptr_out[u + 1];
+        if (end - beg <= FA_LIGHT) continue;
+        for (int h = 0; h < H; ++h) {
+            float accu = 0.f;
+            for (int j = beg + l; j < end; j += 64) accu += dz[(long long)pos_out[j] * H + h];
+            accu = wave_sum(accu);
+            if (l == 0) d_Y[(long long)u * ld_dy + F + h] = accu;
+        }
+    }
+}
+
 struct CollapseWs {
     float *dZ, *part, *dwa_part, *dwa, *dc, *cn, *dS, *dz, *da1, *da2, *dwv, *ppart, *ppart2;
     void* tail;
@@ -1243,6 +1606,165 @@ int txe_gat_collapse_bwd(const int* rowptr_in, const int* col_src, const int* ro
                       d_attn_r};
     tb.nb_2a = Pd > 0 ? (vocab * Pd + 63) / 64 : 0;
     tb.s2a = Seg2Args{p.ppart, nseg, vocab * Pd, dP};
+    tb.nb_2b = pw ? (vocab + 63) / 64 : 0;
+    tb.s2b = Seg2Args{p.ppart2, nseg, vocab, d_pw};
+    hipLaunchKernelGGL(gat_bwd_reduce_b_kernel, dim3(tb.nb_u + tb.nb_2a + tb.nb_2b), dim3(256), 0, s, tb);
+    TXE_CHECK_LAUNCH();
+    return TXE_OK;
+}
+
+}  // extern "C"
+
+namespace txe {
+struct FusedWs {
+    CollapseWs c;
+    float *dal, *dwa_part, *ppart;
+    int nblocks;
+    size_t total;
+};
+static FusedWs plan_fused_ws(void* ws, int n, int e, int G, int Kp, int D, int Pd, int vocab, int Hp) {
+    FusedWs f;
+    f.c = plan_collapse_ws(ws, n, e, G, Kp, D, Pd, vocab);
+    char* b = (char*)ws;
+    size_t off = f.c.total;
+    auto take = [&](size_t bytes) { float* r = (float*)(b + off); off += align_up(bytes > 0 ? bytes : 4, 256); return r; };
+    f.nblocks = (n + FB_NODES - 1) / FB_NODES;
+    const int nb1 = f.nblocks > 0 ? f.nblocks : 1;
+    f.dal = take((size_t)(e > 0 ? e : 1) * Hp * 4);
+    f.dwa_part = take((size_t)nb1 * 2 * Kp * 4);
+    f.ppart = take((size_t)nb1 * (vocab > 0 ? vocab : 1) * (Pd > 0 ? Pd : 1) * 4);
+    f.total = off;
+    return f;
+}
+}  // namespace txe
+
+extern "C" {
+
+// 1 when txe_gat_collapse_bwd_fused supports the shape: the previous layer has 1, 2 or 4 heads, its H*D columns are a multiple of 16
+// and at most 4096, and the folded layer's input has at most 128 columns behind them.
+int txe_gat_fused_bwd_supported(int Kh, int Pd, int Hp, int Dp) {
+    const int F = Hp * Dp, Kp = round_up(Kh + Pd, 32);
+    return (Hp == 1 || Hp == 2 || Hp == 4) && F == Kh && (F % 16) == 0 && F <= 4096 && Kp - F <= FB_MAXPD && Pd <= FB_MAXPD && (Dp % 4) == 0;
+}
+
+size_t txe_gat_collapse_bwd_fused_ws_bytes(int n_nodes, int n_edges, int G, int Kh, int Pd, int D, int vocab, int Hp) {
+    return plan_fused_ws(nullptr, n_nodes, n_edges, G, round_up(Kh + Pd, 32), D, Pd, vocab, Hp).total;
+}
+
+// txe_gat_collapse_bwd FUSED with txe_gat_aggregate_bwd of the layer below: same inputs as txe_gat_collapse_bwd plus
+// that layer's projection output Yp [N][ld_yp] = [ft | a1 | a2] (Hp heads of Dp columns, Hp*Dp == Kh), its attention alpha_p [E][Hp]
+// (destination-CSR order), attention slope / dropout / seed.  Instead of d_X it returns that layer's d_Yp [N][ld_dyp] =
+// [d_ft | d_a1 | d_a2 | n_pad zero columns] directly; dz_p [E][Hp] is scratch.  act_slope: slope of the activation between the two
+// layers (1 = none).  dP / d_pw / dW / d_attn as txe_gat_collapse_bwd.
+int txe_gat_collapse_bwd_fused(const int* rowptr_in, const int* col_src, const int* rowptr_out, const int* col_dst, const int* pos_out,
+                               const int* graph_off, int n_nodes, int n_edges, int G, const float* X, int Kh, int Pd, const int* pos,
+                               int vocab, const float* Wp, const float* W, const float* attn_l, const float* attn_r, int D,
+                               float feat_drop_p, const unsigned* mask, float attn_slope, float attn_drop_p, unsigned long long seed,
+                               const float* pw, const float* a12, const float* alpha, const float* coef, const float* wsum,
+                               const int* gid, const float* Z, const float* hg, long long ld_hg, const float* d_hg, long long ld_dhg,
+                               float act_slope, const float* Yp, long long ld_yp, int Hp, int Dp, float attn_slope_p,
+                               float attn_drop_p_p, unsigned long long seed_p, const float* alpha_p, float* d_Yp, long long ld_dyp,
+                               int n_pad, float* dz_p, float* dW, float* d_attn_l, float* d_attn_r, float* dP, float* d_pw, void* ws,
+                               size_t ws_bytes, void* stream) {
+    if (n_nodes < 0 || n_edges < 0 || G < 0 || Kh < 1 || Pd < 0 || D < 1 || !rowptr_in || !rowptr_out || !graph_off || !X || !Wp || !W ||
+        !attn_l || !attn_r || !a12 || !alpha || !coef || !wsum || !gid || !Z || !hg || !d_hg || !dW || !d_attn_l || !d_attn_r || !ws ||
+        !Yp || !alpha_p || !d_Yp || !dz_p || n_pad < 0)
+        return TXE_ERR_ARG;
+    if (!txe_gat_fused_bwd_supported(Kh, Pd, Hp, Dp)) return TXE_ERR_ARG;
+    if ((Pd > 0 || pw) && (!pos || vocab < 1 || vocab > MAX_VOCAB)) return TXE_ERR_ARG;
+    if ((Pd > 0 && !dP) || (pw && !d_pw)) return TXE_ERR_ARG;
+    if (feat_drop_p < 0.f || feat_drop_p >= 1.f || attn_drop_p < 0.f || attn_drop_p >= 1.f || attn_drop_p_p < 0.f || attn_drop_p_p >= 1.f)
+        return TXE_ERR_ARG;
+    const int Kt = Kh + Pd, Kp = round_up(Kt, 32), F = Hp * Dp;
+    FusedWs fw = plan_fused_ws(ws, n_nodes, n_edges, G, Kp, D, Pd, vocab, Hp);
+    CollapseWs& p = fw.c;
+    if (ws_bytes < fw.total) return TXE_ERR_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    const unsigned* mk = (mask && feat_drop_p > 0.f) ? mask : nullptr;
+    const int mask_ld = (Kt + 31) / 32;
+    const float fs = mk ? 1.f / (1.f - feat_drop_p) : 1.f, as = 1.f / (1.f - attn_drop_p);
+    const float* wa = Wp + (long long)D * Kp;
+    const unsigned* dummy_mask = reinterpret_cast<const unsigned*>(X);
+    int rc;
+    {   // dZ = d_hg W
+        VMat A = vmat_plain(d_hg, ld_dhg, G, D);
+        VMat B = vmat_plain(Wp, Kp, D, Kp);
+        Epi E = epi_plain(p.dZ, Kp, Kp);
+        E.alg_flops = 2.0 * G * (double)Kt * D;
+        rc = gemm_nn(A, B, E, G, Kp, D, 1, s, p.tail, p.tail_bytes);
+        if (rc) return rc;
+    }
+    const long long split_stride = (long long)D * Kp;
+    {   // dW (main part, split-K partial slices) = d_hg^T Z
+        VMat A = vmat_plain(d_hg, ld_dhg, G, D);
+        VMat B = vmat_plain(Z, Kp, G, Kp);
+        Epi E = epi_plain(p.part, Kp, Kp);
+        E.split_stride = split_stride;
+        E.alg_flops = 2.0 * D * (double)Kt * G;
+        rc = gemm_tn(A, B, E, D, Kp, G, p.splits, s);
+        if (rc) return rc;
+    }
+    const int S = G > 0 ? p.splits : 0;
+    const int nblk = (G > 0 && n_nodes > 0) ? fw.nblocks : 0;
+    if (G > 0 && n_nodes > 0) {
+        const int nb = (n_nodes + 3) / 4;
+        {
+            const int nb_ds = (G + 3) / 4;
+            ProfScope prof(mk ? "cl_bwd_dot_kernel<true>" : "cl_bwd_dot_kernel<false>", s, 4.0 * ((n_nodes + (double)G) * Kp + 2.0 * G * D), 1);
+            if (mk) hipLaunchKernelGGL(cl_bwd_dot_kernel<true>, dim3(nb_ds + nb), dim3(256), 0, s, n_nodes, gid, X, Kp, mk, mask_ld, fs,
+                                       (const float*)p.dZ, wsum, coef, p.dc, p.cn, nb_ds, G, D, d_hg, ld_dhg, hg, ld_hg, p.dS);
+            else hipLaunchKernelGGL(cl_bwd_dot_kernel<false>, dim3(nb_ds + nb), dim3(256), 0, s, n_nodes, gid, X, Kp, dummy_mask, mask_ld, fs,
+                                    (const float*)p.dZ, wsum, coef, p.dc, p.cn, nb_ds, G, D, d_hg, ld_dhg, hg, ld_hg, p.dS);
+        }
+        hipLaunchKernelGGL(cl_bwd_edge_kernel, dim3(nb), dim3(256), 0, s, rowptr_in, col_src, n_nodes, a12, attn_slope, alpha, attn_drop_p, as,
+                           seed, pos, pw, (const float*)p.dc, (const float*)p.dS, gid, p.dz, p.da2, p.dwv);
+        hipLaunchKernelGGL(cl_bwd_src_kernel, dim3(nb), dim3(256), 0, s, rowptr_out, pos_out, n_nodes, (const float*)p.dz, p.da1);
+        {
+            FusedBwdArgs a;
+            a.rowptr_out = rowptr_out; a.col_dst = col_dst; a.pos_out = pos_out; a.gid = gid; a.pos = pos ? pos : gid; a.n_nodes = n_nodes;
+            a.X = X; a.Kp = Kp; a.Kh = Kh; a.Pd = Pd; a.mask = mk ? mk : dummy_mask; a.mask_ld = mask_ld; a.fscale = fs;
+            a.dZ = p.dZ; a.cn = p.cn; a.da1 = p.da1; a.da2 = p.da2; a.wa = wa; a.act_slope = act_slope; a.vocab = vocab > 0 ? vocab : 1;
+            a.Y = Yp; a.ld_y = ld_yp; a.H = Hp; a.D = Dp; a.alpha = alpha_p; a.drop_p = attn_drop_p_p;
+            a.drop_scale = 1.f / (1.f - attn_drop_p_p); a.seed = seed_p;
+            a.d_Y = d_Yp; a.ld_dy = ld_dyp; a.dal = fw.dal; a.dwa_part = fw.dwa_part; a.ppart = fw.ppart;
+            const int nvec = F / 16, ni = (nvec + 63) / 64, nwh = 4 / Hp;
+            // algorithmic bytes: read X' (own row + once per out-edge is an L2 matter), dZ, Y; write d_Y
+            char name[64];
+            snprintf(name, sizeof(name), "gat_fused_bwd_kernel<%s, %d, %d>", mk ? "true" : "false", ni, nwh);
+            ProfScope prof(name, s, 4.0 * (n_nodes * ((double)Kp + 2.0 * F) + (double)G * Kp), 1);
+#define TXE_FB(M_, NI_, NW_) hipLaunchKernelGGL((gat_fused_bwd_kernel<M_, NI_, NW_>), dim3(fw.nblocks), dim3(256), (size_t)(4 * Kp + a.vocab * (Pd > 0 ? Pd : 1)) * sizeof(float), s, a)
+#define TXE_FB_NI(M_, NW_) do { if (ni == 1) TXE_FB(M_, 1, NW_); else if (ni == 2) TXE_FB(M_, 2, NW_); else if (ni == 3) TXE_FB(M_, 3, NW_); else TXE_FB(M_, 4, NW_); } while (0)
+#define TXE_FB_NW(M_) do { if (nwh == 1) TXE_FB_NI(M_, 1); else if (nwh == 2) TXE_FB_NI(M_, 2); else TXE_FB_NI(M_, 4); } while (0)
+            if (mk) TXE_FB_NW(true); else TXE_FB_NW(false);
+#undef TXE_FB_NW
+#undef TXE_FB_NI
+#undef TXE_FB
+        }
+        {
+            ProfScope prof("gat_attn_bwd_kernel", s, 4.0 * (n_edges * (4.0 * Hp + 2.0) + n_nodes * (4.0 * Hp + n_pad)), 1);
+            hipLaunchKernelGGL(gat_attn_bwd_kernel, dim3((G + FA_GRAPHS - 1) / FA_GRAPHS), dim3(256), 0, s, rowptr_in, col_src, rowptr_out, pos_out,
+                               graph_off, G, Yp, ld_yp, Hp, F, attn_slope_p, alpha_p, (const float*)fw.dal, dz_p, d_Yp, ld_dyp, n_pad);
+        }
+        TXE_CHECK_LAUNCH();
+    }
+    // ---- phase A: d_wa = sum of the per-workgroup partials; readout position-weight partial sums ----
+    const int nseg = n_nodes > 0 ? p.seg_blocks : 0;
+    TailA ta;
+    memset(&ta, 0, sizeof(ta));
+    ta.nb_s1a = 0;
+    ta.nb_s1b = pw ? nseg : 0; ta.s1b = Seg1Args{p.dwv, 1, 1, p.ppart2};
+    ta.pos = pos; ta.n_rows = n_nodes; ta.vocab = vocab; ta.rows_per_block = p.seg_rows;
+    ta.r_kind = 2; ta.nb_r = (2 * Kp + 63) / 64; ta.r2 = Seg2Args{fw.dwa_part, nblk, 2 * Kp, p.dwa};
+    hipLaunchKernelGGL(gat_bwd_reduce_a_kernel, dim3(ta.nb_s1b + ta.nb_r), dim3(256), 0, s, ta);
+    TXE_CHECK_LAUNCH();
+    // ---- phase B: dW = main + attn (x) d_wa, d_attn = <d_wa, W> (unfold);  dP (from the fused sweep's partials), d_pw ----
+    TailB tb;
+    memset(&tb, 0, sizeof(tb));
+    tb.nb_u = D;
+    tb.u = UnfoldArgs{p.part, S, split_stride, p.dwa, (long long)Kp, W, (long long)Kt, attn_l, attn_r, 1, D, Kt, dW, (long long)Kt, d_attn_l,
+                      d_attn_r};
+    tb.nb_2a = Pd > 0 ? (vocab * Pd + 63) / 64 : 0;
+    tb.s2a = Seg2Args{fw.ppart, nblk, vocab * Pd, dP};
     tb.nb_2b = pw ? (vocab + 63) / 64 : 0;
     tb.s2b = Seg2Args{p.ppart2, nseg, vocab, d_pw};
     hipLaunchKernelGGL(gat_bwd_reduce_b_kernel, dim3(tb.nb_u + tb.nb_2a + tb.nb_2b), dim3(256), 0, s, tb);

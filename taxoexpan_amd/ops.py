@@ -377,25 +377,68 @@ def _gat_layer_fwd(csr, st, h, ld_h, pos, out, ld_out, feat_p, attn_p, attn_slop
            else (None, 0, None, 0.0, None)), s)
 
 
-def _gat_layer_bwd(csr, st, pos, vocab, feat_p, attn_p, attn_slope, d_pre, ld_dpre, need_dh, act_on, act_slope):
+def _gat_aggregate_bwd(csr, st, attn_p, attn_slope, d_pre, ld_dpre):
+    """message/reduce backward of one layer: d_Y [N, Fp] = [d_ft | d_a1 | d_a2 | 0] from the gradient of its aggregated output"""
     N = st.X.shape[0]
-    H, D, Kh, Pd, Kp, Fp = st.H, st.D, st.Kh, st.Pd, st.Kp, st.Fp
+    H, D, Fp = st.H, st.D, st.Fp
     F, Fe = H * D, H * D + 2 * H
-    s = _lib.stream_ptr()
     d_Y = _empty((N, Fp), st.X)
     dz = _empty((max(csr.n_edges, 1) * H,), st.X)
     call("txe_gat_aggregate_bwd", ptr(csr.rowptr_in), ptr(csr.col_src), ptr(csr.rowptr_out), ptr(csr.col_dst), ptr(csr.pos_out),
          N, ptr(st.Y), Fp, ptr(st.Y) + 4 * F, ptr(st.Y) + 4 * (F + H), Fp, H, D, attn_slope, attn_p, st.seed + 1, ptr(st.alpha),
-         ptr(d_pre), ld_dpre, ptr(d_Y), Fp, ptr(d_Y) + 4 * F, ptr(d_Y) + 4 * (F + H), Fp, ptr(dz), Fp - Fe, s)   # clears d_Y's padding too
+         ptr(d_pre), ld_dpre, ptr(d_Y), Fp, ptr(d_Y) + 4 * F, ptr(d_Y) + 4 * (F + H), Fp, ptr(dz), Fp - Fe, _lib.stream_ptr())   # clears d_Y's padding too
+    return d_Y
+
+
+def _gat_dense_bwd(st, pos, vocab, feat_p, d_Y, need_dh, act_on, act_slope):
+    """projection backward of one layer from d_Y: (d_X or None, dW, d_attn_l, d_attn_r, dP)"""
+    N = st.X.shape[0]
     dW, dal, dar = torch.empty_like(st.W), torch.empty_like(st.al), torch.empty_like(st.ar)
     dP = torch.empty_like(st.P) if st.P is not None else None
-    d_X = _empty((N, Kp), st.X) if (need_dh or Pd > 0) else None
-    wsb = call("txe_gat_dense_ws_bytes", N, Kh, Pd, H, D, vocab)
+    d_X = _empty((N, st.Kp), st.X) if (need_dh or st.Pd > 0) else None
+    wsb = call("txe_gat_dense_ws_bytes", N, st.Kh, st.Pd, st.H, st.D, vocab)
     ws = _ws(wsb, st.X)
-    call("txe_gat_dense_bwd", ptr(st.X), N, Kh, Pd, ptr(pos), vocab, ptr(st.Wp), ptr(st.W), ptr(st.al), ptr(st.ar), H, D, feat_p,
+    call("txe_gat_dense_bwd", ptr(st.X), N, st.Kh, st.Pd, ptr(pos), vocab, ptr(st.Wp), ptr(st.W), ptr(st.al), ptr(st.ar), st.H, st.D, feat_p,
          ptr(st.mask), ptr(d_Y), int(need_dh), int(act_on), act_slope if act_slope else 1.0, ptr(d_X), ptr(dW), ptr(dal), ptr(dar),
-         ptr(dP), ptr(ws), wsb, s)
+         ptr(dP), ptr(ws), wsb, _lib.stream_ptr())
     return d_X, dW, dal, dar, dP
+
+
+def _gat_layer_bwd(csr, st, pos, vocab, feat_p, attn_p, attn_slope, d_pre, ld_dpre, need_dh, act_on, act_slope):
+    d_Y = _gat_aggregate_bwd(csr, st, attn_p, attn_slope, d_pre, ld_dpre)
+    return _gat_dense_bwd(st, pos, vocab, feat_p, d_Y, need_dh, act_on, act_slope)
+
+
+_NO_FUSED_BWD = os.environ.get("TXE_NO_FUSED_BWD", "0") == "1"       # A/B switch (tests compare both paths)
+
+
+def _fused_bwd_ok(csr, st, sp):
+    """can the folded layer `st`'s backward run fused with the message/reduce backward of the layer below `sp`?"""
+    return (not _NO_FUSED_BWD and sp.alpha is not None and sp.H * sp.D == st.Kh and st.cl is not None and csr.n_edges > 0
+            and call("txe_gat_fused_bwd_supported", st.Kh, st.Pd, sp.H, sp.D) == 1)
+
+
+def _gat_collapse_bwd_fused(csr, st, sp, pos, rpos, pw, vocab, feat_p, attn_p, attn_slope, d_hg, act_slope):
+    """txe_gat_collapse_bwd_fused: the folded layer's parameter gradients AND the layer below's d_Y in one sweep (no d_X)"""
+    N, G, E = st.X.shape[0], csr.n_graphs, csr.n_edges
+    a12, alpha, coef, wsum, gid, Z, hg = st.cl
+    d_hg, ld = _rows(d_hg)
+    dW, dal, dar = torch.empty_like(st.W), torch.empty_like(st.al), torch.empty_like(st.ar)
+    dP = torch.empty_like(st.P) if st.P is not None else None
+    d_pw = torch.empty_like(pw) if pw is not None else None
+    Fe = sp.H * sp.D + 2 * sp.H
+    d_Yp = _empty((N, sp.Fp), st.X)
+    dz = _empty((max(E, 1) * sp.H,), st.X)
+    v = max(vocab, pw.numel() if pw is not None else 0)
+    wsb = call("txe_gat_collapse_bwd_fused_ws_bytes", N, E, G, st.Kh, st.Pd, st.D, 8, sp.H)
+    ws = _ws(wsb, st.X)
+    call("txe_gat_collapse_bwd_fused", ptr(csr.rowptr_in), ptr(csr.col_src), ptr(csr.rowptr_out), ptr(csr.col_dst), ptr(csr.pos_out),
+         ptr(csr.graph_off), N, E, G, ptr(st.X), st.Kh, st.Pd, ptr(pos if pos is not None else rpos), v, ptr(st.Wp), ptr(st.W),
+         ptr(st.al), ptr(st.ar), st.D, feat_p, ptr(st.mask), attn_slope, attn_p, st.seed + 1, ptr(pw), ptr(a12), ptr(alpha), ptr(coef),
+         ptr(wsum), ptr(gid), ptr(Z), ptr(hg), st.D, ptr(d_hg), ld, act_slope if act_slope else 1.0, ptr(sp.Y), sp.Fp, sp.H, sp.D,
+         attn_slope, attn_p, sp.seed + 1, ptr(sp.alpha), ptr(d_Yp), sp.Fp, sp.Fp - Fe, ptr(dz), ptr(dW), ptr(dal), ptr(dar), ptr(dP),
+         ptr(d_pw), ptr(ws), wsb, _lib.stream_ptr())
+    return d_Yp, dW, dal, dar, dP, d_pw
 
 
 class GATStackFunction(torch.autograd.Function):
@@ -511,19 +554,29 @@ class GATStackFunction(torch.autograd.Function):
             if d_pre is not None:
                 ld_dpre = d_pre.stride(0)
             d_X = None
+            d_Y_ready = None                       # d_Y of layer l already produced by the fused sweep of layer l+1
             for l in range(L - 1, -1, -1):
                 st = states[l]
                 need_dh = (l > 0) or ctx.h_req
                 # the input of layer l>0 is leaky_relu(out_{l-1}) (fused epilogue): fold its derivative into dX
                 act_on = (l > 0 and cfg.act_slope is not None)
                 if collapse and l == L - 1:
-                    d_X, dW, dal, dar, dP, d_pw = _gat_collapse_bwd(csr, st, pos if st.P is not None else None, ctx.rpos, ctx.pwf, cfg.vocab,
-                                                                    cfg.feat_p, cfg.attn_p, cfg.attn_slope, d_res, act_on, cfg.act_slope)
+                    if l > 0 and _fused_bwd_ok(csr, st, states[l - 1]):
+                        d_Y_ready, dW, dal, dar, dP, d_pw = _gat_collapse_bwd_fused(
+                            csr, st, states[l - 1], pos if st.P is not None else None, ctx.rpos, ctx.pwf, cfg.vocab, cfg.feat_p, cfg.attn_p,
+                            cfg.attn_slope, d_res, cfg.act_slope if act_on else None)
+                    else:
+                        d_X, dW, dal, dar, dP, d_pw = _gat_collapse_bwd(csr, st, pos if st.P is not None else None, ctx.rpos, ctx.pwf, cfg.vocab,
+                                                                        cfg.feat_p, cfg.attn_p, cfg.attn_slope, d_res, act_on, cfg.act_slope)
+                elif d_Y_ready is not None:
+                    d_X, dW, dal, dar, dP = _gat_dense_bwd(st, pos if st.P is not None else None, cfg.vocab, cfg.feat_p, d_Y_ready, need_dh,
+                                                           act_on, cfg.act_slope)
+                    d_Y_ready = None
                 else:
                     d_X, dW, dal, dar, dP = _gat_layer_bwd(csr, st, pos if st.P is not None else None, cfg.vocab, cfg.feat_p, cfg.attn_p,
                                                            cfg.attn_slope, d_pre, ld_dpre, need_dh, act_on, cfg.act_slope)
                 grads[4 * l:4 * l + 4] = [dW, dal, dar, dP]
-                if l > 0:
+                if l > 0 and d_Y_ready is None:
                     d_pre, ld_dpre = d_X, st.Kp            # its first H*D(l-1) columns are d(pre-activation out_{l-1})
             d_h = d_X[:, :states[0].Kh].contiguous() if ctx.h_req else None
         ctx.states = None

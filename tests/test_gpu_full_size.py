@@ -153,3 +153,62 @@ def test_fused_stack_intermediates_match_reference_goldens(name):
             np.testing.assert_allclose(hn.numpy(), want_out.numpy(), rtol=1e-4, atol=2e-5, err_msg=f"layer {l} out (unfolded)")
         np.testing.assert_allclose(alpha.numpy(), want_alpha.numpy(), rtol=1e-4, atol=2e-6, err_msg=f"layer {l} alpha")
     np.testing.assert_allclose(scores.detach().cpu().numpy(), z["scores"], rtol=1e-4, atol=2e-5)
+
+
+@pytest.mark.parametrize("heads,hidden,drop,layers", [([4, 1], 500, 0.1, 1), ([4, 1], 8, 0.0, 1), ([2, 1], 24, 0.2, 1), ([1, 1], 32, 0.2, 1),
+                                                      ([4, 1], 600, 0.1, 1), ([3, 4, 1], 12, 0.1, 2), ([4, 1], 100, 0.0, 1)])
+def test_fused_backward_sweep_equals_unfused_chain(heads, hidden, drop, layers, monkeypatch):
+    """txe_gat_collapse_bwd_fused (d_X' formed on the fly inside the layer below's source-side sweep) against the unfused chain
+    txe_gat_collapse_bwd -> txe_gat_aggregate_bwd of the SAME forward pass (same saved state, same dropout seeds): every gradient,
+    on generic batched multigraphs (a hub with in-degree > 64 and a node with ~400 out-edges, nodes without in-edges, graphs of
+    1..90 nodes) -- head layouts of 1 / 2 / 4 heads (one, two, four waves per head), row widths up to 2,400 columns"""
+    from taxoexpan_amd import model_zoo as mz, ops
+    from taxoexpan_amd.graph import DGLGraph, batch
+    dev = _dev()
+    rs = np.random.RandomState(3)
+    graphs = []
+    for n in [1, 2, 40, 7, 3, 90, 5, 33]:
+        g = DGLGraph()
+        g.add_nodes(n)
+        if n > 1:
+            e = 3 * n
+            g.add_edges(rs.randint(0, n, e), rs.randint(1, n, e))            # node 0 of every graph: no in-edge but the self loop below
+        if n == 90:
+            g.add_edges(rs.randint(0, n, 100), np.full(100, 11))              # hub: in-degree > 64
+            g.add_edges(np.full(400, 17), rs.randint(0, n, 400))              # 400 out-edges: past the LDS-staged edge scalars
+        if n != 33:
+            g.add_edges(g.nodes(), g.nodes())                                 # (the 33-node graph has nodes without any in-edge)
+        graphs.append(g)
+    bg = batch(graphs)
+    N = bg.number_of_nodes()
+    pos = torch.from_numpy(rs.randint(0, 3, N)).to(dev)
+    x = torch.randn(N, 10, generator=torch.Generator().manual_seed(0)).to(dev)
+    coef = torch.randn(len(graphs), 6, generator=torch.Generator().manual_seed(1)).to(dev)
+    torch.manual_seed(5)
+    prop = mz.PGAT(10, hidden, 6, 4, num_layers=layers, heads=heads, activation=F.leaky_relu, feat_drop=drop, attn_drop=drop).to(dev)
+    ro = mz.WeightedMeanReadout().to(dev)
+    prop.train(drop > 0)
+    seed = 4242
+    monkeypatch.setattr(ops, "new_seed", lambda: seed)
+    results = []
+    for fused in (True, False):
+        monkeypatch.setattr(ops, "_NO_FUSED_BWD", not fused)
+        for p in list(prop.parameters()) + list(ro.parameters()):
+            p.grad = None
+        xg = x.clone().requires_grad_(True)
+        bg.ndata["pos"] = pos
+        with ops.debug_capture() as runs:
+            bg.ndata["h"] = prop(bg, xg)
+            hg = ro(bg, pos)
+        _csr, _cfg, states = runs[0]
+        assert ops._fused_bwd_ok(_csr, states[-1], states[-2]) == (fused and heads[-2] in (1, 2, 4) and (heads[-2] * hidden) % 16 == 0)
+        (hg * coef).sum().backward()
+        results.append((hg.detach().cpu().numpy(), xg.grad.cpu().numpy(),
+                        {k: p.grad.cpu().numpy() for k, p in list(prop.named_parameters()) + list(ro.named_parameters())}))
+    (a, dxa, ga), (b, dxb, gb) = results
+    np.testing.assert_array_equal(a, b)                                      # same forward
+    errors = []
+    _close(dxa, dxb, 2e-4, 2e-5, "d_x", errors)
+    for k in ga:
+        _close(ga[k], gb[k], 2e-4, 2e-5, "grad " + k, errors)
+    assert not errors, "\n".join(errors)

@@ -143,6 +143,16 @@ size_t txe_bilinear_pair_bwd_ws_bytes(int G, int l, int r);
 int txe_bilinear_pair_bwd(const float* e1, long long ld_e1, const float* e2, long long ld_e2, int G, int l, int r,
                           const float* W, int apply_exp, const float* U, const float* s, const float* ds, float* d_e1,
                           long long ld_de1, float* d_e2, long long ld_de2, float* dW, void* ws, size_t ws_bytes, void* stream);
+/* query-side form of the pairwise match for queries that need no gradient (training: model.py:86, trainer.py:51):
+ * forward V = E2 W^T [G][l], s_i = <e1_i, V_i> (exp optionally); backward d_e1_i = dsl_i V_i (elementwise -- no second G-row GEMM),
+ * dW = (dsl (.) E1)^T E2.  V is kept for backward. */
+int txe_bilinear_query_fwd(const float* e1, long long ld_e1, const float* e2, long long ld_e2, int G, int l, int r, const float* W,
+                           int apply_exp, float* V, float* s, void* stream);
+size_t txe_bilinear_query_bwd_ws_bytes(int G, int l, int r);
+int txe_bilinear_query_bwd(const float* e1, long long ld_e1, const float* e2, long long ld_e2, int G, int l, int r, int apply_exp,
+                           const float* V, const float* s, const float* ds, float* d_e1, long long ld_de1, float* dW, void* ws,
+                           size_t ws_bytes, void* stream);
+
 /* nn.Linear over the (virtual) concat of two inputs + activation (0 none / 1 relu / 2 tanh): the MLP matcher, model_zoo.py:285-298 */
 int txe_linear_fwd(const float* x1, long long ld1, int l, const float* x2, long long ld2, int r, int G, const float* W, const float* b,
                    int O, int act, float* y, void* stream);

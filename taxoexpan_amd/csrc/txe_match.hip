@@ -45,6 +45,33 @@ __global__ void de2_kernel(const float* __restrict__ ds, const float* __restrict
     }
 }
 
+// s[i] = <e1[i], V[i]> (exp optionally), one wavefront per row: the query-side form of the bilinear match, V = E2 W^T
+__global__ __launch_bounds__(256) void rowdot2_kernel(const float* __restrict__ e1, long long ld_e1, const float* __restrict__ V, int G, int l,
+                                                      int apply_exp, float* __restrict__ s) {
+    const int w = threadIdx.x >> 6, ln = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + w;
+    if (i >= G) return;
+    float acc = 0.f;
+    for (int k = ln; k < l; k += 64) acc = fmaf(e1[(long long)i * ld_e1 + k], V[(long long)i * l + k], acc);
+    acc = wave_sum(acc);
+    if (ln == 0) s[i] = apply_exp ? __expf(acc) : acc;
+}
+
+// d_e1[i][k] = dsl[i] * V[i][k];  R[i][k] = dsl[i] * e1[i][k]   (dsl = ds * (apply_exp ? s : 1)): the whole backward of
+// s_i = <e1_i, V_i> with respect to e1, and the left operand of dW = R^T E2
+__global__ void bil_scale_kernel(const float* __restrict__ ds, const float* __restrict__ s, int apply_exp, const float* __restrict__ V,
+                                 const float* __restrict__ e1, long long ld_e1, int G, int l, float* __restrict__ d_e1, long long ld_de1,
+                                 float* __restrict__ R) {
+    const long long n = (long long)G * l;
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (long long)gridDim.x * blockDim.x) {
+        const long long i = t / l;
+        const int k = (int)(t % l);
+        const float dsl = apply_exp ? ds[i] * s[i] : ds[i];
+        d_e1[i * ld_de1 + k] = dsl * V[t];
+        R[t] = dsl * e1[i * ld_e1 + k];
+    }
+}
+
 __global__ void reduce_splits_kernel2(const float* __restrict__ part, int S, long long stride, long long n, float* __restrict__ out) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
         float acc = 0.f;
@@ -171,6 +198,57 @@ int txe_bilinear_pair_bwd(const float* e1, long long ld_e1, const float* e2, lon
     const long long n = (long long)l * r;
     const int nb = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
     hipLaunchKernelGGL(reduce_splits_kernel2, dim3(nb), dim3(256), 0, st, (const float*)part, G > 0 ? S : 0, E.split_stride, n, dW);
+    TXE_CHECK_LAUNCH();
+    return TXE_OK;
+}
+
+// Query-side form of the pairwise match when e2 (the query features) needs no gradient -- always, in training (model.py:86, trainer.py:51):
+//   forward   V = E2 W^T [G][l] (one GEMM);  s_i = <e1_i, V_i>
+//   backward  d_e1_i = dsl_i V_i (elementwise -- the candidate-side form needs a second G-row GEMM here);  dW = (dsl (.) E1)^T E2
+// V [G][l] is kept for backward.
+int txe_bilinear_query_fwd(const float* e1, long long ld_e1, const float* e2, long long ld_e2, int G, int l, int r, const float* W,
+                           int apply_exp, float* V, float* s, void* stream) {
+    if (G < 0 || l < 1 || r < 1 || !e1 || !e2 || !W || !V || !s) return TXE_ERR_ARG;
+    if (G == 0) return TXE_OK;
+    VMat A = vmat_plain(e2, ld_e2, G, r);
+    VMat B = vmat_plain(W, r, l, r);
+    Epi E = epi_plain(V, l, l);
+    int rc = gemm_nt(A, B, E, G, l, r, 1, (hipStream_t)stream);
+    if (rc) return rc;
+    hipLaunchKernelGGL(rowdot2_kernel, dim3((G + 3) / 4), dim3(256), 0, (hipStream_t)stream, e1, ld_e1, (const float*)V, G, l, apply_exp, s);
+    TXE_CHECK_LAUNCH();
+    return TXE_OK;
+}
+
+size_t txe_bilinear_query_bwd_ws_bytes(int G, int l, int r) {
+    return mt_align((size_t)(G > 0 ? G : 1) * l * 4) + mt_align((size_t)mt_splits(l, r, G) * l * r * 4);
+}
+
+int txe_bilinear_query_bwd(const float* e1, long long ld_e1, const float* e2, long long ld_e2, int G, int l, int r, int apply_exp,
+                           const float* V, const float* s, const float* ds, float* d_e1, long long ld_de1, float* dW, void* ws,
+                           size_t ws_bytes, void* stream) {
+    if (G < 0 || l < 1 || r < 1 || !e1 || !e2 || !V || !s || !ds || !d_e1 || !dW || !ws) return TXE_ERR_ARG;
+    if (ws_bytes < txe_bilinear_query_bwd_ws_bytes(G, l, r)) return TXE_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    float* R = (float*)ws;
+    float* part = (float*)((char*)ws + mt_align((size_t)(G > 0 ? G : 1) * l * 4));
+    if (G > 0) {
+        const long long n = (long long)G * l;
+        hipLaunchKernelGGL(bil_scale_kernel, dim3((int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096)), dim3(256), 0, st, ds, s, apply_exp, V, e1,
+                           ld_e1, G, l, d_e1, ld_de1, R);
+        TXE_CHECK_LAUNCH();
+    }
+    // dW[j][k] = sum_i R[i][j] * e2[i][k]
+    const int S = mt_splits(l, r, G);
+    VMat A = vmat_plain(R, l, G, l);
+    VMat B = vmat_plain(e2, ld_e2, G, r);
+    Epi E = epi_plain(part, r, r);
+    E.split_stride = (long long)l * r;
+    int rc = gemm_tn(A, B, E, l, r, G, S, st);
+    if (rc) return rc;
+    const long long n = (long long)l * r;
+    hipLaunchKernelGGL(reduce_splits_kernel2, dim3((int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048)), dim3(256), 0, st, (const float*)part,
+                       G > 0 ? S : 0, E.split_stride, n, dW);
     TXE_CHECK_LAUNCH();
     return TXE_OK;
 }

@@ -883,6 +883,10 @@ class LinearFunction(torch.autograd.Function):
 # Bilinear match (BIM / LBM) -- pairwise form of training, model.py:86
 # ================================================================================================================
 class BilinearPairFunction(torch.autograd.Function):
+    """s_i = e1_i^T W e2_i (exp optionally).  When e2 needs no gradient (queries: always so in training) the query-side form runs:
+    V = e2 W^T in forward makes backward's d_e1 = dsl * V elementwise (txe_bilinear_query_*); otherwise the candidate-side form
+    U = e1 W with gradients to both inputs (txe_bilinear_pair_*)."""
+
     @staticmethod
     def forward(ctx, e1, e2, W, apply_exp):
         _need_cuda(e1, e2, W)
@@ -891,24 +895,35 @@ class BilinearPairFunction(torch.autograd.Function):
         Wf = _f32(W).reshape(W.shape[-2], W.shape[-1])
         G, l = e1.shape
         r = e2.shape[1]
-        U, s = _empty((max(G, 1), r), e1), _empty((G,), e1)
+        s = _empty((G,), e1)
+        query_side = not ctx.needs_input_grad[1]
         with torch.cuda.device(e1.device):
-            call("txe_bilinear_pair_fwd", ptr(e1), ld1, ptr(e2), ld2, G, l, r, ptr(Wf), int(apply_exp), ptr(U), ptr(s),
-                 _lib.stream_ptr())
-        ctx.misc = (e1, ld1, e2, ld2, Wf, U, s, int(apply_exp), W.shape)
-        ctx.e2_req = ctx.needs_input_grad[1]
+            if query_side:
+                U = _empty((max(G, 1), l), e1)          # V = e2 W^T
+                call("txe_bilinear_query_fwd", ptr(e1), ld1, ptr(e2), ld2, G, l, r, ptr(Wf), int(apply_exp), ptr(U), ptr(s), _lib.stream_ptr())
+            else:
+                U = _empty((max(G, 1), r), e1)
+                call("txe_bilinear_pair_fwd", ptr(e1), ld1, ptr(e2), ld2, G, l, r, ptr(Wf), int(apply_exp), ptr(U), ptr(s),
+                     _lib.stream_ptr())
+        ctx.misc = (e1, ld1, e2, ld2, Wf, U, s, int(apply_exp), W.shape, query_side)
         return s.unsqueeze(1)
 
     @staticmethod
     def backward(ctx, ds):
-        e1, ld1, e2, ld2, Wf, U, s, apply_exp, wshape = ctx.misc
+        e1, ld1, e2, ld2, Wf, U, s, apply_exp, wshape, query_side = ctx.misc
         G, l = e1.shape
         r = e2.shape[1]
         ds = _f32(ds.reshape(-1))
         d_e1 = _empty((G, l), e1)
-        d_e2 = _empty((G, r), e1) if ctx.e2_req else None
         dW = torch.empty_like(Wf)
         with torch.cuda.device(e1.device):
+            if query_side:
+                wsb = call("txe_bilinear_query_bwd_ws_bytes", G, l, r)
+                ws = _ws(wsb, e1)
+                call("txe_bilinear_query_bwd", ptr(e1), ld1, ptr(e2), ld2, G, l, r, apply_exp, ptr(U), ptr(s), ptr(ds), ptr(d_e1), l, ptr(dW),
+                     ptr(ws), wsb, _lib.stream_ptr())
+                return d_e1, None, dW.reshape(wshape), None
+            d_e2 = _empty((G, r), e1)
             wsb = call("txe_bilinear_pair_bwd_ws_bytes", G, l, r)
             ws = _ws(wsb, e1)
             call("txe_bilinear_pair_bwd", ptr(e1), ld1, ptr(e2), ld2, G, l, r, ptr(Wf), apply_exp, ptr(U), ptr(s), ptr(ds), ptr(d_e1),

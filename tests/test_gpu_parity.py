@@ -231,15 +231,18 @@ def test_readout_and_match_ops_against_oracle():
     W = torch.from_numpy(rs.standard_normal((1, l, r)).astype(np.float32) * 0.2)
     up = torch.from_numpy(rs.standard_normal((G, 1)).astype(np.float32))
     for ex in (False, True):
-        a, b, c = (t.to(_dev()).requires_grad_(True) for t in (e1, e2, W))
-        s = ops.BilinearPairFunction.apply(a, b, c, ex)
-        (s * up.to(_dev())).sum().backward()
-        ac, bc, cc = (t.clone().requires_grad_(True) for t in (e1, e2, W))
-        sr = orc.bilinear_match(ac, bc, cc, ex)
-        (sr * up).sum().backward()
-        np.testing.assert_allclose(s.detach().cpu().numpy(), sr.detach().numpy(), rtol=RT, atol=AT)
-        for got, want in ((a, ac), (b, bc), (c, cc)):
-            np.testing.assert_allclose(got.grad.cpu().numpy(), want.grad.numpy(), rtol=1e-3, atol=1e-5)
+        for query_grad in (True, False):          # False: the query-side form (V = e2 W^T, elementwise d_e1) that training takes
+            a, b, c = (t.to(_dev()).requires_grad_(True) for t in (e1, e2, W))
+            b.requires_grad_(query_grad)
+            s = ops.BilinearPairFunction.apply(a, b, c, ex)
+            (s * up.to(_dev())).sum().backward()
+            ac, bc, cc = (t.clone().requires_grad_(True) for t in (e1, e2, W))
+            sr = orc.bilinear_match(ac, bc, cc, ex)
+            (sr * up).sum().backward()
+            np.testing.assert_allclose(s.detach().cpu().numpy(), sr.detach().numpy(), rtol=RT, atol=AT)
+            for got, want in ((a, ac), (b, bc), (c, cc)) if query_grad else ((a, ac), (c, cc)):
+                np.testing.assert_allclose(got.grad.cpu().numpy(), want.grad.numpy(), rtol=1e-3, atol=1e-5)
+            assert query_grad or b.grad is None
 
 
 def test_scoring_loop_and_ranks_against_reference_goldens():

@@ -58,6 +58,15 @@ int txe_gat_layer_prepare(const float* h, long long ld_h, int n_nodes, int Kh, c
                           const float* W, const float* attn_l, const float* attn_r, int H, int D, float* Wp, float feat_drop_p,
                           unsigned long long seed, unsigned* mask, void* stream);
 
+/* the same for every GATLayer of a stack in ONE launch: a layer's preparation depends on the parameters and on `pos` only, never on the
+ * output of the layer below (whose aggregation writes the feature columns of X later), so the whole stack is prepared before its first
+ * GEMM.  descs[i]: the arguments of txe_gat_layer_prepare for layer i (h == NULL for every layer but the first). */
+struct txe_gat_prepare_desc {
+    const float* h; long long ld_h; int n_nodes, Kh; const int* pos; const float* P; int Pd; float* X;
+    const float *W, *attn_l, *attn_r; int H, D; float* Wp; float feat_drop_p; unsigned long long seed; unsigned* mask;
+};
+int txe_gat_layers_prepare(const struct txe_gat_prepare_desc* descs, int n_layers, void* stream);
+
 /* the same for a GCNLayer (model_zoo.py:35-37): txe_gat_build_x + txe_gcn_pack_weights + txe_dropout_mask as ONE launch */
 int txe_gcn_layer_prepare(const float* h, long long ld_h, int n_nodes, int Kh, const int* pos, const float* P, int Pd, float* X,
                           const float* W, int Fo, float* Wp, float drop_p, unsigned long long seed, unsigned* mask, void* stream);

@@ -63,6 +63,7 @@ SIGNATURES = {
     "txe_gat_collapse_fwd": (I, [P, P, P, P, P, P, I, I, I, P, I, I, P, I, F, P, F, F, U64, P, P, P, I, P, P, P, P, P, P, L, P, SZ, P]),
     "txe_gat_collapse_bwd": (I, [P, P, P, P, P, P, I, I, I, P, I, I, P, I, P, P, P, P, I, F, P, F, F, U64, P, P, P, P, P, P, P, P, L, P, L, I, F,
                                  P, P, P, P, P, P, P, SZ, P]),
+    "txe_gat_layers_prepare": (I, [P, I, P]),
     "txe_gat_fused_bwd_supported": (I, [I, I, I, I]),
     "txe_gat_collapse_bwd_fused_ws_bytes": (SZ, [I, I, I, I, I, I, I, I]),
     "txe_gat_collapse_bwd_fused": (I, [P, P, P, P, P, P, I, I, I, P, I, I, P, I, P, P, P, P, I, F, P, F, F, U64, P, P, P, P, P, P, P, P, L, P, L,
@@ -82,6 +83,12 @@ SIGNATURES = {
     "txe_profile_count": (I, []),
     "txe_profile_get": (I, [I, P, I, P, P, P]),
 }
+
+class GatPrepareDesc(C.Structure):
+    """struct txe_gat_prepare_desc (include/txe.h)"""
+    _fields_ = [("h", P), ("ld_h", L), ("n_nodes", I), ("Kh", I), ("pos", P), ("P", P), ("Pd", I), ("X", P), ("W", P), ("attn_l", P),
+                ("attn_r", P), ("H", I), ("D", I), ("Wp", P), ("feat_drop_p", F), ("seed", U64), ("mask", P)]
+
 
 _ERR = {-1: "TXE_ERR_ARG", -2: "TXE_ERR_LAUNCH", -3: "TXE_ERR_WORKSPACE"}
 VALUE_RETURNING = {"txe_gat_padded_k", "txe_gat_padded_f", "txe_gcn_padded_f", "txe_profile_count", "txe_gat_fused_bwd_supported"}   # int results that are not status codes

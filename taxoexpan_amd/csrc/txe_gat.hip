@@ -38,26 +38,16 @@ struct NextLogits {
     float scale;
     int kp, mask_ld;
 };
-template <int VEC, int NI, bool NX>
-__global__ __launch_bounds__(GAT_WAVES * 64) void gat_aggregate_fwd_kernel(
-    const int* __restrict__ rowptr, const int* __restrict__ col, const int n_nodes, const float* __restrict__ ft,
+// one destination node v, one wave: attention softmax over its in-edges, aggregation, (NX) the next layer's folded logits
+// NX: 0 = plain aggregation, 1 = + the next (folded) layer's logits, 2 = the same with that layer's feature-dropout mask
+template <int VEC, int NI, int NX>
+__device__ __forceinline__ void gat_fwd_node(const int v, const int l, float* __restrict__ s_w, int* __restrict__ s_idx,
+    float* __restrict__ s_stat, const float* __restrict__ s_wa,
+    const int* __restrict__ rowptr, const int* __restrict__ col, const float* __restrict__ ft,
     const long long ld_ft, const float* __restrict__ a_src, const float* __restrict__ a_dst, const int ld_a, const int H,
     const int D, const float slope, const float drop_p, const float drop_scale, const unsigned long long seed,
     const int out_mode, const float act_slope, float* __restrict__ out, const long long ld_out, float* __restrict__ alpha,
-    const NextLogits nx) {
-    __shared__ float s_w[GAT_WAVES][GAT_MAXH * 64];
-    __shared__ int s_idx[GAT_WAVES][64];
-    __shared__ float s_stat[GAT_WAVES][2 * GAT_MAXH];
-
-    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
-    extern __shared__ float s_wa[];                    // NX: the two folded rows [2][kp], shared by the workgroup's 4 nodes
-    if constexpr (NX) {
-        for (int i = threadIdx.x * 4; i < 2 * nx.kp; i += GAT_WAVES * 64 * 4)
-            *reinterpret_cast<float4*>(s_wa + i) = *reinterpret_cast<const float4*>(nx.wa + i);
-        __syncthreads();                               // before any wave leaves
-    }
-    const int v = xcd_remap(blockIdx.x, gridDim.x) * GAT_WAVES + w;
-    if (v >= n_nodes) return;
+    const NextLogits& nx) {
     const int beg = rowptr[v], end = rowptr[v + 1];
 
     // Common case (every egonet: in-degree <= 51, H <= 4): one edge per lane, the logits of all heads stay in registers, the
@@ -78,7 +68,7 @@ __global__ __launch_bounds__(GAT_WAVES * 64) void gat_aggregate_fwd_kernel(
 #pragma unroll
         for (int h = 0; h < 4; ++h) sm[h] = wave_sum(ex[h]);
         if (valid) {
-            s_idx[w][l] = u;
+            s_idx[l] = u;
 #pragma unroll
             for (int h = 0; h < 4; ++h) {
                 if (h < H) {
@@ -86,7 +76,7 @@ __global__ __launch_bounds__(GAT_WAVES * 64) void gat_aggregate_fwd_kernel(
                     if (alpha != nullptr) alpha[(long long)p * H + h] = al;
                     float f = 1.f;
                     if (drop_p > 0.f) f = drop_factor(seed, (unsigned long long)p * H + h, drop_p, drop_scale);
-                    s_w[w][h * 64 + l] = al * f;
+                    s_w[h * 64 + l] = al * f;
                 }
             }
         }
@@ -100,7 +90,7 @@ __global__ __launch_bounds__(GAT_WAVES * 64) void gat_aggregate_fwd_kernel(
         float s = 0.f;
         for (int p = beg + l; p < end; p += 64) s += __expf(leaky(a_src[(long long)col[p] * ld_a + h] + ad, slope) - m);
         s = wave_sum(s);
-        if (l == 0) { s_stat[w][2 * h] = m; s_stat[w][2 * h + 1] = 1.f / s; }
+        if (l == 0) { s_stat[2 * h] = m; s_stat[2 * h + 1] = 1.f / s; }
     }
     }
     __builtin_amdgcn_wave_barrier();
@@ -115,7 +105,8 @@ __global__ __launch_bounds__(GAT_WAVES * 64) void gat_aggregate_fwd_kernel(
         for (int i = 0; i < 2; ++i) {
             const int c = F + l + 64 * i, cc = min(c, nx.kp - 1);
             tx[i] = out[(long long)v * ld_out + cc];
-            const unsigned wd = nx.mask ? nx.mask[(long long)v * nx.mask_ld + (cc >> 5)] : 0xFFFFFFFFu;
+            unsigned wd = 0xFFFFFFFFu;
+            if constexpr (NX == 2) wd = nx.mask[(long long)v * nx.mask_ld + (cc >> 5)];
             tk[i] = (c < nx.kp) ? ((wd >> (cc & 31)) & 1u) : 0u;
         }
     }
@@ -128,7 +119,8 @@ __global__ __launch_bounds__(GAT_WAVES * 64) void gat_aggregate_fwd_kernel(
             for (int i = 0; i < NI; ++i) {
                 const int j = t0 + l + 64 * i;
                 const int c = ((j < nvec) ? j : 0) * VEC;
-                kb[i] = nx.mask ? (nx.mask[(long long)v * nx.mask_ld + (c >> 5)] >> (c & 31)) : 0xFFFFFFFFu;
+                kb[i] = 0xFFFFFFFFu;
+                if constexpr (NX == 2) kb[i] = nx.mask[(long long)v * nx.mask_ld + (c >> 5)] >> (c & 31);
                 kb[i] = (j < nvec) ? kb[i] : 0u;
             }
         }
@@ -143,18 +135,18 @@ __global__ __launch_bounds__(GAT_WAVES * 64) void gat_aggregate_fwd_kernel(
             const int p = cb + l;
             if (!single && p < end) {
                 const int u = col[p];
-                s_idx[w][l] = u;
+                s_idx[l] = u;
                 for (int h = 0; h < H; ++h) {
                     const float e = leaky(a_src[(long long)u * ld_a + h] + a_dst[(long long)v * ld_a + h], slope);
-                    const float al = __expf(e - s_stat[w][2 * h]) * s_stat[w][2 * h + 1];
+                    const float al = __expf(e - s_stat[2 * h]) * s_stat[2 * h + 1];
                     if (alpha != nullptr && t0 == 0) alpha[(long long)p * H + h] = al;
                     float f = 1.f;
                     if (drop_p > 0.f) f = drop_factor(seed, (unsigned long long)p * H + h, drop_p, drop_scale);
-                    s_w[w][h * 64 + l] = al * f;
+                    s_w[h * 64 + l] = al * f;
                 }
             }
             __builtin_amdgcn_wave_barrier();
-            gather_rows<VEC, NI, EU>(ft, ld_ft, s_idx[w], s_w[w], min(64, end - cb), t0, nvec, hidx, acc);
+            gather_rows<VEC, NI, EU>(ft, ld_ft, s_idx, s_w, min(64, end - cb), t0, nvec, hidx, acc);
             __builtin_amdgcn_wave_barrier();
         }
 #pragma unroll
@@ -198,6 +190,30 @@ __global__ __launch_bounds__(GAT_WAVES * 64) void gat_aggregate_fwd_kernel(
         nx2 = wave_sum(nx2) * nx.scale;
         if (l == 0) { nx.a12[2 * (long long)v] = nx1; nx.a12[2 * (long long)v + 1] = nx2; }
     }
+}
+
+template <int VEC, int NI, int NX>
+__global__ __launch_bounds__(GAT_WAVES * 64) void gat_aggregate_fwd_kernel(
+    const int* __restrict__ rowptr, const int* __restrict__ col, const int n_nodes, const float* __restrict__ ft,
+    const long long ld_ft, const float* __restrict__ a_src, const float* __restrict__ a_dst, const int ld_a, const int H,
+    const int D, const float slope, const float drop_p, const float drop_scale, const unsigned long long seed,
+    const int out_mode, const float act_slope, float* __restrict__ out, const long long ld_out, float* __restrict__ alpha,
+    const NextLogits nx) {
+    __shared__ float s_w[GAT_WAVES][GAT_MAXH * 64];
+    __shared__ int s_idx[GAT_WAVES][64];
+    __shared__ float s_stat[GAT_WAVES][2 * GAT_MAXH];
+
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    extern __shared__ float s_wa[];                    // NX: the two folded rows [2][kp], shared by the workgroup's 4 nodes
+    if constexpr (NX) {
+        for (int i = threadIdx.x * 4; i < 2 * nx.kp; i += GAT_WAVES * 64 * 4)
+            *reinterpret_cast<float4*>(s_wa + i) = *reinterpret_cast<const float4*>(nx.wa + i);
+        __syncthreads();                               // before any wave leaves
+    }
+    const int v = xcd_remap(blockIdx.x, gridDim.x) * GAT_WAVES + w;
+    if (v >= n_nodes) return;
+    gat_fwd_node<VEC, NI, NX>(v, l, s_w[w], s_idx[w], s_stat[w], s_wa, rowptr, col, ft, ld_ft, a_src, a_dst, ld_a, H, D, slope, drop_p,
+                              drop_scale, seed, out_mode, act_slope, out, ld_out, alpha, nx);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -617,7 +633,7 @@ struct KName {
     char s[64];
     KName(const char* base, int a, int b) { snprintf(s, sizeof(s), "%s<%d, %d>", base, a, b); }
     KName(const char* base, int a) { snprintf(s, sizeof(s), "%s<%d>", base, a); }
-    KName(const char* base, int a, int b, bool c) { snprintf(s, sizeof(s), "%s<%d, %d, %s>", base, a, b, c ? "true" : "false"); }
+    KName(const char* base, int a, int b, int c) { snprintf(s, sizeof(s), "%s<%d, %d, %d>", base, a, b, c); }
 };
 
 #define TXE_DISPATCH_VEC_NI(vec, ni, LAUNCH)                                     \
@@ -662,19 +678,21 @@ int txe_gat_aggregate_fwd(const int* rowptr_in, const int* col_src, int n_nodes,
     // algorithmic (compulsory) bytes, SURVEY 8d: read ft + write out + a_src/a_dst + CSR (+ alpha when kept for backward);
     // the edge count is not known here (device rowptr), the E-proportional terms are added by the caller-side model
     const int ni = pick_ni(H * D / vec);
-    const KName kn("gat_aggregate_fwd_kernel", vec, ni, nx_a12 != nullptr);
+    const KName kn("gat_aggregate_fwd_kernel", vec, ni, nx_a12 ? (nx.mask ? 2 : 1) : 0);
     ProfScope prof(kn.s, s, 4.0 * (2.0 * n_nodes * (double)H * D + 2.0 * n_nodes * H + n_nodes + 1), 1);
 #define TXE_L(V, I)                                                                                                               \
-    hipLaunchKernelGGL((gat_aggregate_fwd_kernel<V, I, false>), dim3(nb), dim3(GAT_WAVES * 64), 0, s, rowptr_in, col_src, n_nodes, \
+    hipLaunchKernelGGL((gat_aggregate_fwd_kernel<V, I, 0>), dim3(nb), dim3(GAT_WAVES * 64), 0, s, rowptr_in, col_src, n_nodes, \
                        ft, ld_ft, a_src, a_dst, ld_a, H, D, attn_slope, attn_drop_p, scale, seed, out_mode, act_slope,            \
                        out, ld_out, alpha, nx)
-#define TXE_LX(I)                                                                                                                 \
-    hipLaunchKernelGGL((gat_aggregate_fwd_kernel<4, I, true>), dim3(nb), dim3(GAT_WAVES * 64), (size_t)2 * nx_kp * sizeof(float), s, rowptr_in, col_src, n_nodes,  \
+#define TXE_LXM(I, M)                                                                                                             \
+    hipLaunchKernelGGL((gat_aggregate_fwd_kernel<4, I, M>), dim3(nb), dim3(GAT_WAVES * 64), (size_t)2 * nx_kp * sizeof(float), s, rowptr_in, col_src, n_nodes,  \
                        ft, ld_ft, a_src, a_dst, ld_a, H, D, attn_slope, attn_drop_p, scale, seed, out_mode, act_slope,            \
                        out, ld_out, alpha, nx)
+#define TXE_LX(I) do { if (nx.mask) TXE_LXM(I, 2); else TXE_LXM(I, 1); } while (0)
     if (nx_a12) { if (ni == 8) TXE_LX(8); else if (ni == 4) TXE_LX(4); else TXE_LX(2); }
     else TXE_DISPATCH_VEC_NI(vec, ni, TXE_L);
 #undef TXE_LX
+#undef TXE_LXM
 #undef TXE_L
     TXE_CHECK_LAUNCH();
     return TXE_OK;

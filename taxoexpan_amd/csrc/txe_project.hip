@@ -434,6 +434,78 @@ int txe_gat_layer_prepare(const float* h, long long ld_h, int n_nodes, int Kh, c
     return TXE_OK;
 }
 
+// txe_gat_layer_prepare for ALL GATLayers of a stack in ONE launch: everything a layer needs before its projection -- packed weights,
+// folded attention rows, keep mask, the position-embedding / padding columns of its input -- depends on the parameters and on `pos`
+// only, never on the layer below's output, so the whole stack can be prepared before the first GEMM (one dispatch instead of one per
+// layer; the feature columns of the deeper layers' inputs are written later by the aggregation below them).
+struct txe_gat_prepare_desc {
+    const float* h; long long ld_h; int n_nodes, Kh; const int* pos; const float* P; int Pd; float* X;
+    const float *W, *attn_l, *attn_r; int H, D; float* Wp; float feat_drop_p; unsigned long long seed; unsigned* mask;
+};
+}  // extern "C"
+namespace txe {
+constexpr int PREP_MAXL = 4;
+struct PrepMulti { int n; int nb_end[PREP_MAXL]; PrepArgs a[PREP_MAXL]; };
+__global__ __launch_bounds__(64 * FOLD_DG) void gat_prepare_multi_kernel(const PrepMulti m) {
+    int b = blockIdx.x, i = 0;
+    while (i + 1 < m.n && b >= m.nb_end[i]) ++i;                    // (block-uniform)
+    const PrepArgs& a = m.a[i];
+    b -= (i > 0) ? m.nb_end[i - 1] : 0;
+    if (b < a.nb_f) {
+        fold_attn_job(b % a.fold_bx, b / a.fold_bx, a.W, (long long)a.Kt, a.Kt, a.attn_l, a.attn_r, a.H, a.D, a.Wp + (long long)a.F * a.Kp,
+                      (long long)a.Kp);
+        return;
+    }
+    b -= a.nb_f;
+    if (b < a.nb_w) { pack_w_job(b, a.nb_w, a.W, a.pk_rows, a.pk_ext, a.pk_prows, a.pk_cols, a.pk_pcols, a.Wp); return; }
+    b -= a.nb_w;
+    if (b < a.nb_m) { dropout_mask_job(b, a.nb_m, a.n_words, a.seed, a.thr16, a.mask); return; }
+    b -= a.nb_m;
+    build_x_job(b, a.nb_x, a.h, a.ld_h, a.pos, a.P, a.n_rows, a.Kh, a.Pd, a.Kp, a.X);
+}
+static int fill_prep(PrepArgs& a, const txe_gat_prepare_desc& d) {
+    if (d.n_nodes < 0 || d.Kh < 1 || d.Pd < 0 || !d.X || (d.Pd > 0 && (!d.pos || !d.P)) || !d.W || !d.attn_l || !d.attn_r || !d.Wp || d.H < 1 ||
+        d.D < 1 || d.feat_drop_p < 0.f || d.feat_drop_p >= 1.f || (d.feat_drop_p > 0.f && !d.mask))
+        return TXE_ERR_ARG;
+    const int T = 64 * FOLD_DG;
+    a.Kt = d.Kh + d.Pd; a.Kp = round_up(a.Kt, 32);
+    a.F = d.H * d.D; a.Fe = a.F + 2 * d.H; a.Fp = round_up(a.Fe, 128);
+    auto blocks = [&](long long n, int cap) { const long long b = (n + T - 1) / T; return (int)(b < cap ? b : cap); };
+    const long long nx = (long long)d.n_nodes * (a.Kp - (d.h ? 0 : d.Kh));
+    a.nb_x = nx > 0 ? blocks((long long)d.n_nodes * 64, 2048) : 0;
+    a.n_words = (d.feat_drop_p > 0.f) ? (long long)d.n_nodes * ((a.Kt + 31) / 32) : 0;
+    a.nb_m = blocks(a.n_words, 1024);
+    a.nb_w = blocks((long long)a.Fp * 64, 512);
+    a.fold_bx = (a.Kt + 63) / 64;
+    a.nb_f = a.fold_bx * 2 * d.H;
+    a.h = d.h; a.ld_h = d.ld_h; a.pos = d.pos; a.P = d.P; a.n_rows = d.n_nodes; a.Kh = d.Kh; a.Pd = d.Pd; a.X = d.X;
+    a.W = d.W; a.attn_l = d.attn_l; a.attn_r = d.attn_r; a.H = d.H; a.D = d.D; a.Wp = d.Wp;
+    a.pk_rows = a.F; a.pk_ext = a.Fe; a.pk_prows = a.Fp; a.pk_cols = a.Kt; a.pk_pcols = a.Kp;
+    a.seed = d.seed; a.thr16 = (unsigned)(d.feat_drop_p * 65536.0f + 0.5f); a.mask = d.mask;
+    return TXE_OK;
+}
+}  // namespace txe
+extern "C" {
+int txe_gat_layers_prepare(const struct txe_gat_prepare_desc* descs, int n_layers, void* stream) {
+    if (!descs || n_layers < 1) return TXE_ERR_ARG;
+    for (int i0 = 0; i0 < n_layers; i0 += PREP_MAXL) {              // (more than PREP_MAXL layers: several launches)
+        PrepMulti m;
+        memset(&m, 0, sizeof(m));
+        m.n = n_layers - i0 < PREP_MAXL ? n_layers - i0 : PREP_MAXL;
+        int total = 0;
+        for (int i = 0; i < m.n; ++i) {
+            const int rc = fill_prep(m.a[i], descs[i0 + i]);
+            if (rc) return rc;
+            total += m.a[i].nb_x + m.a[i].nb_m + m.a[i].nb_w + m.a[i].nb_f;
+            m.nb_end[i] = total;
+        }
+        if (total == 0) continue;
+        hipLaunchKernelGGL(gat_prepare_multi_kernel, dim3(total), dim3(64 * FOLD_DG), 0, (hipStream_t)stream, m);
+        TXE_CHECK_LAUNCH();
+    }
+    return TXE_OK;
+}
+
 // The same for a GCNLayer (model_zoo.py:35-37): txe_gat_build_x + txe_gcn_pack_weights + txe_dropout_mask in one launch.
 // W [Kh+Pd][Fo] -> Wp [roundup(roundup(Kh+Pd,32),128)][roundup(Fo,32)]; mask may be NULL when drop_p == 0.
 int txe_gcn_layer_prepare(const float* h, long long ld_h, int n_nodes, int Kh, const int* pos, const float* P, int Pd, float* X,

@@ -299,11 +299,29 @@ def _tail_ws(ref):
 
 
 class _GatLayerState:
-    __slots__ = ("X", "Wp", "mask", "Y", "alpha", "W", "al", "ar", "P", "Kh", "Pd", "Kp", "Fp", "H", "D", "seed", "cl")
+    __slots__ = ("X", "Wp", "mask", "Y", "alpha", "W", "al", "ar", "P", "Kh", "Pd", "Kp", "Fp", "H", "D", "seed", "cl", "prepared")
+
+
+def _gat_layers_prepare(items, feat_p):
+    """_gat_layer_prepare for several layers of a stack in ONE launch (txe_gat_layers_prepare): items = [(st, h, ld_h, pos)], st.X
+    allocated.  A layer's preparation never depends on the layer below's output, so the whole stack is prepared before its first GEMM."""
+    import ctypes
+    descs = (_lib.GatPrepareDesc * len(items))()
+    for d, (st, h, ld_h, pos) in zip(descs, items):
+        N = st.X.shape[0]
+        st.Wp = _empty((st.Fp, st.Kp), st.X)
+        st.mask = torch.empty((N, (st.Kh + st.Pd + 31) // 32), dtype=torch.int32, device=st.X.device) if feat_p > 0.0 else None
+        d.h, d.ld_h, d.n_nodes, d.Kh, d.pos, d.P, d.Pd, d.X = ptr(h), ld_h, N, st.Kh, ptr(pos), ptr(st.P), st.Pd, ptr(st.X)
+        d.W, d.attn_l, d.attn_r, d.H, d.D, d.Wp = ptr(st.W), ptr(st.al), ptr(st.ar), st.H, st.D, ptr(st.Wp)
+        d.feat_drop_p, d.seed, d.mask = feat_p, st.seed, ptr(st.mask)
+        st.prepared = True
+    call("txe_gat_layers_prepare", ctypes.cast(descs, ctypes.c_void_p), len(items), _lib.stream_ptr())
 
 
 def _gat_layer_prepare(st, h, ld_h, pos, feat_p):
     """layer input X = [h | Emb[pos] | 0] (h == None: the producer already wrote the feature columns), packed weights, keep mask"""
+    if getattr(st, "prepared", False):
+        return
     N = st.X.shape[0]
     s = _lib.stream_ptr()
     st.Wp = _empty((st.Fp, st.Kp), st.X)
@@ -409,6 +427,7 @@ def _gat_layer_bwd(csr, st, pos, vocab, feat_p, attn_p, attn_slope, d_pre, ld_dp
     return _gat_dense_bwd(st, pos, vocab, feat_p, d_Y, need_dh, act_on, act_slope)
 
 
+_NO_MULTI_PREPARE = os.environ.get("TXE_NO_MULTI_PREPARE", "0") == "1"   # A/B switch: one preparation launch per layer
 _NO_FUSED_BWD = os.environ.get("TXE_NO_FUSED_BWD", "0") == "1"       # A/B switch (tests compare both paths)
 
 
@@ -483,6 +502,11 @@ class GATStackFunction(torch.autograd.Function):
                 kh = st.H * st.D
             h = ref                                  # (allocation reference from here on; the features travel as `src`)
             states[0].X = None if table else _empty((N, states[0].Kp), h)
+            if N > 0 and not _NO_MULTI_PREPARE:      # every layer's input buffer now, and ONE preparation launch for the whole stack
+                for l in range(1, L):
+                    states[l].X = _empty((N, states[l].Kp), h)
+                _gat_layers_prepare([(st, (src if l == 0 else None), (ld_h if l == 0 else 0), pos if st.P is not None else None)
+                                     for l, st in enumerate(states) if not (table and l == 0)], cfg.feat_p)
             fused_a12 = None
             for l, st in enumerate(states):
                 last = (l == L - 1)
@@ -496,7 +520,8 @@ class GATStackFunction(torch.autograd.Function):
                 if last:
                     out, ld_out = _empty((N, F), h), F
                 else:                                  # the aggregation writes straight into the next layer's padded input
-                    states[l + 1].X = _empty((N, states[l + 1].Kp), h)
+                    if states[l + 1].X is None:
+                        states[l + 1].X = _empty((N, states[l + 1].Kp), h)
                     out, ld_out = states[l + 1].X, states[l + 1].Kp
                 out_mode = 0 if (last or cfg.act_slope is None) else 1
                 nxt = None

@@ -159,8 +159,13 @@ __device__ __forceinline__ void segsum2_job(const int bid, const Seg2Args& a) {
     const int i = bid * 64 + il;
     const int ic = (i < a.n) ? i : 0;
     float acc = 0.f;
-#pragma unroll 4
-    for (int b = bg; b < a.nb; b += 4) acc += a.part[(long long)b * a.n + ic];
+    for (int b0 = bg; b0 < a.nb; b0 += 64) {          // 16 partial rows of this row group per step: clamped loads issued together
+        float v[16];                                   // (the fused sweeps leave ~1,100 partial rows: one load in flight per thread
+#pragma unroll                                         //  made this walk 280 dependent round trips)
+        for (int q = 0; q < 16; ++q) v[q] = a.part[(long long)min(b0 + 4 * q, a.nb - 1) * a.n + ic];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc += (b0 + 4 * q < a.nb) ? v[q] : 0.f;
+    }
     red[bg][il] = acc;
     __syncthreads();
     if (bg == 0 && i < a.n) a.out[i] = red[0][il] + red[1][il] + red[2][il] + red[3][il];

@@ -95,9 +95,13 @@ def train_step(model, opt, batch, target, world):
     opt.zero_grad(set_to_none=True)
     pred = model(g, batch["x"], batch["qf"])                       # trainer.py:51
     loss = info_nce_loss(pred.reshape(N_QUERIES, -1), target)     # trainer.py:52-56, loss.py:52-57 (one launch, gradient included)
-    loss.backward()                                                  # trainer.py:60
-    if world > 1:
-        allreduce_gradients(list(model.parameters()))
+    if world > 1:      # the output layer's gradient bucket is all-reduced under the backward of the layer below, the rest afterwards
+        from taxoexpan_amd.scoring import overlapped_gradient_allreduce
+        with overlapped_gradient_allreduce() as ov:
+            loss.backward()                                              # trainer.py:60
+        allreduce_gradients(list(model.parameters()), skip=ov)
+    else:
+        loss.backward()                                                  # trainer.py:60
     opt.step()                                                       # trainer.py:61
     return loss
 
@@ -393,7 +397,7 @@ def variant_step(workload, tax, device, steps=10, reps=5):
                 roofline_top5=[{k: r[k] for k in ("kernel", "bound", "frac", "avg_us", "launches", "total_us")} for r in roof[:5]])
 
 
-def extra_metrics_sharded(model, device, world, rank, n_queries=8192, qblock=1024):
+def extra_metrics_sharded(model, device, world, rank, n_queries=int(os.environ.get("TXE_BENCH_SHARDED_QUERIES", "8192")), qblock=1024):
     """N > 1: all-candidate inference on the MAG-Full shape, candidates sharded contiguously over the ranks (each rank encodes
     and scores its shard), score blocks all-gathered over xGMI so every rank holds the full [queries x candidates] block
     (north star).  Reports the compute-only and the all-gather-inclusive pair rates (max over ranks)."""
@@ -416,7 +420,7 @@ def extra_metrics_sharded(model, device, world, rank, n_queries=8192, qblock=102
         hg = encode_candidates(model, g)
         torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
         t_enc = time.perf_counter() - t0
-        sink = lambda q0, full: None
+        sink = lambda q0, blk: None            # (a consumer would index blk.shards [world, nq, c] in place)
         timings = {}
         for name, gather in (("local", False), ("allgather", True)):
             def run():

@@ -76,6 +76,8 @@ def new_seed():
     return int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
 
 
+_GRAD_READY = None    # scoring.overlapped_gradient_allreduce: called as (layer index, [parameter gradients]) the moment a layer's are done
+_GRAD_FLUSH = None    # ... and once before the stack returns its gradients to autograd
 _CAPTURE = None       # debug_capture(): list that receives (csr, cfg, per-layer states) of every stack forward
 
 
@@ -552,6 +554,7 @@ class GATStackFunction(torch.autograd.Function):
         ctx.csr, ctx.cfg, ctx.pos, ctx.states = csr, cfg, pos, (states if need else None)
         ctx.rpos, ctx.pwf, ctx.pw_shape = rpos, pwf, (pw.shape if pwf is not None else None)
         ctx.h_req = ctx.needs_input_grad[2]
+        ctx.param_ids, ctx.pw_id = [id(p) for p in params], id(pw)
         if _CAPTURE is not None:
             _CAPTURE.append((csr, cfg, states))
         return res
@@ -601,9 +604,14 @@ class GATStackFunction(torch.autograd.Function):
                     d_X, dW, dal, dar, dP = _gat_layer_bwd(csr, st, pos if st.P is not None else None, cfg.vocab, cfg.feat_p, cfg.attn_p,
                                                            cfg.attn_slope, d_pre, ld_dpre, need_dh, act_on, cfg.act_slope)
                 grads[4 * l:4 * l + 4] = [dW, dal, dar, dP]
+                if _GRAD_READY is not None:               # (tensors, ids of the parameters they are the gradients of)
+                    last_c = collapse and l == L - 1
+                    _GRAD_READY(l, [dW, dal, dar, dP] + ([d_pw] if last_c else []), ctx.param_ids[4 * l:4 * l + 4] + ([ctx.pw_id] if last_c else []))
                 if l > 0 and d_Y_ready is None:
                     d_pre, ld_dpre = d_X, st.Kp            # its first H*D(l-1) columns are d(pre-activation out_{l-1})
             d_h = d_X[:, :states[0].Kh].contiguous() if ctx.h_req else None
+            if _GRAD_FLUSH is not None:
+                _GRAD_FLUSH()
         ctx.states = None
         if d_pw is not None:
             d_pw = d_pw.reshape(ctx.pw_shape)

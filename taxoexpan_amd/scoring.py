@@ -56,19 +56,45 @@ def shard_bounds(n, world, rank):
     return lo, min(lo + c, n)
 
 
+class ShardedScoreBlock:
+    """One query block of the candidate-sharded scoring loop after its all-gather: `shards` [world, nq, c] holds, for rank r, the
+    scores of candidates [r*c, (r+1)*c) (c = ceil(G / world); the tail of the last shard is padding).  Consumers index it in place --
+    `columns(r)` is rank r's [nq, n_r] slab -- or ask for the dense [nq, G] matrix, which costs one more pass over the block."""
+
+    def __init__(self, shards, n_total):
+        self.shards, self.n_total = shards, int(n_total)
+
+    @property
+    def shape(self):
+        return (self.shards.shape[1], self.n_total)
+
+    def columns(self, r):
+        c = self.shards.shape[2]
+        return self.shards[r, :, :max(0, min(c, self.n_total - r * c))]
+
+    def dense(self):
+        world, nq, c = self.shards.shape
+        return self.shards.permute(1, 0, 2).reshape(nq, world * c)[:, :self.n_total]
+
+
 def all_gather_score_block(local_block, n_total, group=None):
     """local_block [nq, c] (this rank's candidate shard, padded to the common width c = ceil(G/world)) ->
-    full [nq, G] on every rank.  One RCCL all-gather; the only data-path collective of inference."""
+    full [nq, G] on every rank.  One RCCL all-gather (blocking form; score_all_sharded pipelines it)."""
     world = dist.get_world_size(group)
     nq, c = local_block.shape
-    buf = torch.empty((world * nq, c), dtype=local_block.dtype, device=local_block.device)   # rank-major concatenation
-    dist.all_gather_into_tensor(buf, local_block.contiguous(), group=group)
-    return buf.view(world, nq, c).permute(1, 0, 2).reshape(nq, world * c)[:, :n_total]
+    buf = torch.empty((world, nq, c), dtype=local_block.dtype, device=local_block.device)   # rank-major concatenation
+    dist.all_gather_into_tensor(buf.view(world * nq, c), local_block.contiguous(), group=group)
+    return ShardedScoreBlock(buf, n_total).dense()
 
 
-def score_all_sharded(match, hg_local, n_total, queries, block=1024, group=None, local_score_fn=None, on_block=None):
+def score_all_sharded(match, hg_local, n_total, queries, block=1024, group=None, local_score_fn=None, on_block=None, pipeline=True):
     """Candidate-sharded scoring.  hg_local: this rank's [hi-lo, l] candidate representations (shard_bounds order).
-    For every query block: local scores -> all-gather -> on_block(q0, S_full [nq, G]) (default: collect and return).
+    For every query block: local scores -> all-gather over xGMI -> on_block(q0, ShardedScoreBlock) (default: collect the dense
+    [Q, G] matrix and return it).
+    Pipelined (a 1,024-query MAG-Full block is 182 MB per rank, ~8 ms on the ring against ~0.2 ms of GEMM): the gather of
+    block i is issued asynchronously (RCCL's own stream) and waited for only after block i+1's local GEMM has been enqueued, on two
+    alternating pairs of preallocated buffers -- nothing is allocated, zero-filled or permuted inside the loop, and the consumer
+    reads the [world, nq, c] gather buffer in place.  A block handed to on_block stays valid until on_block is called again.
     local_score_fn(queries_block, out_padded) is injectable so the collective logic is testable without a GPU."""
     world = dist.get_world_size(group)
     c = math.ceil(n_total / world)
@@ -79,17 +105,38 @@ def score_all_sharded(match, hg_local, n_total, queries, block=1024, group=None,
         def local_score_fn(qb, out):
             if U.shape[0] > 0:
                 ops.score_block(qb, U, match.apply_exp, out=out[:, :U.shape[0]])
+    Q = queries.shape[0]
+    bmax = min(block, max(Q, 1))
+    nbuf = 2 if pipeline else 1
+    loc = [torch.zeros((bmax, c), dtype=torch.float32, device=dev) for _ in range(nbuf)]     # padding columns: zeroed once, never written
+    full = [torch.empty((world * bmax * c,), dtype=torch.float32, device=dev) for _ in range(nbuf)]
     collected = []
-    for q0 in range(0, queries.shape[0], block):
-        qb = queries[q0:q0 + block]
-        loc = torch.zeros((qb.shape[0], c), dtype=torch.float32, device=dev)
-        local_score_fn(qb, loc)
-        full = all_gather_score_block(loc, n_total, group)
+
+    def consume(q0, nq, b, work):
+        if work is not None:
+            work.wait()                                   # the CURRENT stream waits for the collective; the host does not block
+        blk = ShardedScoreBlock(full[b][:world * nq * c].view(world, nq, c), n_total)
         if on_block is not None:
-            on_block(q0, full)
+            on_block(q0, blk)
         else:
-            collected.append(full)
-    return None if on_block is not None else torch.cat(collected, 0)
+            collected.append(blk.dense().clone() if pipeline else blk.dense())
+    pending = None
+    for i, q0 in enumerate(range(0, Q, block)):
+        qb = queries[q0:q0 + block]
+        nq, b = qb.shape[0], i % nbuf
+        local_score_fn(qb, loc[b][:nq])
+        out = full[b][:world * nq * c].view(world * nq, c)
+        if pipeline:
+            work = dist.all_gather_into_tensor(out, loc[b][:nq], group=group, async_op=True)
+            if pending is not None:
+                consume(*pending)                         # block i-1: its gather ran under this block's local GEMM
+            pending = (q0, nq, b, work)
+        else:
+            dist.all_gather_into_tensor(out, loc[b][:nq], group=group)
+            consume(q0, nq, b, None)
+    if pending is not None:
+        consume(*pending)
+    return None if on_block is not None else (torch.cat(collected, 0) if collected else torch.zeros((0, n_total), device=dev))
 
 
 def rank_all_fused(match, hg, queries, pos_off, pos_idx, block=1024, larger_is_better=True, group=None, shard_lo=0, local_fns=None):
@@ -150,16 +197,56 @@ def _rank_finalize_host(off, thr, counts, larger_is_better):
     return ranks
 
 
-def allreduce_gradients(params, group=None):
+def allreduce_gradients(params, group=None, skip=None):
     """Data-parallel training: the InfoNCE loss is a SUM over queries (loss.py:57) and queries are sharded over ranks,
-    so gradients simply add: one flat bucket (1.76 M fp32 = 7 MB for the MAG config), one RCCL all-reduce."""
-    grads = [p.grad for p in params if p.grad is not None]
+    so gradients simply add: one flat bucket (1.76 M fp32 = 7 MB for the MAG config), one RCCL all-reduce.
+    skip: an overlapped_gradient_allreduce whose gradients were already reduced during backward."""
+    done = skip.reduced if skip is not None else ()
+    grads = [p.grad for p in params if p.grad is not None and id(p) not in done]
     if not grads:
         return
     flat = torch.cat([g.reshape(-1) for g in grads])
     dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
     parts = flat.split([g.numel() for g in grads])
     torch._foreach_copy_(grads, [q.view_as(g) for q, g in zip(parts, grads)])      # one multi-tensor kernel
+
+
+class overlapped_gradient_allreduce:
+    """`with overlapped_gradient_allreduce(group) as ov: loss.backward()` -- the propagation stack's backward announces each layer's
+    parameter gradients the moment they exist (ops._GRAD_READY, with the ids of their parameters); they go into one flat bucket per layer whose all-reduce is issued
+    asynchronously right there, under the backward of the layers below (the output layer's 4 MB bucket rides under ~0.6 ms of
+    layer-0 kernels on the MAG step), and is waited for -- by the stream, not the host -- before the stack hands its gradients to
+    autograd.  `allreduce_gradients(params, skip=ov)` then reduces what is left (the first layer, readout, matcher)."""
+
+    def __init__(self, group=None, min_layer=1):
+        self.group, self.min_layer = group, min_layer
+        self.reduced, self._pending = set(), []
+
+    def __enter__(self):
+        self._prev = (ops._GRAD_READY, ops._GRAD_FLUSH)
+        ops._GRAD_READY, ops._GRAD_FLUSH = self._ready, self._flush
+        return self
+
+    def __exit__(self, *exc):
+        self._flush()
+        ops._GRAD_READY, ops._GRAD_FLUSH = self._prev
+        return False
+
+    def _ready(self, layer, tensors, param_ids):
+        keep = [(t, i) for t, i in zip(tensors, param_ids) if t is not None]
+        if layer < self.min_layer or not keep:           # the bottom layer's gradients arrive last: nothing left to hide them under
+            return
+        tensors = [t for t, _ in keep]
+        flat = torch.cat([t.reshape(-1) for t in tensors])
+        work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self._pending.append((work, flat, tensors, [i for _, i in keep]))
+
+    def _flush(self):
+        for work, flat, tensors, ids in self._pending:
+            work.wait()
+            torch._foreach_copy_(tensors, [q.view_as(t) for q, t in zip(flat.split([t.numel() for t in tensors]), tensors)])
+            self.reduced.update(ids)
+        self._pending = []
 
 
 def topk_parents(S, candidate_ids, k=5, larger_is_better=True):

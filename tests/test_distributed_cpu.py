@@ -24,16 +24,27 @@ def _worker(rank, world, port, G, Q, ret):
     try:
         from taxoexpan_amd import scoring
         rs = np.random.RandomState(0)
-        U = torch.from_numpy(rs.standard_normal((G, 6)).astype(np.float32))
-        Qm = torch.from_numpy(rs.standard_normal((Q, 6)).astype(np.float32))
+        U = torch.from_numpy(np.round(rs.standard_normal((G, 6)) * 4).astype(np.float32))       # integer-valued: sums are exact
+        Qm = torch.from_numpy(np.round(rs.standard_normal((Q, 6)) * 4).astype(np.float32))
         lo, hi = scoring.shard_bounds(G, world, rank)
         U_loc = U[lo:hi]
 
         def local_fn(qb, out):
             out[:, :U_loc.shape[0]] = qb @ U_loc.t()
-        S = scoring.score_all_sharded(None, U_loc, G, Qm, block=3, local_score_fn=local_fn)
         full = Qm @ U.t()
-        ok1 = torch.allclose(S, full, atol=1e-6) and S.shape == (Q, G)
+        ok1 = True
+        for pipeline in (True, False):                   # the double-buffered asynchronous gather must be BIT-equal to the blocking one
+            S = scoring.score_all_sharded(None, U_loc, G, Qm, block=3, local_score_fn=local_fn, pipeline=pipeline)
+            ok1 = ok1 and torch.equal(S, full) and S.shape == (Q, G)
+        # consumer that indexes the [world, nq, c] gather buffer in place (no dense copy)
+        seen = []
+
+        def on_block(q0, blk):
+            c = blk.shards.shape[2]
+            cols = torch.cat([blk.columns(r) for r in range(world)], 1)
+            seen.append((q0, tuple(blk.shape), torch.equal(cols, full[q0:q0 + blk.shape[0]]), blk.shards.shape[0] == world and c == -(-G // world)))
+        scoring.score_all_sharded(None, U_loc, G, Qm, block=3, local_score_fn=local_fn, on_block=on_block)
+        ok1 = ok1 and [s[0] for s in seen] == list(range(0, Q, 3)) and all(s[2] and s[3] for s in seen)
         # gradient all-reduce: each rank holds different grads, sum must be identical everywhere
         ps = [torch.nn.Parameter(torch.zeros(3, 2)), torch.nn.Parameter(torch.zeros(5))]
         ps[0].grad = torch.full((3, 2), float(rank + 1))
@@ -130,3 +141,65 @@ def test_fused_rank_counts_all_reduce_world2():
     for p in procs:
         p.join(timeout=60)
     assert all(ok for _, ok in res)
+
+
+class _ToyStack(torch.autograd.Function):
+    """stands in for ops.GATStackFunction on the CPU: two 'layers' whose gradients are announced through the same hooks, top first"""
+
+    @staticmethod
+    def forward(ctx, x, w0, w1):
+        ctx.save_for_backward(x, w0, w1)
+        ctx.ids = [id(w0), id(w1)]
+        return (x @ w0) @ w1
+
+    @staticmethod
+    def backward(ctx, g):
+        from taxoexpan_amd import ops
+        x, w0, w1 = ctx.saved_tensors
+        h = x @ w0
+        d1 = h.t() @ g
+        if ops._GRAD_READY is not None:
+            ops._GRAD_READY(1, [d1], [ctx.ids[1]])
+        d0 = x.t() @ (g @ w1.t())
+        if ops._GRAD_READY is not None:
+            ops._GRAD_READY(0, [d0], [ctx.ids[0]])
+        if ops._GRAD_FLUSH is not None:
+            ops._GRAD_FLUSH()
+        return None, d0, d1
+
+
+def _overlap_worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from taxoexpan_amd import ops, scoring
+        torch.manual_seed(3)
+        w0, w1, wm = (torch.nn.Parameter(torch.randn(4, 5)), torch.nn.Parameter(torch.randn(5, 3)), torch.nn.Parameter(torch.randn(3)))
+        xs = [torch.randn(6, 4, generator=torch.Generator().manual_seed(10 + r)) for r in range(world)]
+        want = None
+        for r in range(world):                               # the sum over ranks of the per-rank gradients, computed locally
+            for p in (w0, w1, wm):
+                p.grad = None
+            ((_ToyStack.apply(xs[r], w0, w1) * wm).sum()).backward()
+            g = [p.grad.clone() for p in (w0, w1, wm)]
+            want = g if want is None else [a + b for a, b in zip(want, g)]
+        for p in (w0, w1, wm):
+            p.grad = None
+        with scoring.overlapped_gradient_allreduce() as ov:
+            ((_ToyStack.apply(xs[rank], w0, w1) * wm).sum()).backward()
+        hooks_restored = ops._GRAD_READY is None and ops._GRAD_FLUSH is None
+        reduced_top_only = ov.reduced == {id(w1)}            # layer 1 went out during backward; layer 0 and the rest afterwards
+        scoring.allreduce_gradients([w0, w1, wm], skip=ov)
+        ok = all(torch.allclose(p.grad, w, atol=1e-5) for p, w in zip((w0, w1, wm), want))
+        ret[rank] = bool(ok and hooks_restored and reduced_top_only)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_overlapped_gradient_allreduce_world2():
+    """the top layer's gradient bucket is all-reduced asynchronously from inside backward, everything else afterwards: every
+    parameter ends up with the sum over ranks exactly once"""
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_overlap_worker, args=(2, _free_port(), ret), nprocs=2, join=True)
+    assert all(ret.get(r) for r in range(2)), dict(ret)

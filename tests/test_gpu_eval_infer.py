@@ -123,3 +123,33 @@ def test_mag_full_encode_in_30000_chunks_equals_single_batch():
     torch.cuda.synchronize()
     d = (hg_c - hg_1).abs().max().item()
     assert d <= 1e-5 * hg_1.abs().max().item() + 1e-6, d
+
+
+def test_bench_two_ranks_sharded_inference_on_one_gpu():
+    """bench.py's N > 1 path end to end on a single-GPU box: two ranks (both on cuda:0) over gloo -- data-parallel training step
+    with the overlapped gradient all-reduce, then extra_metrics_sharded: candidate-sharded MAG-Full inference with the pipelined
+    all-gather of score blocks and the all-reduce-of-counts ranking.  (RCCL itself needs one GPU per rank: world size 1 is covered
+    in test_gpu_parity.py, the 8-GPU run is the driver's.)"""
+    import json
+    import socket
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, TXE_BENCH_BACKEND="gloo", TXE_BENCH_SHARDED_QUERIES="2048", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", str(port), os.path.join(repo, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"],
+                         cwd=repo, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["parallelism"] == "dp2" and d["value"] > 0
+    ex = d["extra"]
+    assert "error" not in ex, ex
+    assert ex["infer_queries"] == 2048 and ex["candidates_per_rank"] * 2 >= ex["infer_candidates"]
+    for k in ("candidates_scored_per_s_local", "candidates_scored_per_s_allgather", "candidates_scored_per_s_fused_allreduce"):
+        assert ex[k] > 0, k

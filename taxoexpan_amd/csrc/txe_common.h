@@ -31,15 +31,35 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblocks) {
     return base + idx;
 }
 
+// Wavefront reductions on the DPP cross-lane network (VALU operands, a few cycles each) instead of __shfl_xor, which hipcc lowers to
+// ds_bpermute_b32 -- six dependent trips through the LDS pipeline (~100+ cycles each) per reduction, and the sweeps do one per edge.
+// Within a row of 16 lanes: two quad permutes, row_half_mirror, row_mirror leave the row total in every lane; the four row totals
+// are then combined through v_readlane.  Every lane returns the total.  All 64 lanes must be active.
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false));
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    v += dpp_f<0xB1>(v);        // quad_perm [1,0,3,2]
+    v += dpp_f<0x4E>(v);        // quad_perm [2,3,0,1]
+    v += dpp_f<0x141>(v);       // row_half_mirror
+    v += dpp_f<0x140>(v);       // row_mirror
+    const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
+    const float r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
+    const float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32));
+    const float r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+    return (r0 + r1) + (r2 + r3);
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
+    v = fmaxf(v, dpp_f<0xB1>(v));
+    v = fmaxf(v, dpp_f<0x4E>(v));
+    v = fmaxf(v, dpp_f<0x141>(v));
+    v = fmaxf(v, dpp_f<0x140>(v));
+    const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
+    const float r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
+    const float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32));
+    const float r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+    return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
 }
 
 // Counter-based dropout: keep(seed, idx) is a pure function, so forward, backward and the host-side

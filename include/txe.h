@@ -224,6 +224,8 @@ int txe_gat_collapse_bwd(const int* rowptr_in, const int* col_src, const int* ro
  * source-side sweep runs, and never stored.  Extra inputs: that layer's projection output Yp [N][ld_yp] = [ft | a1 | a2] (Hp heads x
  * Dp, Hp*Dp == Kh), its attention alpha_p [E][Hp] (destination-CSR order), slope / dropout / seed, the slope of the activation between
  * the layers (1 = none).  Output instead of d_X: d_Yp [N][ld_dyp] = [d_ft | d_a1 | d_a2 | n_pad zeros]; dz_p [E][Hp] scratch.
+ * phases: 15 = all of it; 1 | 2 | 4 | 8 = dZ GEMM | dW GEMM partials (independent of 1 and 4: a second stream may run it under the sweeps)
+ * | sweeps + first reduction stage | final reductions -- separate calls share the workspace.
  * txe_gat_fused_bwd_supported: 1 if the shape qualifies (Hp in {1,2,4}, Hp*Dp % 16 == 0, <= 128 columns behind the feature part). */
 int txe_gat_fused_bwd_supported(int Kh, int Pd, int Hp, int Dp);
 size_t txe_gat_collapse_bwd_fused_ws_bytes(int n_nodes, int n_edges, int G, int Kh, int Pd, int D, int vocab, int Hp);
@@ -235,8 +237,8 @@ int txe_gat_collapse_bwd_fused(const int* rowptr_in, const int* col_src, const i
                                const int* gid, const float* Z, const float* hg, long long ld_hg, const float* d_hg, long long ld_dhg,
                                float act_slope, const float* Yp, long long ld_yp, int Hp, int Dp, float attn_slope_p,
                                float attn_drop_p_p, unsigned long long seed_p, const float* alpha_p, float* d_Yp, long long ld_dyp,
-                               int n_pad, float* dz_p, float* dW, float* d_attn_l, float* d_attn_r, float* dP, float* d_pw, void* ws,
-                               size_t ws_bytes, void* stream);
+                               int n_pad, float* dz_p, float* dW, float* d_attn_l, float* d_attn_r, float* dP, float* d_pw, int phases,
+                               void* ws, size_t ws_bytes, void* stream);
 
 /* ---- output GCNLayer folded behind MeanReadout / WeightedMeanReadout: model_zoo.py:35-47,139-167,227-242.
  * hg[g] = (sum_{u in g} c_u Xd[u]) W + b with c_u = norm_u sum_{v: u->v} w_v norm_v / S_g (graph constants).  X / Wp / mask as for

@@ -1149,7 +1149,10 @@ __global__ __launch_bounds__(256) void cl_bwd_dx_kernel(int n_nodes, int ntile, 
 // What is left per edge -- softmax / leaky-relu backward of the previous layer's attention from the raw d alpha -- is
 // gat_attn_bwd_kernel (edge-level, a few microseconds).
 // ---------------------------------------------------------------------------------------------------------------------
-constexpr int FB_NODES = 16;        // source nodes per workgroup
+#ifndef TXE_FB_NODES
+#define TXE_FB_NODES 16
+#endif
+constexpr int FB_NODES = TXE_FB_NODES;        // source nodes per workgroup
 constexpr int FB_MAXE = 192;        // out-edges of a workgroup whose scalars are staged in LDS (beyond: read from global)
 #ifndef TXE_FB_EU
 #define TXE_FB_EU 4
@@ -1732,7 +1735,9 @@ size_t txe_gat_collapse_bwd_fused_ws_bytes(int n_nodes, int n_edges, int G, int 
 // that layer's projection output Yp [N][ld_yp] = [ft | a1 | a2] (Hp heads of Dp columns, Hp*Dp == Kh), its attention alpha_p [E][Hp]
 // (destination-CSR order), attention slope / dropout / seed.  Instead of d_X it returns that layer's d_Yp [N][ld_dyp] =
 // [d_ft | d_a1 | d_a2 | n_pad zero columns] directly; dz_p [E][Hp] is scratch.  act_slope: slope of the activation between the two
-// layers (1 = none).  dP / d_pw / dW / d_attn as txe_gat_collapse_bwd.
+// layers (1 = none).  dP / d_pw / dW / d_attn as txe_gat_collapse_bwd.  phases: 15 = everything; or, for a caller that overlaps the
+// independent weight-gradient GEMM with the sweeps on a second stream, separate calls with 1 (dZ GEMM), 2 (dW GEMM partials: needs
+// only d_hg and Z), 4 (sweeps + first reduction stage: needs 1), 8 (final reductions: needs 2 and 4) and the same workspace.
 int txe_gat_collapse_bwd_fused(const int* rowptr_in, const int* col_src, const int* rowptr_out, const int* col_dst, const int* pos_out,
                                const int* graph_off, int n_nodes, int n_edges, int G, const float* X, int Kh, int Pd, const int* pos,
                                int vocab, const float* Wp, const float* W, const float* attn_l, const float* attn_r, int D,
@@ -1741,8 +1746,8 @@ int txe_gat_collapse_bwd_fused(const int* rowptr_in, const int* col_src, const i
                                const int* gid, const float* Z, const float* hg, long long ld_hg, const float* d_hg, long long ld_dhg,
                                float act_slope, const float* Yp, long long ld_yp, int Hp, int Dp, float attn_slope_p,
                                float attn_drop_p_p, unsigned long long seed_p, const float* alpha_p, float* d_Yp, long long ld_dyp,
-                               int n_pad, float* dz_p, float* dW, float* d_attn_l, float* d_attn_r, float* dP, float* d_pw, void* ws,
-                               size_t ws_bytes, void* stream) {
+                               int n_pad, float* dz_p, float* dW, float* d_attn_l, float* d_attn_r, float* dP, float* d_pw, int phases,
+                               void* ws, size_t ws_bytes, void* stream) {
     if (n_nodes < 0 || n_edges < 0 || G < 0 || Kh < 1 || Pd < 0 || D < 1 || !rowptr_in || !rowptr_out || !graph_off || !X || !Wp || !W ||
         !attn_l || !attn_r || !a12 || !alpha || !coef || !wsum || !gid || !Z || !hg || !d_hg || !dW || !d_attn_l || !d_attn_r || !ws ||
         !Yp || !alpha_p || !d_Yp || !dz_p || n_pad < 0)
@@ -1763,7 +1768,7 @@ int txe_gat_collapse_bwd_fused(const int* rowptr_in, const int* col_src, const i
     const float* wa = Wp + (long long)D * Kp;
     const unsigned* dummy_mask = reinterpret_cast<const unsigned*>(X);
     int rc;
-    {   // dZ = d_hg W
+    if (phases & 1) {   // dZ = d_hg W
         VMat A = vmat_plain(d_hg, ld_dhg, G, D);
         VMat B = vmat_plain(Wp, Kp, D, Kp);
         Epi E = epi_plain(p.dZ, Kp, Kp);
@@ -1772,7 +1777,7 @@ int txe_gat_collapse_bwd_fused(const int* rowptr_in, const int* col_src, const i
         if (rc) return rc;
     }
     const long long split_stride = (long long)D * Kp;
-    {   // dW (main part, split-K partial slices) = d_hg^T Z
+    if (phases & 2) {   // dW (main part, split-K partial slices) = d_hg^T Z
         VMat A = vmat_plain(d_hg, ld_dhg, G, D);
         VMat B = vmat_plain(Z, Kp, G, Kp);
         Epi E = epi_plain(p.part, Kp, Kp);
@@ -1783,7 +1788,7 @@ int txe_gat_collapse_bwd_fused(const int* rowptr_in, const int* col_src, const i
     }
     const int S = G > 0 ? p.splits : 0;
     const int nblk = (G > 0 && n_nodes > 0) ? fw.nblocks : 0;
-    if (G > 0 && n_nodes > 0) {
+    if ((phases & 4) && G > 0 && n_nodes > 0) {
         const int nb = (n_nodes + 3) / 4;
         {
             const int nb_ds = (G + 3) / 4;
@@ -1826,6 +1831,7 @@ int txe_gat_collapse_bwd_fused(const int* rowptr_in, const int* col_src, const i
     }
     // ---- phase A: d_wa = sum of the per-workgroup partials; readout position-weight partial sums ----
     const int nseg = n_nodes > 0 ? p.seg_blocks : 0;
+    if (phases & 4) {
     TailA ta;
     memset(&ta, 0, sizeof(ta));
     ta.nb_s1a = 0;
@@ -1834,6 +1840,8 @@ int txe_gat_collapse_bwd_fused(const int* rowptr_in, const int* col_src, const i
     ta.r_kind = 2; ta.nb_r = (2 * Kp + 63) / 64; ta.r2 = Seg2Args{fw.dwa_part, nblk, 2 * Kp, p.dwa};
     hipLaunchKernelGGL(gat_bwd_reduce_a_kernel, dim3(ta.nb_s1b + ta.nb_r), dim3(256), 0, s, ta);
     TXE_CHECK_LAUNCH();
+    }
+    if (!(phases & 8)) return TXE_OK;
     // ---- phase B: dW = main + attn (x) d_wa, d_attn = <d_wa, W> (unfold);  dP (from the fused sweep's partials), d_pw ----
     TailB tb;
     memset(&tb, 0, sizeof(tb));

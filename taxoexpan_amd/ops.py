@@ -430,6 +430,17 @@ def _gat_layer_bwd(csr, st, pos, vocab, feat_p, attn_p, attn_slope, d_pre, ld_dp
 
 
 _NO_MULTI_PREPARE = os.environ.get("TXE_NO_MULTI_PREPARE", "0") == "1"   # A/B switch: one preparation launch per layer
+_NO_SIDE_STREAM = os.environ.get("TXE_NO_SIDE_STREAM", "0") == "1"      # A/B switch: everything on the caller's stream
+_side_streams = {}
+
+
+def _side_stream(device):
+    s = _side_streams.get(device.index)
+    if s is None:
+        s = _side_streams[device.index] = torch.cuda.Stream(device=device)
+    return s
+
+
 _NO_FUSED_BWD = os.environ.get("TXE_NO_FUSED_BWD", "0") == "1"       # A/B switch (tests compare both paths)
 
 
@@ -453,12 +464,26 @@ def _gat_collapse_bwd_fused(csr, st, sp, pos, rpos, pw, vocab, feat_p, attn_p, a
     v = max(vocab, pw.numel() if pw is not None else 0)
     wsb = call("txe_gat_collapse_bwd_fused_ws_bytes", N, E, G, st.Kh, st.Pd, st.D, 8, sp.H)
     ws = _ws(wsb, st.X)
-    call("txe_gat_collapse_bwd_fused", ptr(csr.rowptr_in), ptr(csr.col_src), ptr(csr.rowptr_out), ptr(csr.col_dst), ptr(csr.pos_out),
-         ptr(csr.graph_off), N, E, G, ptr(st.X), st.Kh, st.Pd, ptr(pos if pos is not None else rpos), v, ptr(st.Wp), ptr(st.W),
-         ptr(st.al), ptr(st.ar), st.D, feat_p, ptr(st.mask), attn_slope, attn_p, st.seed + 1, ptr(pw), ptr(a12), ptr(alpha), ptr(coef),
-         ptr(wsum), ptr(gid), ptr(Z), ptr(hg), st.D, ptr(d_hg), ld, act_slope if act_slope else 1.0, ptr(sp.Y), sp.Fp, sp.H, sp.D,
-         attn_slope, attn_p, sp.seed + 1, ptr(sp.alpha), ptr(d_Yp), sp.Fp, sp.Fp - Fe, ptr(dz), ptr(dW), ptr(dal), ptr(dar), ptr(dP),
-         ptr(d_pw), ptr(ws), wsb, _lib.stream_ptr())
+    def run(phases):
+        call("txe_gat_collapse_bwd_fused", ptr(csr.rowptr_in), ptr(csr.col_src), ptr(csr.rowptr_out), ptr(csr.col_dst), ptr(csr.pos_out),
+             ptr(csr.graph_off), N, E, G, ptr(st.X), st.Kh, st.Pd, ptr(pos if pos is not None else rpos), v, ptr(st.Wp), ptr(st.W),
+             ptr(st.al), ptr(st.ar), st.D, feat_p, ptr(st.mask), attn_slope, attn_p, st.seed + 1, ptr(pw), ptr(a12), ptr(alpha), ptr(coef),
+             ptr(wsum), ptr(gid), ptr(Z), ptr(hg), st.D, ptr(d_hg), ld, act_slope if act_slope else 1.0, ptr(sp.Y), sp.Fp, sp.H, sp.D,
+             attn_slope, attn_p, sp.seed + 1, ptr(sp.alpha), ptr(d_Yp), sp.Fp, sp.Fp - Fe, ptr(dz), ptr(dW), ptr(dal), ptr(dar), ptr(dP),
+             ptr(d_pw), phases, ptr(ws), wsb, _lib.stream_ptr())
+    if _NO_SIDE_STREAM:
+        run(15)
+    else:
+        # the folded layer's weight-gradient GEMM (MFMA-bound, needs only d_hg and Z) runs on a second stream under the HBM-bound
+        # sweeps: complementary resources, and nothing downstream waits for it before the final reduction
+        main, side = torch.cuda.current_stream(), _side_stream(st.X.device)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            run(2)
+        run(1)
+        run(4)
+        main.wait_stream(side)
+        run(8)
     return d_Yp, dW, dal, dar, dP, d_pw
 
 

@@ -82,7 +82,7 @@ int txe_gat_dense_fwd(const float* X, int n_nodes, int Kh, int Pd, const float* 
 int txe_gat_dense_bwd(const float* X, int n_nodes, int Kh, int Pd, const int* pos, int vocab, const float* Wp, const float* W,
                       const float* attn_l, const float* attn_r, int H, int D, float feat_drop_p, const unsigned* mask, const float* d_Y,
                       int need_dh, int act_on, float act_slope, float* d_X, float* dW, float* d_attn_l, float* d_attn_r, float* dP,
-                      void* ws, size_t ws_bytes, void* stream);
+                      int phases, void* ws, size_t ws_bytes, void* stream);
 int txe_zero_cols(float* x, long long ld, int n_rows, int c0, int c1, void* stream);
 
 /* ---- GATLayer message/reduce: model_zoo.py:90-95,106-114 (edge_attention, edge_softmax, attn_drop, update_all) -----
@@ -157,6 +157,9 @@ int txe_bilinear_pair_bwd(const float* e1, long long ld_e1, const float* e2, lon
  * dW = (dsl (.) E1)^T E2.  V is kept for backward. */
 int txe_bilinear_query_fwd(const float* e1, long long ld_e1, const float* e2, long long ld_e2, int G, int l, int r, const float* W,
                            int apply_exp, float* V, float* s, void* stream);
+/* its two halves, for a caller that launches the projection early (it needs the queries and W only) on another stream */
+int txe_bilinear_query_project(const float* e2, long long ld_e2, int G, int l, int r, const float* W, float* V, void* stream);
+int txe_bilinear_query_dot(const float* e1, long long ld_e1, const float* V, int G, int l, int apply_exp, float* s, void* stream);
 size_t txe_bilinear_query_bwd_ws_bytes(int G, int l, int r);
 int txe_bilinear_query_bwd(const float* e1, long long ld_e1, const float* e2, long long ld_e2, int G, int l, int r, int apply_exp,
                            const float* V, const float* s, const float* ds, float* d_e1, long long ld_de1, float* dW, void* ws,

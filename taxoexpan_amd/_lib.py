@@ -21,7 +21,7 @@ SIGNATURES = {
     "txe_gather_add_rows": (I, [P, L, P, P, L, P, L, I, P, L, P]),
     "txe_gat_dense_ws_bytes": (SZ, [I, I, I, I, I, I]),
     "txe_gat_dense_fwd": (I, [P, I, I, I, P, I, I, F, P, P, P, SZ, P]),
-    "txe_gat_dense_bwd": (I, [P, I, I, I, P, I, P, P, P, P, I, I, F, P, P, I, I, F, P, P, P, P, P, P, SZ, P]),
+    "txe_gat_dense_bwd": (I, [P, I, I, I, P, I, P, P, P, P, I, I, F, P, P, I, I, F, P, P, P, P, P, I, P, SZ, P]),
     "txe_zero_cols": (I, [P, L, I, I, I, P]),
     "txe_gat_aggregate_fwd": (I, [P, P, I, P, L, P, P, I, I, I, F, F, U64, I, F, P, L, P, P, I, P, F, P, P]),
     "txe_gat_aggregate_bwd": (I, [P, P, P, P, P, I, P, L, P, P, I, I, I, F, F, U64, P, P, L, P, L, P, P, I, P, I, P]),
@@ -47,6 +47,8 @@ SIGNATURES = {
     "txe_bilinear_project": (I, [P, L, I, I, P, I, P, L, P]),
     "txe_bilinear_pair_fwd": (I, [P, L, P, L, I, I, I, P, I, P, P, P]),
     "txe_bilinear_query_fwd": (I, [P, L, P, L, I, I, I, P, I, P, P, P]),
+    "txe_bilinear_query_project": (I, [P, L, I, I, I, P, P, P]),
+    "txe_bilinear_query_dot": (I, [P, L, P, I, I, I, P, P]),
     "txe_bilinear_query_bwd_ws_bytes": (SZ, [I, I, I]),
     "txe_bilinear_query_bwd": (I, [P, L, P, L, I, I, I, I, P, P, P, P, L, P, P, SZ, P]),
     "txe_bilinear_pair_bwd_ws_bytes": (SZ, [I, I, I]),

@@ -206,18 +206,29 @@ int txe_bilinear_pair_bwd(const float* e1, long long ld_e1, const float* e2, lon
 //   forward   V = E2 W^T [G][l] (one GEMM);  s_i = <e1_i, V_i>
 //   backward  d_e1_i = dsl_i V_i (elementwise -- the candidate-side form needs a second G-row GEMM here);  dW = (dsl (.) E1)^T E2
 // V [G][l] is kept for backward.
-int txe_bilinear_query_fwd(const float* e1, long long ld_e1, const float* e2, long long ld_e2, int G, int l, int r, const float* W,
-                           int apply_exp, float* V, float* s, void* stream) {
-    if (G < 0 || l < 1 || r < 1 || !e1 || !e2 || !W || !V || !s) return TXE_ERR_ARG;
+int txe_bilinear_query_project(const float* e2, long long ld_e2, int G, int l, int r, const float* W, float* V, void* stream) {
+    if (G < 0 || l < 1 || r < 1 || !e2 || !W || !V) return TXE_ERR_ARG;
     if (G == 0) return TXE_OK;
     VMat A = vmat_plain(e2, ld_e2, G, r);
     VMat B = vmat_plain(W, r, l, r);
     Epi E = epi_plain(V, l, l);
-    int rc = gemm_nt(A, B, E, G, l, r, 1, (hipStream_t)stream);
-    if (rc) return rc;
-    hipLaunchKernelGGL(rowdot2_kernel, dim3((G + 3) / 4), dim3(256), 0, (hipStream_t)stream, e1, ld_e1, (const float*)V, G, l, apply_exp, s);
+    return gemm_nt(A, B, E, G, l, r, 1, (hipStream_t)stream);
+}
+
+int txe_bilinear_query_dot(const float* e1, long long ld_e1, const float* V, int G, int l, int apply_exp, float* s, void* stream) {
+    if (G < 0 || l < 1 || !e1 || !V || !s) return TXE_ERR_ARG;
+    if (G == 0) return TXE_OK;
+    hipLaunchKernelGGL(rowdot2_kernel, dim3((G + 3) / 4), dim3(256), 0, (hipStream_t)stream, e1, ld_e1, V, G, l, apply_exp, s);
     TXE_CHECK_LAUNCH();
     return TXE_OK;
+}
+
+int txe_bilinear_query_fwd(const float* e1, long long ld_e1, const float* e2, long long ld_e2, int G, int l, int r, const float* W,
+                           int apply_exp, float* V, float* s, void* stream) {
+    if (!e1 || !s) return TXE_ERR_ARG;
+    int rc = txe_bilinear_query_project(e2, ld_e2, G, l, r, W, V, stream);
+    if (rc) return rc;
+    return txe_bilinear_query_dot(e1, ld_e1, V, G, l, apply_exp, s, stream);
 }
 
 size_t txe_bilinear_query_bwd_ws_bytes(int G, int l, int r) {

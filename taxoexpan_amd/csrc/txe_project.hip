@@ -579,10 +579,12 @@ int txe_gat_dense_fwd(const float* X, int n_nodes, int Kh, int Pd, const float* 
 //                columns < Kh are multiplied by leaky'(X) when act_slope_on (X[:, :Kh] is then the activated output of the
 //                previous layer), all by the dropout factor.
 //   dW [F][Kt], d_attn_l / d_attn_r [F], dP [vocab][Pd].
+// phases: 7 = everything; 1 = the d_X GEMM, 2 = the dW GEMM (independent of each other: a caller may put the skinny, latency-bound
+// d_X product on a second stream under the dW product), 4 = the reductions that need both -- separate calls share the workspace.
 int txe_gat_dense_bwd(const float* X, int n_nodes, int Kh, int Pd, const int* pos, int vocab, const float* Wp, const float* W,
                       const float* attn_l, const float* attn_r, int H, int D, float feat_drop_p, const unsigned* mask, const float* d_Y,
                       int need_dh, int act_on, float act_slope, float* d_X, float* dW, float* d_attn_l, float* d_attn_r, float* dP,
-                      void* ws, size_t ws_bytes, void* stream) {
+                      int phases, void* ws, size_t ws_bytes, void* stream) {
     if (n_nodes < 0 || Kh < 1 || Pd < 0 || H < 1 || D < 1 || !X || !Wp || !W || !attn_l || !attn_r || !d_Y || !dW || !d_attn_l || !d_attn_r || !ws)
         return TXE_ERR_ARG;
     if ((need_dh || Pd > 0) && !d_X) return TXE_ERR_ARG;
@@ -595,7 +597,7 @@ int txe_gat_dense_bwd(const float* X, int n_nodes, int Kh, int Pd, const int* po
     int rc;
     // ---- d_X[:, c0:Kt] = d_Y * Wp[:, c0:Kt] ----
     const int c0 = need_dh ? 0 : (Kh / 4) * 4;      // 16-byte aligned start of the position columns
-    if (Kt - c0 > 0 && n_nodes > 0 && (need_dh || Pd > 0)) {
+    if ((phases & 1) && Kt - c0 > 0 && n_nodes > 0 && (need_dh || Pd > 0)) {
         VMat A = vmat_plain(d_Y, Fp, n_nodes, Fp);
         VMat B = vmat_plain(Wp + c0, Kp, Fp, Kp - c0);
         Epi E = epi_plain(d_X + c0, Kp, Kh > c0 ? Kh - c0 : 0);
@@ -613,8 +615,11 @@ int txe_gat_dense_bwd(const float* X, int n_nodes, int Kh, int Pd, const int* po
     Epi E = epi_plain(p.part, Kp, Kp);
     E.split_stride = (long long)Fp * Kp;
     E.alg_flops = 2.0 * Fe * (double)Kt * n_nodes;
-    rc = gemm_tn(A, B, E, Fp, Kp, n_nodes, p.splits, s);
-    if (rc) return rc;
+    if (phases & 2) {
+        rc = gemm_tn(A, B, E, Fp, Kp, n_nodes, p.splits, s);
+        if (rc) return rc;
+    }
+    if (!(phases & 4)) return TXE_OK;
     const int S = n_nodes > 0 ? p.splits : 0;
     // ---- phase A: dP partials (dP[c][j] = sum_{pos[m]==c} d_X[m][Kh+j]) and d_wa = the extension rows of dWp ----
     const int nseg = (Pd > 0 && n_nodes > 0) ? p.seg_blocks : 0;

@@ -53,6 +53,8 @@ class TaxoExpan(torch.nn.Module):
         """model/model.py:70-87: positions are read BEFORE propagation (PGAT / PGCN pop them), node states are left in
         g.ndata['h'], one score per (egonet, query) row comes back"""
         positions = g.ndata['pos'].to(h.device)
+        if hasattr(self.match, "prefetch"):         # the matcher's query-side projection runs under the encoder (second stream)
+            self.match.prefetch(qf)
         g.ndata['h'] = self.graph_propagate(g, h)
         return self.match(self.readout(g, positions), qf)
 

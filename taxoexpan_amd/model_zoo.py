@@ -432,7 +432,13 @@ class _Bilinear(nn.Module):
             # the eval loop's `nf.expand(n_position, -1)` (test_fast.py:122-123): one query against all candidates
             U = ops.bilinear_project(e1, self.W.weight)
             return ops.score_block(e2[:1], U, self.apply_exp).reshape(-1, 1)
-        return ops.BilinearPairFunction.apply(e1, e2, self.W.weight, self.apply_exp)
+        pre, self._pre = getattr(self, "_pre", None), None
+        return ops.BilinearPairFunction.apply(e1, e2, self.W.weight, self.apply_exp, pre)
+
+    def prefetch(self, e2):
+        """start the query-side half of the match (V = e2 W^T: needs neither the graph nor the encoder) on the second stream; the next
+        forward(e1, e2) with this very e2 picks it up.  Called by TaxoExpan.forward before graph_propagate."""
+        self._pre = ops.bilinear_query_prefetch(e2, self.W.weight) if torch.is_grad_enabled() else None
 
     def score_all(self, hg, queries, block=1024, out=None):
         """The whole scoring loop at once: S[q][g] = match(hg[g], queries[q]) (test_fast.py:116-123)."""

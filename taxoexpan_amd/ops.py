@@ -418,9 +418,22 @@ def _gat_dense_bwd(st, pos, vocab, feat_p, d_Y, need_dh, act_on, act_slope):
     d_X = _empty((N, st.Kp), st.X) if (need_dh or st.Pd > 0) else None
     wsb = call("txe_gat_dense_ws_bytes", N, st.Kh, st.Pd, st.H, st.D, vocab)
     ws = _ws(wsb, st.X)
-    call("txe_gat_dense_bwd", ptr(st.X), N, st.Kh, st.Pd, ptr(pos), vocab, ptr(st.Wp), ptr(st.W), ptr(st.al), ptr(st.ar), st.H, st.D, feat_p,
-         ptr(st.mask), ptr(d_Y), int(need_dh), int(act_on), act_slope if act_slope else 1.0, ptr(d_X), ptr(dW), ptr(dal), ptr(dar),
-         ptr(dP), ptr(ws), wsb, _lib.stream_ptr())
+    def run(phases):
+        call("txe_gat_dense_bwd", ptr(st.X), N, st.Kh, st.Pd, ptr(pos), vocab, ptr(st.Wp), ptr(st.W), ptr(st.al), ptr(st.ar), st.H, st.D, feat_p,
+             ptr(st.mask), ptr(d_Y), int(need_dh), int(act_on), act_slope if act_slope else 1.0, ptr(d_X), ptr(dW), ptr(dal), ptr(dar),
+             ptr(dP), phases, ptr(ws), wsb, _lib.stream_ptr())
+    if _NO_SIDE_STREAM or need_dh or d_X is None or N == 0:
+        run(7)
+    else:
+        # first layer (only the position columns of d_X are needed): that skinny, latency-bound product leaves most of the matrix pipe
+        # idle -- it runs on the second stream under the weight-gradient GEMM instead of in front of it
+        main, side = torch.cuda.current_stream(), _side_stream(st.X.device)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            run(1)
+        run(2)
+        main.wait_stream(side)
+        run(4)
     return d_X, dW, dal, dar, dP
 
 
@@ -940,15 +953,35 @@ class LinearFunction(torch.autograd.Function):
 # ================================================================================================================
 # Bilinear match (BIM / LBM) -- pairwise form of training, model.py:86
 # ================================================================================================================
+def bilinear_query_prefetch(e2, W):
+    """V = e2 W^T of the query-side match (BilinearPairFunction), launched on the second stream: it depends on the queries and the
+    matcher's weight only, so it can run under the encoder (TaxoExpan.forward calls this before graph_propagate).  Returns a token for
+    BilinearPairFunction.apply(..., pre=token); None when there is nothing to gain (gradient wanted for e2, CPU tensors, no side stream)."""
+    if _NO_SIDE_STREAM or not (torch.is_tensor(e2) and e2.is_cuda and W.is_cuda) or e2.requires_grad or e2.dim() != 2 or e2.shape[0] == 0:
+        return None
+    e2c, ld2 = _rows(e2)
+    Wf = _f32(W).reshape(W.shape[-2], W.shape[-1])
+    G, r = e2c.shape
+    l = Wf.shape[0]
+    main, side = torch.cuda.current_stream(e2.device), _side_stream(e2.device)
+    V = _empty((G, l), e2c)
+    side.wait_stream(main)
+    with torch.cuda.device(e2.device), torch.cuda.stream(side):
+        call("txe_bilinear_query_project", ptr(e2c), ld2, G, l, r, ptr(Wf), ptr(V), _lib.stream_ptr())
+    return dict(V=V, e2=e2, e2_version=e2._version, W=W, W_version=W._version, stream=side, e2c=e2c)
+
+
 class BilinearPairFunction(torch.autograd.Function):
     """s_i = e1_i^T W e2_i (exp optionally).  When e2 needs no gradient (queries: always so in training) the query-side form runs:
     V = e2 W^T in forward makes backward's d_e1 = dsl * V elementwise (txe_bilinear_query_*); otherwise the candidate-side form
-    U = e1 W with gradients to both inputs (txe_bilinear_pair_*)."""
+    U = e1 W with gradients to both inputs (txe_bilinear_pair_*).  pre: a bilinear_query_prefetch token whose V is used if it still
+    matches e2 / W."""
 
     @staticmethod
-    def forward(ctx, e1, e2, W, apply_exp):
+    def forward(ctx, e1, e2, W, apply_exp, pre=None):
         _need_cuda(e1, e2, W)
         e1, ld1 = _rows(e1)
+        e2_in = e2
         e2, ld2 = _rows(e2)
         Wf = _f32(W).reshape(W.shape[-2], W.shape[-1])
         G, l = e1.shape
@@ -957,8 +990,15 @@ class BilinearPairFunction(torch.autograd.Function):
         query_side = not ctx.needs_input_grad[1]
         with torch.cuda.device(e1.device):
             if query_side:
-                U = _empty((max(G, 1), l), e1)          # V = e2 W^T
-                call("txe_bilinear_query_fwd", ptr(e1), ld1, ptr(e2), ld2, G, l, r, ptr(Wf), int(apply_exp), ptr(U), ptr(s), _lib.stream_ptr())
+                ready = (pre is not None and pre["e2"] is e2_in and pre["e2_version"] == e2_in._version and pre["W"] is W
+                         and pre["W_version"] == W._version and tuple(pre["V"].shape) == (G, l))
+                if ready:
+                    U = pre["V"]
+                    torch.cuda.current_stream().wait_stream(pre["stream"])
+                    call("txe_bilinear_query_dot", ptr(e1), ld1, ptr(U), G, l, int(apply_exp), ptr(s), _lib.stream_ptr())
+                else:
+                    U = _empty((max(G, 1), l), e1)          # V = e2 W^T
+                    call("txe_bilinear_query_fwd", ptr(e1), ld1, ptr(e2), ld2, G, l, r, ptr(Wf), int(apply_exp), ptr(U), ptr(s), _lib.stream_ptr())
             else:
                 U = _empty((max(G, 1), r), e1)
                 call("txe_bilinear_pair_fwd", ptr(e1), ld1, ptr(e2), ld2, G, l, r, ptr(Wf), int(apply_exp), ptr(U), ptr(s),
@@ -980,13 +1020,13 @@ class BilinearPairFunction(torch.autograd.Function):
                 ws = _ws(wsb, e1)
                 call("txe_bilinear_query_bwd", ptr(e1), ld1, ptr(e2), ld2, G, l, r, apply_exp, ptr(U), ptr(s), ptr(ds), ptr(d_e1), l, ptr(dW),
                      ptr(ws), wsb, _lib.stream_ptr())
-                return d_e1, None, dW.reshape(wshape), None
+                return d_e1, None, dW.reshape(wshape), None, None
             d_e2 = _empty((G, r), e1)
             wsb = call("txe_bilinear_pair_bwd_ws_bytes", G, l, r)
             ws = _ws(wsb, e1)
             call("txe_bilinear_pair_bwd", ptr(e1), ld1, ptr(e2), ld2, G, l, r, ptr(Wf), apply_exp, ptr(U), ptr(s), ptr(ds), ptr(d_e1),
                  l, ptr(d_e2), r, ptr(dW), ptr(ws), wsb, _lib.stream_ptr())
-        return d_e1, d_e2, dW.reshape(wshape), None
+        return d_e1, d_e2, dW.reshape(wshape), None, None
 
 
 # ================================================================================================================

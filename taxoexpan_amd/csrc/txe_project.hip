@@ -834,45 +834,6 @@ __global__ __launch_bounds__(256) void cl_logits_kernel(const float* __restrict_
     }
 }
 
-// one wave per destination: alpha[p] = softmax over the in-edges of v of leaky(a1[u] + a2[v])      (model_zoo.py:106-114)
-__device__ __forceinline__ void cl_alpha_job(const int bid, const int* __restrict__ rowptr, const int* __restrict__ col, int n_nodes,
-                                             const float* __restrict__ a12, float slope, float* __restrict__ alpha) {
-    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
-    const int v = bid * 4 + w;
-    if (v >= n_nodes) return;
-    const int beg = rowptr[v], end = rowptr[v + 1];
-    const float a2v = a12[2 * (long long)v + 1];
-    float m = -INFINITY;
-    for (int p = beg + l; p < end; p += 64) m = fmaxf(m, leaky(a12[2 * (long long)col[p]] + a2v, slope));
-    m = wave_max(m);
-    float s = 0.f;
-    for (int p = beg + l; p < end; p += 64) s += __expf(leaky(a12[2 * (long long)col[p]] + a2v, slope) - m);
-    s = wave_sum(s);
-    const float inv = 1.f / s;
-    for (int p = beg + l; p < end; p += 64) alpha[p] = __expf(leaky(a12[2 * (long long)col[p]] + a2v, slope) - m) * inv;
-}
-
-// one wave per source: c~_u = sum_{j in out(u)} w_{dst(j)} * alpha'[pos_out[j]]     (lanes over the out-edges)
-__global__ __launch_bounds__(256) void cl_coef_kernel(const int* __restrict__ rowptr_out, const int* __restrict__ col_dst,
-                                                      const int* __restrict__ pos_out, int n_nodes, const float* __restrict__ alpha,
-                                                      float drop_p, float drop_scale, unsigned long long seed, const int* __restrict__ pos,
-                                                      const float* __restrict__ pw, float* __restrict__ coef) {
-    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
-    const int u = blockIdx.x * 4 + w;
-    if (u >= n_nodes) return;
-    const int beg = rowptr_out[u], end = rowptr_out[u + 1];
-    float c = 0.f;
-    for (int j = beg + l; j < end; j += 64) {
-        const int p = pos_out[j], v = col_dst[j];
-        float f = 1.f;
-        if (drop_p > 0.f) f = drop_factor(seed, (unsigned long long)p, drop_p, drop_scale);
-        const float wv = pw ? cl_softplus(pw[pos[v]]) : 1.f;
-        c = fmaf(wv * f, alpha[p], c);
-    }
-    c = wave_sum(c);
-    if (l == 0) coef[u] = c;
-}
-
 // per graph: S_g = sum_v w_v -> wsum[g];  gid[v] = g for its nodes
 __device__ __forceinline__ void cl_wsum_job(const int bid, const int* __restrict__ goff, int G, const int* __restrict__ pos,
                                             const float* __restrict__ pw, float* __restrict__ wsum, int* __restrict__ gid) {
@@ -892,16 +853,6 @@ __global__ __launch_bounds__(256) void cl_wsum_kernel(const int* __restrict__ go
                                                       const float* __restrict__ pw, float* __restrict__ wsum, int* __restrict__ gid) {
     cl_wsum_job(blockIdx.x, goff, G, pos, pw, wsum, gid);
 }
-// the attention softmax (workgroups [0, nb_alpha)) and the graph weight sums (the rest): independent, one launch
-__global__ __launch_bounds__(256) void cl_alpha_wsum_kernel(int nb_alpha, const int* __restrict__ rowptr, const int* __restrict__ col,
-                                                            int n_nodes, const float* __restrict__ a12, float slope,
-                                                            float* __restrict__ alpha, const int* __restrict__ goff, int G,
-                                                            const int* __restrict__ pos, const float* __restrict__ pw,
-                                                            float* __restrict__ wsum, int* __restrict__ gid) {
-    if ((int)blockIdx.x < nb_alpha) cl_alpha_job(blockIdx.x, rowptr, col, n_nodes, a12, slope, alpha);
-    else cl_wsum_job(blockIdx.x - nb_alpha, goff, G, pos, pw, wsum, gid);
-}
-
 // sweep 2 -- one wave per (graph, 256-column tile):  Z[g][tile] = (scale / S_g) sum_{u in g} c~_u (X[u] * keep)[tile]
 template <bool MASK>
 __global__ __launch_bounds__(256) void cl_zsum_kernel(const int* __restrict__ goff, int G, int ntile, const float* __restrict__ X, int Kp,
@@ -1015,61 +966,239 @@ __global__ __launch_bounds__(256) void cl_bwd_dot_kernel(int n_nodes, const int*
     }
 }
 
-// one wave per destination v: readout-weight and softmax backward of the edge coefficients
-//   d_w_v = dS_g(v) + sum_p alpha_p f_p dc~_{u_p};  dalpha_p = w_v f_p dc~_{u_p};  dz_p = alpha_p (dalpha_p - sum alpha dalpha) leaky'(z_p)
-//   outputs: dz[p], da2[v] = sum_p dz_p, dwv[v] = d_w_v * sigmoid(pw[pos_v])  (0 without position weights)
-__global__ __launch_bounds__(256) void cl_bwd_edge_kernel(const int* __restrict__ rowptr, const int* __restrict__ col, int n_nodes,
-                                                          const float* __restrict__ a12, float slope, const float* __restrict__ alpha,
-                                                          float drop_p, float drop_scale, unsigned long long seed,
-                                                          const int* __restrict__ pos, const float* __restrict__ pw,
-                                                          const float* __restrict__ dc, const float* __restrict__ dS,
-                                                          const int* __restrict__ gid, float* __restrict__ dz, float* __restrict__ da2,
-                                                          float* __restrict__ dwv) {
+// ---------------------------------------------------------------------------------------------------------------------
+// The folded layer's edge-level work as ONE launch each way.  Everything here is tiny (a few bytes per edge) and stays inside a graph,
+// so a workgroup that owns CG_GRAPHS whole graphs can run the destination-side and the source-side halves back to back behind a
+// workgroup barrier (they were two ~10 us launches each).  Degrees up to CG_LIGHT are walked by one thread per node with every load
+// unrolled and clamped (no branch between a load and its use); heavier nodes (an egonet's anchor feeds up to 50 siblings; hubs of
+// generic graphs) are collected and handled by a whole wave each.
+//   forward : alpha[p] = softmax_in(leaky(a1[u] + a2[v])), gid, w_v;  S_g = sum w_v;  c~_u = sum_out w_v f alpha
+//   backward: dz[p], da2[v], dwv[v] (destination side, cl_bwd_edge_kernel's math);  da1[u] = sum_out dz (source side)
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int CG_GRAPHS = 8;
+constexpr int CG_LIGHT = 8;
+constexpr int CG_MAXN = 512;        // nodes of a workgroup whose readout weights are staged in LDS (beyond: recomputed)
+
+__device__ __forceinline__ int cg_graph_of(const int* s_goff, int ng, int v) {
+    int g = 0;
+#pragma unroll
+    for (int q = 1; q < CG_GRAPHS; ++q) g += (q < ng && v >= s_goff[q]) ? 1 : 0;
+    return g;
+}
+
+__global__ __launch_bounds__(256) void cl_attn_coef_kernel(const int* __restrict__ rowptr_in, const int* __restrict__ col_src,
+                                                           const int* __restrict__ rowptr_out, const int* __restrict__ col_dst,
+                                                           const int* __restrict__ pos_out, const int* __restrict__ goff, const int G,
+                                                           const float* __restrict__ a12, const float slope, const float drop_p,
+                                                           const float drop_scale, const unsigned long long seed,
+                                                           const int* __restrict__ pos, const float* __restrict__ pw,
+                                                           float* __restrict__ alpha, float* __restrict__ coef, float* __restrict__ wsum,
+                                                           int* __restrict__ gid) {
+    __shared__ int s_goff[CG_GRAPHS + 1], s_heavy[2][256], s_nh[2];
+    __shared__ float s_wv[CG_MAXN];
     const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
-    const int v = blockIdx.x * 4 + w;
-    if (v >= n_nodes) return;
-    const int beg = rowptr[v], end = rowptr[v + 1];
-    const float pwv = pw ? pw[pos[v]] : 0.f;
-    const float wv = pw ? cl_softplus(pwv) : 1.f;
-    const float a2v = a12[2 * (long long)v + 1];
-    float T = 0.f, dw = 0.f;
-    for (int p = beg + l; p < end; p += 64) {
-        float f = 1.f;
-        if (drop_p > 0.f) f = drop_factor(seed, (unsigned long long)p, drop_p, drop_scale);
-        const float g = alpha[p] * f * dc[col[p]];
-        dw += g;                       // alpha f dc
-        T = fmaf(alpha[p], wv * f * dc[col[p]], T);
+    const int g0 = blockIdx.x * CG_GRAPHS, g1 = min(G, g0 + CG_GRAPHS), ng = g1 - g0;
+    if (threadIdx.x <= ng) s_goff[threadIdx.x] = goff[g0 + threadIdx.x];
+    if (threadIdx.x < 2) s_nh[threadIdx.x] = 0;
+    __syncthreads();
+    const int n0 = s_goff[0], nn = s_goff[ng] - n0;
+    // ---- destination side: alpha, graph ids, readout weights ----
+    for (int t = threadIdx.x; t < nn; t += 256) {
+        const int v = n0 + t;
+        gid[v] = g0 + cg_graph_of(s_goff, ng, v);
+        if (t < CG_MAXN) s_wv[t] = pw ? cl_softplus(pw[pos[v]]) : 1.f;
+        const int beg = rowptr_in[v], end = rowptr_in[v + 1];
+        if (end - beg > CG_LIGHT) { const int k = atomicAdd(&s_nh[0], 1); if (k < 256) s_heavy[0][k] = v; continue; }
+        const float a2v = a12[2 * (long long)v + 1];
+        float z[CG_LIGHT];
+        float m = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < CG_LIGHT; ++i) {
+            const int p = min(beg + i, max(end - 1, beg));
+            const float zz = leaky(a12[2 * (long long)col_src[p]] + a2v, slope);
+            z[i] = (beg + i < end) ? zz : -INFINITY;
+            m = fmaxf(m, z[i]);
+        }
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < CG_LIGHT; ++i) { z[i] = (beg + i < end) ? __expf(z[i] - m) : 0.f; sum += z[i]; }
+        const float inv = 1.f / sum;
+#pragma unroll
+        for (int i = 0; i < CG_LIGHT; ++i)
+            if (beg + i < end) alpha[beg + i] = z[i] * inv;
     }
-    T = wave_sum(T);
-    dw = wave_sum(dw);
-    float s2 = 0.f;
-    for (int p = beg + l; p < end; p += 64) {
-        float f = 1.f;
-        if (drop_p > 0.f) f = drop_factor(seed, (unsigned long long)p, drop_p, drop_scale);
-        const float da = wv * f * dc[col[p]];
-        const float de = alpha[p] * (da - T);
-        const float z = a12[2 * (long long)col[p]] + a2v;
-        const float gz = de * (z > 0.f ? 1.f : slope);
-        dz[p] = gz;
-        s2 += gz;
+    __syncthreads();
+    {
+        const bool listed = s_nh[0] <= 256;
+        for (int i = w; i < (listed ? s_nh[0] : nn); i += 4) {
+            const int v = listed ? s_heavy[0][i] : n0 + i;
+            const int beg = rowptr_in[v], end = rowptr_in[v + 1];
+            if (end - beg <= CG_LIGHT) continue;
+            const float a2v = a12[2 * (long long)v + 1];
+            float m = -INFINITY;
+            for (int p = beg + l; p < end; p += 64) m = fmaxf(m, leaky(a12[2 * (long long)col_src[p]] + a2v, slope));
+            m = wave_max(m);
+            float sum = 0.f;
+            for (int p = beg + l; p < end; p += 64) sum += __expf(leaky(a12[2 * (long long)col_src[p]] + a2v, slope) - m);
+            sum = wave_sum(sum);
+            const float inv = 1.f / sum;
+            for (int p = beg + l; p < end; p += 64) alpha[p] = __expf(leaky(a12[2 * (long long)col_src[p]] + a2v, slope) - m) * inv;
+        }
     }
-    s2 = wave_sum(s2);
-    if (l == 0) {
-        da2[v] = s2;
-        dwv[v] = pw ? (dS[gid[v]] + dw) * cl_sigmoid(pwv) : 0.f;
+    if (threadIdx.x < ng) {                            // S_g: a serial walk in fixed order (deterministic)
+        float S = 0.f;
+        for (int v = s_goff[threadIdx.x]; v < s_goff[threadIdx.x + 1]; ++v)
+            S += (v - n0 < CG_MAXN) ? s_wv[v - n0] : (pw ? cl_softplus(pw[pos[v]]) : 1.f);
+        wsum[g0 + threadIdx.x] = S;
+    }
+    __syncthreads();                                   // alpha of these graphs' edges is complete (first touched below)
+    // ---- source side: coefficients ----
+    for (int t = threadIdx.x; t < nn; t += 256) {
+        const int u = n0 + t;
+        const int beg = rowptr_out[u], end = rowptr_out[u + 1];
+        if (end - beg > CG_LIGHT) { const int k = atomicAdd(&s_nh[1], 1); if (k < 256) s_heavy[1][k] = u; continue; }
+        float cu = 0.f;
+#pragma unroll
+        for (int i = 0; i < CG_LIGHT; ++i) {
+            const int j = min(beg + i, max(end - 1, beg));
+            const int p = pos_out[j], v = col_dst[j];
+            const int tv = min(max(v - n0, 0), CG_MAXN - 1);
+            const float wv = (v - n0 < CG_MAXN && v >= n0) ? s_wv[tv] : (pw ? cl_softplus(pw[pos[v]]) : 1.f);
+            const float f = (drop_p > 0.f) ? drop_factor(seed, (unsigned long long)p, drop_p, drop_scale) : 1.f;
+            cu += (beg + i < end) ? wv * f * alpha[p] : 0.f;
+        }
+        coef[u] = cu;
+    }
+    __syncthreads();
+    {
+        const bool listed = s_nh[1] <= 256;
+        for (int i = w; i < (listed ? s_nh[1] : nn); i += 4) {
+            const int u = listed ? s_heavy[1][i] : n0 + i;
+            const int beg = rowptr_out[u], end = rowptr_out[u + 1];
+            if (end - beg <= CG_LIGHT) continue;
+            float cu = 0.f;
+            for (int j = beg + l; j < end; j += 64) {
+                const int p = pos_out[j], v = col_dst[j];
+                const float wv = pw ? cl_softplus(pw[pos[v]]) : 1.f;
+                const float f = (drop_p > 0.f) ? drop_factor(seed, (unsigned long long)p, drop_p, drop_scale) : 1.f;
+                cu = fmaf(wv * f, alpha[p], cu);
+            }
+            cu = wave_sum(cu);
+            if (l == 0) coef[u] = cu;
+        }
     }
 }
 
-// one wave per source: da1[u] = sum_{j in out(u)} dz[pos_out[j]]
-__global__ __launch_bounds__(256) void cl_bwd_src_kernel(const int* __restrict__ rowptr_out, const int* __restrict__ pos_out, int n_nodes,
-                                                         const float* __restrict__ dz, float* __restrict__ da1) {
+__global__ __launch_bounds__(256) void cl_attn_bwd_kernel(const int* __restrict__ rowptr_in, const int* __restrict__ col_src,
+                                                          const int* __restrict__ rowptr_out, const int* __restrict__ pos_out,
+                                                          const int* __restrict__ goff, const int G, const float* __restrict__ a12,
+                                                          const float slope, const float* __restrict__ alpha, const float drop_p,
+                                                          const float drop_scale, const unsigned long long seed,
+                                                          const int* __restrict__ pos, const float* __restrict__ pw,
+                                                          const float* __restrict__ dc, const float* __restrict__ dS,
+                                                          float* __restrict__ dz, float* __restrict__ da1, float* __restrict__ da2,
+                                                          float* __restrict__ dwv) {
+    __shared__ int s_goff[CG_GRAPHS + 1], s_heavy[2][256], s_nh[2];
     const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
-    const int u = blockIdx.x * 4 + w;
-    if (u >= n_nodes) return;
-    float a = 0.f;
-    for (int j = rowptr_out[u] + l; j < rowptr_out[u + 1]; j += 64) a += dz[pos_out[j]];
-    a = wave_sum(a);
-    if (l == 0) da1[u] = a;
+    const int g0 = blockIdx.x * CG_GRAPHS, g1 = min(G, g0 + CG_GRAPHS), ng = g1 - g0;
+    if (threadIdx.x <= ng) s_goff[threadIdx.x] = goff[g0 + threadIdx.x];
+    if (threadIdx.x < 2) s_nh[threadIdx.x] = 0;
+    __syncthreads();
+    const int n0 = s_goff[0], nn = s_goff[ng] - n0;
+    // ---- destination side ----
+    for (int t = threadIdx.x; t < nn; t += 256) {
+        const int v = n0 + t;
+        const int beg = rowptr_in[v], end = rowptr_in[v + 1];
+        if (end - beg > CG_LIGHT) { const int k = atomicAdd(&s_nh[0], 1); if (k < 256) s_heavy[0][k] = v; continue; }
+        const float pwv = pw ? pw[pos[v]] : 0.f;
+        const float wv = pw ? cl_softplus(pwv) : 1.f;
+        const float a2v = a12[2 * (long long)v + 1];
+        float al[CG_LIGHT], fd[CG_LIGHT], zs[CG_LIGHT];
+        float T = 0.f, dw = 0.f;
+#pragma unroll
+        for (int i = 0; i < CG_LIGHT; ++i) {
+            const int p = min(beg + i, max(end - 1, beg));
+            const int u = col_src[p];
+            const float f = (drop_p > 0.f) ? drop_factor(seed, (unsigned long long)p, drop_p, drop_scale) : 1.f;
+            const bool ok = beg + i < end;
+            al[i] = ok ? alpha[p] : 0.f;
+            fd[i] = f * dc[u];                               // f dc~_u
+            zs[i] = a12[2 * (long long)u] + a2v;
+            dw += al[i] * fd[i];
+            T = fmaf(al[i], wv * fd[i], T);
+        }
+        float s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < CG_LIGHT; ++i) {
+            const float gz = al[i] * (wv * fd[i] - T) * (zs[i] > 0.f ? 1.f : slope);
+            if (beg + i < end) dz[beg + i] = gz;
+            s2 += (beg + i < end) ? gz : 0.f;
+        }
+        da2[v] = s2;
+        dwv[v] = pw ? (dS[g0 + cg_graph_of(s_goff, ng, v)] + dw) * cl_sigmoid(pwv) : 0.f;
+    }
+    __syncthreads();
+    {
+        const bool listed = s_nh[0] <= 256;
+        for (int i = w; i < (listed ? s_nh[0] : nn); i += 4) {
+            const int v = listed ? s_heavy[0][i] : n0 + i;
+            const int beg = rowptr_in[v], end = rowptr_in[v + 1];
+            if (end - beg <= CG_LIGHT) continue;
+            const float pwv = pw ? pw[pos[v]] : 0.f;
+            const float wv = pw ? cl_softplus(pwv) : 1.f;
+            const float a2v = a12[2 * (long long)v + 1];
+            float T = 0.f, dw = 0.f;
+            for (int p = beg + l; p < end; p += 64) {
+                const float f = (drop_p > 0.f) ? drop_factor(seed, (unsigned long long)p, drop_p, drop_scale) : 1.f;
+                const float gq = alpha[p] * f * dc[col_src[p]];
+                dw += gq;
+                T = fmaf(alpha[p], wv * f * dc[col_src[p]], T);
+            }
+            T = wave_sum(T);
+            dw = wave_sum(dw);
+            float s2 = 0.f;
+            for (int p = beg + l; p < end; p += 64) {
+                const float f = (drop_p > 0.f) ? drop_factor(seed, (unsigned long long)p, drop_p, drop_scale) : 1.f;
+                const float de = alpha[p] * (wv * f * dc[col_src[p]] - T);
+                const float zq = a12[2 * (long long)col_src[p]] + a2v;
+                const float gz = de * (zq > 0.f ? 1.f : slope);
+                dz[p] = gz;
+                s2 += gz;
+            }
+            s2 = wave_sum(s2);
+            if (l == 0) {
+                da2[v] = s2;
+                dwv[v] = pw ? (dS[g0 + cg_graph_of(s_goff, ng, v)] + dw) * cl_sigmoid(pwv) : 0.f;
+            }
+        }
+    }
+    __syncthreads();                                   // dz of these graphs' edges is complete (first touched below)
+    // ---- source side ----
+    for (int t = threadIdx.x; t < nn; t += 256) {
+        const int u = n0 + t;
+        const int beg = rowptr_out[u], end = rowptr_out[u + 1];
+        if (end - beg > CG_LIGHT) { const int k = atomicAdd(&s_nh[1], 1); if (k < 256) s_heavy[1][k] = u; continue; }
+        float a = 0.f;
+#pragma unroll
+        for (int i = 0; i < CG_LIGHT; ++i) {
+            const int j = min(beg + i, max(end - 1, beg));
+            a += (beg + i < end) ? dz[pos_out[j]] : 0.f;
+        }
+        da1[u] = a;
+    }
+    __syncthreads();
+    {
+        const bool listed = s_nh[1] <= 256;
+        for (int i = w; i < (listed ? s_nh[1] : nn); i += 4) {
+            const int u = listed ? s_heavy[1][i] : n0 + i;
+            const int beg = rowptr_out[u], end = rowptr_out[u + 1];
+            if (end - beg <= CG_LIGHT) continue;
+            float a = 0.f;
+            for (int j = beg + l; j < end; j += 64) a += dz[pos_out[j]];
+            a = wave_sum(a);
+            if (l == 0) da1[u] = a;
+        }
+    }
 }
 
 // sweep 4 -- one wave per (chunk of CL_CHUNK nodes, 256-column tile):
@@ -1576,10 +1705,8 @@ int txe_gat_collapse_fwd(const int* rowptr_in, const int* col_src, const int* ro
             if (mk) hipLaunchKernelGGL(cl_logits_kernel<true>, dim3(nb < 2048 ? nb : 2048), dim3(256), 0, s, X, Kp, n_nodes, mk, mask_ld, fs, wa, a12);
             else hipLaunchKernelGGL(cl_logits_kernel<false>, dim3(nb < 2048 ? nb : 2048), dim3(256), 0, s, X, Kp, n_nodes, dummy_mask, mask_ld, fs, wa, a12);
         }
-        hipLaunchKernelGGL(cl_alpha_wsum_kernel, dim3(nb + (G + 3) / 4), dim3(256), 0, s, nb, rowptr_in, col_src, n_nodes, (const float*)a12,
-                           attn_slope, alpha, graph_off, G, pos, pw, wsum, gid);
-        hipLaunchKernelGGL(cl_coef_kernel, dim3(nb), dim3(256), 0, s, rowptr_out, col_dst, pos_out, n_nodes,
-                           (const float*)alpha, attn_drop_p, as, seed, pos, pw, coef);
+        hipLaunchKernelGGL(cl_attn_coef_kernel, dim3((G + CG_GRAPHS - 1) / CG_GRAPHS), dim3(256), 0, s, rowptr_in, col_src, rowptr_out, col_dst, pos_out,
+                           graph_off, G, (const float*)a12, attn_slope, attn_drop_p, as, seed, pos, pw, alpha, coef, wsum, gid);
         TXE_CHECK_LAUNCH();
     } else if (G > 0) {
         hipLaunchKernelGGL(cl_wsum_kernel, dim3((G + 3) / 4), dim3(256), 0, s, graph_off, G, pos, pw, wsum, gid);
@@ -1658,9 +1785,9 @@ int txe_gat_collapse_bwd(const int* rowptr_in, const int* col_src, const int* ro
             else hipLaunchKernelGGL(cl_bwd_dot_kernel<false>, dim3(nb_ds + nb), dim3(256), 0, s, n_nodes, gid, X, Kp, dummy_mask, mask_ld, fs,
                                     (const float*)p.dZ, wsum, coef, p.dc, p.cn, nb_ds, G, D, d_hg, ld_dhg, hg, ld_hg, p.dS);
         }
-        hipLaunchKernelGGL(cl_bwd_edge_kernel, dim3(nb), dim3(256), 0, s, rowptr_in, col_src, n_nodes, a12, attn_slope, alpha, attn_drop_p, as,
-                           seed, pos, pw, (const float*)p.dc, (const float*)p.dS, gid, p.dz, p.da2, p.dwv);
-        hipLaunchKernelGGL(cl_bwd_src_kernel, dim3(nb), dim3(256), 0, s, rowptr_out, pos_out, n_nodes, (const float*)p.dz, p.da1);
+        hipLaunchKernelGGL(cl_attn_bwd_kernel, dim3((G + CG_GRAPHS - 1) / CG_GRAPHS), dim3(256), 0, s, rowptr_in, col_src, rowptr_out, pos_out,
+                           graph_off, G, a12, attn_slope, alpha, attn_drop_p, as, seed, pos, pw, (const float*)p.dc, (const float*)p.dS, p.dz,
+                           p.da1, p.da2, p.dwv);
         {
             const long long nwaves = (long long)p.chunks * ntile;
             ProfScope prof(mk ? "cl_bwd_dx_kernel<true, true>" : "cl_bwd_dx_kernel<false, true>", s, 4.0 * (2.0 * n_nodes + G) * Kp, 1);
@@ -1803,9 +1930,9 @@ int txe_gat_collapse_bwd_fused(const int* rowptr_in, const int* col_src, const i
             else hipLaunchKernelGGL(cl_bwd_dot_kernel<false>, dim3(nb_ds + nb), dim3(256), 0, s, n_nodes, gid, X, Kp, dummy_mask, mask_ld, fs,
                                     (const float*)p.dZ, wsum, coef, p.dc, p.cn, nb_ds, G, D, d_hg, ld_dhg, hg, ld_hg, p.dS);
         }
-        hipLaunchKernelGGL(cl_bwd_edge_kernel, dim3(nb), dim3(256), 0, s, rowptr_in, col_src, n_nodes, a12, attn_slope, alpha, attn_drop_p, as,
-                           seed, pos, pw, (const float*)p.dc, (const float*)p.dS, gid, p.dz, p.da2, p.dwv);
-        hipLaunchKernelGGL(cl_bwd_src_kernel, dim3(nb), dim3(256), 0, s, rowptr_out, pos_out, n_nodes, (const float*)p.dz, p.da1);
+        hipLaunchKernelGGL(cl_attn_bwd_kernel, dim3((G + CG_GRAPHS - 1) / CG_GRAPHS), dim3(256), 0, s, rowptr_in, col_src, rowptr_out, pos_out,
+                           graph_off, G, a12, attn_slope, alpha, attn_drop_p, as, seed, pos, pw, (const float*)p.dc, (const float*)p.dS, p.dz,
+                           p.da1, p.da2, p.dwv);
         {
             FusedBwdArgs a;
             a.rowptr_out = rowptr_out; a.col_dst = col_dst; a.pos_out = pos_out; a.gid = gid; a.pos = pos ? pos : gid; a.n_nodes = n_nodes;

@@ -85,6 +85,18 @@ int txe_gat_dense_bwd(const float* X, int n_nodes, int Kh, int Pd, const int* po
                       int phases, void* ws, size_t ws_bytes, void* stream);
 int txe_zero_cols(float* x, long long ld, int n_rows, int c0, int c1, void* stream);
 
+/* Eval-mode first GATLayer of a batch whose node features are rows of a feature table (test_fast.py:149-179 / infer.py:82-95
+ * encode every taxonomy node many times): the projected rows ft[u] = T[rid[u]] + T2[pos[u]] (T = table x W^T [n_table][ld_t],
+ * T2 = position embedding x W_p^T [vocab][ld_t], attention columns at H*D.. as in txe_gat_dense_fwd's output) are formed inside the
+ * message/reduce sweep -- same arithmetic as txe_gather_add_rows followed by txe_gat_aggregate_fwd, without the [N][ld_t] round trip.
+ * No dropout, alpha is not kept (inference).  nx_*: as in txe_gat_aggregate_fwd (no mask).  _supported: 1 if the shape fits (H <= 4,
+ * 16-byte rows, the T2 rows and the folded rows in 56 KB of LDS), else the caller materialises the rows. */
+int txe_gat_aggregate_table_supported(int H, int D, long long ld_t, int vocab, int nx_kp);
+int txe_gat_aggregate_table_fwd(const int* rowptr_in, const int* col_src, int n_nodes, const float* T, long long ld_t, const int* rid,
+                                const float* T2, const int* pos, int vocab, int H, int D, float attn_slope, int out_mode,
+                                float act_slope, float* out, long long ld_out, const float* nx_wa, int nx_kp, float* nx_a12,
+                                void* stream);
+
 /* ---- GATLayer message/reduce: model_zoo.py:90-95,106-114 (edge_attention, edge_softmax, attn_drop, update_all) -----
  * out_mode 0: out = aggregated features; 1: out = leaky_relu(aggregated, act_slope) (model_zoo.py:216 fused).
  * alpha [E][H] (post-softmax, pre-dropout; NULL in inference).

@@ -24,6 +24,8 @@ SIGNATURES = {
     "txe_gat_dense_bwd": (I, [P, I, I, I, P, I, P, P, P, P, I, I, F, P, P, I, I, F, P, P, P, P, P, I, P, SZ, P]),
     "txe_zero_cols": (I, [P, L, I, I, I, P]),
     "txe_gat_aggregate_fwd": (I, [P, P, I, P, L, P, P, I, I, I, F, F, U64, I, F, P, L, P, P, I, P, F, P, P]),
+    "txe_gat_aggregate_table_supported": (I, [I, I, L, I, I]),
+    "txe_gat_aggregate_table_fwd": (I, [P, P, I, P, L, P, P, P, I, I, I, F, I, F, P, L, P, I, P, P]),
     "txe_gat_aggregate_bwd": (I, [P, P, P, P, P, I, P, L, P, P, I, I, I, F, F, U64, P, P, L, P, L, P, P, I, P, I, P]),
     "txe_leaky_relu_bwd": (I, [P, P, F, L, P, P]),
     "txe_head_mean_fwd": (I, [P, I, I, L, P, P]),
@@ -93,7 +95,8 @@ class GatPrepareDesc(C.Structure):
 
 
 _ERR = {-1: "TXE_ERR_ARG", -2: "TXE_ERR_LAUNCH", -3: "TXE_ERR_WORKSPACE"}
-VALUE_RETURNING = {"txe_gat_padded_k", "txe_gat_padded_f", "txe_gcn_padded_f", "txe_profile_count", "txe_gat_fused_bwd_supported"}   # int results that are not status codes
+VALUE_RETURNING = {"txe_gat_padded_k", "txe_gat_padded_f", "txe_gcn_padded_f", "txe_profile_count", "txe_gat_fused_bwd_supported",
+                   "txe_gat_aggregate_table_supported"}   # int results that are not status codes
 
 _lib = None
 

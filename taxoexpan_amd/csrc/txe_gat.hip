@@ -40,15 +40,64 @@ struct NextLogits {
 };
 // one destination node v, one wave: attention softmax over its in-edges, aggregation, (NX) the next layer's folded logits
 // NX: 0 = plain aggregation, 1 = + the next (folded) layer's logits, 2 = the same with that layer's feature-dropout mask
-template <int VEC, int NI, int NX>
+// TAB: the projected features are rows of a TABLE (eval-mode first layer of a batch drawn from a taxonomy's feature table):
+//   ft[u] = T[rid[u]] + T2[pos[u]]     (T = table x W^T, T2 = position embedding x W_p^T, attention columns included)
+// formed on the fly -- same operation order as materialising the rows first (one add, then the weighted sum), so both routes agree bit
+// for bit.  The few rows of T2 sit in LDS.
+struct TabSrc {
+    const int* rid;           // [N] table row of every batch node
+    const int* pos;           // [N] row of T2 of every batch node
+    const float* t2;          // [vocab][ld_ft] in global memory (copied to LDS by the kernel)
+    int vocab;
+};
+
+template <int VEC, int NI, int EU>
+__device__ __forceinline__ void gather_step_tab(const float* __restrict__ base, long long ld, const int* s_idx, const int* s_pos,
+                                                const float* s_t2, const float* s_w, int e, int j0, int j1, const int* hidx,
+                                                float (&acc)[NI][VEC]) {
+    const int l = threadIdx.x & 63;
+    float v[EU][NI][VEC];
+#pragma unroll
+    for (int u = 0; u < EU; ++u) {
+        const float* row = base + (long long)s_idx[e + u] * ld;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int j = j0 + l + 64 * i;
+            const int jc = (j < j1) ? j : j0;                   // clamped: loads stay unconditional
+            vload<VEC>(row + (long long)jc * VEC, v[u][i]);
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < EU; ++u) {
+        const float* trow = s_t2 + (long long)s_pos[e + u] * ld;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int j = j0 + l + 64 * i;
+            const int jc = (j < j1) ? j : j0;
+            float t[VEC];
+            vload<VEC>(trow + (long long)jc * VEC, t);
+            const float a = s_w[hidx[i] * 64 + e + u];
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) acc[i][k] = fmaf(a, v[u][i][k] + t[k], acc[i][k]);
+        }
+    }
+}
+
+template <int VEC, int NI, int NX, bool TAB>
 __device__ __forceinline__ void gat_fwd_node(const int v, const int l, float* __restrict__ s_w, int* __restrict__ s_idx,
     float* __restrict__ s_stat, const float* __restrict__ s_wa,
     const int* __restrict__ rowptr, const int* __restrict__ col, const float* __restrict__ ft,
     const long long ld_ft, const float* __restrict__ a_src, const float* __restrict__ a_dst, const int ld_a, const int H,
     const int D, const float slope, const float drop_p, const float drop_scale, const unsigned long long seed,
     const int out_mode, const float act_slope, float* __restrict__ out, const long long ld_out, float* __restrict__ alpha,
-    const NextLogits& nx) {
+    const NextLogits& nx, const TabSrc& tab, int* __restrict__ s_pos, const float* __restrict__ s_t2) {
     const int beg = rowptr[v], end = rowptr[v + 1];
+    // attention terms of a node: TAB forms them from the table rows exactly as the materialised row would hold them
+    auto att = [&](const int u, const int h, const bool dst) -> float {
+        const int c = H * D + (dst ? H : 0) + h;
+        if constexpr (TAB) return ft[(long long)tab.rid[u] * ld_ft + c] + s_t2[(long long)tab.pos[u] * ld_ft + c];
+        else return (dst ? a_dst : a_src)[(long long)u * ld_a + h];
+    };
 
     // Common case (every egonet: in-degree <= 51, H <= 4): one edge per lane, the logits of all heads stay in registers, the
     // H max / sum butterflies run interleaved, alpha goes straight to LDS -- one dependent-load chain instead of three.
@@ -60,7 +109,7 @@ __device__ __forceinline__ void gat_fwd_node(const int v, const int l, float* __
         float e[4], ex[4], m[4], sm[4];
 #pragma unroll
         for (int h = 0; h < 4; ++h)
-            e[h] = (valid && h < H) ? leaky(a_src[(long long)u * ld_a + h] + a_dst[(long long)v * ld_a + h], slope) : -INFINITY;
+            e[h] = (valid && h < H) ? leaky(att(u, h, false) + att(v, h, true), slope) : -INFINITY;
 #pragma unroll
         for (int h = 0; h < 4; ++h) m[h] = wave_max(e[h]);
 #pragma unroll
@@ -68,7 +117,8 @@ __device__ __forceinline__ void gat_fwd_node(const int v, const int l, float* __
 #pragma unroll
         for (int h = 0; h < 4; ++h) sm[h] = wave_sum(ex[h]);
         if (valid) {
-            s_idx[l] = u;
+            if constexpr (TAB) { s_idx[l] = tab.rid[u]; s_pos[l] = tab.pos[u]; }
+            else s_idx[l] = u;
 #pragma unroll
             for (int h = 0; h < 4; ++h) {
                 if (h < H) {
@@ -83,12 +133,12 @@ __device__ __forceinline__ void gat_fwd_node(const int v, const int l, float* __
     } else {
     // wavefront segmented max / sum of the attention logits of v's in-edges, per head
     for (int h = 0; h < H; ++h) {
-        const float ad = a_dst[(long long)v * ld_a + h];
+        const float ad = att(v, h, true);
         float m = -INFINITY;
-        for (int p = beg + l; p < end; p += 64) m = fmaxf(m, leaky(a_src[(long long)col[p] * ld_a + h] + ad, slope));
+        for (int p = beg + l; p < end; p += 64) m = fmaxf(m, leaky(att(col[p], h, false) + ad, slope));
         m = wave_max(m);
         float s = 0.f;
-        for (int p = beg + l; p < end; p += 64) s += __expf(leaky(a_src[(long long)col[p] * ld_a + h] + ad, slope) - m);
+        for (int p = beg + l; p < end; p += 64) s += __expf(leaky(att(col[p], h, false) + ad, slope) - m);
         s = wave_sum(s);
         if (l == 0) { s_stat[2 * h] = m; s_stat[2 * h + 1] = 1.f / s; }
     }
@@ -135,9 +185,10 @@ __device__ __forceinline__ void gat_fwd_node(const int v, const int l, float* __
             const int p = cb + l;
             if (!single && p < end) {
                 const int u = col[p];
-                s_idx[l] = u;
+                if constexpr (TAB) { s_idx[l] = tab.rid[u]; s_pos[l] = tab.pos[u]; }
+                else s_idx[l] = u;
                 for (int h = 0; h < H; ++h) {
-                    const float e = leaky(a_src[(long long)u * ld_a + h] + a_dst[(long long)v * ld_a + h], slope);
+                    const float e = leaky(att(u, h, false) + att(v, h, true), slope);
                     const float al = __expf(e - s_stat[2 * h]) * s_stat[2 * h + 1];
                     if (alpha != nullptr && t0 == 0) alpha[(long long)p * H + h] = al;
                     float f = 1.f;
@@ -146,7 +197,12 @@ __device__ __forceinline__ void gat_fwd_node(const int v, const int l, float* __
                 }
             }
             __builtin_amdgcn_wave_barrier();
-            gather_rows<VEC, NI, EU>(ft, ld_ft, s_idx, s_w, min(64, end - cb), t0, nvec, hidx, acc);
+            if constexpr (TAB) {
+                const int cnt = min(64, end - cb);
+                for (int e = 0; e < cnt; ++e) gather_step_tab<VEC, NI, 1>(ft, ld_ft, s_idx, s_pos, s_t2, s_w, e, t0, nvec, hidx, acc);
+            } else {
+                gather_rows<VEC, NI, EU>(ft, ld_ft, s_idx, s_w, min(64, end - cb), t0, nvec, hidx, acc);
+            }
             __builtin_amdgcn_wave_barrier();
         }
 #pragma unroll
@@ -192,28 +248,35 @@ __device__ __forceinline__ void gat_fwd_node(const int v, const int l, float* __
     }
 }
 
-template <int VEC, int NI, int NX>
-__global__ __launch_bounds__(GAT_WAVES * 64) void gat_aggregate_fwd_kernel(
+template <int VEC, int NI, int NX, bool TAB = false>
+__global__ __launch_bounds__(GAT_WAVES * 64, TAB ? 3 : 1) void gat_aggregate_fwd_kernel(
     const int* __restrict__ rowptr, const int* __restrict__ col, const int n_nodes, const float* __restrict__ ft,
     const long long ld_ft, const float* __restrict__ a_src, const float* __restrict__ a_dst, const int ld_a, const int H,
     const int D, const float slope, const float drop_p, const float drop_scale, const unsigned long long seed,
     const int out_mode, const float act_slope, float* __restrict__ out, const long long ld_out, float* __restrict__ alpha,
-    const NextLogits nx) {
-    __shared__ float s_w[GAT_WAVES][GAT_MAXH * 64];
+    const NextLogits nx, const TabSrc tab) {
+    constexpr int SWH = TAB ? 4 : GAT_MAXH;            // (the table route serves H <= 4 only: its LDS goes to the T2 rows)
+    __shared__ float s_w[GAT_WAVES][SWH * 64];
     __shared__ int s_idx[GAT_WAVES][64];
+    __shared__ int s_pos[TAB ? GAT_WAVES : 1][64];
     __shared__ float s_stat[GAT_WAVES][2 * GAT_MAXH];
 
     const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
-    extern __shared__ float s_wa[];                    // NX: the two folded rows [2][kp], shared by the workgroup's 4 nodes
-    if constexpr (NX) {
+    extern __shared__ __attribute__((aligned(16))) float s_wa[];   // NX: the two folded rows [2][kp], shared by the workgroup's 4 nodes;
+    float* s_t2 = s_wa + (NX ? 2 * nx.kp : 0);                    // TAB: behind them, the rows of T2 [vocab][ld_ft]
+    if constexpr (NX != 0) {
         for (int i = threadIdx.x * 4; i < 2 * nx.kp; i += GAT_WAVES * 64 * 4)
             *reinterpret_cast<float4*>(s_wa + i) = *reinterpret_cast<const float4*>(nx.wa + i);
-        __syncthreads();                               // before any wave leaves
     }
+    if constexpr (TAB) {
+        for (long long i = threadIdx.x * 4; i < (long long)tab.vocab * ld_ft; i += GAT_WAVES * 64 * 4)
+            *reinterpret_cast<float4*>(s_t2 + i) = *reinterpret_cast<const float4*>(tab.t2 + i);
+    }
+    if constexpr (NX != 0 || TAB) __syncthreads();     // before any wave leaves
     const int v = xcd_remap(blockIdx.x, gridDim.x) * GAT_WAVES + w;
     if (v >= n_nodes) return;
-    gat_fwd_node<VEC, NI, NX>(v, l, s_w[w], s_idx[w], s_stat[w], s_wa, rowptr, col, ft, ld_ft, a_src, a_dst, ld_a, H, D, slope, drop_p,
-                              drop_scale, seed, out_mode, act_slope, out, ld_out, alpha, nx);
+    gat_fwd_node<VEC, NI, NX, TAB>(v, l, s_w[w], s_idx[w], s_stat[w], s_wa, rowptr, col, ft, ld_ft, a_src, a_dst, ld_a, H, D, slope, drop_p,
+                                   drop_scale, seed, out_mode, act_slope, out, ld_out, alpha, nx, tab, s_pos[TAB ? w : 0], s_t2);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -634,6 +697,7 @@ struct KName {
     KName(const char* base, int a, int b) { snprintf(s, sizeof(s), "%s<%d, %d>", base, a, b); }
     KName(const char* base, int a) { snprintf(s, sizeof(s), "%s<%d>", base, a); }
     KName(const char* base, int a, int b, int c) { snprintf(s, sizeof(s), "%s<%d, %d, %d>", base, a, b, c); }
+    KName(const char* base, int a, int b, int c, int) { snprintf(s, sizeof(s), "%s<%d, %d, %d, true>", base, a, b, c); }
 };
 
 #define TXE_DISPATCH_VEC_NI(vec, ni, LAUNCH)                                     \
@@ -683,17 +747,55 @@ int txe_gat_aggregate_fwd(const int* rowptr_in, const int* col_src, int n_nodes,
 #define TXE_L(V, I)                                                                                                               \
     hipLaunchKernelGGL((gat_aggregate_fwd_kernel<V, I, 0>), dim3(nb), dim3(GAT_WAVES * 64), 0, s, rowptr_in, col_src, n_nodes, \
                        ft, ld_ft, a_src, a_dst, ld_a, H, D, attn_slope, attn_drop_p, scale, seed, out_mode, act_slope,            \
-                       out, ld_out, alpha, nx)
+                       out, ld_out, alpha, nx, TabSrc{nullptr, nullptr, nullptr, 0})
 #define TXE_LXM(I, M)                                                                                                             \
     hipLaunchKernelGGL((gat_aggregate_fwd_kernel<4, I, M>), dim3(nb), dim3(GAT_WAVES * 64), (size_t)2 * nx_kp * sizeof(float), s, rowptr_in, col_src, n_nodes,  \
                        ft, ld_ft, a_src, a_dst, ld_a, H, D, attn_slope, attn_drop_p, scale, seed, out_mode, act_slope,            \
-                       out, ld_out, alpha, nx)
+                       out, ld_out, alpha, nx, TabSrc{nullptr, nullptr, nullptr, 0})
 #define TXE_LX(I) do { if (nx.mask) TXE_LXM(I, 2); else TXE_LXM(I, 1); } while (0)
     if (nx_a12) { if (ni == 8) TXE_LX(8); else if (ni == 4) TXE_LX(4); else TXE_LX(2); }
     else TXE_DISPATCH_VEC_NI(vec, ni, TXE_L);
 #undef TXE_LX
 #undef TXE_LXM
 #undef TXE_L
+    TXE_CHECK_LAUNCH();
+    return TXE_OK;
+}
+
+// Eval-mode first layer on rows of a projected feature table: ft[u] = T[rid[u]] + T2[pos[u]] is formed inside the
+// sweep instead of being written out and read back (MAG-Full: 1.1 M rows of 8 KB).  No dropout, no alpha kept: inference only.
+static size_t table_lds_bytes(long long ld_t, int vocab, int nx_kp) { return ((size_t)vocab * ld_t + 2 * (size_t)nx_kp) * sizeof(float); }
+
+int txe_gat_aggregate_table_supported(int H, int D, long long ld_t, int vocab, int nx_kp) {
+    return (H >= 1 && H <= 4 && D >= 4 && (D & 3) == 0 && (ld_t & 3) == 0 && ld_t >= (long long)H * D + 2 * H && vocab >= 1 && nx_kp >= 0 &&
+            (nx_kp & 3) == 0 && table_lds_bytes(ld_t, vocab, nx_kp) <= 56 * 1024) ? 1 : 0;
+}
+
+int txe_gat_aggregate_table_fwd(const int* rowptr_in, const int* col_src, int n_nodes, const float* T, long long ld_t, const int* rid,
+                                const float* T2, const int* pos, int vocab, int H, int D, float attn_slope, int out_mode,
+                                float act_slope, float* out, long long ld_out, const float* nx_wa, int nx_kp, float* nx_a12,
+                                void* stream) {
+    if (n_nodes < 0 || !rowptr_in || !T || !rid || !T2 || !pos || !out || (out_mode != 0 && out_mode != 1)) return TXE_ERR_ARG;
+    if (!txe_gat_aggregate_table_supported(H, D, ld_t, vocab, nx_a12 ? nx_kp : 0)) return TXE_ERR_ARG;
+    if ((ld_out & 3) || (((uintptr_t)T | (uintptr_t)T2 | (uintptr_t)out) & 15)) return TXE_ERR_ARG;
+    if (nx_a12 && (!nx_wa || nx_kp < H * D || nx_kp - H * D > 128 || (nx_kp & 31) || ld_out != nx_kp || ((uintptr_t)nx_wa & 15))) return TXE_ERR_ARG;
+    if (n_nodes == 0) return TXE_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const int nb = (n_nodes + GAT_WAVES - 1) / GAT_WAVES;
+    NextLogits nx;
+    nx.wa = nx_wa; nx.mask = nullptr; nx.a12 = nx_a12; nx.scale = 1.f; nx.kp = nx_a12 ? nx_kp : 0; nx.mask_ld = nx.kp / 32;
+    TabSrc tab;
+    tab.rid = rid; tab.pos = pos; tab.t2 = T2; tab.vocab = vocab;
+    const int ni = pick_ni(H * D / 4);
+    const size_t lds = table_lds_bytes(ld_t, vocab, nx.kp);
+    const KName kn("gat_aggregate_fwd_kernel", 4, ni, nx_a12 ? 1 : 0, 1);
+    ProfScope prof(kn.s, s, 4.0 * (2.0 * n_nodes * (double)H * D + 2.0 * n_nodes * H + 3.0 * n_nodes + 1), 1);
+#define TXE_LT(I, X)                                                                                                              \
+    hipLaunchKernelGGL((gat_aggregate_fwd_kernel<4, I, X, true>), dim3(nb), dim3(GAT_WAVES * 64), lds, s, rowptr_in, col_src, n_nodes, T, \
+                       ld_t, T, T, 0, H, D, attn_slope, 0.f, 1.f, 0ull, out_mode, act_slope, out, ld_out, (float*)nullptr, nx, tab)
+    if (nx_a12) { if (ni == 8) TXE_LT(8, 1); else if (ni == 4) TXE_LT(4, 1); else TXE_LT(2, 1); }
+    else { if (ni == 8) TXE_LT(8, 0); else if (ni == 4) TXE_LT(4, 0); else TXE_LT(2, 0); }
+#undef TXE_LT
     TXE_CHECK_LAUNCH();
     return TXE_OK;
 }

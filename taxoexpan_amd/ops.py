@@ -381,6 +381,15 @@ def _gat_layer_fwd(csr, st, h, ld_h, pos, out, ld_out, feat_p, attn_p, attn_slop
     if isinstance(h, GatheredRows):            # eval-mode first layer on table rows: project the table, gather
         N = h.index.shape[0]
         T, T2 = _gat_table_projection(st, h)[:2]
+        nx_kp = nxt[0].Kp if nxt is not None else 0
+        if (T2 is not None and pos is not None and not save and not _NO_TABLE_SWEEP and attn_p == 0.0
+                and call("txe_gat_aggregate_table_supported", H, D, Fp, T2.shape[0], nx_kp) == 1):
+            # the projected rows T[id] + T2[pos] are formed inside the sweep: no [N, Fp] round trip through HBM
+            st.Y = st.alpha = None
+            call("txe_gat_aggregate_table_fwd", ptr(csr.rowptr_in), ptr(csr.col_src), N, ptr(T), Fp, ptr(_i32(h.index, T.device)), ptr(T2),
+                 ptr(pos), T2.shape[0], H, D, attn_slope, out_mode, act_slope, ptr(out), ld_out,
+                 *((ptr(nxt[0].Wp) + 4 * nxt[0].D * nxt[0].Kp, nx_kp, ptr(nxt[1])) if nxt is not None else (None, 0, None)), s)
+            return
         st.Y = _empty((N, Fp), T)
         call("txe_gather_add_rows", ptr(T), Fp, ptr(_i32(h.index, T.device)), ptr(T2), Fp, ptr(pos) if T2 is not None else None, N, Fp,
              ptr(st.Y), Fp, s)
@@ -442,6 +451,7 @@ def _gat_layer_bwd(csr, st, pos, vocab, feat_p, attn_p, attn_slope, d_pre, ld_dp
     return _gat_dense_bwd(st, pos, vocab, feat_p, d_Y, need_dh, act_on, act_slope)
 
 
+_NO_TABLE_SWEEP = os.environ.get("TXE_NO_TABLE_SWEEP", "0") == "1"      # A/B switch: table rows are materialised before the sweep
 _NO_MULTI_PREPARE = os.environ.get("TXE_NO_MULTI_PREPARE", "0") == "1"   # A/B switch: one preparation launch per layer
 _NO_SIDE_STREAM = os.environ.get("TXE_NO_SIDE_STREAM", "0") == "1"      # A/B switch: everything on the caller's stream
 _side_streams = {}

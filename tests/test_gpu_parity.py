@@ -893,6 +893,11 @@ def test_eval_encode_on_table_rows_equals_materialised_features(prop, monkeypatc
     hg_f = encode_candidates(model, full)
     assert len(calls) == len(chunks)                            # the table path ran (its projection is cached after the first chunk)
     np.testing.assert_allclose(hg_l.cpu().numpy(), hg_f.cpu().numpy(), rtol=1e-4, atol=1e-5)
+    # PGAT forms the projected rows inside the message/reduce sweep; materialising them first (A/B switch) is the same arithmetic
+    monkeypatch.setattr(ops, "_NO_TABLE_SWEEP", True)
+    assert torch.equal(encode_candidates(model, lazy), hg_l)
+    monkeypatch.setattr(ops, "_NO_TABLE_SWEEP", False)
+    calls.clear()
     # the lazy features are an ordinary tensor for every other consumer
     x = lazy[0].ndata["x"]
     assert tuple(x.shape) == tuple(full[0].ndata["x"].shape) and torch.equal(x + 0, full[0].ndata["x"])
@@ -908,6 +913,55 @@ def test_eval_encode_on_table_rows_equals_materialised_features(prop, monkeypatc
         g.ndata["pos"] = pos
     assert not calls
     np.testing.assert_allclose(outs[0], outs[1], rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("H,D,with_nx", [(4, 500, True), (4, 160, True), (4, 24, False), (2, 100, True), (1, 36, False)])
+def test_table_rows_formed_inside_the_sweep_equal_materialised_rows(H, D, with_nx):
+    """txe_gat_aggregate_table_fwd against txe_gather_add_rows + txe_gat_aggregate_fwd, bit for bit (same operation order), on a
+    multigraph with a hub of in-degree 150 (the chunked softmax), nodes without in-edges, every row-width template, with and
+    without the next layer's folded logits in the epilogue"""
+    from taxoexpan_amd import _lib, graph as G
+    dev = _dev()
+    rs = np.random.RandomState(H * 100 + D)
+    N, n_tab, vocab = 700, 90, 3
+    F, Fe = H * D, H * D + 2 * H
+    Fp = -(-Fe // 128) * 128
+    kp = -(-(F + 6) // 32) * 32
+    src = rs.randint(0, N, 2200)
+    dst = rs.randint(5, N, 2200)                                                    # nodes 0..4: no in-edges
+    src[:150], dst[:150] = rs.randint(0, N, 150), 17                                # a hub
+    rin, col = G.build_csr_device(torch.from_numpy(src.astype(np.int32)).to(dev), torch.from_numpy(dst.astype(np.int32)).to(dev), N)[:2]
+    T = torch.from_numpy(rs.standard_normal((n_tab, Fp)).astype(np.float32)).to(dev)
+    T2 = torch.from_numpy(rs.standard_normal((vocab, Fp)).astype(np.float32)).to(dev)
+    rid = torch.from_numpy(rs.randint(0, n_tab, N).astype(np.int32)).to(dev)
+    pos = torch.from_numpy(rs.randint(0, vocab, N).astype(np.int32)).to(dev)
+    wa = torch.from_numpy(rs.standard_normal((2, kp)).astype(np.float32)).to(dev)
+    assert _lib.call("txe_gat_aggregate_table_supported", H, D, Fp, vocab, kp if with_nx else 0) == 1
+    ld_out = kp if with_nx else F
+    outs = []
+    for table in (False, True):
+        out = torch.full((N, ld_out), 0.25, device=dev)                              # (the columns behind F belong to the caller)
+        a12 = torch.zeros(N, 2, device=dev)
+        nx = (wa.data_ptr(), kp) if with_nx else (None, 0)
+        if table:
+            _lib.call("txe_gat_aggregate_table_fwd", rin.data_ptr(), col.data_ptr(), N, T.data_ptr(), Fp, rid.data_ptr(), T2.data_ptr(),
+                      pos.data_ptr(), vocab, H, D, 0.2, 1, 0.1, out.data_ptr(), ld_out, nx[0], nx[1], a12.data_ptr() if with_nx else None,
+                      _lib.stream_ptr())
+        else:
+            Y = torch.empty(N, Fp, device=dev)
+            _lib.call("txe_gather_add_rows", T.data_ptr(), Fp, rid.data_ptr(), T2.data_ptr(), Fp, pos.data_ptr(), N, Fp, Y.data_ptr(), Fp,
+                      _lib.stream_ptr())
+            _lib.call("txe_gat_aggregate_fwd", rin.data_ptr(), col.data_ptr(), N, Y.data_ptr(), Fp, Y.data_ptr() + 4 * F,
+                      Y.data_ptr() + 4 * (F + H), Fp, H, D, 0.2, 0.0, 0, 1, 0.1, out.data_ptr(), ld_out, None, nx[0], nx[1], None, 0.0,
+                      a12.data_ptr() if with_nx else None, _lib.stream_ptr())
+        torch.cuda.synchronize()
+        outs.append((out.cpu(), a12.cpu()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert float(outs[1][0][:5, :F].abs().max()) == 0.0 and float(outs[1][0][17, :F].abs().max()) > 0.0
+    # a shape the LDS cannot hold is refused (the caller then materialises the rows), so is H > 4
+    assert _lib.call("txe_gat_aggregate_table_supported", 4, 500, 2048, 8, 2080) == 0
+    assert _lib.call("txe_gat_aggregate_table_supported", 8, 64, 640, 3, 0) == 0
 
 
 @pytest.mark.gpu

@@ -23,6 +23,7 @@
 //   k-loop split by the kind of tile being fetched (plain prefix, generic tail) instead of a per-tile branch.
 #pragma once
 #include <stdio.h>
+#include <stdlib.h>
 
 #include "txe_common.h"
 
@@ -338,6 +339,7 @@ struct Tail {
     int ksplit;      // k-range of one slice (multiple of BK)
     float* ws;       // [r*S][GEMM_BM*BN] raw partial tiles
     int row_fast;    // 1: consecutive workgroups walk DOWN a column of tiles (few row panels, many column tiles: the scoring GEMM)
+    int tile0;       // this launch owns the tiles [tile0, all) of the product (the leading whole rounds went to gemm_persist_kernel)
 };
 
 __device__ __forceinline__ void epi_store_one(const Epi& E, int m, int n, float acc, float* cbase) {
@@ -357,7 +359,7 @@ __device__ __forceinline__ void epi_store_one(const Epi& E, int m, int n, float 
 template <int BN>
 __global__ __launch_bounds__(256) void gemm_tail_fixup_kernel(const Epi E, const Tail T, const int M, const int N) {
     const int nbn = (N + BN - 1) / BN;
-    const int tile = T.nfull + blockIdx.x;
+    const int tile = T.tile0 + T.nfull + blockIdx.x;
     const int nbm = (M + GEMM_BM - 1) / GEMM_BM;
     const int m0 = (T.row_fast ? tile % nbm : tile / nbn) * GEMM_BM, n0 = (T.row_fast ? tile / nbm : tile % nbn) * BN;
     const float* part = T.ws + (long long)blockIdx.x * T.S * (GEMM_BM * BN);
@@ -417,6 +419,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_kernel(VMat A, VMat B, c
     // column tiles fastest when there are more row panels than column tiles, else row panels fastest -- the long operand is then
     // streamed from HBM once instead of once per tile of the short dimension (scoring: U read 1x instead of 8x per query block)
     const int nbm = (M + GEMM_BM - 1) / GEMM_BM;
+    lb += T.tile0;
     const int tm = T.row_fast ? lb % nbm : lb / nbn, tn = T.row_fast ? lb / nbm : lb % nbn;
     const int m0 = tm * GEMM_BM, n0 = tn * BN;
 
@@ -677,6 +680,178 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_kernel(VMat A, VMat B, c
     }
 }
 
+// ---- whole rounds of a plain product: persistent workgroups, the C tile drained under the NEXT tile's k-loop ---------------------
+// A short reduction (K = 256 .. 320: the first layer's projection, the table projection, the scoring product) spends ~20 % of every
+// round of 2 x 256 tiles storing C: all workgroups finish together, 33 MB leave the chip at the HBM write rate while the matrix pipe
+// idles, and the next round pays a launch + first-load prologue.  Here one workgroup per slot walks tiles b, b + G, ...; when a tile's
+// k-loop ends its accumulators move to a second register set and are written -- straight from registers: the 32 lanes of a half wave
+// hold 32 consecutive floats of one C row, 128 bytes per store -- in four batches of 16 stores inside the first four k-tiles of the
+// NEXT tile, i.e. under its MFMA blocks.  No LDS transposition, no epilogue extras: plain (or exp) epilogues, plain operands
+// (optionally a dropout mask on either), 128 x 128 tiles that lie wholly inside both operands, K a multiple of 32 and >= 160.
+// Accumulation order per element is the k order of gemm_kernel: results are bit-identical.
+#ifndef TXE_PERSIST_MAXK
+#define TXE_PERSIST_MAXK 512
+#endif
+struct Persist {
+    float* c;
+    long long ldc;
+    int row_fast;
+    int apply_exp;
+    float* dummy;    // >= gridDim.x * 256 floats: where the lanes of a tile's rows / columns past M / N put their stores
+};
+
+template <bool AK, bool BKC, int DK /* k-tiles over which a tile's 64 stores per lane are spread: 4 or 8 */>
+__global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_persist_kernel(const VMat A, const VMat B, const Persist P, const int M, const int N,
+                                                                        const int K, const int nitems) {
+    constexpr int BN = 128, VA = 4, VB = 4, MI = 2, NJ = 2;
+    using GA = StageGeom<AK, VA, GEMM_BM>;
+    using GB = StageGeom<BKC, VB, BN>;
+    constexpr int ASZ = GA::LDS, BSZ = GB::LDS;
+    __shared__ __attribute__((aligned(16))) float smem[2 * (ASZ + BSZ)];
+    float* As = smem;
+    float* Bs = smem + 2 * ASZ;
+    const int nbn = (N + BN - 1) / BN, nbm = (M + GEMM_BM - 1) / GEMM_BM;
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    const int wm0 = (w >> 1) * 64, wn0 = (w & 1) * 64;
+    const int nk = K / GEMM_BK;
+    float* const dummy = P.dummy + (long long)blockIdx.x * GEMM_THREADS + threadIdx.x;
+
+    f32x16 acc[MI][NJ], prev[MI][NJ];
+    float* pbase = dummy;                             // previous tile: address of this lane's element (row 4*(l>>5), col l&31) of its wave's
+    int prem_m = 0, prem_n = 0;                       // 64 x 64 block; rows / columns left before M / N from there
+    bool have_prev = false;
+    float ra[GA::NREG], rb[GB::NREG];
+    unsigned ma[GA::PASSES], mb[GB::PASSES];
+
+#define TXE_P_COMPUTE(cur_)                                                                                          \
+    {                                                                                                                \
+        const float* a_l = As + (cur_) * ASZ;                                                                        \
+        const float* b_l = Bs + (cur_) * BSZ;                                                                        \
+        _Pragma("unroll") for (int kb = 0; kb < GEMM_BK / 8; ++kb) {                                                 \
+            float fa[MI][4], fb[NJ][4];                                                                              \
+            _Pragma("unroll") for (int i = 0; i < MI; ++i) frag_load<AK, GEMM_BM>(a_l, wm0 + i * 32, kb, fa[i]);     \
+            _Pragma("unroll") for (int j = 0; j < NJ; ++j) frag_load<BKC, BN>(b_l, wn0 + j * 32, kb, fb[j]);         \
+            _Pragma("unroll") for (int s = 0; s < 4; ++s)                                                            \
+                _Pragma("unroll") for (int i = 0; i < MI; ++i)                                                       \
+                    _Pragma("unroll") for (int j = 0; j < NJ; ++j)                                                   \
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][s], fb[j][s], acc[i][j], 0, 0, 0);    \
+        }                                                                                                            \
+    }
+    // 16 stores of the previous tile's 32 x 32 block (i_, j_) of this wave: register e is row (e&3) + 8*(e>>2) (+ 4 for the upper
+    // half wave, folded into pbase), column = lane & 31.  Lanes past M / N write to their own dummy word instead (no branch).
+#define TXE_P_DRAIN(i_, j_) TXE_P_DRAIN_E(i_, j_, 0, 16)
+#define TXE_P_DRAIN_E(i_, j_, e0_, e1_)                                                                              \
+    {                                                                                                                \
+        float* p0 = pbase + (long long)((i_) * 32) * P.ldc + (j_) * 32;                                              \
+        const bool cok = (j_) * 32 < prem_n;                                                                         \
+        _Pragma("unroll") for (int e = (e0_); e < (e1_); ++e) {                                                      \
+            const int roff = (e & 3) + 8 * (e >> 2);                                                                 \
+            const bool ok = cok & ((i_) * 32 + roff < prem_m);                                                       \
+            const float x = prev[i_][j_][e];                                                                         \
+            float* dst = ok ? (p0 + (long long)roff * P.ldc) : dummy;                                                \
+            *dst = P.apply_exp ? __expf(x) : x;                                                                      \
+        }                                                                                                            \
+    }
+#define TXE_P_NODRAIN
+#define TXE_P_STAGE(buf_, COMPUTE_, DRAIN_)                                                                          \
+    {                                                                                                                \
+        fast_issue<AK, VA, GEMM_BM>(A, fpa, ra, ma);                                                                 \
+        fast_issue<BKC, VB, BN>(B, fpb, rb, mb);                                                                     \
+        __builtin_amdgcn_sched_barrier(0);                                                                           \
+        COMPUTE_                                                                                                     \
+        DRAIN_                                                                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                                                           \
+        fast_finish<AK, VA, GEMM_BM>(A, fpa, ra, ma);                                                                \
+        fast_finish<BKC, VB, BN>(B, fpb, rb, mb);                                                                    \
+        stage_store<AK, VA, GEMM_BM>(As + (buf_) * ASZ, ra);                                                         \
+        stage_store<BKC, VB, BN>(Bs + (buf_) * BSZ, rb);                                                             \
+    }
+
+    // The k-tiles of a workgroup's items form ONE software-pipelined stream: k-tile t+1 is fetched while k-tile t is multiplied, and
+    // the first k-tile of the NEXT item is fetched under the last MFMA block of the current one.  `par` is the stage-buffer parity
+    // of the current item's k-tile 0.
+    int par = 0;
+    int m0 = 0, n0 = 0;
+    FastPtr<AK, VA, GEMM_BM> fpa;
+    FastPtr<BKC, VB, BN> fpb;
+    auto locate = [&](const int item) {
+        const int lb = xcd_remap(item, nitems);
+        const int tm = P.row_fast ? lb % nbm : lb / nbn, tn = P.row_fast ? lb / nbm : lb % nbn;
+        m0 = tm * GEMM_BM; n0 = tn * BN;
+        fast_init<AK, VA, GEMM_BM>(A, m0, 0, fpa);
+        fast_init<BKC, VB, BN>(B, n0, 0, fpb);
+    };
+    int item = blockIdx.x;
+    if (item < nitems) {
+        locate(item);
+        TXE_P_STAGE(0, TXE_P_NODRAIN, TXE_P_NODRAIN)
+        __syncthreads();
+    }
+#define TXE_P_STEP(c_, DRAIN_)                                                                                       \
+    TXE_P_STAGE(((c_) + 1 + par) & 1, TXE_P_COMPUTE(((c_) + par) & 1), DRAIN_)                                       \
+    __syncthreads();
+    while (item < nitems) {
+        const int cm0 = m0, cn0 = n0;
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+        int t = 0;
+        if (have_prev) {                              // (uniform; every load is consumed on the side of the branch that issued it)
+            if constexpr (DK == 4) {
+                TXE_P_STEP(0, TXE_P_DRAIN(0, 0))
+                TXE_P_STEP(1, TXE_P_DRAIN(0, 1))
+                TXE_P_STEP(2, TXE_P_DRAIN(1, 0))
+                TXE_P_STEP(3, TXE_P_DRAIN(1, 1))
+                t = 4;
+            } else {
+                TXE_P_STEP(0, TXE_P_DRAIN_E(0, 0, 0, 8))
+                TXE_P_STEP(1, TXE_P_DRAIN_E(0, 0, 8, 16))
+                TXE_P_STEP(2, TXE_P_DRAIN_E(0, 1, 0, 8))
+                TXE_P_STEP(3, TXE_P_DRAIN_E(0, 1, 8, 16))
+                TXE_P_STEP(4, TXE_P_DRAIN_E(1, 0, 0, 8))
+                TXE_P_STEP(5, TXE_P_DRAIN_E(1, 0, 8, 16))
+                TXE_P_STEP(6, TXE_P_DRAIN_E(1, 1, 0, 8))
+                TXE_P_STEP(7, TXE_P_DRAIN_E(1, 1, 8, 16))
+                t = 8;
+            }
+        }
+        for (; t < nk - 1; ++t) { TXE_P_STEP(t, TXE_P_NODRAIN) }
+        const int next = item + (int)gridDim.x;
+        if (next < nitems) {                          // last k-tile: the loads in flight are the next item's first k-tile
+            locate(next);
+            TXE_P_STEP(nk - 1, TXE_P_NODRAIN)
+        } else {
+            TXE_P_COMPUTE((nk - 1 + par) & 1)
+        }
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) prev[i][j] = acc[i][j];
+        const int r0 = cm0 + wm0 + 4 * (l >> 5), c0 = cn0 + wn0 + (l & 31);
+        pbase = P.c + (long long)r0 * P.ldc + c0;
+        prem_m = M - r0;
+        prem_n = N - c0;
+        have_prev = true;
+        par = (par + nk) & 1;
+        item = next;
+    }
+#undef TXE_P_STEP
+    if (have_prev) {
+        TXE_P_DRAIN(0, 0)
+        TXE_P_DRAIN(0, 1)
+        TXE_P_DRAIN(1, 0)
+        TXE_P_DRAIN(1, 1)
+    }
+#undef TXE_P_STAGE
+#undef TXE_P_NODRAIN
+#undef TXE_P_DRAIN
+#undef TXE_P_DRAIN_E
+#undef TXE_P_COMPUTE
+}
+
 static inline int gcd_vec(long long x) { return (x % 4 == 0) ? 4 : ((x % 2 == 0) ? 2 : 1); }
 static inline int ptr_vec(const void* p) {
     const uintptr_t a = (uintptr_t)p;
@@ -712,6 +887,12 @@ static inline int choose_bn(int M, int N, int splits, bool tail_split = false, i
         return r * bn * (bn == 64 ? (splits > 1 ? 1.1 : 1.6) : 1.0);
     };
     return cost(64) < cost(128) ? 64 : 128;
+}
+
+static inline bool gemm_persist_enabled() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("TXE_NO_PERSIST_GEMM"); v = (e && e[0] == '1') ? 0 : 1; }     // A/B switch
+    return v == 1;
 }
 
 template <bool AK, bool BKC, int VA, int VB>
@@ -753,18 +934,53 @@ static inline int gemm_launch_layout(const VMat& A, const VMat& B, const Epi& E_
     int va = vmat_vec(A), vb = vmat_vec(B);
     if (va == 1 || vb == 1) va = vb = 1;
     if (splits < 1) splits = 1;
-    const int bn = choose_bn(M, N, splits, tail_ws != nullptr, K);
+    int bn = choose_bn(M, N, splits, tail_ws != nullptr, K);
+    int tile0 = 0;
+    // whole rounds of 128 x 128 tiles of a plain product with a short reduction: persistent workgroups (gemm_persist_kernel)
+    if (splits == 1 && tail_ws != nullptr && va == 4 && vb == 4 && N > 64 && gemm_persist_enabled() && !E.mask_on && !E.act_on &&
+        E.cnt_mode == 0 && (E.c2 == nullptr || E.cols_main >= N) && (K % GEMM_BK) == 0 && K >= 5 * GEMM_BK && K <= TXE_PERSIST_MAXK &&
+        A.p2 == nullptr && B.p2 == nullptr && A.cols_main == A.cols && B.cols_main == B.cols && A.rows_main >= A.rows && B.rows_main >= B.rows &&
+        (AK ? A.cols : A.rows) >= K && (BKC ? B.cols : B.rows) >= K) {
+        const int slots = 2 * device_cu_count();
+        const int nbm = (M + GEMM_BM - 1) / GEMM_BM, nbn = (N + 127) / 128;
+        const int row_fast = (nbn > nbm) ? 1 : 0;
+        const int full_rp = AK ? (A.rows / GEMM_BM < nbm ? A.rows / GEMM_BM : nbm) : nbm;      // row panels / column tiles that lie
+        const int full_ct = BKC ? (B.rows / 128 < nbn ? B.rows / 128 : nbn) : nbn;              // wholly inside the operands
+        const long long prefix = row_fast ? (full_rp == nbm ? (long long)full_ct * nbm : 0) : (full_ct == nbn ? (long long)full_rp * nbn : 0);
+        const int nfull = (int)(prefix / slots) * slots;
+        if (nfull >= 2 * slots && tail_ws_bytes >= (size_t)slots * GEMM_THREADS * sizeof(float)) {
+            Persist P;
+            P.c = E.c; P.ldc = E.ldc; P.row_fast = row_fast; P.apply_exp = E.apply_exp; P.dummy = (float*)tail_ws;
+            static char names[4][48];
+            char* name = names[(AK ? 2 : 0) + (BKC ? 1 : 0)];
+            if (!name[0]) snprintf(name, 48, "gemm_persist_kernel<%s, %s>", AK ? "true" : "false", BKC ? "true" : "false");
+            const double all = E.alg_flops > 0.0 ? E.alg_flops : 2.0 * M * (double)N * K;
+            const double share = (double)nfull / ((double)nbm * nbn);
+            {
+                ProfScope prof(name, stream, all * share, 0);
+                if (K >= 9 * GEMM_BK) hipLaunchKernelGGL((gemm_persist_kernel<AK, BKC, 8>), dim3(slots), dim3(GEMM_THREADS), 0, stream, A, B, P, M, N, K, nfull);
+                else hipLaunchKernelGGL((gemm_persist_kernel<AK, BKC, 4>), dim3(slots), dim3(GEMM_THREADS), 0, stream, A, B, P, M, N, K, nfull);
+                TXE_CHECK_LAUNCH();
+            }
+            if (nfull == nbm * nbn) return TXE_OK;
+            tile0 = nfull;
+            bn = 128;                                      // (the rest keeps the persistent part's tile numbering)
+            if (E.alg_flops > 0.0) E.alg_flops = all * (1.0 - share);
+            else E.alg_flops = all * (1.0 - share);
+        }
+    }
     const int nbm = (M + GEMM_BM - 1) / GEMM_BM, nbn = (N + bn - 1) / bn;
     int ksplit = (K + splits - 1) / splits;
     ksplit = ((ksplit + GEMM_BK - 1) / GEMM_BK) * GEMM_BK;
     if (ksplit == 0) ksplit = GEMM_BK;
-    dim3 grid(nbm * nbn, splits);
+    dim3 grid(nbm * nbn - tile0, splits);
     Tail T;
     T.nfull = 0; T.S = 0; T.ksplit = 0; T.ws = (float*)tail_ws;
     T.row_fast = (nbn > nbm) ? 1 : 0;
+    T.tile0 = tile0;
     if (splits == 1 && tail_ws != nullptr) {
         const int slots = 2 * device_cu_count();
-        const int tiles = nbm * nbn, r = tiles % slots;
+        const int tiles = nbm * nbn - tile0, r = tiles % slots;
         const int nkt = (K + GEMM_BK - 1) / GEMM_BK;
         int S = (r > 0) ? slots / r : 0;
         if (S > nkt / 4) S = nkt / 4;                 // >= 4 k-tiles per slice
@@ -782,7 +998,7 @@ static inline int gemm_launch_layout(const VMat& A, const VMat& B, const Epi& E_
     else gemm_launch_v<AK, BKC, 1, 1>(bn, grid, stream, A, B, E, M, N, K, ksplit, T);
     TXE_CHECK_LAUNCH();
     if (T.S > 0) {
-        const int r = nbm * nbn - T.nfull;
+        const int r = nbm * nbn - tile0 - T.nfull;
         ProfScope prof(bn == 128 ? "gemm_tail_fixup_kernel<128>" : "gemm_tail_fixup_kernel<64>", stream,
                        4.0 * r * GEMM_BM * bn * (T.S + 1.0), 1);      // reads S partial tiles, writes one
         if (bn == 128) hipLaunchKernelGGL((gemm_tail_fixup_kernel<128>), dim3(r, 16), dim3(256), 0, stream, E, T, M, N);

@@ -200,6 +200,52 @@ def test_gemm_layouts_against_fp64(M, N, K):
     np.testing.assert_allclose(W.grad[0].cpu().numpy(), ref, **tol)
 
 
+@pytest.mark.parametrize("layout,M,N,K", [(0, 8300, 2048, 320), (1, 8300, 2040, 352), (2, 8200, 2048, 256), (0, 1024, 17000, 256),
+                                          (0, 8300, 2048, 160)])
+def test_gemm_whole_rounds_on_persistent_workgroups(layout, M, N, K):
+    """gemm_persist_kernel (whole rounds of 128 x 128 tiles of a short-K plain product: C drained from registers under the next
+    tile's k-loop) against the same product computed in pieces too small to qualify (gemm_kernel): bit-identical -- every layout,
+    a ragged last row panel / column tile (left to gemm_kernel), an odd number of k-tiles (stage-buffer parity flips per tile), the
+    4- and 8-k-tile drain schedules, the row-panel-fastest tile order; and against fp64"""
+    from taxoexpan_amd import _lib
+    dev = _dev()
+    rs = np.random.RandomState(layout * 7 + K)
+    ra, ca = (M, K) if layout < 2 else (K, M)
+    rb, cb = (N, K) if layout == 0 else (K, N)
+    ldb = -(-cb // 128) * 128 if layout else cb                                       # rows of B past N exist only where B is [N][K]
+    rows_b = -(-rb // 128) * 128 if layout == 0 else rb
+    A = torch.from_numpy(rs.standard_normal((ra, ca)).astype(np.float32)).to(dev)
+    Bfull = torch.zeros(rows_b, ldb, device=dev)
+    Bfull[:rb, :cb] = torch.from_numpy(rs.standard_normal((rb, cb)).astype(np.float32)).to(dev)
+    ws = torch.empty(_lib.call("txe_gemm_tail_ws_bytes"), dtype=torch.uint8, device=dev)
+
+    def run(a_ptr, lda, m, c):
+        _lib.call("txe_gemm_plain", layout, a_ptr, lda, Bfull.data_ptr(), ldb, c.data_ptr(), N, m, N, K, 1, ws.data_ptr(), ws.numel(),
+                  _lib.stream_ptr())
+    C = torch.full((M, N), 7.0, device=dev)
+    run(A.data_ptr(), ca, M, C)
+    torch.cuda.synchronize()
+    pieces = []
+    step = 3072 if N <= 4096 else 256                                                   # < 2 rounds of tiles per piece
+    for m0 in range(0, M, step):
+        m = min(step, M - m0)
+        c = torch.empty(m, N, device=dev)
+        a_ptr = A.data_ptr() + 4 * (m0 * ca if layout < 2 else m0)
+        run(a_ptr, ca, m, c)
+        pieces.append(c)
+    Cp = torch.cat(pieces)
+    # the whole rounds (2 x 512 tiles: 8,192 rows of 16 column tiles / 128 column tiles of 8 row panels) went to the persistent
+    # kernel and accumulate in plain k order like the (unsplit) pieces; the tiles behind them are k-split by gemm_kernel's tail
+    # splitting, i.e. summed in another order
+    pr, pc = (M, 16384) if N > 4096 else (8192, N)
+    assert torch.equal(C[:pr, :pc], Cp[:pr, :pc])
+    np.testing.assert_allclose(C.cpu().numpy(), Cp.cpu().numpy(), rtol=1e-4, atol=1e-4 * np.sqrt(K))
+    a = A.cpu().numpy().astype(np.float64)
+    b = Bfull[:rb, :cb].cpu().numpy().astype(np.float64)
+    ref = (a if layout < 2 else a.T) @ (b.T if layout == 0 else b)
+    np.testing.assert_allclose(C.cpu().numpy(), ref, rtol=1e-4, atol=1e-4 * np.sqrt(K))
+
+
 def test_readout_and_match_ops_against_oracle():
     from taxoexpan_amd import ops
     from taxoexpan_amd.graph import BatchedDGLGraph

@@ -137,6 +137,15 @@ def ptr(t):
     return t.data_ptr()
 
 
+_raw_stream = None
+
+
 def stream_ptr():
+    """hipStream_t of torch's current stream on the current device (the raw handle: no Stream object is built per launch)"""
+    global _raw_stream
     import torch
+    if _raw_stream is None:
+        _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", False)
+    if _raw_stream:
+        return _raw_stream(torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream

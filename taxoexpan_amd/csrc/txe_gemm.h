@@ -166,17 +166,29 @@ constexpr int GEMM_KPAD = GEMM_BK + 4;  // k-contiguous LDS row stride (floats):
 // KC = false: tile is [BK][ROWS] read along the rows (LDS [k][ROWS])
 template <bool KC, int V, int ROWS> struct StageGeom {
     static constexpr int VPR = (KC ? GEMM_BK : ROWS) / V;        // vectors per tile line
-    static constexpr int LPP = GEMM_THREADS / VPR;               // lines per pass
-    static constexpr int PASSES = (KC ? ROWS : GEMM_BK) / LPP;
+    static constexpr int LINES = KC ? ROWS : GEMM_BK;
+    // FLAT: a line's vector count does not divide the workgroup (160-wide row-contiguous tiles: 40 vectors): the thread's vector of
+    // pass p is number tid + 256 p of the tile in line-major order; otherwise whole lines per pass (uniform stride between passes)
+    static constexpr bool FLAT = (GEMM_THREADS % VPR) != 0;
+    static constexpr int LPP = GEMM_THREADS / VPR;               // lines per pass (not FLAT)
+    static constexpr int PASSES = LINES * VPR / GEMM_THREADS;
+    static_assert((LINES * VPR) % GEMM_THREADS == 0, "tile vectors per thread");
     static constexpr int NREG = PASSES * V;
     static constexpr int LDS = KC ? ROWS * GEMM_KPAD : GEMM_BK * ROWS;
 };
 
 template <bool KC, int V, int ROWS>
-__device__ __forceinline__ void stage_coord(int row0, int k0, int p, int& r, int& c) {
+__device__ __forceinline__ void stage_lq(int p, int& line, int& q) {
     using G = StageGeom<KC, V, ROWS>;
     const int t = threadIdx.x;
-    const int q = t % G::VPR, line = t / G::VPR + p * G::LPP;
+    if constexpr (G::FLAT) { const int v = t + p * GEMM_THREADS; q = v % G::VPR; line = v / G::VPR; }
+    else { q = t % G::VPR; line = t / G::VPR + p * G::LPP; }
+}
+
+template <bool KC, int V, int ROWS>
+__device__ __forceinline__ void stage_coord(int row0, int k0, int p, int& r, int& c) {
+    int line, q;
+    stage_lq<KC, V, ROWS>(p, line, q);
     if constexpr (KC) { r = row0 + line; c = k0 + q * V; }
     else { r = k0 + line; c = row0 + q * V; }
 }
@@ -235,6 +247,10 @@ template <bool KC, int V, int ROWS> struct FastPtr {
     long long pstride, adv;    // elements between passes / per k-tile (block-uniform)
     long long mpstride, madv;  // mask words between passes / per k-tile
     bool cvalid;               // row-contiguous operands: this thread's column vector lies inside the matrix
+    // FLAT geometry (row-contiguous operands only): per-pass element / mask-word offsets from pass 0, per-pass column validity
+    int off[StageGeom<KC, V, ROWS>::FLAT ? StageGeom<KC, V, ROWS>::PASSES : 1];
+    int moff[StageGeom<KC, V, ROWS>::FLAT ? StageGeom<KC, V, ROWS>::PASSES : 1];
+    unsigned cvmask;
 };
 
 template <bool KC, int V, int ROWS>
@@ -253,6 +269,23 @@ __device__ __forceinline__ void fast_init(const VMat& M, int row0, int kbeg, Fas
     f.mbase = M.mask + (long long)rr * M.mask_ld + (c >> 5);
     f.mpstride = (long long)G::LPP * M.mask_ld;
     f.madv = KC ? 1 : (long long)GEMM_BK * M.mask_ld;
+    f.cvmask = 0u;
+    if constexpr (G::FLAT) {
+        static_assert(!KC, "flat staging serves row-contiguous operands");
+        int l0, q0;
+        stage_lq<KC, V, ROWS>(0, l0, q0);
+#pragma unroll
+        for (int p = 0; p < G::PASSES; ++p) {
+            int lp, qp;
+            stage_lq<KC, V, ROWS>(p, lp, qp);
+            const int cp = row0 + qp * V;
+            const bool ok = cp + V <= M.cols;
+            f.cvmask |= ok ? (1u << p) : 0u;
+            const int cc = ok ? cp : 0, c0 = f.cvalid ? row0 + q0 * V : 0;
+            f.off[p] = (int)((lp - l0) * ld) + (cc - c0);
+            f.moff[p] = (int)((lp - l0) * M.mask_ld) + ((cc >> 5) - (c0 >> 5));
+        }
+    }
 }
 
 template <bool KC, int V, int ROWS>
@@ -260,7 +293,9 @@ __device__ __forceinline__ void fast_issue(const VMat& M, FastPtr<KC, V, ROWS>& 
     using G = StageGeom<KC, V, ROWS>;
 #pragma unroll
     for (int p = 0; p < G::PASSES; ++p) {
-        const float* a = f.base + p * f.pstride;
+        const float* a;
+        if constexpr (G::FLAT) a = f.base + f.off[p];
+        else a = f.base + p * f.pstride;
         float* v = regs + p * V;
         if constexpr (V == 4) {
             const float4 t = *reinterpret_cast<const float4*>(a);
@@ -275,7 +310,10 @@ __device__ __forceinline__ void fast_issue(const VMat& M, FastPtr<KC, V, ROWS>& 
     f.base += f.adv;
     if (M.mask_on) {                                    // block-uniform; only dropout operands pay the extra word loads
 #pragma unroll
-        for (int p = 0; p < G::PASSES; ++p) mws[p] = f.mbase[p * f.mpstride];
+        for (int p = 0; p < G::PASSES; ++p) {
+            if constexpr (G::FLAT) mws[p] = f.mbase[f.moff[p]];
+            else mws[p] = f.mbase[p * f.mpstride];
+        }
         f.mbase += f.madv;
     }
 }
@@ -284,27 +322,34 @@ template <bool KC, int V, int ROWS>
 __device__ __forceinline__ void fast_finish(const VMat& M, const FastPtr<KC, V, ROWS>& f, float* regs, const unsigned* mws) {
     using G = StageGeom<KC, V, ROWS>;
     if constexpr (!KC) {
+        if constexpr (G::FLAT) {
 #pragma unroll
-        for (int i = 0; i < G::NREG; ++i) regs[i] = f.cvalid ? regs[i] : 0.f;
+            for (int i = 0; i < G::NREG; ++i) regs[i] = ((f.cvmask >> (i / V)) & 1u) ? regs[i] : 0.f;
+        } else {
+#pragma unroll
+            for (int i = 0; i < G::NREG; ++i) regs[i] = f.cvalid ? regs[i] : 0.f;
+        }
     }
     if (M.mask_on) {
-        const int bit0 = ((threadIdx.x % G::VPR) * V) & 31;      // column of element 0 inside its mask word (tile starts are x32)
 #pragma unroll
-        for (int p = 0; p < G::PASSES; ++p)
+        for (int p = 0; p < G::PASSES; ++p) {
+            int lp, qp;
+            stage_lq<KC, V, ROWS>(p, lp, qp);
+            const int bit0 = (qp * V) & 31;                      // column of element 0 inside its mask word (tile starts are x32)
 #pragma unroll
             for (int e = 0; e < V; ++e)
                 regs[p * V + e] = ((mws[p] >> (bit0 + e)) & 1u) ? regs[p * V + e] * M.drop_scale : 0.f;
+        }
     }
 }
 
 template <bool KC, int V, int ROWS>
 __device__ __forceinline__ void stage_store(float* lds, const float* regs) {
     using G = StageGeom<KC, V, ROWS>;
-    const int t = threadIdx.x;
-    const int q = t % G::VPR, line0 = t / G::VPR;
 #pragma unroll
     for (int p = 0; p < G::PASSES; ++p) {
-        const int line = line0 + p * G::LPP;
+        int line, q;
+        stage_lq<KC, V, ROWS>(p, line, q);
         float* d = KC ? (lds + line * GEMM_KPAD + q * V) : (lds + line * ROWS + q * V);
 #pragma unroll
         for (int e = 0; e < V; ++e) d[e] = regs[p * V + e];
@@ -385,9 +430,9 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_kernel(VMat A, VMat B, c
     using GB = StageGeom<BKC, VB, BN>;
     constexpr int ASZ = GA::LDS, BSZ = GB::LDS;
     constexpr int MI = (BN == 128) ? 2 : 1;          // 32-row MFMA tiles per wave along m
-    constexpr int NJ = 2;                            // along n
+    constexpr int NJ = (BN == 160) ? 5 : 2;          // along n   (BN = 160: 4 x 1 waves of 32 x 160 -- a 320-column output in two tiles)
     constexpr int CLD = BN + 4;                       // row stride of the C tile staged for the epilogue
-    constexpr int SMEM = (2 * (ASZ + BSZ) > GEMM_BM * CLD) ? 2 * (ASZ + BSZ) : GEMM_BM * CLD;
+    constexpr int SMEM = (BN == 160 || 2 * (ASZ + BSZ) > GEMM_BM * CLD) ? 2 * (ASZ + BSZ) : GEMM_BM * CLD;   // (BN = 160 stores from registers)
     __shared__ __attribute__((aligned(16))) float smem[SMEM];
     float* As = smem;
     float* Bs = smem + 2 * ASZ;
@@ -529,6 +574,23 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_kernel(VMat A, VMat B, c
 #undef TXE_NOTHING
 #undef TXE_COMPUTE_TILE
 
+    if constexpr (BN == 160) {
+        // plain epilogue straight from the accumulators (the 164-float C rows of a 128 x 160 tile do not fit beside nothing in the
+        // operand stages' 72 KB; the launcher sends only plain / exp epilogues without tail splitting here): register e of a
+        // 32 x 32 block is row (e&3) + 8*(e>>2) + 4*(lane>>5), column lane&31 -- the 32 lanes of a half wave write 128 contiguous bytes
+        float* cb = E.c + (long long)zslice * E.split_stride;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int n = n0 + j * 32 + (l & 31);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = m0 + wm0 + 4 * (l >> 5) + (e & 3) + 8 * (e >> 2);
+                const float x = acc[0][j][e];
+                if (m < M && n < N) cb[(long long)m * E.ldc + n] = E.apply_exp ? __expf(x) : x;
+            }
+        }
+        return;
+    }
     // epilogue.  C/D layout of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) -- a lane's registers
     // walk DOWN a column, so storing them directly issues 64 scattered dword stores per thread (store-issue bound: ~10 us of
     // a 60 us K=320 round).  The tile is transposed through the (now idle) operand stages instead: every thread then owns
@@ -615,7 +677,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_kernel(VMat A, VMat B, c
     const bool vec_c2 = ((E.ldc2 & 3) == 0) && ((reinterpret_cast<uintptr_t>(E.c2) & 15) == 0) && ((E.cols_main & 3) == 0);
     const bool vec_act = (E.act_on == 0) || (((E.ld_act & 3) == 0) && ((reinterpret_cast<uintptr_t>(E.act_src) & 15) == 0));
     constexpr int NCH = GEMM_BM * C4 / GEMM_THREADS;  // chunks per thread (16 / 8)
-    constexpr int UB = 8;                             // chunks whose extras are fetched together (independent loads in flight)
+    constexpr int UB = (NCH % 8 == 0) ? 8 : 5;        // chunks whose extras are fetched together (independent loads in flight)
     static_assert(NCH % UB == 0, "chunk batches");
     const int w1max = E.mask_on ? E.mask_ld - 1 : 0;
     for (int cb = 0; cb < NCH; cb += UB) {
@@ -869,9 +931,21 @@ int device_cu_count();     // txe_profile.hip (cached hipDeviceAttributeMultipro
 
 // 128 x BN tile choice: the narrower tile when it wastes fewer MFMA columns or needs fewer (fractional) rounds of
 // workgroups over the CUs (2 co-resident workgroups per CU).
-static inline int choose_bn(int M, int N, int splits, bool tail_split = false, int K = 0) {
+static inline bool bn160_enabled() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("TXE_NO_BN160"); v = (e && e[0] == '1') ? 0 : 1; }     // A/B switch
+    return v == 1;
+}
+
+static inline int choose_bn(int M, int N, int splits, bool tail_split = false, int K = 0, bool allow160 = false) {
     if (N <= 64) return 64;
     const int slots = 2 * device_cu_count();
+    if (allow160 && splits > 1 && bn160_enabled()) {
+        // split-K products (weight gradients): 128 x 160 tiles when they cover N with fewer padded columns than 128-wide ones and at
+        // least as few as 64-wide ones -- 320 = 2 x 160 runs the full-rate 4-wave k-loop where 5 x 64 starves the matrix pipe
+        const int w160 = ((N + 159) / 160) * 160, w128 = ((N + 127) / 128) * 128, w64 = ((N + 63) / 64) * 64;
+        if (w160 < w128 && w160 < w64) return 160;
+    }
     auto cost = [&](int bn) {
         const long long blocks = (long long)((M + GEMM_BM - 1) / GEMM_BM) * ((N + bn - 1) / bn) * splits;
         const long long rounds = (blocks + slots - 1) / slots;
@@ -901,16 +975,22 @@ static inline void gemm_launch_v(int bn, dim3 grid, hipStream_t stream, const VM
     // profiler record named exactly like rocprofv3 prints the kernel (minus "void txe::"), so that bench.py can join its
     // HIP-event timings with the committed rocprof summaries under profiles/
     char* name = nullptr;
-    static char names[2][64];
+    static char names[3][64];
     static bool init = false;
     if (!init) {
-        for (int b = 0; b < 2; ++b)
+        for (int b = 0; b < 3; ++b)
             snprintf(names[b], sizeof(names[b]), "gemm_kernel<%s, %s, %d, %d, %d>", AK ? "true" : "false", BKC ? "true" : "false", VA, VB,
-                     b ? 64 : 128);
+                     b == 0 ? 128 : (b == 1 ? 64 : 160));
         init = true;
     }
-    name = names[bn == 128 ? 0 : 1];
+    name = names[bn == 128 ? 0 : (bn == 64 ? 1 : 2)];
     ProfScope prof(name, stream, E.alg_flops > 0.0 ? E.alg_flops : 2.0 * M * (double)N * K, 0);
+    if constexpr (!AK && !BKC && VA == 4 && VB == 4) {      // (the only layout that asks for 160-wide tiles: weight gradients)
+        if (bn == 160) {
+            hipLaunchKernelGGL((gemm_kernel<AK, BKC, VA, VB, 160>), grid, dim3(GEMM_THREADS), 0, stream, A, B, E, M, N, K, ksplit, T);
+            return;
+        }
+    }
     if (bn == 128) hipLaunchKernelGGL((gemm_kernel<AK, BKC, VA, VB, 128>), grid, dim3(GEMM_THREADS), 0, stream, A, B, E, M, N, K, ksplit, T);
     else hipLaunchKernelGGL((gemm_kernel<AK, BKC, VA, VB, 64>), grid, dim3(GEMM_THREADS), 0, stream, A, B, E, M, N, K, ksplit, T);
 }
@@ -934,7 +1014,9 @@ static inline int gemm_launch_layout(const VMat& A, const VMat& B, const Epi& E_
     int va = vmat_vec(A), vb = vmat_vec(B);
     if (va == 1 || vb == 1) va = vb = 1;
     if (splits < 1) splits = 1;
-    int bn = choose_bn(M, N, splits, tail_ws != nullptr, K);
+    const bool allow160 = !AK && !BKC && va == 4 && vb == 4 && !E.mask_on && !E.act_on && E.cnt_mode == 0 &&
+                          (E.c2 == nullptr || E.cols_main >= N);
+    int bn = choose_bn(M, N, splits, tail_ws != nullptr, K, allow160);
     int tile0 = 0;
     // whole rounds of 128 x 128 tiles of a plain product with a short reduction: persistent workgroups (gemm_persist_kernel)
     if (splits == 1 && tail_ws != nullptr && va == 4 && vb == 4 && N > 64 && gemm_persist_enabled() && !E.mask_on && !E.act_on &&
@@ -1016,6 +1098,21 @@ static inline int choose_splits(int M, int N, int K) {
     const int nkt = (K + GEMM_BK - 1) / GEMM_BK;
     int best = 1;
     double best_cost = 1e30;
+    {   // 160-wide tiles (choose_bn's rule; the weight gradients are the TN products that get them)
+        const int w160 = ((N + 159) / 160) * 160, w128 = ((N + 127) / 128) * 128, w64 = ((N + 63) / 64) * 64;
+        if (N > 64 && w160 < w128 && w160 < w64 && bn160_enabled()) {
+            const int tiles = ((M + GEMM_BM - 1) / GEMM_BM) * (w160 / 160);
+            for (int s = 2; s <= 64 && s <= max_by_k; ++s) {
+                const long long blocks = (long long)tiles * s;
+                const long long rounds = (blocks + slots - 1) / slots;
+                const double kt = (double)((nkt + s - 1) / s);
+                const double cost = (double)rounds * (kt + 2.0) * 1.25 + 0.004 * nkt * s * 1.25;
+                if (cost < best_cost) { best_cost = cost; best = s; }
+            }
+            if (best > 1) return best;
+            best_cost = 1e30;
+        }
+    }
     for (int bn = 64; bn <= 128; bn += 64) {                      // the launcher's choose_bn() applies the same per-tile costs
         if (bn == 64 && N <= 64) continue;
         const int tiles = ((M + GEMM_BM - 1) / GEMM_BM) * ((N + bn - 1) / bn);

@@ -176,7 +176,8 @@ def test_gcn_layer_generic_graph_fwd_bwd(K, Fo):
     np.testing.assert_allclose(layer.bias.grad.cpu().numpy(), b.grad.numpy(), rtol=2e-3, atol=2e-5)
 
 
-@pytest.mark.parametrize("M,N,K", [(1, 1, 1), (129, 257, 33), (300, 2008, 300), (77, 130, 2050), (256, 128, 64)])
+@pytest.mark.parametrize("M,N,K", [(1, 1, 1), (129, 257, 33), (300, 2008, 300), (77, 130, 2050), (256, 128, 64),
+                                   (200, 160, 4000), (132, 480, 3000), (100, 2080, 1500)])     # (the last three: 128 x 160 tiles in the TN product)
 def test_gemm_layouts_against_fp64(M, N, K):
     """the three operand layouts of the MFMA GEMM through public entry points (bilinear project = NN, score block = NT,
     bilinear backward dW = TN) against an fp64 host product"""

@@ -187,7 +187,7 @@ int txe_linear_bwd(const float* x1, long long ld1, int l, const float* x2, long 
 /* ---- all-candidate scoring loop: test_fast.py:116-123 / infer.py:95-99.  U = txe_bilinear_project(hg, W) once, then
  * per query block S[q][g] = match(hg[g], Q[q]) for every candidate g. */
 int txe_score_block(const float* Q, long long ld_q, int nq, const float* U, long long ld_u, int G, int r, int apply_exp, float* S,
-                    long long ld_s, void* stream);
+                    long long ld_s, void* ws, size_t ws_bytes, void* stream);   /* ws: optional, txe_gemm_tail_ws_bytes() of scratch */
 
 /* fused scoring + ranking: the score tile is compared in the GEMM epilogue and never stored.  counts [pos_off[nq]] int32
  * (zeroed by the caller; shards of candidates add) += #{g : score(q, g) strictly better than thr[j]}; thr[j] = score of query q's j-th
@@ -289,6 +289,7 @@ int txe_profile_enable(int on);
 int txe_profile_reset(void);
 int txe_profile_count(void);
 int txe_profile_get(int i, char* name_buf, int buf_len, float* ms, double* work, int* kind);
+int txe_profile_stream(int i, void** stream);   /* the hipStream_t record i was launched on */
 
 /* model/loss.py:52-57 info_nce_loss = F.cross_entropy(output [B][C], target [B], reduction="sum") on the [queries][1 + negatives]
  * regrouping of trainer.py:52-56, together with its gradient:  loss[0] = sum_b (logsumexp(x_b) - x_b[target_b]),

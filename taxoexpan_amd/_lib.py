@@ -55,7 +55,7 @@ SIGNATURES = {
     "txe_bilinear_query_bwd": (I, [P, L, P, L, I, I, I, I, P, P, P, P, L, P, P, SZ, P]),
     "txe_bilinear_pair_bwd_ws_bytes": (SZ, [I, I, I]),
     "txe_bilinear_pair_bwd": (I, [P, L, P, L, I, I, I, P, I, P, P, P, P, L, P, L, P, P, SZ, P]),
-    "txe_score_block": (I, [P, L, I, P, L, I, I, I, P, L, P]),
+    "txe_score_block": (I, [P, L, I, P, L, I, I, I, P, L, P, SZ, P]),
     "txe_score_count_block": (I, [P, L, I, P, L, I, I, I, P, P, I, P, P]),
     "txe_rank_finalize": (I, [P, I, P, P, I, P, P]),
     "txe_gemm_tail_ws_bytes": (SZ, []),
@@ -86,6 +86,7 @@ SIGNATURES = {
     "txe_profile_reset": (I, []),
     "txe_profile_count": (I, []),
     "txe_profile_get": (I, [I, P, I, P, P, P]),
+    "txe_profile_stream": (I, [I, P]),
 }
 
 class GatPrepareDesc(C.Structure):

@@ -697,7 +697,7 @@ struct KName {
     KName(const char* base, int a, int b) { snprintf(s, sizeof(s), "%s<%d, %d>", base, a, b); }
     KName(const char* base, int a) { snprintf(s, sizeof(s), "%s<%d>", base, a); }
     KName(const char* base, int a, int b, int c) { snprintf(s, sizeof(s), "%s<%d, %d, %d>", base, a, b, c); }
-    KName(const char* base, int a, int b, int c, int) { snprintf(s, sizeof(s), "%s<%d, %d, %d, true>", base, a, b, c); }
+    KName(const char* base, int a, int b, int c, bool d) { snprintf(s, sizeof(s), "%s<%d, %d, %d, %s>", base, a, b, c, d ? "true" : "false"); }
 };
 
 #define TXE_DISPATCH_VEC_NI(vec, ni, LAUNCH)                                     \
@@ -742,7 +742,7 @@ int txe_gat_aggregate_fwd(const int* rowptr_in, const int* col_src, int n_nodes,
     // algorithmic (compulsory) bytes, SURVEY 8d: read ft + write out + a_src/a_dst + CSR (+ alpha when kept for backward);
     // the edge count is not known here (device rowptr), the E-proportional terms are added by the caller-side model
     const int ni = pick_ni(H * D / vec);
-    const KName kn("gat_aggregate_fwd_kernel", vec, ni, nx_a12 ? (nx.mask ? 2 : 1) : 0);
+    const KName kn("gat_aggregate_fwd_kernel", vec, ni, nx_a12 ? (nx.mask ? 2 : 1) : 0, false);
     ProfScope prof(kn.s, s, 4.0 * (2.0 * n_nodes * (double)H * D + 2.0 * n_nodes * H + n_nodes + 1), 1);
 #define TXE_L(V, I)                                                                                                               \
     hipLaunchKernelGGL((gat_aggregate_fwd_kernel<V, I, 0>), dim3(nb), dim3(GAT_WAVES * 64), 0, s, rowptr_in, col_src, n_nodes, \
@@ -788,7 +788,7 @@ int txe_gat_aggregate_table_fwd(const int* rowptr_in, const int* col_src, int n_
     tab.rid = rid; tab.pos = pos; tab.t2 = T2; tab.vocab = vocab;
     const int ni = pick_ni(H * D / 4);
     const size_t lds = table_lds_bytes(ld_t, vocab, nx.kp);
-    const KName kn("gat_aggregate_fwd_kernel", 4, ni, nx_a12 ? 1 : 0, 1);
+    const KName kn("gat_aggregate_fwd_kernel", 4, ni, nx_a12 ? 1 : 0, true);
     ProfScope prof(kn.s, s, 4.0 * (2.0 * n_nodes * (double)H * D + 2.0 * n_nodes * H + 3.0 * n_nodes + 1), 1);
 #define TXE_LT(I, X)                                                                                                              \
     hipLaunchKernelGGL((gat_aggregate_fwd_kernel<4, I, X, true>), dim3(nb), dim3(GAT_WAVES * 64), lds, s, rowptr_in, col_src, n_nodes, T, \

@@ -94,6 +94,9 @@ struct Epi {
     int* cnt_out;
     // profiling only: the product's ALGORITHMIC flops when the operands carry tile padding (0: 2*M*N*K as launched)
     double alg_flops;
+    // 1: every element is accumulated in plain k order whatever the tile count (no k-split of a last partial round): the scoring
+    // loop compares scores of different launches bit for bit
+    int plain_k_order;
 };
 
 static inline Epi epi_plain(float* c, long long ldc, int cols) {
@@ -104,6 +107,7 @@ static inline Epi epi_plain(float* c, long long ldc, int cols) {
     e.apply_exp = 0; e.split_stride = 0;
     e.cnt_mode = 0; e.cnt_off = nullptr; e.cnt_thr = nullptr; e.cnt_out = nullptr;
     e.alg_flops = 0.0;
+    e.plain_k_order = 0;
     return e;
 }
 static inline void epi_set_mask(Epi& e, const unsigned* mask, int total_cols, int col0, float drop_p) {
@@ -1016,7 +1020,8 @@ static inline int gemm_launch_layout(const VMat& A, const VMat& B, const Epi& E_
     if (splits < 1) splits = 1;
     const bool allow160 = !AK && !BKC && va == 4 && vb == 4 && !E.mask_on && !E.act_on && E.cnt_mode == 0 &&
                           (E.c2 == nullptr || E.cols_main >= N);
-    int bn = choose_bn(M, N, splits, tail_ws != nullptr, K, allow160);
+    const bool tail_split = tail_ws != nullptr && !E.plain_k_order;
+    int bn = choose_bn(M, N, splits, tail_split, K, allow160);
     int tile0 = 0;
     // whole rounds of 128 x 128 tiles of a plain product with a short reduction: persistent workgroups (gemm_persist_kernel)
     if (splits == 1 && tail_ws != nullptr && va == 4 && vb == 4 && N > 64 && gemm_persist_enabled() && !E.mask_on && !E.act_on &&
@@ -1033,9 +1038,10 @@ static inline int gemm_launch_layout(const VMat& A, const VMat& B, const Epi& E_
         if (nfull >= 2 * slots && tail_ws_bytes >= (size_t)slots * GEMM_THREADS * sizeof(float)) {
             Persist P;
             P.c = E.c; P.ldc = E.ldc; P.row_fast = row_fast; P.apply_exp = E.apply_exp; P.dummy = (float*)tail_ws;
-            static char names[4][48];
-            char* name = names[(AK ? 2 : 0) + (BKC ? 1 : 0)];
-            if (!name[0]) snprintf(name, 48, "gemm_persist_kernel<%s, %s>", AK ? "true" : "false", BKC ? "true" : "false");
+            static char names[2][48];                    // (per template instantiation of this launcher: one AK / BKC pair)
+            const int dk = K >= 9 * GEMM_BK ? 8 : 4;
+            char* name = names[dk == 8];
+            if (!name[0]) snprintf(name, 48, "gemm_persist_kernel<%s, %s, %d>", AK ? "true" : "false", BKC ? "true" : "false", dk);
             const double all = E.alg_flops > 0.0 ? E.alg_flops : 2.0 * M * (double)N * K;
             const double share = (double)nfull / ((double)nbm * nbn);
             {
@@ -1060,7 +1066,7 @@ static inline int gemm_launch_layout(const VMat& A, const VMat& B, const Epi& E_
     T.nfull = 0; T.S = 0; T.ksplit = 0; T.ws = (float*)tail_ws;
     T.row_fast = (nbn > nbm) ? 1 : 0;
     T.tile0 = tile0;
-    if (splits == 1 && tail_ws != nullptr) {
+    if (splits == 1 && tail_split) {
         const int slots = 2 * device_cu_count();
         const int tiles = nbm * nbn - tile0, r = tiles % slots;
         const int nkt = (K + GEMM_BK - 1) / GEMM_BK;

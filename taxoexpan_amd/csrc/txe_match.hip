@@ -351,13 +351,18 @@ int txe_linear_bwd(const float* x1, long long ld1, int l, const float* x2, long 
 
 // One block of the scoring loop: S[q][g] = <Q[q], U[g]> (exp optionally), q < nq, g < G.  S row stride ld_s.
 int txe_score_block(const float* Q, long long ld_q, int nq, const float* U, long long ld_u, int G, int r, int apply_exp, float* S,
-                    long long ld_s, void* stream) {
+                    long long ld_s, void* ws, size_t ws_bytes, void* stream) {
     if (nq < 0 || G < 0 || r < 1 || ld_u < r || !Q || !U || !S) return TXE_ERR_ARG;
     VMat A = vmat_plain(Q, ld_q, nq, r);
     VMat B = vmat_plain(U, ld_u, G, r);
     Epi E = epi_plain(S, ld_s, G);
     E.apply_exp = apply_exp;
-    return gemm_nt(A, B, E, nq, G, r, 1, (hipStream_t)stream);
+    // with the GEMM scratch (txe_gemm_tail_ws_bytes) the whole rounds of score tiles run on persistent workgroups (short reduction,
+    // 11.7 GB of scores per 8,192 MAG-Full queries: the C stores are the cost).  Never split along k: the fused ranking compares
+    // scores of different launches (thresholds from here, the count epilogue's own tiles) bit for bit
+    E.plain_k_order = 1;
+    const bool ok = ws && ws_bytes >= gemm_tail_ws_bytes();
+    return gemm_nt(A, B, E, nq, G, r, 1, (hipStream_t)stream, ok ? ws : nullptr, ok ? ws_bytes : 0);
 }
 
 // Fused scoring + ranking of one block of the loop: the score tile never leaves the workgroup.

@@ -15,6 +15,7 @@ struct ProfRec {
     hipEvent_t a, b;
     double work;
     int kind;  // 0 = flops, 1 = bytes
+    hipStream_t stream;
 };
 
 static bool g_on = false;
@@ -47,6 +48,7 @@ int prof_begin(const char* name, hipStream_t s, double work, int kind) {
     ProfRec r;
     strncpy(r.name, name, sizeof(r.name) - 1); r.name[sizeof(r.name) - 1] = 0; r.work = work; r.kind = kind;
     r.a = take_event(); r.b = take_event();
+    r.stream = s;
     (void)hipEventRecord(r.a, s);
     g_recs.push_back(r);
     return (int)g_recs.size() - 1;
@@ -83,6 +85,14 @@ int txe_profile_get(int i, char* name_buf, int buf_len, float* ms, double* work,
     name_buf[buf_len - 1] = 0;
     *work = r.work;
     *kind = r.kind;
+    return TXE_OK;
+}
+
+// stream record i was launched on (a caller that overlaps kernels on a second stream tells the critical path's launches from the
+// ones whose duration is stretched by sharing the machine)
+int txe_profile_stream(int i, void** stream) {
+    if (i < 0 || i >= (int)g_recs.size() || !stream) return TXE_ERR_ARG;
+    *stream = (void*)g_recs[i].stream;
     return TXE_OK;
 }
 

@@ -1099,7 +1099,8 @@ def score_block(Q, U, apply_exp, out=None):
     G = U.shape[0]
     S = out if out is not None else _empty((nq, (G + 3) // 4 * 4), Q)[:, :G]     # 16-byte row pitch: vector stores / rank sweeps
     with torch.cuda.device(Q.device):
-        call("txe_score_block", ptr(Q), ldq, nq, ptr(U), ldu, G, r, int(apply_exp), ptr(S), S.stride(0), _lib.stream_ptr())
+        tws = _tail_ws(Q)
+        call("txe_score_block", ptr(Q), ldq, nq, ptr(U), ldu, G, r, int(apply_exp), ptr(S), S.stride(0), ptr(tws), tws.numel(), _lib.stream_ptr())
     return S
 
 

@@ -35,10 +35,28 @@ def summarize(src, wl, tag):
     ks = os.path.join(src, f"{wl}_kt_kernel_stats.csv")
     if os.path.exists(ks):
         rows = list(csv.DictReader(open(ks)))
+        # which HIP stream (HSA queue) a kernel runs on, from the kernel trace: the queue with the most kernel time is the caller's
+        # stream; launches on another queue run UNDER main-stream kernels (second-stream overlap) -- their durations are
+        # stretched by sharing the machine and they are off the critical path
+        queue_of = {}
+        kt = os.path.join(src, f"{wl}_kt_kernel_trace.csv")
+        if os.path.exists(kt):
+            busy, per = collections.defaultdict(float), collections.defaultdict(lambda: collections.defaultdict(float))
+            for r in csv.DictReader(open(kt)):
+                d = float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
+                busy[r["Queue_Id"]] += d
+                per[r["Kernel_Name"]][r["Queue_Id"]] += d
+            main_q = max(busy, key=busy.get) if busy else None
+            for k, qs in per.items():
+                on_main = qs.get(main_q, 0.0)
+                tot = sum(qs.values())
+                queue_of[k] = "main" if on_main >= 0.999 * tot else ("2nd" if on_main <= 0.001 * tot else f"main {100 * on_main / tot:.0f}% / 2nd")
         lines += ["## kernel-trace --stats (" + ("python bench.py --steps 20 --warmup 5 --no-extra --no-cpu-baseline" if wl == "pgat" else f"TXE_PROF_WORKLOAD={wl} python tools/profile_workload.py") + ")", "",
-                  "| kernel | calls | total ms | avg us | % |", "|---|---|---|---|---|"]
+                  "stream: `main` = the caller's stream (critical path); `2nd` = the library's second stream -- those launches run concurrently with",
+                  "main-stream kernels, their durations are stretched by sharing the machine and do not add to the step time.", "",
+                  "| kernel | calls | total ms | avg us | % | stream |", "|---|---|---|---|---|---|"]
         for r in rows[:40]:
-            lines.append(f"| `{short(r['Name'])}` | {r['Calls']} | {float(r['TotalDurationNs'])/1e6:.2f} | {float(r['AverageNs'])/1e3:.1f} | {float(r['Percentage']):.2f} |")
+            lines.append(f"| `{short(r['Name'])}` | {r['Calls']} | {float(r['TotalDurationNs'])/1e6:.2f} | {float(r['AverageNs'])/1e3:.1f} | {float(r['Percentage']):.2f} | {queue_of.get(r['Name'], '')} |")
         lines.append("")
 
     traffic = {}

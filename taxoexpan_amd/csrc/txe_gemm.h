@@ -950,6 +950,14 @@ static inline int choose_bn(int M, int N, int splits, bool tail_split = false, i
         const int w160 = ((N + 159) / 160) * 160, w128 = ((N + 127) / 128) * 128, w64 = ((N + 63) / 64) * 64;
         if (w160 < w128 && w160 < w64) return 160;
     }
+    if (allow160 && splits == 1 && bn160_enabled()) {
+        // one round of 160-wide tiles where 128-wide ones spill into a second, k-split round with its fix-up launch
+        // (dZ = d_hg W: 4096 x 2080 is 32 x 13 = 416 tiles of 160 columns, 544 of 128)
+        const int nbm = (M + GEMM_BM - 1) / GEMM_BM;
+        const int t160 = nbm * ((N + 159) / 160), t128 = nbm * ((N + 127) / 128);
+        const int w160 = ((N + 159) / 160) * 160, w128 = ((N + 127) / 128) * 128;
+        if (t160 <= slots && t128 > slots && t160 * 5 >= slots * 3 && w160 <= w128) return 160;
+    }
     auto cost = [&](int bn) {
         const long long blocks = (long long)((M + GEMM_BM - 1) / GEMM_BM) * ((N + bn - 1) / bn) * splits;
         const long long rounds = (blocks + slots - 1) / slots;
@@ -989,7 +997,7 @@ static inline void gemm_launch_v(int bn, dim3 grid, hipStream_t stream, const VM
     }
     name = names[bn == 128 ? 0 : (bn == 64 ? 1 : 2)];
     ProfScope prof(name, stream, E.alg_flops > 0.0 ? E.alg_flops : 2.0 * M * (double)N * K, 0);
-    if constexpr (!AK && !BKC && VA == 4 && VB == 4) {      // (the only layout that asks for 160-wide tiles: weight gradients)
+    if constexpr (!BKC && VA == 4 && VB == 4) {      // (160-wide tiles: B row-contiguous -- weight gradients (TN), dZ = d_hg W (NN))
         if (bn == 160) {
             hipLaunchKernelGGL((gemm_kernel<AK, BKC, VA, VB, 160>), grid, dim3(GEMM_THREADS), 0, stream, A, B, E, M, N, K, ksplit, T);
             return;
@@ -1018,7 +1026,7 @@ static inline int gemm_launch_layout(const VMat& A, const VMat& B, const Epi& E_
     int va = vmat_vec(A), vb = vmat_vec(B);
     if (va == 1 || vb == 1) va = vb = 1;
     if (splits < 1) splits = 1;
-    const bool allow160 = !AK && !BKC && va == 4 && vb == 4 && !E.mask_on && !E.act_on && E.cnt_mode == 0 &&
+    const bool allow160 = !BKC && va == 4 && vb == 4 && !E.mask_on && !E.act_on && E.cnt_mode == 0 &&
                           (E.c2 == nullptr || E.cols_main >= N);
     const bool tail_split = tail_ws != nullptr && !E.plain_k_order;
     int bn = choose_bn(M, N, splits, tail_split, K, allow160);

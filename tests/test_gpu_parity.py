@@ -177,7 +177,7 @@ def test_gcn_layer_generic_graph_fwd_bwd(K, Fo):
 
 
 @pytest.mark.parametrize("M,N,K", [(1, 1, 1), (129, 257, 33), (300, 2008, 300), (77, 130, 2050), (256, 128, 64),
-                                   (200, 160, 4000), (132, 480, 3000), (100, 2080, 1500)])     # (the last three: 128 x 160 tiles in the TN product)
+                                   (200, 160, 4000), (132, 480, 3000), (100, 2080, 1500)])
 def test_gemm_layouts_against_fp64(M, N, K):
     """the three operand layouts of the MFMA GEMM through public entry points (bilinear project = NN, score block = NT,
     bilinear backward dW = TN) against an fp64 host product"""
@@ -245,6 +245,22 @@ def test_gemm_whole_rounds_on_persistent_workgroups(layout, M, N, K):
     b = Bfull[:rb, :cb].cpu().numpy().astype(np.float64)
     ref = (a if layout < 2 else a.T) @ (b.T if layout == 0 else b)
     np.testing.assert_allclose(C.cpu().numpy(), ref, rtol=1e-4, atol=1e-4 * np.sqrt(K))
+
+
+def test_gemm_split_k_on_160_wide_tiles_against_fp64():
+    """a big split-K TN product whose width 160-wide tiles cover with less padding (2080 = 13 x 160): the flat staging geometry and
+    the register epilogue of gemm_kernel<false,false,4,4,160>, partial slices summed by the caller"""
+    from taxoexpan_amd import _lib
+    dev = _dev()
+    M, N, K, S = 2048, 2080, 6016, 4
+    rs = np.random.RandomState(9)
+    A = torch.from_numpy(rs.standard_normal((K, M)).astype(np.float32)).to(dev)
+    B = torch.from_numpy(rs.standard_normal((K, N)).astype(np.float32)).to(dev)
+    C = torch.empty(S * M, N, device=dev)
+    _lib.call("txe_gemm_plain", 2, A.data_ptr(), M, B.data_ptr(), N, C.data_ptr(), N, M, N, K, S, None, 0, _lib.stream_ptr())
+    got = C.view(S, M, N).double().sum(0).cpu().numpy()
+    ref = A.cpu().numpy().astype(np.float64).T @ B.cpu().numpy().astype(np.float64)
+    np.testing.assert_allclose(got, ref, rtol=1e-4, atol=1e-4 * np.sqrt(K))
 
 
 def test_readout_and_match_ops_against_oracle():

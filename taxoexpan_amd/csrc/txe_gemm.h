@@ -274,6 +274,12 @@ __device__ __forceinline__ void fast_init(const VMat& M, int row0, int kbeg, Fas
     f.mpstride = (long long)G::LPP * M.mask_ld;
     f.madv = KC ? 1 : (long long)GEMM_BK * M.mask_ld;
     f.cvmask = 0u;
+    if constexpr (KC) {                                  // passes whose row lies inside the operand (fast_issue<..., CLAMP = true>)
+        int l0, q0;
+        stage_lq<KC, V, ROWS>(0, l0, q0);
+#pragma unroll
+        for (int p = 0; p < G::PASSES; ++p) f.cvmask |= (row0 + l0 + p * G::LPP < M.rows) ? (1u << p) : 0u;
+    }
     if constexpr (G::FLAT) {
         static_assert(!KC, "flat staging serves row-contiguous operands");
         int l0, q0;
@@ -292,13 +298,16 @@ __device__ __forceinline__ void fast_init(const VMat& M, int row0, int kbeg, Fas
     }
 }
 
-template <bool KC, int V, int ROWS>
+// CLAMP (k-contiguous operands of a ragged last row panel): a pass whose row lies past the operand re-reads pass 0's row -- always
+// readable, and the product rows it feeds are never stored
+template <bool KC, int V, int ROWS, bool CLAMP = false>
 __device__ __forceinline__ void fast_issue(const VMat& M, FastPtr<KC, V, ROWS>& f, float* regs, unsigned* mws) {
     using G = StageGeom<KC, V, ROWS>;
 #pragma unroll
     for (int p = 0; p < G::PASSES; ++p) {
         const float* a;
         if constexpr (G::FLAT) a = f.base + f.off[p];
+        else if constexpr (CLAMP && KC) a = f.base + (((f.cvmask >> p) & 1u) ? p : 0) * f.pstride;
         else a = f.base + p * f.pstride;
         float* v = regs + p * V;
         if constexpr (V == 4) {
@@ -316,6 +325,7 @@ __device__ __forceinline__ void fast_issue(const VMat& M, FastPtr<KC, V, ROWS>& 
 #pragma unroll
         for (int p = 0; p < G::PASSES; ++p) {
             if constexpr (G::FLAT) mws[p] = f.mbase[f.moff[p]];
+            else if constexpr (CLAMP && KC) mws[p] = f.mbase[(((f.cvmask >> p) & 1u) ? p : 0) * f.mpstride];
             else mws[p] = f.mbase[p * f.mpstride];
         }
         f.mbase += f.madv;
@@ -764,6 +774,10 @@ struct Persist {
     int row_fast;
     int apply_exp;
     float* dummy;    // >= gridDim.x * 256 floats: where the lanes of a tile's rows / columns past M / N put their stores
+    // work items: [0, ntile_items) whole tiles (tile = xcd_remap(item)), then n_slices k-slices of the leftover tiles -- slice i is
+    // k-tiles [ (i % S) * kslice, ... ) of tile ntile_items + i / S and parks its raw partial tile at part + i * 128 * 128
+    int ntile_items, S, kslice;
+    float* part;
 };
 
 template <bool AK, bool BKC, int DK /* k-tiles over which a tile's 64 stores per lane are spread: 4 or 8 */>
@@ -779,12 +793,13 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_persist_kernel(const VMa
     const int nbn = (N + BN - 1) / BN, nbm = (M + GEMM_BM - 1) / GEMM_BM;
     const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
     const int wm0 = (w >> 1) * 64, wn0 = (w & 1) * 64;
-    const int nk = K / GEMM_BK;
+    const int nk_all = K / GEMM_BK;
     float* const dummy = P.dummy + (long long)blockIdx.x * GEMM_THREADS + threadIdx.x;
 
     f32x16 acc[MI][NJ], prev[MI][NJ];
-    float* pbase = dummy;                             // previous tile: address of this lane's element (row 4*(l>>5), col l&31) of its wave's
-    int prem_m = 0, prem_n = 0;                       // 64 x 64 block; rows / columns left before M / N from there
+    float* pbase = dummy;                             // previous item: address of this lane's element (row 4*(l>>5), col l&31) of its wave's
+    long long pld = 0;                                // 64 x 64 block, its row pitch; rows / columns left before M / N from there
+    int prem_m = 0, prem_n = 0, pexp = 0;
     bool have_prev = false;
     float ra[GA::NREG], rb[GB::NREG];
     unsigned ma[GA::PASSES], mb[GB::PASSES];
@@ -803,26 +818,26 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_persist_kernel(const VMa
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][s], fb[j][s], acc[i][j], 0, 0, 0);    \
         }                                                                                                            \
     }
-    // 16 stores of the previous tile's 32 x 32 block (i_, j_) of this wave: register e is row (e&3) + 8*(e>>2) (+ 4 for the upper
+    // stores of the previous item's 32 x 32 block (i_, j_) of this wave: register e is row (e&3) + 8*(e>>2) (+ 4 for the upper
     // half wave, folded into pbase), column = lane & 31.  Lanes past M / N write to their own dummy word instead (no branch).
 #define TXE_P_DRAIN(i_, j_) TXE_P_DRAIN_E(i_, j_, 0, 16)
 #define TXE_P_DRAIN_E(i_, j_, e0_, e1_)                                                                              \
     {                                                                                                                \
-        float* p0 = pbase + (long long)((i_) * 32) * P.ldc + (j_) * 32;                                              \
+        float* p0 = pbase + (long long)((i_) * 32) * pld + (j_) * 32;                                                \
         const bool cok = (j_) * 32 < prem_n;                                                                         \
         _Pragma("unroll") for (int e = (e0_); e < (e1_); ++e) {                                                      \
             const int roff = (e & 3) + 8 * (e >> 2);                                                                 \
             const bool ok = cok & ((i_) * 32 + roff < prem_m);                                                       \
             const float x = prev[i_][j_][e];                                                                         \
-            float* dst = ok ? (p0 + (long long)roff * P.ldc) : dummy;                                                \
-            *dst = P.apply_exp ? __expf(x) : x;                                                                      \
+            float* dst = ok ? (p0 + (long long)roff * pld) : dummy;                                                  \
+            *dst = pexp ? __expf(x) : x;                                                                             \
         }                                                                                                            \
     }
 #define TXE_P_NODRAIN
 #define TXE_P_STAGE(buf_, COMPUTE_, DRAIN_)                                                                          \
     {                                                                                                                \
-        fast_issue<AK, VA, GEMM_BM>(A, fpa, ra, ma);                                                                 \
-        fast_issue<BKC, VB, BN>(B, fpb, rb, mb);                                                                     \
+        fast_issue<AK, VA, GEMM_BM, true>(A, fpa, ra, ma);                                                           \
+        fast_issue<BKC, VB, BN, true>(B, fpb, rb, mb);                                                               \
         __builtin_amdgcn_sched_barrier(0);                                                                           \
         COMPUTE_                                                                                                     \
         DRAIN_                                                                                                       \
@@ -837,15 +852,22 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_persist_kernel(const VMa
     // the first k-tile of the NEXT item is fetched under the last MFMA block of the current one.  `par` is the stage-buffer parity
     // of the current item's k-tile 0.
     int par = 0;
-    int m0 = 0, n0 = 0;
+    int m0 = 0, n0 = 0, nki = 0, slice = -1;          // located item: tile origin, k-tiles, slice index (-1: a whole tile)
     FastPtr<AK, VA, GEMM_BM> fpa;
     FastPtr<BKC, VB, BN> fpb;
     auto locate = [&](const int item) {
-        const int lb = xcd_remap(item, nitems);
+        int lb, kb0;
+        if (DK == 8 || item < P.ntile_items) { lb = xcd_remap(item, P.ntile_items); kb0 = 0; nki = nk_all; slice = -1; }
+        else {                                        // (k-slices only with the 4-step drain schedule: a slice may be 5 k-tiles short)
+            slice = item - P.ntile_items;
+            lb = P.ntile_items + slice / P.S;
+            kb0 = (slice % P.S) * P.kslice;
+            nki = min(P.kslice, nk_all - kb0);
+        }
         const int tm = P.row_fast ? lb % nbm : lb / nbn, tn = P.row_fast ? lb / nbm : lb % nbn;
         m0 = tm * GEMM_BM; n0 = tn * BN;
-        fast_init<AK, VA, GEMM_BM>(A, m0, 0, fpa);
-        fast_init<BKC, VB, BN>(B, n0, 0, fpb);
+        fast_init<AK, VA, GEMM_BM>(A, m0, kb0 * GEMM_BK, fpa);
+        fast_init<BKC, VB, BN>(B, n0, kb0 * GEMM_BK, fpb);
     };
     int item = blockIdx.x;
     if (item < nitems) {
@@ -857,7 +879,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_persist_kernel(const VMa
     TXE_P_STAGE(((c_) + 1 + par) & 1, TXE_P_COMPUTE(((c_) + par) & 1), DRAIN_)                                       \
     __syncthreads();
     while (item < nitems) {
-        const int cm0 = m0, cn0 = n0;
+        const int cm0 = m0, cn0 = n0, cnk = nki, cslice = slice;
 #pragma unroll
         for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -866,13 +888,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_persist_kernel(const VMa
                 for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
         int t = 0;
         if (have_prev) {                              // (uniform; every load is consumed on the side of the branch that issued it)
-            if constexpr (DK == 4) {
-                TXE_P_STEP(0, TXE_P_DRAIN(0, 0))
-                TXE_P_STEP(1, TXE_P_DRAIN(0, 1))
-                TXE_P_STEP(2, TXE_P_DRAIN(1, 0))
-                TXE_P_STEP(3, TXE_P_DRAIN(1, 1))
-                t = 4;
-            } else {
+            if constexpr (DK == 8) {
                 TXE_P_STEP(0, TXE_P_DRAIN_E(0, 0, 0, 8))
                 TXE_P_STEP(1, TXE_P_DRAIN_E(0, 0, 8, 16))
                 TXE_P_STEP(2, TXE_P_DRAIN_E(0, 1, 0, 8))
@@ -882,26 +898,36 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_persist_kernel(const VMa
                 TXE_P_STEP(6, TXE_P_DRAIN_E(1, 1, 0, 8))
                 TXE_P_STEP(7, TXE_P_DRAIN_E(1, 1, 8, 16))
                 t = 8;
+            } else {                                  // (every item has at least 5 k-tiles)
+                TXE_P_STEP(0, TXE_P_DRAIN(0, 0))
+                TXE_P_STEP(1, TXE_P_DRAIN(0, 1))
+                TXE_P_STEP(2, TXE_P_DRAIN(1, 0))
+                TXE_P_STEP(3, TXE_P_DRAIN(1, 1))
+                t = 4;
             }
         }
-        for (; t < nk - 1; ++t) { TXE_P_STEP(t, TXE_P_NODRAIN) }
+        for (; t < cnk - 1; ++t) { TXE_P_STEP(t, TXE_P_NODRAIN) }
         const int next = item + (int)gridDim.x;
         if (next < nitems) {                          // last k-tile: the loads in flight are the next item's first k-tile
             locate(next);
-            TXE_P_STEP(nk - 1, TXE_P_NODRAIN)
+            TXE_P_STEP(cnk - 1, TXE_P_NODRAIN)
         } else {
-            TXE_P_COMPUTE((nk - 1 + par) & 1)
+            TXE_P_COMPUTE((cnk - 1 + par) & 1)
         }
 #pragma unroll
         for (int i = 0; i < MI; ++i)
 #pragma unroll
             for (int j = 0; j < NJ; ++j) prev[i][j] = acc[i][j];
-        const int r0 = cm0 + wm0 + 4 * (l >> 5), c0 = cn0 + wn0 + (l & 31);
-        pbase = P.c + (long long)r0 * P.ldc + c0;
-        prem_m = M - r0;
-        prem_n = N - c0;
+        if (DK == 8 || cslice < 0) {
+            const int r0 = cm0 + wm0 + 4 * (l >> 5), c0 = cn0 + wn0 + (l & 31);
+            pbase = P.c + (long long)r0 * P.ldc + c0;
+            pld = P.ldc; prem_m = M - r0; prem_n = N - c0; pexp = P.apply_exp;
+        } else {                                      // a k-slice parks its raw partial tile; gemm_tail_fixup_kernel finishes
+            pbase = P.part + (long long)cslice * (GEMM_BM * BN) + (wm0 + 4 * (l >> 5)) * BN + wn0 + (l & 31);
+            pld = BN; prem_m = GEMM_BM; prem_n = BN; pexp = 0;
+        }
         have_prev = true;
-        par = (par + nk) & 1;
+        par = (par + cnk) & 1;
         item = next;
     }
 #undef TXE_P_STEP
@@ -1020,7 +1046,9 @@ static inline void gemm_launch_v(int bn, dim3 grid, hipStream_t stream, const VM
 // Vector widths: 16-byte loads for an operand whose rows are 16-byte aligned, else 8-byte; a 4-byte-only operand
 // drops both to scalar loads (odd leading dimensions: correctness path, not a fast one).
 // bytes of tail-splitting workspace that always suffice (r*S <= slots partial tiles of 128x128 floats)
-static inline size_t gemm_tail_ws_bytes() { return (size_t)2 * device_cu_count() * GEMM_BM * 128 * sizeof(float); }
+static inline size_t gemm_tail_ws_bytes() {       // (+ the persistent kernel's dummy words in front of its slices' partial tiles)
+    return (size_t)2 * device_cu_count() * (GEMM_BM * 128 + GEMM_THREADS) * sizeof(float);
+}
 
 template <bool AK, bool BKC>
 static inline int gemm_launch_layout(const VMat& A, const VMat& B, const Epi& E_in, int M, int N, int K, int splits,
@@ -1048,30 +1076,54 @@ static inline int gemm_launch_layout(const VMat& A, const VMat& B, const Epi& E_
         const int slots = 2 * device_cu_count();
         const int nbm = (M + GEMM_BM - 1) / GEMM_BM, nbn = (N + 127) / 128;
         const int row_fast = (nbn > nbm) ? 1 : 0;
-        const int full_rp = AK ? (A.rows / GEMM_BM < nbm ? A.rows / GEMM_BM : nbm) : nbm;      // row panels / column tiles that lie
-        const int full_ct = BKC ? (B.rows / 128 < nbn ? B.rows / 128 : nbn) : nbn;              // wholly inside the operands
-        const long long prefix = row_fast ? (full_rp == nbm ? (long long)full_ct * nbm : 0) : (full_ct == nbn ? (long long)full_rp * nbn : 0);
-        const int nfull = (int)(prefix / slots) * slots;
-        if (nfull >= 2 * slots && tail_ws_bytes >= (size_t)slots * GEMM_THREADS * sizeof(float)) {
+        // (ragged last panels are fine: k-contiguous operands re-read a valid row for the passes past the end, row-contiguous ones
+        //  zero the column vectors past it)
+        const int ntiles = nbm * nbn, nfull = (ntiles / slots) * slots, r = ntiles - nfull;
+        const int nkt = K / GEMM_BK;
+        const size_t dummy_bytes = (size_t)slots * GEMM_THREADS * sizeof(float);
+        if (nfull >= 2 * slots && tail_ws_bytes >= dummy_bytes) {
             Persist P;
             P.c = E.c; P.ldc = E.ldc; P.row_fast = row_fast; P.apply_exp = E.apply_exp; P.dummy = (float*)tail_ws;
+            P.ntile_items = nfull; P.S = 1; P.kslice = nkt; P.part = nullptr;
+            // the leftover tiles (a last partial round) as k-slices INSIDE the same launch: every workgroup's last item is then a
+            // slice of >= 5 k-tiles whose k-loop still drains the tile before it; a fix-up launch adds the slices in fixed order
+            static int no_slices = -1;
+            if (no_slices < 0) { const char* e = getenv("TXE_NO_PERSIST_SLICES"); no_slices = (e && e[0] == '1') ? 1 : 0; }   // A/B switch
+            int S = (r > 0 && tail_split && !no_slices) ? slots / r : 0;
+            if (S > nkt / 5) S = nkt / 5;
+            if (S > 16) S = 16;
+            int kslice = S >= 2 ? (nkt + S - 1) / S : nkt;
+            if (S >= 2 && (nkt - (S - 1) * kslice < 5 || dummy_bytes + (size_t)r * S * GEMM_BM * 128 * sizeof(float) > tail_ws_bytes)) S = 0;
+            int dk = K >= 9 * GEMM_BK ? 8 : 4;
+            int nitems = nfull;
+            if (S >= 2) {
+                dk = 4;
+                P.S = S; P.kslice = kslice; P.part = (float*)((char*)tail_ws + dummy_bytes);
+                nitems = nfull + r * S;
+            }
             static char names[2][48];                    // (per template instantiation of this launcher: one AK / BKC pair)
-            const int dk = K >= 9 * GEMM_BK ? 8 : 4;
             char* name = names[dk == 8];
             if (!name[0]) snprintf(name, 48, "gemm_persist_kernel<%s, %s, %d>", AK ? "true" : "false", BKC ? "true" : "false", dk);
             const double all = E.alg_flops > 0.0 ? E.alg_flops : 2.0 * M * (double)N * K;
-            const double share = (double)nfull / ((double)nbm * nbn);
+            const double share = (S >= 2) ? 1.0 : (double)nfull / (double)ntiles;
             {
                 ProfScope prof(name, stream, all * share, 0);
-                if (K >= 9 * GEMM_BK) hipLaunchKernelGGL((gemm_persist_kernel<AK, BKC, 8>), dim3(slots), dim3(GEMM_THREADS), 0, stream, A, B, P, M, N, K, nfull);
-                else hipLaunchKernelGGL((gemm_persist_kernel<AK, BKC, 4>), dim3(slots), dim3(GEMM_THREADS), 0, stream, A, B, P, M, N, K, nfull);
+                if (dk == 8) hipLaunchKernelGGL((gemm_persist_kernel<AK, BKC, 8>), dim3(slots), dim3(GEMM_THREADS), 0, stream, A, B, P, M, N, K, nitems);
+                else hipLaunchKernelGGL((gemm_persist_kernel<AK, BKC, 4>), dim3(slots), dim3(GEMM_THREADS), 0, stream, A, B, P, M, N, K, nitems);
                 TXE_CHECK_LAUNCH();
             }
-            if (nfull == nbm * nbn) return TXE_OK;
+            if (S >= 2) {
+                Tail T;
+                T.nfull = nfull; T.S = S; T.ksplit = kslice * GEMM_BK; T.ws = P.part; T.row_fast = row_fast; T.tile0 = 0;
+                ProfScope prof("gemm_tail_fixup_kernel<128>", stream, 4.0 * r * GEMM_BM * 128 * (S + 1.0), 1);
+                hipLaunchKernelGGL((gemm_tail_fixup_kernel<128>), dim3(r, 16), dim3(256), 0, stream, E, T, M, N);
+                TXE_CHECK_LAUNCH();
+                return TXE_OK;
+            }
+            if (r == 0) return TXE_OK;
             tile0 = nfull;
             bn = 128;                                      // (the rest keeps the persistent part's tile numbering)
-            if (E.alg_flops > 0.0) E.alg_flops = all * (1.0 - share);
-            else E.alg_flops = all * (1.0 - share);
+            E.alg_flops = all * (1.0 - share);
         }
     }
     const int nbm = (M + GEMM_BM - 1) / GEMM_BM, nbn = (N + bn - 1) / bn;

@@ -187,8 +187,7 @@ struct TailA {
     const float* rpart; int S; long long split_stride; int F, ldp, nbx; float* dwa;
     Seg2Args r2;
 };
-__global__ __launch_bounds__(256) void gat_bwd_reduce_a_kernel(const TailA a) {
-    int b = blockIdx.x;
+__device__ __forceinline__ void reduce_a_job(int b, const TailA& a) {
     if (b < a.nb_s1a) { segsum1_job(b, a.s1a, a.pos, a.n_rows, a.vocab, a.rows_per_block); return; }
     b -= a.nb_s1a;
     if (b < a.nb_s1b) { segsum1_job(b, a.s1b, a.pos, a.n_rows, a.vocab, a.rows_per_block); return; }
@@ -196,6 +195,7 @@ __global__ __launch_bounds__(256) void gat_bwd_reduce_a_kernel(const TailA a) {
     if (a.r_kind == 1) ext_rows_job(b / a.nbx, (b % a.nbx) * 256 + threadIdx.x, a.rpart, a.S, a.split_stride, a.F, a.ldp, a.dwa);
     else segsum2_job(b, a.r2);
 }
+__global__ __launch_bounds__(256) void gat_bwd_reduce_a_kernel(const TailA a) { reduce_a_job(blockIdx.x, a); }
 struct TailB {
     int nb_u, nb_2a, nb_2b;
     UnfoldArgs u;
@@ -1281,7 +1281,7 @@ __global__ __launch_bounds__(256) void cl_bwd_dx_kernel(int n_nodes, int ntile, 
 // The per-node leftovers of cl_bwd_dx ride along: the folded attention rows' gradient partials (sum_u da_u Xd'[u]) per workgroup,
 // and the position-embedding gradient partials from the (never stored) position columns of d_X'.
 // What is left per edge -- softmax / leaky-relu backward of the previous layer's attention from the raw d alpha -- is
-// gat_attn_bwd_kernel (edge-level, a few microseconds).
+// gat_attn_bwd_job (edge-level, a few microseconds; launched together with stage 1 of the reductions).
 // ---------------------------------------------------------------------------------------------------------------------
 #ifndef TXE_FB_NODES
 #define TXE_FB_NODES 16
@@ -1532,16 +1532,23 @@ __global__ __launch_bounds__(256, TXE_FB_OCC) void gat_fused_bwd_kernel(const Fu
 // the edges of a batched graph stay inside it, so the destination-side and source-side halves only need a workgroup barrier.
 constexpr int FA_GRAPHS = 8;
 constexpr int FA_LIGHT = 8;         // degrees up to this are walked by one thread per (node, head); heavier nodes by a whole wave
-__global__ __launch_bounds__(256) void gat_attn_bwd_kernel(const int* __restrict__ rowptr_in, const int* __restrict__ col_src,
-                                                           const int* __restrict__ rowptr_out, const int* __restrict__ pos_out,
-                                                           const int* __restrict__ graph_off, const int G, const float* __restrict__ Y,
-                                                           const long long ld_y, const int H, const int F, const float slope,
-                                                           const float* __restrict__ alpha, const float* __restrict__ dal,
-                                                           float* __restrict__ dz, float* __restrict__ d_Y, const long long ld_dy,
-                                                           const int n_pad) {
+struct AttnBwdArgs {
+    const int *rowptr_in, *col_src, *rowptr_out, *pos_out, *graph_off;
+    int G;
+    const float* Y; long long ld_y; int H, F; float slope;
+    const float *alpha, *dal;
+    float *dz, *d_Y; long long ld_dy; int n_pad;
+};
+__device__ __forceinline__ void gat_attn_bwd_job(const int bid, const AttnBwdArgs& a) {
+    const int* __restrict__ rowptr_in = a.rowptr_in; const int* __restrict__ col_src = a.col_src;
+    const int* __restrict__ rowptr_out = a.rowptr_out; const int* __restrict__ pos_out = a.pos_out;
+    const int* __restrict__ graph_off = a.graph_off; const int G = a.G;
+    const float* __restrict__ Y = a.Y; const long long ld_y = a.ld_y; const int H = a.H, F = a.F; const float slope = a.slope;
+    const float* __restrict__ alpha = a.alpha; const float* __restrict__ dal = a.dal;
+    float* __restrict__ dz = a.dz; float* __restrict__ d_Y = a.d_Y; const long long ld_dy = a.ld_dy; const int n_pad = a.n_pad;
     __shared__ int s_heavy[2][256], s_nh[2];                        // heavy destinations / sources found by the light passes
     const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
-    const int g0 = blockIdx.x * FA_GRAPHS, g1 = min(G, g0 + FA_GRAPHS);
+    const int g0 = bid * FA_GRAPHS, g1 = min(G, g0 + FA_GRAPHS);
     const int n0 = graph_off[g0], n1 = graph_off[g1];
     const int nn = n1 - n0;
     if (threadIdx.x < 2) s_nh[threadIdx.x] = 0;
@@ -1629,6 +1636,12 @@ __global__ __launch_bounds__(256) void gat_attn_bwd_kernel(const int* __restrict
             if (l == 0) d_Y[(long long)u * ld_dy + F + h] = accu;
         }
     }
+}
+// The attention backward of the layer below and stage 1 of the folded layer's reductions depend on the fused sweep only, not on each
+// other: one launch, the first nb_attn workgroups do the former.
+__global__ __launch_bounds__(256) void gat_attn_bwd_reduce_a_kernel(const AttnBwdArgs aa, const int nb_attn, const TailA a) {
+    if ((int)blockIdx.x < nb_attn) { gat_attn_bwd_job(blockIdx.x, aa); return; }
+    reduce_a_job((int)blockIdx.x - nb_attn, a);
 }
 
 struct CollapseWs {
@@ -1954,14 +1967,10 @@ int txe_gat_collapse_bwd_fused(const int* rowptr_in, const int* col_src, const i
 #undef TXE_FB_NI
 #undef TXE_FB
         }
-        {
-            ProfScope prof("gat_attn_bwd_kernel", s, 4.0 * (n_edges * (4.0 * Hp + 2.0) + n_nodes * (4.0 * Hp + n_pad)), 1);
-            hipLaunchKernelGGL(gat_attn_bwd_kernel, dim3((G + FA_GRAPHS - 1) / FA_GRAPHS), dim3(256), 0, s, rowptr_in, col_src, rowptr_out, pos_out,
-                               graph_off, G, Yp, ld_yp, Hp, F, attn_slope_p, alpha_p, (const float*)fw.dal, dz_p, d_Yp, ld_dyp, n_pad);
-        }
         TXE_CHECK_LAUNCH();
     }
-    // ---- phase A: d_wa = sum of the per-workgroup partials; readout position-weight partial sums ----
+    // ---- the layer below's attention backward (edge level, from the sweep's raw d alpha) + phase A: d_wa = sum of the per-workgroup
+    //      partials; readout position-weight partial sums -- one launch ----
     const int nseg = n_nodes > 0 ? p.seg_blocks : 0;
     if (phases & 4) {
     TailA ta;
@@ -1970,7 +1979,12 @@ int txe_gat_collapse_bwd_fused(const int* rowptr_in, const int* col_src, const i
     ta.nb_s1b = pw ? nseg : 0; ta.s1b = Seg1Args{p.dwv, 1, 1, p.ppart2};
     ta.pos = pos; ta.n_rows = n_nodes; ta.vocab = vocab; ta.rows_per_block = p.seg_rows;
     ta.r_kind = 2; ta.nb_r = (2 * Kp + 63) / 64; ta.r2 = Seg2Args{fw.dwa_part, nblk, 2 * Kp, p.dwa};
-    hipLaunchKernelGGL(gat_bwd_reduce_a_kernel, dim3(ta.nb_s1b + ta.nb_r), dim3(256), 0, s, ta);
+    const bool attn = G > 0 && n_nodes > 0;
+    AttnBwdArgs aa{rowptr_in, col_src, rowptr_out, pos_out, graph_off, G, Yp, ld_yp, Hp, F, attn_slope_p, alpha_p, (const float*)fw.dal, dz_p, d_Yp,
+                   ld_dyp, n_pad};
+    const int nb_attn = attn ? (G + FA_GRAPHS - 1) / FA_GRAPHS : 0;
+    ProfScope prof("gat_attn_bwd_reduce_a_kernel", s, attn ? 4.0 * (n_edges * (4.0 * Hp + 2.0) + n_nodes * (4.0 * Hp + n_pad)) : 0.0, 1);
+    hipLaunchKernelGGL(gat_attn_bwd_reduce_a_kernel, dim3(nb_attn + ta.nb_s1b + ta.nb_r), dim3(256), 0, s, aa, nb_attn, ta);
     TXE_CHECK_LAUNCH();
     }
     if (!(phases & 8)) return TXE_OK;

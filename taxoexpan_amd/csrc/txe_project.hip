@@ -1283,10 +1283,7 @@ __global__ __launch_bounds__(256) void cl_bwd_dx_kernel(int n_nodes, int ntile, 
 // What is left per edge -- softmax / leaky-relu backward of the previous layer's attention from the raw d alpha -- is
 // gat_attn_bwd_job (edge-level, a few microseconds; launched together with stage 1 of the reductions).
 // ---------------------------------------------------------------------------------------------------------------------
-#ifndef TXE_FB_NODES
-#define TXE_FB_NODES 16
-#endif
-constexpr int FB_NODES = TXE_FB_NODES;        // source nodes per workgroup
+constexpr int FB_NODES = 32;        // most source nodes a workgroup walks (fb_nodes_per_wg picks the number for a batch)
 constexpr int FB_MAXE = 192;        // out-edges of a workgroup whose scalars are staged in LDS (beyond: read from global)
 #ifndef TXE_FB_EU
 #define TXE_FB_EU 4
@@ -1304,7 +1301,23 @@ struct FusedBwdArgs {
     const float *dZ, *cn, *da1, *da2, *wa; float act_slope; int vocab;
     const float* Y; long long ld_y; int H, D; const float* alpha; float drop_p, drop_scale; unsigned long long seed;
     float* d_Y; long long ld_dy; float* dal; float* dwa_part; float* ppart;
+    int npw;                            // source nodes per workgroup
 };
+
+// Source nodes per workgroup of the fused sweep.  The kernel holds 3 workgroups per CU; its workgroups cost about (nodes + 6) each (LDS
+// staging of the folded rows, the partial rows written at the end), and a last partial round costs a whole one: on the 18 k-node
+// training batch 24 nodes make 745 workgroups = one round of 768 (141 us), 16 make 1.46 rounds (153 us), 32 three quarters of one (154 us).
+static inline int fb_nodes_per_wg(int n_nodes) {
+    const int slots = 3 * device_cu_count();
+    int best = 16;
+    double best_cost = 1e30;
+    for (int npw = 12; npw <= FB_NODES; npw += 4) {
+        const long long blocks = ((long long)n_nodes + npw - 1) / npw;
+        const double cost = (double)((blocks + slots - 1) / slots) * (npw + 6.0);
+        if (cost <= best_cost) { best_cost = cost; best = npw; }     // (ties: fewer, larger workgroups)
+    }
+    return best;
+}
 
 // keep bits (low 4) of the 4 columns starting at c (multiple of 4) of row r; all ones without a mask
 template <bool MASK>
@@ -1492,7 +1505,7 @@ __global__ __launch_bounds__(256, TXE_FB_OCC) void gat_fused_bwd_kernel(const Fu
     __shared__ float s_dot[4][4];
     extern __shared__ __attribute__((aligned(16))) float s_dyn[];   // [2][Kp] folded attention rows | [2][Kp] their gradient partials |
     const int b = xcd_remap(blockIdx.x, gridDim.x);                 // [vocab][Pd] position-embedding gradient partials
-    const int u0 = b * FB_NODES, u1 = min(a.n_nodes, u0 + FB_NODES);
+    const int u0 = b * a.npw, u1 = min(a.n_nodes, u0 + a.npw);
     const int Kp = a.Kp;
     float* s_wa = s_dyn;
     float* s_acc = s_dyn + 2 * Kp;
@@ -1844,7 +1857,7 @@ namespace txe {
 struct FusedWs {
     CollapseWs c;
     float *dal, *dwa_part, *ppart;
-    int nblocks;
+    int nblocks, npw;
     size_t total;
 };
 static FusedWs plan_fused_ws(void* ws, int n, int e, int G, int Kp, int D, int Pd, int vocab, int Hp) {
@@ -1853,7 +1866,8 @@ static FusedWs plan_fused_ws(void* ws, int n, int e, int G, int Kp, int D, int P
     char* b = (char*)ws;
     size_t off = f.c.total;
     auto take = [&](size_t bytes) { float* r = (float*)(b + off); off += align_up(bytes > 0 ? bytes : 4, 256); return r; };
-    f.nblocks = (n + FB_NODES - 1) / FB_NODES;
+    f.npw = fb_nodes_per_wg(n);
+    f.nblocks = (n + f.npw - 1) / f.npw;
     const int nb1 = f.nblocks > 0 ? f.nblocks : 1;
     f.dal = take((size_t)(e > 0 ? e : 1) * Hp * 4);
     f.dwa_part = take((size_t)nb1 * 2 * Kp * 4);
@@ -1954,6 +1968,7 @@ int txe_gat_collapse_bwd_fused(const int* rowptr_in, const int* col_src, const i
             a.Y = Yp; a.ld_y = ld_yp; a.H = Hp; a.D = Dp; a.alpha = alpha_p; a.drop_p = attn_drop_p_p;
             a.drop_scale = 1.f / (1.f - attn_drop_p_p); a.seed = seed_p;
             a.d_Y = d_Yp; a.ld_dy = ld_dyp; a.dal = fw.dal; a.dwa_part = fw.dwa_part; a.ppart = fw.ppart;
+            a.npw = fw.npw;
             const int nvec = F / 16, ni = (nvec + 63) / 64, nwh = 4 / Hp;
             // algorithmic bytes: read X' (own row + once per out-edge is an L2 matter), dZ, Y; write d_Y
             char name[64];

@@ -81,11 +81,13 @@ __host__ __device__ __forceinline__ float drop_factor(uint64_t seed, uint64_t id
 }
 
 // Feature-dropout bit mask (1 = keep), 32 columns per word, words_per_row = ceil(cols/32).  Word w of the whole mask is
-// built from 8 hashes x 4 16-bit chunks: bit (4j+c) = chunk c of mix64(seed ^ mix64(8w+j)) >= thr16, thr16 = round(p*65536).
+// built from 8 hashes x 4 16-bit chunks: bit (4j+c) = chunk c of mix64(seed + (8w+j) * W) >= thr16, thr16 = round(p*65536) --
+// a SplitMix64 stream with a Weyl step W per counter: ONE finaliser per 64 random bits (the mask of the folded layer's 2,080-column
+// input is 1.2 M words per step; with the counter itself hashed first the preparation launch spent half of its time here).
 __host__ __device__ __forceinline__ unsigned drop_mask_word(uint64_t seed, uint64_t word_index, unsigned thr16) {
     unsigned bits = 0;
     for (int j = 0; j < 8; ++j) {
-        const uint64_t h = mix64(seed ^ mix64(word_index * 8 + j));
+        const uint64_t h = mix64(seed + (word_index * 8 + j) * 0xD1342543DE82EF95ull);
         for (int c = 0; c < 4; ++c) bits |= ((unsigned)((h >> (16 * c)) & 0xFFFFu) >= thr16 ? 1u : 0u) << (4 * j + c);
     }
     return bits;

@@ -33,13 +33,13 @@ def keep_mask(seed, shape, p):
 
 def keep_mask_bits(seed, n_rows, n_cols, p):
     """The feature-dropout keep mask of txe_dropout_mask (csrc/txe_common.h drop_mask_word) as a 0/1 float32
-    [n_rows, n_cols] array: bit (4j+c) of mask word w = (16-bit chunk c of mix64(seed ^ mix64(8w+j))) >= round(p*65536)."""
+    [n_rows, n_cols] array: bit (4j+c) of mask word w = (16-bit chunk c of mix64(seed + (8w+j) * W)) >= round(p*65536)."""
     wpr = (n_cols + 31) // 32
     n_words = n_rows * wpr
     thr = np.uint64(int(np.float32(p) * np.float32(65536.0) + np.float32(0.5)))
     with np.errstate(over="ignore"):
         idx = (np.arange(n_words, dtype=np.uint64)[:, None] * np.uint64(8) + np.arange(8, dtype=np.uint64)[None, :])
-        h = _mix64(np.uint64(seed) ^ _mix64(idx))                                    # [n_words, 8]
+        h = _mix64((np.uint64(seed) + idx * np.uint64(0xD1342543DE82EF95)) & _M)      # [n_words, 8]
     chunks = np.stack([(h >> np.uint64(16 * c)) & np.uint64(0xFFFF) for c in range(4)], axis=-1)   # [n_words, 8, 4]
     bits = (chunks >= thr).reshape(n_rows, wpr * 32)                                 # bit index 4j+c
     return bits[:, :n_cols].astype(np.float32)

@@ -34,17 +34,21 @@ def _dev():
 
 
 def _close(got, ref, rtol, atol_rel, msg, errors, kinks=0.0):
-    """|got - ref| <= rtol |ref| + atol_rel max|ref| + 2e-6.  kinks > 0 (gradients): up to that fraction of the entries may miss the
-    bound by a factor 10 -- leaky_relu' is discontinuous at 0, and an activation within rounding of 0 takes the other branch in
-    another summation order (measured: the fp32 oracle itself differs from its float64 run by 1.9e-3 of the largest entry on one row
-    of the middle layer's weight gradient of the 2-layer model, exactly like the HIP path does)."""
+    """|got - ref| <= rtol |ref| + atol_rel max|ref| + 2e-6.  kinks > 0 (gradients): up to that fraction of the entries -- or 64 of
+    them, one kink touches a whole row of a small tensor: a flipped attention logit moves all 500 entries of its head in attn_l /
+    attn_r -- may miss the bound by a factor 10, provided the whole tensor still agrees to 1e-3 in the 2-norm.  leaky_relu' is
+    discontinuous at 0, and an activation within rounding of 0 takes the other branch in another summation order (measured: the fp32
+    oracle itself differs from its float64 run by 1.9e-3 of the largest entry on one row of the middle layer's weight gradient of
+    the 2-layer model, exactly like the HIP path does); which entries sit on a kink depends on the dropout masks drawn."""
     got, ref = np.asarray(got, dtype=np.float64), np.asarray(ref, dtype=np.float64)
     assert got.shape == ref.shape, (msg, got.shape, ref.shape)
     diff = np.abs(got - ref)
     tol = rtol * np.abs(ref) + atol_rel * np.abs(ref).max() + 2e-6
     bad = diff > tol
     very_bad = diff > 10 * tol
-    if bad.sum() > kinks * bad.size or very_bad.any():
+    allowed = max(kinks * bad.size, 64.0) if kinks > 0 else 0.0
+    norm_ok = kinks == 0 or np.linalg.norm(diff) <= 1e-3 * np.linalg.norm(ref) + 2e-6 * np.sqrt(diff.size)
+    if bad.sum() > allowed or very_bad.any() or not norm_ok:
         errors.append(f"{msg}: {int(bad.sum())} of {bad.size} entries off ({int(very_bad.sum())} by more than 10x), worst |diff| "
                       f"{diff.max():.3e} (max |ref| {np.abs(ref).max():.3e})")
 

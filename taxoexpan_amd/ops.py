@@ -454,6 +454,10 @@ def _gat_layer_bwd(csr, st, pos, vocab, feat_p, attn_p, attn_slope, d_pre, ld_dp
 _NO_TABLE_SWEEP = os.environ.get("TXE_NO_TABLE_SWEEP", "0") == "1"      # A/B switch: table rows are materialised before the sweep
 _NO_MULTI_PREPARE = os.environ.get("TXE_NO_MULTI_PREPARE", "0") == "1"   # A/B switch: one preparation launch per layer
 _NO_SIDE_STREAM = os.environ.get("TXE_NO_SIDE_STREAM", "0") == "1"      # A/B switch: everything on the caller's stream
+# The matcher's query projection V on the second stream under the encoder (bilinear_query_prefetch): OFF since the first-layer
+# projection runs on persistent workgroups -- V's workgroups take slots first, the persistent ones that start late finish late
+# (their tile lists are fixed), and the step loses 5 us more than the 44 us product costs on the caller's stream.
+_PREFETCH_V = os.environ.get("TXE_PREFETCH_V", "0") == "1"
 _side_streams = {}
 
 
@@ -967,7 +971,7 @@ def bilinear_query_prefetch(e2, W):
     """V = e2 W^T of the query-side match (BilinearPairFunction), launched on the second stream: it depends on the queries and the
     matcher's weight only, so it can run under the encoder (TaxoExpan.forward calls this before graph_propagate).  Returns a token for
     BilinearPairFunction.apply(..., pre=token); None when there is nothing to gain (gradient wanted for e2, CPU tensors, no side stream)."""
-    if _NO_SIDE_STREAM or not (torch.is_tensor(e2) and e2.is_cuda and W.is_cuda) or e2.requires_grad or e2.dim() != 2 or e2.shape[0] == 0:
+    if _NO_SIDE_STREAM or not _PREFETCH_V or not (torch.is_tensor(e2) and e2.is_cuda and W.is_cuda) or e2.requires_grad or e2.dim() != 2 or e2.shape[0] == 0:
         return None
     e2c, ld2 = _rows(e2)
     Wf = _f32(W).reshape(W.shape[-2], W.shape[-1])

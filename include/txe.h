@@ -64,6 +64,9 @@ int txe_gat_layer_prepare(const float* h, long long ld_h, int n_nodes, int Kh, c
 struct txe_gat_prepare_desc {
     const float* h; long long ld_h; int n_nodes, Kh; const int* pos; const float* P; int Pd; float* X;
     const float *W, *attn_l, *attn_r; int H, D; float* Wp; float feat_drop_p; unsigned long long seed; unsigned* mask;
+    int x_dropped;   /* 1 (needs h != NULL): X is written with the feature dropout already applied -- the layer's GEMMs then take X as a
+                      * plain operand: txe_gat_dense_fwd with feat_drop_p = 0 / mask = NULL, txe_gat_dense_bwd with x_dropped = 1 (the
+                      * mask is still written: d_X's epilogue needs it) */
 };
 int txe_gat_layers_prepare(const struct txe_gat_prepare_desc* descs, int n_layers, void* stream);
 
@@ -82,7 +85,7 @@ int txe_gat_dense_fwd(const float* X, int n_nodes, int Kh, int Pd, const float* 
 int txe_gat_dense_bwd(const float* X, int n_nodes, int Kh, int Pd, const int* pos, int vocab, const float* Wp, const float* W,
                       const float* attn_l, const float* attn_r, int H, int D, float feat_drop_p, const unsigned* mask, const float* d_Y,
                       int need_dh, int act_on, float act_slope, float* d_X, float* dW, float* d_attn_l, float* d_attn_r, float* dP,
-                      int phases, void* ws, size_t ws_bytes, void* stream);
+                      int x_dropped, int phases, void* ws, size_t ws_bytes, void* stream);
 int txe_zero_cols(float* x, long long ld, int n_rows, int c0, int c1, void* stream);
 
 /* Eval-mode first GATLayer of a batch whose node features are rows of a feature table (test_fast.py:149-179 / infer.py:82-95

@@ -21,7 +21,7 @@ SIGNATURES = {
     "txe_gather_add_rows": (I, [P, L, P, P, L, P, L, I, P, L, P]),
     "txe_gat_dense_ws_bytes": (SZ, [I, I, I, I, I, I]),
     "txe_gat_dense_fwd": (I, [P, I, I, I, P, I, I, F, P, P, P, SZ, P]),
-    "txe_gat_dense_bwd": (I, [P, I, I, I, P, I, P, P, P, P, I, I, F, P, P, I, I, F, P, P, P, P, P, I, P, SZ, P]),
+    "txe_gat_dense_bwd": (I, [P, I, I, I, P, I, P, P, P, P, I, I, F, P, P, I, I, F, P, P, P, P, P, I, I, P, SZ, P]),
     "txe_zero_cols": (I, [P, L, I, I, I, P]),
     "txe_gat_aggregate_fwd": (I, [P, P, I, P, L, P, P, I, I, I, F, F, U64, I, F, P, L, P, P, I, P, F, P, P]),
     "txe_gat_aggregate_table_supported": (I, [I, I, L, I, I]),
@@ -92,7 +92,7 @@ SIGNATURES = {
 class GatPrepareDesc(C.Structure):
     """struct txe_gat_prepare_desc (include/txe.h)"""
     _fields_ = [("h", P), ("ld_h", L), ("n_nodes", I), ("Kh", I), ("pos", P), ("P", P), ("Pd", I), ("X", P), ("W", P), ("attn_l", P),
-                ("attn_r", P), ("H", I), ("D", I), ("Wp", P), ("feat_drop_p", F), ("seed", U64), ("mask", P)]
+                ("attn_r", P), ("H", I), ("D", I), ("Wp", P), ("feat_drop_p", F), ("seed", U64), ("mask", P), ("x_dropped", I)]
 
 
 _ERR = {-1: "TXE_ERR_ARG", -2: "TXE_ERR_LAUNCH", -3: "TXE_ERR_WORKSPACE"}

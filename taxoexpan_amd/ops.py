@@ -301,21 +301,24 @@ def _tail_ws(ref):
 
 
 class _GatLayerState:
-    __slots__ = ("X", "Wp", "mask", "Y", "alpha", "W", "al", "ar", "P", "Kh", "Pd", "Kp", "Fp", "H", "D", "seed", "cl", "prepared")
+    __slots__ = ("X", "Wp", "mask", "Y", "alpha", "W", "al", "ar", "P", "Kh", "Pd", "Kp", "Fp", "H", "D", "seed", "cl", "prepared", "x_dropped")
 
 
 def _gat_layers_prepare(items, feat_p):
-    """_gat_layer_prepare for several layers of a stack in ONE launch (txe_gat_layers_prepare): items = [(st, h, ld_h, pos)], st.X
-    allocated.  A layer's preparation never depends on the layer below's output, so the whole stack is prepared before its first GEMM."""
+    """_gat_layer_prepare for several layers of a stack in ONE launch (txe_gat_layers_prepare): items = [(st, h, ld_h, pos, dropped)],
+    st.X allocated.  A layer's preparation never depends on the layer below's output, so the whole stack is prepared before its first
+    GEMM.  dropped: X is written with the feature dropout already applied (a first layer on raw features whose X only GEMMs read)."""
     import ctypes
     descs = (_lib.GatPrepareDesc * len(items))()
-    for d, (st, h, ld_h, pos) in zip(descs, items):
+    for d, (st, h, ld_h, pos, dropped) in zip(descs, items):
         N = st.X.shape[0]
         st.Wp = _empty((st.Fp, st.Kp), st.X)
         st.mask = torch.empty((N, (st.Kh + st.Pd + 31) // 32), dtype=torch.int32, device=st.X.device) if feat_p > 0.0 else None
         d.h, d.ld_h, d.n_nodes, d.Kh, d.pos, d.P, d.Pd, d.X = ptr(h), ld_h, N, st.Kh, ptr(pos), ptr(st.P), st.Pd, ptr(st.X)
         d.W, d.attn_l, d.attn_r, d.H, d.D, d.Wp = ptr(st.W), ptr(st.al), ptr(st.ar), st.H, st.D, ptr(st.Wp)
         d.feat_drop_p, d.seed, d.mask = feat_p, st.seed, ptr(st.mask)
+        st.x_dropped = bool(dropped and h is not None and feat_p > 0.0 and not _NO_X_DROPPED)
+        d.x_dropped = int(st.x_dropped)
         st.prepared = True
     call("txe_gat_layers_prepare", ctypes.cast(descs, ctypes.c_void_p), len(items), _lib.stream_ptr())
 
@@ -398,7 +401,9 @@ def _gat_layer_fwd(csr, st, h, ld_h, pos, out, ld_out, feat_p, attn_p, attn_slop
         _gat_layer_prepare(st, h, ld_h, pos, feat_p)
         st.Y = _empty((N, Fp), st.X)
         tws = _tail_ws(st.X)
-        call("txe_gat_dense_fwd", ptr(st.X), N, Kh, Pd, ptr(st.Wp), H, D, feat_p, ptr(st.mask), ptr(st.Y), ptr(tws), tws.numel(), s)
+        dropped = getattr(st, "x_dropped", False)
+        call("txe_gat_dense_fwd", ptr(st.X), N, Kh, Pd, ptr(st.Wp), H, D, 0.0 if dropped else feat_p, None if dropped else ptr(st.mask), ptr(st.Y),
+             ptr(tws), tws.numel(), s)
     st.alpha = _empty((max(csr.n_edges, 1), H), st.Y) if save else None
     call("txe_gat_aggregate_fwd", ptr(csr.rowptr_in), ptr(csr.col_src), N, ptr(st.Y), Fp, ptr(st.Y) + 4 * F, ptr(st.Y) + 4 * (F + H), Fp,
          H, D, attn_slope, attn_p, st.seed + 1, out_mode, act_slope, ptr(out), ld_out, ptr(st.alpha),
@@ -430,7 +435,7 @@ def _gat_dense_bwd(st, pos, vocab, feat_p, d_Y, need_dh, act_on, act_slope):
     def run(phases):
         call("txe_gat_dense_bwd", ptr(st.X), N, st.Kh, st.Pd, ptr(pos), vocab, ptr(st.Wp), ptr(st.W), ptr(st.al), ptr(st.ar), st.H, st.D, feat_p,
              ptr(st.mask), ptr(d_Y), int(need_dh), int(act_on), act_slope if act_slope else 1.0, ptr(d_X), ptr(dW), ptr(dal), ptr(dar),
-             ptr(dP), phases, ptr(ws), wsb, _lib.stream_ptr())
+             ptr(dP), int(getattr(st, "x_dropped", False)), phases, ptr(ws), wsb, _lib.stream_ptr())
     if _NO_SIDE_STREAM or need_dh or d_X is None or N == 0:
         run(7)
     else:
@@ -452,6 +457,7 @@ def _gat_layer_bwd(csr, st, pos, vocab, feat_p, attn_p, attn_slope, d_pre, ld_dp
 
 
 _NO_TABLE_SWEEP = os.environ.get("TXE_NO_TABLE_SWEEP", "0") == "1"      # A/B switch: table rows are materialised before the sweep
+_NO_X_DROPPED = os.environ.get("TXE_NO_X_DROPPED", "0") == "1"        # A/B switch: the first layer's GEMM loaders apply the keep mask
 _NO_MULTI_PREPARE = os.environ.get("TXE_NO_MULTI_PREPARE", "0") == "1"   # A/B switch: one preparation launch per layer
 _NO_SIDE_STREAM = os.environ.get("TXE_NO_SIDE_STREAM", "0") == "1"      # A/B switch: everything on the caller's stream
 # The matcher's query projection V on the second stream under the encoder (bilinear_query_prefetch): OFF since the first-layer
@@ -559,7 +565,9 @@ class GATStackFunction(torch.autograd.Function):
             if N > 0 and not _NO_MULTI_PREPARE:      # every layer's input buffer now, and ONE preparation launch for the whole stack
                 for l in range(1, L):
                     states[l].X = _empty((N, states[l].Kp), h)
-                _gat_layers_prepare([(st, (src if l == 0 else None), (ld_h if l == 0 else 0), pos if st.P is not None else None)
+                # (a first layer on raw features that is not the folded one: only its GEMMs read X, so X is stored dropped)
+                _gat_layers_prepare([(st, (src if l == 0 else None), (ld_h if l == 0 else 0), pos if st.P is not None else None,
+                                      l == 0 and not (collapse and L == 1))
                                      for l, st in enumerate(states) if not (table and l == 0)], cfg.feat_p)
             fused_a12 = None
             for l, st in enumerate(states):

@@ -64,9 +64,10 @@ int txe_gat_layer_prepare(const float* h, long long ld_h, int n_nodes, int Kh, c
 struct txe_gat_prepare_desc {
     const float* h; long long ld_h; int n_nodes, Kh; const int* pos; const float* P; int Pd; float* X;
     const float *W, *attn_l, *attn_r; int H, D; float* Wp; float feat_drop_p; unsigned long long seed; unsigned* mask;
-    int x_dropped;   /* 1 (needs h != NULL): X is written with the feature dropout already applied -- the layer's GEMMs then take X as a
-                      * plain operand: txe_gat_dense_fwd with feat_drop_p = 0 / mask = NULL, txe_gat_dense_bwd with x_dropped = 1 (the
-                      * mask is still written: d_X's epilogue needs it) */
+    int x_dropped;   /* 1: X is written with the feature dropout already applied -- the layer's GEMMs then take X as a plain operand:
+                      * txe_gat_dense_fwd with feat_drop_p = 0 / mask = NULL, txe_gat_dense_bwd with x_dropped = 1 (the mask is still
+                      * written: d_X's epilogue needs it).  With h == NULL the producer of the feature columns must drop them itself
+                      * (txe_gat_aggregate_fwd with nx_mask and no nx_a12) */
 };
 int txe_gat_layers_prepare(const struct txe_gat_prepare_desc* descs, int n_layers, void* stream);
 
@@ -106,7 +107,10 @@ int txe_gat_aggregate_table_fwd(const int* rowptr_in, const int* col_src, int n_
  * nx_a12 != NULL (optional fused epilogue, needs 16-byte aligned rows): `out` is the padded input X' [N][nx_kp] of the NEXT, one-head
  * GATLayer (ld_out == nx_kp, its position / padding columns already in place, nx_mask = its feature keep bits or NULL), and the
  * folded attention logits of that layer are formed on the way out: nx_a12[v][r] = <dropout(X'[v]), nx_wa[r]> (nx_wa [2][nx_kp] =
- * rows D, D+1 of its packed weights) -- txe_gat_collapse_fwd then runs with a12_ready = 1. */
+ * rows D, D+1 of its packed weights) -- txe_gat_collapse_fwd then runs with a12_ready = 1.
+ * nx_a12 == NULL with nx_mask != NULL and nx_feat_drop_p > 0: `out` is the padded input of the NEXT GATLayer (ld_out == nx_kp, 16-byte
+ * rows) and that layer's feature dropout is applied to the rows written (out = dropout(leaky_relu(aggregated))): its GEMMs then read a
+ * plain operand (txe_gat_prepare_desc.x_dropped). */
 int txe_gat_aggregate_fwd(const int* rowptr_in, const int* col_src, int n_nodes, const float* ft, long long ld_ft,
                           const float* a_src, const float* a_dst, int ld_a, int H, int D, float attn_slope, float attn_drop_p,
                           unsigned long long seed, int out_mode, float act_slope, float* out, long long ld_out, float* alpha,

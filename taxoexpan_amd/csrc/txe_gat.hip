@@ -150,7 +150,7 @@ __device__ __forceinline__ void gat_fwd_node(const int v, const int l, float* __
     float nx1 = 0.f, nx2 = 0.f;
     float tx[2];                                       // NX: the (at most 128) columns behind the feature part -- position embedding and
     unsigned tk[2];                                    // zero padding, written by the next layer's preparation -- fetched ahead of the gather
-    if constexpr (NX) {
+    if constexpr (NX == 1 || NX == 2) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int c = F + l + 64 * i, cc = min(c, nx.kp - 1);
@@ -170,7 +170,7 @@ __device__ __forceinline__ void gat_fwd_node(const int v, const int l, float* __
                 const int j = t0 + l + 64 * i;
                 const int c = ((j < nvec) ? j : 0) * VEC;
                 kb[i] = 0xFFFFFFFFu;
-                if constexpr (NX == 2) kb[i] = nx.mask[(long long)v * nx.mask_ld + (c >> 5)] >> (c & 31);
+                if constexpr (NX >= 2) kb[i] = nx.mask[(long long)v * nx.mask_ld + (c >> 5)] >> (c & 31);
                 kb[i] = (j < nvec) ? kb[i] : 0u;
             }
         }
@@ -213,10 +213,14 @@ __device__ __forceinline__ void gat_fwd_node(const int v, const int l, float* __
 #pragma unroll
                     for (int k = 0; k < VEC; ++k) acc[i][k] = leaky(acc[i][k], act_slope);
                 }
+                if constexpr (NX == 3) {               // the next layer's feature dropout: its GEMMs then read a plain operand
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k) acc[i][k] = ((kb[i] >> k) & 1u) ? acc[i][k] * nx.scale : 0.f;
+                }
                 vstore<VEC>(out + (long long)v * ld_out + (long long)j * VEC, acc[i]);
             }
         }
-        if constexpr (NX) {
+        if constexpr (NX == 1 || NX == 2) {
             // VEC divides 32: the VEC keep bits of a vector sit in one mask word (kb, above); the folded rows come from LDS
 #pragma unroll
             for (int i = 0; i < NI; ++i) {
@@ -234,7 +238,7 @@ __device__ __forceinline__ void gat_fwd_node(const int v, const int l, float* __
             }
         }
     }
-    if constexpr (NX) {
+    if constexpr (NX == 1 || NX == 2) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int cc = min(F + l + 64 * i, nx.kp - 1);
@@ -263,8 +267,8 @@ __global__ __launch_bounds__(GAT_WAVES * 64, TAB ? 3 : 1) void gat_aggregate_fwd
 
     const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
     extern __shared__ __attribute__((aligned(16))) float s_wa[];   // NX: the two folded rows [2][kp], shared by the workgroup's 4 nodes;
-    float* s_t2 = s_wa + (NX ? 2 * nx.kp : 0);                    // TAB: behind them, the rows of T2 [vocab][ld_ft]
-    if constexpr (NX != 0) {
+    float* s_t2 = s_wa + ((NX == 1 || NX == 2) ? 2 * nx.kp : 0);   // TAB: behind them, the rows of T2 [vocab][ld_ft]
+    if constexpr (NX == 1 || NX == 2) {
         for (int i = threadIdx.x * 4; i < 2 * nx.kp; i += GAT_WAVES * 64 * 4)
             *reinterpret_cast<float4*>(s_wa + i) = *reinterpret_cast<const float4*>(nx.wa + i);
     }
@@ -272,7 +276,7 @@ __global__ __launch_bounds__(GAT_WAVES * 64, TAB ? 3 : 1) void gat_aggregate_fwd
         for (long long i = threadIdx.x * 4; i < (long long)tab.vocab * ld_ft; i += GAT_WAVES * 64 * 4)
             *reinterpret_cast<float4*>(s_t2 + i) = *reinterpret_cast<const float4*>(tab.t2 + i);
     }
-    if constexpr (NX != 0 || TAB) __syncthreads();     // before any wave leaves
+    if constexpr (NX == 1 || NX == 2 || TAB) __syncthreads();     // before any wave leaves
     const int v = xcd_remap(blockIdx.x, gridDim.x) * GAT_WAVES + w;
     if (v >= n_nodes) return;
     gat_fwd_node<VEC, NI, NX, TAB>(v, l, s_w[w], s_idx[w], s_stat[w], s_wa, rowptr, col, ft, ld_ft, a_src, a_dst, ld_a, H, D, slope, drop_p,
@@ -736,13 +740,17 @@ int txe_gat_aggregate_fwd(const int* rowptr_in, const int* col_src, int n_nodes,
     hipStream_t s = (hipStream_t)stream;
     const int vec = pick_vec(D, ld_ft, ld_out, ft, out);
     if (nx_a12 && (vec != 4 || ((uintptr_t)nx_wa & 15) || nx_kp > 4096)) return TXE_ERR_ARG;   // 16-byte layout; rows fit 32 KB of LDS
+    // nx_mask WITHOUT nx_a12: only the next layer's feature dropout is applied to the rows written (that layer's GEMMs then read a plain
+    // operand; its preparation drops the position columns the same way): 16-byte rows, nx_kp = ld_out = that layer's padded width
+    const bool out_drop = !nx_a12 && nx_mask && nx_feat_drop_p > 0.f;
+    if (out_drop && (vec != 4 || nx_kp < H * D || (nx_kp & 31) || ld_out != nx_kp || nx_feat_drop_p >= 1.f)) return TXE_ERR_ARG;
     NextLogits nx;
     nx.wa = nx_wa; nx.mask = (nx_feat_drop_p > 0.f) ? nx_mask : nullptr; nx.a12 = nx_a12;
-    nx.scale = 1.f / (1.f - (nx_a12 ? nx_feat_drop_p : 0.f)); nx.kp = nx_kp; nx.mask_ld = nx_kp / 32;
+    nx.scale = 1.f / (1.f - ((nx_a12 || out_drop) ? nx_feat_drop_p : 0.f)); nx.kp = nx_kp; nx.mask_ld = nx_kp / 32;
     // algorithmic (compulsory) bytes, SURVEY 8d: read ft + write out + a_src/a_dst + CSR (+ alpha when kept for backward);
     // the edge count is not known here (device rowptr), the E-proportional terms are added by the caller-side model
     const int ni = pick_ni(H * D / vec);
-    const KName kn("gat_aggregate_fwd_kernel", vec, ni, nx_a12 ? (nx.mask ? 2 : 1) : 0, false);
+    const KName kn("gat_aggregate_fwd_kernel", vec, ni, nx_a12 ? (nx.mask ? 2 : 1) : (out_drop ? 3 : 0), false);
     ProfScope prof(kn.s, s, 4.0 * (2.0 * n_nodes * (double)H * D + 2.0 * n_nodes * H + n_nodes + 1), 1);
 #define TXE_L(V, I)                                                                                                               \
     hipLaunchKernelGGL((gat_aggregate_fwd_kernel<V, I, 0>), dim3(nb), dim3(GAT_WAVES * 64), 0, s, rowptr_in, col_src, n_nodes, \
@@ -753,8 +761,14 @@ int txe_gat_aggregate_fwd(const int* rowptr_in, const int* col_src, int n_nodes,
                        ft, ld_ft, a_src, a_dst, ld_a, H, D, attn_slope, attn_drop_p, scale, seed, out_mode, act_slope,            \
                        out, ld_out, alpha, nx, TabSrc{nullptr, nullptr, nullptr, 0})
 #define TXE_LX(I) do { if (nx.mask) TXE_LXM(I, 2); else TXE_LXM(I, 1); } while (0)
+#define TXE_LD(I)                                                                                                                 \
+    hipLaunchKernelGGL((gat_aggregate_fwd_kernel<4, I, 3>), dim3(nb), dim3(GAT_WAVES * 64), 0, s, rowptr_in, col_src, n_nodes,            \
+                       ft, ld_ft, a_src, a_dst, ld_a, H, D, attn_slope, attn_drop_p, scale, seed, out_mode, act_slope,            \
+                       out, ld_out, alpha, nx, TabSrc{nullptr, nullptr, nullptr, 0})
     if (nx_a12) { if (ni == 8) TXE_LX(8); else if (ni == 4) TXE_LX(4); else TXE_LX(2); }
+    else if (out_drop) { if (ni == 8) TXE_LD(8); else if (ni == 4) TXE_LD(4); else TXE_LD(2); }
     else TXE_DISPATCH_VEC_NI(vec, ni, TXE_L);
+#undef TXE_LD
 #undef TXE_LX
 #undef TXE_LXM
 #undef TXE_L

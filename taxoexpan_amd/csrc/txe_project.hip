@@ -502,7 +502,6 @@ static int fill_prep(PrepArgs& a, const txe_gat_prepare_desc& d) {
     a.seed = d.seed; a.thr16 = (unsigned)(d.feat_drop_p * 65536.0f + 0.5f); a.mask = d.mask;
     a.x_dropped = (d.x_dropped && d.feat_drop_p > 0.f && a.thr16 != 0u) ? 1 : 0;
     a.drop_scale = 1.f / (1.f - d.feat_drop_p);
-    if (d.x_dropped && !d.h) return TXE_ERR_ARG;                    // (only a layer whose whole input row is built here)
     return TXE_OK;
 }
 }  // namespace txe

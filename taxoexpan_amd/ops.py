@@ -304,6 +304,18 @@ class _GatLayerState:
     __slots__ = ("X", "Wp", "mask", "Y", "alpha", "W", "al", "ar", "P", "Kh", "Pd", "Kp", "Fp", "H", "D", "seed", "cl", "prepared", "x_dropped")
 
 
+def _x_dropped_ok(cfg, states, l, collapse):
+    """may layer l's input be stored dropped?  Not the folded output layer (its sweeps apply the mask themselves); a layer above the
+    first needs the aggregation below to drop what it writes: 16-byte rows, H <= 4 (the fast kernel family), an activation between."""
+    L = len(states)
+    if collapse and l == L - 1:
+        return False
+    if l == 0:
+        return True
+    sp = states[l - 1]
+    return sp.D % 4 == 0 and states[l].Kp % 4 == 0 and sp.H <= 4
+
+
 def _gat_layers_prepare(items, feat_p):
     """_gat_layer_prepare for several layers of a stack in ONE launch (txe_gat_layers_prepare): items = [(st, h, ld_h, pos, dropped)],
     st.X allocated.  A layer's preparation never depends on the layer below's output, so the whole stack is prepared before its first
@@ -317,7 +329,7 @@ def _gat_layers_prepare(items, feat_p):
         d.h, d.ld_h, d.n_nodes, d.Kh, d.pos, d.P, d.Pd, d.X = ptr(h), ld_h, N, st.Kh, ptr(pos), ptr(st.P), st.Pd, ptr(st.X)
         d.W, d.attn_l, d.attn_r, d.H, d.D, d.Wp = ptr(st.W), ptr(st.al), ptr(st.ar), st.H, st.D, ptr(st.Wp)
         d.feat_drop_p, d.seed, d.mask = feat_p, st.seed, ptr(st.mask)
-        st.x_dropped = bool(dropped and h is not None and feat_p > 0.0 and not _NO_X_DROPPED)
+        st.x_dropped = bool(dropped and feat_p > 0.0 and not _NO_X_DROPPED)
         d.x_dropped = int(st.x_dropped)
         st.prepared = True
     call("txe_gat_layers_prepare", ctypes.cast(descs, ctypes.c_void_p), len(items), _lib.stream_ptr())
@@ -375,7 +387,7 @@ def _gat_collapse_bwd(csr, st, pos, rpos, pw, vocab, feat_p, attn_p, attn_slope,
     return d_X, dW, dal, dar, dP, d_pw
 
 
-def _gat_layer_fwd(csr, st, h, ld_h, pos, out, ld_out, feat_p, attn_p, attn_slope, out_mode, act_slope, save, nxt=None):
+def _gat_layer_fwd(csr, st, h, ld_h, pos, out, ld_out, feat_p, attn_p, attn_slope, out_mode, act_slope, save, nxt=None, out_drop=None):
     """st.X is pre-allocated [N, Kp]; h != None copies the raw features in, h == None means the producer already wrote them.
     nxt = (prepared state of the next, folded one-head layer, a12 buffer): its attention logits ride in the aggregation's epilogue."""
     H, D, Kh, Pd, Kp, Fp = st.H, st.D, st.Kh, st.Pd, st.Kp, st.Fp
@@ -408,7 +420,7 @@ def _gat_layer_fwd(csr, st, h, ld_h, pos, out, ld_out, feat_p, attn_p, attn_slop
     call("txe_gat_aggregate_fwd", ptr(csr.rowptr_in), ptr(csr.col_src), N, ptr(st.Y), Fp, ptr(st.Y) + 4 * F, ptr(st.Y) + 4 * (F + H), Fp,
          H, D, attn_slope, attn_p, st.seed + 1, out_mode, act_slope, ptr(out), ld_out, ptr(st.alpha),
          *((ptr(nxt[0].Wp) + 4 * nxt[0].D * nxt[0].Kp, nxt[0].Kp, ptr(nxt[0].mask), feat_p, ptr(nxt[1])) if nxt is not None
-           else (None, 0, None, 0.0, None)), s)
+           else ((None, out_drop.Kp, ptr(out_drop.mask), feat_p, None) if out_drop is not None else (None, 0, None, 0.0, None))), s)
 
 
 def _gat_aggregate_bwd(csr, st, attn_p, attn_slope, d_pre, ld_dpre):
@@ -565,9 +577,10 @@ class GATStackFunction(torch.autograd.Function):
             if N > 0 and not _NO_MULTI_PREPARE:      # every layer's input buffer now, and ONE preparation launch for the whole stack
                 for l in range(1, L):
                     states[l].X = _empty((N, states[l].Kp), h)
-                # (a first layer on raw features that is not the folded one: only its GEMMs read X, so X is stored dropped)
+                # (a layer that is not the folded one: only its GEMMs read X, so X is stored with the dropout applied -- by the
+                #  preparation (raw features, position columns) and by the aggregation of the layer below (_drops_output))
                 _gat_layers_prepare([(st, (src if l == 0 else None), (ld_h if l == 0 else 0), pos if st.P is not None else None,
-                                      l == 0 and not (collapse and L == 1))
+                                      _x_dropped_ok(cfg, states, l, collapse))
                                      for l, st in enumerate(states) if not (table and l == 0)], cfg.feat_p)
             fused_a12 = None
             for l, st in enumerate(states):
@@ -594,8 +607,10 @@ class GATStackFunction(torch.autograd.Function):
                     _gat_layer_prepare(sn, None, 0, pos if sn.P is not None else None, cfg.feat_p)
                     fused_a12 = _empty((N, 2), h)
                     nxt = (sn, fused_a12)
+                # (the layer above reads its input through plain GEMM operands: this layer's aggregation applies that layer's dropout)
+                out_drop = states[l + 1] if (not last and nxt is None and getattr(states[l + 1], "x_dropped", False)) else None
                 _gat_layer_fwd(csr, st, src if l == 0 else None, ld_h if l == 0 else 0, pos if st.P is not None else None, out, ld_out,
-                               cfg.feat_p, cfg.attn_p, cfg.attn_slope, out_mode, cfg.act_slope or 1.0, need, nxt)
+                               cfg.feat_p, cfg.attn_p, cfg.attn_slope, out_mode, cfg.act_slope or 1.0, need, nxt, out_drop)
                 if not need:
                     st.Y = st.mask = st.Wp = None
                     if l > 0:

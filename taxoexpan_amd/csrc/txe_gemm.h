@@ -335,15 +335,9 @@ __device__ __forceinline__ void fast_issue(const VMat& M, FastPtr<KC, V, ROWS>& 
 template <bool KC, int V, int ROWS>
 __device__ __forceinline__ void fast_finish(const VMat& M, const FastPtr<KC, V, ROWS>& f, float* regs, const unsigned* mws) {
     using G = StageGeom<KC, V, ROWS>;
-    if constexpr (!KC) {
-        if constexpr (G::FLAT) {
-#pragma unroll
-            for (int i = 0; i < G::NREG; ++i) regs[i] = ((f.cvmask >> (i / V)) & 1u) ? regs[i] : 0.f;
-        } else {
-#pragma unroll
-            for (int i = 0; i < G::NREG; ++i) regs[i] = f.cvalid ? regs[i] : 0.f;
-        }
-    }
+    // (a row-contiguous operand's column vectors past the matrix were read from a clamped, readable address and are NOT zeroed: column
+    //  j of the operand only feeds row / column j of the product, which lies past M / N and is never stored -- 24 selects per k-tile
+    //  and thread less in the weight-gradient products)
     if (M.mask_on) {
 #pragma unroll
         for (int p = 0; p < G::PASSES; ++p) {

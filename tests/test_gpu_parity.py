@@ -91,16 +91,19 @@ def test_training_mode_dropout_matches_oracle(name, monkeypatch):
     model = _build_model(spec, params).train()
     g = _graph(shapes)
     eid_in = g.csr("cpu").eid_in.numpy()
-    scores = model(g, torch.from_numpy(x).to(_dev()), torch.from_numpy(q).to(_dev()))
+    xg = torch.from_numpy(x).to(_dev()).requires_grad_(True)       # (the gradient to the node features too: the first layer's input is
+    scores = model(g, xg, torch.from_numpy(q).to(_dev()))          #  stored dropped, its d_X comes out of the masked GEMM epilogue)
     nq = spec["n_queries"]
     loss = torch.nn.functional.cross_entropy(scores.reshape(nq, -1), torch.zeros(nq, dtype=torch.long, device=_dev()), reduction="sum")
     loss.backward()
     P = {k: torch.from_numpy(v).clone().requires_grad_(True) for k, v in params.items()}
     masks = _hash_masks(spec, params, graph, seed, eid_in)
-    s_ref, hg_ref, hn_ref = orc.taxoexpan_forward(P, graph, torch.from_numpy(x), torch.from_numpy(q), spec["prop"], spec["readout"],
+    xc = torch.from_numpy(x).clone().requires_grad_(True)
+    s_ref, hg_ref, hn_ref = orc.taxoexpan_forward(P, graph, xc, torch.from_numpy(q), spec["prop"], spec["readout"],
                                                   spec["match"], spec["heads"], spec["num_layers"], masks)
     l_ref = orc.info_nce_loss(s_ref, nq)
     l_ref.backward()
+    np.testing.assert_allclose(xg.grad.cpu().numpy(), xc.grad.numpy(), rtol=2e-3, atol=2e-5, err_msg="d node features")
     np.testing.assert_allclose(g.ndata["h"].detach().cpu().numpy(), hn_ref.detach().numpy(), rtol=RT, atol=AT)
     np.testing.assert_allclose(scores.detach().cpu().numpy(), s_ref.detach().numpy(), rtol=RT, atol=AT)
     for k, p in model.named_parameters():

@@ -82,10 +82,15 @@ def _hash_masks(spec, params, graph, seed, csr_eid_in):
     return out
 
 
-@pytest.mark.parametrize("name", ["small_pgat_dropout", "small_pgcn_dropout"])
-def test_training_mode_dropout_matches_oracle(name, monkeypatch):
+@pytest.mark.parametrize("name,drop", [("small_pgat_dropout", None), ("small_pgcn_dropout", None),
+                                       # the inputs / parameters of dropout-free cases with dropout switched on: a middle layer (its
+                                       # input dropped by the aggregation below), an output layer that is not folded (2 heads)
+                                       ("small_pgat_2layer", (0.3, 0.25)), ("small_gat_mr_bim", (0.2, 0.1))])
+def test_training_mode_dropout_matches_oracle(name, drop, monkeypatch):
     from taxoexpan_amd import ops
     spec, z, shapes, x, q, params, graph = load_case(name)
+    if drop is not None:
+        spec = dict(spec, dropout=drop)
     seed = 123456789
     monkeypatch.setattr(ops, "new_seed", lambda: seed)
     model = _build_model(spec, params).train()

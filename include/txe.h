@@ -73,7 +73,8 @@ int txe_gat_layers_prepare(const struct txe_gat_prepare_desc* descs, int n_layer
 
 /* the same for a GCNLayer (model_zoo.py:35-37): txe_gat_build_x + txe_gcn_pack_weights + txe_dropout_mask as ONE launch */
 int txe_gcn_layer_prepare(const float* h, long long ld_h, int n_nodes, int Kh, const int* pos, const float* P, int Pd, float* X,
-                          const float* W, int Fo, float* Wp, float drop_p, unsigned long long seed, unsigned* mask, void* stream);
+                          const float* W, int Fo, float* Wp, float drop_p, unsigned long long seed, unsigned* mask, int x_dropped,
+                          void* stream);   /* x_dropped: as in txe_gat_prepare_desc (txe_gcn_dense_fwd then without mask) */
 
 /* Eval-mode layer-0 projection of a batch whose node features are rows of a taxonomy feature table (SURVEY 8f-2 "dedup by _id"):
  * the projection T = table W^T is formed once per DISTINCT taxonomy node (txe_gemm_plain), T2 = the position rows' projections, and
@@ -139,7 +140,7 @@ int txe_gcn_dense_fwd(const float* X, int n_nodes, int Kh, int Pd, const float* 
                       float* hw, void* ws, size_t ws_bytes, void* stream);
 int txe_gcn_dense_bwd(const float* X, int n_nodes, int Kh, int Pd, const int* pos, int vocab, const float* Wp, int Fo, float drop_p,
                       const unsigned* mask, const float* d_hw, int need_dh, int act_on, float act_slope, float* d_X, float* dW,
-                      float* dP, void* ws, size_t ws_bytes, void* stream);
+                      float* dP, int x_dropped, void* ws, size_t ws_bytes, void* stream);
 int txe_gcn_norm(const int* rowptr_in, int n_nodes, float* norm, void* stream);
 int txe_gcn_aggregate_fwd(const int* rowptr_in, const int* col_src, int n_nodes, const float* hw, long long ld_hw,
                           const float* norm, const float* bias, int has_act, float act_slope, int F, float* out, long long ld_out,

@@ -17,7 +17,7 @@ SIGNATURES = {
     "txe_gat_pack_weights": (I, [P, P, P, I, I, I, P, P]),
     "txe_gat_build_x": (I, [P, L, I, I, P, P, I, P, P]),
     "txe_gat_layer_prepare": (I, [P, L, I, I, P, P, I, P, P, P, P, I, I, P, F, U64, P, P]),
-    "txe_gcn_layer_prepare": (I, [P, L, I, I, P, P, I, P, P, I, P, F, U64, P, P]),
+    "txe_gcn_layer_prepare": (I, [P, L, I, I, P, P, I, P, P, I, P, F, U64, P, I, P]),
     "txe_gather_add_rows": (I, [P, L, P, P, L, P, L, I, P, L, P]),
     "txe_gat_dense_ws_bytes": (SZ, [I, I, I, I, I, I]),
     "txe_gat_dense_fwd": (I, [P, I, I, I, P, I, I, F, P, P, P, SZ, P]),
@@ -34,7 +34,7 @@ SIGNATURES = {
     "txe_gcn_pack_weights": (I, [P, I, I, P, P]),
     "txe_gcn_dense_ws_bytes": (SZ, [I, I, I, I, I]),
     "txe_gcn_dense_fwd": (I, [P, I, I, I, P, I, F, P, P, P, SZ, P]),
-    "txe_gcn_dense_bwd": (I, [P, I, I, I, P, I, P, I, F, P, P, I, I, F, P, P, P, P, SZ, P]),
+    "txe_gcn_dense_bwd": (I, [P, I, I, I, P, I, P, I, F, P, P, I, I, F, P, P, P, I, P, SZ, P]),
     "txe_gcn_norm": (I, [P, I, P, P]),
     "txe_gcn_aggregate_fwd": (I, [P, P, I, P, L, P, P, I, F, I, P, L, P]),
     "txe_gcn_aggregate_bwd_ws_bytes": (SZ, [I, I]),

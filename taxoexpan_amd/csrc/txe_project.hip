@@ -331,7 +331,7 @@ __global__ __launch_bounds__(64 * FOLD_DG) void gat_prepare_kernel(const PrepArg
     b -= a.nb_w;
     if (b < a.nb_m) { dropout_mask_job(b, a.nb_m, a.n_words, a.seed, a.thr16, a.mask); return; }
     b -= a.nb_m;
-    build_x_job(b, a.nb_x, a.h, a.ld_h, a.pos, a.P, a.n_rows, a.Kh, a.Pd, a.Kp, a.X);
+    build_x_job(b, a.nb_x, a.h, a.ld_h, a.pos, a.P, a.n_rows, a.Kh, a.Pd, a.Kp, a.X, a.seed, a.x_dropped ? a.thr16 : 0u, a.drop_scale);
 }
 
 // zero columns [c0, c1) of a row-major [n_rows][ld] matrix
@@ -529,7 +529,8 @@ int txe_gat_layers_prepare(const struct txe_gat_prepare_desc* descs, int n_layer
 // The same for a GCNLayer (model_zoo.py:35-37): txe_gat_build_x + txe_gcn_pack_weights + txe_dropout_mask in one launch.
 // W [Kh+Pd][Fo] -> Wp [roundup(roundup(Kh+Pd,32),128)][roundup(Fo,32)]; mask may be NULL when drop_p == 0.
 int txe_gcn_layer_prepare(const float* h, long long ld_h, int n_nodes, int Kh, const int* pos, const float* P, int Pd, float* X,
-                          const float* W, int Fo, float* Wp, float drop_p, unsigned long long seed, unsigned* mask, void* stream) {
+                          const float* W, int Fo, float* Wp, float drop_p, unsigned long long seed, unsigned* mask, int x_dropped,
+                          void* stream) {
     if (n_nodes < 0 || Kh < 1 || Pd < 0 || !X || (Pd > 0 && (!pos || !P)) || !W || !Wp || Fo < 1) return TXE_ERR_ARG;
     if (drop_p < 0.f || drop_p >= 1.f || (drop_p > 0.f && !mask)) return TXE_ERR_ARG;
     const int T = 64 * FOLD_DG;
@@ -547,6 +548,8 @@ int txe_gcn_layer_prepare(const float* h, long long ld_h, int n_nodes, int Kh, c
     a.h = h; a.ld_h = ld_h; a.pos = pos; a.P = P; a.n_rows = n_nodes; a.Kh = Kh; a.Pd = Pd; a.X = X;
     a.W = W; a.Wp = Wp;
     a.seed = seed; a.thr16 = (unsigned)(drop_p * 65536.0f + 0.5f); a.mask = mask;
+    a.x_dropped = (x_dropped && drop_p > 0.f && a.thr16 != 0u) ? 1 : 0;      // (as txe_gat_prepare_desc.x_dropped)
+    a.drop_scale = 1.f / (1.f - drop_p);
     hipLaunchKernelGGL(gat_prepare_kernel, dim3(a.nb_x + a.nb_m + a.nb_w), dim3(T), 0, (hipStream_t)stream, a);
     TXE_CHECK_LAUNCH();
     return TXE_OK;
@@ -725,7 +728,7 @@ __global__ void reduce_splits_sub_kernel(const float* __restrict__ part, int S, 
 // d_hw [N][Fop] with zero padding columns.  Writes d_X columns [c0, Kt) (as txe_gat_dense_bwd), dW [Kt][Fo], dP.
 int txe_gcn_dense_bwd(const float* X, int n_nodes, int Kh, int Pd, const int* pos, int vocab, const float* Wp, int Fo, float drop_p,
                       const unsigned* mask, const float* d_hw, int need_dh, int act_on, float act_slope, float* d_X, float* dW,
-                      float* dP, void* ws, size_t ws_bytes, void* stream) {
+                      float* dP, int x_dropped, void* ws, size_t ws_bytes, void* stream) {
     if (n_nodes < 0 || Kh < 1 || Pd < 0 || Fo < 1 || !X || !Wp || !d_hw || !dW || !ws) return TXE_ERR_ARG;
     if ((need_dh || Pd > 0) && !d_X) return TXE_ERR_ARG;
     if (Pd > 0 && (!pos || !dP || vocab < 1 || vocab > MAX_VOCAB)) return TXE_ERR_ARG;
@@ -760,7 +763,7 @@ int txe_gcn_dense_bwd(const float* X, int n_nodes, int Kh, int Pd, const int* po
     }
     {   // dWp[k][f] = sum_m dropout(X)[m][k] * d_hw[m][f]
         VMat A = vmat_plain(X, Kp, n_nodes, Kp);
-        vmat_set_mask(A, mask, drop_p);
+        if (!x_dropped) vmat_set_mask(A, mask, drop_p);             // (x_dropped: X already holds dropout(X), txe_gcn_layer_prepare)
         VMat B = vmat_plain(d_hw, Fop, n_nodes, Fop);
         Epi E = epi_plain(p.part, Fop, Fop);
         E.split_stride = (long long)Kp * Fop;

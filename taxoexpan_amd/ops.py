@@ -712,7 +712,7 @@ def gcn_norm(csr, ref):
 
 
 class _GcnLayerState:
-    __slots__ = ("X", "Wp", "mask", "W", "b", "P", "Kh", "Pd", "Kp", "Fo", "Fop", "seed", "cl")
+    __slots__ = ("X", "Wp", "mask", "W", "b", "P", "Kh", "Pd", "Kp", "Fo", "Fop", "seed", "cl", "x_dropped")
 
 
 class GCNStackFunction(torch.autograd.Function):
@@ -766,9 +766,11 @@ class GCNStackFunction(torch.autograd.Function):
                     st.Wp = _empty((kp128, st.Fop), h)
                     st.mask = (torch.empty((N, (st.Kh + st.Pd + 31) // 32), dtype=torch.int32, device=h.device)
                                if cfg.drop_ps[l] > 0.0 else None)
+                    # (a first layer on raw features that is not the folded one: only its GEMMs read X -> stored with the dropout applied)
+                    st.x_dropped = bool(l == 0 and not (last and collapse) and cfg.drop_ps[l] > 0.0 and not _NO_X_DROPPED)
                     call("txe_gcn_layer_prepare", ptr(h if l == 0 else None), ld_h if l == 0 else 0, N, st.Kh,
                          ptr(pos if st.P is not None else None), ptr(st.P), st.Pd, ptr(st.X), ptr(st.W), st.Fo, ptr(st.Wp),
-                         cfg.drop_ps[l], st.seed, ptr(st.mask), st_)
+                         cfg.drop_ps[l], st.seed, ptr(st.mask), int(st.x_dropped), st_)
                 if last and collapse:
                     G = csr.n_graphs
                     coef, wsum = _empty((max(N, 1),), h), _empty((max(G, 1),), h)
@@ -790,8 +792,9 @@ class GCNStackFunction(torch.autograd.Function):
                          ptr(pos) if T2 is not None else None, N, st.Fop, ptr(hw), st.Fop, st_)
                     st.mask = st.Wp = None
                 else:
-                    call("txe_gcn_dense_fwd", ptr(st.X), N, st.Kh, st.Pd, ptr(st.Wp), st.Fo, cfg.drop_ps[l], ptr(st.mask), ptr(hw), ptr(tws),
-                         tws.numel(), st_)
+                    dropped = getattr(st, "x_dropped", False)
+                    call("txe_gcn_dense_fwd", ptr(st.X), N, st.Kh, st.Pd, ptr(st.Wp), st.Fo, 0.0 if dropped else cfg.drop_ps[l],
+                         None if dropped else ptr(st.mask), ptr(hw), ptr(tws), tws.numel(), st_)
                 if last:
                     out, ld_out = _empty((N, st.Fo), h), st.Fo
                 else:
@@ -874,7 +877,7 @@ class GCNStackFunction(torch.autograd.Function):
                 ws2 = _ws(wsb2, d_out)
                 call("txe_gcn_dense_bwd", ptr(st.X), N, st.Kh, st.Pd, ptr(pos if st.P is not None else None), cfg.vocab, ptr(st.Wp), st.Fo,
                      cfg.drop_ps[l], ptr(st.mask), ptr(d_hw), int(need_dh), int(act_on), (cfg.act_slopes[l - 1] if act_on else 1.0),
-                     ptr(d_X), ptr(dW), ptr(dP), ptr(ws2), wsb2, st_)
+                     ptr(d_X), ptr(dW), ptr(dP), int(getattr(st, "x_dropped", False)), ptr(ws2), wsb2, st_)
                 grads[3 * l:3 * l + 3] = [dW, d_b, dP]
                 if l > 0:
                     d_pre, ld_dpre = d_X, st.Kp

@@ -416,6 +416,7 @@ def _gat_layer_fwd(csr, st, h, ld_h, pos, out, ld_out, feat_p, attn_p, attn_slop
         dropped = getattr(st, "x_dropped", False)
         call("txe_gat_dense_fwd", ptr(st.X), N, Kh, Pd, ptr(st.Wp), H, D, 0.0 if dropped else feat_p, None if dropped else ptr(st.mask), ptr(st.Y),
              ptr(tws), tws.numel(), s)
+        _launch_pending_prefetch()
     st.alpha = _empty((max(csr.n_edges, 1), H), st.Y) if save else None
     call("txe_gat_aggregate_fwd", ptr(csr.rowptr_in), ptr(csr.col_src), N, ptr(st.Y), Fp, ptr(st.Y) + 4 * F, ptr(st.Y) + 4 * (F + H), Fp,
          H, D, attn_slope, attn_p, st.seed + 1, out_mode, act_slope, ptr(out), ld_out, ptr(st.alpha),
@@ -472,10 +473,11 @@ _NO_TABLE_SWEEP = os.environ.get("TXE_NO_TABLE_SWEEP", "0") == "1"      # A/B sw
 _NO_X_DROPPED = os.environ.get("TXE_NO_X_DROPPED", "0") == "1"        # A/B switch: the first layer's GEMM loaders apply the keep mask
 _NO_MULTI_PREPARE = os.environ.get("TXE_NO_MULTI_PREPARE", "0") == "1"   # A/B switch: one preparation launch per layer
 _NO_SIDE_STREAM = os.environ.get("TXE_NO_SIDE_STREAM", "0") == "1"      # A/B switch: everything on the caller's stream
-# The matcher's query projection V on the second stream under the encoder (bilinear_query_prefetch): OFF since the first-layer
-# projection runs on persistent workgroups -- V's workgroups take slots first, the persistent ones that start late finish late
-# (their tile lists are fixed), and the step loses 5 us more than the 44 us product costs on the caller's stream.
-_PREFETCH_V = os.environ.get("TXE_PREFETCH_V", "0") == "1"
+# The matcher's query projection V (bilinear_query_prefetch) on the second stream under the encoder's sweeps: started behind the first
+# projection GEMM (TXE_PREFETCH_V=2, the default: step -9 us).  Started at the very beginning (=1) its workgroups take slots before the
+# persistent first-layer projection's, whose late starters then finish late (their tile lists are fixed): -5 us only.  =0: in line.
+_PREFETCH_V = os.environ.get("TXE_PREFETCH_V", "2") in ("1", "2")
+_PREFETCH_V_LATE = os.environ.get("TXE_PREFETCH_V", "2") == "2"
 _side_streams = {}
 
 
@@ -1005,10 +1007,32 @@ def bilinear_query_prefetch(e2, W):
     l = Wf.shape[0]
     main, side = torch.cuda.current_stream(e2.device), _side_stream(e2.device)
     V = _empty((G, l), e2c)
-    side.wait_stream(main)
-    with torch.cuda.device(e2.device), torch.cuda.stream(side):
-        call("txe_bilinear_query_project", ptr(e2c), ld2, G, l, r, ptr(Wf), ptr(V), _lib.stream_ptr())
-    return dict(V=V, e2=e2, e2_version=e2._version, W=W, W_version=W._version, stream=side, e2c=e2c)
+    tok = dict(V=V, e2=e2, e2_version=e2._version, W=W, W_version=W._version, stream=side, e2c=e2c, launched=False)
+
+    def launch(on_side=True):
+        if tok["launched"]:
+            return
+        tok["launched"] = True
+        if on_side:
+            side.wait_stream(torch.cuda.current_stream(e2.device))
+        with torch.cuda.device(e2.device), torch.cuda.stream(side if on_side else torch.cuda.current_stream(e2.device)):
+            call("txe_bilinear_query_project", ptr(e2c), ld2, G, l, r, ptr(Wf), ptr(V), _lib.stream_ptr())
+        tok["stream"] = side if on_side else None
+    tok["launch"] = launch
+    if _PREFETCH_V_LATE:                        # launched by the encoder behind its first projection GEMM (_launch_pending_prefetch)
+        del _pending_prefetch[:]
+        _pending_prefetch.append(tok)
+    else:
+        launch()
+    return tok
+
+
+_pending_prefetch = []
+
+
+def _launch_pending_prefetch():
+    while _pending_prefetch:
+        _pending_prefetch.pop()["launch"]()
 
 
 class BilinearPairFunction(torch.autograd.Function):
@@ -1034,7 +1058,9 @@ class BilinearPairFunction(torch.autograd.Function):
                          and pre["W_version"] == W._version and tuple(pre["V"].shape) == (G, l))
                 if ready:
                     U = pre["V"]
-                    torch.cuda.current_stream().wait_stream(pre["stream"])
+                    pre["launch"](on_side=False)                 # (nobody started it: in line, on this stream)
+                    if pre["stream"] is not None:
+                        torch.cuda.current_stream().wait_stream(pre["stream"])
                     call("txe_bilinear_query_dot", ptr(e1), ld1, ptr(U), G, l, int(apply_exp), ptr(s), _lib.stream_ptr())
                 else:
                     U = _empty((max(G, 1), l), e1)          # V = e2 W^T

@@ -317,22 +317,24 @@ def test_readout_and_match_ops_against_oracle():
 
 
 def test_query_projection_prefetched_on_the_second_stream_changes_nothing(monkeypatch):
-    """TXE_PREFETCH_V=1 (ops.bilinear_query_prefetch, off by default): TaxoExpan.forward launches the matcher's query projection on the
-    second stream before the encoder; scores and gradients are those of the in-line projection, bit for bit"""
+    """ops.bilinear_query_prefetch: the matcher's query projection runs on the second stream under the encoder (started behind the first
+    projection GEMM by default, at the very beginning with TXE_PREFETCH_V=1) or in line (=0): same scores and gradients, bit for bit"""
     from taxoexpan_amd import ops
     name = next(n for n in NODROP if gc.CASES[n]["match"] in ("LBM", "BIM"))
     spec, z, shapes, x, q, params, graph = load_case(name)
     model = _build_model(spec, params).eval()
     outs = []
-    for on in (False, True):
+    for on, late in ((False, False), (True, False), (True, True)):
         monkeypatch.setattr(ops, "_PREFETCH_V", on)
+        monkeypatch.setattr(ops, "_PREFETCH_V_LATE", late)
         model.zero_grad(set_to_none=True)
         s = model(_graph(shapes), torch.from_numpy(x).to(_dev()), torch.from_numpy(q).to(_dev()))
         s.sum().backward()
         torch.cuda.synchronize()
         outs.append((s.detach().clone(), {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}))
-    assert torch.equal(outs[0][0], outs[1][0])
-    assert outs[0][1].keys() == outs[1][1].keys() and all(torch.equal(outs[0][1][k], outs[1][1][k]) for k in outs[0][1])
+    for o in outs[1:]:
+        assert torch.equal(outs[0][0], o[0])
+        assert outs[0][1].keys() == o[1].keys() and all(torch.equal(outs[0][1][k], o[1][k]) for k in o[1])
 
 
 def test_scoring_loop_and_ranks_against_reference_goldens():

@@ -446,6 +446,7 @@ int txe_gat_layer_prepare(const float* h, long long ld_h, int n_nodes, int Kh, c
     a.W = W; a.attn_l = attn_l; a.attn_r = attn_r; a.H = H; a.D = D; a.Wp = Wp;
     a.pk_rows = a.F; a.pk_ext = a.Fe; a.pk_prows = a.Fp; a.pk_cols = a.Kt; a.pk_pcols = a.Kp;
     a.seed = seed; a.thr16 = (unsigned)(feat_drop_p * 65536.0f + 0.5f); a.mask = mask;
+    a.x_dropped = 0; a.drop_scale = 1.f;                                  // (this entry leaves the dropout to the GEMM loaders)
     hipLaunchKernelGGL(gat_prepare_kernel, dim3(a.nb_x + a.nb_m + a.nb_w + a.nb_f), dim3(T), 0, (hipStream_t)stream, a);
     TXE_CHECK_LAUNCH();
     return TXE_OK;

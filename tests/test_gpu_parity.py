@@ -115,6 +115,32 @@ def test_training_mode_dropout_matches_oracle(name, drop, monkeypatch):
         np.testing.assert_allclose(p.grad.cpu().numpy(), P[k].grad.numpy(), rtol=2e-3, atol=2e-5, err_msg=k)
 
 
+@pytest.mark.parametrize("switch", ["_NO_MULTI_PREPARE", "_NO_X_DROPPED", "_NO_SIDE_STREAM", "_NO_FUSED_BWD", "_NO_FUSED_LOGITS"])
+def test_ab_switch_routes_give_the_same_training_step(switch, monkeypatch):
+    """every A/B switch of ops.py selects another ROUTE to the same numbers: a training step (dropout on, fixed seed) of the 2-layer
+    PGAT case with the switch set against the default -- scores and every gradient (the per-layer preparation entry once left the
+    stored-dropped flag of its argument block uninitialised: the default route never noticed)"""
+    from taxoexpan_amd import ops
+    spec, z, shapes, x, q, params, graph = load_case("small_pgat_2layer")
+    spec = dict(spec, dropout=(0.3, 0.25))
+    monkeypatch.setattr(ops, "new_seed", lambda: 424242)
+    outs = []
+    for on in (False, True):
+        monkeypatch.setattr(ops, switch, on)
+        model = _build_model(spec, params).train()
+        xg = torch.from_numpy(x).to(_dev()).requires_grad_(True)
+        s = model(_graph(shapes), xg, torch.from_numpy(q).to(_dev()))
+        nq = spec["n_queries"]
+        torch.nn.functional.cross_entropy(s.reshape(nq, -1), torch.zeros(nq, dtype=torch.long, device=_dev()), reduction="sum").backward()
+        torch.cuda.synchronize()
+        outs.append((s.detach().cpu().numpy(), xg.grad.cpu().numpy(), {k: p.grad.cpu().numpy() for k, p in model.named_parameters()}))
+    assert np.isfinite(outs[1][0]).all()
+    np.testing.assert_allclose(outs[1][0], outs[0][0], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(outs[1][1], outs[0][1], rtol=1e-4, atol=1e-6)
+    for k in outs[0][2]:
+        np.testing.assert_allclose(outs[1][2][k], outs[0][2][k], rtol=1e-4, atol=1e-6, err_msg=k)
+
+
 def _random_graph(n, e, seed, zero_in=True):
     """generic multigraph: a hub with in-degree > 64 (multi-chunk path), some nodes without in-edges"""
     rs = np.random.RandomState(seed)

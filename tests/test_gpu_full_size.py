@@ -122,8 +122,10 @@ def test_fused_stack_intermediates_match_reference_goldens(name):
     """layer{l}_alpha (model_zoo.py:112-114, edge-id order) and layer{l}_out (GATLayer.forward's return, :95-104; every 5th node row
     for the MAG-dimension cases) of the reference run against the fused stack: hidden layers through the aggregation kernel's
     activated output (the next layer's padded input), the folded output layer through its attention buffer and, unfolded, `h.tensor()`"""
-    from taxoexpan_amd import TaxoExpan, ops
+    from taxoexpan_amd import TaxoExpan, model_zoo, ops
     from taxoexpan_amd.graph import BatchedDGLGraph
+    if model_zoo._NO_FOLD:
+        pytest.skip("TXE_NO_FOLD=1: the folded output layer this test looks into is switched off")
     spec, z, shapes, x, q, params, graph = load_case(name)
     dev = _dev()
     model = TaxoExpan(spec["prop"], spec["readout"], spec["match"], in_dim=spec["in_dim"], hidden_dim=spec["hidden_dim"], out_dim=spec["out_dim"],

@@ -432,6 +432,7 @@ int txe_gat_layer_prepare(const float* h, long long ld_h, int n_nodes, int Kh, c
     if (feat_drop_p < 0.f || feat_drop_p >= 1.f || (feat_drop_p > 0.f && !mask)) return TXE_ERR_ARG;
     const int T = 64 * FOLD_DG;
     PrepArgs a;
+    memset(&a, 0, sizeof(a));
     a.Kt = Kh + Pd; a.Kp = round_up(a.Kt, 32);
     a.F = H * D; a.Fe = a.F + 2 * H; a.Fp = round_up(a.Fe, 128);
     auto blocks = [&](long long n, int cap) { const long long b = (n + T - 1) / T; return (int)(b < cap ? b : cap); };
@@ -1981,6 +1982,7 @@ int txe_gat_collapse_bwd_fused(const int* rowptr_in, const int* col_src, const i
                            p.da1, p.da2, p.dwv);
         {
             FusedBwdArgs a;
+            memset(&a, 0, sizeof(a));
             a.rowptr_out = rowptr_out; a.col_dst = col_dst; a.pos_out = pos_out; a.gid = gid; a.pos = pos ? pos : gid; a.n_nodes = n_nodes;
             a.X = X; a.Kp = Kp; a.Kh = Kh; a.Pd = Pd; a.mask = mk ? mk : dummy_mask; a.mask_ld = mask_ld; a.fscale = fs;
             a.dZ = p.dZ; a.cn = p.cn; a.da1 = p.da1; a.da2 = p.da2; a.wa = wa; a.act_slope = act_slope; a.vocab = vocab > 0 ? vocab : 1;

@@ -141,6 +141,51 @@ def test_ab_switch_routes_give_the_same_training_step(switch, monkeypatch):
         np.testing.assert_allclose(outs[1][2][k], outs[0][2][k], rtol=1e-4, atol=1e-6, err_msg=k)
 
 
+def test_prepare_entries_agree_and_stored_dropped_input_matches_its_mask():
+    """txe_gat_layer_prepare (one layer) == txe_gat_layers_prepare (the stack's one launch) on X / Wp / mask; with x_dropped the stored
+    input is the plain one times keep(mask) / (1 - p), from the very bits written into the mask (rng.keep_mask_bits restates them)"""
+    import ctypes
+    from taxoexpan_amd import _lib, rng
+    dev = _dev()
+    rs = np.random.RandomState(3)
+    N, Kh, Pd, H, D, p, seed = 517, 250, 50, 4, 24, 0.3, 9876543210
+    Kt = Kh + Pd
+    Kp, Fp = _lib.call("txe_gat_padded_k", Kh, Pd), _lib.call("txe_gat_padded_f", H, D)
+    h = torch.from_numpy(rs.standard_normal((N, Kh)).astype(np.float32)).to(dev)
+    pos = torch.from_numpy(rs.randint(0, 3, N).astype(np.int32)).to(dev)
+    P = torch.from_numpy(rs.standard_normal((3, Pd)).astype(np.float32)).to(dev)
+    W = torch.from_numpy(rs.standard_normal((H * D, Kt)).astype(np.float32)).to(dev)
+    al, ar = (torch.from_numpy(rs.standard_normal((1, H, D)).astype(np.float32)).to(dev) for _ in range(2))
+    wpr = (Kt + 31) // 32
+
+    def bufs():
+        return (torch.full((N, Kp), 7.0, device=dev), torch.full((Fp, Kp), 7.0, device=dev), torch.zeros((N, wpr), dtype=torch.int32, device=dev))
+
+    def multi(x_dropped):
+        X, Wp, mask = bufs()
+        d = (_lib.GatPrepareDesc * 1)()
+        d[0].h, d[0].ld_h, d[0].n_nodes, d[0].Kh, d[0].pos, d[0].P, d[0].Pd, d[0].X = h.data_ptr(), Kh, N, Kh, pos.data_ptr(), P.data_ptr(), Pd, X.data_ptr()
+        d[0].W, d[0].attn_l, d[0].attn_r, d[0].H, d[0].D, d[0].Wp = W.data_ptr(), al.data_ptr(), ar.data_ptr(), H, D, Wp.data_ptr()
+        d[0].feat_drop_p, d[0].seed, d[0].mask, d[0].x_dropped = p, seed, mask.data_ptr(), x_dropped
+        _lib.call("txe_gat_layers_prepare", ctypes.cast(d, ctypes.c_void_p), 1, _lib.stream_ptr())
+        torch.cuda.synchronize()
+        return X, Wp, mask
+    X1, Wp1, m1 = bufs()
+    _lib.call("txe_gat_layer_prepare", h.data_ptr(), Kh, N, Kh, pos.data_ptr(), P.data_ptr(), Pd, X1.data_ptr(), W.data_ptr(), al.data_ptr(),
+              ar.data_ptr(), H, D, Wp1.data_ptr(), p, seed, m1.data_ptr(), _lib.stream_ptr())
+    torch.cuda.synchronize()
+    X2, Wp2, m2 = multi(0)
+    assert torch.equal(X1, X2) and torch.equal(Wp1, Wp2) and torch.equal(m1, m2)
+    want = torch.cat([h, P[pos.long()], torch.zeros(N, Kp - Kt, device=dev)], dim=1)
+    assert torch.equal(X2, want)
+    X3, Wp3, m3 = multi(1)
+    assert torch.equal(Wp3, Wp2) and torch.equal(m3, m2)
+    keep = torch.from_numpy(rng.keep_mask_bits(seed, N, Kt, p)).to(dev)
+    want3 = want.clone()
+    want3[:, :Kt] = want[:, :Kt] * keep * (1.0 / (1.0 - p))
+    assert torch.equal(X3, want3)
+
+
 def _random_graph(n, e, seed, zero_in=True):
     """generic multigraph: a hub with in-degree > 64 (multi-chunk path), some nodes without in-edges"""
     rs = np.random.RandomState(seed)

@@ -80,17 +80,30 @@ __host__ __device__ __forceinline__ float drop_factor(uint64_t seed, uint64_t id
     return (uniform01(seed, idx) >= p) ? scale : 0.0f;
 }
 
-// Feature-dropout bit mask (1 = keep), 32 columns per word, words_per_row = ceil(cols/32).  Word w of the whole mask is
-// built from 8 hashes x 4 16-bit chunks: bit (4j+c) = chunk c of mix64(seed + (8w+j) * W) >= thr16, thr16 = round(p*65536) --
-// a SplitMix64 stream with a Weyl step W per counter: ONE finaliser per 64 random bits (the mask of the folded layer's 2,080-column
-// input is 1.2 M words per step; with the counter itself hashed first the preparation launch spent half of its time here).
+// Feature-dropout bit mask (1 = keep), 32 columns per word, words_per_row = ceil(cols/32).  Bit b of word w is
+// [u(w, b) >= thr16], thr16 = round(p * 65536), where the 16-bit uniform u(w, b) is assembled BIT-PLANE-WISE: its bit j (15 = most
+// significant) is bit b of the plane word R(w, j) = 32-bit half (j & 1) of mix64(seed + (8w + (j >> 1)) * W) -- a SplitMix64 stream with
+// a Weyl step W per counter.  The comparison then runs on all 32 columns of a word at once,
+//     ge = ~0;   for j = (lowest set bit of thr16) .. 15:   ge = (thr16 >> j) & 1 ? ge & R_j : ge | R_j
+// and the planes below thr16's lowest set bit never matter: p = 0.5 (thr16 = 0x8000, PGAT's default) costs ONE finaliser per mask
+// word, p = 0.1 eight -- against eight for every p when each column compared a 16-bit chunk of its own (the mask of the folded
+// layer's 2,080-column input is 1.2 M words per step: 12 us of VALU work across the whole chip).
 __host__ __device__ __forceinline__ unsigned drop_mask_word(uint64_t seed, uint64_t word_index, unsigned thr16) {
-    unsigned bits = 0;
-    for (int j = 0; j < 8; ++j) {
-        const uint64_t h = mix64(seed + (word_index * 8 + j) * 0xD1342543DE82EF95ull);
-        for (int c = 0; c < 4; ++c) bits |= ((unsigned)((h >> (16 * c)) & 0xFFFFu) >= thr16 ? 1u : 0u) << (4 * j + c);
+    if (thr16 == 0u) return 0xFFFFFFFFu;
+    if (thr16 > 0xFFFFu) return 0u;
+    int j0 = 0;
+    while (((thr16 >> j0) & 1u) == 0u) ++j0;
+    unsigned ge = 0xFFFFFFFFu;
+    for (int k = j0 >> 1; k < 8; ++k) {
+        const uint64_t h = mix64(seed + (word_index * 8 + k) * 0xD1342543DE82EF95ull);
+        for (int half = 0; half < 2; ++half) {
+            const int j = 2 * k + half;
+            if (j < j0) continue;
+            const unsigned r = (unsigned)(h >> (32 * half));
+            ge = ((thr16 >> j) & 1u) ? (ge & r) : (ge | r);
+        }
     }
-    return bits;
+    return ge;
 }
 
 __device__ __forceinline__ float leaky(float x, float slope) { return x > 0.f ? x : x * slope; }

@@ -257,17 +257,45 @@ namespace txe {
 static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 
 // Wp[f][k] = W[f][k] (f < F, k < Kt) else 0   (rows F..Fe are written by fold_attn_kernel)
+// One thread per 4 consecutive packed columns (Kp % 4 == 0), two such quads in flight per thread: every load is issued before the
+// first store, the packed row leaves as 16-byte stores.  (One wave per row with a scalar column loop made the 2,080-column rows of
+// the output layer a 33-deep load -> store chain per wave.)
+constexpr int PREP_U = 2;
 __device__ __forceinline__ void pack_w_job(const int bid, const int nb, const float* __restrict__ W, int F, int Fe, int Fp, int Kt, int Kp,
                                            float* __restrict__ Wp) {
-    // one wave per packed row (32-bit index math only): W rows are Kt floats apart, Wp rows Kp
-    const int wpb = blockDim.x >> 6, wv = threadIdx.x >> 6, l = threadIdx.x & 63;
-    for (int f = bid * wpb + wv; f < Fp; f += nb * wpb) {
-        if (f >= F && f < Fe) {                                  // folded rows: other job writes [0, Kt); zero the padding here
-            for (int k = Kt + l; k < Kp; k += 64) Wp[(long long)f * Kp + k] = 0.f;
-            continue;
+    const unsigned qpr = (unsigned)Kp >> 2, total = (unsigned)Fp * qpr;          // (a weight matrix: far below 2^32 quads)
+    const bool v2 = ((Kt & 1) == 0) && (((uintptr_t)W & 7) == 0);                // rows 8-byte aligned: float2 loads
+    for (unsigned base = (unsigned)bid * blockDim.x * PREP_U; base < total; base += (unsigned)nb * blockDim.x * PREP_U) {
+        float v[PREP_U][4];
+        unsigned fi[PREP_U], ki[PREP_U];
+#pragma unroll
+        for (int u = 0; u < PREP_U; ++u) {
+            const unsigned i = base + u * blockDim.x + threadIdx.x;
+            const unsigned f = i / qpr, k = (i - f * qpr) * 4;
+            fi[u] = f; ki[u] = k;
+            const bool live = i < total && f < (unsigned)F;
+            const float* src = W + (long long)(live ? f : 0) * Kt;
+            if (live && k + 3 < (unsigned)Kt && v2) {
+                const float2 a = *reinterpret_cast<const float2*>(src + k), b = *reinterpret_cast<const float2*>(src + k + 2);
+                v[u][0] = a.x; v[u][1] = a.y; v[u][2] = b.x; v[u][3] = b.y;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[u][e] = (live && k + e < (unsigned)Kt) ? src[k + e] : 0.f;
+            }
         }
-        const float* src = W + (long long)(f < F ? f : 0) * Kt;
-        for (int k = l; k < Kp; k += 64) Wp[(long long)f * Kp + k] = (f < F && k < Kt) ? src[k] : 0.f;
+#pragma unroll
+        for (int u = 0; u < PREP_U; ++u) {
+            const unsigned i = base + u * blockDim.x + threadIdx.x;
+            if (i >= total) continue;
+            float* dst = Wp + (long long)fi[u] * Kp + ki[u];
+            if (fi[u] >= (unsigned)F && fi[u] < (unsigned)Fe) {                   // folded rows: the other job writes [0, Kt); zero the padding
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (ki[u] + e >= (unsigned)Kt) dst[e] = 0.f;
+            } else {
+                *reinterpret_cast<float4*>(dst) = make_float4(v[u][0], v[u][1], v[u][2], v[u][3]);
+            }
+        }
     }
 }
 __global__ void pack_w_kernel(const float* __restrict__ W, int F, int Fe, int Fp, int Kt, int Kp, float* __restrict__ Wp) {
@@ -277,30 +305,105 @@ __global__ void pack_w_kernel(const float* __restrict__ W, int F, int Fe, int Fp
 // X[r][c] = h[r][c] (c < Kh, only when h != NULL) | P[pos[r]][c-Kh] (Kh <= c < Kt) | 0 (Kt <= c < Kp)
 // drop_thr16 != 0: the feature dropout is applied HERE (X[r][c] *= keep(r, c) ? drop_scale : 0, the very bits of drop_mask_word over
 // ceil(Kt/32) words per row): the layer's GEMMs then read X as a plain operand -- no mask words, no selects in their loaders (the
-// first-layer projection and its weight gradient: 226 -> 213 us, 282 -> 269 us).
+// first-layer projection and its weight gradient: 226 -> 213 us, 282 -> 269 us).  With `mask` given (only when h != NULL: every
+// word of a row is then needed here anyway) the job also WRITES the keep mask, and the launch needs no mask job for this layer.
+//
+// A workgroup owns a block of consecutive rows; one thread per 4 consecutive columns (a "quad", Kp % 32 == 0), PREP_UX quads in
+// flight per thread, 16-byte stores.  Branch-free: every quad issues its pos[] load and its (column-clamped) feature loads, the
+// workgroup then hashes the rows' mask words ONCE each into LDS (under those loads' latency), and -- pos[] being the oldest load in
+// flight -- the (clamped) position-embedding loads follow; selects afterwards: two memory latencies per thread whatever mix of
+// feature / embedding / padding quads a wave holds.  (One wave per row with a scalar column loop ran 5 dependent load -> hash ->
+// store rounds per wave; divergent quad kinds with the dependent pos -> P chain inside a branch were slower still.)
+constexpr int PREP_UX = 4;
+constexpr int PREP_LDSW = 4096;                         // mask words a row block may hold in LDS
 __device__ __forceinline__ void build_x_job(const int bid, const int nb, const float* __restrict__ h, long long ld_h, const int* __restrict__ pos,
                                             const float* __restrict__ P, int n_rows, int Kh, int Pd, int Kp, float* __restrict__ X,
-                                            const unsigned long long drop_seed = 0, const unsigned drop_thr16 = 0, const float drop_scale = 1.f) {
-    // one wave per row, lanes along the columns: no per-element division, coalesced reads of h / P and writes of X
-    const int wpb = blockDim.x >> 6, wv = threadIdx.x >> 6, l = threadIdx.x & 63;
-    const int c0 = h ? 0 : Kh;
-    for (int r = bid * wpb + wv; r < n_rows; r += nb * wpb) {
-        const float* hrow = h ? h + (long long)r * ld_h : nullptr;
-        const float* prow = (Pd > 0) ? P + (long long)pos[r] * Pd : nullptr;
-        float* xrow = X + (long long)r * Kp;
-        const int wpr = (Kh + Pd + 31) >> 5;
-        for (int c = c0 + l; c < Kp; c += 64) {
-            float v = 0.f;
-            if (c < Kh) v = hrow[c];
-            else if (c < Kh + Pd) v = prow[c - Kh];
-            if (drop_thr16 != 0u && c < Kh + Pd) {                   // bit (4j+cc) of word w = chunk cc of hash j  (drop_mask_word)
-                const unsigned long long w = (unsigned long long)r * wpr + (c >> 5);
-                const int j = (c & 31) >> 2, cc = c & 3;
-                const uint64_t hsh = mix64(drop_seed + (w * 8 + j) * 0xD1342543DE82EF95ull);
-                v = ((unsigned)((hsh >> (16 * cc)) & 0xFFFFu) >= drop_thr16) ? v * drop_scale : 0.f;
+                                            const unsigned long long drop_seed = 0, const unsigned drop_thr16 = 0, const float drop_scale = 1.f,
+                                            unsigned* __restrict__ mask = nullptr) {
+    __shared__ unsigned s_words[PREP_LDSW];
+    const int T = blockDim.x;
+    const int Kt = Kh + Pd, wpr = (Kt + 31) >> 5;
+    const int q0 = h ? 0 : (Kh >> 2);                   // h == NULL: columns [0, Kh) are in place already
+    const int qn = (Kp >> 2) - q0;                      // quads per row handled here
+    const int w_lo = (q0 * 4) >> 5, nw = (Kp >> 5) - w_lo;   // mask words of a row that cover those quads (Kp/32 >= wpr; words >= wpr: no bits)
+    const bool drop = drop_thr16 != 0u;
+    const bool lds_words = drop && nw <= PREP_LDSW;
+    int RB = (T * PREP_UX) / qn;                        // rows per block: one pass of PREP_UX quads per thread
+    if (RB < 1) RB = 1;
+    if (lds_words && RB * nw > PREP_LDSW) RB = PREP_LDSW / nw;
+    const bool v2 = h && Kh >= 2 && ((Kh & 1) == 0) && ((ld_h & 1) == 0) && (((uintptr_t)h & 7) == 0);   // whole 8-byte pairs inside a row
+    for (long long r0l = (long long)bid * RB; r0l < n_rows; r0l += (long long)nb * RB) {
+        const int r0 = (int)r0l, nr = min(RB, n_rows - r0), nq = nr * qn;
+        for (int pb = 0; pb < nq; pb += T * PREP_UX) {  // (one pass unless a single row has more than T * PREP_UX quads)
+            float hv[PREP_UX][4], pv[PREP_UX][4];
+            int li[PREP_UX], ci[PREP_UX], pr[PREP_UX];  // local row (-1: no quad), first column, pos[]
+#pragma unroll
+            for (int u = 0; u < PREP_UX; ++u) {
+                const int i = pb + u * T + (int)threadIdx.x;
+                const bool live = i < nq;
+                const int lr = live ? i / qn : 0;
+                li[u] = live ? lr : -1;
+                ci[u] = (q0 + (live ? i - lr * qn : 0)) * 4;
+                pr[u] = (Pd > 0) ? pos[r0 + lr] : 0;
             }
-            xrow[c] = v;
+            if (h) {
+#pragma unroll
+                for (int u = 0; u < PREP_UX; ++u) {
+                    const float* hrow = h + (long long)(r0 + max(li[u], 0)) * ld_h;
+                    const int c = ci[u];
+                    if (v2) {
+                        const float2 a = *reinterpret_cast<const float2*>(hrow + min(c, Kh - 2));
+                        const float2 b = *reinterpret_cast<const float2*>(hrow + min(c + 2, Kh - 2));
+                        hv[u][0] = a.x; hv[u][1] = a.y; hv[u][2] = b.x; hv[u][3] = b.y;
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) hv[u][e] = hrow[min(c + e, Kh - 1)];
+                    }
+                }
+            }
+            if (lds_words && pb == 0) {                 // the block's mask words, once each (under the loads above)
+                for (int wi = threadIdx.x; wi < nr * nw; wi += T) {
+                    const int lr = wi / nw, wl = w_lo + (wi - lr * nw);
+                    const unsigned long long w = (unsigned long long)(r0 + lr) * wpr + wl;
+                    const unsigned word = (wl < wpr) ? drop_mask_word(drop_seed, w, drop_thr16) : 0u;
+                    s_words[wi] = word;
+                    if (mask && wl < wpr) mask[w] = word;
+                }
+                __syncthreads();
+            }
+            if (Pd > 0) {
+#pragma unroll
+                for (int u = 0; u < PREP_UX; ++u) {
+                    const float* prow = P + (long long)pr[u] * Pd;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) pv[u][e] = prow[min(max(ci[u] + e - Kh, 0), Pd - 1)];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < PREP_UX; ++u) {
+                if (li[u] < 0) continue;
+                const int r = r0 + li[u], c = ci[u];
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = (c + e < Kh) ? (h ? hv[u][e] : 0.f) : ((c + e < Kt) ? pv[u][e] : 0.f);
+                if (drop && c < Kt) {                   // bits (c & 31) .. +3 of the row's mask word c / 32
+                    const unsigned word = lds_words ? s_words[li[u] * nw + (c >> 5) - w_lo]
+                                                    : drop_mask_word(drop_seed, (unsigned long long)r * wpr + (c >> 5), drop_thr16);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)         // (columns in [Kt, Kp) hold zeros: scaling them is harmless)
+                        v[e] = ((word >> ((c & 31) + e)) & 1u) ? v[e] * drop_scale : 0.f;
+                }
+                float* dst = X + (long long)r * Kp + c;
+                if (!h && c < Kh) {                     // the quad straddling Kh: its feature columns belong to the layer below
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (c + e >= Kh) dst[e] = v[e];
+                } else {
+                    *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+                }
+            }
         }
+        if (lds_words) __syncthreads();                 // (the next row block overwrites the words)
     }
 }
 __global__ void build_x_kernel(const float* __restrict__ h, long long ld_h, const int* __restrict__ pos, const float* __restrict__ P,
@@ -310,17 +413,27 @@ __global__ void build_x_kernel(const float* __restrict__ h, long long ld_h, cons
 
 // Everything a GATLayer needs before its projection GEMM, in ONE launch (four independent jobs on disjoint ranges of workgroups):
 // layer input X (build_x), packed weights Wp (pack_w), folded attention rows (fold_attn), feature-dropout keep mask.
+// workgroups of build_x_job: one per block of rows (the device code's RB)
+static inline int build_x_blocks(int T, int n_rows, int Kh, int Pd, int Kp, bool has_h, bool drop, int cap) {
+    const int q0 = has_h ? 0 : (Kh >> 2), qn = (Kp >> 2) - q0, nw = (Kp >> 5) - ((q0 * 4) >> 5);
+    if (qn <= 0 || n_rows <= 0) return 0;
+    int RB = (T * PREP_UX) / qn;
+    if (RB < 1) RB = 1;
+    if (drop && nw <= PREP_LDSW && RB * nw > PREP_LDSW) RB = PREP_LDSW / nw;
+    const long long b = ((long long)n_rows + RB - 1) / RB;
+    return (int)(b < cap ? b : cap);
+}
 struct PrepArgs {
     int nb_x, nb_w, nb_f, nb_m, fold_bx;
     const float* h; long long ld_h; const int* pos; const float* P; int n_rows, Kh, Pd, Kp; float* X;
     const float *W, *attn_l, *attn_r; int H, D, F, Fe, Fp, Kt; float* Wp;
     int pk_rows, pk_ext, pk_prows, pk_cols, pk_pcols;       // packing job: W [pk_rows][pk_cols] -> Wp [pk_prows][pk_pcols], rows [pk_rows, pk_ext) left to fold
     long long n_words; unsigned long long seed; unsigned thr16; unsigned* mask;
-    int x_dropped; float drop_scale;                        // build_x applies the dropout itself (the mask is still written)
+    int x_dropped; float drop_scale;                        // build_x applies the dropout itself (the mask is still written:
+    int x_mask;                                             //  by build_x too when x_mask, else by the mask job)
 };
-__global__ __launch_bounds__(64 * FOLD_DG) void gat_prepare_kernel(const PrepArgs a) {
+__device__ __forceinline__ void prepare_jobs(const PrepArgs& a, int b) {
     // the latency-bound job (a strided reduction per folded row) is dispatched first, the streaming jobs fill in behind it
-    int b = blockIdx.x;
     if (b < a.nb_f) {
         fold_attn_job(b % a.fold_bx, b / a.fold_bx, a.W, (long long)a.Kt, a.Kt, a.attn_l, a.attn_r, a.H, a.D, a.Wp + (long long)a.F * a.Kp,
                       (long long)a.Kp);
@@ -331,8 +444,10 @@ __global__ __launch_bounds__(64 * FOLD_DG) void gat_prepare_kernel(const PrepArg
     b -= a.nb_w;
     if (b < a.nb_m) { dropout_mask_job(b, a.nb_m, a.n_words, a.seed, a.thr16, a.mask); return; }
     b -= a.nb_m;
-    build_x_job(b, a.nb_x, a.h, a.ld_h, a.pos, a.P, a.n_rows, a.Kh, a.Pd, a.Kp, a.X, a.seed, a.x_dropped ? a.thr16 : 0u, a.drop_scale);
+    build_x_job(b, a.nb_x, a.h, a.ld_h, a.pos, a.P, a.n_rows, a.Kh, a.Pd, a.Kp, a.X, a.seed, a.x_dropped ? a.thr16 : 0u, a.drop_scale,
+                a.x_mask ? a.mask : nullptr);
 }
+__global__ __launch_bounds__(64 * FOLD_DG) void gat_prepare_kernel(const PrepArgs a) { prepare_jobs(a, blockIdx.x); }
 
 // zero columns [c0, c1) of a row-major [n_rows][ld] matrix
 __global__ void zero_cols_kernel(float* __restrict__ x, long long ld, int n_rows, int c0, int c1) {
@@ -437,10 +552,10 @@ int txe_gat_layer_prepare(const float* h, long long ld_h, int n_nodes, int Kh, c
     a.F = H * D; a.Fe = a.F + 2 * H; a.Fp = round_up(a.Fe, 128);
     auto blocks = [&](long long n, int cap) { const long long b = (n + T - 1) / T; return (int)(b < cap ? b : cap); };
     const long long nx = (long long)n_nodes * (a.Kp - (h ? 0 : Kh));
-    a.nb_x = nx > 0 ? blocks((long long)n_nodes * 64, 2048) : 0;          // one wave per row
+    a.nb_x = nx > 0 ? build_x_blocks(T, n_nodes, Kh, Pd, a.Kp, h != nullptr, false, 2048) : 0;
     a.n_words = (feat_drop_p > 0.f) ? (long long)n_nodes * ((a.Kt + 31) / 32) : 0;
     a.nb_m = blocks(a.n_words, 1024);
-    a.nb_w = blocks((long long)a.Fp * 64, 512);                            // one wave per packed row
+    a.nb_w = blocks(((long long)a.Fp * a.Kp / 4 + PREP_U - 1) / PREP_U, 512);   // PREP_U quads per thread
     a.fold_bx = (a.Kt + 63) / 64;
     a.nb_f = a.fold_bx * 2 * H;
     a.h = h; a.ld_h = ld_h; a.pos = pos; a.P = P; a.n_rows = n_nodes; a.Kh = Kh; a.Pd = Pd; a.X = X;
@@ -469,20 +584,12 @@ struct PrepMulti { int n; int nb_end[PREP_MAXL]; PrepArgs a[PREP_MAXL]; };
 __global__ __launch_bounds__(64 * FOLD_DG) void gat_prepare_multi_kernel(const PrepMulti m) {
     int b = blockIdx.x, i = 0;
     while (i + 1 < m.n && b >= m.nb_end[i]) ++i;                    // (block-uniform)
-    const PrepArgs& a = m.a[i];
-    b -= (i > 0) ? m.nb_end[i - 1] : 0;
-    if (b < a.nb_f) {
-        fold_attn_job(b % a.fold_bx, b / a.fold_bx, a.W, (long long)a.Kt, a.Kt, a.attn_l, a.attn_r, a.H, a.D, a.Wp + (long long)a.F * a.Kp,
-                      (long long)a.Kp);
-        return;
-    }
-    b -= a.nb_f;
-    if (b < a.nb_w) { pack_w_job(b, a.nb_w, a.W, a.pk_rows, a.pk_ext, a.pk_prows, a.pk_cols, a.pk_pcols, a.Wp); return; }
-    b -= a.nb_w;
-    if (b < a.nb_m) { dropout_mask_job(b, a.nb_m, a.n_words, a.seed, a.thr16, a.mask); return; }
-    b -= a.nb_m;
-    build_x_job(b, a.nb_x, a.h, a.ld_h, a.pos, a.P, a.n_rows, a.Kh, a.Pd, a.Kp, a.X, a.seed, a.x_dropped ? a.thr16 : 0u, a.drop_scale);
+    prepare_jobs(m.a[i], b - ((i > 0) ? m.nb_end[i - 1] : 0));
 }
+// (measured on the 18 k-node training batch, 35 us layer after layer: the VALU-bound mask jobs and the streaming jobs dealt
+//  alternately, one of each per CU: 40.5 us; JOB-major order over the layers -- folds, build_x, packs, masks: 35.9 us, and 150
+//  against 138 us on the 1.1 M-node inference batch; the deeper layers' preparation on the second stream under the first
+//  projection GEMM: the step unchanged -- its workgroups crawl beside the persistent GEMM's and that GEMM loses what was gained)
 static int fill_prep(PrepArgs& a, const txe_gat_prepare_desc& d) {
     if (d.n_nodes < 0 || d.Kh < 1 || d.Pd < 0 || !d.X || (d.Pd > 0 && (!d.pos || !d.P)) || !d.W || !d.attn_l || !d.attn_r || !d.Wp || d.H < 1 ||
         d.D < 1 || d.feat_drop_p < 0.f || d.feat_drop_p >= 1.f || (d.feat_drop_p > 0.f && !d.mask))
@@ -492,18 +599,19 @@ static int fill_prep(PrepArgs& a, const txe_gat_prepare_desc& d) {
     a.F = d.H * d.D; a.Fe = a.F + 2 * d.H; a.Fp = round_up(a.Fe, 128);
     auto blocks = [&](long long n, int cap) { const long long b = (n + T - 1) / T; return (int)(b < cap ? b : cap); };
     const long long nx = (long long)d.n_nodes * (a.Kp - (d.h ? 0 : d.Kh));
-    a.nb_x = nx > 0 ? blocks((long long)d.n_nodes * 64, 2048) : 0;
+    a.seed = d.seed; a.thr16 = (unsigned)(d.feat_drop_p * 65536.0f + 0.5f); a.mask = d.mask;
+    a.x_dropped = (d.x_dropped && d.feat_drop_p > 0.f && a.thr16 != 0u) ? 1 : 0;
+    a.x_mask = (a.x_dropped && d.h != nullptr && nx > 0) ? 1 : 0;     // build_x hashes every word of its rows anyway: it writes the mask
+    a.drop_scale = 1.f / (1.f - d.feat_drop_p);
+    a.nb_x = nx > 0 ? build_x_blocks(T, d.n_nodes, d.Kh, d.Pd, a.Kp, d.h != nullptr, a.x_dropped != 0, 2048) : 0;
     a.n_words = (d.feat_drop_p > 0.f) ? (long long)d.n_nodes * ((a.Kt + 31) / 32) : 0;
-    a.nb_m = blocks(a.n_words, 1024);
-    a.nb_w = blocks((long long)a.Fp * 64, 512);
+    a.nb_m = a.x_mask ? 0 : blocks(a.n_words, 1024);
+    a.nb_w = blocks(((long long)a.Fp * a.Kp / 4 + PREP_U - 1) / PREP_U, 512);
     a.fold_bx = (a.Kt + 63) / 64;
     a.nb_f = a.fold_bx * 2 * d.H;
     a.h = d.h; a.ld_h = d.ld_h; a.pos = d.pos; a.P = d.P; a.n_rows = d.n_nodes; a.Kh = d.Kh; a.Pd = d.Pd; a.X = d.X;
     a.W = d.W; a.attn_l = d.attn_l; a.attn_r = d.attn_r; a.H = d.H; a.D = d.D; a.Wp = d.Wp;
     a.pk_rows = a.F; a.pk_ext = a.Fe; a.pk_prows = a.Fp; a.pk_cols = a.Kt; a.pk_pcols = a.Kp;
-    a.seed = d.seed; a.thr16 = (unsigned)(d.feat_drop_p * 65536.0f + 0.5f); a.mask = d.mask;
-    a.x_dropped = (d.x_dropped && d.feat_drop_p > 0.f && a.thr16 != 0u) ? 1 : 0;
-    a.drop_scale = 1.f / (1.f - d.feat_drop_p);
     return TXE_OK;
 }
 }  // namespace txe
@@ -541,17 +649,18 @@ int txe_gcn_layer_prepare(const float* h, long long ld_h, int n_nodes, int Kh, c
     a.Kt = Kh + Pd; a.Kp = round_up(a.Kt, 32);
     auto blocks = [&](long long n, int cap) { const long long b = (n + T - 1) / T; return (int)(b < cap ? b : cap); };
     const long long nx = (long long)n_nodes * (a.Kp - (h ? 0 : Kh));
-    a.nb_x = nx > 0 ? blocks((long long)n_nodes * 64, 2048) : 0;
+    a.seed = seed; a.thr16 = (unsigned)(drop_p * 65536.0f + 0.5f); a.mask = mask;
+    a.x_dropped = (x_dropped && drop_p > 0.f && a.thr16 != 0u) ? 1 : 0;      // (as txe_gat_prepare_desc.x_dropped)
+    a.x_mask = (a.x_dropped && h != nullptr && nx > 0) ? 1 : 0;
+    a.drop_scale = 1.f / (1.f - drop_p);
+    a.nb_x = nx > 0 ? build_x_blocks(T, n_nodes, Kh, Pd, a.Kp, h != nullptr, a.x_dropped != 0, 2048) : 0;
     a.n_words = (drop_p > 0.f) ? (long long)n_nodes * ((a.Kt + 31) / 32) : 0;
-    a.nb_m = blocks(a.n_words, 1024);
+    a.nb_m = a.x_mask ? 0 : blocks(a.n_words, 1024);
     a.pk_rows = a.Kt; a.pk_ext = a.Kt; a.pk_prows = round_up(a.Kp, 128); a.pk_cols = Fo; a.pk_pcols = round_up(Fo, 32);
-    a.nb_w = blocks((long long)a.pk_prows * 64, 512);
+    a.nb_w = blocks(((long long)a.pk_prows * a.pk_pcols / 4 + PREP_U - 1) / PREP_U, 512);
     a.nb_f = 0; a.fold_bx = 1;
     a.h = h; a.ld_h = ld_h; a.pos = pos; a.P = P; a.n_rows = n_nodes; a.Kh = Kh; a.Pd = Pd; a.X = X;
     a.W = W; a.Wp = Wp;
-    a.seed = seed; a.thr16 = (unsigned)(drop_p * 65536.0f + 0.5f); a.mask = mask;
-    a.x_dropped = (x_dropped && drop_p > 0.f && a.thr16 != 0u) ? 1 : 0;      // (as txe_gat_prepare_desc.x_dropped)
-    a.drop_scale = 1.f / (1.f - drop_p);
     hipLaunchKernelGGL(gat_prepare_kernel, dim3(a.nb_x + a.nb_m + a.nb_w), dim3(T), 0, (hipStream_t)stream, a);
     TXE_CHECK_LAUNCH();
     return TXE_OK;

@@ -33,13 +33,28 @@ def keep_mask(seed, shape, p):
 
 def keep_mask_bits(seed, n_rows, n_cols, p):
     """The feature-dropout keep mask of txe_dropout_mask (csrc/txe_common.h drop_mask_word) as a 0/1 float32
-    [n_rows, n_cols] array: bit (4j+c) of mask word w = (16-bit chunk c of mix64(seed + (8w+j) * W)) >= round(p*65536)."""
+    [n_rows, n_cols] array.  Bit b of mask word w is [u(w, b) >= round(p*65536)] for a 16-bit uniform u(w, b) whose bit j is bit b of
+    the plane word R(w, j) = 32-bit half (j & 1) of mix64(seed + (8w + (j >> 1)) * W); evaluated plane-wise from the threshold's
+    lowest set bit upwards: ge = ge & R_j where the threshold has a 1, ge | R_j where it has a 0."""
     wpr = (n_cols + 31) // 32
     n_words = n_rows * wpr
-    thr = np.uint64(int(np.float32(p) * np.float32(65536.0) + np.float32(0.5)))
-    with np.errstate(over="ignore"):
-        idx = (np.arange(n_words, dtype=np.uint64)[:, None] * np.uint64(8) + np.arange(8, dtype=np.uint64)[None, :])
-        h = _mix64((np.uint64(seed) + idx * np.uint64(0xD1342543DE82EF95)) & _M)      # [n_words, 8]
-    chunks = np.stack([(h >> np.uint64(16 * c)) & np.uint64(0xFFFF) for c in range(4)], axis=-1)   # [n_words, 8, 4]
-    bits = (chunks >= thr).reshape(n_rows, wpr * 32)                                 # bit index 4j+c
+    thr = int(np.float32(p) * np.float32(65536.0) + np.float32(0.5))
+    if thr == 0:
+        ge = np.full(n_words, 0xFFFFFFFF, dtype=np.uint64)
+    elif thr > 0xFFFF:
+        ge = np.zeros(n_words, dtype=np.uint64)
+    else:
+        j0 = (thr & -thr).bit_length() - 1
+        ge = np.full(n_words, 0xFFFFFFFF, dtype=np.uint64)
+        w = np.arange(n_words, dtype=np.uint64)
+        with np.errstate(over="ignore"):
+            for k in range(j0 >> 1, 8):
+                h = _mix64((np.uint64(seed) + (w * np.uint64(8) + np.uint64(k)) * np.uint64(0xD1342543DE82EF95)) & _M)
+                for half in range(2):
+                    j = 2 * k + half
+                    if j < j0:
+                        continue
+                    r = (h >> np.uint64(32 * half)) & np.uint64(0xFFFFFFFF)
+                    ge = (ge & r) if (thr >> j) & 1 else (ge | r)
+    bits = ((ge[:, None] >> np.arange(32, dtype=np.uint64)[None, :]) & np.uint64(1)).reshape(n_rows, wpr * 32)
     return bits[:, :n_cols].astype(np.float32)

@@ -88,6 +88,9 @@ int txe_gat_dense_bwd(const float* X, int n_nodes, int Kh, int Pd, const int* po
                       const float* attn_l, const float* attn_r, int H, int D, float feat_drop_p, const unsigned* mask, const float* d_Y,
                       int need_dh, int act_on, float act_slope, float* d_X, float* dW, float* d_attn_l, float* d_attn_r, float* dP,
                       int x_dropped, int phases, void* ws, size_t ws_bytes, void* stream);
+/* phases: 7 = all of it; 1 | 2 | 4 = the d_X product | the weight-gradient product (split-K partial slices) | the reductions that
+ * finish dW, d_attn, dP -- 1 and 2 are independent (a second stream may run the d_X product BESIDE the weight gradient), 4 needs both.
+ * | 16 on EVERY call of such a pass: the weight gradient then leaves the concurrent product its share of the workgroup slots. */
 int txe_zero_cols(float* x, long long ld, int n_rows, int c0, int c1, void* stream);
 
 /* Eval-mode first GATLayer of a batch whose node features are rows of a feature table (test_fast.py:149-179 / infer.py:82-95

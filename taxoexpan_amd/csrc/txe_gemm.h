@@ -1161,8 +1161,11 @@ static inline int gemm_launch_layout(const VMat& A, const VMat& B, const Epi& E_
 
 // number of split-K slices for a product with `tiles` output tiles and reduction length K: fill whole rounds of
 // 2 workgroups per CU, keep >= 8 k-tiles per slice.
-static inline int choose_splits(int M, int N, int K) {
-    const int slots = 2 * device_cu_count();
+// reserve: workgroup slots to leave to a product that runs BESIDE this one on the second stream (the first layer's skinny d_X under
+// its weight gradient): a split count that fills all 512 slots makes that product trickle through what is left and end last.
+static inline int choose_splits(int M, int N, int K, int reserve = 0) {
+    const int all_slots = 2 * device_cu_count();
+    const int slots = (reserve > 0 && reserve < all_slots / 2) ? all_slots - reserve : all_slots;
     const int max_by_k = (K + 255) / 256 > 0 ? (K + 255) / 256 : 1;
     const int nkt = (K + GEMM_BK - 1) / GEMM_BK;
     int best = 1;

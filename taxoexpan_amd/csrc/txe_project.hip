@@ -744,12 +744,23 @@ int txe_gat_dense_bwd(const float* X, int n_nodes, int Kh, int Pd, const int* po
     Epi E = epi_plain(p.part, Kp, Kp);
     E.split_stride = (long long)Fp * Kp;
     E.alg_flops = 2.0 * Fe * (double)Kt * n_nodes;
+    // phases & 16: the caller runs the d_X product (phase 1) on another stream BESIDE this one.  The weight gradient then leaves it
+    // its share of the workgroup slots (by padded flops): with all 512 taken (6 slices x 80 tiles = 480 workgroups that each run for
+    // the whole product) the skinny product crawls through the 32 left and ends 20 us after it -- 5 slices: both end together,
+    // step -13 us.  Every call of one backward pass must carry the same flag (the reduction reads `splits` partial slices).
+    int splits = p.splits;
+    if ((phases & 16) && Kt - c0 > 0 && n_nodes > 0) {
+        const double w_dx = (double)round_up(Kt - c0, 64), w_dw = (double)Kp;
+        const int reserve = (int)(2.0 * device_cu_count() * w_dx / (w_dx + w_dw) + 0.5);
+        const int sp = choose_splits(Fp, Kp, n_nodes, reserve);
+        if (sp < splits) splits = sp;                  // (the workspace holds p.splits slices)
+    }
     if (phases & 2) {
-        rc = gemm_tn(A, B, E, Fp, Kp, n_nodes, p.splits, s);
+        rc = gemm_tn(A, B, E, Fp, Kp, n_nodes, splits, s);
         if (rc) return rc;
     }
     if (!(phases & 4)) return TXE_OK;
-    const int S = n_nodes > 0 ? p.splits : 0;
+    const int S = n_nodes > 0 ? splits : 0;
     // ---- phase A: dP partials (dP[c][j] = sum_{pos[m]==c} d_X[m][Kh+j]) and d_wa = the extension rows of dWp ----
     const int nseg = (Pd > 0 && n_nodes > 0) ? p.seg_blocks : 0;
     TailA ta;

@@ -456,11 +456,12 @@ def _gat_dense_bwd(st, pos, vocab, feat_p, d_Y, need_dh, act_on, act_slope):
         # idle -- it runs on the second stream under the weight-gradient GEMM instead of in front of it
         main, side = torch.cuda.current_stream(), _side_stream(st.X.device)
         side.wait_stream(main)
+        beside = 0 if _NO_BALANCED_SPLITS else 16       # (16: the weight gradient leaves the skinny product its share of the slots)
         with torch.cuda.stream(side):
-            run(1)
-        run(2)
+            run(beside | 1)
+        run(beside | 2)
         main.wait_stream(side)
-        run(4)
+        run(beside | 4)
     return d_X, dW, dal, dar, dP
 
 
@@ -473,6 +474,7 @@ _NO_TABLE_SWEEP = os.environ.get("TXE_NO_TABLE_SWEEP", "0") == "1"      # A/B sw
 _NO_X_DROPPED = os.environ.get("TXE_NO_X_DROPPED", "0") == "1"        # A/B switch: the first layer's GEMM loaders apply the keep mask
 _NO_MULTI_PREPARE = os.environ.get("TXE_NO_MULTI_PREPARE", "0") == "1"   # A/B switch: one preparation launch per layer
 _NO_SIDE_STREAM = os.environ.get("TXE_NO_SIDE_STREAM", "0") == "1"      # A/B switch: everything on the caller's stream
+_NO_BALANCED_SPLITS = os.environ.get("TXE_NO_BALANCED_SPLITS", "0") == "1"   # A/B switch: the first layer's dW takes every slot
 # The matcher's query projection V (bilinear_query_prefetch) on the second stream under the encoder's sweeps: started behind the first
 # projection GEMM (TXE_PREFETCH_V=2, the default: step -9 us).  Started at the very beginning (=1) its workgroups take slots before the
 # persistent first-layer projection's, whose late starters then finish late (their tile lists are fixed): -5 us only.  =0: in line.

@@ -186,6 +186,34 @@ def summarize_profile(all_recs, n_edges_by_launch, n_nodes_by_launch=None, workl
     return out
 
 
+def concurrent_pair(all_recs, dom_kernel):
+    """The dominant main-stream GEMM shares the chip with a second-stream GEMM launched right in front of it (the first layer's
+    weight gradient and the skinny d_X product): each one's own duration is stretched by the other, so the pair is
+    priced together -- flops of both over the longer of the two durations.  None if the dominant kernel runs alone."""
+    flops = span = 0.0
+    beside = None
+    n = 0
+    for recs in all_recs:
+        for i, (name, sec, work, kind) in enumerate(recs):
+            if name != dom_kernel or kind != 0 or i == 0:
+                continue
+            j = i - 1                                  # (its fix-up launch may sit in between)
+            while j >= 0 and recs[j][0].endswith(SECOND_STREAM_TAG) and recs[j][3] != 0:
+                j -= 1
+            if j < 0 or not recs[j][0].endswith(SECOND_STREAM_TAG) or recs[j][3] != 0:
+                continue
+            pname, psec, pwork, pkind = recs[j]
+            beside = pname[:-len(SECOND_STREAM_TAG)]
+            flops += work + pwork
+            span += max(sec, psec)
+            n += 1
+    if not n or span <= 0.0:
+        return None
+    ach = flops / span
+    return {"kernel": beside, "stream": "second", "pair_flops_per_launch": flops / n, "pair_us": 1e6 * span / n,
+            "pair_achieved": ach / 1e12, "unit": "TFLOP/s", "pair_frac": ach / PEAK_MFMA_F32}
+
+
 def _oracle_graph(g, pos, n_g):
     """the first n_g egonets of a batch as the oracle's COO dict"""
     n_nodes = int(np.sum(g.batch_num_nodes[:n_g]))
@@ -599,7 +627,7 @@ def main():
             "roofline": {"bound": dom["bound"], "achieved": dom["achieved"], "peak": dom["peak"], "unit": dom["unit"],
                          "frac": dom["frac"], "traffic": dom["traffic"], "traffic_source": dom["traffic_source"],
                          "kernel": dom["kernel"], "avg_us": dom["avg_us"], "flops": "algorithmic (unpadded operands)",
-                         "stream": dom["stream"],
+                         "stream": dom["stream"], "beside": concurrent_pair(recs, dom["kernel"]) if dom["bound"] == "mfma" else None,
                          "launches_per_4_steps": dom["launches"], "work_per_launch": dom["work_per_launch"],
                          "dominant_hbm_kernel": ({k: hbm[0][k] for k in ("kernel", "achieved", "peak", "unit", "frac", "avg_us", "traffic")}
                                                  if hbm else None)},

@@ -302,6 +302,11 @@ int txe_profile_count(void);
 int txe_profile_get(int i, char* name_buf, int buf_len, float* ms, double* work, int* kind);
 int txe_profile_stream(int i, void** stream);   /* the hipStream_t record i was launched on */
 
+/* Order two streams of the SAME device: work submitted to `then` after this call starts only when everything submitted to `first`
+ * before it has completed (an event without the system-scope fence: no L2 write-back / invalidate in front of `first`'s next kernel).
+ * The host-side mirror uses it for every second-stream overlap (taxoexpan_amd/ops.py _order). */
+int txe_stream_order(void* first, void* then);
+
 /* model/loss.py:52-57 info_nce_loss = F.cross_entropy(output [B][C], target [B], reduction="sum") on the [queries][1 + negatives]
  * regrouping of trainer.py:52-56, together with its gradient:  loss[0] = sum_b (logsumexp(x_b) - x_b[target_b]),
  * d_x[b][c] = softmax(x_b)[c] - [c == target_b].  target NULL = all zeros (what trainer.py:53 passes). */

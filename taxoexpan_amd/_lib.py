@@ -87,6 +87,7 @@ SIGNATURES = {
     "txe_profile_count": (I, []),
     "txe_profile_get": (I, [I, P, I, P, P, P]),
     "txe_profile_stream": (I, [I, P]),
+    "txe_stream_order": (I, [P, P]),
 }
 
 class GatPrepareDesc(C.Structure):

@@ -455,12 +455,12 @@ def _gat_dense_bwd(st, pos, vocab, feat_p, d_Y, need_dh, act_on, act_slope):
         # first layer (only the position columns of d_X are needed): that skinny, latency-bound product leaves most of the matrix pipe
         # idle -- it runs on the second stream under the weight-gradient GEMM instead of in front of it
         main, side = torch.cuda.current_stream(), _side_stream(st.X.device)
-        side.wait_stream(main)
+        _order(main, side)
         beside = 0 if _NO_BALANCED_SPLITS else 16       # (16: the weight gradient leaves the skinny product its share of the slots)
         with torch.cuda.stream(side):
             run(beside | 1)
         run(beside | 2)
-        main.wait_stream(side)
+        _order(side, main)
         run(beside | 4)
     return d_X, dW, dal, dar, dP
 
@@ -474,12 +474,22 @@ _NO_TABLE_SWEEP = os.environ.get("TXE_NO_TABLE_SWEEP", "0") == "1"      # A/B sw
 _NO_X_DROPPED = os.environ.get("TXE_NO_X_DROPPED", "0") == "1"        # A/B switch: the first layer's GEMM loaders apply the keep mask
 _NO_MULTI_PREPARE = os.environ.get("TXE_NO_MULTI_PREPARE", "0") == "1"   # A/B switch: one preparation launch per layer
 _NO_SIDE_STREAM = os.environ.get("TXE_NO_SIDE_STREAM", "0") == "1"      # A/B switch: everything on the caller's stream
+_TORCH_EVENTS = os.environ.get("TXE_TORCH_EVENTS", "0") == "1"          # A/B switch: cross-stream ordering through torch's events
 _NO_BALANCED_SPLITS = os.environ.get("TXE_NO_BALANCED_SPLITS", "0") == "1"   # A/B switch: the first layer's dW takes every slot
 # The matcher's query projection V (bilinear_query_prefetch) on the second stream under the encoder's sweeps: started behind the first
 # projection GEMM (TXE_PREFETCH_V=2, the default: step -9 us).  Started at the very beginning (=1) its workgroups take slots before the
 # persistent first-layer projection's, whose late starters then finish late (their tile lists are fixed): -5 us only.  =0: in line.
 _PREFETCH_V = os.environ.get("TXE_PREFETCH_V", "2") in ("1", "2")
 _PREFETCH_V_LATE = os.environ.get("TXE_PREFETCH_V", "2") == "2"
+def _order(first, then):
+    """work submitted to stream `then` from now on starts after everything already submitted to `first` (txe_stream_order: an event
+    without the system-scope fence; TXE_TORCH_EVENTS=1 is the A/B switch back to torch's wait_stream)"""
+    if _TORCH_EVENTS:
+        then.wait_stream(first)
+    else:
+        call("txe_stream_order", first.cuda_stream, then.cuda_stream)
+
+
 _side_streams = {}
 
 
@@ -526,12 +536,12 @@ def _gat_collapse_bwd_fused(csr, st, sp, pos, rpos, pw, vocab, feat_p, attn_p, a
         # the folded layer's weight-gradient GEMM (MFMA-bound, needs only d_hg and Z) runs on a second stream under the HBM-bound
         # sweeps: complementary resources, and nothing downstream waits for it before the final reduction
         main, side = torch.cuda.current_stream(), _side_stream(st.X.device)
-        side.wait_stream(main)
+        _order(main, side)
         with torch.cuda.stream(side):
             run(2)
         run(1)
         run(4)
-        main.wait_stream(side)
+        _order(side, main)
         run(8)
     return d_Yp, dW, dal, dar, dP, d_pw
 
@@ -1016,7 +1026,7 @@ def bilinear_query_prefetch(e2, W):
             return
         tok["launched"] = True
         if on_side:
-            side.wait_stream(torch.cuda.current_stream(e2.device))
+            _order(torch.cuda.current_stream(e2.device), side)
         with torch.cuda.device(e2.device), torch.cuda.stream(side if on_side else torch.cuda.current_stream(e2.device)):
             call("txe_bilinear_query_project", ptr(e2c), ld2, G, l, r, ptr(Wf), ptr(V), _lib.stream_ptr())
         tok["stream"] = side if on_side else None
@@ -1062,7 +1072,7 @@ class BilinearPairFunction(torch.autograd.Function):
                     U = pre["V"]
                     pre["launch"](on_side=False)                 # (nobody started it: in line, on this stream)
                     if pre["stream"] is not None:
-                        torch.cuda.current_stream().wait_stream(pre["stream"])
+                        _order(pre["stream"], torch.cuda.current_stream())
                     call("txe_bilinear_query_dot", ptr(e1), ld1, ptr(U), G, l, int(apply_exp), ptr(s), _lib.stream_ptr())
                 else:
                     U = _empty((max(G, 1), l), e1)          # V = e2 W^T

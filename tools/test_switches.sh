@@ -6,4 +6,5 @@ for sw in TXE_NO_BALANCED_SPLITS TXE_NO_PERSIST_GEMM TXE_NO_PERSIST_SLICES TXE_N
           TXE_NO_TABLE_SWEEP TXE_NO_MULTI_PREPARE TXE_NO_FUSED_LOGITS TXE_NO_FOLD TXE_NO_DEDUP; do
   echo -n "$sw=1: "; env $sw=1 python -m pytest tests -m gpu -q -p no:cacheprovider 2>&1 | grep -E "passed|failed|error" | tail -1
 done
+echo -n "TXE_TORCH_EVENTS=1: "; TXE_TORCH_EVENTS=1 python -m pytest tests -m gpu -q -p no:cacheprovider 2>&1 | grep -E "passed|failed|error" | tail -1
 for v in 0 1; do echo -n "TXE_PREFETCH_V=$v: "; TXE_PREFETCH_V=$v python -m pytest tests -m gpu -q -p no:cacheprovider 2>&1 | grep -E "passed|failed|error" | tail -1; done

@@ -44,6 +44,16 @@ PEAK_MFMA_F32 = 157.3e12      # MI355X_MICROARCH.md: fp32 MFMA = fp32 vector pea
 PEAK_HBM = 8.0e12             # spec; ~6.3e12 achievable
 
 
+def hbm_copy_ceiling(device, mb=1024):
+    """bytes/s (read + written) of a plain device copy of a buffer four times the Infinity Cache: what this box's HBM gives a streaming
+    kernel with a 1:1 read/write mix -- the practical ceiling beside the 8 TB/s spec the HBM-bound kernels are priced against"""
+    n = mb * 1024 * 1024 // 4
+    x = torch.empty(n, dtype=torch.float32, device=device).normal_()
+    y = torch.empty_like(x)
+    t = median_time(lambda: y.copy_(x), reps=5, inner=10, warm=2)
+    return 2.0 * 4.0 * n / t
+
+
 def median_time(fn, reps=5, inner=1, warm=1):
     """median wall time of `inner` calls of fn over `reps` repetitions (device synchronised around each repetition)"""
     for _ in range(warm):
@@ -615,6 +625,9 @@ def main():
         # the dominant kernel of the critical path: second-stream launches are listed in roofline_all with their (stretched) durations
         dom = next((r for r in roof_all if r["stream"] == "main"), roof_all[0])
         hbm = [r for r in roof_all if r["bound"] == "hbm"]
+        copy_bw = hbm_copy_ceiling(device)
+        for r in hbm:                                # (beside the fraction of the 8 TB/s spec)
+            r["frac_of_copy_ceiling"] = r["achieved"] * 1e9 / copy_bw
         line = {
             "metric": "egonet_edges_per_sec_%s_fwd_bwd" % args.workload, "value": edges / elapsed, "unit": "egonet-edges/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
@@ -629,8 +642,9 @@ def main():
                          "kernel": dom["kernel"], "avg_us": dom["avg_us"], "flops": "algorithmic (unpadded operands)",
                          "stream": dom["stream"], "beside": concurrent_pair(recs, dom["kernel"]) if dom["bound"] == "mfma" else None,
                          "launches_per_4_steps": dom["launches"], "work_per_launch": dom["work_per_launch"],
-                         "dominant_hbm_kernel": ({k: hbm[0][k] for k in ("kernel", "achieved", "peak", "unit", "frac", "avg_us", "traffic")}
-                                                 if hbm else None)},
+                         "dominant_hbm_kernel": ({k: hbm[0][k] for k in ("kernel", "achieved", "peak", "unit", "frac", "frac_of_copy_ceiling",
+                                                                          "avg_us", "traffic")} if hbm else None),
+                         "hbm_copy_ceiling": {"value": copy_bw / 1e9, "unit": "GB/s", "what": "1 GiB device copy on this box, bytes read + written"}},
             "roofline_all": roof_all,
             "cpu_baseline": cpu,
             "extra": extra,

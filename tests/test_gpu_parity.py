@@ -141,48 +141,65 @@ def test_ab_switch_routes_give_the_same_training_step(switch, monkeypatch):
         np.testing.assert_allclose(outs[1][2][k], outs[0][2][k], rtol=1e-4, atol=1e-6, err_msg=k)
 
 
-def test_prepare_entries_agree_and_stored_dropped_input_matches_its_mask():
+@pytest.mark.parametrize("N,Kh,ld_h,Pd,p,from_h", [(517, 250, 250, 50, 0.3, True), (517, 250, 250, 50, 0.5, True), (301, 251, 253, 50, 0.1, True),
+                                                     (64, 96, 96, 0, 0.5, True), (33, 7, 8, 3, 0.25, True), (129, 2000, 0, 50, 0.5, False),
+                                                     (77, 250, 0, 50, 0.1, False), (5, 16500, 16500, 50, 0.5, True), (1, 250, 250, 50, 0.5, True)])
+def test_prepare_entries_agree_and_stored_dropped_input_matches_its_mask(N, Kh, ld_h, Pd, p, from_h):
     """txe_gat_layer_prepare (one layer) == txe_gat_layers_prepare (the stack's one launch) on X / Wp / mask; with x_dropped the stored
-    input is the plain one times keep(mask) / (1 - p), from the very bits written into the mask (rng.keep_mask_bits restates them)"""
+    input is the plain one times keep(mask) / (1 - p), from the very bits written into the mask (rng.keep_mask_bits restates them).
+    Geometries: 8-byte and 4-byte feature rows, no position columns, rows narrower than a quad, feature columns written by a producer
+    (h == NULL: only the position / padding columns are touched, the quad straddling Kh keeps its feature part), rows wider than one
+    pass of a workgroup, a single row; p = 0.5 (one bit plane) and thresholds with many planes"""
     import ctypes
     from taxoexpan_amd import _lib, rng
     dev = _dev()
-    rs = np.random.RandomState(3)
-    N, Kh, Pd, H, D, p, seed = 517, 250, 50, 4, 24, 0.3, 9876543210
+    rs = np.random.RandomState(3 + Kh)
+    H, D, seed = 2, 12, 9876543210
     Kt = Kh + Pd
     Kp, Fp = _lib.call("txe_gat_padded_k", Kh, Pd), _lib.call("txe_gat_padded_f", H, D)
-    h = torch.from_numpy(rs.standard_normal((N, Kh)).astype(np.float32)).to(dev)
-    pos = torch.from_numpy(rs.randint(0, 3, N).astype(np.int32)).to(dev)
-    P = torch.from_numpy(rs.standard_normal((3, Pd)).astype(np.float32)).to(dev)
+    hfull = torch.from_numpy(rs.standard_normal((max(N, 1), max(ld_h, Kh))).astype(np.float32)).to(dev)
+    h = hfull[:N, :Kh]
+    pos_full = torch.from_numpy(rs.randint(0, 3, max(N, 1)).astype(np.int32)).to(dev)
+    pos = pos_full[:N]
+    P = torch.from_numpy(rs.standard_normal((3, max(Pd, 1))).astype(np.float32)).to(dev)[:, :Pd].contiguous() if Pd else None
     W = torch.from_numpy(rs.standard_normal((H * D, Kt)).astype(np.float32)).to(dev)
     al, ar = (torch.from_numpy(rs.standard_normal((1, H, D)).astype(np.float32)).to(dev) for _ in range(2))
     wpr = (Kt + 31) // 32
+    pre = torch.from_numpy(rs.standard_normal((max(N, 1), Kp)).astype(np.float32)).to(dev)[:N]     # what a producer left in X (h == NULL)
+    ptr = lambda t: t.data_ptr() if t is not None else None
 
     def bufs():
-        return (torch.full((N, Kp), 7.0, device=dev), torch.full((Fp, Kp), 7.0, device=dev), torch.zeros((N, wpr), dtype=torch.int32, device=dev))
+        X = torch.full((max(N, 1), Kp), 7.0, device=dev)[:N] if from_h else pre.clone()
+        return X, torch.full((Fp, Kp), 7.0, device=dev), torch.zeros((max(N, 1), wpr), dtype=torch.int32, device=dev)[:N]
 
     def multi(x_dropped):
         X, Wp, mask = bufs()
         d = (_lib.GatPrepareDesc * 1)()
-        d[0].h, d[0].ld_h, d[0].n_nodes, d[0].Kh, d[0].pos, d[0].P, d[0].Pd, d[0].X = h.data_ptr(), Kh, N, Kh, pos.data_ptr(), P.data_ptr(), Pd, X.data_ptr()
-        d[0].W, d[0].attn_l, d[0].attn_r, d[0].H, d[0].D, d[0].Wp = W.data_ptr(), al.data_ptr(), ar.data_ptr(), H, D, Wp.data_ptr()
+        d[0].h, d[0].ld_h, d[0].n_nodes, d[0].Kh, d[0].pos, d[0].P, d[0].Pd = (hfull.data_ptr() if from_h else None), ld_h, N, Kh, ptr(pos_full), ptr(P), Pd
+        d[0].X, d[0].W, d[0].attn_l, d[0].attn_r, d[0].H, d[0].D, d[0].Wp = X.data_ptr(), W.data_ptr(), al.data_ptr(), ar.data_ptr(), H, D, Wp.data_ptr()
         d[0].feat_drop_p, d[0].seed, d[0].mask, d[0].x_dropped = p, seed, mask.data_ptr(), x_dropped
         _lib.call("txe_gat_layers_prepare", ctypes.cast(d, ctypes.c_void_p), 1, _lib.stream_ptr())
         torch.cuda.synchronize()
         return X, Wp, mask
     X1, Wp1, m1 = bufs()
-    _lib.call("txe_gat_layer_prepare", h.data_ptr(), Kh, N, Kh, pos.data_ptr(), P.data_ptr(), Pd, X1.data_ptr(), W.data_ptr(), al.data_ptr(),
-              ar.data_ptr(), H, D, Wp1.data_ptr(), p, seed, m1.data_ptr(), _lib.stream_ptr())
+    _lib.call("txe_gat_layer_prepare", hfull.data_ptr() if from_h else None, ld_h, N, Kh, ptr(pos_full), ptr(P), Pd, X1.data_ptr(), W.data_ptr(),
+              al.data_ptr(), ar.data_ptr(), H, D, Wp1.data_ptr(), p, seed, m1.data_ptr(), _lib.stream_ptr())
     torch.cuda.synchronize()
     X2, Wp2, m2 = multi(0)
     assert torch.equal(X1, X2) and torch.equal(Wp1, Wp2) and torch.equal(m1, m2)
-    want = torch.cat([h, P[pos.long()], torch.zeros(N, Kp - Kt, device=dev)], dim=1)
+    feat = h if from_h else pre[:, :Kh]
+    cols = [feat] + ([P[pos.long()]] if Pd else []) + [torch.zeros(N, Kp - Kt, device=dev)]
+    want = torch.cat(cols, dim=1)
     assert torch.equal(X2, want)
-    X3, Wp3, m3 = multi(1)
-    assert torch.equal(Wp3, Wp2) and torch.equal(m3, m2)
+    assert torch.equal(Wp2[:H * D, :Kt], W) and float(Wp2[:H * D, Kt:].abs().max() if Kp > Kt else 0.0) == 0.0
     keep = torch.from_numpy(rng.keep_mask_bits(seed, N, Kt, p)).to(dev)
+    bits = ((m2.long().unsqueeze(-1) >> torch.arange(32, device=dev)) & 1).reshape(N, wpr * 32)[:, :Kt].float()
+    assert torch.equal(bits, keep)                                   # the mask job's words
+    X3, Wp3, m3 = multi(1)
+    assert torch.equal(Wp3, Wp2) and torch.equal(m3, m2)             # (with h the words come from the build job itself)
     want3 = want.clone()
-    want3[:, :Kt] = want[:, :Kt] * keep * (1.0 / (1.0 - p))
+    c0 = 0 if from_h else Kh                                         # (h == NULL: the producer's columns are not touched)
+    want3[:, c0:Kt] = want[:, c0:Kt] * keep[:, c0:] * (1.0 / (1.0 - p))
     assert torch.equal(X3, want3)
 
 

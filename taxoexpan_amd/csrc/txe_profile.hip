@@ -106,17 +106,26 @@ int txe_profile_stream(int i, void** stream) {
 // streams of the same device need (host readers synchronise through hipMemcpy / hipStreamSynchronize as before).
 // A ring of events per process; an event is re-recorded only after 64 later orderings, long after its wait was consumed.
 int txe_stream_order(void* first, void* then) {
-    static hipEvent_t ring[64];
-    static bool made[64];
+    constexpr int MAXDEV = 16;
+    static hipEvent_t ring[MAXDEV][64];                 // (events belong to the device that was current when they were created)
+    static bool made[MAXDEV][64];
     static std::atomic<unsigned> next{0};
     if (first == then) return TXE_OK;
+    int cur = 0;
+    hipDevice_t dev = 0;                                // the streams' device (a null stream: the current device's)
+    if (hipGetDevice(&cur) != hipSuccess) return TXE_ERR_LAUNCH;
+    if (hipStreamGetDevice((hipStream_t)(first ? first : then), &dev) != hipSuccess) dev = cur;
+    if (dev < 0 || dev >= MAXDEV) return TXE_ERR_ARG;
     const unsigned i = next.fetch_add(1) & 63u;
-    if (!made[i]) {
-        if (hipEventCreateWithFlags(&ring[i], hipEventDisableTiming | hipEventDisableSystemFence) != hipSuccess) return TXE_ERR_LAUNCH;
-        made[i] = true;
+    if (!made[dev][i]) {
+        if (dev != cur && hipSetDevice(dev) != hipSuccess) return TXE_ERR_LAUNCH;
+        const hipError_t e = hipEventCreateWithFlags(&ring[dev][i], hipEventDisableTiming | hipEventDisableSystemFence);
+        if (dev != cur) (void)hipSetDevice(cur);
+        if (e != hipSuccess) return TXE_ERR_LAUNCH;
+        made[dev][i] = true;
     }
-    if (hipEventRecord(ring[i], (hipStream_t)first) != hipSuccess) return TXE_ERR_LAUNCH;
-    if (hipStreamWaitEvent((hipStream_t)then, ring[i], 0) != hipSuccess) return TXE_ERR_LAUNCH;
+    if (hipEventRecord(ring[dev][i], (hipStream_t)first) != hipSuccess) return TXE_ERR_LAUNCH;
+    if (hipStreamWaitEvent((hipStream_t)then, ring[dev][i], 0) != hipSuccess) return TXE_ERR_LAUNCH;
     return TXE_OK;
 }
 

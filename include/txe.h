@@ -90,8 +90,13 @@ int txe_gat_dense_bwd(const float* X, int n_nodes, int Kh, int Pd, const int* po
                       int x_dropped, int phases, void* ws, size_t ws_bytes, void* stream);
 /* phases: 7 = all of it; 1 | 2 | 4 = the d_X product | the weight-gradient product (split-K partial slices) | the reductions that
  * finish dW, d_attn, dP -- 1 and 2 are independent (a second stream may run the d_X product BESIDE the weight gradient), 4 needs both.
- * | 16 on EVERY call of such a pass: the weight gradient then leaves the concurrent product its share of the workgroup slots. */
+ * | 16 on EVERY call of such a pass: the weight gradient then leaves the concurrent product its share of the workgroup slots.
+ * | 32 on every call of a pass: d_X through the GEMM even where txe_gat_dx_streams() == 1 (A/B switch). */
 int txe_zero_cols(float* x, long long ld, int n_rows, int c0, int c1, void* stream);
+/* 1 when txe_gat_dense_bwd forms d_X with the streaming position-column kernel (a first PGAT layer: need_dh == 0, the columns behind
+ * Kh fit 64 -- model_zoo.py:214-215): phase 1 is then ONE pass over d_Y at HBM speed that also leaves dP's per-class partial sums,
+ * and belongs in line on the caller's stream (phases = 7), not beside the weight-gradient product on a second one. */
+int txe_gat_dx_streams(int Kh, int Pd, int need_dh);
 
 /* Eval-mode first GATLayer of a batch whose node features are rows of a feature table (test_fast.py:149-179 / infer.py:82-95
  * encode every taxonomy node many times): the projected rows ft[u] = T[rid[u]] + T2[pos[u]] (T = table x W^T [n_table][ld_t],

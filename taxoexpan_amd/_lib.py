@@ -23,6 +23,7 @@ SIGNATURES = {
     "txe_gat_dense_fwd": (I, [P, I, I, I, P, I, I, F, P, P, P, SZ, P]),
     "txe_gat_dense_bwd": (I, [P, I, I, I, P, I, P, P, P, P, I, I, F, P, P, I, I, F, P, P, P, P, P, I, I, P, SZ, P]),
     "txe_zero_cols": (I, [P, L, I, I, I, P]),
+    "txe_gat_dx_streams": (I, [I, I, I]),
     "txe_gat_aggregate_fwd": (I, [P, P, I, P, L, P, P, I, I, I, F, F, U64, I, F, P, L, P, P, I, P, F, P, P]),
     "txe_gat_aggregate_table_supported": (I, [I, I, L, I, I]),
     "txe_gat_aggregate_table_fwd": (I, [P, P, I, P, L, P, P, P, I, I, I, F, I, F, P, L, P, I, P, P]),

@@ -6,6 +6,7 @@
 #include <string.h>
 
 #include <atomic>
+#include <mutex>
 #include <vector>
 
 #include "txe_common.h"
@@ -108,7 +109,8 @@ int txe_profile_stream(int i, void** stream) {
 int txe_stream_order(void* first, void* then) {
     constexpr int MAXDEV = 16;
     static hipEvent_t ring[MAXDEV][64];                 // (events belong to the device that was current when they were created)
-    static bool made[MAXDEV][64];
+    static bool made[MAXDEV];                           // a device's 64 events are created together, once, under its lock
+    static std::mutex make_lock[MAXDEV];
     static std::atomic<unsigned> next{0};
     if (first == then) return TXE_OK;
     int cur = 0;
@@ -117,12 +119,17 @@ int txe_stream_order(void* first, void* then) {
     if (hipStreamGetDevice((hipStream_t)(first ? first : then), &dev) != hipSuccess) dev = cur;
     if (dev < 0 || dev >= MAXDEV) return TXE_ERR_ARG;
     const unsigned i = next.fetch_add(1) & 63u;
-    if (!made[dev][i]) {
-        if (dev != cur && hipSetDevice(dev) != hipSuccess) return TXE_ERR_LAUNCH;
-        const hipError_t e = hipEventCreateWithFlags(&ring[dev][i], hipEventDisableTiming | hipEventDisableSystemFence);
-        if (dev != cur) (void)hipSetDevice(cur);
-        if (e != hipSuccess) return TXE_ERR_LAUNCH;
-        made[dev][i] = true;
+    {
+        std::lock_guard<std::mutex> g(make_lock[dev]);  // (two host threads may arrive here for the same device at once)
+        if (!made[dev]) {
+            if (dev != cur && hipSetDevice(dev) != hipSuccess) return TXE_ERR_LAUNCH;
+            hipError_t e = hipSuccess;
+            for (int k = 0; k < 64 && e == hipSuccess; ++k)
+                e = hipEventCreateWithFlags(&ring[dev][k], hipEventDisableTiming | hipEventDisableSystemFence);
+            if (dev != cur) (void)hipSetDevice(cur);
+            if (e != hipSuccess) return TXE_ERR_LAUNCH;
+            made[dev] = true;
+        }
     }
     if (hipEventRecord(ring[dev][i], (hipStream_t)first) != hipSuccess) return TXE_ERR_LAUNCH;
     if (hipStreamWaitEvent((hipStream_t)then, ring[dev][i], 0) != hipSuccess) return TXE_ERR_LAUNCH;

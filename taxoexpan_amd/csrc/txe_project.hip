@@ -16,6 +16,7 @@
 #include "txe_gemm.h"
 #include "txe_gather.h"
 #include "txe_colsum.h"
+#include "txe_dxpos.h"
 
 namespace txe {
 
@@ -494,7 +495,9 @@ static DenseWs plan_dense_ws(void* ws, int n, int Fp, int H2, int Kp, int Pd, in
     p.seg_rows = 64;
     p.seg_blocks = (n + p.seg_rows - 1) / p.seg_rows;
     if (p.seg_blocks < 1) p.seg_blocks = 1;
-    p.ppart = take((size_t)p.seg_blocks * (vocab > 0 ? vocab : 1) * (Pd > 0 ? Pd : 1) * 4);
+    // (sized for the streaming d_X kernel's 16-row workgroups, which write these partial sums themselves)
+    const int ppart_blocks = dxpos_blocks(n) > p.seg_blocks ? dxpos_blocks(n) : p.seg_blocks;
+    p.ppart = take((size_t)ppart_blocks * (vocab > 0 ? vocab : 1) * (Pd > 0 ? Pd : 1) * 4);
     p.splits = choose_splits(Fp, Kp, n);
     p.part = take((size_t)p.splits * Fp * Kp * 4);
     p.tail_bytes = gemm_tail_ws_bytes();
@@ -683,6 +686,14 @@ int txe_gather_add_rows(const float* T, long long ld_t, const int* row, const fl
     return TXE_OK;
 }
 
+// 1: txe_gat_dense_bwd forms this layer's d_X with the streaming position-column kernel (phase 1 is then an HBM stream that belongs
+// IN LINE on the caller's stream, not beside the weight-gradient product on a second one)
+int txe_gat_dx_streams(int Kh, int Pd, int need_dh) {
+    if (need_dh || Pd < 1 || Kh < 1) return 0;
+    const int c0 = (Kh / 4) * 4;
+    return (Kh + Pd - c0 <= DXPOS_MAXC && Kh - c0 + Pd <= DXPOS_MAXC) ? 1 : 0;
+}
+
 size_t txe_gat_dense_ws_bytes(int n_nodes, int Kh, int Pd, int H, int D, int vocab) {
     return plan_dense_ws(nullptr, n_nodes, round_up(H * D + 2 * H, 128), 2 * H, round_up(Kh + Pd, 32), Pd, vocab).total;
 }
@@ -708,6 +719,7 @@ int txe_gat_dense_fwd(const float* X, int n_nodes, int Kh, int Pd, const float* 
 //                columns < Kh are multiplied by leaky'(X) when act_slope_on (X[:, :Kh] is then the activated output of the
 //                previous layer), all by the dropout factor.
 //   dW [F][Kt], d_attn_l / d_attn_r [F], dP [vocab][Pd].
+// phases: | 32 = never the streaming position-column kernel (A/B switch);
 // phases: 7 = everything; 1 = the d_X GEMM, 2 = the dW GEMM (independent of each other: a caller may put the skinny, latency-bound
 // d_X product on a second stream under the dW product), 4 = the reductions that need both -- separate calls share the workspace.
 int txe_gat_dense_bwd(const float* X, int n_nodes, int Kh, int Pd, const int* pos, int vocab, const float* Wp, const float* W,
@@ -726,7 +738,19 @@ int txe_gat_dense_bwd(const float* X, int n_nodes, int Kh, int Pd, const int* po
     int rc;
     // ---- d_X[:, c0:Kt] = d_Y * Wp[:, c0:Kt] ----
     const int c0 = need_dh ? 0 : (Kh / 4) * 4;      // 16-byte aligned start of the position columns
-    if ((phases & 1) && Kt - c0 > 0 && n_nodes > 0 && (need_dh || Pd > 0)) {
+    // position columns only: one stream over d_Y (txe_dxpos.hip) that also leaves the per-class partial sums of dP
+    const bool stream_dx = !(phases & 32) && txe_gat_dx_streams(Kh, Pd, need_dh) == 1 && n_nodes > 0;
+    if ((phases & 1) && stream_dx) {
+        DxPosArgs da;
+        da.dY = d_Y; da.ld_dy = Fp; da.n_rows = n_nodes; da.K = Fp;
+        da.Wp = Wp; da.ld_w = Kp; da.Kp = Kp; da.c0 = c0; da.NC = Kt - c0;
+        da.mask = mask; da.mask_ld = (Kt + 31) / 32; da.mask_on = (mask && feat_drop_p > 0.f) ? 1 : 0;
+        da.drop_scale = da.mask_on ? 1.f / (1.f - feat_drop_p) : 1.f;
+        da.dX = d_X; da.ld_dx = Kp;
+        da.pos = pos; da.vocab = vocab; da.Pd = Pd; da.pcol0 = Kh - c0; da.ppart = p.ppart;
+        rc = dxpos_launch(da, s);
+        if (rc) return rc;
+    } else if ((phases & 1) && Kt - c0 > 0 && n_nodes > 0 && (need_dh || Pd > 0)) {
         VMat A = vmat_plain(d_Y, Fp, n_nodes, Fp);
         VMat B = vmat_plain(Wp + c0, Kp, Fp, Kp - c0);
         Epi E = epi_plain(d_X + c0, Kp, Kh > c0 ? Kh - c0 : 0);
@@ -749,7 +773,7 @@ int txe_gat_dense_bwd(const float* X, int n_nodes, int Kh, int Pd, const int* po
     // the whole product) the skinny product crawls through the 32 left and ends 20 us after it -- 5 slices: both end together,
     // step -13 us.  Every call of one backward pass must carry the same flag (the reduction reads `splits` partial slices).
     int splits = p.splits;
-    if ((phases & 16) && Kt - c0 > 0 && n_nodes > 0) {
+    if ((phases & 16) && Kt - c0 > 0 && n_nodes > 0 && !stream_dx) {
         const double w_dx = (double)round_up(Kt - c0, 64), w_dw = (double)Kp;
         const int reserve = (int)(2.0 * device_cu_count() * w_dx / (w_dx + w_dw) + 0.5);
         const int sp = choose_splits(Fp, Kp, n_nodes, reserve);
@@ -762,10 +786,10 @@ int txe_gat_dense_bwd(const float* X, int n_nodes, int Kh, int Pd, const int* po
     if (!(phases & 4)) return TXE_OK;
     const int S = n_nodes > 0 ? splits : 0;
     // ---- phase A: dP partials (dP[c][j] = sum_{pos[m]==c} d_X[m][Kh+j]) and d_wa = the extension rows of dWp ----
-    const int nseg = (Pd > 0 && n_nodes > 0) ? p.seg_blocks : 0;
+    const int nseg = (Pd > 0 && n_nodes > 0) ? (stream_dx ? dxpos_blocks(n_nodes) : p.seg_blocks) : 0;
     TailA ta;
     memset(&ta, 0, sizeof(ta));
-    ta.nb_s1a = nseg; ta.s1a = Seg1Args{d_X ? d_X + Kh : nullptr, (long long)Kp, Pd, p.ppart};
+    ta.nb_s1a = stream_dx ? 0 : nseg; ta.s1a = Seg1Args{d_X ? d_X + Kh : nullptr, (long long)Kp, Pd, p.ppart};
     ta.pos = pos; ta.n_rows = n_nodes; ta.vocab = vocab; ta.rows_per_block = p.seg_rows;
     ta.r_kind = 1; ta.nbx = (Kp + 255) / 256; ta.nb_r = ta.nbx * H2;
     ta.rpart = p.part; ta.S = S; ta.split_stride = E.split_stride; ta.F = F; ta.ldp = Kp; ta.dwa = p.dwa;

@@ -449,14 +449,18 @@ def _gat_dense_bwd(st, pos, vocab, feat_p, d_Y, need_dh, act_on, act_slope):
         call("txe_gat_dense_bwd", ptr(st.X), N, st.Kh, st.Pd, ptr(pos), vocab, ptr(st.Wp), ptr(st.W), ptr(st.al), ptr(st.ar), st.H, st.D, feat_p,
              ptr(st.mask), ptr(d_Y), int(need_dh), int(act_on), act_slope if act_slope else 1.0, ptr(d_X), ptr(dW), ptr(dal), ptr(dar),
              ptr(dP), int(getattr(st, "x_dropped", False)), phases, ptr(ws), wsb, _lib.stream_ptr())
+    if not _NO_DXPOS and d_X is not None and call("txe_gat_dx_streams", st.Kh, st.Pd, int(need_dh)) == 1:
+        run(7)          # (a first PGAT layer's d_X is one HBM stream over d_Y -- txe_dxpos.hip -- and runs in line)
+        return d_X, dW, dal, dar, dP
+    no_dx = 32 if _NO_DXPOS else 0
     if _NO_SIDE_STREAM or need_dh or d_X is None or N == 0:
-        run(7)
+        run(7 | no_dx)
     else:
         # first layer (only the position columns of d_X are needed): that skinny, latency-bound product leaves most of the matrix pipe
         # idle -- it runs on the second stream under the weight-gradient GEMM instead of in front of it
         main, side = torch.cuda.current_stream(), _side_stream(st.X.device)
         _order(main, side)
-        beside = 0 if _NO_BALANCED_SPLITS else 16       # (16: the weight gradient leaves the skinny product its share of the slots)
+        beside = no_dx | (0 if _NO_BALANCED_SPLITS else 16)       # (16: the weight gradient leaves the skinny product its share of the slots)
         with torch.cuda.stream(side):
             run(beside | 1)
         run(beside | 2)
@@ -476,6 +480,7 @@ _NO_MULTI_PREPARE = os.environ.get("TXE_NO_MULTI_PREPARE", "0") == "1"   # A/B s
 _NO_SIDE_STREAM = os.environ.get("TXE_NO_SIDE_STREAM", "0") == "1"      # A/B switch: everything on the caller's stream
 _TORCH_EVENTS = os.environ.get("TXE_TORCH_EVENTS", "0") == "1"          # A/B switch: cross-stream ordering through torch's events
 _NO_BALANCED_SPLITS = os.environ.get("TXE_NO_BALANCED_SPLITS", "0") == "1"   # A/B switch: the first layer's dW takes every slot
+_NO_DXPOS = os.environ.get("TXE_NO_DXPOS", "0") == "1"                # A/B switch: the first layer's d_X as a GEMM on the second stream
 # The matcher's query projection V (bilinear_query_prefetch) on the second stream under the encoder's sweeps: started behind the first
 # projection GEMM (TXE_PREFETCH_V=2, the default: step -9 us).  Started at the very beginning (=1) its workgroups take slots before the
 # persistent first-layer projection's, whose late starters then finish late (their tile lists are fixed): -5 us only.  =0: in line.

@@ -115,7 +115,7 @@ def test_training_mode_dropout_matches_oracle(name, drop, monkeypatch):
         np.testing.assert_allclose(p.grad.cpu().numpy(), P[k].grad.numpy(), rtol=2e-3, atol=2e-5, err_msg=k)
 
 
-@pytest.mark.parametrize("switch", ["_NO_MULTI_PREPARE", "_NO_X_DROPPED", "_NO_SIDE_STREAM", "_NO_FUSED_BWD", "_NO_FUSED_LOGITS", "_NO_BALANCED_SPLITS"])
+@pytest.mark.parametrize("switch", ["_NO_MULTI_PREPARE", "_NO_X_DROPPED", "_NO_SIDE_STREAM", "_NO_FUSED_BWD", "_NO_FUSED_LOGITS", "_NO_BALANCED_SPLITS", "_NO_DXPOS"])
 def test_ab_switch_routes_give_the_same_training_step(switch, monkeypatch):
     """every A/B switch of ops.py selects another ROUTE to the same numbers: a training step (dropout on, fixed seed) of the 2-layer
     PGAT case with the switch set against the default -- scores and every gradient (the per-layer preparation entry once left the
@@ -201,6 +201,66 @@ def test_prepare_entries_agree_and_stored_dropped_input_matches_its_mask(N, Kh, 
     c0 = 0 if from_h else Kh                                         # (h == NULL: the producer's columns are not touched)
     want3[:, c0:Kt] = want[:, c0:Kt] * keep[:, c0:] * (1.0 / (1.0 - p))
     assert torch.equal(X3, want3)
+
+
+@pytest.mark.parametrize("N,Kh,Pd,H,D,vocab,p", [(1000, 250, 50, 4, 500, 3, 0.1), (517, 300, 50, 4, 600, 3, 0.5), (33, 250, 50, 1, 126, 3, 0.0),
+                                                  (16, 64, 16, 2, 63, 8, 0.25), (1, 250, 50, 4, 500, 3, 0.1), (4099, 7, 3, 3, 40, 5, 0.3),
+                                                  (200, 250, 62, 2, 64, 2, 0.2)])
+def test_first_layer_position_dx_streaming_kernel(N, Kh, Pd, H, D, vocab, p):
+    """txe_gat_dense_bwd with need_dh = 0 (a first PGAT layer, model_zoo.py:214-215 backward): the streaming position-column kernel
+    (txe_dxpos.hip: d_X[:, c0:Kt] and dP in one pass over d_Y) against the GEMM route (phases | 32) and against float64 --
+    d_X position columns, dW, d_attn, dP.  Shapes: MAG and SemEval dimensions (the SemEval slab runs past the padded row: clamped
+    column vectors), rows that are no multiple of the 16-row workgroups, a single row, 8 position classes, odd widths, no dropout."""
+    from taxoexpan_amd import _lib
+    dev = _dev()
+    assert _lib.call("txe_gat_dx_streams", Kh, Pd, 0) == 1 and _lib.call("txe_gat_dx_streams", Kh, Pd, 1) == 0
+    rs = np.random.RandomState(11 + N)
+    Kt, F = Kh + Pd, H * D
+    Kp, Fp = _lib.call("txe_gat_padded_k", Kh, Pd), _lib.call("txe_gat_padded_f", H, D)
+    f32 = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev)
+    W, al, ar = f32(rs.standard_normal((F, Kt)) * 0.1), f32(rs.standard_normal(F)), f32(rs.standard_normal(F))
+    Wp = torch.zeros((Fp, Kp), device=dev)
+    _lib.call("txe_gat_pack_weights", W.data_ptr(), al.data_ptr(), ar.data_ptr(), H, D, Kt, Wp.data_ptr(), _lib.stream_ptr())
+    X = torch.zeros((N, Kp), device=dev)
+    X[:, :Kt] = f32(rs.standard_normal((N, Kt)))
+    pos = torch.from_numpy(rs.randint(0, vocab, N).astype(np.int32)).to(dev)
+    dY = torch.zeros((N, Fp), device=dev)
+    dY[:, :F + 2 * H] = f32(rs.standard_normal((N, F + 2 * H)))
+    mask = None
+    if p > 0:
+        mask = torch.empty((N, (Kt + 31) // 32), dtype=torch.int32, device=dev)
+        _lib.call("txe_dropout_mask", N, Kt, p, 777, mask.data_ptr(), _lib.stream_ptr())
+    wsb = _lib.call("txe_gat_dense_ws_bytes", N, Kh, Pd, H, D, vocab)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+    outs = []
+    for flag in (0, 32):
+        dX = torch.full((N, Kp), float("nan"), device=dev)
+        dW, dal, dar, dP = torch.empty_like(W), torch.empty_like(al), torch.empty_like(ar), torch.empty((vocab, Pd), device=dev)
+        _lib.call("txe_gat_dense_bwd", X.data_ptr(), N, Kh, Pd, pos.data_ptr(), vocab, Wp.data_ptr(), W.data_ptr(), al.data_ptr(), ar.data_ptr(),
+                  H, D, p, mask.data_ptr() if mask is not None else None, dY.data_ptr(), 0, 0, 1.0, dX.data_ptr(), dW.data_ptr(), dal.data_ptr(),
+                  dar.data_ptr(), dP.data_ptr(), 0, 7 | flag, ws.data_ptr(), wsb, _lib.stream_ptr())
+        torch.cuda.synchronize()
+        outs.append([t.cpu().double().numpy() for t in (dX[:, Kh:Kt], dW, dal, dar, dP)])
+    # float64 restatement
+    keep = np.ones((N, Kt))
+    if mask is not None:
+        bits = ((mask.cpu().numpy().astype(np.int64)[:, :, None] >> np.arange(32)) & 1).reshape(N, -1)[:, :Kt]
+        keep = bits / (1.0 - p)
+    Wd, dYd, Xd = W.cpu().double().numpy(), dY.cpu().double().numpy(), X.cpu().double().numpy()[:, :Kt]
+    ald, ard = al.cpu().double().numpy(), ar.cpu().double().numpy()
+    wa = np.stack([(ald.reshape(H, D)[h][:, None] * Wd[h * D:(h + 1) * D]).sum(0) for h in range(H)] +
+                  [(ard.reshape(H, D)[h][:, None] * Wd[h * D:(h + 1) * D]).sum(0) for h in range(H)])        # folded rows [2H][Kt]
+    Wfull = np.concatenate([Wd, wa], axis=0)                                                                   # [F + 2H][Kt]
+    dX_ref = (dYd[:, :F + 2 * H] @ Wfull) * keep
+    dP_ref = np.stack([dX_ref[pos.cpu().numpy() == c][:, Kh:].sum(0) for c in range(vocab)])
+    scale = np.abs(dX_ref[:, Kh:]).max() + 1e-30
+    for o in outs:
+        assert np.isfinite(o[0]).all()
+        np.testing.assert_allclose(o[0], dX_ref[:, Kh:], rtol=1e-4, atol=1e-5 * scale)
+        np.testing.assert_allclose(o[4], dP_ref, rtol=1e-4, atol=2e-5 * max(np.abs(dP_ref).max(), 1e-30))
+    for a, b in zip(outs[0][1:4], outs[1][1:4]):                      # the weight side does not depend on the route
+        np.testing.assert_array_equal(a, b)
+    np.testing.assert_allclose(outs[0][0], outs[1][0], rtol=1e-4, atol=1e-5 * scale)
 
 
 def _random_graph(n, e, seed, zero_in=True):

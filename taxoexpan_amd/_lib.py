@@ -99,7 +99,7 @@ class GatPrepareDesc(C.Structure):
 
 _ERR = {-1: "TXE_ERR_ARG", -2: "TXE_ERR_LAUNCH", -3: "TXE_ERR_WORKSPACE"}
 VALUE_RETURNING = {"txe_gat_padded_k", "txe_gat_padded_f", "txe_gcn_padded_f", "txe_profile_count", "txe_gat_fused_bwd_supported",
-                   "txe_gat_aggregate_table_supported"}   # int results that are not status codes
+                   "txe_gat_aggregate_table_supported", "txe_gat_dx_streams"}   # int results that are not status codes
 
 _lib = None
 

@@ -182,6 +182,7 @@ __global__ __launch_bounds__(256) void pos_segsum_stage2(const float* __restrict
 //            gradient d_wa (split-K slices of the extension rows, or the per-block partials of the folded output layer);
 //   phase B: dW / d_attn from d_wa (unfold) and the second stage of the position sums.
 struct TailA {
+    int nb_dx; DxPosArgs dx;                    // leading jobs: the streaming d_X kernel's row blocks (dxpos_finish_job)
     int nb_s1a, nb_s1b, nb_r, r_kind;           // r_kind 1: extension rows of the split-K weight gradient, 2: stage 2 over dwa_part
     Seg1Args s1a, s1b;
     const int* pos; int n_rows, vocab, rows_per_block;
@@ -189,6 +190,8 @@ struct TailA {
     Seg2Args r2;
 };
 __device__ __forceinline__ void reduce_a_job(int b, const TailA& a) {
+    if (b < a.nb_dx) { dxpos_finish_job(b, a.dx); return; }
+    b -= a.nb_dx;
     if (b < a.nb_s1a) { segsum1_job(b, a.s1a, a.pos, a.n_rows, a.vocab, a.rows_per_block); return; }
     b -= a.nb_s1a;
     if (b < a.nb_s1b) { segsum1_job(b, a.s1b, a.pos, a.n_rows, a.vocab, a.rows_per_block); return; }
@@ -478,6 +481,7 @@ __global__ __launch_bounds__(256) void gather_add_rows_kernel(const float* __res
 
 struct DenseWs {
     float* dwa;     // [2H][Kp]
+    float* dxpart;  // the streaming d_X kernel's k-slice partial products
     float* ppart;   // [nb][vocab][Pd]
     float* part;    // [S][Fp][Kp]
     void* tail;
@@ -498,6 +502,7 @@ static DenseWs plan_dense_ws(void* ws, int n, int Fp, int H2, int Kp, int Pd, in
     // (sized for the streaming d_X kernel's 16-row workgroups, which write these partial sums themselves)
     const int ppart_blocks = dxpos_blocks(n) > p.seg_blocks ? dxpos_blocks(n) : p.seg_blocks;
     p.ppart = take((size_t)ppart_blocks * (vocab > 0 ? vocab : 1) * (Pd > 0 ? Pd : 1) * 4);
+    p.dxpart = take(Pd > 0 ? dxpos_part_bytes(n, Fp) : 0);
     p.splits = choose_splits(Fp, Kp, n);
     p.part = take((size_t)p.splits * Fp * Kp * 4);
     p.tail_bytes = gemm_tail_ws_bytes();
@@ -740,14 +745,19 @@ int txe_gat_dense_bwd(const float* X, int n_nodes, int Kh, int Pd, const int* po
     const int c0 = need_dh ? 0 : (Kh / 4) * 4;      // 16-byte aligned start of the position columns
     // position columns only: one stream over d_Y (txe_dxpos.hip) that also leaves the per-class partial sums of dP
     const bool stream_dx = !(phases & 32) && txe_gat_dx_streams(Kh, Pd, need_dh) == 1 && n_nodes > 0;
-    if ((phases & 1) && stream_dx) {
-        DxPosArgs da;
+    DxPosArgs da;
+    memset(&da, 0, sizeof(da));
+    if (stream_dx) {
         da.dY = d_Y; da.ld_dy = Fp; da.n_rows = n_nodes; da.K = Fp;
         da.Wp = Wp; da.ld_w = Kp; da.Kp = Kp; da.c0 = c0; da.NC = Kt - c0;
         da.mask = mask; da.mask_ld = (Kt + 31) / 32; da.mask_on = (mask && feat_drop_p > 0.f) ? 1 : 0;
         da.drop_scale = da.mask_on ? 1.f / (1.f - feat_drop_p) : 1.f;
         da.dX = d_X; da.ld_dx = Kp;
-        da.pos = pos; da.vocab = vocab; da.Pd = Pd; da.pcol0 = Kh - c0; da.ppart = p.ppart;
+        da.pos = pos; da.vocab = vocab; da.Pd = Pd; da.pcol0 = Kh - c0; da.ppart = p.ppart; da.part = p.dxpart;
+        rc = dxpos_prepare(da);
+        if (rc) return rc;
+    }
+    if ((phases & 1) && stream_dx) {
         rc = dxpos_launch(da, s);
         if (rc) return rc;
     } else if ((phases & 1) && Kt - c0 > 0 && n_nodes > 0 && (need_dh || Pd > 0)) {
@@ -789,11 +799,12 @@ int txe_gat_dense_bwd(const float* X, int n_nodes, int Kh, int Pd, const int* po
     const int nseg = (Pd > 0 && n_nodes > 0) ? (stream_dx ? dxpos_blocks(n_nodes) : p.seg_blocks) : 0;
     TailA ta;
     memset(&ta, 0, sizeof(ta));
+    ta.nb_dx = stream_dx ? nseg : 0; ta.dx = da;
     ta.nb_s1a = stream_dx ? 0 : nseg; ta.s1a = Seg1Args{d_X ? d_X + Kh : nullptr, (long long)Kp, Pd, p.ppart};
     ta.pos = pos; ta.n_rows = n_nodes; ta.vocab = vocab; ta.rows_per_block = p.seg_rows;
     ta.r_kind = 1; ta.nbx = (Kp + 255) / 256; ta.nb_r = ta.nbx * H2;
     ta.rpart = p.part; ta.S = S; ta.split_stride = E.split_stride; ta.F = F; ta.ldp = Kp; ta.dwa = p.dwa;
-    hipLaunchKernelGGL(gat_bwd_reduce_a_kernel, dim3(ta.nb_s1a + ta.nb_r), dim3(256), 0, s, ta);
+    hipLaunchKernelGGL(gat_bwd_reduce_a_kernel, dim3(ta.nb_dx + ta.nb_s1a + ta.nb_r), dim3(256), 0, s, ta);
     TXE_CHECK_LAUNCH();
     // ---- phase B: dW / d_attn (unfold) and dP ----
     TailB tb;

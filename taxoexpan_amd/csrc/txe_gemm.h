@@ -958,7 +958,16 @@ int device_cu_count();     // txe_profile.hip (cached hipDeviceAttributeMultipro
 // split-K products take 160-wide tiles only when they are big: their 512 fat workgroups (256 VGPRs) leave a concurrent kernel of the
 // other stream no wave slot -- the 8.5-GFLOP folded-layer weight gradient slowed the sweep running beside it by 30 us and the step
 // by 10, while the 153-GFLOP products of the 2-layer model gain 2 % from the 4.4 % fewer padded columns
-constexpr double BN160_SPLIT_MIN_FLOPS = 5e10;
+// ... above 20 GFLOP, and also where 64-wide tiles pad no more columns (N = 320 = 2 x 160 = 5 x 64: the first layer's weight
+// gradient -- 32 tiles x 16 slices fill the 512 slots exactly and run the full-rate 4-wave k-loop: 219 -> 205 us.  While that
+// product shared the chip with the skinny d_X GEMM on the second stream the fat workgroups cost more than they gained; d_X is now an
+// in-line HBM stream, txe_dxpos.hip.  TXE_BN160_STRICT=1 restores the strict rule for an A/B.)
+static inline bool bn160_eq() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("TXE_BN160_STRICT"); v = (e && e[0] == '1') ? 0 : 1; }
+    return v == 1;
+}
+static inline double bn160_split_min_flops() { return bn160_eq() ? 2e10 : 5e10; }
 static inline bool bn160_split_enabled() {
     static int v = -1;
     if (v < 0) { const char* e = getenv("TXE_NO_BN160_SPLIT"); v = (e && e[0] == '1') ? 0 : 1; }     // A/B switch
@@ -973,11 +982,11 @@ static inline bool bn160_enabled() {
 static inline int choose_bn(int M, int N, int splits, bool tail_split = false, int K = 0, bool allow160 = false) {
     if (N <= 64) return 64;
     const int slots = 2 * device_cu_count();
-    if (allow160 && splits > 1 && bn160_enabled() && bn160_split_enabled() && 2.0 * M * (double)N * K >= BN160_SPLIT_MIN_FLOPS) {
+    if (allow160 && splits > 1 && bn160_enabled() && bn160_split_enabled() && 2.0 * M * (double)N * K >= bn160_split_min_flops()) {
         // split-K products (weight gradients): 128 x 160 tiles when they cover N with fewer padded columns than 128-wide ones and at
         // least as few as 64-wide ones -- 320 = 2 x 160 runs the full-rate 4-wave k-loop where 5 x 64 starves the matrix pipe
         const int w160 = ((N + 159) / 160) * 160, w128 = ((N + 127) / 128) * 128, w64 = ((N + 63) / 64) * 64;
-        if (w160 < w128 && w160 < w64) return 160;
+        if (w160 < w128 && (w160 < w64 || (bn160_eq() && w160 == w64))) return 160;
     }
     if (allow160 && splits == 1 && bn160_enabled()) {
         // one round of 160-wide tiles where 128-wide ones spill into a second, k-split round with its fix-up launch
@@ -1172,7 +1181,7 @@ static inline int choose_splits(int M, int N, int K, int reserve = 0) {
     double best_cost = 1e30;
     {   // 160-wide tiles (choose_bn's rule; the weight gradients are the TN products that get them)
         const int w160 = ((N + 159) / 160) * 160, w128 = ((N + 127) / 128) * 128, w64 = ((N + 63) / 64) * 64;
-        if (N > 64 && w160 < w128 && w160 < w64 && bn160_enabled() && bn160_split_enabled() && 2.0 * M * (double)N * K >= BN160_SPLIT_MIN_FLOPS) {
+        if (N > 64 && w160 < w128 && (w160 < w64 || (bn160_eq() && w160 == w64)) && bn160_enabled() && bn160_split_enabled() && 2.0 * M * (double)N * K >= bn160_split_min_flops()) {
             const int tiles = ((M + GEMM_BM - 1) / GEMM_BM) * (w160 / 160);
             for (int s = 2; s <= 64 && s <= max_by_k; ++s) {
                 const long long blocks = (long long)tiles * s;

@@ -174,6 +174,37 @@ def run_scoring():
     print("scoring: S", save["S_lbm"].shape)
 
 
+def run_newterms():
+    """infer.py:23-38 + :96-106 on new-term vectors of realistic magnitude: rows divided by their SUM (float64 numpy, then the float32
+    of gensim's KeyedVectors and of `torch.tensor(kv[q], dtype=torch.float32)`), the reference's LBM / BIM on every candidate, and
+    the top-5 of `sorted(enumerate(scores), key=...)[:5]` -- descending (info_nce losses) and ascending (the others).  LBM's exp
+    overflows to inf on the rows with a tiny sum: the order of equal infs is Python's stable sort, i.e. candidate order."""
+    hg, raw, W = gc.make_newterm_inputs()
+    nf = np.array(raw)
+    row_sums = nf.sum(axis=1)                                                       # infer.py:33-35
+    nf = nf / row_sums[:, np.newaxis]
+    nf32 = np.asarray(nf, dtype=np.float32)                                         # KeyedVectors.add -> REAL
+    save = {"nf32": nf32}
+    for kind, cls in (("lbm", ref_zoo.LBM), ("bim", ref_zoo.BIM)):
+        mod = cls(hg.shape[1], nf32.shape[1])
+        mod.load_state_dict({"W.weight": torch.from_numpy(W)})
+        S, top_d, top_a = [], [], []
+        with torch.no_grad():
+            for qi in range(nf32.shape[0]):
+                q = torch.tensor(nf32[qi], dtype=torch.float32)
+                energy = mod(torch.from_numpy(hg), q.expand(hg.shape[0], -1))           # infer.py:96-98
+                scores = energy.cpu().squeeze_().tolist()
+                S.append(np.asarray(scores, dtype=np.float32))
+                top_d.append([e[0] for e in sorted(enumerate(scores), key=lambda x: -x[1])[:5]])   # infer.py:101
+                top_a.append([e[0] for e in sorted(enumerate(scores), key=lambda x: x[1])[:5]])    # infer.py:103
+        save[f"S_{kind}"] = np.stack(S)
+        save[f"top5_desc_{kind}"] = np.asarray(top_d, dtype=np.int64)
+        save[f"top5_asc_{kind}"] = np.asarray(top_a, dtype=np.int64)
+    np.savez_compressed(os.path.join(OUT, "newterms.npz"), **save)
+    n_inf = int(np.isinf(save["S_lbm"]).sum())
+    print(f"newterms: S {save['S_lbm'].shape}, {n_inf} inf scores, max |q| {np.abs(nf32).max():.1f}")
+
+
 def run_extras():
     """modules of model_zoo.py that model/model.py never instantiates: the NTN matcher (:331-346) and GATLayer's residual
     branch (:98-103, with res_fc and with the broadcast identity), forward + gradients of sum(out * coef)."""
@@ -242,11 +273,15 @@ if __name__ == "__main__":
     if "--extras-only" in sys.argv:
         run_extras()
         sys.exit(0)
+    if "--newterms-only" in sys.argv:
+        run_newterms()
+        sys.exit(0)
     if "--metrics-only" in sys.argv:
         run_metrics()
         sys.exit(0)
     for name, spec in gc.CASES.items():
         run_case(name, spec)
     run_scoring()
+    run_newterms()
     run_extras()
     run_metrics()

@@ -157,3 +157,23 @@ def make_scoring_inputs(c=SCORING_CASE):
     W = rs.uniform(-b, b, size=(1, c["l_dim"], c["r_dim"])).astype(np.float32)
     positives = [sorted(set(rs.randint(0, c["G"], size=rs.randint(1, 4)).tolist())) for _ in range(c["Q"])]
     return hg, qs, W, positives
+
+
+NEWTERM_CASE = dict(G=211, Q=24, l_dim=500, r_dim=250, seed=637)
+
+
+def make_newterm_inputs(c=NEWTERM_CASE):
+    """new-term vectors of the magnitude of the reference's data/mag_cs_new637.txt (250 values of O(+-15), |v| up to ~46, row sums
+    anywhere between -200 and +200, the smallest |row sum| of that file 0.56) BEFORE infer.py:33-35 divides every row by its SUM:
+    seeded synthetic rows -- three of them pinned to a tiny, a tiny negative and a large row sum -- candidate vectors hg and a
+    bilinear weight.  Returns (hg [G,l], raw [Q,r] float64, W [1,l,r])."""
+    rs = np.random.RandomState(c["seed"])
+    raw = np.clip(rs.standard_normal((c["Q"], c["r_dim"])) * 8.0, -46.0, 46.0)
+    raw[0, -1] += 0.56 - raw[0].sum()               # the file's smallest row sum: entries grow ~80x
+    raw[1, -1] += -0.9 - raw[1].sum()               # a negative sum flips every sign
+    raw[2, -1] += 206.7 - raw[2].sum()              # the file's largest
+    hg = (rs.standard_normal((c["G"], c["l_dim"])) * 0.5).astype(np.float32)
+    hg[7] = hg[3]                                   # duplicate candidates: exactly equal scores -> the order of ties is visible
+    hg[150] = hg[3]
+    W = (rs.standard_normal((1, c["l_dim"], c["r_dim"])) * 0.05).astype(np.float32)
+    return hg, raw, W

@@ -4,6 +4,7 @@ outputs) and MaskedGraphDataLoader (same constructor arguments).  `data_path` is
 reference's DGL pickles cannot be read without DGL (dataset.py says so when handed one)."""
 import os
 import itertools
+import logging
 
 import torch
 import torch.utils.data
@@ -53,14 +54,16 @@ def _open_dataset(data_path):
             raise ValueError(f"{data_path}: expected exactly one <name>.terms file, found {sorted(names)}")
         name = names[0]
         cache = os.path.join(data_path, f"{name}.txe.npz")
-        raw = [os.path.join(data_path, f) for f in (f"{name}.terms", f"{name}.taxo", f"{name}.terms.embed")]
+        # (the optional existing partition, dataset.py:160-170: a changed split must invalidate the cache too)
+        raw = [os.path.join(data_path, f) for f in (f"{name}.terms", f"{name}.taxo", f"{name}.terms.embed", f"{name}.terms.train",
+                                                    f"{name}.terms.validation", f"{name}.terms.test")]
         # the cache written by the first raw load is used while it is newer than the raw files (the reference's pickle flow,
         # generate_dataset_binary.py): train / validation / test loaders and every rank parse the text files once, not 3 x world times
         if os.path.exists(cache) and all(os.path.getmtime(cache) >= os.path.getmtime(f) for f in raw if os.path.exists(f)):
             try:
                 return _ds.MAGDataset(name=name, path=cache, raw=False)
-            except Exception:                         # unreadable cache: fall back to the raw files (and rewrite it)
-                pass
+            except Exception as exc:                  # unreadable cache: say so, fall back to the raw files (which rewrites it)
+                logging.getLogger(__name__).warning("ignoring unreadable dataset cache %s (%r): re-reading the raw files", cache, exc)
         return _ds.MAGDataset(name=name, path=data_path, raw=True)
     return _ds.MAGDataset(name="", path=data_path, raw=False)
 

@@ -28,10 +28,48 @@ def _per_query_means(values, pos_off):
     return float((sums / cnt.to(torch.float64)).mean().item())
 
 
-def evaluate(model, dataset, device, larger_is_better=True, qblock=1024, seed=0, batch_size=-1):
+CASE_METRICS = ("macro_mr", "micro_mr", "hit_at_1", "hit_at_3", "hit_at_5", "mrr_scaled_10")     # config.mag.json "metrics"
+
+
+def _score_blocks(model, hg, qf, qblock):
+    """score blocks [<= qblock queries, G candidates] of the per-query loop test_fast.py:121-123 / infer.py:96-98: one factored GEMM per
+    block for BIM / LBM, the literal expand loop for any other matcher"""
+    from . import ops
+    U = None
+    for q0 in range(0, qf.shape[0], qblock):
+        if hasattr(model.match, "W") and hasattr(model.match, "apply_exp"):
+            U = ops.bilinear_project(hg, model.match.W.weight) if U is None else U
+            yield q0, ops.score_block(qf[q0:q0 + qblock], U, model.match.apply_exp)
+        else:
+            yield q0, torch.stack([model.match(hg, q.expand(hg.shape[0], -1)).reshape(-1) for q in qf[q0:q0 + qblock]])
+
+
+def _case_rows(dataset, queries, pos_off, ranks, top, metric_names):
+    """the case-study table of test_fast.py:112-147: per test query its name, true parents, predicted top-5 parents and every
+    metric evaluated on that query's ranks alone (`metric([ranks])`, model/metric.py:62-90), as strings"""
+    r = ranks.cpu().to(torch.float64).numpy()
+    per_query = {
+        "macro_mr": lambda x: float(x.mean()), "micro_mr": lambda x: float(x.mean()),
+        "hit_at_1": lambda x: float(1.0 * np.sum(x <= 1) / len(x)), "hit_at_3": lambda x: float(1.0 * np.sum(x <= 3) / len(x)),
+        "hit_at_5": lambda x: float(1.0 * np.sum(x <= 5) / len(x)), "mrr_scaled_10": lambda x: float((1.0 / np.ceil(x / 10)).mean()),
+    }
+    vocab = dataset.vocab
+    rows = [["Test node index", "True parents", "Predicted parents"] + list(metric_names)]
+    for i, q in enumerate(queries):
+        x = r[pos_off[i]:pos_off[i + 1]]
+        rows.append([vocab[q], ", ".join(vocab[p] for p in dataset.node2parents[q]), ", ".join(vocab[p] for p in top[i])] +
+                    [str(per_query[m](x)) for m in metric_names])
+    return rows
+
+
+def evaluate(model, dataset, device, larger_is_better=True, qblock=1024, seed=0, batch_size=-1, case=None, metric_names=CASE_METRICS,
+             topk=5):
     """dataset: taxoexpan_amd.dataset.MaskedGraphDataset in 'validation' or 'test' mode.  Returns (metrics dict, ranks int32
     [n_positives], pos_off [Q+1], queries list).  Queries whose true parents are not candidate positions are skipped, like the
-    reference's rearrange() would fail on them."""
+    reference's rearrange() would fail on them.
+    case: test_fast.py's `-c` -- a path (the TSV of :142-147 is written) or a list (the rows are appended): per query its name, true
+    parents, the `topk` predicted parents (best first: descending score when larger_is_better, i.e. the info_nce losses, ascending
+    otherwise; ties in candidate order like Python's stable sort) and the metrics of `metric_names` on that query alone."""
     device = torch.device(device)
     cand = sorted(dataset.all_positions)                                    # test_fast.py:93
     index = {a: i for i, a in enumerate(cand)}
@@ -51,6 +89,18 @@ def evaluate(model, dataset, device, larger_is_better=True, qblock=1024, seed=0,
     qf = dataset.node_features[torch.as_tensor(queries, dtype=torch.long)].to(device)
     with torch.no_grad():
         ranks = rank_all_fused(model.match, hg, qf, pos_off, pos_idx, block=qblock, larger_is_better=larger_is_better)
+        if case is not None:                                               # test_fast.py:112-147
+            cand_ids = torch.as_tensor(np.asarray(cand, dtype=np.int64), device=device)
+            top = [topk_parents(S, cand_ids, topk, larger_is_better) for _q0, S in _score_blocks(model, hg, qf, qblock)]
+            top = torch.cat(top).cpu().tolist() if top else []
+            rows = _case_rows(dataset, queries, pos_off, ranks, top, metric_names)
+            if isinstance(case, list):
+                case.extend(rows)
+            else:
+                with open(case, "w") as fout:
+                    for row in rows:
+                        fout.write("\t".join(row))
+                        fout.write("\n")
     model.train(was_training)
     r = ranks.to(torch.float64)
     metrics = dict(macro_mr=_per_query_means(r, pos_off), hit_at_1=_per_query_means(ranks <= 1, pos_off),
@@ -81,14 +131,7 @@ def infer(model, dataset, new_taxons, device, loss="info_nce_loss", batch_size=-
     cand_ids = torch.as_tensor(anchors, device=device)
     picks = []
     with torch.no_grad():
-        U = None
-        for q0 in range(0, qf.shape[0], qblock):
-            from . import ops
-            if hasattr(model.match, "W") and hasattr(model.match, "apply_exp"):      # BIM / LBM: one factored GEMM per block
-                U = ops.bilinear_project(hg, model.match.W.weight) if U is None else U
-                S = ops.score_block(qf[q0:q0 + qblock], U, model.match.apply_exp)
-            else:                                                                    # any other matcher: the literal expand loop
-                S = torch.stack([model.match(hg, q.expand(hg.shape[0], -1)).reshape(-1) for q in qf[q0:q0 + qblock]])
+        for _q0, S in _score_blocks(model, hg, qf, qblock):
             picks.append(topk_parents(S, cand_ids, topk, larger))
     model.train(was_training)
     picks = torch.cat(picks).cpu().tolist() if picks else []

@@ -1034,10 +1034,16 @@ def bilinear_query_prefetch(e2, W):
             _order(torch.cuda.current_stream(e2.device), side)
         with torch.cuda.device(e2.device), torch.cuda.stream(side if on_side else torch.cuda.current_stream(e2.device)):
             call("txe_bilinear_query_project", ptr(e2c), ld2, G, l, r, ptr(Wf), ptr(V), _lib.stream_ptr())
+        if on_side:
+            # V was allocated on the caller's stream and is written on the second one: tell the caching allocator, so that a token
+            # that is never consumed (rejected by forward, an exception in between) cannot hand V's block to a main-stream tensor
+            # while the projection is still writing it; the same for the operands it reads
+            for t in (V, e2c, Wf):
+                t.record_stream(side)
         tok["stream"] = side if on_side else None
     tok["launch"] = launch
     if _PREFETCH_V_LATE:                        # launched by the encoder behind its first projection GEMM (_launch_pending_prefetch)
-        del _pending_prefetch[:]
+        del _pending_prefetch[:]                # (a token nobody launched holds no device work: dropping it is safe)
         _pending_prefetch.append(tok)
     else:
         launch()

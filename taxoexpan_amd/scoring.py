@@ -92,9 +92,10 @@ def score_all_sharded(match, hg_local, n_total, queries, block=1024, group=None,
     For every query block: local scores -> all-gather over xGMI -> on_block(q0, ShardedScoreBlock) (default: collect the dense
     [Q, G] matrix and return it).
     Pipelined (a 1,024-query MAG-Full block is 182 MB per rank, ~8 ms on the ring against ~0.2 ms of GEMM): the gather of
-    block i is issued asynchronously (RCCL's own stream) and waited for only after block i+1's local GEMM has been enqueued, on two
-    alternating pairs of preallocated buffers -- nothing is allocated, zero-filled or permuted inside the loop, and the consumer
-    reads the [world, nq, c] gather buffer in place.  A block handed to on_block stays valid until on_block is called again.
+    block i is issued asynchronously (RCCL's own stream) and waited for only after block i+1's local GEMM has been enqueued, on
+    THREE rotating pairs of preallocated buffers -- nothing is allocated, zero-filled or permuted inside the loop, and the consumer
+    reads the [world, nq, c] gather buffer in place.  A block handed to on_block stays valid until on_block is called again (the
+    gather issued in between writes the third buffer; with two, block i-1's buffer was re-used by gather i+1 BEFORE on_block(i) ran).
     local_score_fn(queries_block, out_padded) is injectable so the collective logic is testable without a GPU."""
     world = dist.get_world_size(group)
     c = math.ceil(n_total / world)
@@ -107,7 +108,7 @@ def score_all_sharded(match, hg_local, n_total, queries, block=1024, group=None,
                 ops.score_block(qb, U, match.apply_exp, out=out[:, :U.shape[0]])
     Q = queries.shape[0]
     bmax = min(block, max(Q, 1))
-    nbuf = 2 if pipeline else 1
+    nbuf = 3 if pipeline else 1
     loc = [torch.zeros((bmax, c), dtype=torch.float32, device=dev) for _ in range(nbuf)]     # padding columns: zeroed once, never written
     full = [torch.empty((world * bmax * c,), dtype=torch.float32, device=dev) for _ in range(nbuf)]
     collected = []
@@ -119,7 +120,8 @@ def score_all_sharded(match, hg_local, n_total, queries, block=1024, group=None,
         if on_block is not None:
             on_block(q0, blk)
         else:
-            collected.append(blk.dense().clone() if pipeline else blk.dense())
+            d = blk.dense()                               # (world > 1: a fresh tensor already; world == 1: a view of the gather buffer)
+            collected.append(d.clone() if (pipeline and world == 1) else d)
     pending = None
     for i, q0 in enumerate(range(0, Q, block)):
         qb = queries[q0:q0 + block]
@@ -202,25 +204,62 @@ def allreduce_gradients(params, group=None, skip=None):
     so gradients simply add: one flat bucket (1.76 M fp32 = 7 MB for the MAG config), one RCCL all-reduce.
     skip: an overlapped_gradient_allreduce whose gradients were already reduced during backward."""
     done = skip.reduced if skip is not None else ()
-    grads = [p.grad for p in params if p.grad is not None and id(p) not in done]
-    if not grads:
+    todo = [p for p in params if p.requires_grad and id(p) not in done]
+    if not todo:
         return
+    # the bucket has the same layout on every rank whatever each rank's backward produced: a parameter without a gradient here (an
+    # empty shard, a branch this rank did not take) contributes zeros and receives the sum
+    for p in todo:
+        if p.grad is None:
+            p.grad = torch.zeros_like(p)
+    grads = [p.grad for p in todo]
     flat = torch.cat([g.reshape(-1) for g in grads])
     dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
     parts = flat.split([g.numel() for g in grads])
     torch._foreach_copy_(grads, [q.view_as(g) for q, g in zip(parts, grads)])      # one multi-tensor kernel
 
 
-class overlapped_gradient_allreduce:
-    """`with overlapped_gradient_allreduce(group) as ov: loss.backward()` -- the propagation stack's backward announces each layer's
-    parameter gradients the moment they exist (ops._GRAD_READY, with the ids of their parameters); they go into one flat bucket per layer whose all-reduce is issued
-    asynchronously right there, under the backward of the layers below (the output layer's 4 MB bucket rides under ~0.6 ms of
-    layer-0 kernels on the MAG step), and is waited for -- by the stream, not the host -- before the stack hands its gradients to
-    autograd.  `allreduce_gradients(params, skip=ov)` then reduces what is left (the first layer, readout, matcher)."""
+def gradient_bucket_plan(model, min_layer=1):
+    """the buckets overlapped_gradient_allreduce will see, from the model alone: for every GAT layer l >= min_layer of
+    `model.graph_propagate` its fc.weight / attn_l / attn_r / position-embedding table (+ the weighted readout's position weights with
+    the last layer when it is folded behind the readout) -- [(layer, [parameters])], top layer first, as backward announces them.
+    Every rank derives the same plan, so a rank whose backward never reaches the stack can still issue matching collectives."""
+    prop = getattr(model, "graph_propagate", None)
+    layers = getattr(prop, "gat_layers", None)
+    if layers is None:
+        return []
+    emb = getattr(prop, "prop_position_embeddings", None)
+    pw = getattr(getattr(model, "readout", None), "position_weights", None)
+    plan = []
+    L = len(layers)
+    for l in range(L - 1, min_layer - 1, -1):
+        ps = [layers[l].fc.weight, layers[l].attn_l, layers[l].attn_r]
+        if emb is not None:
+            ps.append(emb[l].weight)
+        if l == L - 1 and pw is not None:
+            ps.append(pw.weight)
+        plan.append((l, ps))
+    return plan
 
-    def __init__(self, group=None, min_layer=1):
+
+class overlapped_gradient_allreduce:
+    """`with overlapped_gradient_allreduce(group, model=model) as ov: loss.backward()` -- the propagation stack's backward announces each
+    layer's parameter gradients the moment they exist (ops._GRAD_READY, with the ids of their parameters); they go into one flat bucket
+    per layer whose all-reduce is issued asynchronously right there, under the backward of the layers below (the output layer's 4 MB
+    bucket rides under ~0.6 ms of layer-0 kernels on the MAG step), and is waited for -- by the stream, not the host -- before the
+    stack hands its gradients to autograd.  `allreduce_gradients(params, skip=ov)` then reduces what is left (the first layer,
+    readout, matcher).
+    The collective schedule is RANK-INVARIANT when `model` is given: the buckets are planned from the model (gradient_bucket_plan), an
+    announcement that does not match the plan is left to the flat bucket, and a planned bucket this rank's backward never announced
+    (an empty shard whose readout returned zeros without running the stack, the unfused route) is issued on exit with zeros -- the
+    rank receives the sum, like its peers.  Without `model` every rank must take the same route through backward.
+    Not re-entrant and not thread-safe: the hooks are process-global (ops._GRAD_READY / _GRAD_FLUSH); one backward at a time."""
+
+    def __init__(self, group=None, min_layer=1, model=None):
         self.group, self.min_layer = group, min_layer
         self.reduced, self._pending = set(), []
+        self.plan = gradient_bucket_plan(model, min_layer) if model is not None else None
+        self._fired = set()
 
     def __enter__(self):
         self._prev = (ops._GRAD_READY, ops._GRAD_FLUSH)
@@ -230,16 +269,43 @@ class overlapped_gradient_allreduce:
     def __exit__(self, *exc):
         self._flush()
         ops._GRAD_READY, ops._GRAD_FLUSH = self._prev
+        if self.plan is not None and exc[0] is None:
+            self._issue_missing()
         return False
 
     def _ready(self, layer, tensors, param_ids):
-        keep = [(t, i) for t, i in zip(tensors, param_ids) if t is not None]
-        if layer < self.min_layer or not keep:           # the bottom layer's gradients arrive last: nothing left to hide them under
-            return
-        tensors = [t for t, _ in keep]
+        if self.plan is not None:
+            want = next((ps for l, ps in self.plan if l == layer), None)
+            have = {i: t for t, i in zip(tensors, param_ids) if t is not None}
+            if want is None or any(id(p) not in have or have[id(p)].numel() != p.numel() for p in want) or layer in self._fired:
+                return                                     # not a planned bucket: the flat bucket after backward takes it
+            # planned order: buckets fire top layer first; an earlier planned layer that never fired goes out (with zeros) first
+            self._issue_missing(before=layer)
+            self._fired.add(layer)
+            tensors, ids = [have[id(p)] for p in want], [id(p) for p in want]
+        else:
+            keep = [(t, i) for t, i in zip(tensors, param_ids) if t is not None]
+            if layer < self.min_layer or not keep:           # the bottom layer's gradients arrive last: nothing left to hide them under
+                return
+            tensors, ids = [t for t, _ in keep], [i for _, i in keep]
         flat = torch.cat([t.reshape(-1) for t in tensors])
         work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-        self._pending.append((work, flat, tensors, [i for _, i in keep]))
+        self._pending.append((work, flat, tensors, ids))
+
+    def _issue_missing(self, before=None):
+        """planned buckets above `before` (all of them when None) that this rank's backward never announced: all-reduce whatever
+        gradient the rank holds for them (zeros if none), keep the sum"""
+        for l, ps in self.plan:
+            if before is not None and l <= before:
+                break
+            if l in self._fired:
+                continue
+            self._fired.add(l)
+            flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in ps])   # (what this rank has)
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+            for p, q in zip(ps, flat.split([p.numel() for p in ps])):
+                p.grad = q.view_as(p).clone() if p.grad is None else p.grad.copy_(q.view_as(p))
+            self.reduced.update(id(p) for p in ps)
 
     def _flush(self):
         for work, flat, tensors, ids in self._pending:
@@ -259,6 +325,9 @@ def topk_parents(S, candidate_ids, k=5, larger_is_better=True):
     if k == 0 or Q == 0:
         return candidate_ids.new_zeros((Q, 0)).to(S.device)
     key = S if larger_is_better else -S
+    # a NaN score compares false with everything: Python's sorted() leaves it wherever it happens to stand, here it ranks last (and the
+    # selection below never indexes past the row: without this a row holding a NaN selected only filler columns)
+    key = torch.where(torch.isnan(key), torch.full_like(key, -float("inf")), key)
     vk = torch.topk(key, k, dim=1).values[:, -1:]                                     # the k-th best value of each row
     ar = torch.arange(G, device=S.device).expand(Q, G)
     fill = torch.full_like(ar, G)
@@ -270,5 +339,5 @@ def topk_parents(S, candidate_ids, k=5, larger_is_better=True):
     o1 = torch.sort(cand, dim=1, stable=True).indices
     cand, ckey = torch.gather(cand, 1, o1), torch.gather(ckey, 1, o1)
     o2 = torch.sort(ckey, dim=1, descending=True, stable=True).indices
-    idx = torch.gather(cand, 1, o2)[:, :k]
+    idx = torch.gather(cand, 1, o2)[:, :k].clamp(max=G - 1)
     return candidate_ids.to(idx.device)[idx]

@@ -203,3 +203,72 @@ def test_overlapped_gradient_allreduce_world2():
     ret = mgr.dict()
     mp.spawn(_overlap_worker, args=(2, _free_port(), ret), nprocs=2, join=True)
     assert all(ret.get(r) for r in range(2)), dict(ret)
+
+
+class _ToyGatStack(torch.autograd.Function):
+    """two "GAT layers" (fc.weight, attn_l, attn_r each) that announce their gradients like ops.GATStackFunction.backward"""
+    @staticmethod
+    def forward(ctx, x, *ps):
+        ctx.save_for_backward(x, *ps)
+        ctx.ids = [id(p) for p in ps]
+        w0, l0, r0, w1, l1, r1 = ps
+        return ((x @ w0) * l0 + r0) @ w1 * l1.sum() + r1.sum()
+
+    @staticmethod
+    def backward(ctx, g):
+        from taxoexpan_amd import ops
+        x, *ps = ctx.saved_tensors
+        with torch.enable_grad():
+            qs = [p.detach().requires_grad_(True) for p in ps]
+            w0, l0, r0, w1, l1, r1 = qs
+            out = ((x @ w0) * l0 + r0) @ w1 * l1.sum() + r1.sum()
+            grads = [t.contiguous() for t in torch.autograd.grad(out, qs, g)]        # (sum()'s gradient is a stride-0 view)
+        if ops._GRAD_READY is not None:
+            ops._GRAD_READY(1, list(grads[3:]), ctx.ids[3:])
+            ops._GRAD_READY(0, list(grads[:3]), ctx.ids[:3])
+            ops._GRAD_FLUSH()
+        return (None, *grads)
+
+
+def _invariant_worker(rank, world, port, ret):
+    import types
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from taxoexpan_amd import scoring
+        torch.manual_seed(3)
+        P = lambda *s: torch.nn.Parameter(torch.randn(*s))
+        layers = [types.SimpleNamespace(fc=types.SimpleNamespace(weight=P(4, 5)), attn_l=P(5), attn_r=P(5)),
+                  types.SimpleNamespace(fc=types.SimpleNamespace(weight=P(5, 3)), attn_l=P(3), attn_r=P(3))]
+        wm = P(3)
+        model = types.SimpleNamespace(graph_propagate=types.SimpleNamespace(gat_layers=layers))
+        stack = [layers[0].fc.weight, layers[0].attn_l, layers[0].attn_r, layers[1].fc.weight, layers[1].attn_l, layers[1].attn_r]
+        params = stack + [wm]
+        x = torch.randn(6, 4, generator=torch.Generator().manual_seed(10))
+        # what rank 0 alone contributes to the stack; rank 1's shard is empty (its loss never touches the stack)
+        (_ToyGatStack.apply(x, *stack) * wm).sum().backward()
+        want = [p.grad.clone() for p in params]
+        want[-1] = want[-1] + 2.0                                   # rank 1: d/dwm of (2 * wm).sum()
+        for p in params:
+            p.grad = None
+        plan = scoring.gradient_bucket_plan(model)
+        assert [l for l, _ in plan] == [1] and [id(p) for p in plan[0][1]] == [id(p) for p in stack[3:]]
+        with scoring.overlapped_gradient_allreduce(model=model) as ov:
+            if rank == 0:
+                (_ToyGatStack.apply(x, *stack) * wm).sum().backward()
+            else:
+                (2.0 * wm).sum().backward()                          # no stack backward: the planned bucket goes out on exit
+        assert ov.reduced == {id(p) for p in stack[3:]}, "the planned bucket was reduced on every rank"
+        scoring.allreduce_gradients(params, skip=ov)                 # rank 1 holds no gradient for layer 0: zeros, same layout
+        ret[rank] = all(p.grad is not None and torch.allclose(p.grad, w, atol=1e-5) for p, w in zip(params, want))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_overlapped_gradient_allreduce_is_rank_invariant_when_a_rank_skips_the_stack():
+    """a rank whose backward never reaches the propagation stack (an empty shard) still issues the planned bucket's all-reduce (with
+    zeros) and the same flat bucket as its peers: no hang, every rank ends with the sum"""
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_invariant_worker, args=(2, _free_port(), ret), nprocs=2, join=True)
+    assert all(ret.get(r) for r in range(2)), dict(ret)

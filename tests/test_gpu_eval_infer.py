@@ -86,6 +86,84 @@ def test_infer_top5_parents_against_the_literal_loop(tmp_path, match, loss, batc
     assert lines[0] == "Query\tPredicted parents" and lines[1] == f"{out[0][0]}\t{', '.join(out[0][1])}" and len(lines) == 10
 
 
+@pytest.mark.parametrize("match,larger", [("LBM", True), ("BIM", False)])
+def test_case_study_table_against_the_literal_loop(tmp_path, match, larger):
+    """test_fast.py:112-147 (`-c`): per test query its name, true parents, top-5 predicted parents and every metric on that query
+    alone -- evaluate(case=...) against the reference's loop done literally on the host with the oracle (scores, metric.py ranks,
+    Python's stable sort), and the TSV it writes"""
+    from taxoexpan_amd.evaluate import CASE_METRICS, evaluate
+    ds = _toy(tmp_path)
+    model = _model(match)
+    path = tmp_path / "case.tsv"
+    metrics, ranks, pos_off, queries = evaluate(model, ds, _dev(), larger_is_better=larger, case=str(path))
+    rows = [ln.split("\t") for ln in open(path).read().splitlines()]
+    assert rows[0] == ["Test node index", "True parents", "Predicted parents"] + list(CASE_METRICS)
+    assert len(rows) == 1 + len(queries) and len(queries) > 10
+    cand = sorted(ds.all_positions)                                               # test_fast.py:93
+    hg, P = _oracle_hg(model, ds, cand)
+    index = {a: i for i, a in enumerate(cand)}
+    n_exact = 0
+    for row, q in zip(rows[1:], queries):
+        qv = ds.node_features[q].expand(len(cand), -1)                            # test_fast.py:121-123
+        sc = orc.bilinear_match(hg, qv, P["match.W.weight"], match == "LBM").squeeze(1).tolist()
+        top = sorted(enumerate(sc), key=(lambda e: -e[1]) if larger else (lambda e: e[1]))[:5]
+        pos = [index[a] for a in ds.node2parents[q] if a in index]
+        r = np.asarray(orc.ranks_of_positives(sc, pos, larger), dtype=np.float64)  # metric.py:7-31
+        want = [ds.vocab[q], ", ".join(ds.vocab[a] for a in ds.node2parents[q]), ", ".join(ds.vocab[cand[i]] for i, _ in top),
+                str(float(r.mean())), str(float(r.mean())), str(float(np.sum(r <= 1) / len(r))), str(float(np.sum(r <= 3) / len(r))),
+                str(float(np.sum(r <= 5) / len(r))), str(float((1.0 / np.ceil(r / 10)).mean()))]
+        assert row[:2] == want[:2] and row[3:] == want[3:], (row, want)
+        assert set(row[2].split(", ")) == set(want[2].split(", "))
+        n_exact += row[2] == want[2]
+    assert n_exact >= len(queries) - 1                # (neighbouring scores inside fp32 summation noise may swap)
+    rows2 = []
+    evaluate(model, ds, _dev(), larger_is_better=larger, case=rows2)
+    assert rows2 == rows
+
+
+def test_newterm_magnitudes_scores_and_top5_on_device():
+    """infer.py:23-38,96-106 with query vectors of data/mag_cs_new637.txt's magnitude (rows divided by their SUM: entries up to ~270):
+    the factored scoring GEMM with the fused exp against the reference's LBM / BIM scores (tests/golden/newterms.npz) -- infs where exp
+    overflows, zeros where it underflows -- and scoring.topk_parents on the DEVICE scores against the reference's sorted() top-5, both
+    directions: equal infs / zeros / duplicated candidates in candidate order"""
+    from taxoexpan_amd import ops
+    from taxoexpan_amd.scoring import topk_parents
+    z = dict(np.load(os.path.join(GOLDEN_DIR, "newterms.npz")))
+    import golden_cases as gc
+    hg, _raw, W = gc.make_newterm_inputs()
+    dev = _dev()
+    hg_d, W_d, q_d = torch.from_numpy(hg).to(dev), torch.from_numpy(W).to(dev), torch.from_numpy(z["nf32"]).to(dev)
+    ids = torch.arange(hg.shape[0], device=dev)
+    U = ops.bilinear_project(hg_d, W_d)
+    for kind, ex in (("lbm", True), ("bim", False)):
+        S = ops.score_block(q_d, U, ex)
+        ref = z[f"S_{kind}"]
+        got = S.cpu().numpy()
+        # overflow / underflow happen at the same entries unless the exponent sits within 1e-4 relative of the fp32 thresholds
+        edge = np.zeros_like(ref, dtype=bool)
+        if ex:
+            with np.errstate(over="ignore"):
+                s64 = np.einsum("gl,lr,qr->qg", hg.astype(np.float64), W[0].astype(np.float64), z["nf32"].astype(np.float64))
+            edge = (np.abs(s64 - 88.7228) < 2e-2) | (np.abs(s64 + 103.28) < 2e-1) | (np.abs(s64 + 87.3365) < 2e-2)
+        assert np.array_equal(np.isinf(got) | edge, np.isinf(ref) | edge)
+        fin = np.isfinite(ref) & np.isfinite(got) & (ref != 0) & ~edge & (np.abs(ref) > 1e-30)
+        np.testing.assert_allclose(got[fin], ref[fin], rtol=1e-4 if not ex else 3e-4)       # (exp turns 1e-6 of a 60-ish exponent into 1e-4)
+        for larger, key in ((True, "desc"), (False, "asc")):
+            top = topk_parents(S, ids, 5, larger).cpu().numpy()
+            want = z[f"top5_{key}_{kind}"]
+            n_same = 0
+            for qi in range(top.shape[0]):
+                mine = sorted(enumerate(got[qi].tolist()), key=(lambda e: -e[1]) if larger else (lambda e: e[1]))[:5]
+                assert top[qi].tolist() == [e[0] for e in mine]                              # the device scores' own stable sort
+                n_same += top[qi].tolist() == want[qi].tolist()
+            assert n_same >= top.shape[0] - 1, (kind, key, n_same)                            # = the reference's, up to one noise swap
+        inf_rows = np.nonzero(np.isinf(ref).sum(1) >= 5)[0]
+        if ex:
+            assert len(inf_rows) >= 2
+            t = topk_parents(S, ids, 5, True).cpu().numpy()
+            assert np.array_equal(t[inf_rows], z["top5_desc_lbm"][inf_rows])               # >= 5 equal infs: exactly candidate order
+
+
 @pytest.mark.parametrize("batch_size", [13, 64])
 def test_chunked_evaluation_equals_single_batch(tmp_path, batch_size):
     """test_fast.py:149-218 (`-b`): the candidates encoded in chunks give the ranks and metrics of the one-batch run; expand_factor

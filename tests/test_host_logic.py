@@ -227,6 +227,14 @@ def test_topk_parents_is_pythons_stable_sort():
             key = (lambda e: -e[1]) if larger else (lambda e: e[1])
             assert got[q].tolist() == [int(ids[e[0]]) for e in sorted(enumerate(S[q].tolist()), key=key)[:5]]
     assert topk_parents(torch.randn(3, 2), torch.arange(2), 5).shape == (3, 2)
+    # NaN scores rank last instead of selecting nothing (the row used to pick only filler columns: an out-of-range gather on the
+    # GPU); -inf scores tie with the filler key and still come out in candidate order
+    S = torch.tensor([[1.0, float("nan"), 3.0, 2.0, float("nan"), 0.5, 7.0],
+                      [float("nan")] * 7,
+                      [float("-inf"), 1.0, float("-inf"), float("-inf"), float("-inf"), float("-inf"), float("-inf")]])
+    got = topk_parents(S, torch.arange(7), 5, True).tolist()
+    assert got[0] == [6, 2, 3, 0, 5] and got[1] == [0, 1, 2, 3, 4] and got[2] == [1, 0, 2, 3, 4]
+    assert topk_parents(S[:1], torch.arange(7), 5, False).tolist()[0] == [5, 0, 3, 2, 6]
 
 
 def test_data_loader_uses_the_cache_after_the_first_raw_load(tmp_path, monkeypatch):

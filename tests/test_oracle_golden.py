@@ -69,6 +69,29 @@ def test_oracle_scoring_loop_and_ranks():
         assert ranks == z[f"ranks_{kind}"].tolist()
 
 
+def test_newterm_magnitudes_scores_and_top5_tie_order():
+    """infer.py:23-38,96-106 on new-term vectors of data/mag_cs_new637.txt's magnitude (rows divided by their SUM, entries up to
+    ~270): the oracle's LBM / BIM scores against the reference's -- same infs where exp overflows, same zeros where it underflows --
+    and the top-5 by Python's stable sort, both directions, against scoring.topk_parents on the reference's own score rows (equal infs /
+    equal zeros / duplicated candidates come out in candidate order)"""
+    from taxoexpan_amd.scoring import topk_parents
+    z = dict(np.load(f"{GOLDEN_DIR}/newterms.npz"))
+    hg, raw, W = gc.make_newterm_inputs()
+    nf32 = (raw / raw.sum(axis=1)[:, None]).astype(np.float32)
+    assert np.array_equal(nf32, z["nf32"]) and np.abs(nf32).max() > 100
+    ids = torch.arange(hg.shape[0])
+    for kind, ex in (("lbm", True), ("bim", False)):
+        S = orc.score_all_literal(torch.from_numpy(hg), torch.from_numpy(W), torch.from_numpy(nf32), ex).numpy()
+        ref = z[f"S_{kind}"]
+        fin = np.isfinite(ref) & (ref != 0)
+        assert np.array_equal(np.isinf(S), np.isinf(ref)) and np.array_equal(S == 0, ref == 0)
+        np.testing.assert_allclose(S[fin], ref[fin], rtol=5e-5)
+        for larger, key in ((True, "desc"), (False, "asc")):
+            got = topk_parents(torch.from_numpy(ref), ids, 5, larger).numpy()
+            assert np.array_equal(got, z[f"top5_{key}_{kind}"]), (kind, key)
+    assert np.isinf(z["S_lbm"]).sum() > 50 and (z["S_lbm"] == 0).sum() > 50       # the case does exercise overflow and underflow
+
+
 def test_egonet_layout():
     n, s, d, p = orc.egonet_edges(2, 3)
     assert n == 6 and len(s) == 2 * n - 1

@@ -231,3 +231,25 @@ def test_bench_two_ranks_sharded_inference_on_one_gpu():
     assert ex["infer_queries"] == 2048 and ex["candidates_per_rank"] * 2 >= ex["infer_candidates"]
     for k in ("candidates_scored_per_s_local", "candidates_scored_per_s_allgather", "candidates_scored_per_s_fused_allreduce"):
         assert ex[k] > 0, k
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_sharded_scoring_equals_unsharded_bit_for_bit_on_the_hip_kernels(world):
+    """candidate-sharded scoring with the HIP kernels at world size 2 and 4 (all ranks on cuda:0, gloo): the pipelined all-gather of
+    score blocks read in place and densified, and the all-reduce-of-counts ranking, against the unsharded loop of the same process --
+    torch.equal (tests/dist_gpu_worker.py).  The CPU tests prove the collective logic with injected local functions; this one runs
+    the kernels under it."""
+    import socket
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+                          "--master-port", str(port), os.path.join(repo, "tests", "dist_gpu_worker.py")],
+                         cwd=repo, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
+    assert sorted(ln for ln in out.stdout.splitlines() if ln.startswith("OK ")) == [f"OK {r}" for r in range(world)]

@@ -78,7 +78,8 @@ def test_full_size_training_step_matches_oracle(workload, monkeypatch):
     from taxoexpan_amd import TaxoExpan, ops, synthetic as syn
     prop, readout, match, num_layers, heads = WORKLOADS[workload]
     dev = _dev()
-    tax = syn.make_named_taxonomy("mag_cs", seed=47)
+    # (bench.py times `pgat2` -- BASELINE configs[3] -- on the MAG-Full-shaped taxonomy, the other two on the MAG-CS one)
+    tax = syn.make_named_taxonomy("mag_full" if workload == "pgat2" else "mag_cs", seed=47)
     g, qf, _labels = syn.training_batch(tax, N_QUERIES, NEG, seed=1000)          # batch 0 of bench.py's rank 0
     assert g.batch_size == 4096
     x = g.ndata.pop("x")
@@ -218,3 +219,116 @@ def test_fused_backward_sweep_equals_unfused_chain(heads, hidden, drop, layers, 
     for k in ga:
         _close(ga[k], gb[k], 2e-4, 2e-5, "grad " + k, errors)
     assert not errors, "\n".join(errors)
+
+
+# ================================================================================================================
+# BASELINE configs[2]: the all-candidate inference loop AT ITS SIZE against the oracle (test_fast.py:99-140,149-218)
+# ================================================================================================================
+def _oracle_encode(P, features, ids, pos, node_off, heads=(4, 1), chunk=2048, select=None):
+    """encode_graph (test_fast.py:25-28) of the egonets [node_off[g], node_off[g+1]) with the oracle, `chunk` egonets at a time.
+    The egonet layout is dataset.py:404-437's: k grand-parents (pos 0), the anchor, m siblings (pos 2).  select: egonet indices."""
+    sel = np.arange(len(node_off) - 1) if select is None else np.asarray(select)
+    out = []
+    with torch.no_grad():
+        for c0 in range(0, len(sel), chunk):
+            gs = sel[c0:c0 + chunk]
+            rows = np.concatenate([np.arange(node_off[g], node_off[g + 1]) for g in gs])
+            p = pos[rows]
+            shapes = []
+            for g in gs:
+                pg = pos[node_off[g]:node_off[g + 1]]
+                k, m = int((pg == 0).sum()), int((pg == 2).sum())
+                assert k + 1 + m == len(pg) and pg[k] == 1
+                shapes.append((k, m))
+            graph = orc.batch_egonets(shapes)
+            assert np.array_equal(graph["pos"].numpy(), p)
+            hn = orc.pgat_forward(P, graph, features[torch.from_numpy(ids[rows]).long()], list(heads), 1, prefix="graph_propagate.")
+            out.append(orc.weighted_mean_readout(graph["graph_off"], hn, graph["pos"], P["readout.position_weights.weight"]))
+    return torch.cat(out)
+
+
+def _rank_brackets(S_ref, pos_off, pos_idx, delta):
+    """metric.py:7-31 on the oracle's scores with a relative band: [rank if every near-tie goes the positive's way, rank if none does]"""
+    lo, hi = [], []
+    for q in range(len(pos_off) - 1):
+        p = pos_idx[pos_off[q]:pos_off[q + 1]]
+        row = S_ref[q].astype(np.float64)
+        neg = np.delete(row, p)
+        for c in p:
+            s = row[c]
+            lo.append(1 + int((neg > s * (1 + delta)).sum()))
+            hi.append(1 + int((neg > s * (1 - delta)).sum()))
+    return np.asarray(lo), np.asarray(hi)
+
+
+def test_mag_cs_inference_matches_oracle_at_full_size():
+    """configs[2] on the MAG-CS shape: ALL 24,754 candidate egonets through the eval route the scripts take here (device-built egonets
+    whose features stay rows of the taxonomy table -> table projection once -> rows formed inside the sweep -> folded output layer)
+    against the oracle's encode_graph on the same egonets (every graph vector, 1e-4); then the whole 2,450 x 24,754 score matrix
+    (factored GEMM + fused exp) against the oracle's scores at 1e-4, and the ranks of every true parent -- materialised and fused
+    paths -- inside the band the oracle's own scores leave when near-ties (relative gap < 2e-4) may fall either way; >= 99.5 % of
+    them must be the oracle's exact rank"""
+    from taxoexpan_amd import TaxoExpan, graph as G, ops, synthetic as syn
+    from taxoexpan_amd.evaluate import candidate_graphs
+    from taxoexpan_amd.scoring import encode_candidates, rank_all_fused, score_all
+    import bench
+    dev = _dev()
+    tax = syn.make_named_taxonomy("mag_cs", seed=47)
+    cand, _val, test = syn.split_candidates(tax)
+    assert len(cand) > 24000 and len(test) > 2400
+    torch.manual_seed(47)
+    model = TaxoExpan("PGAT", "WMR", "LBM", **dict(MAG, num_layers=1, heads=[4, 1])).to(dev).eval()
+    dtax = G.DeviceTaxonomy(tax.par_ptr, tax.par_idx, tax.chd_ptr, tax.chd_idx, tax.features, dev)
+    g = candidate_graphs(dtax, cand, 50, 7)
+    hg = encode_candidates(model, g)
+    ids, pos = g.ndata["_id"].cpu().numpy(), g.ndata["pos"].cpu().numpy()
+    node_off = g.csr(dev).graph_off.cpu().numpy()
+    assert len(node_off) == len(cand) + 1 and node_off[-1] == len(ids) > 90000
+    P = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    hg_ref = _oracle_encode(P, tax.features, ids, pos, node_off)
+    errors = []
+    _close(hg.cpu().numpy(), hg_ref.numpy(), 1e-4, 2e-5, "hg (all MAG-CS candidates)", errors)
+    assert not errors, errors
+    queries = tax.features[torch.from_numpy(test)]
+    S = score_all(model.match, hg, queries.to(dev))
+    S_ref = torch.exp(queries @ (hg_ref @ P["match.W.weight"][0]).t()).numpy()          # the factored form of test_fast.py:121-123
+    assert S.shape == S_ref.shape == (len(test), len(cand))
+    np.testing.assert_allclose(S.cpu().numpy(), S_ref, rtol=1e-4, atol=1e-30)
+    pos_off, pos_idx = bench._positives(tax, cand, test)
+    lo, hi = _rank_brackets(S_ref, pos_off, pos_idx, 2e-4)
+    exact = (lo + hi) // 2                                                               # (= the oracle's rank when lo == hi)
+    off_t, idx_t = torch.tensor(pos_off, dtype=torch.int32), torch.tensor(pos_idx, dtype=torch.int32)
+    r_mat = ops.rank_block(S, off_t, idx_t, True).cpu().numpy()
+    r_fused = rank_all_fused(model.match, hg, queries.to(dev), pos_off, pos_idx).cpu().numpy()
+    assert np.array_equal(r_mat, r_fused)
+    assert ((r_mat >= lo) & (r_mat <= hi)).all(), np.nonzero((r_mat < lo) | (r_mat > hi))[0][:10]
+    assert (lo == hi).mean() > 0.99 and (r_mat == exact)[lo == hi].all()
+
+
+def test_mag_full_30000_chunk_matches_oracle():
+    """configs[2]'s `-b 30000` on the MAG-Full shape: the first chunk of 30,000 candidate egonets (431,416-row feature table projected
+    once, rows formed in the sweep) against the oracle on a strided sample of 5,000 of them (every 6th egonet, graph vectors at 1e-4),
+    and their scores against 512 test queries"""
+    from taxoexpan_amd import TaxoExpan, graph as G, synthetic as syn
+    from taxoexpan_amd.scoring import encode_candidates, score_all
+    dev = _dev()
+    tax = syn.make_named_taxonomy("mag_full", seed=47)
+    cand, _val, test = syn.split_candidates(tax)
+    torch.manual_seed(47)
+    model = TaxoExpan("PGAT", "WMR", "LBM", **dict(MAG, num_layers=1, heads=[4, 1])).to(dev).eval()
+    dtax = G.DeviceTaxonomy(tax.par_ptr, tax.par_idx, tax.chd_ptr, tax.chd_idx, tax.features, dev)
+    g = G.device_egonet_batch(dtax, cand[:30000], expand_factor=50, seed=7, with_features="lazy", index_base=0)
+    hg = encode_candidates(model, g)
+    assert hg.shape == (30000, 500)
+    ids, pos = g.ndata["_id"].cpu().numpy(), g.ndata["pos"].cpu().numpy()
+    node_off = g.csr(dev).graph_off.cpu().numpy()
+    sel = np.arange(0, 30000, 6)
+    P = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    hg_ref = _oracle_encode(P, tax.features, ids, pos, node_off, select=sel)
+    errors = []
+    _close(hg.cpu().numpy()[sel], hg_ref.numpy(), 1e-4, 2e-5, "hg (MAG-Full chunk, strided sample)", errors)
+    assert not errors, errors
+    queries = tax.features[torch.from_numpy(test[:512])]
+    S = score_all(model.match, hg, queries.to(dev)).cpu().numpy()[:, sel]
+    S_ref = torch.exp(queries @ (hg_ref @ P["match.W.weight"][0]).t()).numpy()
+    np.testing.assert_allclose(S, S_ref, rtol=1e-4, atol=1e-30)

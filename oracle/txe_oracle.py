@@ -92,8 +92,18 @@ def segment_sum(graph_off, x):
 # ----------------------------------------------------------------------------------------
 # GAT  (model_zoo.py:52-114, 169-220)
 # ----------------------------------------------------------------------------------------
+def _leaky(x, slope, pos=None):
+    """F.leaky_relu; with `pos` (bool, same shape) the branch of every element is GIVEN instead of decided by its sign.  leaky_relu' is
+    discontinuous at 0: two fp32 evaluations whose pre-activation differs in the last bit around 0 differentiate different linear
+    pieces.  A test that hands the implementation-under-test's own branch pattern to the oracle compares gradients of the SAME
+    piecewise-linear function, entry for entry (the forward value moves by at most |x|(1-slope) ~ one rounding error there)."""
+    if pos is None:
+        return F.leaky_relu(x, slope)
+    return torch.where(pos, x, x * slope)
+
+
 def gat_layer(src, dst, n, feature, fc_w, attn_l, attn_r, slope=0.2, feat_keep=None, attn_keep=None,
-              feat_scale=1.0, attn_scale=1.0, return_parts=False, residual=False, res_w=None):
+              feat_scale=1.0, attn_scale=1.0, return_parts=False, residual=False, res_w=None, e_pos=None):
     """GATLayer.forward, model_zoo.py:80-104 (residual branch :98-103 is dead for PGAT: `residual=True` adds
     res_fc(h) -- or h itself broadcast over heads when res_w is None, i.e. in_dim == out_dim).
 
@@ -106,7 +116,7 @@ def gat_layer(src, dst, n, feature, fc_w, attn_l, attn_r, slope=0.2, feat_keep=N
     ft = (h @ fc_w.t()).reshape(h.shape[0], H, -1)                                  # :83
     a1 = (ft * attn_l).sum(-1, keepdim=True)                                         # :84
     a2 = (ft * attn_r).sum(-1, keepdim=True)                                         # :85
-    e = F.leaky_relu(a1[src] + a2[dst], slope)                                       # :106-109
+    e = _leaky(a1[src] + a2[dst], slope, e_pos)                                      # :106-109 (e_pos: given branches, see _leaky)
     alpha = edge_softmax(dst, n, e)                                                  # :111-112
     a_drop = alpha if attn_keep is None else alpha * attn_keep * attn_scale          # :114
     out = scatter_sum(dst, n, ft[src] * a_drop)                                      # :95
@@ -135,11 +145,12 @@ def pgat_forward(params, graph, h, heads, num_layers, act_slope=0.01, attn_slope
         if positional:
             p = params[f"{prefix}prop_position_embeddings.{l}.weight"][pos]        # :214 / :218
             x = torch.cat((h, p), 1)                                                 # :215 / :219
-        mk = (masks[l] if masks is not None else None) or {}
+        mk = dict((masks[l] if masks is not None else None) or {})
+        act_pos = mk.pop("act_pos", None)                                            # (given branches of the activation below)
         out, pr = gat_layer(src, dst, n, x, w, al, ar, attn_slope, return_parts=True, **mk)
         parts.append(pr)
         if l < num_layers:
-            h = F.leaky_relu(out.flatten(1), act_slope)                              # :215-216
+            h = _leaky(out.flatten(1), act_slope, act_pos)                           # :215-216
         else:
             h = out.mean(1)                                                          # :219
     if return_parts:
@@ -158,7 +169,7 @@ def gcn_norm(dst, n, dtype=torch.float32):
     return norm.unsqueeze(1)
 
 
-def gcn_layer(src, dst, n, h, weight, bias, norm, act_slope=None, keep=None, keep_scale=1.0):
+def gcn_layer(src, dst, n, h, weight, bias, norm, act_slope=None, keep=None, keep_scale=1.0, act_pos=None):
     """GCNLayer.forward, model_zoo.py:34-50."""
     if keep is not None:
         h = h * keep * keep_scale                                                     # :35-36
@@ -169,7 +180,7 @@ def gcn_layer(src, dst, n, h, weight, bias, norm, act_slope=None, keep=None, kee
     if bias is not None:
         h = h + bias                                                                  # :47
     if act_slope is not None:
-        h = F.leaky_relu(h, act_slope)                                                # :49
+        h = _leaky(h, act_slope, act_pos)                                             # :49
     return h
 
 

@@ -8,7 +8,11 @@
   the unmodified model_zoo.GATLayer by oracle/gen_golden.py) against the buffers of the fused / folded stack: a compensating pair of
   errors inside the stack cannot hide behind correct final scores.
 Tolerance: 1e-4 relative on logits / hidden states (north star); gradients 2e-3 relative plus 2e-4 of the tensor's largest entry (they
-are sums over ~18,000 node rows in a different order than MKL's), see `_close` for the leaky_relu kinks."""
+are sums over ~18,000 node rows in a different order than MKL's) for EVERY entry: the oracle is handed the branch each leaky_relu
+took on the device (`_device_branches`), so both sides differentiate the same piecewise-linear function and no outlier allowance is
+needed;
+* BASELINE configs[2] at its size: every MAG-CS candidate's graph vector, the whole score matrix and the ranks against the oracle,
+  and a 30,000-egonet MAG-Full chunk."""
 import numpy as np
 import pytest
 import torch
@@ -33,24 +37,44 @@ def _dev():
     return torch.device("cuda:0")
 
 
-def _close(got, ref, rtol, atol_rel, msg, errors, kinks=0.0):
-    """|got - ref| <= rtol |ref| + atol_rel max|ref| + 2e-6.  kinks > 0 (gradients): up to that fraction of the entries -- or 64 of
-    them, one kink touches a whole row of a small tensor: a flipped attention logit moves all 500 entries of its head in attn_l /
-    attn_r -- may miss the bound by a factor 10, provided the whole tensor still agrees to 1e-3 in the 2-norm.  leaky_relu' is
-    discontinuous at 0, and an activation within rounding of 0 takes the other branch in another summation order (measured: the fp32
-    oracle itself differs from its float64 run by 1.9e-3 of the largest entry on one row of the middle layer's weight gradient of
-    the 2-layer model, exactly like the HIP path does); which entries sit on a kink depends on the dropout masks drawn."""
+def _close(got, ref, rtol, atol_rel, msg, errors):
+    """|got - ref| <= rtol |ref| + atol_rel max|ref| + 2e-6 for EVERY entry -- no allowance for outliers: the oracle differentiates
+    the same linear piece of every leaky_relu as the device did (`_device_branches`), so what is left is fp32 summation order."""
     got, ref = np.asarray(got, dtype=np.float64), np.asarray(ref, dtype=np.float64)
     assert got.shape == ref.shape, (msg, got.shape, ref.shape)
     diff = np.abs(got - ref)
     tol = rtol * np.abs(ref) + atol_rel * np.abs(ref).max() + 2e-6
     bad = diff > tol
-    very_bad = diff > 10 * tol
-    allowed = max(kinks * bad.size, 64.0) if kinks > 0 else 0.0
-    norm_ok = kinks == 0 or np.linalg.norm(diff) <= 1e-3 * np.linalg.norm(ref) + 2e-6 * np.sqrt(diff.size)
-    if bad.sum() > allowed or very_bad.any() or not norm_ok:
-        errors.append(f"{msg}: {int(bad.sum())} of {bad.size} entries off ({int(very_bad.sum())} by more than 10x), worst |diff| "
-                      f"{diff.max():.3e} (max |ref| {np.abs(ref).max():.3e})")
+    if bad.any():
+        errors.append(f"{msg}: {int(bad.sum())} of {bad.size} entries off, worst |diff| {diff.max():.3e} (max |ref| {np.abs(ref).max():.3e})")
+
+
+def _device_branches(kind, states, src, dst, masks):
+    """the branch every leaky_relu of the DEVICE forward pass took, added to the oracle's per-layer mask dicts (txe_oracle._leaky):
+    leaky_relu' jumps at 0, and a pre-activation within rounding of 0 lands on the other side in another summation order -- the fp32
+    oracle differs from its own float64 run by ~2e-3 of a tensor's largest entry on such rows.  With the branches given, both sides
+    differentiate the same piecewise-linear function and every gradient entry is held to the plain tolerance.
+      attention logits (model_zoo.py:106-109): z = a1[src] + a2[dst] from the projection's a1 / a2 columns (the folded output layer:
+        its a12 buffer) -- the same fp32 add the kernel does;
+      inter-layer activation (model_zoo.py:216 / :49): the sign of the activated row the layer wrote into the next layer's input
+        (entries the next layer's dropout zeroed carry no gradient either way)."""
+    L = len(states)
+    for l, st in enumerate(states):
+        if kind == "PGAT":
+            H, F_ = st.H, st.H * st.D
+            if l < L - 1:
+                a1, a2 = st.Y[:, F_:F_ + H].cpu().numpy(), st.Y[:, F_ + H:F_ + 2 * H].cpu().numpy()
+            else:
+                a12 = st.cl[0].cpu().numpy()
+                a1, a2 = a12[:, 0:1], a12[:, 1:2]
+            z = a1[src] + a2[dst]                                     # float32 + float32, like the kernels
+            masks[l]["e_pos"] = torch.from_numpy(z > 0).unsqueeze(-1)
+            width = F_
+        else:
+            width = st.Fo
+        if l < L - 1:
+            masks[l]["act_pos"] = (states[l + 1].X[:, :width] > 0).cpu()
+    return masks
 
 
 def _masks(kind, P, heads, num_layers, N, E, seed, eid_in, pf, pa):
@@ -90,7 +114,12 @@ def test_full_size_training_step_matches_oracle(workload, monkeypatch):
     monkeypatch.setattr(ops, "new_seed", lambda: seed)
     caps = {}
     model.readout.register_forward_hook(lambda m, i, o: caps.__setitem__("hg", o.detach()))
-    scores = model(g, x.to(dev), qf.to(dev))
+    with ops.debug_capture() as runs:
+        scores = model(g, x.to(dev), qf.to(dev))
+    assert len(runs) == 1
+    _csr_dev, _cfg, states = runs[0]
+    src_np, dst_np = np.asarray(g._src), np.asarray(g._dst)
+    branches = _device_branches("PGAT" if prop == "PGAT" else "PGCN", states, src_np, dst_np, [{} for _ in states])   # (before backward frees anything)
     loss = F.cross_entropy(scores.reshape(N_QUERIES, -1), torch.zeros(N_QUERIES, dtype=torch.long, device=dev), reduction="sum")
     loss.backward()
     torch.cuda.synchronize()
@@ -102,6 +131,8 @@ def test_full_size_training_step_matches_oracle(workload, monkeypatch):
     graph = dict(src=torch.from_numpy(np.asarray(g._src)).long(), dst=torch.from_numpy(np.asarray(g._dst)).long(), pos=pos.long(),
                  graph_off=csr.graph_off.long(), num_nodes=N)
     masks = _masks("PGAT" if prop == "PGAT" else "PGCN", P, heads, num_layers, N, E, seed, csr.eid_in.numpy(), 0.1, 0.1)
+    for mk, br in zip(masks, branches):
+        mk.update(br)
     s_ref, hg_ref, _ = orc.taxoexpan_forward(P, graph, x, qf, prop, readout, match, heads, num_layers, masks)
     l_ref = orc.info_nce_loss(s_ref, N_QUERIES)
     l_ref.backward()
@@ -111,7 +142,7 @@ def test_full_size_training_step_matches_oracle(workload, monkeypatch):
     _close(scores.detach().cpu().numpy(), s_ref.detach().numpy(), 1e-4, 2e-5, "scores", errors)
     np.testing.assert_allclose(loss.item(), l_ref.item(), rtol=1e-4)
     for k, p in model.named_parameters():
-        _close(p.grad.cpu().numpy(), P[k].grad.numpy(), 2e-3, 2e-4, "grad " + k, errors, kinks=1e-4)
+        _close(p.grad.cpu().numpy(), P[k].grad.numpy(), 2e-3, 2e-4, "grad " + k, errors)
     assert not errors, "\n".join(errors)
 
 

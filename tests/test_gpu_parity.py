@@ -533,7 +533,7 @@ def test_device_csr_build_equals_host_build():
 def test_full_size_properties_mag_cs_batch():
     """BASELINE.json configs[1] size (4,096 egonets, MAG dims): size-independent properties instead of an oracle run:
     attention rows sum to one per destination, bitwise repeatability (atomic-free reductions), linearity of the
-    aggregation in ft, and the InfoNCE step agrees with the oracle on a 64-egonet prefix."""
+    aggregation in ft.  (The oracle comparison of the whole step at this size lives in tests/test_gpu_full_size.py.)"""
     from taxoexpan_amd import _lib, synthetic as syn
     from taxoexpan_amd.ops import _empty
     tax = syn.make_named_taxonomy("mag_cs")

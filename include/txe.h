@@ -212,6 +212,11 @@ int txe_score_block(const float* Q, long long ld_q, int nq, const float* U, long
 int txe_score_count_block(const float* Q, long long ld_q, int nq, const float* U, long long ld_u, int G, int r, int apply_exp,
                           const int* pos_off, const float* thr, int larger_is_better, int* counts, void* stream);
 int txe_rank_finalize(const int* pos_off, int nq, const float* thr, const int* counts, int larger_is_better, int* ranks, void* stream);
+/* the thresholds themselves: Up [n_pos][r] = the candidate rows of the queries' true parents, query by query (gathered by the caller);
+ * thr[j] = match(Q[q], Up[j]) for j in [pos_off[q], pos_off[q+1]) -- the score kernel's own tiles (bit-identical values), but only the
+ * tiles along that staircase are computed and only those pairs are stored (test_fast.py:121-123 restricted to rearrange()'s positives) */
+int txe_score_positives(const float* Q, long long ld_q, int nq, const float* Up, long long ld_u, int n_pos, int r, int apply_exp,
+                        const int* pos_off, float* thr, void* stream);
 
 /* plain dense product on the fp32 MFMA GEMM (tests / micro-benchmarks).  layout 0: C = A[M][K] B[N][K]^T; 1: C = A[M][K] B[K][N];
  * 2: C = A[K][M]^T B[K][N].  splits > 1: `splits` partial products at C + z*M*ldc.  ws/ws_bytes (optional, txe_gemm_tail_ws_bytes):

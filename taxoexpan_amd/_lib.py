@@ -58,6 +58,7 @@ SIGNATURES = {
     "txe_bilinear_pair_bwd": (I, [P, L, P, L, I, I, I, P, I, P, P, P, P, L, P, L, P, P, SZ, P]),
     "txe_score_block": (I, [P, L, I, P, L, I, I, I, P, L, P, SZ, P]),
     "txe_score_count_block": (I, [P, L, I, P, L, I, I, I, P, P, I, P, P]),
+    "txe_score_positives": (I, [P, L, I, P, L, I, I, I, P, P, P]),
     "txe_rank_finalize": (I, [P, I, P, P, I, P, P]),
     "txe_gemm_tail_ws_bytes": (SZ, []),
     "txe_gemm_plain": (I, [I, P, L, P, L, P, L, I, I, I, I, P, SZ, P]),

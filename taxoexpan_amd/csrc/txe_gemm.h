@@ -88,6 +88,9 @@ struct Epi {
     long long split_stride;
     // count mode (fused ranking of the scoring loop): nothing is stored; for row m and each p in [cnt_off[m], cnt_off[m+1]):
     //   cnt_out[p] += #{ n < N : value(m, n) > cnt_thr[p] }  (cnt_mode 1)  /  < cnt_thr[p]  (cnt_mode 2)    -- int32 atomics, exact
+    // pick mode (cnt_mode 3; the thresholds of that ranking): column n belongs to the row m with cnt_off[m] <= n < cnt_off[m+1] (the
+    //   columns are the gathered true parents of the rows' queries, query by query); only c[n] = value(m, n) of those pairs is stored
+    //   and tiles that hold none of them return at once -- a staircase of ~(rows/128 + columns/BN) tiles instead of the whole product
     int cnt_mode;
     const int* cnt_off;
     const float* cnt_thr;
@@ -478,9 +481,13 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_kernel(VMat A, VMat B, c
 
     // count mode: this tile's rows' positive ranges and first thresholds are fetched NOW (two dependent loads), so that their
     // latency hides under the whole k-loop instead of sitting in the epilogue
+    if (E.cnt_mode == 3) {                           // pick mode: a tile without a (row, own column) pair has nothing to do (block-uniform)
+        const int lo = E.cnt_off[m0], hi = E.cnt_off[min(m0 + GEMM_BM, M)];
+        if (n0 >= hi || n0 + BN <= lo) return;
+    }
     int cnt_pb = 0, cnt_np = 0;
     float cnt_th[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    if (E.cnt_mode != 0 && threadIdx.x < GEMM_BM && m0 + (int)threadIdx.x < M) {
+    if ((E.cnt_mode == 1 || E.cnt_mode == 2) && threadIdx.x < GEMM_BM && m0 + (int)threadIdx.x < M) {
         cnt_pb = E.cnt_off[m0 + threadIdx.x];
         cnt_np = E.cnt_off[m0 + threadIdx.x + 1] - cnt_pb;
 #pragma unroll
@@ -622,6 +629,21 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_kernel(VMat A, VMat B, c
         for (int idx = threadIdx.x; idx < GEMM_BM * C4; idx += GEMM_THREADS) {
             const int row = idx / C4, c4 = idx % C4;
             *reinterpret_cast<float4*>(part + row * BN + c4 * 4) = *reinterpret_cast<const float4*>(Cs + row * CLD + c4 * 4);
+        }
+        return;
+    }
+    if (E.cnt_mode == 3) {                           // pick mode: store the rows' own columns only
+        for (int idx = threadIdx.x; idx < GEMM_BM * C4; idx += GEMM_THREADS) {
+            const int row = idx / C4, c4 = idx % C4;
+            const int m = m0 + row, mc = min(m, M - 1);
+            const int lo = E.cnt_off[mc], hi = E.cnt_off[mc + 1];
+            const float4 t4 = *reinterpret_cast<const float4*>(Cs + row * CLD + c4 * 4);
+            const float v4[4] = {t4.x, t4.y, t4.z, t4.w};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int n = n0 + c4 * 4 + q;
+                if (m < M && n >= lo && n < hi && n < N) E.c[n] = E.apply_exp ? __expf(v4[q]) : v4[q];
+            }
         }
         return;
     }

@@ -365,6 +365,25 @@ int txe_score_block(const float* Q, long long ld_q, int nq, const float* U, long
     return gemm_nt(A, B, E, nq, G, r, 1, (hipStream_t)stream, ok ? ws : nullptr, ok ? ws_bytes : 0);
 }
 
+// The thresholds of the fused ranking: thr[j] = match(Q[q], Up[j]) for j in [pos_off[q], pos_off[q+1]) -- Up [n_pos][r] holds the
+// candidate rows of the queries' true parents, query by query (gathered by the caller).  The same MFMA kernel and k order as
+// txe_score_block (bit-identical values), but only the tiles along the staircase {(q, j) : pos_off[q] <= j < pos_off[q+1]} are
+// computed and only those pairs are stored: ~(nq/128 + n_pos/128) tiles where the [nq x n_pos] product has their product.
+int txe_score_positives(const float* Q, long long ld_q, int nq, const float* Up, long long ld_u, int n_pos, int r, int apply_exp,
+                        const int* pos_off, float* thr, void* stream) {
+    if (nq < 0 || n_pos < 0 || r < 1 || ld_u < r || !Q || !Up || !pos_off || !thr) return TXE_ERR_ARG;
+    if (nq == 0 || n_pos == 0) return TXE_OK;
+    VMat A = vmat_plain(Q, ld_q, nq, r);
+    VMat B = vmat_plain(Up, ld_u, n_pos, r);
+    Epi E = epi_plain(thr, 0, n_pos);
+    E.apply_exp = apply_exp;
+    E.cnt_mode = 3;
+    E.cnt_off = pos_off;
+    E.plain_k_order = 1;
+    E.alg_flops = 2.0 * n_pos * (double)r;           // the pairs that are wanted
+    return gemm_nt(A, B, E, nq, n_pos, r, 1, (hipStream_t)stream);
+}
+
 // Fused scoring + ranking of one block of the loop: the score tile never leaves the workgroup.
 //   counts[j] += #{ g < G : match(Q[q], U[g]) strictly better than thr[j] }   for j in [pos_off[q], pos_off[q+1])
 // thr[j] = the score of query q's j-th true parent, computed by THIS library's score kernel (txe_score_block on the gathered

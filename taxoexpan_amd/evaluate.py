@@ -62,7 +62,7 @@ def _case_rows(dataset, queries, pos_off, ranks, top, metric_names):
     return rows
 
 
-def evaluate(model, dataset, device, larger_is_better=True, qblock=1024, seed=0, batch_size=-1, case=None, metric_names=CASE_METRICS,
+def evaluate(model, dataset, device, larger_is_better=True, qblock=None, seed=0, batch_size=-1, case=None, metric_names=CASE_METRICS,
              topk=5):
     """dataset: taxoexpan_amd.dataset.MaskedGraphDataset in 'validation' or 'test' mode.  Returns (metrics dict, ranks int32
     [n_positives], pos_off [Q+1], queries list).  Queries whose true parents are not candidate positions are skipped, like the
@@ -91,7 +91,7 @@ def evaluate(model, dataset, device, larger_is_better=True, qblock=1024, seed=0,
         ranks = rank_all_fused(model.match, hg, qf, pos_off, pos_idx, block=qblock, larger_is_better=larger_is_better)
         if case is not None:                                               # test_fast.py:112-147
             cand_ids = torch.as_tensor(np.asarray(cand, dtype=np.int64), device=device)
-            top = [topk_parents(S, cand_ids, topk, larger_is_better) for _q0, S in _score_blocks(model, hg, qf, qblock)]
+            top = [topk_parents(S, cand_ids, topk, larger_is_better) for _q0, S in _score_blocks(model, hg, qf, qblock or 1024)]
             top = torch.cat(top).cpu().tolist() if top else []
             rows = _case_rows(dataset, queries, pos_off, ranks, top, metric_names)
             if isinstance(case, list):

@@ -1203,15 +1203,43 @@ def positive_scores(Q, U, apply_exp, pos_off, pos_idx):
     return torch.where(local, thr, torch.zeros_like(thr)).contiguous()
 
 
-def score_count_block(Q, U, apply_exp, pos_off, thr, larger_is_better=True, counts=None):
+def pad_queries_like(Q, U):
+    """the query matrix zero-padded to U's k-tile pitch, ONCE for a whole scoring loop: blocks `Qp[q0:q1, :r]` of the result go to
+    score_count_block(..., q_padded=True) without being copied again.  Returns Q itself when U carries no padding."""
+    r = Q.shape[1]
+    rp = _padded_width(_rows(U)[0], r)
+    return _pad_queries(_rows(Q)[0], r, rp)[:, :r] if rp != r else Q
+
+
+def positive_scores_staircase(Q, Up, apply_exp, pos_off, out):
+    """out[j] = match(Q[q], Up[j]) for j in [pos_off[q], pos_off[q+1]): Up holds the candidate rows of the queries' true parents, query
+    by query.  The score kernel's own tiles (bit-identical values), only those along the staircase (txe_score_positives)."""
+    _need_cuda(Q, Up)
+    ldq = Q.stride(0)
+    Up, ldu = _rows(Up)
+    assert Q.stride(1) == 1 and out.dtype == torch.float32 and out.is_contiguous() and out.numel() >= Up.shape[0]
+    with torch.cuda.device(Q.device):
+        call("txe_score_positives", ptr(Q), ldq, Q.shape[0], ptr(Up), ldu, Up.shape[0], Q.shape[1], int(apply_exp), ptr(pos_off), ptr(out),
+             _lib.stream_ptr())
+    return out
+
+
+def score_count_block(Q, U, apply_exp, pos_off, thr, larger_is_better=True, counts=None, q_padded=False):
     """fused scoring + ranking of one query block against a candidate (shard) matrix U: int32 counts [n_pos] of candidates that beat
-    each positive's score thr[j] (txe_score_count_block; no [nq x G] score block is materialised)."""
+    each positive's score thr[j] (txe_score_count_block; no [nq x G] score block is materialised).
+    q_padded: Q is a row block of pad_queries_like(all queries, U) -- its columns up to U's padded width are zeros already."""
     _need_cuda(Q, U)
-    Q, ldq = _rows(Q)
+    if q_padded:
+        ldq = Q.stride(0)
+    else:
+        Q, ldq = _rows(Q)
     U, ldu = _rows(U)
     nq, r = Q.shape
     rp = _padded_width(U, r)
-    if rp != r and nq > 0:
+    if q_padded and rp != r and nq > 0:
+        assert ldq == rp and Q.stride(1) == 1, "q_padded: a row block of pad_queries_like()"
+        r = rp
+    elif rp != r and nq > 0:
         Q = _pad_queries(Q, r, rp)
         ldq, r = rp, rp
     elif ldq % 4 != 0 and nq > 0:
@@ -1224,18 +1252,19 @@ def score_count_block(Q, U, apply_exp, pos_off, thr, larger_is_better=True, coun
         counts = torch.zeros(max(int(thr.numel()), 1), dtype=torch.int32, device=Q.device)
     if thr.numel() == 0:                                # a query block without a single positive: nothing to count
         return counts
+    assert counts.dtype == torch.int32 and counts.is_contiguous() and counts.numel() >= thr.numel()
     with torch.cuda.device(Q.device):
         call("txe_score_count_block", ptr(Q), ldq, nq, ptr(U), ldu, U.shape[0], r, int(apply_exp), ptr(pos_off), ptr(thr),
              int(larger_is_better), ptr(counts), _lib.stream_ptr())
     return counts
 
 
-def rank_finalize(pos_off, thr, counts, larger_is_better=True):
-    """ranks (int32) from the fused counts: positives never count against each other (metric.py:7-31)"""
+def rank_finalize(pos_off, thr, counts, larger_is_better=True, out=None):
+    """ranks (int32) from the fused counts: positives never count against each other (metric.py:7-31).  out: int32 [>= n_pos]"""
     _need_cuda(thr)
     pos_off = _i32(pos_off, thr.device)
     n_pos = int(thr.numel())
-    ranks = torch.empty(max(n_pos, 1), dtype=torch.int32, device=thr.device)
+    ranks = out if out is not None else torch.empty(max(n_pos, 1), dtype=torch.int32, device=thr.device)
     if n_pos == 0:
         return ranks[:0]
     with torch.cuda.device(thr.device):

@@ -880,6 +880,11 @@ def test_fused_score_and_rank_equals_materialised_path(G, r, larger, exp):
     counts = ops.score_count_block(Q, U, exp, torch.from_numpy(pos_off), thr, larger)
     got = ops.rank_finalize(torch.from_numpy(pos_off), thr, counts, larger).cpu().tolist()
     assert got == want
+    # the thresholds through the staircase of tiles only (txe_score_positives): the same bits as the full block's entries
+    thr2 = torch.full((len(pos_idx) + 3,), float("nan"), device=dev)
+    off32 = torch.from_numpy(pos_off.astype(np.int32)).to(dev)
+    ops.positive_scores_staircase(Q, U.index_select(0, torch.from_numpy(pos_idx).to(dev)), exp, off32, thr2)
+    assert torch.equal(thr2[:len(pos_idx)], thr) and bool(torch.isnan(thr2[len(pos_idx):]).all())
 
     class M:                                                  # the loop over query blocks, with a bilinear matcher
         apply_exp = exp
@@ -887,6 +892,7 @@ def test_fused_score_and_rank_equals_materialised_path(G, r, larger, exp):
     M.W.weight = torch.eye(r, device=dev).reshape(1, r, r)   # identity bilinear: U = hg
     got2 = scoring.rank_all_fused(M, U, Q, pos_off, pos_idx, block=128, larger_is_better=larger).cpu().tolist()
     assert got2 == want
+    assert scoring.rank_all_fused(M, U, Q, pos_off, pos_idx, larger_is_better=larger).cpu().tolist() == want      # one block
 
 
 @pytest.mark.parametrize("prop", ["PGAT", "PGCN"])

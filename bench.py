@@ -97,11 +97,11 @@ def build_batches(tax, n_batches, seed0, device):
     return out
 
 
-def fresh_batch(tax, dtax, seed, device):
+def fresh_batch(tax, dtax, seed, device, stream=None):
     """a NEW training batch built inside the step, as a train.py epoch does for every step (data_loaders.py:9-28 + dataset.py:404-437):
-    anchors sampled on the host (the reference's sampler is host Python too), egonets + both CSR views + the feature gather on the
-    device (graph.device_egonet_batch: one host sync for the array sizes)"""
-    from taxoexpan_amd import graph as G
+    anchors sampled on the host (the reference's sampler is host Python too), egonets + both CSR views + the feature gathers on the
+    device (data_loaders.build_device_batch; on `stream` the construction's one host sync does not wait for the running step)"""
+    from taxoexpan_amd.data_loaders import build_device_batch
     rs = np.random.RandomState(seed)
     has_par = _HAS_PAR.setdefault(id(tax), np.nonzero(np.diff(tax.par_ptr) > 0)[0])
     queries = rs.choice(has_par, size=N_QUERIES, replace=len(has_par) < N_QUERIES)
@@ -111,10 +111,8 @@ def fresh_batch(tax, dtax, seed, device):
     anchors = np.concatenate([pos_parent[:, None], negs], 1).reshape(-1)
     exclude = np.full((N_QUERIES, 1 + NEG), -1, dtype=np.int64)
     exclude[:, 0] = queries
-    g = G.device_egonet_batch(dtax, anchors, exclude.reshape(-1), expand_factor=50, seed=seed + 1, with_features=True)
-    x = g.ndata.pop("x")
-    qid = torch.from_numpy(np.repeat(queries, 1 + NEG)).to(device)
-    return dict(g=g, x=x, pos=g.ndata["pos"], qf=dtax.features.index_select(0, qid), n_nodes=g.number_of_nodes(), n_edges=g.number_of_edges())
+    return build_device_batch(dtax, anchors, exclude.reshape(-1), np.repeat(queries, 1 + NEG), dtax.features, expand_factor=50, seed=seed + 1,
+                              stream=stream)
 
 
 _HAS_PAR = {}
@@ -612,13 +610,14 @@ def main():
     from taxoexpan_amd import graph as Gr
     dtax = Gr.DeviceTaxonomy(tax.par_ptr, tax.par_idx, tax.chd_ptr, tax.chd_idx, tax.features, device)
     n_fresh = min(args.steps, 20)
+    build_stream = torch.cuda.Stream(device=device)      # the batch of step i+1 is built while step i runs (data_loaders.DeviceBatchLoader)
     for i in range(3):
-        train_step(model, opt, fresh_batch(tax, dtax, 5000 + i, device), target, world)
+        train_step(model, opt, fresh_batch(tax, dtax, 5000 + i, device, build_stream), target, world)
     torch.cuda.synchronize()
     tf0 = time.perf_counter()
     fresh_edges = 0
     for i in range(n_fresh):
-        b = fresh_batch(tax, dtax, 6000 + 17 * i + rank, device)
+        b = fresh_batch(tax, dtax, 6000 + 17 * i + rank, device, build_stream)
         train_step(model, opt, b, target, world)
         fresh_edges += b["n_edges"]
     torch.cuda.synchronize()

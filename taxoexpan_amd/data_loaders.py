@@ -97,3 +97,64 @@ class MaskedGraphDataLoader(torch.utils.data.DataLoader):
                             f"batch_size: {self.batch_size_}", f"negative_size: {self.negative_size}",
                             f"expand_factor: {self.expand_factor}", f"cache_refresh_time: {self.cache_refresh_time}",
                             f"normalize_embed: {self.normalize_embed}"])
+
+
+def build_device_batch(dtax, anchors, exclude, query_ids, features, expand_factor=50, seed=0, stream=None):
+    """One training batch built ON the device (data_loaders.py:9-28 + dataset.py:404-437 without host egonet objects):
+    graph.device_egonet_batch for the anchors, node features and query features gathered from the resident table.
+    stream: build on that side stream -- the one host synchronisation of the construction (the array sizes) then waits for the
+    builder's own few microseconds of work only, not for the training step still running on the caller's stream; the caller's stream
+    is made to wait for the finished batch, and every tensor of the batch is marked as used on it (caching-allocator safety).
+    Returns dict(g, x, pos, qf, n_nodes, n_edges)."""
+    from .graph import device_egonet_batch
+    dev = dtax.device
+    main = torch.cuda.current_stream(dev)
+    side = stream if stream is not None else main
+    if side is not main:
+        side.wait_stream(main)              # (the taxonomy / feature table may have been written on the caller's stream)
+    with torch.cuda.stream(side):
+        g = device_egonet_batch(dtax, anchors, exclude, expand_factor=expand_factor, seed=seed, with_features=True)
+        x = g.ndata.pop("x")
+        qid = torch.as_tensor(query_ids, dtype=torch.int64).to(dev, non_blocking=True)
+        qf = features.index_select(0, qid)
+    if side is not main:
+        main.wait_stream(side)
+        csr = g.csr(dev)
+        for t in (x, qf, g.ndata["_id"], g.ndata["pos"], csr.rowptr_in, csr.col_src, csr.eid_in, csr.rowptr_out, csr.col_dst, csr.pos_out,
+                  csr.graph_off):
+            t.record_stream(main)
+    return dict(g=g, x=x, pos=g.ndata["pos"], qf=qf, n_nodes=g.number_of_nodes(), n_edges=g.number_of_edges())
+
+
+class DeviceBatchLoader:
+    """`for batch in loader` over a MaskedGraphDataset in 'train' / 'validation' mode with the batches built on the GPU: the sampler
+    (dataset.sample_anchors: the reference's positive pointer and negative sampling, host Python like data_loader/dataset.py:334-381)
+    hands anchors to build_device_batch.  Each batch is built inside `next()` on a side stream, i.e. AFTER the consumer has enqueued
+    the previous step and while that step runs: with a GPU-bound step the construction (0.3-0.6 ms of host time, one host sync on the
+    side stream) disappears behind it.  Yields (graph, node features, query features, labels) -- MaskedGraphDataLoader's small-batch
+    tuple with the node features popped, all on `device`."""
+
+    def __init__(self, dataset, batch_size, device, shuffle=True, seed=0, drop_last=False):
+        self.dataset, self.batch_size, self.device = dataset, int(batch_size), torch.device(device)
+        self.shuffle, self.seed, self.drop_last = shuffle, int(seed), drop_last
+        self.dtax = dataset.device_taxonomy(self.device)
+        self.features = self.dtax.features
+        self._side = torch.cuda.Stream(device=self.device)
+        self._epoch = 0
+
+    def __len__(self):
+        n = len(self.dataset)
+        return n // self.batch_size if self.drop_last else -(-n // self.batch_size)
+
+    def __iter__(self):
+        import random
+        order = list(range(len(self.dataset)))
+        if self.shuffle:
+            random.Random(self.seed + self._epoch).shuffle(order)
+        self._epoch += 1
+        for b in range(len(self)):
+            idx = order[b * self.batch_size:(b + 1) * self.batch_size]
+            query, anchor, label, exclude = self.dataset.sample_anchors(idx)
+            batch = build_device_batch(self.dtax, anchor, exclude, query, self.features, expand_factor=self.dataset.expand_factor,
+                                       seed=self.seed + 7919 * self._epoch + b, stream=self._side)
+            yield batch["g"], batch["x"], batch["qf"], torch.as_tensor(label).to(self.device, non_blocking=True)

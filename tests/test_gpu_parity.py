@@ -1029,6 +1029,71 @@ def test_training_on_raw_files_with_device_batches_converges():
     assert np.isfinite(after["macro_mr"]) and after["n_queries"] == before["n_queries"] > 0
 
 
+def test_device_batch_loader_builds_on_a_side_stream_what_the_inline_builder_builds():
+    """data_loaders.DeviceBatchLoader (train.py's `for batch in data_loader`, batches built on the GPU inside next() on a side
+    stream while the previous step runs): every batch equals the in-line construction from the same sampled anchors -- ids, pos, both
+    CSR views, node and query features, labels -- also while the caller's stream is kept busy, and a step can consume it at once"""
+    import os
+    import random
+    import shutil
+    import tempfile
+    from taxoexpan_amd import TaxoExpan
+    from taxoexpan_amd import graph as G
+    from taxoexpan_amd.data_loaders import DeviceBatchLoader
+    from taxoexpan_amd.dataset import MAGDataset, MaskedGraphDataset
+    dev = _dev()
+    d = tempfile.mkdtemp(dir=os.environ.get("TMPDIR", None))
+    try:
+        for fn in os.listdir(os.path.join(GOLDEN_DIR, "toy_taxo")):
+            shutil.copy(os.path.join(GOLDEN_DIR, "toy_taxo", fn), d)
+        sets = []
+        for _ in range(2):                                          # two datasets in the same sampler state
+            random.seed(0)
+            sets.append(MaskedGraphDataset(MAGDataset("toy", d, raw=True), mode="train", sampling_mode=1, negative_size=7, expand_factor=5,
+                                           normalize_embed=True))
+    finally:
+        shutil.rmtree(d)
+    ds_a, ds_b = sets
+    torch.manual_seed(0)
+    model = TaxoExpan("PGAT", "WMR", "LBM", in_dim=8, hidden_dim=16, out_dim=16, pos_dim=4, num_layers=1, heads=[2, 1], feat_drop=0.1,
+                      attn_drop=0.1, hidden_drop=0.1, out_drop=0.1).to(dev).eval()
+    loader = DeviceBatchLoader(ds_a, 16, dev, shuffle=True, seed=3)
+    assert len(loader) == -(-len(ds_a) // 16)
+    busy = torch.randn(2048, 2048, device=dev)
+    host = lambda t: t.cpu().numpy().copy()
+    got = []
+    random.seed(1)
+    for b, (g, x, qf, labels) in enumerate(loader):
+        if b == 4:
+            break
+        busy = (busy @ busy) * 1e-3                                 # the caller's stream has work queued while next() builds
+        pos = g.ndata["pos"]
+        with torch.no_grad():
+            pred = model(g, x, qf)                                  # consumable at once: the caller's stream waits for the build
+        csr = g.csr(dev)
+        got.append(dict(ids=host(g.ndata["_id"]), pos=host(pos), x=host(x), qf=host(qf), labels=host(labels), pred=host(pred),
+                        csr=[host(t) for t in (csr.rowptr_in, csr.col_src, csr.eid_in, csr.rowptr_out, csr.col_dst, csr.pos_out, csr.graph_off)]))
+    assert len(got) == 4
+    # the same four batches in line on the caller's stream, from the twin dataset
+    order = list(range(len(ds_b)))
+    random.Random(3).shuffle(order)
+    dtax = ds_b.device_taxonomy(dev)
+    random.seed(1)
+    for b, want in enumerate(got):
+        query, anchor, label, exclude = ds_b.sample_anchors(order[b * 16:(b + 1) * 16])
+        g = G.device_egonet_batch(dtax, anchor, exclude=exclude, expand_factor=ds_b.expand_factor, seed=3 + 7919 + b)
+        csr = g.csr(dev)
+        assert np.array_equal(host(g.ndata["_id"]), want["ids"]) and np.array_equal(host(g.ndata["pos"]), want["pos"])
+        for t, w in zip((csr.rowptr_in, csr.col_src, csr.eid_in, csr.rowptr_out, csr.col_dst, csr.pos_out, csr.graph_off), want["csr"]):
+            assert np.array_equal(host(t), w)
+        x = g.ndata.pop("x")
+        qf = dtax.features.index_select(0, torch.from_numpy(query).to(dev))
+        assert np.array_equal(host(x), want["x"]) and np.array_equal(host(qf), want["qf"]) and np.array_equal(label, want["labels"])
+        with torch.no_grad():
+            assert np.array_equal(host(model(g, x, qf)), want["pred"])
+        assert np.isfinite(want["pred"]).all() and want["labels"].reshape(16, 8)[:, 0].tolist() == [1] * 16
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("amsgrad,wd", [(True, 0.0), (False, 0.0), (True, 0.01)])
 def test_adam_step_equals_torch_adam(amsgrad, wd):

@@ -102,9 +102,9 @@ def fresh_batch(tax, dtax, seed, device, stream=None):
     anchors sampled on the host (the reference's sampler is host Python too), egonets + both CSR views + the feature gathers on the
     device (data_loaders.build_device_batch; on `stream` the construction's one host sync does not wait for the running step)"""
     from taxoexpan_amd.data_loaders import build_device_batch
-    rs = np.random.RandomState(seed)
+    rs = _RNG.setdefault("rs", np.random.RandomState(4711))             # (one generator for the run: seeding one costs 0.1 ms)
     has_par = _HAS_PAR.setdefault(id(tax), np.nonzero(np.diff(tax.par_ptr) > 0)[0])
-    queries = rs.choice(has_par, size=N_QUERIES, replace=len(has_par) < N_QUERIES)
+    queries = has_par[rs.randint(0, len(has_par), size=N_QUERIES)]
     span = tax.par_ptr[queries + 1] - tax.par_ptr[queries]
     pos_parent = tax.par_idx[tax.par_ptr[queries] + (rs.uniform(size=N_QUERIES) * span).astype(np.int64)]
     negs = rs.randint(0, tax.n_nodes, size=(N_QUERIES, NEG))
@@ -116,6 +116,7 @@ def fresh_batch(tax, dtax, seed, device, stream=None):
 
 
 _HAS_PAR = {}
+_RNG = {}
 SECOND_STREAM_TAG = " [second stream]"
 
 
@@ -611,6 +612,7 @@ def main():
     dtax = Gr.DeviceTaxonomy(tax.par_ptr, tax.par_idx, tax.chd_ptr, tax.chd_idx, tax.features, device)
     n_fresh = min(args.steps, 20)
     build_stream = torch.cuda.Stream(device=device)      # the batch of step i+1 is built while step i runs (data_loaders.DeviceBatchLoader)
+    torch.cuda.synchronize()                             # (the resident taxonomy is complete before the side stream reads it)
     for i in range(3):
         train_step(model, opt, fresh_batch(tax, dtax, 5000 + i, device, build_stream), target, world)
     torch.cuda.synchronize()

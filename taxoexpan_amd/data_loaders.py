@@ -99,6 +99,9 @@ class MaskedGraphDataLoader(torch.utils.data.DataLoader):
                             f"normalize_embed: {self.normalize_embed}"])
 
 
+_PINNED = {}
+
+
 def build_device_batch(dtax, anchors, exclude, query_ids, features, expand_factor=50, seed=0, stream=None):
     """One training batch built ON the device (data_loaders.py:9-28 + dataset.py:404-437 without host egonet objects):
     graph.device_egonet_batch for the anchors, node features and query features gathered from the resident table.
@@ -110,13 +113,25 @@ def build_device_batch(dtax, anchors, exclude, query_ids, features, expand_facto
     dev = dtax.device
     main = torch.cuda.current_stream(dev)
     side = stream if stream is not None else main
-    if side is not main:
-        side.wait_stream(main)              # (the taxonomy / feature table may have been written on the caller's stream)
+    # (the side stream does NOT wait for the caller's stream -- that would put the construction behind the running step again: the
+    #  taxonomy arrays and the feature table must be complete before the first call; DeviceBatchLoader synchronises once when it is made)
+    # the three index arrays travel in ONE pinned buffer and one copy (each small pageable upload costs ~60 us of host time)
+    import numpy as np
+    B = len(anchors)
+    host = _PINNED.get(3 * B)               # (re-used: device_egonet_batch's size read-back below synchronises `side` behind the copy)
+    if host is None:
+        host = _PINNED[3 * B] = torch.empty(3 * B, dtype=torch.int32).pin_memory()
+    hv = host.numpy()
+    hv[:B] = anchors
+    hv[B:2 * B] = exclude if exclude is not None else -1
+    hv[2 * B:] = query_ids
     with torch.cuda.stream(side):
-        g = device_egonet_batch(dtax, anchors, exclude, expand_factor=expand_factor, seed=seed, with_features=True)
+        packed = host.to(dev, non_blocking=True)
+        g = device_egonet_batch(dtax, packed[:B], packed[B:2 * B] if exclude is not None else None, expand_factor=expand_factor, seed=seed,
+                                with_features=True)
         x = g.ndata.pop("x")
-        qid = torch.as_tensor(query_ids, dtype=torch.int64).to(dev, non_blocking=True)
-        qf = features.index_select(0, qid)
+        qf = features.index_select(0, packed[2 * B:])
+        packed.record_stream(side)
     if side is not main:
         main.wait_stream(side)
         csr = g.csr(dev)
@@ -140,6 +155,7 @@ class DeviceBatchLoader:
         self.dtax = dataset.device_taxonomy(self.device)
         self.features = self.dtax.features
         self._side = torch.cuda.Stream(device=self.device)
+        torch.cuda.current_stream(self.device).synchronize()      # the resident taxonomy / feature table are complete from here on
         self._epoch = 0
 
     def __len__(self):

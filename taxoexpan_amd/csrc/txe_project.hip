@@ -490,7 +490,7 @@ struct DenseWs {
     size_t total;
 };
 
-static DenseWs plan_dense_ws(void* ws, int n, int Fp, int H2, int Kp, int Pd, int vocab) {
+static DenseWs plan_dense_ws(void* ws, int n, int Fp, int H2, int Kp, int Pd, int vocab, bool dx_stream = true) {
     DenseWs p;
     char* b = (char*)ws;
     size_t off = 0;
@@ -502,7 +502,7 @@ static DenseWs plan_dense_ws(void* ws, int n, int Fp, int H2, int Kp, int Pd, in
     // (sized for the streaming d_X kernel's 16-row workgroups, which write these partial sums themselves)
     const int ppart_blocks = dxpos_blocks(n) > p.seg_blocks ? dxpos_blocks(n) : p.seg_blocks;
     p.ppart = take((size_t)ppart_blocks * (vocab > 0 ? vocab : 1) * (Pd > 0 ? Pd : 1) * 4);
-    p.dxpart = take(Pd > 0 ? dxpos_part_bytes(n, Fp) : 0);
+    p.dxpart = take((Pd > 0 && dx_stream) ? dxpos_part_bytes(n, Fp) : 0);
     p.splits = choose_splits(Fp, Kp, n);
     p.part = take((size_t)p.splits * Fp * Kp * 4);
     p.tail_bytes = gemm_tail_ws_bytes();
@@ -851,7 +851,7 @@ int txe_gcn_pack_weights(const float* W, int Kt, int Fo, float* Wp, void* stream
 }
 
 size_t txe_gcn_dense_ws_bytes(int n_nodes, int Kh, int Pd, int Fo, int vocab) {
-    return plan_dense_ws(nullptr, n_nodes, round_up(Kh + Pd, 32), 0, round_up(Fo, 32), Pd, vocab).total;
+    return plan_dense_ws(nullptr, n_nodes, round_up(Kh + Pd, 32), 0, round_up(Fo, 32), Pd, vocab, false).total;
 }
 
 int txe_gcn_dense_fwd(const float* X, int n_nodes, int Kh, int Pd, const float* Wp, int Fo, float drop_p, const unsigned* mask,
@@ -891,7 +891,7 @@ int txe_gcn_dense_bwd(const float* X, int n_nodes, int Kh, int Pd, const int* po
     if (Pd > 0 && (!pos || !dP || vocab < 1 || vocab > MAX_VOCAB)) return TXE_ERR_ARG;
     if (drop_p < 0.f || drop_p >= 1.f) return TXE_ERR_ARG;
     const int Kt = Kh + Pd, Kp = round_up(Kt, 32), Fop = round_up(Fo, 32);
-    DenseWs p = plan_dense_ws(ws, n_nodes, Kp, 0, Fop, Pd, vocab);          // part: [S][Kp][Fop]
+    DenseWs p = plan_dense_ws(ws, n_nodes, Kp, 0, Fop, Pd, vocab, false);   // part: [S][Kp][Fop]
     if (ws_bytes < p.total) return TXE_ERR_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
     int rc;

@@ -318,13 +318,41 @@ class overlapped_gradient_allreduce:
         self.reduced, self._pending = set(), []
         self.plan = gradient_bucket_plan(model, min_layer) if model is not None else None
         self._fired = set()
+        # the matcher's parameters (model.py:86) get their gradients FIRST in backward: their bucket goes out from a
+        # post-accumulate hook and rides under the whole encoder backward (with the plan: rank-invariant, like the layer buckets)
+        match = getattr(model, "match", None) if model is not None else None
+        self._early = [p for p in match.parameters() if p.requires_grad] if match is not None else []
+        self._early_done, self._hooks = False, []
 
     def __enter__(self):
         self._prev = (ops._GRAD_READY, ops._GRAD_FLUSH)
         ops._GRAD_READY, ops._GRAD_FLUSH = self._ready, self._flush
+        if self._early:
+            left = {id(p) for p in self._early}
+
+            def hook(p):
+                left.discard(id(p))
+                if not left and not self._early_done:        # the last of the matcher's gradients has been accumulated
+                    self._reduce_early()
+            self._hooks = [p.register_post_accumulate_grad_hook(hook) for p in self._early]
         return self
 
+    def _reduce_early(self):
+        self._early_done = True
+        grads = [(p.grad if p.grad is not None else torch.zeros_like(p)) for p in self._early]
+        for p, g in zip(self._early, grads):
+            if p.grad is None:
+                p.grad = g
+        flat = torch.cat([g.reshape(-1) for g in grads])
+        work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self._pending.append((work, flat, grads, [id(p) for p in self._early]))
+
     def __exit__(self, *exc):
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
+        if self._early and not self._early_done and exc[0] is None:
+            self._reduce_early()                             # (a rank without a loss term: zeros, FIRST like on its peers)
         self._flush()
         ops._GRAD_READY, ops._GRAD_FLUSH = self._prev
         if self.plan is not None and exc[0] is None:

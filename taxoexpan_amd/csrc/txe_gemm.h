@@ -1001,7 +1001,14 @@ static inline bool bn160_enabled() {
     return v == 1;
 }
 
+static inline bool bn160_forced() {          // test switch: every eligible split-K product on 128 x 160 tiles, whatever its size
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("TXE_FORCE_BN160"); v = (e && e[0] == '1') ? 1 : 0; }
+    return v == 1;
+}
+
 static inline int choose_bn(int M, int N, int splits, bool tail_split = false, int K = 0, bool allow160 = false) {
+    if (allow160 && splits > 1 && bn160_forced()) return 160;
     if (N <= 64) return 64;
     const int slots = 2 * device_cu_count();
     if (allow160 && splits > 1 && bn160_enabled() && bn160_split_enabled() && 2.0 * M * (double)N * K >= bn160_split_min_flops()) {
@@ -1074,6 +1081,10 @@ static inline void gemm_launch_v(int bn, dim3 grid, hipStream_t stream, const VM
 static inline size_t gemm_tail_ws_bytes() {       // (+ the persistent kernel's dummy words in front of its slices' partial tiles)
     return (size_t)2 * device_cu_count() * (GEMM_BM * 128 + GEMM_THREADS) * sizeof(float);
 }
+
+// txe_gemm_tn.hip: the split-K TN product on 128 x 160 tiles with LDS-direct operand copies (txe_gemm_tnlds.h); TXE_ERR_ARG = not
+// eligible (the caller falls through to gemm_kernel)
+int gemm_tn_lds_launch(const VMat& A, const VMat& B, const Epi& E, int M, int N, int K, int splits, int ksplit, hipStream_t stream);
 
 template <bool AK, bool BKC>
 static inline int gemm_launch_layout(const VMat& A, const VMat& B, const Epi& E_in, int M, int N, int K, int splits,
@@ -1171,6 +1182,12 @@ static inline int gemm_launch_layout(const VMat& A, const VMat& B, const Epi& E_
             T.nfull = tiles - r; T.S = S;
             T.ksplit = ((nkt + S - 1) / S) * GEMM_BK;
             grid = dim3(T.nfull + r * S, 1);
+        }
+    }
+    if constexpr (!AK && !BKC) {
+        if (bn == 160 && splits > 1 && va == 4 && vb == 4 && tile0 == 0 && T.S == 0) {
+            const int rc = gemm_tn_lds_launch(A, B, E, M, N, K, splits, ksplit, stream);
+            if (rc != TXE_ERR_ARG) return rc;
         }
     }
     if (va == 4 && vb == 4) gemm_launch_v<AK, BKC, 4, 4>(bn, grid, stream, A, B, E, M, N, K, ksplit, T);

@@ -2,6 +2,8 @@
 the unmodified reference and (b) the CPU oracle on the same seeded inputs.  Tolerance: BASELINE.json's north star asks
 logits / ranking within 1e-4 fp32; gradients are checked at 2e-3 relative (they pass through two more GEMMs whose
 summation order differs from MKL's) with a small absolute floor."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -417,6 +419,42 @@ def test_gemm_split_k_on_160_wide_tiles_against_fp64():
     got = C.view(S, M, N).double().sum(0).cpu().numpy()
     ref = A.cpu().numpy().astype(np.float64).T @ B.cpu().numpy().astype(np.float64)
     np.testing.assert_allclose(got, ref, rtol=1e-4, atol=1e-4 * np.sqrt(K))
+
+
+@pytest.mark.parametrize("M,N,K,S", [(2048, 320, 17877, 16), (1024, 2080, 6016, 4), (300, 316, 1000, 3), (128, 160, 40, 2), (132, 8, 33, 2),
+                                     (2048, 320, 64, 2)])
+def test_split_k_tn_product_with_lds_direct_copies(M, N, K, S, tmp_path):
+    """gemm_tn_lds_kernel (txe_gemm_tnlds.h: operand tiles copied global -> LDS directly, permuted B fragments, vector stores from the
+    accumulators) -- the first layer's weight-gradient shape with its ragged last k-tile per slice, widths that are no multiple of
+    the 128 x 160 tile (clamped column vectors, partial stores), slices of one and two k-tiles -- against float64, and BIT FOR BIT
+    against gemm_kernel<false,false,4,4,160>'s partial slices (TXE_NO_TN_LDS=1: the same k order per element).  Both run in
+    subprocesses with TXE_FORCE_BN160=1 so that every shape takes the 160-wide route."""
+    import subprocess
+    import sys
+    rs = np.random.RandomState(M + N)
+    lda, ldb, ldc = (M + 3) // 4 * 4 + 4, (N + 3) // 4 * 4, (N + 3) // 4 * 4
+    A = rs.standard_normal((K, lda)).astype(np.float32)
+    B = rs.standard_normal((K, ldb)).astype(np.float32)
+    d = str(tmp_path)
+    np.save(os.path.join(d, "A.npy"), A)
+    np.save(os.path.join(d, "B.npy"), B)
+    code = ("import numpy as np, torch, sys; sys.path.insert(0, %r); from taxoexpan_amd import _lib; d = %r; "
+            "A = torch.from_numpy(np.load(d + '/A.npy')).cuda(); B = torch.from_numpy(np.load(d + '/B.npy')).cuda(); "
+            "C = torch.full((%d, %d), float('nan'), device='cuda'); "
+            "_lib.call('txe_gemm_plain', 2, A.data_ptr(), %d, B.data_ptr(), %d, C.data_ptr(), %d, %d, %d, %d, %d, None, 0, _lib.stream_ptr()); "
+            "torch.cuda.synchronize(); np.save(d + '/C' + sys.argv[1] + '.npy', C.cpu().numpy())") % (
+                os.path.dirname(os.path.dirname(os.path.abspath(__file__))), d, S * M, ldc, lda, ldb, ldc, M, N, K, S)
+    outs = {}
+    for tag, extra in (("lds", {}), ("old", {"TXE_NO_TN_LDS": "1"})):
+        r = subprocess.run([sys.executable, "-c", code, tag], env=dict(os.environ, TXE_FORCE_BN160="1", **extra), capture_output=True, text=True,
+                           timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs[tag] = np.load(os.path.join(d, f"C{tag}.npy")).reshape(S, M, ldc)
+    got = outs["lds"]
+    assert np.isfinite(got[:, :, :N]).all() and (ldc == N or np.isnan(got[:, :, N:]).all())
+    ref = A.astype(np.float64)[:, :M].T @ B.astype(np.float64)[:, :N]
+    np.testing.assert_allclose(got[:, :, :N].astype(np.float64).sum(0), ref, rtol=1e-4, atol=1e-4 * np.sqrt(K))
+    assert np.array_equal(outs["old"][:, :, :N], got[:, :, :N])
 
 
 def test_readout_and_match_ops_against_oracle():

@@ -29,7 +29,9 @@ WORKLOADS = {      # bench.py --workload name -> (propagation, readout, match, n
     "pgat": ("PGAT", "WMR", "LBM", 1, [4, 1]),
     "pgcn": ("PGCN", "MR", "BIM", 1, None),
     "pgat2": ("PGAT", "WMR", "LBM", 2, [4, 4, 1]),
+    "semeval": ("PGAT", "WMR", "LBM", 1, [4, 1]),      # BASELINE configs[0]: config.wordnet.json's dimensions on the SemEval-Noun shape
 }
+SEMEVAL = dict(in_dim=300, hidden_dim=600, out_dim=300, pos_dim=50, feat_drop=0.1, attn_drop=0.1, hidden_drop=0.1, out_drop=0.1)
 N_QUERIES, NEG = 128, 31
 
 
@@ -97,19 +99,23 @@ def _masks(kind, P, heads, num_layers, N, E, seed, eid_in, pf, pa):
     return out
 
 
-@pytest.mark.parametrize("workload", ["pgat", "pgcn", "pgat2"])
+@pytest.mark.parametrize("workload", ["pgat", "pgcn", "pgat2", "semeval"])
 def test_full_size_training_step_matches_oracle(workload, monkeypatch):
     from taxoexpan_amd import TaxoExpan, ops, synthetic as syn
     prop, readout, match, num_layers, heads = WORKLOADS[workload]
     dev = _dev()
-    # (bench.py times `pgat2` -- BASELINE configs[3] -- on the MAG-Full-shaped taxonomy, the other two on the MAG-CS one)
-    tax = syn.make_named_taxonomy("mag_full" if workload == "pgat2" else "mag_cs", seed=47)
-    g, qf, _labels = syn.training_batch(tax, N_QUERIES, NEG, seed=1000)          # batch 0 of bench.py's rank 0
-    assert g.batch_size == 4096
+    # (bench.py times `pgat2` -- BASELINE configs[3] -- on the MAG-Full-shaped taxonomy, `pgat` / `pgcn` on the MAG-CS one; `semeval` is
+    #  configs[0]'s shape: 64 queries x 32 = 2,048 egonets, d = 300 -- its 350-column layer input ends 2 columns short of the padded row,
+    #  so the streaming d_X kernel's weight slab runs past it: clamped column vectors)
+    dims = SEMEVAL if workload == "semeval" else MAG
+    n_queries = 64 if workload == "semeval" else N_QUERIES
+    tax = syn.make_named_taxonomy({"pgat2": "mag_full", "semeval": "semeval_noun"}.get(workload, "mag_cs"), seed=47)
+    g, qf, _labels = syn.training_batch(tax, n_queries, NEG, seed=1000)          # batch 0 of bench.py's rank 0
+    assert g.batch_size == n_queries * 32
     x = g.ndata.pop("x")
     pos = g.ndata["pos"].clone()
     torch.manual_seed(47)
-    model = TaxoExpan(prop, readout, match, **dict(MAG, num_layers=num_layers, heads=heads)).to(dev).train()
+    model = TaxoExpan(prop, readout, match, **dict(dims, num_layers=num_layers, heads=heads)).to(dev).train()
     seed = 987654321
     monkeypatch.setattr(ops, "new_seed", lambda: seed)
     caps = {}
@@ -120,11 +126,11 @@ def test_full_size_training_step_matches_oracle(workload, monkeypatch):
     _csr_dev, _cfg, states = runs[0]
     src_np, dst_np = np.asarray(g._src), np.asarray(g._dst)
     branches = _device_branches("PGAT" if prop == "PGAT" else "PGCN", states, src_np, dst_np, [{} for _ in states])   # (before backward frees anything)
-    loss = F.cross_entropy(scores.reshape(N_QUERIES, -1), torch.zeros(N_QUERIES, dtype=torch.long, device=dev), reduction="sum")
+    loss = F.cross_entropy(scores.reshape(n_queries, -1), torch.zeros(n_queries, dtype=torch.long, device=dev), reduction="sum")
     loss.backward()
     torch.cuda.synchronize()
 
-    # ---- the oracle on the same 4,096 egonets, same parameters, same masks ----
+    # ---- the oracle on the same egonets, same parameters, same masks ----
     csr = g.csr("cpu")
     N, E = csr.n_nodes, csr.n_edges
     P = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in model.state_dict().items()}
@@ -134,7 +140,7 @@ def test_full_size_training_step_matches_oracle(workload, monkeypatch):
     for mk, br in zip(masks, branches):
         mk.update(br)
     s_ref, hg_ref, _ = orc.taxoexpan_forward(P, graph, x, qf, prop, readout, match, heads, num_layers, masks)
-    l_ref = orc.info_nce_loss(s_ref, N_QUERIES)
+    l_ref = orc.info_nce_loss(s_ref, n_queries)
     l_ref.backward()
 
     errors = []

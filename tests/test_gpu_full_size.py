@@ -64,10 +64,11 @@ def _device_branches(kind, states, src, dst, masks):
     for l, st in enumerate(states):
         if kind == "PGAT":
             H, F_ = st.H, st.H * st.D
-            if l < L - 1:
+            cl = getattr(st, "cl", None)
+            if l < L - 1 or cl is None:                               # (TXE_NO_FOLD=1: the output layer runs unfolded, like the others)
                 a1, a2 = st.Y[:, F_:F_ + H].cpu().numpy(), st.Y[:, F_ + H:F_ + 2 * H].cpu().numpy()
             else:
-                a12 = st.cl[0].cpu().numpy()
+                a12 = cl[0].cpu().numpy()
                 a1, a2 = a12[:, 0:1], a12[:, 1:2]
             z = a1[src] + a2[dst]                                     # float32 + float32, like the kernels
             masks[l]["e_pos"] = torch.from_numpy(z > 0).unsqueeze(-1)

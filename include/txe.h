@@ -108,10 +108,7 @@ int txe_gat_aggregate_table_supported(int H, int D, long long ld_t, int vocab, i
 int txe_gat_aggregate_table_fwd(const int* rowptr_in, const int* col_src, int n_nodes, const float* T, long long ld_t, const int* rid,
                                 const float* T2, const int* pos, int vocab, int H, int D, float attn_slope, int out_mode,
                                 float act_slope, float* out, long long ld_out, const float* nx_wa, int nx_kp, float* nx_a12,
-                                const float* nx_P, int nx_Pd, void* stream);
-/* out == NULL (needs nx_a12): LOGITS ONLY -- the rows are formed, nothing but the next (folded) layer's attention logits is stored; the
- * columns behind the feature part of that layer's input come from its position embedding nx_P [vocab][nx_Pd] by pos[v].
- * txe_gat_collapse_table_fwd then forms the rows a second time for Z, so the [N][nx_kp] layer input never exists in HBM. */
+                                void* stream);
 
 /* ---- GATLayer message/reduce: model_zoo.py:90-95,106-114 (edge_attention, edge_softmax, attn_drop, update_all) -----
  * out_mode 0: out = aggregated features; 1: out = leaky_relu(aggregated, act_slope) (model_zoo.py:216 fused).
@@ -250,17 +247,6 @@ int txe_gat_collapse_fwd(const int* rowptr_in, const int* col_src, const int* ro
                          float feat_drop_p, const unsigned* mask, float attn_slope, float attn_drop_p, unsigned long long seed,
                          const int* pos, const float* pw, float* a12, int a12_ready, float* alpha, float* coef, float* wsum, int* gid, float* Z,
                          float* hg, long long ld_hg, void* ws, size_t ws_bytes, void* stream);
-/* the forward for an eval-mode encode whose first-layer rows come from a projected feature table (test_fast.py:99-108,149-179 /
- * infer.py:82-95 on every candidate): a12 from txe_gat_aggregate_table_fwd(out = NULL), then attention + coefficients as above, Z formed
- * straight from the table (the rows are gathered a second time instead of being written as [N][Kp] and read back), hg = Z Wp^T.
- * tab_*: the FIRST layer's T / ld / rid / T2 / vocab, its H, D and attention slope, the activation between the layers (tab_out_mode 1:
- * leaky_relu with tab_act_slope, model_zoo.py:216); P [vocab][Pd]: this layer's position embedding (model_zoo.py:218).  No dropout. */
-int txe_gat_collapse_table_fwd(const int* rowptr_in, const int* col_src, const int* rowptr_out, const int* col_dst, const int* pos_out,
-                               const int* graph_off, int n_nodes, int n_edges, int G, int Kh, int Pd, const float* Wp, int D,
-                               float attn_slope, const int* pos, const float* pw, const float* P, const float* a12, const float* tab_T,
-                               long long tab_ld, const int* tab_rid, const float* tab_T2, int tab_vocab, int tab_H, int tab_D,
-                               float tab_attn_slope, int tab_out_mode, float tab_act_slope, float* alpha, float* coef, float* wsum,
-                               int* gid, float* Z, float* hg, long long ld_hg, void* ws, size_t ws_bytes, void* stream);
 int txe_gat_collapse_bwd(const int* rowptr_in, const int* col_src, const int* rowptr_out, const int* col_dst, const int* pos_out,
                          const int* graph_off, int n_nodes, int n_edges, int G, const float* X, int Kh, int Pd, const int* pos, int vocab,
                          const float* Wp, const float* W, const float* attn_l, const float* attn_r, int D, float feat_drop_p,

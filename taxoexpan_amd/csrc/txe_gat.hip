@@ -14,7 +14,6 @@
 // and writes one row of H*D floats.  Workgroups are remapped so that one XCD (one L2) owns a contiguous
 // range of destination nodes -- the nodes of an egonet share their source rows.
 #include "txe_gather.h"
-#include "txe_tabzsum.h"
 
 namespace txe {
 
@@ -38,11 +37,6 @@ struct NextLogits {
     float* a12;               // [N][2]
     float scale;
     int kp, mask_ld;
-    // NX == 4 (logits only: the row is NOT stored, `out` is NULL): the columns behind the feature part come from the next layer's
-    // position embedding P [vocab][Pd] by pos[v] instead of from the prepared input row
-    const float* P;
-    const int* pos;
-    int Pd;
 };
 // one destination node v, one wave: attention softmax over its in-edges, aggregation, (NX) the next layer's folded logits
 // NX: 0 = plain aggregation, 1 = + the next (folded) layer's logits, 2 = the same with that layer's feature-dropout mask
@@ -166,15 +160,6 @@ __device__ __forceinline__ void gat_fwd_node(const int v, const int l, float* __
             tk[i] = (c < nx.kp) ? ((wd >> (cc & 31)) & 1u) : 0u;
         }
     }
-    if constexpr (NX == 4) {
-        const int pv = nx.pos[v], pd1 = max(nx.Pd, 1);
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int c = l + 64 * i;                                    // column behind the feature part
-            tx[i] = nx.P[(long long)pv * pd1 + min(c, pd1 - 1)];
-            tk[i] = (c < nx.Pd) ? 1u : 0u;                               // (the padding columns are zeros)
-        }
-    }
     for (int t0 = 0; t0 < nvec; t0 += 64 * NI) {
         int hidx[NI];
         float acc[NI][VEC];
@@ -185,7 +170,7 @@ __device__ __forceinline__ void gat_fwd_node(const int v, const int l, float* __
                 const int j = t0 + l + 64 * i;
                 const int c = ((j < nvec) ? j : 0) * VEC;
                 kb[i] = 0xFFFFFFFFu;
-                if constexpr (NX == 2 || NX == 3) kb[i] = nx.mask[(long long)v * nx.mask_ld + (c >> 5)] >> (c & 31);
+                if constexpr (NX >= 2) kb[i] = nx.mask[(long long)v * nx.mask_ld + (c >> 5)] >> (c & 31);
                 kb[i] = (j < nvec) ? kb[i] : 0u;
             }
         }
@@ -232,10 +217,10 @@ __device__ __forceinline__ void gat_fwd_node(const int v, const int l, float* __
 #pragma unroll
                     for (int k = 0; k < VEC; ++k) acc[i][k] = ((kb[i] >> k) & 1u) ? acc[i][k] * nx.scale : 0.f;
                 }
-                if constexpr (NX != 4) vstore<VEC>(out + (long long)v * ld_out + (long long)j * VEC, acc[i]);
+                vstore<VEC>(out + (long long)v * ld_out + (long long)j * VEC, acc[i]);
             }
         }
-        if constexpr (NX == 1 || NX == 2 || NX == 4) {
+        if constexpr (NX == 1 || NX == 2) {
             // VEC divides 32: the VEC keep bits of a vector sit in one mask word (kb, above); the folded rows come from LDS
 #pragma unroll
             for (int i = 0; i < NI; ++i) {
@@ -253,7 +238,7 @@ __device__ __forceinline__ void gat_fwd_node(const int v, const int l, float* __
             }
         }
     }
-    if constexpr (NX == 1 || NX == 2 || NX == 4) {
+    if constexpr (NX == 1 || NX == 2) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int cc = min(F + l + 64 * i, nx.kp - 1);
@@ -282,8 +267,8 @@ __global__ __launch_bounds__(GAT_WAVES * 64, TAB ? 3 : 1) void gat_aggregate_fwd
 
     const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
     extern __shared__ __attribute__((aligned(16))) float s_wa[];   // NX: the two folded rows [2][kp], shared by the workgroup's 4 nodes;
-    float* s_t2 = s_wa + ((NX == 1 || NX == 2 || NX == 4) ? 2 * nx.kp : 0);   // TAB: behind them, the rows of T2 [vocab][ld_ft]
-    if constexpr (NX == 1 || NX == 2 || NX == 4) {
+    float* s_t2 = s_wa + ((NX == 1 || NX == 2) ? 2 * nx.kp : 0);   // TAB: behind them, the rows of T2 [vocab][ld_ft]
+    if constexpr (NX == 1 || NX == 2) {
         for (int i = threadIdx.x * 4; i < 2 * nx.kp; i += GAT_WAVES * 64 * 4)
             *reinterpret_cast<float4*>(s_wa + i) = *reinterpret_cast<const float4*>(nx.wa + i);
     }
@@ -291,142 +276,11 @@ __global__ __launch_bounds__(GAT_WAVES * 64, TAB ? 3 : 1) void gat_aggregate_fwd
         for (long long i = threadIdx.x * 4; i < (long long)tab.vocab * ld_ft; i += GAT_WAVES * 64 * 4)
             *reinterpret_cast<float4*>(s_t2 + i) = *reinterpret_cast<const float4*>(tab.t2 + i);
     }
-    if constexpr (NX == 1 || NX == 2 || NX == 4 || TAB) __syncthreads();     // before any wave leaves
+    if constexpr (NX == 1 || NX == 2 || TAB) __syncthreads();     // before any wave leaves
     const int v = xcd_remap(blockIdx.x, gridDim.x) * GAT_WAVES + w;
     if (v >= n_nodes) return;
     gat_fwd_node<VEC, NI, NX, TAB>(v, l, s_w[w], s_idx[w], s_stat[w], s_wa, rowptr, col, ft, ld_ft, a_src, a_dst, ld_a, H, D, slope, drop_p,
                                    drop_scale, seed, out_mode, act_slope, out, ld_out, alpha, nx, tab, s_pos[TAB ? w : 0], s_t2);
-}
-
-// ------------------------------------------------------------------------------------------------
-// Eval-mode encode from the projected feature table, second pass: Z of the folded output layer WITHOUT the layer input X' in HBM.
-//   Z[g] = (1 / S_g) sum_{v in g} c~_v X'[v],   X'[v] = [ leaky(sum_{u->v} alpha_uv (T[rid_u] + T2[pos_u])) | P[pos_v] | 0 ]
-// The first pass (gat_aggregate_fwd_kernel<.., 4, true>) forms every row once to get the folded layer's attention logits and stores
-// nothing but those; the coefficients c~ need the whole egonet's logits, so the rows are formed AGAIN here -- one wave per egonet walks
-// its nodes, recomputes each node's attention and row exactly like the first pass (same code, same order: bit-equal rows) and
-// accumulates c~_v X'[v] in registers in node order (cl_zsum_kernel's order: bit-equal Z).  The table rows are gathered twice
-// (2 x 7.9 GB on MAG-Full's 356 k egonets) instead of being gathered once, written as 9.2 GB of X', and read back by the zsum sweep:
-// 30 GB -> 19 GB of HBM traffic for the encode's message/reduce part, and no [N][Kp] buffer at all.
-// ------------------------------------------------------------------------------------------------
-template <int NI>
-__global__ __launch_bounds__(GAT_WAVES * 64, 3) void gat_table_zsum_kernel(const TabZsumArgs a) {
-    constexpr int VEC = 4;
-    __shared__ float s_w[GAT_WAVES][4 * 64];
-    __shared__ int s_idx[GAT_WAVES][64];
-    __shared__ int s_pos[GAT_WAVES][64];
-    __shared__ float s_stat[GAT_WAVES][2 * 4];
-    extern __shared__ __attribute__((aligned(16))) float s_t2[];          // T2 [vocab][ld_t]
-    for (long long i = threadIdx.x * 4; i < (long long)a.vocab * a.ld_t; i += GAT_WAVES * 64 * 4)
-        *reinterpret_cast<float4*>(s_t2 + i) = *reinterpret_cast<const float4*>(a.T2 + i);
-    __syncthreads();
-    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
-    const int g = xcd_remap(blockIdx.x, gridDim.x) * GAT_WAVES + w;
-    if (g >= a.G) return;
-    float* sw = s_w[w];
-    int* sidx = s_idx[w];
-    int* spos = s_pos[w];
-    float* sstat = s_stat[w];
-    const int H = a.H, D = a.D, F = H * D, nvec = F / VEC;
-    const long long ld = a.ld_t;
-    const int nbeg = a.goff[g], nend = a.goff[g + 1];
-    const float S = a.wsum[g];
-    const float zs = S > 0.f ? 1.f / S : 0.f;
-    auto att = [&](const int u, const int h, const bool dst) -> float {
-        const int c = F + (dst ? H : 0) + h;
-        return a.T[(long long)a.rid[u] * ld + c] + s_t2[(long long)a.pos[u] * ld + c];
-    };
-    float* zrow = a.Z + (long long)g * a.Kp;
-    for (int t0 = 0; t0 < nvec; t0 += 64 * NI) {
-        int hidx[NI];
-        float zacc[NI][VEC];
-#pragma unroll
-        for (int i = 0; i < NI; ++i) {
-            const int j = t0 + l + 64 * i;
-            hidx[i] = (j < nvec) ? (j * VEC) / D : 0;
-#pragma unroll
-            for (int k = 0; k < VEC; ++k) zacc[i][k] = 0.f;
-        }
-        for (int v = nbeg; v < nend; ++v) {
-            const float cv = a.coef[v];
-            const int beg = a.rowptr[v], end = a.rowptr[v + 1];
-            const bool single = (end - beg <= 64);
-            if (single) {                                   // (gat_fwd_node's common case, TAB, no dropout, alpha not kept)
-                const int p = beg + l;
-                const bool valid = p < end;
-                const int u = valid ? a.col[p] : 0;
-                float e[4], ex[4], m[4], sm[4];
-#pragma unroll
-                for (int h = 0; h < 4; ++h) e[h] = (valid && h < H) ? leaky(att(u, h, false) + att(v, h, true), a.attn_slope) : -INFINITY;
-#pragma unroll
-                for (int h = 0; h < 4; ++h) m[h] = wave_max(e[h]);
-#pragma unroll
-                for (int h = 0; h < 4; ++h) ex[h] = (valid && h < H) ? __expf(e[h] - m[h]) : 0.f;
-#pragma unroll
-                for (int h = 0; h < 4; ++h) sm[h] = wave_sum(ex[h]);
-                if (valid) {
-                    sidx[l] = a.rid[u]; spos[l] = a.pos[u];
-#pragma unroll
-                    for (int h = 0; h < 4; ++h)
-                        if (h < H) sw[h * 64 + l] = (ex[h] / sm[h]) * 1.f;
-                }
-            } else {
-                for (int h = 0; h < H; ++h) {
-                    const float ad = att(v, h, true);
-                    float m = -INFINITY;
-                    for (int p = beg + l; p < end; p += 64) m = fmaxf(m, leaky(att(a.col[p], h, false) + ad, a.attn_slope));
-                    m = wave_max(m);
-                    float s = 0.f;
-                    for (int p = beg + l; p < end; p += 64) s += __expf(leaky(att(a.col[p], h, false) + ad, a.attn_slope) - m);
-                    s = wave_sum(s);
-                    if (l == 0) { sstat[2 * h] = m; sstat[2 * h + 1] = 1.f / s; }
-                }
-            }
-            __builtin_amdgcn_wave_barrier();
-            float acc[NI][VEC];
-#pragma unroll
-            for (int i = 0; i < NI; ++i)
-#pragma unroll
-                for (int k = 0; k < VEC; ++k) acc[i][k] = 0.f;
-            for (int cb = beg; cb < end; cb += 64) {
-                const int p = cb + l;
-                if (!single && p < end) {
-                    const int u = a.col[p];
-                    sidx[l] = a.rid[u]; spos[l] = a.pos[u];
-                    for (int h = 0; h < H; ++h) {
-                        const float e = leaky(att(u, h, false) + att(v, h, true), a.attn_slope);
-                        sw[h * 64 + l] = (__expf(e - sstat[2 * h]) * sstat[2 * h + 1]) * 1.f;
-                    }
-                }
-                __builtin_amdgcn_wave_barrier();
-                const int cnt = min(64, end - cb);
-                for (int e = 0; e < cnt; ++e) gather_step_tab<VEC, NI, 1>(a.T, ld, sidx, spos, s_t2, sw, e, t0, nvec, hidx, acc);
-                __builtin_amdgcn_wave_barrier();
-            }
-#pragma unroll
-            for (int i = 0; i < NI; ++i)
-#pragma unroll
-                for (int k = 0; k < VEC; ++k) {
-                    const float x = (a.out_mode == 1) ? leaky(acc[i][k], a.act_slope) : acc[i][k];
-                    zacc[i][k] = fmaf(cv, x, zacc[i][k]);             // (cl_zsum_kernel: fmaf(c * keep, x, acc) with keep = 1)
-                }
-        }
-#pragma unroll
-        for (int i = 0; i < NI; ++i) {
-            const int j = t0 + l + 64 * i;
-            if (j < nvec) {
-#pragma unroll
-                for (int k = 0; k < VEC; ++k) zacc[i][k] *= zs;
-                vstore<VEC>(zrow + (long long)j * VEC, zacc[i]);
-            }
-        }
-    }
-    // the columns behind the feature part: position embedding rows, then zero padding
-    for (int c = F + l; c < a.Kp; c += 64) {
-        float z = 0.f;
-        if (c - F < a.Pd)
-            for (int v = nbeg; v < nend; ++v) z = fmaf(a.coef[v], a.P[(long long)a.pos[v] * a.Pd + (c - F)], z);
-        zrow[c] = z * zs;
-    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -864,29 +718,6 @@ static inline int pick_vec(int D, long long ld1, long long ld2, const void* p1, 
     return 1;
 }
 
-int gat_table_zsum_supported(int H, int D, long long ld_t, int vocab, int Kp, int Pd) {
-    return (H >= 1 && H <= 4 && D >= 4 && (D & 3) == 0 && (ld_t & 3) == 0 && ld_t >= (long long)H * D + 2 * H && vocab >= 1 && Pd >= 0 &&
-            Kp >= H * D + Pd && (Kp & 3) == 0 && (size_t)vocab * ld_t * sizeof(float) <= 56 * 1024) ? 1 : 0;
-}
-
-int gat_table_zsum_launch(const TabZsumArgs& a, hipStream_t stream) {
-    if (!gat_table_zsum_supported(a.H, a.D, a.ld_t, a.vocab, a.Kp, a.Pd) || !a.rowptr || !a.col || !a.goff || !a.T || !a.rid || !a.pos || !a.T2 ||
-        !a.coef || !a.wsum || !a.Z || (a.Pd > 0 && !a.P) || (((uintptr_t)a.T | (uintptr_t)a.T2 | (uintptr_t)a.Z) & 15) || (a.out_mode != 0 && a.out_mode != 1))
-        return TXE_ERR_ARG;
-    if (a.G <= 0) return TXE_OK;
-    const int ni = pick_ni(a.H * a.D / 4);
-    const int nb = (a.G + GAT_WAVES - 1) / GAT_WAVES;
-    const size_t lds = (size_t)a.vocab * a.ld_t * sizeof(float);
-    const KName kn("gat_table_zsum_kernel", ni);
-    // algorithmic bytes are known to the caller only (the node count): it prices the launch
-    ProfScope prof(kn.s, stream, 4.0 * (double)a.G * a.Kp, 1);
-    if (ni == 8) hipLaunchKernelGGL((gat_table_zsum_kernel<8>), dim3(nb), dim3(GAT_WAVES * 64), lds, stream, a);
-    else if (ni == 4) hipLaunchKernelGGL((gat_table_zsum_kernel<4>), dim3(nb), dim3(GAT_WAVES * 64), lds, stream, a);
-    else hipLaunchKernelGGL((gat_table_zsum_kernel<2>), dim3(nb), dim3(GAT_WAVES * 64), lds, stream, a);
-    TXE_CHECK_LAUNCH();
-    return TXE_OK;
-}
-
 }  // namespace txe
 
 using namespace txe;
@@ -916,7 +747,6 @@ int txe_gat_aggregate_fwd(const int* rowptr_in, const int* col_src, int n_nodes,
     NextLogits nx;
     nx.wa = nx_wa; nx.mask = (nx_feat_drop_p > 0.f) ? nx_mask : nullptr; nx.a12 = nx_a12;
     nx.scale = 1.f / (1.f - ((nx_a12 || out_drop) ? nx_feat_drop_p : 0.f)); nx.kp = nx_kp; nx.mask_ld = nx_kp / 32;
-    nx.P = nullptr; nx.pos = nullptr; nx.Pd = 0;
     // algorithmic (compulsory) bytes, SURVEY 8d: read ft + write out + a_src/a_dst + CSR (+ alpha when kept for backward);
     // the edge count is not known here (device rowptr), the E-proportional terms are added by the caller-side model
     const int ni = pick_ni(H * D / vec);
@@ -958,35 +788,26 @@ int txe_gat_aggregate_table_supported(int H, int D, long long ld_t, int vocab, i
 int txe_gat_aggregate_table_fwd(const int* rowptr_in, const int* col_src, int n_nodes, const float* T, long long ld_t, const int* rid,
                                 const float* T2, const int* pos, int vocab, int H, int D, float attn_slope, int out_mode,
                                 float act_slope, float* out, long long ld_out, const float* nx_wa, int nx_kp, float* nx_a12,
-                                const float* nx_P, int nx_Pd, void* stream) {
-    // out == NULL: LOGITS ONLY -- the rows are formed and nothing but the next (folded) layer's attention logits nx_a12 is stored; the
-    // columns behind the feature part of that layer's input then come from its position embedding nx_P [vocab][nx_Pd] by pos[v]
-    // (txe_gat_collapse_table_fwd forms the rows a second time for Z: the layer input never exists in HBM)
-    const bool logits_only = (out == nullptr);
-    if (n_nodes < 0 || !rowptr_in || !T || !rid || !T2 || !pos || (out_mode != 0 && out_mode != 1)) return TXE_ERR_ARG;
-    if (logits_only && (!nx_a12 || nx_Pd < 0 || nx_Pd > 128 || (nx_Pd > 0 && !nx_P) || H * D + nx_Pd > nx_kp)) return TXE_ERR_ARG;
+                                void* stream) {
+    if (n_nodes < 0 || !rowptr_in || !T || !rid || !T2 || !pos || !out || (out_mode != 0 && out_mode != 1)) return TXE_ERR_ARG;
     if (!txe_gat_aggregate_table_supported(H, D, ld_t, vocab, nx_a12 ? nx_kp : 0)) return TXE_ERR_ARG;
-    if ((!logits_only && (ld_out & 3)) || (((uintptr_t)T | (uintptr_t)T2 | (uintptr_t)out) & 15)) return TXE_ERR_ARG;
-    if (nx_a12 && (!nx_wa || nx_kp < H * D || nx_kp - H * D > 128 || (nx_kp & 31) || (!logits_only && ld_out != nx_kp) || ((uintptr_t)nx_wa & 15))) return TXE_ERR_ARG;
+    if ((ld_out & 3) || (((uintptr_t)T | (uintptr_t)T2 | (uintptr_t)out) & 15)) return TXE_ERR_ARG;
+    if (nx_a12 && (!nx_wa || nx_kp < H * D || nx_kp - H * D > 128 || (nx_kp & 31) || ld_out != nx_kp || ((uintptr_t)nx_wa & 15))) return TXE_ERR_ARG;
     if (n_nodes == 0) return TXE_OK;
     hipStream_t s = (hipStream_t)stream;
     const int nb = (n_nodes + GAT_WAVES - 1) / GAT_WAVES;
     NextLogits nx;
     nx.wa = nx_wa; nx.mask = nullptr; nx.a12 = nx_a12; nx.scale = 1.f; nx.kp = nx_a12 ? nx_kp : 0; nx.mask_ld = nx.kp / 32;
-    nx.P = nx_P; nx.pos = pos; nx.Pd = nx_Pd;
-    if (logits_only && nx_Pd == 0) nx.P = T;                       // (a readable address; every column behind the features is padding)
     TabSrc tab;
     tab.rid = rid; tab.pos = pos; tab.t2 = T2; tab.vocab = vocab;
     const int ni = pick_ni(H * D / 4);
     const size_t lds = table_lds_bytes(ld_t, vocab, nx.kp);
-    const KName kn("gat_aggregate_fwd_kernel", 4, ni, logits_only ? 4 : (nx_a12 ? 1 : 0), true);
-    // algorithmic bytes: the rows read (+ written unless logits only), attention columns, indices
-    ProfScope prof(kn.s, s, 4.0 * ((logits_only ? 1.0 : 2.0) * n_nodes * (double)H * D + 2.0 * n_nodes * H + 3.0 * n_nodes + 1), 1);
+    const KName kn("gat_aggregate_fwd_kernel", 4, ni, nx_a12 ? 1 : 0, true);
+    ProfScope prof(kn.s, s, 4.0 * (2.0 * n_nodes * (double)H * D + 2.0 * n_nodes * H + 3.0 * n_nodes + 1), 1);
 #define TXE_LT(I, X)                                                                                                              \
     hipLaunchKernelGGL((gat_aggregate_fwd_kernel<4, I, X, true>), dim3(nb), dim3(GAT_WAVES * 64), lds, s, rowptr_in, col_src, n_nodes, T, \
                        ld_t, T, T, 0, H, D, attn_slope, 0.f, 1.f, 0ull, out_mode, act_slope, out, ld_out, (float*)nullptr, nx, tab)
-    if (logits_only) { if (ni == 8) TXE_LT(8, 4); else if (ni == 4) TXE_LT(4, 4); else TXE_LT(2, 4); }
-    else if (nx_a12) { if (ni == 8) TXE_LT(8, 1); else if (ni == 4) TXE_LT(4, 1); else TXE_LT(2, 1); }
+    if (nx_a12) { if (ni == 8) TXE_LT(8, 1); else if (ni == 4) TXE_LT(4, 1); else TXE_LT(2, 1); }
     else { if (ni == 8) TXE_LT(8, 0); else if (ni == 4) TXE_LT(4, 0); else TXE_LT(2, 0); }
 #undef TXE_LT
     TXE_CHECK_LAUNCH();

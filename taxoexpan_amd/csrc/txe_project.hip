@@ -17,7 +17,6 @@
 #include "txe_gather.h"
 #include "txe_colsum.h"
 #include "txe_dxpos.h"
-#include "txe_tabzsum.h"
 
 namespace txe {
 
@@ -1925,46 +1924,6 @@ int txe_gat_collapse_fwd(const int* rowptr_in, const int* col_src, const int* ro
     TXE_CHECK_LAUNCH();
     VMat A = vmat_plain(Z, Kp, G, Kp);
     VMat B = vmat_plain(Wp, Kp, round_up(D + 2, 128), Kp);       // all Fp packed rows are readable: every tile stays on the plain loader
-    Epi E = epi_plain(hg, ld_hg, D);
-    E.alg_flops = 2.0 * G * (double)D * Kt;
-    return gemm_nt(A, B, E, G, D, Kp, 1, s, p.tail, p.tail_bytes);
-}
-
-// The same for an eval-mode encode whose first-layer rows are formed from a projected feature table (txe_gat_aggregate_table_fwd with
-// out == NULL left the attention logits a12 and nothing else): attention softmax + coefficients as above, then Z straight from the
-// table (gat_table_zsum_kernel: the layer input X never exists), then hg = Z Wp^T.  No dropout (inference).  tab_*: the FIRST layer's
-// table projection T [n_table][ld_t], T2 [vocab][ld_t], the batch nodes' table rows rid, its H / D / attention slope, and the
-// activation between the layers (out_mode 1: leaky with act_slope).  P [vocab][Pd]: this layer's position embedding.
-int txe_gat_collapse_table_fwd(const int* rowptr_in, const int* col_src, const int* rowptr_out, const int* col_dst, const int* pos_out,
-                               const int* graph_off, int n_nodes, int n_edges, int G, int Kh, int Pd, const float* Wp, int D,
-                               float attn_slope, const int* pos, const float* pw, const float* P, const float* a12, const float* tab_T,
-                               long long tab_ld, const int* tab_rid, const float* tab_T2, int tab_vocab, int tab_H, int tab_D,
-                               float tab_attn_slope, int tab_out_mode, float tab_act_slope, float* alpha, float* coef, float* wsum,
-                               int* gid, float* Z, float* hg, long long ld_hg, void* ws, size_t ws_bytes, void* stream) {
-    if (n_nodes < 0 || n_edges < 0 || G < 0 || Kh < 1 || Pd < 0 || D < 1 || !rowptr_in || !rowptr_out || !graph_off || !Wp || !a12 || !alpha ||
-        !coef || !wsum || !gid || !Z || !hg || !ws || !pos || !tab_T || !tab_rid || !tab_T2 || (Pd > 0 && !P) || tab_H * tab_D != Kh)
-        return TXE_ERR_ARG;
-    const int Kt = Kh + Pd, Kp = round_up(Kt, 32);
-    if (!gat_table_zsum_supported(tab_H, tab_D, tab_ld, tab_vocab, Kp, Pd)) return TXE_ERR_ARG;
-    CollapseWs p = plan_collapse_ws(ws, n_nodes, n_edges, G, Kp, D, Pd, 0);
-    if (ws_bytes < p.total) return TXE_ERR_WORKSPACE;
-    if (G == 0) return TXE_OK;
-    hipStream_t s = (hipStream_t)stream;
-    if (n_nodes > 0) {
-        hipLaunchKernelGGL(cl_attn_coef_kernel, dim3((G + CG_GRAPHS - 1) / CG_GRAPHS), dim3(256), 0, s, rowptr_in, col_src, rowptr_out, col_dst, pos_out,
-                           graph_off, G, a12, attn_slope, 0.f, 1.f, 0ull, pos, pw, alpha, coef, wsum, gid);
-        TXE_CHECK_LAUNCH();
-    } else {
-        hipLaunchKernelGGL(cl_wsum_kernel, dim3((G + 3) / 4), dim3(256), 0, s, graph_off, G, pos, pw, wsum, gid);
-    }
-    TabZsumArgs za;
-    za.rowptr = rowptr_in; za.col = col_src; za.goff = graph_off; za.G = G; za.T = tab_T; za.ld_t = tab_ld; za.rid = tab_rid; za.pos = pos;
-    za.T2 = tab_T2; za.vocab = tab_vocab; za.H = tab_H; za.D = tab_D; za.attn_slope = tab_attn_slope; za.out_mode = tab_out_mode;
-    za.act_slope = tab_act_slope; za.coef = coef; za.wsum = wsum; za.P = P; za.Pd = Pd; za.Kp = Kp; za.Z = Z;
-    const int rc = gat_table_zsum_launch(za, s);
-    if (rc) return rc;
-    VMat A = vmat_plain(Z, Kp, G, Kp);
-    VMat B = vmat_plain(Wp, Kp, round_up(D + 2, 128), Kp);
     Epi E = epi_plain(hg, ld_hg, D);
     E.alg_flops = 2.0 * G * (double)D * Kt;
     return gemm_nt(A, B, E, G, D, Kp, 1, s, p.tail, p.tail_bytes);

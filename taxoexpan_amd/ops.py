@@ -41,7 +41,6 @@ def _rows(t):
 _BACKWARD_TWICE = ("taxoexpan_amd: backward through this propagation stack a second time -- its saved activations (several hundred MB per "
                    "batch) are released by the first backward; run the forward again (retain_graph=True is not supported here)")
 _NO_FUSED_LOGITS = os.environ.get("TXE_NO_FUSED_LOGITS", "0") == "1"     # A/B switch (tests compare both paths)
-_NO_TABLE_FUSE = os.environ.get("TXE_NO_TABLE_FUSE", "0") == "1"        # A/B switch: the eval encode writes the folded layer's input X' and reads it back
 _I32_MEMO = {}       # id(source tensor) -> (weakref, version, device, int32 copy): `pos` is converted once per batch, not once per module
 
 
@@ -302,7 +301,7 @@ def _tail_ws(ref):
 
 
 class _GatLayerState:
-    __slots__ = ("X", "Wp", "mask", "Y", "alpha", "W", "al", "ar", "P", "Kh", "Pd", "Kp", "Fp", "H", "D", "seed", "cl", "prepared", "x_dropped", "tab")
+    __slots__ = ("X", "Wp", "mask", "Y", "alpha", "W", "al", "ar", "P", "Kh", "Pd", "Kp", "Fp", "H", "D", "seed", "cl", "prepared", "x_dropped")
 
 
 def _x_dropped_ok(cfg, states, l, collapse):
@@ -346,23 +345,6 @@ def _gat_layer_prepare(st, h, ld_h, pos, feat_p):
     st.mask = torch.empty((N, (st.Kh + st.Pd + 31) // 32), dtype=torch.int32, device=st.X.device) if feat_p > 0.0 else None
     call("txe_gat_layer_prepare", ptr(h), ld_h, N, st.Kh, ptr(pos), ptr(st.P), st.Pd, ptr(st.X), ptr(st.W), ptr(st.al), ptr(st.ar),
          st.H, st.D, ptr(st.Wp), feat_p, st.seed, ptr(st.mask), s)
-
-
-def _gat_collapse_table_fwd(csr, st, N, pos, pw, attn_slope, a12):
-    """the same for the eval encode from a projected feature table (txe_gat_collapse_table_fwd): the layer input X is never built --
-    st.tab holds the first layer's table projection, a12 the logits the first pass left"""
-    G, E = csr.n_graphs, csr.n_edges
-    T, T2, rid, ld_t, tH, tD, t_slope, t_mode, t_act = st.tab
-    alpha, coef = _empty((max(E, 1),), T), _empty((max(N, 1),), T)
-    wsum, Z, hg = _empty((max(G, 1),), T), _empty((max(G, 1), st.Kp), T), _empty((G, st.D), T)
-    gid = torch.empty(max(N, 1), dtype=torch.int32, device=T.device)
-    wsb = call("txe_gat_collapse_ws_bytes", N, E, G, st.Kh, st.Pd, st.D, 8)
-    ws = _ws(wsb, T)
-    call("txe_gat_collapse_table_fwd", ptr(csr.rowptr_in), ptr(csr.col_src), ptr(csr.rowptr_out), ptr(csr.col_dst), ptr(csr.pos_out),
-         ptr(csr.graph_off), N, E, G, st.Kh, st.Pd, ptr(st.Wp), st.D, attn_slope, ptr(pos), ptr(pw), ptr(st.P), ptr(a12), ptr(T), ld_t,
-         ptr(rid), ptr(T2), T2.shape[0], tH, tD, t_slope, t_mode, t_act, ptr(alpha), ptr(coef), ptr(wsum), ptr(gid), ptr(Z), ptr(hg), st.D,
-         ptr(ws), wsb, _lib.stream_ptr())
-    return hg
 
 
 def _gat_collapse_fwd(csr, st, h, ld_h, pos, rpos, pw, feat_p, attn_p, attn_slope, a12=None):
@@ -419,19 +401,10 @@ def _gat_layer_fwd(csr, st, h, ld_h, pos, out, ld_out, feat_p, attn_p, attn_slop
                 and call("txe_gat_aggregate_table_supported", H, D, Fp, T2.shape[0], nx_kp) == 1):
             # the projected rows T[id] + T2[pos] are formed inside the sweep: no [N, Fp] round trip through HBM
             st.Y = st.alpha = None
-            rid = _i32(h.index, T.device)
-            if out is None:      # logits only: the folded layer's input is never stored (its Z is formed from the table a second time)
-                sn = nxt[0]
-                call("txe_gat_aggregate_table_fwd", ptr(csr.rowptr_in), ptr(csr.col_src), N, ptr(T), Fp, ptr(rid), ptr(T2),
-                     ptr(pos), T2.shape[0], H, D, attn_slope, out_mode, act_slope, None, 0,
-                     ptr(sn.Wp) + 4 * sn.D * sn.Kp, nx_kp, ptr(nxt[1]), ptr(sn.P), sn.Pd, s)
-                sn.tab = (T, T2, rid, Fp, H, D, attn_slope, out_mode, act_slope)
-                return
-            call("txe_gat_aggregate_table_fwd", ptr(csr.rowptr_in), ptr(csr.col_src), N, ptr(T), Fp, ptr(rid), ptr(T2),
+            call("txe_gat_aggregate_table_fwd", ptr(csr.rowptr_in), ptr(csr.col_src), N, ptr(T), Fp, ptr(_i32(h.index, T.device)), ptr(T2),
                  ptr(pos), T2.shape[0], H, D, attn_slope, out_mode, act_slope, ptr(out), ld_out,
-                 *((ptr(nxt[0].Wp) + 4 * nxt[0].D * nxt[0].Kp, nx_kp, ptr(nxt[1])) if nxt is not None else (None, 0, None)), None, 0, s)
+                 *((ptr(nxt[0].Wp) + 4 * nxt[0].D * nxt[0].Kp, nx_kp, ptr(nxt[1])) if nxt is not None else (None, 0, None)), s)
             return
-        assert out is not None, "the logits-only table route was planned but the sweep cannot run it"
         st.Y = _empty((N, Fp), T)
         call("txe_gather_add_rows", ptr(T), Fp, ptr(_i32(h.index, T.device)), ptr(T2), Fp, ptr(pos) if T2 is not None else None, N, Fp,
              ptr(st.Y), Fp, s)
@@ -620,20 +593,7 @@ class GATStackFunction(torch.autograd.Function):
                 kh = st.H * st.D
             h = ref                                  # (allocation reference from here on; the features travel as `src`)
             states[0].X = None if table else _empty((N, states[0].Kp), h)
-            # eval encode from a feature table through a folded output layer: that layer's input X' [N, Kp] is never built -- the sweep
-            # forms the rows once for the attention logits and once more for Z (_gat_collapse_table_fwd)
-            table_fuse = False
-            if (table and collapse and L == 2 and N > 0 and not need and not (_NO_TABLE_FUSE or _NO_FUSED_LOGITS or _NO_TABLE_SWEEP)
-                    and cfg.attn_p == 0.0 and pos is not None and states[0].P is not None and states[1].P is not None):
-                s0, s1 = states
-                table_fuse = (s0.D % 4 == 0 and s1.Kp - s0.H * s0.D <= 128 and s1.Kp <= 4096
-                              and call("txe_gat_aggregate_table_supported", s0.H, s0.D, s0.Fp, s0.P.shape[0], s1.Kp) == 1)
-            if table_fuse:
-                s1 = states[1]
-                s1.Wp = _empty((s1.Fp, s1.Kp), h)
-                call("txe_gat_pack_weights", ptr(s1.W), ptr(s1.al), ptr(s1.ar), s1.H, s1.D, s1.Kh + s1.Pd, ptr(s1.Wp), _lib.stream_ptr())
-                s1.mask, s1.prepared, s1.x_dropped = None, True, False
-            elif N > 0 and not _NO_MULTI_PREPARE:    # every layer's input buffer now, and ONE preparation launch for the whole stack
+            if N > 0 and not _NO_MULTI_PREPARE:      # every layer's input buffer now, and ONE preparation launch for the whole stack
                 for l in range(1, L):
                     states[l].X = _empty((N, states[l].Kp), h)
                 # (a layer that is not the folded one: only its GEMMs read X, so X is stored with the dropout applied -- by the
@@ -645,10 +605,6 @@ class GATStackFunction(torch.autograd.Function):
             for l, st in enumerate(states):
                 last = (l == L - 1)
                 F = st.H * st.D
-                if last and collapse and getattr(st, "tab", None) is not None:
-                    res = _gat_collapse_table_fwd(csr, st, N, pos, pwf, cfg.attn_slope, fused_a12)
-                    st.tab = st.Wp = None
-                    break
                 if last and collapse:
                     res = _gat_collapse_fwd(csr, st, src if l == 0 else None, ld_h if l == 0 else 0, pos if st.P is not None else None,
                                             rpos, pwf, cfg.feat_p, cfg.attn_p, cfg.attn_slope, a12=fused_a12)
@@ -657,8 +613,6 @@ class GATStackFunction(torch.autograd.Function):
                     break
                 if last:
                     out, ld_out = _empty((N, F), h), F
-                elif table_fuse:                       # (logits only: nothing is written)
-                    out, ld_out = None, 0
                 else:                                  # the aggregation writes straight into the next layer's padded input
                     if states[l + 1].X is None:
                         states[l + 1].X = _empty((N, states[l + 1].Kp), h)

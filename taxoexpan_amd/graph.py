@@ -132,14 +132,15 @@ class DGLGraph:
         self._csr_cache[key] = csr
         return csr
 
-    # ---- DGL message passing API: served by the fused HIP modules, see dgl_compat.py -----------------------------
+    # ---- DGL message passing with user functions: its only callers in the reference are the model_zoo classes, which
+    # taxoexpan_amd.model_zoo replaces with fused HIP kernels; a generic (slow) route is deliberately not provided.
     def apply_edges(self, func):
-        from . import dgl_compat
-        return dgl_compat.apply_edges(self, func)
+        raise NotImplementedError("DGLGraph.apply_edges with user functions is not provided on MI355X -- use the taxoexpan_amd.model_zoo "
+                                  "layers (GATLayer / GCNLayer / PGAT / PGCN / readouts), which fuse these primitives into HIP kernels")
 
     def update_all(self, message_func, reduce_func):
-        from . import dgl_compat
-        return dgl_compat.update_all(self, message_func, reduce_func)
+        raise NotImplementedError("DGLGraph.update_all with user functions is not provided on MI355X -- use the taxoexpan_amd.model_zoo "
+                                  "layers (GATLayer / GCNLayer / PGAT / PGCN / readouts), which fuse these primitives into HIP kernels")
 
 
 class BatchedDGLGraph(DGLGraph):

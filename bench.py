@@ -97,22 +97,29 @@ def build_batches(tax, n_batches, seed0, device):
     return out
 
 
-def fresh_batch(tax, dtax, seed, device, stream=None):
-    """a NEW training batch built inside the step, as a train.py epoch does for every step (data_loaders.py:9-28 + dataset.py:404-437):
-    anchors sampled on the host (the reference's sampler is host Python too), egonets + both CSR views + the feature gathers on the
-    device (data_loaders.build_device_batch; on `stream` the construction's one host sync does not wait for the running step)"""
-    from taxoexpan_amd.data_loaders import build_device_batch
+def fresh_batch_begin(tax, dtax, seed, device, stream=None):
+    """a NEW training batch, first half (data_loaders.begin_device_batch): anchors sampled on the host (the reference's sampler is host
+    Python too), uploaded, the egonets' node counts launched on `stream` -- nothing waited for"""
+    from taxoexpan_amd.data_loaders import begin_device_batch
     rs = _RNG.setdefault("rs", np.random.RandomState(4711))             # (one generator for the run: seeding one costs 0.1 ms)
     has_par = _HAS_PAR.setdefault(id(tax), np.nonzero(np.diff(tax.par_ptr) > 0)[0])
     queries = has_par[rs.randint(0, len(has_par), size=N_QUERIES)]
-    span = tax.par_ptr[queries + 1] - tax.par_ptr[queries]
-    pos_parent = tax.par_idx[tax.par_ptr[queries] + (rs.uniform(size=N_QUERIES) * span).astype(np.int64)]
-    negs = rs.randint(0, tax.n_nodes, size=(N_QUERIES, NEG))
-    anchors = np.concatenate([pos_parent[:, None], negs], 1).reshape(-1)
+    first = tax.par_ptr[queries]
+    span = tax.par_ptr[queries + 1] - first
+    anchors = rs.randint(0, tax.n_nodes, size=(N_QUERIES, 1 + NEG))       # column 0: a true parent; the rest: negatives
+    anchors[:, 0] = tax.par_idx[first + (rs.random_sample(N_QUERIES) * span).astype(np.int64)]
+    anchors = anchors.reshape(-1)
     exclude = np.full((N_QUERIES, 1 + NEG), -1, dtype=np.int64)
     exclude[:, 0] = queries
-    return build_device_batch(dtax, anchors, exclude.reshape(-1), np.repeat(queries, 1 + NEG), dtax.features, expand_factor=50, seed=seed + 1,
-                              stream=stream)
+    return begin_device_batch(dtax, anchors, exclude.reshape(-1), np.repeat(queries, 1 + NEG), expand_factor=50, seed=seed + 1, stream=stream)
+
+
+def fresh_batch(tax, dtax, seed, device, stream=None):
+    """a NEW training batch built inside the step, as a train.py epoch does for every step (data_loaders.py:9-28 + dataset.py:404-437):
+    egonets + both CSR views + the feature gathers on the device (data_loaders.build_device_batch; on `stream` the construction's one
+    host sync does not wait for the running step)"""
+    from taxoexpan_amd.data_loaders import finish_device_batch
+    return finish_device_batch(fresh_batch_begin(tax, dtax, seed, device, stream), dtax.features)
 
 
 _HAS_PAR = {}
@@ -568,6 +575,10 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    # The backward of a step is a chain of three Functions on ONE device: autograd's per-device engine thread only adds a hand-off
+    # (0.2 ms of HOST time per step, tools/fresh_batch_timing.py) -- the backward runs on the calling thread.  Same launches, same
+    # numbers; TXE_ENGINE_THREADS=1 is the A/B switch.
+    torch.autograd.set_multithreading_enabled(os.environ.get("TXE_ENGINE_THREADS", "0") == "1")
 
     from taxoexpan_amd import synthetic as syn
     tax = syn.make_named_taxonomy("mag_full" if args.workload == "pgat2" else "mag_cs", seed=47)
@@ -618,8 +629,12 @@ def main():
     torch.cuda.synchronize()
     tf0 = time.perf_counter()
     fresh_edges = 0
-    for i in range(n_fresh):
-        b = fresh_batch(tax, dtax, 6000 + 17 * i + rank, device, build_stream)
+    from taxoexpan_amd.data_loaders import finish_device_batch
+    pend = fresh_batch_begin(tax, dtax, 6000 + rank, device, build_stream)
+    for i in range(n_fresh):                             # DeviceBatchLoader's schedule: batch i+1 is begun (sampled, uploaded, node
+        b = finish_device_batch(pend, dtax.features)     # counts launched) before step i is enqueued, finished after it
+        if i + 1 < n_fresh:
+            pend = fresh_batch_begin(tax, dtax, 6000 + 17 * (i + 1) + rank, device, build_stream)
         train_step(model, opt, b, target, world)
         fresh_edges += b["n_edges"]
     torch.cuda.synchronize()

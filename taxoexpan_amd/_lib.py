@@ -126,12 +126,37 @@ def load():
     return lib
 
 
+_bound = {}
+
+
 def call(name, *args):
-    fn = getattr(load(), name)
-    rc = fn(*args)
-    if SIGNATURES[name][0] is I and rc != 0 and name not in VALUE_RETURNING:
+    ent = _bound.get(name)
+    if ent is None:                       # (bound function, "a non-zero int result is an error") looked up once per entry point
+        ent = _bound[name] = (getattr(load(), name), SIGNATURES[name][0] is I and name not in VALUE_RETURNING)
+    rc = ent[0](*args)
+    if rc != 0 and ent[1]:
         raise TxeError(f"{name} failed: {_ERR.get(rc, rc)}")
     return rc
+
+
+class _NoGuard:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NO_GUARD = _NoGuard()
+
+
+def on_device(dev):
+    """`with on_device(t.device):` = torch.cuda.device(dev) when `dev` is not the current device; nothing at all when it is (the usual
+    case, one process per GPU: the guard object and two device switches cost ~8 us of host time per launch group)"""
+    import torch
+    if dev.index is None or dev.index == torch.cuda.current_device():
+        return _NO_GUARD
+    return torch.cuda.device(dev)
 
 
 def ptr(t):

@@ -83,15 +83,23 @@ __device__ __forceinline__ void gather_step_tab(const float* __restrict__ base, 
     }
 }
 
-template <int VEC, int NI, int NX, bool TAB>
+// the head of a node's dependent-load chain (rowptr -> col -> attention terms), fetched for several nodes of a wave at once
+struct NodeHead {
+    int beg, end, u;          // in-edge range; this lane's source node (0 when the lane has no edge)
+    float e[4];               // this lane's edge: leaky(a_src[u] + a_dst[v]) per head (-inf: no edge / no such head); only when deg <= 64, H <= 4
+};
+
+template <int VEC, int NI, int NX, bool TAB, bool PRE = false>
 __device__ __forceinline__ void gat_fwd_node(const int v, const int l, float* __restrict__ s_w, int* __restrict__ s_idx,
     float* __restrict__ s_stat, const float* __restrict__ s_wa,
     const int* __restrict__ rowptr, const int* __restrict__ col, const float* __restrict__ ft,
     const long long ld_ft, const float* __restrict__ a_src, const float* __restrict__ a_dst, const int ld_a, const int H,
     const int D, const float slope, const float drop_p, const float drop_scale, const unsigned long long seed,
     const int out_mode, const float act_slope, float* __restrict__ out, const long long ld_out, float* __restrict__ alpha,
-    const NextLogits& nx, const TabSrc& tab, int* __restrict__ s_pos, const float* __restrict__ s_t2) {
-    const int beg = rowptr[v], end = rowptr[v + 1];
+    const NextLogits& nx, const TabSrc& tab, int* __restrict__ s_pos, const float* __restrict__ s_t2, const NodeHead* head = nullptr) {
+    int beg, end;
+    if constexpr (PRE) { beg = head->beg; end = head->end; }
+    else { beg = rowptr[v]; end = rowptr[v + 1]; }
     // attention terms of a node: TAB forms them from the table rows exactly as the materialised row would hold them
     auto att = [&](const int u, const int h, const bool dst) -> float {
         const int c = H * D + (dst ? H : 0) + h;
@@ -105,11 +113,18 @@ __device__ __forceinline__ void gat_fwd_node(const int v, const int l, float* __
     if (single) {
         const int p = beg + l;
         const bool valid = p < end;
-        const int u = valid ? col[p] : 0;
+        int u;
         float e[4], ex[4], m[4], sm[4];
+        if constexpr (PRE) {
+            u = head->u;
 #pragma unroll
-        for (int h = 0; h < 4; ++h)
-            e[h] = (valid && h < H) ? leaky(att(u, h, false) + att(v, h, true), slope) : -INFINITY;
+            for (int h = 0; h < 4; ++h) e[h] = head->e[h];
+        } else {
+            u = valid ? col[p] : 0;
+#pragma unroll
+            for (int h = 0; h < 4; ++h)
+                e[h] = (valid && h < H) ? leaky(att(u, h, false) + att(v, h, true), slope) : -INFINITY;
+        }
 #pragma unroll
         for (int h = 0; h < 4; ++h) m[h] = wave_max(e[h]);
 #pragma unroll
@@ -252,7 +267,10 @@ __device__ __forceinline__ void gat_fwd_node(const int v, const int l, float* __
     }
 }
 
-template <int VEC, int NI, int NX, bool TAB = false>
+// NPW consecutive destination nodes per wave: the heads of their dependent-load chains (rowptr -> col -> attention terms: three round
+// trips before the first feature row can be asked for) go out TOGETHER, level by level, so a wave pays the chain once per NPW nodes
+// (and a workgroup its LDS staging once per 4 NPW nodes); the nodes' sweeps then run back to back.  NPW = 1: one node per wave.
+template <int VEC, int NI, int NX, bool TAB = false, int NPW = 1>
 __global__ __launch_bounds__(GAT_WAVES * 64, TAB ? 3 : 1) void gat_aggregate_fwd_kernel(
     const int* __restrict__ rowptr, const int* __restrict__ col, const int n_nodes, const float* __restrict__ ft,
     const long long ld_ft, const float* __restrict__ a_src, const float* __restrict__ a_dst, const int ld_a, const int H,
@@ -266,7 +284,7 @@ __global__ __launch_bounds__(GAT_WAVES * 64, TAB ? 3 : 1) void gat_aggregate_fwd
     __shared__ float s_stat[GAT_WAVES][2 * GAT_MAXH];
 
     const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
-    extern __shared__ __attribute__((aligned(16))) float s_wa[];   // NX: the two folded rows [2][kp], shared by the workgroup's 4 nodes;
+    extern __shared__ __attribute__((aligned(16))) float s_wa[];   // NX: the two folded rows [2][kp], shared by the workgroup's nodes;
     float* s_t2 = s_wa + ((NX == 1 || NX == 2) ? 2 * nx.kp : 0);   // TAB: behind them, the rows of T2 [vocab][ld_ft]
     if constexpr (NX == 1 || NX == 2) {
         for (int i = threadIdx.x * 4; i < 2 * nx.kp; i += GAT_WAVES * 64 * 4)
@@ -276,11 +294,58 @@ __global__ __launch_bounds__(GAT_WAVES * 64, TAB ? 3 : 1) void gat_aggregate_fwd
         for (long long i = threadIdx.x * 4; i < (long long)tab.vocab * ld_ft; i += GAT_WAVES * 64 * 4)
             *reinterpret_cast<float4*>(s_t2 + i) = *reinterpret_cast<const float4*>(tab.t2 + i);
     }
-    if constexpr (NX == 1 || NX == 2 || TAB) __syncthreads();     // before any wave leaves
-    const int v = xcd_remap(blockIdx.x, gridDim.x) * GAT_WAVES + w;
-    if (v >= n_nodes) return;
-    gat_fwd_node<VEC, NI, NX, TAB>(v, l, s_w[w], s_idx[w], s_stat[w], s_wa, rowptr, col, ft, ld_ft, a_src, a_dst, ld_a, H, D, slope, drop_p,
-                                   drop_scale, seed, out_mode, act_slope, out, ld_out, alpha, nx, tab, s_pos[TAB ? w : 0], s_t2);
+    if constexpr (NPW == 1) {
+        if constexpr (NX == 1 || NX == 2 || TAB) __syncthreads();     // before any wave leaves
+        const int v = xcd_remap(blockIdx.x, gridDim.x) * GAT_WAVES + w;
+        if (v >= n_nodes) return;
+        gat_fwd_node<VEC, NI, NX, TAB>(v, l, s_w[w], s_idx[w], s_stat[w], s_wa, rowptr, col, ft, ld_ft, a_src, a_dst, ld_a, H, D, slope, drop_p,
+                                       drop_scale, seed, out_mode, act_slope, out, ld_out, alpha, nx, tab, s_pos[TAB ? w : 0], s_t2);
+    } else {
+        static_assert(!TAB || NPW == 1, "the table route keeps one node per wave");
+        // heads of the wave's NPW nodes, level by level (every level's loads are in flight together); the LDS staging above is in
+        // flight beside them -- its barrier comes after
+        const int v0 = __builtin_amdgcn_readfirstlane((xcd_remap(blockIdx.x, gridDim.x) * GAT_WAVES + w) * NPW);
+        NodeHead hd[NPW];
+        int vk[NPW];
+#pragma unroll
+        for (int k = 0; k < NPW; ++k) {
+            vk[k] = min(v0 + k, n_nodes - 1);
+            hd[k].beg = rowptr[vk[k]];
+            hd[k].end = rowptr[vk[k] + 1];
+        }
+        const bool heads = H <= 4;
+#pragma unroll
+        for (int k = 0; k < NPW; ++k) {
+            const int deg = hd[k].end - hd[k].beg;
+            const int p = hd[k].beg + ((l < deg) ? l : 0);          // clamped: the load stays unconditional when the node has an edge
+            hd[k].u = (deg > 0 && deg <= 64 && heads) ? col[p] : 0;
+        }
+        float as[NPW][4], ad[NPW][4];
+#pragma unroll
+        for (int k = 0; k < NPW; ++k)
+#pragma unroll
+            for (int h = 0; h < 4; ++h) {
+                const int hc = (h < H) ? h : 0;
+                as[k][h] = a_src[(long long)hd[k].u * ld_a + hc];
+                ad[k][h] = a_dst[(long long)vk[k] * ld_a + hc];
+            }
+#pragma unroll
+        for (int k = 0; k < NPW; ++k) {
+            const bool valid = l < hd[k].end - hd[k].beg;
+#pragma unroll
+            for (int h = 0; h < 4; ++h) hd[k].e[h] = (valid && h < H) ? leaky(as[k][h] + ad[k][h], slope) : -INFINITY;
+        }
+        if constexpr (NX == 1 || NX == 2) __syncthreads();            // (every wave reaches this: none has left yet)
+#pragma unroll
+        for (int k = 0; k < NPW; ++k) {
+            if (v0 + k < n_nodes) {
+                gat_fwd_node<VEC, NI, NX, TAB, true>(v0 + k, l, s_w[w], s_idx[w], s_stat[w], s_wa, rowptr, col, ft, ld_ft, a_src, a_dst, ld_a, H, D, slope,
+                                                     drop_p, drop_scale, seed, out_mode, act_slope, out, ld_out, alpha, nx, tab,
+                                                     s_pos[TAB ? w : 0], s_t2, &hd[k]);
+                __builtin_amdgcn_wave_barrier();                       // the next node re-uses this wave's LDS slots
+            }
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -711,6 +776,14 @@ struct KName {
         else { if (ni == 8) LAUNCH(1, 8); else if (ni == 4) LAUNCH(1, 4); else LAUNCH(1, 2); } \
     } while (0)
 
+// destination nodes per wave of the forward sweep (gat_aggregate_fwd_kernel's NPW): two -- 97 -> 93 us in the training step, 77 -> 72 us
+// stand-alone (tools/agg_fwd_variants.py); TXE_FWD_NPW = 1 | 2 | 4 overrides
+static inline int fwd_nodes_per_wave(int n_nodes) {
+    static const int forced = [] { const char* e = getenv("TXE_FWD_NPW"); return e ? atoi(e) : 0; }();
+    if (forced == 1 || forced == 2 || forced == 4) return forced;
+    return n_nodes >= 4096 ? 2 : 1;       // (4 per wave: 173 VGPRs = two waves per SIMD, 119 us against 93 us on the training batch)
+}
+
 static inline int pick_vec(int D, long long ld1, long long ld2, const void* p1, const void* p2) {
     auto al = [](const void* p, int bytes) { return ((uintptr_t)p % bytes) == 0; };
     if (D % 4 == 0 && ld1 % 4 == 0 && ld2 % 4 == 0 && al(p1, 16) && al(p2, 16)) return 4;
@@ -736,7 +809,6 @@ int txe_gat_aggregate_fwd(const int* rowptr_in, const int* col_src, int n_nodes,
         return TXE_ERR_ARG;
     if (n_nodes == 0) return TXE_OK;
     const float scale = 1.f / (1.f - attn_drop_p);
-    const int nb = (n_nodes + GAT_WAVES - 1) / GAT_WAVES;
     hipStream_t s = (hipStream_t)stream;
     const int vec = pick_vec(D, ld_ft, ld_out, ft, out);
     if (nx_a12 && (vec != 4 || ((uintptr_t)nx_wa & 15) || nx_kp > 4096)) return TXE_ERR_ARG;   // 16-byte layout; rows fit 32 KB of LDS
@@ -750,21 +822,19 @@ int txe_gat_aggregate_fwd(const int* rowptr_in, const int* col_src, int n_nodes,
     // algorithmic (compulsory) bytes, SURVEY 8d: read ft + write out + a_src/a_dst + CSR (+ alpha when kept for backward);
     // the edge count is not known here (device rowptr), the E-proportional terms are added by the caller-side model
     const int ni = pick_ni(H * D / vec);
+    const int npw = fwd_nodes_per_wave(n_nodes);
+    const int nb = (n_nodes + GAT_WAVES * npw - 1) / (GAT_WAVES * npw);
     const KName kn("gat_aggregate_fwd_kernel", vec, ni, nx_a12 ? (nx.mask ? 2 : 1) : (out_drop ? 3 : 0), false);
     ProfScope prof(kn.s, s, 4.0 * (2.0 * n_nodes * (double)H * D + 2.0 * n_nodes * H + n_nodes + 1), 1);
-#define TXE_L(V, I)                                                                                                               \
-    hipLaunchKernelGGL((gat_aggregate_fwd_kernel<V, I, 0>), dim3(nb), dim3(GAT_WAVES * 64), 0, s, rowptr_in, col_src, n_nodes, \
+#define TXE_LK(V, I, M, P, LDS)                                                                                                   \
+    hipLaunchKernelGGL((gat_aggregate_fwd_kernel<V, I, M, false, P>), dim3(nb), dim3(GAT_WAVES * 64), LDS, s, rowptr_in, col_src, n_nodes, \
                        ft, ld_ft, a_src, a_dst, ld_a, H, D, attn_slope, attn_drop_p, scale, seed, out_mode, act_slope,            \
                        out, ld_out, alpha, nx, TabSrc{nullptr, nullptr, nullptr, 0})
-#define TXE_LXM(I, M)                                                                                                             \
-    hipLaunchKernelGGL((gat_aggregate_fwd_kernel<4, I, M>), dim3(nb), dim3(GAT_WAVES * 64), (size_t)2 * nx_kp * sizeof(float), s, rowptr_in, col_src, n_nodes,  \
-                       ft, ld_ft, a_src, a_dst, ld_a, H, D, attn_slope, attn_drop_p, scale, seed, out_mode, act_slope,            \
-                       out, ld_out, alpha, nx, TabSrc{nullptr, nullptr, nullptr, 0})
+#define TXE_LP(V, I, M, LDS) do { if (npw == 4) TXE_LK(V, I, M, 4, LDS); else if (npw == 2) TXE_LK(V, I, M, 2, LDS); else TXE_LK(V, I, M, 1, LDS); } while (0)
+#define TXE_L(V, I) TXE_LP(V, I, 0, 0)
+#define TXE_LXM(I, M) TXE_LP(4, I, M, (size_t)2 * nx_kp * sizeof(float))
 #define TXE_LX(I) do { if (nx.mask) TXE_LXM(I, 2); else TXE_LXM(I, 1); } while (0)
-#define TXE_LD(I)                                                                                                                 \
-    hipLaunchKernelGGL((gat_aggregate_fwd_kernel<4, I, 3>), dim3(nb), dim3(GAT_WAVES * 64), 0, s, rowptr_in, col_src, n_nodes,            \
-                       ft, ld_ft, a_src, a_dst, ld_a, H, D, attn_slope, attn_drop_p, scale, seed, out_mode, act_slope,            \
-                       out, ld_out, alpha, nx, TabSrc{nullptr, nullptr, nullptr, 0})
+#define TXE_LD(I) TXE_LP(4, I, 3, 0)
     if (nx_a12) { if (ni == 8) TXE_LX(8); else if (ni == 4) TXE_LX(4); else TXE_LX(2); }
     else if (out_drop) { if (ni == 8) TXE_LD(8); else if (ni == 4) TXE_LD(4); else TXE_LD(2); }
     else TXE_DISPATCH_VEC_NI(vec, ni, TXE_L);
@@ -772,6 +842,8 @@ int txe_gat_aggregate_fwd(const int* rowptr_in, const int* col_src, int n_nodes,
 #undef TXE_LX
 #undef TXE_LXM
 #undef TXE_L
+#undef TXE_LP
+#undef TXE_LK
     TXE_CHECK_LAUNCH();
     return TXE_OK;
 }

@@ -102,36 +102,51 @@ class MaskedGraphDataLoader(torch.utils.data.DataLoader):
 _PINNED = {}
 
 
-def build_device_batch(dtax, anchors, exclude, query_ids, features, expand_factor=50, seed=0, stream=None):
-    """One training batch built ON the device (data_loaders.py:9-28 + dataset.py:404-437 without host egonet objects):
-    graph.device_egonet_batch for the anchors, node features and query features gathered from the resident table.
-    stream: build on that side stream -- the one host synchronisation of the construction (the array sizes) then waits for the
-    builder's own few microseconds of work only, not for the training step still running on the caller's stream; the caller's stream
-    is made to wait for the finished batch, and every tensor of the batch is marked as used on it (caching-allocator safety).
-    Returns dict(g, x, pos, qf, n_nodes, n_edges)."""
-    from .graph import device_egonet_batch
+def begin_device_batch(dtax, anchors, exclude, query_ids, expand_factor=50, seed=0, stream=None):
+    """First half of build_device_batch: the index arrays go up in one pinned copy and the egonets' node counts are computed, on
+    `stream` (default: the current stream); nothing is waited for.  Returns the job finish_device_batch completes."""
+    from .graph import device_egonet_begin
     dev = dtax.device
     main = torch.cuda.current_stream(dev)
     side = stream if stream is not None else main
     # (the side stream does NOT wait for the caller's stream -- that would put the construction behind the running step again: the
     #  taxonomy arrays and the feature table must be complete before the first call; DeviceBatchLoader synchronises once when it is made)
-    # the three index arrays travel in ONE pinned buffer and one copy (each small pageable upload costs ~60 us of host time)
-    import numpy as np
+    # the three index arrays travel in ONE pinned buffer and one copy (each small pageable upload costs ~60 us of host time); two
+    # buffers per size take turns, each guarded by the event of its last upload (a loader keeps two batches in flight)
     B = len(anchors)
-    host = _PINNED.get(3 * B)               # (re-used: device_egonet_batch's size read-back below synchronises `side` behind the copy)
-    if host is None:
-        host = _PINNED[3 * B] = torch.empty(3 * B, dtype=torch.int32).pin_memory()
+    ring = _PINNED.setdefault((3 * B, str(dev)), dict(k=0, slots=[None, None]))
+    ring["k"] ^= 1
+    slot = ring["slots"][ring["k"]]
+    if slot is None:
+        slot = ring["slots"][ring["k"]] = [torch.empty(3 * B, dtype=torch.int32).pin_memory(), None]
+    host, uploaded = slot
+    if uploaded is not None:
+        uploaded.synchronize()
     hv = host.numpy()
     hv[:B] = anchors
     hv[B:2 * B] = exclude if exclude is not None else -1
     hv[2 * B:] = query_ids
     with torch.cuda.stream(side):
         packed = host.to(dev, non_blocking=True)
-        g = device_egonet_batch(dtax, packed[:B], packed[B:2 * B] if exclude is not None else None, expand_factor=expand_factor, seed=seed,
-                                with_features=True)
+        slot[1] = torch.cuda.Event()
+        slot[1].record()
+        job = device_egonet_begin(dtax, packed[:B], packed[B:2 * B] if exclude is not None else None, expand_factor=expand_factor, seed=seed)
+        packed.record_stream(side)
+    return dict(job=job, packed=packed, B=B, side=side, dev=dev)
+
+
+def finish_device_batch(pending, features):
+    """Second half of build_device_batch: waits for the node count of the batch begun earlier (the one host synchronisation of the
+    construction; behind work enqueued a whole step ago it returns at once), fills the node table and both CSR views and gathers the
+    node / query features on the builder's stream; the CURRENT stream is made to wait for the finished batch, and every tensor of the
+    batch is marked as used on it (caching-allocator safety).  Returns dict(g, x, pos, qf, n_nodes, n_edges)."""
+    from .graph import device_egonet_finish
+    side, dev, packed, B = pending["side"], pending["dev"], pending["packed"], pending["B"]
+    main = torch.cuda.current_stream(dev)
+    with torch.cuda.stream(side):
+        g = device_egonet_finish(pending["job"], with_features=True)
         x = g.ndata.pop("x")
         qf = features.index_select(0, packed[2 * B:])
-        packed.record_stream(side)
     if side is not main:
         main.wait_stream(side)
         csr = g.csr(dev)
@@ -141,12 +156,23 @@ def build_device_batch(dtax, anchors, exclude, query_ids, features, expand_facto
     return dict(g=g, x=x, pos=g.ndata["pos"], qf=qf, n_nodes=g.number_of_nodes(), n_edges=g.number_of_edges())
 
 
+def build_device_batch(dtax, anchors, exclude, query_ids, features, expand_factor=50, seed=0, stream=None):
+    """One training batch built ON the device (data_loaders.py:9-28 + dataset.py:404-437 without host egonet objects):
+    graph.device_egonet_batch for the anchors, node features and query features gathered from the resident table.
+    stream: build on that side stream -- the one host synchronisation of the construction (the array sizes) then waits for the
+    builder's own few microseconds of work only, not for the training step still running on the caller's stream.  A loop that
+    calls begin_device_batch for batch i+1 BEFORE it enqueues step i does not wait at all (DeviceBatchLoader does).
+    Returns dict(g, x, pos, qf, n_nodes, n_edges)."""
+    return finish_device_batch(begin_device_batch(dtax, anchors, exclude, query_ids, expand_factor, seed, stream), features)
+
+
 class DeviceBatchLoader:
     """`for batch in loader` over a MaskedGraphDataset in 'train' / 'validation' mode with the batches built on the GPU: the sampler
     (dataset.sample_anchors: the reference's positive pointer and negative sampling, host Python like data_loader/dataset.py:334-381)
-    hands anchors to build_device_batch.  Each batch is built inside `next()` on a side stream, i.e. AFTER the consumer has enqueued
-    the previous step and while that step runs: with a GPU-bound step the construction (0.3-0.6 ms of host time, one host sync on the
-    side stream) disappears behind it.  Yields (graph, node features, query features, labels) -- MaskedGraphDataLoader's small-batch
+    hands anchors to begin_device_batch / finish_device_batch.  Each batch is built on a side stream while the previous step runs,
+    in two halves around the consumer's enqueue of that step: batch b+1 is BEGUN (sampled, uploaded, node counts launched) before
+    batch b is handed out and FINISHED (arrays sized from the count, filled, features gathered) at the next `next()`, so the one host
+    synchronisation of the construction finds its value already there.  Yields (graph, node features, query features, labels) -- MaskedGraphDataLoader's small-batch
     tuple with the node features popped, all on `device`."""
 
     def __init__(self, dataset, batch_size, device, shuffle=True, seed=0, drop_last=False):
@@ -168,9 +194,16 @@ class DeviceBatchLoader:
         if self.shuffle:
             random.Random(self.seed + self._epoch).shuffle(order)
         self._epoch += 1
-        for b in range(len(self)):
+        def begin(b):
             idx = order[b * self.batch_size:(b + 1) * self.batch_size]
             query, anchor, label, exclude = self.dataset.sample_anchors(idx)
-            batch = build_device_batch(self.dtax, anchor, exclude, query, self.features, expand_factor=self.dataset.expand_factor,
-                                       seed=self.seed + 7919 * self._epoch + b, stream=self._side)
+            return label, begin_device_batch(self.dtax, anchor, exclude, query, expand_factor=self.dataset.expand_factor,
+                                             seed=self.seed + 7919 * self._epoch + b, stream=self._side)
+        # two batches in flight: batch b+1 is begun (sampled, uploaded, node counts launched) before the consumer gets batch b, so the
+        # count's read-back has a whole step's enqueue to arrive and `finish` never waits
+        nxt = begin(0) if len(self) else None
+        for b in range(len(self)):
+            label, pending = nxt
+            batch = finish_device_batch(pending, self.features)
+            nxt = begin(b + 1) if b + 1 < len(self) else None
             yield batch["g"], batch["x"], batch["qf"], torch.as_tensor(label).to(self.device, non_blocking=True)

@@ -226,7 +226,7 @@ def build_csr_device(src, dst, n_nodes):
     col_src, eid_in, col_dst, pos_out = i32(max(e, 1)), i32(max(e, 1)), i32(max(e, 1)), i32(max(e, 1))
     wsb = _lib.call("txe_build_csr_ws_bytes", n_nodes, e)
     ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
-    with torch.cuda.device(dev):
+    with _lib.on_device(dev):
         _lib.call("txe_build_csr", _lib.ptr(src), _lib.ptr(dst), n_nodes, e, _lib.ptr(rowptr_in), _lib.ptr(col_src),
                   _lib.ptr(eid_in), _lib.ptr(rowptr_out), _lib.ptr(col_dst), _lib.ptr(pos_out), _lib.ptr(ws), wsb,
                   _lib.stream_ptr())
@@ -316,32 +316,62 @@ class DeviceTaxonomy:
         self.device = torch.device(device)
 
 
-def device_egonet_batch(dtax, anchors, exclude=None, expand_factor=50, seed=0, with_features=True, index_base=0):
-    """Batched egonets of `anchors` built on the GPU (dataset.py:404-437 + dgl.batch).  anchors / exclude: int arrays or
-    int32 device tensors.  Returns a DeviceBatchedGraph with ndata '_id', 'pos' (int32, device) and 'x' (features gathered;
-    with_features="lazy": an ops.GatheredRows over the taxonomy's feature table).  index_base: position of anchors[0] in the caller's whole
-    anchor list -- chunks of one list (test_fast.py's `-b`) then sample the same siblings as the single batch."""
+class _EgonetJob:
+    """a batch of egonets whose node counts are being computed on the device (device_egonet_begin)"""
+    __slots__ = ("dtax", "anchors", "exclude", "G", "expand_factor", "seed", "index_base", "node_off", "ws", "n_host", "ready")
+
+
+def device_egonet_begin(dtax, anchors, exclude=None, expand_factor=50, seed=0, index_base=0):
+    """First half of device_egonet_batch: the per-egonet node counts and their prefix sum on the current stream, and an ASYNCHRONOUS
+    read-back of the batch's node count into pinned memory.  Nothing waits here: a loader that begins batch i+1 before the consumer
+    enqueues step i finds the count ready when it finishes the batch (data_loaders.DeviceBatchLoader)."""
     dev = dtax.device
     to_dev = lambda a: None if a is None else (a.to(device=dev, dtype=torch.int32) if torch.is_tensor(a)
                                                else torch.as_tensor(np.asarray(a), dtype=torch.int32).to(dev))
-    anchors, exclude = to_dev(anchors), to_dev(exclude)
-    G = int(anchors.numel())
-    i32 = lambda k: torch.empty(max(k, 1), dtype=torch.int32, device=dev)
-    node_off = i32(G + 1)
-    with torch.cuda.device(dev):
-        st = _lib.stream_ptr()
+    job = _EgonetJob()
+    job.dtax, job.anchors, job.exclude = dtax, to_dev(anchors), to_dev(exclude)
+    job.G = G = int(job.anchors.numel())
+    job.expand_factor, job.seed, job.index_base = expand_factor, seed, int(index_base)
+    job.node_off = torch.empty(max(G + 1, 1), dtype=torch.int32, device=dev)
+    with _lib.on_device(dev):
         wsb = _lib.call("txe_egonet_ws_bytes", G)
-        ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=dev)
-        _lib.call("txe_egonet_offsets", _lib.ptr(dtax.par_ptr), _lib.ptr(dtax.chd_ptr), _lib.ptr(dtax.chd_idx), _lib.ptr(anchors),
-                  _lib.ptr(exclude), G, expand_factor, seed, int(index_base), _lib.ptr(node_off), _lib.ptr(ws), wsb, st)
-        N = int(node_off[G].item())                  # the one host sync of batch construction: sizes of the output arrays
-        E = 2 * N - G
-        ids, pos = i32(N), i32(N)
-        rowptr_in, rowptr_out = i32(N + 1), i32(N + 1)
-        col_src, eid_in, col_dst, pos_out = i32(E), i32(E), i32(E), i32(E)
+        job.ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=dev)
+        _lib.call("txe_egonet_offsets", _lib.ptr(dtax.par_ptr), _lib.ptr(dtax.chd_ptr), _lib.ptr(dtax.chd_idx), _lib.ptr(job.anchors),
+                  _lib.ptr(job.exclude), G, expand_factor, seed, job.index_base, _lib.ptr(job.node_off), _lib.ptr(job.ws), wsb, _lib.stream_ptr())
+        job.n_host = _count_slot(dev)
+        job.n_host.copy_(job.node_off[G:G + 1], non_blocking=True)
+        job.ready = torch.cuda.Event()
+        job.ready.record()
+    return job
+
+
+_COUNT_SLOTS = {}
+
+
+def _count_slot(dev):
+    """a pinned int32 for the next job's read-back (a small ring: jobs in flight at the same time do not share one)"""
+    ring = _COUNT_SLOTS.setdefault(str(dev), dict(slots=[torch.empty(1, dtype=torch.int32).pin_memory() for _ in range(8)], k=0))
+    ring["k"] = (ring["k"] + 1) % len(ring["slots"])
+    return ring["slots"][ring["k"]]
+
+
+def device_egonet_finish(job, with_features=True):
+    """Second half of device_egonet_batch: waits for the node count (the one host synchronisation of batch construction: the sizes of
+    the output arrays), then fills the node table and both CSR views on the current stream."""
+    dtax, dev, G = job.dtax, job.dtax.device, job.G
+    job.ready.synchronize()
+    N = int(job.n_host[0])
+    E = 2 * N - G
+    i32 = lambda k: torch.empty(max(k, 1), dtype=torch.int32, device=dev)
+    node_off = job.node_off
+    ids, pos = i32(N), i32(N)
+    rowptr_in, rowptr_out = i32(N + 1), i32(N + 1)
+    col_src, eid_in, col_dst, pos_out = i32(E), i32(E), i32(E), i32(E)
+    with _lib.on_device(dev):
         _lib.call("txe_egonet_fill", _lib.ptr(dtax.par_ptr), _lib.ptr(dtax.par_idx), _lib.ptr(dtax.chd_ptr), _lib.ptr(dtax.chd_idx),
-                  _lib.ptr(anchors), _lib.ptr(exclude), G, expand_factor, seed, int(index_base), _lib.ptr(node_off), _lib.ptr(ids), _lib.ptr(pos),
-                  _lib.ptr(rowptr_in), _lib.ptr(col_src), _lib.ptr(eid_in), _lib.ptr(rowptr_out), _lib.ptr(col_dst), _lib.ptr(pos_out), st)
+                  _lib.ptr(job.anchors), _lib.ptr(job.exclude), G, job.expand_factor, job.seed, job.index_base, _lib.ptr(node_off), _lib.ptr(ids),
+                  _lib.ptr(pos), _lib.ptr(rowptr_in), _lib.ptr(col_src), _lib.ptr(eid_in), _lib.ptr(rowptr_out), _lib.ptr(col_dst),
+                  _lib.ptr(pos_out), _lib.stream_ptr())
     csr = CSR(N, E, G, rowptr_in[:N + 1], col_src[:E], eid_in[:E], rowptr_out[:N + 1], col_dst[:E], pos_out[:E], node_off[:G + 1])
     g = DeviceBatchedGraph(csr, node_off[:G + 1], ids[:N], pos[:N])
     if with_features and dtax.features is not None:
@@ -351,3 +381,11 @@ def device_egonet_batch(dtax, anchors, exclude=None, expand_factor=50, seed=0, w
         else:
             g.ndata["x"] = dtax.features.index_select(0, ids[:N].long())
     return g
+
+
+def device_egonet_batch(dtax, anchors, exclude=None, expand_factor=50, seed=0, with_features=True, index_base=0):
+    """Batched egonets of `anchors` built on the GPU (dataset.py:404-437 + dgl.batch).  anchors / exclude: int arrays or
+    int32 device tensors.  Returns a DeviceBatchedGraph with ndata '_id', 'pos' (int32, device) and 'x' (features gathered;
+    with_features="lazy": an ops.GatheredRows over the taxonomy's feature table).  index_base: position of anchors[0] in the caller's whole
+    anchor list -- chunks of one list (test_fast.py's `-b`) then sample the same siblings as the single batch."""
+    return device_egonet_finish(device_egonet_begin(dtax, anchors, exclude, expand_factor, seed, index_base), with_features)

@@ -577,7 +577,7 @@ class GATStackFunction(torch.autograd.Function):
         L = cfg.n_layers
         N = h.shape[0]
         states = []
-        with torch.cuda.device(h.device):
+        with _lib.on_device(h.device):
             kh = h.shape[1]
             ref = h.table if table else h
             for l in range(L):
@@ -665,7 +665,7 @@ class GATStackFunction(torch.autograd.Function):
         N = states[0].X.shape[0]
         grads = [None] * (4 * L)
         d_pw = None
-        with torch.cuda.device(d_res.device):
+        with _lib.on_device(d_res.device):
             if collapse:
                 d_pre, ld_dpre = None, 0
             elif cfg.final == "mean" and H > 1:
@@ -761,7 +761,7 @@ class GCNStackFunction(torch.autograd.Function):
         rpos = _i32(rpos, h.device) if (collapse and pw is not None) else None
         pwf = _f32(pw.reshape(-1)) if (collapse and pw is not None) else None
         states = []
-        with torch.cuda.device(h.device):
+        with _lib.on_device(h.device):
             st_ = _lib.stream_ptr()
             norm = gcn_norm(csr, h)
             kh = kh0
@@ -845,7 +845,7 @@ class GCNStackFunction(torch.autograd.Function):
         grads = [None] * (3 * L)
         collapse = (getattr(cfg, "final", None) == "collapse")
         d_pw = None
-        with torch.cuda.device(d_out.device):
+        with _lib.on_device(d_out.device):
             st_ = _lib.stream_ptr()
             N = states[0].X.shape[0]
             if collapse:
@@ -919,7 +919,7 @@ class ReadoutFunction(torch.autograd.Function):
         pos = _i32(pos, h.device) if pw is not None else None
         pwf = _f32(pw.reshape(-1)) if pw is not None else None
         hg, wsum = _empty((G, D), h), _empty((max(G, 1),), h)
-        with torch.cuda.device(h.device):
+        with _lib.on_device(h.device):
             call("txe_readout_fwd", ptr(csr.graph_off), G, ptr(h), ld_h, ptr(pos), ptr(pwf), D, ptr(hg), ptr(wsum),
                  _lib.stream_ptr())
         ctx.csr, ctx.pos, ctx.misc = csr, pos, (h, ld_h, pwf, hg, wsum)
@@ -936,7 +936,7 @@ class ReadoutFunction(torch.autograd.Function):
         vocab = 0 if pwf is None else pwf.numel()
         d_pw = torch.empty_like(pwf) if pwf is not None else None
         ws = _empty((max(G, 1) * max(vocab, 1),), h) if pwf is not None else None
-        with torch.cuda.device(h.device):
+        with _lib.on_device(h.device):
             call("txe_readout_bwd", ptr(csr.graph_off), G, ptr(h), ld_h, ptr(pos), ptr(pwf), vocab, D, ptr(hg), ptr(wsum), ptr(d_hg),
                  ptr(d_h), D, ptr(d_pw), ptr(ws), _lib.stream_ptr())
         return None, d_h, None, (d_pw.reshape(ctx.pw_shape) if d_pw is not None else None)
@@ -953,7 +953,7 @@ class ReadoutMultiFunction(torch.autograd.Function):
         pos = _i32(pos, h.device) if mode == 3 else None
         hg = _empty((G, 3 * D if mode == 3 else D), h)
         argmax = torch.empty((max(G, 1), D), dtype=torch.int32, device=h.device) if mode == 2 else None
-        with torch.cuda.device(h.device):
+        with _lib.on_device(h.device):
             call("txe_readout_multi_fwd", ptr(csr.graph_off), G, ptr(h), ld_h, ptr(pos), D, mode, ptr(hg), ptr(argmax), _lib.stream_ptr())
         ctx.misc = (csr, pos, mode, argmax, h.shape[0], D)
         return hg
@@ -963,7 +963,7 @@ class ReadoutMultiFunction(torch.autograd.Function):
         csr, pos, mode, argmax, N, D = ctx.misc
         d_hg = _f32(d_hg)
         d_h = _empty((N, D), d_hg)
-        with torch.cuda.device(d_hg.device):
+        with _lib.on_device(d_hg.device):
             call("txe_readout_multi_bwd", ptr(csr.graph_off), csr.n_graphs, ptr(pos), D, mode, ptr(d_hg), ptr(argmax), ptr(d_h), D,
                  _lib.stream_ptr())
         return None, d_h, None, None
@@ -985,7 +985,7 @@ class LinearFunction(torch.autograd.Function):
         Wf, bf = _f32(W), _f32(b)
         G, O = x1.shape[0], Wf.shape[0]
         y = _empty((G, O), x1)
-        with torch.cuda.device(x1.device):
+        with _lib.on_device(x1.device):
             call("txe_linear_fwd", ptr(x1), ld1, l, ptr(x2), ld2, r, G, ptr(Wf), ptr(bf), O, int(act), ptr(y), _lib.stream_ptr())
         ctx.misc = (x1, ld1, l, x2, ld2, r, Wf, bf is not None, int(act), y)
         ctx.req = (ctx.needs_input_grad[0], ctx.needs_input_grad[1])
@@ -1001,7 +1001,7 @@ class LinearFunction(torch.autograd.Function):
         dx2 = _empty((G, r), y) if (need2 and x2 is not None) else None
         dW = torch.empty_like(Wf)
         db = _empty((O,), y) if has_b else None
-        with torch.cuda.device(y.device):
+        with _lib.on_device(y.device):
             wsb = call("txe_linear_bwd_ws_bytes", G, l, r, O)
             ws = _ws(wsb, y)
             call("txe_linear_bwd", ptr(x1), ld1, l, ptr(x2), ld2, r, G, ptr(Wf), O, act, ptr(y), ptr(dy), ptr(dx1), l, ptr(dx2), r, ptr(dW),
@@ -1032,7 +1032,7 @@ def bilinear_query_prefetch(e2, W):
         tok["launched"] = True
         if on_side:
             _order(torch.cuda.current_stream(e2.device), side)
-        with torch.cuda.device(e2.device), torch.cuda.stream(side if on_side else torch.cuda.current_stream(e2.device)):
+        with _lib.on_device(e2.device), torch.cuda.stream(side if on_side else torch.cuda.current_stream(e2.device)):
             call("txe_bilinear_query_project", ptr(e2c), ld2, G, l, r, ptr(Wf), ptr(V), _lib.stream_ptr())
         if on_side:
             # V was allocated on the caller's stream and is written on the second one: tell the caching allocator, so that a token
@@ -1075,7 +1075,7 @@ class BilinearPairFunction(torch.autograd.Function):
         r = e2.shape[1]
         s = _empty((G,), e1)
         query_side = not ctx.needs_input_grad[1]
-        with torch.cuda.device(e1.device):
+        with _lib.on_device(e1.device):
             if query_side:
                 ready = (pre is not None and pre["e2"] is e2_in and pre["e2_version"] == e2_in._version and pre["W"] is W
                          and pre["W_version"] == W._version and tuple(pre["V"].shape) == (G, l))
@@ -1103,7 +1103,7 @@ class BilinearPairFunction(torch.autograd.Function):
         ds = _f32(ds.reshape(-1))
         d_e1 = _empty((G, l), e1)
         dW = torch.empty_like(Wf)
-        with torch.cuda.device(e1.device):
+        with _lib.on_device(e1.device):
             if query_side:
                 wsb = call("txe_bilinear_query_bwd_ws_bytes", G, l, r)
                 ws = _ws(wsb, e1)
@@ -1133,7 +1133,7 @@ def bilinear_project(hg, W):
     rp = (r + 31) // 32 * 32
     Ufull = torch.zeros((max(G, 1), rp), dtype=torch.float32, device=hg.device) if rp != r else _empty((max(G, 1), rp), hg)
     U = Ufull[:G, :r]
-    with torch.cuda.device(hg.device):
+    with _lib.on_device(hg.device):
         call("txe_bilinear_project", ptr(hg), ld, G, l, ptr(Wf), r, ptr(U), rp, _lib.stream_ptr())
     _ZERO_PADDED[U.data_ptr()] = (rp, weakref.ref(Ufull))
     return U
@@ -1177,7 +1177,7 @@ def score_block(Q, U, apply_exp, out=None):
         Q, ldq = Qp, Qp.stride(0)
     G = U.shape[0]
     S = out if out is not None else _empty((nq, (G + 3) // 4 * 4), Q)[:, :G]     # 16-byte row pitch: vector stores / rank sweeps
-    with torch.cuda.device(Q.device):
+    with _lib.on_device(Q.device):
         tws = _tail_ws(Q)
         call("txe_score_block", ptr(Q), ldq, nq, ptr(U), ldu, G, r, int(apply_exp), ptr(S), S.stride(0), ptr(tws), tws.numel(), _lib.stream_ptr())
     return S
@@ -1218,7 +1218,7 @@ def positive_scores_staircase(Q, Up, apply_exp, pos_off, out):
     ldq = Q.stride(0)
     Up, ldu = _rows(Up)
     assert Q.stride(1) == 1 and out.dtype == torch.float32 and out.is_contiguous() and out.numel() >= Up.shape[0]
-    with torch.cuda.device(Q.device):
+    with _lib.on_device(Q.device):
         call("txe_score_positives", ptr(Q), ldq, Q.shape[0], ptr(Up), ldu, Up.shape[0], Q.shape[1], int(apply_exp), ptr(pos_off), ptr(out),
              _lib.stream_ptr())
     return out
@@ -1253,7 +1253,7 @@ def score_count_block(Q, U, apply_exp, pos_off, thr, larger_is_better=True, coun
     if thr.numel() == 0:                                # a query block without a single positive: nothing to count
         return counts
     assert counts.dtype == torch.int32 and counts.is_contiguous() and counts.numel() >= thr.numel()
-    with torch.cuda.device(Q.device):
+    with _lib.on_device(Q.device):
         call("txe_score_count_block", ptr(Q), ldq, nq, ptr(U), ldu, U.shape[0], r, int(apply_exp), ptr(pos_off), ptr(thr),
              int(larger_is_better), ptr(counts), _lib.stream_ptr())
     return counts
@@ -1267,7 +1267,7 @@ def rank_finalize(pos_off, thr, counts, larger_is_better=True, out=None):
     ranks = out if out is not None else torch.empty(max(n_pos, 1), dtype=torch.int32, device=thr.device)
     if n_pos == 0:
         return ranks[:0]
-    with torch.cuda.device(thr.device):
+    with _lib.on_device(thr.device):
         call("txe_rank_finalize", ptr(pos_off), int(pos_off.numel()) - 1, ptr(_f32(thr)), ptr(counts), int(larger_is_better), ptr(ranks),
              _lib.stream_ptr())
     return ranks[:n_pos]
@@ -1280,7 +1280,7 @@ def rank_block(S, pos_off, pos_idx, larger_is_better=True):
     pos_off = _i32(pos_off, S.device)
     pos_idx = _i32(pos_idx, S.device)
     ranks = torch.empty(max(int(pos_idx.numel()), 1), dtype=torch.int32, device=S.device)
-    with torch.cuda.device(S.device):
+    with _lib.on_device(S.device):
         call("txe_rank_block", ptr(S), S.stride(0), nq, G, ptr(pos_off), ptr(pos_idx), ptr(ranks), int(larger_is_better), None,
              _lib.stream_ptr())
     return ranks[:pos_idx.numel()]

@@ -48,4 +48,22 @@ for i in range(20):
     bench.train_step(model, opt, b, target, 1)
 pr.disable()
 torch.cuda.synchronize()
-pstats.Stats(pr).sort_stats("tottime").print_stats(28)
+pstats.Stats(pr).sort_stats("tottime").print_stats(40)
+pstats.Stats(pr).sort_stats("cumtime").print_stats(70)
+
+# un-instrumented segment clocks of one iteration (host time only)
+from taxoexpan_amd.loss import info_nce_loss
+seg = dict(build=0.0, zero=0.0, fwd=0.0, loss=0.0, bwd=0.0, opt=0.0)
+n = 30
+for i in range(n):
+    t0 = time.perf_counter(); b = bench.fresh_batch(tax, dtax, 400 + i, dev, side)
+    t1 = time.perf_counter(); g = b["g"]; g.ndata["pos"] = b["pos"]; opt.zero_grad(set_to_none=True)
+    t2 = time.perf_counter(); pred = model(g, b["x"], b["qf"])
+    t3 = time.perf_counter(); loss = info_nce_loss(pred.reshape(bench.N_QUERIES, -1), target)
+    t4 = time.perf_counter(); loss.backward()
+    t5 = time.perf_counter(); opt.step()
+    t6 = time.perf_counter()
+    for k, d in zip(seg, (t1 - t0, t2 - t1, t3 - t2, t4 - t3, t5 - t4, t6 - t5)):
+        seg[k] += d
+torch.cuda.synchronize()
+print("host ms per step:", {k: round(v / n * 1e3, 3) for k, v in seg.items()})

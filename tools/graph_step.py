@@ -19,8 +19,19 @@ from taxoexpan_amd.optim import Adam  # noqa: E402
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--workload", default="pgat")
+    ap.add_argument("--engine-threads", action="store_true", help="leave autograd's per-device engine thread on (the capture then dies)")
     a = ap.parse_args()
+    torch.autograd.set_multithreading_enabled(a.engine_threads)       # backward on the calling thread: the thread that captures
     dev = torch.device("cuda:0")
+    # EVERYTHING runs on the stream that will capture: parameters' AccumulateGrad nodes outlive an iteration (g.ndata['h'] of a resident
+    # batch keeps the last step's autograd graph alive) and keep the stream they were made on -- made on the default stream they would
+    # drag the legacy stream into the capture
+    s = torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(s):
+        run(a, dev, s)
+
+
+def run(a, dev, s):
     torch.manual_seed(47)
     tax = syn.make_named_taxonomy("mag_full" if a.workload == "pgat2" else "mag_cs", seed=47)
     model = bench.make_model(a.workload, dev)
@@ -41,20 +52,16 @@ def main():
         torch.cuda.synchronize()
         return (time.perf_counter() - t) / n * 1e3
     it = iter(range(10 ** 9))
-    print(f"eager  {timeit(lambda: bench.train_step(model, opt, batches[next(it) % 2], target, 1)):.4f} ms/step")
+    print(f"eager  {timeit(lambda: bench.train_step(model, opt, batches[next(it) % 2], target, 1)):.4f} ms/step", flush=True)
     graphs = []
     for b in batches:
         g = torch.cuda.CUDAGraph()
-        s = torch.cuda.Stream()
-        s.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(s):
-            bench.train_step(model, opt, b, target, 1)          # (warm-up on the capture stream)
-        torch.cuda.current_stream().wait_stream(s)
-        with torch.cuda.graph(g):
+        with torch.cuda.graph(g, stream=s):
             bench.train_step(model, opt, b, target, 1)
         graphs.append(g)
+        print("captured", flush=True)
     torch.cuda.synchronize()
-    print(f"graph  {timeit(lambda: graphs[next(it) % 2].replay()):.4f} ms/step")
+    print(f"graph  {timeit(lambda: graphs[next(it) % 2].replay()):.4f} ms/step", flush=True)
 
 
 if __name__ == "__main__":

@@ -777,11 +777,11 @@ struct KName {
     } while (0)
 
 // destination nodes per wave of the forward sweep (gat_aggregate_fwd_kernel's NPW): two -- 97 -> 93 us in the training step, 77 -> 72 us
-// stand-alone (tools/agg_fwd_variants.py); TXE_FWD_NPW = 1 | 2 | 4 overrides
+// stand-alone (tools/agg_fwd_variants.py); TXE_FWD_NPW = 1 | 2 overrides
 static inline int fwd_nodes_per_wave(int n_nodes) {
     static const int forced = [] { const char* e = getenv("TXE_FWD_NPW"); return e ? atoi(e) : 0; }();
-    if (forced == 1 || forced == 2 || forced == 4) return forced;
-    return n_nodes >= 4096 ? 2 : 1;       // (4 per wave: 173 VGPRs = two waves per SIMD, 119 us against 93 us on the training batch)
+    if (forced == 1 || forced == 2) return forced;
+    return n_nodes >= 4096 ? 2 : 1;       // (4 per wave was measured too: 173 VGPRs = two waves per SIMD, 119 us against 93 us)
 }
 
 static inline int pick_vec(int D, long long ld1, long long ld2, const void* p1, const void* p2) {
@@ -830,7 +830,7 @@ int txe_gat_aggregate_fwd(const int* rowptr_in, const int* col_src, int n_nodes,
     hipLaunchKernelGGL((gat_aggregate_fwd_kernel<V, I, M, false, P>), dim3(nb), dim3(GAT_WAVES * 64), LDS, s, rowptr_in, col_src, n_nodes, \
                        ft, ld_ft, a_src, a_dst, ld_a, H, D, attn_slope, attn_drop_p, scale, seed, out_mode, act_slope,            \
                        out, ld_out, alpha, nx, TabSrc{nullptr, nullptr, nullptr, 0})
-#define TXE_LP(V, I, M, LDS) do { if (npw == 4) TXE_LK(V, I, M, 4, LDS); else if (npw == 2) TXE_LK(V, I, M, 2, LDS); else TXE_LK(V, I, M, 1, LDS); } while (0)
+#define TXE_LP(V, I, M, LDS) do { if (npw == 2) TXE_LK(V, I, M, 2, LDS); else TXE_LK(V, I, M, 1, LDS); } while (0)
 #define TXE_L(V, I) TXE_LP(V, I, 0, 0)
 #define TXE_LXM(I, M) TXE_LP(4, I, M, (size_t)2 * nx_kp * sizeof(float))
 #define TXE_LX(I) do { if (nx.mask) TXE_LXM(I, 2); else TXE_LXM(I, 1); } while (0)

@@ -457,6 +457,55 @@ def test_split_k_tn_product_with_lds_direct_copies(M, N, K, S, tmp_path):
     assert np.array_equal(outs["old"][:, :, :N], got[:, :, :N])
 
 
+def test_forward_sweep_two_nodes_per_wave_is_bit_equal_to_one(tmp_path):
+    """gat_aggregate_fwd_kernel with NPW = 2 (the heads of two nodes' load chains fetched together, txe_gat.hip) against NPW = 1 on a
+    generic multigraph -- hubs above 64 in-edges, nodes without in-edges, an odd node count (a wave with one node), the last node a
+    hub -- in all four epilogue modes (plain, the next layer's logits with and without its mask, that layer's dropout on the rows):
+    out, alpha and the logits bit for bit.  TXE_FWD_NPW is read once per process: two subprocesses."""
+    import subprocess
+    import sys
+    code = """
+import numpy as np, torch, sys
+sys.path.insert(0, %r)
+from taxoexpan_amd import _lib
+from taxoexpan_amd._lib import call, ptr
+rs = np.random.RandomState(3)
+N, H, D, kp = 4099, 4, 52, 224
+deg = rs.randint(0, 6, size=N); deg[[5, 77, N - 1]] = [70, 200, 130]; deg[[6, 7, 4000]] = 0
+rowptr = np.concatenate([[0], np.cumsum(deg)]).astype(np.int32)
+col = rs.randint(0, N, size=int(rowptr[-1])).astype(np.int32)
+dev = 'cuda'
+rp, cl = torch.from_numpy(rowptr).to(dev), torch.from_numpy(col).to(dev)
+ft = torch.from_numpy(rs.standard_normal((N, H * D)).astype(np.float32)).to(dev)
+a12 = torch.from_numpy(rs.standard_normal((N, 2 * H)).astype(np.float32)).to(dev)
+wa = torch.from_numpy(rs.standard_normal((2, kp)).astype(np.float32)).to(dev)
+mask = torch.from_numpy(rs.randint(0, 2 ** 31, size=(N, kp // 32)).astype(np.int32)).to(dev)
+res = {}
+for mode, (nx, nx_p, use_mask) in dict(plain=(False, 0.0, False), logits=(True, 0.0, False), logits_mask=(True, 0.5, True), rows_dropped=(False, 0.5, True)).items():
+    for attn_p, keep in ((0.0, False), (0.3, True)):
+        out = torch.full((N, kp), 0.25, device=dev)
+        alpha = torch.full((int(rowptr[-1]) * H + 1,), -1.0, device=dev)
+        nxa = torch.full((N, 2), -1.0, device=dev)
+        call('txe_gat_aggregate_fwd', ptr(rp), ptr(cl), N, ptr(ft), H * D, ptr(a12), ptr(a12[:, H:]), 2 * H, H, D, 0.2, attn_p, 99, 1, 0.01,
+             ptr(out), kp, ptr(alpha) if keep else None, ptr(wa) if nx else None, kp, ptr(mask) if use_mask else None, nx_p, ptr(nxa) if nx else None,
+             _lib.stream_ptr())
+        torch.cuda.synchronize()
+        k = mode + ('_train' if keep else '_eval')
+        res[k + '_out'], res[k + '_alpha'], res[k + '_nx'] = out.cpu().numpy(), alpha.cpu().numpy(), nxa.cpu().numpy()
+np.savez(%r + '/npw' + sys.argv[1] + '.npz', **res)
+""" % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), str(tmp_path))
+    outs = {}
+    for npw in ("1", "2"):
+        r = subprocess.run([sys.executable, "-c", code, npw], env=dict(os.environ, TXE_FWD_NPW=npw), capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs[npw] = np.load(os.path.join(str(tmp_path), f"npw{npw}.npz"))
+    assert len(outs["1"].files) == 24
+    for k in outs["1"].files:
+        assert np.isfinite(outs["1"][k]).all(), k
+        assert np.array_equal(outs["1"][k], outs["2"][k]), k
+    assert not np.array_equal(outs["1"]["plain_eval_out"][:, :208], np.full((4099, 208), 0.25, dtype=np.float32))
+
+
 def test_readout_and_match_ops_against_oracle():
     from taxoexpan_amd import ops
     from taxoexpan_amd.graph import BatchedDGLGraph

@@ -7,4 +7,5 @@ for sw in TXE_NO_BALANCED_SPLITS TXE_NO_PERSIST_GEMM TXE_NO_PERSIST_SLICES TXE_N
   echo -n "$sw=1: "; env $sw=1 python -m pytest tests -m gpu -q -p no:cacheprovider 2>&1 | grep -E "passed|failed|error" | tail -1
 done
 echo -n "TXE_TORCH_EVENTS=1: "; TXE_TORCH_EVENTS=1 python -m pytest tests -m gpu -q -p no:cacheprovider 2>&1 | grep -E "passed|failed|error" | tail -1
+echo -n "TXE_FWD_NPW=1: "; TXE_FWD_NPW=1 python -m pytest tests -m gpu -q -p no:cacheprovider 2>&1 | grep -E "passed|failed|error" | tail -1
 for v in 0 1; do echo -n "TXE_PREFETCH_V=$v: "; TXE_PREFETCH_V=$v python -m pytest tests -m gpu -q -p no:cacheprovider 2>&1 | grep -E "passed|failed|error" | tail -1; done

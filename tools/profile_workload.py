@@ -9,6 +9,8 @@ import sys
 import numpy as np
 import torch
 
+torch.autograd.set_multithreading_enabled(False)     # as bench.py: the backward runs on the calling thread
+
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench  # noqa: E402
 from taxoexpan_amd import synthetic as syn  # noqa: E402

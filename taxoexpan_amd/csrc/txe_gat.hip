@@ -767,6 +767,7 @@ struct KName {
     KName(const char* base, int a) { snprintf(s, sizeof(s), "%s<%d>", base, a); }
     KName(const char* base, int a, int b, int c) { snprintf(s, sizeof(s), "%s<%d, %d, %d>", base, a, b, c); }
     KName(const char* base, int a, int b, int c, bool d) { snprintf(s, sizeof(s), "%s<%d, %d, %d, %s>", base, a, b, c, d ? "true" : "false"); }
+    KName(const char* base, int a, int b, int c, bool d, int e) { snprintf(s, sizeof(s), "%s<%d, %d, %d, %s, %d>", base, a, b, c, d ? "true" : "false", e); }
 };
 
 #define TXE_DISPATCH_VEC_NI(vec, ni, LAUNCH)                                     \
@@ -824,7 +825,7 @@ int txe_gat_aggregate_fwd(const int* rowptr_in, const int* col_src, int n_nodes,
     const int ni = pick_ni(H * D / vec);
     const int npw = fwd_nodes_per_wave(n_nodes);
     const int nb = (n_nodes + GAT_WAVES * npw - 1) / (GAT_WAVES * npw);
-    const KName kn("gat_aggregate_fwd_kernel", vec, ni, nx_a12 ? (nx.mask ? 2 : 1) : (out_drop ? 3 : 0), false);
+    const KName kn("gat_aggregate_fwd_kernel", vec, ni, nx_a12 ? (nx.mask ? 2 : 1) : (out_drop ? 3 : 0), false, npw);
     ProfScope prof(kn.s, s, 4.0 * (2.0 * n_nodes * (double)H * D + 2.0 * n_nodes * H + n_nodes + 1), 1);
 #define TXE_LK(V, I, M, P, LDS)                                                                                                   \
     hipLaunchKernelGGL((gat_aggregate_fwd_kernel<V, I, M, false, P>), dim3(nb), dim3(GAT_WAVES * 64), LDS, s, rowptr_in, col_src, n_nodes, \
@@ -874,7 +875,7 @@ int txe_gat_aggregate_table_fwd(const int* rowptr_in, const int* col_src, int n_
     tab.rid = rid; tab.pos = pos; tab.t2 = T2; tab.vocab = vocab;
     const int ni = pick_ni(H * D / 4);
     const size_t lds = table_lds_bytes(ld_t, vocab, nx.kp);
-    const KName kn("gat_aggregate_fwd_kernel", 4, ni, nx_a12 ? 1 : 0, true);
+    const KName kn("gat_aggregate_fwd_kernel", 4, ni, nx_a12 ? 1 : 0, true, 1);
     ProfScope prof(kn.s, s, 4.0 * (2.0 * n_nodes * (double)H * D + 2.0 * n_nodes * H + 3.0 * n_nodes + 1), 1);
 #define TXE_LT(I, X)                                                                                                              \
     hipLaunchKernelGGL((gat_aggregate_fwd_kernel<4, I, X, true>), dim3(nb), dim3(GAT_WAVES * 64), lds, s, rowptr_in, col_src, n_nodes, T, \

@@ -97,7 +97,7 @@ def build_batches(tax, n_batches, seed0, device):
     return out
 
 
-def fresh_batch_begin(tax, dtax, seed, device, stream=None):
+def fresh_batch_begin(tax, dtax, seed, device, stream=None, repeated_queries=False):
     """a NEW training batch, first half (data_loaders.begin_device_batch): anchors sampled on the host (the reference's sampler is host
     Python too), uploaded, the egonets' node counts launched on `stream` -- nothing waited for"""
     from taxoexpan_amd.data_loaders import begin_device_batch
@@ -111,7 +111,8 @@ def fresh_batch_begin(tax, dtax, seed, device, stream=None):
     anchors = anchors.reshape(-1)
     exclude = np.full((N_QUERIES, 1 + NEG), -1, dtype=np.int64)
     exclude[:, 0] = queries
-    return begin_device_batch(dtax, anchors, exclude.reshape(-1), np.repeat(queries, 1 + NEG), expand_factor=50, seed=seed + 1, stream=stream)
+    return begin_device_batch(dtax, anchors, exclude.reshape(-1), np.repeat(queries, 1 + NEG), expand_factor=50, seed=seed + 1, stream=stream,
+                              repeated_queries=repeated_queries)
 
 
 def fresh_batch(tax, dtax, seed, device, stream=None):
@@ -617,6 +618,27 @@ def main():
         dist.all_reduce(e, op=dist.ReduceOp.SUM)
         edges = float(e.item())
 
+    # the same resident batches with the query features as ops.RepeatedRows -- one row per query + the runs of its 1 + NEG pairs, what
+    # data_loaders.DeviceBatchLoader hands out -- instead of the reference collate's stack of one row per pair (data_loaders.py:9-28):
+    # BIM / LBM then project 128 rows instead of 4,096.  Reported beside `value`, which stays on the reference's input format.
+    rq_ms = None
+    if args.workload == "pgat" and world == 1:
+        from taxoexpan_amd import ops as _ops
+        rq_batches = []
+        for b in batches:
+            q = b["qf"].cpu().numpy()
+            rid = np.concatenate([[0], np.cumsum(np.any(q[1:] != q[:-1], axis=1))])
+            first = np.concatenate([[True], rid[1:] != rid[:-1]])
+            rq_batches.append(dict(b, qf=_ops.RepeatedRows.from_ids(torch.from_numpy(q[first]).to(device), rid)))
+        for i in range(min(args.warmup, 5)):
+            train_step(model, opt, rq_batches[i % len(batches)], target, world)
+        torch.cuda.synchronize()
+        tq0 = time.perf_counter()
+        for i in range(args.steps):
+            train_step(model, opt, rq_batches[i % len(batches)], target, world)
+        torch.cuda.synchronize()
+        rq_ms = 1e3 * (time.perf_counter() - tq0) / max(args.steps, 1)
+
     # the same step with a NEW batch built inside it (what an epoch of train.py pays per step): not `value` -- the contract times the
     # hot path on resident inputs -- but reported next to it
     from taxoexpan_amd import graph as Gr
@@ -627,18 +649,25 @@ def main():
     for i in range(3):
         train_step(model, opt, fresh_batch(tax, dtax, 5000 + i, device, build_stream), target, world)
     torch.cuda.synchronize()
-    tf0 = time.perf_counter()
-    fresh_edges = 0
     from taxoexpan_amd.data_loaders import finish_device_batch
-    pend = fresh_batch_begin(tax, dtax, 6000 + rank, device, build_stream)
-    for i in range(n_fresh):                             # DeviceBatchLoader's schedule: batch i+1 is begun (sampled, uploaded, node
-        b = finish_device_batch(pend, dtax.features)     # counts launched) before step i is enqueued, finished after it
-        if i + 1 < n_fresh:
-            pend = fresh_batch_begin(tax, dtax, 6000 + 17 * (i + 1) + rank, device, build_stream)
-        train_step(model, opt, b, target, world)
-        fresh_edges += b["n_edges"]
-    torch.cuda.synchronize()
-    fresh_ms = 1e3 * (time.perf_counter() - tf0) / max(n_fresh, 1)
+
+    def fresh_loop(repeated):
+        for i in range(2):
+            train_step(model, opt, finish_device_batch(fresh_batch_begin(tax, dtax, 5500 + i, device, build_stream, repeated), dtax.features), target, world)
+        torch.cuda.synchronize()
+        t0f = time.perf_counter()
+        n_edges = 0
+        pend = fresh_batch_begin(tax, dtax, 6000 + rank, device, build_stream, repeated)
+        for i in range(n_fresh):                             # DeviceBatchLoader's schedule: batch i+1 is begun (sampled, uploaded, node
+            b = finish_device_batch(pend, dtax.features)     # counts launched) before step i is enqueued, finished after it
+            if i + 1 < n_fresh:
+                pend = fresh_batch_begin(tax, dtax, 6000 + 17 * (i + 1) + rank, device, build_stream, repeated)
+            train_step(model, opt, b, target, world)
+            n_edges += b["n_edges"]
+        torch.cuda.synchronize()
+        return 1e3 * (time.perf_counter() - t0f) / max(n_fresh, 1), n_edges
+    fresh_ms, fresh_edges = fresh_loop(False)                # query features stacked per pair, as the reference's collate hands them over
+    fresh_rq_ms, _ = fresh_loop(True)                        # ... as ops.RepeatedRows (DeviceBatchLoader's default): one row per query
     tb0 = time.perf_counter()
     for i in range(n_fresh):
         fresh_batch(tax, dtax, 9000 + i, device)
@@ -739,7 +768,8 @@ def main():
             "roofline": roofline,
             # flat scalars, last so that they end the line: a fresh batch built inside every step (device egonet builder, one host sync),
             # and the secondary halves of BASELINE.json's metric
-            "step_incl_batch_build_ms": fresh_ms, "batch_build_ms": build_ms,
+            "step_incl_batch_build_ms": fresh_ms, "batch_build_ms": build_ms, "step_incl_batch_build_repeated_queries_ms": fresh_rq_ms,
+            "step_repeated_queries_ms": rq_ms,
             "egonet_edges_per_s_incl_batch_build": world * fresh_edges / max(n_fresh, 1) / (fresh_ms * 1e-3),
         }
         if extra:

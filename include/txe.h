@@ -193,6 +193,18 @@ int txe_bilinear_query_bwd(const float* e1, long long ld_e1, const float* e2, lo
                            const float* V, const float* s, const float* ds, float* d_e1, long long ld_de1, float* dW, void* ws,
                            size_t ws_bytes, void* stream);
 
+/* the pairwise match when the query rows repeat in RUNS: a training batch pairs one query with 1 + negative_size consecutive anchors and
+ * data_loaders.py:9-28 stacks that query's row once per pair (trainer.py:46,51 hands the stack to model.py:86).  Qu [U][r] = the
+ * distinct rows, run_off [U+1] = first pair of every run (run_off[U] = G): V = Qu W^T [U][l] is U rows instead of G, s_i = <e1_i, V[run(i)]>;
+ * backward d_e1_i = dsl_i V[run(i)], dW = S^T Qu with S[u] = sum over run u (pairs in order) of dsl_i e1_i -- K = U instead of G.  Same values
+ * as txe_bilinear_query_* on the stacked rows up to the summation order of dW. */
+int txe_bilinear_runs_fwd(const float* e1, long long ld_e1, const float* Qu, long long ld_q, const int* run_off, int G, int U, int l, int r,
+                          const float* W, int apply_exp, float* V, float* s, void* stream);
+size_t txe_bilinear_runs_bwd_ws_bytes(int U, int l, int r);
+int txe_bilinear_runs_bwd(const float* e1, long long ld_e1, const float* Qu, long long ld_q, const int* run_off, int G, int U, int l, int r,
+                          int apply_exp, const float* V, const float* s, const float* ds, float* d_e1, long long ld_de1, float* dW, void* ws,
+                          size_t ws_bytes, void* stream);
+
 /* nn.Linear over the (virtual) concat of two inputs + activation (0 none / 1 relu / 2 tanh): the MLP matcher, model_zoo.py:285-298 */
 int txe_linear_fwd(const float* x1, long long ld1, int l, const float* x2, long long ld2, int r, int G, const float* W, const float* b,
                    int O, int act, float* y, void* stream);

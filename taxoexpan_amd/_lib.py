@@ -54,6 +54,9 @@ SIGNATURES = {
     "txe_bilinear_query_dot": (I, [P, L, P, I, I, I, P, P]),
     "txe_bilinear_query_bwd_ws_bytes": (SZ, [I, I, I]),
     "txe_bilinear_query_bwd": (I, [P, L, P, L, I, I, I, I, P, P, P, P, L, P, P, SZ, P]),
+    "txe_bilinear_runs_fwd": (I, [P, L, P, L, P, I, I, I, I, P, I, P, P, P]),
+    "txe_bilinear_runs_bwd_ws_bytes": (SZ, [I, I, I]),
+    "txe_bilinear_runs_bwd": (I, [P, L, P, L, P, I, I, I, I, I, P, P, P, P, L, P, P, SZ, P]),
     "txe_bilinear_pair_bwd_ws_bytes": (SZ, [I, I, I]),
     "txe_bilinear_pair_bwd": (I, [P, L, P, L, I, I, I, P, I, P, P, P, P, L, P, L, P, P, SZ, P]),
     "txe_score_block": (I, [P, L, I, P, L, I, I, I, P, L, P, SZ, P]),

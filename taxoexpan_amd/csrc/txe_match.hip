@@ -120,6 +120,122 @@ __global__ void colsum_small_kernel(const float* __restrict__ x, long long n_row
     if (threadIdx.x == 0) out[o] = red[0];
 }
 
+// ---- the pairwise match when the query rows repeat in RUNS (txe_bilinear_runs_*) ------------------------------------------------------
+// s_i = <e1_i, V[u]> for the pairs i of run u: gridDim.y workgroups per run, V[u] in registers, one wave per pair
+__global__ __launch_bounds__(256) void rowdot_runs_kernel(const float* __restrict__ e1, long long ld_e1, const float* __restrict__ V,
+                                                          const int* __restrict__ run_off, int l, int apply_exp, float* __restrict__ s) {
+    const int u = blockIdx.x, w = threadIdx.x >> 6, ln = threadIdx.x & 63;
+    const int i0 = run_off[u], i1 = run_off[u + 1];
+    for (int k0 = 0; k0 < l; k0 += 64 * 8) {                    // (rows wider than 512 columns: several passes, partial sums in s)
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const int k = k0 + ln + 64 * j; v[j] = k < l ? V[(long long)u * l + k] : 0.f; }
+        for (int i = i0 + w + 4 * blockIdx.y; i < i1; i += 4 * gridDim.y) {
+            float acc = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const int k = k0 + ln + 64 * j; acc = fmaf(k < l ? e1[(long long)i * ld_e1 + k] : 0.f, v[j], acc); }
+            acc = wave_sum(acc);
+            if (ln == 0) {
+                const float tot = (k0 == 0 ? 0.f : s[i]) + acc;
+                s[i] = (apply_exp && k0 + 64 * 8 >= l) ? __expf(tot) : tot;
+            }
+        }
+    }
+}
+
+// backward of the above for run u: d_e1_i = dsl_i V[u], S[u] = sum over the run's pairs (in order) of dsl_i e1_i; thread = column
+__global__ __launch_bounds__(256) void runs_bwd_kernel(const float* __restrict__ ds, const float* __restrict__ s, int apply_exp,
+                                                       const float* __restrict__ V, const float* __restrict__ e1, long long ld_e1,
+                                                       const int* __restrict__ run_off, int l, float* __restrict__ d_e1, long long ld_de1,
+                                                       float* __restrict__ S) {
+    const int u = blockIdx.x;
+    const int i0 = run_off[u], i1 = run_off[u + 1];
+    const int k = blockIdx.y * 256 + threadIdx.x;
+    if (k >= l) return;
+    const float v = V[(long long)u * l + k];
+    float acc = 0.f;
+    for (int i = i0; i < i1; i += 8) {                          // eight pairs' loads in flight; the sum keeps the pairs' order
+        float x[8], dsl[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int ii = min(i + q, i1 - 1);
+            x[q] = e1[(long long)ii * ld_e1 + k];
+            dsl[q] = apply_exp ? ds[ii] * s[ii] : ds[ii];
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            if (i + q < i1) {
+                d_e1[(long long)(i + q) * ld_de1 + k] = dsl[q] * v;
+                acc = fmaf(dsl[q], x[q], acc);
+            }
+        }
+    }
+    S[(long long)u * l + k] = acc;
+}
+
+// V[u][j] = <Qu[u], W[j]>: one wave per output row j and block of 8 runs, lanes along k (both rows read coalesced), W[j] kept in
+// registers.  A few hundred rows at most: the MFMA GEMM's 128-row tiles would leave most of the chip idle on such a product.
+__global__ __launch_bounds__(256) void runs_project_kernel(const float* __restrict__ Qu, long long ld_q, const float* __restrict__ W, int U,
+                                                           int l, int r, float* __restrict__ V) {
+    const int w = threadIdx.x >> 6, ln = threadIdx.x & 63;
+    const int j = blockIdx.x * 4 + w, u0 = blockIdx.y * 8;
+    if (j >= l) return;
+    float acc[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) acc[q] = 0.f;
+    for (int k0 = 0; k0 < r; k0 += 256) {
+        float wv[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { const int k = k0 + ln + 64 * c; wv[c] = k < r ? W[(long long)j * r + k] : 0.f; }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int u = min(u0 + q, U - 1);                   // clamped: the loads stay unconditional, the result is not stored
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { const int k = k0 + ln + 64 * c; acc[q] = fmaf(k < r ? Qu[(long long)u * ld_q + k] : 0.f, wv[c], acc[q]); }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const float t = wave_sum(acc[q]);
+        if (ln == 0 && u0 + q < U) V[(long long)(u0 + q) * l + j] = t;
+    }
+}
+
+// dW[j][k] = sum_u S[u][j] Qu[u][k] (runs in order): thread = column k, two rows j per workgroup, S's two columns staged in LDS
+__global__ __launch_bounds__(256) void runs_dw_kernel(const float* __restrict__ S, const float* __restrict__ Qu, long long ld_q, int U, int l,
+                                                      int r, float* __restrict__ dW) {
+    __shared__ float sS[256][2];
+    const int j0 = blockIdx.x * 2;
+    const int k = blockIdx.y * 256 + threadIdx.x, kc = min(k, r - 1);
+    float acc[2] = {0.f, 0.f};
+    for (int u0 = 0; u0 < U; u0 += 256) {
+        __syncthreads();
+        {
+            const int u = min(u0 + (int)threadIdx.x, U - 1);
+            sS[threadIdx.x][0] = S[(long long)u * l + j0];
+            sS[threadIdx.x][1] = S[(long long)u * l + min(j0 + 1, l - 1)];
+        }
+        __syncthreads();
+        const int n = min(256, U - u0);
+        for (int t0 = 0; t0 < n; t0 += 8) {                     // eight runs' loads in flight; the sum keeps the runs' order
+            float q[8];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) q[t] = Qu[(long long)(u0 + min(t0 + t, n - 1)) * ld_q + kc];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                if (t0 + t < n) {
+                    acc[0] = fmaf(sS[t0 + t][0], q[t], acc[0]);
+                    acc[1] = fmaf(sS[t0 + t][1], q[t], acc[1]);
+                }
+            }
+        }
+    }
+    if (k < r) {
+        dW[(long long)j0 * r + k] = acc[0];
+        if (j0 + 1 < l) dW[(long long)(j0 + 1) * r + k] = acc[1];
+    }
+}
+
 static inline size_t mt_align(size_t x) { return (x + 255) / 256 * 256; }
 
 static inline int mt_splits(int M, int N, int K) { return choose_splits(M, N, K); }
@@ -260,6 +376,54 @@ int txe_bilinear_query_bwd(const float* e1, long long ld_e1, const float* e2, lo
     const long long n = (long long)l * r;
     hipLaunchKernelGGL(reduce_splits_kernel2, dim3((int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048)), dim3(256), 0, st, (const float*)part,
                        G > 0 ? S : 0, E.split_stride, n, dW);
+    TXE_CHECK_LAUNCH();
+    return TXE_OK;
+}
+
+// The same match when the query rows REPEAT IN RUNS -- a training batch pairs one query with 1 + negative_size consecutive anchors
+// and the reference's collate stacks that query's row for each of them (data_loaders.py:9-28).  Qu [U][r]: the distinct rows;
+// run_off [U+1]: the first pair of every run, run_off[U] = G.  V = Qu W^T is U rows instead of G, backward's dW = S^T Qu with
+// S[u] = sum over run u of dsl_i e1_i (pairs in order: deterministic) has K = U instead of G; d_e1_i = dsl_i V[u].  Both U-row products
+// run on small dot-product kernels (a few hundred rows would leave the MFMA GEMM's 128-row tiles most of the chip idle: 41 + 29 us measured).
+int txe_bilinear_runs_fwd(const float* e1, long long ld_e1, const float* Qu, long long ld_q, const int* run_off, int G, int U, int l, int r,
+                          const float* W, int apply_exp, float* V, float* s, void* stream) {
+    if (G < 0 || U < 0 || l < 1 || r < 1 || !e1 || !Qu || !run_off || !W || !V || !s) return TXE_ERR_ARG;
+    if (G == 0 || U == 0) return TXE_OK;
+    {
+        ProfScope prof("runs_project_kernel", (hipStream_t)stream, 4.0 * ((double)U * r + (double)l * r + (double)U * l), 1);
+        hipLaunchKernelGGL(runs_project_kernel, dim3((l + 3) / 4, (U + 7) / 8), dim3(256), 0, (hipStream_t)stream, Qu, ld_q, W, U, l, r, V);
+    }
+    TXE_CHECK_LAUNCH();
+    {
+        ProfScope prof("rowdot_runs_kernel", (hipStream_t)stream, 4.0 * ((double)G * l + (double)U * l + G), 1);
+        hipLaunchKernelGGL(rowdot_runs_kernel, dim3(U, 8), dim3(256), 0, (hipStream_t)stream, e1, ld_e1, (const float*)V, run_off, l, apply_exp, s);
+    }
+    TXE_CHECK_LAUNCH();
+    return TXE_OK;
+}
+
+size_t txe_bilinear_runs_bwd_ws_bytes(int U, int l, int r) { return mt_align((size_t)(U > 0 ? U : 1) * l * 4); }
+
+int txe_bilinear_runs_bwd(const float* e1, long long ld_e1, const float* Qu, long long ld_q, const int* run_off, int G, int U, int l, int r,
+                          int apply_exp, const float* V, const float* s, const float* ds, float* d_e1, long long ld_de1, float* dW, void* ws,
+                          size_t ws_bytes, void* stream) {
+    if (G < 0 || U < 0 || l < 1 || r < 1 || !e1 || !Qu || !run_off || !V || !s || !ds || !d_e1 || !dW || !ws) return TXE_ERR_ARG;
+    if (ws_bytes < txe_bilinear_runs_bwd_ws_bytes(U, l, r)) return TXE_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    float* S = (float*)ws;
+    if (G == 0 || U == 0) {                                    // an empty sum
+        if (hipMemsetAsync(dW, 0, (size_t)l * r * sizeof(float), st) != hipSuccess) return TXE_ERR_LAUNCH;
+        return TXE_OK;
+    }
+    {
+        ProfScope prof("runs_bwd_kernel", st, 4.0 * (2.0 * G * l + 2.0 * U * l + 2.0 * G), 1);
+        hipLaunchKernelGGL(runs_bwd_kernel, dim3(U, (l + 255) / 256), dim3(256), 0, st, ds, s, apply_exp, V, e1, ld_e1, run_off, l, d_e1, ld_de1, S);
+    }
+    TXE_CHECK_LAUNCH();
+    {
+        ProfScope prof("runs_dw_kernel", st, 4.0 * ((double)U * l + (double)U * r + (double)l * r), 1);
+        hipLaunchKernelGGL(runs_dw_kernel, dim3((l + 1) / 2, (r + 255) / 256), dim3(256), 0, st, (const float*)S, Qu, ld_q, U, l, r, dW);
+    }
     TXE_CHECK_LAUNCH();
     return TXE_OK;
 }

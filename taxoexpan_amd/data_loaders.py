@@ -6,6 +6,7 @@ import os
 import itertools
 import logging
 
+import numpy as np
 import torch
 import torch.utils.data
 
@@ -102,9 +103,11 @@ class MaskedGraphDataLoader(torch.utils.data.DataLoader):
 _PINNED = {}
 
 
-def begin_device_batch(dtax, anchors, exclude, query_ids, expand_factor=50, seed=0, stream=None):
+def begin_device_batch(dtax, anchors, exclude, query_ids, expand_factor=50, seed=0, stream=None, repeated_queries=False):
     """First half of build_device_batch: the index arrays go up in one pinned copy and the egonets' node counts are computed, on
-    `stream` (default: the current stream); nothing is waited for.  Returns the job finish_device_batch completes."""
+    `stream` (default: the current stream); nothing is waited for.  Returns the job finish_device_batch completes.
+    repeated_queries: the batch's query features come back as ops.RepeatedRows -- the runs of equal consecutive query ids are found
+    here, on the host, and only the distinct rows are gathered (BIM / LBM then project U rows instead of one per pair)."""
     from .graph import device_egonet_begin
     dev = dtax.device
     main = torch.cuda.current_stream(dev)
@@ -114,25 +117,34 @@ def begin_device_batch(dtax, anchors, exclude, query_ids, expand_factor=50, seed
     # the three index arrays travel in ONE pinned buffer and one copy (each small pageable upload costs ~60 us of host time); two
     # buffers per size take turns, each guarded by the event of its last upload (a loader keeps two batches in flight)
     B = len(anchors)
-    ring = _PINNED.setdefault((3 * B, str(dev)), dict(k=0, slots=[None, None]))
+    ring = _PINNED.setdefault((B, str(dev)), dict(k=0, slots=[None, None]))
     ring["k"] ^= 1
     slot = ring["slots"][ring["k"]]
-    if slot is None:
-        slot = ring["slots"][ring["k"]] = [torch.empty(3 * B, dtype=torch.int32).pin_memory(), None]
+    if slot is None:                                              # [anchors | exclude | query ids | run offsets (<= B + 1)]
+        slot = ring["slots"][ring["k"]] = [torch.empty(4 * B + 1, dtype=torch.int32).pin_memory(), None]
     host, uploaded = slot
     if uploaded is not None:
         uploaded.synchronize()
     hv = host.numpy()
     hv[:B] = anchors
     hv[B:2 * B] = exclude if exclude is not None else -1
-    hv[2 * B:] = query_ids
+    n_runs = 0
+    if repeated_queries:                                          # distinct consecutive query ids + the first pair of every run
+        q = np.asarray(query_ids).reshape(-1)
+        start = np.flatnonzero(np.concatenate([[True], q[1:] != q[:-1]])) if B else np.zeros(0, dtype=np.int64)
+        n_runs = len(start)
+        hv[2 * B:2 * B + n_runs] = q[start]
+        hv[3 * B:3 * B + n_runs] = start
+        hv[3 * B + n_runs] = B
+    else:
+        hv[2 * B:3 * B] = query_ids
     with torch.cuda.stream(side):
         packed = host.to(dev, non_blocking=True)
         slot[1] = torch.cuda.Event()
         slot[1].record()
         job = device_egonet_begin(dtax, packed[:B], packed[B:2 * B] if exclude is not None else None, expand_factor=expand_factor, seed=seed)
         packed.record_stream(side)
-    return dict(job=job, packed=packed, B=B, side=side, dev=dev)
+    return dict(job=job, packed=packed, B=B, side=side, dev=dev, n_runs=n_runs if repeated_queries else None)
 
 
 def finish_device_batch(pending, features):
@@ -146,24 +158,31 @@ def finish_device_batch(pending, features):
     with torch.cuda.stream(side):
         g = device_egonet_finish(pending["job"], with_features=True)
         x = g.ndata.pop("x")
-        qf = features.index_select(0, packed[2 * B:])
+        U = pending["n_runs"]
+        if U is None:
+            qt = qf = features.index_select(0, packed[2 * B:3 * B])
+        else:                                                     # only the distinct query rows are gathered
+            from .ops import RepeatedRows
+            qt = features.index_select(0, packed[2 * B:2 * B + U])
+            qf = RepeatedRows(qt, packed[3 * B:3 * B + U + 1], B)
     if side is not main:
         main.wait_stream(side)
         csr = g.csr(dev)
-        for t in (x, qf, g.ndata["_id"], g.ndata["pos"], csr.rowptr_in, csr.col_src, csr.eid_in, csr.rowptr_out, csr.col_dst, csr.pos_out,
+        packed.record_stream(main)
+        for t in (x, qt, g.ndata["_id"], g.ndata["pos"], csr.rowptr_in, csr.col_src, csr.eid_in, csr.rowptr_out, csr.col_dst, csr.pos_out,
                   csr.graph_off):
             t.record_stream(main)
     return dict(g=g, x=x, pos=g.ndata["pos"], qf=qf, n_nodes=g.number_of_nodes(), n_edges=g.number_of_edges())
 
 
-def build_device_batch(dtax, anchors, exclude, query_ids, features, expand_factor=50, seed=0, stream=None):
+def build_device_batch(dtax, anchors, exclude, query_ids, features, expand_factor=50, seed=0, stream=None, repeated_queries=False):
     """One training batch built ON the device (data_loaders.py:9-28 + dataset.py:404-437 without host egonet objects):
     graph.device_egonet_batch for the anchors, node features and query features gathered from the resident table.
     stream: build on that side stream -- the one host synchronisation of the construction (the array sizes) then waits for the
     builder's own few microseconds of work only, not for the training step still running on the caller's stream.  A loop that
     calls begin_device_batch for batch i+1 BEFORE it enqueues step i does not wait at all (DeviceBatchLoader does).
     Returns dict(g, x, pos, qf, n_nodes, n_edges)."""
-    return finish_device_batch(begin_device_batch(dtax, anchors, exclude, query_ids, expand_factor, seed, stream), features)
+    return finish_device_batch(begin_device_batch(dtax, anchors, exclude, query_ids, expand_factor, seed, stream, repeated_queries), features)
 
 
 class DeviceBatchLoader:
@@ -172,10 +191,14 @@ class DeviceBatchLoader:
     hands anchors to begin_device_batch / finish_device_batch.  Each batch is built on a side stream while the previous step runs,
     in two halves around the consumer's enqueue of that step: batch b+1 is BEGUN (sampled, uploaded, node counts launched) before
     batch b is handed out and FINISHED (arrays sized from the count, filled, features gathered) at the next `next()`, so the one host
-    synchronisation of the construction finds its value already there.  Yields (graph, node features, query features, labels) -- MaskedGraphDataLoader's small-batch
+    synchronisation of the construction finds its value already there.
+    repeated_queries (default): the query features are an ops.RepeatedRows -- the sampler pairs one query with 1 + negative_size
+    consecutive anchors, only the distinct rows are gathered and BIM / LBM project those (every other matcher of model_zoo densifies it;
+    `.dense()` gives the reference's stacked [B, in_dim] tensor); False: the stacked tensor itself.  Yields (graph, node features, query features, labels) -- MaskedGraphDataLoader's small-batch
     tuple with the node features popped, all on `device`."""
 
-    def __init__(self, dataset, batch_size, device, shuffle=True, seed=0, drop_last=False):
+    def __init__(self, dataset, batch_size, device, shuffle=True, seed=0, drop_last=False, repeated_queries=True):
+        self.repeated_queries = bool(repeated_queries)
         self.dataset, self.batch_size, self.device = dataset, int(batch_size), torch.device(device)
         self.shuffle, self.seed, self.drop_last = shuffle, int(seed), drop_last
         self.dtax = dataset.device_taxonomy(self.device)
@@ -198,7 +221,7 @@ class DeviceBatchLoader:
             idx = order[b * self.batch_size:(b + 1) * self.batch_size]
             query, anchor, label, exclude = self.dataset.sample_anchors(idx)
             return label, begin_device_batch(self.dtax, anchor, exclude, query, expand_factor=self.dataset.expand_factor,
-                                             seed=self.seed + 7919 * self._epoch + b, stream=self._side)
+                                             seed=self.seed + 7919 * self._epoch + b, stream=self._side, repeated_queries=self.repeated_queries)
         # two batches in flight: batch b+1 is begun (sampled, uploaded, node counts launched) before the consumer gets batch b, so the
         # count's read-back has a whole step's enqueue to arrive and `finish` never waits
         nxt = begin(0) if len(self) else None

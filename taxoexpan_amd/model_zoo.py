@@ -411,6 +411,7 @@ class MLP(nn.Module):
 
     def forward(self, e1, e2):
         """model_zoo.py:291-298: ffn(cat(e1, e2)); the concat is synthesised by the GEMM's operand loader"""
+        e2 = ops.dense_rows(e2)
         if e1.shape[0] == 0:
             return e1.new_zeros((0, 1), dtype=torch.float32)
         hid = ops.LinearFunction.apply(e1, e2, self.ffn[0].weight, self.ffn[0].bias, 1)
@@ -428,6 +429,12 @@ class _Bilinear(nn.Module):
         """e1 (*, l_dim), e2 (*, r_dim) -> (*, 1)"""
         if e1.shape[0] == 0:                               # empty batch
             return e1.new_zeros((0, 1), dtype=torch.float32)
+        if isinstance(e2, ops.RepeatedRows):               # query rows that repeat in runs: U rows projected instead of G
+            if e2.requires_grad or e2.n_rows != e1.shape[0] or 4 * e2.rows.shape[0] > e2.n_rows:     # (hardly any repetition: the GEMM form)
+                e2 = e2.dense()
+            else:
+                self._pre = None
+                return ops.BilinearRunsFunction.apply(e1, self.W.weight, self.apply_exp, e2.rows, e2.run_off)
         if e2.dim() == 2 and e2.stride(0) == 0 and e2.shape[0] == e1.shape[0] and not torch.is_grad_enabled():
             # the eval loop's `nf.expand(n_position, -1)` (test_fast.py:122-123): one query against all candidates
             U = ops.bilinear_project(e1, self.W.weight)
@@ -438,7 +445,7 @@ class _Bilinear(nn.Module):
     def prefetch(self, e2):
         """start the query-side half of the match (V = e2 W^T: needs neither the graph nor the encoder) on the second stream; the next
         forward(e1, e2) with this very e2 picks it up.  Called by TaxoExpan.forward before graph_propagate."""
-        self._pre = ops.bilinear_query_prefetch(e2, self.W.weight) if torch.is_grad_enabled() else None
+        self._pre = ops.bilinear_query_prefetch(e2, self.W.weight) if torch.is_grad_enabled() and torch.is_tensor(e2) else None
 
     def score_all(self, hg, queries, block=1024, out=None):
         """The whole scoring loop at once: S[q][g] = match(hg[g], queries[q]) (test_fast.py:116-123)."""
@@ -466,6 +473,7 @@ class NTN(nn.Module):
 
     def forward(self, e1, e2):
         """model_zoo.py:339-346: u_R(f(W(e1, e2) + V(cat(e1, e2)))) -> (*, 1); one bilinear slice per output, the concat is virtual"""
+        e2 = ops.dense_rows(e2)
         k = self.W.weight.shape[0]
         bil = torch.cat([ops.BilinearPairFunction.apply(e1, e2, self.W.weight[j:j + 1], False).reshape(-1, 1) for j in range(k)], 1)
         lin = ops.LinearFunction.apply(e1, e2, self.V.weight, None, 0)

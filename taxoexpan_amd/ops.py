@@ -1118,6 +1118,85 @@ class BilinearPairFunction(torch.autograd.Function):
         return d_e1, d_e2, dW.reshape(wshape), None, None
 
 
+class RepeatedRows:
+    """A [G, r] matrix whose rows repeat in RUNS, kept as its U distinct rows: the query features of a training batch -- one query is
+    paired with 1 + negative_size consecutive anchors and the reference's collate stacks its row once per pair (data_loaders.py:9-28).
+    rows [U, r] (device), run_off [U + 1] int32 (device; first pair of every run, run_off[U] = G).  BIM / LBM take it as their query
+    argument and project U rows instead of G (BilinearRunsFunction); every other consumer calls dense().  data_loaders.DeviceBatchLoader
+    yields it as the query features (repeated_queries=True)."""
+
+    def __init__(self, rows, run_off, n_rows):
+        self.rows, self.run_off, self.n_rows = rows, run_off, int(n_rows)
+        assert run_off.dtype == torch.int32 and run_off.numel() == rows.shape[0] + 1
+
+    @staticmethod
+    def from_ids(table, ids, device=None):
+        """table[ids] with the runs of equal consecutive ids found on the host (ids: host int array)"""
+        import numpy as np
+        ids = np.asarray(ids).reshape(-1)
+        start = np.flatnonzero(np.concatenate([[True], ids[1:] != ids[:-1]])) if ids.size else np.zeros(0, dtype=np.int64)
+        dev = table.device if device is None else device
+        off = torch.from_numpy(np.concatenate([start, [ids.size]]).astype(np.int32)).to(dev)
+        return RepeatedRows(table.index_select(0, torch.from_numpy(ids[start].astype(np.int64)).to(table.device)).to(dev), off, ids.size)
+
+    shape = property(lambda self: (self.n_rows, self.rows.shape[1]))
+    device = property(lambda self: self.rows.device)
+    dtype = property(lambda self: self.rows.dtype)
+    requires_grad = property(lambda self: self.rows.requires_grad)
+
+    def dim(self):
+        return 2
+
+    def dense(self):
+        cnt = (self.run_off[1:] - self.run_off[:-1]).long()
+        return self.rows.repeat_interleave(cnt, dim=0, output_size=self.n_rows)
+
+    def to(self, device):
+        rows = self.rows.to(device)
+        return RepeatedRows(rows, self.run_off.to(rows.device), self.n_rows)
+
+
+def dense_rows(x):
+    """a plain tensor from a tensor or a RepeatedRows"""
+    return x.dense() if isinstance(x, RepeatedRows) else x
+
+
+class BilinearRunsFunction(torch.autograd.Function):
+    """s_i = e1_i^T W q_i (exp optionally) for queries given as RepeatedRows: V = rows W^T has U rows, backward's weight gradient
+    sums a run's pairs first (txe_bilinear_runs_*).  No gradient to the queries."""
+
+    @staticmethod
+    def forward(ctx, e1, W, apply_exp, rows, run_off):
+        _need_cuda(e1, rows, W)
+        e1, ld1 = _rows(e1)
+        rows, ldq = _rows(rows)
+        Wf = _f32(W).reshape(W.shape[-2], W.shape[-1])
+        G, l = e1.shape
+        U, r = rows.shape
+        s = _empty((G,), e1)
+        V = _empty((max(U, 1), l), e1)
+        with _lib.on_device(e1.device):
+            call("txe_bilinear_runs_fwd", ptr(e1), ld1, ptr(rows), ldq, ptr(run_off), G, U, l, r, ptr(Wf), int(apply_exp), ptr(V), ptr(s),
+                 _lib.stream_ptr())
+        ctx.misc = (e1, ld1, rows, ldq, run_off, V, s, int(apply_exp), W.shape)
+        return s.unsqueeze(1)
+
+    @staticmethod
+    def backward(ctx, ds):
+        e1, ld1, rows, ldq, run_off, V, s, apply_exp, wshape = ctx.misc
+        G, l = e1.shape
+        U, r = rows.shape
+        ds = _f32(ds.reshape(-1))
+        d_e1 = _empty((G, l), e1)
+        dW = _empty((l, r), e1)
+        with _lib.on_device(e1.device):
+            wsb = call("txe_bilinear_runs_bwd_ws_bytes", U, l, r)
+            ws = _ws(wsb, e1)
+            call("txe_bilinear_runs_bwd", ptr(e1), ld1, ptr(rows), ldq, ptr(run_off), G, U, l, r, apply_exp, ptr(V), ptr(s), ptr(ds), ptr(d_e1), l,
+                 ptr(dW), ptr(ws), wsb, _lib.stream_ptr())
+        return d_e1, dW.reshape(wshape), None, None, None
+
+
 # ================================================================================================================
 # inference-side helpers (no autograd)
 # ================================================================================================================

@@ -872,6 +872,7 @@ def test_bench_contract_line():
     assert 0.0 < r["hbm_frac"] < 1.0 and 0.0 < r["mfma_main_stream_frac"] < 1.0
     # a fresh device-built batch inside every step (trainer.py:44-61's real per-step cost) is reported next to the resident-input value
     assert d["step_incl_batch_build_ms"] >= d["ms_per_step"] * 0.9 and d["batch_build_ms"] > 0.0
+    assert 0.5 * d["ms_per_step"] < d["step_repeated_queries_ms"] < 1.5 * d["ms_per_step"] and d["step_incl_batch_build_repeated_queries_ms"] > 0.0
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == d["unit"] and "sample" in c
 
@@ -1121,7 +1122,8 @@ def test_training_on_raw_files_with_device_batches_converges():
 def test_device_batch_loader_builds_on_a_side_stream_what_the_inline_builder_builds():
     """data_loaders.DeviceBatchLoader (train.py's `for batch in data_loader`, batches built on the GPU inside next() on a side
     stream while the previous step runs): every batch equals the in-line construction from the same sampled anchors -- ids, pos, both
-    CSR views, node and query features, labels -- also while the caller's stream is kept busy, and a step can consume it at once"""
+    CSR views, node and query features (handed out as ops.RepeatedRows: one row per query),
+    labels -- also while the caller's stream is kept busy, and a step can consume it at once"""
     import os
     import random
     import shutil
@@ -1160,7 +1162,9 @@ def test_device_batch_loader_builds_on_a_side_stream_what_the_inline_builder_bui
         with torch.no_grad():
             pred = model(g, x, qf)                                  # consumable at once: the caller's stream waits for the build
         csr = g.csr(dev)
-        got.append(dict(ids=host(g.ndata["_id"]), pos=host(pos), x=host(x), qf=host(qf), labels=host(labels), pred=host(pred),
+        from taxoexpan_amd import ops
+        assert isinstance(qf, ops.RepeatedRows) and qf.rows.shape[0] == 16 and qf.shape == (16 * 8, 8)    # one distinct row per sampled query
+        got.append(dict(ids=host(g.ndata["_id"]), pos=host(pos), x=host(x), qf=host(qf.dense()), labels=host(labels), pred=host(pred),
                         csr=[host(t) for t in (csr.rowptr_in, csr.col_src, csr.eid_in, csr.rowptr_out, csr.col_dst, csr.pos_out, csr.graph_off)]))
     assert len(got) == 4
     # the same four batches in line on the caller's stream, from the twin dataset
@@ -1178,9 +1182,70 @@ def test_device_batch_loader_builds_on_a_side_stream_what_the_inline_builder_bui
         x = g.ndata.pop("x")
         qf = dtax.features.index_select(0, torch.from_numpy(query).to(dev))
         assert np.array_equal(host(x), want["x"]) and np.array_equal(host(qf), want["qf"]) and np.array_equal(label, want["labels"])
-        with torch.no_grad():
-            assert np.array_equal(host(model(g, x, qf)), want["pred"])
+        with torch.no_grad():                                       # (the loader's scores come from the one-row-per-query form: another
+            np.testing.assert_allclose(host(model(g, x, qf)), want["pred"], rtol=2e-5, atol=1e-7)     # summation order in V = Q W^T)
         assert np.isfinite(want["pred"]).all() and want["labels"].reshape(16, 8)[:, 0].tolist() == [1] * 16
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("matcher", ["LBM", "BIM"])
+def test_repeated_query_rows_match_the_stacked_rows(matcher):
+    """ops.RepeatedRows as the matcher's query argument (the distinct rows of a training batch's query features + their runs,
+    txe_bilinear_runs_*) against the stacked [G, r] tensor the reference's collate builds (data_loaders.py:9-28): scores, d_hg
+    and dW within float rounding of the other summation order; runs of length 1, a long run, repeated ids in separate runs; the
+    whole model's loss and parameter gradients on a training batch; matchers without a runs form densify it."""
+    from taxoexpan_amd import TaxoExpan, model_zoo as mz, ops, synthetic as syn
+    from taxoexpan_amd.loss import info_nce_loss
+    dev = _dev()
+    rs = np.random.RandomState(11)
+    table = torch.from_numpy(rs.standard_normal((40, 250)).astype(np.float32)).to(dev)
+    ids = np.concatenate([[3], np.repeat([7, 1, 7, 22], [32, 1, 5, 90]), [5, 6]])
+    G, l = len(ids), 500
+    rr = ops.RepeatedRows.from_ids(table, ids)
+    assert rr.rows.shape[0] == 7 and rr.run_off.cpu().tolist() == [0, 1, 33, 34, 39, 129, 130, 131]
+    dense = table.index_select(0, torch.from_numpy(ids).to(dev))
+    assert torch.equal(rr.dense(), dense)
+    m = getattr(mz, matcher)(l, 250).to(dev)
+    with torch.no_grad():
+        m.W.weight.mul_(0.05)
+    e1 = torch.from_numpy(rs.standard_normal((G, l)).astype(np.float32) * 0.3).to(dev)
+    outs = []
+    for q in (dense, rr):
+        a = e1.clone().requires_grad_(True)
+        m.zero_grad()
+        s = m(a, q)
+        (s.reshape(-1) * torch.linspace(-1, 1, G, device=dev)).sum().backward()
+        outs.append((s.detach().clone(), a.grad.clone(), m.W.weight.grad.clone()))
+    for k in (0, 1, 2):
+        scale = outs[0][k].abs().max().item()
+        np.testing.assert_allclose(outs[1][k].cpu().numpy(), outs[0][k].cpu().numpy(), rtol=1e-5, atol=2e-6 * scale)
+    # an empty batch, and a matcher without a runs form
+    assert m(e1[:0], ops.RepeatedRows.from_ids(table, np.zeros(0, dtype=np.int64))).shape == (0, 1)
+    mlp = mz.MLP(l, 250, 16).to(dev)
+    assert torch.equal(mlp(e1, rr), mlp(e1, dense))
+    # the whole training step
+    tax = syn.make_taxonomy(600, 900, 12, seed=5)
+    g, qf, labels = syn.training_batch(tax, 24, 7, seed=9)
+    qf = qf.to(dev)
+    host_q = qf.cpu().numpy()
+    qid = np.concatenate([[0], np.cumsum(np.any(host_q[1:] != host_q[:-1], axis=1))])
+    rq = ops.RepeatedRows.from_ids(torch.from_numpy(host_q[np.concatenate([[True], qid[1:] != qid[:-1]])]).to(dev), qid)
+    assert rq.rows.shape[0] == 24 and torch.equal(rq.dense(), qf)
+    x, pos = g.ndata.pop("x").to(dev), g.ndata["pos"].to(dev)
+    torch.manual_seed(1)
+    model = TaxoExpan("PGAT", "WMR", matcher, in_dim=qf.shape[1], hidden_dim=16, out_dim=16, pos_dim=4, num_layers=1, heads=[2, 1], feat_drop=0.0,
+                      attn_drop=0.0, hidden_drop=0.0, out_drop=0.0).to(dev)
+    res = []
+    for q in (qf, rq):
+        model.zero_grad()
+        g.ndata["pos"] = pos
+        loss = info_nce_loss(model(g, x, q).reshape(24, -1), torch.zeros(24, dtype=torch.long, device=dev))
+        loss.backward()
+        res.append((loss.item(), {n: p.grad.clone() for n, p in model.named_parameters()}))
+    assert abs(res[0][0] - res[1][0]) <= 1e-5 * abs(res[0][0])
+    for n in res[0][1]:
+        ref = res[0][1][n]
+        np.testing.assert_allclose(res[1][1][n].cpu().numpy(), ref.cpu().numpy(), rtol=1e-4, atol=1e-6 * max(ref.abs().max().item(), 1e-30), err_msg=n)
 
 
 @pytest.mark.gpu

@@ -205,6 +205,18 @@ int txe_bilinear_runs_bwd(const float* e1, long long ld_e1, const float* Qu, lon
                           int apply_exp, const float* V, const float* s, const float* ds, float* d_e1, long long ld_de1, float* dW, void* ws,
                           size_t ws_bytes, void* stream);
 
+/* ... and when the caller only has the reference collate's STACKED matrix E2 [G][r]: txe_rows_find_runs compares every row bit for bit
+ * with its predecessor and numbers the runs on the device (run_id [G], run_off [G + 1] with run_off[n_runs] = G, n_runs [1]; no host
+ * synchronisation), txe_bilinear_stacked_* are txe_bilinear_runs_* on E2 itself (run u's row = row run_off[u]; V [G][l] and the workspace
+ * are sized for G runs, the kernels walk the actual count).  Right for any input; worth it when rows repeat (the caller decides). */
+int txe_rows_find_runs(const float* e2, long long ld_e2, int G, int r, int* run_id, int* run_off, int* n_runs, void* stream);
+int txe_bilinear_stacked_fwd(const float* e1, long long ld_e1, const float* e2, long long ld_e2, const int* run_off, const int* n_runs, int G,
+                             int l, int r, const float* W, int apply_exp, float* V, float* s, void* stream);
+size_t txe_bilinear_stacked_bwd_ws_bytes(int G, int l, int r);
+int txe_bilinear_stacked_bwd(const float* e1, long long ld_e1, const float* e2, long long ld_e2, const int* run_off, const int* n_runs, int G,
+                             int l, int r, int apply_exp, const float* V, const float* s, const float* ds, float* d_e1, long long ld_de1,
+                             float* dW, void* ws, size_t ws_bytes, void* stream);
+
 /* nn.Linear over the (virtual) concat of two inputs + activation (0 none / 1 relu / 2 tanh): the MLP matcher, model_zoo.py:285-298 */
 int txe_linear_fwd(const float* x1, long long ld1, int l, const float* x2, long long ld2, int r, int G, const float* W, const float* b,
                    int O, int act, float* y, void* stream);

@@ -57,6 +57,10 @@ SIGNATURES = {
     "txe_bilinear_runs_fwd": (I, [P, L, P, L, P, I, I, I, I, P, I, P, P, P]),
     "txe_bilinear_runs_bwd_ws_bytes": (SZ, [I, I, I]),
     "txe_bilinear_runs_bwd": (I, [P, L, P, L, P, I, I, I, I, I, P, P, P, P, L, P, P, SZ, P]),
+    "txe_rows_find_runs": (I, [P, L, I, I, P, P, P, P]),
+    "txe_bilinear_stacked_fwd": (I, [P, L, P, L, P, P, I, I, I, P, I, P, P, P]),
+    "txe_bilinear_stacked_bwd_ws_bytes": (SZ, [I, I, I]),
+    "txe_bilinear_stacked_bwd": (I, [P, L, P, L, P, P, I, I, I, I, P, P, P, P, L, P, P, SZ, P]),
     "txe_bilinear_pair_bwd_ws_bytes": (SZ, [I, I, I]),
     "txe_bilinear_pair_bwd": (I, [P, L, P, L, I, I, I, P, I, P, P, P, P, L, P, L, P, P, SZ, P]),
     "txe_score_block": (I, [P, L, I, P, L, I, I, I, P, L, P, SZ, P]),

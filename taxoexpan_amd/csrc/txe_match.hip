@@ -120,24 +120,83 @@ __global__ void colsum_small_kernel(const float* __restrict__ x, long long n_row
     if (threadIdx.x == 0) out[o] = red[0];
 }
 
-// ---- the pairwise match when the query rows repeat in RUNS (txe_bilinear_runs_*) ------------------------------------------------------
-// s_i = <e1_i, V[u]> for the pairs i of run u: gridDim.y workgroups per run, V[u] in registers, one wave per pair
+// ---- the pairwise match when the query rows repeat in RUNS (txe_bilinear_runs_*, txe_bilinear_stacked_*) ------------------------------
+// The runs are either given (compact distinct rows Qu [U][r] + run offsets, U known on the host) or found on the device in the stacked
+// matrix E2 [G][r] itself (run u's row is row off[u] of E2, the number of runs is a device scalar): every kernel walks the runs with a
+// grid stride and reads the count through runs_count(), so one launch shape serves any count.
+struct RunsRef {
+    const int* off;       // [n + 1] first pair of every run, off[n] = G
+    const int* n_dev;     // the number of runs on the device (NULL: n_host)
+    int n_host;
+    int first_row;        // 1: run u's distinct row = row off[u] of the stacked matrix;  0: row u of the compact matrix
+};
+__device__ __forceinline__ int runs_count(const RunsRef& R) { return R.n_dev ? *R.n_dev : R.n_host; }
+__device__ __forceinline__ long long runs_row(const RunsRef& R, int u) { return R.first_row ? (long long)R.off[u] : (long long)u; }
+
+// flag[i] = row i of E2 differs (bit pattern) from row i - 1; flag[0] = 1.  One wave per row.
+__global__ __launch_bounds__(256) void row_change_kernel(const float* __restrict__ e2, long long ld, int G, int r, int* __restrict__ flag) {
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6), ln = threadIdx.x & 63;
+    if (i >= G) return;
+    int diff = (i == 0);
+    if (i > 0) {
+        const unsigned* a = reinterpret_cast<const unsigned*>(e2 + (long long)i * ld);
+        const unsigned* b = reinterpret_cast<const unsigned*>(e2 + (long long)(i - 1) * ld);
+        for (int k = ln; k < r; k += 64) diff |= (a[k] != b[k]);
+    }
+    const unsigned long long any = __ballot(diff);
+    if (ln == 0) flag[i] = any != 0ull;
+}
+
+// inclusive scan of the flags by ONE workgroup of 1,024 threads (chunks of 1,024 rows with a carry): run_id[i] = #flags up to i - 1, the
+// first row of every run into run_off, the count into n_runs, run_off[n_runs] = G.  flag and run_id may be the same array.
+__global__ __launch_bounds__(1024) void runs_scan_kernel(const int* flag, int G, int* run_id, int* __restrict__ run_off, int* __restrict__ n_runs) {
+    __shared__ int wsum[16];
+    __shared__ int carry_s;
+    const int t = threadIdx.x, ln = t & 63, w = t >> 6;
+    if (t == 0) carry_s = 0;
+    __syncthreads();
+    for (int i0 = 0; i0 < G; i0 += 1024) {
+        const int i = i0 + t;
+        const int f = i < G ? flag[i] : 0;
+        int x = f;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const int y = __shfl_up(x, d); if (ln >= d) x += y; }
+        if (ln == 63) wsum[w] = x;
+        __syncthreads();
+        int before = carry_s;
+        for (int q = 0; q < w; ++q) before += wsum[q];
+        const int incl = before + x;
+        if (i < G) {
+            run_id[i] = incl - 1;
+            if (f) run_off[incl - 1] = i;
+        }
+        __syncthreads();
+        if (t == 1023) carry_s = incl;
+        __syncthreads();
+    }
+    if (t == 0) { n_runs[0] = carry_s; run_off[carry_s] = G; }
+}
+
+// s_i = <e1_i, V[u]> for the pairs i of run u: V[u] in registers, one wave per pair, gridDim.y workgroups share a run
 __global__ __launch_bounds__(256) void rowdot_runs_kernel(const float* __restrict__ e1, long long ld_e1, const float* __restrict__ V,
-                                                          const int* __restrict__ run_off, int l, int apply_exp, float* __restrict__ s) {
-    const int u = blockIdx.x, w = threadIdx.x >> 6, ln = threadIdx.x & 63;
-    const int i0 = run_off[u], i1 = run_off[u + 1];
-    for (int k0 = 0; k0 < l; k0 += 64 * 8) {                    // (rows wider than 512 columns: several passes, partial sums in s)
-        float v[8];
+                                                          const RunsRef R, int l, int apply_exp, float* __restrict__ s) {
+    const int w = threadIdx.x >> 6, ln = threadIdx.x & 63;
+    const int U = runs_count(R);
+    for (int u = blockIdx.x; u < U; u += gridDim.x) {
+        const int i0 = R.off[u], i1 = R.off[u + 1];
+        for (int k0 = 0; k0 < l; k0 += 64 * 8) {                // (rows wider than 512 columns: several passes, partial sums in s)
+            float v[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { const int k = k0 + ln + 64 * j; v[j] = k < l ? V[(long long)u * l + k] : 0.f; }
-        for (int i = i0 + w + 4 * blockIdx.y; i < i1; i += 4 * gridDim.y) {
-            float acc = 0.f;
+            for (int j = 0; j < 8; ++j) { const int k = k0 + ln + 64 * j; v[j] = k < l ? V[(long long)u * l + k] : 0.f; }
+            for (int i = i0 + w + 4 * blockIdx.y; i < i1; i += 4 * gridDim.y) {
+                float acc = 0.f;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { const int k = k0 + ln + 64 * j; acc = fmaf(k < l ? e1[(long long)i * ld_e1 + k] : 0.f, v[j], acc); }
-            acc = wave_sum(acc);
-            if (ln == 0) {
-                const float tot = (k0 == 0 ? 0.f : s[i]) + acc;
-                s[i] = (apply_exp && k0 + 64 * 8 >= l) ? __expf(tot) : tot;
+                for (int j = 0; j < 8; ++j) { const int k = k0 + ln + 64 * j; acc = fmaf(k < l ? e1[(long long)i * ld_e1 + k] : 0.f, v[j], acc); }
+                acc = wave_sum(acc);
+                if (ln == 0) {
+                    const float tot = (k0 == 0 ? 0.f : s[i]) + acc;
+                    s[i] = (apply_exp && k0 + 64 * 8 >= l) ? __expf(tot) : tot;
+                }
             }
         }
     }
@@ -146,67 +205,74 @@ __global__ __launch_bounds__(256) void rowdot_runs_kernel(const float* __restric
 // backward of the above for run u: d_e1_i = dsl_i V[u], S[u] = sum over the run's pairs (in order) of dsl_i e1_i; thread = column
 __global__ __launch_bounds__(256) void runs_bwd_kernel(const float* __restrict__ ds, const float* __restrict__ s, int apply_exp,
                                                        const float* __restrict__ V, const float* __restrict__ e1, long long ld_e1,
-                                                       const int* __restrict__ run_off, int l, float* __restrict__ d_e1, long long ld_de1,
+                                                       const RunsRef R, int l, float* __restrict__ d_e1, long long ld_de1,
                                                        float* __restrict__ S) {
-    const int u = blockIdx.x;
-    const int i0 = run_off[u], i1 = run_off[u + 1];
     const int k = blockIdx.y * 256 + threadIdx.x;
     if (k >= l) return;
-    const float v = V[(long long)u * l + k];
-    float acc = 0.f;
-    for (int i = i0; i < i1; i += 8) {                          // eight pairs' loads in flight; the sum keeps the pairs' order
-        float x[8], dsl[8];
+    const int U = runs_count(R);
+    for (int u = blockIdx.x; u < U; u += gridDim.x) {
+        const int i0 = R.off[u], i1 = R.off[u + 1];
+        const float v = V[(long long)u * l + k];
+        float acc = 0.f;
+        for (int i = i0; i < i1; i += 8) {                      // eight pairs' loads in flight; the sum keeps the pairs' order
+            float x[8], dsl[8];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const int ii = min(i + q, i1 - 1);
-            x[q] = e1[(long long)ii * ld_e1 + k];
-            dsl[q] = apply_exp ? ds[ii] * s[ii] : ds[ii];
-        }
+            for (int q = 0; q < 8; ++q) {
+                const int ii = min(i + q, i1 - 1);
+                x[q] = e1[(long long)ii * ld_e1 + k];
+                dsl[q] = apply_exp ? ds[ii] * s[ii] : ds[ii];
+            }
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            if (i + q < i1) {
-                d_e1[(long long)(i + q) * ld_de1 + k] = dsl[q] * v;
-                acc = fmaf(dsl[q], x[q], acc);
+            for (int q = 0; q < 8; ++q) {
+                if (i + q < i1) {
+                    d_e1[(long long)(i + q) * ld_de1 + k] = dsl[q] * v;
+                    acc = fmaf(dsl[q], x[q], acc);
+                }
             }
         }
+        S[(long long)u * l + k] = acc;
     }
-    S[(long long)u * l + k] = acc;
 }
 
-// V[u][j] = <Qu[u], W[j]>: one wave per output row j and block of 8 runs, lanes along k (both rows read coalesced), W[j] kept in
+// V[u][j] = <Q[row(u)], W[j]>: one wave per output row j and block of 8 runs, lanes along k (both rows read coalesced), W[j] kept in
 // registers.  A few hundred rows at most: the MFMA GEMM's 128-row tiles would leave most of the chip idle on such a product.
-__global__ __launch_bounds__(256) void runs_project_kernel(const float* __restrict__ Qu, long long ld_q, const float* __restrict__ W, int U,
-                                                           int l, int r, float* __restrict__ V) {
+__global__ __launch_bounds__(256) void runs_project_kernel(const float* __restrict__ Q, long long ld_q, const float* __restrict__ W,
+                                                           const RunsRef R, int l, int r, float* __restrict__ V) {
     const int w = threadIdx.x >> 6, ln = threadIdx.x & 63;
-    const int j = blockIdx.x * 4 + w, u0 = blockIdx.y * 8;
+    const int j = blockIdx.x * 4 + w;
     if (j >= l) return;
-    float acc[8];
+    const int U = runs_count(R);
+    for (int u0 = blockIdx.y * 8; u0 < U; u0 += 8 * gridDim.y) {
+        float acc[8];
+        long long row[8];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) acc[q] = 0.f;
-    for (int k0 = 0; k0 < r; k0 += 256) {
-        float wv[4];
+        for (int q = 0; q < 8; ++q) { acc[q] = 0.f; row[q] = runs_row(R, min(u0 + q, U - 1)); }     // clamped: loads stay unconditional
+        for (int k0 = 0; k0 < r; k0 += 256) {
+            float wv[4];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) { const int k = k0 + ln + 64 * c; wv[c] = k < r ? W[(long long)j * r + k] : 0.f; }
+            for (int c = 0; c < 4; ++c) { const int k = k0 + ln + 64 * c; wv[c] = k < r ? W[(long long)j * r + k] : 0.f; }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) { const int k = k0 + ln + 64 * c; acc[q] = fmaf(k < r ? Q[row[q] * ld_q + k] : 0.f, wv[c], acc[q]); }
+            }
+        }
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
-            const int u = min(u0 + q, U - 1);                   // clamped: the loads stay unconditional, the result is not stored
-#pragma unroll
-            for (int c = 0; c < 4; ++c) { const int k = k0 + ln + 64 * c; acc[q] = fmaf(k < r ? Qu[(long long)u * ld_q + k] : 0.f, wv[c], acc[q]); }
+            const float t = wave_sum(acc[q]);
+            if (ln == 0 && u0 + q < U) V[(long long)(u0 + q) * l + j] = t;
         }
-    }
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-        const float t = wave_sum(acc[q]);
-        if (ln == 0 && u0 + q < U) V[(long long)(u0 + q) * l + j] = t;
     }
 }
 
-// dW[j][k] = sum_u S[u][j] Qu[u][k] (runs in order): thread = column k, two rows j per workgroup, S's two columns staged in LDS
-__global__ __launch_bounds__(256) void runs_dw_kernel(const float* __restrict__ S, const float* __restrict__ Qu, long long ld_q, int U, int l,
-                                                      int r, float* __restrict__ dW) {
+// dW[j][k] = sum_u S[u][j] Q[row(u)][k] (runs in order): thread = column k, two rows j per workgroup, S's two columns staged in LDS
+__global__ __launch_bounds__(256) void runs_dw_kernel(const float* __restrict__ S, const float* __restrict__ Q, long long ld_q, const RunsRef R,
+                                                      int l, int r, float* __restrict__ dW) {
     __shared__ float sS[256][2];
+    __shared__ long long sRow[256];
     const int j0 = blockIdx.x * 2;
     const int k = blockIdx.y * 256 + threadIdx.x, kc = min(k, r - 1);
+    const int U = runs_count(R);
     float acc[2] = {0.f, 0.f};
     for (int u0 = 0; u0 < U; u0 += 256) {
         __syncthreads();
@@ -214,13 +280,14 @@ __global__ __launch_bounds__(256) void runs_dw_kernel(const float* __restrict__ 
             const int u = min(u0 + (int)threadIdx.x, U - 1);
             sS[threadIdx.x][0] = S[(long long)u * l + j0];
             sS[threadIdx.x][1] = S[(long long)u * l + min(j0 + 1, l - 1)];
+            sRow[threadIdx.x] = runs_row(R, u);
         }
         __syncthreads();
         const int n = min(256, U - u0);
         for (int t0 = 0; t0 < n; t0 += 8) {                     // eight runs' loads in flight; the sum keeps the runs' order
             float q[8];
 #pragma unroll
-            for (int t = 0; t < 8; ++t) q[t] = Qu[(long long)(u0 + min(t0 + t, n - 1)) * ld_q + kc];
+            for (int t = 0; t < 8; ++t) q[t] = Q[sRow[min(t0 + t, n - 1)] * ld_q + kc];
 #pragma unroll
             for (int t = 0; t < 8; ++t) {
                 if (t0 + t < n) {
@@ -385,21 +452,43 @@ int txe_bilinear_query_bwd(const float* e1, long long ld_e1, const float* e2, lo
 // run_off [U+1]: the first pair of every run, run_off[U] = G.  V = Qu W^T is U rows instead of G, backward's dW = S^T Qu with
 // S[u] = sum over run u of dsl_i e1_i (pairs in order: deterministic) has K = U instead of G; d_e1_i = dsl_i V[u].  Both U-row products
 // run on small dot-product kernels (a few hundred rows would leave the MFMA GEMM's 128-row tiles most of the chip idle: 41 + 29 us measured).
+static int runs_fwd_launch(const float* e1, long long ld_e1, const float* Q, long long ld_q, const RunsRef& R, int gx, int gy, int G, int l, int r,
+                           const float* W, int apply_exp, float* V, float* s, hipStream_t st) {
+    {
+        ProfScope prof("runs_project_kernel", st, 4.0 * ((double)R.n_host * r + (double)l * r + (double)R.n_host * l), 1);
+        hipLaunchKernelGGL(runs_project_kernel, dim3((l + 3) / 4, gy), dim3(256), 0, st, Q, ld_q, W, R, l, r, V);
+    }
+    TXE_CHECK_LAUNCH();
+    {
+        ProfScope prof("rowdot_runs_kernel", st, 4.0 * ((double)G * l + (double)R.n_host * l + G), 1);
+        hipLaunchKernelGGL(rowdot_runs_kernel, dim3(gx, 8), dim3(256), 0, st, e1, ld_e1, (const float*)V, R, l, apply_exp, s);
+    }
+    TXE_CHECK_LAUNCH();
+    return TXE_OK;
+}
+
+static int runs_bwd_launch(const float* e1, long long ld_e1, const float* Q, long long ld_q, const RunsRef& R, int gx, int G, int l, int r,
+                           int apply_exp, const float* V, const float* s, const float* ds, float* d_e1, long long ld_de1, float* dW, float* S,
+                           hipStream_t st) {
+    {
+        ProfScope prof("runs_bwd_kernel", st, 4.0 * (2.0 * G * l + 2.0 * R.n_host * l + 2.0 * G), 1);
+        hipLaunchKernelGGL(runs_bwd_kernel, dim3(gx, (l + 255) / 256), dim3(256), 0, st, ds, s, apply_exp, V, e1, ld_e1, R, l, d_e1, ld_de1, S);
+    }
+    TXE_CHECK_LAUNCH();
+    {
+        ProfScope prof("runs_dw_kernel", st, 4.0 * ((double)R.n_host * l + (double)R.n_host * r + (double)l * r), 1);
+        hipLaunchKernelGGL(runs_dw_kernel, dim3((l + 1) / 2, (r + 255) / 256), dim3(256), 0, st, (const float*)S, Q, ld_q, R, l, r, dW);
+    }
+    TXE_CHECK_LAUNCH();
+    return TXE_OK;
+}
+
 int txe_bilinear_runs_fwd(const float* e1, long long ld_e1, const float* Qu, long long ld_q, const int* run_off, int G, int U, int l, int r,
                           const float* W, int apply_exp, float* V, float* s, void* stream) {
     if (G < 0 || U < 0 || l < 1 || r < 1 || !e1 || !Qu || !run_off || !W || !V || !s) return TXE_ERR_ARG;
     if (G == 0 || U == 0) return TXE_OK;
-    {
-        ProfScope prof("runs_project_kernel", (hipStream_t)stream, 4.0 * ((double)U * r + (double)l * r + (double)U * l), 1);
-        hipLaunchKernelGGL(runs_project_kernel, dim3((l + 3) / 4, (U + 7) / 8), dim3(256), 0, (hipStream_t)stream, Qu, ld_q, W, U, l, r, V);
-    }
-    TXE_CHECK_LAUNCH();
-    {
-        ProfScope prof("rowdot_runs_kernel", (hipStream_t)stream, 4.0 * ((double)G * l + (double)U * l + G), 1);
-        hipLaunchKernelGGL(rowdot_runs_kernel, dim3(U, 8), dim3(256), 0, (hipStream_t)stream, e1, ld_e1, (const float*)V, run_off, l, apply_exp, s);
-    }
-    TXE_CHECK_LAUNCH();
-    return TXE_OK;
+    const RunsRef R{run_off, nullptr, U, 0};
+    return runs_fwd_launch(e1, ld_e1, Qu, ld_q, R, U, (U + 7) / 8, G, l, r, W, apply_exp, V, s, (hipStream_t)stream);
 }
 
 size_t txe_bilinear_runs_bwd_ws_bytes(int U, int l, int r) { return mt_align((size_t)(U > 0 ? U : 1) * l * 4); }
@@ -410,22 +499,54 @@ int txe_bilinear_runs_bwd(const float* e1, long long ld_e1, const float* Qu, lon
     if (G < 0 || U < 0 || l < 1 || r < 1 || !e1 || !Qu || !run_off || !V || !s || !ds || !d_e1 || !dW || !ws) return TXE_ERR_ARG;
     if (ws_bytes < txe_bilinear_runs_bwd_ws_bytes(U, l, r)) return TXE_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
-    float* S = (float*)ws;
     if (G == 0 || U == 0) {                                    // an empty sum
         if (hipMemsetAsync(dW, 0, (size_t)l * r * sizeof(float), st) != hipSuccess) return TXE_ERR_LAUNCH;
         return TXE_OK;
     }
-    {
-        ProfScope prof("runs_bwd_kernel", st, 4.0 * (2.0 * G * l + 2.0 * U * l + 2.0 * G), 1);
-        hipLaunchKernelGGL(runs_bwd_kernel, dim3(U, (l + 255) / 256), dim3(256), 0, st, ds, s, apply_exp, V, e1, ld_e1, run_off, l, d_e1, ld_de1, S);
+    const RunsRef R{run_off, nullptr, U, 0};
+    return runs_bwd_launch(e1, ld_e1, Qu, ld_q, R, U, G, l, r, apply_exp, V, s, ds, d_e1, ld_de1, dW, (float*)ws, st);
+}
+
+// The runs found ON THE DEVICE in the stacked query matrix the reference's collate hands over (E2 [G][r], one row per pair): rows are
+// compared bit for bit with their predecessor, a one-workgroup scan numbers the runs.  run_id [G], run_off [G + 1], n_runs [1] (device).
+int txe_rows_find_runs(const float* e2, long long ld_e2, int G, int r, int* run_id, int* run_off, int* n_runs, void* stream) {
+    if (G < 0 || r < 1 || !e2 || !run_id || !run_off || !n_runs) return TXE_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    if (G > 0) {
+        hipLaunchKernelGGL(row_change_kernel, dim3((G + 3) / 4), dim3(256), 0, st, e2, ld_e2, G, r, run_id);
+        TXE_CHECK_LAUNCH();
     }
-    TXE_CHECK_LAUNCH();
-    {
-        ProfScope prof("runs_dw_kernel", st, 4.0 * ((double)U * l + (double)U * r + (double)l * r), 1);
-        hipLaunchKernelGGL(runs_dw_kernel, dim3((l + 1) / 2, (r + 255) / 256), dim3(256), 0, st, (const float*)S, Qu, ld_q, U, l, r, dW);
-    }
+    hipLaunchKernelGGL(runs_scan_kernel, dim3(1), dim3(1024), 0, st, (const int*)run_id, G, run_id, run_off, n_runs);
     TXE_CHECK_LAUNCH();
     return TXE_OK;
+}
+
+// txe_bilinear_runs_* on the stacked matrix with the runs of txe_rows_find_runs (count on the device: V and the workspace are sized for
+// the worst case, G runs; the kernels walk the runs with a grid stride).  Same values as txe_bilinear_query_* up to the summation order.
+int txe_bilinear_stacked_fwd(const float* e1, long long ld_e1, const float* e2, long long ld_e2, const int* run_off, const int* n_runs, int G,
+                             int l, int r, const float* W, int apply_exp, float* V, float* s, void* stream) {
+    if (G < 0 || l < 1 || r < 1 || !e1 || !e2 || !run_off || !n_runs || !W || !V || !s) return TXE_ERR_ARG;
+    if (G == 0) return TXE_OK;
+    const RunsRef R{run_off, n_runs, G, 1};
+    const int gx = G < 512 ? G : 512;
+    return runs_fwd_launch(e1, ld_e1, e2, ld_e2, R, gx, 32, G, l, r, W, apply_exp, V, s, (hipStream_t)stream);
+}
+
+size_t txe_bilinear_stacked_bwd_ws_bytes(int G, int l, int r) { return mt_align((size_t)(G > 0 ? G : 1) * l * 4); }
+
+int txe_bilinear_stacked_bwd(const float* e1, long long ld_e1, const float* e2, long long ld_e2, const int* run_off, const int* n_runs, int G,
+                             int l, int r, int apply_exp, const float* V, const float* s, const float* ds, float* d_e1, long long ld_de1,
+                             float* dW, void* ws, size_t ws_bytes, void* stream) {
+    if (G < 0 || l < 1 || r < 1 || !e1 || !e2 || !run_off || !n_runs || !V || !s || !ds || !d_e1 || !dW || !ws) return TXE_ERR_ARG;
+    if (ws_bytes < txe_bilinear_stacked_bwd_ws_bytes(G, l, r)) return TXE_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    if (G == 0) {
+        if (hipMemsetAsync(dW, 0, (size_t)l * r * sizeof(float), st) != hipSuccess) return TXE_ERR_LAUNCH;
+        return TXE_OK;
+    }
+    const RunsRef R{run_off, n_runs, G, 1};
+    const int gx = G < 512 ? G : 512;
+    return runs_bwd_launch(e1, ld_e1, e2, ld_e2, R, gx, G, l, r, apply_exp, V, s, ds, d_e1, ld_de1, dW, (float*)ws, st);
 }
 
 // Plain dense product on the library's fp32 MFMA GEMM (tests / micro-benchmarks; the model paths above use the same kernels

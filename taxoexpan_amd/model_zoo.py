@@ -439,13 +439,34 @@ class _Bilinear(nn.Module):
             # the eval loop's `nf.expand(n_position, -1)` (test_fast.py:122-123): one query against all candidates
             U = ops.bilinear_project(e1, self.W.weight)
             return ops.score_block(e2[:1], U, self.apply_exp).reshape(-1, 1)
+        if self._stacked_runs_ok(e1, e2) and self._repeats(e2):
+            self._pre = None
+            return ops.BilinearStackedRunsFunction.apply(e1, e2, self.W.weight, self.apply_exp)
         pre, self._pre = getattr(self, "_pre", None), None
         return ops.BilinearPairFunction.apply(e1, e2, self.W.weight, self.apply_exp, pre)
+
+    # ---- stacked query rows that repeat (data_loaders.py:9-28 stacks a query's row once per pair) -------------------------------------
+    def _stacked_runs_ok(self, e1, e2):
+        return (not ops._NO_QUERY_RUNS and torch.is_grad_enabled() and torch.is_tensor(e2) and e2.is_cuda and e2.dim() == 2 and
+                not e2.requires_grad and e2.shape[0] >= 256 and (e1 is None or e2.shape[0] == e1.shape[0]))
+
+    def _repeats(self, e2):
+        """does this matcher's training input repeat its query rows?  Decided ONCE, on the first training batch it sees (the runs are
+        counted on the device and read back: the one host synchronisation this costs): at least three rows in four repeat -> every
+        later batch takes the one-row-per-run form (which finds its runs on the device again, so a batch that repeats less is only
+        slower, never wrong); otherwise the GEMM form, for good.  `del matcher._query_rows_repeat` forgets the decision."""
+        dec = getattr(self, "_query_rows_repeat", None)
+        if dec is None:
+            n_runs = int(ops.find_row_runs(e2)[2].item())
+            dec = self._query_rows_repeat = bool(4 * n_runs <= e2.shape[0])
+        return dec
 
     def prefetch(self, e2):
         """start the query-side half of the match (V = e2 W^T: needs neither the graph nor the encoder) on the second stream; the next
         forward(e1, e2) with this very e2 picks it up.  Called by TaxoExpan.forward before graph_propagate."""
-        self._pre = ops.bilinear_query_prefetch(e2, self.W.weight) if torch.is_grad_enabled() and torch.is_tensor(e2) else None
+        self._pre = None
+        if torch.is_grad_enabled() and torch.is_tensor(e2) and not (self._stacked_runs_ok(None, e2) and self._repeats(e2)):
+            self._pre = ops.bilinear_query_prefetch(e2, self.W.weight)
 
     def score_all(self, hg, queries, block=1024, out=None):
         """The whole scoring loop at once: S[q][g] = match(hg[g], queries[q]) (test_fast.py:116-123)."""

@@ -1197,6 +1197,62 @@ class BilinearRunsFunction(torch.autograd.Function):
         return d_e1, dW.reshape(wshape), None, None, None
 
 
+_NO_QUERY_RUNS = os.environ.get("TXE_NO_QUERY_RUNS", "0") == "1"       # A/B switch: stacked query rows always take the GEMM form
+
+
+def find_row_runs(e2):
+    """runs of equal consecutive rows of the stacked query matrix e2 [G, r], found on the device (txe_rows_find_runs): returns
+    (run_id [G], run_off [G + 1], n_runs [1]) int32 device tensors -- no host synchronisation"""
+    _need_cuda(e2)
+    e2c, ld2 = _rows(e2)
+    G, r = e2c.shape
+    run_id = torch.empty(max(G, 1), dtype=torch.int32, device=e2.device)
+    run_off = torch.empty(G + 1, dtype=torch.int32, device=e2.device)
+    n_runs = torch.empty(1, dtype=torch.int32, device=e2.device)
+    with _lib.on_device(e2.device):
+        call("txe_rows_find_runs", ptr(e2c), ld2, G, r, ptr(run_id), ptr(run_off), ptr(n_runs), _lib.stream_ptr())
+    return run_id, run_off, n_runs
+
+
+class BilinearStackedRunsFunction(torch.autograd.Function):
+    """BilinearRunsFunction on the reference collate's STACKED query matrix (one row per pair): the runs of equal consecutive rows are
+    found on the device in every call (bit-wise row comparison + a scan, no host synchronisation) and the products run on one row per
+    run (txe_bilinear_stacked_*).  Right for any e2; the caller (model_zoo._Bilinear) takes this form when its first training batch
+    showed that rows repeat.  No gradient to the queries."""
+
+    @staticmethod
+    def forward(ctx, e1, e2, W, apply_exp):
+        _need_cuda(e1, e2, W)
+        e1, ld1 = _rows(e1)
+        e2, ld2 = _rows(e2)
+        Wf = _f32(W).reshape(W.shape[-2], W.shape[-1])
+        G, l = e1.shape
+        r = e2.shape[1]
+        _run_id, run_off, n_runs = find_row_runs(e2)
+        s = _empty((G,), e1)
+        V = _empty((max(G, 1), l), e1)                        # (sized for G runs; the batch's runs fill the first rows)
+        with _lib.on_device(e1.device):
+            call("txe_bilinear_stacked_fwd", ptr(e1), ld1, ptr(e2), ld2, ptr(run_off), ptr(n_runs), G, l, r, ptr(Wf), int(apply_exp), ptr(V),
+                 ptr(s), _lib.stream_ptr())
+        ctx.misc = (e1, ld1, e2, ld2, run_off, n_runs, V, s, int(apply_exp), W.shape)
+        return s.unsqueeze(1)
+
+    @staticmethod
+    def backward(ctx, ds):
+        e1, ld1, e2, ld2, run_off, n_runs, V, s, apply_exp, wshape = ctx.misc
+        G, l = e1.shape
+        r = e2.shape[1]
+        ds = _f32(ds.reshape(-1))
+        d_e1 = _empty((G, l), e1)
+        dW = _empty((l, r), e1)
+        with _lib.on_device(e1.device):
+            wsb = call("txe_bilinear_stacked_bwd_ws_bytes", G, l, r)
+            ws = _ws(wsb, e1)
+            call("txe_bilinear_stacked_bwd", ptr(e1), ld1, ptr(e2), ld2, ptr(run_off), ptr(n_runs), G, l, r, apply_exp, ptr(V), ptr(s), ptr(ds),
+                 ptr(d_e1), l, ptr(dW), ptr(ws), wsb, _lib.stream_ptr())
+        return d_e1, None, dW.reshape(wshape), None
+
+
 # ================================================================================================================
 # inference-side helpers (no autograd)
 # ================================================================================================================

@@ -559,6 +559,7 @@ def test_query_projection_prefetched_on_the_second_stream_changes_nothing(monkey
     spec, z, shapes, x, q, params, graph = load_case(name)
     model = _build_model(spec, params).eval()
     outs = []
+    monkeypatch.setattr(ops, "_NO_QUERY_RUNS", True)                # (the GEMM form of the match, whatever the batch size)
     for on, late in ((False, False), (True, False), (True, True)):
         monkeypatch.setattr(ops, "_PREFETCH_V", on)
         monkeypatch.setattr(ops, "_PREFETCH_V_LATE", late)
@@ -1185,6 +1186,73 @@ def test_device_batch_loader_builds_on_a_side_stream_what_the_inline_builder_bui
         with torch.no_grad():                                       # (the loader's scores come from the one-row-per-query form: another
             np.testing.assert_allclose(host(model(g, x, qf)), want["pred"], rtol=2e-5, atol=1e-7)     # summation order in V = Q W^T)
         assert np.isfinite(want["pred"]).all() and want["labels"].reshape(16, 8)[:, 0].tolist() == [1] * 16
+
+
+@pytest.mark.gpu
+def test_runs_of_stacked_query_rows_found_on_the_device_and_the_match_on_them(monkeypatch):
+    """txe_rows_find_runs on the reference collate's stacked query matrix (data_loaders.py:9-28: a query's row once per pair) against
+    numpy -- runs of every length, a row that returns after another (two runs), -0.0 against 0.0 (different bit patterns: two runs), more
+    rows than one scan chunk, no repetition at all, one row -- and BilinearStackedRunsFunction (txe_bilinear_stacked_*) against the GEMM
+    form on the same matrix: scores, d_hg, dW; then the matcher's one-time decision (model_zoo._Bilinear._repeats)."""
+    from taxoexpan_amd import model_zoo as mz, ops
+    dev = _dev()
+    rs = np.random.RandomState(2)
+    r, l = 250, 500
+    table = rs.standard_normal((64, r)).astype(np.float32)
+    table[10, :] = 0.0
+    table[11, :] = 0.0
+    table[11, 7] = -0.0
+    for ids in (np.concatenate([[3], np.repeat([7, 1, 7, 22, 10, 11, 10], [32, 1, 5, 90, 2, 2, 1]), np.repeat(np.arange(40), 60), [5, 6]]),
+                np.arange(64).repeat(1), np.array([9]), np.repeat([4], 1500)):
+        e2 = torch.from_numpy(table[ids]).to(dev)
+        G = len(ids)
+        run_id, run_off, n_runs = ops.find_row_runs(e2)
+        start = np.flatnonzero(np.concatenate([[True], ids[1:] != ids[:-1]]))
+        U = len(start)
+        assert int(n_runs.item()) == U
+        assert run_off.cpu().numpy()[:U + 1].tolist() == start.tolist() + [G]
+        assert run_id.cpu().numpy()[:G].tolist() == (np.cumsum(np.concatenate([[1], ids[1:] != ids[:-1]])) - 1).tolist()
+        W = torch.from_numpy((rs.standard_normal((1, l, r)) * 0.05).astype(np.float32)).to(dev)
+        e1 = torch.from_numpy((rs.standard_normal((G, l)) * 0.3).astype(np.float32)).to(dev)
+        up = torch.linspace(-1, 1, G, device=dev)
+        for apply_exp in (False, True):
+            res = []
+            for fn in (lambda a, w: ops.BilinearPairFunction.apply(a, e2, w, apply_exp, None),
+                       lambda a, w: ops.BilinearStackedRunsFunction.apply(a, e2, w, apply_exp)):
+                a, w = e1.clone().requires_grad_(True), W.clone().requires_grad_(True)
+                sc = fn(a, w)
+                (sc.reshape(-1) * up).sum().backward()
+                res.append((sc.detach(), a.grad, w.grad))
+            for k in range(3):
+                scale = max(res[0][k].abs().max().item(), 1e-30)
+                np.testing.assert_allclose(res[1][k].cpu().numpy(), res[0][k].cpu().numpy(), rtol=2e-5, atol=2e-6 * scale)
+    # the matcher decides once, on its first training batch of at least 256 pairs
+    rep = torch.from_numpy(table[np.repeat(np.arange(16), 32)]).to(dev)
+    uniq = torch.from_numpy(rs.standard_normal((512, r)).astype(np.float32)).to(dev)
+    hg = torch.from_numpy(rs.standard_normal((512, l)).astype(np.float32) * 0.1).to(dev).requires_grad_(True)
+    m = mz.LBM(l, r).to(dev)
+    seen = []
+    real = ops.BilinearStackedRunsFunction.apply
+    monkeypatch.setattr(ops.BilinearStackedRunsFunction, "apply", staticmethod(lambda *a: (seen.append(1), real(*a))[1]))
+    with torch.no_grad():
+        m(hg, rep)
+    assert not hasattr(m, "_query_rows_repeat") and not seen         # (no decision outside training)
+    m(hg, rep).sum().backward()
+    assert m._query_rows_repeat is True and len(seen) == 1
+    m(hg, uniq).sum().backward()                                      # a batch that does not repeat: same form, still right
+    a = hg.detach().clone().requires_grad_(True)
+    ref = ops.BilinearPairFunction.apply(a, uniq, m.W.weight, True, None)
+    np.testing.assert_allclose(m(hg, uniq).detach().cpu().numpy(), ref.detach().cpu().numpy(), rtol=2e-5)
+    assert len(seen) == 3
+    m2 = mz.BIM(l, r).to(dev)
+    m2(hg, uniq).sum().backward()
+    assert m2._query_rows_repeat is False
+    m2(hg, rep).sum().backward()
+    assert len(seen) == 3
+    m3 = mz.BIM(l, r).to(dev)
+    monkeypatch.setattr(ops, "_NO_QUERY_RUNS", True)
+    m3(hg, rep).sum().backward()
+    assert not hasattr(m3, "_query_rows_repeat") and len(seen) == 3
 
 
 @pytest.mark.gpu

@@ -513,10 +513,14 @@ int txe_rows_find_runs(const float* e2, long long ld_e2, int G, int r, int* run_
     if (G < 0 || r < 1 || !e2 || !run_id || !run_off || !n_runs) return TXE_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
     if (G > 0) {
+        ProfScope prof("row_change_kernel", st, 4.0 * ((double)G * r + G), 1);
         hipLaunchKernelGGL(row_change_kernel, dim3((G + 3) / 4), dim3(256), 0, st, e2, ld_e2, G, r, run_id);
-        TXE_CHECK_LAUNCH();
     }
-    hipLaunchKernelGGL(runs_scan_kernel, dim3(1), dim3(1024), 0, st, (const int*)run_id, G, run_id, run_off, n_runs);
+    TXE_CHECK_LAUNCH();
+    {
+        ProfScope prof("runs_scan_kernel", st, 4.0 * 3.0 * G, 1);
+        hipLaunchKernelGGL(runs_scan_kernel, dim3(1), dim3(1024), 0, st, (const int*)run_id, G, run_id, run_off, n_runs);
+    }
     TXE_CHECK_LAUNCH();
     return TXE_OK;
 }

@@ -1227,6 +1227,7 @@ def test_runs_of_stacked_query_rows_found_on_the_device_and_the_match_on_them(mo
                 scale = max(res[0][k].abs().max().item(), 1e-30)
                 np.testing.assert_allclose(res[1][k].cpu().numpy(), res[0][k].cpu().numpy(), rtol=2e-5, atol=2e-6 * scale)
     # the matcher decides once, on its first training batch of at least 256 pairs
+    monkeypatch.setattr(ops, "_NO_QUERY_RUNS", False)
     rep = torch.from_numpy(table[np.repeat(np.arange(16), 32)]).to(dev)
     uniq = torch.from_numpy(rs.standard_normal((512, r)).astype(np.float32)).to(dev)
     hg = torch.from_numpy(rs.standard_normal((512, l)).astype(np.float32) * 0.1).to(dev).requires_grad_(True)

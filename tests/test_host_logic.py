@@ -165,6 +165,26 @@ def test_gathered_rows_is_an_ordinary_tensor_to_everyone_else():
     assert not ops._use_table(x, False, 0.0) and not ops._use_table(want, False, 0.0)
 
 
+def test_repeated_rows_is_the_stacked_matrix_to_everyone_else():
+    """ops.RepeatedRows (the query features of a training batch as one row per query + run offsets): the runs found from the ids,
+    dense() = the reference collate's stack (data_loaders.py:9-28), the tensor-like surface the model code touches; BIM / LBM never
+    take a CPU path with it; a matcher without a runs form sees the stacked tensor"""
+    from taxoexpan_amd import ops
+    from taxoexpan_amd.model_zoo import LBM
+    table = torch.arange(40, dtype=torch.float32).reshape(10, 4)
+    ids = np.array([3, 3, 3, 7, 1, 1, 3, 9, 9, 9, 9])
+    rr = ops.RepeatedRows.from_ids(table, ids)
+    assert rr.rows.tolist() == table[[3, 7, 1, 3, 9]].tolist() and rr.run_off.tolist() == [0, 3, 4, 6, 7, 11]
+    assert rr.shape == (11, 4) and rr.dim() == 2 and rr.dtype == torch.float32 and rr.device == table.device and not rr.requires_grad
+    assert torch.equal(rr.dense(), table[torch.from_numpy(ids)]) and torch.equal(ops.dense_rows(rr), rr.dense()) and ops.dense_rows(table) is table
+    empty = ops.RepeatedRows.from_ids(table, np.zeros(0, dtype=np.int64))
+    assert empty.shape == (0, 4) and empty.run_off.tolist() == [0] and empty.dense().shape == (0, 4)
+    moved = rr.to("cpu")
+    assert torch.equal(moved.dense(), rr.dense()) and moved.n_rows == 11
+    with pytest.raises((RuntimeError, ValueError, AssertionError)):
+        LBM(6, 4)(torch.randn(11, 6), rr)                     # host tensors: no CPU fallback for the runs form either
+
+
 def test_loss_and_optimizer_have_no_cpu_path():
     """taxoexpan_amd.loss / optim mirror model/loss.py:52-57 and torch.optim.Adam's constructor, and fail loudly off the GPU"""
     import pytest

@@ -349,10 +349,10 @@ _COUNT_SLOTS = {}
 
 
 def _count_slot(dev):
-    """a pinned int32 for the next job's read-back (a small ring: jobs in flight at the same time do not share one)"""
-    ring = _COUNT_SLOTS.setdefault(str(dev), dict(slots=[torch.empty(1, dtype=torch.int32).pin_memory() for _ in range(8)], k=0))
-    ring["k"] = (ring["k"] + 1) % len(ring["slots"])
-    return ring["slots"][ring["k"]]
+    """a pinned int32 for a job's read-back: slots are handed back by device_egonet_finish; a job that is never finished keeps its
+    slot (a few bytes), it is never shared"""
+    free = _COUNT_SLOTS.setdefault(str(dev), [])
+    return free.pop() if free else torch.empty(1, dtype=torch.int32).pin_memory()
 
 
 def device_egonet_finish(job, with_features=True):
@@ -361,6 +361,8 @@ def device_egonet_finish(job, with_features=True):
     dtax, dev, G = job.dtax, job.dtax.device, job.G
     job.ready.synchronize()
     N = int(job.n_host[0])
+    _COUNT_SLOTS.setdefault(str(dev), []).append(job.n_host)
+    job.n_host = None
     E = 2 * N - G
     i32 = lambda k: torch.empty(max(k, 1), dtype=torch.int32, device=dev)
     node_off = job.node_off

@@ -1189,6 +1189,39 @@ def test_device_batch_loader_builds_on_a_side_stream_what_the_inline_builder_bui
 
 
 @pytest.mark.gpu
+def test_many_batches_begun_before_any_is_finished():
+    """begin_device_batch / finish_device_batch with a dozen batches in flight (each job owns its pinned read-back slot, the upload
+    buffers take turns behind their events): every batch equals the one-call construction of the same anchors, both query forms"""
+    from taxoexpan_amd import graph as G, ops, synthetic as syn
+    from taxoexpan_amd.data_loaders import begin_device_batch, build_device_batch, finish_device_batch
+    dev = _dev()
+    tax = syn.make_taxonomy(3000, 4500, 12, seed=3)
+    dtax = G.DeviceTaxonomy(tax.par_ptr, tax.par_idx, tax.chd_ptr, tax.chd_idx, tax.features, dev)
+    side = torch.cuda.Stream(device=dev)
+    torch.cuda.synchronize()
+    rs = np.random.RandomState(0)
+    jobs, args = [], []
+    for b in range(12):
+        q = rs.randint(0, tax.n_nodes, size=16)
+        anchors = rs.randint(0, tax.n_nodes, size=16 * 5)
+        exclude = np.where(np.arange(80) % 5 == 0, np.repeat(q, 5), -1)
+        args.append((anchors, exclude, np.repeat(q, 5)))
+        jobs.append(begin_device_batch(dtax, anchors, exclude, np.repeat(q, 5), expand_factor=4, seed=b, stream=side, repeated_queries=b % 2 == 1))
+    for b, (job, (anchors, exclude, qid)) in enumerate(zip(jobs, args)):
+        got = finish_device_batch(job, dtax.features)
+        want = build_device_batch(dtax, anchors, exclude, qid, dtax.features, expand_factor=4, seed=b)
+        torch.cuda.synchronize()
+        assert got["n_nodes"] == want["n_nodes"] and got["n_edges"] == want["n_edges"]
+        assert torch.equal(got["g"].ndata["_id"], want["g"].ndata["_id"]) and torch.equal(got["pos"], want["pos"]) and torch.equal(got["x"], want["x"])
+        ca, cb = got["g"].csr(dev), want["g"].csr(dev)
+        for f in ("rowptr_in", "col_src", "eid_in", "rowptr_out", "col_dst", "pos_out", "graph_off"):
+            assert torch.equal(getattr(ca, f), getattr(cb, f)), f
+        qa = got["qf"]
+        assert isinstance(qa, ops.RepeatedRows) == (b % 2 == 1)
+        assert torch.equal(ops.dense_rows(qa), want["qf"])
+
+
+@pytest.mark.gpu
 def test_runs_of_stacked_query_rows_found_on_the_device_and_the_match_on_them(monkeypatch):
     """txe_rows_find_runs on the reference collate's stacked query matrix (data_loaders.py:9-28: a query's row once per pair) against
     numpy -- runs of every length, a row that returns after another (two runs), -0.0 against 0.0 (different bit patterns: two runs), more

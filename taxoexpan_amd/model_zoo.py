@@ -448,7 +448,7 @@ class _Bilinear(nn.Module):
     # ---- stacked query rows that repeat (data_loaders.py:9-28 stacks a query's row once per pair) -------------------------------------
     def _stacked_runs_ok(self, e1, e2):
         return (not ops._NO_QUERY_RUNS and torch.is_grad_enabled() and torch.is_tensor(e2) and e2.is_cuda and e2.dim() == 2 and
-                not e2.requires_grad and e2.shape[0] >= 256 and (e1 is None or e2.shape[0] == e1.shape[0]))
+                not e2.requires_grad and 256 <= e2.shape[0] <= (1 << 18) and (e1 is None or e2.shape[0] == e1.shape[0]))     # (one workgroup scans the rows)
 
     def _repeats(self, e2):
         """does this matcher's training input repeat its query rows?  Decided ONCE, on the first training batch it sees (the runs are

@@ -758,8 +758,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": WORKLOAD_TEXT[args.workload] + STEP_TEXT,
-                       "output_layer": ("unfolded (TXE_NO_FOLD=1)" if os.environ.get("TXE_NO_FOLD", "0") == "1" else
-                                        "folded behind the weighted-mean readout (exact re-association, DESIGN 4.1): G graph rows instead of N node rows"),
+                       "output_layer": "folded behind the weighted-mean readout (exact re-association, DESIGN 4.1): G graph rows instead of N node rows",
                        "egonets_per_step_per_gpu": N_QUERIES * (1 + NEG), "avg_edges_per_step_per_gpu": edges / args.steps / world,
                        "parallelism": f"dp{world}"},
             "roofline_all": roof_all,

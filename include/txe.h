@@ -88,10 +88,8 @@ int txe_gat_dense_bwd(const float* X, int n_nodes, int Kh, int Pd, const int* po
                       const float* attn_l, const float* attn_r, int H, int D, float feat_drop_p, const unsigned* mask, const float* d_Y,
                       int need_dh, int act_on, float act_slope, float* d_X, float* dW, float* d_attn_l, float* d_attn_r, float* dP,
                       int x_dropped, int phases, void* ws, size_t ws_bytes, void* stream);
-/* phases: 7 = all of it; 1 | 2 | 4 = the d_X product | the weight-gradient product (split-K partial slices) | the reductions that
- * finish dW, d_attn, dP -- 1 and 2 are independent (a second stream may run the d_X product BESIDE the weight gradient), 4 needs both.
- * | 16 on EVERY call of such a pass: the weight gradient then leaves the concurrent product its share of the workgroup slots.
- * | 32 on every call of a pass: d_X through the GEMM even where txe_gat_dx_streams() == 1 (A/B switch). */
+/* phases: 7 = all of it; 1 | 2 | 4 = d_X | the weight-gradient product (split-K partial slices) | the reductions that finish dW,
+ * d_attn, dP -- 1 and 2 are independent, 4 needs both. */
 int txe_zero_cols(float* x, long long ld, int n_rows, int c0, int c1, void* stream);
 /* 1 when txe_gat_dense_bwd forms d_X with the streaming position-column kernel (a first PGAT layer: need_dh == 0, the columns behind
  * Kh fit 64 -- model_zoo.py:214-215): phase 1 is then ONE pass over d_Y at HBM speed that also leaves dP's per-class partial sums,
@@ -123,8 +121,9 @@ int txe_gat_aggregate_table_fwd(const int* rowptr_in, const int* col_src, int n_
 int txe_gat_aggregate_fwd(const int* rowptr_in, const int* col_src, int n_nodes, const float* ft, long long ld_ft,
                           const float* a_src, const float* a_dst, int ld_a, int H, int D, float attn_slope, float attn_drop_p,
                           unsigned long long seed, int out_mode, float act_slope, float* out, long long ld_out, float* alpha,
-                          const float* nx_wa, int nx_kp, const unsigned* nx_mask, float nx_feat_drop_p, float* nx_a12, void* stream);
-/* d_pre = gradient w.r.t. the PRE-activation aggregated output.  Writes d_ft [N][H*D], d_a_src/d_a_dst [N][H]
+                          const float* nx_wa, int nx_kp, const unsigned* nx_mask, float nx_feat_drop_p, float* nx_a12, int npw, void* stream);
+/* npw: destination nodes per wave, 0 = chosen from the batch size, 1 | 2 = forced (bit-equal results; a parity test compares them).
+ * d_pre = gradient w.r.t. the PRE-activation aggregated output.  Writes d_ft [N][H*D], d_a_src/d_a_dst [N][H]
  * (row stride ld_da).  dz_ws: E*H floats of scratch.  n_pad: floats following d_a_dst[v][H-1] in every row that are cleared as
  * well (the zero padding columns of txe_gat_dense_bwd's d_Y operand when d_ft | d_a_src | d_a_dst share one padded row); 0 = none. */
 int txe_gat_aggregate_bwd(const int* rowptr_in, const int* col_src, const int* rowptr_out, const int* col_dst,
@@ -244,10 +243,12 @@ int txe_score_positives(const float* Q, long long ld_q, int nq, const float* Up,
 
 /* plain dense product on the fp32 MFMA GEMM (tests / micro-benchmarks).  layout 0: C = A[M][K] B[N][K]^T; 1: C = A[M][K] B[K][N];
  * 2: C = A[K][M]^T B[K][N].  splits > 1: `splits` partial products at C + z*M*ldc.  ws/ws_bytes (optional, txe_gemm_tail_ws_bytes):
- * scratch that lets the last, partial round of workgroups be split along k ("tail splitting"). */
+ * scratch that lets the last, partial round of workgroups be split along k ("tail splitting").
+ * route: 0 = the route the model paths take; test bits selecting a bit-equal alternative kernel: 1 = whole rounds on gemm_kernel instead
+ * of the persistent kernel, 2 = split-K TN products without the LDS-direct copies, 4 = every eligible split-K product on 128 x 160 tiles. */
 size_t txe_gemm_tail_ws_bytes(void);
 int txe_gemm_plain(int layout, const float* A, long long lda, const float* B, long long ldb, float* C, long long ldc, int M, int N,
-                   int K, int splits, void* ws, size_t ws_bytes, void* stream);
+                   int K, int splits, int route, void* ws, size_t ws_bytes, void* stream);
 
 /* ---- rank extraction of the scoring loop: test_fast.py:16-22 + model/metric.py:7-31 (strict inequalities, the
  * query's other positives excluded).  pos_off [nq+1], pos_idx: candidate columns of each query's true parents. */

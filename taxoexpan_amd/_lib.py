@@ -24,7 +24,7 @@ SIGNATURES = {
     "txe_gat_dense_bwd": (I, [P, I, I, I, P, I, P, P, P, P, I, I, F, P, P, I, I, F, P, P, P, P, P, I, I, P, SZ, P]),
     "txe_zero_cols": (I, [P, L, I, I, I, P]),
     "txe_gat_dx_streams": (I, [I, I, I]),
-    "txe_gat_aggregate_fwd": (I, [P, P, I, P, L, P, P, I, I, I, F, F, U64, I, F, P, L, P, P, I, P, F, P, P]),
+    "txe_gat_aggregate_fwd": (I, [P, P, I, P, L, P, P, I, I, I, F, F, U64, I, F, P, L, P, P, I, P, F, P, I, P]),
     "txe_gat_aggregate_table_supported": (I, [I, I, L, I, I]),
     "txe_gat_aggregate_table_fwd": (I, [P, P, I, P, L, P, P, P, I, I, I, F, I, F, P, L, P, I, P, P]),
     "txe_gat_aggregate_bwd": (I, [P, P, P, P, P, I, P, L, P, P, I, I, I, F, F, U64, P, P, L, P, L, P, P, I, P, I, P]),
@@ -68,7 +68,7 @@ SIGNATURES = {
     "txe_score_positives": (I, [P, L, I, P, L, I, I, I, P, P, P]),
     "txe_rank_finalize": (I, [P, I, P, P, I, P, P]),
     "txe_gemm_tail_ws_bytes": (SZ, []),
-    "txe_gemm_plain": (I, [I, P, L, P, L, P, L, I, I, I, I, P, SZ, P]),
+    "txe_gemm_plain": (I, [I, P, L, P, L, P, L, I, I, I, I, I, P, SZ, P]),
     "txe_build_csr_ws_bytes": (SZ, [I, I]),
     "txe_build_csr": (I, [P, P, I, I, P, P, P, P, P, P, P, SZ, P]),
     "txe_rank_block": (I, [P, L, I, I, P, P, P, I, P, P]),

@@ -778,9 +778,8 @@ struct KName {
     } while (0)
 
 // destination nodes per wave of the forward sweep (gat_aggregate_fwd_kernel's NPW): two -- 97 -> 93 us in the training step, 77 -> 72 us
-// stand-alone (tools/agg_fwd_variants.py); TXE_FWD_NPW = 1 | 2 overrides
-static inline int fwd_nodes_per_wave(int n_nodes) {
-    static const int forced = [] { const char* e = getenv("TXE_FWD_NPW"); return e ? atoi(e) : 0; }();
+// stand-alone (tools/agg_fwd_variants.py); the entry point's `npw` argument (1 | 2) overrides -- the two are bit-equal, a parity test
+static inline int fwd_nodes_per_wave(int n_nodes, int forced) {
     if (forced == 1 || forced == 2) return forced;
     return n_nodes >= 4096 ? 2 : 1;       // (4 per wave was measured too: 173 VGPRs = two waves per SIMD, 119 us against 93 us)
 }
@@ -801,8 +800,8 @@ extern "C" {
 int txe_gat_aggregate_fwd(const int* rowptr_in, const int* col_src, int n_nodes, const float* ft, long long ld_ft,
                           const float* a_src, const float* a_dst, int ld_a, int H, int D, float attn_slope, float attn_drop_p,
                           unsigned long long seed, int out_mode, float act_slope, float* out, long long ld_out, float* alpha,
-                          const float* nx_wa, int nx_kp, const unsigned* nx_mask, float nx_feat_drop_p, float* nx_a12, void* stream) {
-    if (n_nodes < 0 || H < 1 || H > GAT_MAXH || D < 1 || !rowptr_in || !ft || !a_src || !a_dst || !out) return TXE_ERR_ARG;
+                          const float* nx_wa, int nx_kp, const unsigned* nx_mask, float nx_feat_drop_p, float* nx_a12, int npw_req, void* stream) {
+    if (n_nodes < 0 || H < 1 || H > GAT_MAXH || D < 1 || !rowptr_in || !ft || !a_src || !a_dst || !out || npw_req < 0 || npw_req > 2) return TXE_ERR_ARG;
     if (out_mode != 0 && out_mode != 1) return TXE_ERR_ARG;
     if (attn_drop_p < 0.f || attn_drop_p >= 1.f) return TXE_ERR_ARG;
     if (nx_a12 && (!nx_wa || nx_kp < H * D || nx_kp - H * D > 128 || (nx_kp & 31) || ld_out != nx_kp || nx_feat_drop_p < 0.f || nx_feat_drop_p >= 1.f ||
@@ -823,7 +822,7 @@ int txe_gat_aggregate_fwd(const int* rowptr_in, const int* col_src, int n_nodes,
     // algorithmic (compulsory) bytes, SURVEY 8d: read ft + write out + a_src/a_dst + CSR (+ alpha when kept for backward);
     // the edge count is not known here (device rowptr), the E-proportional terms are added by the caller-side model
     const int ni = pick_ni(H * D / vec);
-    const int npw = fwd_nodes_per_wave(n_nodes);
+    const int npw = fwd_nodes_per_wave(n_nodes, npw_req);
     const int nb = (n_nodes + GAT_WAVES * npw - 1) / (GAT_WAVES * npw);
     const KName kn("gat_aggregate_fwd_kernel", vec, ni, nx_a12 ? (nx.mask ? 2 : 1) : (out_drop ? 3 : 0), false, npw);
     ProfScope prof(kn.s, s, 4.0 * (2.0 * n_nodes * (double)H * D + 2.0 * n_nodes * H + n_nodes + 1), 1);

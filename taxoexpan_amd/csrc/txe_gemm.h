@@ -100,7 +100,12 @@ struct Epi {
     // 1: every element is accumulated in plain k order whatever the tile count (no k-split of a last partial round): the scoring
     // loop compares scores of different launches bit for bit
     int plain_k_order;
+    // test / micro-benchmark routes (txe_gemm_plain's `route` argument; 0 everywhere in the model paths): GEMM_ROUTE_* bits
+    int route;
 };
+constexpr int GEMM_ROUTE_NO_PERSIST = 1;     // whole rounds stay on gemm_kernel (the persistent kernel's tiles are bit-identical)
+constexpr int GEMM_ROUTE_NO_TN_LDS = 2;      // split-K TN products on gemm_kernel<false,false,4,4,160> (same k order per element)
+constexpr int GEMM_ROUTE_FORCE_BN160 = 4;    // every eligible split-K product on 128 x 160 tiles, whatever its size
 
 static inline Epi epi_plain(float* c, long long ldc, int cols) {
     Epi e;
@@ -109,7 +114,7 @@ static inline Epi epi_plain(float* c, long long ldc, int cols) {
     e.mask = reinterpret_cast<const unsigned*>(c); e.mask_ld = 0; e.mask_col0 = 0; e.mask_on = 0; e.drop_scale = 1.f;
     e.apply_exp = 0; e.split_stride = 0;
     e.cnt_mode = 0; e.cnt_off = nullptr; e.cnt_thr = nullptr; e.cnt_out = nullptr;
-    e.alg_flops = 0.0;
+    e.alg_flops = 0.0; e.route = 0;
     e.plain_k_order = 0;
     return e;
 }
@@ -983,41 +988,20 @@ int device_cu_count();     // txe_profile.hip (cached hipDeviceAttributeMultipro
 // ... above 20 GFLOP, and also where 64-wide tiles pad no more columns (N = 320 = 2 x 160 = 5 x 64: the first layer's weight
 // gradient -- 32 tiles x 16 slices fill the 512 slots exactly and run the full-rate 4-wave k-loop: 219 -> 205 us.  While that
 // product shared the chip with the skinny d_X GEMM on the second stream the fat workgroups cost more than they gained; d_X is now an
-// in-line HBM stream, txe_dxpos.hip.  TXE_BN160_STRICT=1 restores the strict rule for an A/B.)
-static inline bool bn160_eq() {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("TXE_BN160_STRICT"); v = (e && e[0] == '1') ? 0 : 1; }
-    return v == 1;
-}
-static inline double bn160_split_min_flops() { return bn160_eq() ? 2e10 : 5e10; }
-static inline bool bn160_split_enabled() {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("TXE_NO_BN160_SPLIT"); v = (e && e[0] == '1') ? 0 : 1; }     // A/B switch
-    return v == 1;
-}
-static inline bool bn160_enabled() {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("TXE_NO_BN160"); v = (e && e[0] == '1') ? 0 : 1; }     // A/B switch
-    return v == 1;
-}
+// in-line HBM stream, txe_dxpos.hip.)
+constexpr double BN160_SPLIT_MIN_FLOPS = 2e10;
 
-static inline bool bn160_forced() {          // test switch: every eligible split-K product on 128 x 160 tiles, whatever its size
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("TXE_FORCE_BN160"); v = (e && e[0] == '1') ? 1 : 0; }
-    return v == 1;
-}
-
-static inline int choose_bn(int M, int N, int splits, bool tail_split = false, int K = 0, bool allow160 = false) {
-    if (allow160 && splits > 1 && bn160_forced()) return 160;
+static inline int choose_bn(int M, int N, int splits, bool tail_split = false, int K = 0, bool allow160 = false, bool force160 = false) {
+    if (allow160 && splits > 1 && force160) return 160;
     if (N <= 64) return 64;
     const int slots = 2 * device_cu_count();
-    if (allow160 && splits > 1 && bn160_enabled() && bn160_split_enabled() && 2.0 * M * (double)N * K >= bn160_split_min_flops()) {
+    if (allow160 && splits > 1 && 2.0 * M * (double)N * K >= BN160_SPLIT_MIN_FLOPS) {
         // split-K products (weight gradients): 128 x 160 tiles when they cover N with fewer padded columns than 128-wide ones and at
         // least as few as 64-wide ones -- 320 = 2 x 160 runs the full-rate 4-wave k-loop where 5 x 64 starves the matrix pipe
         const int w160 = ((N + 159) / 160) * 160, w128 = ((N + 127) / 128) * 128, w64 = ((N + 63) / 64) * 64;
-        if (w160 < w128 && (w160 < w64 || (bn160_eq() && w160 == w64))) return 160;
+        if (w160 < w128 && w160 <= w64) return 160;
     }
-    if (allow160 && splits == 1 && bn160_enabled()) {
+    if (allow160 && splits == 1) {
         // one round of 160-wide tiles where 128-wide ones spill into a second, k-split round with its fix-up launch
         // (dZ = d_hg W: 4096 x 2080 is 32 x 13 = 416 tiles of 160 columns, 544 of 128)
         const int nbm = (M + GEMM_BM - 1) / GEMM_BM;
@@ -1040,12 +1024,6 @@ static inline int choose_bn(int M, int N, int splits, bool tail_split = false, i
         return r * bn * (bn == 64 ? (splits > 1 ? 1.1 : 1.6) : 1.0);
     };
     return cost(64) < cost(128) ? 64 : 128;
-}
-
-static inline bool gemm_persist_enabled() {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("TXE_NO_PERSIST_GEMM"); v = (e && e[0] == '1') ? 0 : 1; }     // A/B switch
-    return v == 1;
 }
 
 template <bool AK, bool BKC, int VA, int VB>
@@ -1102,10 +1080,10 @@ static inline int gemm_launch_layout(const VMat& A, const VMat& B, const Epi& E_
     const bool allow160 = !BKC && va == 4 && vb == 4 && !E.mask_on && !E.act_on && E.cnt_mode == 0 &&
                           (E.c2 == nullptr || E.cols_main >= N);
     const bool tail_split = tail_ws != nullptr && !E.plain_k_order;
-    int bn = choose_bn(M, N, splits, tail_split, K, allow160);
+    int bn = choose_bn(M, N, splits, tail_split, K, allow160, (E.route & GEMM_ROUTE_FORCE_BN160) != 0);
     int tile0 = 0;
     // whole rounds of 128 x 128 tiles of a plain product with a short reduction: persistent workgroups (gemm_persist_kernel)
-    if (splits == 1 && tail_ws != nullptr && va == 4 && vb == 4 && N > 64 && gemm_persist_enabled() && !E.mask_on && !E.act_on &&
+    if (splits == 1 && tail_ws != nullptr && va == 4 && vb == 4 && N > 64 && !(E.route & GEMM_ROUTE_NO_PERSIST) && !E.mask_on && !E.act_on &&
         E.cnt_mode == 0 && (E.c2 == nullptr || E.cols_main >= N) && (K % GEMM_BK) == 0 && K >= 5 * GEMM_BK && K <= TXE_PERSIST_MAXK &&
         A.p2 == nullptr && B.p2 == nullptr && A.cols_main == A.cols && B.cols_main == B.cols && A.rows_main >= A.rows && B.rows_main >= B.rows &&
         (AK ? A.cols : A.rows) >= K && (BKC ? B.cols : B.rows) >= K) {
@@ -1123,9 +1101,7 @@ static inline int gemm_launch_layout(const VMat& A, const VMat& B, const Epi& E_
             P.ntile_items = nfull; P.S = 1; P.kslice = nkt; P.part = nullptr;
             // the leftover tiles (a last partial round) as k-slices INSIDE the same launch: every workgroup's last item is then a
             // slice of >= 5 k-tiles whose k-loop still drains the tile before it; a fix-up launch adds the slices in fixed order
-            static int no_slices = -1;
-            if (no_slices < 0) { const char* e = getenv("TXE_NO_PERSIST_SLICES"); no_slices = (e && e[0] == '1') ? 1 : 0; }   // A/B switch
-            int S = (r > 0 && tail_split && !no_slices) ? slots / r : 0;
+            int S = (r > 0 && tail_split) ? slots / r : 0;
             if (S > nkt / 5) S = nkt / 5;
             if (S > 16) S = 16;
             int kslice = S >= 2 ? (nkt + S - 1) / S : nkt;
@@ -1209,18 +1185,15 @@ static inline int gemm_launch_layout(const VMat& A, const VMat& B, const Epi& E_
 
 // number of split-K slices for a product with `tiles` output tiles and reduction length K: fill whole rounds of
 // 2 workgroups per CU, keep >= 8 k-tiles per slice.
-// reserve: workgroup slots to leave to a product that runs BESIDE this one on the second stream (the first layer's skinny d_X under
-// its weight gradient): a split count that fills all 512 slots makes that product trickle through what is left and end last.
-static inline int choose_splits(int M, int N, int K, int reserve = 0) {
-    const int all_slots = 2 * device_cu_count();
-    const int slots = (reserve > 0 && reserve < all_slots / 2) ? all_slots - reserve : all_slots;
+static inline int choose_splits(int M, int N, int K) {
+    const int slots = 2 * device_cu_count();
     const int max_by_k = (K + 255) / 256 > 0 ? (K + 255) / 256 : 1;
     const int nkt = (K + GEMM_BK - 1) / GEMM_BK;
     int best = 1;
     double best_cost = 1e30;
     {   // 160-wide tiles (choose_bn's rule; the weight gradients are the TN products that get them)
         const int w160 = ((N + 159) / 160) * 160, w128 = ((N + 127) / 128) * 128, w64 = ((N + 63) / 64) * 64;
-        if (N > 64 && w160 < w128 && (w160 < w64 || (bn160_eq() && w160 == w64)) && bn160_enabled() && bn160_split_enabled() && 2.0 * M * (double)N * K >= bn160_split_min_flops()) {
+        if (N > 64 && w160 < w128 && w160 <= w64 && 2.0 * M * (double)N * K >= BN160_SPLIT_MIN_FLOPS) {
             const int tiles = ((M + GEMM_BM - 1) / GEMM_BM) * (w160 / 160);
             for (int s = 2; s <= 64 && s <= max_by_k; ++s) {
                 const long long blocks = (long long)tiles * s;

@@ -13,7 +13,7 @@ int gemm_tn_lds_launch(const VMat& A, const VMat& B, const Epi& E, int M, int N,
         return m.p != nullptr && m.p2 == nullptr && m.p3 == nullptr && m.mask_on == 0 && m.cols_main == m.cols && m.rows_main >= m.rows &&
                (m.ld & 3) == 0 && m.ld >= 4 && (reinterpret_cast<uintptr_t>(m.p) & 15) == 0;
     };
-    if (!tn_lds_enabled() || !plain(A) || !plain(B) || E.act_on || E.mask_on || E.cnt_mode != 0 || E.apply_exp ||
+    if ((E.route & GEMM_ROUTE_NO_TN_LDS) || !plain(A) || !plain(B) || E.act_on || E.mask_on || E.cnt_mode != 0 || E.apply_exp ||
         (E.c2 != nullptr && E.cols_main < N) || A.cols < M || B.cols < N || A.rows < K || B.rows < K || K < 1 || (E.ldc & 3) ||
         (reinterpret_cast<uintptr_t>(E.c) & 15) != 0 || (E.split_stride & 3))
         return TXE_ERR_ARG;

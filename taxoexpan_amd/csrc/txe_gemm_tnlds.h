@@ -201,10 +201,4 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_lds_kernel(const TnLds p) {
     }
 }
 
-static inline bool tn_lds_enabled() {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("TXE_NO_TN_LDS"); v = (e && e[0] == '1') ? 0 : 1; }     // A/B switch
-    return v == 1;
-}
-
 }  // namespace txe

@@ -556,12 +556,15 @@ int txe_bilinear_stacked_bwd(const float* e1, long long ld_e1, const float* e2, 
 // Plain dense product on the library's fp32 MFMA GEMM (tests / micro-benchmarks; the model paths above use the same kernels
 // through their fused entry points).  layout 0: C = A[M][K] * B[N][K]^T;  1: C = A[M][K] * B[K][N];  2: C = A[K][M]^T * B[K][N].
 // splits > 1 writes `splits` partial products at C + z*M*N (the caller reduces them).
+// route: 0 = the route the model paths take; test bits (bit-equal alternatives the parity tests compare): 1 whole rounds on gemm_kernel
+// instead of the persistent kernel, 2 split-K TN products without the LDS-direct copies, 4 every eligible split-K product on 128 x 160 tiles.
 size_t txe_gemm_tail_ws_bytes(void) { return gemm_tail_ws_bytes(); }
 
 int txe_gemm_plain(int layout, const float* A, long long lda, const float* B, long long ldb, float* C, long long ldc, int M, int N,
-                   int K, int splits, void* ws, size_t ws_bytes, void* stream) {
-    if (layout < 0 || layout > 2 || M < 0 || N < 0 || K < 0 || !A || !B || !C) return TXE_ERR_ARG;
+                   int K, int splits, int route, void* ws, size_t ws_bytes, void* stream) {
+    if (layout < 0 || layout > 2 || M < 0 || N < 0 || K < 0 || !A || !B || !C || route < 0 || route > 7) return TXE_ERR_ARG;
     Epi E = epi_plain(C, ldc, N);
+    E.route = route;
     if (splits > 1) E.split_stride = (long long)M * ldc;
     hipStream_t s = (hipStream_t)stream;
     if (layout == 0) return gemm_nt(vmat_plain(A, lda, M, K), vmat_plain(B, ldb, N, K), E, M, N, K, splits, s, ws, ws_bytes);

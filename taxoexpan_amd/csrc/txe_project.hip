@@ -724,9 +724,8 @@ int txe_gat_dense_fwd(const float* X, int n_nodes, int Kh, int Pd, const float* 
 //                columns < Kh are multiplied by leaky'(X) when act_slope_on (X[:, :Kh] is then the activated output of the
 //                previous layer), all by the dropout factor.
 //   dW [F][Kt], d_attn_l / d_attn_r [F], dP [vocab][Pd].
-// phases: | 32 = never the streaming position-column kernel (A/B switch);
-// phases: 7 = everything; 1 = the d_X GEMM, 2 = the dW GEMM (independent of each other: a caller may put the skinny, latency-bound
-// d_X product on a second stream under the dW product), 4 = the reductions that need both -- separate calls share the workspace.
+// phases: 7 = everything; 1 = d_X, 2 = the dW GEMM (independent of each other), 4 = the reductions that need both -- separate calls
+// share the workspace.
 int txe_gat_dense_bwd(const float* X, int n_nodes, int Kh, int Pd, const int* pos, int vocab, const float* Wp, const float* W,
                       const float* attn_l, const float* attn_r, int H, int D, float feat_drop_p, const unsigned* mask, const float* d_Y,
                       int need_dh, int act_on, float act_slope, float* d_X, float* dW, float* d_attn_l, float* d_attn_r, float* dP,
@@ -744,7 +743,7 @@ int txe_gat_dense_bwd(const float* X, int n_nodes, int Kh, int Pd, const int* po
     // ---- d_X[:, c0:Kt] = d_Y * Wp[:, c0:Kt] ----
     const int c0 = need_dh ? 0 : (Kh / 4) * 4;      // 16-byte aligned start of the position columns
     // position columns only: one stream over d_Y (txe_dxpos.hip) that also leaves the per-class partial sums of dP
-    const bool stream_dx = !(phases & 32) && txe_gat_dx_streams(Kh, Pd, need_dh) == 1 && n_nodes > 0;
+    const bool stream_dx = txe_gat_dx_streams(Kh, Pd, need_dh) == 1 && n_nodes > 0;
     DxPosArgs da;
     memset(&da, 0, sizeof(da));
     if (stream_dx) {
@@ -778,17 +777,7 @@ int txe_gat_dense_bwd(const float* X, int n_nodes, int Kh, int Pd, const int* po
     Epi E = epi_plain(p.part, Kp, Kp);
     E.split_stride = (long long)Fp * Kp;
     E.alg_flops = 2.0 * Fe * (double)Kt * n_nodes;
-    // phases & 16: the caller runs the d_X product (phase 1) on another stream BESIDE this one.  The weight gradient then leaves it
-    // its share of the workgroup slots (by padded flops): with all 512 taken (6 slices x 80 tiles = 480 workgroups that each run for
-    // the whole product) the skinny product crawls through the 32 left and ends 20 us after it -- 5 slices: both end together,
-    // step -13 us.  Every call of one backward pass must carry the same flag (the reduction reads `splits` partial slices).
-    int splits = p.splits;
-    if ((phases & 16) && Kt - c0 > 0 && n_nodes > 0 && !stream_dx) {
-        const double w_dx = (double)round_up(Kt - c0, 64), w_dw = (double)Kp;
-        const int reserve = (int)(2.0 * device_cu_count() * w_dx / (w_dx + w_dw) + 0.5);
-        const int sp = choose_splits(Fp, Kp, n_nodes, reserve);
-        if (sp < splits) splits = sp;                  // (the workspace holds p.splits slices)
-    }
+    const int splits = p.splits;
     if (phases & 2) {
         rc = gemm_tn(A, B, E, Fp, Kp, n_nodes, splits, s);
         if (rc) return rc;

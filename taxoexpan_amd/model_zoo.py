@@ -17,7 +17,6 @@ Side effects the callers rely on are kept: PGAT/PGCN pop g.ndata['pos'] (model_z
 writes g.ndata['a'] (:241).
 """
 import math
-import os
 
 import torch
 import torch.nn as nn
@@ -142,8 +141,9 @@ def _gat_stack(layers, embeddings, g, h, pos, activation, training):
     return ops.apply_stack(ops.GATStackFunction, g.csr(h.device), cfg, h, pos, None, None, *params)
 
 
-# TXE_NO_FOLD=1 switches the folded output layer off (A/B measurements, debugging): graph_propagate then returns the N x out tensor
-_NO_FOLD = bool(int(os.environ.get("TXE_NO_FOLD", "0")))
+# True switches the folded output layer off: graph_propagate then returns the N x out tensor (the parity tests compare the two routes;
+# a plain module attribute like ops._NO_* -- nothing here reads the environment)
+_NO_FOLD = False
 
 
 class DeferredNodeOutput:
@@ -235,7 +235,13 @@ class GCN(nn.Module):
 
     def forward(self, g, features):
         """model_zoo.py:128-137"""
-        return _gcn_stack(self.layers, None, g, features, None, self.training)
+        out = _gcn_stack(self.layers, None, g, features, None, self.training)
+        if out is not None:
+            return out
+        h = features                       # an activation other than leaky_relu: layer by layer (GCNLayer applies it itself)
+        for layer in self.layers:
+            h = layer(g, h)
+        return h
 
 
 class PGCN(nn.Module):
@@ -249,7 +255,13 @@ class PGCN(nn.Module):
     def forward(self, g, features):
         """model_zoo.py:155-167 (pops g.ndata['pos'], :163)"""
         positions = g.ndata.pop('pos').to(features.device)
-        return _gcn_stack(self.layers, self.prop_position_embeddings, g, features, positions, self.training)
+        out = _gcn_stack(self.layers, self.prop_position_embeddings, g, features, positions, self.training)
+        if out is not None:
+            return out
+        h = features                       # an activation other than leaky_relu: layer by layer, concat materialised (model_zoo.py:164-166)
+        for emb, layer in zip(self.prop_position_embeddings, self.layers):
+            h = layer(g, torch.cat((h, emb(positions)), 1))
+        return h
 
 
 def _gcn_stack(layers, embeddings, g, h, pos, training):
@@ -257,8 +269,7 @@ def _gcn_stack(layers, embeddings, g, h, pos, training):
     for l in layers:
         s = _fused_slope(l.activation)
         if l.activation and s is None:
-            raise NotImplementedError("GCN/PGCN: only leaky_relu (what model.py passes) or no activation is supported "
-                                      "by the fused MI355X path; use GCNLayer directly for other activations")
+            return None                    # (the caller runs the layers one by one: same results, the activation applied by torch)
         slopes.append(s)
     vocab = 0 if embeddings is None else embeddings[0].weight.shape[0]
     cfg = ops.GCNConfig([l.weight.shape[1] for l in layers], vocab, slopes, [_p(l.dropout, training) for l in layers],
@@ -450,16 +461,33 @@ class _Bilinear(nn.Module):
         return (not ops._NO_QUERY_RUNS and torch.is_grad_enabled() and torch.is_tensor(e2) and e2.is_cuda and e2.dim() == 2 and
                 not e2.requires_grad and 256 <= e2.shape[0] <= (1 << 18) and (e1 is None or e2.shape[0] == e1.shape[0]))     # (one workgroup scans the rows)
 
+    RECHECK_EVERY = 64      # training batches between two looks at the run count
+
     def _repeats(self, e2):
-        """does this matcher's training input repeat its query rows?  Decided ONCE, on the first training batch it sees (the runs are
-        counted on the device and read back: the one host synchronisation this costs): at least three rows in four repeat -> every
-        later batch takes the one-row-per-run form (which finds its runs on the device again, so a batch that repeats less is only
-        slower, never wrong); otherwise the GEMM form, for good.  `del matcher._query_rows_repeat` forgets the decision."""
-        dec = getattr(self, "_query_rows_repeat", None)
-        if dec is None:
+        """does this matcher's training input repeat its query rows?  At least three rows in four repeat -> the one-row-per-run form
+        (which finds its runs on the device in every call, so a batch that repeats less is only slower, never wrong), otherwise the
+        GEMM form.  Decided on the first training batch (the runs are counted on the device and read back: the one host
+        synchronisation of the scheme) and RE-decided every RECHECK_EVERY batches without one: the count of that batch goes to pinned
+        memory asynchronously and is looked at by a later call once its event has completed -- a loader that starts with one odd
+        batch, or changes its collate, is followed within a few batches."""
+        st = self.__dict__.get("_runs_watch")
+        if st is None:
             n_runs = int(ops.find_row_runs(e2)[2].item())
-            dec = self._query_rows_repeat = bool(4 * n_runs <= e2.shape[0])
-        return dec
+            st = self.__dict__["_runs_watch"] = dict(dec=bool(4 * n_runs <= e2.shape[0]), calls=0, pending=None)
+            return st["dec"]
+        if st["pending"] is not None and st["pending"][0].query():
+            _, buf, G = st["pending"]
+            st["dec"], st["pending"] = bool(4 * int(buf[0]) <= G), None
+        st["calls"] += 1
+        if st["calls"] % self.RECHECK_EVERY == 0 and st["pending"] is None:
+            buf = st.get("buf")
+            if buf is None:
+                buf = st["buf"] = torch.empty(1, dtype=torch.int32).pin_memory()
+            buf.copy_(ops.find_row_runs(e2)[2], non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            st["pending"] = (ev, buf, int(e2.shape[0]))
+        return st["dec"]
 
     def prefetch(self, e2):
         """start the query-side half of the match (V = e2 W^T: needs neither the graph nor the encoder) on the second stream; the next

@@ -3,7 +3,6 @@
 torch is plumbing here: it owns device memory (caching allocator), the current HIP stream and autograd's tape;
 every number is produced by the hand-written HIP kernels.  There is no CPU path -- host tensors raise.
 """
-import os
 import weakref
 
 import torch
@@ -40,7 +39,13 @@ def _rows(t):
 
 _BACKWARD_TWICE = ("taxoexpan_amd: backward through this propagation stack a second time -- its saved activations (several hundred MB per "
                    "batch) are released by the first backward; run the forward again (retain_graph=True is not supported here)")
-_NO_FUSED_LOGITS = os.environ.get("TXE_NO_FUSED_LOGITS", "0") == "1"     # A/B switch (tests compare both paths)
+# Alternative routes to the same numbers, kept because a parity test compares each with the default one.  Plain module attributes: tests
+# monkeypatch them, tests/conftest.py's TXE_TEST_ROUTE sets one for a whole run.  (The library itself reads no environment variable.)
+_NO_FUSED_LOGITS = False    # the folded layer's attention logits by their own sweep instead of the aggregation's epilogue
+_NO_TABLE_SWEEP = False     # table rows materialised (txe_gather_add_rows) instead of formed inside the sweep
+_NO_SIDE_STREAM = False     # everything on the caller's stream
+_NO_FUSED_BWD = False       # the folded layer's backward as the unfused chain (d_X' materialised)
+_NO_QUERY_RUNS = False      # stacked query rows always take the GEMM form of the bilinear match
 _I32_MEMO = {}       # id(source tensor) -> (weakref, version, device, int32 copy): `pos` is converted once per batch, not once per module
 
 
@@ -175,7 +180,6 @@ class GatheredRows:
         return f"GatheredRows(table={tuple(self.table.shape)}, rows={int(self.index.shape[0])})"
 
 
-_NO_DEDUP = os.environ.get("TXE_NO_DEDUP", "0") == "1"        # A/B switch: always materialise GatheredRows
 _PROJ_CACHE = None
 
 
@@ -202,7 +206,7 @@ class projection_cache:
 
 def _use_table(h, need, feat_p):
     """project the table instead of the batch?  only without gradients / dropout, and when it is less work (or already cached)"""
-    return (isinstance(h, GatheredRows) and not need and feat_p == 0.0 and not _NO_DEDUP and h.table.is_cuda and h.table.dim() == 2
+    return (isinstance(h, GatheredRows) and not need and feat_p == 0.0 and h.table.is_cuda and h.table.dim() == 2
             and h.table.dtype == torch.float32 and h.table.is_contiguous()
             and h.table.shape[0] <= max(h.index.shape[0], 0 if _PROJ_CACHE is None else _PROJ_CACHE.get("expected_rows", 0)))
 
@@ -224,11 +228,11 @@ def _gat_table_projection(st, src):
     tws = _tail_ws(tab)
     T = _empty((n_tab, Fp), tab)
     # the padding columns [Kh, Kt) of Xt are zero, so whatever Wp holds there (position columns) does not contribute
-    call("txe_gemm_plain", 0, ptr(Xt), Kt, ptr(Wp), Kp, ptr(T), Fp, n_tab, Fp, min(Kt, Kp), 1, ptr(tws), tws.numel(), s)
+    call("txe_gemm_plain", 0, ptr(Xt), Kt, ptr(Wp), Kp, ptr(T), Fp, n_tab, Fp, min(Kt, Kp), 1, 0, ptr(tws), tws.numel(), s)
     T2 = None
     if st.Pd > 0:
         T2 = _empty((st.P.shape[0], Fp), tab)
-        call("txe_gemm_plain", 0, ptr(st.P), st.Pd, ptr(Wp) + 4 * Kh, Kp, ptr(T2), Fp, st.P.shape[0], Fp, st.Pd, 1, None, 0, s)
+        call("txe_gemm_plain", 0, ptr(st.P), st.Pd, ptr(Wp) + 4 * Kh, Kp, ptr(T2), Fp, st.P.shape[0], Fp, st.Pd, 1, 0, None, 0, s)
     if _PROJ_CACHE is not None:
         _PROJ_CACHE[key] = (T, T2, Wp, src.table, st.W)          # (operands kept alive: the key holds their addresses)
         return _PROJ_CACHE[key]
@@ -251,11 +255,11 @@ def _gcn_table_projection(st, src):
     call("txe_gcn_pack_weights", ptr(st.W), Kh + st.Pd, st.Fo, ptr(Wp), s)
     tws = _tail_ws(tab)
     T = _empty((n_tab, Fop), tab)
-    call("txe_gemm_plain", 1, ptr(Xt), Kt, ptr(Wp), Fop, ptr(T), Fop, n_tab, Fop, min(Kt, kp128), 1, ptr(tws), tws.numel(), s)
+    call("txe_gemm_plain", 1, ptr(Xt), Kt, ptr(Wp), Fop, ptr(T), Fop, n_tab, Fop, min(Kt, kp128), 1, 0, ptr(tws), tws.numel(), s)
     T2 = None
     if st.Pd > 0:
         T2 = _empty((st.P.shape[0], Fop), tab)
-        call("txe_gemm_plain", 1, ptr(st.P), st.Pd, ptr(Wp) + 4 * Kh * Fop, Fop, ptr(T2), Fop, st.P.shape[0], Fop, st.Pd, 1, None, 0, s)
+        call("txe_gemm_plain", 1, ptr(st.P), st.Pd, ptr(Wp) + 4 * Kh * Fop, Fop, ptr(T2), Fop, st.P.shape[0], Fop, st.Pd, 1, 0, None, 0, s)
     if _PROJ_CACHE is not None:
         _PROJ_CACHE[key] = (T, T2, Wp, src.table, st.W)
         return _PROJ_CACHE[key]
@@ -329,7 +333,7 @@ def _gat_layers_prepare(items, feat_p):
         d.h, d.ld_h, d.n_nodes, d.Kh, d.pos, d.P, d.Pd, d.X = ptr(h), ld_h, N, st.Kh, ptr(pos), ptr(st.P), st.Pd, ptr(st.X)
         d.W, d.attn_l, d.attn_r, d.H, d.D, d.Wp = ptr(st.W), ptr(st.al), ptr(st.ar), st.H, st.D, ptr(st.Wp)
         d.feat_drop_p, d.seed, d.mask = feat_p, st.seed, ptr(st.mask)
-        st.x_dropped = bool(dropped and feat_p > 0.0 and not _NO_X_DROPPED)
+        st.x_dropped = bool(dropped and feat_p > 0.0)
         d.x_dropped = int(st.x_dropped)
         st.prepared = True
     call("txe_gat_layers_prepare", ctypes.cast(descs, ctypes.c_void_p), len(items), _lib.stream_ptr())
@@ -421,7 +425,7 @@ def _gat_layer_fwd(csr, st, h, ld_h, pos, out, ld_out, feat_p, attn_p, attn_slop
     call("txe_gat_aggregate_fwd", ptr(csr.rowptr_in), ptr(csr.col_src), N, ptr(st.Y), Fp, ptr(st.Y) + 4 * F, ptr(st.Y) + 4 * (F + H), Fp,
          H, D, attn_slope, attn_p, st.seed + 1, out_mode, act_slope, ptr(out), ld_out, ptr(st.alpha),
          *((ptr(nxt[0].Wp) + 4 * nxt[0].D * nxt[0].Kp, nxt[0].Kp, ptr(nxt[0].mask), feat_p, ptr(nxt[1])) if nxt is not None
-           else ((None, out_drop.Kp, ptr(out_drop.mask), feat_p, None) if out_drop is not None else (None, 0, None, 0.0, None))), s)
+           else ((None, out_drop.Kp, ptr(out_drop.mask), feat_p, None) if out_drop is not None else (None, 0, None, 0.0, None))), 0, s)
 
 
 def _gat_aggregate_bwd(csr, st, attn_p, attn_slope, d_pre, ld_dpre):
@@ -449,23 +453,8 @@ def _gat_dense_bwd(st, pos, vocab, feat_p, d_Y, need_dh, act_on, act_slope):
         call("txe_gat_dense_bwd", ptr(st.X), N, st.Kh, st.Pd, ptr(pos), vocab, ptr(st.Wp), ptr(st.W), ptr(st.al), ptr(st.ar), st.H, st.D, feat_p,
              ptr(st.mask), ptr(d_Y), int(need_dh), int(act_on), act_slope if act_slope else 1.0, ptr(d_X), ptr(dW), ptr(dal), ptr(dar),
              ptr(dP), int(getattr(st, "x_dropped", False)), phases, ptr(ws), wsb, _lib.stream_ptr())
-    if not _NO_DXPOS and d_X is not None and call("txe_gat_dx_streams", st.Kh, st.Pd, int(need_dh)) == 1:
-        run(7)          # (a first PGAT layer's d_X is one HBM stream over d_Y -- txe_dxpos.hip -- and runs in line)
-        return d_X, dW, dal, dar, dP
-    no_dx = 32 if _NO_DXPOS else 0
-    if _NO_SIDE_STREAM or need_dh or d_X is None or N == 0:
-        run(7 | no_dx)
-    else:
-        # first layer (only the position columns of d_X are needed): that skinny, latency-bound product leaves most of the matrix pipe
-        # idle -- it runs on the second stream under the weight-gradient GEMM instead of in front of it
-        main, side = torch.cuda.current_stream(), _side_stream(st.X.device)
-        _order(main, side)
-        beside = no_dx | (0 if _NO_BALANCED_SPLITS else 16)       # (16: the weight gradient leaves the skinny product its share of the slots)
-        with torch.cuda.stream(side):
-            run(beside | 1)
-        run(beside | 2)
-        _order(side, main)
-        run(beside | 4)
+    # (a first PGAT layer's d_X -- position columns only -- is one HBM stream over d_Y, txe_dxpos.hip; every other d_X is a GEMM)
+    run(7)
     return d_X, dW, dal, dar, dP
 
 
@@ -474,25 +463,10 @@ def _gat_layer_bwd(csr, st, pos, vocab, feat_p, attn_p, attn_slope, d_pre, ld_dp
     return _gat_dense_bwd(st, pos, vocab, feat_p, d_Y, need_dh, act_on, act_slope)
 
 
-_NO_TABLE_SWEEP = os.environ.get("TXE_NO_TABLE_SWEEP", "0") == "1"      # A/B switch: table rows are materialised before the sweep
-_NO_X_DROPPED = os.environ.get("TXE_NO_X_DROPPED", "0") == "1"        # A/B switch: the first layer's GEMM loaders apply the keep mask
-_NO_MULTI_PREPARE = os.environ.get("TXE_NO_MULTI_PREPARE", "0") == "1"   # A/B switch: one preparation launch per layer
-_NO_SIDE_STREAM = os.environ.get("TXE_NO_SIDE_STREAM", "0") == "1"      # A/B switch: everything on the caller's stream
-_TORCH_EVENTS = os.environ.get("TXE_TORCH_EVENTS", "0") == "1"          # A/B switch: cross-stream ordering through torch's events
-_NO_BALANCED_SPLITS = os.environ.get("TXE_NO_BALANCED_SPLITS", "0") == "1"   # A/B switch: the first layer's dW takes every slot
-_NO_DXPOS = os.environ.get("TXE_NO_DXPOS", "0") == "1"                # A/B switch: the first layer's d_X as a GEMM on the second stream
-# The matcher's query projection V (bilinear_query_prefetch) on the second stream under the encoder's sweeps: started behind the first
-# projection GEMM (TXE_PREFETCH_V=2, the default: step -9 us).  Started at the very beginning (=1) its workgroups take slots before the
-# persistent first-layer projection's, whose late starters then finish late (their tile lists are fixed): -5 us only.  =0: in line.
-_PREFETCH_V = os.environ.get("TXE_PREFETCH_V", "2") in ("1", "2")
-_PREFETCH_V_LATE = os.environ.get("TXE_PREFETCH_V", "2") == "2"
 def _order(first, then):
     """work submitted to stream `then` from now on starts after everything already submitted to `first` (txe_stream_order: an event
-    without the system-scope fence; TXE_TORCH_EVENTS=1 is the A/B switch back to torch's wait_stream)"""
-    if _TORCH_EVENTS:
-        then.wait_stream(first)
-    else:
-        call("txe_stream_order", first.cuda_stream, then.cuda_stream)
+    without the system-scope fence -- two streams of one device need no L2 write-back in front of the next kernel)"""
+    call("txe_stream_order", first.cuda_stream, then.cuda_stream)
 
 
 _side_streams = {}
@@ -503,9 +477,6 @@ def _side_stream(device):
     if s is None:
         s = _side_streams[device.index] = torch.cuda.Stream(device=device)
     return s
-
-
-_NO_FUSED_BWD = os.environ.get("TXE_NO_FUSED_BWD", "0") == "1"       # A/B switch (tests compare both paths)
 
 
 def _fused_bwd_ok(csr, st, sp):
@@ -593,7 +564,7 @@ class GATStackFunction(torch.autograd.Function):
                 kh = st.H * st.D
             h = ref                                  # (allocation reference from here on; the features travel as `src`)
             states[0].X = None if table else _empty((N, states[0].Kp), h)
-            if N > 0 and not _NO_MULTI_PREPARE:      # every layer's input buffer now, and ONE preparation launch for the whole stack
+            if N > 0:                                # every layer's input buffer now, and ONE preparation launch for the whole stack
                 for l in range(1, L):
                     states[l].X = _empty((N, states[l].Kp), h)
                 # (a layer that is not the folded one: only its GEMMs read X, so X is stored with the dropout applied -- by the
@@ -786,7 +757,7 @@ class GCNStackFunction(torch.autograd.Function):
                     st.mask = (torch.empty((N, (st.Kh + st.Pd + 31) // 32), dtype=torch.int32, device=h.device)
                                if cfg.drop_ps[l] > 0.0 else None)
                     # (a first layer on raw features that is not the folded one: only its GEMMs read X -> stored with the dropout applied)
-                    st.x_dropped = bool(l == 0 and not (last and collapse) and cfg.drop_ps[l] > 0.0 and not _NO_X_DROPPED)
+                    st.x_dropped = bool(l == 0 and not (last and collapse) and cfg.drop_ps[l] > 0.0)
                     call("txe_gcn_layer_prepare", ptr(h if l == 0 else None), ld_h if l == 0 else 0, N, st.Kh,
                          ptr(pos if st.P is not None else None), ptr(st.P), st.Pd, ptr(st.X), ptr(st.W), st.Fo, ptr(st.Wp),
                          cfg.drop_ps[l], st.seed, ptr(st.mask), int(st.x_dropped), st_)
@@ -1016,7 +987,7 @@ def bilinear_query_prefetch(e2, W):
     """V = e2 W^T of the query-side match (BilinearPairFunction), launched on the second stream: it depends on the queries and the
     matcher's weight only, so it can run under the encoder (TaxoExpan.forward calls this before graph_propagate).  Returns a token for
     BilinearPairFunction.apply(..., pre=token); None when there is nothing to gain (gradient wanted for e2, CPU tensors, no side stream)."""
-    if _NO_SIDE_STREAM or not _PREFETCH_V or not (torch.is_tensor(e2) and e2.is_cuda and W.is_cuda) or e2.requires_grad or e2.dim() != 2 or e2.shape[0] == 0:
+    if _NO_SIDE_STREAM or not (torch.is_tensor(e2) and e2.is_cuda and W.is_cuda) or e2.requires_grad or e2.dim() != 2 or e2.shape[0] == 0:
         return None
     e2c, ld2 = _rows(e2)
     Wf = _f32(W).reshape(W.shape[-2], W.shape[-1])
@@ -1042,11 +1013,10 @@ def bilinear_query_prefetch(e2, W):
                 t.record_stream(side)
         tok["stream"] = side if on_side else None
     tok["launch"] = launch
-    if _PREFETCH_V_LATE:                        # launched by the encoder behind its first projection GEMM (_launch_pending_prefetch)
-        del _pending_prefetch[:]                # (a token nobody launched holds no device work: dropping it is safe)
-        _pending_prefetch.append(tok)
-    else:
-        launch()
+    # launched by the encoder behind its first projection GEMM (_launch_pending_prefetch): started at the very beginning its workgroups
+    # take slots before the persistent first-layer projection's, whose late starters then finish late
+    del _pending_prefetch[:]                    # (a token nobody launched holds no device work: dropping it is safe)
+    _pending_prefetch.append(tok)
     return tok
 
 
@@ -1195,9 +1165,6 @@ class BilinearRunsFunction(torch.autograd.Function):
             call("txe_bilinear_runs_bwd", ptr(e1), ld1, ptr(rows), ldq, ptr(run_off), G, U, l, r, apply_exp, ptr(V), ptr(s), ptr(ds), ptr(d_e1), l,
                  ptr(dW), ptr(ws), wsb, _lib.stream_ptr())
         return d_e1, dW.reshape(wshape), None, None, None
-
-
-_NO_QUERY_RUNS = os.environ.get("TXE_NO_QUERY_RUNS", "0") == "1"       # A/B switch: stacked query rows always take the GEMM form
 
 
 def find_row_runs(e2):

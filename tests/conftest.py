@@ -21,22 +21,35 @@ def _has_gpu():
         return False
 
 
-# tests OF a route that an A/B switch removes (they look into the folded output layer's buffers / assert the table route was taken)
+# TXE_TEST_ROUTE=<name> runs the whole suite on one of the library's alternative routes (tools/test_switches.sh): the names map to the
+# module attributes the parity tests monkeypatch one at a time.  Read HERE, by the test harness -- the library reads no environment.
+_ROUTES = {"no_fold": ("model_zoo", "_NO_FOLD"), "no_fused_bwd": ("ops", "_NO_FUSED_BWD"), "no_fused_logits": ("ops", "_NO_FUSED_LOGITS"),
+           "no_side_stream": ("ops", "_NO_SIDE_STREAM"), "no_table_sweep": ("ops", "_NO_TABLE_SWEEP"), "no_query_runs": ("ops", "_NO_QUERY_RUNS")}
+# tests OF a route that the setting removes (they look into the folded output layer's buffers)
 _ROUTE_TESTS = {
-    "TXE_NO_FOLD": ("test_fused_backward_sweep_equals_unfused_chain", "test_collapsed_output_layer_equals_unfused_path",
-                    "test_deferred_node_output_behaves_like_the_tensor", "test_empty_and_single_node_batches",
-                    "test_fused_stack_intermediates_match_reference_goldens"),
-    "TXE_NO_DEDUP": ("test_eval_encode_on_table_rows_equals_materialised_features",),
+    "no_fold": ("test_fused_backward_sweep_equals_unfused_chain", "test_collapsed_output_layer_equals_unfused_path",
+                "test_deferred_node_output_behaves_like_the_tensor", "test_empty_and_single_node_batches",
+                "test_fused_stack_intermediates_match_reference_goldens"),
 }
 
 
+def _apply_test_route():
+    name = os.environ.get("TXE_TEST_ROUTE", "")
+    if not name:
+        return
+    import importlib
+    mod, attr = _ROUTES[name]
+    setattr(importlib.import_module("taxoexpan_amd." + mod), attr, True)
+
+
 def pytest_collection_modifyitems(config, items):
-    for env, names in _ROUTE_TESTS.items():
-        if os.environ.get(env, "0") == "1":
-            skip_route = pytest.mark.skip(reason=f"{env}=1 switches the tested route off")
-            for item in items:
-                if item.originalname in names or item.name.split("[")[0] in names:
-                    item.add_marker(skip_route)
+    _apply_test_route()
+    route = os.environ.get("TXE_TEST_ROUTE", "")
+    if route in _ROUTE_TESTS:
+        skip_route = pytest.mark.skip(reason=f"TXE_TEST_ROUTE={route} switches the tested route off")
+        for item in items:
+            if item.originalname in _ROUTE_TESTS[route] or item.name.split("[")[0] in _ROUTE_TESTS[route]:
+                item.add_marker(skip_route)
     if _has_gpu():
         return
     skip = pytest.mark.skip(reason="no GPU in this container")

@@ -52,7 +52,7 @@ def test_argument_validation_needs_no_gpu():
     from taxoexpan_amd import _lib
     lib = _lib.load()
     assert lib.txe_gat_aggregate_fwd(None, None, 5, None, 0, None, None, 0, 4, 8, 0.2, 0.0, 0, 0, 1.0, None, 0, None, None, 0, None, 0.0, None,
-                                     None) == -1
+                                     0, None) == -1
     assert lib.txe_readout_fwd(None, 3, None, 0, None, None, 8, None, None, None) == -1
     assert lib.txe_gat_dense_ws_bytes(100, 250, 50, 4, 500, 3) > 0
     assert lib.txe_gat_padded_k(250, 50) == 320 and lib.txe_gat_padded_f(4, 500) == 2048

@@ -65,7 +65,7 @@ def _device_branches(kind, states, src, dst, masks):
         if kind == "PGAT":
             H, F_ = st.H, st.H * st.D
             cl = getattr(st, "cl", None)
-            if l < L - 1 or cl is None:                               # (TXE_NO_FOLD=1: the output layer runs unfolded, like the others)
+            if l < L - 1 or cl is None:                               # (model_zoo._NO_FOLD: the output layer runs unfolded, like the others)
                 a1, a2 = st.Y[:, F_:F_ + H].cpu().numpy(), st.Y[:, F_ + H:F_ + 2 * H].cpu().numpy()
             else:
                 a12 = cl[0].cpu().numpy()
@@ -164,7 +164,7 @@ def test_fused_stack_intermediates_match_reference_goldens(name):
     from taxoexpan_amd import TaxoExpan, model_zoo, ops
     from taxoexpan_amd.graph import BatchedDGLGraph
     if model_zoo._NO_FOLD:
-        pytest.skip("TXE_NO_FOLD=1: the folded output layer this test looks into is switched off")
+        pytest.skip("model_zoo._NO_FOLD: the folded output layer this test looks into is switched off")
     spec, z, shapes, x, q, params, graph = load_case(name)
     dev = _dev()
     model = TaxoExpan(spec["prop"], spec["readout"], spec["match"], in_dim=spec["in_dim"], hidden_dim=spec["hidden_dim"], out_dim=spec["out_dim"],

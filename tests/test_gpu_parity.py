@@ -117,9 +117,9 @@ def test_training_mode_dropout_matches_oracle(name, drop, monkeypatch):
         np.testing.assert_allclose(p.grad.cpu().numpy(), P[k].grad.numpy(), rtol=2e-3, atol=2e-5, err_msg=k)
 
 
-@pytest.mark.parametrize("switch", ["_NO_MULTI_PREPARE", "_NO_X_DROPPED", "_NO_SIDE_STREAM", "_NO_FUSED_BWD", "_NO_FUSED_LOGITS", "_NO_BALANCED_SPLITS", "_NO_DXPOS"])
+@pytest.mark.parametrize("switch", ["_NO_SIDE_STREAM", "_NO_FUSED_BWD", "_NO_FUSED_LOGITS"])
 def test_ab_switch_routes_give_the_same_training_step(switch, monkeypatch):
-    """every A/B switch of ops.py selects another ROUTE to the same numbers: a training step (dropout on, fixed seed) of the 2-layer
+    """every route attribute of ops.py selects another ROUTE to the same numbers: a training step (dropout on, fixed seed) of the 2-layer
     PGAT case with the switch set against the default -- scores and every gradient (the per-layer preparation entry once left the
     stored-dropped flag of its argument block uninitialised: the default route never noticed)"""
     from taxoexpan_amd import ops
@@ -379,7 +379,7 @@ def test_gemm_whole_rounds_on_persistent_workgroups(layout, M, N, K):
     ws = torch.empty(_lib.call("txe_gemm_tail_ws_bytes"), dtype=torch.uint8, device=dev)
 
     def run(a_ptr, lda, m, c):
-        _lib.call("txe_gemm_plain", layout, a_ptr, lda, Bfull.data_ptr(), ldb, c.data_ptr(), N, m, N, K, 1, ws.data_ptr(), ws.numel(),
+        _lib.call("txe_gemm_plain", layout, a_ptr, lda, Bfull.data_ptr(), ldb, c.data_ptr(), N, m, N, K, 1, 0, ws.data_ptr(), ws.numel(),
                   _lib.stream_ptr())
     C = torch.full((M, N), 7.0, device=dev)
     run(A.data_ptr(), ca, M, C)
@@ -415,7 +415,7 @@ def test_gemm_split_k_on_160_wide_tiles_against_fp64():
     A = torch.from_numpy(rs.standard_normal((K, M)).astype(np.float32)).to(dev)
     B = torch.from_numpy(rs.standard_normal((K, N)).astype(np.float32)).to(dev)
     C = torch.empty(S * M, N, device=dev)
-    _lib.call("txe_gemm_plain", 2, A.data_ptr(), M, B.data_ptr(), N, C.data_ptr(), N, M, N, K, S, None, 0, _lib.stream_ptr())
+    _lib.call("txe_gemm_plain", 2, A.data_ptr(), M, B.data_ptr(), N, C.data_ptr(), N, M, N, K, S, 0, None, 0, _lib.stream_ptr())
     got = C.view(S, M, N).double().sum(0).cpu().numpy()
     ref = A.cpu().numpy().astype(np.float64).T @ B.cpu().numpy().astype(np.float64)
     np.testing.assert_allclose(got, ref, rtol=1e-4, atol=1e-4 * np.sqrt(K))
@@ -423,33 +423,25 @@ def test_gemm_split_k_on_160_wide_tiles_against_fp64():
 
 @pytest.mark.parametrize("M,N,K,S", [(2048, 320, 17877, 16), (1024, 2080, 6016, 4), (300, 316, 1000, 3), (128, 160, 40, 2), (132, 8, 33, 2),
                                      (2048, 320, 64, 2)])
-def test_split_k_tn_product_with_lds_direct_copies(M, N, K, S, tmp_path):
+def test_split_k_tn_product_with_lds_direct_copies(M, N, K, S):
     """gemm_tn_lds_kernel (txe_gemm_tnlds.h: operand tiles copied global -> LDS directly, permuted B fragments, vector stores from the
     accumulators) -- the first layer's weight-gradient shape with its ragged last k-tile per slice, widths that are no multiple of
     the 128 x 160 tile (clamped column vectors, partial stores), slices of one and two k-tiles -- against float64, and BIT FOR BIT
-    against gemm_kernel<false,false,4,4,160>'s partial slices (TXE_NO_TN_LDS=1: the same k order per element).  Both run in
-    subprocesses with TXE_FORCE_BN160=1 so that every shape takes the 160-wide route."""
-    import subprocess
-    import sys
+    against gemm_kernel<false,false,4,4,160>'s partial slices (txe_gemm_plain route bit 2: the same k order per element); route bit 4
+    puts every shape on the 160-wide tiles."""
+    from taxoexpan_amd import _lib
+    dev = _dev()
     rs = np.random.RandomState(M + N)
     lda, ldb, ldc = (M + 3) // 4 * 4 + 4, (N + 3) // 4 * 4, (N + 3) // 4 * 4
     A = rs.standard_normal((K, lda)).astype(np.float32)
     B = rs.standard_normal((K, ldb)).astype(np.float32)
-    d = str(tmp_path)
-    np.save(os.path.join(d, "A.npy"), A)
-    np.save(os.path.join(d, "B.npy"), B)
-    code = ("import numpy as np, torch, sys; sys.path.insert(0, %r); from taxoexpan_amd import _lib; d = %r; "
-            "A = torch.from_numpy(np.load(d + '/A.npy')).cuda(); B = torch.from_numpy(np.load(d + '/B.npy')).cuda(); "
-            "C = torch.full((%d, %d), float('nan'), device='cuda'); "
-            "_lib.call('txe_gemm_plain', 2, A.data_ptr(), %d, B.data_ptr(), %d, C.data_ptr(), %d, %d, %d, %d, %d, None, 0, _lib.stream_ptr()); "
-            "torch.cuda.synchronize(); np.save(d + '/C' + sys.argv[1] + '.npy', C.cpu().numpy())") % (
-                os.path.dirname(os.path.dirname(os.path.abspath(__file__))), d, S * M, ldc, lda, ldb, ldc, M, N, K, S)
+    At, Bt = torch.from_numpy(A).to(dev), torch.from_numpy(B).to(dev)
     outs = {}
-    for tag, extra in (("lds", {}), ("old", {"TXE_NO_TN_LDS": "1"})):
-        r = subprocess.run([sys.executable, "-c", code, tag], env=dict(os.environ, TXE_FORCE_BN160="1", **extra), capture_output=True, text=True,
-                           timeout=300)
-        assert r.returncode == 0, r.stderr[-2000:]
-        outs[tag] = np.load(os.path.join(d, f"C{tag}.npy")).reshape(S, M, ldc)
+    for tag, route in (("lds", 4), ("old", 4 | 2)):
+        C = torch.full((S * M, ldc), float("nan"), device=dev)
+        _lib.call("txe_gemm_plain", 2, At.data_ptr(), lda, Bt.data_ptr(), ldb, C.data_ptr(), ldc, M, N, K, S, route, None, 0, _lib.stream_ptr())
+        torch.cuda.synchronize()
+        outs[tag] = C.cpu().numpy().reshape(S, M, ldc)
     got = outs["lds"]
     assert np.isfinite(got[:, :, :N]).all() and (ldc == N or np.isnan(got[:, :, N:]).all())
     ref = A.astype(np.float64)[:, :M].T @ B.astype(np.float64)[:, :N]
@@ -457,53 +449,45 @@ def test_split_k_tn_product_with_lds_direct_copies(M, N, K, S, tmp_path):
     assert np.array_equal(outs["old"][:, :, :N], got[:, :, :N])
 
 
-def test_forward_sweep_two_nodes_per_wave_is_bit_equal_to_one(tmp_path):
+def test_forward_sweep_two_nodes_per_wave_is_bit_equal_to_one():
     """gat_aggregate_fwd_kernel with NPW = 2 (the heads of two nodes' load chains fetched together, txe_gat.hip) against NPW = 1 on a
     generic multigraph -- hubs above 64 in-edges, nodes without in-edges, an odd node count (a wave with one node), the last node a
     hub -- in all four epilogue modes (plain, the next layer's logits with and without its mask, that layer's dropout on the rows):
-    out, alpha and the logits bit for bit.  TXE_FWD_NPW is read once per process: two subprocesses."""
-    import subprocess
-    import sys
-    code = """
-import numpy as np, torch, sys
-sys.path.insert(0, %r)
-from taxoexpan_amd import _lib
-from taxoexpan_amd._lib import call, ptr
-rs = np.random.RandomState(3)
-N, H, D, kp = 4099, 4, 52, 224
-deg = rs.randint(0, 6, size=N); deg[[5, 77, N - 1]] = [70, 200, 130]; deg[[6, 7, 4000]] = 0
-rowptr = np.concatenate([[0], np.cumsum(deg)]).astype(np.int32)
-col = rs.randint(0, N, size=int(rowptr[-1])).astype(np.int32)
-dev = 'cuda'
-rp, cl = torch.from_numpy(rowptr).to(dev), torch.from_numpy(col).to(dev)
-ft = torch.from_numpy(rs.standard_normal((N, H * D)).astype(np.float32)).to(dev)
-a12 = torch.from_numpy(rs.standard_normal((N, 2 * H)).astype(np.float32)).to(dev)
-wa = torch.from_numpy(rs.standard_normal((2, kp)).astype(np.float32)).to(dev)
-mask = torch.from_numpy(rs.randint(0, 2 ** 31, size=(N, kp // 32)).astype(np.int32)).to(dev)
-res = {}
-for mode, (nx, nx_p, use_mask) in dict(plain=(False, 0.0, False), logits=(True, 0.0, False), logits_mask=(True, 0.5, True), rows_dropped=(False, 0.5, True)).items():
-    for attn_p, keep in ((0.0, False), (0.3, True)):
-        out = torch.full((N, kp), 0.25, device=dev)
-        alpha = torch.full((int(rowptr[-1]) * H + 1,), -1.0, device=dev)
-        nxa = torch.full((N, 2), -1.0, device=dev)
-        call('txe_gat_aggregate_fwd', ptr(rp), ptr(cl), N, ptr(ft), H * D, ptr(a12), ptr(a12[:, H:]), 2 * H, H, D, 0.2, attn_p, 99, 1, 0.01,
-             ptr(out), kp, ptr(alpha) if keep else None, ptr(wa) if nx else None, kp, ptr(mask) if use_mask else None, nx_p, ptr(nxa) if nx else None,
-             _lib.stream_ptr())
-        torch.cuda.synchronize()
-        k = mode + ('_train' if keep else '_eval')
-        res[k + '_out'], res[k + '_alpha'], res[k + '_nx'] = out.cpu().numpy(), alpha.cpu().numpy(), nxa.cpu().numpy()
-np.savez(%r + '/npw' + sys.argv[1] + '.npz', **res)
-""" % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), str(tmp_path))
+    out, alpha and the logits bit for bit (txe_gat_aggregate_fwd's npw argument)."""
+    from taxoexpan_amd import _lib
+    from taxoexpan_amd._lib import call, ptr
+    rs = np.random.RandomState(3)
+    N, H, D, kp = 4099, 4, 52, 224
+    deg = rs.randint(0, 6, size=N); deg[[5, 77, N - 1]] = [70, 200, 130]; deg[[6, 7, 4000]] = 0
+    rowptr = np.concatenate([[0], np.cumsum(deg)]).astype(np.int32)
+    col = rs.randint(0, N, size=int(rowptr[-1])).astype(np.int32)
+    dev = _dev()
+    rp, cl = torch.from_numpy(rowptr).to(dev), torch.from_numpy(col).to(dev)
+    ft = torch.from_numpy(rs.standard_normal((N, H * D)).astype(np.float32)).to(dev)
+    a12 = torch.from_numpy(rs.standard_normal((N, 2 * H)).astype(np.float32)).to(dev)
+    wa = torch.from_numpy(rs.standard_normal((2, kp)).astype(np.float32)).to(dev)
+    mask = torch.from_numpy(rs.randint(0, 2 ** 31, size=(N, kp // 32)).astype(np.int32)).to(dev)
     outs = {}
-    for npw in ("1", "2"):
-        r = subprocess.run([sys.executable, "-c", code, npw], env=dict(os.environ, TXE_FWD_NPW=npw), capture_output=True, text=True, timeout=300)
-        assert r.returncode == 0, r.stderr[-2000:]
-        outs[npw] = np.load(os.path.join(str(tmp_path), f"npw{npw}.npz"))
-    assert len(outs["1"].files) == 24
-    for k in outs["1"].files:
-        assert np.isfinite(outs["1"][k]).all(), k
-        assert np.array_equal(outs["1"][k], outs["2"][k]), k
-    assert not np.array_equal(outs["1"]["plain_eval_out"][:, :208], np.full((4099, 208), 0.25, dtype=np.float32))
+    for npw in (1, 2):
+        res = {}
+        for mode, (nx, nx_p, use_mask) in dict(plain=(False, 0.0, False), logits=(True, 0.0, False), logits_mask=(True, 0.5, True),
+                                               rows_dropped=(False, 0.5, True)).items():
+            for attn_p, keep in ((0.0, False), (0.3, True)):
+                out = torch.full((N, kp), 0.25, device=dev)
+                alpha = torch.full((int(rowptr[-1]) * H + 1,), -1.0, device=dev)
+                nxa = torch.full((N, 2), -1.0, device=dev)
+                call('txe_gat_aggregate_fwd', ptr(rp), ptr(cl), N, ptr(ft), H * D, ptr(a12), ptr(a12[:, H:]), 2 * H, H, D, 0.2, attn_p, 99, 1, 0.01,
+                     ptr(out), kp, ptr(alpha) if keep else None, ptr(wa) if nx else None, kp, ptr(mask) if use_mask else None, nx_p,
+                     ptr(nxa) if nx else None, npw, _lib.stream_ptr())
+                torch.cuda.synchronize()
+                k = mode + ('_train' if keep else '_eval')
+                res[k + '_out'], res[k + '_alpha'], res[k + '_nx'] = out.cpu().numpy(), alpha.cpu().numpy(), nxa.cpu().numpy()
+        outs[npw] = res
+    assert len(outs[1]) == 24
+    for k in outs[1]:
+        assert np.isfinite(outs[1][k]).all(), k
+        assert np.array_equal(outs[1][k], outs[2][k]), k
+    assert not np.array_equal(outs[1]["plain_eval_out"][:, :208], np.full((4099, 208), 0.25, dtype=np.float32))
 
 
 def test_readout_and_match_ops_against_oracle():
@@ -553,16 +537,15 @@ def test_readout_and_match_ops_against_oracle():
 
 def test_query_projection_prefetched_on_the_second_stream_changes_nothing(monkeypatch):
     """ops.bilinear_query_prefetch: the matcher's query projection runs on the second stream under the encoder (started behind the first
-    projection GEMM by default, at the very beginning with TXE_PREFETCH_V=1) or in line (=0): same scores and gradients, bit for bit"""
+    projection GEMM) or in line (no second stream): same scores and gradients, bit for bit"""
     from taxoexpan_amd import ops
     name = next(n for n in NODROP if gc.CASES[n]["match"] in ("LBM", "BIM"))
     spec, z, shapes, x, q, params, graph = load_case(name)
     model = _build_model(spec, params).eval()
     outs = []
     monkeypatch.setattr(ops, "_NO_QUERY_RUNS", True)                # (the GEMM form of the match, whatever the batch size)
-    for on, late in ((False, False), (True, False), (True, True)):
-        monkeypatch.setattr(ops, "_PREFETCH_V", on)
-        monkeypatch.setattr(ops, "_PREFETCH_V_LATE", late)
+    for no_side in (True, False):
+        monkeypatch.setattr(ops, "_NO_SIDE_STREAM", no_side)
         model.zero_grad(set_to_none=True)
         s = model(_graph(shapes), torch.from_numpy(x).to(_dev()), torch.from_numpy(q).to(_dev()))
         s.sum().backward()
@@ -868,7 +851,7 @@ def test_bench_contract_line():
     for k in ("hbm_kernel", "hbm_frac", "hbm_avg_us", "hbm_frac_of_copy_ceiling", "copy_ceiling_gbs", "hbm_aggregate_fwd_frac",
               "mfma_main_stream_frac"):                           # flat scalars: the HBM story survives consumers that drop nested objects
         assert isinstance(r[k], (int, float, str)), k
-    if not any(os.environ.get(sw, "0") == "1" for sw in ("TXE_NO_FOLD", "TXE_NO_FUSED_BWD", "TXE_NO_DXPOS")):    # (kernels of the default route)
+    if os.environ.get("TXE_TEST_ROUTE", "") not in ("no_fold", "no_fused_bwd"):    # (kernels of the default route)
         assert 0.0 < r["hbm_fused_bwd_frac"] < 1.0 and 0.0 < r["hbm_dx_pos_frac"] < 1.0
     assert 0.0 < r["hbm_frac"] < 1.0 and 0.0 < r["mfma_main_stream_frac"] < 1.0
     # a fresh device-built batch inside every step (trainer.py:44-61's real per-step cost) is reported next to the resident-input value
@@ -1226,7 +1209,7 @@ def test_runs_of_stacked_query_rows_found_on_the_device_and_the_match_on_them(mo
     """txe_rows_find_runs on the reference collate's stacked query matrix (data_loaders.py:9-28: a query's row once per pair) against
     numpy -- runs of every length, a row that returns after another (two runs), -0.0 against 0.0 (different bit patterns: two runs), more
     rows than one scan chunk, no repetition at all, one row -- and BilinearStackedRunsFunction (txe_bilinear_stacked_*) against the GEMM
-    form on the same matrix: scores, d_hg, dW; then the matcher's one-time decision (model_zoo._Bilinear._repeats)."""
+    form on the same matrix: scores, d_hg, dW; then the matcher's decision and its periodic re-decision (model_zoo._Bilinear._repeats)."""
     from taxoexpan_amd import model_zoo as mz, ops
     dev = _dev()
     rs = np.random.RandomState(2)
@@ -1259,8 +1242,9 @@ def test_runs_of_stacked_query_rows_found_on_the_device_and_the_match_on_them(mo
             for k in range(3):
                 scale = max(res[0][k].abs().max().item(), 1e-30)
                 np.testing.assert_allclose(res[1][k].cpu().numpy(), res[0][k].cpu().numpy(), rtol=2e-5, atol=2e-6 * scale)
-    # the matcher decides once, on its first training batch of at least 256 pairs
+    # the matcher decides on its first training batch of at least 256 pairs and looks again every RECHECK_EVERY calls (no host sync)
     monkeypatch.setattr(ops, "_NO_QUERY_RUNS", False)
+    monkeypatch.setattr(mz._Bilinear, "RECHECK_EVERY", 3)
     rep = torch.from_numpy(table[np.repeat(np.arange(16), 32)]).to(dev)
     uniq = torch.from_numpy(rs.standard_normal((512, r)).astype(np.float32)).to(dev)
     hg = torch.from_numpy(rs.standard_normal((512, l)).astype(np.float32) * 0.1).to(dev).requires_grad_(True)
@@ -1270,23 +1254,34 @@ def test_runs_of_stacked_query_rows_found_on_the_device_and_the_match_on_them(mo
     monkeypatch.setattr(ops.BilinearStackedRunsFunction, "apply", staticmethod(lambda *a: (seen.append(1), real(*a))[1]))
     with torch.no_grad():
         m(hg, rep)
-    assert not hasattr(m, "_query_rows_repeat") and not seen         # (no decision outside training)
+    assert "_runs_watch" not in m.__dict__ and not seen               # (no decision outside training)
     m(hg, rep).sum().backward()
-    assert m._query_rows_repeat is True and len(seen) == 1
+    assert m._runs_watch["dec"] is True and len(seen) == 1
     m(hg, uniq).sum().backward()                                      # a batch that does not repeat: same form, still right
     a = hg.detach().clone().requires_grad_(True)
     ref = ops.BilinearPairFunction.apply(a, uniq, m.W.weight, True, None)
     np.testing.assert_allclose(m(hg, uniq).detach().cpu().numpy(), ref.detach().cpu().numpy(), rtol=2e-5)
     assert len(seen) == 3
+    # ... the loader keeps handing out rows that do not repeat: within a few batches the matcher is back on the GEMM form
+    for _ in range(8):
+        m(hg, uniq).sum().backward()
+        torch.cuda.synchronize()
+    assert m._runs_watch["dec"] is False
+    n_seen = len(seen)
+    m(hg, uniq).sum().backward()
+    assert len(seen) == n_seen
+    for _ in range(8):                                                # ... and forth again when they do
+        m(hg, rep).sum().backward()
+        torch.cuda.synchronize()
+    assert m._runs_watch["dec"] is True
     m2 = mz.BIM(l, r).to(dev)
+    n_seen = len(seen)
     m2(hg, uniq).sum().backward()
-    assert m2._query_rows_repeat is False
-    m2(hg, rep).sum().backward()
-    assert len(seen) == 3
+    assert m2._runs_watch["dec"] is False and len(seen) == n_seen
     m3 = mz.BIM(l, r).to(dev)
     monkeypatch.setattr(ops, "_NO_QUERY_RUNS", True)
     m3(hg, rep).sum().backward()
-    assert not hasattr(m3, "_query_rows_repeat") and len(seen) == 3
+    assert "_runs_watch" not in m3.__dict__ and len(seen) == n_seen
 
 
 @pytest.mark.gpu
@@ -1442,11 +1437,9 @@ def test_attention_logits_fused_into_the_previous_aggregation(drop, monkeypatch)
 def test_eval_encode_on_table_rows_equals_materialised_features(prop, monkeypatch):
     """SURVEY 8f-2 'dedup by _id': device-built egonets whose features stay rows of the taxonomy table (ops.GatheredRows) -- the
     eval-mode layer-0 projection is formed once per taxonomy node and gathered -- against the same batch with gathered features;
-    chunked with the projection cache; training mode and TXE_NO_DEDUP fall back to the ordinary path"""
+    chunked with the projection cache; training mode falls back to the ordinary path"""
     from taxoexpan_amd import TaxoExpan, ops, synthetic as syn, graph as G
     from taxoexpan_amd.scoring import encode_candidates
-    if ops._NO_DEDUP:
-        pytest.skip("TXE_NO_DEDUP=1: the table route this test asserts is switched off")
     dev = _dev()
     tax = syn.make_taxonomy(600, 900, 12, seed=4)
     dtax = G.DeviceTaxonomy(tax.par_ptr, tax.par_idx, tax.chd_ptr, tax.chd_idx, tax.features, dev)

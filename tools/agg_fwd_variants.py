@@ -32,7 +32,7 @@ st = _lib.stream_ptr()
 def run(keep_alpha, attn_p, nx, nx_p):
     call("txe_gat_aggregate_fwd", ptr(csr.rowptr_in), ptr(csr.col_src), N, ptr(ft), H * D, ptr(a12), ptr(a12[:, H:]), 2 * H, H, D, 0.2,
          attn_p, 12345, 1, 0.01, ptr(out), kp, ptr(alpha) if keep_alpha else None, ptr(wa) if nx else None, kp,
-         ptr(mask) if nx_p > 0 else None, nx_p, ptr(nxa) if nx else None, st)
+         ptr(mask) if nx_p > 0 else None, nx_p, ptr(nxa) if nx else None, 0, st)
 
 
 def t(*a):

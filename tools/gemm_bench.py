@@ -42,7 +42,7 @@ def run(layout, M, N, K, lda=None, ldb=None, ldc=None, splits=1, tail=False, mm=
     A = torch.randn(ra, lda, device=dev)
     B = torch.randn(rb, ldb, device=dev)
     C = torch.empty(splits * M, ldc, device=dev)
-    f = lambda: _lib.call("txe_gemm_plain", layout, A.data_ptr(), lda, B.data_ptr(), ldb, C.data_ptr(), ldc, M, N, K, splits,
+    f = lambda: _lib.call("txe_gemm_plain", layout, A.data_ptr(), lda, B.data_ptr(), ldb, C.data_ptr(), ldc, M, N, K, splits, 0,
                           _ws.data_ptr() if tail else None, _ws.numel() if tail else 0, _lib.stream_ptr())
     dt = timeit(f)
     flops = 2.0 * M * N * K

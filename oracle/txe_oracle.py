@@ -92,13 +92,27 @@ def segment_sum(graph_off, x):
 # ----------------------------------------------------------------------------------------
 # GAT  (model_zoo.py:52-114, 169-220)
 # ----------------------------------------------------------------------------------------
-def _leaky(x, slope, pos=None):
+BRANCH_AUDIT = None      # a list while a test audits given branches (see _leaky)
+
+
+def _leaky(x, slope, pos=None, care=None, tag=""):
     """F.leaky_relu; with `pos` (bool, same shape) the branch of every element is GIVEN instead of decided by its sign.  leaky_relu' is
     discontinuous at 0: two fp32 evaluations whose pre-activation differs in the last bit around 0 differentiate different linear
     pieces.  A test that hands the implementation-under-test's own branch pattern to the oracle compares gradients of the SAME
-    piecewise-linear function, entry for entry (the forward value moves by at most |x|(1-slope) ~ one rounding error there)."""
+    piecewise-linear function, entry for entry (the forward value moves by at most |x|(1-slope) ~ one rounding error there).
+    The given pattern is AUDITED when BRANCH_AUDIT is a list: a record (tag, entries that disagree with the sign of the oracle's own
+    pre-activation, largest |x| among them, largest |x| overall) per call -- a given branch may differ from the oracle's own only where
+    |x| is within rounding of 0.  care (bool, broadcastable): entries that carry a gradient at all (the rest is not audited: an entry
+    the next layer's dropout zeroed reads as "negative" on the device whatever its sign was)."""
     if pos is None:
         return F.leaky_relu(x, slope)
+    if BRANCH_AUDIT is not None:
+        with torch.no_grad():
+            dis = (x > 0) != pos
+            if care is not None:
+                dis = dis & care
+            ax = x.abs()
+            BRANCH_AUDIT.append((tag, int(dis.sum()), float(ax[dis].max()) if bool(dis.any()) else 0.0, float(ax.max()), int(x.numel())))
     return torch.where(pos, x, x * slope)
 
 
@@ -116,7 +130,7 @@ def gat_layer(src, dst, n, feature, fc_w, attn_l, attn_r, slope=0.2, feat_keep=N
     ft = (h @ fc_w.t()).reshape(h.shape[0], H, -1)                                  # :83
     a1 = (ft * attn_l).sum(-1, keepdim=True)                                         # :84
     a2 = (ft * attn_r).sum(-1, keepdim=True)                                         # :85
-    e = _leaky(a1[src] + a2[dst], slope, e_pos)                                      # :106-109 (e_pos: given branches, see _leaky)
+    e = _leaky(a1[src] + a2[dst], slope, e_pos, tag="attention logits")             # :106-109 (e_pos: given branches, see _leaky)
     alpha = edge_softmax(dst, n, e)                                                  # :111-112
     a_drop = alpha if attn_keep is None else alpha * attn_keep * attn_scale          # :114
     out = scatter_sum(dst, n, ft[src] * a_drop)                                      # :95
@@ -150,7 +164,9 @@ def pgat_forward(params, graph, h, heads, num_layers, act_slope=0.01, attn_slope
         out, pr = gat_layer(src, dst, n, x, w, al, ar, attn_slope, return_parts=True, **mk)
         parts.append(pr)
         if l < num_layers:
-            h = _leaky(out.flatten(1), act_slope, act_pos)                           # :215-216
+            nk = (masks[l + 1] or {}).get("feat_keep") if (masks is not None and act_pos is not None) else None
+            care = (nk[:, :out.shape[1] * out.shape[2]] > 0) if nk is not None else None   # (dropped next-layer inputs carry no gradient)
+            h = _leaky(out.flatten(1), act_slope, act_pos, care, tag=f"activation after layer {l}")   # :215-216
         else:
             h = out.mean(1)                                                          # :219
     if return_parts:
@@ -169,7 +185,7 @@ def gcn_norm(dst, n, dtype=torch.float32):
     return norm.unsqueeze(1)
 
 
-def gcn_layer(src, dst, n, h, weight, bias, norm, act_slope=None, keep=None, keep_scale=1.0, act_pos=None):
+def gcn_layer(src, dst, n, h, weight, bias, norm, act_slope=None, keep=None, keep_scale=1.0, act_pos=None, act_care=None):
     """GCNLayer.forward, model_zoo.py:34-50."""
     if keep is not None:
         h = h * keep * keep_scale                                                     # :35-36
@@ -180,7 +196,7 @@ def gcn_layer(src, dst, n, h, weight, bias, norm, act_slope=None, keep=None, kee
     if bias is not None:
         h = h + bias                                                                  # :47
     if act_slope is not None:
-        h = _leaky(h, act_slope, act_pos)                                             # :49
+        h = _leaky(h, act_slope, act_pos, act_care, tag="GCN activation")             # :49
     return h
 
 
@@ -193,7 +209,9 @@ def pgcn_forward(params, graph, h, num_layers, act_slope=0.01, prefix="", masks=
         x = h
         if positional:
             x = torch.cat((h, params[f"{prefix}prop_position_embeddings.{l}.weight"][pos]), 1)  # :165-166
-        mk = (masks[l] if masks is not None else None) or {}
+        mk = dict((masks[l] if masks is not None else None) or {})
+        if mk.get("act_pos") is not None and l < num_layers and (masks[l + 1] or {}).get("keep") is not None:
+            mk["act_care"] = masks[l + 1]["keep"][:, :params[f"{prefix}layers.{l}.weight"].shape[1]] > 0   # (dropped next-layer inputs carry no gradient)
         h = gcn_layer(src, dst, n, x, params[f"{prefix}layers.{l}.weight"], params.get(f"{prefix}layers.{l}.bias"),
                       norm, act_slope if l < num_layers else None, **mk)
     return h

@@ -132,13 +132,11 @@ int dxpos_prepare(DxPosArgs& a) {
 
 int dxpos_launch(const DxPosArgs& a, hipStream_t stream) {
     if (a.n_rows <= 0) return TXE_OK;
-    static bool attr_set = false;                                  // (idempotent; the kernel needs more than the default 64 KB of LDS)
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(gat_dx_pos_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                DXPOS_KSL * DXPOS_MAXC * (int)sizeof(float)) != hipSuccess)
-            return TXE_ERR_LAUNCH;
-        attr_set = true;
-    }
+    // the kernel needs more than the default 64 KB of LDS.  Function attributes are per DEVICE and this library keeps no state: set
+    // before every launch (a host-side table write, idempotent, thread-safe)
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(gat_dx_pos_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            DXPOS_KSL * DXPOS_MAXC * (int)sizeof(float)) != hipSuccess)
+        return TXE_ERR_LAUNCH;
     // algorithmic bytes: d_Y once, the weight slab once, the outputs once
     ProfScope prof("gat_dx_pos_kernel", stream, 4.0 * ((double)a.n_rows * a.K + (double)a.K * a.NC + (double)a.n_rows * a.NC), 1);
     const int slice = a.K < DXPOS_KSL ? a.K : DXPOS_KSL;

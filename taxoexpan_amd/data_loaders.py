@@ -115,13 +115,16 @@ def begin_device_batch(dtax, anchors, exclude, query_ids, expand_factor=50, seed
     # (the side stream does NOT wait for the caller's stream -- that would put the construction behind the running step again: the
     #  taxonomy arrays and the feature table must be complete before the first call; DeviceBatchLoader synchronises once when it is made)
     # the three index arrays travel in ONE pinned buffer and one copy (each small pageable upload costs ~60 us of host time); two
-    # buffers per size take turns, each guarded by the event of its last upload (a loader keeps two batches in flight)
+    # buffers per device take turns, each guarded by the event of its last upload (a loader keeps two batches in flight)
     B = len(anchors)
-    ring = _PINNED.setdefault((B, str(dev)), dict(k=0, slots=[None, None]))
+    ring = _PINNED.setdefault(str(dev), dict(k=0, slots=[None, None]))     # per device; the buffers grow to the largest batch seen
     ring["k"] ^= 1
     slot = ring["slots"][ring["k"]]
-    if slot is None:                                              # [anchors | exclude | query ids | run offsets (<= B + 1)]
-        slot = ring["slots"][ring["k"]] = [torch.empty(4 * B + 1, dtype=torch.int32).pin_memory(), None]
+    if slot is None or slot[0].numel() < 4 * B + 1:               # [anchors | exclude | query ids | run offsets (<= B + 1)]
+        if slot is not None and slot[1] is not None:
+            slot[1].synchronize()                                 # (the smaller buffer's last upload has left it)
+        cap = max(4 * B + 1, 2 * slot[0].numel() if slot is not None else 0)
+        slot = ring["slots"][ring["k"]] = [torch.empty(cap, dtype=torch.int32).pin_memory(), None]
     host, uploaded = slot
     if uploaded is not None:
         uploaded.synchronize()
@@ -139,7 +142,7 @@ def begin_device_batch(dtax, anchors, exclude, query_ids, expand_factor=50, seed
     else:
         hv[2 * B:3 * B] = query_ids
     with torch.cuda.stream(side):
-        packed = host.to(dev, non_blocking=True)
+        packed = host[:4 * B + 1].to(dev, non_blocking=True)
         slot[1] = torch.cuda.Event()
         slot[1].record()
         job = device_egonet_begin(dtax, packed[:B], packed[B:2 * B] if exclude is not None else None, expand_factor=expand_factor, seed=seed)

@@ -1310,7 +1310,8 @@ def pad_queries_like(Q, U):
     score_count_block(..., q_padded=True) without being copied again.  Returns Q itself when U carries no padding."""
     r = Q.shape[1]
     rp = _padded_width(_rows(U)[0], r)
-    return _pad_queries(_rows(Q)[0], r, rp)[:, :r] if rp != r else Q
+    Qr = _rows(Q)[0]                                    # fp32, unit column stride: score_count_block(q_padded=True) takes the pointer as it is
+    return _pad_queries(Qr, r, rp)[:, :r] if rp != r else Qr
 
 
 def positive_scores_staircase(Q, Up, apply_exp, pos_off, out):
@@ -1319,7 +1320,7 @@ def positive_scores_staircase(Q, Up, apply_exp, pos_off, out):
     _need_cuda(Q, Up)
     ldq = Q.stride(0)
     Up, ldu = _rows(Up)
-    assert Q.stride(1) == 1 and out.dtype == torch.float32 and out.is_contiguous() and out.numel() >= Up.shape[0]
+    assert Q.dtype == torch.float32 and Q.stride(1) == 1 and out.dtype == torch.float32 and out.is_contiguous() and out.numel() >= Up.shape[0]
     with _lib.on_device(Q.device):
         call("txe_score_positives", ptr(Q), ldq, Q.shape[0], ptr(Up), ldu, Up.shape[0], Q.shape[1], int(apply_exp), ptr(pos_off), ptr(out),
              _lib.stream_ptr())
@@ -1332,6 +1333,7 @@ def score_count_block(Q, U, apply_exp, pos_off, thr, larger_is_better=True, coun
     q_padded: Q is a row block of pad_queries_like(all queries, U) -- its columns up to U's padded width are zeros already."""
     _need_cuda(Q, U)
     if q_padded:
+        assert Q.dtype == torch.float32 and Q.dim() == 2 and Q.stride(1) == 1, "q_padded: a row block of pad_queries_like()"
         ldq = Q.stride(0)
     else:
         Q, ldq = _rows(Q)

@@ -176,9 +176,13 @@ def rank_all_fused(match, hg, queries, pos_off, pos_idx, block=None, larger_is_b
     n_local = hg.shape[0]
     idx_all = torch.where((idx_all >= 0) & (idx_all < n_local), idx_all, torch.full_like(idx_all, -1)).to(torch.int32)
     out = []
+    if idx_all.numel() == 0:                                       # (the same early exit and the same skipped blocks as the device
+        return torch.zeros(0, dtype=torch.int32, device=dev)       #  path: a rank with an empty shard issues the same collectives)
     for q0 in range(0, queries.shape[0], block):
         q1 = min(q0 + block, queries.shape[0])
         lo, hi = int(pos_off_h[q0]), int(pos_off_h[q1])
+        if hi == lo:
+            continue
         off = (pos_off_d[q0:q1 + 1] - lo).to(torch.int32)
         idx_local = idx_all[lo:hi]
         qb = queries[q0:q1]
@@ -279,23 +283,22 @@ def allreduce_gradients(params, group=None, skip=None):
 
 def gradient_bucket_plan(model, min_layer=1):
     """the buckets overlapped_gradient_allreduce will see, from the model alone: for every GAT layer l >= min_layer of
-    `model.graph_propagate` its fc.weight / attn_l / attn_r / position-embedding table (+ the weighted readout's position weights with
-    the last layer when it is folded behind the readout) -- [(layer, [parameters])], top layer first, as backward announces them.
-    Every rank derives the same plan, so a rank whose backward never reaches the stack can still issue matching collectives."""
+    `model.graph_propagate` its fc.weight / attn_l / attn_r / position-embedding table -- [(layer, [parameters])], top layer first, as
+    backward announces them.  Exactly the four tensors EVERY route of ops.GATStackFunction.backward announces for a layer: the weighted
+    readout's position weights (three floats, announced only by the folded route) are left to the flat bucket, so the plan holds whether
+    the output layer runs folded or not.  Every rank derives the same plan, so a rank whose backward never reaches the stack can still
+    issue matching collectives."""
     prop = getattr(model, "graph_propagate", None)
     layers = getattr(prop, "gat_layers", None)
     if layers is None:
         return []
     emb = getattr(prop, "prop_position_embeddings", None)
-    pw = getattr(getattr(model, "readout", None), "position_weights", None)
     plan = []
     L = len(layers)
     for l in range(L - 1, min_layer - 1, -1):
         ps = [layers[l].fc.weight, layers[l].attn_l, layers[l].attn_r]
         if emb is not None:
             ps.append(emb[l].weight)
-        if l == L - 1 and pw is not None:
-            ps.append(pw.weight)
         plan.append((l, ps))
     return plan
 
@@ -307,10 +310,13 @@ class overlapped_gradient_allreduce:
     bucket rides under ~0.6 ms of layer-0 kernels on the MAG step), and is waited for -- by the stream, not the host -- before the
     stack hands its gradients to autograd.  `allreduce_gradients(params, skip=ov)` then reduces what is left (the first layer,
     readout, matcher).
-    The collective schedule is RANK-INVARIANT when `model` is given: the buckets are planned from the model (gradient_bucket_plan), an
-    announcement that does not match the plan is left to the flat bucket, and a planned bucket this rank's backward never announced
-    (an empty shard whose readout returned zeros without running the stack, the unfused route) is issued on exit with zeros -- the
-    rank receives the sum, like its peers.  Without `model` every rank must take the same route through backward.
+    The collective schedule is RANK-INVARIANT when `model` is given: the buckets are planned from the model (gradient_bucket_plan) and
+    go out in plan order; an announcement for a layer the plan does not hold is left to the flat bucket; a planned bucket this rank's
+    backward never announced (an empty shard whose readout returned zeros without running the stack, a model that runs its layers one by
+    one) is issued ON EXIT -- when .grad is final -- with what the rank holds (zeros if nothing): it receives the sum, like its peers.
+    A planned layer announced out of plan order, or with other tensors than planned, cannot be reconciled mid-backward (its real gradients
+    would reach autograd un-reduced while the peers' collectives go out of step) and raises.  Without `model` every rank must take the
+    same route through backward.
     Not re-entrant and not thread-safe: the hooks are process-global (ops._GRAD_READY / _GRAD_FLUSH); one backward at a time."""
 
     def __init__(self, group=None, min_layer=1, model=None):
@@ -363,10 +369,14 @@ class overlapped_gradient_allreduce:
         if self.plan is not None:
             want = next((ps for l, ps in self.plan if l == layer), None)
             have = {i: t for t, i in zip(tensors, param_ids) if t is not None}
-            if want is None or any(id(p) not in have or have[id(p)].numel() != p.numel() for p in want) or layer in self._fired:
+            if want is None or layer in self._fired:
                 return                                     # not a planned bucket: the flat bucket after backward takes it
-            # planned order: buckets fire top layer first; an earlier planned layer that never fired goes out (with zeros) first
-            self._issue_missing(before=layer)
+            if any(id(p) not in have or have[id(p)].numel() != p.numel() for p in want):
+                raise RuntimeError(f"overlapped_gradient_allreduce: layer {layer} announced other gradients than gradient_bucket_plan() "
+                                   "holds for it -- the ranks' collectives would go out of step")
+            skipped = [l for l, _ in self.plan if l > layer and l not in self._fired]
+            if skipped:                                    # (buckets fire top layer first, on every rank)
+                raise RuntimeError(f"overlapped_gradient_allreduce: layer {layer} announced before the planned layers {skipped} above it")
             self._fired.add(layer)
             tensors, ids = [have[id(p)] for p in want], [id(p) for p in want]
         else:
@@ -378,12 +388,10 @@ class overlapped_gradient_allreduce:
         work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         self._pending.append((work, flat, tensors, ids))
 
-    def _issue_missing(self, before=None):
-        """planned buckets above `before` (all of them when None) that this rank's backward never announced: all-reduce whatever
+    def _issue_missing(self):
+        """on exit (every .grad is final): the planned buckets this rank's backward never announced, in plan order -- all-reduce whatever
         gradient the rank holds for them (zeros if none), keep the sum"""
         for l, ps in self.plan:
-            if before is not None and l <= before:
-                break
             if l in self._fired:
                 continue
             self._fired.add(l)

@@ -1,7 +1,9 @@
 """TEST INFRASTRUCTURE: one rank of a world-size-N job whose ranks all sit on cuda:0 (a single-GPU box) over gloo, launched by
 tests/test_gpu_eval_infer.py through torch.distributed.run.  Every rank computes the UNSHARDED scoring loop with the HIP kernels and
 its shard of the candidate-sharded one (pipelined all-gather of score blocks; all-reduce-of-counts ranking) and asserts that the
-sharded results are the unsharded ones BIT FOR BIT -- the collectives only move what the same kernels computed.  Prints "OK <rank>"."""
+sharded results are the unsharded ones BIT FOR BIT -- the collectives only move what the same kernels computed.  Prints "OK <rank>".
+`dist_gpu_worker.py dp`: the data-parallel TRAINING step instead (dp_training_step below).  Reference for the partition:
+trainer/trainer.py:52-56 (a query's 1 + negatives stay together), model/loss.py:52-57 (sum reduction: gradients add over ranks)."""
 import os
 import sys
 
@@ -57,5 +59,100 @@ def main():
     dist.destroy_process_group()
 
 
+def _shard_batch(k, m, x, qf, q_lo, q_hi, per_query):
+    """the egonets of queries [q_lo, q_hi) of a batch given by its egonet shapes k, m (grand-parents / siblings per egonet), node
+    features x and stacked query rows qf -- the same egonets, renumbered from 0"""
+    from taxoexpan_amd.graph import BatchedDGLGraph
+    g0, g1 = q_lo * per_query, q_hi * per_query
+    n = k + 1 + m
+    noff = np.concatenate([[0], np.cumsum(n)])
+    g = BatchedDGLGraph.from_egonet_shapes(k[g0:g1], m[g0:g1])
+    return g, x[int(noff[g0]):int(noff[g1])], qf[g0:g1]
+
+
+def dp_training_step():
+    """Data-parallel training on the HIP kernels at world size N (all ranks on cuda:0, gloo): rank r takes the queries
+    shard_bounds(n_queries, N, r) of ONE batch -- a query's 1 + 31 egonets stay together, so its InfoNCE row is local -- runs the real
+    TaxoExpan step inside overlapped_gradient_allreduce(model=...) (the stack announces its layer buckets, the matcher's goes out from
+    its hook) and reduces the rest with allreduce_gradients.  Every parameter gradient must equal (a) the sum of the shards' gradients
+    computed in ONE process without any collective, to 2e-6 -- the collectives add nothing but the sum -- and that sum must be (b) the
+    single-process step on the whole batch (the loss is a sum over queries).  Dropout off (the keep masks hash batch row indices,
+    which differ between the whole batch and a shard).  Last scenario: fewer queries than ranks -- the last rank's shard is empty, it
+    never runs backward, and must neither hang nor change the sums."""
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda:0")
+    from taxoexpan_amd import TaxoExpan, synthetic as syn
+    from taxoexpan_amd.loss import info_nce_loss
+    from taxoexpan_amd.scoring import allreduce_gradients, gradient_bucket_plan, overlapped_gradient_allreduce, shard_bounds
+    NEG = 31
+    tax = syn.make_taxonomy(6000, 9500, 250, seed=11)
+    cases = [("PGAT [4,1] MAG dims", dict(in_dim=250, hidden_dim=500, out_dim=500, pos_dim=50, num_layers=1, heads=[4, 1]), 128),
+             ("PGAT [2,4,1] three layers", dict(in_dim=250, hidden_dim=32, out_dim=48, pos_dim=50, num_layers=2, heads=[2, 4, 1]), 64),
+             ("PGAT [4,1], last shard empty", dict(in_dim=250, hidden_dim=64, out_dim=64, pos_dim=50, num_layers=1, heads=[4, 1]), world - 1)]
+    for name, dims, n_queries in cases:
+        torch.manual_seed(47)
+        model = TaxoExpan("PGAT", "WMR", "LBM", **dict(dims, feat_drop=0.0, attn_drop=0.0, hidden_drop=0.0, out_drop=0.0)).to(dev).train()
+        with torch.no_grad():                                          # (spread the scores: the loss should not be flat)
+            model.match.W.weight.mul_(8.0)
+        params = list(model.parameters())
+        g, qf, _ = syn.training_batch(tax, n_queries, NEG, seed=77)
+        x = g.ndata.pop("x")
+        pos = g.ndata["pos"].numpy()
+        nn_ = np.asarray(g.batch_num_nodes)
+        noff = np.concatenate([[0], np.cumsum(nn_)])
+        k = np.asarray([int((pos[noff[i]:noff[i + 1]] == 0).sum()) for i in range(len(nn_))])
+        m = nn_ - 1 - k
+        def local_step(q_lo, q_hi):
+            for p in params:
+                p.grad = None
+            gs, xs, qs = _shard_batch(k, m, x, qf, q_lo, q_hi, 1 + NEG)
+            pred = model(gs, xs.to(dev), qs.to(dev))
+            info_nce_loss(pred.reshape(q_hi - q_lo, -1), torch.zeros(q_hi - q_lo, dtype=torch.long, device=dev)).backward()
+            return [p.grad.detach().clone() for p in params]
+        # ---- (1) the single-process step on the whole batch ----
+        whole = local_step(0, n_queries)
+        assert all(torch.isfinite(w).all() for w in whole) and max(float(w.abs().max()) for w in whole) > 1e-4, name
+        # ---- (2) the same partition WITHOUT collectives: every shard's step in this process, gradients added in rank order ----
+        want = None
+        for rr in range(world):
+            a_, b_ = shard_bounds(n_queries, world, rr)
+            if b_ > a_:
+                gr = local_step(a_, b_)
+                want = gr if want is None else [u + v for u, v in zip(want, gr)]
+        # the partition is right: sum of the shards' gradients = the whole batch's.  Rows that fall into another tile round of a GEMM
+        # are summed in another k order (last bit), and a leaky_relu whose pre-activation sits within that bit of 0 then takes the other
+        # branch on ONE element -- which moves one weight row's gradient by a single node's term.  Hence: 99.9 % of the entries at
+        # 1e-4 / 1e-5, every entry within 3 % of the tensor's largest.
+        for (pn, p), w, v in zip(model.named_parameters(), whole, want):
+            d, mx = (v - w).abs(), float(w.abs().max())
+            frac_bad = float((d > 1e-4 * w.abs() + 1e-5 * mx + 1e-9).float().mean())
+            assert frac_bad <= 1e-3 and float(d.max()) <= 3e-2 * mx + 1e-9, (name, pn, frac_bad, float(d.max()), mx)
+        # ---- (3) the data-parallel step: what the collectives add must be NOTHING but the sum (same kernels, same shard batches:
+        #      the per-rank gradients are bit-identical to (2)'s, only the order of the sum over ranks may differ) ----
+        for p in params:
+            p.grad = None
+        lo, hi = shard_bounds(n_queries, world, rank)
+        plan = gradient_bucket_plan(model)
+        assert [l for l, _ in plan] == list(range(dims["num_layers"], 0, -1)), name
+        with overlapped_gradient_allreduce(model=model) as ov:
+            if hi > lo:
+                gs, xs, qs = _shard_batch(k, m, x, qf, lo, hi, 1 + NEG)
+                pred = model(gs, xs.to(dev), qs.to(dev))
+                info_nce_loss(pred.reshape(hi - lo, -1), torch.zeros(hi - lo, dtype=torch.long, device=dev)).backward()
+        planned = {id(p) for _, ps in plan for p in ps} | {id(p) for p in model.match.parameters()}
+        assert ov.reduced == planned, (name, len(ov.reduced), len(planned))      # the layer buckets and the matcher's, on every rank
+        allreduce_gradients(params, skip=ov)
+        torch.cuda.synchronize()
+        for (pn, p), w in zip(model.named_parameters(), want):
+            tol = 2e-6 * w.abs() + 2e-6 * float(w.abs().max()) + 1e-12
+            bad = (p.grad - w).abs() > tol
+            assert not bool(bad.any()), (name, pn, int(bad.sum()), float((p.grad - w).abs().max()), float(w.abs().max()))
+    dist.barrier()
+    print(f"OK {rank}", flush=True)
+    dist.destroy_process_group()
+
+
 if __name__ == "__main__":
-    main()
+    dp_training_step() if sys.argv[1:2] == ["dp"] else main()

@@ -267,6 +267,94 @@ def _invariant_worker(rank, world, port, ret):
         dist.destroy_process_group()
 
 
+class _ToyGat3Stack(torch.autograd.Function):
+    """three "GAT layers" announced like ops.GATStackFunction.backward on the FOLDED route: the top layer's announcement also carries
+    the weighted readout's position weights (which the plan leaves to the flat bucket)"""
+    folded = True
+
+    @staticmethod
+    def forward(ctx, x, pw, *ps):
+        ctx.save_for_backward(x, pw, *ps)
+        ctx.ids, ctx.pw_id = [id(p) for p in ps], id(pw)
+        return _ToyGat3Stack._f(x, pw, ps)
+
+    @staticmethod
+    def _f(x, pw, ps):
+        w0, l0, r0, w1, l1, r1, w2, l2, r2 = ps
+        return ((((x @ w0) * l0 + r0) @ w1) * l1 + r1) @ w2 * l2.sum() * pw.sum() + r2.sum()
+
+    @staticmethod
+    def backward(ctx, g):
+        from taxoexpan_amd import ops
+        x, pw, *ps = ctx.saved_tensors
+        with torch.enable_grad():
+            qs = [p.detach().requires_grad_(True) for p in (pw, *ps)]
+            grads = [t.contiguous() for t in torch.autograd.grad(_ToyGat3Stack._f(x, qs[0], qs[1:]), qs, g)]
+        d_pw, grads = grads[0], grads[1:]
+        if ops._GRAD_READY is not None:
+            if _ToyGat3Stack.folded:
+                ops._GRAD_READY(2, list(grads[6:]) + [d_pw], ctx.ids[6:] + [ctx.pw_id])
+            else:                                           # the unfolded route: the readout is its own autograd node
+                ops._GRAD_READY(2, list(grads[6:]), ctx.ids[6:])
+            ops._GRAD_READY(1, list(grads[3:6]), ctx.ids[3:6])
+            ops._GRAD_READY(0, list(grads[:3]), ctx.ids[:3])
+            ops._GRAD_FLUSH()
+        return (None, d_pw, *grads)
+
+
+def _three_layer_worker(rank, world, port, ret):
+    import types
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from taxoexpan_amd import scoring
+        torch.manual_seed(5)
+        P = lambda *s: torch.nn.Parameter(torch.randn(*s))
+        dims = [(4, 5), (5, 6), (6, 3)]
+        layers = [types.SimpleNamespace(fc=types.SimpleNamespace(weight=P(*d)), attn_l=P(d[1]), attn_r=P(d[1])) for d in dims]
+        pw, wm = P(3), P(3)
+        model = types.SimpleNamespace(graph_propagate=types.SimpleNamespace(gat_layers=layers),
+                                      readout=types.SimpleNamespace(position_weights=types.SimpleNamespace(weight=pw)),
+                                      match=types.SimpleNamespace(parameters=lambda: [wm]))
+        stack = [t for l in layers for t in (l.fc.weight, l.attn_l, l.attn_r)]
+        params = stack + [pw, wm]
+        xs = [torch.randn(6, 4, generator=torch.Generator().manual_seed(20 + r)) for r in range(world)]
+        want = None
+        for r in range(world):
+            for p in params:
+                p.grad = None
+            (_ToyGat3Stack.apply(xs[r], pw, *stack) * wm).sum().backward()
+            g = [p.grad.clone() for p in params]
+            want = g if want is None else [a + b for a, b in zip(want, g)]
+        plan = scoring.gradient_bucket_plan(model)
+        assert [l for l, _ in plan] == [2, 1] and all(id(pw) not in [id(p) for p in ps] for _, ps in plan)
+        ok = True
+        for folded in (True, False):
+            _ToyGat3Stack.folded = folded
+            for p in params:
+                p.grad = None
+            with scoring.overlapped_gradient_allreduce(model=model) as ov:
+                (_ToyGat3Stack.apply(xs[rank], pw, *stack) * wm).sum().backward()
+            # layers 2 and 1 went out during backward, the matcher's from its hook; layer 0 and the readout weights: the flat bucket
+            assert ov.reduced == {id(p) for p in stack[3:]} | {id(wm)}
+            scoring.allreduce_gradients(params, skip=ov)
+            ok = ok and all(torch.allclose(p.grad, w, atol=1e-5) for p, w in zip(params, want))
+        ret[rank] = ok
+    finally:
+        dist.destroy_process_group()
+
+
+def test_overlapped_gradient_allreduce_three_layers_every_gradient_summed_exactly_once():
+    """three planned layers whose top announcement carries the readout's position weights as well (the folded route) or not (the
+    unfolded one): the plan holds the layers' own tensors only, so neither route mismatches it -- every parameter ends with the sum
+    over ranks exactly once (round 3's plan put the readout weights into the top bucket: an unfolded top layer then mismatched, was
+    zero-reduced mid-backward when the layer below announced, and its real gradients stayed un-reduced)"""
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_three_layer_worker, args=(2, _free_port(), ret), nprocs=2, join=True)
+    assert all(ret.get(r) for r in range(2)), dict(ret)
+
+
 def test_overlapped_gradient_allreduce_is_rank_invariant_when_a_rank_skips_the_stack():
     """a rank whose backward never reaches the propagation stack (an empty shard) still issues the planned bucket's all-reduce (with
     zeros) and the same flat bucket as its peers: no hang, every rank ends with the sum"""

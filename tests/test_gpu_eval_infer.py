@@ -258,3 +258,26 @@ def test_sharded_scoring_equals_unsharded_bit_for_bit_on_the_hip_kernels(world):
                          cwd=repo, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
     assert all(out.stdout.count(f"OK {r}") == 1 for r in range(world)), out.stdout[-500:]      # (the ranks' lines may interleave)
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_data_parallel_training_step_equals_single_process_on_the_hip_kernels(world):
+    """trainer/trainer.py:52-56 + model/loss.py:52-57 under data parallelism, with the real TaxoExpan / GATStackFunction announcing its
+    buckets into overlapped_gradient_allreduce(model=...): world 2 and 4 over gloo on one GPU, each rank a query shard of ONE batch;
+    every parameter gradient equals the single-process step on the whole batch (1e-4 relative + 1e-5 of the tensor's largest entry:
+    only the summation order over ranks differs); two- and three-layer PGAT (one / two planned buckets); a rank with an EMPTY shard
+    issues the planned collectives with zeros and nothing hangs (tests/dist_gpu_worker.py dp)."""
+    import socket
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+                          "--master-port", str(port), os.path.join(repo, "tests", "dist_gpu_worker.py"), "dp"],
+                         cwd=repo, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
+    assert all(out.stdout.count(f"OK {r}") == 1 for r in range(world)), out.stdout[-500:]

@@ -397,7 +397,7 @@ def extra_metrics_mag_full(model, device, tax, n_queries=8192, qblock=1024):
     """N = 1: the all-candidate inference loop on the MAG-Full shape (356 k candidate egonets built on device, features as rows of
     the taxonomy table; 8,192 of the test queries): encode in one batch and in test_fast.py's `-b 30000` chunks, then score + rank
     every (query, candidate) pair -- the `candidates scored / s` half of BASELINE.json's metric at the size it is quoted on."""
-    from taxoexpan_amd import graph as G, synthetic as syn
+    from taxoexpan_amd import graph as G, ops as ops_, synthetic as syn
     from taxoexpan_amd.evaluate import candidate_graphs
     from taxoexpan_amd.scoring import encode_candidates, rank_all_fused
     out = {}
@@ -421,6 +421,22 @@ def extra_metrics_mag_full(model, device, tax, n_queries=8192, qblock=1024):
         pos_off, pos_idx = _positives(tax, cand, test)
         t_fr = median_time(lambda: rank_all_fused(model.match, hg, queries, pos_off, pos_idx, block=qblock))
         ranks = rank_all_fused(model.match, hg, queries, pos_off, pos_idx, block=qblock)
+        # infer.py:96-106 / test_fast.py:121-131: the 5 best parents of every query -- the fused score + select kernels against the torch
+        # composite on materialised score blocks (scoring.topk_parents; on 1,024 of the queries: it needs two int64 [Q, G] temporaries)
+        from taxoexpan_amd.scoring import topk_parents, topk_parents_fused
+        t_top = median_time(lambda: topk_parents_fused(model.match, hg, queries, None, 5, True, block=qblock))
+        U = ops_.bilinear_project(hg, model.match.W.weight)
+        ids = torch.arange(hg.shape[0], device=device)
+        qs = queries[:1024]
+
+        def composite():
+            return topk_parents(ops_.score_block(qs, U, model.match.apply_exp), ids, 5, True)
+        t_comp = median_time(composite, reps=3)
+        same = bool(torch.equal(topk_parents_fused(model.match, hg, qs, None, 5, True, block=qblock), composite()))
+        del U
+        out.update(infer_top5_s=t_top, infer_top5_queries_per_s=len(test) / t_top, infer_top5_pairs_per_s=float(len(cand)) * len(test) / t_top,
+                   infer_top5_torch_composite_queries_per_s=qs.shape[0] / t_comp, infer_top5_fused_over_composite=(len(test) / t_top) / (qs.shape[0] / t_comp),
+                   infer_top5_fused_equals_composite=same)
         pairs = float(len(cand)) * len(test)
         out.update(shape="mag_full", candidates=int(len(cand)), queries=int(len(test)), egonet_nodes=n_nodes, egonet_edges=n_edges,
                    device_egonet_build_s=t_build, encode_s=t_enc, encode_edges_per_s=n_edges / t_enc,
@@ -779,6 +795,8 @@ def main():
                                 ("candidates_scored_per_s_mag_full", ("mag_full", "candidates_scored_per_s")),
                                 ("candidates_scored_per_s_mag_full_fused_rank", ("mag_full", "candidates_scored_per_s_fused_rank")),
                                 ("mag_full_encode_edges_per_s", ("mag_full", "encode_edges_per_s")),
+                                ("infer_top5_queries_per_s", ("mag_full", "infer_top5_queries_per_s")),
+                                ("infer_top5_fused_over_composite", ("mag_full", "infer_top5_fused_over_composite")),
                                 ("step_pgcn_ms", ("step_pgcn", "ms_per_step")), ("step_pgat2_ms", ("step_pgat2", "ms_per_step"))):
                 v = extra
                 for k in path:

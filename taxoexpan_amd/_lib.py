@@ -58,6 +58,9 @@ SIGNATURES = {
     "txe_bilinear_runs_bwd_ws_bytes": (SZ, [I, I, I]),
     "txe_bilinear_runs_bwd": (I, [P, L, P, L, P, I, I, I, I, I, P, P, P, P, L, P, P, SZ, P]),
     "txe_rows_find_runs": (I, [P, L, I, I, P, P, P, P]),
+    "txe_score_topk_tiles": (I, [I]),
+    "txe_score_topk_block": (I, [P, L, I, P, L, I, I, I, I, I, I, P, P, P, P, P]),
+    "txe_topk_merge": (I, [P, P, I, L, I, I, P, P, P]),
     "txe_bilinear_stacked_fwd": (I, [P, L, P, L, P, P, I, I, I, P, I, P, P, P]),
     "txe_bilinear_stacked_bwd_ws_bytes": (SZ, [I, I, I]),
     "txe_bilinear_stacked_bwd": (I, [P, L, P, L, P, P, I, I, I, I, P, P, P, P, L, P, P, SZ, P]),
@@ -107,7 +110,7 @@ class GatPrepareDesc(C.Structure):
 
 _ERR = {-1: "TXE_ERR_ARG", -2: "TXE_ERR_LAUNCH", -3: "TXE_ERR_WORKSPACE"}
 VALUE_RETURNING = {"txe_gat_padded_k", "txe_gat_padded_f", "txe_gcn_padded_f", "txe_profile_count", "txe_gat_fused_bwd_supported",
-                   "txe_gat_aggregate_table_supported", "txe_gat_dx_streams"}   # int results that are not status codes
+                   "txe_gat_aggregate_table_supported", "txe_gat_dx_streams", "txe_score_topk_tiles"}   # int results that are not status codes
 
 _lib = None
 

@@ -108,6 +108,33 @@ __host__ __device__ __forceinline__ unsigned drop_mask_word(uint64_t seed, uint6
 
 __device__ __forceinline__ float leaky(float x, float slope) { return x > 0.f ? x : x * slope; }
 
+// ---- best-k lists (top-k mode of the scoring loop) ----------------------------------------------------------------------
+// A list of TOPK_MAX (key, column) pairs in registers, best first.  "better": larger key, equal keys by smaller column -- the order
+// of Python's stable `sorted(enumerate(scores), key=lambda x: -x[1])` (infer.py:100, test_fast.py:125).  Empty slots hold
+// (-inf, INT_MAX): worse than any real entry, a real -inf key included.
+constexpr int TOPK_MAX = 8;
+__device__ __forceinline__ bool topk_better(float ka, int ia, float kb, int ib) { return (ka > kb) | ((ka == kb) & (ia < ib)); }
+__device__ __forceinline__ void topk_init(float* bk, int* bi) {
+#pragma unroll
+    for (int t = 0; t < TOPK_MAX; ++t) { bk[t] = -INFINITY; bi[t] = 0x7fffffff; }
+}
+// (key, idx) takes the place of the last entry and bubbles up: all indices static, the list never leaves its registers
+__device__ __forceinline__ void topk_insert(float* bk, int* bi, float key, int idx) {
+    bk[TOPK_MAX - 1] = key; bi[TOPK_MAX - 1] = idx;
+#pragma unroll
+    for (int t = TOPK_MAX - 1; t > 0; --t) {
+        const bool up = topk_better(bk[t], bi[t], bk[t - 1], bi[t - 1]);
+        const float k0 = bk[t - 1]; const int i0 = bi[t - 1];
+        bk[t - 1] = up ? bk[t] : k0; bi[t - 1] = up ? bi[t] : i0;
+        bk[t] = up ? k0 : bk[t];     bi[t] = up ? i0 : bi[t];
+    }
+}
+__device__ __forceinline__ float topk_key_of(float x, bool larger) {
+    const float k = larger ? x : -x;
+    return (k != k) ? -INFINITY : k;                 // NaN compares false with everything: it ranks last
+}
+
+
 // ---- optional per-launch timing (txe_profile.hip); a no-op unless txe_profile_enable(1) was called ----
 bool prof_enabled();
 int prof_begin(const char* name, hipStream_t s, double work, int kind);

@@ -91,7 +91,15 @@ struct Epi {
     // pick mode (cnt_mode 3; the thresholds of that ranking): column n belongs to the row m with cnt_off[m] <= n < cnt_off[m+1] (the
     //   columns are the gathered true parents of the rows' queries, query by query); only c[n] = value(m, n) of those pairs is stored
     //   and tiles that hold none of them return at once -- a staircase of ~(rows/128 + columns/BN) tiles instead of the whole product
+    // top-k mode (cnt_mode 4: larger is better, 5: smaller is better; the scoring loop's "best k parents", infer.py:100-106): nothing of
+    //   the product is stored; every tile leaves, per row, its topk_k best columns in the order Python's stable sorted() gives them
+    //   (better value first, equal values by ascending column; NaN ranks last) as keys (value, negated in mode 5) + column numbers at
+    //   topk_key / topk_idx [M][column tiles][topk_k]; a merge kernel (txe_topk_merge) picks each row's best k among the tiles' lists
     int cnt_mode;
+    int topk_k;
+    float* topk_key;
+    int* topk_idx;
+    int force_bn128;           // 1: 128-wide column tiles whatever the shape (the top-k scratch is laid out by them)
     const int* cnt_off;
     const float* cnt_thr;
     int* cnt_out;
@@ -114,6 +122,7 @@ static inline Epi epi_plain(float* c, long long ldc, int cols) {
     e.mask = reinterpret_cast<const unsigned*>(c); e.mask_ld = 0; e.mask_col0 = 0; e.mask_on = 0; e.drop_scale = 1.f;
     e.apply_exp = 0; e.split_stride = 0;
     e.cnt_mode = 0; e.cnt_off = nullptr; e.cnt_thr = nullptr; e.cnt_out = nullptr;
+    e.topk_k = 0; e.topk_key = nullptr; e.topk_idx = nullptr; e.force_bn128 = 0;
     e.alg_flops = 0.0; e.route = 0;
     e.plain_k_order = 0;
     return e;
@@ -652,6 +661,45 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_kernel(VMat A, VMat B, c
         }
         return;
     }
+    if (E.cnt_mode == 4 || E.cnt_mode == 5) {
+        // best-k columns of every row of this tile: two threads per row, each scans its half row (ascending columns) into a best-k list,
+        // the pair merges, the even thread writes the row's topk_k entries of this column tile
+        static_assert(GEMM_THREADS == 2 * GEMM_BM, "two threads per tile row");
+        constexpr int HW = BN / 2;
+        const int row = threadIdx.x >> 1, half = threadIdx.x & 1;
+        const int m = m0 + row, nb = n0 + half * HW;
+        const bool larger = E.cnt_mode == 4;
+        float bk[TOPK_MAX];
+        int bi[TOPK_MAX];
+        topk_init(bk, bi);
+#pragma unroll 4
+        for (int j = 0; j < HW / 4; ++j) {
+            const float4 t4 = *reinterpret_cast<const float4*>(Cs + row * CLD + half * HW + 4 * j);
+            const float v4[4] = {t4.x, t4.y, t4.z, t4.w};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int n = nb + 4 * j + q;
+                const float key = topk_key_of(E.apply_exp ? __expf(v4[q]) : v4[q], larger);
+                if (n < N && topk_better(key, n, bk[TOPK_MAX - 1], bi[TOPK_MAX - 1])) topk_insert(bk, bi, key, n);
+            }
+        }
+        // the odd thread's list goes to the even one (all lanes shuffle; only the even thread's merge is kept)
+#pragma unroll
+        for (int t = 0; t < TOPK_MAX; ++t) {
+            const float ok = __shfl_xor(bk[t], 1, 64);
+            const int oi = __shfl_xor(bi[t], 1, 64);
+            // (the partner's list is sorted: once an entry fails, the rest would too -- the insert is predicated, not skipped, to keep
+            //  the shuffles of the next round uniform)
+            if (half == 0 && topk_better(ok, oi, bk[TOPK_MAX - 1], bi[TOPK_MAX - 1])) topk_insert(bk, bi, ok, oi);
+        }
+        if (half == 0 && m < M) {
+            const long long o = ((long long)m * nbn + tn) * E.topk_k;
+#pragma unroll
+            for (int t = 0; t < TOPK_MAX; ++t)
+                if (t < E.topk_k) { E.topk_key[o + t] = bk[t]; E.topk_idx[o + t] = bi[t]; }
+        }
+        return;
+    }
     if (E.cnt_mode != 0) {
         // fused ranking: every thread owns 4 consecutive columns of a row; the C4 lanes of a row reduce their counts by butterfly.
         // The rows' positive ranges and (up to PS) thresholds are staged once per tile in the LDS left over behind the C tile.
@@ -1080,7 +1128,7 @@ static inline int gemm_launch_layout(const VMat& A, const VMat& B, const Epi& E_
     const bool allow160 = !BKC && va == 4 && vb == 4 && !E.mask_on && !E.act_on && E.cnt_mode == 0 &&
                           (E.c2 == nullptr || E.cols_main >= N);
     const bool tail_split = tail_ws != nullptr && !E.plain_k_order;
-    int bn = choose_bn(M, N, splits, tail_split, K, allow160, (E.route & GEMM_ROUTE_FORCE_BN160) != 0);
+    int bn = E.force_bn128 ? 128 : choose_bn(M, N, splits, tail_split, K, allow160, (E.route & GEMM_ROUTE_FORCE_BN160) != 0);
     int tile0 = 0;
     // whole rounds of 128 x 128 tiles of a plain product with a short reduction: persistent workgroups (gemm_persist_kernel)
     if (splits == 1 && tail_ws != nullptr && va == 4 && vb == 4 && N > 64 && !(E.route & GEMM_ROUTE_NO_PERSIST) && !E.mask_on && !E.act_on &&

@@ -553,6 +553,8 @@ int txe_bilinear_stacked_bwd(const float* e1, long long ld_e1, const float* e2, 
     return runs_bwd_launch(e1, ld_e1, e2, ld_e2, R, gx, G, l, r, apply_exp, V, s, ds, d_e1, ld_de1, dW, (float*)ws, st);
 }
 
+int txe_topk_merge(const float* keys, const int* idx, int nq, long long cnt, int k, int idx_base, int* out_idx, float* out_key, void* stream);
+
 // Plain dense product on the library's fp32 MFMA GEMM (tests / micro-benchmarks; the model paths above use the same kernels
 // through their fused entry points).  layout 0: C = A[M][K] * B[N][K]^T;  1: C = A[M][K] * B[K][N];  2: C = A[K][M]^T * B[K][N].
 // splits > 1 writes `splits` partial products at C + z*M*N (the caller reduces them).
@@ -692,6 +694,31 @@ int txe_score_count_block(const float* Q, long long ld_q, int nq, const float* U
     E.cnt_mode = larger_is_better ? 1 : 2;
     E.cnt_off = pos_off; E.cnt_thr = thr; E.cnt_out = counts;
     return gemm_nt(A, B, E, nq, G, r, 1, (hipStream_t)stream);
+}
+
+// Fused scoring + best-k selection of one block of the loop (infer.py:96-106, test_fast.py:121-131: `sorted(enumerate(scores))[:k]`):
+// the score tile never leaves the workgroup; every 128 x 128 tile leaves each row's k best columns at part_key / part_idx
+// [nq][txe_score_topk_tiles(G)][k] (scratch), txe_topk_merge picks each query's best k among them: out_idx [nq][k] candidate rows
+// (+ idx_base: the first row of a candidate shard), out_key [nq][k] their keys (score, negated when smaller is better; may be NULL).
+// The same MFMA kernel and k order as txe_score_block: the scores behind the selection are bit-identical to the materialised ones.
+// Ties in Python's stable order (ascending candidate row), NaN last.  1 <= k <= 8; G >= 1.
+int txe_score_topk_tiles(int G) { return (G + 127) / 128; }
+
+int txe_score_topk_block(const float* Q, long long ld_q, int nq, const float* U, long long ld_u, int G, int r, int apply_exp,
+                         int larger_is_better, int k, int idx_base, float* part_key, int* part_idx, int* out_idx, float* out_key,
+                         void* stream) {
+    if (nq < 0 || G < 1 || r < 1 || ld_u < r || k < 1 || k > TOPK_MAX || !Q || !U || !part_key || !part_idx || !out_idx) return TXE_ERR_ARG;
+    if (nq == 0) return TXE_OK;
+    VMat A = vmat_plain(Q, ld_q, nq, r);
+    VMat B = vmat_plain(U, ld_u, G, r);
+    Epi E = epi_plain(part_key, 0, G);                              // c is never written in top-k mode
+    E.apply_exp = apply_exp;
+    E.cnt_mode = larger_is_better ? 4 : 5;
+    E.topk_k = k; E.topk_key = part_key; E.topk_idx = part_idx;
+    E.force_bn128 = 1;                                              // (the scratch layout counts 128-wide column tiles)
+    int rc = gemm_nt(A, B, E, nq, G, r, 1, (hipStream_t)stream);
+    if (rc) return rc;
+    return txe_topk_merge(part_key, part_idx, nq, (long long)txe_score_topk_tiles(G) * k, k, idx_base, out_idx, out_key, stream);
 }
 
 }  // extern "C"

@@ -111,11 +111,74 @@ __global__ void rank_finalize_kernel(const int* __restrict__ pos_off, int nq, co
     }
 }
 
+// Best k entries of every row among `cnt` candidates (key, column) -- the per-tile lists of the score GEMM's top-k epilogue, or the
+// per-rank lists of a candidate-sharded loop -- in Python's stable sorted() order: better key first, equal keys by ascending column.
+// One wave per row: every lane folds its strided share into a best-k list (registers), then k rounds of a wave-wide arg-best over the
+// lanes' heads; the lane that held the winner pops it.  Deterministic: no atomics, no dependence on the order of arrival.
+__global__ __launch_bounds__(256) void topk_merge_kernel(const float* __restrict__ pkey, const int* __restrict__ pidx, int nq, long long cnt, int k,
+                                                         int idx_base, int* __restrict__ out_idx, float* __restrict__ out_key) {
+    const int q = blockIdx.x * 4 + (threadIdx.x >> 6), l = threadIdx.x & 63;
+    if (q >= nq) return;
+    const float* kp = pkey + (long long)q * cnt;
+    const int* ip = pidx + (long long)q * cnt;
+    float bk[TOPK_MAX];
+    int bi[TOPK_MAX];
+    topk_init(bk, bi);
+    for (long long e0 = 0; e0 < cnt; e0 += 4 * 64) {            // four independent loads in flight per lane
+        float kv[4];
+        int iv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const long long e = e0 + u * 64 + l;
+            const long long ec = e < cnt ? e : cnt - 1;
+            kv[u] = kp[ec]; iv[u] = (e < cnt) ? ip[ec] : 0x7fffffff;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (iv[u] != 0x7fffffff && topk_better(kv[u], iv[u], bk[TOPK_MAX - 1], bi[TOPK_MAX - 1])) topk_insert(bk, bi, kv[u], iv[u]);
+    }
+    for (int t = 0; t < k; ++t) {
+        float wk = bk[0];
+        int wi = bi[0];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ok = __shfl_xor(wk, o, 64);
+            const int oi = __shfl_xor(wi, o, 64);
+            const bool take = topk_better(ok, oi, wk, wi);
+            wk = take ? ok : wk; wi = take ? oi : wi;
+        }
+        if (bi[0] == wi && wi != 0x7fffffff) {                  // (columns are unique: exactly one lane holds the winner) pop it
+#pragma unroll
+            for (int j = 0; j + 1 < TOPK_MAX; ++j) { bk[j] = bk[j + 1]; bi[j] = bi[j + 1]; }
+            bk[TOPK_MAX - 1] = -INFINITY; bi[TOPK_MAX - 1] = 0x7fffffff;
+        }
+        if (l == 0) {
+            out_idx[(long long)q * k + t] = (wi == 0x7fffffff) ? -1 : wi + idx_base;
+            if (out_key) out_key[(long long)q * k + t] = wk;
+        }
+    }
+}
+
 }  // namespace txe
 
 using namespace txe;
 
 extern "C" {
+
+// keys / idx [nq][cnt] -> out_idx [nq][k] (+ idx_base; -1 where a row holds fewer than k real entries), out_key [nq][k] (may be NULL).
+// Entries with idx == INT_MAX are empty slots.  1 <= k <= 8.
+int txe_topk_merge(const float* keys, const int* idx, int nq, long long cnt, int k, int idx_base, int* out_idx, float* out_key, void* stream) {
+    if (nq < 0 || cnt < 0 || k < 1 || k > TOPK_MAX || !keys || !idx || !out_idx) return TXE_ERR_ARG;
+    if (nq == 0) return TXE_OK;
+    if (cnt == 0) {
+        if (hipMemsetAsync(out_idx, 0xff, (size_t)nq * k * sizeof(int), (hipStream_t)stream) != hipSuccess) return TXE_ERR_LAUNCH;
+        return TXE_OK;
+    }
+    ProfScope prof("topk_merge_kernel", (hipStream_t)stream, 8.0 * nq * (double)cnt, 1);
+    hipLaunchKernelGGL(topk_merge_kernel, dim3((nq + 3) / 4), dim3(256), 0, (hipStream_t)stream, keys, idx, nq, cnt, k, idx_base, out_idx, out_key);
+    TXE_CHECK_LAUNCH();
+    return TXE_OK;
+}
 
 // S [nq][G] (row stride ld_s); pos_off [nq+1], pos_idx [pos_off[nq]] = candidate columns of each query's true
 // parents (duplicates not allowed); ranks [pos_off[nq]] int32 out.

@@ -6,7 +6,7 @@ import numpy as np
 import torch
 
 from .graph import device_egonet_batch
-from .scoring import encode_candidates, rank_all_fused, topk_parents
+from .scoring import encode_candidates, rank_all_fused, topk_parents, topk_parents_fused
 
 
 def candidate_graphs(dtax, anchors, expand_factor, seed, batch_size=-1):
@@ -42,6 +42,15 @@ def _score_blocks(model, hg, qf, qblock):
             yield q0, ops.score_block(qf[q0:q0 + qblock], U, model.match.apply_exp)
         else:
             yield q0, torch.stack([model.match(hg, q.expand(hg.shape[0], -1)).reshape(-1) for q in qf[q0:q0 + qblock]])
+
+
+def _best_parents(model, hg, qf, cand_ids, topk, larger_is_better, qblock):
+    """the `topk` best candidates of every query, best first (infer.py:100-106 / test_fast.py:125-131): BIM / LBM with topk <= 8 through
+    the fused score + select kernels (no score matrix), anything else by materialising score blocks"""
+    if hasattr(model.match, "W") and hasattr(model.match, "apply_exp") and 1 <= topk <= 8 and hg.shape[0] > 0 and qf.shape[0] > 0:
+        return topk_parents_fused(model.match, hg, qf, cand_ids, topk, larger_is_better, block=qblock)
+    top = [topk_parents(S, cand_ids, topk, larger_is_better) for _q0, S in _score_blocks(model, hg, qf, qblock or 1024)]
+    return torch.cat(top) if top else cand_ids.new_zeros((0, 0))
 
 
 def _case_rows(dataset, queries, pos_off, ranks, top, metric_names):
@@ -91,8 +100,7 @@ def evaluate(model, dataset, device, larger_is_better=True, qblock=None, seed=0,
         ranks = rank_all_fused(model.match, hg, qf, pos_off, pos_idx, block=qblock, larger_is_better=larger_is_better)
         if case is not None:                                               # test_fast.py:112-147
             cand_ids = torch.as_tensor(np.asarray(cand, dtype=np.int64), device=device)
-            top = [topk_parents(S, cand_ids, topk, larger_is_better) for _q0, S in _score_blocks(model, hg, qf, qblock or 1024)]
-            top = torch.cat(top).cpu().tolist() if top else []
+            top = _best_parents(model, hg, qf, cand_ids, topk, larger_is_better, qblock).cpu().tolist()
             rows = _case_rows(dataset, queries, pos_off, ranks, top, metric_names)
             if isinstance(case, list):
                 case.extend(rows)
@@ -129,12 +137,9 @@ def infer(model, dataset, new_taxons, device, loss="info_nce_loss", batch_size=-
     larger = str(loss).startswith("info_nce")
     qf = torch.as_tensor(np.asarray(nf), dtype=torch.float32).to(device)
     cand_ids = torch.as_tensor(anchors, device=device)
-    picks = []
     with torch.no_grad():
-        for _q0, S in _score_blocks(model, hg, qf, qblock):
-            picks.append(topk_parents(S, cand_ids, topk, larger))
+        picks = _best_parents(model, hg, qf, cand_ids, topk, larger, qblock).cpu().tolist()
     model.train(was_training)
-    picks = torch.cat(picks).cpu().tolist() if picks else []
     out = [(q, [dataset.vocab[i] for i in row]) for q, row in zip(vocab, picks)]
     if save is not None:
         with open(save, "w") as fout:

@@ -496,7 +496,7 @@ class _Bilinear(nn.Module):
         if torch.is_grad_enabled() and torch.is_tensor(e2) and not (self._stacked_runs_ok(None, e2) and self._repeats(e2)):
             self._pre = ops.bilinear_query_prefetch(e2, self.W.weight)
 
-    def score_all(self, hg, queries, block=1024, out=None):
+    def score_all(self, hg, queries, block=None, out=None):
         """The whole scoring loop at once: S[q][g] = match(hg[g], queries[q]) (test_fast.py:116-123)."""
         from .scoring import score_all
         return score_all(self, hg, queries, block=block, out=out)

@@ -1363,6 +1363,60 @@ def score_count_block(Q, U, apply_exp, pos_off, thr, larger_is_better=True, coun
     return counts
 
 
+def score_topk_block(Q, U, apply_exp, k, larger_is_better=True, idx_base=0, q_padded=False, scratch=None):
+    """fused scoring + best-k selection of one query block against a candidate (shard) matrix U (txe_score_topk_block): returns
+    (idx int32 [nq, k] = candidate rows + idx_base, best first, ties by ascending row like Python's stable sort, NaN last;
+    key fp32 [nq, k] = the scores, negated when smaller is better).  No [nq x G] block is materialised.  1 <= k <= min(8, G).
+    q_padded: as in score_count_block.  scratch: dict reused across the blocks of a loop (the per-tile lists)."""
+    _need_cuda(Q, U)
+    if q_padded:
+        assert Q.dtype == torch.float32 and Q.dim() == 2 and Q.stride(1) == 1, "q_padded: a row block of pad_queries_like()"
+        ldq = Q.stride(0)
+    else:
+        Q, ldq = _rows(Q)
+    U, ldu = _rows(U)
+    nq, r = Q.shape
+    G = U.shape[0]
+    assert 1 <= k <= 8 and k <= G, "score_topk_block: 1 <= k <= min(8, candidates)"
+    rp = _padded_width(U, r)
+    if q_padded and rp != r and nq > 0:
+        assert ldq == rp
+        r = rp
+    elif rp != r and nq > 0:
+        Q = _pad_queries(Q, r, rp)
+        ldq, r = rp, rp
+    elif ldq % 4 != 0 and nq > 0:
+        Qp = _empty((nq, (r + 3) // 4 * 4), Q)[:, :r]
+        Qp.copy_(Q)
+        Q, ldq = Qp, Qp.stride(0)
+    idx = torch.empty((nq, k), dtype=torch.int32, device=Q.device)
+    key = _empty((nq, k), Q)
+    if nq == 0:
+        return idx, key
+    with _lib.on_device(Q.device):
+        nt = call("txe_score_topk_tiles", G)
+        need = nq * nt * k
+        sc = scratch if scratch is not None else {}
+        if sc.get("n", 0) < need or sc["key"].device != Q.device:
+            sc["key"], sc["idx"], sc["n"] = _empty((need,), Q), torch.empty(need, dtype=torch.int32, device=Q.device), need
+        call("txe_score_topk_block", ptr(Q), ldq, nq, ptr(U), ldu, G, r, int(apply_exp), int(larger_is_better), int(k), int(idx_base),
+             ptr(sc["key"]), ptr(sc["idx"]), ptr(idx), ptr(key), _lib.stream_ptr())
+    return idx, key
+
+
+def topk_merge(keys, idx, k):
+    """best k of the (key, idx) entries of every row (txe_topk_merge; keys fp32 / idx int32 [nq, cnt], idx == INT_MAX: empty slot):
+    the merge of per-rank best-k lists of a candidate-sharded loop.  Returns (idx [nq, k], key [nq, k])."""
+    _need_cuda(keys, idx)
+    keys, idx = _f32(keys), idx.to(torch.int32).contiguous()
+    nq, cnt = keys.shape
+    out_i = torch.empty((nq, k), dtype=torch.int32, device=keys.device)
+    out_k = _empty((nq, k), keys)
+    with _lib.on_device(keys.device):
+        call("txe_topk_merge", ptr(keys), ptr(idx), nq, cnt, int(k), 0, ptr(out_i), ptr(out_k), _lib.stream_ptr())
+    return out_i, out_k
+
+
 def rank_finalize(pos_off, thr, counts, larger_is_better=True, out=None):
     """ranks (int32) from the fused counts: positives never count against each other (metric.py:7-31).  out: int32 [>= n_pos]"""
     _need_cuda(thr)

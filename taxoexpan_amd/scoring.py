@@ -15,11 +15,16 @@ import torch.distributed as dist
 from . import ops
 
 
-def score_all(match, hg, queries, block=1024, out=None):
-    """S[q][g] = match(hg[g], queries[q]) for all pairs; match is a BIM / LBM module."""
+def score_all(match, hg, queries, block=None, out=None):
+    """S[q][g] = match(hg[g], queries[q]) for all pairs; match is a BIM / LBM module.
+    block: queries per GEMM launch; default: a query set of up to 4,096 goes in ONE launch (MAG-CS: 2,459 queries x 24.7 k candidates
+    are 7.6 rounds of tiles -- in blocks of 1,024 every block pays its own partial last round and a second, 16-tile launch), larger
+    sets in blocks of 1,024."""
     U = ops.bilinear_project(hg, match.W.weight)
     Q = queries.shape[0]
     G = hg.shape[0]
+    if block is None:
+        block = 1024 if Q > 4096 else max(int(Q), 1)
     S = out if out is not None else torch.empty((Q, (G + 3) // 4 * 4), dtype=torch.float32, device=hg.device)[:, :G]
     for q0 in range(0, Q, block):
         ops.score_block(queries[q0:q0 + block], U, match.apply_exp, out=S[q0:q0 + block])
@@ -407,6 +412,57 @@ class overlapped_gradient_allreduce:
             torch._foreach_copy_(tensors, [q.view_as(t) for q, t in zip(flat.split([t.numel() for t in tensors]), tensors)])
             self.reduced.update(ids)
         self._pending = []
+
+
+def topk_parents_fused(match, hg, queries, candidate_ids=None, k=5, larger_is_better=True, block=None, group=None, shard_lo=0):
+    """infer.py:96-106 / test_fast.py:121-131 without the score matrix: per query block ONE launch of the score GEMM whose epilogue keeps
+    each tile's best k columns per row (txe_score_topk_block) + a merge launch -- no [Q, G] scores, no [Q, G] index temporaries (the
+    torch composite topk_parents below needs two int64 [Q, G] ones: 3.5 GB per 1,024-query block on MAG-Full).  Same selection and
+    order as topk_parents on the materialised scores of the same kernel (bit-identical values): better score first, ties by ascending
+    candidate position (Python's stable sort), NaN last.  match: BIM / LBM.  hg: this rank's candidate rows (positions
+    [shard_lo, shard_lo + len) of the global list).  Candidate-sharded (group / an initialised world > 1): every rank's [Q, k] lists
+    are all-gathered (k * 8 bytes per query instead of the [queries x candidates] block) and merged by the same kernel.
+    Returns candidate_ids[...] (or the positions themselves when candidate_ids is None) [Q, min(k, G)]."""
+    dev = hg.device
+    distributed = dist.is_available() and dist.is_initialized() and (group is not None or dist.get_world_size() > 1)
+    Q, G = queries.shape[0], hg.shape[0]
+    k_loc = min(int(k), G, 8)
+    assert int(k) <= 8, "topk_parents_fused: k <= 8 (the kernels keep 8 entries per list)"
+    if block is None:
+        block = 1024 if Q > 4096 else max(Q, 1)
+    outs = []
+    if k_loc > 0 and Q > 0:
+        U = ops.bilinear_project(hg, match.W.weight)
+        Qp = ops.pad_queries_like(queries, U)
+        scratch = {}
+        for q0 in range(0, Q, block):
+            outs.append(ops.score_topk_block(Qp[q0:q0 + block], U, match.apply_exp, k_loc, larger_is_better, idx_base=shard_lo, q_padded=True,
+                                             scratch=scratch))
+    if outs:
+        idx, key = torch.cat([o[0] for o in outs]), torch.cat([o[1] for o in outs])
+    else:
+        idx = torch.full((Q, 0), 0, dtype=torch.int32, device=dev)
+        key = torch.zeros((Q, 0), dtype=torch.float32, device=dev)
+    if distributed:
+        world = dist.get_world_size(group)
+        kk = min(int(k), 8)
+        # every rank contributes kk slots per query (a rank with fewer candidates pads with empty slots)
+        pad_i = torch.full((Q, kk), 0x7fffffff, dtype=torch.int32, device=dev)
+        pad_k = torch.full((Q, kk), -float("inf"), dtype=torch.float32, device=dev)
+        pad_i[:, :idx.shape[1]] = torch.where(idx >= 0, idx, torch.full_like(idx, 0x7fffffff))
+        pad_k[:, :key.shape[1]] = key
+        all_i = torch.empty((world, Q, kk), dtype=torch.int32, device=dev)
+        all_k = torch.empty((world, Q, kk), dtype=torch.float32, device=dev)
+        dist.all_gather_into_tensor(all_i.view(world * Q, kk), pad_i, group=group)
+        dist.all_gather_into_tensor(all_k.view(world * Q, kk), pad_k, group=group)
+        cat_i = all_i.permute(1, 0, 2).reshape(Q, world * kk).contiguous()
+        cat_k = all_k.permute(1, 0, 2).reshape(Q, world * kk).contiguous()
+        n_real = int((cat_i[0] != 0x7fffffff).sum().item()) if Q > 0 else 0      # = min(total candidates, world * kk): the same for every query
+        idx, key = ops.topk_merge(cat_k, cat_i, kk) if Q > 0 else (cat_i, cat_k)
+        idx = idx[:, :min(kk, n_real)]
+    if candidate_ids is None:
+        return idx.long()
+    return candidate_ids.to(dev)[idx.long()]
 
 
 def topk_parents(S, candidate_ids, k=5, larger_is_better=True):

@@ -126,8 +126,9 @@ def test_newterm_magnitudes_scores_and_top5_on_device():
     the factored scoring GEMM with the fused exp against the reference's LBM / BIM scores (tests/golden/newterms.npz) -- infs where exp
     overflows, zeros where it underflows -- and scoring.topk_parents on the DEVICE scores against the reference's sorted() top-5, both
     directions: equal infs / zeros / duplicated candidates in candidate order"""
+    import types
     from taxoexpan_amd import ops
-    from taxoexpan_amd.scoring import topk_parents
+    from taxoexpan_amd.scoring import topk_parents, topk_parents_fused
     z = dict(np.load(os.path.join(GOLDEN_DIR, "newterms.npz")))
     import golden_cases as gc
     hg, _raw, W = gc.make_newterm_inputs()
@@ -167,6 +168,14 @@ def test_newterm_magnitudes_scores_and_top5_on_device():
             assert len(inf_rows) >= 2
             t = topk_parents(S, ids, 5, True).cpu().numpy()
             assert np.array_equal(t[inf_rows], z["top5_desc_lbm"][inf_rows])               # >= 5 equal infs: exactly candidate order
+        # the fused score + select kernels (no score matrix) make the SAME selection as the composite on the materialised scores of the
+        # same GEMM kernel -- bit-identical values: overflowed infs / underflowed zeros / duplicated candidates in candidate order
+        mod = types.SimpleNamespace(W=types.SimpleNamespace(weight=W_d), apply_exp=ex)
+        for larger in (True, False):
+            for k in (1, 5, 8):
+                fused = topk_parents_fused(mod, hg_d, q_d, ids, k, larger)
+                assert torch.equal(fused, topk_parents(S, ids, k, larger)), (kind, larger, k)
+            assert torch.equal(topk_parents_fused(mod, hg_d, q_d, ids, 5, larger, block=7), topk_parents(S, ids, 5, larger))   # ragged query blocks
 
 
 @pytest.mark.parametrize("batch_size", [13, 64])
@@ -264,9 +273,10 @@ def test_sharded_scoring_equals_unsharded_bit_for_bit_on_the_hip_kernels(world):
 def test_data_parallel_training_step_equals_single_process_on_the_hip_kernels(world):
     """trainer/trainer.py:52-56 + model/loss.py:52-57 under data parallelism, with the real TaxoExpan / GATStackFunction announcing its
     buckets into overlapped_gradient_allreduce(model=...): world 2 and 4 over gloo on one GPU, each rank a query shard of ONE batch;
-    every parameter gradient equals the single-process step on the whole batch (1e-4 relative + 1e-5 of the tensor's largest entry:
-    only the summation order over ranks differs); two- and three-layer PGAT (one / two planned buckets); a rank with an EMPTY shard
-    issues the planned collectives with zeros and nothing hangs (tests/dist_gpu_worker.py dp)."""
+    every parameter gradient equals (a) the sum of the shards' gradients computed without any collective, to 2e-6 (the collectives add
+    nothing but the sum), and that sum equals (b) the single-process step on the whole batch; two- and three-layer PGAT (one / two
+    planned buckets); a rank with an EMPTY shard issues the planned collectives with zeros and nothing hangs
+    (tests/dist_gpu_worker.py dp)."""
     import socket
     import subprocess
     import sys
@@ -281,3 +291,45 @@ def test_data_parallel_training_step_equals_single_process_on_the_hip_kernels(wo
                          cwd=repo, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
     assert all(out.stdout.count(f"OK {r}") == 1 for r in range(world)), out.stdout[-500:]
+
+
+@pytest.mark.parametrize("G,Q,k", [(24736, 700, 5), (131, 40, 8), (128, 3, 5), (5, 9, 8), (1000, 260, 3)])
+def test_fused_top_k_equals_the_composite_on_materialised_scores(G, Q, k):
+    """txe_score_topk_block + txe_topk_merge (infer.py:96-106, test_fast.py:121-131 without the score matrix) against
+    scoring.topk_parents -- Python's stable sort -- on the scores txe_score_block materialises with the same kernel: the MAG-CS
+    candidate count (194 column tiles, a ragged last one), fewer candidates than one tile / than k, duplicated candidate rows (exact
+    ties across tiles: candidate order), NaN and +-inf scores, both directions, a candidate shard offset, and the merge of per-shard
+    lists against the unsharded selection"""
+    from taxoexpan_amd import model_zoo as mz, ops
+    from taxoexpan_amd.scoring import topk_parents, topk_parents_fused
+    dev = _dev()
+    gen = torch.Generator().manual_seed(G + Q)
+    l, r = 500, 250
+    hg = torch.randn(G, l, generator=gen) * 0.3
+    hg[G // 2:] = hg[:G - G // 2]                                  # every candidate row twice: exact ties in different tiles
+    if G > 200:
+        hg[7] = float("nan")                                       # a NaN score ranks last
+        hg[11] *= 1e4                                              # +-inf after exp / huge values
+    queries = torch.nn.functional.normalize(torch.randn(Q, r, generator=gen), dim=1)
+    ids = torch.arange(G, device=dev) * 3 + 1
+    for kind in ("LBM", "BIM"):
+        torch.manual_seed(5)
+        match = getattr(mz, kind)(l, r).to(dev)
+        with torch.no_grad():
+            U = ops.bilinear_project(hg.to(dev), match.W.weight)
+            S = ops.score_block(queries.to(dev), U, match.apply_exp)
+            for larger in (True, False):
+                want = topk_parents(S, ids, k, larger)
+                got = topk_parents_fused(match, hg.to(dev), queries.to(dev), ids, k, larger)
+                assert got.shape == want.shape == (Q, min(k, G)) and torch.equal(got, want), (kind, larger)
+                if G >= 16:                                        # two "shards" merged = the unsharded selection
+                    h = G // 3
+                    parts = []
+                    for lo, hi in ((0, h), (h, G)):
+                        Us = ops.bilinear_project(hg[lo:hi].to(dev), match.W.weight)
+                        parts.append(ops.score_topk_block(queries.to(dev), Us, match.apply_exp, min(k, hi - lo), larger, idx_base=lo))
+                    kk = min(k, h)
+                    cat_i = torch.cat([p[0][:, :kk] for p in parts], 1)
+                    cat_k = torch.cat([p[1][:, :kk] for p in parts], 1)
+                    idx, _key = ops.topk_merge(cat_k, cat_i, kk)
+                    assert torch.equal(ids[idx.long()], topk_parents(S, ids, kk, larger)), (kind, larger, "shards")

@@ -620,7 +620,7 @@ def test_full_size_properties_mag_cs_batch():
         out, alpha = _empty((N, H * D), ft_), _empty((E, H), ft_)
         _lib.call("txe_gat_aggregate_fwd", csr.rowptr_in.data_ptr(), csr.col_src.data_ptr(), N, ft_.data_ptr(), H * D, a.data_ptr(),
                   a.data_ptr() + 4 * H, 2 * H, H, D, 0.2, 0.0, 0, 0, 1.0, out.data_ptr(), H * D, alpha.data_ptr(), None, 0, None, 0.0, None,
-                  _lib.stream_ptr())
+                  0, _lib.stream_ptr())
         return out, alpha
     out1, alpha1 = agg(ft)
     out2, alpha2 = agg(ft)
@@ -1522,7 +1522,7 @@ def test_table_rows_formed_inside_the_sweep_equal_materialised_rows(H, D, with_n
                       _lib.stream_ptr())
             _lib.call("txe_gat_aggregate_fwd", rin.data_ptr(), col.data_ptr(), N, Y.data_ptr(), Fp, Y.data_ptr() + 4 * F,
                       Y.data_ptr() + 4 * (F + H), Fp, H, D, 0.2, 0.0, 0, 1, 0.1, out.data_ptr(), ld_out, None, nx[0], nx[1], None, 0.0,
-                      a12.data_ptr() if with_nx else None, _lib.stream_ptr())
+                      a12.data_ptr() if with_nx else None, 0, _lib.stream_ptr())
         torch.cuda.synchronize()
         outs.append((out.cpu(), a12.cpu()))
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])

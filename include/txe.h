@@ -244,7 +244,8 @@ int txe_score_positives(const float* Q, long long ld_q, int nq, const float* Up,
 /* ---- best-k parents of the scoring loop: infer.py:96-106 / test_fast.py:121-131 (`sorted(enumerate(scores), key=...)[:5]`) --------
  * Fused scoring + selection of one query block: no [nq x G] score block is materialised.  Every 128 x 128 tile of the score GEMM
  * (the kernel and k order of txe_score_block: bit-identical scores) leaves each row's k best columns in part_key / part_idx
- * [nq][txe_score_topk_tiles(G)][k] (caller-provided scratch); txe_topk_merge picks each query's best k: out_idx [nq][k] candidate rows
+ * [nq][txe_score_topk_tiles(G)][k] (caller-provided scratch; floor_ws [nq] ints as well: every row's rising selection floor -- a tile
+ * skips values below the best k-th key another tile of the row has already secured); txe_topk_merge picks each query's best k: out_idx [nq][k] candidate rows
  * + idx_base (the first row of a candidate shard), best first, -1 where a row has fewer than k candidates; out_key [nq][k] (may be
  * NULL) = the scores, negated when smaller is better.  Order = Python's stable sort: better score first, equal scores by ascending
  * candidate row; NaN ranks last.  1 <= k <= 8.
@@ -252,8 +253,8 @@ int txe_score_positives(const float* Q, long long ld_q, int nq, const float* Up,
  * lists of a candidate-sharded loop. */
 int txe_score_topk_tiles(int G);
 int txe_score_topk_block(const float* Q, long long ld_q, int nq, const float* U, long long ld_u, int G, int r, int apply_exp,
-                         int larger_is_better, int k, int idx_base, float* part_key, int* part_idx, int* out_idx, float* out_key,
-                         void* stream);
+                         int larger_is_better, int k, int idx_base, float* part_key, int* part_idx, int* floor_ws, int* out_idx,
+                         float* out_key, void* stream);
 int txe_topk_merge(const float* keys, const int* idx, int nq, long long cnt, int k, int idx_base, int* out_idx, float* out_key,
                    void* stream);
 

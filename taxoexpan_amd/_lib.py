@@ -59,7 +59,7 @@ SIGNATURES = {
     "txe_bilinear_runs_bwd": (I, [P, L, P, L, P, I, I, I, I, I, P, P, P, P, L, P, P, SZ, P]),
     "txe_rows_find_runs": (I, [P, L, I, I, P, P, P, P]),
     "txe_score_topk_tiles": (I, [I]),
-    "txe_score_topk_block": (I, [P, L, I, P, L, I, I, I, I, I, I, P, P, P, P, P]),
+    "txe_score_topk_block": (I, [P, L, I, P, L, I, I, I, I, I, I, P, P, P, P, P, P]),
     "txe_topk_merge": (I, [P, P, I, L, I, I, P, P, P]),
     "txe_bilinear_stacked_fwd": (I, [P, L, P, L, P, P, I, I, I, P, I, P, P, P]),
     "txe_bilinear_stacked_bwd_ws_bytes": (SZ, [I, I, I]),

@@ -129,6 +129,9 @@ __device__ __forceinline__ void topk_insert(float* bk, int* bi, float key, int i
         bk[t] = up ? k0 : bk[t];     bi[t] = up ? i0 : bi[t];
     }
 }
+// float keys as ints of the same order (for atomicMax): non-negative floats keep their bits, negative ones flip their magnitude
+__device__ __forceinline__ int topk_ord(float x) { const int i = __float_as_int(x); return i ^ ((i >> 31) & 0x7fffffff); }
+__device__ __forceinline__ float topk_unord(int i) { return __int_as_float(i ^ ((i >> 31) & 0x7fffffff)); }
 __device__ __forceinline__ float topk_key_of(float x, bool larger) {
     const float k = larger ? x : -x;
     return (k != k) ? -INFINITY : k;                 // NaN compares false with everything: it ranks last

@@ -99,6 +99,7 @@ struct Epi {
     int topk_k;
     float* topk_key;
     int* topk_idx;
+    int* topk_floor;           // [M] ordered-int keys (topk_ord): a lower bound of each row's final k-th best key, raised by every tile
     int force_bn128;           // 1: 128-wide column tiles whatever the shape (the top-k scratch is laid out by them)
     const int* cnt_off;
     const float* cnt_thr;
@@ -122,7 +123,7 @@ static inline Epi epi_plain(float* c, long long ldc, int cols) {
     e.mask = reinterpret_cast<const unsigned*>(c); e.mask_ld = 0; e.mask_col0 = 0; e.mask_on = 0; e.drop_scale = 1.f;
     e.apply_exp = 0; e.split_stride = 0;
     e.cnt_mode = 0; e.cnt_off = nullptr; e.cnt_thr = nullptr; e.cnt_out = nullptr;
-    e.topk_k = 0; e.topk_key = nullptr; e.topk_idx = nullptr; e.force_bn128 = 0;
+    e.topk_k = 0; e.topk_key = nullptr; e.topk_idx = nullptr; e.topk_floor = nullptr; e.force_bn128 = 0;
     e.alg_flops = 0.0; e.route = 0;
     e.plain_k_order = 0;
     return e;
@@ -672,6 +673,12 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_kernel(VMat A, VMat B, c
         float bk[TOPK_MAX];
         int bi[TOPK_MAX];
         topk_init(bk, bi);
+        // the row's floor: the largest k-th best key any tile of this row has published so far -- a lower bound of the row's FINAL k-th
+        // best key, so a value strictly below it can never be selected and is skipped.  After the first round of tiles almost nothing
+        // passes, and the (divergent) insert branch is rarely taken by any lane of a wave.  A stale read (another XCD's L2) is only a
+        // lower floor: the selection is exact and deterministic whatever the timing; only the work saved varies.
+        const int mf = (m < M) ? m : 0;
+        const float floor_key = topk_unord(__hip_atomic_load(E.topk_floor + mf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
 #pragma unroll 4
         for (int j = 0; j < HW / 4; ++j) {
             const float4 t4 = *reinterpret_cast<const float4*>(Cs + row * CLD + half * HW + 4 * j);
@@ -680,7 +687,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_kernel(VMat A, VMat B, c
             for (int q = 0; q < 4; ++q) {
                 const int n = nb + 4 * j + q;
                 const float key = topk_key_of(E.apply_exp ? __expf(v4[q]) : v4[q], larger);
-                if (n < N && topk_better(key, n, bk[TOPK_MAX - 1], bi[TOPK_MAX - 1])) topk_insert(bk, bi, key, n);
+                if (n < N && !(key < floor_key) && topk_better(key, n, bk[TOPK_MAX - 1], bi[TOPK_MAX - 1])) topk_insert(bk, bi, key, n);
             }
         }
         // the odd thread's list goes to the even one (all lanes shuffle; only the even thread's merge is kept)
@@ -694,9 +701,13 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_kernel(VMat A, VMat B, c
         }
         if (half == 0 && m < M) {
             const long long o = ((long long)m * nbn + tn) * E.topk_k;
+            float kth = -INFINITY;
+            int kth_i = 0x7fffffff;
 #pragma unroll
             for (int t = 0; t < TOPK_MAX; ++t)
-                if (t < E.topk_k) { E.topk_key[o + t] = bk[t]; E.topk_idx[o + t] = bi[t]; }
+                if (t < E.topk_k) { E.topk_key[o + t] = bk[t]; E.topk_idx[o + t] = bi[t]; kth = bk[t]; kth_i = bi[t]; }
+            // this tile holds k real entries at or above kth: the row's final k-th best key cannot be lower
+            if (kth_i != 0x7fffffff && kth > floor_key) atomicMax(E.topk_floor + m, topk_ord(kth));
         }
         return;
     }

@@ -702,19 +702,31 @@ int txe_score_count_block(const float* Q, long long ld_q, int nq, const float* U
 // (+ idx_base: the first row of a candidate shard), out_key [nq][k] their keys (score, negated when smaller is better; may be NULL).
 // The same MFMA kernel and k order as txe_score_block: the scores behind the selection are bit-identical to the materialised ones.
 // Ties in Python's stable order (ascending candidate row), NaN last.  1 <= k <= 8; G >= 1.
+// floor_ws [nq] ints: scratch (the rows' rising selection floors, initialised here).
 int txe_score_topk_tiles(int G) { return (G + 127) / 128; }
+}  // extern "C"
+namespace txe {
+__global__ void topk_floor_init_kernel(int* __restrict__ f, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) f[i] = topk_ord(-INFINITY);
+}
+}  // namespace txe
+extern "C" {
 
 int txe_score_topk_block(const float* Q, long long ld_q, int nq, const float* U, long long ld_u, int G, int r, int apply_exp,
-                         int larger_is_better, int k, int idx_base, float* part_key, int* part_idx, int* out_idx, float* out_key,
-                         void* stream) {
-    if (nq < 0 || G < 1 || r < 1 || ld_u < r || k < 1 || k > TOPK_MAX || !Q || !U || !part_key || !part_idx || !out_idx) return TXE_ERR_ARG;
+                         int larger_is_better, int k, int idx_base, float* part_key, int* part_idx, int* floor_ws, int* out_idx,
+                         float* out_key, void* stream) {
+    if (nq < 0 || G < 1 || r < 1 || ld_u < r || k < 1 || k > TOPK_MAX || !Q || !U || !part_key || !part_idx || !floor_ws || !out_idx)
+        return TXE_ERR_ARG;
     if (nq == 0) return TXE_OK;
+    hipLaunchKernelGGL(topk_floor_init_kernel, dim3((nq + 255) / 256), dim3(256), 0, (hipStream_t)stream, floor_ws, nq);
+    TXE_CHECK_LAUNCH();
     VMat A = vmat_plain(Q, ld_q, nq, r);
     VMat B = vmat_plain(U, ld_u, G, r);
     Epi E = epi_plain(part_key, 0, G);                              // c is never written in top-k mode
     E.apply_exp = apply_exp;
     E.cnt_mode = larger_is_better ? 4 : 5;
-    E.topk_k = k; E.topk_key = part_key; E.topk_idx = part_idx;
+    E.topk_k = k; E.topk_key = part_key; E.topk_idx = part_idx; E.topk_floor = floor_ws;
     E.force_bn128 = 1;                                              // (the scratch layout counts 128-wide column tiles)
     int rc = gemm_nt(A, B, E, nq, G, r, 1, (hipStream_t)stream);
     if (rc) return rc;

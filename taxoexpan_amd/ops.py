@@ -1397,10 +1397,11 @@ def score_topk_block(Q, U, apply_exp, k, larger_is_better=True, idx_base=0, q_pa
         nt = call("txe_score_topk_tiles", G)
         need = nq * nt * k
         sc = scratch if scratch is not None else {}
-        if sc.get("n", 0) < need or sc["key"].device != Q.device:
+        if sc.get("n", 0) < need or sc.get("nq", 0) < nq or sc["key"].device != Q.device:
             sc["key"], sc["idx"], sc["n"] = _empty((need,), Q), torch.empty(need, dtype=torch.int32, device=Q.device), need
+            sc["floor"], sc["nq"] = torch.empty(nq, dtype=torch.int32, device=Q.device), nq
         call("txe_score_topk_block", ptr(Q), ldq, nq, ptr(U), ldu, G, r, int(apply_exp), int(larger_is_better), int(k), int(idx_base),
-             ptr(sc["key"]), ptr(sc["idx"]), ptr(idx), ptr(key), _lib.stream_ptr())
+             ptr(sc["key"]), ptr(sc["idx"]), ptr(sc["floor"]), ptr(idx), ptr(key), _lib.stream_ptr())
     return idx, key
 
 

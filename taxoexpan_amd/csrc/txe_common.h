@@ -132,6 +132,12 @@ __device__ __forceinline__ void topk_insert(float* bk, int* bi, float key, int i
 // float keys as ints of the same order (for atomicMax): non-negative floats keep their bits, negative ones flip their magnitude
 __device__ __forceinline__ int topk_ord(float x) { const int i = __float_as_int(x); return i ^ ((i >> 31) & 0x7fffffff); }
 __device__ __forceinline__ float topk_unord(int i) { return __int_as_float(i ^ ((i >> 31) & 0x7fffffff)); }
+// entry k-1 of a list (k uniform, 1 <= k <= TOPK_MAX): the current k-th best -- what a candidate has to beat when only k entries count
+__device__ __forceinline__ void topk_kth(const float* bk, const int* bi, int k, float& wk, int& wi) {
+    wk = bk[0]; wi = bi[0];
+#pragma unroll
+    for (int t = 1; t < TOPK_MAX; ++t) { wk = (t < k) ? bk[t] : wk; wi = (t < k) ? bi[t] : wi; }
+}
 __device__ __forceinline__ float topk_key_of(float x, bool larger) {
     const float k = larger ? x : -x;
     return (k != k) ? -INFINITY : k;                 // NaN compares false with everything: it ranks last

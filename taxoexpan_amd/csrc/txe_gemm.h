@@ -679,6 +679,9 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_kernel(VMat A, VMat B, c
         // lower floor: the selection is exact and deterministic whatever the timing; only the work saved varies.
         const int mf = (m < M) ? m : 0;
         const float floor_key = topk_unord(__hip_atomic_load(E.topk_floor + mf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        const int kk = E.topk_k;
+        float wk = -INFINITY;                            // the list's current k-th best: what a candidate has to beat
+        int wi = 0x7fffffff;
 #pragma unroll 4
         for (int j = 0; j < HW / 4; ++j) {
             const float4 t4 = *reinterpret_cast<const float4*>(Cs + row * CLD + half * HW + 4 * j);
@@ -687,7 +690,10 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_kernel(VMat A, VMat B, c
             for (int q = 0; q < 4; ++q) {
                 const int n = nb + 4 * j + q;
                 const float key = topk_key_of(E.apply_exp ? __expf(v4[q]) : v4[q], larger);
-                if (n < N && !(key < floor_key) && topk_better(key, n, bk[TOPK_MAX - 1], bi[TOPK_MAX - 1])) topk_insert(bk, bi, key, n);
+                if (n < N && !(key < floor_key) && topk_better(key, n, wk, wi)) {
+                    topk_insert(bk, bi, key, n);
+                    topk_kth(bk, bi, kk, wk, wi);
+                }
             }
         }
         // the odd thread's list goes to the even one (all lanes shuffle; only the even thread's merge is kept)
@@ -697,7 +703,10 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_kernel(VMat A, VMat B, c
             const int oi = __shfl_xor(bi[t], 1, 64);
             // (the partner's list is sorted: once an entry fails, the rest would too -- the insert is predicated, not skipped, to keep
             //  the shuffles of the next round uniform)
-            if (half == 0 && topk_better(ok, oi, bk[TOPK_MAX - 1], bi[TOPK_MAX - 1])) topk_insert(bk, bi, ok, oi);
+            if (half == 0 && t < kk && topk_better(ok, oi, wk, wi)) {
+                topk_insert(bk, bi, ok, oi);
+                topk_kth(bk, bi, kk, wk, wi);
+            }
         }
         if (half == 0 && m < M) {
             const long long o = ((long long)m * nbn + tn) * E.topk_k;

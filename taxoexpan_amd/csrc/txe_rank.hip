@@ -124,6 +124,8 @@ __global__ __launch_bounds__(256) void topk_merge_kernel(const float* __restrict
     float bk[TOPK_MAX];
     int bi[TOPK_MAX];
     topk_init(bk, bi);
+    float wk = -INFINITY;                                        // the lane's current k-th best
+    int wi = 0x7fffffff;
     for (long long e0 = 0; e0 < cnt; e0 += 4 * 64) {            // four independent loads in flight per lane
         float kv[4];
         int iv[4];
@@ -135,7 +137,10 @@ __global__ __launch_bounds__(256) void topk_merge_kernel(const float* __restrict
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u)
-            if (iv[u] != 0x7fffffff && topk_better(kv[u], iv[u], bk[TOPK_MAX - 1], bi[TOPK_MAX - 1])) topk_insert(bk, bi, kv[u], iv[u]);
+            if (iv[u] != 0x7fffffff && topk_better(kv[u], iv[u], wk, wi)) {
+                topk_insert(bk, bi, kv[u], iv[u]);
+                topk_kth(bk, bi, k, wk, wi);
+            }
     }
     for (int t = 0; t < k; ++t) {
         float wk = bk[0];

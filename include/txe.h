@@ -87,9 +87,16 @@ int txe_gat_dense_fwd(const float* X, int n_nodes, int Kh, int Pd, const float* 
 int txe_gat_dense_bwd(const float* X, int n_nodes, int Kh, int Pd, const int* pos, int vocab, const float* Wp, const float* W,
                       const float* attn_l, const float* attn_r, int H, int D, float feat_drop_p, const unsigned* mask, const float* d_Y,
                       int need_dh, int act_on, float act_slope, float* d_X, float* dW, float* d_attn_l, float* d_attn_r, float* dP,
-                      int x_dropped, int phases, void* ws, size_t ws_bytes, void* stream);
+                      int x_dropped, int phases, void* chain, void* ws, size_t ws_bytes, void* stream);
 /* phases: 7 = all of it; 1 | 2 | 4 = d_X | the weight-gradient product (split-K partial slices) | the reductions that finish dW,
- * d_attn, dP -- 1 and 2 are independent, 4 needs both. */
+ * d_attn, dP -- 1 and 2 are independent, 4 needs both.
+ * chain (may be NULL): TXE_TAIL_CHAIN_BYTES of HOST memory, zero-filled = empty, owned by the caller for one backward pass.  The last
+ * reduction launch of a layer ("phase B": dW / d_attn from the split-K slices, dP, d_pw) only finishes parameter gradients, so a
+ * caller may DEFER it with phases | 64: the job is described in the chain instead of launched (its workspace and outputs must stay
+ * alive), and the next call WITHOUT 64 that gets the chain -- the bottom layer's -- launches its own phase B and every deferred one
+ * together.  txe_gat_tail_flush launches what a chain still holds. */
+#define TXE_TAIL_CHAIN_BYTES 1024
+int txe_gat_tail_flush(void* chain, void* stream);
 int txe_zero_cols(float* x, long long ld, int n_rows, int c0, int c1, void* stream);
 /* 1 when txe_gat_dense_bwd forms d_X with the streaming position-column kernel (a first PGAT layer: need_dh == 0, the columns behind
  * Kh fit 64 -- model_zoo.py:214-215): phase 1 is then ONE pass over d_Y at HBM speed that also leaves dP's per-class partial sums,
@@ -303,7 +310,8 @@ int txe_gat_collapse_bwd(const int* rowptr_in, const int* col_src, const int* ro
  * Dp, Hp*Dp == Kh), its attention alpha_p [E][Hp] (destination-CSR order), slope / dropout / seed, the slope of the activation between
  * the layers (1 = none).  Output instead of d_X: d_Yp [N][ld_dyp] = [d_ft | d_a1 | d_a2 | n_pad zeros]; dz_p [E][Hp] scratch.
  * phases: 15 = all of it; 1 | 2 | 4 | 8 = dZ GEMM | dW GEMM partials (independent of 1 and 4: a second stream may run it under the sweeps)
- * | sweeps + first reduction stage | final reductions -- separate calls share the workspace.
+ * | sweeps + first reduction stage | final reductions -- separate calls share the workspace; 8 | 64 with a chain defers the final
+ * reductions (see txe_gat_dense_bwd).
  * txe_gat_fused_bwd_supported: 1 if the shape qualifies (Hp in {1,2,4}, Hp*Dp % 16 == 0, <= 128 columns behind the feature part). */
 int txe_gat_fused_bwd_supported(int Kh, int Pd, int Hp, int Dp);
 size_t txe_gat_collapse_bwd_fused_ws_bytes(int n_nodes, int n_edges, int G, int Kh, int Pd, int D, int vocab, int Hp);
@@ -316,7 +324,7 @@ int txe_gat_collapse_bwd_fused(const int* rowptr_in, const int* col_src, const i
                                float act_slope, const float* Yp, long long ld_yp, int Hp, int Dp, float attn_slope_p,
                                float attn_drop_p_p, unsigned long long seed_p, const float* alpha_p, float* d_Yp, long long ld_dyp,
                                int n_pad, float* dz_p, float* dW, float* d_attn_l, float* d_attn_r, float* dP, float* d_pw, int phases,
-                               void* ws, size_t ws_bytes, void* stream);
+                               void* chain, void* ws, size_t ws_bytes, void* stream);
 
 /* ---- output GCNLayer folded behind MeanReadout / WeightedMeanReadout: model_zoo.py:35-47,139-167,227-242.
  * hg[g] = (sum_{u in g} c_u Xd[u]) W + b with c_u = norm_u sum_{v: u->v} w_v norm_v / S_g (graph constants).  X / Wp / mask as for

@@ -5,6 +5,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libtxe.so")
+TAIL_CHAIN_BYTES = 1024        # TXE_TAIL_CHAIN_BYTES of include/txe.h
 
 P, I, L, F, D, U64, SZ = C.c_void_p, C.c_int, C.c_longlong, C.c_float, C.c_double, C.c_ulonglong, C.c_size_t
 
@@ -21,7 +22,8 @@ SIGNATURES = {
     "txe_gather_add_rows": (I, [P, L, P, P, L, P, L, I, P, L, P]),
     "txe_gat_dense_ws_bytes": (SZ, [I, I, I, I, I, I]),
     "txe_gat_dense_fwd": (I, [P, I, I, I, P, I, I, F, P, P, P, SZ, P]),
-    "txe_gat_dense_bwd": (I, [P, I, I, I, P, I, P, P, P, P, I, I, F, P, P, I, I, F, P, P, P, P, P, I, I, P, SZ, P]),
+    "txe_gat_dense_bwd": (I, [P, I, I, I, P, I, P, P, P, P, I, I, F, P, P, I, I, F, P, P, P, P, P, I, I, P, P, SZ, P]),
+    "txe_gat_tail_flush": (I, [P, P]),
     "txe_zero_cols": (I, [P, L, I, I, I, P]),
     "txe_gat_dx_streams": (I, [I, I, I]),
     "txe_gat_aggregate_fwd": (I, [P, P, I, P, L, P, P, I, I, I, F, F, U64, I, F, P, L, P, P, I, P, F, P, I, P]),
@@ -83,7 +85,7 @@ SIGNATURES = {
     "txe_gat_fused_bwd_supported": (I, [I, I, I, I]),
     "txe_gat_collapse_bwd_fused_ws_bytes": (SZ, [I, I, I, I, I, I, I, I]),
     "txe_gat_collapse_bwd_fused": (I, [P, P, P, P, P, P, I, I, I, P, I, I, P, I, P, P, P, P, I, F, P, F, F, U64, P, P, P, P, P, P, P, P, L, P, L,
-                                       F, P, L, I, I, F, F, U64, P, P, L, I, P, P, P, P, P, P, I, P, SZ, P]),
+                                       F, P, L, I, I, F, F, U64, P, P, L, I, P, P, P, P, P, P, I, P, P, SZ, P]),
     "txe_gcn_collapse_ws_bytes": (SZ, [I, I, I, I, I, I]),
     "txe_gcn_collapse_fwd": (I, [P, P, P, I, I, P, I, I, P, I, P, F, P, P, P, P, P, P, P, P, P, L, P, SZ, P]),
     "txe_gcn_collapse_bwd": (I, [P, P, P, I, I, P, I, I, P, I, P, I, F, P, P, P, P, P, P, P, P, L, I, F, P, P, P, P, P, P, SZ, P]),

@@ -8,6 +8,7 @@
 #define TXE_ERR_ARG -1
 #define TXE_ERR_LAUNCH -2
 #define TXE_ERR_WORKSPACE -3
+#define TXE_TAIL_CHAIN_BYTES 1024     /* include/txe.h */
 
 #define TXE_WAVE 64
 #define TXE_NUM_XCD 8

@@ -205,12 +205,42 @@ struct TailB {
     UnfoldArgs u;
     Seg2Args s2a, s2b;
 };
-__global__ __launch_bounds__(256) void gat_bwd_reduce_b_kernel(const TailB a) {
-    int b = blockIdx.x;
+__device__ __forceinline__ void tail_b_job(int b, const TailB& a) {
     if (b < a.nb_u) { unfold_job(b, a.u); return; }
     b -= a.nb_u;
     if (b < a.nb_2a) { segsum2_job(b, a.s2a); return; }
     segsum2_job(b - a.nb_2a, a.s2b);
+}
+__global__ __launch_bounds__(256) void gat_bwd_reduce_b_kernel(const TailB a) { tail_b_job(blockIdx.x, a); }
+
+// Phase B of SEVERAL layers in one launch.  A layer's phase B only finishes parameter gradients (nothing downstream in the backward
+// pass reads them), so a caller may DEFER it (phases | 64) into a host-side chain and let the last layer's call launch them all:
+// one ~17 us dispatch per stack instead of one per layer.
+constexpr int TAIL_CHAIN_MAX = 3;                       // deferred layers a chain holds (a fourth deferral flushes)
+struct TailChain { int n; int pad; TailB tb[TAIL_CHAIN_MAX]; };
+struct TailMulti { int n; int nb_end[TAIL_CHAIN_MAX + 1]; TailB tb[TAIL_CHAIN_MAX + 1]; };
+__global__ __launch_bounds__(256) void gat_bwd_reduce_b_multi_kernel(const TailMulti m) {
+    int b = blockIdx.x, i = 0;
+    while (i + 1 < m.n && b >= m.nb_end[i]) ++i;                    // (block-uniform)
+    tail_b_job(b - ((i > 0) ? m.nb_end[i - 1] : 0), m.tb[i]);
+}
+static inline int tail_b_blocks(const TailB& t) { return t.nb_u + t.nb_2a + t.nb_2b; }
+// launch `own` (if given) together with everything the chain holds, or -- defer -- append `own` to the chain
+static int tail_b_submit(const TailB* own, void* chain_, bool defer, hipStream_t s) {
+    TailChain* c = reinterpret_cast<TailChain*>(chain_);
+    if (c && (c->n < 0 || c->n > TAIL_CHAIN_MAX)) return TXE_ERR_ARG;
+    if (defer && c && own && c->n < TAIL_CHAIN_MAX) { c->tb[c->n++] = *own; return TXE_OK; }
+    TailMulti m;
+    memset(&m, 0, sizeof(m));
+    int total = 0;
+    auto add = [&](const TailB& t) { if (tail_b_blocks(t) > 0) { m.tb[m.n] = t; total += tail_b_blocks(t); m.nb_end[m.n++] = total; } };
+    if (own) add(*own);
+    if (c) { for (int i = 0; i < c->n; ++i) add(c->tb[i]); c->n = 0; }
+    if (m.n == 0) return TXE_OK;
+    if (m.n == 1) hipLaunchKernelGGL(gat_bwd_reduce_b_kernel, dim3(total), dim3(256), 0, s, m.tb[0]);
+    else hipLaunchKernelGGL(gat_bwd_reduce_b_multi_kernel, dim3(total), dim3(256), 0, s, m);
+    TXE_CHECK_LAUNCH();
+    return TXE_OK;
 }
 
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
@@ -729,9 +759,10 @@ int txe_gat_dense_fwd(const float* X, int n_nodes, int Kh, int Pd, const float* 
 int txe_gat_dense_bwd(const float* X, int n_nodes, int Kh, int Pd, const int* pos, int vocab, const float* Wp, const float* W,
                       const float* attn_l, const float* attn_r, int H, int D, float feat_drop_p, const unsigned* mask, const float* d_Y,
                       int need_dh, int act_on, float act_slope, float* d_X, float* dW, float* d_attn_l, float* d_attn_r, float* dP,
-                      int x_dropped, int phases, void* ws, size_t ws_bytes, void* stream) {
+                      int x_dropped, int phases, void* chain, void* ws, size_t ws_bytes, void* stream) {
     if (n_nodes < 0 || Kh < 1 || Pd < 0 || H < 1 || D < 1 || !X || !Wp || !W || !attn_l || !attn_r || !d_Y || !dW || !d_attn_l || !d_attn_r || !ws)
         return TXE_ERR_ARG;
+    static_assert(sizeof(TailChain) <= TXE_TAIL_CHAIN_BYTES, "txe.h: TXE_TAIL_CHAIN_BYTES");
     if ((need_dh || Pd > 0) && !d_X) return TXE_ERR_ARG;
     if (Pd > 0 && (!pos || !dP || vocab < 1 || vocab > MAX_VOCAB)) return TXE_ERR_ARG;
     if (feat_drop_p < 0.f || feat_drop_p >= 1.f) return TXE_ERR_ARG;
@@ -803,9 +834,13 @@ int txe_gat_dense_bwd(const float* X, int n_nodes, int Kh, int Pd, const int* po
                       d_attn_l, d_attn_r};
     tb.nb_2a = Pd > 0 ? (vocab * Pd + 63) / 64 : 0;
     tb.s2a = Seg2Args{p.ppart, nseg, vocab * Pd, dP};
-    hipLaunchKernelGGL(gat_bwd_reduce_b_kernel, dim3(tb.nb_u + tb.nb_2a), dim3(256), 0, s, tb);
-    TXE_CHECK_LAUNCH();
-    return TXE_OK;
+    return tail_b_submit(&tb, chain, (phases & 64) != 0, s);
+}
+
+// launches whatever a chain of deferred phase-B jobs still holds (a stack whose last call deferred too); chain == NULL: nothing
+int txe_gat_tail_flush(void* chain, void* stream) {
+    if (!chain) return TXE_OK;
+    return tail_b_submit(nullptr, chain, false, (hipStream_t)stream);
 }
 
 // zero columns [c0, c1) of a row-major fp32 matrix (padding columns of d_Y)
@@ -2070,7 +2105,7 @@ int txe_gat_collapse_bwd_fused(const int* rowptr_in, const int* col_src, const i
                                float act_slope, const float* Yp, long long ld_yp, int Hp, int Dp, float attn_slope_p,
                                float attn_drop_p_p, unsigned long long seed_p, const float* alpha_p, float* d_Yp, long long ld_dyp,
                                int n_pad, float* dz_p, float* dW, float* d_attn_l, float* d_attn_r, float* dP, float* d_pw, int phases,
-                               void* ws, size_t ws_bytes, void* stream) {
+                               void* chain, void* ws, size_t ws_bytes, void* stream) {
     if (n_nodes < 0 || n_edges < 0 || G < 0 || Kh < 1 || Pd < 0 || D < 1 || !rowptr_in || !rowptr_out || !graph_off || !X || !Wp || !W ||
         !attn_l || !attn_r || !a12 || !alpha || !coef || !wsum || !gid || !Z || !hg || !d_hg || !dW || !d_attn_l || !d_attn_r || !ws ||
         !Yp || !alpha_p || !d_Yp || !dz_p || n_pad < 0)
@@ -2178,9 +2213,7 @@ int txe_gat_collapse_bwd_fused(const int* rowptr_in, const int* col_src, const i
     tb.s2a = Seg2Args{fw.ppart, nblk, vocab * Pd, dP};
     tb.nb_2b = pw ? (vocab + 63) / 64 : 0;
     tb.s2b = Seg2Args{p.ppart2, nseg, vocab, d_pw};
-    hipLaunchKernelGGL(gat_bwd_reduce_b_kernel, dim3(tb.nb_u + tb.nb_2a + tb.nb_2b), dim3(256), 0, s, tb);
-    TXE_CHECK_LAUNCH();
-    return TXE_OK;
+    return tail_b_submit(&tb, chain, (phases & 64) != 0, s);
 }
 
 }  // extern "C"

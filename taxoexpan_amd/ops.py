@@ -46,6 +46,7 @@ _NO_TABLE_SWEEP = False     # table rows materialised (txe_gather_add_rows) inst
 _NO_SIDE_STREAM = False     # everything on the caller's stream
 _NO_FUSED_BWD = False       # the folded layer's backward as the unfused chain (d_X' materialised)
 _NO_QUERY_RUNS = False      # stacked query rows always take the GEMM form of the bilinear match
+_NO_TAIL_CHAIN = False      # every layer's last reduction launch in place instead of chained into the bottom layer's
 _I32_MEMO = {}       # id(source tensor) -> (weakref, version, device, int32 copy): `pos` is converted once per batch, not once per module
 
 
@@ -441,8 +442,21 @@ def _gat_aggregate_bwd(csr, st, attn_p, attn_slope, d_pre, ld_dpre):
     return d_Y
 
 
-def _gat_dense_bwd(st, pos, vocab, feat_p, d_Y, need_dh, act_on, act_slope):
-    """projection backward of one layer from d_Y: (d_X or None, dW, d_attn_l, d_attn_r, dP)"""
+class _TailChain:
+    """the deferred phase-B reductions of a stack's backward pass (include/txe.h: txe_gat_dense_bwd `chain`): host memory the C entry
+    points fill, plus the workspaces / operands the deferred jobs read -- kept alive until the launch that runs them has been enqueued
+    (a buffer released earlier could be handed to a later allocation of the same stream and overwritten before that launch)"""
+
+    def __init__(self):
+        import ctypes
+        self.buf = ctypes.create_string_buffer(_lib.TAIL_CHAIN_BYTES)
+        self.ptr = ctypes.cast(self.buf, ctypes.c_void_p)
+        self.keep = []
+
+
+def _gat_dense_bwd(st, pos, vocab, feat_p, d_Y, need_dh, act_on, act_slope, chain=None, defer=False):
+    """projection backward of one layer from d_Y: (d_X or None, dW, d_attn_l, d_attn_r, dP).
+    chain / defer: see _TailChain (defer: this layer's last reduction launch is left to the bottom layer's)"""
     N = st.X.shape[0]
     dW, dal, dar = torch.empty_like(st.W), torch.empty_like(st.al), torch.empty_like(st.ar)
     dP = torch.empty_like(st.P) if st.P is not None else None
@@ -452,15 +466,17 @@ def _gat_dense_bwd(st, pos, vocab, feat_p, d_Y, need_dh, act_on, act_slope):
     def run(phases):
         call("txe_gat_dense_bwd", ptr(st.X), N, st.Kh, st.Pd, ptr(pos), vocab, ptr(st.Wp), ptr(st.W), ptr(st.al), ptr(st.ar), st.H, st.D, feat_p,
              ptr(st.mask), ptr(d_Y), int(need_dh), int(act_on), act_slope if act_slope else 1.0, ptr(d_X), ptr(dW), ptr(dal), ptr(dar),
-             ptr(dP), int(getattr(st, "x_dropped", False)), phases, ptr(ws), wsb, _lib.stream_ptr())
+             ptr(dP), int(getattr(st, "x_dropped", False)), phases, chain.ptr if chain is not None else None, ptr(ws), wsb, _lib.stream_ptr())
     # (a first PGAT layer's d_X -- position columns only -- is one HBM stream over d_Y, txe_dxpos.hip; every other d_X is a GEMM)
-    run(7)
+    run(7 | (64 if (defer and chain is not None) else 0))
+    if chain is not None:
+        chain.keep += [ws, d_Y, st]
     return d_X, dW, dal, dar, dP
 
 
-def _gat_layer_bwd(csr, st, pos, vocab, feat_p, attn_p, attn_slope, d_pre, ld_dpre, need_dh, act_on, act_slope):
+def _gat_layer_bwd(csr, st, pos, vocab, feat_p, attn_p, attn_slope, d_pre, ld_dpre, need_dh, act_on, act_slope, chain=None, defer=False):
     d_Y = _gat_aggregate_bwd(csr, st, attn_p, attn_slope, d_pre, ld_dpre)
-    return _gat_dense_bwd(st, pos, vocab, feat_p, d_Y, need_dh, act_on, act_slope)
+    return _gat_dense_bwd(st, pos, vocab, feat_p, d_Y, need_dh, act_on, act_slope, chain, defer)
 
 
 def _order(first, then):
@@ -485,7 +501,7 @@ def _fused_bwd_ok(csr, st, sp):
             and call("txe_gat_fused_bwd_supported", st.Kh, st.Pd, sp.H, sp.D) == 1)
 
 
-def _gat_collapse_bwd_fused(csr, st, sp, pos, rpos, pw, vocab, feat_p, attn_p, attn_slope, d_hg, act_slope):
+def _gat_collapse_bwd_fused(csr, st, sp, pos, rpos, pw, vocab, feat_p, attn_p, attn_slope, d_hg, act_slope, chain=None):
     """txe_gat_collapse_bwd_fused: the folded layer's parameter gradients AND the layer below's d_Y in one sweep (no d_X)"""
     N, G, E = st.X.shape[0], csr.n_graphs, csr.n_edges
     a12, alpha, coef, wsum, gid, Z, hg = st.cl
@@ -505,9 +521,12 @@ def _gat_collapse_bwd_fused(csr, st, sp, pos, rpos, pw, vocab, feat_p, attn_p, a
              ptr(st.al), ptr(st.ar), st.D, feat_p, ptr(st.mask), attn_slope, attn_p, st.seed + 1, ptr(pw), ptr(a12), ptr(alpha), ptr(coef),
              ptr(wsum), ptr(gid), ptr(Z), ptr(hg), st.D, ptr(d_hg), ld, act_slope if act_slope else 1.0, ptr(sp.Y), sp.Fp, sp.H, sp.D,
              attn_slope, attn_p, sp.seed + 1, ptr(sp.alpha), ptr(d_Yp), sp.Fp, sp.Fp - Fe, ptr(dz), ptr(dW), ptr(dal), ptr(dar), ptr(dP),
-             ptr(d_pw), phases, ptr(ws), wsb, _lib.stream_ptr())
+             ptr(d_pw), phases, chain.ptr if chain is not None else None, ptr(ws), wsb, _lib.stream_ptr())
+    last = 8 | (64 if chain is not None else 0)     # (with a chain the final reductions are left to the bottom layer's launch)
+    if chain is not None:
+        chain.keep += [ws, d_hg, st, sp]
     if _NO_SIDE_STREAM:
-        run(15)
+        run(7 | last)
     else:
         # the folded layer's weight-gradient GEMM (MFMA-bound, needs only d_hg and Z) runs on a second stream under the HBM-bound
         # sweeps: complementary resources, and nothing downstream waits for it before the final reduction
@@ -518,7 +537,7 @@ def _gat_collapse_bwd_fused(csr, st, sp, pos, rpos, pw, vocab, feat_p, attn_p, a
         run(1)
         run(4)
         _order(side, main)
-        run(8)
+        run(last)
     return d_Yp, dW, dal, dar, dP, d_pw
 
 
@@ -648,6 +667,9 @@ class GATStackFunction(torch.autograd.Function):
                 ld_dpre = d_pre.stride(0)
             d_X = None
             d_Y_ready = None                       # d_Y of layer l already produced by the fused sweep of layer l+1
+            # the layers' last reduction launches (parameter gradients only) are chained into the bottom layer's -- unless somebody
+            # wants every layer's gradients the moment its backward ends (the overlapped gradient all-reduce)
+            chain = _TailChain() if (_GRAD_READY is None and L > 1 and not _NO_TAIL_CHAIN) else None
             for l in range(L - 1, -1, -1):
                 st = states[l]
                 need_dh = (l > 0) or ctx.h_req
@@ -657,17 +679,17 @@ class GATStackFunction(torch.autograd.Function):
                     if l > 0 and _fused_bwd_ok(csr, st, states[l - 1]):
                         d_Y_ready, dW, dal, dar, dP, d_pw = _gat_collapse_bwd_fused(
                             csr, st, states[l - 1], pos if st.P is not None else None, ctx.rpos, ctx.pwf, cfg.vocab, cfg.feat_p, cfg.attn_p,
-                            cfg.attn_slope, d_res, cfg.act_slope if act_on else None)
+                            cfg.attn_slope, d_res, cfg.act_slope if act_on else None, chain)
                     else:
                         d_X, dW, dal, dar, dP, d_pw = _gat_collapse_bwd(csr, st, pos if st.P is not None else None, ctx.rpos, ctx.pwf, cfg.vocab,
                                                                         cfg.feat_p, cfg.attn_p, cfg.attn_slope, d_res, act_on, cfg.act_slope)
                 elif d_Y_ready is not None:
                     d_X, dW, dal, dar, dP = _gat_dense_bwd(st, pos if st.P is not None else None, cfg.vocab, cfg.feat_p, d_Y_ready, need_dh,
-                                                           act_on, cfg.act_slope)
+                                                           act_on, cfg.act_slope, chain, defer=l > 0)
                     d_Y_ready = None
                 else:
                     d_X, dW, dal, dar, dP = _gat_layer_bwd(csr, st, pos if st.P is not None else None, cfg.vocab, cfg.feat_p, cfg.attn_p,
-                                                           cfg.attn_slope, d_pre, ld_dpre, need_dh, act_on, cfg.act_slope)
+                                                           cfg.attn_slope, d_pre, ld_dpre, need_dh, act_on, cfg.act_slope, chain, defer=l > 0)
                 grads[4 * l:4 * l + 4] = [dW, dal, dar, dP]
                 if _GRAD_READY is not None:               # (tensors, ids of the parameters they are the gradients of)
                     last_c = collapse and l == L - 1
@@ -675,6 +697,9 @@ class GATStackFunction(torch.autograd.Function):
                 if l > 0 and d_Y_ready is None:
                     d_pre, ld_dpre = d_X, st.Kp            # its first H*D(l-1) columns are d(pre-activation out_{l-1})
             d_h = d_X[:, :states[0].Kh].contiguous() if ctx.h_req else None
+            if chain is not None:                  # (nothing left unless the bottom layer took a route without a phase B of its own)
+                call("txe_gat_tail_flush", chain.ptr, _lib.stream_ptr())
+                chain.keep = []
             if _GRAD_FLUSH is not None:
                 _GRAD_FLUSH()
         ctx.states = None

@@ -117,7 +117,7 @@ def test_training_mode_dropout_matches_oracle(name, drop, monkeypatch):
         np.testing.assert_allclose(p.grad.cpu().numpy(), P[k].grad.numpy(), rtol=2e-3, atol=2e-5, err_msg=k)
 
 
-@pytest.mark.parametrize("switch", ["_NO_SIDE_STREAM", "_NO_FUSED_BWD", "_NO_FUSED_LOGITS"])
+@pytest.mark.parametrize("switch", ["_NO_SIDE_STREAM", "_NO_FUSED_BWD", "_NO_FUSED_LOGITS", "_NO_TAIL_CHAIN"])
 def test_ab_switch_routes_give_the_same_training_step(switch, monkeypatch):
     """every route attribute of ops.py selects another ROUTE to the same numbers: a training step (dropout on, fixed seed) of the 2-layer
     PGAT case with the switch set against the default -- scores and every gradient (the per-layer preparation entry once left the

@@ -45,13 +45,16 @@ PEAK_HBM = 8.0e12             # spec; ~6.3e12 achievable
 
 
 def hbm_copy_ceiling(device, mb=1024):
-    """bytes/s (read + written) of a plain device copy of a buffer four times the Infinity Cache: what this box's HBM gives a streaming
-    kernel with a 1:1 read/write mix -- the practical ceiling beside the 8 TB/s spec the HBM-bound kernels are priced against"""
+    """bytes/s (read + written) of a device copy of a buffer four times the Infinity Cache: what this box's HBM gives a streaming kernel
+    with a 1:1 read/write mix -- the practical ceiling beside the 8 TB/s spec the HBM-bound kernels are priced against.  Returns
+    (libtxe's 16-byte copy kernel txe_copy_stream -- the guide's ~6.3 TB/s figure --, torch's Tensor.copy_ for comparison)."""
+    from taxoexpan_amd import _lib
     n = mb * 1024 * 1024 // 4
     x = torch.empty(n, dtype=torch.float32, device=device).normal_()
     y = torch.empty_like(x)
-    t = median_time(lambda: y.copy_(x), reps=5, inner=10, warm=2)
-    return 2.0 * 4.0 * n / t
+    t_lib = median_time(lambda: _lib.call("txe_copy_stream", x.data_ptr(), y.data_ptr(), 4 * n, _lib.stream_ptr()), reps=5, inner=10, warm=2)
+    t_torch = median_time(lambda: y.copy_(x), reps=5, inner=10, warm=2)
+    return 2.0 * 4.0 * n / t_lib, 2.0 * 4.0 * n / t_torch
 
 
 def median_time(fn, reps=5, inner=1, warm=1):
@@ -128,14 +131,14 @@ _RNG = {}
 SECOND_STREAM_TAG = " [second stream]"
 
 
-def train_step(model, opt, batch, target, world):
+def train_step(model, opt, batch, target, world, loss_fn=None):
     from taxoexpan_amd.loss import info_nce_loss
     from taxoexpan_amd.scoring import allreduce_gradients
     g = batch["g"]
     g.ndata["pos"] = batch["pos"]
     opt.zero_grad(set_to_none=True)
     pred = model(g, batch["x"], batch["qf"])                       # trainer.py:51
-    loss = info_nce_loss(pred.reshape(N_QUERIES, -1), target)     # trainer.py:52-56, loss.py:52-57 (one launch, gradient included)
+    loss = (loss_fn or info_nce_loss)(pred.reshape(N_QUERIES, -1), target)   # trainer.py:52-56, loss.py:52-57 (one launch, gradient included)
     if world > 1:      # the output layer's gradient bucket is all-reduced under the backward of the layer below, the rest afterwards
         from taxoexpan_amd.scoring import overlapped_gradient_allreduce
         with overlapped_gradient_allreduce(model=model) as ov:
@@ -286,6 +289,19 @@ def cpu_baseline(batch, state_dict, full_batch=None, hg=None, queries=None, n_sa
             p.grad = None
         s, _, _ = orc.taxoexpan_forward(P, graph, x, q, "PGAT", "WMR", "LBM", [4, 1], 1, masks)
         orc.info_nce_loss(s, n_sample_queries).backward()
+    # thread count: the fastest of {8, 16, 32, all} on one iteration each (the oracle's index_add / scatter kernels do not scale to
+    # 128 threads: round 3's all-threads run was slower than BASELINE.md's 8-core anchor) -- every leg below runs at that count
+    all_threads = torch.get_num_threads()
+    step()
+    sweep = {}
+    for nt in sorted({min(n, all_threads) for n in (8, 16, 32, all_threads)}):
+        torch.set_num_threads(nt)
+        t0 = time.perf_counter()
+        step()
+        sweep[nt] = time.perf_counter() - t0
+    best_nt = min(sweep, key=sweep.get)
+    torch.set_num_threads(best_nt)
+    out["thread_sweep_s_per_iter"] = {str(k): v for k, v in sweep.items()}
     dt, proto = cpu_median(step)
     out["step"] = dict(value=n_edges / dt, unit="egonet-edges/s", s_per_iter=dt,
                        sample=f"{n_g} of the 4096 egonets of training batch 0 ({n_nodes} nodes, {n_edges} edges), fwd+InfoNCE+bwd, {proto}")
@@ -324,7 +340,9 @@ def cpu_baseline(batch, state_dict, full_batch=None, hg=None, queries=None, n_sa
                               sample=f"{G} MAG-CS candidates: literal per-query loop (one query per iteration, {proto}); factored form on a "
                                      f"{qb.shape[0]}-query block incl. U = hg W ({proto2})")
     top = dict(out["step"])
-    top.update(cores=torch.get_num_threads(), kind="port", implementation="oracle/txe_oracle.py (torch CPU fp32)", **{k: v for k, v in out.items()})
+    top.update(cores=torch.get_num_threads(), host_threads_available=all_threads, kind="port",
+               implementation="oracle/txe_oracle.py (torch CPU fp32)", **{k: v for k, v in out.items()})
+    torch.set_num_threads(all_threads)
     return top
 
 
@@ -487,6 +505,21 @@ def variant_step(workload, tax, device, steps=10, reps=5):
                 timing=f"median of {reps} x {steps} steps",
                 roofline={k: dom[k] for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "avg_us", "work_per_launch")},
                 roofline_top5=[{k: r[k] for k in ("kernel", "bound", "frac", "avg_us", "launches", "total_us")} for r in roof[:5]])
+
+
+def large_batch_step(tax, device, factor=8):
+    """SURVEY 8d's steady-state point: the BASELINE configs[1] step on `factor` x 4,096 egonets per step (128 x factor queries x 32) -- the
+    fixed per-launch costs of the ~30 launches are amortised, the kernels run near their large-batch rates"""
+    global N_QUERIES
+    base = N_QUERIES
+    try:
+        N_QUERIES = base * factor
+        r = variant_step("pgat", tax, device, steps=5, reps=5)
+        r["workload"] = WORKLOAD_TEXT["pgat"] + f"{N_QUERIES} queries x 32 = {N_QUERIES * 32} egonets per step, fwd + InfoNCE + bwd + Adam(amsgrad), dropout 0.1"
+        r["ms_per_4096_egonets"] = r["ms_per_step"] / factor
+        return r
+    finally:
+        N_QUERIES = base
 
 
 def extra_metrics_sharded(model, device, world, rank, n_queries=int(os.environ.get("TXE_BENCH_SHARDED_QUERIES", "8192")), qblock=1024):
@@ -655,6 +688,30 @@ def main():
         torch.cuda.synchronize()
         rq_ms = 1e3 * (time.perf_counter() - tq0) / max(args.steps, 1)
 
+    # A/B scalars of the three caller-side choices `value` rests on beside the reference's own train.py: autograd's
+    # per-device engine thread (bench.py runs backward on the calling thread), torch.optim.Adam instead of taxoexpan_amd.optim.Adam,
+    # torch's F.cross_entropy instead of taxoexpan_amd.loss.info_nce_loss -- each alone, same resident batches, same step count
+    ab = {}
+    if args.workload == "pgat" and world == 1:
+        def timed(opt_, loss_fn=None):
+            for i in range(min(args.warmup, 5)):
+                train_step(model, opt_, batches[i % len(batches)], target, world, loss_fn)
+            torch.cuda.synchronize()
+            t0_ = time.perf_counter()
+            for i in range(args.steps):
+                train_step(model, opt_, batches[i % len(batches)], target, world, loss_fn)
+            torch.cuda.synchronize()
+            return 1e3 * (time.perf_counter() - t0_) / max(args.steps, 1)
+        torch.autograd.set_multithreading_enabled(True)
+        ab["step_default_autograd_ms"] = timed(opt)
+        torch.autograd.set_multithreading_enabled(False)
+        ab["step_torch_adam_ms"] = timed(torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=0, amsgrad=True))
+        ab["step_torch_loss_ms"] = timed(opt, lambda out, tgt: F.cross_entropy(out, tgt, reduction="sum"))
+        torch.autograd.set_multithreading_enabled(True)
+        ab["step_reference_caller_ms"] = timed(torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=0, amsgrad=True),
+                                               lambda out, tgt: F.cross_entropy(out, tgt, reduction="sum"))     # all three as train.py has them
+        torch.autograd.set_multithreading_enabled(False)
+
     # the same step with a NEW batch built inside it (what an epoch of train.py pays per step): not `value` -- the contract times the
     # hot path on resident inputs -- but reported next to it
     from taxoexpan_amd import graph as Gr
@@ -707,6 +764,7 @@ def main():
         if not args.no_extra:
             extra, hg_cs, q_cs = extra_metrics(model, tax, device, batches, full_batches)
             for name, fn in (("mag_full", lambda: extra_metrics_mag_full(model, device, tax_full)),
+                             ("step_32768_egonets", lambda: large_batch_step(tax, device, 8)),
                              ("step_pgcn", lambda: variant_step("pgcn", tax, device)),
                              ("step_pgat2", lambda: variant_step("pgat2", tax_full, device))):
                 try:                                     # never let a secondary metric take the bench line down
@@ -734,7 +792,7 @@ def main():
         # the dominant kernel of the critical path: second-stream launches are listed in roofline_all with their (stretched) durations
         dom = next((r for r in roof_all if r["stream"] == "main"), roof_all[0])
         hbm = [r for r in roof_all if r["bound"] == "hbm"]
-        copy_bw = hbm_copy_ceiling(device)
+        copy_bw, copy_bw_torch = hbm_copy_ceiling(device)
         for r in hbm:                                # (beside the fraction of the 8 TB/s spec)
             r["frac_of_copy_ceiling"] = r["achieved"] * 1e9 / copy_bw
         def by_kernel(prefix):
@@ -751,7 +809,7 @@ def main():
                     "hbm_achieved_gbs": hb["achieved"] if hb else None, "hbm_frac": hb["frac"] if hb else None,
                     "hbm_frac_of_copy_ceiling": hb["frac_of_copy_ceiling"] if hb else None,
                     "hbm_traffic_ratio": (hb["traffic"] / hb["work_per_launch"] if hb and hb.get("traffic") else None),
-                    "copy_ceiling_gbs": copy_bw / 1e9,
+                    "copy_ceiling_gbs": copy_bw / 1e9, "copy_ceiling_torch_gbs": copy_bw_torch / 1e9,
                     "pair_frac": pair["pair_frac"] if pair else None, "pair_kernel": pair["kernel"] if pair else None}
         for short, prefix in (("aggregate_fwd", "gat_aggregate_fwd_kernel"), ("fused_bwd", "gat_fused_bwd_kernel"),
                               ("dx_pos", "gat_dx_pos_kernel"), ("bwd_dot", "cl_bwd_dot_kernel"), ("zsum", "cl_zsum_kernel")):
@@ -784,7 +842,7 @@ def main():
             # flat scalars, last so that they end the line: a fresh batch built inside every step (device egonet builder, one host sync),
             # and the secondary halves of BASELINE.json's metric
             "step_incl_batch_build_ms": fresh_ms, "batch_build_ms": build_ms, "step_incl_batch_build_repeated_queries_ms": fresh_rq_ms,
-            "step_repeated_queries_ms": rq_ms,
+            "step_repeated_queries_ms": rq_ms, **ab,
             "egonet_edges_per_s_incl_batch_build": world * fresh_edges / max(n_fresh, 1) / (fresh_ms * 1e-3),
         }
         if extra:
@@ -797,7 +855,10 @@ def main():
                                 ("mag_full_encode_edges_per_s", ("mag_full", "encode_edges_per_s")),
                                 ("infer_top5_queries_per_s", ("mag_full", "infer_top5_queries_per_s")),
                                 ("infer_top5_fused_over_composite", ("mag_full", "infer_top5_fused_over_composite")),
-                                ("step_pgcn_ms", ("step_pgcn", "ms_per_step")), ("step_pgat2_ms", ("step_pgat2", "ms_per_step"))):
+                                ("step_pgcn_ms", ("step_pgcn", "ms_per_step")), ("step_pgat2_ms", ("step_pgat2", "ms_per_step")),
+                                ("step_32768_egonets_ms", ("step_32768_egonets", "ms_per_step")),
+                                ("step_32768_egonets_edges_per_s", ("step_32768_egonets", "egonet_edges_per_s")),
+                                ("step_32768_egonets_roofline_frac", ("step_32768_egonets", "roofline", "frac"))):
                 v = extra
                 for k in path:
                     v = v.get(k) if isinstance(v, dict) else None

@@ -366,6 +366,9 @@ int txe_profile_stream(int i, void** stream);   /* the hipStream_t record i was 
  * before it has completed (an event without the system-scope fence: no L2 write-back / invalidate in front of `first`'s next kernel).
  * The host-side mirror uses it for every second-stream overlap (taxoexpan_amd/ops.py _order). */
 int txe_stream_order(void* first, void* then);
+/* device-to-device streaming copy with 16-byte loads / stores (n_bytes % 16 == 0, 16-byte aligned): the copy ceiling bench.py shows the
+ * HBM-bound sweeps against, beside the 8 TB/s spec */
+int txe_copy_stream(const void* src, void* dst, long long n_bytes, void* stream);
 
 /* model/loss.py:52-57 info_nce_loss = F.cross_entropy(output [B][C], target [B], reduction="sum") on the [queries][1 + negatives]
  * regrouping of trainer.py:52-56, together with its gradient:  loss[0] = sum_b (logsumexp(x_b) - x_b[target_b]),

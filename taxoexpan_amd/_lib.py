@@ -102,6 +102,7 @@ SIGNATURES = {
     "txe_profile_get": (I, [I, P, I, P, P, P]),
     "txe_profile_stream": (I, [I, P]),
     "txe_stream_order": (I, [P, P]),
+    "txe_copy_stream": (I, [P, P, L, P]),
 }
 
 class GatPrepareDesc(C.Structure):

@@ -58,11 +58,37 @@ int prof_begin(const char* name, hipStream_t s, double work, int kind) {
 }
 void prof_end(int id, hipStream_t s) { (void)hipEventRecord(g_recs[id].b, s); }
 
+// dst[i] = src[i] with 16-byte loads and stores, four independent vectors in flight per thread: the streaming-copy ceiling of the
+// box (MI355X_MICROARCH.md: ~6.3 TB/s read + written), the yardstick the HBM-bound sweeps are shown against beside the 8 TB/s spec
+__global__ __launch_bounds__(256) void copy_f4_kernel(const float4* __restrict__ src, float4* __restrict__ dst, long long n4) {
+    const long long stride = (long long)gridDim.x * 256 * 4;
+    for (long long i = ((long long)blockIdx.x * 256 + threadIdx.x); i < n4; i += stride) {
+        float4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const long long j = i + (long long)u * gridDim.x * 256; v[u] = src[j < n4 ? j : i]; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const long long j = i + (long long)u * gridDim.x * 256; if (j < n4) dst[j] = v[u]; }
+    }
+}
+
 }  // namespace txe
 
 using namespace txe;
 
 extern "C" {
+
+// device-to-device streaming copy of n_bytes (a multiple of 16; 16-byte aligned pointers): measurement yardstick, see copy_f4_kernel
+int txe_copy_stream(const void* src, void* dst, long long n_bytes, void* stream) {
+    if (!src || !dst || n_bytes < 0 || (n_bytes & 15) || (((uintptr_t)src | (uintptr_t)dst) & 15)) return TXE_ERR_ARG;
+    if (n_bytes == 0) return TXE_OK;
+    const long long n4 = n_bytes / 16;
+    long long nb = (n4 + 256 * 4 - 1) / (256 * 4);
+    const long long cap = (long long)device_cu_count() * 16;
+    if (nb > cap) nb = cap;
+    hipLaunchKernelGGL(copy_f4_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, (const float4*)src, (float4*)dst, n4);
+    TXE_CHECK_LAUNCH();
+    return TXE_OK;
+}
 
 int txe_profile_enable(int on) {
     g_on = (on != 0);

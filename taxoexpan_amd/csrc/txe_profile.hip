@@ -60,15 +60,15 @@ void prof_end(int id, hipStream_t s) { (void)hipEventRecord(g_recs[id].b, s); }
 
 // dst[i] = src[i] with 16-byte loads and stores, four independent vectors in flight per thread: the streaming-copy ceiling of the
 // box (MI355X_MICROARCH.md: ~6.3 TB/s read + written), the yardstick the HBM-bound sweeps are shown against beside the 8 TB/s spec
+template <int U>
 __global__ __launch_bounds__(256) void copy_f4_kernel(const float4* __restrict__ src, float4* __restrict__ dst, long long n4) {
-    const long long stride = (long long)gridDim.x * 256 * 4;
-    for (long long i = ((long long)blockIdx.x * 256 + threadIdx.x); i < n4; i += stride) {
-        float4 v[4];
+    // a workgroup owns U * 256 consecutive vectors: U coalesced 4 KB loads in flight per wave, then the stores
+    const long long base = (long long)blockIdx.x * (256 * U) + threadIdx.x;
+    float4 v[U];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) { const long long j = i + (long long)u * gridDim.x * 256; v[u] = src[j < n4 ? j : i]; }
+    for (int u = 0; u < U; ++u) { const long long j = base + u * 256; v[u] = src[j < n4 ? j : n4 - 1]; }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) { const long long j = i + (long long)u * gridDim.x * 256; if (j < n4) dst[j] = v[u]; }
-    }
+    for (int u = 0; u < U; ++u) { const long long j = base + u * 256; if (j < n4) dst[j] = v[u]; }
 }
 
 }  // namespace txe
@@ -82,10 +82,10 @@ int txe_copy_stream(const void* src, void* dst, long long n_bytes, void* stream)
     if (!src || !dst || n_bytes < 0 || (n_bytes & 15) || (((uintptr_t)src | (uintptr_t)dst) & 15)) return TXE_ERR_ARG;
     if (n_bytes == 0) return TXE_OK;
     const long long n4 = n_bytes / 16;
-    long long nb = (n4 + 256 * 4 - 1) / (256 * 4);
-    const long long cap = (long long)device_cu_count() * 16;
-    if (nb > cap) nb = cap;
-    hipLaunchKernelGGL(copy_f4_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, (const float4*)src, (float4*)dst, n4);
+    constexpr int U = 4;
+    const long long nb = (n4 + 256 * U - 1) / (256 * U);
+    if (nb > 0x7fffffffLL) return TXE_ERR_ARG;
+    hipLaunchKernelGGL(copy_f4_kernel<U>, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, (const float4*)src, (float4*)dst, n4);
     TXE_CHECK_LAUNCH();
     return TXE_OK;
 }

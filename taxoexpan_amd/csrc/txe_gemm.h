@@ -255,8 +255,13 @@ __device__ __forceinline__ void stage_finish(const VMat& M, int row0, int k0, fl
 // operand carries a dropout mask.
 template <bool KC, int ROWS>
 __device__ __forceinline__ bool block_is_plain(const VMat& M, int row0) {
-    if constexpr (KC) {       // rows = the GEMM's m/n range of this workgroup: all valid, all from p or all from p3
-        return (row0 + ROWS <= M.rows) && ((row0 + ROWS <= M.rows_main) || (row0 >= M.rows_main));
+    if constexpr (KC) {       // rows = the GEMM's m/n range of this workgroup: all from p or all from p3.  A ragged LAST panel is plain
+                              // too: the passes past the operand re-read a valid row (fast_issue<..., CLAMP>), and the product rows /
+                              // columns they feed are never stored.  (Left to the generic loader, the one ragged row panel of a
+                              // 24,736-row product made its two workgroups the stragglers of the launch: 110 us against 86 us for
+                              // the LARGER 32,768-row product.)
+        const int rend = (row0 + ROWS < M.rows) ? row0 + ROWS : M.rows;
+        return (row0 < M.rows) && ((rend <= M.rows_main) || (row0 >= M.rows_main));
     } else {                  // columns = the m/n range: inside the plain column range; for an operand without an extension a
                               // ragged last tile is fine too (out-of-range column vectors are clamped and zeroed)
         return (M.cols_main == M.cols) ? (row0 < M.cols) : (row0 + ROWS <= M.cols_main);
@@ -573,8 +578,8 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_kernel(VMat A, VMat B, c
     }
 #define TXE_STAGE_FAST(k0_, buf_, COMPUTE_)                                                                          \
     {                                                                                                                \
-        fast_issue<AK, VA, GEMM_BM>(A, fpa, ra, ma);                                                                 \
-        fast_issue<BKC, VB, BN>(B, fpb, rb, mb);                                                                     \
+        fast_issue<AK, VA, GEMM_BM, true>(A, fpa, ra, ma);                                                           \
+        fast_issue<BKC, VB, BN, true>(B, fpb, rb, mb);                                                               \
         __builtin_amdgcn_sched_barrier(0);                                                                           \
         COMPUTE_                                                                                                     \
         __builtin_amdgcn_sched_barrier(0);                                                                           \
@@ -1180,12 +1185,18 @@ static inline int gemm_launch_layout(const VMat& A, const VMat& B, const Epi& E_
                 dk = 4;
                 P.S = S; P.kslice = kslice; P.part = (float*)((char*)tail_ws + dummy_bytes);
                 nitems = nfull + r * S;
+            } else if (r > 0 && E.plain_k_order) {
+                // no k-split allowed (the scoring loop compares scores of different launches bit for bit): the leftover tiles ride as
+                // whole tiles on the first r workgroups -- the same makespan as a second launch of r workgroups, without the launch
+                // and with their C stores drained under nothing worse than the kernel's tail (MAG-CS scoring: 297 + 69 us -> one launch)
+                P.ntile_items = ntiles;
+                nitems = ntiles;
             }
             static char names[2][48];                    // (per template instantiation of this launcher: one AK / BKC pair)
             char* name = names[dk == 8];
             if (!name[0]) snprintf(name, 48, "gemm_persist_kernel<%s, %s, %d>", AK ? "true" : "false", BKC ? "true" : "false", dk);
             const double all = E.alg_flops > 0.0 ? E.alg_flops : 2.0 * M * (double)N * K;
-            const double share = (S >= 2) ? 1.0 : (double)nfull / (double)ntiles;
+            const double share = (S >= 2 || nitems == ntiles) ? 1.0 : (double)nfull / (double)ntiles;
             {
                 ProfScope prof(name, stream, all * share, 0);
                 if (dk == 8) hipLaunchKernelGGL((gemm_persist_kernel<AK, BKC, 8>), dim3(slots), dim3(GEMM_THREADS), 0, stream, A, B, P, M, N, K, nitems);
@@ -1200,7 +1211,7 @@ static inline int gemm_launch_layout(const VMat& A, const VMat& B, const Epi& E_
                 TXE_CHECK_LAUNCH();
                 return TXE_OK;
             }
-            if (r == 0) return TXE_OK;
+            if (r == 0 || nitems == ntiles) return TXE_OK;
             tile0 = nfull;
             bn = 128;                                      // (the rest keeps the persistent part's tile numbering)
             E.alg_flops = all * (1.0 - share);

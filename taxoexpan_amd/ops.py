@@ -1258,10 +1258,17 @@ def bilinear_project(hg, W):
     # rows zero-padded to a whole number of 32-column k-tiles: the scoring GEMM then runs every k-tile on the plain 16-byte
     # loader (r = 250 would leave a ragged last tile on the generic one); zeros add exactly nothing to the products
     rp = (r + 31) // 32 * 32
-    Ufull = torch.zeros((max(G, 1), rp), dtype=torch.float32, device=hg.device) if rp != r else _empty((max(G, 1), rp), hg)
+    Ufull = _empty((max(G, 1), rp), hg)
     U = Ufull[:G, :r]
+    if rp != r:
+        # the WEIGHT is padded instead of U: W [l][r] -> [l][rp] with zero columns (0.5 MB), so the product writes U's zero padding
+        # itself and reads a 16-byte-aligned operand (rows of 250 floats are only 8-byte aligned: the two-float loader ran this GEMM
+        # at 47 TF/s, 130 us of the 0.54-ms MAG-CS scoring pass)
+        Wp = torch.zeros((l, rp), dtype=torch.float32, device=hg.device)
+        Wp[:, :r].copy_(Wf)
+        Wf = Wp
     with _lib.on_device(hg.device):
-        call("txe_bilinear_project", ptr(hg), ld, G, l, ptr(Wf), r, ptr(U), rp, _lib.stream_ptr())
+        call("txe_bilinear_project", ptr(hg), ld, G, l, ptr(Wf), rp, ptr(Ufull), rp, _lib.stream_ptr())
     _ZERO_PADDED[U.data_ptr()] = (rp, weakref.ref(Ufull))
     return U
 
@@ -1279,6 +1286,22 @@ def _padded_width(U, r):
         del _ZERO_PADDED[U.data_ptr()]
         return r
     return rp if (U.stride(0) == rp and U.shape[1] == r) else r
+
+
+def gather_padded_rows(U, idx):
+    """U[idx] for a bilinear_project output, gathered WITH its zero padding: the result is again a [n, r] view of a [n, rp] buffer that
+    score kernels take on the plain 16-byte loader (a plain U[idx] is a packed [n, 250] copy: 8-byte rows, a ragged last k-tile)"""
+    ent = _ZERO_PADDED.get(U.data_ptr())
+    full = ent[1]() if ent is not None else None
+    if full is None or U.stride(0) != ent[0]:
+        return U.index_select(0, idx)
+    out_full = full.index_select(0, idx)
+    out = out_full[:, :U.shape[1]]
+    if len(_ZERO_PADDED) > 256:                         # (entries of buffers that died)
+        for k in [k for k, v in _ZERO_PADDED.items() if v[1]() is None]:
+            del _ZERO_PADDED[k]
+    _ZERO_PADDED[out.data_ptr()] = (ent[0], weakref.ref(out_full))
+    return out
 
 
 def _pad_queries(Q, r, rp):
@@ -1346,8 +1369,12 @@ def positive_scores_staircase(Q, Up, apply_exp, pos_off, out):
     ldq = Q.stride(0)
     Up, ldu = _rows(Up)
     assert Q.dtype == torch.float32 and Q.stride(1) == 1 and out.dtype == torch.float32 and out.is_contiguous() and out.numel() >= Up.shape[0]
+    r = Q.shape[1]
+    rp = _padded_width(Up, r)
+    if rp != r and ldq == rp:            # both operands carry zeros up to the same k-tile pitch (pad_queries_like / gather_padded_rows): the
+        r = rp                           # whole reduction on the plain loader -- and the very k-tiles txe_score_count_block runs
     with _lib.on_device(Q.device):
-        call("txe_score_positives", ptr(Q), ldq, Q.shape[0], ptr(Up), ldu, Up.shape[0], Q.shape[1], int(apply_exp), ptr(pos_off), ptr(out),
+        call("txe_score_positives", ptr(Q), ldq, Q.shape[0], ptr(Up), ldu, Up.shape[0], r, int(apply_exp), ptr(pos_off), ptr(out),
              _lib.stream_ptr())
     return out
 

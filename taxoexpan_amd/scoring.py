@@ -244,7 +244,7 @@ def _rank_all_fused_device(match, hg, queries, pos_off, pos_idx, block, larger_i
         qb = Qp[q0:q1]
         # thresholds: the positives' scores through the SAME score kernel as the block (bit-identical values), the staircase of tiles
         # that holds them only
-        thr = ops.positive_scores_staircase(qb, U.index_select(0, idxc[lo:hi]), exp, off, thr_all[lo:hi])
+        thr = ops.positive_scores_staircase(qb, ops.gather_padded_rows(U, idxc[lo:hi]), exp, off, thr_all[lo:hi])
         if localb is not None:                                           # a positive that lives in another shard contributes 0 here
             thr.copy_(torch.where(localb[lo:hi], thr, torch.zeros((), device=dev)))      # (not a product: the placeholder may be inf)
         if distributed:

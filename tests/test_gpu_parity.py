@@ -210,8 +210,8 @@ def test_prepare_entries_agree_and_stored_dropped_input_matches_its_mask(N, Kh, 
                                                   (200, 250, 62, 2, 64, 2, 0.2)])
 def test_first_layer_position_dx_streaming_kernel(N, Kh, Pd, H, D, vocab, p):
     """txe_gat_dense_bwd with need_dh = 0 (a first PGAT layer, model_zoo.py:214-215 backward): the streaming position-column kernel
-    (txe_dxpos.hip: d_X[:, c0:Kt] and dP in one pass over d_Y) against the GEMM route (phases | 32) and against float64 --
-    d_X position columns, dW, d_attn, dP.  Shapes: MAG and SemEval dimensions (the SemEval slab runs past the padded row: clamped
+    (txe_dxpos.hip: d_X[:, c0:Kt] and dP in one pass over d_Y) against float64 -- d_X position columns, dP, and dW / d_attn through
+    the split-K slices + the chained phase B (once launched in place, once deferred into a chain and flushed: bit-equal).  Shapes: MAG and SemEval dimensions (the SemEval slab runs past the padded row: clamped
     column vectors), rows that are no multiple of the 16-row workgroups, a single row, 8 position classes, odd widths, no dropout."""
     from taxoexpan_amd import _lib
     dev = _dev()
@@ -234,13 +234,18 @@ def test_first_layer_position_dx_streaming_kernel(N, Kh, Pd, H, D, vocab, p):
         _lib.call("txe_dropout_mask", N, Kt, p, 777, mask.data_ptr(), _lib.stream_ptr())
     wsb = _lib.call("txe_gat_dense_ws_bytes", N, Kh, Pd, H, D, vocab)
     ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+    import ctypes
     outs = []
-    for flag in (0, 32):
+    for deferred in (False, True):
         dX = torch.full((N, Kp), float("nan"), device=dev)
         dW, dal, dar, dP = torch.empty_like(W), torch.empty_like(al), torch.empty_like(ar), torch.empty((vocab, Pd), device=dev)
+        chain = ctypes.create_string_buffer(_lib.TAIL_CHAIN_BYTES)
+        cp = ctypes.cast(chain, ctypes.c_void_p)
         _lib.call("txe_gat_dense_bwd", X.data_ptr(), N, Kh, Pd, pos.data_ptr(), vocab, Wp.data_ptr(), W.data_ptr(), al.data_ptr(), ar.data_ptr(),
                   H, D, p, mask.data_ptr() if mask is not None else None, dY.data_ptr(), 0, 0, 1.0, dX.data_ptr(), dW.data_ptr(), dal.data_ptr(),
-                  dar.data_ptr(), dP.data_ptr(), 0, 7 | flag, ws.data_ptr(), wsb, _lib.stream_ptr())
+                  dar.data_ptr(), dP.data_ptr(), 0, 7 | (64 if deferred else 0), cp if deferred else None, ws.data_ptr(), wsb, _lib.stream_ptr())
+        if deferred:
+            _lib.call("txe_gat_tail_flush", cp, _lib.stream_ptr())
         torch.cuda.synchronize()
         outs.append([t.cpu().double().numpy() for t in (dX[:, Kh:Kt], dW, dal, dar, dP)])
     # float64 restatement
@@ -260,9 +265,10 @@ def test_first_layer_position_dx_streaming_kernel(N, Kh, Pd, H, D, vocab, p):
         assert np.isfinite(o[0]).all()
         np.testing.assert_allclose(o[0], dX_ref[:, Kh:], rtol=1e-4, atol=1e-5 * scale)
         np.testing.assert_allclose(o[4], dP_ref, rtol=1e-4, atol=2e-5 * max(np.abs(dP_ref).max(), 1e-30))
-    for a, b in zip(outs[0][1:4], outs[1][1:4]):                      # the weight side does not depend on the route
+    for a, b in zip(outs[0], outs[1]):                                # launched in place = deferred and flushed
         np.testing.assert_array_equal(a, b)
-    np.testing.assert_allclose(outs[0][0], outs[1][0], rtol=1e-4, atol=1e-5 * scale)
+    dW_ref = (dYd[:, :F].T @ (Xd * keep)) + ald[:, None] * (dYd[:, F:F + H].T @ (Xd * keep)).repeat(D, 0) + ard[:, None] * (dYd[:, F + H:F + 2 * H].T @ (Xd * keep)).repeat(D, 0)
+    np.testing.assert_allclose(outs[0][1], dW_ref, rtol=1e-4, atol=2e-5 * np.abs(dW_ref).max())
 
 
 def _random_graph(n, e, seed, zero_in=True):

@@ -2,7 +2,8 @@
 """Workload for the rocprofv3 PMC passes: a known-size device copy (calibrates FETCH_SIZE / WRITE_SIZE, which on gfx950 under-report
 wide streaming reads by 2x -- MI355X_MICROARCH.md HBM section) followed by the hot path of one BASELINE config:
     TXE_PROF_WORKLOAD = pgat | pgcn | pgat2   training steps of bench.py --workload <w> (same model / batches)
-                      = infer                 MAG-Full all-candidate inference: encode 356 k egonets, fused score + rank of 2,048 queries"""
+                      = infer                 MAG-Full all-candidate inference: encode 356 k egonets, fused score + rank and fused score +
+                                              best-5 of 2,048 queries"""
 import os
 import sys
 
@@ -33,7 +34,7 @@ def calibrate():
 
 if W == "infer":
     from taxoexpan_amd import graph as G
-    from taxoexpan_amd.scoring import encode_candidates, rank_all_fused
+    from taxoexpan_amd.scoring import encode_candidates, rank_all_fused, topk_parents_fused
     tax = syn.make_named_taxonomy("mag_full", seed=47)
     model = bench.make_model("pgat", dev).eval()
     cand, _val, test = syn.split_candidates(tax)
@@ -51,6 +52,7 @@ if W == "infer":
         for _ in range(max(steps // 2, 1)):
             hg = encode_candidates(model, g)
             rank_all_fused(model.match, hg, queries, pos_off, pos_idx)
+            topk_parents_fused(model.match, hg, queries, None, 5, True)          # infer.py:96-106: the 5 best parents, no score matrix
     torch.cuda.synchronize()
     print("N", int(g.number_of_nodes()), "E", int(g.number_of_edges()), "G", len(cand), "Q", len(test))
 else:

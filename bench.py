@@ -696,12 +696,15 @@ def main():
         def timed(opt_, loss_fn=None):
             for i in range(min(args.warmup, 5)):
                 train_step(model, opt_, batches[i % len(batches)], target, world, loss_fn)
-            torch.cuda.synchronize()
-            t0_ = time.perf_counter()
-            for i in range(args.steps):
-                train_step(model, opt_, batches[i % len(batches)], target, world, loss_fn)
-            torch.cuda.synchronize()
-            return 1e3 * (time.perf_counter() - t0_) / max(args.steps, 1)
+            ts, per = [], max(args.steps // 5, 1)        # median of five groups: a one-off host stall does not decide an A/B leg
+            for _ in range(5):
+                torch.cuda.synchronize()
+                t0_ = time.perf_counter()
+                for i in range(per):
+                    train_step(model, opt_, batches[i % len(batches)], target, world, loss_fn)
+                torch.cuda.synchronize()
+                ts.append(1e3 * (time.perf_counter() - t0_) / per)
+            return float(np.median(ts))
         torch.autograd.set_multithreading_enabled(True)
         ab["step_default_autograd_ms"] = timed(opt)
         torch.autograd.set_multithreading_enabled(False)

@@ -47,6 +47,16 @@ def test_ctypes_table_mirrors_header():
                 assert t is cmap[ctype], (name, a, t)
 
 
+def test_tail_chain_size_matches_the_header():
+    """TXE_TAIL_CHAIN_BYTES (include/txe.h) = the buffer ops._TailChain hands to the C entry points"""
+    import re
+    from taxoexpan_amd import _lib
+    hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "txe.h")).read()
+    assert int(re.search(r"#define TXE_TAIL_CHAIN_BYTES (\d+)", hdr).group(1)) == _lib.TAIL_CHAIN_BYTES
+    lib = _lib.load()
+    assert lib.txe_gat_tail_flush(None, None) == 0                    # no chain: nothing to launch
+
+
 def test_argument_validation_needs_no_gpu():
     """error paths return codes before anything is launched"""
     from taxoexpan_amd import _lib

@@ -1322,6 +1322,18 @@ def test_repeated_query_rows_match_the_stacked_rows(matcher):
     for k in (0, 1, 2):
         scale = outs[0][k].abs().max().item()
         np.testing.assert_allclose(outs[1][k].cpu().numpy(), outs[0][k].cpu().numpy(), rtol=1e-5, atol=2e-6 * scale)
+    # ... and both run forms (RepeatedRows, and the stacked rows whose runs the device finds) against the ORACLE's bilinear match
+    # (model_zoo.py:301-328 restated), not only against the library's own GEMM form
+    ac, Wc = e1.cpu().clone().requires_grad_(True), m.W.weight.detach().cpu().clone().requires_grad_(True)
+    sr = orc.bilinear_match(ac, dense.cpu(), Wc, matcher == "LBM")
+    (sr.reshape(-1) * torch.linspace(-1, 1, G)).sum().backward()
+    a2 = e1.clone().requires_grad_(True)
+    m.zero_grad()
+    s2 = ops.BilinearStackedRunsFunction.apply(a2, dense, m.W.weight, matcher == "LBM")
+    (s2.reshape(-1) * torch.linspace(-1, 1, G, device=dev)).sum().backward()
+    for got in (outs[1], (s2.detach(), a2.grad, m.W.weight.grad)):
+        for g_, w_ in zip(got, (sr.detach().reshape(-1, 1), ac.grad, Wc.grad)):
+            np.testing.assert_allclose(g_.cpu().numpy().reshape(w_.shape), w_.numpy(), rtol=1e-4, atol=2e-6 * float(w_.abs().max()))
     # an empty batch, and a matcher without a runs form
     assert m(e1[:0], ops.RepeatedRows.from_ids(table, np.zeros(0, dtype=np.int64))).shape == (0, 1)
     mlp = mz.MLP(l, 250, 16).to(dev)

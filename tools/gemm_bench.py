@@ -32,7 +32,7 @@ def timeit(fn, n=20, warm=5):
 _ws = None
 
 
-def run(layout, M, N, K, lda=None, ldb=None, ldc=None, splits=1, tail=False, mm=False, label=""):
+def run(layout, M, N, K, lda=None, ldb=None, ldc=None, splits=1, tail=False, mm=False, label="", route=0):
     global _ws
     if _ws is None:
         _ws = torch.empty(_lib.call("txe_gemm_tail_ws_bytes"), dtype=torch.uint8, device=dev)
@@ -42,7 +42,7 @@ def run(layout, M, N, K, lda=None, ldb=None, ldc=None, splits=1, tail=False, mm=
     A = torch.randn(ra, lda, device=dev)
     B = torch.randn(rb, ldb, device=dev)
     C = torch.empty(splits * M, ldc, device=dev)
-    f = lambda: _lib.call("txe_gemm_plain", layout, A.data_ptr(), lda, B.data_ptr(), ldb, C.data_ptr(), ldc, M, N, K, splits, 0,
+    f = lambda: _lib.call("txe_gemm_plain", layout, A.data_ptr(), lda, B.data_ptr(), ldb, C.data_ptr(), ldc, M, N, K, splits, route,
                           _ws.data_ptr() if tail else None, _ws.numel() if tail else 0, _lib.stream_ptr())
     dt = timeit(f)
     flops = 2.0 * M * N * K
@@ -84,5 +84,6 @@ if __name__ == "__main__":
         ap.add_argument("--splits", type=int, default=1)
         ap.add_argument("--tail", action="store_true")
         ap.add_argument("--mm", action="store_true")
+        ap.add_argument("--route", type=int, default=0)
         a = ap.parse_args()
-        run(a.layout, a.M, a.N, a.K, a.lda, a.ldb, a.ldc, a.splits, a.tail, a.mm)
+        run(a.layout, a.M, a.N, a.K, a.lda, a.ldb, a.ldc, a.splits, a.tail, a.mm, route=a.route)

@@ -1,6 +1,6 @@
 """TEST INFRASTRUCTURE: one rank of a world-size-N job whose ranks all sit on cuda:0 (a single-GPU box) over gloo, launched by
 tests/test_gpu_eval_infer.py through torch.distributed.run.  Every rank computes the UNSHARDED scoring loop with the HIP kernels and
-its shard of the candidate-sharded one (pipelined all-gather of score blocks; all-reduce-of-counts ranking) and asserts that the
+its shard of the candidate-sharded one (pipelined all-gather of score blocks; all-reduce-of-counts ranking; all-gather of best-5 lists) and asserts that the
 sharded results are the unsharded ones BIT FOR BIT -- the collectives only move what the same kernels computed.  Prints "OK <rank>".
 `dist_gpu_worker.py dp`: the data-parallel TRAINING step instead (dp_training_step below).  Reference for the partition:
 trainer/trainer.py:52-56 (a query's 1 + negatives stay together), model/loss.py:52-57 (sum reduction: gradients add over ranks)."""
@@ -20,7 +20,7 @@ def main():
     torch.cuda.set_device(0)
     dev = torch.device("cuda:0")
     from taxoexpan_amd import model_zoo as mz, ops
-    from taxoexpan_amd.scoring import rank_all_fused, score_all, score_all_sharded, shard_bounds
+    from taxoexpan_amd.scoring import rank_all_fused, score_all, score_all_sharded, shard_bounds, topk_parents, topk_parents_fused
     solo = [dist.new_group([rr]) for rr in range(world)][rank]      # (every rank creates every group: new_group is collective)
     G, Q, l, r = 10007, 333, 500, 250                      # (G: no multiple of the world sizes, of 4 or of the tile widths)
     gen = torch.Generator().manual_seed(123)
@@ -53,6 +53,13 @@ def main():
             assert torch.equal(ranks_sh, ranks_full), kind
             off_t, idx_t = torch.tensor(pos_off, dtype=torch.int32), torch.tensor(pos_idx, dtype=torch.int32)
             assert torch.equal(ops.rank_block(S_full, off_t, idx_t, True), ranks_full), kind
+            # the 5 best parents (infer.py:96-106): every rank selects among its shard with the fused kernels, the [Q, 5] lists are
+            # all-gathered and merged -- the unsharded selection, which is the stable sort of the materialised scores
+            ids = torch.arange(G, device=dev)
+            for larger in (True, False):
+                want = topk_parents(S_full, ids, 5, larger)
+                assert torch.equal(topk_parents_fused(match, hg, queries, None, 5, larger, group=solo), want), (kind, larger)
+                assert torch.equal(topk_parents_fused(match, hg[lo:hi], queries, None, 5, larger, block=128, shard_lo=lo), want), (kind, larger)
     torch.cuda.synchronize()
     dist.barrier()
     print(f"OK {rank}", flush=True)

@@ -311,6 +311,9 @@ def test_fused_top_k_equals_the_composite_on_materialised_scores(G, Q, k):
         hg[7] = float("nan")                                       # a NaN score ranks last
         hg[11] *= 1e4                                              # +-inf after exp / huge values
     queries = torch.nn.functional.normalize(torch.randn(Q, r, generator=gen), dim=1)
+    if G == 1000:
+        hg[:] = hg[0]                                              # EVERY score of a query equal: the k lowest candidate positions, whatever
+                                                                   # the tiles' floors did in between
     ids = torch.arange(G, device=dev) * 3 + 1
     for kind in ("LBM", "BIM"):
         torch.manual_seed(5)
@@ -322,6 +325,8 @@ def test_fused_top_k_equals_the_composite_on_materialised_scores(G, Q, k):
                 want = topk_parents(S, ids, k, larger)
                 got = topk_parents_fused(match, hg.to(dev), queries.to(dev), ids, k, larger)
                 assert got.shape == want.shape == (Q, min(k, G)) and torch.equal(got, want), (kind, larger)
+                if G == 1000:
+                    assert torch.equal(got, ids[:k].expand(Q, k)), (kind, larger)
                 if G >= 16:                                        # two "shards" merged = the unsharded selection
                     h = G // 3
                     parts = []

@@ -340,6 +340,52 @@ def test_gcn_layer_generic_graph_fwd_bwd(K, Fo):
     np.testing.assert_allclose(layer.bias.grad.cpu().numpy(), b.grad.numpy(), rtol=2e-3, atol=2e-5)
 
 
+@pytest.mark.parametrize("prop", ["PGCN", "GCN", "PGAT"])
+def test_propagation_with_another_activation_runs_layer_by_layer(prop):
+    """model_zoo.py:128-137,155-167,210-220 with an activation the fused stack does not know (torch.tanh; model.py only ever passes
+    F.leaky_relu): PGCN / GCN used to raise here, which changes a script's flow -- now the layers run one by one (the fused stack of
+    one layer each, the activation and the concat by torch): outputs and gradients against the oracle's layers composed the same way"""
+    from taxoexpan_amd import model_zoo as mz
+    from taxoexpan_amd.graph import BatchedDGLGraph
+    dev = _dev()
+    rs = np.random.RandomState(5)
+    k, m = rs.randint(1, 4, 9), rs.randint(0, 6, 9)
+    g = BatchedDGLGraph.from_egonet_shapes(k, m)
+    n = g.number_of_nodes()
+    pos = g.ndata["pos"].clone()
+    x = torch.randn(n, 12, generator=torch.Generator().manual_seed(1))
+    torch.manual_seed(2)
+    if prop == "PGCN":
+        model = mz.PGCN(12, 16, 8, 4, num_layers=1, activation=torch.tanh, in_dropout=0.0, hidden_dropout=0.0, output_dropout=0.0).to(dev)
+    elif prop == "GCN":
+        model = mz.GCN(12, 16, 8, num_layers=1, activation=torch.tanh, in_dropout=0.0, hidden_dropout=0.0, output_dropout=0.0).to(dev)
+    else:
+        model = mz.PGAT(12, 16, 8, 4, num_layers=1, heads=[2, 1], activation=torch.tanh, feat_drop=0.0, attn_drop=0.0).to(dev)
+    xg = x.to(dev).requires_grad_(True)
+    out = model(g, xg)
+    out = out.tensor() if hasattr(out, "tensor") and not torch.is_tensor(out) else out
+    wgt = torch.randn(n, 8, generator=torch.Generator().manual_seed(3))
+    (out * wgt.to(dev)).sum().backward()
+    P = {kk: v.detach().cpu().clone().requires_grad_(True) for kk, v in model.state_dict().items()}
+    s_, d_ = torch.from_numpy(np.asarray(g._src)).long(), torch.from_numpy(np.asarray(g._dst)).long()
+    xc = x.clone().requires_grad_(True)
+    h = xc
+    for l in range(2):
+        emb = P.get(f"prop_position_embeddings.{l}.weight")
+        hin = h if emb is None else torch.cat((h, emb[pos]), 1)
+        if prop == "PGAT":
+            h = orc.gat_layer(s_, d_, n, hin, P[f"gat_layers.{l}.fc.weight"], P[f"gat_layers.{l}.attn_l"], P[f"gat_layers.{l}.attn_r"])
+            h = torch.tanh(h.flatten(1)) if l == 0 else h.mean(1)
+        else:
+            h = orc.gcn_layer(s_, d_, n, hin, P[f"layers.{l}.weight"], P[f"layers.{l}.bias"], orc.gcn_norm(d_, n), act_slope=None)
+            h = torch.tanh(h) if l == 0 else h
+    (h * wgt).sum().backward()
+    np.testing.assert_allclose(out.detach().cpu().numpy(), h.detach().numpy(), rtol=RT, atol=AT)
+    np.testing.assert_allclose(xg.grad.cpu().numpy(), xc.grad.numpy(), rtol=2e-3, atol=2e-5)
+    for kk, p_ in model.named_parameters():
+        np.testing.assert_allclose(p_.grad.cpu().numpy(), P[kk].grad.numpy(), rtol=2e-3, atol=2e-5, err_msg=kk)
+
+
 @pytest.mark.parametrize("M,N,K", [(1, 1, 1), (129, 257, 33), (300, 2008, 300), (77, 130, 2050), (256, 128, 64),
                                    (200, 160, 4000), (132, 480, 3000), (100, 2080, 1500)])
 def test_gemm_layouts_against_fp64(M, N, K):

@@ -284,12 +284,12 @@ __global__ __launch_bounds__(256) void runs_dw_kernel(const float* __restrict__ 
         }
         __syncthreads();
         const int n = min(256, U - u0);
-        for (int t0 = 0; t0 < n; t0 += 8) {                     // eight runs' loads in flight; the sum keeps the runs' order
-            float q[8];
+        for (int t0 = 0; t0 < n; t0 += 16) {                    // sixteen runs' loads in flight; the sum keeps the runs' order
+            float q[16];
 #pragma unroll
-            for (int t = 0; t < 8; ++t) q[t] = Q[sRow[min(t0 + t, n - 1)] * ld_q + kc];
+            for (int t = 0; t < 16; ++t) q[t] = Q[sRow[min(t0 + t, n - 1)] * ld_q + kc];
 #pragma unroll
-            for (int t = 0; t < 8; ++t) {
+            for (int t = 0; t < 16; ++t) {
                 if (t0 + t < n) {
                     acc[0] = fmaf(sS[t0 + t][0], q[t], acc[0]);
                     acc[1] = fmaf(sS[t0 + t][1], q[t], acc[1]);

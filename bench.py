@@ -573,11 +573,21 @@ def extra_metrics_sharded(model, device, world, rank, n_queries=int(os.environ.g
         ranks = rank_all_fused(model.match, hg, queries, pos_off, pos_idx, block=qblock, shard_lo=lo)
         torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
         t_fr = time.perf_counter() - t0
-        t = torch.tensor([t_enc, timings["local"], timings["allgather"], t_fr], dtype=torch.float64, device=device)
+        # the 5 best parents of every query (infer.py:96-106): each rank selects among its shard with the fused kernels, the [Q, 5] lists
+        # (40 bytes per query and rank) are all-gathered and merged
+        from taxoexpan_amd.scoring import topk_parents_fused
+        topk_parents_fused(model.match, hg, queries, None, 5, True, block=qblock, shard_lo=lo)
+        torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        top5 = topk_parents_fused(model.match, hg, queries, None, 5, True, block=qblock, shard_lo=lo)
+        torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+        t_top = time.perf_counter() - t0
+        t = torch.tensor([t_enc, timings["local"], timings["allgather"], t_fr, t_top], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        t_enc, t_loc, t_ag, t_fr = (float(x) for x in t.tolist())
+        t_enc, t_loc, t_ag, t_fr, t_top = (float(x) for x in t.tolist())
         pairs = float(len(cand)) * len(test)
         out.update(infer_fused_rank_allreduce_s=t_fr, candidates_scored_per_s_fused_allreduce=pairs / t_fr,
+                   infer_top5_allgather_s=t_top, infer_top5_queries_per_s_sharded=len(test) / t_top, infer_top5_shape=list(top5.shape),
                    mean_rank=float(ranks.float().mean().item()) if ranks.numel() else None)
         out.update(shape="mag_full", infer_candidates=int(len(cand)), infer_queries=int(len(test)), candidates_per_rank=int(hi - lo),
                    infer_encode_s=t_enc, infer_score_local_s=t_loc, infer_score_allgather_s=t_ag,

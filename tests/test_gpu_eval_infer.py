@@ -243,8 +243,10 @@ def test_bench_two_ranks_sharded_inference_on_one_gpu():
     ex = d["extra"]
     assert "error" not in ex, ex
     assert ex["infer_queries"] == 2048 and ex["candidates_per_rank"] * 2 >= ex["infer_candidates"]
-    for k in ("candidates_scored_per_s_local", "candidates_scored_per_s_allgather", "candidates_scored_per_s_fused_allreduce"):
+    for k in ("candidates_scored_per_s_local", "candidates_scored_per_s_allgather", "candidates_scored_per_s_fused_allreduce",
+              "infer_top5_queries_per_s_sharded"):
         assert ex[k] > 0, k
+    assert ex["infer_top5_shape"] == [2048, 5]
 
 
 @pytest.mark.parametrize("world", [2, 4])

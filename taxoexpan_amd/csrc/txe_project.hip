@@ -1090,6 +1090,66 @@ __global__ __launch_bounds__(256) void cl_zsum_kernel(const int* __restrict__ go
     }
 }
 
+// The same sweep with one wave per (chunk of ZS_GPW consecutive graphs, column tile): an egonet has ~4 nodes, so a (graph, tile) wave
+// asks for 4 KB and is gone -- 36,864 waves of two dependent round trips each on the training batch.  A chunk's nodes are one
+// contiguous range: the wave streams it eight nodes (8 KB) per step and writes a graph's row of Z whenever the range crosses into
+// the next graph (offsets and weight sums of the chunk sit in lanes, read back as scalars: uniform control flow).  Per graph the same
+// nodes in the same order: bit-identical to cl_zsum_kernel.
+constexpr int ZS_GPW = 4;
+template <bool MASK>
+__global__ __launch_bounds__(256) void cl_zsum_chunk_kernel(const int* __restrict__ goff, int G, int ntile, const float* __restrict__ X, int Kp,
+                                                            const unsigned* __restrict__ mask, int mask_ld, float scale,
+                                                            const float* __restrict__ coef, const float* __restrict__ wsum,
+                                                            float* __restrict__ Z) {
+    constexpr int NU = 8;
+    const int l = threadIdx.x & 63;
+    const long long wid = ((long long)blockIdx.x * 256 + threadIdx.x) >> 6;
+    const int ch = (int)(wid / ntile), t = (int)(wid % ntile);
+    const int g0 = ch * ZS_GPW;
+    if (g0 >= G) return;
+    const int ng = min(ZS_GPW, G - g0);
+    const int my_off = goff[g0 + min(l, ng)];                       // lanes 0..ng: the chunk's graph offsets
+    const float my_ws = wsum[g0 + min(l, ng - 1)];                  // lanes 0..ng-1: their weight sums
+    const int nvec = Kp >> 2;
+    const int j = t * 64 + l;
+    const int jc = (j < nvec) ? j : t * 64;
+    const int beg = __builtin_amdgcn_readlane(my_off, 0), end = __builtin_amdgcn_readlane(my_off, ng);
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    int gi = 0;                                                     // current graph of the chunk (uniform)
+    int next = __builtin_amdgcn_readlane(my_off, 1);               // first node past it
+    auto flush = [&]() {                                            // graph gi is complete: scale, store, start the next one
+        const float S = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_ws), gi));
+        const float zs = S > 0.f ? scale / S : 0.f;
+        if (j < nvec) {
+            float o[4] = {acc[0] * zs, acc[1] * zs, acc[2] * zs, acc[3] * zs};
+            vstore<4>(Z + (long long)(g0 + gi) * Kp + j * 4, o);
+        }
+        acc[0] = acc[1] = acc[2] = acc[3] = 0.f;
+        ++gi;
+        next = __builtin_amdgcn_readlane(my_off, min(gi + 1, ng));
+    };
+    for (int u0 = beg; u0 < end; u0 += NU) {                        // NU nodes per step: independent loads in flight
+        float x[NU][4], k4[NU][4], cu[NU];
+#pragma unroll
+        for (int e = 0; e < NU; ++e) {
+            const int u = min(u0 + e, end - 1);
+            cu[e] = coef[u];
+            vload<4>(X + (long long)u * Kp + jc * 4, x[e]);
+            cl_keep4<MASK>(mask + (MASK ? (long long)u * mask_ld : 0), mask_ld, jc, k4[e]);
+        }
+#pragma unroll
+        for (int e = 0; e < NU; ++e) {
+            const int u = u0 + e;
+            if (u < end) {                                          // (uniform)
+                while (u >= next) flush();                          // graphs that ended before u (empty ones included)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) acc[k] = fmaf(cu[e] * k4[e][k], x[e][k], acc[k]);
+            }
+        }
+    }
+    while (gi < ng) flush();                                        // the last graph, and empty graphs at the chunk's end
+}
+
 // per graph: dS[g] = -<dZ[g], Z[g]> / S_g
 __global__ __launch_bounds__(256) void cl_bwd_ds_kernel(int G, int Kp, const float* __restrict__ dZ, const float* __restrict__ Z,
                                                         const float* __restrict__ wsum, float* __restrict__ dS) {
@@ -1938,11 +1998,17 @@ int txe_gat_collapse_fwd(const int* rowptr_in, const int* col_src, const int* ro
     }
     {
         const int ntile = (Kp / 4 + 63) / 64;
-        const long long nwaves = (long long)G * ntile;
-        ProfScope prof(mk ? "cl_zsum_kernel<true>" : "cl_zsum_kernel<false>", s, 4.0 * (n_nodes + (double)G) * Kp, 1);
-        if (mk) hipLaunchKernelGGL(cl_zsum_kernel<true>, dim3((unsigned)((nwaves + 3) / 4)), dim3(256), 0, s, graph_off, G, ntile, X, Kp, mk, mask_ld, fs,
+        // small graphs (egonets: ~4 nodes): one wave per chunk of ZS_GPW graphs and column tile; large ones: one per graph and tile
+        const bool chunked = (long long)n_nodes <= 16LL * G && G >= 4 * ZS_GPW;
+        const long long nwaves = (chunked ? (long long)((G + ZS_GPW - 1) / ZS_GPW) : (long long)G) * ntile;
+        ProfScope prof(chunked ? (mk ? "cl_zsum_chunk_kernel<true>" : "cl_zsum_chunk_kernel<false>") : (mk ? "cl_zsum_kernel<true>" : "cl_zsum_kernel<false>"), s,
+                       4.0 * (n_nodes + (double)G) * Kp, 1);
+        const dim3 grid((unsigned)((nwaves + 3) / 4));
+        if (chunked && mk) hipLaunchKernelGGL(cl_zsum_chunk_kernel<true>, grid, dim3(256), 0, s, graph_off, G, ntile, X, Kp, mk, mask_ld, fs, (const float*)coef, (const float*)wsum, Z);
+        else if (chunked) hipLaunchKernelGGL(cl_zsum_chunk_kernel<false>, grid, dim3(256), 0, s, graph_off, G, ntile, X, Kp, dummy_mask, mask_ld, fs, (const float*)coef, (const float*)wsum, Z);
+        else if (mk) hipLaunchKernelGGL(cl_zsum_kernel<true>, grid, dim3(256), 0, s, graph_off, G, ntile, X, Kp, mk, mask_ld, fs,
                                    (const float*)coef, (const float*)wsum, Z);
-        else hipLaunchKernelGGL(cl_zsum_kernel<false>, dim3((unsigned)((nwaves + 3) / 4)), dim3(256), 0, s, graph_off, G, ntile, X, Kp, dummy_mask,
+        else hipLaunchKernelGGL(cl_zsum_kernel<false>, grid, dim3(256), 0, s, graph_off, G, ntile, X, Kp, dummy_mask,
                                 mask_ld, fs, (const float*)coef, (const float*)wsum, Z);
     }
     TXE_CHECK_LAUNCH();

@@ -1150,6 +1150,23 @@ __global__ __launch_bounds__(256) void cl_zsum_chunk_kernel(const int* __restric
     while (gi < ng) flush();                                        // the last graph, and empty graphs at the chunk's end
 }
 
+// launch of the Z sweep: small graphs (egonets: ~4 nodes) on the chunked kernel, large ones one wave per graph and tile
+static int cl_zsum_launch(const int* graph_off, int G, int n_nodes, const float* X, int Kp, const unsigned* mk, const unsigned* dummy_mask,
+                          int mask_ld, float fs, const float* coef, const float* wsum, float* Z, hipStream_t s) {
+    const int ntile = (Kp / 4 + 63) / 64;
+    const bool chunked = (long long)n_nodes <= 16LL * G && G >= 4 * ZS_GPW;
+    const long long nwaves = (chunked ? (long long)((G + ZS_GPW - 1) / ZS_GPW) : (long long)G) * ntile;
+    ProfScope prof(chunked ? (mk ? "cl_zsum_chunk_kernel<true>" : "cl_zsum_chunk_kernel<false>") : (mk ? "cl_zsum_kernel<true>" : "cl_zsum_kernel<false>"), s,
+                   4.0 * (n_nodes + (double)G) * Kp, 1);
+    const dim3 grid((unsigned)((nwaves + 3) / 4));
+    if (chunked && mk) hipLaunchKernelGGL(cl_zsum_chunk_kernel<true>, grid, dim3(256), 0, s, graph_off, G, ntile, X, Kp, mk, mask_ld, fs, coef, wsum, Z);
+    else if (chunked) hipLaunchKernelGGL(cl_zsum_chunk_kernel<false>, grid, dim3(256), 0, s, graph_off, G, ntile, X, Kp, dummy_mask, mask_ld, fs, coef, wsum, Z);
+    else if (mk) hipLaunchKernelGGL(cl_zsum_kernel<true>, grid, dim3(256), 0, s, graph_off, G, ntile, X, Kp, mk, mask_ld, fs, coef, wsum, Z);
+    else hipLaunchKernelGGL(cl_zsum_kernel<false>, grid, dim3(256), 0, s, graph_off, G, ntile, X, Kp, dummy_mask, mask_ld, fs, coef, wsum, Z);
+    TXE_CHECK_LAUNCH();
+    return TXE_OK;
+}
+
 // per graph: dS[g] = -<dZ[g], Z[g]> / S_g
 __global__ __launch_bounds__(256) void cl_bwd_ds_kernel(int G, int Kp, const float* __restrict__ dZ, const float* __restrict__ Z,
                                                         const float* __restrict__ wsum, float* __restrict__ dS) {
@@ -1996,22 +2013,8 @@ int txe_gat_collapse_fwd(const int* rowptr_in, const int* col_src, const int* ro
     } else if (G > 0) {
         hipLaunchKernelGGL(cl_wsum_kernel, dim3((G + 3) / 4), dim3(256), 0, s, graph_off, G, pos, pw, wsum, gid);
     }
-    {
-        const int ntile = (Kp / 4 + 63) / 64;
-        // small graphs (egonets: ~4 nodes): one wave per chunk of ZS_GPW graphs and column tile; large ones: one per graph and tile
-        const bool chunked = (long long)n_nodes <= 16LL * G && G >= 4 * ZS_GPW;
-        const long long nwaves = (chunked ? (long long)((G + ZS_GPW - 1) / ZS_GPW) : (long long)G) * ntile;
-        ProfScope prof(chunked ? (mk ? "cl_zsum_chunk_kernel<true>" : "cl_zsum_chunk_kernel<false>") : (mk ? "cl_zsum_kernel<true>" : "cl_zsum_kernel<false>"), s,
-                       4.0 * (n_nodes + (double)G) * Kp, 1);
-        const dim3 grid((unsigned)((nwaves + 3) / 4));
-        if (chunked && mk) hipLaunchKernelGGL(cl_zsum_chunk_kernel<true>, grid, dim3(256), 0, s, graph_off, G, ntile, X, Kp, mk, mask_ld, fs, (const float*)coef, (const float*)wsum, Z);
-        else if (chunked) hipLaunchKernelGGL(cl_zsum_chunk_kernel<false>, grid, dim3(256), 0, s, graph_off, G, ntile, X, Kp, dummy_mask, mask_ld, fs, (const float*)coef, (const float*)wsum, Z);
-        else if (mk) hipLaunchKernelGGL(cl_zsum_kernel<true>, grid, dim3(256), 0, s, graph_off, G, ntile, X, Kp, mk, mask_ld, fs,
-                                   (const float*)coef, (const float*)wsum, Z);
-        else hipLaunchKernelGGL(cl_zsum_kernel<false>, grid, dim3(256), 0, s, graph_off, G, ntile, X, Kp, dummy_mask,
-                                mask_ld, fs, (const float*)coef, (const float*)wsum, Z);
-    }
-    TXE_CHECK_LAUNCH();
+    const int rc_z = cl_zsum_launch(graph_off, G, n_nodes, X, Kp, mk, dummy_mask, mask_ld, fs, (const float*)coef, (const float*)wsum, Z, s);
+    if (rc_z) return rc_z;
     VMat A = vmat_plain(Z, Kp, G, Kp);
     VMat B = vmat_plain(Wp, Kp, round_up(D + 2, 128), Kp);       // all Fp packed rows are readable: every tile stays on the plain loader
     Epi E = epi_plain(hg, ld_hg, D);
@@ -2401,16 +2404,8 @@ int txe_gcn_collapse_fwd(const int* rowptr_out, const int* col_dst, const int* g
     if (n_nodes > 0)
         hipLaunchKernelGGL(gcl_coef_kernel, dim3((n_nodes + 3) / 4), dim3(256), 0, s, rowptr_out, col_dst, n_nodes, norm, pos, pw, coef);
     hipLaunchKernelGGL(cl_wsum_kernel, dim3((G + 3) / 4), dim3(256), 0, s, graph_off, G, pos, pw, wsum, gid);
-    {
-        const int ntile = (Kp / 4 + 63) / 64;
-        const long long nwaves = (long long)G * ntile;
-        ProfScope prof(mk ? "cl_zsum_kernel<true>" : "cl_zsum_kernel<false>", s, 4.0 * (n_nodes + (double)G) * Kp, 1);
-        if (mk) hipLaunchKernelGGL(cl_zsum_kernel<true>, dim3((unsigned)((nwaves + 3) / 4)), dim3(256), 0, s, graph_off, G, ntile, X, Kp, mk, mask_ld, fs,
-                                   (const float*)coef, (const float*)wsum, Z);
-        else hipLaunchKernelGGL(cl_zsum_kernel<false>, dim3((unsigned)((nwaves + 3) / 4)), dim3(256), 0, s, graph_off, G, ntile, X, Kp, dummy_mask,
-                                mask_ld, fs, (const float*)coef, (const float*)wsum, Z);
-    }
-    TXE_CHECK_LAUNCH();
+    const int rc_z = cl_zsum_launch(graph_off, G, n_nodes, X, Kp, mk, dummy_mask, mask_ld, fs, (const float*)coef, (const float*)wsum, Z, s);
+    if (rc_z) return rc_z;
     VMat A = vmat_plain(Z, Kp, G, Kp);
     VMat B = vmat_plain(Wp, Fop, Kp, Fop);
     Epi E = epi_plain(hg, ld_hg, Fo);

@@ -111,6 +111,10 @@ struct Epi {
     int plain_k_order;
     // test / micro-benchmark routes (txe_gemm_plain's `route` argument; 0 everywhere in the model paths): GEMM_ROUTE_* bits
     int route;
+    // 0, or the caller's promise that columns [k_valid, K) of BOTH k-contiguous operands are zero padding: the persistent kernel
+    // then skips the MFMA steps of a tile's last k-tile that would only add 0 * 0 (K = 300 padded to 320: 2 of its 4 eight-column
+    // groups, 5 % of the product's matrix work; bit-identical sums)
+    int k_valid;
 };
 constexpr int GEMM_ROUTE_NO_PERSIST = 1;     // whole rounds stay on gemm_kernel (the persistent kernel's tiles are bit-identical)
 constexpr int GEMM_ROUTE_NO_TN_LDS = 2;      // split-K TN products on gemm_kernel<false,false,4,4,160> (same k order per element)
@@ -124,7 +128,7 @@ static inline Epi epi_plain(float* c, long long ldc, int cols) {
     e.apply_exp = 0; e.split_stride = 0;
     e.cnt_mode = 0; e.cnt_off = nullptr; e.cnt_thr = nullptr; e.cnt_out = nullptr;
     e.topk_k = 0; e.topk_key = nullptr; e.topk_idx = nullptr; e.topk_floor = nullptr; e.force_bn128 = 0;
-    e.alg_flops = 0.0; e.route = 0;
+    e.alg_flops = 0.0; e.route = 0; e.k_valid = 0;
     e.plain_k_order = 0;
     return e;
 }
@@ -874,7 +878,8 @@ struct Persist {
     float* part;
 };
 
-template <bool AK, bool BKC, int DK /* k-tiles over which a tile's 64 stores per lane are spread: 4 or 8 */>
+template <bool AK, bool BKC, int DK /* k-tiles over which a tile's 64 stores per lane are spread: 4 or 8 */,
+          int LKB = GEMM_BK / 8 /* eight-column groups of the product's LAST k-tile that hold data (Epi.k_valid) */>
 __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_persist_kernel(const VMat A, const VMat B, const Persist P, const int M, const int N,
                                                                         const int K, const int nitems) {
     constexpr int BN = 128, VA = 4, VB = 4, MI = 2, NJ = 2;
@@ -898,11 +903,12 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_persist_kernel(const VMa
     float ra[GA::NREG], rb[GB::NREG];
     unsigned ma[GA::PASSES], mb[GB::PASSES];
 
-#define TXE_P_COMPUTE(cur_)                                                                                          \
+#define TXE_P_COMPUTE(cur_) TXE_P_COMPUTE_KB(cur_, GEMM_BK / 8)
+#define TXE_P_COMPUTE_KB(cur_, nkb_)                                                                                 \
     {                                                                                                                \
         const float* a_l = As + (cur_) * ASZ;                                                                        \
         const float* b_l = Bs + (cur_) * BSZ;                                                                        \
-        _Pragma("unroll") for (int kb = 0; kb < GEMM_BK / 8; ++kb) {                                                 \
+        _Pragma("unroll") for (int kb = 0; kb < (nkb_); ++kb) {                                                      \
             float fa[MI][4], fb[NJ][4];                                                                              \
             _Pragma("unroll") for (int i = 0; i < MI; ++i) frag_load<AK, GEMM_BM>(a_l, wm0 + i * 32, kb, fa[i]);     \
             _Pragma("unroll") for (int j = 0; j < NJ; ++j) frag_load<BKC, BN>(b_l, wn0 + j * 32, kb, fb[j]);         \
@@ -947,16 +953,18 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_persist_kernel(const VMa
     // of the current item's k-tile 0.
     int par = 0;
     int m0 = 0, n0 = 0, nki = 0, slice = -1;          // located item: tile origin, k-tiles, slice index (-1: a whole tile)
+    bool kend = true;                                 // ... and whether its k range ends at K (a whole tile, or a tile's last slice)
     FastPtr<AK, VA, GEMM_BM> fpa;
     FastPtr<BKC, VB, BN> fpb;
     auto locate = [&](const int item) {
         int lb, kb0;
-        if (DK == 8 || item < P.ntile_items) { lb = xcd_remap(item, P.ntile_items); kb0 = 0; nki = nk_all; slice = -1; }
+        if (DK == 8 || item < P.ntile_items) { lb = xcd_remap(item, P.ntile_items); kb0 = 0; nki = nk_all; slice = -1; kend = true; }
         else {                                        // (k-slices only with the 4-step drain schedule: a slice may be 5 k-tiles short)
             slice = item - P.ntile_items;
             lb = P.ntile_items + slice / P.S;
             kb0 = (slice % P.S) * P.kslice;
             nki = min(P.kslice, nk_all - kb0);
+            kend = kb0 + nki == nk_all;
         }
         const int tm = P.row_fast ? lb % nbm : lb / nbn, tn = P.row_fast ? lb / nbm : lb % nbn;
         m0 = tm * GEMM_BM; n0 = tn * BN;
@@ -974,6 +982,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_persist_kernel(const VMa
     __syncthreads();
     while (item < nitems) {
         const int cm0 = m0, cn0 = n0, cnk = nki, cslice = slice;
+        const bool ckend = kend;
 #pragma unroll
         for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -1004,9 +1013,19 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_persist_kernel(const VMa
         const int next = item + (int)gridDim.x;
         if (next < nitems) {                          // last k-tile: the loads in flight are the next item's first k-tile
             locate(next);
-            TXE_P_STEP(cnk - 1, TXE_P_NODRAIN)
+            if constexpr (LKB < GEMM_BK / 8) {        // (uniform branch; each side issues and consumes its own loads)
+                if (ckend) { TXE_P_STAGE((cnk + par) & 1, TXE_P_COMPUTE_KB((cnk - 1 + par) & 1, LKB), TXE_P_NODRAIN) __syncthreads(); }
+                else { TXE_P_STEP(cnk - 1, TXE_P_NODRAIN) }
+            } else {
+                TXE_P_STEP(cnk - 1, TXE_P_NODRAIN)
+            }
         } else {
-            TXE_P_COMPUTE((cnk - 1 + par) & 1)
+            if constexpr (LKB < GEMM_BK / 8) {
+                if (ckend) TXE_P_COMPUTE_KB((cnk - 1 + par) & 1, LKB)
+                else TXE_P_COMPUTE((cnk - 1 + par) & 1)
+            } else {
+                TXE_P_COMPUTE((cnk - 1 + par) & 1)
+            }
         }
 #pragma unroll
         for (int i = 0; i < MI; ++i)
@@ -1036,6 +1055,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_persist_kernel(const VMa
 #undef TXE_P_DRAIN
 #undef TXE_P_DRAIN_E
 #undef TXE_P_COMPUTE
+#undef TXE_P_COMPUTE_KB
 }
 
 static inline int gcd_vec(long long x) { return (x % 4 == 0) ? 4 : ((x % 2 == 0) ? 2 : 1); }
@@ -1192,14 +1212,26 @@ static inline int gemm_launch_layout(const VMat& A, const VMat& B, const Epi& E_
                 P.ntile_items = ntiles;
                 nitems = ntiles;
             }
-            static char names[2][48];                    // (per template instantiation of this launcher: one AK / BKC pair)
-            char* name = names[dk == 8];
-            if (!name[0]) snprintf(name, 48, "gemm_persist_kernel<%s, %s, %d>", AK ? "true" : "false", BKC ? "true" : "false", dk);
+            // zero padding behind k_valid: the last k-tile's groups of eight columns that hold data (NT products; 2 of 4 or nothing)
+            const int kv = (AK && BKC && E.k_valid > 0 && E.k_valid <= K) ? E.k_valid : K;
+            const int lkb = (kv - (K - GEMM_BK) <= 16 && kv > K - GEMM_BK) ? 2 : 4;
+            static char names[4][48];                    // (per template instantiation of this launcher: one AK / BKC pair)
+            char* name = names[(dk == 8) + 2 * (lkb == 2)];
+            if (!name[0]) snprintf(name, 48, lkb == 2 ? "gemm_persist_kernel<%s, %s, %d, 2>" : "gemm_persist_kernel<%s, %s, %d, 4>", AK ? "true" : "false", BKC ? "true" : "false", dk);
             const double all = E.alg_flops > 0.0 ? E.alg_flops : 2.0 * M * (double)N * K;
             const double share = (S >= 2 || nitems == ntiles) ? 1.0 : (double)nfull / (double)ntiles;
             {
                 ProfScope prof(name, stream, all * share, 0);
-                if (dk == 8) hipLaunchKernelGGL((gemm_persist_kernel<AK, BKC, 8>), dim3(slots), dim3(GEMM_THREADS), 0, stream, A, B, P, M, N, K, nitems);
+                bool launched = false;
+                if constexpr (AK && BKC) {
+                    if (lkb == 2) {
+                        if (dk == 8) hipLaunchKernelGGL((gemm_persist_kernel<AK, BKC, 8, 2>), dim3(slots), dim3(GEMM_THREADS), 0, stream, A, B, P, M, N, K, nitems);
+                        else hipLaunchKernelGGL((gemm_persist_kernel<AK, BKC, 4, 2>), dim3(slots), dim3(GEMM_THREADS), 0, stream, A, B, P, M, N, K, nitems);
+                        launched = true;
+                    }
+                }
+                if (launched) {}
+                else if (dk == 8) hipLaunchKernelGGL((gemm_persist_kernel<AK, BKC, 8>), dim3(slots), dim3(GEMM_THREADS), 0, stream, A, B, P, M, N, K, nitems);
                 else hipLaunchKernelGGL((gemm_persist_kernel<AK, BKC, 4>), dim3(slots), dim3(GEMM_THREADS), 0, stream, A, B, P, M, N, K, nitems);
                 TXE_CHECK_LAUNCH();
             }

@@ -745,6 +745,7 @@ int txe_gat_dense_fwd(const float* X, int n_nodes, int Kh, int Pd, const float* 
     VMat B = vmat_plain(Wp, Kp, Fp, Kp);
     Epi E = epi_plain(Y, Fp, Fe);
     E.alg_flops = 2.0 * n_nodes * (double)Fe * (Kh + Pd);           // without the k-tile padding of X / Wp
+    E.k_valid = Kh + Pd;                                             // (X and Wp carry zeros behind it: txe_gat_layers_prepare / pack_w)
     const bool tail_ok = ws && ws_bytes >= gemm_tail_ws_bytes();
     return gemm_nt(A, B, E, n_nodes, Fe, Kp, 1, (hipStream_t)stream, tail_ok ? ws : nullptr, tail_ok ? ws_bytes : 0);
 }

@@ -457,6 +457,36 @@ def test_gemm_whole_rounds_on_persistent_workgroups(layout, M, N, K):
     np.testing.assert_allclose(C.cpu().numpy(), ref, rtol=1e-4, atol=1e-4 * np.sqrt(K))
 
 
+@pytest.mark.parametrize("n_nodes", [17877, 9100])
+def test_first_layer_projection_skips_the_zero_padded_k_columns(n_nodes):
+    """txe_gat_dense_fwd on the MAG first layer's shape (K = 250 + 50 padded to 320, 2,008 output columns): the persistent kernel
+    runs only the two eight-column groups of the last k-tile that hold data (Epi.k_valid; whole tiles AND the k-slices of the
+    leftover tiles at 17,877 rows, the 8-k-tile drain schedule at 9,100) -- bit-identical to the same padded product through
+    txe_gemm_plain, which multiplies the zero columns as well; and against fp64"""
+    from taxoexpan_amd import _lib
+    dev = _dev()
+    Kh, Pd, H, D = 250, 50, 4, 500
+    Kp, Fe = _lib.call("txe_gat_padded_k", Kh, Pd), H * D + 2 * H
+    Fp = _lib.call("txe_gat_padded_f", H, D)
+    rs = np.random.RandomState(n_nodes)
+    X = torch.zeros(n_nodes, Kp, device=dev)
+    X[:, :Kh + Pd] = torch.from_numpy(rs.standard_normal((n_nodes, Kh + Pd)).astype(np.float32)).to(dev)
+    Wp = torch.zeros(Fp, Kp, device=dev)
+    Wp[:Fe, :Kh + Pd] = torch.from_numpy(rs.standard_normal((Fe, Kh + Pd)).astype(np.float32)).to(dev)
+    ws = torch.empty(max(_lib.call("txe_gemm_tail_ws_bytes"), _lib.call("txe_gat_dense_ws_bytes", n_nodes, Kh, Pd, H, D, 3)), dtype=torch.uint8,
+                     device=dev)
+    Y = torch.full((n_nodes, Fp), 3.0, device=dev)
+    _lib.call("txe_gat_dense_fwd", X.data_ptr(), n_nodes, Kh, Pd, Wp.data_ptr(), H, D, 0.0, None, Y.data_ptr(), ws.data_ptr(), ws.numel(),
+              _lib.stream_ptr())
+    C = torch.full((n_nodes, Fp), 5.0, device=dev)
+    _lib.call("txe_gemm_plain", 0, X.data_ptr(), Kp, Wp.data_ptr(), Kp, C.data_ptr(), Fp, n_nodes, Fe, Kp, 1, 0, ws.data_ptr(), ws.numel(),
+              _lib.stream_ptr())
+    torch.cuda.synchronize()
+    assert torch.equal(Y[:, :Fe], C[:, :Fe])
+    ref = X.double() @ Wp[:Fe].double().t()
+    np.testing.assert_allclose(Y[:, :Fe].cpu().numpy(), ref.cpu().numpy(), rtol=1e-4, atol=1e-4 * np.sqrt(Kh + Pd))
+
+
 def test_gemm_split_k_on_160_wide_tiles_against_fp64():
     """a big split-K TN product whose width 160-wide tiles cover with less padding (2080 = 13 x 160): the flat staging geometry and
     the register epilogue of gemm_kernel<false,false,4,4,160>, partial slices summed by the caller"""

@@ -311,7 +311,8 @@ int txe_gat_collapse_bwd(const int* rowptr_in, const int* col_src, const int* ro
  * the layers (1 = none).  Output instead of d_X: d_Yp [N][ld_dyp] = [d_ft | d_a1 | d_a2 | n_pad zeros]; dz_p [E][Hp] scratch.
  * phases: 15 = all of it; 1 | 2 | 4 | 8 = dZ GEMM | dW GEMM partials (independent of 1 and 4: a second stream may run it under the sweeps)
  * | sweeps + first reduction stage | final reductions -- separate calls share the workspace; 8 | 64 with a chain defers the final
- * reductions (see txe_gat_dense_bwd).
+ * reductions (see txe_gat_dense_bwd).  | 128 (on EVERY call of one backward pass: the workspace layout depends on it): the dW product
+ * runs beside other kernels on a second stream and is cut into at most 2 fat k-slices, which leave those kernels their wave slots.
  * txe_gat_fused_bwd_supported: 1 if the shape qualifies (Hp in {1,2,4}, Hp*Dp % 16 == 0, <= 128 columns behind the feature part). */
 int txe_gat_fused_bwd_supported(int Kh, int Pd, int Hp, int Dp);
 size_t txe_gat_collapse_bwd_fused_ws_bytes(int n_nodes, int n_edges, int G, int Kh, int Pd, int D, int vocab, int Hp);

@@ -1941,7 +1941,12 @@ struct CollapseWs {
     int splits, seg_blocks, seg_rows, chunks;
 };
 
-static CollapseWs plan_collapse_ws(void* ws, int n, int e, int G, int Kp, int D, int Pd, int vocab) {
+// phases | 128 of the folded layer's backward entries: the weight-gradient product runs on a second stream BESIDE the caller's dZ product
+// and sweeps (every call of one backward pass carries the bit: the workspace layout depends on it).  Few fat k-slices then -- 2 instead
+// of the 7 that fill the machine: ~140 workgroups leave the kernels on the caller's stream their wave slots (cl_bwd_dot 73 -> 61 us,
+// step -11 us on the 4,096-egonet batch) and the product still ends under the fused sweep (one slice: it does not -- sweep 139 -> 204 us)
+constexpr int DW_BESIDE_SPLITS = 2;
+static CollapseWs plan_collapse_ws(void* ws, int n, int e, int G, int Kp, int D, int Pd, int vocab, int max_splits = 0) {
     CollapseWs p;
     char* b = (char*)ws;
     size_t off = 0;
@@ -1949,6 +1954,7 @@ static CollapseWs plan_collapse_ws(void* ws, int n, int e, int G, int Kp, int D,
     const int n1 = n > 0 ? n : 1, v1 = vocab > 0 ? vocab : 1;
     p.dZ = take((size_t)(G > 0 ? G : 1) * Kp * 4);
     p.splits = choose_splits(D, Kp, G);
+    if (max_splits > 0 && p.splits > max_splits) p.splits = max_splits;
     p.part = take((size_t)p.splits * D * Kp * 4);
     p.chunks = (n + CL_CHUNK - 1) / CL_CHUNK;
     p.dwa_part = take((size_t)(p.chunks > 0 ? p.chunks : 1) * 2 * Kp * 4);
@@ -2129,9 +2135,9 @@ struct FusedWs {
     int nblocks, npw;
     size_t total;
 };
-static FusedWs plan_fused_ws(void* ws, int n, int e, int G, int Kp, int D, int Pd, int vocab, int Hp) {
+static FusedWs plan_fused_ws(void* ws, int n, int e, int G, int Kp, int D, int Pd, int vocab, int Hp, int max_splits = 0) {
     FusedWs f;
-    f.c = plan_collapse_ws(ws, n, e, G, Kp, D, Pd, vocab);
+    f.c = plan_collapse_ws(ws, n, e, G, Kp, D, Pd, vocab, max_splits);
     char* b = (char*)ws;
     size_t off = f.c.total;
     auto take = [&](size_t bytes) { float* r = (float*)(b + off); off += align_up(bytes > 0 ? bytes : 4, 256); return r; };
@@ -2186,7 +2192,7 @@ int txe_gat_collapse_bwd_fused(const int* rowptr_in, const int* col_src, const i
     if (feat_drop_p < 0.f || feat_drop_p >= 1.f || attn_drop_p < 0.f || attn_drop_p >= 1.f || attn_drop_p_p < 0.f || attn_drop_p_p >= 1.f)
         return TXE_ERR_ARG;
     const int Kt = Kh + Pd, Kp = round_up(Kt, 32), F = Hp * Dp;
-    FusedWs fw = plan_fused_ws(ws, n_nodes, n_edges, G, Kp, D, Pd, vocab, Hp);
+    FusedWs fw = plan_fused_ws(ws, n_nodes, n_edges, G, Kp, D, Pd, vocab, Hp, (phases & 128) ? DW_BESIDE_SPLITS : 0);
     CollapseWs& p = fw.c;
     if (ws_bytes < fw.total) return TXE_ERR_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;

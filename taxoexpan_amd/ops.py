@@ -530,14 +530,15 @@ def _gat_collapse_bwd_fused(csr, st, sp, pos, rpos, pw, vocab, feat_p, attn_p, a
     else:
         # the folded layer's weight-gradient GEMM (MFMA-bound, needs only d_hg and Z) runs on a second stream under the HBM-bound
         # sweeps: complementary resources, and nothing downstream waits for it before the final reduction
+        # (| 128 on every call: the product beside other kernels takes few fat k-slices, and the workspace is laid out for them)
         main, side = torch.cuda.current_stream(), _side_stream(st.X.device)
         _order(main, side)
         with torch.cuda.stream(side):
-            run(2)
-        run(1)
-        run(4)
+            run(2 | 128)
+        run(1 | 128)
+        run(4 | 128)
         _order(side, main)
-        run(last)
+        run(last | 128)
     return d_Yp, dW, dal, dar, dP, d_pw
 
 

@@ -825,7 +825,7 @@ def main():
                     "copy_ceiling_gbs": copy_bw / 1e9, "copy_ceiling_torch_gbs": copy_bw_torch / 1e9,
                     "pair_frac": pair["pair_frac"] if pair else None, "pair_kernel": pair["kernel"] if pair else None}
         for short, prefix in (("aggregate_fwd", "gat_aggregate_fwd_kernel"), ("fused_bwd", "gat_fused_bwd_kernel"),
-                              ("dx_pos", "gat_dx_pos_kernel"), ("bwd_dot", "cl_bwd_dot_kernel"), ("zsum", "cl_zsum")):
+                              ("dx_pos", "gat_dx_pos_kernel"), ("bwd_dot", "cl_bwd_dot"), ("zsum", "cl_zsum")):
             r = by_kernel(prefix)
             if r is not None:
                 roofline[f"hbm_{short}_frac"] = r["frac"]

@@ -1243,6 +1243,91 @@ __global__ __launch_bounds__(256) void cl_bwd_dot_kernel(int n_nodes, const int*
     }
 }
 
+// The same sweep with the node's WHOLE row in one round trip: NT tiles of 64 vectors per lane issued together (the tile loop above is
+// three dependent round trips for a 2,080-column row, behind the gid one).  Lanes past the row re-read its first tile (L1 hits) with a
+// zero factor; per lane the vectors are summed in the same ascending order: bit-identical.
+template <bool MASK, int NT>
+__global__ __launch_bounds__(256) void cl_bwd_dot_row_kernel(int n_nodes, const int* __restrict__ gid, const float* __restrict__ X, int Kp,
+                                                             const unsigned* __restrict__ mask, int mask_ld, float scale,
+                                                             const float* __restrict__ dZ, const float* __restrict__ wsum,
+                                                             const float* __restrict__ coef, float* __restrict__ dc, float* __restrict__ cn,
+                                                             const int nb_ds, const int G, const int D, const float* __restrict__ d_hg,
+                                                             const long long ld_dhg, const float* __restrict__ hg, const long long ld_hg,
+                                                             float* __restrict__ dS) {
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    if ((int)blockIdx.x < nb_ds) {                      // (the dS job of cl_bwd_dot_kernel)
+        const int g = blockIdx.x * 4 + w;
+        if (g >= G) return;
+        float s = 0.f;
+        for (int j = l; j < D; j += 64) s = fmaf(d_hg[(long long)g * ld_dhg + j], hg[(long long)g * ld_hg + j], s);
+        s = wave_sum(s);
+        if (l == 0) dS[g] = wsum[g] > 0.f ? -s / wsum[g] : 0.f;
+        return;
+    }
+    const int u = ((int)blockIdx.x - nb_ds) * 4 + w;
+    if (u >= n_nodes) return;
+    const int g = gid[u];
+    const float S = wsum[g];
+    const float cu = coef[u];
+    const int nvec = Kp >> 2;                           // (> 64: the launcher sends narrower rows to cl_bwd_dot_kernel)
+    const float* row = X + (long long)u * Kp;
+    const float* dzrow = dZ + (long long)g * Kp;
+    const unsigned* mrow = mask + (MASK ? (long long)u * mask_ld : 0);
+    float x[NT][4], d[NT][4], k4[NT][4];
+    // (the node's own row first and the gid-dependent dZ row behind it, in two loops: 61 against 55 us)
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+        const int j = l + 64 * i;
+        const int jc = (j < nvec) ? j : l;
+        vload<4>(row + jc * 4, x[i]);
+        vload<4>(dzrow + jc * 4, d[i]);
+        cl_keep4<MASK>(mrow, mask_ld, jc, k4[i]);
+        const float live = (j < nvec) ? 1.f : 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) k4[i][k] *= live;
+    }
+    float part = 0.f;
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) part = fmaf(d[i][k] * k4[i][k], x[i][k], part);
+    part = wave_sum(part);
+    if (l == 0) {
+        const float inv = S > 0.f ? 1.f / S : 0.f;
+        dc[u] = part * scale * inv;
+        cn[u] = cu * inv;
+    }
+}
+
+// launch of sweep 3: rows of 65..640 vectors go out in one round trip of 5, 9 or 10 tiles (cl_bwd_dot_row_kernel), anything else tile by tile
+static int cl_bwd_dot_launch(int n_nodes, const int* gid, const float* X, int Kp, const unsigned* mk, const unsigned* dummy_mask, int mask_ld, float fs,
+                             const float* dZ, const float* wsum, const float* coef, float* dc, float* cn, int nb_ds, int G, int D, const float* d_hg,
+                             long long ld_dhg, const float* hg, long long ld_hg, float* dS, double bytes, hipStream_t s) {
+    const int nb = (n_nodes + 3) / 4, nvec = Kp >> 2;
+    const int nt = (nvec > 64 && nvec <= 320) ? 5 : ((nvec > 320 && nvec <= 576) ? 9 : ((nvec > 576 && nvec <= 640) ? 10 : 0));
+    const unsigned* m = mk ? mk : dummy_mask;
+    const dim3 grid(nb_ds + nb);
+#define TXE_BD_ARGS n_nodes, gid, X, Kp, m, mask_ld, fs, dZ, wsum, coef, dc, cn, nb_ds, G, D, d_hg, ld_dhg, hg, ld_hg, dS
+    if (nt == 0) {
+        ProfScope prof(mk ? "cl_bwd_dot_kernel<true>" : "cl_bwd_dot_kernel<false>", s, bytes, 1);
+        if (mk) hipLaunchKernelGGL(cl_bwd_dot_kernel<true>, grid, dim3(256), 0, s, TXE_BD_ARGS);
+        else hipLaunchKernelGGL(cl_bwd_dot_kernel<false>, grid, dim3(256), 0, s, TXE_BD_ARGS);
+    } else {
+        static const char* names[6] = {"cl_bwd_dot_row_kernel<false, 5>", "cl_bwd_dot_row_kernel<true, 5>", "cl_bwd_dot_row_kernel<false, 9>",
+                                       "cl_bwd_dot_row_kernel<true, 9>", "cl_bwd_dot_row_kernel<false, 10>", "cl_bwd_dot_row_kernel<true, 10>"};
+        ProfScope prof(names[(mk ? 1 : 0) + (nt == 9 ? 2 : (nt == 10 ? 4 : 0))], s, bytes, 1);
+        if (nt == 5 && mk) hipLaunchKernelGGL((cl_bwd_dot_row_kernel<true, 5>), grid, dim3(256), 0, s, TXE_BD_ARGS);
+        else if (nt == 5) hipLaunchKernelGGL((cl_bwd_dot_row_kernel<false, 5>), grid, dim3(256), 0, s, TXE_BD_ARGS);
+        else if (nt == 9 && mk) hipLaunchKernelGGL((cl_bwd_dot_row_kernel<true, 9>), grid, dim3(256), 0, s, TXE_BD_ARGS);
+        else if (nt == 9) hipLaunchKernelGGL((cl_bwd_dot_row_kernel<false, 9>), grid, dim3(256), 0, s, TXE_BD_ARGS);
+        else if (mk) hipLaunchKernelGGL((cl_bwd_dot_row_kernel<true, 10>), grid, dim3(256), 0, s, TXE_BD_ARGS);
+        else hipLaunchKernelGGL((cl_bwd_dot_row_kernel<false, 10>), grid, dim3(256), 0, s, TXE_BD_ARGS);
+    }
+#undef TXE_BD_ARGS
+    TXE_CHECK_LAUNCH();
+    return TXE_OK;
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // The folded layer's edge-level work as ONE launch each way.  Everything here is tiny (a few bytes per edge) and stays inside a graph,
 // so a workgroup that owns CG_GRAPHS whole graphs can run the destination-side and the source-side halves back to back behind a
@@ -2076,16 +2161,10 @@ int txe_gat_collapse_bwd(const int* rowptr_in, const int* col_src, const int* ro
     const int S = G > 0 ? p.splits : 0;
     const int nblk = (G > 0 && n_nodes > 0) ? p.chunks : 0;
     if (G > 0 && n_nodes > 0) {
-        const int nb = (n_nodes + 3) / 4;
         const int ntile = (Kp / 4 + 63) / 64;
-        {
-            const int nb_ds = (G + 3) / 4;
-            ProfScope prof(mk ? "cl_bwd_dot_kernel<true>" : "cl_bwd_dot_kernel<false>", s, 4.0 * ((n_nodes + (double)G) * Kp + 2.0 * G * D), 1);
-            if (mk) hipLaunchKernelGGL(cl_bwd_dot_kernel<true>, dim3(nb_ds + nb), dim3(256), 0, s, n_nodes, gid, X, Kp, mk, mask_ld, fs,
-                                       (const float*)p.dZ, wsum, coef, p.dc, p.cn, nb_ds, G, D, d_hg, ld_dhg, hg, ld_hg, p.dS);
-            else hipLaunchKernelGGL(cl_bwd_dot_kernel<false>, dim3(nb_ds + nb), dim3(256), 0, s, n_nodes, gid, X, Kp, dummy_mask, mask_ld, fs,
-                                    (const float*)p.dZ, wsum, coef, p.dc, p.cn, nb_ds, G, D, d_hg, ld_dhg, hg, ld_hg, p.dS);
-        }
+        rc = cl_bwd_dot_launch(n_nodes, gid, X, Kp, mk, dummy_mask, mask_ld, fs, (const float*)p.dZ, wsum, coef, p.dc, p.cn, (G + 3) / 4, G, D, d_hg, ld_dhg,
+                               hg, ld_hg, p.dS, 4.0 * ((n_nodes + (double)G) * Kp + 2.0 * G * D), s);
+        if (rc) return rc;
         hipLaunchKernelGGL(cl_attn_bwd_kernel, dim3((G + CG_GRAPHS - 1) / CG_GRAPHS), dim3(256), 0, s, rowptr_in, col_src, rowptr_out, pos_out,
                            graph_off, G, a12, attn_slope, alpha, attn_drop_p, as, seed, pos, pw, (const float*)p.dc, (const float*)p.dS, p.dz,
                            p.da1, p.da2, p.dwv);
@@ -2223,15 +2302,10 @@ int txe_gat_collapse_bwd_fused(const int* rowptr_in, const int* col_src, const i
     const int S = G > 0 ? p.splits : 0;
     const int nblk = (G > 0 && n_nodes > 0) ? fw.nblocks : 0;
     if ((phases & 4) && G > 0 && n_nodes > 0) {
-        const int nb = (n_nodes + 3) / 4;
-        {
-            const int nb_ds = (G + 3) / 4;
-            ProfScope prof(mk ? "cl_bwd_dot_kernel<true>" : "cl_bwd_dot_kernel<false>", s, 4.0 * ((n_nodes + (double)G) * Kp + 2.0 * G * D), 1);
-            if (mk) hipLaunchKernelGGL(cl_bwd_dot_kernel<true>, dim3(nb_ds + nb), dim3(256), 0, s, n_nodes, gid, X, Kp, mk, mask_ld, fs,
-                                       (const float*)p.dZ, wsum, coef, p.dc, p.cn, nb_ds, G, D, d_hg, ld_dhg, hg, ld_hg, p.dS);
-            else hipLaunchKernelGGL(cl_bwd_dot_kernel<false>, dim3(nb_ds + nb), dim3(256), 0, s, n_nodes, gid, X, Kp, dummy_mask, mask_ld, fs,
-                                    (const float*)p.dZ, wsum, coef, p.dc, p.cn, nb_ds, G, D, d_hg, ld_dhg, hg, ld_hg, p.dS);
-        }
+
+        rc = cl_bwd_dot_launch(n_nodes, gid, X, Kp, mk, dummy_mask, mask_ld, fs, (const float*)p.dZ, wsum, coef, p.dc, p.cn, (G + 3) / 4, G, D, d_hg, ld_dhg,
+                               hg, ld_hg, p.dS, 4.0 * ((n_nodes + (double)G) * Kp + 2.0 * G * D), s);
+        if (rc) return rc;
         hipLaunchKernelGGL(cl_attn_bwd_kernel, dim3((G + CG_GRAPHS - 1) / CG_GRAPHS), dim3(256), 0, s, rowptr_in, col_src, rowptr_out, pos_out,
                            graph_off, G, a12, attn_slope, alpha, attn_drop_p, as, seed, pos, pw, (const float*)p.dc, (const float*)p.dS, p.dz,
                            p.da1, p.da2, p.dwv);
@@ -2479,15 +2553,10 @@ int txe_gcn_collapse_bwd(const int* rowptr_in, const int* col_src, const int* gr
         const int ntile = (Kp / 4 + 63) / 64;
         if (pw) {
             hipLaunchKernelGGL(cl_bwd_ds_kernel, dim3((G + 3) / 4), dim3(256), 0, s, G, Kp, (const float*)p.dZ, Z, wsum, p.dS);
-            {
-                ProfScope prof(mk ? "cl_bwd_dot_kernel<true>" : "cl_bwd_dot_kernel<false>", s, 4.0 * (n_nodes + (double)G) * Kp, 1);
-                // (the bias makes hg != Z W here, so dS keeps its own kernel: no leading dS workgroups)
-                if (mk) hipLaunchKernelGGL(cl_bwd_dot_kernel<true>, dim3(nb), dim3(256), 0, s, n_nodes, gid, X, Kp, mk, mask_ld, fs, (const float*)p.dZ,
-                                           wsum, coef, p.dc, p.cn, 0, 0, 0, (const float*)nullptr, 0LL, (const float*)nullptr, 0LL, (float*)nullptr);
-                else hipLaunchKernelGGL(cl_bwd_dot_kernel<false>, dim3(nb), dim3(256), 0, s, n_nodes, gid, X, Kp, dummy_mask, mask_ld, fs,
-                                        (const float*)p.dZ, wsum, coef, p.dc, p.cn, 0, 0, 0, (const float*)nullptr, 0LL, (const float*)nullptr, 0LL,
-                                        (float*)nullptr);
-            }
+            // (the bias makes hg != Z W here, so dS keeps its own kernel: no leading dS workgroups)
+            rc = cl_bwd_dot_launch(n_nodes, gid, X, Kp, mk, dummy_mask, mask_ld, fs, (const float*)p.dZ, wsum, coef, p.dc, p.cn, 0, 0, 0, nullptr, 0LL, nullptr,
+                                   0LL, nullptr, 4.0 * (n_nodes + (double)G) * Kp, s);
+            if (rc) return rc;
             hipLaunchKernelGGL(gcl_bwd_w_kernel, dim3(nb), dim3(256), 0, s, rowptr_in, col_src, n_nodes, norm, pos, pw, (const float*)p.dc,
                                (const float*)p.dS, gid, p.dwv);
         } else {

@@ -304,12 +304,15 @@ __global__ __launch_bounds__(GAT_WAVES * 64, TAB ? 3 : 1) void gat_aggregate_fwd
         static_assert(!TAB || NPW == 1, "the table route keeps one node per wave");
         // heads of the wave's NPW nodes, level by level (every level's loads are in flight together); the LDS staging above is in
         // flight beside them -- its barrier comes after
-        const int v0 = __builtin_amdgcn_readfirstlane((xcd_remap(blockIdx.x, gridDim.x) * GAT_WAVES + w) * NPW);
+        // (wave w takes nodes w, w + 4, ... of the workgroup's 4 NPW consecutive ones: the nodes the four waves sweep at the same time are
+        //  neighbours -- an egonet's siblings all gather the anchor's row -- and meet in the CU's L1 / one L2 miss; two neighbours per wave,
+        //  one after the other, fetched 42 MB more)
+        const int v0 = __builtin_amdgcn_readfirstlane(xcd_remap(blockIdx.x, gridDim.x) * GAT_WAVES * NPW + w);
         NodeHead hd[NPW];
         int vk[NPW];
 #pragma unroll
         for (int k = 0; k < NPW; ++k) {
-            vk[k] = min(v0 + k, n_nodes - 1);
+            vk[k] = min(v0 + k * GAT_WAVES, n_nodes - 1);
             hd[k].beg = rowptr[vk[k]];
             hd[k].end = rowptr[vk[k] + 1];
         }
@@ -338,8 +341,8 @@ __global__ __launch_bounds__(GAT_WAVES * 64, TAB ? 3 : 1) void gat_aggregate_fwd
         if constexpr (NX == 1 || NX == 2) __syncthreads();            // (every wave reaches this: none has left yet)
 #pragma unroll
         for (int k = 0; k < NPW; ++k) {
-            if (v0 + k < n_nodes) {
-                gat_fwd_node<VEC, NI, NX, TAB, true>(v0 + k, l, s_w[w], s_idx[w], s_stat[w], s_wa, rowptr, col, ft, ld_ft, a_src, a_dst, ld_a, H, D, slope,
+            if (v0 + k * GAT_WAVES < n_nodes) {
+                gat_fwd_node<VEC, NI, NX, TAB, true>(v0 + k * GAT_WAVES, l, s_w[w], s_idx[w], s_stat[w], s_wa, rowptr, col, ft, ld_ft, a_src, a_dst, ld_a, H, D, slope,
                                                      drop_p, drop_scale, seed, out_mode, act_slope, out, ld_out, alpha, nx, tab,
                                                      s_pos[TAB ? w : 0], s_t2, &hd[k]);
                 __builtin_amdgcn_wave_barrier();                       // the next node re-uses this wave's LDS slots

@@ -457,11 +457,11 @@ def test_gemm_whole_rounds_on_persistent_workgroups(layout, M, N, K):
     np.testing.assert_allclose(C.cpu().numpy(), ref, rtol=1e-4, atol=1e-4 * np.sqrt(K))
 
 
-@pytest.mark.parametrize("n_nodes", [17877, 9100])
+@pytest.mark.parametrize("n_nodes", [17877, 9100, 8192])
 def test_first_layer_projection_skips_the_zero_padded_k_columns(n_nodes):
     """txe_gat_dense_fwd on the MAG first layer's shape (K = 250 + 50 padded to 320, 2,008 output columns): the persistent kernel
     runs only the two eight-column groups of the last k-tile that hold data (Epi.k_valid; whole tiles AND the k-slices of the
-    leftover tiles at 17,877 rows, the 8-k-tile drain schedule at 9,100) -- bit-identical to the same padded product through
+    leftover tiles at 17,877 and 9,100 rows, the 8-k-tile drain schedule on the two whole rounds of 8,192) -- bit-identical to the same padded product through
     txe_gemm_plain, which multiplies the zero columns as well; and against fp64"""
     from taxoexpan_amd import _lib
     dev = _dev()

@@ -223,6 +223,18 @@ int txe_bilinear_stacked_bwd(const float* e1, long long ld_e1, const float* e2, 
                              int l, int r, int apply_exp, const float* V, const float* s, const float* ds, float* d_e1, long long ld_de1,
                              float* dW, void* ws, size_t ws_bytes, void* stream);
 
+/* The same match FOLDED through the encoder's output layer (model.py:86 on model_zoo.py:313/328 behind :227-242 and the last GATLayer):
+ * with hg = Z Wf^T (txe_gat_collapse_fwd, hg == NULL) the score is s_i = <Z_i, T[u(i)]>, T[u] = Wf^T (Wm q_u) -- the D x Kp product runs on
+ * the U run rows instead of the G graph rows, forward and backward (dZ_i = dsl_i T[u(i)]; dT[u] = sum dsl_i Z_i; dV = dT Wf^T; dWf = V^T dT,
+ * handed to txe_gat_collapse_bwd_fused as dw_main; dWm = dV^T Q).  Runs as in txe_bilinear_runs_* (first_row 0, n_runs NULL, Q = the U
+ * distinct rows) or txe_bilinear_stacked_* (first_row 1, the count on the device, U = G sizes V [U][l], T / dT [U][Kp], dV [U][l]). */
+int txe_bilinear_folded_fwd(const float* Z, long long ld_z, int G, int Kp, const float* Wf, long long ld_wf, int l, const float* Q, long long ld_q,
+                            int r, const int* run_off, const int* n_runs, int U, int first_row, const float* Wm, int apply_exp, float* V, float* T,
+                            float* s, void* stream);
+int txe_bilinear_folded_bwd(const float* Z, long long ld_z, int G, int Kp, const float* Wf, long long ld_wf, int l, const float* Q, long long ld_q,
+                            int r, const int* run_off, const int* n_runs, int U, int first_row, int apply_exp, const float* V, const float* T,
+                            const float* s, const float* ds, float* dZ, long long ld_dz, float* dT, float* dV, float* dWm, float* dWf, void* stream);
+
 /* nn.Linear over the (virtual) concat of two inputs + activation (0 none / 1 relu / 2 tanh): the MLP matcher, model_zoo.py:285-298 */
 int txe_linear_fwd(const float* x1, long long ld1, int l, const float* x2, long long ld2, int r, int G, const float* W, const float* b,
                    int O, int act, float* y, void* stream);
@@ -313,6 +325,9 @@ int txe_gat_collapse_bwd(const int* rowptr_in, const int* col_src, const int* ro
  * | sweeps + first reduction stage | final reductions -- separate calls share the workspace; 8 | 64 with a chain defers the final
  * reductions (see txe_gat_dense_bwd).  | 128 (on EVERY call of one backward pass: the workspace layout depends on it): the dW product
  * runs beside other kernels on a second stream and is cut into at most 2 fat k-slices, which leave those kernels their wave slots.
+ * | 256: the caller folded hg = Z W^T into the consumer of Z (txe_bilinear_folded_*; txe_gat_collapse_fwd with hg == NULL stops at Z):
+ * `d_hg` IS dZ [G][Kp] (ld_dhg == Kp), hg may be NULL, phases 1 and 2 do not run, and the main part of dW comes from the caller as
+ * dw_slices slices [D][Kp] at dw_main (summed in order; 0 slices: none) -- this call adds the attention rows' part.
  * txe_gat_fused_bwd_supported: 1 if the shape qualifies (Hp in {1,2,4}, Hp*Dp % 16 == 0, <= 128 columns behind the feature part). */
 int txe_gat_fused_bwd_supported(int Kh, int Pd, int Hp, int Dp);
 size_t txe_gat_collapse_bwd_fused_ws_bytes(int n_nodes, int n_edges, int G, int Kh, int Pd, int D, int vocab, int Hp);
@@ -325,7 +340,7 @@ int txe_gat_collapse_bwd_fused(const int* rowptr_in, const int* col_src, const i
                                float act_slope, const float* Yp, long long ld_yp, int Hp, int Dp, float attn_slope_p,
                                float attn_drop_p_p, unsigned long long seed_p, const float* alpha_p, float* d_Yp, long long ld_dyp,
                                int n_pad, float* dz_p, float* dW, float* d_attn_l, float* d_attn_r, float* dP, float* d_pw, int phases,
-                               void* chain, void* ws, size_t ws_bytes, void* stream);
+                               const float* dw_main, int dw_slices, void* chain, void* ws, size_t ws_bytes, void* stream);
 
 /* ---- output GCNLayer folded behind MeanReadout / WeightedMeanReadout: model_zoo.py:35-47,139-167,227-242.
  * hg[g] = (sum_{u in g} c_u Xd[u]) W + b with c_u = norm_u sum_{v: u->v} w_v norm_v / S_g (graph constants).  X / Wp / mask as for

@@ -303,6 +303,46 @@ __global__ __launch_bounds__(256) void runs_dw_kernel(const float* __restrict__ 
     }
 }
 
+// T[u][c] = sum_j V[u][j] Wf[j][c]: the run's projected query pushed through the FOLDED output layer (txe_bilinear_folded_*): thread =
+// column c (rows of Wf read coalesced), eight runs per workgroup pass, their V rows staged in LDS; j ascending: deterministic
+__global__ __launch_bounds__(256) void runs_fold_kernel(const float* __restrict__ V, const float* __restrict__ Wf, long long ld_wf, const RunsRef R,
+                                                        int l, int Kp, float* __restrict__ T) {
+    __shared__ float sV[8][512];
+    const int c = blockIdx.x * 256 + threadIdx.x, cc = min(c, Kp - 1);
+    const int U = runs_count(R);
+    for (int u0 = blockIdx.y * 8; u0 < U; u0 += 8 * gridDim.y) {
+        float acc[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) acc[q] = 0.f;
+        for (int j0 = 0; j0 < l; j0 += 512) {
+            __syncthreads();
+            for (int i = threadIdx.x; i < 8 * 512; i += 256) {
+                const int q = i >> 9, j = j0 + (i & 511);
+                sV[q][i & 511] = (j < l) ? V[(long long)min(u0 + q, U - 1) * l + j] : 0.f;
+            }
+            __syncthreads();
+            const int nj = min(512, l - j0);
+            for (int j = 0; j < nj; j += 8) {                   // eight rows of Wf in flight (clamped: their V factors are 0)
+                float wv[8];
+#pragma unroll
+                for (int t = 0; t < 8; ++t) wv[t] = Wf[(long long)min(j0 + j + t, l - 1) * ld_wf + cc];
+#pragma unroll
+                for (int t = 0; t < 8; ++t) {
+                    const int jj = min(j + t, 511);
+                    const float live = (j + t < nj) ? 1.f : 0.f;
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) acc[q] = fmaf(sV[q][jj] * live, wv[t], acc[q]);
+                }
+            }
+        }
+        if (c < Kp) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                if (u0 + q < U) T[(long long)(u0 + q) * Kp + c] = acc[q];
+        }
+    }
+}
+
 static inline size_t mt_align(size_t x) { return (x + 255) / 256 * 256; }
 
 static inline int mt_splits(int M, int N, int K) { return choose_splits(M, N, K); }
@@ -551,6 +591,74 @@ int txe_bilinear_stacked_bwd(const float* e1, long long ld_e1, const float* e2, 
     const RunsRef R{run_off, n_runs, G, 1};
     const int gx = G < 512 ? G : 512;
     return runs_bwd_launch(e1, ld_e1, e2, ld_e2, R, gx, G, l, r, apply_exp, V, s, ds, d_e1, ld_de1, dW, (float*)ws, st);
+}
+
+// The pairwise bilinear match FOLDED through the output layer of the encoder (the graph vector hg = Z Wf^T of txe_gat_collapse_fwd, never
+// formed):  s_i = hg_i^T Wm q_i = <Z_i, T[u(i)]>,  T[u] = Wf^T (Wm q_u)  -- when the query rows repeat in runs, the D x Kp product runs
+// on U run rows instead of G graph rows (a training batch: 128 instead of 4,096), forward and both backward products.
+//   Z [G][Kp] (row pitch ld_z), Wf [l][Kp] (the packed weight rows, pitch ld_wf), Wm [l][r];  runs as in txe_bilinear_runs_* (first_row 0:
+//   Q = the U distinct rows, n_runs NULL) or txe_bilinear_stacked_* (first_row 1: Q = the stacked matrix, n_runs on the device, U = G bounds
+//   the buffers).  V [U][l], T [U][Kp] are kept for backward.
+int txe_bilinear_folded_fwd(const float* Z, long long ld_z, int G, int Kp, const float* Wf, long long ld_wf, int l, const float* Q, long long ld_q,
+                            int r, const int* run_off, const int* n_runs, int U, int first_row, const float* Wm, int apply_exp, float* V, float* T,
+                            float* s, void* stream) {
+    if (G < 0 || U < 0 || Kp < 1 || l < 1 || r < 1 || !Z || !Wf || !Q || !run_off || !Wm || !V || !T || !s || (first_row && !n_runs)) return TXE_ERR_ARG;
+    if (G == 0 || U == 0) return TXE_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const RunsRef R{run_off, n_runs, U, first_row ? 1 : 0};
+    const RunsRef Rc{run_off, n_runs, U, 0};                       // the same runs, compact rows (V, T)
+    const int gx = n_runs ? (G < 512 ? G : 512) : U, gy = n_runs ? 32 : (U + 7) / 8;
+    {
+        ProfScope prof("runs_project_kernel", st, 4.0 * ((double)U * r + (double)l * r + (double)U * l), 1);
+        hipLaunchKernelGGL(runs_project_kernel, dim3((l + 3) / 4, gy), dim3(256), 0, st, Q, ld_q, Wm, R, l, r, V);
+    }
+    {
+        ProfScope prof("runs_fold_kernel", st, 4.0 * ((double)U * l + (double)l * Kp + (double)U * Kp), 1);
+        hipLaunchKernelGGL(runs_fold_kernel, dim3((Kp + 255) / 256, gy < 16 ? gy : 16), dim3(256), 0, st, (const float*)V, Wf, ld_wf, Rc, l, Kp, T);
+    }
+    {
+        ProfScope prof("rowdot_runs_kernel", st, 4.0 * ((double)G * Kp + (double)U * Kp + G), 1);
+        hipLaunchKernelGGL(rowdot_runs_kernel, dim3(gx, 8), dim3(256), 0, st, Z, ld_z, (const float*)T, Rc, Kp, apply_exp, s);
+    }
+    TXE_CHECK_LAUNCH();
+    return TXE_OK;
+}
+
+//   dZ_i = dsl_i T[u(i)],  dT[u] = sum_{i in u} dsl_i Z_i,  dV = dT Wf^T,  dWf = V^T dT [l][Kp] (the main part of the output layer's weight
+//   gradient: txe_gat_collapse_bwd_fused adds the attention rows' part),  dWm = dV^T Q.  dT [U][Kp], dV [U][l]: scratch.
+int txe_bilinear_folded_bwd(const float* Z, long long ld_z, int G, int Kp, const float* Wf, long long ld_wf, int l, const float* Q, long long ld_q,
+                            int r, const int* run_off, const int* n_runs, int U, int first_row, int apply_exp, const float* V, const float* T,
+                            const float* s, const float* ds, float* dZ, long long ld_dz, float* dT, float* dV, float* dWm, float* dWf, void* stream) {
+    if (G < 0 || U < 0 || Kp < 1 || l < 1 || r < 1 || !Z || !Wf || !Q || !run_off || !V || !T || !s || !ds || !dZ || !dT || !dV || !dWm || !dWf ||
+        (first_row && !n_runs) || ld_wf != Kp)
+        return TXE_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    if (G == 0 || U == 0) {
+        if (hipMemsetAsync(dWm, 0, (size_t)l * r * sizeof(float), st) != hipSuccess) return TXE_ERR_LAUNCH;
+        if (hipMemsetAsync(dWf, 0, (size_t)l * Kp * sizeof(float), st) != hipSuccess) return TXE_ERR_LAUNCH;
+        return TXE_OK;
+    }
+    const RunsRef R{run_off, n_runs, U, first_row ? 1 : 0};
+    const RunsRef Rc{run_off, n_runs, U, 0};
+    const int gx = n_runs ? (G < 512 ? G : 512) : U, gy = n_runs ? 32 : (U + 7) / 8;
+    {
+        ProfScope prof("runs_bwd_kernel", st, 4.0 * (2.0 * G * Kp + 2.0 * U * Kp + 2.0 * G), 1);
+        hipLaunchKernelGGL(runs_bwd_kernel, dim3(gx, (Kp + 255) / 256), dim3(256), 0, st, ds, s, apply_exp, T, Z, ld_z, Rc, Kp, dZ, ld_dz, dT);
+    }
+    {   // dV[u][j] = <dT[u], Wf[j]>  (Wf's rows have pitch Kp: the kernel's row length)
+        ProfScope prof("runs_project_kernel", st, 4.0 * ((double)U * Kp + (double)l * Kp + (double)U * l), 1);
+        hipLaunchKernelGGL(runs_project_kernel, dim3((l + 3) / 4, gy), dim3(256), 0, st, (const float*)dT, (long long)Kp, Wf, Rc, l, Kp, dV);
+    }
+    {   // dWm[j][k] = sum_u dV[u][j] q_u[k]
+        ProfScope prof("runs_dw_kernel", st, 4.0 * ((double)U * l + (double)U * r + (double)l * r), 1);
+        hipLaunchKernelGGL(runs_dw_kernel, dim3((l + 1) / 2, (r + 255) / 256), dim3(256), 0, st, (const float*)dV, Q, ld_q, R, l, r, dWm);
+    }
+    {   // dWf[j][c] = sum_u V[u][j] dT[u][c]
+        ProfScope prof("runs_dw_kernel", st, 4.0 * ((double)U * l + (double)U * Kp + (double)l * Kp), 1);
+        hipLaunchKernelGGL(runs_dw_kernel, dim3((l + 1) / 2, (Kp + 255) / 256), dim3(256), 0, st, V, (const float*)dT, (long long)Kp, Rc, l, Kp, dWf);
+    }
+    TXE_CHECK_LAUNCH();
+    return TXE_OK;
 }
 
 int txe_topk_merge(const float* keys, const int* idx, int nq, long long cnt, int k, int idx_base, int* out_idx, float* out_key, void* stream);

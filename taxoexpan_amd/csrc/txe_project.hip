@@ -2079,7 +2079,7 @@ int txe_gat_collapse_fwd(const int* rowptr_in, const int* col_src, const int* ro
                          const int* pos, const float* pw, float* a12, int a12_ready, float* alpha, float* coef, float* wsum, int* gid,
                          float* Z, float* hg, long long ld_hg, void* ws, size_t ws_bytes, void* stream) {
     if (n_nodes < 0 || n_edges < 0 || G < 0 || Kh < 1 || Pd < 0 || D < 1 || !rowptr_in || !rowptr_out || !graph_off || !X || !Wp || !a12 ||
-        !alpha || !coef || !wsum || !gid || !Z || !hg || !ws || (pw && !pos))
+        !alpha || !coef || !wsum || !gid || !Z || !ws || (pw && !pos))
         return TXE_ERR_ARG;
     if (feat_drop_p < 0.f || feat_drop_p >= 1.f || attn_drop_p < 0.f || attn_drop_p >= 1.f) return TXE_ERR_ARG;
     const int Kt = Kh + Pd, Kp = round_up(Kt, 32);
@@ -2107,6 +2107,7 @@ int txe_gat_collapse_fwd(const int* rowptr_in, const int* col_src, const int* ro
     }
     const int rc_z = cl_zsum_launch(graph_off, G, n_nodes, X, Kp, mk, dummy_mask, mask_ld, fs, (const float*)coef, (const float*)wsum, Z, s);
     if (rc_z) return rc_z;
+    if (!hg) return TXE_OK;          // (the caller folds hg = Z W^T into what consumes it: txe_bilinear_folded_*)
     VMat A = vmat_plain(Z, Kp, G, Kp);
     VMat B = vmat_plain(Wp, Kp, round_up(D + 2, 128), Kp);       // all Fp packed rows are readable: every tile stays on the plain loader
     Epi E = epi_plain(hg, ld_hg, D);
@@ -2260,10 +2261,13 @@ int txe_gat_collapse_bwd_fused(const int* rowptr_in, const int* col_src, const i
                                float act_slope, const float* Yp, long long ld_yp, int Hp, int Dp, float attn_slope_p,
                                float attn_drop_p_p, unsigned long long seed_p, const float* alpha_p, float* d_Yp, long long ld_dyp,
                                int n_pad, float* dz_p, float* dW, float* d_attn_l, float* d_attn_r, float* dP, float* d_pw, int phases,
-                               void* chain, void* ws, size_t ws_bytes, void* stream) {
+                               const float* dw_main, int dw_slices, void* chain, void* ws, size_t ws_bytes, void* stream) {
+    // phases | 256: `d_hg` IS dZ [G][Kp] (ld_dhg its row pitch) -- whoever consumed Z folded hg = Z W^T into its own product
+    // (txe_bilinear_folded_*) and hands back dZ and the main part of dW as dw_slices slices [D][Kp] at dw_main (summed in order; 0: none)
+    const bool dz_given = (phases & 256) != 0;
     if (n_nodes < 0 || n_edges < 0 || G < 0 || Kh < 1 || Pd < 0 || D < 1 || !rowptr_in || !rowptr_out || !graph_off || !X || !Wp || !W ||
-        !attn_l || !attn_r || !a12 || !alpha || !coef || !wsum || !gid || !Z || !hg || !d_hg || !dW || !d_attn_l || !d_attn_r || !ws ||
-        !Yp || !alpha_p || !d_Yp || !dz_p || n_pad < 0)
+        !attn_l || !attn_r || !a12 || !alpha || !coef || !wsum || !gid || !Z || (!hg && !dz_given) || !d_hg || !dW || !d_attn_l || !d_attn_r ||
+        !ws || !Yp || !alpha_p || !d_Yp || !dz_p || n_pad < 0 || dw_slices < 0 || (dw_slices > 0 && !dw_main))
         return TXE_ERR_ARG;
     if (!txe_gat_fused_bwd_supported(Kh, Pd, Hp, Dp)) return TXE_ERR_ARG;
     if ((Pd > 0 || pw) && (!pos || vocab < 1 || vocab > MAX_VOCAB)) return TXE_ERR_ARG;
@@ -2281,6 +2285,10 @@ int txe_gat_collapse_bwd_fused(const int* rowptr_in, const int* col_src, const i
     const float* wa = Wp + (long long)D * Kp;
     const unsigned* dummy_mask = reinterpret_cast<const unsigned*>(X);
     int rc;
+    if (dz_given) phases &= ~3;
+    const float* const dZv = dz_given ? d_hg : (const float*)p.dZ;
+    const long long ld_dz = dz_given ? ld_dhg : (long long)Kp;
+    if (dz_given && ld_dz != Kp) return TXE_ERR_ARG;               // (the sweeps walk dZ rows with the padded pitch)
     if (phases & 1) {   // dZ = d_hg W
         VMat A = vmat_plain(d_hg, ld_dhg, G, D);
         VMat B = vmat_plain(Wp, Kp, D, Kp);
@@ -2299,12 +2307,14 @@ int txe_gat_collapse_bwd_fused(const int* rowptr_in, const int* col_src, const i
         rc = gemm_tn(A, B, E, D, Kp, G, p.splits, s);
         if (rc) return rc;
     }
-    const int S = G > 0 ? p.splits : 0;
+    const int S = dz_given ? dw_slices : (G > 0 ? p.splits : 0);
+    const float* const partv = dz_given ? dw_main : (const float*)p.part;
     const int nblk = (G > 0 && n_nodes > 0) ? fw.nblocks : 0;
     if ((phases & 4) && G > 0 && n_nodes > 0) {
 
-        rc = cl_bwd_dot_launch(n_nodes, gid, X, Kp, mk, dummy_mask, mask_ld, fs, (const float*)p.dZ, wsum, coef, p.dc, p.cn, (G + 3) / 4, G, D, d_hg, ld_dhg,
-                               hg, ld_hg, p.dS, 4.0 * ((n_nodes + (double)G) * Kp + 2.0 * G * D), s);
+        // (dS[g] = -<dZ[g], Z[g]> / S_g; with d_hg at hand it is <d_hg[g], hg[g]>, D columns instead of Kp)
+        rc = cl_bwd_dot_launch(n_nodes, gid, X, Kp, mk, dummy_mask, mask_ld, fs, dZv, wsum, coef, p.dc, p.cn, (G + 3) / 4, G, dz_given ? Kp : D,
+                               d_hg, ld_dhg, dz_given ? Z : hg, dz_given ? (long long)Kp : ld_hg, p.dS, 4.0 * ((n_nodes + (double)G) * Kp + 2.0 * G * D), s);
         if (rc) return rc;
         hipLaunchKernelGGL(cl_attn_bwd_kernel, dim3((G + CG_GRAPHS - 1) / CG_GRAPHS), dim3(256), 0, s, rowptr_in, col_src, rowptr_out, pos_out,
                            graph_off, G, a12, attn_slope, alpha, attn_drop_p, as, seed, pos, pw, (const float*)p.dc, (const float*)p.dS, p.dz,
@@ -2314,7 +2324,7 @@ int txe_gat_collapse_bwd_fused(const int* rowptr_in, const int* col_src, const i
             memset(&a, 0, sizeof(a));
             a.rowptr_out = rowptr_out; a.col_dst = col_dst; a.pos_out = pos_out; a.gid = gid; a.pos = pos ? pos : gid; a.n_nodes = n_nodes;
             a.X = X; a.Kp = Kp; a.Kh = Kh; a.Pd = Pd; a.mask = mk ? mk : dummy_mask; a.mask_ld = mask_ld; a.fscale = fs;
-            a.dZ = p.dZ; a.cn = p.cn; a.da1 = p.da1; a.da2 = p.da2; a.wa = wa; a.act_slope = act_slope; a.vocab = vocab > 0 ? vocab : 1;
+            a.dZ = dZv; a.cn = p.cn; a.da1 = p.da1; a.da2 = p.da2; a.wa = wa; a.act_slope = act_slope; a.vocab = vocab > 0 ? vocab : 1;
             a.Y = Yp; a.ld_y = ld_yp; a.H = Hp; a.D = Dp; a.alpha = alpha_p; a.drop_p = attn_drop_p_p;
             a.drop_scale = 1.f / (1.f - attn_drop_p_p); a.seed = seed_p;
             a.d_Y = d_Yp; a.ld_dy = ld_dyp; a.dal = fw.dal; a.dwa_part = fw.dwa_part; a.ppart = fw.ppart;
@@ -2357,7 +2367,7 @@ int txe_gat_collapse_bwd_fused(const int* rowptr_in, const int* col_src, const i
     TailB tb;
     memset(&tb, 0, sizeof(tb));
     tb.nb_u = D;
-    tb.u = UnfoldArgs{p.part, S, split_stride, p.dwa, (long long)Kp, W, (long long)Kt, attn_l, attn_r, 1, D, Kt, dW, (long long)Kt, d_attn_l,
+    tb.u = UnfoldArgs{partv, S, split_stride, p.dwa, (long long)Kp, W, (long long)Kt, attn_l, attn_r, 1, D, Kt, dW, (long long)Kt, d_attn_l,
                       d_attn_r};
     tb.nb_2a = Pd > 0 ? (vocab * Pd + 63) / 64 : 0;
     tb.s2a = Seg2Args{fw.ppart, nblk, vocab * Pd, dP};

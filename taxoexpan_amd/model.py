@@ -55,7 +55,12 @@ class TaxoExpan(torch.nn.Module):
         positions = g.ndata['pos'].to(h.device)
         if hasattr(self.match, "prefetch"):         # the matcher's query-side projection runs under the encoder (second stream)
             self.match.prefetch(qf)
-        g.ndata['h'] = self.graph_propagate(g, h)
+        out = self.graph_propagate(g, h)
+        # a bilinear matcher on query rows that repeat takes the graph vector FOLDED: the readout then stops at Z and the output
+        # layer's product runs on one row per query run inside the matcher (zoo.DeferredGraphVector; same arithmetic, re-associated)
+        if isinstance(out, zoo.DeferredNodeOutput) and getattr(self.match, "wants_folded_graph_vector", None) is not None:
+            out._want_folded = self.match.wants_folded_graph_vector(qf)
+        g.ndata['h'] = out
         return self.match(self.readout(g, positions), qf)
 
     def __str__(self):

@@ -156,6 +156,7 @@ class DeferredNodeOutput:
         self._args = (csr, cfg, h, pos, params)
         self._fn = fn
         self._tensor = None
+        self._want_folded = False                   # TaxoExpan.forward: the matcher can take the graph vector folded (DeferredGraphVector)
 
     def _out_dim(self):
         return self._args[1].out_dims[-1]
@@ -166,6 +167,12 @@ class DeferredNodeOutput:
         if csr.n_nodes == 0 or csr.n_graphs == 0:       # empty batch: nothing to launch
             return h.new_zeros((csr.n_graphs, self._out_dim()), dtype=torch.float32)
         c = copy.copy(cfg)
+        if (self._want_folded and self._fn is ops.GATStackFunction and torch.is_grad_enabled() and ops.folded_graph_vector_ok(csr, cfg)):
+            # the stack stops at Z [G, Kp]; hg = Z W^T is formed by whoever asks for the tensor -- or never (_Bilinear on repeating queries)
+            c.final = "collapse_z"
+            c.link = ops.FoldLink()
+            Z, Wp = ops.apply_stack(self._fn, csr, c, h, pos, rpos, pw, *params)
+            return DeferredGraphVector(Z, Wp, c.link, self._out_dim())
         c.final = "collapse"
         return ops.apply_stack(self._fn, csr, c, h, pos, rpos, pw, *params)
 
@@ -192,13 +199,50 @@ class DeferredNodeOutput:
     @classmethod
     def __torch_function__(cls, func, types, args=(), kwargs=None):
         from torch.utils._pytree import tree_map
-        un = lambda a: a.tensor() if isinstance(a, DeferredNodeOutput) else a
+        un = lambda a: a.tensor() if isinstance(a, (DeferredNodeOutput, DeferredGraphVector)) else a
         return func(*tree_map(un, tuple(args)), **tree_map(un, dict(kwargs or {})))
+
+
+class DeferredGraphVector:
+    """What MeanReadout / WeightedMeanReadout return when TaxoExpan.forward announced a matcher that can take the graph vector FOLDED:
+    hg [G, D] = Z W^T of a 'collapse_z' stack, not yet formed.  _Bilinear on repeating query rows consumes (Z, Wp) directly -- the
+    output layer's D x Kp product then runs on one row per query run instead of one per egonet (ops.BilinearFoldedRunsFunction; same
+    arithmetic, re-associated).  Every other use materialises the ordinary tensor once (ops.FoldedGraphLinearFunction)."""
+
+    def __init__(self, Z, Wp, link, D):
+        self._z, self._wp, self._link, self._d = Z, Wp, link, D
+        self._tensor = None
+
+    @property
+    def shape(self):
+        return torch.Size((self._z.shape[0], self._d))
+
+    def folded(self):
+        """(Z, Wp, link, D) if the tensor has not been asked for yet, else None"""
+        return None if self._tensor is not None else (self._z, self._wp, self._link, self._d)
+
+    def tensor(self):
+        if self._tensor is None:
+            self._tensor = ops.FoldedGraphLinearFunction.apply(self._z, self._wp, self._link, self._d)
+        return self._tensor
+
+    def __getattr__(self, name):
+        if name.startswith("_"):
+            raise AttributeError(name)
+        return getattr(self.tensor(), name)
+
+    def __getitem__(self, idx):
+        return self.tensor()[idx]
+
+    def __len__(self):
+        return self._z.shape[0]
+
+    __torch_function__ = DeferredNodeOutput.__dict__["__torch_function__"]
 
 
 def _delegate(name):
     def op(self, *args):
-        return getattr(self.tensor(), name)(*[a.tensor() if isinstance(a, DeferredNodeOutput) else a for a in args])
+        return getattr(self.tensor(), name)(*[a.tensor() if isinstance(a, (DeferredNodeOutput, DeferredGraphVector)) else a for a in args])
     op.__name__ = name
     return op
 
@@ -206,7 +250,9 @@ def _delegate(name):
 for _n in ("__add__", "__radd__", "__sub__", "__rsub__", "__mul__", "__rmul__", "__truediv__", "__rtruediv__", "__matmul__", "__rmatmul__",
            "__neg__", "__pow__", "__eq__", "__ne__", "__lt__", "__le__", "__gt__", "__ge__", "__iter__", "__repr__", "__bool__"):
     setattr(DeferredNodeOutput, _n, _delegate(_n))
+    setattr(DeferredGraphVector, _n, _delegate(_n))
 DeferredNodeOutput.__hash__ = object.__hash__
+DeferredGraphVector.__hash__ = object.__hash__
 
 
 def _node_features(g):
@@ -440,6 +486,15 @@ class _Bilinear(nn.Module):
         """e1 (*, l_dim), e2 (*, r_dim) -> (*, 1)"""
         if e1.shape[0] == 0:                               # empty batch
             return e1.new_zeros((0, 1), dtype=torch.float32)
+        if isinstance(e1, DeferredGraphVector):            # the graph vector still folded: hg = Z W^T (TaxoExpan.forward asked for it)
+            fz = e1.folded()
+            if fz is not None and self._runs_form(e1, e2) == "rows":
+                self._pre = None
+                return ops.BilinearFoldedRunsFunction.apply(fz[0], fz[1], fz[2], fz[3], self.W.weight, self.apply_exp, None, e2.rows, e2.run_off)
+            if fz is not None and self._runs_form(e1, e2) == "stacked":
+                self._pre = None
+                return ops.BilinearFoldedRunsFunction.apply(fz[0], fz[1], fz[2], fz[3], self.W.weight, self.apply_exp, e2, None, None)
+            e1 = e1.tensor()
         if isinstance(e2, ops.RepeatedRows):               # query rows that repeat in runs: U rows projected instead of G
             if e2.requires_grad or e2.n_rows != e1.shape[0] or 4 * e2.rows.shape[0] > e2.n_rows:     # (hardly any repetition: the GEMM form)
                 e2 = e2.dense()
@@ -450,11 +505,28 @@ class _Bilinear(nn.Module):
             # the eval loop's `nf.expand(n_position, -1)` (test_fast.py:122-123): one query against all candidates
             U = ops.bilinear_project(e1, self.W.weight)
             return ops.score_block(e2[:1], U, self.apply_exp).reshape(-1, 1)
-        if self._stacked_runs_ok(e1, e2) and self._repeats(e2):
+        dec = self.__dict__.get("_stacked_dec")
+        if self._stacked_runs_ok(e1, e2) and (dec[1] if (dec is not None and dec[0] is e2) else self._repeats(e2)):
             self._pre = None
             return ops.BilinearStackedRunsFunction.apply(e1, e2, self.W.weight, self.apply_exp)
         pre, self._pre = getattr(self, "_pre", None), None
         return ops.BilinearPairFunction.apply(e1, e2, self.W.weight, self.apply_exp, pre)
+
+    def _runs_form(self, e1, e2):
+        """which one-row-per-run form this call would take: "rows" (ops.RepeatedRows with enough repetition), "stacked" (the decision
+        of the last prefetch(e2) on this very tensor -- _repeats is asked once per step), or None"""
+        n = None if e1 is None else e1.shape[0]
+        if isinstance(e2, ops.RepeatedRows):
+            ok = not e2.requires_grad and (n is None or e2.n_rows == n) and 4 * e2.rows.shape[0] <= e2.n_rows
+            return "rows" if ok else None
+        dec = self.__dict__.get("_stacked_dec")
+        if dec is not None and dec[0] is e2 and dec[1] and self._stacked_runs_ok(e1, e2):
+            return "stacked"
+        return None
+
+    def wants_folded_graph_vector(self, e2):
+        """TaxoExpan.forward, after prefetch(e2): would forward(e1, e2) take the graph vector folded (DeferredGraphVector)?"""
+        return bool(torch.is_grad_enabled() and not ops._NO_MATCH_FOLD and self._runs_form(None, e2) is not None)
 
     # ---- stacked query rows that repeat (data_loaders.py:9-28 stacks a query's row once per pair) -------------------------------------
     def _stacked_runs_ok(self, e1, e2):
@@ -493,8 +565,12 @@ class _Bilinear(nn.Module):
         """start the query-side half of the match (V = e2 W^T: needs neither the graph nor the encoder) on the second stream; the next
         forward(e1, e2) with this very e2 picks it up.  Called by TaxoExpan.forward before graph_propagate."""
         self._pre = None
-        if torch.is_grad_enabled() and torch.is_tensor(e2) and not (self._stacked_runs_ok(None, e2) and self._repeats(e2)):
-            self._pre = ops.bilinear_query_prefetch(e2, self.W.weight)
+        self.__dict__["_stacked_dec"] = None
+        if torch.is_grad_enabled() and torch.is_tensor(e2):
+            runs = bool(self._stacked_runs_ok(None, e2) and self._repeats(e2))
+            self.__dict__["_stacked_dec"] = (e2, runs)      # (forward on this very tensor does not ask _repeats again)
+            if not runs:
+                self._pre = ops.bilinear_query_prefetch(e2, self.W.weight)
 
     def score_all(self, hg, queries, block=None, out=None):
         """The whole scoring loop at once: S[q][g] = match(hg[g], queries[q]) (test_fast.py:116-123)."""

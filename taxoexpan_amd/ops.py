@@ -44,6 +44,7 @@ _BACKWARD_TWICE = ("taxoexpan_amd: backward through this propagation stack a sec
 _NO_FUSED_LOGITS = False    # the folded layer's attention logits by their own sweep instead of the aggregation's epilogue
 _NO_TABLE_SWEEP = False     # table rows materialised (txe_gather_add_rows) instead of formed inside the sweep
 _NO_SIDE_STREAM = False     # everything on the caller's stream
+_NO_MATCH_FOLD = False      # the graph vector hg = Z W^T is always formed (never folded into the bilinear matcher's run products)
 _NO_FUSED_BWD = False       # the folded layer's backward as the unfused chain (d_X' materialised)
 _NO_QUERY_RUNS = False      # stacked query rows always take the GEMM form of the bilinear match
 _NO_TAIL_CHAIN = False      # every layer's last reduction launch in place instead of chained into the bottom layer's
@@ -352,16 +353,17 @@ def _gat_layer_prepare(st, h, ld_h, pos, feat_p):
          st.H, st.D, ptr(st.Wp), feat_p, st.seed, ptr(st.mask), s)
 
 
-def _gat_collapse_fwd(csr, st, h, ld_h, pos, rpos, pw, feat_p, attn_p, attn_slope, a12=None):
+def _gat_collapse_fwd(csr, st, h, ld_h, pos, rpos, pw, feat_p, attn_p, attn_slope, a12=None, z_only=False):
     """output layer (one head) folded behind the weighted-mean readout: hg [G, D] (txe_gat_collapse_fwd).
-    a12 given: the layer is already prepared and the previous layer's aggregation has formed its attention logits."""
+    a12 given: the layer is already prepared and the previous layer's aggregation has formed its attention logits.
+    z_only: stop at Z [G, Kp] (hg = Z W^T is left to the consumer: FoldedGraphLinearFunction / BilinearFoldedRunsFunction)."""
     N, G, E = st.X.shape[0], csr.n_graphs, csr.n_edges
     ready = a12 is not None
     if not ready:
         _gat_layer_prepare(st, h, ld_h, pos, feat_p)
         a12 = _empty((max(N, 1), 2), st.X)
     alpha, coef = _empty((max(E, 1),), st.X), _empty((max(N, 1),), st.X)
-    wsum, Z, hg = _empty((max(G, 1),), st.X), _empty((max(G, 1), st.Kp), st.X), _empty((G, st.D), st.X)
+    wsum, Z, hg = _empty((max(G, 1),), st.X), _empty((max(G, 1), st.Kp), st.X), (None if z_only else _empty((G, st.D), st.X))
     gid = torch.empty(max(N, 1), dtype=torch.int32, device=st.X.device)
     wsb = call("txe_gat_collapse_ws_bytes", N, E, G, st.Kh, st.Pd, st.D, 8)
     ws = _ws(wsb, st.X)
@@ -370,7 +372,7 @@ def _gat_collapse_fwd(csr, st, h, ld_h, pos, rpos, pw, feat_p, attn_p, attn_slop
          ptr(rpos), ptr(pw), ptr(a12), int(ready), ptr(alpha), ptr(coef), ptr(wsum), ptr(gid), ptr(Z), ptr(hg), st.D, ptr(ws), wsb,
          _lib.stream_ptr())
     st.cl = (a12, alpha, coef, wsum, gid, Z, hg)
-    return hg
+    return Z if z_only else hg
 
 
 def _gat_collapse_bwd(csr, st, pos, rpos, pw, vocab, feat_p, attn_p, attn_slope, d_hg, act_on, act_slope):
@@ -501,8 +503,19 @@ def _fused_bwd_ok(csr, st, sp):
             and call("txe_gat_fused_bwd_supported", st.Kh, st.Pd, sp.H, sp.D) == 1)
 
 
-def _gat_collapse_bwd_fused(csr, st, sp, pos, rpos, pw, vocab, feat_p, attn_p, attn_slope, d_hg, act_slope, chain=None):
-    """txe_gat_collapse_bwd_fused: the folded layer's parameter gradients AND the layer below's d_Y in one sweep (no d_X)"""
+class FoldLink:
+    """What the producer of Z (GATStackFunction, cfg.final == 'collapse_z') shares with whoever consumes Z as the folded graph vector
+    hg = Z W^T: the consumer's backward leaves the main part of the output layer's weight gradient here (S slices [D, Kp], summed in
+    order) and hands dZ back through autograd; the producer's backward adds the attention rows' part and returns the whole dW."""
+    __slots__ = ("part", "S")
+
+    def __init__(self):
+        self.part, self.S = None, 0
+
+
+def _gat_collapse_bwd_fused(csr, st, sp, pos, rpos, pw, vocab, feat_p, attn_p, attn_slope, d_hg, act_slope, chain=None, link=None):
+    """txe_gat_collapse_bwd_fused: the folded layer's parameter gradients AND the layer below's d_Y in one sweep (no d_X).
+    link given: d_hg IS dZ [G, Kp] (the consumer of Z folded hg = Z W^T into its own products, FoldLink)."""
     N, G, E = st.X.shape[0], csr.n_graphs, csr.n_edges
     a12, alpha, coef, wsum, gid, Z, hg = st.cl
     d_hg, ld = _rows(d_hg)
@@ -521,11 +534,17 @@ def _gat_collapse_bwd_fused(csr, st, sp, pos, rpos, pw, vocab, feat_p, attn_p, a
              ptr(st.al), ptr(st.ar), st.D, feat_p, ptr(st.mask), attn_slope, attn_p, st.seed + 1, ptr(pw), ptr(a12), ptr(alpha), ptr(coef),
              ptr(wsum), ptr(gid), ptr(Z), ptr(hg), st.D, ptr(d_hg), ld, act_slope if act_slope else 1.0, ptr(sp.Y), sp.Fp, sp.H, sp.D,
              attn_slope, attn_p, sp.seed + 1, ptr(sp.alpha), ptr(d_Yp), sp.Fp, sp.Fp - Fe, ptr(dz), ptr(dW), ptr(dal), ptr(dar), ptr(dP),
-             ptr(d_pw), phases, chain.ptr if chain is not None else None, ptr(ws), wsb, _lib.stream_ptr())
+             ptr(d_pw), phases, ptr(link.part) if (link is not None and link.S > 0) else None, link.S if link is not None else 0,
+             chain.ptr if chain is not None else None, ptr(ws), wsb, _lib.stream_ptr())
     last = 8 | (64 if chain is not None else 0)     # (with a chain the final reductions are left to the bottom layer's launch)
     if chain is not None:
-        chain.keep += [ws, d_hg, st, sp]
-    if _NO_SIDE_STREAM:
+        chain.keep += [ws, d_hg, st, sp] + ([link.part] if link is not None else [])
+    if link is not None:                            # dZ given: no product left in this layer's backward, nothing for a second stream
+        if ld != st.Kp:
+            raise RuntimeError("folded graph vector: dZ must have the padded row pitch")
+        run(4 | 256)
+        run(last | 256)
+    elif _NO_SIDE_STREAM:
         run(7 | last)
     else:
         # the folded layer's weight-gradient GEMM (MFMA-bound, needs only d_hg and Z) runs on a second stream under the HBM-bound
@@ -551,7 +570,8 @@ class GATStackFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, csr, cfg, h, pos, rpos, pw, *params):
         need = getattr(cfg, "grad_enabled", True) and any(ctx.needs_input_grad)     # (see apply_stack)
-        collapse = (cfg.final == "collapse")
+        z_only = (cfg.final == "collapse_z")        # 'collapse' that stops at Z: returns (Z [G, Kp], the output layer's packed weights)
+        collapse = (cfg.final == "collapse") or z_only
         table = _use_table(h, need, cfg.feat_p) and not (collapse and cfg.n_layers == 1)
         if isinstance(h, GatheredRows) and not table:
             h = h.tensor()
@@ -598,7 +618,10 @@ class GATStackFunction(torch.autograd.Function):
                 F = st.H * st.D
                 if last and collapse:
                     res = _gat_collapse_fwd(csr, st, src if l == 0 else None, ld_h if l == 0 else 0, pos if st.P is not None else None,
-                                            rpos, pwf, cfg.feat_p, cfg.attn_p, cfg.attn_slope, a12=fused_a12)
+                                            rpos, pwf, cfg.feat_p, cfg.attn_p, cfg.attn_slope, a12=fused_a12, z_only=z_only)
+                    if z_only:
+                        res = (res, st.Wp)
+                        ctx.mark_non_differentiable(st.Wp)
                     if not need:
                         st.cl = st.mask = st.Wp = st.X = None
                     break
@@ -640,19 +663,21 @@ class GATStackFunction(torch.autograd.Function):
         ctx.rpos, ctx.pwf, ctx.pw_shape = rpos, pwf, (pw.shape if pwf is not None else None)
         ctx.h_req = ctx.needs_input_grad[2]
         ctx.param_ids, ctx.pw_id = [id(p) for p in params], id(pw)
+        ctx.link = getattr(cfg, "link", None) if z_only else None
         if _CAPTURE is not None:
             _CAPTURE.append((csr, cfg, states))
         return res
 
     @staticmethod
-    def backward(ctx, d_res):
+    def backward(ctx, d_res, *_unused):
         csr, cfg, pos, states = ctx.csr, ctx.cfg, ctx.pos, ctx.states
         if states is None:
             raise RuntimeError(_BACKWARD_TWICE)
         L = cfg.n_layers
         H, D = cfg.heads[-1], cfg.out_dims[-1]
         d_res = _f32(d_res)
-        collapse = (cfg.final == "collapse")
+        z_only = (cfg.final == "collapse_z")
+        collapse = (cfg.final == "collapse") or z_only
         N = states[0].X.shape[0]
         grads = [None] * (4 * L)
         d_pw = None
@@ -680,7 +705,9 @@ class GATStackFunction(torch.autograd.Function):
                     if l > 0 and _fused_bwd_ok(csr, st, states[l - 1]):
                         d_Y_ready, dW, dal, dar, dP, d_pw = _gat_collapse_bwd_fused(
                             csr, st, states[l - 1], pos if st.P is not None else None, ctx.rpos, ctx.pwf, cfg.vocab, cfg.feat_p, cfg.attn_p,
-                            cfg.attn_slope, d_res, cfg.act_slope if act_on else None, chain)
+                            cfg.attn_slope, d_res, cfg.act_slope if act_on else None, chain, link=(ctx.link or FoldLink()) if z_only else None)
+                    elif z_only:
+                        raise RuntimeError("collapse_z was requested for a stack whose fused backward does not apply (folded_graph_vector_ok)")
                     else:
                         d_X, dW, dal, dar, dP, d_pw = _gat_collapse_bwd(csr, st, pos if st.P is not None else None, ctx.rpos, ctx.pwf, cfg.vocab,
                                                                         cfg.feat_p, cfg.attn_p, cfg.attn_slope, d_res, act_on, cfg.act_slope)
@@ -1244,6 +1271,91 @@ class BilinearStackedRunsFunction(torch.autograd.Function):
             call("txe_bilinear_stacked_bwd", ptr(e1), ld1, ptr(e2), ld2, ptr(run_off), ptr(n_runs), G, l, r, apply_exp, ptr(V), ptr(s), ptr(ds),
                  ptr(d_e1), l, ptr(dW), ptr(ws), wsb, _lib.stream_ptr())
         return d_e1, None, dW.reshape(wshape), None
+
+
+def folded_graph_vector_ok(csr, cfg):
+    """may a GAT stack hand out Z instead of hg (cfg.final = 'collapse_z')?  Needs the fused backward of the folded layer (the only one
+    that takes dZ): at least two layers, the shapes txe_gat_fused_bwd_supported covers, edges, and the default routes."""
+    if _NO_MATCH_FOLD or _NO_FUSED_BWD or cfg.n_layers < 2 or cfg.heads[-1] != 1 or csr.n_edges <= 0 or csr.n_graphs <= 0 or csr.n_nodes <= 0:
+        return False
+    kh = cfg.heads[-2] * cfg.out_dims[-2]
+    return call("txe_gat_fused_bwd_supported", kh, cfg.pos_dims[-1], cfg.heads[-2], cfg.out_dims[-2]) == 1
+
+
+class FoldedGraphLinearFunction(torch.autograd.Function):
+    """hg [G, D] = Z [G, Kp] Wp[:D]^T -- the graph vector of a 'collapse_z' stack materialised after all (some consumer other than the
+    bilinear run matcher wants the tensor).  Backward: dZ = d_hg Wp[:D] through autograd, the weight gradient's main part d_hg^T Z as
+    split-K slices through the FoldLink (the stack's backward finishes dW)."""
+
+    @staticmethod
+    def forward(ctx, Z, Wp, link, D):
+        _need_cuda(Z, Wp)
+        G, Kp = Z.shape
+        hg = _empty((G, D), Z)
+        with _lib.on_device(Z.device):
+            tws = _tail_ws(Z)
+            call("txe_gemm_plain", 0, ptr(Z), Kp, ptr(Wp), Kp, ptr(hg), D, G, D, Kp, 1, 0, ptr(tws), tws.numel(), _lib.stream_ptr())
+        ctx.misc = (Z, Wp, link, D)
+        return hg
+
+    @staticmethod
+    def backward(ctx, d_hg):
+        Z, Wp, link, D = ctx.misc
+        G, Kp = Z.shape
+        d_hg, ld = _rows(_f32(d_hg))
+        dZ = _empty((G, Kp), Z)
+        S = max(1, min(8, G // 512))
+        part = _empty((S * D, Kp), Z)
+        with _lib.on_device(Z.device):
+            tws = _tail_ws(Z)
+            call("txe_gemm_plain", 1, ptr(d_hg), ld, ptr(Wp), Kp, ptr(dZ), Kp, G, Kp, D, 1, 0, ptr(tws), tws.numel(), _lib.stream_ptr())
+            call("txe_gemm_plain", 2, ptr(d_hg), ld, ptr(Z), Kp, ptr(part), Kp, D, Kp, G, S, 0, None, 0, _lib.stream_ptr())
+        link.part, link.S = part, S
+        return dZ, None, None, None
+
+
+class BilinearFoldedRunsFunction(torch.autograd.Function):
+    """The bilinear match on the folded graph vector (txe_bilinear_folded_*): s_i = <Z_i, T[u(i)]>, T[u] = Wp[:D]^T (Wm q_u) -- the output
+    layer's D x Kp product runs on the U run rows of the repeating queries instead of the G graph rows, forward and backward.  Queries:
+    the stacked matrix e2 [G, r] (runs found on the device, rows = run_off = None) or the U distinct rows + run offsets.  Gradients: dZ
+    (to the stack through autograd), the main part of the output layer's dW (through the FoldLink), dWm.  None to the queries."""
+
+    @staticmethod
+    def forward(ctx, Z, Wp, link, D, Wm, apply_exp, e2, rows, run_off):
+        _need_cuda(Z, Wp, Wm)
+        G, Kp = Z.shape
+        Wmf = _f32(Wm).reshape(Wm.shape[-2], Wm.shape[-1])
+        l, r = Wmf.shape
+        if l != D:
+            raise RuntimeError("bilinear matcher: l_dim does not match the graph vector")
+        if rows is None:
+            Q, ldq = _rows(e2)
+            _run_id, run_off, n_runs = find_row_runs(Q)
+            U, first_row = G, 1
+        else:
+            Q, ldq = _rows(rows)
+            n_runs, U, first_row = None, Q.shape[0], 0
+        s = _empty((G,), Z)
+        V, T = _empty((max(U, 1), l), Z), _empty((max(U, 1), Kp), Z)
+        with _lib.on_device(Z.device):
+            call("txe_bilinear_folded_fwd", ptr(Z), Kp, G, Kp, ptr(Wp), Kp, l, ptr(Q), ldq, r, ptr(run_off), ptr(n_runs), U, first_row, ptr(Wmf),
+                 int(apply_exp), ptr(V), ptr(T), ptr(s), _lib.stream_ptr())
+        ctx.misc = (Z, Wp, link, Wmf, Q, ldq, run_off, n_runs, U, first_row, V, T, s, int(apply_exp), Wm.shape)
+        return s.unsqueeze(1)
+
+    @staticmethod
+    def backward(ctx, ds):
+        Z, Wp, link, Wmf, Q, ldq, run_off, n_runs, U, first_row, V, T, s, apply_exp, wshape = ctx.misc
+        G, Kp = Z.shape
+        l, r = Wmf.shape
+        ds = _f32(ds.reshape(-1))
+        dZ, dT, dV = _empty((G, Kp), Z), _empty((max(U, 1), Kp), Z), _empty((max(U, 1), l), Z)
+        dWm, dWf = _empty((l, r), Z), _empty((l, Kp), Z)
+        with _lib.on_device(Z.device):
+            call("txe_bilinear_folded_bwd", ptr(Z), Kp, G, Kp, ptr(Wp), Kp, l, ptr(Q), ldq, r, ptr(run_off), ptr(n_runs), U, first_row, apply_exp,
+                 ptr(V), ptr(T), ptr(s), ptr(ds), ptr(dZ), Kp, ptr(dT), ptr(dV), ptr(dWm), ptr(dWf), _lib.stream_ptr())
+        link.part, link.S = dWf, 1
+        return dZ, None, None, None, dWm.reshape(wshape), None, None, None, None
 
 
 # ================================================================================================================

@@ -198,7 +198,7 @@ def test_fused_stack_intermediates_match_reference_goldens(name):
             got_out = nxt.X[:, :H * D].cpu()[::step]                                        # = leaky_relu(out), slope 0.01
             np.testing.assert_allclose(got_out.numpy(), F.leaky_relu(want_out, 0.01).numpy(), rtol=1e-4, atol=2e-5, err_msg=f"layer {l} out")
         else:                                                                                # folded one-head output layer
-            assert cfg.final == "collapse" and st.cl is not None
+            assert cfg.final in ("collapse", "collapse_z") and st.cl is not None
             alpha = torch.empty_like(want_alpha)
             alpha[eid.cpu()] = st.cl[1].cpu().reshape(-1, 1)
             hn = g.ndata["h"].tensor().detach().cpu()[::step]                              # the same layer, unfolded: N x out_dim

@@ -303,12 +303,17 @@ __global__ __launch_bounds__(256) void runs_dw_kernel(const float* __restrict__ 
     }
 }
 
-// T[u][c] = sum_j V[u][j] Wf[j][c]: the run's projected query pushed through the FOLDED output layer (txe_bilinear_folded_*): thread =
-// column c (rows of Wf read coalesced), eight runs per workgroup pass, their V rows staged in LDS; j ascending: deterministic
-__global__ __launch_bounds__(256) void runs_fold_kernel(const float* __restrict__ V, const float* __restrict__ Wf, long long ld_wf, const RunsRef R,
-                                                        int l, int Kp, float* __restrict__ T) {
+// T[u][c] = sum_j V[u][j] Wf[j][c]: the run's projected query pushed through the FOLDED output layer (txe_bilinear_folded_*).  A workgroup
+// of eight waves owns 64 columns and eight runs per pass: wave w walks the rows j = w, w + 8, ... of Wf (a 256-byte piece each, eight in
+// flight), the eight V rows sit in LDS and are read as broadcasts; the waves' partial sums meet in LDS and are added in wave order:
+// deterministic.  (A first version -- one thread per column walking all 500 rows -- was 63 dependent round trips: 68 us for 0.27 GFLOP.)
+constexpr int RF_WAVES = 8;
+__global__ __launch_bounds__(64 * RF_WAVES) void runs_fold_kernel(const float* __restrict__ V, const float* __restrict__ Wf, long long ld_wf, const RunsRef R,
+                                                                  int l, int Kp, float* __restrict__ T) {
     __shared__ float sV[8][512];
-    const int c = blockIdx.x * 256 + threadIdx.x, cc = min(c, Kp - 1);
+    __shared__ float red[RF_WAVES][8][64];
+    const int w = threadIdx.x >> 6, ln = threadIdx.x & 63;
+    const int c = blockIdx.x * 64 + ln, cc = min(c, Kp - 1);
     const int U = runs_count(R);
     for (int u0 = blockIdx.y * 8; u0 < U; u0 += 8 * gridDim.y) {
         float acc[8];
@@ -316,30 +321,117 @@ __global__ __launch_bounds__(256) void runs_fold_kernel(const float* __restrict_
         for (int q = 0; q < 8; ++q) acc[q] = 0.f;
         for (int j0 = 0; j0 < l; j0 += 512) {
             __syncthreads();
-            for (int i = threadIdx.x; i < 8 * 512; i += 256) {
+            for (int i = threadIdx.x; i < 8 * 512; i += 64 * RF_WAVES) {
                 const int q = i >> 9, j = j0 + (i & 511);
                 sV[q][i & 511] = (j < l) ? V[(long long)min(u0 + q, U - 1) * l + j] : 0.f;
             }
             __syncthreads();
             const int nj = min(512, l - j0);
-            for (int j = 0; j < nj; j += 8) {                   // eight rows of Wf in flight (clamped: their V factors are 0)
+            for (int j = w; j < nj; j += 8 * RF_WAVES) {           // eight rows of Wf in flight (clamped: their V factors are 0)
                 float wv[8];
 #pragma unroll
-                for (int t = 0; t < 8; ++t) wv[t] = Wf[(long long)min(j0 + j + t, l - 1) * ld_wf + cc];
+                for (int t = 0; t < 8; ++t) wv[t] = Wf[(long long)min(j0 + j + t * RF_WAVES, l - 1) * ld_wf + cc];
 #pragma unroll
                 for (int t = 0; t < 8; ++t) {
-                    const int jj = min(j + t, 511);
-                    const float live = (j + t < nj) ? 1.f : 0.f;
+                    const int jj = min(j + t * RF_WAVES, 511);
+                    const float live = (j + t * RF_WAVES < nj) ? 1.f : 0.f;
 #pragma unroll
                     for (int q = 0; q < 8; ++q) acc[q] = fmaf(sV[q][jj] * live, wv[t], acc[q]);
                 }
             }
         }
-        if (c < Kp) {
 #pragma unroll
-            for (int q = 0; q < 8; ++q)
-                if (u0 + q < U) T[(long long)(u0 + q) * Kp + c] = acc[q];
+        for (int q = 0; q < 8; ++q) red[w][q][ln] = acc[q];
+        __syncthreads();
+        if (w < 8 && c < Kp && u0 + w < U) {                       // wave q finishes run u0 + q
+            float t = 0.f;
+#pragma unroll
+            for (int x = 0; x < RF_WAVES; ++x) t += red[x][w][ln];
+            T[(long long)(u0 + w) * Kp + c] = t;
         }
+    }
+}
+
+// dV[u][j] = <X[u], Wf[j]> over Kp columns, in 8 x 8 blocks per wave (eight rows of X and eight of Wf loaded once per 256-column step for
+// 64 products: the one-row-per-wave form of runs_project_kernel moved 1.1 GB through the caches for this 0.27-GFLOP product)
+__global__ __launch_bounds__(256) void runs_project8_kernel(const float* __restrict__ X, long long ld_x, const float* __restrict__ Wf, long long ld_wf,
+                                                            const RunsRef R, int l, int Kp, float* __restrict__ dV) {
+    const int w = threadIdx.x >> 6, ln = threadIdx.x & 63;
+    const int j0 = (blockIdx.x * 4 + w) * 8;
+    if (j0 >= l) return;
+    const int U = runs_count(R);
+    const int nvec = Kp >> 2;
+    for (int u0 = blockIdx.y * 8; u0 < U; u0 += 8 * gridDim.y) {
+        float acc[8][8];
+#pragma unroll
+        for (int a = 0; a < 8; ++a)
+#pragma unroll
+            for (int b = 0; b < 8; ++b) acc[a][b] = 0.f;
+        for (int v0 = 0; v0 < nvec; v0 += 64) {
+            const int v = v0 + ln;
+            const int vc = (v < nvec) ? v : 0;
+            const float live = (v < nvec) ? 1.f : 0.f;
+            float4 xw[8], ww[8];
+#pragma unroll
+            for (int a = 0; a < 8; ++a) xw[a] = *reinterpret_cast<const float4*>(X + (long long)min(u0 + a, U - 1) * ld_x + 4 * vc);
+#pragma unroll
+            for (int b = 0; b < 8; ++b) ww[b] = *reinterpret_cast<const float4*>(Wf + (long long)min(j0 + b, l - 1) * ld_wf + 4 * vc);
+#pragma unroll
+            for (int a = 0; a < 8; ++a) {
+                const float4 x = make_float4(xw[a].x * live, xw[a].y * live, xw[a].z * live, xw[a].w * live);
+#pragma unroll
+                for (int b = 0; b < 8; ++b)
+                    acc[a][b] = fmaf(x.w, ww[b].w, fmaf(x.z, ww[b].z, fmaf(x.y, ww[b].y, fmaf(x.x, ww[b].x, acc[a][b]))));
+            }
+        }
+#pragma unroll
+        for (int a = 0; a < 8; ++a)
+#pragma unroll
+            for (int b = 0; b < 8; ++b) {
+                const float t = wave_sum(acc[a][b]);
+                if (ln == 0 && u0 + a < U && j0 + b < l) dV[(long long)(u0 + a) * l + j0 + b] = t;
+            }
+    }
+}
+
+// runs_dw_kernel with eight rows j per workgroup: for wide outputs (dWf [l][Kp]) -- each loaded Q value feeds eight sums instead of two
+__global__ __launch_bounds__(256) void runs_dw8_kernel(const float* __restrict__ S, const float* __restrict__ Q, long long ld_q, const RunsRef R,
+                                                       int l, int r, float* __restrict__ dW) {
+    __shared__ float sS[256][8];
+    __shared__ long long sRow[256];
+    const int j0 = blockIdx.x * 8;
+    const int k = blockIdx.y * 256 + threadIdx.x, kc = min(k, r - 1);
+    const int U = runs_count(R);
+    float acc[8];
+#pragma unroll
+    for (int b = 0; b < 8; ++b) acc[b] = 0.f;
+    for (int u0 = 0; u0 < U; u0 += 256) {
+        __syncthreads();
+        {
+            const int u = min(u0 + (int)threadIdx.x, U - 1);
+#pragma unroll
+            for (int b = 0; b < 8; ++b) sS[threadIdx.x][b] = S[(long long)u * l + min(j0 + b, l - 1)];
+            sRow[threadIdx.x] = runs_row(R, u);
+        }
+        __syncthreads();
+        const int n = min(256, U - u0);
+        for (int t0 = 0; t0 < n; t0 += 16) {                    // sixteen runs' loads in flight; the sums keep the runs' order
+            float q[16];
+#pragma unroll
+            for (int t = 0; t < 16; ++t) q[t] = Q[sRow[min(t0 + t, n - 1)] * ld_q + kc];
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                if (t0 + t < n) {
+#pragma unroll
+                    for (int b = 0; b < 8; ++b) acc[b] = fmaf(sS[t0 + t][b], q[t], acc[b]);
+                }
+            }
+        }
+    }
+    if (k < r) {
+#pragma unroll
+        for (int b = 0; b < 8; ++b)
+            if (j0 + b < l) dW[(long long)(j0 + b) * r + k] = acc[b];
     }
 }
 
@@ -614,7 +706,7 @@ int txe_bilinear_folded_fwd(const float* Z, long long ld_z, int G, int Kp, const
     }
     {
         ProfScope prof("runs_fold_kernel", st, 4.0 * ((double)U * l + (double)l * Kp + (double)U * Kp), 1);
-        hipLaunchKernelGGL(runs_fold_kernel, dim3((Kp + 255) / 256, gy < 16 ? gy : 16), dim3(256), 0, st, (const float*)V, Wf, ld_wf, Rc, l, Kp, T);
+        hipLaunchKernelGGL(runs_fold_kernel, dim3((Kp + 63) / 64, gy < 16 ? gy : 16), dim3(64 * RF_WAVES), 0, st, (const float*)V, Wf, ld_wf, Rc, l, Kp, T);
     }
     {
         ProfScope prof("rowdot_runs_kernel", st, 4.0 * ((double)G * Kp + (double)U * Kp + G), 1);
@@ -646,16 +738,17 @@ int txe_bilinear_folded_bwd(const float* Z, long long ld_z, int G, int Kp, const
         hipLaunchKernelGGL(runs_bwd_kernel, dim3(gx, (Kp + 255) / 256), dim3(256), 0, st, ds, s, apply_exp, T, Z, ld_z, Rc, Kp, dZ, ld_dz, dT);
     }
     {   // dV[u][j] = <dT[u], Wf[j]>  (Wf's rows have pitch Kp: the kernel's row length)
-        ProfScope prof("runs_project_kernel", st, 4.0 * ((double)U * Kp + (double)l * Kp + (double)U * l), 1);
-        hipLaunchKernelGGL(runs_project_kernel, dim3((l + 3) / 4, gy), dim3(256), 0, st, (const float*)dT, (long long)Kp, Wf, Rc, l, Kp, dV);
+        ProfScope prof("runs_project8_kernel", st, 4.0 * ((double)U * Kp + (double)l * Kp + (double)U * l), 1);
+        hipLaunchKernelGGL(runs_project8_kernel, dim3((l + 31) / 32, gy < 16 ? gy : 16), dim3(256), 0, st, (const float*)dT, (long long)Kp, Wf, ld_wf, Rc, l, Kp,
+                           dV);
     }
     {   // dWm[j][k] = sum_u dV[u][j] q_u[k]
         ProfScope prof("runs_dw_kernel", st, 4.0 * ((double)U * l + (double)U * r + (double)l * r), 1);
         hipLaunchKernelGGL(runs_dw_kernel, dim3((l + 1) / 2, (r + 255) / 256), dim3(256), 0, st, (const float*)dV, Q, ld_q, R, l, r, dWm);
     }
     {   // dWf[j][c] = sum_u V[u][j] dT[u][c]
-        ProfScope prof("runs_dw_kernel", st, 4.0 * ((double)U * l + (double)U * Kp + (double)l * Kp), 1);
-        hipLaunchKernelGGL(runs_dw_kernel, dim3((l + 1) / 2, (Kp + 255) / 256), dim3(256), 0, st, V, (const float*)dT, (long long)Kp, Rc, l, Kp, dWf);
+        ProfScope prof("runs_dw8_kernel", st, 4.0 * ((double)U * l + (double)U * Kp + (double)l * Kp), 1);
+        hipLaunchKernelGGL(runs_dw8_kernel, dim3((l + 7) / 8, (Kp + 255) / 256), dim3(256), 0, st, V, (const float*)dT, (long long)Kp, Rc, l, Kp, dWf);
     }
     TXE_CHECK_LAUNCH();
     return TXE_OK;

@@ -1436,7 +1436,9 @@ def test_repeated_query_rows_match_the_stacked_rows(matcher):
     assert abs(res[0][0] - res[1][0]) <= 1e-5 * abs(res[0][0])
     for n in res[0][1]:
         ref = res[0][1][n]
-        np.testing.assert_allclose(res[1][1][n].cpu().numpy(), ref.cpu().numpy(), rtol=1e-4, atol=1e-6 * max(ref.abs().max().item(), 1e-30), err_msg=n)
+        # (the RepeatedRows step takes the graph vector folded into the matcher, the 168 stacked rows -- too few for the run detection --
+        #  the materialised one: the same sums in another association, hence the fp32-rounding atol)
+        np.testing.assert_allclose(res[1][1][n].cpu().numpy(), ref.cpu().numpy(), rtol=1e-4, atol=2e-5 * max(ref.abs().max().item(), 1e-30), err_msg=n)
 
 
 @pytest.mark.gpu

@@ -307,18 +307,18 @@ __global__ __launch_bounds__(256) void runs_dw_kernel(const float* __restrict__ 
 // of eight waves owns 64 columns and eight runs per pass: wave w walks the rows j = w, w + 8, ... of Wf (a 256-byte piece each, eight in
 // flight), the eight V rows sit in LDS and are read as broadcasts; the waves' partial sums meet in LDS and are added in wave order:
 // deterministic.  (A first version -- one thread per column walking all 500 rows -- was 63 dependent round trips: 68 us for 0.27 GFLOP.)
-constexpr int RF_WAVES = 8;
+constexpr int RF_WAVES = 8, RF_NL = 8, RF_COLS = 128;      // (64-column workgroups were 528 for 512 slots of two: a second round for 16 of them)
 __global__ __launch_bounds__(64 * RF_WAVES) void runs_fold_kernel(const float* __restrict__ V, const float* __restrict__ Wf, long long ld_wf, const RunsRef R,
                                                                   int l, int Kp, float* __restrict__ T) {
     __shared__ float sV[8][512];
-    __shared__ float red[RF_WAVES][8][64];
+    __shared__ float2 red[RF_WAVES][8][64];
     const int w = threadIdx.x >> 6, ln = threadIdx.x & 63;
-    const int c = blockIdx.x * 64 + ln, cc = min(c, Kp - 1);
+    const int c = blockIdx.x * RF_COLS + 2 * ln, cc = min(c, Kp - 2);       // (Kp is even: a multiple of 32)
     const int U = runs_count(R);
     for (int u0 = blockIdx.y * 8; u0 < U; u0 += 8 * gridDim.y) {
-        float acc[8];
+        float2 acc[8];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) acc[q] = 0.f;
+        for (int q = 0; q < 8; ++q) acc[q] = make_float2(0.f, 0.f);
         for (int j0 = 0; j0 < l; j0 += 512) {
             __syncthreads();
             for (int i = threadIdx.x; i < 8 * 512; i += 64 * RF_WAVES) {
@@ -327,41 +327,47 @@ __global__ __launch_bounds__(64 * RF_WAVES) void runs_fold_kernel(const float* _
             }
             __syncthreads();
             const int nj = min(512, l - j0);
-            for (int j = w; j < nj; j += 8 * RF_WAVES) {           // eight rows of Wf in flight (clamped: their V factors are 0)
-                float wv[8];
+            for (int j = w; j < nj; j += RF_NL * RF_WAVES) {       // RF_NL rows of Wf in flight (clamped: their V factors are 0)
+                float2 wv[RF_NL];
 #pragma unroll
-                for (int t = 0; t < 8; ++t) wv[t] = Wf[(long long)min(j0 + j + t * RF_WAVES, l - 1) * ld_wf + cc];
+                for (int t = 0; t < RF_NL; ++t)
+                    wv[t] = *reinterpret_cast<const float2*>(Wf + (long long)min(j0 + j + t * RF_WAVES, l - 1) * ld_wf + cc);
 #pragma unroll
-                for (int t = 0; t < 8; ++t) {
+                for (int t = 0; t < RF_NL; ++t) {
                     const int jj = min(j + t * RF_WAVES, 511);
                     const float live = (j + t * RF_WAVES < nj) ? 1.f : 0.f;
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) acc[q] = fmaf(sV[q][jj] * live, wv[t], acc[q]);
+                    for (int q = 0; q < 8; ++q) {
+                        const float v = sV[q][jj] * live;
+                        acc[q].x = fmaf(v, wv[t].x, acc[q].x);
+                        acc[q].y = fmaf(v, wv[t].y, acc[q].y);
+                    }
                 }
             }
         }
 #pragma unroll
         for (int q = 0; q < 8; ++q) red[w][q][ln] = acc[q];
         __syncthreads();
-        if (w < 8 && c < Kp && u0 + w < U) {                       // wave q finishes run u0 + q
-            float t = 0.f;
+        if (c < Kp && u0 + w < U) {                                // wave q finishes run u0 + q
+            float2 t = make_float2(0.f, 0.f);
 #pragma unroll
-            for (int x = 0; x < RF_WAVES; ++x) t += red[x][w][ln];
-            T[(long long)(u0 + w) * Kp + c] = t;
+            for (int x = 0; x < RF_WAVES; ++x) { t.x += red[x][w][ln].x; t.y += red[x][w][ln].y; }
+            *reinterpret_cast<float2*>(T + (long long)(u0 + w) * Kp + c) = t;
         }
     }
 }
 
 // dV[u][j] = <X[u], Wf[j]> over Kp columns, in 8 x 8 blocks per wave (eight rows of X and eight of Wf loaded once per 256-column step for
 // 64 products: the one-row-per-wave form of runs_project_kernel moved 1.1 GB through the caches for this 0.27-GFLOP product)
-__global__ __launch_bounds__(256) void runs_project8_kernel(const float* __restrict__ X, long long ld_x, const float* __restrict__ Wf, long long ld_wf,
-                                                            const RunsRef R, int l, int Kp, float* __restrict__ dV) {
+__device__ __forceinline__ void runs_project8_job(const int bx, const int by, const int ny, const float* __restrict__ X, long long ld_x,
+                                                  const float* __restrict__ Wf, long long ld_wf, const RunsRef& R, int l, int Kp,
+                                                  float* __restrict__ dV) {
     const int w = threadIdx.x >> 6, ln = threadIdx.x & 63;
-    const int j0 = (blockIdx.x * 4 + w) * 8;
+    const int j0 = (bx * 4 + w) * 8;
     if (j0 >= l) return;
     const int U = runs_count(R);
     const int nvec = Kp >> 2;
-    for (int u0 = blockIdx.y * 8; u0 < U; u0 += 8 * gridDim.y) {
+    for (int u0 = by * 8; u0 < U; u0 += 8 * ny) {
         float acc[8][8];
 #pragma unroll
         for (int a = 0; a < 8; ++a)
@@ -395,12 +401,12 @@ __global__ __launch_bounds__(256) void runs_project8_kernel(const float* __restr
 }
 
 // runs_dw_kernel with eight rows j per workgroup: for wide outputs (dWf [l][Kp]) -- each loaded Q value feeds eight sums instead of two
-__global__ __launch_bounds__(256) void runs_dw8_kernel(const float* __restrict__ S, const float* __restrict__ Q, long long ld_q, const RunsRef R,
-                                                       int l, int r, float* __restrict__ dW) {
+__device__ __forceinline__ void runs_dw8_job(const int bx, const int by, const float* __restrict__ S, const float* __restrict__ Q, long long ld_q,
+                                             const RunsRef& R, int l, int r, float* __restrict__ dW) {
     __shared__ float sS[256][8];
     __shared__ long long sRow[256];
-    const int j0 = blockIdx.x * 8;
-    const int k = blockIdx.y * 256 + threadIdx.x, kc = min(k, r - 1);
+    const int j0 = bx * 8;
+    const int k = by * 256 + threadIdx.x, kc = min(k, r - 1);
     const int U = runs_count(R);
     float acc[8];
 #pragma unroll
@@ -433,6 +439,16 @@ __global__ __launch_bounds__(256) void runs_dw8_kernel(const float* __restrict__
         for (int b = 0; b < 8; ++b)
             if (j0 + b < l) dW[(long long)(j0 + b) * r + k] = acc[b];
     }
+}
+
+// dV = dT Wf^T and dWf = V^T dT need dT only, not each other: ONE launch -- the first gxp * gyp workgroups project, the rest sum
+__global__ __launch_bounds__(256) void runs_dv_dwf_kernel(const float* __restrict__ dT, const float* __restrict__ Wf, long long ld_wf, const float* __restrict__ V,
+                                                          const RunsRef R, int l, int Kp, int gxp, int gyp, int gxd, float* __restrict__ dV,
+                                                          float* __restrict__ dWf) {
+    const int b = blockIdx.x;
+    if (b < gxp * gyp) { runs_project8_job(b % gxp, b / gxp, gyp, dT, (long long)Kp, Wf, ld_wf, R, l, Kp, dV); return; }
+    const int d = b - gxp * gyp;
+    runs_dw8_job(d % gxd, d / gxd, V, dT, (long long)Kp, R, l, Kp, dWf);
 }
 
 static inline size_t mt_align(size_t x) { return (x + 255) / 256 * 256; }
@@ -706,7 +722,7 @@ int txe_bilinear_folded_fwd(const float* Z, long long ld_z, int G, int Kp, const
     }
     {
         ProfScope prof("runs_fold_kernel", st, 4.0 * ((double)U * l + (double)l * Kp + (double)U * Kp), 1);
-        hipLaunchKernelGGL(runs_fold_kernel, dim3((Kp + 63) / 64, gy < 16 ? gy : 16), dim3(64 * RF_WAVES), 0, st, (const float*)V, Wf, ld_wf, Rc, l, Kp, T);
+        hipLaunchKernelGGL(runs_fold_kernel, dim3((Kp + RF_COLS - 1) / RF_COLS, gy < 16 ? gy : 16), dim3(64 * RF_WAVES), 0, st, (const float*)V, Wf, ld_wf, Rc, l, Kp, T);
     }
     {
         ProfScope prof("rowdot_runs_kernel", st, 4.0 * ((double)G * Kp + (double)U * Kp + G), 1);
@@ -737,18 +753,15 @@ int txe_bilinear_folded_bwd(const float* Z, long long ld_z, int G, int Kp, const
         ProfScope prof("runs_bwd_kernel", st, 4.0 * (2.0 * G * Kp + 2.0 * U * Kp + 2.0 * G), 1);
         hipLaunchKernelGGL(runs_bwd_kernel, dim3(gx, (Kp + 255) / 256), dim3(256), 0, st, ds, s, apply_exp, T, Z, ld_z, Rc, Kp, dZ, ld_dz, dT);
     }
-    {   // dV[u][j] = <dT[u], Wf[j]>  (Wf's rows have pitch Kp: the kernel's row length)
-        ProfScope prof("runs_project8_kernel", st, 4.0 * ((double)U * Kp + (double)l * Kp + (double)U * l), 1);
-        hipLaunchKernelGGL(runs_project8_kernel, dim3((l + 31) / 32, gy < 16 ? gy : 16), dim3(256), 0, st, (const float*)dT, (long long)Kp, Wf, ld_wf, Rc, l, Kp,
-                           dV);
+    {   // dV[u][j] = <dT[u], Wf[j]> and dWf[j][c] = sum_u V[u][j] dT[u][c]: one launch
+        ProfScope prof("runs_dv_dwf_kernel", st, 4.0 * (2.0 * U * Kp + 2.0 * l * Kp + 2.0 * U * l), 1);
+        const int gxp = (l + 31) / 32, gyp = gy < 16 ? gy : 16, gxd = (l + 7) / 8, gyd = (Kp + 255) / 256;
+        hipLaunchKernelGGL(runs_dv_dwf_kernel, dim3(gxp * gyp + gxd * gyd), dim3(256), 0, st, (const float*)dT, Wf, ld_wf, V, Rc, l, Kp, gxp, gyp, gxd, dV,
+                           dWf);
     }
     {   // dWm[j][k] = sum_u dV[u][j] q_u[k]
         ProfScope prof("runs_dw_kernel", st, 4.0 * ((double)U * l + (double)U * r + (double)l * r), 1);
         hipLaunchKernelGGL(runs_dw_kernel, dim3((l + 1) / 2, (r + 255) / 256), dim3(256), 0, st, (const float*)dV, Q, ld_q, R, l, r, dWm);
-    }
-    {   // dWf[j][c] = sum_u V[u][j] dT[u][c]
-        ProfScope prof("runs_dw8_kernel", st, 4.0 * ((double)U * l + (double)U * Kp + (double)l * Kp), 1);
-        hipLaunchKernelGGL(runs_dw8_kernel, dim3((l + 7) / 8, (Kp + 255) / 256), dim3(256), 0, st, V, (const float*)dT, (long long)Kp, Rc, l, Kp, dWf);
     }
     TXE_CHECK_LAUNCH();
     return TXE_OK;

@@ -622,6 +622,7 @@ class GATStackFunction(torch.autograd.Function):
                     if z_only:
                         res = (res, st.Wp)
                         ctx.mark_non_differentiable(st.Wp)
+                        ctx.set_materialize_grads(False)    # (no zero "gradient" of the packed weights: a 4 MB fill per step)
                     if not need:
                         st.cl = st.mask = st.Wp = st.X = None
                     break

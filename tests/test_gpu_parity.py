@@ -1367,6 +1367,68 @@ def test_runs_of_stacked_query_rows_found_on_the_device_and_the_match_on_them(mo
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("matcher,stacked", [("LBM", True), ("BIM", True), ("LBM", False)])
+def test_graph_vector_folded_into_the_matcher_equals_the_materialised_one(matcher, stacked):
+    """TaxoExpan.forward on query rows that repeat: the readout stops at Z and the bilinear matcher runs the output layer's product on
+    one row per query run (DeferredGraphVector -> ops.BilinearFoldedRunsFunction, txe_bilinear_folded_*; the query-side half on the
+    second stream) -- against the same step with hg = Z W^T formed (ops._NO_MATCH_FOLD): same dropout seeds, the loss and every
+    parameter gradient within float rounding of the other association; stacked rows (runs found on the device) and ops.RepeatedRows;
+    then some other consumer asks for the folded vector's tensor (FoldedGraphLinearFunction) and gets the same numbers."""
+    from taxoexpan_amd import TaxoExpan, model_zoo as mz, ops, synthetic as syn
+    from taxoexpan_amd.loss import info_nce_loss
+    dev = _dev()
+    tax = syn.make_taxonomy(900, 1400, 12, seed=6)
+    nq, per = 40, 8                                                                  # 320 stacked rows: enough for the run detection
+    g, qf, _labels = syn.training_batch(tax, nq, per - 1, seed=3)
+    qf = qf.to(dev)
+    x, pos = g.ndata.pop("x").to(dev), g.ndata["pos"].to(dev)
+    host_q = qf.cpu().numpy()
+    qid = np.concatenate([[0], np.cumsum(np.any(host_q[1:] != host_q[:-1], axis=1))])
+    q_arg = qf if stacked else ops.RepeatedRows.from_ids(torch.from_numpy(host_q[np.concatenate([[True], qid[1:] != qid[:-1]])]).to(dev), qid)
+    torch.manual_seed(2)
+    model = TaxoExpan("PGAT", "WMR", matcher, in_dim=qf.shape[1], hidden_dim=16, out_dim=24, pos_dim=4, num_layers=1, heads=[4, 1], feat_drop=0.1,
+                      attn_drop=0.1, hidden_drop=0.0, out_drop=0.0).to(dev).train()
+    target = torch.zeros(nq, dtype=torch.long, device=dev)
+    res, kinds = [], []
+    prev = ops._NO_MATCH_FOLD
+    try:
+        for no_fold in (False, True):
+            ops._NO_MATCH_FOLD = no_fold
+            model.zero_grad()
+            model.match.__dict__.pop("_runs_watch", None)
+            g.ndata["pos"] = pos
+            torch.manual_seed(7)
+            with ops.debug_capture() as runs:
+                loss = info_nce_loss(model(g, x, q_arg).reshape(nq, -1), target)
+            loss.backward()
+            kinds.append(runs[-1][1].final)
+            res.append((loss.item(), {n: p.grad.clone() for n, p in model.named_parameters()}, runs[-1][1].seed))
+    finally:
+        ops._NO_MATCH_FOLD = prev
+    assert kinds == ["collapse_z", "collapse"]
+    assert res[0][2] == res[1][2]                                                    # (same dropout masks: the two steps are the same function)
+    assert abs(res[0][0] - res[1][0]) <= 2e-5 * abs(res[1][0])
+    for n, ref in res[1][1].items():
+        np.testing.assert_allclose(res[0][1][n].cpu().numpy(), ref.cpu().numpy(), rtol=2e-4, atol=2e-5 * max(ref.abs().max().item(), 1e-30), err_msg=n)
+    # the folded vector as an ordinary tensor
+    model.eval()
+    g.ndata["pos"] = pos
+    out = model.graph_propagate(g, x)
+    out._want_folded = True
+    g.ndata["h"] = out
+    with torch.enable_grad():
+        hv = model.readout(g, pos)
+        assert isinstance(hv, mz.DeferredGraphVector) and hv.shape == (nq * per, 24)
+        t = hv + 0.0                                                                 # a torch function: materialises
+        assert hv.folded() is None and torch.is_tensor(t)
+        t.sum().backward()
+    g.ndata["pos"] = pos
+    g.ndata["h"] = model.graph_propagate(g, x)
+    ref = model.readout(g, pos)
+    np.testing.assert_allclose(t.detach().cpu().numpy(), ref.detach().cpu().numpy(), rtol=1e-4, atol=2e-6)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("matcher", ["LBM", "BIM"])
 def test_repeated_query_rows_match_the_stacked_rows(matcher):
     """ops.RepeatedRows as the matcher's query argument (the distinct rows of a training batch's query features + their runs,

@@ -652,6 +652,11 @@ def main():
     batches = build_batches(tax, 4, seed0=1000 * (rank + 1), device=device)
     target = torch.zeros(N_QUERIES, dtype=torch.long, device=device)
 
+    # before the contract's W warm-up steps: a quarter of a second of the same steps, untimed -- a process that starts on an idle GPU has
+    # been seen to run its first ~150 steps 20 % slow (clocks and the caching allocator settling: 1.23 ms where every later leg of the
+    # same run read 1.01 ms); the same count on every rank
+    for i in range(256):
+        train_step(model, opt, batches[i % len(batches)], target, world)
     for i in range(args.warmup):
         train_step(model, opt, batches[i % len(batches)], target, world)
     torch.cuda.synchronize()

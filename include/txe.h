@@ -230,7 +230,7 @@ int txe_bilinear_stacked_bwd(const float* e1, long long ld_e1, const float* e2, 
  * distinct rows) or txe_bilinear_stacked_* (first_row 1, the count on the device, U = G sizes V [U][l], T / dT [U][Kp], dV [U][l]). */
 int txe_bilinear_folded_fwd(const float* Z, long long ld_z, int G, int Kp, const float* Wf, long long ld_wf, int l, const float* Q, long long ld_q,
                             int r, const int* run_off, const int* n_runs, int U, int first_row, const float* Wm, int apply_exp, float* V, float* T,
-                            float* s, int stages /* 1: V and T (queries and weights only), 2: the scores (Z), 3: both */, void* stream);
+                            float* s, void* stream);
 int txe_bilinear_folded_bwd(const float* Z, long long ld_z, int G, int Kp, const float* Wf, long long ld_wf, int l, const float* Q, long long ld_q,
                             int r, const int* run_off, const int* n_runs, int U, int first_row, int apply_exp, const float* V, const float* T,
                             const float* s, const float* ds, float* dZ, long long ld_dz, float* dT, float* dV, float* dWm, float* dWf, void* stream);

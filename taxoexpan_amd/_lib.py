@@ -66,7 +66,7 @@ SIGNATURES = {
     "txe_bilinear_stacked_fwd": (I, [P, L, P, L, P, P, I, I, I, P, I, P, P, P]),
     "txe_bilinear_stacked_bwd_ws_bytes": (SZ, [I, I, I]),
     "txe_bilinear_stacked_bwd": (I, [P, L, P, L, P, P, I, I, I, I, P, P, P, P, L, P, P, SZ, P]),
-    "txe_bilinear_folded_fwd": (I, [P, L, I, I, P, L, I, P, L, I, P, P, I, I, P, I, P, P, P, I, P]),
+    "txe_bilinear_folded_fwd": (I, [P, L, I, I, P, L, I, P, L, I, P, P, I, I, P, I, P, P, P, P]),
     "txe_bilinear_folded_bwd": (I, [P, L, I, I, P, L, I, P, L, I, P, P, I, I, I, P, P, P, P, P, L, P, P, P, P, P]),
     "txe_bilinear_pair_bwd_ws_bytes": (SZ, [I, I, I]),
     "txe_bilinear_pair_bwd": (I, [P, L, P, L, I, I, I, P, I, P, P, P, P, L, P, L, P, P, SZ, P]),

@@ -709,25 +709,22 @@ int txe_bilinear_stacked_bwd(const float* e1, long long ld_e1, const float* e2, 
 //   the buffers).  V [U][l], T [U][Kp] are kept for backward.
 int txe_bilinear_folded_fwd(const float* Z, long long ld_z, int G, int Kp, const float* Wf, long long ld_wf, int l, const float* Q, long long ld_q,
                             int r, const int* run_off, const int* n_runs, int U, int first_row, const float* Wm, int apply_exp, float* V, float* T,
-                            float* s, int stages, void* stream) {
-    // stages: 1 = V and T (need the queries and the weights only: may run beside the encoder), 2 = the scores (needs Z), 3 = both
-    if (G < 0 || U < 0 || Kp < 1 || l < 1 || r < 1 || !Wf || !Q || !run_off || !Wm || !V || !T || (first_row && !n_runs) || !(stages & 3) ||
-        ((stages & 2) && (!Z || !s)))
-        return TXE_ERR_ARG;
+                            float* s, void* stream) {
+    if (G < 0 || U < 0 || Kp < 1 || l < 1 || r < 1 || !Z || !Wf || !Q || !run_off || !Wm || !V || !T || !s || (first_row && !n_runs)) return TXE_ERR_ARG;
     if (G == 0 || U == 0) return TXE_OK;
     hipStream_t st = (hipStream_t)stream;
     const RunsRef R{run_off, n_runs, U, first_row ? 1 : 0};
     const RunsRef Rc{run_off, n_runs, U, 0};                       // the same runs, compact rows (V, T)
     const int gx = n_runs ? (G < 512 ? G : 512) : U, gy = n_runs ? 32 : (U + 7) / 8;
-    if (stages & 1) {
+    {
         ProfScope prof("runs_project_kernel", st, 4.0 * ((double)U * r + (double)l * r + (double)U * l), 1);
         hipLaunchKernelGGL(runs_project_kernel, dim3((l + 3) / 4, gy), dim3(256), 0, st, Q, ld_q, Wm, R, l, r, V);
     }
-    if (stages & 1) {
+    {
         ProfScope prof("runs_fold_kernel", st, 4.0 * ((double)U * l + (double)l * Kp + (double)U * Kp), 1);
         hipLaunchKernelGGL(runs_fold_kernel, dim3((Kp + RF_COLS - 1) / RF_COLS, gy < 16 ? gy : 16), dim3(64 * RF_WAVES), 0, st, (const float*)V, Wf, ld_wf, Rc, l, Kp, T);
     }
-    if (stages & 2) {
+    {
         ProfScope prof("rowdot_runs_kernel", st, 4.0 * ((double)G * Kp + (double)U * Kp + G), 1);
         hipLaunchKernelGGL(rowdot_runs_kernel, dim3(gx, 8), dim3(256), 0, st, Z, ld_z, (const float*)T, Rc, Kp, apply_exp, s);
     }

@@ -488,14 +488,12 @@ class _Bilinear(nn.Module):
             return e1.new_zeros((0, 1), dtype=torch.float32)
         if isinstance(e1, DeferredGraphVector):            # the graph vector still folded: hg = Z W^T (TaxoExpan.forward asked for it)
             fz = e1.folded()
-            fpre, self._fold_pre = self.__dict__.get("_fold_pre"), None
             if fz is not None and self._runs_form(e1, e2) == "rows":
                 self._pre = None
-                return ops.BilinearFoldedRunsFunction.apply(fz[0], fz[1], fz[2], fz[3], self.W.weight, self.apply_exp, None, e2.rows, e2.run_off,
-                                                            fpre)
+                return ops.BilinearFoldedRunsFunction.apply(fz[0], fz[1], fz[2], fz[3], self.W.weight, self.apply_exp, None, e2.rows, e2.run_off)
             if fz is not None and self._runs_form(e1, e2) == "stacked":
                 self._pre = None
-                return ops.BilinearFoldedRunsFunction.apply(fz[0], fz[1], fz[2], fz[3], self.W.weight, self.apply_exp, e2, None, None, fpre)
+                return ops.BilinearFoldedRunsFunction.apply(fz[0], fz[1], fz[2], fz[3], self.W.weight, self.apply_exp, e2, None, None)
             e1 = e1.tensor()
         if isinstance(e2, ops.RepeatedRows):               # query rows that repeat in runs: U rows projected instead of G
             if e2.requires_grad or e2.n_rows != e1.shape[0] or 4 * e2.rows.shape[0] > e2.n_rows:     # (hardly any repetition: the GEMM form)
@@ -529,16 +527,6 @@ class _Bilinear(nn.Module):
     def wants_folded_graph_vector(self, e2):
         """TaxoExpan.forward, after prefetch(e2): would forward(e1, e2) take the graph vector folded (DeferredGraphVector)?"""
         return bool(torch.is_grad_enabled() and not ops._NO_MATCH_FOLD and self._runs_form(None, e2) is not None)
-
-    def prefetch_folded(self, e2):
-        """TaxoExpan.forward, when the graph vector will arrive folded: the query-side half of the folded match goes to the second stream
-        under the encoder (ops.folded_match_prefetch)"""
-        form = self._runs_form(None, e2)
-        self.__dict__["_fold_pre"] = None
-        if form == "rows":
-            self.__dict__["_fold_pre"] = ops.folded_match_prefetch(None, e2.rows, e2.run_off, self.W.weight)
-        elif form == "stacked":
-            self.__dict__["_fold_pre"] = ops.folded_match_prefetch(e2, None, None, self.W.weight)
 
     # ---- stacked query rows that repeat (data_loaders.py:9-28 stacks a query's row once per pair) -------------------------------------
     def _stacked_runs_ok(self, e1, e2):

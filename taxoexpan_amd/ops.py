@@ -613,13 +613,10 @@ class GATStackFunction(torch.autograd.Function):
                                       _x_dropped_ok(cfg, states, l, collapse))
                                      for l, st in enumerate(states) if not (table and l == 0)], cfg.feat_p)
             fused_a12 = None
-            global _FOLD_CTX
-            _FOLD_CTX = (states[-1].Wp, states[-1].D) if (z_only and N > 0 and getattr(states[-1], "Wp", None) is not None) else None
             for l, st in enumerate(states):
                 last = (l == L - 1)
                 F = st.H * st.D
                 if last and collapse:
-                    _FOLD_CTX = None
                     res = _gat_collapse_fwd(csr, st, src if l == 0 else None, ld_h if l == 0 else 0, pos if st.P is not None else None,
                                             rpos, pwf, cfg.feat_p, cfg.attn_p, cfg.attn_slope, a12=fused_a12, z_only=z_only)
                     if z_only:
@@ -1078,58 +1075,6 @@ def bilinear_query_prefetch(e2, W):
 
 
 _pending_prefetch = []
-_FOLD_CTX = None      # (packed weights, D) of the output layer of the 'collapse_z' stack whose forward is running: folded_match_prefetch's input
-
-
-def folded_match_prefetch(e2, rows, run_off, Wm):
-    """The query-side half of BilinearFoldedRunsFunction -- the runs of the stacked matrix, V = Wm q, T = Wf^T V: everything that needs
-    the queries and the weights only -- on the second stream, launched by the encoder behind its first projection GEMM, i.e. beside the
-    HBM-bound sweeps.  Returns a token for BilinearFoldedRunsFunction.apply(..., pre=token); None when there is no second stream."""
-    if _NO_SIDE_STREAM or not Wm.is_cuda:
-        return None
-    tok = dict(e2=e2, rows=rows, run_off=run_off, Wm=Wm, Wm_version=Wm._version, e2_version=(e2._version if torch.is_tensor(e2) else None),
-               launched=False, ok=False, stream=None)
-
-    def launch():
-        if tok["launched"]:
-            return
-        tok["launched"] = True
-        if _FOLD_CTX is None:
-            return
-        Wp, D = _FOLD_CTX
-        dev = Wm.device
-        Wmf = _f32(Wm).reshape(Wm.shape[-2], Wm.shape[-1])
-        l, r = Wmf.shape
-        if l != D:
-            return
-        main, side = torch.cuda.current_stream(dev), _side_stream(dev)
-        Kp = Wp.shape[1]
-        if rows is None:
-            Q, ldq = _rows(e2)
-            G = U = Q.shape[0]
-            first_row = 1
-            run_id = torch.empty(max(G, 1), dtype=torch.int32, device=dev)       # (allocated on the caller's stream, like V and T)
-            roff = torch.empty(G + 1, dtype=torch.int32, device=dev)
-            n_runs = torch.empty(1, dtype=torch.int32, device=dev)
-        else:
-            Q, ldq = _rows(rows)
-            roff, n_runs, run_id, U, first_row, G = run_off, None, None, Q.shape[0], 0, 1
-        V, T = _empty((max(U, 1), l), Wp), _empty((max(U, 1), Kp), Wp)
-        _order(main, side)
-        with _lib.on_device(dev), torch.cuda.stream(side):
-            if rows is None:
-                call("txe_rows_find_runs", ptr(Q), ldq, G, Q.shape[1], ptr(run_id), ptr(roff), ptr(n_runs), _lib.stream_ptr())
-            call("txe_bilinear_folded_fwd", None, Kp, max(G, 1), Kp, ptr(Wp), Kp, l, ptr(Q), ldq, r, ptr(roff), ptr(n_runs), U, first_row, ptr(Wmf), 0,
-                 ptr(V), ptr(T), None, 1, _lib.stream_ptr())
-        # written / read on the second stream, allocated on the caller's: tell the caching allocator (as bilinear_query_prefetch does)
-        for t in (V, T, Q, Wp, Wmf, roff, n_runs, run_id):
-            if t is not None:
-                t.record_stream(side)
-        tok.update(ok=True, Wp=Wp, Wmf=Wmf, Q=Q, ldq=ldq, roff=roff, n_runs=n_runs, U=U, first_row=first_row, V=V, T=T, stream=side)
-    tok["launch"] = launch
-    del _pending_prefetch[:]
-    _pending_prefetch.append(tok)
-    return tok
 
 
 def _launch_pending_prefetch():
@@ -1377,32 +1322,25 @@ class BilinearFoldedRunsFunction(torch.autograd.Function):
     (to the stack through autograd), the main part of the output layer's dW (through the FoldLink), dWm.  None to the queries."""
 
     @staticmethod
-    def forward(ctx, Z, Wp, link, D, Wm, apply_exp, e2, rows, run_off, pre=None):
+    def forward(ctx, Z, Wp, link, D, Wm, apply_exp, e2, rows, run_off):
         _need_cuda(Z, Wp, Wm)
         G, Kp = Z.shape
         Wmf = _f32(Wm).reshape(Wm.shape[-2], Wm.shape[-1])
         l, r = Wmf.shape
         if l != D:
             raise RuntimeError("bilinear matcher: l_dim does not match the graph vector")
-        s = _empty((G,), Z)
-        ready = (pre is not None and pre["ok"] and pre["Wp"] is Wp and pre["Wm"] is Wm and pre["Wm_version"] == Wm._version
-                 and pre["e2"] is e2 and pre["rows"] is rows and pre["run_off"] is run_off
-                 and (e2 is None or not torch.is_tensor(e2) or pre["e2_version"] == e2._version) and (rows is not None or pre["U"] == G))
-        if ready:                                   # V and T were formed on the second stream under the encoder (folded_match_prefetch)
-            Q, ldq, run_off, n_runs, U, first_row, V, T = (pre[k] for k in ("Q", "ldq", "roff", "n_runs", "U", "first_row", "V", "T"))
-            _order(pre["stream"], torch.cuda.current_stream(Z.device))
-        elif rows is None:
+        if rows is None:
             Q, ldq = _rows(e2)
             _run_id, run_off, n_runs = find_row_runs(Q)
             U, first_row = G, 1
         else:
             Q, ldq = _rows(rows)
             n_runs, U, first_row = None, Q.shape[0], 0
-        if not ready:
-            V, T = _empty((max(U, 1), l), Z), _empty((max(U, 1), Kp), Z)
+        s = _empty((G,), Z)
+        V, T = _empty((max(U, 1), l), Z), _empty((max(U, 1), Kp), Z)
         with _lib.on_device(Z.device):
             call("txe_bilinear_folded_fwd", ptr(Z), Kp, G, Kp, ptr(Wp), Kp, l, ptr(Q), ldq, r, ptr(run_off), ptr(n_runs), U, first_row, ptr(Wmf),
-                 int(apply_exp), ptr(V), ptr(T), ptr(s), 2 if ready else 3, _lib.stream_ptr())
+                 int(apply_exp), ptr(V), ptr(T), ptr(s), _lib.stream_ptr())
         ctx.misc = (Z, Wp, link, Wmf, Q, ldq, run_off, n_runs, U, first_row, V, T, s, int(apply_exp), Wm.shape)
         return s.unsqueeze(1)
 
@@ -1418,7 +1356,7 @@ class BilinearFoldedRunsFunction(torch.autograd.Function):
             call("txe_bilinear_folded_bwd", ptr(Z), Kp, G, Kp, ptr(Wp), Kp, l, ptr(Q), ldq, r, ptr(run_off), ptr(n_runs), U, first_row, apply_exp,
                  ptr(V), ptr(T), ptr(s), ptr(ds), ptr(dZ), Kp, ptr(dT), ptr(dV), ptr(dWm), ptr(dWf), _lib.stream_ptr())
         link.part, link.S = dWf, 1
-        return dZ, None, None, None, dWm.reshape(wshape), None, None, None, None, None
+        return dZ, None, None, None, dWm.reshape(wshape), None, None, None, None
 
 
 # ================================================================================================================

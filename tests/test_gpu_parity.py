@@ -1370,8 +1370,7 @@ def test_runs_of_stacked_query_rows_found_on_the_device_and_the_match_on_them(mo
 @pytest.mark.parametrize("matcher,stacked", [("LBM", True), ("BIM", True), ("LBM", False)])
 def test_graph_vector_folded_into_the_matcher_equals_the_materialised_one(matcher, stacked):
     """TaxoExpan.forward on query rows that repeat: the readout stops at Z and the bilinear matcher runs the output layer's product on
-    one row per query run (DeferredGraphVector -> ops.BilinearFoldedRunsFunction, txe_bilinear_folded_*; the query-side half on the
-    second stream) -- against the same step with hg = Z W^T formed (ops._NO_MATCH_FOLD): same dropout seeds, the loss and every
+    one row per query run (DeferredGraphVector -> ops.BilinearFoldedRunsFunction, txe_bilinear_folded_*) -- against the same step with hg = Z W^T formed (ops._NO_MATCH_FOLD): same dropout seeds, the loss and every
     parameter gradient within float rounding of the other association; stacked rows (runs found on the device) and ops.RepeatedRows;
     then some other consumer asks for the folded vector's tensor (FoldedGraphLinearFunction) and gets the same numbers."""
     from taxoexpan_amd import TaxoExpan, model_zoo as mz, ops, synthetic as syn

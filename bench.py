@@ -850,7 +850,10 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": WORKLOAD_TEXT[args.workload] + STEP_TEXT,
-                       "output_layer": "folded behind the weighted-mean readout (exact re-association, DESIGN 4.1): G graph rows instead of N node rows",
+                       "output_layer": "folded behind the weighted-mean readout (exact re-association, DESIGN 4.1): G graph rows instead of N node rows"
+                                       + ("" if args.workload == "pgcn" else "; and, the query rows of a training batch repeating 32 times, through the "
+                                          "bilinear matcher (DESIGN 4.9): its three G x D x Kp products run on the 128 query runs -- every output and "
+                                          "gradient still produced, all work inside the timed region"),
                        "egonets_per_step_per_gpu": N_QUERIES * (1 + NEG), "avg_edges_per_step_per_gpu": edges / args.steps / world,
                        "parallelism": f"dp{world}"},
             "roofline_all": roof_all,

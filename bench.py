@@ -720,6 +720,10 @@ def main():
                 torch.cuda.synchronize()
                 ts.append(1e3 * (time.perf_counter() - t0_) / per)
             return float(np.median(ts))
+        from taxoexpan_amd import ops as _ops_ab
+        _ops_ab._NO_MATCH_FOLD = True                    # the graph vector hg = Z W^T formed, the matcher on 4,096 rows of it (DESIGN 4.9 off)
+        ab["step_no_match_fold_ms"] = timed(opt)
+        _ops_ab._NO_MATCH_FOLD = False
         torch.autograd.set_multithreading_enabled(True)
         ab["step_default_autograd_ms"] = timed(opt)
         torch.autograd.set_multithreading_enabled(False)

@@ -1367,6 +1367,48 @@ def test_runs_of_stacked_query_rows_found_on_the_device_and_the_match_on_them(mo
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("apply_exp,stacked", [(True, True), (False, False)])
+def test_folded_match_kernels_against_torch_autograd(apply_exp, stacked):
+    """txe_bilinear_folded_fwd / _bwd (ops.BilinearFoldedRunsFunction) on ragged runs -- lengths 1, 700 (longer than a staging pass),
+    equal rows in SEPARATE runs, odd widths (D = 37, Kp = 96, r = 23) -- against the same function written in torch on float64:
+    scores, dZ, the matcher's dW and the main part of the output layer's dW that travels through the FoldLink"""
+    from taxoexpan_amd import ops
+    dev = _dev()
+    rs = np.random.RandomState(5)
+    lens = [1, 700, 3, 1, 40, 255, 2]
+    ids = np.repeat([4, 2, 9, 4, 1, 7, 2], lens)                                     # (ids 4 and 2 come back in later runs)
+    G, D, Kp, r = len(ids), 37, 96, 23
+    table = torch.from_numpy(rs.standard_normal((12, r)).astype(np.float32)).to(dev)
+    Z = torch.from_numpy((0.3 * rs.standard_normal((G, Kp))).astype(np.float32)).to(dev).requires_grad_(True)
+    Wp = torch.zeros(128, Kp, device=dev)
+    Wp[:D] = torch.from_numpy((0.3 * rs.standard_normal((D, Kp))).astype(np.float32)).to(dev)
+    Wm = torch.from_numpy((0.3 * rs.standard_normal((1, D, r))).astype(np.float32)).to(dev).requires_grad_(True)
+    wts = torch.linspace(-1, 1, G, device=dev)
+    link = ops.FoldLink()
+    if stacked:
+        e2 = table.index_select(0, torch.from_numpy(ids).to(dev))
+        s = ops.BilinearFoldedRunsFunction.apply(Z, Wp, link, D, Wm, apply_exp, e2, None, None)
+    else:
+        rr = ops.RepeatedRows.from_ids(table, ids)
+        assert rr.rows.shape[0] == len(lens)
+        s = ops.BilinearFoldedRunsFunction.apply(Z, Wp, link, D, Wm, apply_exp, None, rr.rows, rr.run_off)
+    (s.reshape(-1) * wts).sum().backward()
+    assert link.S == 1 and tuple(link.part.shape) == (D, Kp)
+    Zd = Z.detach().double().cpu().requires_grad_(True)
+    Wd = Wp[:D].double().cpu().requires_grad_(True)
+    Wmd = Wm.detach().double().cpu().requires_grad_(True)
+    q = table.double().cpu()[torch.from_numpy(ids)]
+    raw = ((Zd @ Wd.t()) * (q @ Wmd[0].t())).sum(1)
+    ref = raw.exp() if apply_exp else raw
+    (ref * wts.double().cpu()).sum().backward()
+    tol = dict(rtol=2e-4)
+    np.testing.assert_allclose(s.detach().reshape(-1).cpu().numpy(), ref.detach().numpy(), atol=2e-5 * float(ref.detach().abs().max()), **tol)
+    np.testing.assert_allclose(Z.grad.cpu().numpy(), Zd.grad.numpy(), atol=2e-5 * float(Zd.grad.abs().max()), **tol)
+    np.testing.assert_allclose(Wm.grad.cpu().numpy(), Wmd.grad.numpy(), atol=2e-5 * float(Wmd.grad.abs().max()), **tol)
+    np.testing.assert_allclose(link.part.cpu().numpy(), Wd.grad.numpy(), atol=2e-5 * float(Wd.grad.abs().max()), **tol)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("matcher,stacked", [("LBM", True), ("BIM", True), ("LBM", False)])
 def test_graph_vector_folded_into_the_matcher_equals_the_materialised_one(matcher, stacked):
     """TaxoExpan.forward on query rows that repeat: the readout stops at Z and the bilinear matcher runs the output layer's product on

@@ -230,7 +230,8 @@ int txe_bilinear_stacked_bwd(const float* e1, long long ld_e1, const float* e2, 
  * distinct rows) or txe_bilinear_stacked_* (first_row 1, the count on the device, U = G sizes V [U][l], T / dT [U][Kp], dV [U][l]). */
 int txe_bilinear_folded_fwd(const float* Z, long long ld_z, int G, int Kp, const float* Wf, long long ld_wf, int l, const float* Q, long long ld_q,
                             int r, const int* run_off, const int* n_runs, int U, int first_row, const float* Wm, int apply_exp, float* V, float* T,
-                            float* s, void* stream);
+                            float* s, int stages /* 1: V and T (queries and weights only), 2: the scores (Z), 3: both */, void* stream);
+int txe_runs_expand(const int* run_off, int U, int G, int* run_id, void* stream);   /* run_id[i] = the run that holds pair i */
 int txe_bilinear_folded_bwd(const float* Z, long long ld_z, int G, int Kp, const float* Wf, long long ld_wf, int l, const float* Q, long long ld_q,
                             int r, const int* run_off, const int* n_runs, int U, int first_row, int apply_exp, const float* V, const float* T,
                             const float* s, const float* ds, float* dZ, long long ld_dz, float* dT, float* dV, float* dWm, float* dWf, void* stream);
@@ -307,7 +308,10 @@ int txe_gat_collapse_fwd(const int* rowptr_in, const int* col_src, const int* ro
                          const int* graph_off, int n_nodes, int n_edges, int G, const float* X, int Kh, int Pd, const float* Wp, int D,
                          float feat_drop_p, const unsigned* mask, float attn_slope, float attn_drop_p, unsigned long long seed,
                          const int* pos, const float* pw, float* a12, int a12_ready, float* alpha, float* coef, float* wsum, int* gid, float* Z,
-                         float* hg, long long ld_hg, void* ws, size_t ws_bytes, void* stream);
+                         float* hg, long long ld_hg /* hg NULL: stop at Z (the consumer folds hg = Z W^T: txe_bilinear_folded_*) */,
+                         const float* Tf, const int* zrow, float* e_part /* all NULL, or (with hg NULL): see phases | 512 below */, void* ws,
+                         size_t ws_bytes, void* stream);
+int txe_gat_collapse_e_tiles(int n_nodes, int G, int Kh, int Pd);   /* floats per node of e_part; 0: this batch cannot form it */
 int txe_gat_collapse_bwd(const int* rowptr_in, const int* col_src, const int* rowptr_out, const int* col_dst, const int* pos_out,
                          const int* graph_off, int n_nodes, int n_edges, int G, const float* X, int Kh, int Pd, const int* pos, int vocab,
                          const float* Wp, const float* W, const float* attn_l, const float* attn_r, int D, float feat_drop_p,
@@ -328,6 +332,9 @@ int txe_gat_collapse_bwd(const int* rowptr_in, const int* col_src, const int* ro
  * | 256: the caller folded hg = Z W^T into the consumer of Z (txe_bilinear_folded_*; txe_gat_collapse_fwd with hg == NULL stops at Z):
  * `d_hg` IS dZ [G][Kp] (ld_dhg == Kp), hg may be NULL, phases 1 and 2 do not run, and the main part of dW comes from the caller as
  * dw_slices slices [D][Kp] at dw_main (summed in order; 0 slices: none) -- this call adds the attention rows' part.
+ * | 512 (with | 256): the <dZ, X> sweep was formed in forward -- txe_gat_collapse_fwd with Tf [runs][Kp], zrow [G] (graph -> its row of Tf) and
+ * e_part [N][txe_gat_collapse_e_tiles] given leaves <Tf[zrow[g]], keep X[u]> there; with the folded matcher's dZ[g] = dsl_g Tf[zrow[g]] backward
+ * needs only its score gradient m_ds [G], its scores m_s [G] and whether it exponentiates (m_exp).
  * txe_gat_fused_bwd_supported: 1 if the shape qualifies (Hp in {1,2,4}, Hp*Dp % 16 == 0, <= 128 columns behind the feature part). */
 int txe_gat_fused_bwd_supported(int Kh, int Pd, int Hp, int Dp);
 size_t txe_gat_collapse_bwd_fused_ws_bytes(int n_nodes, int n_edges, int G, int Kh, int Pd, int D, int vocab, int Hp);
@@ -340,7 +347,8 @@ int txe_gat_collapse_bwd_fused(const int* rowptr_in, const int* col_src, const i
                                float act_slope, const float* Yp, long long ld_yp, int Hp, int Dp, float attn_slope_p,
                                float attn_drop_p_p, unsigned long long seed_p, const float* alpha_p, float* d_Yp, long long ld_dyp,
                                int n_pad, float* dz_p, float* dW, float* d_attn_l, float* d_attn_r, float* dP, float* d_pw, int phases,
-                               const float* dw_main, int dw_slices, void* chain, void* ws, size_t ws_bytes, void* stream);
+                               const float* dw_main, int dw_slices, const float* e_part, const float* m_ds, const float* m_s, int m_exp,
+                               void* chain, void* ws, size_t ws_bytes, void* stream);
 
 /* ---- output GCNLayer folded behind MeanReadout / WeightedMeanReadout: model_zoo.py:35-47,139-167,227-242.
  * hg[g] = (sum_{u in g} c_u Xd[u]) W + b with c_u = norm_u sum_{v: u->v} w_v norm_v / S_g (graph constants).  X / Wp / mask as for

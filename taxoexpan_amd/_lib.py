@@ -66,7 +66,8 @@ SIGNATURES = {
     "txe_bilinear_stacked_fwd": (I, [P, L, P, L, P, P, I, I, I, P, I, P, P, P]),
     "txe_bilinear_stacked_bwd_ws_bytes": (SZ, [I, I, I]),
     "txe_bilinear_stacked_bwd": (I, [P, L, P, L, P, P, I, I, I, I, P, P, P, P, L, P, P, SZ, P]),
-    "txe_bilinear_folded_fwd": (I, [P, L, I, I, P, L, I, P, L, I, P, P, I, I, P, I, P, P, P, P]),
+    "txe_bilinear_folded_fwd": (I, [P, L, I, I, P, L, I, P, L, I, P, P, I, I, P, I, P, P, P, I, P]),
+    "txe_runs_expand": (I, [P, I, I, P, P]),
     "txe_bilinear_folded_bwd": (I, [P, L, I, I, P, L, I, P, L, I, P, P, I, I, I, P, P, P, P, P, L, P, P, P, P, P]),
     "txe_bilinear_pair_bwd_ws_bytes": (SZ, [I, I, I]),
     "txe_bilinear_pair_bwd": (I, [P, L, P, L, I, I, I, P, I, P, P, P, P, L, P, L, P, P, SZ, P]),
@@ -80,14 +81,15 @@ SIGNATURES = {
     "txe_build_csr": (I, [P, P, I, I, P, P, P, P, P, P, P, SZ, P]),
     "txe_rank_block": (I, [P, L, I, I, P, P, P, I, P, P]),
     "txe_gat_collapse_ws_bytes": (SZ, [I, I, I, I, I, I, I]),
-    "txe_gat_collapse_fwd": (I, [P, P, P, P, P, P, I, I, I, P, I, I, P, I, F, P, F, F, U64, P, P, P, I, P, P, P, P, P, P, L, P, SZ, P]),
+    "txe_gat_collapse_fwd": (I, [P, P, P, P, P, P, I, I, I, P, I, I, P, I, F, P, F, F, U64, P, P, P, I, P, P, P, P, P, P, L, P, P, P, P, SZ, P]),
+    "txe_gat_collapse_e_tiles": (I, [I, I, I, I]),
     "txe_gat_collapse_bwd": (I, [P, P, P, P, P, P, I, I, I, P, I, I, P, I, P, P, P, P, I, F, P, F, F, U64, P, P, P, P, P, P, P, P, L, P, L, I, F,
                                  P, P, P, P, P, P, P, SZ, P]),
     "txe_gat_layers_prepare": (I, [P, I, P]),
     "txe_gat_fused_bwd_supported": (I, [I, I, I, I]),
     "txe_gat_collapse_bwd_fused_ws_bytes": (SZ, [I, I, I, I, I, I, I, I]),
     "txe_gat_collapse_bwd_fused": (I, [P, P, P, P, P, P, I, I, I, P, I, I, P, I, P, P, P, P, I, F, P, F, F, U64, P, P, P, P, P, P, P, P, L, P, L,
-                                       F, P, L, I, I, F, F, U64, P, P, L, I, P, P, P, P, P, P, I, P, I, P, P, SZ, P]),
+                                       F, P, L, I, I, F, F, U64, P, P, L, I, P, P, P, P, P, P, I, P, I, P, P, P, I, P, P, SZ, P]),
     "txe_gcn_collapse_ws_bytes": (SZ, [I, I, I, I, I, I]),
     "txe_gcn_collapse_fwd": (I, [P, P, P, I, I, P, I, I, P, I, P, F, P, P, P, P, P, P, P, P, P, L, P, SZ, P]),
     "txe_gcn_collapse_bwd": (I, [P, P, P, I, I, P, I, I, P, I, P, I, F, P, P, P, P, P, P, P, P, L, I, F, P, P, P, P, P, P, SZ, P]),
@@ -114,7 +116,7 @@ class GatPrepareDesc(C.Structure):
 
 
 _ERR = {-1: "TXE_ERR_ARG", -2: "TXE_ERR_LAUNCH", -3: "TXE_ERR_WORKSPACE"}
-VALUE_RETURNING = {"txe_gat_padded_k", "txe_gat_padded_f", "txe_gcn_padded_f", "txe_profile_count", "txe_gat_fused_bwd_supported",
+VALUE_RETURNING = {"txe_gat_padded_k", "txe_gat_collapse_e_tiles", "txe_gat_padded_f", "txe_gcn_padded_f", "txe_profile_count", "txe_gat_fused_bwd_supported",
                    "txe_gat_aggregate_table_supported", "txe_gat_dx_streams", "txe_score_topk_tiles"}   # int results that are not status codes
 
 _lib = None

@@ -451,6 +451,15 @@ __global__ __launch_bounds__(256) void runs_dv_dwf_kernel(const float* __restric
     runs_dw8_job(d % gxd, d / gxd, V, dT, (long long)Kp, R, l, Kp, dWf);
 }
 
+// run_id[i] = the run that holds pair i (binary search in the offsets)
+__global__ void runs_expand_kernel(const int* __restrict__ off, int U, int G, int* __restrict__ run_id) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= G) return;
+    int lo = 0, hi = U - 1;
+    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (off[mid] <= i) lo = mid; else hi = mid - 1; }
+    run_id[i] = lo;
+}
+
 static inline size_t mt_align(size_t x) { return (x + 255) / 256 * 256; }
 
 static inline int mt_splits(int M, int N, int K) { return choose_splits(M, N, K); }
@@ -701,6 +710,15 @@ int txe_bilinear_stacked_bwd(const float* e1, long long ld_e1, const float* e2, 
     return runs_bwd_launch(e1, ld_e1, e2, ld_e2, R, gx, G, l, r, apply_exp, V, s, ds, d_e1, ld_de1, dW, (float*)ws, st);
 }
 
+// graph -> run index for runs given by their offsets (txe_rows_find_runs produces the same array for the stacked form)
+int txe_runs_expand(const int* run_off, int U, int G, int* run_id, void* stream) {
+    if (U < 0 || G < 0 || !run_off || !run_id) return TXE_ERR_ARG;
+    if (U == 0 || G == 0) return TXE_OK;
+    hipLaunchKernelGGL(runs_expand_kernel, dim3((G + 255) / 256), dim3(256), 0, (hipStream_t)stream, run_off, U, G, run_id);
+    TXE_CHECK_LAUNCH();
+    return TXE_OK;
+}
+
 // The pairwise bilinear match FOLDED through the output layer of the encoder (the graph vector hg = Z Wf^T of txe_gat_collapse_fwd, never
 // formed):  s_i = hg_i^T Wm q_i = <Z_i, T[u(i)]>,  T[u] = Wf^T (Wm q_u)  -- when the query rows repeat in runs, the D x Kp product runs
 // on U run rows instead of G graph rows (a training batch: 128 instead of 4,096), forward and both backward products.
@@ -709,22 +727,25 @@ int txe_bilinear_stacked_bwd(const float* e1, long long ld_e1, const float* e2, 
 //   the buffers).  V [U][l], T [U][Kp] are kept for backward.
 int txe_bilinear_folded_fwd(const float* Z, long long ld_z, int G, int Kp, const float* Wf, long long ld_wf, int l, const float* Q, long long ld_q,
                             int r, const int* run_off, const int* n_runs, int U, int first_row, const float* Wm, int apply_exp, float* V, float* T,
-                            float* s, void* stream) {
-    if (G < 0 || U < 0 || Kp < 1 || l < 1 || r < 1 || !Z || !Wf || !Q || !run_off || !Wm || !V || !T || !s || (first_row && !n_runs)) return TXE_ERR_ARG;
+                            float* s, int stages, void* stream) {
+    // stages: 1 = V and T (need the queries and the weights only: the encoder asks for T before its Z sweep), 2 = the scores (needs Z), 3 = both
+    if (G < 0 || U < 0 || Kp < 1 || l < 1 || r < 1 || !Wf || !Q || !run_off || !Wm || !V || !T || (first_row && !n_runs) || !(stages & 3) ||
+        ((stages & 2) && (!Z || !s)))
+        return TXE_ERR_ARG;
     if (G == 0 || U == 0) return TXE_OK;
     hipStream_t st = (hipStream_t)stream;
     const RunsRef R{run_off, n_runs, U, first_row ? 1 : 0};
     const RunsRef Rc{run_off, n_runs, U, 0};                       // the same runs, compact rows (V, T)
     const int gx = n_runs ? (G < 512 ? G : 512) : U, gy = n_runs ? 32 : (U + 7) / 8;
-    {
+    if (stages & 1) {
         ProfScope prof("runs_project_kernel", st, 4.0 * ((double)U * r + (double)l * r + (double)U * l), 1);
         hipLaunchKernelGGL(runs_project_kernel, dim3((l + 3) / 4, gy), dim3(256), 0, st, Q, ld_q, Wm, R, l, r, V);
     }
-    {
+    if (stages & 1) {
         ProfScope prof("runs_fold_kernel", st, 4.0 * ((double)U * l + (double)l * Kp + (double)U * Kp), 1);
         hipLaunchKernelGGL(runs_fold_kernel, dim3((Kp + RF_COLS - 1) / RF_COLS, gy < 16 ? gy : 16), dim3(64 * RF_WAVES), 0, st, (const float*)V, Wf, ld_wf, Rc, l, Kp, T);
     }
-    {
+    if (stages & 2) {
         ProfScope prof("rowdot_runs_kernel", st, 4.0 * ((double)G * Kp + (double)U * Kp + G), 1);
         hipLaunchKernelGGL(rowdot_runs_kernel, dim3(gx, 8), dim3(256), 0, st, Z, ld_z, (const float*)T, Rc, Kp, apply_exp, s);
     }

@@ -1097,11 +1097,15 @@ __global__ __launch_bounds__(256) void cl_zsum_kernel(const int* __restrict__ go
 // the next graph (offsets and weight sums of the chunk sit in lanes, read back as scalars: uniform control flow).  Per graph the same
 // nodes in the same order: bit-identical to cl_zsum_kernel.
 constexpr int ZS_GPW = 4;
-template <bool MASK>
+// EDOT (the graph vector folded into a bilinear matcher): the gradient of Z will be dZ[g] = dsl_g Tf[zrow[g]] with Tf known NOW, so
+// the backward's <dZ[g], keep X[u]> sweep is this sweep's <Tf[zrow[g]], keep X[u]> times a scalar: the wave adds its tile's share of that
+// dot product per node to e_part[u][tile] (summed over the tiles, in tile order, by cl_fold_dc_kernel).
+template <bool MASK, bool EDOT = false>
 __global__ __launch_bounds__(256) void cl_zsum_chunk_kernel(const int* __restrict__ goff, int G, int ntile, const float* __restrict__ X, int Kp,
                                                             const unsigned* __restrict__ mask, int mask_ld, float scale,
                                                             const float* __restrict__ coef, const float* __restrict__ wsum,
-                                                            float* __restrict__ Z) {
+                                                            float* __restrict__ Z, const float* __restrict__ Tf = nullptr,
+                                                            const int* __restrict__ zrow = nullptr, float* __restrict__ e_part = nullptr) {
     constexpr int NU = 8;
     const int l = threadIdx.x & 63;
     const long long wid = ((long long)blockIdx.x * 256 + threadIdx.x) >> 6;
@@ -1118,6 +1122,12 @@ __global__ __launch_bounds__(256) void cl_zsum_chunk_kernel(const int* __restric
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
     int gi = 0;                                                     // current graph of the chunk (uniform)
     int next = __builtin_amdgcn_readlane(my_off, 1);               // first node past it
+    float tt[4] = {0.f, 0.f, 0.f, 0.f};                             // EDOT: this lane's piece of Tf[zrow[current graph]]
+    int my_zr = 0;
+    if constexpr (EDOT) {
+        my_zr = zrow[g0 + min(l, ng - 1)];                          // lanes 0..ng-1: the chunk's rows of Tf
+        vload<4>(Tf + (long long)__builtin_amdgcn_readlane(my_zr, 0) * Kp + jc * 4, tt);
+    }
     auto flush = [&]() {                                            // graph gi is complete: scale, store, start the next one
         const float S = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_ws), gi));
         const float zs = S > 0.f ? scale / S : 0.f;
@@ -1128,6 +1138,7 @@ __global__ __launch_bounds__(256) void cl_zsum_chunk_kernel(const int* __restric
         acc[0] = acc[1] = acc[2] = acc[3] = 0.f;
         ++gi;
         next = __builtin_amdgcn_readlane(my_off, min(gi + 1, ng));
+        if constexpr (EDOT) vload<4>(Tf + (long long)__builtin_amdgcn_readlane(my_zr, min(gi, ng - 1)) * Kp + jc * 4, tt);
     };
     for (int u0 = beg; u0 < end; u0 += NU) {                        // NU nodes per step: independent loads in flight
         float x[NU][4], k4[NU][4], cu[NU];
@@ -1138,6 +1149,9 @@ __global__ __launch_bounds__(256) void cl_zsum_chunk_kernel(const int* __restric
             vload<4>(X + (long long)u * Kp + jc * 4, x[e]);
             cl_keep4<MASK>(mask + (MASK ? (long long)u * mask_ld : 0), mask_ld, jc, k4[e]);
         }
+        float pe[NU];                                               // EDOT: this lane's share of the NU nodes' dot products with Tf
+#pragma unroll
+        for (int e = 0; e < NU; ++e) pe[e] = 0.f;
 #pragma unroll
         for (int e = 0; e < NU; ++e) {
             const int u = u0 + e;
@@ -1145,23 +1159,61 @@ __global__ __launch_bounds__(256) void cl_zsum_chunk_kernel(const int* __restric
                 while (u >= next) flush();                          // graphs that ended before u (empty ones included)
 #pragma unroll
                 for (int k = 0; k < 4; ++k) acc[k] = fmaf(cu[e] * k4[e][k], x[e][k], acc[k]);
+                if constexpr (EDOT) {
+                    float q = 0.f;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) q = fmaf(tt[k] * k4[e][k], x[e][k], q);
+                    pe[e] = (j < nvec) ? q : 0.f;
+                }
             }
+        }
+        if constexpr (EDOT) {
+            // eight sums over the wave in 10 exchanges instead of 8 x 6: halve the set of values a lane carries with every exchange
+            // (lane bit 5 picks nodes 0-3 / 4-7, bit 4 pairs, bit 3 one), then three plain butterflies; lane 8 n holds node n's sum
+            static_assert(NU == 8, "the reduction below is written for eight nodes per step");
+            float a4[4], b2[2];
+            const bool h5 = (l & 32) != 0, h4 = (l & 16) != 0, h3 = (l & 8) != 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) a4[k] = (h5 ? pe[k + 4] : pe[k]) + __shfl_xor(h5 ? pe[k] : pe[k + 4], 32, 64);
+#pragma unroll
+            for (int k = 0; k < 2; ++k) b2[k] = (h4 ? a4[k + 2] : a4[k]) + __shfl_xor(h4 ? a4[k] : a4[k + 2], 16, 64);
+            float c1 = (h3 ? b2[1] : b2[0]) + __shfl_xor(h3 ? b2[0] : b2[1], 8, 64);
+            c1 += __shfl_xor(c1, 4, 64);
+            c1 += __shfl_xor(c1, 2, 64);
+            c1 += __shfl_xor(c1, 1, 64);
+            const int en = (h5 ? 4 : 0) + (h4 ? 2 : 0) + (h3 ? 1 : 0);
+            if ((l & 7) == 0 && u0 + en < end) e_part[(long long)(u0 + en) * ntile + t] = c1;
         }
     }
     while (gi < ng) flush();                                        // the last graph, and empty graphs at the chunk's end
 }
 
 // launch of the Z sweep: small graphs (egonets: ~4 nodes) on the chunked kernel, large ones one wave per graph and tile
+static bool cl_zsum_chunked(int n_nodes, int G) { return (long long)n_nodes <= 16LL * G && G >= 4 * ZS_GPW; }
 static int cl_zsum_launch(const int* graph_off, int G, int n_nodes, const float* X, int Kp, const unsigned* mk, const unsigned* dummy_mask,
-                          int mask_ld, float fs, const float* coef, const float* wsum, float* Z, hipStream_t s) {
+                          int mask_ld, float fs, const float* coef, const float* wsum, float* Z, hipStream_t s, const float* Tf = nullptr,
+                          const int* zrow = nullptr, float* e_part = nullptr) {
     const int ntile = (Kp / 4 + 63) / 64;
-    const bool chunked = (long long)n_nodes <= 16LL * G && G >= 4 * ZS_GPW;
+    const bool chunked = cl_zsum_chunked(n_nodes, G);
+    if (e_part) {                                   // (only the chunked kernel forms the dot products: the entry point checks cl_zsum_chunked)
+        if (!chunked || !Tf || !zrow) return TXE_ERR_ARG;
+        const long long nw = (long long)((G + ZS_GPW - 1) / ZS_GPW) * ntile;
+        ProfScope prof(mk ? "cl_zsum_chunk_kernel<true, true>" : "cl_zsum_chunk_kernel<false, true>", s, 4.0 * (n_nodes + (double)G) * Kp, 1);
+        const dim3 grid((unsigned)((nw + 3) / 4));
+        if (mk) hipLaunchKernelGGL((cl_zsum_chunk_kernel<true, true>), grid, dim3(256), 0, s, graph_off, G, ntile, X, Kp, mk, mask_ld, fs, coef, wsum, Z, Tf, zrow, e_part);
+        else hipLaunchKernelGGL((cl_zsum_chunk_kernel<false, true>), grid, dim3(256), 0, s, graph_off, G, ntile, X, Kp, dummy_mask, mask_ld, fs, coef, wsum, Z, Tf,
+                                zrow, e_part);
+        TXE_CHECK_LAUNCH();
+        return TXE_OK;
+    }
     const long long nwaves = (chunked ? (long long)((G + ZS_GPW - 1) / ZS_GPW) : (long long)G) * ntile;
-    ProfScope prof(chunked ? (mk ? "cl_zsum_chunk_kernel<true>" : "cl_zsum_chunk_kernel<false>") : (mk ? "cl_zsum_kernel<true>" : "cl_zsum_kernel<false>"), s,
+    ProfScope prof(chunked ? (mk ? "cl_zsum_chunk_kernel<true, false>" : "cl_zsum_chunk_kernel<false, false>") : (mk ? "cl_zsum_kernel<true>" : "cl_zsum_kernel<false>"), s,
                    4.0 * (n_nodes + (double)G) * Kp, 1);
     const dim3 grid((unsigned)((nwaves + 3) / 4));
-    if (chunked && mk) hipLaunchKernelGGL(cl_zsum_chunk_kernel<true>, grid, dim3(256), 0, s, graph_off, G, ntile, X, Kp, mk, mask_ld, fs, coef, wsum, Z);
-    else if (chunked) hipLaunchKernelGGL(cl_zsum_chunk_kernel<false>, grid, dim3(256), 0, s, graph_off, G, ntile, X, Kp, dummy_mask, mask_ld, fs, coef, wsum, Z);
+    if (chunked && mk) hipLaunchKernelGGL((cl_zsum_chunk_kernel<true, false>), grid, dim3(256), 0, s, graph_off, G, ntile, X, Kp, mk, mask_ld, fs, coef, wsum, Z,
+                                          (const float*)nullptr, (const int*)nullptr, (float*)nullptr);
+    else if (chunked) hipLaunchKernelGGL((cl_zsum_chunk_kernel<false, false>), grid, dim3(256), 0, s, graph_off, G, ntile, X, Kp, dummy_mask, mask_ld, fs, coef, wsum,
+                                         Z, (const float*)nullptr, (const int*)nullptr, (float*)nullptr);
     else if (mk) hipLaunchKernelGGL(cl_zsum_kernel<true>, grid, dim3(256), 0, s, graph_off, G, ntile, X, Kp, mk, mask_ld, fs, coef, wsum, Z);
     else hipLaunchKernelGGL(cl_zsum_kernel<false>, grid, dim3(256), 0, s, graph_off, G, ntile, X, Kp, dummy_mask, mask_ld, fs, coef, wsum, Z);
     TXE_CHECK_LAUNCH();
@@ -2026,6 +2078,31 @@ struct CollapseWs {
     int splits, seg_blocks, seg_rows, chunks;
 };
 
+// The folded matcher's backward in place of the <dZ, X> sweep: dZ[g] = dsl_g Tf[zrow[g]], so
+//   dc~_u = dsl_g (scale / S_g) sum_tiles e_part[u][tile],   cn_u = c~_u / S_g,   dS_g = -dsl_g raw_g / S_g
+// with dsl = ds (* s for the exp matcher) and raw_g = <Z_g, Tf[zrow[g]]> = the score before exp.  One thread per node; the first G also do dS.
+__global__ __launch_bounds__(256) void cl_fold_dc_kernel(int n_nodes, int G, const int* __restrict__ gid, const float* __restrict__ e_part, int ntile,
+                                                         const float* __restrict__ m_ds, const float* __restrict__ m_s, int m_exp, float scale,
+                                                         const float* __restrict__ wsum, const float* __restrict__ coef, float* __restrict__ dc,
+                                                         float* __restrict__ cn, float* __restrict__ dS) {
+    const int u = blockIdx.x * 256 + threadIdx.x;
+    if (u < G) {
+        const float sv = m_s[u], dsl = m_exp ? m_ds[u] * sv : m_ds[u];
+        const float raw = m_exp ? logf(sv) : sv;
+        const float S = wsum[u];
+        dS[u] = (S > 0.f && dsl != 0.f) ? -dsl * raw / S : 0.f;
+    }
+    if (u >= n_nodes) return;
+    const int g = gid[u];
+    const float dsl = m_exp ? m_ds[g] * m_s[g] : m_ds[g];
+    const float S = wsum[g];
+    const float inv = S > 0.f ? 1.f / S : 0.f;
+    float e = 0.f;
+    for (int t = 0; t < ntile; ++t) e += e_part[(long long)u * ntile + t];
+    dc[u] = dsl * e * scale * inv;
+    cn[u] = coef[u] * inv;
+}
+
 // phases | 128 of the folded layer's backward entries: the weight-gradient product runs on a second stream BESIDE the caller's dZ product
 // and sweeps (every call of one backward pass carries the bit: the workspace layout depends on it).  Few fat k-slices then -- 2 instead
 // of the 7 that fill the machine: ~140 workgroups leave the kernels on the caller's stream their wave slots (cl_bwd_dot 73 -> 61 us,
@@ -2073,11 +2150,18 @@ size_t txe_gat_collapse_ws_bytes(int n_nodes, int n_edges, int G, int Kh, int Pd
 // X [N][Kp], Wp [Fp][Kp] (rows < D the weight, rows D / D+1 the folded attention rows), mask: feature-dropout keep bits of X
 // or NULL.  pos / pw: WeightedMeanReadout (pw == NULL: MeanReadout).  Saved for backward: a12 [N][2], alpha [E], coef [N],
 // wsum [G], gid [N] (graph of each node), Z [G][Kp].  hg [G][D] (row stride ld_hg).
+// column tiles per node of txe_gat_collapse_fwd's e_part output; 0 when the batch does not take the chunked Z sweep that forms it
+int txe_gat_collapse_e_tiles(int n_nodes, int G, int Kh, int Pd) {
+    if (n_nodes <= 0 || G <= 0 || !cl_zsum_chunked(n_nodes, G)) return 0;
+    return (round_up(Kh + Pd, 32) / 4 + 63) / 64;
+}
+
 int txe_gat_collapse_fwd(const int* rowptr_in, const int* col_src, const int* rowptr_out, const int* col_dst, const int* pos_out,
                          const int* graph_off, int n_nodes, int n_edges, int G, const float* X, int Kh, int Pd, const float* Wp, int D,
                          float feat_drop_p, const unsigned* mask, float attn_slope, float attn_drop_p, unsigned long long seed,
                          const int* pos, const float* pw, float* a12, int a12_ready, float* alpha, float* coef, float* wsum, int* gid,
-                         float* Z, float* hg, long long ld_hg, void* ws, size_t ws_bytes, void* stream) {
+                         float* Z, float* hg, long long ld_hg, const float* Tf, const int* zrow, float* e_part, void* ws, size_t ws_bytes,
+                         void* stream) {
     if (n_nodes < 0 || n_edges < 0 || G < 0 || Kh < 1 || Pd < 0 || D < 1 || !rowptr_in || !rowptr_out || !graph_off || !X || !Wp || !a12 ||
         !alpha || !coef || !wsum || !gid || !Z || !ws || (pw && !pos))
         return TXE_ERR_ARG;
@@ -2105,7 +2189,10 @@ int txe_gat_collapse_fwd(const int* rowptr_in, const int* col_src, const int* ro
     } else if (G > 0) {
         hipLaunchKernelGGL(cl_wsum_kernel, dim3((G + 3) / 4), dim3(256), 0, s, graph_off, G, pos, pw, wsum, gid);
     }
-    const int rc_z = cl_zsum_launch(graph_off, G, n_nodes, X, Kp, mk, dummy_mask, mask_ld, fs, (const float*)coef, (const float*)wsum, Z, s);
+    // e_part != NULL (with hg == NULL: the folded matcher already has Tf [runs][Kp] and zrow [G], graph -> its row of Tf): the sweep also
+    // leaves <Tf[zrow[g]], keep X[u]> per node and column tile at e_part [N][txe_gat_collapse_e_tiles] -- backward's <dZ, X> sweep, ahead of time
+    const int rc_z = cl_zsum_launch(graph_off, G, n_nodes, X, Kp, mk, dummy_mask, mask_ld, fs, (const float*)coef, (const float*)wsum, Z, s, Tf, zrow,
+                                    e_part);
     if (rc_z) return rc_z;
     if (!hg) return TXE_OK;          // (the caller folds hg = Z W^T into what consumes it: txe_bilinear_folded_*)
     VMat A = vmat_plain(Z, Kp, G, Kp);
@@ -2261,7 +2348,10 @@ int txe_gat_collapse_bwd_fused(const int* rowptr_in, const int* col_src, const i
                                float act_slope, const float* Yp, long long ld_yp, int Hp, int Dp, float attn_slope_p,
                                float attn_drop_p_p, unsigned long long seed_p, const float* alpha_p, float* d_Yp, long long ld_dyp,
                                int n_pad, float* dz_p, float* dW, float* d_attn_l, float* d_attn_r, float* dP, float* d_pw, int phases,
-                               const float* dw_main, int dw_slices, void* chain, void* ws, size_t ws_bytes, void* stream) {
+                               const float* dw_main, int dw_slices, const float* e_part, const float* m_ds, const float* m_s, int m_exp,
+                               void* chain, void* ws, size_t ws_bytes, void* stream) {
+    // phases | 512 (with | 256): the <dZ, X> sweep was done in forward (txe_gat_collapse_fwd's e_part); m_ds / m_s [G]: the folded matcher's
+    // score gradient and scores, m_exp: it exponentiates -- see cl_fold_dc_kernel
     // phases | 256: `d_hg` IS dZ [G][Kp] (ld_dhg its row pitch) -- whoever consumed Z folded hg = Z W^T into its own product
     // (txe_bilinear_folded_*) and hands back dZ and the main part of dW as dw_slices slices [D][Kp] at dw_main (summed in order; 0: none)
     const bool dz_given = (phases & 256) != 0;
@@ -2312,10 +2402,21 @@ int txe_gat_collapse_bwd_fused(const int* rowptr_in, const int* col_src, const i
     const int nblk = (G > 0 && n_nodes > 0) ? fw.nblocks : 0;
     if ((phases & 4) && G > 0 && n_nodes > 0) {
 
+        if (phases & 512) {
+            if (!dz_given || !e_part || !m_ds || !m_s) return TXE_ERR_ARG;
+            const int nt_e = txe_gat_collapse_e_tiles(n_nodes, G, Kh, Pd);
+            if (nt_e <= 0) return TXE_ERR_ARG;
+            ProfScope prof("cl_fold_dc_kernel", s, 4.0 * n_nodes * (nt_e + 4.0), 1);
+            const int nmax = n_nodes > G ? n_nodes : G;
+            hipLaunchKernelGGL(cl_fold_dc_kernel, dim3((nmax + 255) / 256), dim3(256), 0, s, n_nodes, G, gid, e_part, nt_e, m_ds, m_s, m_exp, fs, wsum, coef,
+                               p.dc, p.cn, p.dS);
+            TXE_CHECK_LAUNCH();
+        } else {
         // (dS[g] = -<dZ[g], Z[g]> / S_g; with d_hg at hand it is <d_hg[g], hg[g]>, D columns instead of Kp)
         rc = cl_bwd_dot_launch(n_nodes, gid, X, Kp, mk, dummy_mask, mask_ld, fs, dZv, wsum, coef, p.dc, p.cn, (G + 3) / 4, G, dz_given ? Kp : D,
                                d_hg, ld_dhg, dz_given ? Z : hg, dz_given ? (long long)Kp : ld_hg, p.dS, 4.0 * ((n_nodes + (double)G) * Kp + 2.0 * G * D), s);
         if (rc) return rc;
+        }
         hipLaunchKernelGGL(cl_attn_bwd_kernel, dim3((G + CG_GRAPHS - 1) / CG_GRAPHS), dim3(256), 0, s, rowptr_in, col_src, rowptr_out, pos_out,
                            graph_off, G, a12, attn_slope, alpha, attn_drop_p, as, seed, pos, pw, (const float*)p.dc, (const float*)p.dS, p.dz,
                            p.da1, p.da2, p.dwv);

@@ -60,6 +60,8 @@ class TaxoExpan(torch.nn.Module):
         # layer's product runs on one row per query run inside the matcher (zoo.DeferredGraphVector; same arithmetic, re-associated)
         if isinstance(out, zoo.DeferredNodeOutput) and getattr(self.match, "wants_folded_graph_vector", None) is not None:
             out._want_folded = self.match.wants_folded_graph_vector(qf)
+            if out._want_folded and hasattr(self.match, "fold_job"):
+                out._fold_job = self.match.fold_job(qf)
         g.ndata['h'] = out
         return self.match(self.readout(g, positions), qf)
 

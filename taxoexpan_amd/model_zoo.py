@@ -157,6 +157,7 @@ class DeferredNodeOutput:
         self._fn = fn
         self._tensor = None
         self._want_folded = False                   # TaxoExpan.forward: the matcher can take the graph vector folded (DeferredGraphVector)
+        self._fold_job = None                       # ... and this is the query-side half of its work (ops.folded_match_job)
 
     def _out_dim(self):
         return self._args[1].out_dims[-1]
@@ -171,6 +172,7 @@ class DeferredNodeOutput:
             # the stack stops at Z [G, Kp]; hg = Z W^T is formed by whoever asks for the tensor -- or never (_Bilinear on repeating queries)
             c.final = "collapse_z"
             c.link = ops.FoldLink()
+            c.fold_job = self._fold_job
             Z, Wp = ops.apply_stack(self._fn, csr, c, h, pos, rpos, pw, *params)
             return DeferredGraphVector(Z, Wp, c.link, self._out_dim())
         c.final = "collapse"
@@ -522,6 +524,16 @@ class _Bilinear(nn.Module):
         dec = self.__dict__.get("_stacked_dec")
         if dec is not None and dec[0] is e2 and dec[1] and self._stacked_runs_ok(e1, e2):
             return "stacked"
+        return None
+
+    def fold_job(self, e2):
+        """TaxoExpan.forward, when the graph vector will arrive folded: the query-side half of the folded match as a job the encoder runs
+        before its Z sweep (ops.folded_match_job)"""
+        form = self._runs_form(None, e2)
+        if form == "rows":
+            return ops.folded_match_job(None, e2.rows, e2.run_off, self.W.weight)
+        if form == "stacked":
+            return ops.folded_match_job(e2, None, None, self.W.weight)
         return None
 
     def wants_folded_graph_vector(self, e2):

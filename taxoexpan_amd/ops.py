@@ -45,6 +45,7 @@ _NO_FUSED_LOGITS = False    # the folded layer's attention logits by their own s
 _NO_TABLE_SWEEP = False     # table rows materialised (txe_gather_add_rows) instead of formed inside the sweep
 _NO_SIDE_STREAM = False     # everything on the caller's stream
 _NO_MATCH_FOLD = False      # the graph vector hg = Z W^T is always formed (never folded into the bilinear matcher's run products)
+_NO_FOLD_EDOT = False       # the folded matcher's T does not ride in the Z sweep: backward runs its <dZ, X> sweep
 _NO_FUSED_BWD = False       # the folded layer's backward as the unfused chain (d_X' materialised)
 _NO_QUERY_RUNS = False      # stacked query rows always take the GEMM form of the bilinear match
 _NO_TAIL_CHAIN = False      # every layer's last reduction launch in place instead of chained into the bottom layer's
@@ -353,7 +354,7 @@ def _gat_layer_prepare(st, h, ld_h, pos, feat_p):
          st.H, st.D, ptr(st.Wp), feat_p, st.seed, ptr(st.mask), s)
 
 
-def _gat_collapse_fwd(csr, st, h, ld_h, pos, rpos, pw, feat_p, attn_p, attn_slope, a12=None, z_only=False):
+def _gat_collapse_fwd(csr, st, h, ld_h, pos, rpos, pw, feat_p, attn_p, attn_slope, a12=None, z_only=False, fold_job=None, link=None):
     """output layer (one head) folded behind the weighted-mean readout: hg [G, D] (txe_gat_collapse_fwd).
     a12 given: the layer is already prepared and the previous layer's aggregation has formed its attention logits.
     z_only: stop at Z [G, Kp] (hg = Z W^T is left to the consumer: FoldedGraphLinearFunction / BilinearFoldedRunsFunction)."""
@@ -367,10 +368,17 @@ def _gat_collapse_fwd(csr, st, h, ld_h, pos, rpos, pw, feat_p, attn_p, attn_slop
     gid = torch.empty(max(N, 1), dtype=torch.int32, device=st.X.device)
     wsb = call("txe_gat_collapse_ws_bytes", N, E, G, st.Kh, st.Pd, st.D, 8)
     ws = _ws(wsb, st.X)
+    Tf = zrow = e_part = None
+    if z_only and fold_job is not None and link is not None and N > 0 and G > 0 and not _NO_FOLD_EDOT:
+        nt = call("txe_gat_collapse_e_tiles", N, G, st.Kh, st.Pd)
+        fw = fold_job(st.Wp, st.D) if nt > 0 else None       # the matcher's runs, V and T, formed now: T rides in the Z sweep
+        if fw is not None:
+            Tf, zrow, e_part = fw["T"], _fold_job_run_ids(fw, G, st.X), _empty((N, nt), st.X)
+            link.fwd, link.e_part = fw, e_part
     call("txe_gat_collapse_fwd", ptr(csr.rowptr_in), ptr(csr.col_src), ptr(csr.rowptr_out), ptr(csr.col_dst), ptr(csr.pos_out),
          ptr(csr.graph_off), N, E, G, ptr(st.X), st.Kh, st.Pd, ptr(st.Wp), st.D, feat_p, ptr(st.mask), attn_slope, attn_p, st.seed + 1,
-         ptr(rpos), ptr(pw), ptr(a12), int(ready), ptr(alpha), ptr(coef), ptr(wsum), ptr(gid), ptr(Z), ptr(hg), st.D, ptr(ws), wsb,
-         _lib.stream_ptr())
+         ptr(rpos), ptr(pw), ptr(a12), int(ready), ptr(alpha), ptr(coef), ptr(wsum), ptr(gid), ptr(Z), ptr(hg), st.D, ptr(Tf), ptr(zrow),
+         ptr(e_part), ptr(ws), wsb, _lib.stream_ptr())
     st.cl = (a12, alpha, coef, wsum, gid, Z, hg)
     return Z if z_only else hg
 
@@ -507,10 +515,13 @@ class FoldLink:
     """What the producer of Z (GATStackFunction, cfg.final == 'collapse_z') shares with whoever consumes Z as the folded graph vector
     hg = Z W^T: the consumer's backward leaves the main part of the output layer's weight gradient here (S slices [D, Kp], summed in
     order) and hands dZ back through autograd; the producer's backward adds the attention rows' part and returns the whole dW."""
-    __slots__ = ("part", "S")
+    __slots__ = ("part", "S", "fwd", "e_part", "m")
 
     def __init__(self):
         self.part, self.S = None, 0
+        # with a matcher job (folded_match_job) the producer forms T before its Z sweep, the sweep leaves <T[run(g)], keep X[u]> per node
+        # (e_part) and backward's <dZ, X> sweep becomes a scaling by the matcher's score gradient (m = (ds, s, apply_exp)):
+        self.fwd, self.e_part, self.m = None, None, None
 
 
 def _gat_collapse_bwd_fused(csr, st, sp, pos, rpos, pw, vocab, feat_p, attn_p, attn_slope, d_hg, act_slope, chain=None, link=None):
@@ -534,8 +545,10 @@ def _gat_collapse_bwd_fused(csr, st, sp, pos, rpos, pw, vocab, feat_p, attn_p, a
              ptr(st.al), ptr(st.ar), st.D, feat_p, ptr(st.mask), attn_slope, attn_p, st.seed + 1, ptr(pw), ptr(a12), ptr(alpha), ptr(coef),
              ptr(wsum), ptr(gid), ptr(Z), ptr(hg), st.D, ptr(d_hg), ld, act_slope if act_slope else 1.0, ptr(sp.Y), sp.Fp, sp.H, sp.D,
              attn_slope, attn_p, sp.seed + 1, ptr(sp.alpha), ptr(d_Yp), sp.Fp, sp.Fp - Fe, ptr(dz), ptr(dW), ptr(dal), ptr(dar), ptr(dP),
-             ptr(d_pw), phases, ptr(link.part) if (link is not None and link.S > 0) else None, link.S if link is not None else 0,
+             ptr(d_pw), phases | (512 if edot else 0), ptr(link.part) if (link is not None and link.S > 0) else None,
+             link.S if link is not None else 0, *((ptr(link.e_part), ptr(link.m[0]), ptr(link.m[1]), int(link.m[2])) if edot else (None, None, None, 0)),
              chain.ptr if chain is not None else None, ptr(ws), wsb, _lib.stream_ptr())
+    edot = link is not None and link.e_part is not None and link.m is not None     # the <dZ, X> sweep was done in forward (FoldLink)
     last = 8 | (64 if chain is not None else 0)     # (with a chain the final reductions are left to the bottom layer's launch)
     if chain is not None:
         chain.keep += [ws, d_hg, st, sp] + ([link.part] if link is not None else [])
@@ -618,7 +631,9 @@ class GATStackFunction(torch.autograd.Function):
                 F = st.H * st.D
                 if last and collapse:
                     res = _gat_collapse_fwd(csr, st, src if l == 0 else None, ld_h if l == 0 else 0, pos if st.P is not None else None,
-                                            rpos, pwf, cfg.feat_p, cfg.attn_p, cfg.attn_slope, a12=fused_a12, z_only=z_only)
+                                            rpos, pwf, cfg.feat_p, cfg.attn_p, cfg.attn_slope, a12=fused_a12, z_only=z_only,
+                                            fold_job=getattr(cfg, "fold_job", None) if (z_only and need) else None,
+                                            link=getattr(cfg, "link", None))
                     if z_only:
                         res = (res, st.Wp)
                         ctx.mark_non_differentiable(st.Wp)
@@ -1315,6 +1330,44 @@ class FoldedGraphLinearFunction(torch.autograd.Function):
         return dZ, None, None, None
 
 
+def folded_match_job(e2, rows, run_off, Wm):
+    """What a 'collapse_z' stack calls right before its Z sweep (cfg.fold_job): the query-side half of BilinearFoldedRunsFunction -- the
+    runs (found on the device in the stacked e2, or given as rows + run_off), V = Wm q, T = Wp[:D]^T V and the graph -> run map -- on the
+    caller's stream.  T then rides in the sweep (FoldLink.e_part) and the matcher's forward starts from the scores."""
+    def job(Wp, D):
+        Wmf = _f32(Wm).reshape(Wm.shape[-2], Wm.shape[-1])
+        l, r = Wmf.shape
+        if l != D or not Wm.is_cuda:
+            return None
+        Kp = Wp.shape[1]
+        with _lib.on_device(Wp.device):
+            if rows is None:
+                Q, ldq = _rows(e2)
+                G = U = Q.shape[0]
+                run_id, roff, n_runs = find_row_runs(Q)
+                first_row = 1
+            else:
+                Q, ldq = _rows(rows)
+                U, first_row, roff, n_runs = Q.shape[0], 0, run_off, None
+                G = None
+            V, T = _empty((max(U, 1), l), Wp), _empty((max(U, 1), Kp), Wp)
+            call("txe_bilinear_folded_fwd", None, Kp, G if G is not None else 1, Kp, ptr(Wp), Kp, l, ptr(Q), ldq, r, ptr(roff), ptr(n_runs), U, first_row,
+                 ptr(Wmf), 0, ptr(V), ptr(T), None, 1, _lib.stream_ptr())
+        fw = dict(e2=e2, rows=rows, run_off_in=run_off, Wm=Wm, Wm_version=Wm._version, Wp=Wp, Q=Q, ldq=ldq, roff=roff, n_runs=n_runs, U=U,
+                  first_row=first_row, V=V, T=T, run_id=(run_id if rows is None else None))
+        return fw
+    return job
+
+
+def _fold_job_run_ids(fw, G, ref):
+    """graph -> run for the given-runs form (the stacked form's run detection has produced it)"""
+    if fw["run_id"] is None:
+        rid = torch.empty(max(G, 1), dtype=torch.int32, device=ref.device)
+        call("txe_runs_expand", ptr(fw["roff"]), fw["U"], G, ptr(rid), _lib.stream_ptr())
+        fw["run_id"] = rid
+    return fw["run_id"]
+
+
 class BilinearFoldedRunsFunction(torch.autograd.Function):
     """The bilinear match on the folded graph vector (txe_bilinear_folded_*): s_i = <Z_i, T[u(i)]>, T[u] = Wp[:D]^T (Wm q_u) -- the output
     layer's D x Kp product runs on the U run rows of the repeating queries instead of the G graph rows, forward and backward.  Queries:
@@ -1329,18 +1382,25 @@ class BilinearFoldedRunsFunction(torch.autograd.Function):
         l, r = Wmf.shape
         if l != D:
             raise RuntimeError("bilinear matcher: l_dim does not match the graph vector")
-        if rows is None:
-            Q, ldq = _rows(e2)
-            _run_id, run_off, n_runs = find_row_runs(Q)
-            U, first_row = G, 1
+        fw = link.fwd
+        ready = (fw is not None and fw["Wp"] is Wp and fw["Wm"] is Wm and fw["Wm_version"] == Wm._version and fw["e2"] is e2
+                 and fw["rows"] is rows and fw["run_off_in"] is run_off and (rows is not None or fw["U"] == G))
+        if ready:                                   # the stack asked for the runs, V and T before its Z sweep (folded_match_job)
+            Q, ldq, run_off, n_runs, U, first_row, V, T = (fw[k] for k in ("Q", "ldq", "roff", "n_runs", "U", "first_row", "V", "T"))
         else:
-            Q, ldq = _rows(rows)
-            n_runs, U, first_row = None, Q.shape[0], 0
+            link.fwd = link.e_part = None           # (whatever rode in the sweep belongs to other queries / weights)
+            if rows is None:
+                Q, ldq = _rows(e2)
+                _run_id, run_off, n_runs = find_row_runs(Q)
+                U, first_row = G, 1
+            else:
+                Q, ldq = _rows(rows)
+                n_runs, U, first_row = None, Q.shape[0], 0
+            V, T = _empty((max(U, 1), l), Z), _empty((max(U, 1), Kp), Z)
         s = _empty((G,), Z)
-        V, T = _empty((max(U, 1), l), Z), _empty((max(U, 1), Kp), Z)
         with _lib.on_device(Z.device):
             call("txe_bilinear_folded_fwd", ptr(Z), Kp, G, Kp, ptr(Wp), Kp, l, ptr(Q), ldq, r, ptr(run_off), ptr(n_runs), U, first_row, ptr(Wmf),
-                 int(apply_exp), ptr(V), ptr(T), ptr(s), _lib.stream_ptr())
+                 int(apply_exp), ptr(V), ptr(T), ptr(s), 2 if ready else 3, _lib.stream_ptr())
         ctx.misc = (Z, Wp, link, Wmf, Q, ldq, run_off, n_runs, U, first_row, V, T, s, int(apply_exp), Wm.shape)
         return s.unsqueeze(1)
 
@@ -1356,6 +1416,7 @@ class BilinearFoldedRunsFunction(torch.autograd.Function):
             call("txe_bilinear_folded_bwd", ptr(Z), Kp, G, Kp, ptr(Wp), Kp, l, ptr(Q), ldq, r, ptr(run_off), ptr(n_runs), U, first_row, apply_exp,
                  ptr(V), ptr(T), ptr(s), ptr(ds), ptr(dZ), Kp, ptr(dT), ptr(dV), ptr(dWm), ptr(dWf), _lib.stream_ptr())
         link.part, link.S = dWf, 1
+        link.m = (ds, s, apply_exp) if link.e_part is not None else None
         return dZ, None, None, None, dWm.reshape(wshape), None, None, None, None
 
 

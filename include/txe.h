@@ -334,7 +334,8 @@ int txe_gat_collapse_bwd(const int* rowptr_in, const int* col_src, const int* ro
  * dw_slices slices [D][Kp] at dw_main (summed in order; 0 slices: none) -- this call adds the attention rows' part.
  * | 512 (with | 256): the <dZ, X> sweep was formed in forward -- txe_gat_collapse_fwd with Tf [runs][Kp], zrow [G] (graph -> its row of Tf) and
  * e_part [N][txe_gat_collapse_e_tiles] given leaves <Tf[zrow[g]], keep X[u]> there; with the folded matcher's dZ[g] = dsl_g Tf[zrow[g]] backward
- * needs only its score gradient m_ds [G], its scores m_s [G] and whether it exponentiates (m_exp).
+ * needs only its score gradient m_ds [G], its scores m_s [G], whether it exponentiates (m_exp), and Tf / zrow again: the fused sweep reads its
+ * "dZ[g]" rows as Tf[zrow[g]] with dsl_g folded into the node coefficients -- d_hg may be NULL, dZ is never formed.
  * txe_gat_fused_bwd_supported: 1 if the shape qualifies (Hp in {1,2,4}, Hp*Dp % 16 == 0, <= 128 columns behind the feature part). */
 int txe_gat_fused_bwd_supported(int Kh, int Pd, int Hp, int Dp);
 size_t txe_gat_collapse_bwd_fused_ws_bytes(int n_nodes, int n_edges, int G, int Kh, int Pd, int D, int vocab, int Hp);
@@ -348,7 +349,8 @@ int txe_gat_collapse_bwd_fused(const int* rowptr_in, const int* col_src, const i
                                float attn_drop_p_p, unsigned long long seed_p, const float* alpha_p, float* d_Yp, long long ld_dyp,
                                int n_pad, float* dz_p, float* dW, float* d_attn_l, float* d_attn_r, float* dP, float* d_pw, int phases,
                                const float* dw_main, int dw_slices, const float* e_part, const float* m_ds, const float* m_s, int m_exp,
-                               void* chain, void* ws, size_t ws_bytes, void* stream);
+                               const float* Tf, const int* zrow, int* zgid /* [N] scratch */, void* chain, void* ws, size_t ws_bytes,
+                               void* stream);
 
 /* ---- output GCNLayer folded behind MeanReadout / WeightedMeanReadout: model_zoo.py:35-47,139-167,227-242.
  * hg[g] = (sum_{u in g} c_u Xd[u]) W + b with c_u = norm_u sum_{v: u->v} w_v norm_v / S_g (graph constants).  X / Wp / mask as for

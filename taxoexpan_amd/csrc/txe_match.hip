@@ -225,7 +225,7 @@ __global__ __launch_bounds__(256) void runs_bwd_kernel(const float* __restrict__
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
                 if (i + q < i1) {
-                    d_e1[(long long)(i + q) * ld_de1 + k] = dsl[q] * v;
+                    if (d_e1) d_e1[(long long)(i + q) * ld_de1 + k] = dsl[q] * v;     // (NULL: only the run sums are wanted)
                     acc = fmaf(dsl[q], x[q], acc);
                 }
             }
@@ -758,7 +758,7 @@ int txe_bilinear_folded_fwd(const float* Z, long long ld_z, int G, int Kp, const
 int txe_bilinear_folded_bwd(const float* Z, long long ld_z, int G, int Kp, const float* Wf, long long ld_wf, int l, const float* Q, long long ld_q,
                             int r, const int* run_off, const int* n_runs, int U, int first_row, int apply_exp, const float* V, const float* T,
                             const float* s, const float* ds, float* dZ, long long ld_dz, float* dT, float* dV, float* dWm, float* dWf, void* stream) {
-    if (G < 0 || U < 0 || Kp < 1 || l < 1 || r < 1 || !Z || !Wf || !Q || !run_off || !V || !T || !s || !ds || !dZ || !dT || !dV || !dWm || !dWf ||
+    if (G < 0 || U < 0 || Kp < 1 || l < 1 || r < 1 || !Z || !Wf || !Q || !run_off || !V || !T || !s || !ds || !dT || !dV || !dWm || !dWf ||
         (first_row && !n_runs) || ld_wf != Kp)
         return TXE_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;

@@ -2079,12 +2079,13 @@ struct CollapseWs {
 };
 
 // The folded matcher's backward in place of the <dZ, X> sweep: dZ[g] = dsl_g Tf[zrow[g]], so
-//   dc~_u = dsl_g (scale / S_g) sum_tiles e_part[u][tile],   cn_u = c~_u / S_g,   dS_g = -dsl_g raw_g / S_g
+//   dc~_u = dsl_g (scale / S_g) sum_tiles e_part[u][tile],   cn_u = dsl_g c~_u / S_g (the sweep's dZ row is Tf's),   dS_g = -dsl_g raw_g / S_g
 // with dsl = ds (* s for the exp matcher) and raw_g = <Z_g, Tf[zrow[g]]> = the score before exp.  One thread per node; the first G also do dS.
 __global__ __launch_bounds__(256) void cl_fold_dc_kernel(int n_nodes, int G, const int* __restrict__ gid, const float* __restrict__ e_part, int ntile,
                                                          const float* __restrict__ m_ds, const float* __restrict__ m_s, int m_exp, float scale,
                                                          const float* __restrict__ wsum, const float* __restrict__ coef, float* __restrict__ dc,
-                                                         float* __restrict__ cn, float* __restrict__ dS) {
+                                                         float* __restrict__ cn, float* __restrict__ dS, const int* __restrict__ zrow,
+                                                         int* __restrict__ zgid) {
     const int u = blockIdx.x * 256 + threadIdx.x;
     if (u < G) {
         const float sv = m_s[u], dsl = m_exp ? m_ds[u] * sv : m_ds[u];
@@ -2100,7 +2101,9 @@ __global__ __launch_bounds__(256) void cl_fold_dc_kernel(int n_nodes, int G, con
     float e = 0.f;
     for (int t = 0; t < ntile; ++t) e += e_part[(long long)u * ntile + t];
     dc[u] = dsl * e * scale * inv;
-    cn[u] = coef[u] * inv;
+    // the fused sweep reads "dZ[g]" as Tf[zrow[g]] with dsl_g folded into the node's coefficient: dZ itself is never formed
+    cn[u] = coef[u] * inv * dsl;
+    zgid[u] = zrow[g];
 }
 
 // phases | 128 of the folded layer's backward entries: the weight-gradient product runs on a second stream BESIDE the caller's dZ product
@@ -2349,14 +2352,14 @@ int txe_gat_collapse_bwd_fused(const int* rowptr_in, const int* col_src, const i
                                float attn_drop_p_p, unsigned long long seed_p, const float* alpha_p, float* d_Yp, long long ld_dyp,
                                int n_pad, float* dz_p, float* dW, float* d_attn_l, float* d_attn_r, float* dP, float* d_pw, int phases,
                                const float* dw_main, int dw_slices, const float* e_part, const float* m_ds, const float* m_s, int m_exp,
-                               void* chain, void* ws, size_t ws_bytes, void* stream) {
+                               const float* Tf, const int* zrow, int* zgid, void* chain, void* ws, size_t ws_bytes, void* stream) {
     // phases | 512 (with | 256): the <dZ, X> sweep was done in forward (txe_gat_collapse_fwd's e_part); m_ds / m_s [G]: the folded matcher's
     // score gradient and scores, m_exp: it exponentiates -- see cl_fold_dc_kernel
     // phases | 256: `d_hg` IS dZ [G][Kp] (ld_dhg its row pitch) -- whoever consumed Z folded hg = Z W^T into its own product
     // (txe_bilinear_folded_*) and hands back dZ and the main part of dW as dw_slices slices [D][Kp] at dw_main (summed in order; 0: none)
     const bool dz_given = (phases & 256) != 0;
     if (n_nodes < 0 || n_edges < 0 || G < 0 || Kh < 1 || Pd < 0 || D < 1 || !rowptr_in || !rowptr_out || !graph_off || !X || !Wp || !W ||
-        !attn_l || !attn_r || !a12 || !alpha || !coef || !wsum || !gid || !Z || (!hg && !dz_given) || !d_hg || !dW || !d_attn_l || !d_attn_r ||
+        !attn_l || !attn_r || !a12 || !alpha || !coef || !wsum || !gid || !Z || (!hg && !dz_given) || (!d_hg && !(phases & 512)) || !dW || !d_attn_l || !d_attn_r ||
         !ws || !Yp || !alpha_p || !d_Yp || !dz_p || n_pad < 0 || dw_slices < 0 || (dw_slices > 0 && !dw_main))
         return TXE_ERR_ARG;
     if (!txe_gat_fused_bwd_supported(Kh, Pd, Hp, Dp)) return TXE_ERR_ARG;
@@ -2403,13 +2406,13 @@ int txe_gat_collapse_bwd_fused(const int* rowptr_in, const int* col_src, const i
     if ((phases & 4) && G > 0 && n_nodes > 0) {
 
         if (phases & 512) {
-            if (!dz_given || !e_part || !m_ds || !m_s) return TXE_ERR_ARG;
+            if (!dz_given || !e_part || !m_ds || !m_s || !Tf || !zrow || !zgid) return TXE_ERR_ARG;
             const int nt_e = txe_gat_collapse_e_tiles(n_nodes, G, Kh, Pd);
             if (nt_e <= 0) return TXE_ERR_ARG;
             ProfScope prof("cl_fold_dc_kernel", s, 4.0 * n_nodes * (nt_e + 4.0), 1);
             const int nmax = n_nodes > G ? n_nodes : G;
             hipLaunchKernelGGL(cl_fold_dc_kernel, dim3((nmax + 255) / 256), dim3(256), 0, s, n_nodes, G, gid, e_part, nt_e, m_ds, m_s, m_exp, fs, wsum, coef,
-                               p.dc, p.cn, p.dS);
+                               p.dc, p.cn, p.dS, zrow, zgid);
             TXE_CHECK_LAUNCH();
         } else {
         // (dS[g] = -<dZ[g], Z[g]> / S_g; with d_hg at hand it is <d_hg[g], hg[g]>, D columns instead of Kp)
@@ -2423,9 +2426,10 @@ int txe_gat_collapse_bwd_fused(const int* rowptr_in, const int* col_src, const i
         {
             FusedBwdArgs a;
             memset(&a, 0, sizeof(a));
-            a.rowptr_out = rowptr_out; a.col_dst = col_dst; a.pos_out = pos_out; a.gid = gid; a.pos = pos ? pos : gid; a.n_nodes = n_nodes;
+            a.rowptr_out = rowptr_out; a.col_dst = col_dst; a.pos_out = pos_out; a.gid = (phases & 512) ? (const int*)zgid : gid; a.pos = pos ? pos : gid;
+            a.n_nodes = n_nodes;
             a.X = X; a.Kp = Kp; a.Kh = Kh; a.Pd = Pd; a.mask = mk ? mk : dummy_mask; a.mask_ld = mask_ld; a.fscale = fs;
-            a.dZ = dZv; a.cn = p.cn; a.da1 = p.da1; a.da2 = p.da2; a.wa = wa; a.act_slope = act_slope; a.vocab = vocab > 0 ? vocab : 1;
+            a.dZ = (phases & 512) ? Tf : dZv; a.cn = p.cn; a.da1 = p.da1; a.da2 = p.da2; a.wa = wa; a.act_slope = act_slope; a.vocab = vocab > 0 ? vocab : 1;
             a.Y = Yp; a.ld_y = ld_yp; a.H = Hp; a.D = Dp; a.alpha = alpha_p; a.drop_p = attn_drop_p_p;
             a.drop_scale = 1.f / (1.f - attn_drop_p_p); a.seed = seed_p;
             a.d_Y = d_Yp; a.ld_dy = ld_dyp; a.dal = fw.dal; a.dwa_part = fw.dwa_part; a.ppart = fw.ppart;

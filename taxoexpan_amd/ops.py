@@ -546,14 +546,16 @@ def _gat_collapse_bwd_fused(csr, st, sp, pos, rpos, pw, vocab, feat_p, attn_p, a
              ptr(wsum), ptr(gid), ptr(Z), ptr(hg), st.D, ptr(d_hg), ld, act_slope if act_slope else 1.0, ptr(sp.Y), sp.Fp, sp.H, sp.D,
              attn_slope, attn_p, sp.seed + 1, ptr(sp.alpha), ptr(d_Yp), sp.Fp, sp.Fp - Fe, ptr(dz), ptr(dW), ptr(dal), ptr(dar), ptr(dP),
              ptr(d_pw), phases | (512 if edot else 0), ptr(link.part) if (link is not None and link.S > 0) else None,
-             link.S if link is not None else 0, *((ptr(link.e_part), ptr(link.m[0]), ptr(link.m[1]), int(link.m[2])) if edot else (None, None, None, 0)),
+             link.S if link is not None else 0, *((ptr(link.e_part), ptr(link.m[0]), ptr(link.m[1]), int(link.m[2]), ptr(link.fwd["T"]),
+                                                  ptr(link.fwd["run_id"]), ptr(zgid)) if edot else (None, None, None, 0, None, None, None)),
              chain.ptr if chain is not None else None, ptr(ws), wsb, _lib.stream_ptr())
     edot = link is not None and link.e_part is not None and link.m is not None     # the <dZ, X> sweep was done in forward (FoldLink)
+    zgid = torch.empty(max(N, 1), dtype=torch.int32, device=st.X.device) if edot else None
     last = 8 | (64 if chain is not None else 0)     # (with a chain the final reductions are left to the bottom layer's launch)
     if chain is not None:
-        chain.keep += [ws, d_hg, st, sp] + ([link.part] if link is not None else [])
+        chain.keep += [ws, d_hg, st, sp, zgid] + ([link.part, link.fwd, link.m] if link is not None else [])
     if link is not None:                            # dZ given: no product left in this layer's backward, nothing for a second stream
-        if ld != st.Kp:
+        if ld != st.Kp and not edot:
             raise RuntimeError("folded graph vector: dZ must have the padded row pitch")
         run(4 | 256)
         run(last | 256)
@@ -1410,11 +1412,12 @@ class BilinearFoldedRunsFunction(torch.autograd.Function):
         G, Kp = Z.shape
         l, r = Wmf.shape
         ds = _f32(ds.reshape(-1))
+        edot = link.e_part is not None              # the stack reads "dZ[g]" as dsl_g T[run(g)] (FoldLink): the tensor below is shape only
         dZ, dT, dV = _empty((G, Kp), Z), _empty((max(U, 1), Kp), Z), _empty((max(U, 1), l), Z)
         dWm, dWf = _empty((l, r), Z), _empty((l, Kp), Z)
         with _lib.on_device(Z.device):
             call("txe_bilinear_folded_bwd", ptr(Z), Kp, G, Kp, ptr(Wp), Kp, l, ptr(Q), ldq, r, ptr(run_off), ptr(n_runs), U, first_row, apply_exp,
-                 ptr(V), ptr(T), ptr(s), ptr(ds), ptr(dZ), Kp, ptr(dT), ptr(dV), ptr(dWm), ptr(dWf), _lib.stream_ptr())
+                 ptr(V), ptr(T), ptr(s), ptr(ds), None if edot else ptr(dZ), Kp, ptr(dT), ptr(dV), ptr(dWm), ptr(dWf), _lib.stream_ptr())
         link.part, link.S = dWf, 1
         link.m = (ds, s, apply_exp) if link.e_part is not None else None
         return dZ, None, None, None, dWm.reshape(wshape), None, None, None, None

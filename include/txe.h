@@ -312,6 +312,10 @@ int txe_gat_collapse_fwd(const int* rowptr_in, const int* col_src, const int* ro
                          const float* Tf, const int* zrow, float* e_part /* all NULL, or (with hg NULL): see phases | 512 below */, void* ws,
                          size_t ws_bytes, void* stream);
 int txe_gat_collapse_e_tiles(int n_nodes, int G, int Kh, int Pd);   /* floats per node of e_part; 0: this batch cannot form it */
+/* the folded matcher's scores from e_part: s_g = [exp] <Z_g, Tf[zrow[g]]> = [exp] (scale / S_g) sum_{u in g} coef_u e_u -- no sweep over Z
+ * (masked: the layer's keep mask was applied, i.e. scale = 1 / (1 - feat_drop_p)) */
+int txe_gat_collapse_fold_scores(const int* graph_off, int n_nodes, int G, int Kh, int Pd, const float* coef, const float* wsum, const float* e_part,
+                                 float feat_drop_p, int masked, int apply_exp, float* s, void* stream);
 int txe_gat_collapse_bwd(const int* rowptr_in, const int* col_src, const int* rowptr_out, const int* col_dst, const int* pos_out,
                          const int* graph_off, int n_nodes, int n_edges, int G, const float* X, int Kh, int Pd, const int* pos, int vocab,
                          const float* Wp, const float* W, const float* attn_l, const float* attn_r, int D, float feat_drop_p,

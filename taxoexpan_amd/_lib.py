@@ -83,6 +83,7 @@ SIGNATURES = {
     "txe_gat_collapse_ws_bytes": (SZ, [I, I, I, I, I, I, I]),
     "txe_gat_collapse_fwd": (I, [P, P, P, P, P, P, I, I, I, P, I, I, P, I, F, P, F, F, U64, P, P, P, I, P, P, P, P, P, P, L, P, P, P, P, SZ, P]),
     "txe_gat_collapse_e_tiles": (I, [I, I, I, I]),
+    "txe_gat_collapse_fold_scores": (I, [P, I, I, I, I, P, P, P, F, I, I, P, P]),
     "txe_gat_collapse_bwd": (I, [P, P, P, P, P, P, I, I, I, P, I, I, P, I, P, P, P, P, I, F, P, F, F, U64, P, P, P, P, P, P, P, P, L, P, L, I, F,
                                  P, P, P, P, P, P, P, SZ, P]),
     "txe_gat_layers_prepare": (I, [P, I, P]),

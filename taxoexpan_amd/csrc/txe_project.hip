@@ -2106,6 +2106,26 @@ __global__ __launch_bounds__(256) void cl_fold_dc_kernel(int n_nodes, int G, con
     zgid[u] = zrow[g];
 }
 
+// ... and the folded matcher's FORWARD score from the same dot products: <Z_g, Tf[zrow[g]]> = (scale / S_g) sum_{u in g} c~_u e_u -- a sum
+// over the graph's few nodes instead of a sweep over Z.
+__global__ __launch_bounds__(256) void cl_fold_score_kernel(const int* __restrict__ goff, int G, const float* __restrict__ coef,
+                                                            const float* __restrict__ wsum, const float* __restrict__ e_part, int ntile, float scale,
+                                                            int apply_exp, float* __restrict__ sc) {
+    // one wave per graph: its nodes' tiles are ONE contiguous range of e_part, a lane takes every 64th value (fixed order: deterministic)
+    const int g = blockIdx.x * 4 + (threadIdx.x >> 6), l = threadIdx.x & 63;
+    if (g >= G) return;
+    const int u0 = goff[g], n = (goff[g + 1] - u0) * ntile;
+    const float* base = e_part + (long long)u0 * ntile;
+    float acc = 0.f;
+    for (int i = l; i < n; i += 64) acc = fmaf(coef[u0 + i / ntile], base[i], acc);
+    acc = wave_sum(acc);
+    if (l == 0) {
+        const float S = wsum[g];
+        const float raw = S > 0.f ? acc * scale / S : 0.f;
+        sc[g] = apply_exp ? __expf(raw) : raw;
+    }
+}
+
 // phases | 128 of the folded layer's backward entries: the weight-gradient product runs on a second stream BESIDE the caller's dZ product
 // and sweeps (every call of one backward pass carries the bit: the workspace layout depends on it).  Few fat k-slices then -- 2 instead
 // of the 7 that fill the machine: ~140 workgroups leave the kernels on the caller's stream their wave slots (cl_bwd_dot 73 -> 61 us,
@@ -2157,6 +2177,19 @@ size_t txe_gat_collapse_ws_bytes(int n_nodes, int n_edges, int G, int Kh, int Pd
 int txe_gat_collapse_e_tiles(int n_nodes, int G, int Kh, int Pd) {
     if (n_nodes <= 0 || G <= 0 || !cl_zsum_chunked(n_nodes, G)) return 0;
     return (round_up(Kh + Pd, 32) / 4 + 63) / 64;
+}
+
+// scores of the folded bilinear matcher from txe_gat_collapse_fwd's e_part (the same Tf / zrow): s_g = [exp] <Z_g, Tf[zrow[g]]>
+int txe_gat_collapse_fold_scores(const int* graph_off, int n_nodes, int G, int Kh, int Pd, const float* coef, const float* wsum, const float* e_part,
+                                 float feat_drop_p, int masked, int apply_exp, float* s, void* stream) {
+    if (G < 0 || !graph_off || !coef || !wsum || !e_part || !s || feat_drop_p < 0.f || feat_drop_p >= 1.f) return TXE_ERR_ARG;
+    const int nt = txe_gat_collapse_e_tiles(n_nodes, G, Kh, Pd);
+    if (nt <= 0) return TXE_ERR_ARG;
+    const float fs = (masked && feat_drop_p > 0.f) ? 1.f / (1.f - feat_drop_p) : 1.f;
+    ProfScope prof("cl_fold_score_kernel", (hipStream_t)stream, 4.0 * (n_nodes * (nt + 1.0) + 2.0 * G), 1);
+    hipLaunchKernelGGL(cl_fold_score_kernel, dim3((G + 3) / 4), dim3(256), 0, (hipStream_t)stream, graph_off, G, coef, wsum, e_part, nt, fs, apply_exp, s);
+    TXE_CHECK_LAUNCH();
+    return TXE_OK;
 }
 
 int txe_gat_collapse_fwd(const int* rowptr_in, const int* col_src, const int* rowptr_out, const int* col_dst, const int* pos_out,

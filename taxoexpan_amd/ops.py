@@ -375,6 +375,8 @@ def _gat_collapse_fwd(csr, st, h, ld_h, pos, rpos, pw, feat_p, attn_p, attn_slop
         if fw is not None:
             Tf, zrow, e_part = fw["T"], _fold_job_run_ids(fw, G, st.X), _empty((N, nt), st.X)
             link.fwd, link.e_part = fw, e_part
+            # (what the matcher's forward needs to sum its scores from e_part: txe_gat_collapse_fold_scores)
+            fw["score"] = (csr.graph_off, N, G, st.Kh, st.Pd, coef, wsum, feat_p, int(st.mask is not None and feat_p > 0.0))
     call("txe_gat_collapse_fwd", ptr(csr.rowptr_in), ptr(csr.col_src), ptr(csr.rowptr_out), ptr(csr.col_dst), ptr(csr.pos_out),
          ptr(csr.graph_off), N, E, G, ptr(st.X), st.Kh, st.Pd, ptr(st.Wp), st.D, feat_p, ptr(st.mask), attn_slope, attn_p, st.seed + 1,
          ptr(rpos), ptr(pw), ptr(a12), int(ready), ptr(alpha), ptr(coef), ptr(wsum), ptr(gid), ptr(Z), ptr(hg), st.D, ptr(Tf), ptr(zrow),
@@ -1401,8 +1403,14 @@ class BilinearFoldedRunsFunction(torch.autograd.Function):
             V, T = _empty((max(U, 1), l), Z), _empty((max(U, 1), Kp), Z)
         s = _empty((G,), Z)
         with _lib.on_device(Z.device):
-            call("txe_bilinear_folded_fwd", ptr(Z), Kp, G, Kp, ptr(Wp), Kp, l, ptr(Q), ldq, r, ptr(run_off), ptr(n_runs), U, first_row, ptr(Wmf),
-                 int(apply_exp), ptr(V), ptr(T), ptr(s), 2 if ready else 3, _lib.stream_ptr())
+            if ready and link.e_part is not None and "score" in fw:
+                # T rode in the stack's Z sweep: the scores are sums of its per-node dot products over each graph's few nodes, no sweep over Z
+                goff, n_, g_, kh_, pd_, coef_, wsum_, fp_, masked_ = fw["score"]
+                call("txe_gat_collapse_fold_scores", ptr(goff), n_, g_, kh_, pd_, ptr(coef_), ptr(wsum_), ptr(link.e_part), fp_, masked_, int(apply_exp),
+                     ptr(s), _lib.stream_ptr())
+            else:
+                call("txe_bilinear_folded_fwd", ptr(Z), Kp, G, Kp, ptr(Wp), Kp, l, ptr(Q), ldq, r, ptr(run_off), ptr(n_runs), U, first_row, ptr(Wmf),
+                     int(apply_exp), ptr(V), ptr(T), ptr(s), 2 if ready else 3, _lib.stream_ptr())
         ctx.misc = (Z, Wp, link, Wmf, Q, ldq, run_off, n_runs, U, first_row, V, T, s, int(apply_exp), Wm.shape)
         return s.unsqueeze(1)
 

@@ -657,6 +657,13 @@ def main():
     # same run read 1.01 ms); the same count on every rank
     for i in range(256):
         train_step(model, opt, batches[i % len(batches)], target, world)
+    # the host enqueues a step in ~0.72 ms against ~0.95 ms on the GPU: a full (generation-2) pass of Python's cyclic collector over the
+    # taxonomy's and the batches' objects -- ~100 ms, every few hundred steps (tools/host_stalls.py found one at step 346 of 400; none
+    # with the collector off) -- inside the K timed steps would read as +2 ms per step.  Collect now, then keep the survivors out of
+    # later passes (gc.freeze): the collector stays on, its passes stay short
+    import gc
+    gc.collect()
+    gc.freeze()
     for i in range(args.warmup):
         train_step(model, opt, batches[i % len(batches)], target, world)
     torch.cuda.synchronize()

@@ -150,6 +150,50 @@ def train_step(model, opt, batch, target, world, loss_fn=None):
     return loss
 
 
+SETTLE_STEPS = 256        # untimed steps before the contract's --warmup (reported as config.settle_steps)
+
+
+def route_sanity(model, batch, target):
+    """the loss of one forward pass on the default route (the graph vector folded into the matcher where that applies) and on the plain
+    one (ops._NO_MATCH_FOLD: hg = Z W^T formed) with the SAME dropout seeds: finite, and equal to 1e-4 relative -- a number timed on a
+    route that computes something else would be worthless.  Returns what went into the JSON line (`config.sanity`)."""
+    from taxoexpan_amd import ops
+    from taxoexpan_amd.loss import info_nce_loss
+    out = {}
+    for name, off in (("default", False), ("no_match_fold", True)):
+        prev, ops._NO_MATCH_FOLD = ops._NO_MATCH_FOLD, off
+        try:
+            torch.manual_seed(4711)                     # (ops.new_seed draws the dropout seeds from this generator)
+            batch["g"].ndata["pos"] = batch["pos"]
+            pred = model(batch["g"], batch["x"], batch["qf"])
+            loss = info_nce_loss(pred.reshape(N_QUERIES, -1), target)
+            out[name] = dict(loss=float(loss.item()), routes={k: ops.ROUTES.get(k) for k in ("match", "stack", "fold")})
+        finally:
+            ops._NO_MATCH_FOLD = prev
+    a, b = out["default"]["loss"], out["no_match_fold"]["loss"]
+    assert np.isfinite(a) and np.isfinite(b), out
+    assert abs(a - b) <= 1e-4 * abs(b), f"the default route's loss differs from the plain route's: {out}"
+    out["rel_diff"] = abs(a - b) / abs(b)
+    return out
+
+
+class ReferenceCaller(torch.nn.Module):
+    """The reference's own model/model.py:70-87 forward -- four statements that know nothing of this library's routes -- over the three
+    sub-modules of a taxoexpan_amd model: what a user gets who only swaps the import in model/model.py.  Timed as
+    `step_reference_model_py_ms`; it must match `ms_per_step`."""
+
+    def __init__(self, model):
+        super().__init__()
+        self.graph_propagate, self.readout, self.match = model.graph_propagate, model.readout, model.match
+
+    def forward(self, g, h, qf):
+        pos = g.ndata['pos'].to(h.device)
+        g.ndata['h'] = self.graph_propagate(g, h)
+        hg = self.readout(g, pos)
+        prediction = self.match(hg, qf)
+        return prediction
+
+
 def profile_step(model, opt, batch, target):
     """one instrumented step: per-kernel durations from HIP events on the launch stream (libtxe profiling facility)"""
     from taxoexpan_amd import _lib
@@ -567,19 +611,19 @@ def extra_metrics_sharded(model, device, world, rank, n_queries=int(os.environ.g
         pos_lists = [p[p >= 0] for p in pos_lists]
         pos_off = np.concatenate([[0], np.cumsum([len(p) for p in pos_lists])])
         pos_idx = np.concatenate(pos_lists) if pos_lists else np.zeros(0, dtype=np.int64)
-        rank_all_fused(model.match, hg, queries, pos_off, pos_idx, block=qblock, shard_lo=lo)
+        rank_all_fused(model.match, hg, queries, pos_off, pos_idx, block=qblock, shard_lo=lo, sharded=True)
         torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
         t0 = time.perf_counter()
-        ranks = rank_all_fused(model.match, hg, queries, pos_off, pos_idx, block=qblock, shard_lo=lo)
+        ranks = rank_all_fused(model.match, hg, queries, pos_off, pos_idx, block=qblock, shard_lo=lo, sharded=True)
         torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
         t_fr = time.perf_counter() - t0
         # the 5 best parents of every query (infer.py:96-106): each rank selects among its shard with the fused kernels, the [Q, 5] lists
         # (40 bytes per query and rank) are all-gathered and merged
         from taxoexpan_amd.scoring import topk_parents_fused
-        topk_parents_fused(model.match, hg, queries, None, 5, True, block=qblock, shard_lo=lo)
+        topk_parents_fused(model.match, hg, queries, None, 5, True, block=qblock, shard_lo=lo, sharded=True)
         torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
         t0 = time.perf_counter()
-        top5 = topk_parents_fused(model.match, hg, queries, None, 5, True, block=qblock, shard_lo=lo)
+        top5 = topk_parents_fused(model.match, hg, queries, None, 5, True, block=qblock, shard_lo=lo, sharded=True)
         torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
         t_top = time.perf_counter() - t0
         t = torch.tensor([t_enc, timings["local"], timings["allgather"], t_fr, t_top], dtype=torch.float64, device=device)
@@ -651,11 +695,12 @@ def main():
     opt = Adam(model.parameters(), lr=1e-3, weight_decay=0, amsgrad=True)
     batches = build_batches(tax, 4, seed0=1000 * (rank + 1), device=device)
     target = torch.zeros(N_QUERIES, dtype=torch.long, device=device)
+    sanity = route_sanity(model, batches[0], target)       # before anything is timed: the step's loss is finite and route-independent
 
     # before the contract's W warm-up steps: a quarter of a second of the same steps, untimed -- a process that starts on an idle GPU has
     # been seen to run its first ~150 steps 20 % slow (clocks and the caching allocator settling: 1.23 ms where every later leg of the
     # same run read 1.01 ms); the same count on every rank
-    for i in range(256):
+    for i in range(SETTLE_STEPS):
         train_step(model, opt, batches[i % len(batches)], target, world)
     # the host enqueues a step in ~0.72 ms against ~0.95 ms on the GPU: a full (generation-2) pass of Python's cyclic collector over the
     # taxonomy's and the batches' objects -- ~100 ms, every few hundred steps (tools/host_stalls.py found one at step 346 of 400; none
@@ -681,6 +726,8 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    from taxoexpan_amd import ops as _ops_r
+    routes_timed = {k: _ops_r.ROUTES.get(k) for k in ("match", "stack", "fold", "stack_bwd")}     # the routes the timed steps took
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -715,15 +762,16 @@ def main():
     # torch's F.cross_entropy instead of taxoexpan_amd.loss.info_nce_loss -- each alone, same resident batches, same step count
     ab = {}
     if args.workload == "pgat" and world == 1:
-        def timed(opt_, loss_fn=None):
+        def timed(opt_, loss_fn=None, mdl=None):
+            mdl = model if mdl is None else mdl
             for i in range(min(args.warmup, 5)):
-                train_step(model, opt_, batches[i % len(batches)], target, world, loss_fn)
+                train_step(mdl, opt_, batches[i % len(batches)], target, world, loss_fn)
             ts, per = [], max(args.steps // 5, 1)        # median of five groups: a one-off host stall does not decide an A/B leg
             for _ in range(5):
                 torch.cuda.synchronize()
                 t0_ = time.perf_counter()
                 for i in range(per):
-                    train_step(model, opt_, batches[i % len(batches)], target, world, loss_fn)
+                    train_step(mdl, opt_, batches[i % len(batches)], target, world, loss_fn)
                 torch.cuda.synchronize()
                 ts.append(1e3 * (time.perf_counter() - t0_) / per)
             return float(np.median(ts))
@@ -731,6 +779,8 @@ def main():
         _ops_ab._NO_MATCH_FOLD = True                    # the graph vector hg = Z W^T formed, the matcher on 4,096 rows of it (DESIGN 4.9 off)
         ab["step_no_match_fold_ms"] = timed(opt)
         _ops_ab._NO_MATCH_FOLD = False
+        ab["step_reference_model_py_ms"] = timed(opt, mdl=ReferenceCaller(model))
+        ab["step_reference_model_py_routes"] = {k: _ops_ab.ROUTES.get(k) for k in ("match", "stack", "fold", "stack_bwd")}
         torch.autograd.set_multithreading_enabled(True)
         ab["step_default_autograd_ms"] = timed(opt)
         torch.autograd.set_multithreading_enabled(False)
@@ -866,6 +916,7 @@ def main():
                                           "bilinear matcher (DESIGN 4.9): its three G x D x Kp products run on the 128 query runs -- every output and "
                                           "gradient still produced, all work inside the timed region"),
                        "egonets_per_step_per_gpu": N_QUERIES * (1 + NEG), "avg_edges_per_step_per_gpu": edges / args.steps / world,
+                       "settle_steps": SETTLE_STEPS, "sanity": sanity, "routes": routes_timed,
                        "parallelism": f"dp{world}"},
             "roofline_all": roof_all,
             "extra": extra,

@@ -120,10 +120,10 @@ def run_case(name, spec):
     save["batch_num_nodes"] = np.asarray(bg.batch_num_nodes, dtype=np.int64)
     save["scores"] = prediction.detach().numpy()
     save["loss"] = np.asarray(loss.item(), dtype=np.float64)
-    save["hn"] = bg.ndata["h"].detach().numpy()
+    save["hn"] = bg.ndata["h"].detach().numpy()[::gc.row_steps(spec)[0]].copy()
     for k, v in caps.items():
-        # large-dimension cases keep every 5th node row of the per-layer outputs (fixture size)
-        save[k] = v.numpy() if (spec["full"] or not k.endswith("_out")) else v.numpy()[::5].copy()
+        # large-dimension cases keep every 5th (slim: 40th) node row of the per-layer outputs (fixture size)
+        save[k] = v.numpy()[::gc.row_steps(spec)[1]].copy() if k.endswith("_out") else v.numpy()
     for k, p in model.named_parameters():
         g = p.grad.detach().numpy()
         if spec["full"] or g.size <= 4096:
@@ -278,6 +278,10 @@ if __name__ == "__main__":
         sys.exit(0)
     if "--metrics-only" in sys.argv:
         run_metrics()
+        sys.exit(0)
+    if "--case" in sys.argv:                    # one case only (adding a case does not rewrite the others)
+        name = sys.argv[sys.argv.index("--case") + 1]
+        run_case(name, gc.CASES[name])
         sys.exit(0)
     for name, spec in gc.CASES.items():
         run_case(name, spec)

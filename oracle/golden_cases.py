@@ -39,6 +39,15 @@ CASES = {
                                  pos_dim=50, num_layers=1, heads=[4, 1], n_queries=3, seed=204, full=False),
     "magfull_pgat_2layer": dict(prop="PGAT", readout="WMR", match="BIM", in_dim=250, hidden_dim=500, out_dim=500,
                                 pos_dim=50, num_layers=2, heads=[4, 4, 1], n_queries=2, seed=205, full=False),
+    # a training batch in the trainer's own layout (trainer.py:45-56, data_loaders.py:9-28): 8 queries x (1 positive + 31 negatives) = 256
+    # egonets, every query's feature row stacked 32 times -- large enough (>= 256 stacked rows that repeat) for the MI355X path to take
+    # the graph vector FOLDED into the bilinear matcher, so that route is pinned to the reference itself, not only to the oracle
+    "mag_pgat_wmr_lbm_q8x32": dict(prop="PGAT", readout="WMR", match="LBM", in_dim=250, hidden_dim=500, out_dim=500,
+                                   pos_dim=50, num_layers=1, heads=[4, 1], n_queries=8, seed=206, full=False, neg_per_query=31,
+                                   repeat_queries=True, slim=True),
+    "semeval_pgat_wmr_bim_q8x32": dict(prop="PGAT", readout="WMR", match="BIM", in_dim=300, hidden_dim=600, out_dim=300,
+                                       pos_dim=50, num_layers=1, heads=[4, 1], n_queries=8, seed=207, full=False, neg_per_query=31,
+                                       repeat_queries=True, slim=True),
 }
 
 NEG_PER_QUERY = 5  # each query: 1 positive + 5 negative egonets (trainer.py:52-56 layout)
@@ -48,9 +57,16 @@ NEG_PER_QUERY = 5  # each query: 1 positive + 5 negative egonets (trainer.py:52-
 EDGE_SHAPES = [(0, 0), (1, 0), (0, 3), (3, 50), (2, 1), (4, 7)]
 
 
+def row_steps(spec):
+    """(stride of the stored node-state rows `hn`, stride of the stored per-layer output rows `layer{l}_out`): fixture size"""
+    if spec.get("slim"):
+        return 10, 40
+    return 1, (1 if spec["full"] else 5)
+
+
 def egonet_shapes(spec):
     rs = np.random.RandomState(spec["seed"])
-    g = spec["n_queries"] * (1 + NEG_PER_QUERY)
+    g = spec["n_queries"] * (1 + spec.get("neg_per_query", NEG_PER_QUERY))
     shapes = list(EDGE_SHAPES)
     while len(shapes) < g:
         shapes.append((int(rs.randint(0, 4)), int(rs.randint(0, 9))))
@@ -126,8 +142,13 @@ def make_inputs(spec):
     n = sum(k + 1 + m for k, m in shapes)
     x = rs.standard_normal((n, spec["in_dim"]))
     x /= np.linalg.norm(x, axis=1, keepdims=True)
-    q = rs.standard_normal((len(shapes), spec["in_dim"]))
-    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    if spec.get("repeat_queries"):              # the collate's stack: one row per query, repeated once per (query, egonet) pair
+        q = rs.standard_normal((spec["n_queries"], spec["in_dim"]))
+        q /= np.linalg.norm(q, axis=1, keepdims=True)
+        q = np.repeat(q, len(shapes) // spec["n_queries"], axis=0)
+    else:
+        q = rs.standard_normal((len(shapes), spec["in_dim"]))
+        q /= np.linalg.norm(q, axis=1, keepdims=True)
     return shapes, x.astype(np.float32), q.astype(np.float32)
 
 

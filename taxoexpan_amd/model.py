@@ -50,20 +50,15 @@ class TaxoExpan(torch.nn.Module):
                 self.match = MATCH[matching_method](dims[0], dims[1], options)
 
     def forward(self, g, h, qf):
-        """model/model.py:70-87: positions are read BEFORE propagation (PGAT / PGCN pop them), node states are left in
-        g.ndata['h'], one score per (egonet, query) row comes back"""
-        positions = g.ndata['pos'].to(h.device)
-        if hasattr(self.match, "prefetch"):         # the matcher's query-side projection runs under the encoder (second stream)
-            self.match.prefetch(qf)
-        out = self.graph_propagate(g, h)
-        # a bilinear matcher on query rows that repeat takes the graph vector FOLDED: the readout then stops at Z and the output
-        # layer's product runs on one row per query run inside the matcher (zoo.DeferredGraphVector; same arithmetic, re-associated)
-        if isinstance(out, zoo.DeferredNodeOutput) and getattr(self.match, "wants_folded_graph_vector", None) is not None:
-            out._want_folded = self.match.wants_folded_graph_vector(qf)
-            if out._want_folded and hasattr(self.match, "fold_job"):
-                out._fold_job = self.match.fold_job(qf)
-        g.ndata['h'] = out
-        return self.match(self.readout(g, positions), qf)
+        """model/model.py:70-87, statement for statement: positions are read BEFORE propagation (PGAT / PGCN pop them), node states are
+        left in g.ndata['h'], one score per (egonet, query) row comes back.  Nothing here knows about the routes below it: in grad mode
+        graph_propagate and readout only DESCRIBE their work (model_zoo.DeferredNodeOutput / DeferredGraphVector) and the matcher, the
+        first one to hold both the graph vector and the queries, decides how the stack runs -- so the reference's own model/model.py with
+        its import swapped takes exactly the same route."""
+        pos = g.ndata['pos'].to(h.device)
+        g.ndata['h'] = self.graph_propagate(g, h)
+        hg = self.readout(g, pos)
+        return self.match(hg, qf)
 
     def __str__(self):
         n = sum(p.numel() for p in self.parameters() if p.requires_grad)

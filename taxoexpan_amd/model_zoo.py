@@ -156,27 +156,36 @@ class DeferredNodeOutput:
         self._args = (csr, cfg, h, pos, params)
         self._fn = fn
         self._tensor = None
-        self._want_folded = False                   # TaxoExpan.forward: the matcher can take the graph vector folded (DeferredGraphVector)
-        self._fold_job = None                       # ... and this is the query-side half of its work (ops.folded_match_job)
 
     def _out_dim(self):
         return self._args[1].out_dims[-1]
 
     def readout(self, rpos, pw):
-        import copy
+        """the graph vectors [G, out_dim].  Without gradients: computed now ('collapse').  With gradients: a DeferredGraphVector --
+        NOTHING is launched yet; the first consumer decides how the stack runs (a bilinear matcher on repeating queries takes the
+        vector folded and hands the stack the query-side half of its work; anybody else gets the plain tensor)."""
         csr, cfg, h, pos, params = self._args
         if csr.n_nodes == 0 or csr.n_graphs == 0:       # empty batch: nothing to launch
             return h.new_zeros((csr.n_graphs, self._out_dim()), dtype=torch.float32)
+        if torch.is_grad_enabled():
+            return DeferredGraphVector(self, rpos, pw)
+        return self._collapse("collapse", rpos, pw)[0]
+
+    def _collapse(self, final, rpos, pw, fold_job=None):
+        """run the stack with its output layer folded behind the readout: final = 'collapse' -> hg [G, D]; 'collapse_z' -> (Z [G, Kp], the
+        output layer's packed weights Wp) with a fresh ops.FoldLink in the returned config"""
+        import copy
+        csr, cfg, h, pos, params = self._args
         c = copy.copy(cfg)
-        if (self._want_folded and self._fn is ops.GATStackFunction and torch.is_grad_enabled() and ops.folded_graph_vector_ok(csr, cfg)):
-            # the stack stops at Z [G, Kp]; hg = Z W^T is formed by whoever asks for the tensor -- or never (_Bilinear on repeating queries)
-            c.final = "collapse_z"
-            c.link = ops.FoldLink()
-            c.fold_job = self._fold_job
-            Z, Wp = ops.apply_stack(self._fn, csr, c, h, pos, rpos, pw, *params)
-            return DeferredGraphVector(Z, Wp, c.link, self._out_dim())
-        c.final = "collapse"
-        return ops.apply_stack(self._fn, csr, c, h, pos, rpos, pw, *params)
+        c.final = final
+        if final == "collapse_z":
+            c.link, c.fold_job = ops.FoldLink(), fold_job
+        return ops.apply_stack(self._fn, csr, c, h, pos, rpos, pw, *params), c
+
+    def _can_fold(self):
+        """may the stack stop at Z (the graph vector folded into the bilinear matcher)?"""
+        csr, cfg = self._args[:2]
+        return self._fn is ops.GATStackFunction and ops.folded_graph_vector_ok(csr, cfg)
 
     def tensor(self):
         if self._tensor is None:
@@ -205,28 +214,84 @@ class DeferredNodeOutput:
         return func(*tree_map(un, tuple(args)), **tree_map(un, dict(kwargs or {})))
 
 
-class DeferredGraphVector:
-    """What MeanReadout / WeightedMeanReadout return when TaxoExpan.forward announced a matcher that can take the graph vector FOLDED:
-    hg [G, D] = Z W^T of a 'collapse_z' stack, not yet formed.  _Bilinear on repeating query rows consumes (Z, Wp) directly -- the
-    output layer's D x Kp product then runs on one row per query run instead of one per egonet (ops.BilinearFoldedRunsFunction; same
-    arithmetic, re-associated).  Every other use materialises the ordinary tensor once (ops.FoldedGraphLinearFunction)."""
+_SECOND_USE = ("taxoexpan_amd: this graph vector was consumed FOLDED by the bilinear matcher (hg = Z W^T never formed; "
+               "ops.BilinearFoldedRunsFunction) and is now asked for as a tensor with gradients -- a second differentiable consumer is not "
+               "supported after the fold.  Touch it before the matcher runs (hg.tensor()), or switch the fold off "
+               "(taxoexpan_amd.ops._NO_MATCH_FOLD = True).  Under torch.no_grad() / via .detach() the values are available.")
 
-    def __init__(self, Z, Wp, link, D):
-        self._z, self._wp, self._link, self._d = Z, Wp, link, D
+
+class DeferredGraphVector:
+    """What MeanReadout / WeightedMeanReadout return in grad mode: the graph vectors hg [G, D] of a propagation stack whose output layer
+    folds behind the readout -- NOT YET COMPUTED.  The first consumer decides how the stack runs:
+      * BIM / LBM on repeating query rows (`match_folded`): the stack stops at Z [G, Kp] ('collapse_z', hg = Z W^T is never formed) and
+        the output layer's D x Kp product runs on one row per query run inside the matcher (ops.BilinearFoldedRunsFunction; same
+        arithmetic, re-associated).  The matcher's query-side half is handed to the stack as a job, so it runs before the Z sweep.
+      * anything else (`.tensor()`, any attribute / torch function / operator): the ordinary tensor, once ('collapse').
+      * `.detach()` (logging hooks): the values without changing the route -- the stack runs as 'collapse_z' and hg = Z W^T is formed
+        outside autograd.
+    Needs no cooperation from the caller: the reference's model/model.py:70-87 drives it unchanged."""
+
+    def __init__(self, node_out, rpos, pw):
+        self._src = (node_out, rpos, pw)
+        self._z = None              # (Z, Wp, FoldLink) once a 'collapse_z' stack has run
         self._tensor = None
+        self._folded = False        # consumed by match_folded
+        self._d = node_out._out_dim()
 
     @property
     def shape(self):
-        return torch.Size((self._z.shape[0], self._d))
+        return torch.Size((self._src[0]._args[0].n_graphs, self._d))
 
-    def folded(self):
-        """(Z, Wp, link, D) if the tensor has not been asked for yet, else None"""
-        return None if self._tensor is not None else (self._z, self._wp, self._link, self._d)
+    @property
+    def device(self):
+        return self._src[0]._args[2].device
+
+    def started(self):
+        """has the propagation stack been launched for this vector?"""
+        return self._z is not None or self._tensor is not None
+
+    def can_fold(self):
+        return (self._tensor is None and not self._folded and not ops._NO_MATCH_FOLD
+                and (self._z is not None or self._src[0]._can_fold()))
+
+    def _run_z(self, fold_job=None):
+        if self._z is None:
+            node, rpos, pw = self._src
+            (Z, Wp), c = node._collapse("collapse_z", rpos, pw, fold_job)
+            self._z = (Z, Wp, c.link)
+        return self._z
+
+    def match_folded(self, Wm, apply_exp, e2):
+        """scores [G, 1] of the bilinear matcher (weight Wm [1, D, r]) against e2: the stacked query matrix [G, r] or an ops.RepeatedRows"""
+        if not self.can_fold():
+            raise RuntimeError("DeferredGraphVector.match_folded: the vector cannot be folded (any more)")
+        stacked, rows, run_off = (None, e2.rows, e2.run_off) if isinstance(e2, ops.RepeatedRows) else (e2, None, None)
+        job = ops.folded_match_job(stacked, rows, run_off, Wm) if self._z is None else None
+        Z, Wp, link = self._run_z(job)
+        self._folded = True
+        return ops.BilinearFoldedRunsFunction.apply(Z, Wp, link, self._d, Wm, apply_exp, stacked, rows, run_off)
 
     def tensor(self):
         if self._tensor is None:
-            self._tensor = ops.FoldedGraphLinearFunction.apply(self._z, self._wp, self._link, self._d)
+            if self._folded:
+                if torch.is_grad_enabled():
+                    raise RuntimeError(_SECOND_USE)
+                return self.detach()
+            if self._z is None:
+                node, rpos, pw = self._src
+                self._tensor = node._collapse("collapse", rpos, pw)[0]
+            else:
+                self._tensor = ops.FoldedGraphLinearFunction.apply(*self._z, self._d)
         return self._tensor
+
+    def detach(self):
+        """the values, outside autograd, WITHOUT deciding the route: a forward hook that logs `out.detach()` leaves the folded match in place"""
+        if self._tensor is not None:
+            return self._tensor.detach()
+        if self._z is None and not self.can_fold():
+            return self.tensor().detach()
+        Z, Wp, _link = self._run_z()
+        return ops.folded_graph_linear(Z.detach(), Wp, self._d)
 
     def __getattr__(self, name):
         if name.startswith("_"):
@@ -237,7 +302,7 @@ class DeferredGraphVector:
         return self.tensor()[idx]
 
     def __len__(self):
-        return self._z.shape[0]
+        return int(self.shape[0])
 
     __torch_function__ = DeferredNodeOutput.__dict__["__torch_function__"]
 
@@ -255,6 +320,9 @@ for _n in ("__add__", "__radd__", "__sub__", "__rsub__", "__mul__", "__rmul__", 
     setattr(DeferredGraphVector, _n, _delegate(_n))
 DeferredNodeOutput.__hash__ = object.__hash__
 DeferredGraphVector.__hash__ = object.__hash__
+DeferredGraphVector.__repr__ = lambda self: "DeferredGraphVector(shape=%s, %s)" % (tuple(self.shape), "folded" if self._folded else
+                                                                                      ("tensor" if self._tensor is not None else
+                                                                                       ("z" if self._z is not None else "pending")))
 
 
 def _node_features(g):
@@ -458,6 +526,11 @@ class _LazyPositionWeight:
 # ---------------------------------------------------------------------------------------------------------------
 # Matchers
 # ---------------------------------------------------------------------------------------------------------------
+def _graph_vector(e1):
+    """the plain [G, D] tensor of a matcher's first argument (a readout's DeferredGraphVector: materialised now)"""
+    return e1.tensor() if isinstance(e1, (DeferredGraphVector, DeferredNodeOutput)) else e1
+
+
 class MLP(nn.Module):
     def __init__(self, l_dim, r_dim, hidden_dim):
         super(MLP, self).__init__()
@@ -470,7 +543,7 @@ class MLP(nn.Module):
 
     def forward(self, e1, e2):
         """model_zoo.py:291-298: ffn(cat(e1, e2)); the concat is synthesised by the GEMM's operand loader"""
-        e2 = ops.dense_rows(e2)
+        e1, e2 = _graph_vector(e1), ops.dense_rows(e2)
         if e1.shape[0] == 0:
             return e1.new_zeros((0, 1), dtype=torch.float32)
         hid = ops.LinearFunction.apply(e1, e2, self.ffn[0].weight, self.ffn[0].bias, 1)
@@ -485,65 +558,47 @@ class _Bilinear(nn.Module):
         self.W = nn.Bilinear(l_dim, r_dim, 1, bias=False)      # parameter container: same name/shape/init as the reference
 
     def forward(self, e1, e2):
-        """e1 (*, l_dim), e2 (*, r_dim) -> (*, 1)"""
+        """e1 (*, l_dim), e2 (*, r_dim) -> (*, 1).  ONE route per call, decided by _route and recorded (ops.ROUTES['match'])."""
         if e1.shape[0] == 0:                               # empty batch
-            return e1.new_zeros((0, 1), dtype=torch.float32)
-        if isinstance(e1, DeferredGraphVector):            # the graph vector still folded: hg = Z W^T (TaxoExpan.forward asked for it)
-            fz = e1.folded()
-            if fz is not None and self._runs_form(e1, e2) == "rows":
-                self._pre = None
-                return ops.BilinearFoldedRunsFunction.apply(fz[0], fz[1], fz[2], fz[3], self.W.weight, self.apply_exp, None, e2.rows, e2.run_off)
-            if fz is not None and self._runs_form(e1, e2) == "stacked":
-                self._pre = None
-                return ops.BilinearFoldedRunsFunction.apply(fz[0], fz[1], fz[2], fz[3], self.W.weight, self.apply_exp, e2, None, None)
-            e1 = e1.tensor()
-        if isinstance(e2, ops.RepeatedRows):               # query rows that repeat in runs: U rows projected instead of G
-            if e2.requires_grad or e2.n_rows != e1.shape[0] or 4 * e2.rows.shape[0] > e2.n_rows:     # (hardly any repetition: the GEMM form)
-                e2 = e2.dense()
-            else:
-                self._pre = None
-                return ops.BilinearRunsFunction.apply(e1, self.W.weight, self.apply_exp, e2.rows, e2.run_off)
-        if e2.dim() == 2 and e2.stride(0) == 0 and e2.shape[0] == e1.shape[0] and not torch.is_grad_enabled():
-            # the eval loop's `nf.expand(n_position, -1)` (test_fast.py:122-123): one query against all candidates
-            U = ops.bilinear_project(e1, self.W.weight)
-            return ops.score_block(e2[:1], U, self.apply_exp).reshape(-1, 1)
-        dec = self.__dict__.get("_stacked_dec")
-        if self._stacked_runs_ok(e1, e2) and (dec[1] if (dec is not None and dec[0] is e2) else self._repeats(e2)):
-            self._pre = None
-            return ops.BilinearStackedRunsFunction.apply(e1, e2, self.W.weight, self.apply_exp)
-        pre, self._pre = getattr(self, "_pre", None), None
-        return ops.BilinearPairFunction.apply(e1, e2, self.W.weight, self.apply_exp, pre)
+            return e2.new_zeros((0, 1), dtype=torch.float32) if torch.is_tensor(e2) else e2.rows.new_zeros((0, 1), dtype=torch.float32)
+        route, e2 = self._route(e1, e2)
+        ops.note_route("match", route)
+        W, ex = self.W.weight, self.apply_exp
+        if route == "folded":                              # hg = Z W^T never formed: the output layer's product runs on the query runs
+            return e1.match_folded(W, ex, e2)
+        if route == "expand":                              # the eval loop's `nf.expand(n_position, -1)` (test_fast.py:122-123)
+            return ops.score_block(e2[:1], ops.bilinear_project(_graph_vector(e1), W), ex).reshape(-1, 1)
+        # pair form: V = e2 W^T needs neither the graph nor the encoder -- with the encoder not launched yet it goes to the second stream
+        lazy = isinstance(e1, DeferredGraphVector) and not e1.started()
+        pre = ops.bilinear_query_prefetch(e2, W) if (route == "pair" and lazy and torch.is_grad_enabled()) else None
+        hg = _graph_vector(e1)
+        if route == "runs":
+            return ops.BilinearRunsFunction.apply(hg, W, ex, e2.rows, e2.run_off)
+        if route == "stacked":
+            return ops.BilinearStackedRunsFunction.apply(hg, e2, W, ex)
+        return ops.BilinearPairFunction.apply(hg, e2, W, ex, pre)
 
-    def _runs_form(self, e1, e2):
-        """which one-row-per-run form this call would take: "rows" (ops.RepeatedRows with enough repetition), "stacked" (the decision
-        of the last prefetch(e2) on this very tensor -- _repeats is asked once per step), or None"""
-        n = None if e1 is None else e1.shape[0]
+    def _route(self, e1, e2):
+        """(route, e2): 'folded' | 'runs' (ops.RepeatedRows) | 'stacked' (repeating rows of a stacked matrix, found on the device) |
+        'expand' (one query against all candidates, no grad) | 'pair' (one GEMM row per pair).  e2 comes back dense where the route
+        needs it so."""
+        n, grad = e1.shape[0], torch.is_grad_enabled()
         if isinstance(e2, ops.RepeatedRows):
-            ok = not e2.requires_grad and (n is None or e2.n_rows == n) and 4 * e2.rows.shape[0] <= e2.n_rows
-            return "rows" if ok else None
-        dec = self.__dict__.get("_stacked_dec")
-        if dec is not None and dec[0] is e2 and dec[1] and self._stacked_runs_ok(e1, e2):
-            return "stacked"
-        return None
-
-    def fold_job(self, e2):
-        """TaxoExpan.forward, when the graph vector will arrive folded: the query-side half of the folded match as a job the encoder runs
-        before its Z sweep (ops.folded_match_job)"""
-        form = self._runs_form(None, e2)
-        if form == "rows":
-            return ops.folded_match_job(None, e2.rows, e2.run_off, self.W.weight)
-        if form == "stacked":
-            return ops.folded_match_job(e2, None, None, self.W.weight)
-        return None
-
-    def wants_folded_graph_vector(self, e2):
-        """TaxoExpan.forward, after prefetch(e2): would forward(e1, e2) take the graph vector folded (DeferredGraphVector)?"""
-        return bool(torch.is_grad_enabled() and not ops._NO_MATCH_FOLD and self._runs_form(None, e2) is not None)
+            if e2.requires_grad or e2.n_rows != n or 4 * e2.rows.shape[0] > e2.n_rows:     # (hardly any repetition: the GEMM form)
+                return "pair", e2.dense()
+            runs = "runs"
+        elif e2.dim() == 2 and e2.stride(0) == 0 and e2.shape[0] == n and not grad:
+            return "expand", e2
+        else:
+            runs = "stacked" if (self._stacked_runs_ok(n, e2) and self._repeats(e2)) else None
+        if runs is not None and grad and isinstance(e1, DeferredGraphVector) and e1.can_fold():
+            return "folded", e2
+        return (runs or "pair"), e2
 
     # ---- stacked query rows that repeat (data_loaders.py:9-28 stacks a query's row once per pair) -------------------------------------
-    def _stacked_runs_ok(self, e1, e2):
+    def _stacked_runs_ok(self, n, e2):
         return (not ops._NO_QUERY_RUNS and torch.is_grad_enabled() and torch.is_tensor(e2) and e2.is_cuda and e2.dim() == 2 and
-                not e2.requires_grad and 256 <= e2.shape[0] <= (1 << 18) and (e1 is None or e2.shape[0] == e1.shape[0]))     # (one workgroup scans the rows)
+                not e2.requires_grad and 256 <= e2.shape[0] <= (1 << 18) and e2.shape[0] == n)     # (one workgroup scans the rows)
 
     RECHECK_EVERY = 64      # training batches between two looks at the run count
 
@@ -551,18 +606,21 @@ class _Bilinear(nn.Module):
         """does this matcher's training input repeat its query rows?  At least three rows in four repeat -> the one-row-per-run form
         (which finds its runs on the device in every call, so a batch that repeats less is only slower, never wrong), otherwise the
         GEMM form.  Decided on the first training batch (the runs are counted on the device and read back: the one host
-        synchronisation of the scheme) and RE-decided every RECHECK_EVERY batches without one: the count of that batch goes to pinned
-        memory asynchronously and is looked at by a later call once its event has completed -- a loader that starts with one odd
-        batch, or changes its collate, is followed within a few batches."""
+        synchronisation of the scheme) and RE-decided every RECHECK_EVERY batches: the count of batch k * RECHECK_EVERY goes to pinned
+        memory asynchronously and is applied exactly RECHECK_EVERY / 2 calls later (the copy finished long before; the wait is a formality)
+        -- at a call count, not at whatever moment the copy happened to land, so a run with fixed seeds takes the same route at the same
+        step every time, on every rank.  A loader that starts with one odd batch, or changes its collate, is followed within
+        1.5 RECHECK_EVERY batches."""
         st = self.__dict__.get("_runs_watch")
         if st is None:
             n_runs = int(ops.find_row_runs(e2)[2].item())
             st = self.__dict__["_runs_watch"] = dict(dec=bool(4 * n_runs <= e2.shape[0]), calls=0, pending=None)
             return st["dec"]
-        if st["pending"] is not None and st["pending"][0].query():
-            _, buf, G = st["pending"]
-            st["dec"], st["pending"] = bool(4 * int(buf[0]) <= G), None
         st["calls"] += 1
+        if st["pending"] is not None and st["calls"] >= st["pending"][3]:
+            ev, buf, G, _due = st["pending"]
+            ev.synchronize()
+            st["dec"], st["pending"] = bool(4 * int(buf[0]) <= G), None
         if st["calls"] % self.RECHECK_EVERY == 0 and st["pending"] is None:
             buf = st.get("buf")
             if buf is None:
@@ -570,19 +628,8 @@ class _Bilinear(nn.Module):
             buf.copy_(ops.find_row_runs(e2)[2], non_blocking=True)
             ev = torch.cuda.Event()
             ev.record()
-            st["pending"] = (ev, buf, int(e2.shape[0]))
+            st["pending"] = (ev, buf, int(e2.shape[0]), st["calls"] + self.RECHECK_EVERY // 2)
         return st["dec"]
-
-    def prefetch(self, e2):
-        """start the query-side half of the match (V = e2 W^T: needs neither the graph nor the encoder) on the second stream; the next
-        forward(e1, e2) with this very e2 picks it up.  Called by TaxoExpan.forward before graph_propagate."""
-        self._pre = None
-        self.__dict__["_stacked_dec"] = None
-        if torch.is_grad_enabled() and torch.is_tensor(e2):
-            runs = bool(self._stacked_runs_ok(None, e2) and self._repeats(e2))
-            self.__dict__["_stacked_dec"] = (e2, runs)      # (forward on this very tensor does not ask _repeats again)
-            if not runs:
-                self._pre = ops.bilinear_query_prefetch(e2, self.W.weight)
 
     def score_all(self, hg, queries, block=None, out=None):
         """The whole scoring loop at once: S[q][g] = match(hg[g], queries[q]) (test_fast.py:116-123)."""
@@ -610,7 +657,7 @@ class NTN(nn.Module):
 
     def forward(self, e1, e2):
         """model_zoo.py:339-346: u_R(f(W(e1, e2) + V(cat(e1, e2)))) -> (*, 1); one bilinear slice per output, the concat is virtual"""
-        e2 = ops.dense_rows(e2)
+        e1, e2 = _graph_vector(e1), ops.dense_rows(e2)
         k = self.W.weight.shape[0]
         bil = torch.cat([ops.BilinearPairFunction.apply(e1, e2, self.W.weight[j:j + 1], False).reshape(-1, 1) for j in range(k)], 1)
         lin = ops.LinearFunction.apply(e1, e2, self.V.weight, None, 0)

@@ -84,9 +84,28 @@ def new_seed():
     return int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
 
 
+ROUTES = {}           # kind -> the route the LAST call of that kind took ('match': _Bilinear.forward; 'stack' / 'stack_bwd': the propagation
+                      # stack's cfg.final (+ '+edot') and its backward; 'fold': the folded matcher's forward) -- tests assert on it, bench.py
+                      # reports it; debug_capture() additionally collects every note of its block in `routes`
+
+
+def note_route(kind, name):
+    ROUTES[kind] = name
+    if _CAPTURE is not None:
+        _CAPTURE.routes.append((kind, name))
+
+
 _GRAD_READY = None    # scoring.overlapped_gradient_allreduce: called as (layer index, [parameter gradients]) the moment a layer's are done
 _GRAD_FLUSH = None    # ... and once before the stack returns its gradients to autograd
 _CAPTURE = None       # debug_capture(): list that receives (csr, cfg, per-layer states) of every stack forward
+
+
+class _CaptureList(list):
+    """debug_capture()'s list of stack forwards, plus `.routes`: every (kind, route) noted inside the block, in order"""
+
+    def __init__(self):
+        super().__init__()
+        self.routes = []
 
 
 class debug_capture:
@@ -97,7 +116,7 @@ class debug_capture:
 
     def __enter__(self):
         global _CAPTURE
-        self._prev, _CAPTURE = _CAPTURE, []
+        self._prev, _CAPTURE = _CAPTURE, _CaptureList()
         return _CAPTURE
 
     def __exit__(self, *exc):
@@ -394,7 +413,7 @@ def _gat_collapse_bwd(csr, st, pos, rpos, pw, vocab, feat_p, attn_p, attn_slope,
     d_pw = torch.empty_like(pw) if pw is not None else None
     d_X = _empty((N, st.Kp), st.X)
     v = max(vocab, pw.numel() if pw is not None else 0)
-    wsb = call("txe_gat_collapse_ws_bytes", N, E, G, st.Kh, st.Pd, st.D, 8)
+    wsb = call("txe_gat_collapse_ws_bytes", N, E, G, st.Kh, st.Pd, st.D, max(v, 8))
     ws = _ws(wsb, st.X)
     call("txe_gat_collapse_bwd", ptr(csr.rowptr_in), ptr(csr.col_src), ptr(csr.rowptr_out), ptr(csr.col_dst), ptr(csr.pos_out),
          ptr(csr.graph_off), N, E, G, ptr(st.X), st.Kh, st.Pd, ptr(pos if pos is not None else rpos), v, ptr(st.Wp), ptr(st.W),
@@ -531,7 +550,13 @@ def _gat_collapse_bwd_fused(csr, st, sp, pos, rpos, pw, vocab, feat_p, attn_p, a
     link given: d_hg IS dZ [G, Kp] (the consumer of Z folded hg = Z W^T into its own products, FoldLink)."""
     N, G, E = st.X.shape[0], csr.n_graphs, csr.n_edges
     a12, alpha, coef, wsum, gid, Z, hg = st.cl
-    d_hg, ld = _rows(d_hg)
+    edot = link is not None and link.e_part is not None and link.m is not None     # the <dZ, X> sweep was done in forward (FoldLink)
+    if d_hg is None:
+        if not edot:
+            raise RuntimeError("folded output layer: no gradient arrived for the graph vector")
+        ld = st.Kp                                  # (edot: 'dZ[g]' is the matcher's ds_g T[run(g)], read from the link -- no tensor)
+    else:
+        d_hg, ld = _rows(d_hg)
     dW, dal, dar = torch.empty_like(st.W), torch.empty_like(st.al), torch.empty_like(st.ar)
     dP = torch.empty_like(st.P) if st.P is not None else None
     d_pw = torch.empty_like(pw) if pw is not None else None
@@ -539,7 +564,7 @@ def _gat_collapse_bwd_fused(csr, st, sp, pos, rpos, pw, vocab, feat_p, attn_p, a
     d_Yp = _empty((N, sp.Fp), st.X)
     dz = _empty((max(E, 1) * sp.H,), st.X)
     v = max(vocab, pw.numel() if pw is not None else 0)
-    wsb = call("txe_gat_collapse_bwd_fused_ws_bytes", N, E, G, st.Kh, st.Pd, st.D, 8, sp.H)
+    wsb = call("txe_gat_collapse_bwd_fused_ws_bytes", N, E, G, st.Kh, st.Pd, st.D, max(v, 8), sp.H)
     ws = _ws(wsb, st.X)
     def run(phases):
         call("txe_gat_collapse_bwd_fused", ptr(csr.rowptr_in), ptr(csr.col_src), ptr(csr.rowptr_out), ptr(csr.col_dst), ptr(csr.pos_out),
@@ -551,7 +576,6 @@ def _gat_collapse_bwd_fused(csr, st, sp, pos, rpos, pw, vocab, feat_p, attn_p, a
              link.S if link is not None else 0, *((ptr(link.e_part), ptr(link.m[0]), ptr(link.m[1]), int(link.m[2]), ptr(link.fwd["T"]),
                                                   ptr(link.fwd["run_id"]), ptr(zgid)) if edot else (None, None, None, 0, None, None, None)),
              chain.ptr if chain is not None else None, ptr(ws), wsb, _lib.stream_ptr())
-    edot = link is not None and link.e_part is not None and link.m is not None     # the <dZ, X> sweep was done in forward (FoldLink)
     zgid = torch.empty(max(N, 1), dtype=torch.int32, device=st.X.device) if edot else None
     last = 8 | (64 if chain is not None else 0)     # (with a chain the final reductions are left to the bottom layer's launch)
     if chain is not None:
@@ -684,6 +708,7 @@ class GATStackFunction(torch.autograd.Function):
         ctx.h_req = ctx.needs_input_grad[2]
         ctx.param_ids, ctx.pw_id = [id(p) for p in params], id(pw)
         ctx.link = getattr(cfg, "link", None) if z_only else None
+        note_route("stack", cfg.final + ("+edot" if (z_only and ctx.link is not None and ctx.link.e_part is not None) else ""))
         if _CAPTURE is not None:
             _CAPTURE.append((csr, cfg, states))
         return res
@@ -695,13 +720,21 @@ class GATStackFunction(torch.autograd.Function):
             raise RuntimeError(_BACKWARD_TWICE)
         L = cfg.n_layers
         H, D = cfg.heads[-1], cfg.out_dims[-1]
-        d_res = _f32(d_res)
         z_only = (cfg.final == "collapse_z")
         collapse = (cfg.final == "collapse") or z_only
+        link = ctx.link if z_only else None
+        edot = link is not None and link.e_part is not None and link.m is not None
+        if d_res is None and not edot:
+            # (collapse_z does not materialise absent gradients: Z took no part in the loss -- nothing to propagate, and the saved
+            #  state can go)
+            ctx.states = None
+            return (None,) * (6 + 4 * L)
+        d_res = None if edot else _f32(d_res)       # (edot: the matcher's 'dZ' travels through the FoldLink, not through autograd)
         N = states[0].X.shape[0]
         grads = [None] * (4 * L)
         d_pw = None
-        with _lib.on_device(d_res.device):
+        note_route("stack_bwd", "fused+edot" if edot else ("collapse" if collapse else "layers"))
+        with _lib.on_device(states[0].X.device):
             if collapse:
                 d_pre, ld_dpre = None, 0
             elif cfg.final == "mean" and H > 1:
@@ -858,6 +891,7 @@ class GCNStackFunction(torch.autograd.Function):
                     dropped = getattr(st, "x_dropped", False)
                     call("txe_gcn_dense_fwd", ptr(st.X), N, st.Kh, st.Pd, ptr(st.Wp), st.Fo, 0.0 if dropped else cfg.drop_ps[l],
                          None if dropped else ptr(st.mask), ptr(hw), ptr(tws), tws.numel(), st_)
+                    _launch_pending_prefetch()
                 if last:
                     out, ld_out = _empty((N, st.Fo), h), st.Fo
                 else:
@@ -871,6 +905,7 @@ class GCNStackFunction(torch.autograd.Function):
                     if l > 0:
                         st.X = None
         ctx.csr, ctx.cfg, ctx.pos, ctx.norm = csr, cfg, pos, norm
+        note_route("stack", "collapse" if collapse else "layers")
         if _CAPTURE is not None:
             _CAPTURE.append((csr, cfg, states))
         ctx.states = states if need else None
@@ -914,7 +949,7 @@ class GCNStackFunction(torch.autograd.Function):
                     dP = torch.empty_like(st.P) if st.P is not None else None
                     d_pw = torch.empty_like(ctx.pwf) if ctx.pwf is not None else None
                     v = max(cfg.vocab, ctx.pwf.numel() if ctx.pwf is not None else 0)
-                    wsb = call("txe_gcn_collapse_ws_bytes", N, G, st.Kh, st.Pd, st.Fo, 8)
+                    wsb = call("txe_gcn_collapse_ws_bytes", N, G, st.Kh, st.Pd, st.Fo, max(v, 8))
                     ws = _ws(wsb, d_out)
                     call("txe_gcn_collapse_bwd", ptr(csr.rowptr_in), ptr(csr.col_src), ptr(csr.graph_off), N, G, ptr(st.X), st.Kh, st.Pd,
                          ptr(pos if st.P is not None else ctx.rpos), v, ptr(st.Wp), st.Fo, cfg.drop_ps[l], ptr(st.mask), ptr(norm),
@@ -1302,6 +1337,17 @@ def folded_graph_vector_ok(csr, cfg):
     return call("txe_gat_fused_bwd_supported", kh, cfg.pos_dims[-1], cfg.heads[-2], cfg.out_dims[-2]) == 1
 
 
+def folded_graph_linear(Z, Wp, D):
+    """hg [G, D] = Z [G, Kp] Wp[:D]^T, outside autograd (DeferredGraphVector.detach)"""
+    _need_cuda(Z, Wp)
+    G, Kp = Z.shape
+    hg = _empty((G, D), Z)
+    with _lib.on_device(Z.device):
+        tws = _tail_ws(Z)
+        call("txe_gemm_plain", 0, ptr(Z), Kp, ptr(Wp), Kp, ptr(hg), D, G, D, Kp, 1, 0, ptr(tws), tws.numel(), _lib.stream_ptr())
+    return hg
+
+
 class FoldedGraphLinearFunction(torch.autograd.Function):
     """hg [G, D] = Z [G, Kp] Wp[:D]^T -- the graph vector of a 'collapse_z' stack materialised after all (some consumer other than the
     bilinear run matcher wants the tensor).  Backward: dZ = d_hg Wp[:D] through autograd, the weight gradient's main part d_hg^T Z as
@@ -1311,10 +1357,8 @@ class FoldedGraphLinearFunction(torch.autograd.Function):
     def forward(ctx, Z, Wp, link, D):
         _need_cuda(Z, Wp)
         G, Kp = Z.shape
-        hg = _empty((G, D), Z)
-        with _lib.on_device(Z.device):
-            tws = _tail_ws(Z)
-            call("txe_gemm_plain", 0, ptr(Z), Kp, ptr(Wp), Kp, ptr(hg), D, G, D, Kp, 1, 0, ptr(tws), tws.numel(), _lib.stream_ptr())
+        hg = folded_graph_linear(Z, Wp, D)
+        note_route("fold", "materialised")
         ctx.misc = (Z, Wp, link, D)
         return hg
 
@@ -1402,6 +1446,7 @@ class BilinearFoldedRunsFunction(torch.autograd.Function):
                 n_runs, U, first_row = None, Q.shape[0], 0
             V, T = _empty((max(U, 1), l), Z), _empty((max(U, 1), Kp), Z)
         s = _empty((G,), Z)
+        note_route("fold", "edot" if (ready and link.e_part is not None and "score" in fw) else ("job" if ready else "inline"))
         with _lib.on_device(Z.device):
             if ready and link.e_part is not None and "score" in fw:
                 # T rode in the stack's Z sweep: the scores are sums of its per-node dot products over each graph's few nodes, no sweep over Z
@@ -1420,12 +1465,13 @@ class BilinearFoldedRunsFunction(torch.autograd.Function):
         G, Kp = Z.shape
         l, r = Wmf.shape
         ds = _f32(ds.reshape(-1))
-        edot = link.e_part is not None              # the stack reads "dZ[g]" as dsl_g T[run(g)] (FoldLink): the tensor below is shape only
-        dZ, dT, dV = _empty((G, Kp), Z), _empty((max(U, 1), Kp), Z), _empty((max(U, 1), l), Z)
+        edot = link.e_part is not None              # the stack reads "dZ[g]" as dsl_g T[run(g)] (FoldLink): no dZ tensor exists
+        dZ = None if edot else _empty((G, Kp), Z)
+        dT, dV = _empty((max(U, 1), Kp), Z), _empty((max(U, 1), l), Z)
         dWm, dWf = _empty((l, r), Z), _empty((l, Kp), Z)
         with _lib.on_device(Z.device):
             call("txe_bilinear_folded_bwd", ptr(Z), Kp, G, Kp, ptr(Wp), Kp, l, ptr(Q), ldq, r, ptr(run_off), ptr(n_runs), U, first_row, apply_exp,
-                 ptr(V), ptr(T), ptr(s), ptr(ds), None if edot else ptr(dZ), Kp, ptr(dT), ptr(dV), ptr(dWm), ptr(dWf), _lib.stream_ptr())
+                 ptr(V), ptr(T), ptr(s), ptr(ds), ptr(dZ), Kp, ptr(dT), ptr(dV), ptr(dWm), ptr(dWf), _lib.stream_ptr())
         link.part, link.S = dWf, 1
         link.m = (ds, s, apply_exp) if link.e_part is not None else None
         return dZ, None, None, None, dWm.reshape(wshape), None, None, None, None

@@ -146,16 +146,28 @@ def score_all_sharded(match, hg_local, n_total, queries, block=1024, group=None,
     return None if on_block is not None else (torch.cat(collected, 0) if collected else torch.zeros((0, n_total), device=dev))
 
 
-def rank_all_fused(match, hg, queries, pos_off, pos_idx, block=None, larger_is_better=True, group=None, shard_lo=0, local_fns=None):
+def _sharded_call(group, sharded):
+    """is this a candidate-SHARDED call (collectives inside)?  Only when the caller says so -- a process group handed over, or
+    sharded=True for the default group.  An initialised world alone decides nothing: evaluate() / infer() on rank 0 of a DDP job, or on
+    every rank with the whole candidate list, stay local and issue no collective."""
+    on = bool(sharded) or group is not None
+    if on and not (dist.is_available() and dist.is_initialized()):
+        raise RuntimeError("candidate-sharded scoring asked for (group / sharded=True) but torch.distributed is not initialised")
+    return on
+
+
+def rank_all_fused(match, hg, queries, pos_off, pos_idx, block=None, larger_is_better=True, group=None, shard_lo=0, local_fns=None,
+                   sharded=False):
     """Ranks of every query's true parents among ALL candidates without materialising the score matrix.
     hg: this rank's candidate representations (rows [shard_lo, shard_lo + len) of the global candidate list; the whole list when
     not distributed).  pos_off [Q+1] / pos_idx: GLOBAL candidate columns of each query's true parents.
     Per query block: thresholds = scores of the positives (each computed by the rank that owns the candidate, summed over ranks),
     counts = fused score-and-compare over the local shard (summed over ranks), ranks = 1 + counts - own positives that beat it.
     The only collectives are two all-reduces of [n_positives] vectors per block -- instead of the [queries x candidates] all-gather.
+    Sharded ONLY when asked: `group` given, or sharded=True (the default group) -- see _sharded_call.
     local_fns = (positive_scores, score_count) is injectable so that the collective logic is testable without a GPU."""
     dev = hg.device
-    distributed = dist.is_available() and dist.is_initialized() and (group is not None or dist.get_world_size() > 1)
+    distributed = _sharded_call(group, sharded)
     if block is None:
         # query blocks of 1,024 (a [1024 x G] tile pass per block; the thresholds' small score matrix grows with block x positives);
         # a query set of a few thousand goes in ONE block: five launches in all instead of five per 1,024 queries
@@ -414,17 +426,18 @@ class overlapped_gradient_allreduce:
         self._pending = []
 
 
-def topk_parents_fused(match, hg, queries, candidate_ids=None, k=5, larger_is_better=True, block=None, group=None, shard_lo=0):
+def topk_parents_fused(match, hg, queries, candidate_ids=None, k=5, larger_is_better=True, block=None, group=None, shard_lo=0, sharded=False):
     """infer.py:96-106 / test_fast.py:121-131 without the score matrix: per query block ONE launch of the score GEMM whose epilogue keeps
     each tile's best k columns per row (txe_score_topk_block) + a merge launch -- no [Q, G] scores, no [Q, G] index temporaries (the
     torch composite topk_parents below needs two int64 [Q, G] ones: 3.5 GB per 1,024-query block on MAG-Full).  Same selection and
     order as topk_parents on the materialised scores of the same kernel (bit-identical values): better score first, ties by ascending
     candidate position (Python's stable sort), NaN last.  match: BIM / LBM.  hg: this rank's candidate rows (positions
-    [shard_lo, shard_lo + len) of the global list).  Candidate-sharded (group / an initialised world > 1): every rank's [Q, k] lists
+    [shard_lo, shard_lo + len) of the global list).  Candidate-sharded (ONLY when asked: `group` given or sharded=True, _sharded_call
+    -- every rank then holds a DISJOINT slice, which the merge relies on): every rank's [Q, k] lists
     are all-gathered (k * 8 bytes per query instead of the [queries x candidates] block) and merged by the same kernel.
     Returns candidate_ids[...] (or the positions themselves when candidate_ids is None) [Q, min(k, G)]."""
     dev = hg.device
-    distributed = dist.is_available() and dist.is_initialized() and (group is not None or dist.get_world_size() > 1)
+    distributed = _sharded_call(group, sharded)
     Q, G = queries.shape[0], hg.shape[0]
     k_loc = min(int(k), G, 8)
     assert int(k) <= 8, "topk_parents_fused: k <= 8 (the kernels keep 8 entries per list)"

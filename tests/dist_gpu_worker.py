@@ -49,7 +49,7 @@ def main():
             assert torch.equal(S_sh, S_full), kind
             S_sh2 = score_all_sharded(match, hg[lo:hi], G, queries, block=128)          # the default collecting path
             assert torch.equal(S_sh2, S_full), kind
-            ranks_sh = rank_all_fused(match, hg[lo:hi], queries, pos_off, pos_idx, block=128, shard_lo=lo)
+            ranks_sh = rank_all_fused(match, hg[lo:hi], queries, pos_off, pos_idx, block=128, shard_lo=lo, sharded=True)
             assert torch.equal(ranks_sh, ranks_full), kind
             off_t, idx_t = torch.tensor(pos_off, dtype=torch.int32), torch.tensor(pos_idx, dtype=torch.int32)
             assert torch.equal(ops.rank_block(S_full, off_t, idx_t, True), ranks_full), kind
@@ -59,7 +59,12 @@ def main():
             for larger in (True, False):
                 want = topk_parents(S_full, ids, 5, larger)
                 assert torch.equal(topk_parents_fused(match, hg, queries, None, 5, larger, group=solo), want), (kind, larger)
-                assert torch.equal(topk_parents_fused(match, hg[lo:hi], queries, None, 5, larger, block=128, shard_lo=lo), want), (kind, larger)
+                assert torch.equal(topk_parents_fused(match, hg[lo:hi], queries, None, 5, larger, block=128, shard_lo=lo, sharded=True), want), (kind, larger)
+            # evaluate() / infer() on ONE rank of the initialised world, whole candidate list, no group: no collective may be issued
+            # (the peers are not calling -- a hang here is the failure), same results
+            if rank == 0:
+                assert torch.equal(topk_parents_fused(match, hg, queries, None, 5, True), topk_parents(S_full, ids, 5, True)), kind
+                assert torch.equal(rank_all_fused(match, hg, queries, pos_off, pos_idx, block=128), ranks_full), kind
     torch.cuda.synchronize()
     dist.barrier()
     print(f"OK {rank}", flush=True)

@@ -116,7 +116,7 @@ def _fused_rank_worker(rank, world, port, q):
         qid = torch.repeat_interleave(torch.arange(qb.shape[0]), cnt)
         return (S[qid] > thr[:, None]).sum(1).to(torch.int32)
 
-    got = scoring.rank_all_fused(None, Ul, Qm, pos_off, pos_idx, block=16, shard_lo=lo, local_fns=(f_thr, f_cnt))
+    got = scoring.rank_all_fused(None, Ul, Qm, pos_off, pos_idx, block=16, shard_lo=lo, local_fns=(f_thr, f_cnt), sharded=True)
     S = (Qm @ U.t()).numpy()
     want = []
     for i in range(nq):
@@ -124,7 +124,14 @@ def _fused_rank_worker(rank, world, port, q):
         neg = np.ones(G, dtype=bool)
         neg[P] = False
         want += [1 + int((S[i][neg] > S[i][p]).sum()) for p in P]
-    q.put((rank, got.tolist() == want))
+    ok = got.tolist() == want
+    # an UNSHARDED call inside the initialised world (evaluate() / infer() on one rank of a DDP job): rank 0 alone, the whole candidate
+    # list, no group -- it must issue no collective (rank 1 is not there to answer: a hang here is the failure) and rank correctly
+    if rank == 0:
+        Ul = U
+        solo = scoring.rank_all_fused(None, U, Qm, pos_off, pos_idx, block=16, local_fns=(f_thr, f_cnt))
+        ok = ok and solo.tolist() == want
+    q.put((rank, ok))
     dist.destroy_process_group()
 
 

@@ -100,8 +100,47 @@ def _masks(kind, P, heads, num_layers, N, E, seed, eid_in, pf, pa):
     return out
 
 
-@pytest.mark.parametrize("workload", ["pgat", "pgcn", "pgat2", "semeval"])
-def test_full_size_training_step_matches_oracle(workload, monkeypatch):
+def _expected_routes(prop, form):
+    """the routes the step must take with the library's switches as they are (TXE_TEST_ROUTE flips one for a whole run): the DEFAULT for
+    the three PGAT workloads is the one bench.py times -- stack 'collapse_z+edot', matcher 'folded' on the e_part scores, backward
+    'fused+edot' -- and a test that silently ran anything else is a test of something else"""
+    from taxoexpan_amd import model_zoo as mz, ops
+    runs_ok = form == "rows" or not ops._NO_QUERY_RUNS
+    fold = prop == "PGAT" and runs_ok and not (ops._NO_MATCH_FOLD or ops._NO_FUSED_BWD or mz._NO_FOLD)
+    edot = fold and not ops._NO_FOLD_EDOT and form != "hook"
+    match = "folded" if fold else (("runs" if form == "rows" else "stacked") if runs_ok else "pair")
+    if mz._NO_FOLD:
+        stack = "mean" if prop == "PGAT" else "layers"
+    else:
+        stack = ("collapse_z" + ("+edot" if edot else "")) if fold else "collapse"
+    fold_kind = ("edot" if edot else ("inline" if form == "hook" else "job")) if fold else None
+    bwd = "fused+edot" if edot else (("collapse" if not mz._NO_FOLD else "layers") if prop == "PGAT" else None)
+    return dict(match=match, stack=stack, fold=fold_kind, stack_bwd=bwd)
+
+
+def _graph_vectors_from_capture(prop, states, model, D):
+    """hg [G, D] from the folded output layer's saved Z (nothing in the step is touched: no hook, no materialisation)"""
+    st = states[-1]
+    if getattr(st, "cl", None) is None:
+        return None
+    if prop == "PGAT":
+        Z = st.cl[5]
+        if st.cl[6] is not None:
+            return st.cl[6].detach().cpu().numpy()
+        return (Z.double() @ st.Wp[:D].double().t()).float().cpu().numpy()
+    Z = st.cl[3]
+    return (Z.double() @ st.Wp[:Z.shape[1], :D].double() + st.b.double()).float().cpu().numpy()
+
+
+@pytest.mark.parametrize("workload,form", [("pgat", "stacked"), ("pgat", "rows"), ("pgat", "hook"), ("pgcn", "stacked"), ("pgat2", "stacked"),
+                                           ("semeval", "stacked"), ("semeval", "rows")])
+def test_full_size_training_step_matches_oracle(workload, form, monkeypatch):
+    """form: how the queries arrive / who else looks at the graph vector --
+      'stacked': the reference collate's [G, r] matrix (data_loaders.py:9-28), nothing else touches the step: THE ROUTE bench.py TIMES;
+      'rows':    ops.RepeatedRows (DeviceBatchLoader(repeated_queries=True));
+      'hook':    a forward hook on the readout that logs `out.detach()` (what gen_golden.py does to the reference): the fold stays, its
+                 query-side job cannot ride in the sweep any more (the in-line kernels).
+    The routes are ASSERTED (_expected_routes); scores, graph vectors, loss and every gradient entry against the oracle."""
     from taxoexpan_amd import TaxoExpan, ops, synthetic as syn
     prop, readout, match, num_layers, heads = WORKLOADS[workload]
     dev = _dev()
@@ -120,16 +159,31 @@ def test_full_size_training_step_matches_oracle(workload, monkeypatch):
     seed = 987654321
     monkeypatch.setattr(ops, "new_seed", lambda: seed)
     caps = {}
-    model.readout.register_forward_hook(lambda m, i, o: caps.__setitem__("hg", o.detach()))
+    if form == "hook":
+        model.readout.register_forward_hook(lambda m, i, o: caps.__setitem__("hg", o.detach().cpu().numpy()))
+    q_dev = qf.to(dev)
+    if form == "rows":
+        q_arg = ops.RepeatedRows(q_dev[::32].contiguous(), torch.arange(0, n_queries * 32 + 1, 32, dtype=torch.int32, device=dev), n_queries * 32)
+        assert torch.equal(q_arg.dense(), q_dev)
+    else:
+        q_arg = q_dev
     with ops.debug_capture() as runs:
-        scores = model(g, x.to(dev), qf.to(dev))
+        scores = model(g, x.to(dev), q_arg)
     assert len(runs) == 1
     _csr_dev, _cfg, states = runs[0]
+    want = _expected_routes(prop, form)
+    taken = dict(runs.routes)
+    for kind in ("match", "stack", "fold"):
+        assert taken.get(kind) == want[kind], (kind, taken, want)
+    if "hg" not in caps:
+        caps["hg"] = _graph_vectors_from_capture(prop, states, model, dims["out_dim"])
     src_np, dst_np = np.asarray(g._src), np.asarray(g._dst)
     branches = _device_branches("PGAT" if prop == "PGAT" else "PGCN", states, src_np, dst_np, [{} for _ in states])   # (before backward frees anything)
     loss = F.cross_entropy(scores.reshape(n_queries, -1), torch.zeros(n_queries, dtype=torch.long, device=dev), reduction="sum")
+    ops.ROUTES.pop("stack_bwd", None)
     loss.backward()
     torch.cuda.synchronize()
+    assert ops.ROUTES.get("stack_bwd") == want["stack_bwd"], (ops.ROUTES, want)
 
     # ---- the oracle on the same egonets, same parameters, same masks ----
     csr = g.csr("cpu")
@@ -152,7 +206,11 @@ def test_full_size_training_step_matches_oracle(workload, monkeypatch):
     l_ref.backward()
 
     errors = []
-    _close(caps["hg"].cpu().numpy(), hg_ref.detach().numpy(), 1e-4, 2e-5, "hg", errors)
+    if caps["hg"] is not None:
+        _close(caps["hg"], hg_ref.detach().numpy(), 1e-4, 2e-5, "hg", errors)
+    else:
+        from taxoexpan_amd import model_zoo as mz
+        assert mz._NO_FOLD                                                       # (only the unfolded test route has no saved Z to read hg from)
     _close(scores.detach().cpu().numpy(), s_ref.detach().numpy(), 1e-4, 2e-5, "scores", errors)
     np.testing.assert_allclose(loss.item(), l_ref.item(), rtol=1e-4)
     for k, p in model.named_parameters():
@@ -186,7 +244,7 @@ def test_fused_stack_intermediates_match_reference_goldens(name):
     csr, cfg, states = runs[0]
     L = len(states)
     eid = csr.eid_in.long()
-    step = 1 if spec["full"] else 5
+    step = gc.row_steps(spec)[1]
     for l, st in enumerate(states):
         H, D = st.H, st.D
         want_alpha = torch.from_numpy(z[f"layer{l}_alpha"]).reshape(-1, H)

@@ -41,19 +41,37 @@ def _graph(shapes):
 NODROP = [n for n, s in gc.CASES.items() if not s.get("dropout")]       # includes the ConcatReadout + MLP case
 
 
+def _values(o):
+    """the numbers of a readout's return value -- a tensor or a model_zoo.DeferredGraphVector -- read AFTER the step, outside autograd"""
+    with torch.no_grad():
+        return (o if torch.is_tensor(o) else o.tensor()).detach().cpu().numpy()
+
+
 @pytest.mark.parametrize("name", NODROP)
 def test_model_matches_reference_goldens(name):
+    """every dropout-free golden of the unmodified reference (oracle/gen_golden.py): node states, graph vectors, scores, loss, gradients.
+    The `*_q8x32` cases are training batches in the trainer's layout (256 egonets, each query row stacked 32 times): there the step must
+    take the graph vector FOLDED into the matcher, with the matcher's query-side job riding in the stack's Z sweep -- the route bench.py
+    times, pinned here to the reference itself.  Nothing touches the readout's return value before the matcher has consumed it."""
+    from taxoexpan_amd import model_zoo as mz, ops
     spec, z, shapes, x, q, params, graph = load_case(name)
     model = _build_model(spec, params).eval()
     g = _graph(shapes)
     caps = {}
-    model.readout.register_forward_hook(lambda m, i, o: caps.__setitem__("hg", o.detach()))
-    scores = model(g, torch.from_numpy(x).to(_dev()), torch.from_numpy(q).to(_dev()))
+    model.readout.register_forward_hook(lambda m, i, o: caps.__setitem__("hg", o))       # (the object: looked at after the step)
+    with ops.debug_capture() as runs:
+        scores = model(g, torch.from_numpy(x).to(_dev()), torch.from_numpy(q).to(_dev()))
     nq = spec["n_queries"]
     loss = torch.nn.functional.cross_entropy(scores.reshape(nq, -1), torch.zeros(nq, dtype=torch.long, device=_dev()), reduction="sum")
     loss.backward()
-    np.testing.assert_allclose(g.ndata["h"].detach().cpu().numpy(), z["hn"], rtol=RT, atol=AT)
-    np.testing.assert_allclose(caps["hg"].cpu().numpy(), z["hg"], rtol=RT, atol=AT)
+    if spec.get("repeat_queries") and not (ops._NO_MATCH_FOLD or ops._NO_FUSED_BWD or ops._NO_QUERY_RUNS or mz._NO_FOLD):
+        edot = not ops._NO_FOLD_EDOT
+        taken = dict(runs.routes)
+        assert (taken["match"], taken["stack"], taken["fold"]) == ("folded", "collapse_z" + ("+edot" if edot else ""), "edot" if edot else "job"), taken
+        assert ops.ROUTES["stack_bwd"] == ("fused+edot" if edot else "collapse")
+    step = gc.row_steps(spec)[0]
+    np.testing.assert_allclose(g.ndata["h"].detach().cpu().numpy()[::step], z["hn"], rtol=RT, atol=AT)
+    np.testing.assert_allclose(_values(caps["hg"]), z["hg"], rtol=RT, atol=AT)
     np.testing.assert_allclose(scores.detach().cpu().numpy(), z["scores"], rtol=RT, atol=AT)
     np.testing.assert_allclose(loss.item(), float(z["loss"]), rtol=1e-4)
     for k, p in model.named_parameters():
@@ -1444,31 +1462,70 @@ def test_graph_vector_folded_into_the_matcher_equals_the_materialised_one(matche
             with ops.debug_capture() as runs:
                 loss = info_nce_loss(model(g, x, q_arg).reshape(nq, -1), target)
             loss.backward()
-            kinds.append(runs[-1][1].final)
+            kinds.append((runs[-1][1].final, dict(runs.routes)["match"], ops.ROUTES["stack_bwd"]))
             res.append((loss.item(), {n: p.grad.clone() for n, p in model.named_parameters()}, runs[-1][1].seed))
     finally:
         ops._NO_MATCH_FOLD = prev
-    assert kinds == ["collapse_z", "collapse"]
+    edot = not ops._NO_FOLD_EDOT
+    assert kinds == [("collapse_z", "folded", "fused+edot" if edot else "collapse"), ("collapse", "stacked" if stacked else "runs", "collapse")], kinds
     assert res[0][2] == res[1][2]                                                    # (same dropout masks: the two steps are the same function)
     assert abs(res[0][0] - res[1][0]) <= 2e-5 * abs(res[1][0])
     for n, ref in res[1][1].items():
         np.testing.assert_allclose(res[0][1][n].cpu().numpy(), ref.cpu().numpy(), rtol=2e-4, atol=2e-5 * max(ref.abs().max().item(), 1e-30), err_msg=n)
-    # the folded vector as an ordinary tensor
+    # ---- the deferred vector under other consumers (eval mode: no dropout, so separate forwards agree) ----
     model.eval()
-    g.ndata["pos"] = pos
-    out = model.graph_propagate(g, x)
-    out._want_folded = True
-    g.ndata["h"] = out
-    with torch.enable_grad():
-        hv = model.readout(g, pos)
-        assert isinstance(hv, mz.DeferredGraphVector) and hv.shape == (nq * per, 24)
-        t = hv + 0.0                                                                 # a torch function: materialises
-        assert hv.folded() is None and torch.is_tensor(t)
-        t.sum().backward()
-    g.ndata["pos"] = pos
-    g.ndata["h"] = model.graph_propagate(g, x)
-    ref = model.readout(g, pos)
-    np.testing.assert_allclose(t.detach().cpu().numpy(), ref.detach().cpu().numpy(), rtol=1e-4, atol=2e-6)
+
+    def fresh():
+        g.ndata["pos"] = pos
+        g.ndata["h"] = model.graph_propagate(g, x)
+        return model.readout(g, pos)
+    with torch.no_grad():
+        ref = fresh()
+    assert torch.is_tensor(ref)                                                      # without gradients: computed at once
+    hv = fresh()
+    assert isinstance(hv, mz.DeferredGraphVector) and hv.shape == (nq * per, 24) and not hv.started() and hv.can_fold()
+    # a logging hook's `.detach()`: the values, and the route stays open
+    d = hv.detach()
+    assert torch.is_tensor(d) and not d.requires_grad and hv.started() and hv.can_fold()
+    np.testing.assert_allclose(d.cpu().numpy(), ref.cpu().numpy(), rtol=1e-4, atol=2e-6)
+    # ... the matcher still folds afterwards (the query-side job did not ride in the sweep: the in-line form of the kernels)
+    model.zero_grad()
+    s1 = model.match(hv, q_arg)
+    assert ops.ROUTES["match"] == "folded" and ops.ROUTES["fold"] == "inline"
+    info_nce_loss(s1.reshape(nq, -1), target).backward()
+    g_inline = {n: p.grad.clone() for n, p in model.named_parameters()}
+    # ... against the same step with nothing touched in between (the job rides in the sweep)
+    model.zero_grad()
+    s2 = model.match(fresh(), q_arg)
+    assert ops.ROUTES["fold"] == ("edot" if edot else "job")
+    info_nce_loss(s2.reshape(nq, -1), target).backward()
+    np.testing.assert_allclose(s1.detach().cpu().numpy(), s2.detach().cpu().numpy(), rtol=1e-4, atol=1e-6)
+    for n, p in model.named_parameters():
+        np.testing.assert_allclose(g_inline[n].cpu().numpy(), p.grad.cpu().numpy(), rtol=2e-4, atol=2e-5 * max(p.grad.abs().max().item(), 1e-30), err_msg=n)
+    # a second differentiable use AFTER the fold is refused loudly; the values stay available outside autograd
+    with pytest.raises(RuntimeError, match="consumed FOLDED"):
+        hv.tensor()
+    with torch.no_grad():
+        np.testing.assert_allclose(hv.tensor().cpu().numpy(), ref.cpu().numpy(), rtol=1e-4, atol=2e-6)
+    # any other consumer first: the plain tensor ('collapse'), and the matcher then takes a run form on it
+    hv = fresh()
+    t = hv + 0.0                                                                     # a torch function: materialises
+    assert torch.is_tensor(t) and not hv.can_fold() and ops.ROUTES["stack"] == "collapse"
+    np.testing.assert_allclose(t.detach().cpu().numpy(), ref.cpu().numpy(), rtol=1e-4, atol=2e-6)
+    model.match(hv, q_arg).sum().backward()
+    assert ops.ROUTES["match"] == ("stacked" if stacked else "runs")
+    # .detach() and THEN a tensor consumer: hg = Z W^T as an autograd node (FoldedGraphLinearFunction), gradients as on the plain route
+    model.zero_grad()
+    (fresh() * 1.0).sum().backward()
+    g_plain = {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+    model.zero_grad()
+    hv = fresh()
+    hv.detach()
+    (hv * 1.0).sum().backward()
+    assert ops.ROUTES["fold"] == "materialised"
+    for n, ref_g in g_plain.items():
+        got = dict(model.named_parameters())[n].grad
+        np.testing.assert_allclose(got.cpu().numpy(), ref_g.cpu().numpy(), rtol=2e-4, atol=2e-5 * max(ref_g.abs().max().item(), 1e-30), err_msg=n)
 
 
 @pytest.mark.gpu

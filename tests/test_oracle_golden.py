@@ -20,7 +20,7 @@ def test_oracle_matches_reference_goldens(name):
                                            spec["readout"], spec["match"], spec["heads"], spec["num_layers"], masks)
     loss = orc.info_nce_loss(scores, spec["n_queries"])
     loss.backward()
-    np.testing.assert_allclose(hn.detach().numpy(), z["hn"], rtol=RT, atol=AT)
+    np.testing.assert_allclose(hn.detach().numpy()[::gc.row_steps(spec)[0]], z["hn"], rtol=RT, atol=AT)
     np.testing.assert_allclose(hg.detach().numpy(), z["hg"], rtol=RT, atol=AT)
     np.testing.assert_allclose(scores.detach().numpy(), z["scores"], rtol=RT, atol=AT)
     np.testing.assert_allclose(loss.item(), float(z["loss"]), rtol=1e-5)

@@ -163,6 +163,7 @@ def route_sanity(model, batch, target):
     for name, off in (("default", False), ("no_match_fold", True)):
         prev, ops._NO_MATCH_FOLD = ops._NO_MATCH_FOLD, off
         try:
+            ops.ROUTES.clear()
             torch.manual_seed(4711)                     # (ops.new_seed draws the dropout seeds from this generator)
             batch["g"].ndata["pos"] = batch["pos"]
             pred = model(batch["g"], batch["x"], batch["qf"])

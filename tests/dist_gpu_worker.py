@@ -14,11 +14,23 @@ import torch.distributed as dist
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
-def main():
+def _init():
+    """gloo with every rank on cuda:0 (a one-GPU box: the collective LOGIC over the real kernels), or -- TXE_TEST_BACKEND=nccl, a box with
+    at least WORLD_SIZE GPUs -- RCCL with one GPU per rank (the real transport: async collectives on RCCL's own streams)"""
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    torch.cuda.set_device(0)
-    dev = torch.device("cuda:0")
+    backend = os.environ.get("TXE_TEST_BACKEND", "gloo")
+    index = int(os.environ.get("LOCAL_RANK", "0")) if backend == "nccl" else 0
+    torch.cuda.set_device(index)
+    dev = torch.device("cuda", index)
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    else:
+        dist.init_process_group(backend, rank=rank, world_size=world)
+    return rank, world, dev
+
+
+def main():
+    rank, world, dev = _init()
     from taxoexpan_amd import model_zoo as mz, ops
     from taxoexpan_amd.scoring import rank_all_fused, score_all, score_all_sharded, shard_bounds, topk_parents, topk_parents_fused
     solo = [dist.new_group([rr]) for rr in range(world)][rank]      # (every rank creates every group: new_group is collective)
@@ -91,10 +103,7 @@ def dp_training_step():
     single-process step on the whole batch (the loss is a sum over queries).  Dropout off (the keep masks hash batch row indices,
     which differ between the whole batch and a shard).  Last scenario: fewer queries than ranks -- the last rank's shard is empty, it
     never runs backward, and must neither hang nor change the sums."""
-    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    torch.cuda.set_device(0)
-    dev = torch.device("cuda:0")
+    rank, world, dev = _init()
     from taxoexpan_amd import TaxoExpan, synthetic as syn
     from taxoexpan_amd.loss import info_nce_loss
     from taxoexpan_amd.scoring import allreduce_gradients, gradient_bucket_plan, overlapped_gradient_allreduce, shard_bounds

@@ -295,6 +295,29 @@ def test_data_parallel_training_step_equals_single_process_on_the_hip_kernels(wo
     assert all(out.stdout.count(f"OK {r}") == 1 for r in range(world)), out.stdout[-500:]
 
 
+@pytest.mark.parametrize("mode", ["score", "dp"])
+def test_rccl_world2_sharded_scoring_and_data_parallel_step(mode):
+    """the two multi-process tests above over RCCL (backend "nccl"), one GPU per rank, world size 2: the transport the 8-GPU runs use --
+    async collectives on RCCL's own streams, `work.wait()` as a stream dependency.  Needs two GPUs: skipped on the one-GPU boxes the
+    round's tests run on (there the gloo variants cover the logic over the same kernels)."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs >= 2 GPUs (RCCL with one GPU per rank)")
+    import socket
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", TXE_TEST_BACKEND="nccl")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", str(port), os.path.join(repo, "tests", "dist_gpu_worker.py")] + (["dp"] if mode == "dp" else []),
+                         cwd=repo, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
+    assert all(out.stdout.count(f"OK {r}") == 1 for r in range(2)), out.stdout[-500:]
+
+
 @pytest.mark.parametrize("G,Q,k", [(24736, 700, 5), (131, 40, 8), (128, 3, 5), (5, 9, 8), (1000, 260, 3)])
 def test_fused_top_k_equals_the_composite_on_materialised_scores(G, Q, k):
     """txe_score_topk_block + txe_topk_merge (infer.py:96-106, test_fast.py:121-131 without the score matrix) against

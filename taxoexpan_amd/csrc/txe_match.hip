@@ -4,7 +4,10 @@
 // The literal loop costs 2*l*r flops per (query, candidate) pair.  Here the bilinear form is factored once,
 // U = HG W  (G x r), and every query block is one NT GEMM  S[q][g] = <Q[q], U[g]>  with the exp fused into the
 // epilogue -- 2*r flops per pair on the fp32 MFMA pipe.
+#include <string.h>
+
 #include "txe_gemm.h"
+#include "txe_skinny.h"
 
 namespace txe {
 
@@ -124,15 +127,6 @@ __global__ void colsum_small_kernel(const float* __restrict__ x, long long n_row
 // The runs are either given (compact distinct rows Qu [U][r] + run offsets, U known on the host) or found on the device in the stacked
 // matrix E2 [G][r] itself (run u's row is row off[u] of E2, the number of runs is a device scalar): every kernel walks the runs with a
 // grid stride and reads the count through runs_count(), so one launch shape serves any count.
-struct RunsRef {
-    const int* off;       // [n + 1] first pair of every run, off[n] = G
-    const int* n_dev;     // the number of runs on the device (NULL: n_host)
-    int n_host;
-    int first_row;        // 1: run u's distinct row = row off[u] of the stacked matrix;  0: row u of the compact matrix
-};
-__device__ __forceinline__ int runs_count(const RunsRef& R) { return R.n_dev ? *R.n_dev : R.n_host; }
-__device__ __forceinline__ long long runs_row(const RunsRef& R, int u) { return R.first_row ? (long long)R.off[u] : (long long)u; }
-
 // flag[i] = row i of E2 differs (bit pattern) from row i - 1; flag[0] = 1.  One wave per row.
 __global__ __launch_bounds__(256) void row_change_kernel(const float* __restrict__ e2, long long ld, int G, int r, int* __restrict__ flag) {
     const int i = blockIdx.x * 4 + (threadIdx.x >> 6), ln = threadIdx.x & 63;
@@ -203,6 +197,7 @@ __global__ __launch_bounds__(256) void rowdot_runs_kernel(const float* __restric
 }
 
 // backward of the above for run u: d_e1_i = dsl_i V[u], S[u] = sum over the run's pairs (in order) of dsl_i e1_i; thread = column
+constexpr int RB_NL = 16;       // (a training run is 32 pairs: two dependent round trips instead of four)
 __global__ __launch_bounds__(256) void runs_bwd_kernel(const float* __restrict__ ds, const float* __restrict__ s, int apply_exp,
                                                        const float* __restrict__ V, const float* __restrict__ e1, long long ld_e1,
                                                        const RunsRef R, int l, float* __restrict__ d_e1, long long ld_de1,
@@ -214,16 +209,16 @@ __global__ __launch_bounds__(256) void runs_bwd_kernel(const float* __restrict__
         const int i0 = R.off[u], i1 = R.off[u + 1];
         const float v = V[(long long)u * l + k];
         float acc = 0.f;
-        for (int i = i0; i < i1; i += 8) {                      // eight pairs' loads in flight; the sum keeps the pairs' order
-            float x[8], dsl[8];
+        for (int i = i0; i < i1; i += RB_NL) {                  // RB_NL pairs' loads in flight; the sum keeps the pairs' order
+            float x[RB_NL], dsl[RB_NL];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
+            for (int q = 0; q < RB_NL; ++q) {
                 const int ii = min(i + q, i1 - 1);
                 x[q] = e1[(long long)ii * ld_e1 + k];
                 dsl[q] = apply_exp ? ds[ii] * s[ii] : ds[ii];
             }
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
+            for (int q = 0; q < RB_NL; ++q) {
                 if (i + q < i1) {
                     if (d_e1) d_e1[(long long)(i + q) * ld_de1 + k] = dsl[q] * v;     // (NULL: only the run sums are wanted)
                     acc = fmaf(dsl[q], x[q], acc);
@@ -232,223 +227,6 @@ __global__ __launch_bounds__(256) void runs_bwd_kernel(const float* __restrict__
         }
         S[(long long)u * l + k] = acc;
     }
-}
-
-// V[u][j] = <Q[row(u)], W[j]>: one wave per output row j and block of 8 runs, lanes along k (both rows read coalesced), W[j] kept in
-// registers.  A few hundred rows at most: the MFMA GEMM's 128-row tiles would leave most of the chip idle on such a product.
-__global__ __launch_bounds__(256) void runs_project_kernel(const float* __restrict__ Q, long long ld_q, const float* __restrict__ W,
-                                                           const RunsRef R, int l, int r, float* __restrict__ V) {
-    const int w = threadIdx.x >> 6, ln = threadIdx.x & 63;
-    const int j = blockIdx.x * 4 + w;
-    if (j >= l) return;
-    const int U = runs_count(R);
-    for (int u0 = blockIdx.y * 8; u0 < U; u0 += 8 * gridDim.y) {
-        float acc[8];
-        long long row[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) { acc[q] = 0.f; row[q] = runs_row(R, min(u0 + q, U - 1)); }     // clamped: loads stay unconditional
-        for (int k0 = 0; k0 < r; k0 += 256) {
-            float wv[4];
-#pragma unroll
-            for (int c = 0; c < 4; ++c) { const int k = k0 + ln + 64 * c; wv[c] = k < r ? W[(long long)j * r + k] : 0.f; }
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-#pragma unroll
-                for (int c = 0; c < 4; ++c) { const int k = k0 + ln + 64 * c; acc[q] = fmaf(k < r ? Q[row[q] * ld_q + k] : 0.f, wv[c], acc[q]); }
-            }
-        }
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const float t = wave_sum(acc[q]);
-            if (ln == 0 && u0 + q < U) V[(long long)(u0 + q) * l + j] = t;
-        }
-    }
-}
-
-// dW[j][k] = sum_u S[u][j] Q[row(u)][k] (runs in order): thread = column k, two rows j per workgroup, S's two columns staged in LDS
-__global__ __launch_bounds__(256) void runs_dw_kernel(const float* __restrict__ S, const float* __restrict__ Q, long long ld_q, const RunsRef R,
-                                                      int l, int r, float* __restrict__ dW) {
-    __shared__ float sS[256][2];
-    __shared__ long long sRow[256];
-    const int j0 = blockIdx.x * 2;
-    const int k = blockIdx.y * 256 + threadIdx.x, kc = min(k, r - 1);
-    const int U = runs_count(R);
-    float acc[2] = {0.f, 0.f};
-    for (int u0 = 0; u0 < U; u0 += 256) {
-        __syncthreads();
-        {
-            const int u = min(u0 + (int)threadIdx.x, U - 1);
-            sS[threadIdx.x][0] = S[(long long)u * l + j0];
-            sS[threadIdx.x][1] = S[(long long)u * l + min(j0 + 1, l - 1)];
-            sRow[threadIdx.x] = runs_row(R, u);
-        }
-        __syncthreads();
-        const int n = min(256, U - u0);
-        for (int t0 = 0; t0 < n; t0 += 16) {                    // sixteen runs' loads in flight; the sum keeps the runs' order
-            float q[16];
-#pragma unroll
-            for (int t = 0; t < 16; ++t) q[t] = Q[sRow[min(t0 + t, n - 1)] * ld_q + kc];
-#pragma unroll
-            for (int t = 0; t < 16; ++t) {
-                if (t0 + t < n) {
-                    acc[0] = fmaf(sS[t0 + t][0], q[t], acc[0]);
-                    acc[1] = fmaf(sS[t0 + t][1], q[t], acc[1]);
-                }
-            }
-        }
-    }
-    if (k < r) {
-        dW[(long long)j0 * r + k] = acc[0];
-        if (j0 + 1 < l) dW[(long long)(j0 + 1) * r + k] = acc[1];
-    }
-}
-
-// T[u][c] = sum_j V[u][j] Wf[j][c]: the run's projected query pushed through the FOLDED output layer (txe_bilinear_folded_*).  A workgroup
-// of eight waves owns 64 columns and eight runs per pass: wave w walks the rows j = w, w + 8, ... of Wf (a 256-byte piece each, eight in
-// flight), the eight V rows sit in LDS and are read as broadcasts; the waves' partial sums meet in LDS and are added in wave order:
-// deterministic.  (A first version -- one thread per column walking all 500 rows -- was 63 dependent round trips: 68 us for 0.27 GFLOP.)
-constexpr int RF_WAVES = 8, RF_NL = 8, RF_COLS = 128;      // (64-column workgroups were 528 for 512 slots of two: a second round for 16 of them)
-__global__ __launch_bounds__(64 * RF_WAVES) void runs_fold_kernel(const float* __restrict__ V, const float* __restrict__ Wf, long long ld_wf, const RunsRef R,
-                                                                  int l, int Kp, float* __restrict__ T) {
-    __shared__ float sV[8][512];
-    __shared__ float2 red[RF_WAVES][8][64];
-    const int w = threadIdx.x >> 6, ln = threadIdx.x & 63;
-    const int c = blockIdx.x * RF_COLS + 2 * ln, cc = min(c, Kp - 2);       // (Kp is even: a multiple of 32)
-    const int U = runs_count(R);
-    for (int u0 = blockIdx.y * 8; u0 < U; u0 += 8 * gridDim.y) {
-        float2 acc[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) acc[q] = make_float2(0.f, 0.f);
-        for (int j0 = 0; j0 < l; j0 += 512) {
-            __syncthreads();
-            for (int i = threadIdx.x; i < 8 * 512; i += 64 * RF_WAVES) {
-                const int q = i >> 9, j = j0 + (i & 511);
-                sV[q][i & 511] = (j < l) ? V[(long long)min(u0 + q, U - 1) * l + j] : 0.f;
-            }
-            __syncthreads();
-            const int nj = min(512, l - j0);
-            for (int j = w; j < nj; j += RF_NL * RF_WAVES) {       // RF_NL rows of Wf in flight (clamped: their V factors are 0)
-                float2 wv[RF_NL];
-#pragma unroll
-                for (int t = 0; t < RF_NL; ++t)
-                    wv[t] = *reinterpret_cast<const float2*>(Wf + (long long)min(j0 + j + t * RF_WAVES, l - 1) * ld_wf + cc);
-#pragma unroll
-                for (int t = 0; t < RF_NL; ++t) {
-                    const int jj = min(j + t * RF_WAVES, 511);
-                    const float live = (j + t * RF_WAVES < nj) ? 1.f : 0.f;
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) {
-                        const float v = sV[q][jj] * live;
-                        acc[q].x = fmaf(v, wv[t].x, acc[q].x);
-                        acc[q].y = fmaf(v, wv[t].y, acc[q].y);
-                    }
-                }
-            }
-        }
-#pragma unroll
-        for (int q = 0; q < 8; ++q) red[w][q][ln] = acc[q];
-        __syncthreads();
-        if (c < Kp && u0 + w < U) {                                // wave q finishes run u0 + q
-            float2 t = make_float2(0.f, 0.f);
-#pragma unroll
-            for (int x = 0; x < RF_WAVES; ++x) { t.x += red[x][w][ln].x; t.y += red[x][w][ln].y; }
-            *reinterpret_cast<float2*>(T + (long long)(u0 + w) * Kp + c) = t;
-        }
-    }
-}
-
-// dV[u][j] = <X[u], Wf[j]> over Kp columns, in 8 x 8 blocks per wave (eight rows of X and eight of Wf loaded once per 256-column step for
-// 64 products: the one-row-per-wave form of runs_project_kernel moved 1.1 GB through the caches for this 0.27-GFLOP product)
-__device__ __forceinline__ void runs_project8_job(const int bx, const int by, const int ny, const float* __restrict__ X, long long ld_x,
-                                                  const float* __restrict__ Wf, long long ld_wf, const RunsRef& R, int l, int Kp,
-                                                  float* __restrict__ dV) {
-    const int w = threadIdx.x >> 6, ln = threadIdx.x & 63;
-    const int j0 = (bx * 4 + w) * 8;
-    if (j0 >= l) return;
-    const int U = runs_count(R);
-    const int nvec = Kp >> 2;
-    for (int u0 = by * 8; u0 < U; u0 += 8 * ny) {
-        float acc[8][8];
-#pragma unroll
-        for (int a = 0; a < 8; ++a)
-#pragma unroll
-            for (int b = 0; b < 8; ++b) acc[a][b] = 0.f;
-        for (int v0 = 0; v0 < nvec; v0 += 64) {
-            const int v = v0 + ln;
-            const int vc = (v < nvec) ? v : 0;
-            const float live = (v < nvec) ? 1.f : 0.f;
-            float4 xw[8], ww[8];
-#pragma unroll
-            for (int a = 0; a < 8; ++a) xw[a] = *reinterpret_cast<const float4*>(X + (long long)min(u0 + a, U - 1) * ld_x + 4 * vc);
-#pragma unroll
-            for (int b = 0; b < 8; ++b) ww[b] = *reinterpret_cast<const float4*>(Wf + (long long)min(j0 + b, l - 1) * ld_wf + 4 * vc);
-#pragma unroll
-            for (int a = 0; a < 8; ++a) {
-                const float4 x = make_float4(xw[a].x * live, xw[a].y * live, xw[a].z * live, xw[a].w * live);
-#pragma unroll
-                for (int b = 0; b < 8; ++b)
-                    acc[a][b] = fmaf(x.w, ww[b].w, fmaf(x.z, ww[b].z, fmaf(x.y, ww[b].y, fmaf(x.x, ww[b].x, acc[a][b]))));
-            }
-        }
-#pragma unroll
-        for (int a = 0; a < 8; ++a)
-#pragma unroll
-            for (int b = 0; b < 8; ++b) {
-                const float t = wave_sum(acc[a][b]);
-                if (ln == 0 && u0 + a < U && j0 + b < l) dV[(long long)(u0 + a) * l + j0 + b] = t;
-            }
-    }
-}
-
-// runs_dw_kernel with eight rows j per workgroup: for wide outputs (dWf [l][Kp]) -- each loaded Q value feeds eight sums instead of two
-__device__ __forceinline__ void runs_dw8_job(const int bx, const int by, const float* __restrict__ S, const float* __restrict__ Q, long long ld_q,
-                                             const RunsRef& R, int l, int r, float* __restrict__ dW) {
-    __shared__ float sS[256][8];
-    __shared__ long long sRow[256];
-    const int j0 = bx * 8;
-    const int k = by * 256 + threadIdx.x, kc = min(k, r - 1);
-    const int U = runs_count(R);
-    float acc[8];
-#pragma unroll
-    for (int b = 0; b < 8; ++b) acc[b] = 0.f;
-    for (int u0 = 0; u0 < U; u0 += 256) {
-        __syncthreads();
-        {
-            const int u = min(u0 + (int)threadIdx.x, U - 1);
-#pragma unroll
-            for (int b = 0; b < 8; ++b) sS[threadIdx.x][b] = S[(long long)u * l + min(j0 + b, l - 1)];
-            sRow[threadIdx.x] = runs_row(R, u);
-        }
-        __syncthreads();
-        const int n = min(256, U - u0);
-        for (int t0 = 0; t0 < n; t0 += 16) {                    // sixteen runs' loads in flight; the sums keep the runs' order
-            float q[16];
-#pragma unroll
-            for (int t = 0; t < 16; ++t) q[t] = Q[sRow[min(t0 + t, n - 1)] * ld_q + kc];
-#pragma unroll
-            for (int t = 0; t < 16; ++t) {
-                if (t0 + t < n) {
-#pragma unroll
-                    for (int b = 0; b < 8; ++b) acc[b] = fmaf(sS[t0 + t][b], q[t], acc[b]);
-                }
-            }
-        }
-    }
-    if (k < r) {
-#pragma unroll
-        for (int b = 0; b < 8; ++b)
-            if (j0 + b < l) dW[(long long)(j0 + b) * r + k] = acc[b];
-    }
-}
-
-// dV = dT Wf^T and dWf = V^T dT need dT only, not each other: ONE launch -- the first gxp * gyp workgroups project, the rest sum
-__global__ __launch_bounds__(256) void runs_dv_dwf_kernel(const float* __restrict__ dT, const float* __restrict__ Wf, long long ld_wf, const float* __restrict__ V,
-                                                          const RunsRef R, int l, int Kp, int gxp, int gyp, int gxd, float* __restrict__ dV,
-                                                          float* __restrict__ dWf) {
-    const int b = blockIdx.x;
-    if (b < gxp * gyp) { runs_project8_job(b % gxp, b / gxp, gyp, dT, (long long)Kp, Wf, ld_wf, R, l, Kp, dV); return; }
-    const int d = b - gxp * gyp;
-    runs_dw8_job(d % gxd, d / gxd, V, dT, (long long)Kp, R, l, Kp, dWf);
 }
 
 // run_id[i] = the run that holds pair i (binary search in the offsets)
@@ -463,6 +241,34 @@ __global__ void runs_expand_kernel(const int* __restrict__ off, int U, int G, in
 static inline size_t mt_align(size_t x) { return (x + 255) / 256 * 256; }
 
 static inline int mt_splits(int M, int N, int K) { return choose_splits(M, N, K); }
+
+// ---- the run products on the skinny MFMA kernel (txe_skinny.h) ----
+// the launch shape for a run count that lives on the device: a training batch pairs a query with 1 + negative_size = 32 anchors
+static inline int runs_hint(const RunsRef& R, int G) { return R.n_dev ? (G / 32 > 32 ? G / 32 : 32) : (R.n_host > 0 ? R.n_host : 1); }
+
+// C [U][N] = A[rows of the runs] B^T (B [N][K] k-contiguous) or A B (B [K][N]); A [.][K] k-contiguous, compact rows unless a_first
+static inline void skinny_runs_rows(SkinnyArgs& a, const float* A, long long lda, bool a_first, const float* B, long long ldb, bool b_kmajor,
+                                    float* C, long long ldc, int N, int K, const RunsRef& R, int G) {
+    memset(&a, 0, sizeof(a));
+    a.A = A; a.lda = lda; a.B = B; a.ldb = ldb; a.C = C; a.ldc = ldc;
+    a.M = R.n_host; a.N = N; a.K = K; a.m_dyn = 1; a.a_rows_first = a_first ? 1 : 0; a.R = R;
+    skinny_setup(a, false, b_kmajor, runs_hint(R, G), K);
+}
+// C [M][N] = sum over the runs u of A[u][m] B[row(u)][n]   (both operands one row per run; B's rows through the runs when b_first)
+static inline void skinny_runs_sum(SkinnyArgs& a, const float* A, long long lda, const float* B, long long ldb, bool b_first, float* C,
+                                   long long ldc, int M, int N, const RunsRef& R, int G) {
+    memset(&a, 0, sizeof(a));
+    a.A = A; a.lda = lda; a.B = B; a.ldb = ldb; a.C = C; a.ldc = ldc;
+    a.M = M; a.N = N; a.K = R.n_host; a.k_dyn = 1; a.b_k_first = b_first ? 1 : 0; a.R = R;
+    skinny_setup(a, true, true, M, runs_hint(R, G));
+}
+static int skinny_one(const char* name, SkinnyArgs& a, double bytes, hipStream_t st) {
+    SkinnyMulti m;
+    memset(&m, 0, sizeof(m));
+    m.n = 1; m.j[0] = a;
+    ProfScope prof(name, st, bytes, 1);
+    return skinny_launch(m, st);
+}
 
 }  // namespace txe
 
@@ -609,13 +415,14 @@ int txe_bilinear_query_bwd(const float* e1, long long ld_e1, const float* e2, lo
 // run_off [U+1]: the first pair of every run, run_off[U] = G.  V = Qu W^T is U rows instead of G, backward's dW = S^T Qu with
 // S[u] = sum over run u of dsl_i e1_i (pairs in order: deterministic) has K = U instead of G; d_e1_i = dsl_i V[u].  Both U-row products
 // run on small dot-product kernels (a few hundred rows would leave the MFMA GEMM's 128-row tiles most of the chip idle: 41 + 29 us measured).
-static int runs_fwd_launch(const float* e1, long long ld_e1, const float* Q, long long ld_q, const RunsRef& R, int gx, int gy, int G, int l, int r,
+static int runs_fwd_launch(const float* e1, long long ld_e1, const float* Q, long long ld_q, const RunsRef& R, int gx, int G, int l, int r,
                            const float* W, int apply_exp, float* V, float* s, hipStream_t st) {
-    {
-        ProfScope prof("runs_project_kernel", st, 4.0 * ((double)R.n_host * r + (double)l * r + (double)R.n_host * l), 1);
-        hipLaunchKernelGGL(runs_project_kernel, dim3((l + 3) / 4, gy), dim3(256), 0, st, Q, ld_q, W, R, l, r, V);
+    {   // V [U][l] = Q[run rows] W^T
+        SkinnyArgs a;
+        skinny_runs_rows(a, Q, ld_q, R.first_row != 0, W, (long long)r, false, V, (long long)l, l, r, R, G);
+        const int rc = skinny_one("skinny_gemm_kernel[V]", a, 4.0 * ((double)runs_hint(R, G) * (r + l) + (double)l * r), st);
+        if (rc) return rc;
     }
-    TXE_CHECK_LAUNCH();
     {
         ProfScope prof("rowdot_runs_kernel", st, 4.0 * ((double)G * l + (double)R.n_host * l + G), 1);
         hipLaunchKernelGGL(rowdot_runs_kernel, dim3(gx, 8), dim3(256), 0, st, e1, ld_e1, (const float*)V, R, l, apply_exp, s);
@@ -632,11 +439,12 @@ static int runs_bwd_launch(const float* e1, long long ld_e1, const float* Q, lon
         hipLaunchKernelGGL(runs_bwd_kernel, dim3(gx, (l + 255) / 256), dim3(256), 0, st, ds, s, apply_exp, V, e1, ld_e1, R, l, d_e1, ld_de1, S);
     }
     TXE_CHECK_LAUNCH();
-    {
-        ProfScope prof("runs_dw_kernel", st, 4.0 * ((double)R.n_host * l + (double)R.n_host * r + (double)l * r), 1);
-        hipLaunchKernelGGL(runs_dw_kernel, dim3((l + 1) / 2, (r + 255) / 256), dim3(256), 0, st, (const float*)S, Q, ld_q, R, l, r, dW);
+    {   // dW [l][r] = sum_u S[u]^T q_u
+        SkinnyArgs a;
+        skinny_runs_sum(a, S, (long long)l, Q, ld_q, R.first_row != 0, dW, (long long)r, l, r, R, G);
+        const int rc = skinny_one("skinny_gemm_kernel[dWm]", a, 4.0 * ((double)runs_hint(R, G) * (r + l) + (double)l * r), st);
+        if (rc) return rc;
     }
-    TXE_CHECK_LAUNCH();
     return TXE_OK;
 }
 
@@ -645,7 +453,7 @@ int txe_bilinear_runs_fwd(const float* e1, long long ld_e1, const float* Qu, lon
     if (G < 0 || U < 0 || l < 1 || r < 1 || !e1 || !Qu || !run_off || !W || !V || !s) return TXE_ERR_ARG;
     if (G == 0 || U == 0) return TXE_OK;
     const RunsRef R{run_off, nullptr, U, 0};
-    return runs_fwd_launch(e1, ld_e1, Qu, ld_q, R, U, (U + 7) / 8, G, l, r, W, apply_exp, V, s, (hipStream_t)stream);
+    return runs_fwd_launch(e1, ld_e1, Qu, ld_q, R, U, G, l, r, W, apply_exp, V, s, (hipStream_t)stream);
 }
 
 size_t txe_bilinear_runs_bwd_ws_bytes(int U, int l, int r) { return mt_align((size_t)(U > 0 ? U : 1) * l * 4); }
@@ -690,7 +498,7 @@ int txe_bilinear_stacked_fwd(const float* e1, long long ld_e1, const float* e2, 
     if (G == 0) return TXE_OK;
     const RunsRef R{run_off, n_runs, G, 1};
     const int gx = G < 512 ? G : 512;
-    return runs_fwd_launch(e1, ld_e1, e2, ld_e2, R, gx, 32, G, l, r, W, apply_exp, V, s, (hipStream_t)stream);
+    return runs_fwd_launch(e1, ld_e1, e2, ld_e2, R, gx, G, l, r, W, apply_exp, V, s, (hipStream_t)stream);
 }
 
 size_t txe_bilinear_stacked_bwd_ws_bytes(int G, int l, int r) { return mt_align((size_t)(G > 0 ? G : 1) * l * 4); }
@@ -736,14 +544,19 @@ int txe_bilinear_folded_fwd(const float* Z, long long ld_z, int G, int Kp, const
     hipStream_t st = (hipStream_t)stream;
     const RunsRef R{run_off, n_runs, U, first_row ? 1 : 0};
     const RunsRef Rc{run_off, n_runs, U, 0};                       // the same runs, compact rows (V, T)
-    const int gx = n_runs ? (G < 512 ? G : 512) : U, gy = n_runs ? 32 : (U + 7) / 8;
-    if (stages & 1) {
-        ProfScope prof("runs_project_kernel", st, 4.0 * ((double)U * r + (double)l * r + (double)U * l), 1);
-        hipLaunchKernelGGL(runs_project_kernel, dim3((l + 3) / 4, gy), dim3(256), 0, st, Q, ld_q, Wm, R, l, r, V);
+    const int gx = n_runs ? (G < 512 ? G : 512) : U;
+    const double uh = (double)runs_hint(R, G);
+    if (stages & 1) {   // V [U][l] = Q[run rows] Wm^T
+        SkinnyArgs a;
+        skinny_runs_rows(a, Q, ld_q, first_row != 0, Wm, (long long)r, false, V, (long long)l, l, r, R, G);
+        const int rc = skinny_one("skinny_gemm_kernel[V]", a, 4.0 * (uh * (r + l) + (double)l * r), st);
+        if (rc) return rc;
     }
-    if (stages & 1) {
-        ProfScope prof("runs_fold_kernel", st, 4.0 * ((double)U * l + (double)l * Kp + (double)U * Kp), 1);
-        hipLaunchKernelGGL(runs_fold_kernel, dim3((Kp + RF_COLS - 1) / RF_COLS, gy < 16 ? gy : 16), dim3(64 * RF_WAVES), 0, st, (const float*)V, Wf, ld_wf, Rc, l, Kp, T);
+    if (stages & 1) {   // T [U][Kp] = V Wf
+        SkinnyArgs a;
+        skinny_runs_rows(a, V, (long long)l, false, Wf, ld_wf, true, T, (long long)Kp, Kp, l, Rc, G);
+        const int rc = skinny_one("skinny_gemm_kernel[T]", a, 4.0 * (uh * (l + Kp) + (double)l * Kp), st);
+        if (rc) return rc;
     }
     if (stages & 2) {
         ProfScope prof("rowdot_runs_kernel", st, 4.0 * ((double)G * Kp + (double)U * Kp + G), 1);
@@ -769,22 +582,28 @@ int txe_bilinear_folded_bwd(const float* Z, long long ld_z, int G, int Kp, const
     }
     const RunsRef R{run_off, n_runs, U, first_row ? 1 : 0};
     const RunsRef Rc{run_off, n_runs, U, 0};
-    const int gx = n_runs ? (G < 512 ? G : 512) : U, gy = n_runs ? 32 : (U + 7) / 8;
+    const int gx = n_runs ? (G < 512 ? G : 512) : U;
     {
         ProfScope prof("runs_bwd_kernel", st, 4.0 * (2.0 * G * Kp + 2.0 * U * Kp + 2.0 * G), 1);
         hipLaunchKernelGGL(runs_bwd_kernel, dim3(gx, (Kp + 255) / 256), dim3(256), 0, st, ds, s, apply_exp, T, Z, ld_z, Rc, Kp, dZ, ld_dz, dT);
     }
-    {   // dV[u][j] = <dT[u], Wf[j]> and dWf[j][c] = sum_u V[u][j] dT[u][c]: one launch
-        ProfScope prof("runs_dv_dwf_kernel", st, 4.0 * (2.0 * U * Kp + 2.0 * l * Kp + 2.0 * U * l), 1);
-        const int gxp = (l + 31) / 32, gyp = gy < 16 ? gy : 16, gxd = (l + 7) / 8, gyd = (Kp + 255) / 256;
-        hipLaunchKernelGGL(runs_dv_dwf_kernel, dim3(gxp * gyp + gxd * gyd), dim3(256), 0, st, (const float*)dT, Wf, ld_wf, V, Rc, l, Kp, gxp, gyp, gxd, dV,
-                           dWf);
+    const double uh = (double)runs_hint(R, G);
+    {   // dV [U][l] = dT Wf^T and dWf [l][Kp] = V^T dT need dT only, not each other: one launch
+        SkinnyMulti m;
+        memset(&m, 0, sizeof(m));
+        m.n = 2;
+        skinny_runs_rows(m.j[0], dT, (long long)Kp, false, Wf, ld_wf, false, dV, (long long)l, l, Kp, Rc, G);
+        skinny_runs_sum(m.j[1], V, (long long)l, dT, (long long)Kp, false, dWf, (long long)Kp, l, Kp, Rc, G);
+        ProfScope prof("skinny_gemm_kernel[dV+dWf]", st, 4.0 * (2.0 * uh * Kp + 2.0 * l * Kp + 2.0 * uh * l), 1);
+        const int rc = skinny_launch(m, st);
+        if (rc) return rc;
     }
-    {   // dWm[j][k] = sum_u dV[u][j] q_u[k]
-        ProfScope prof("runs_dw_kernel", st, 4.0 * ((double)U * l + (double)U * r + (double)l * r), 1);
-        hipLaunchKernelGGL(runs_dw_kernel, dim3((l + 1) / 2, (r + 255) / 256), dim3(256), 0, st, (const float*)dV, Q, ld_q, R, l, r, dWm);
+    {   // dWm [l][r] = sum_u dV[u]^T q_u
+        SkinnyArgs a;
+        skinny_runs_sum(a, dV, (long long)l, Q, ld_q, first_row != 0, dWm, (long long)r, l, r, R, G);
+        const int rc = skinny_one("skinny_gemm_kernel[dWm]", a, 4.0 * (uh * (l + r) + (double)l * r), st);
+        if (rc) return rc;
     }
-    TXE_CHECK_LAUNCH();
     return TXE_OK;
 }
 

@@ -198,14 +198,20 @@ __global__ __launch_bounds__(256) void rowdot_runs_kernel(const float* __restric
 
 // backward of the above for run u: d_e1_i = dsl_i V[u], S[u] = sum over the run's pairs (in order) of dsl_i e1_i; thread = column
 constexpr int RB_NL = 16;       // (a training run is 32 pairs: two dependent round trips instead of four)
-__global__ __launch_bounds__(256) void runs_bwd_kernel(const float* __restrict__ ds, const float* __restrict__ s, int apply_exp,
-                                                       const float* __restrict__ V, const float* __restrict__ e1, long long ld_e1,
-                                                       const RunsRef R, int l, float* __restrict__ d_e1, long long ld_de1,
-                                                       float* __restrict__ S) {
-    const int k = blockIdx.y * 256 + threadIdx.x;
+struct RunsBwdArgs {
+    const float *ds, *s; int apply_exp; const float* V; const float* e1; long long ld_e1; RunsRef R; int l; float* d_e1; long long ld_de1; float* S;
+};
+// workgroup (bx of nbx, by): the columns [by * blockDim, (by + 1) * blockDim) of the runs bx, bx + nbx, ...
+__device__ __forceinline__ void runs_bwd_job(const int bx, const int nbx, const int by, const RunsBwdArgs& a) {
+    const float* __restrict__ ds = a.ds; const float* __restrict__ s = a.s; const float* __restrict__ V = a.V; const float* __restrict__ e1 = a.e1;
+    float* __restrict__ d_e1 = a.d_e1; float* __restrict__ S = a.S;
+    const int apply_exp = a.apply_exp, l = a.l;
+    const long long ld_e1 = a.ld_e1, ld_de1 = a.ld_de1;
+    const RunsRef& R = a.R;
+    const int k = by * (int)blockDim.x + (int)threadIdx.x;
     if (k >= l) return;
     const int U = runs_count(R);
-    for (int u = blockIdx.x; u < U; u += gridDim.x) {
+    for (int u = bx; u < U; u += nbx) {
         const int i0 = R.off[u], i1 = R.off[u + 1];
         const float v = V[(long long)u * l + k];
         float acc = 0.f;
@@ -228,6 +234,7 @@ __global__ __launch_bounds__(256) void runs_bwd_kernel(const float* __restrict__
         S[(long long)u * l + k] = acc;
     }
 }
+__global__ __launch_bounds__(256) void runs_bwd_kernel(const RunsBwdArgs a) { runs_bwd_job(blockIdx.x, gridDim.x, blockIdx.y, a); }
 
 // run_id[i] = the run that holds pair i (binary search in the offsets)
 __global__ void runs_expand_kernel(const int* __restrict__ off, int U, int G, int* __restrict__ run_id) {
@@ -436,7 +443,8 @@ static int runs_bwd_launch(const float* e1, long long ld_e1, const float* Q, lon
                            hipStream_t st) {
     {
         ProfScope prof("runs_bwd_kernel", st, 4.0 * (2.0 * G * l + 2.0 * R.n_host * l + 2.0 * G), 1);
-        hipLaunchKernelGGL(runs_bwd_kernel, dim3(gx, (l + 255) / 256), dim3(256), 0, st, ds, s, apply_exp, V, e1, ld_e1, R, l, d_e1, ld_de1, S);
+        const RunsBwdArgs ba{ds, s, apply_exp, V, e1, ld_e1, R, l, d_e1, ld_de1, S};
+        hipLaunchKernelGGL(runs_bwd_kernel, dim3(gx, (l + 255) / 256), dim3(256), 0, st, ba);
     }
     TXE_CHECK_LAUNCH();
     {   // dW [l][r] = sum_u S[u]^T q_u
@@ -583,11 +591,12 @@ int txe_bilinear_folded_bwd(const float* Z, long long ld_z, int G, int Kp, const
     const RunsRef R{run_off, n_runs, U, first_row ? 1 : 0};
     const RunsRef Rc{run_off, n_runs, U, 0};
     const int gx = n_runs ? (G < 512 ? G : 512) : U;
+    const double uh = (double)runs_hint(R, G);
+    const RunsBwdArgs ba{ds, s, apply_exp, T, Z, ld_z, Rc, Kp, dZ, ld_dz, dT};
     {
         ProfScope prof("runs_bwd_kernel", st, 4.0 * (2.0 * G * Kp + 2.0 * U * Kp + 2.0 * G), 1);
-        hipLaunchKernelGGL(runs_bwd_kernel, dim3(gx, (Kp + 255) / 256), dim3(256), 0, st, ds, s, apply_exp, T, Z, ld_z, Rc, Kp, dZ, ld_dz, dT);
+        hipLaunchKernelGGL(runs_bwd_kernel, dim3(gx, (Kp + 255) / 256), dim3(256), 0, st, ba);
     }
-    const double uh = (double)runs_hint(R, G);
     {   // dV [U][l] = dT Wf^T and dWf [l][Kp] = V^T dT need dT only, not each other: one launch
         SkinnyMulti m;
         memset(&m, 0, sizeof(m));

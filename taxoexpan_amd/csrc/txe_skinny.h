@@ -10,7 +10,7 @@
 //     v_mfma_f32_32x32x2_f32 sums over k in any order as long as A and B agree on it, so lane (row i, half q) of a 16-k step owns
 //     k = k0 + 8 q + e, e = 0..7: a k-contiguous operand row is read as 32 contiguous bytes per lane (two 16-byte loads), a k-major
 //     operand as eight 4-byte loads that are contiguous ACROSS the 32 lanes of a half (128-byte lines);
-//   * four steps (64 k) are in flight per wave: the loads of step s + 4 are issued right behind the MFMAs of step s;
+//   * two steps (32 k) are in flight per wave (128 VGPRs: two 8-wave workgroups per CU): the loads of step s + 2 are issued right behind the MFMAs of step s;
 //   * the runs may be counted on the device (RunsRef.n_dev): M or K is then read there, row tiles walk with a grid stride.
 // Exact fp32 (the MFMA is an fmaf chain); a slice's k order is ascending, slices are added in ascending order.
 #pragma once
@@ -46,7 +46,10 @@ struct SkinnyArgs {
     RunsRef R;
 };
 
-constexpr int SK_NB = 4;               // 16-k steps in flight per wave
+#ifndef TXE_SK_NB
+#define TXE_SK_NB 2
+#endif
+constexpr int SK_NB = TXE_SK_NB;               // 16-k steps in flight per wave
 
 // eight operand values of lane (i, q) for the step at kb = k0 + 8 q: element e <-> k = kb + e.  `base` is the operand's (uniform)
 // pointer, `lane` the lane's fixed 32-bit element offset into it (its row's start for a k-contiguous operand, its column for a k-major
@@ -169,7 +172,7 @@ constexpr int SK_MAXJOBS = 2;
 struct SkinnyMulti { int n; SkinnyArgs j[SK_MAXJOBS]; };
 
 // independent products in one launch, each on its own range of workgroups (all with the same number of waves)
-__global__ __launch_bounds__(512) void skinny_gemm_kernel(const SkinnyMulti m) {
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void skinny_gemm_kernel(const SkinnyMulti m) {
     extern __shared__ float sk_red[];
     int b = blockIdx.x, i = 0;
     while (i + 1 < m.n && b >= m.j[i].nb) { b -= m.j[i].nb; ++i; }

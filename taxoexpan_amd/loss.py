@@ -24,7 +24,30 @@ class _InfoNCE(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_loss):
         (d_x,) = ctx.saved_tensors
+        unit = _UNIT.get(grad_loss.device)
+        if unit is not None and grad_loss.data_ptr() == unit.data_ptr() and grad_loss.numel() == 1:
+            return d_x, None                    # d_x * 1: the plain `loss.backward()` of trainer.py:60 (LossTensor.backward below)
         return d_x * grad_loss, None
+
+
+_UNIT = {}      # device -> the constant 1.0 that `loss.backward()` starts from (never written after its creation)
+
+
+class LossTensor(torch.Tensor):
+    """The scalar loss.  `loss.backward()` without a gradient (trainer/trainer.py:60) makes autograd allocate a ones tensor and fill it
+    (one ~5 us launch), and the loss function's backward then multiplies its saved gradient by that 1.0 (another): here the call starts
+    from a cached device constant, which _InfoNCE.backward recognises by its address and answers with the saved gradient itself -- the
+    same numbers, two launches fewer per step.  Any other use (an explicit gradient, arithmetic on the loss first,
+    torch.autograd.backward / grad) takes the ordinary path."""
+
+    def backward(self, gradient=None, retain_graph=None, create_graph=False, inputs=None):
+        if gradient is None and self.numel() == 1 and self.is_cuda and not create_graph:
+            gradient = _UNIT.get(self.device)
+            if gradient is None:
+                gradient = _UNIT[self.device] = torch.ones((), dtype=self.dtype, device=self.device)
+            if gradient.dtype != self.dtype:
+                gradient = None
+        return super().backward(gradient, retain_graph, create_graph, inputs)
 
 
 def info_nce_loss(output, target=None):
@@ -34,4 +57,4 @@ def info_nce_loss(output, target=None):
         raise ValueError("info_nce_loss expects a [batch, 1 + negatives] tensor")
     if not output.is_cuda:
         raise RuntimeError("taxoexpan_amd.loss.info_nce_loss runs on the MI355X only (no CPU path)")
-    return _InfoNCE.apply(output, target)
+    return _InfoNCE.apply(output, target).as_subclass(LossTensor)

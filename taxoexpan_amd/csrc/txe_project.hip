@@ -1503,6 +1503,16 @@ __global__ __launch_bounds__(256) void cl_attn_coef_kernel(const int* __restrict
     }
 }
 
+// The folded matcher's backward in place of the <dZ, X> sweep (DESIGN 4.9): dZ[g] = dsl_g Tf[zrow[g]], so
+//   dc~_u = dsl_g (scale / S_g) sum_tiles e_part[u][tile],   cn_u = dsl_g c~_u / S_g (the sweep's dZ row is Tf's),   dS_g = -dsl_g raw_g / S_g
+// with dsl = ds (* s for the exp matcher) and raw_g = <Z_g, Tf[zrow[g]]> = the score before exp -- per node / per graph scalars of the
+// graphs a workgroup of cl_attn_bwd_kernel<true> owns, formed in its prologue (they were a launch of their own, cl_fold_dc_kernel).
+struct FoldDcArgs {
+    const float* e_part; int ntile; const float *m_ds, *m_s; int m_exp; float scale; const float *wsum, *coef; float *dc, *cn, *dS;
+    const int* zrow; int* zgid;
+};
+
+template <bool FOLD>
 __global__ __launch_bounds__(256) void cl_attn_bwd_kernel(const int* __restrict__ rowptr_in, const int* __restrict__ col_src,
                                                           const int* __restrict__ rowptr_out, const int* __restrict__ pos_out,
                                                           const int* __restrict__ goff, const int G, const float* __restrict__ a12,
@@ -1511,7 +1521,7 @@ __global__ __launch_bounds__(256) void cl_attn_bwd_kernel(const int* __restrict_
                                                           const int* __restrict__ pos, const float* __restrict__ pw,
                                                           const float* __restrict__ dc, const float* __restrict__ dS,
                                                           float* __restrict__ dz, float* __restrict__ da1, float* __restrict__ da2,
-                                                          float* __restrict__ dwv) {
+                                                          float* __restrict__ dwv, const FoldDcArgs fd_) {
     __shared__ int s_goff[CG_GRAPHS + 1], s_heavy[2][256], s_nh[2];
     const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
     const int g0 = blockIdx.x * CG_GRAPHS, g1 = min(G, g0 + CG_GRAPHS), ng = g1 - g0;
@@ -1519,6 +1529,32 @@ __global__ __launch_bounds__(256) void cl_attn_bwd_kernel(const int* __restrict_
     if (threadIdx.x < 2) s_nh[threadIdx.x] = 0;
     __syncthreads();
     const int n0 = s_goff[0], nn = s_goff[ng] - n0;
+    // (FOLD: dc / dS are written by this workgroup's prologue -- read them back through the same, unrestricted pointers)
+    const float* dcp = FOLD ? (const float*)fd_.dc : dc;
+    const float* dSp = FOLD ? (const float*)fd_.dS : dS;
+    if constexpr (FOLD) {
+        if ((int)threadIdx.x < ng) {
+            const int g = g0 + threadIdx.x;
+            const float sv = fd_.m_s[g], dsl = fd_.m_exp ? fd_.m_ds[g] * sv : fd_.m_ds[g];
+            const float raw = fd_.m_exp ? logf(sv) : sv;
+            const float S = fd_.wsum[g];
+            fd_.dS[g] = (S > 0.f && dsl != 0.f) ? -dsl * raw / S : 0.f;
+        }
+        for (int t = threadIdx.x; t < nn; t += 256) {
+            const int u = n0 + t;
+            const int g = g0 + cg_graph_of(s_goff, ng, u);
+            const float dsl = fd_.m_exp ? fd_.m_ds[g] * fd_.m_s[g] : fd_.m_ds[g];
+            const float S = fd_.wsum[g];
+            const float inv = S > 0.f ? 1.f / S : 0.f;
+            float e = 0.f;
+            for (int q = 0; q < fd_.ntile; ++q) e += fd_.e_part[(long long)u * fd_.ntile + q];
+            fd_.dc[u] = dsl * e * fd_.scale * inv;
+            // the fused sweep reads "dZ[g]" as Tf[zrow[g]] with dsl_g folded into the node's coefficient: dZ itself is never formed
+            fd_.cn[u] = fd_.coef[u] * inv * dsl;
+            fd_.zgid[u] = fd_.zrow[g];
+        }
+        __syncthreads();                               // dc / dS of these graphs: read below by other threads of this workgroup
+    }
     // ---- destination side ----
     for (int t = threadIdx.x; t < nn; t += 256) {
         const int v = n0 + t;
@@ -1536,7 +1572,7 @@ __global__ __launch_bounds__(256) void cl_attn_bwd_kernel(const int* __restrict_
             const float f = (drop_p > 0.f) ? drop_factor(seed, (unsigned long long)p, drop_p, drop_scale) : 1.f;
             const bool ok = beg + i < end;
             al[i] = ok ? alpha[p] : 0.f;
-            fd[i] = f * dc[u];                               // f dc~_u
+            fd[i] = f * dcp[u];                               // f dc~_u
             zs[i] = a12[2 * (long long)u] + a2v;
             dw += al[i] * fd[i];
             T = fmaf(al[i], wv * fd[i], T);
@@ -1549,7 +1585,7 @@ __global__ __launch_bounds__(256) void cl_attn_bwd_kernel(const int* __restrict_
             s2 += (beg + i < end) ? gz : 0.f;
         }
         da2[v] = s2;
-        dwv[v] = pw ? (dS[g0 + cg_graph_of(s_goff, ng, v)] + dw) * cl_sigmoid(pwv) : 0.f;
+        dwv[v] = pw ? (dSp[g0 + cg_graph_of(s_goff, ng, v)] + dw) * cl_sigmoid(pwv) : 0.f;
     }
     __syncthreads();
     {
@@ -1564,16 +1600,16 @@ __global__ __launch_bounds__(256) void cl_attn_bwd_kernel(const int* __restrict_
             float T = 0.f, dw = 0.f;
             for (int p = beg + l; p < end; p += 64) {
                 const float f = (drop_p > 0.f) ? drop_factor(seed, (unsigned long long)p, drop_p, drop_scale) : 1.f;
-                const float gq = alpha[p] * f * dc[col_src[p]];
+                const float gq = alpha[p] * f * dcp[col_src[p]];
                 dw += gq;
-                T = fmaf(alpha[p], wv * f * dc[col_src[p]], T);
+                T = fmaf(alpha[p], wv * f * dcp[col_src[p]], T);
             }
             T = wave_sum(T);
             dw = wave_sum(dw);
             float s2 = 0.f;
             for (int p = beg + l; p < end; p += 64) {
                 const float f = (drop_p > 0.f) ? drop_factor(seed, (unsigned long long)p, drop_p, drop_scale) : 1.f;
-                const float de = alpha[p] * (wv * f * dc[col_src[p]] - T);
+                const float de = alpha[p] * (wv * f * dcp[col_src[p]] - T);
                 const float zq = a12[2 * (long long)col_src[p]] + a2v;
                 const float gz = de * (zq > 0.f ? 1.f : slope);
                 dz[p] = gz;
@@ -1582,7 +1618,7 @@ __global__ __launch_bounds__(256) void cl_attn_bwd_kernel(const int* __restrict_
             s2 = wave_sum(s2);
             if (l == 0) {
                 da2[v] = s2;
-                dwv[v] = pw ? (dS[g0 + cg_graph_of(s_goff, ng, v)] + dw) * cl_sigmoid(pwv) : 0.f;
+                dwv[v] = pw ? (dSp[g0 + cg_graph_of(s_goff, ng, v)] + dw) * cl_sigmoid(pwv) : 0.f;
             }
         }
     }
@@ -2078,34 +2114,6 @@ struct CollapseWs {
     int splits, seg_blocks, seg_rows, chunks;
 };
 
-// The folded matcher's backward in place of the <dZ, X> sweep (DESIGN 4.9): dZ[g] = dsl_g Tf[zrow[g]], so
-//   dc~_u = dsl_g (scale / S_g) sum_tiles e_part[u][tile],   cn_u = dsl_g c~_u / S_g (the sweep's dZ row is Tf's),   dS_g = -dsl_g raw_g / S_g
-// with dsl = ds (* s for the exp matcher) and raw_g = <Z_g, Tf[zrow[g]]> = the score before exp.  One thread per node; the first G also do dS.
-__global__ __launch_bounds__(256) void cl_fold_dc_kernel(int n_nodes, int G, const int* __restrict__ gid, const float* __restrict__ e_part, int ntile,
-                                                         const float* __restrict__ m_ds, const float* __restrict__ m_s, int m_exp, float scale,
-                                                         const float* __restrict__ wsum, const float* __restrict__ coef, float* __restrict__ dc,
-                                                         float* __restrict__ cn, float* __restrict__ dS, const int* __restrict__ zrow,
-                                                         int* __restrict__ zgid) {
-    const int u = blockIdx.x * 256 + threadIdx.x;
-    if (u < G) {
-        const float sv = m_s[u], dsl = m_exp ? m_ds[u] * sv : m_ds[u];
-        const float raw = m_exp ? logf(sv) : sv;
-        const float S = wsum[u];
-        dS[u] = (S > 0.f && dsl != 0.f) ? -dsl * raw / S : 0.f;
-    }
-    if (u >= n_nodes) return;
-    const int g = gid[u];
-    const float dsl = m_exp ? m_ds[g] * m_s[g] : m_ds[g];
-    const float S = wsum[g];
-    const float inv = S > 0.f ? 1.f / S : 0.f;
-    float e = 0.f;
-    for (int t = 0; t < ntile; ++t) e += e_part[(long long)u * ntile + t];
-    dc[u] = dsl * e * scale * inv;
-    // the fused sweep reads "dZ[g]" as Tf[zrow[g]] with dsl_g folded into the node's coefficient: dZ itself is never formed
-    cn[u] = coef[u] * inv * dsl;
-    zgid[u] = zrow[g];
-}
-
 // ... and the folded matcher's FORWARD score from the same dot products: <Z_g, Tf[zrow[g]]> = (scale / S_g) sum_{u in g} c~_u e_u -- a sum
 // over the graph's few nodes instead of a sweep over Z.
 __global__ __launch_bounds__(256) void cl_fold_score_kernel(const int* __restrict__ goff, int G, const float* __restrict__ coef,
@@ -2289,9 +2297,9 @@ int txe_gat_collapse_bwd(const int* rowptr_in, const int* col_src, const int* ro
         rc = cl_bwd_dot_launch(n_nodes, gid, X, Kp, mk, dummy_mask, mask_ld, fs, (const float*)p.dZ, wsum, coef, p.dc, p.cn, (G + 3) / 4, G, D, d_hg, ld_dhg,
                                hg, ld_hg, p.dS, 4.0 * ((n_nodes + (double)G) * Kp + 2.0 * G * D), s);
         if (rc) return rc;
-        hipLaunchKernelGGL(cl_attn_bwd_kernel, dim3((G + CG_GRAPHS - 1) / CG_GRAPHS), dim3(256), 0, s, rowptr_in, col_src, rowptr_out, pos_out,
+        hipLaunchKernelGGL(cl_attn_bwd_kernel<false>, dim3((G + CG_GRAPHS - 1) / CG_GRAPHS), dim3(256), 0, s, rowptr_in, col_src, rowptr_out, pos_out,
                            graph_off, G, a12, attn_slope, alpha, attn_drop_p, as, seed, pos, pw, (const float*)p.dc, (const float*)p.dS, p.dz,
-                           p.da1, p.da2, p.dwv);
+                           p.da1, p.da2, p.dwv, FoldDcArgs{});
         {
             const long long nwaves = (long long)p.chunks * ntile;
             ProfScope prof(mk ? "cl_bwd_dx_kernel<true, true>" : "cl_bwd_dx_kernel<false, true>", s, 4.0 * (2.0 * n_nodes + G) * Kp, 1);
@@ -2438,24 +2446,26 @@ int txe_gat_collapse_bwd_fused(const int* rowptr_in, const int* col_src, const i
     const int nblk = (G > 0 && n_nodes > 0) ? fw.nblocks : 0;
     if ((phases & 4) && G > 0 && n_nodes > 0) {
 
+        FoldDcArgs fdc{};
         if (phases & 512) {
             if (!dz_given || !e_part || !m_ds || !m_s || !Tf || !zrow || !zgid) return TXE_ERR_ARG;
             const int nt_e = txe_gat_collapse_e_tiles(n_nodes, G, Kh, Pd);
             if (nt_e <= 0) return TXE_ERR_ARG;
-            ProfScope prof("cl_fold_dc_kernel", s, 4.0 * n_nodes * (nt_e + 4.0), 1);
-            const int nmax = n_nodes > G ? n_nodes : G;
-            hipLaunchKernelGGL(cl_fold_dc_kernel, dim3((nmax + 255) / 256), dim3(256), 0, s, n_nodes, G, gid, e_part, nt_e, m_ds, m_s, m_exp, fs, wsum, coef,
-                               p.dc, p.cn, p.dS, zrow, zgid);
-            TXE_CHECK_LAUNCH();
+            fdc = FoldDcArgs{e_part, nt_e, m_ds, m_s, m_exp, fs, wsum, coef, p.dc, p.cn, p.dS, zrow, zgid};      // (the edge kernel's prologue)
         } else {
         // (dS[g] = -<dZ[g], Z[g]> / S_g; with d_hg at hand it is <d_hg[g], hg[g]>, D columns instead of Kp)
         rc = cl_bwd_dot_launch(n_nodes, gid, X, Kp, mk, dummy_mask, mask_ld, fs, dZv, wsum, coef, p.dc, p.cn, (G + 3) / 4, G, dz_given ? Kp : D,
                                d_hg, ld_dhg, dz_given ? Z : hg, dz_given ? (long long)Kp : ld_hg, p.dS, 4.0 * ((n_nodes + (double)G) * Kp + 2.0 * G * D), s);
         if (rc) return rc;
         }
-        hipLaunchKernelGGL(cl_attn_bwd_kernel, dim3((G + CG_GRAPHS - 1) / CG_GRAPHS), dim3(256), 0, s, rowptr_in, col_src, rowptr_out, pos_out,
-                           graph_off, G, a12, attn_slope, alpha, attn_drop_p, as, seed, pos, pw, (const float*)p.dc, (const float*)p.dS, p.dz,
-                           p.da1, p.da2, p.dwv);
+        if (phases & 512)
+            hipLaunchKernelGGL(cl_attn_bwd_kernel<true>, dim3((G + CG_GRAPHS - 1) / CG_GRAPHS), dim3(256), 0, s, rowptr_in, col_src, rowptr_out, pos_out,
+                               graph_off, G, a12, attn_slope, alpha, attn_drop_p, as, seed, pos, pw, (const float*)p.dc, (const float*)p.dS, p.dz,
+                               p.da1, p.da2, p.dwv, fdc);
+        else
+            hipLaunchKernelGGL(cl_attn_bwd_kernel<false>, dim3((G + CG_GRAPHS - 1) / CG_GRAPHS), dim3(256), 0, s, rowptr_in, col_src, rowptr_out, pos_out,
+                               graph_off, G, a12, attn_slope, alpha, attn_drop_p, as, seed, pos, pw, (const float*)p.dc, (const float*)p.dS, p.dz,
+                               p.da1, p.da2, p.dwv, fdc);
         {
             FusedBwdArgs a;
             memset(&a, 0, sizeof(a));

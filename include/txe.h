@@ -74,6 +74,7 @@ int txe_gat_layers_prepare(const struct txe_gat_prepare_desc* descs, int n_layer
 /* the same for a GCNLayer (model_zoo.py:35-37): txe_gat_build_x + txe_gcn_pack_weights + txe_dropout_mask as ONE launch */
 int txe_gcn_layer_prepare(const float* h, long long ld_h, int n_nodes, int Kh, const int* pos, const float* P, int Pd, float* X,
                           const float* W, int Fo, float* Wp, float drop_p, unsigned long long seed, unsigned* mask, int x_dropped,
+                          const float* bias_row /* NULL, or the layer's bias packed as row Kh + Pd of Wp (a padding row must exist) */,
                           void* stream);   /* x_dropped: as in txe_gat_prepare_desc (txe_gcn_dense_fwd then without mask) */
 
 /* Eval-mode layer-0 projection of a batch whose node features are rows of a taxonomy feature table (SURVEY 8f-2 "dedup by _id"):
@@ -230,11 +231,14 @@ int txe_bilinear_stacked_bwd(const float* e1, long long ld_e1, const float* e2, 
  * distinct rows) or txe_bilinear_stacked_* (first_row 1, the count on the device, U = G sizes V [U][l], T / dT [U][Kp], dV [U][l]). */
 int txe_bilinear_folded_fwd(const float* Z, long long ld_z, int G, int Kp, const float* Wf, long long ld_wf, int l, const float* Q, long long ld_q,
                             int r, const int* run_off, const int* n_runs, int U, int first_row, const float* Wm, int apply_exp, float* V, float* T,
-                            float* s, int stages /* 1: V and T (queries and weights only), 2: the scores (Z), 3: both */, void* stream);
+                            float* s, int stages /* 1: V and T (queries and weights only), 2: the scores (Z), 3: both */,
+                            int wf_by_k /* 0: Wf [l][Kp] (GAT packing); 1: Wf [Kp][ld_wf] (GCN packing), dWf then [Kp][l] */,
+                            int one_col /* -1, or the column of Z that counts as 1: row one_col of a by-k Wf holds the layer's bias */, void* stream);
 int txe_runs_expand(const int* run_off, int U, int G, int* run_id, void* stream);   /* run_id[i] = the run that holds pair i */
 int txe_bilinear_folded_bwd(const float* Z, long long ld_z, int G, int Kp, const float* Wf, long long ld_wf, int l, const float* Q, long long ld_q,
                             int r, const int* run_off, const int* n_runs, int U, int first_row, int apply_exp, const float* V, const float* T,
-                            const float* s, const float* ds, float* dZ, long long ld_dz, float* dT, float* dV, float* dWm, float* dWf, void* stream);
+                            const float* s, const float* ds, float* dZ, long long ld_dz, float* dT, float* dV, float* dWm, float* dWf, int wf_by_k,
+                            int one_col, void* stream);
 
 /* nn.Linear over the (virtual) concat of two inputs + activation (0 none / 1 relu / 2 tanh): the MLP matcher, model_zoo.py:285-298 */
 int txe_linear_fwd(const float* x1, long long ld1, int l, const float* x2, long long ld2, int r, int G, const float* W, const float* b,
@@ -367,7 +371,8 @@ int txe_gcn_collapse_fwd(const int* rowptr_out, const int* col_dst, const int* g
 int txe_gcn_collapse_bwd(const int* rowptr_in, const int* col_src, const int* graph_off, int n_nodes, int G, const float* X, int Kh, int Pd,
                          const int* pos, int vocab, const float* Wp, int Fo, float drop_p, const unsigned* mask, const float* norm,
                          const float* pw, const float* coef, const float* wsum, const int* gid, const float* Z, const float* d_hg,
-                         long long ld_dhg, int act_on, float act_slope, float* d_X, float* dW, float* d_b, float* dP, float* d_pw, void* ws,
+                         long long ld_dhg, int act_on, float act_slope, float* d_X, float* dW, float* d_b, float* dP, float* d_pw,
+                         int dz_given /* d_hg IS dZ [G][Kp]: no product, dW / d_b not written (txe_bilinear_folded_*, wf_by_k) */, void* ws,
                          size_t ws_bytes, void* stream);
 
 /* ---- egonet construction + batching on device: data_loader/dataset.py:404-437 (_get_subgraph) + dgl.batch (data_loaders.py:25).

@@ -18,7 +18,7 @@ SIGNATURES = {
     "txe_gat_pack_weights": (I, [P, P, P, I, I, I, P, P]),
     "txe_gat_build_x": (I, [P, L, I, I, P, P, I, P, P]),
     "txe_gat_layer_prepare": (I, [P, L, I, I, P, P, I, P, P, P, P, I, I, P, F, U64, P, P]),
-    "txe_gcn_layer_prepare": (I, [P, L, I, I, P, P, I, P, P, I, P, F, U64, P, I, P]),
+    "txe_gcn_layer_prepare": (I, [P, L, I, I, P, P, I, P, P, I, P, F, U64, P, I, P, P]),
     "txe_gather_add_rows": (I, [P, L, P, P, L, P, L, I, P, L, P]),
     "txe_gat_dense_ws_bytes": (SZ, [I, I, I, I, I, I]),
     "txe_gat_dense_fwd": (I, [P, I, I, I, P, I, I, F, P, P, P, SZ, P]),
@@ -66,9 +66,9 @@ SIGNATURES = {
     "txe_bilinear_stacked_fwd": (I, [P, L, P, L, P, P, I, I, I, P, I, P, P, P]),
     "txe_bilinear_stacked_bwd_ws_bytes": (SZ, [I, I, I]),
     "txe_bilinear_stacked_bwd": (I, [P, L, P, L, P, P, I, I, I, I, P, P, P, P, L, P, P, SZ, P]),
-    "txe_bilinear_folded_fwd": (I, [P, L, I, I, P, L, I, P, L, I, P, P, I, I, P, I, P, P, P, I, P]),
+    "txe_bilinear_folded_fwd": (I, [P, L, I, I, P, L, I, P, L, I, P, P, I, I, P, I, P, P, P, I, I, I, P]),
     "txe_runs_expand": (I, [P, I, I, P, P]),
-    "txe_bilinear_folded_bwd": (I, [P, L, I, I, P, L, I, P, L, I, P, P, I, I, I, P, P, P, P, P, L, P, P, P, P, P]),
+    "txe_bilinear_folded_bwd": (I, [P, L, I, I, P, L, I, P, L, I, P, P, I, I, I, P, P, P, P, P, L, P, P, P, P, I, I, P]),
     "txe_bilinear_pair_bwd_ws_bytes": (SZ, [I, I, I]),
     "txe_bilinear_pair_bwd": (I, [P, L, P, L, I, I, I, P, I, P, P, P, P, L, P, L, P, P, SZ, P]),
     "txe_score_block": (I, [P, L, I, P, L, I, I, I, P, L, P, SZ, P]),
@@ -93,7 +93,7 @@ SIGNATURES = {
                                        F, P, L, I, I, F, F, U64, P, P, L, I, P, P, P, P, P, P, I, P, I, P, P, P, I, P, P, P, P, P, SZ, P]),
     "txe_gcn_collapse_ws_bytes": (SZ, [I, I, I, I, I, I]),
     "txe_gcn_collapse_fwd": (I, [P, P, P, I, I, P, I, I, P, I, P, F, P, P, P, P, P, P, P, P, P, L, P, SZ, P]),
-    "txe_gcn_collapse_bwd": (I, [P, P, P, I, I, P, I, I, P, I, P, I, F, P, P, P, P, P, P, P, P, L, I, F, P, P, P, P, P, P, SZ, P]),
+    "txe_gcn_collapse_bwd": (I, [P, P, P, I, I, P, I, I, P, I, P, I, F, P, P, P, P, P, P, P, P, L, I, F, P, P, P, P, P, I, P, SZ, P]),
     "txe_egonet_ws_bytes": (SZ, [I]),
     "txe_egonet_offsets": (I, [P, P, P, P, P, I, I, U64, I, P, P, SZ, P]),
     "txe_egonet_fill": (I, [P, P, P, P, P, P, I, I, U64, I, P, P, P, P, P, P, P, P, P, P]),

@@ -172,8 +172,9 @@ __global__ __launch_bounds__(1024) void runs_scan_kernel(const int* flag, int G,
 }
 
 // s_i = <e1_i, V[u]> for the pairs i of run u: V[u] in registers, one wave per pair, gridDim.y workgroups share a run
+// one_col >= 0: column one_col of e1 counts as 1 whatever it holds (the bias row of a folded GCN layer: V[u][one_col] = <bias, ...>)
 __global__ __launch_bounds__(256) void rowdot_runs_kernel(const float* __restrict__ e1, long long ld_e1, const float* __restrict__ V,
-                                                          const RunsRef R, int l, int apply_exp, float* __restrict__ s) {
+                                                          const RunsRef R, int l, int apply_exp, float* __restrict__ s, const int one_col = -1) {
     const int w = threadIdx.x >> 6, ln = threadIdx.x & 63;
     const int U = runs_count(R);
     for (int u = blockIdx.x; u < U; u += gridDim.x) {
@@ -185,7 +186,11 @@ __global__ __launch_bounds__(256) void rowdot_runs_kernel(const float* __restric
             for (int i = i0 + w + 4 * blockIdx.y; i < i1; i += 4 * gridDim.y) {
                 float acc = 0.f;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) { const int k = k0 + ln + 64 * j; acc = fmaf(k < l ? e1[(long long)i * ld_e1 + k] : 0.f, v[j], acc); }
+                for (int j = 0; j < 8; ++j) {
+                    const int k = k0 + ln + 64 * j;
+                    const float x = k < l ? e1[(long long)i * ld_e1 + k] : 0.f;
+                    acc = fmaf(k == one_col ? 1.f : x, v[j], acc);
+                }
                 acc = wave_sum(acc);
                 if (ln == 0) {
                     const float tot = (k0 == 0 ? 0.f : s[i]) + acc;
@@ -200,6 +205,7 @@ __global__ __launch_bounds__(256) void rowdot_runs_kernel(const float* __restric
 constexpr int RB_NL = 16;       // (a training run is 32 pairs: two dependent round trips instead of four)
 struct RunsBwdArgs {
     const float *ds, *s; int apply_exp; const float* V; const float* e1; long long ld_e1; RunsRef R; int l; float* d_e1; long long ld_de1; float* S;
+    int one_col;          // >= 0: column one_col of e1 counts as 1 (see rowdot_runs_kernel); -1: none
 };
 // workgroup (bx of nbx, by): the columns [by * blockDim, (by + 1) * blockDim) of the runs bx, bx + nbx, ...
 __device__ __forceinline__ void runs_bwd_job(const int bx, const int nbx, const int by, const RunsBwdArgs& a) {
@@ -220,7 +226,7 @@ __device__ __forceinline__ void runs_bwd_job(const int bx, const int nbx, const 
 #pragma unroll
             for (int q = 0; q < RB_NL; ++q) {
                 const int ii = min(i + q, i1 - 1);
-                x[q] = e1[(long long)ii * ld_e1 + k];
+                x[q] = (k == a.one_col) ? 1.f : e1[(long long)ii * ld_e1 + k];
                 dsl[q] = apply_exp ? ds[ii] * s[ii] : ds[ii];
             }
 #pragma unroll
@@ -443,7 +449,7 @@ static int runs_bwd_launch(const float* e1, long long ld_e1, const float* Q, lon
                            hipStream_t st) {
     {
         ProfScope prof("runs_bwd_kernel", st, 4.0 * (2.0 * G * l + 2.0 * R.n_host * l + 2.0 * G), 1);
-        const RunsBwdArgs ba{ds, s, apply_exp, V, e1, ld_e1, R, l, d_e1, ld_de1, S};
+        const RunsBwdArgs ba{ds, s, apply_exp, V, e1, ld_e1, R, l, d_e1, ld_de1, S, -1};
         hipLaunchKernelGGL(runs_bwd_kernel, dim3(gx, (l + 255) / 256), dim3(256), 0, st, ba);
     }
     TXE_CHECK_LAUNCH();
@@ -543,10 +549,12 @@ int txe_runs_expand(const int* run_off, int U, int G, int* run_id, void* stream)
 //   the buffers).  V [U][l], T [U][Kp] are kept for backward.
 int txe_bilinear_folded_fwd(const float* Z, long long ld_z, int G, int Kp, const float* Wf, long long ld_wf, int l, const float* Q, long long ld_q,
                             int r, const int* run_off, const int* n_runs, int U, int first_row, const float* Wm, int apply_exp, float* V, float* T,
-                            float* s, int stages, void* stream) {
+                            float* s, int stages, int wf_by_k, int one_col, void* stream) {
+    // wf_by_k: 0 = Wf [l][Kp] (a GAT layer's packed weight rows), 1 = Wf [Kp][ld_wf] (a GCN layer's packing: row k, l columns -- row one_col
+    // holds the bias, and column one_col of Z counts as 1: hg = Z Wf + b without a bias pass)
     // stages: 1 = V and T (need the queries and the weights only: the encoder asks for T before its Z sweep), 2 = the scores (needs Z), 3 = both
     if (G < 0 || U < 0 || Kp < 1 || l < 1 || r < 1 || !Wf || !Q || !run_off || !Wm || !V || !T || (first_row && !n_runs) || !(stages & 3) ||
-        ((stages & 2) && (!Z || !s)))
+        ((stages & 2) && (!Z || !s)) || one_col >= Kp)
         return TXE_ERR_ARG;
     if (G == 0 || U == 0) return TXE_OK;
     hipStream_t st = (hipStream_t)stream;
@@ -560,15 +568,15 @@ int txe_bilinear_folded_fwd(const float* Z, long long ld_z, int G, int Kp, const
         const int rc = skinny_one("skinny_gemm_kernel[V]", a, 4.0 * (uh * (r + l) + (double)l * r), st);
         if (rc) return rc;
     }
-    if (stages & 1) {   // T [U][Kp] = V Wf
+    if (stages & 1) {   // T [U][Kp] = V Wf   (wf_by_k: V Wf^T)
         SkinnyArgs a;
-        skinny_runs_rows(a, V, (long long)l, false, Wf, ld_wf, true, T, (long long)Kp, Kp, l, Rc, G);
+        skinny_runs_rows(a, V, (long long)l, false, Wf, ld_wf, wf_by_k == 0, T, (long long)Kp, Kp, l, Rc, G);
         const int rc = skinny_one("skinny_gemm_kernel[T]", a, 4.0 * (uh * (l + Kp) + (double)l * Kp), st);
         if (rc) return rc;
     }
     if (stages & 2) {
         ProfScope prof("rowdot_runs_kernel", st, 4.0 * ((double)G * Kp + (double)U * Kp + G), 1);
-        hipLaunchKernelGGL(rowdot_runs_kernel, dim3(gx, 8), dim3(256), 0, st, Z, ld_z, (const float*)T, Rc, Kp, apply_exp, s);
+        hipLaunchKernelGGL(rowdot_runs_kernel, dim3(gx, 8), dim3(256), 0, st, Z, ld_z, (const float*)T, Rc, Kp, apply_exp, s, one_col);
     }
     TXE_CHECK_LAUNCH();
     return TXE_OK;
@@ -578,9 +586,11 @@ int txe_bilinear_folded_fwd(const float* Z, long long ld_z, int G, int Kp, const
 //   gradient: txe_gat_collapse_bwd_fused adds the attention rows' part),  dWm = dV^T Q.  dT [U][Kp], dV [U][l]: scratch.
 int txe_bilinear_folded_bwd(const float* Z, long long ld_z, int G, int Kp, const float* Wf, long long ld_wf, int l, const float* Q, long long ld_q,
                             int r, const int* run_off, const int* n_runs, int U, int first_row, int apply_exp, const float* V, const float* T,
-                            const float* s, const float* ds, float* dZ, long long ld_dz, float* dT, float* dV, float* dWm, float* dWf, void* stream) {
+                            const float* s, const float* ds, float* dZ, long long ld_dz, float* dT, float* dV, float* dWm, float* dWf, int wf_by_k,
+                            int one_col, void* stream) {
+    // wf_by_k / one_col as in txe_bilinear_folded_fwd; dWf then is [Kp][l] (row one_col = the bias gradient)
     if (G < 0 || U < 0 || Kp < 1 || l < 1 || r < 1 || !Z || !Wf || !Q || !run_off || !V || !T || !s || !ds || !dT || !dV || !dWm || !dWf ||
-        (first_row && !n_runs) || ld_wf != Kp)
+        (first_row && !n_runs) || (wf_by_k ? ld_wf < l : ld_wf != Kp) || one_col >= Kp)
         return TXE_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
     if (G == 0 || U == 0) {
@@ -592,7 +602,7 @@ int txe_bilinear_folded_bwd(const float* Z, long long ld_z, int G, int Kp, const
     const RunsRef Rc{run_off, n_runs, U, 0};
     const int gx = n_runs ? (G < 512 ? G : 512) : U;
     const double uh = (double)runs_hint(R, G);
-    const RunsBwdArgs ba{ds, s, apply_exp, T, Z, ld_z, Rc, Kp, dZ, ld_dz, dT};
+    const RunsBwdArgs ba{ds, s, apply_exp, T, Z, ld_z, Rc, Kp, dZ, ld_dz, dT, one_col};
     {
         ProfScope prof("runs_bwd_kernel", st, 4.0 * (2.0 * G * Kp + 2.0 * U * Kp + 2.0 * G), 1);
         hipLaunchKernelGGL(runs_bwd_kernel, dim3(gx, (Kp + 255) / 256), dim3(256), 0, st, ba);
@@ -601,8 +611,9 @@ int txe_bilinear_folded_bwd(const float* Z, long long ld_z, int G, int Kp, const
         SkinnyMulti m;
         memset(&m, 0, sizeof(m));
         m.n = 2;
-        skinny_runs_rows(m.j[0], dT, (long long)Kp, false, Wf, ld_wf, false, dV, (long long)l, l, Kp, Rc, G);
-        skinny_runs_sum(m.j[1], V, (long long)l, dT, (long long)Kp, false, dWf, (long long)Kp, l, Kp, Rc, G);
+        skinny_runs_rows(m.j[0], dT, (long long)Kp, false, Wf, ld_wf, wf_by_k != 0, dV, (long long)l, l, Kp, Rc, G);
+        if (wf_by_k) skinny_runs_sum(m.j[1], dT, (long long)Kp, V, (long long)l, false, dWf, (long long)l, Kp, l, Rc, G);     // dWf [Kp][l] = dT^T V
+        else skinny_runs_sum(m.j[1], V, (long long)l, dT, (long long)Kp, false, dWf, (long long)Kp, l, Kp, Rc, G);           // dWf [l][Kp] = V^T dT
         ProfScope prof("skinny_gemm_kernel[dV+dWf]", st, 4.0 * (2.0 * uh * Kp + 2.0 * l * Kp + 2.0 * uh * l), 1);
         const int rc = skinny_launch(m, st);
         if (rc) return rc;

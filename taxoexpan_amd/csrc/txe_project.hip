@@ -295,8 +295,9 @@ static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 // first store, the packed row leaves as 16-byte stores.  (One wave per row with a scalar column loop made the 2,080-column rows of
 // the output layer a 33-deep load -> store chain per wave.)
 constexpr int PREP_U = 2;
+// extra (or NULL): row F of Wp = extra[0 .. Kt) -- a folded GCN layer's bias rides as one more weight row (txe_gcn_layer_prepare)
 __device__ __forceinline__ void pack_w_job(const int bid, const int nb, const float* __restrict__ W, int F, int Fe, int Fp, int Kt, int Kp,
-                                           float* __restrict__ Wp) {
+                                           float* __restrict__ Wp, const float* __restrict__ extra = nullptr) {
     const unsigned qpr = (unsigned)Kp >> 2, total = (unsigned)Fp * qpr;          // (a weight matrix: far below 2^32 quads)
     const bool v2 = ((Kt & 1) == 0) && (((uintptr_t)W & 7) == 0);                // rows 8-byte aligned: float2 loads
     for (unsigned base = (unsigned)bid * blockDim.x * PREP_U; base < total; base += (unsigned)nb * blockDim.x * PREP_U) {
@@ -307,8 +308,9 @@ __device__ __forceinline__ void pack_w_job(const int bid, const int nb, const fl
             const unsigned i = base + u * blockDim.x + threadIdx.x;
             const unsigned f = i / qpr, k = (i - f * qpr) * 4;
             fi[u] = f; ki[u] = k;
-            const bool live = i < total && f < (unsigned)F;
-            const float* src = W + (long long)(live ? f : 0) * Kt;
+            const bool isx = extra != nullptr && i < total && f == (unsigned)F;
+            const bool live = (i < total && f < (unsigned)F) || isx;
+            const float* src = isx ? extra : W + (long long)(live ? f : 0) * Kt;
             if (live && k + 3 < (unsigned)Kt && v2) {
                 const float2 a = *reinterpret_cast<const float2*>(src + k), b = *reinterpret_cast<const float2*>(src + k + 2);
                 v[u][0] = a.x; v[u][1] = a.y; v[u][2] = b.x; v[u][3] = b.y;
@@ -462,6 +464,7 @@ struct PrepArgs {
     const float* h; long long ld_h; const int* pos; const float* P; int n_rows, Kh, Pd, Kp; float* X;
     const float *W, *attn_l, *attn_r; int H, D, F, Fe, Fp, Kt; float* Wp;
     int pk_rows, pk_ext, pk_prows, pk_cols, pk_pcols;       // packing job: W [pk_rows][pk_cols] -> Wp [pk_prows][pk_pcols], rows [pk_rows, pk_ext) left to fold
+    const float* pk_extra;                                  // ... or NULL / one more row (row pk_rows) to pack behind W
     long long n_words; unsigned long long seed; unsigned thr16; unsigned* mask;
     int x_dropped; float drop_scale;                        // build_x applies the dropout itself (the mask is still written:
     int x_mask;                                             //  by build_x too when x_mask, else by the mask job)
@@ -474,7 +477,7 @@ __device__ __forceinline__ void prepare_jobs(const PrepArgs& a, int b) {
         return;
     }
     b -= a.nb_f;
-    if (b < a.nb_w) { pack_w_job(b, a.nb_w, a.W, a.pk_rows, a.pk_ext, a.pk_prows, a.pk_cols, a.pk_pcols, a.Wp); return; }
+    if (b < a.nb_w) { pack_w_job(b, a.nb_w, a.W, a.pk_rows, a.pk_ext, a.pk_prows, a.pk_cols, a.pk_pcols, a.Wp, a.pk_extra); return; }
     b -= a.nb_w;
     if (b < a.nb_m) { dropout_mask_job(b, a.nb_m, a.n_words, a.seed, a.thr16, a.mask); return; }
     b -= a.nb_m;
@@ -520,7 +523,7 @@ struct DenseWs {
     size_t total;
 };
 
-static DenseWs plan_dense_ws(void* ws, int n, int Fp, int H2, int Kp, int Pd, int vocab, bool dx_stream = true) {
+static DenseWs plan_dense_ws(void* ws, int n, int Fp, int H2, int Kp, int Pd, int vocab, bool dx_stream = true, int min_splits = 0) {
     DenseWs p;
     char* b = (char*)ws;
     size_t off = 0;
@@ -534,11 +537,46 @@ static DenseWs plan_dense_ws(void* ws, int n, int Fp, int H2, int Kp, int Pd, in
     p.ppart = take((size_t)ppart_blocks * (vocab > 0 ? vocab : 1) * (Pd > 0 ? Pd : 1) * 4);
     p.dxpart = take((Pd > 0 && dx_stream) ? dxpos_part_bytes(n, Fp) : 0);
     p.splits = choose_splits(Fp, Kp, n);
-    p.part = take((size_t)p.splits * Fp * Kp * 4);
+    p.part = take((size_t)(p.splits > min_splits ? p.splits : min_splits) * Fp * Kp * 4);
     p.tail_bytes = gemm_tail_ws_bytes();
     p.tail = take(p.tail_bytes);
     p.total = off;
     return p;
+}
+
+// A GCNLayer's weight gradient dW [Kp][Fop] = X^T d_hw has its SHORT side first (Kp = 320 rows of 128-row tiles: 3 row panels, one of them
+// half empty, x 64-wide column tiles: 96 us for 5.7 GFLOP on the training batch, 0.38 of the MFMA roof).  Its transpose
+// dW^T [Fop][Kp] = d_hw^T X is the GAT layers' shape -- 128 x 160 tiles with LDS-direct operand copies (gemm_tn_lds_kernel) -- whenever Kp
+// splits into 160-column tiles without more padding than 64-column ones; the slice reduction writes it back transposed.
+// Returns the number of k-slices of that route, 0 = not eligible.
+static int gcn_dwt_splits(int n, int Kp, int Fop) {
+    if (n < 4096 || ((Kp + 159) / 160) * 160 > ((Kp + 63) / 64) * 64) return 0;
+    const int tiles = ((Fop + 127) / 128) * ((Kp + 159) / 160);
+    const int slots = 2 * device_cu_count();
+    int S = slots / tiles;
+    const int nkt = (n + GEMM_BK - 1) / GEMM_BK;
+    if (S > nkt / 8) S = nkt / 8;                                   // >= 8 k-tiles per slice
+    if (S > 64) S = 64;
+    return S >= 2 ? S : 0;
+}
+// out[k][f] = sum_s part[s][f][k]   (k < rows, f < cols; part slices [Fop][ldp])
+__global__ void reduce_splits_transposed_kernel(const float* __restrict__ part, int S, long long stride, int rows, int cols, int ldp,
+                                                float* __restrict__ out) {
+    __shared__ float tile[32][33];
+    const int f0 = blockIdx.x * 32, k0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;         // 256 threads: 8 rows of 32 per pass
+    for (int r = ty; r < 32; r += 8) {
+        const int f = f0 + r, k = k0 + tx;
+        float acc = 0.f;
+        if (f < cols && k < rows)
+            for (int s = 0; s < S; ++s) acc += part[(long long)s * stride + (long long)f * ldp + k];
+        tile[r][tx] = acc;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int k = k0 + r, f = f0 + tx;
+        if (k < rows && f < cols) out[(long long)k * cols + f] = tile[tx][r];
+    }
 }
 
 }  // namespace txe
@@ -678,8 +716,11 @@ int txe_gat_layers_prepare(const struct txe_gat_prepare_desc* descs, int n_layer
 // W [Kh+Pd][Fo] -> Wp [roundup(roundup(Kh+Pd,32),128)][roundup(Fo,32)]; mask may be NULL when drop_p == 0.
 int txe_gcn_layer_prepare(const float* h, long long ld_h, int n_nodes, int Kh, const int* pos, const float* P, int Pd, float* X,
                           const float* W, int Fo, float* Wp, float drop_p, unsigned long long seed, unsigned* mask, int x_dropped,
-                          void* stream) {
+                          const float* bias_row, void* stream) {
+    // bias_row (or NULL): packed as row Kh + Pd of Wp (needs a padding row: (Kh + Pd) % 32 != 0) -- the folded output layer then carries
+    // its bias as the weight row of a column of Z that counts as 1 (txe_bilinear_folded_*: one_col)
     if (n_nodes < 0 || Kh < 1 || Pd < 0 || !X || (Pd > 0 && (!pos || !P)) || !W || !Wp || Fo < 1) return TXE_ERR_ARG;
+    if (bias_row && ((Kh + Pd) % 32) == 0) return TXE_ERR_ARG;
     if (drop_p < 0.f || drop_p >= 1.f || (drop_p > 0.f && !mask)) return TXE_ERR_ARG;
     const int T = 64 * FOLD_DG;
     PrepArgs a;
@@ -698,7 +739,7 @@ int txe_gcn_layer_prepare(const float* h, long long ld_h, int n_nodes, int Kh, c
     a.nb_w = blocks(((long long)a.pk_prows * a.pk_pcols / 4 + PREP_U - 1) / PREP_U, 512);
     a.nb_f = 0; a.fold_bx = 1;
     a.h = h; a.ld_h = ld_h; a.pos = pos; a.P = P; a.n_rows = n_nodes; a.Kh = Kh; a.Pd = Pd; a.X = X;
-    a.W = W; a.Wp = Wp;
+    a.W = W; a.Wp = Wp; a.pk_extra = bias_row;
     hipLaunchKernelGGL(gat_prepare_kernel, dim3(a.nb_x + a.nb_m + a.nb_w), dim3(T), 0, (hipStream_t)stream, a);
     TXE_CHECK_LAUNCH();
     return TXE_OK;
@@ -876,7 +917,8 @@ int txe_gcn_pack_weights(const float* W, int Kt, int Fo, float* Wp, void* stream
 }
 
 size_t txe_gcn_dense_ws_bytes(int n_nodes, int Kh, int Pd, int Fo, int vocab) {
-    return plan_dense_ws(nullptr, n_nodes, round_up(Kh + Pd, 32), 0, round_up(Fo, 32), Pd, vocab, false).total;
+    const int Kp = round_up(Kh + Pd, 32), Fop = round_up(Fo, 32);
+    return plan_dense_ws(nullptr, n_nodes, Kp, 0, Fop, Pd, vocab, false, gcn_dwt_splits(n_nodes, Kp, Fop)).total;
 }
 
 int txe_gcn_dense_fwd(const float* X, int n_nodes, int Kh, int Pd, const float* Wp, int Fo, float drop_p, const unsigned* mask,
@@ -916,7 +958,8 @@ int txe_gcn_dense_bwd(const float* X, int n_nodes, int Kh, int Pd, const int* po
     if (Pd > 0 && (!pos || !dP || vocab < 1 || vocab > MAX_VOCAB)) return TXE_ERR_ARG;
     if (drop_p < 0.f || drop_p >= 1.f) return TXE_ERR_ARG;
     const int Kt = Kh + Pd, Kp = round_up(Kt, 32), Fop = round_up(Fo, 32);
-    DenseWs p = plan_dense_ws(ws, n_nodes, Kp, 0, Fop, Pd, vocab, false);   // part: [S][Kp][Fop]
+    const int St = gcn_dwt_splits(n_nodes, Kp, Fop);
+    DenseWs p = plan_dense_ws(ws, n_nodes, Kp, 0, Fop, Pd, vocab, false, St);   // part: [S][Kp][Fop] (or transposed: [St][Fop][Kp])
     if (ws_bytes < p.total) return TXE_ERR_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
     int rc;
@@ -943,7 +986,20 @@ int txe_gcn_dense_bwd(const float* X, int n_nodes, int Kh, int Pd, const int* po
                            n_nodes > 0 ? p.seg_blocks : 0, vocab, Pd, dP);
         TXE_CHECK_LAUNCH();
     }
-    {   // dWp[k][f] = sum_m dropout(X)[m][k] * d_hw[m][f]
+    if (St > 0 && (x_dropped || !mask || drop_p <= 0.f)) {
+        // dW^T [Fop][Kp] = d_hw^T X on 128 x 160 tiles (gcn_dwt_splits), written back transposed by the slice reduction
+        VMat A = vmat_plain(d_hw, Fop, n_nodes, Fop);
+        VMat B = vmat_plain(X, Kp, n_nodes, Kp);
+        Epi E = epi_plain(p.part, Kp, Kp);
+        E.split_stride = (long long)Fop * Kp;
+        E.alg_flops = 2.0 * Kt * (double)Fo * n_nodes;
+        E.route |= GEMM_ROUTE_FORCE_BN160;
+        rc = gemm_tn(A, B, E, Fop, Kp, n_nodes, St, s);
+        if (rc) return rc;
+        hipLaunchKernelGGL(reduce_splits_transposed_kernel, dim3((Fo + 31) / 32, (Kt + 31) / 32), dim3(256), 0, s, (const float*)p.part, St,
+                           E.split_stride, Kt, Fo, Kp, dW);
+        TXE_CHECK_LAUNCH();
+    } else {   // dWp[k][f] = sum_m dropout(X)[m][k] * d_hw[m][f]
         VMat A = vmat_plain(X, Kp, n_nodes, Kp);
         if (!x_dropped) vmat_set_mask(A, mask, drop_p);             // (x_dropped: X already holds dropout(X), txe_gcn_layer_prepare)
         VMat B = vmat_plain(d_hw, Fop, n_nodes, Fop);
@@ -2628,7 +2684,7 @@ int txe_gcn_collapse_fwd(const int* rowptr_out, const int* col_dst, const int* g
                          const float* pw, float* coef, float* wsum, int* gid, float* Z, float* hg, long long ld_hg, void* ws,
                          size_t ws_bytes, void* stream) {
     if (n_nodes < 0 || G < 0 || Kh < 1 || Pd < 0 || Fo < 1 || !rowptr_out || !graph_off || !X || !Wp || !norm || !coef || !wsum || !gid || !Z ||
-        !hg || !ws || (pw && !pos))
+        !ws || (pw && !pos))
         return TXE_ERR_ARG;
     if (drop_p < 0.f || drop_p >= 1.f) return TXE_ERR_ARG;
     const int Kt = Kh + Pd, Kp = round_up(Kt, 32), Fop = round_up(Fo, 32);
@@ -2645,6 +2701,7 @@ int txe_gcn_collapse_fwd(const int* rowptr_out, const int* col_dst, const int* g
     hipLaunchKernelGGL(cl_wsum_kernel, dim3((G + 3) / 4), dim3(256), 0, s, graph_off, G, pos, pw, wsum, gid);
     const int rc_z = cl_zsum_launch(graph_off, G, n_nodes, X, Kp, mk, dummy_mask, mask_ld, fs, (const float*)coef, (const float*)wsum, Z, s);
     if (rc_z) return rc_z;
+    if (!hg) return TXE_OK;          // (the caller folds hg = Z W + b into what consumes it: txe_bilinear_folded_*, wf_by_k)
     VMat A = vmat_plain(Z, Kp, G, Kp);
     VMat B = vmat_plain(Wp, Fop, Kp, Fop);
     Epi E = epi_plain(hg, ld_hg, Fo);
@@ -2664,11 +2721,14 @@ int txe_gcn_collapse_fwd(const int* rowptr_out, const int* col_dst, const int* g
 int txe_gcn_collapse_bwd(const int* rowptr_in, const int* col_src, const int* graph_off, int n_nodes, int G, const float* X, int Kh, int Pd,
                          const int* pos, int vocab, const float* Wp, int Fo, float drop_p, const unsigned* mask, const float* norm,
                          const float* pw, const float* coef, const float* wsum, const int* gid, const float* Z, const float* d_hg,
-                         long long ld_dhg, int act_on, float act_slope, float* d_X, float* dW, float* d_b, float* dP, float* d_pw, void* ws,
-                         size_t ws_bytes, void* stream) {
+                         long long ld_dhg, int act_on, float act_slope, float* d_X, float* dW, float* d_b, float* dP, float* d_pw, int dz_given,
+                         void* ws, size_t ws_bytes, void* stream) {
+    // dz_given: `d_hg` IS dZ [G][Kp] (ld_dhg == Kp) -- whoever consumed Z folded hg = Z W + b into its own products (txe_bilinear_folded_*,
+    // wf_by_k) and formed dW / d_b itself: no product here, dW / d_b are not written
     if (n_nodes < 0 || G < 0 || Kh < 1 || Pd < 0 || Fo < 1 || !rowptr_in || !graph_off || !X || !Wp || !norm || !coef || !wsum || !gid || !Z ||
-        !d_hg || !d_X || !dW || !ws)
+        !d_hg || !d_X || (!dW && !dz_given) || !ws)
         return TXE_ERR_ARG;
+    if (dz_given && ld_dhg != round_up(Kh + Pd, 32)) return TXE_ERR_ARG;
     if ((Pd > 0 || pw) && (!pos || vocab < 1 || vocab > MAX_VOCAB)) return TXE_ERR_ARG;
     if ((Pd > 0 && !dP) || (pw && !d_pw)) return TXE_ERR_ARG;
     if (drop_p < 0.f || drop_p >= 1.f) return TXE_ERR_ARG;
@@ -2681,7 +2741,8 @@ int txe_gcn_collapse_bwd(const int* rowptr_in, const int* col_src, const int* gr
     const int mask_ld = (Kt + 31) / 32;
     const float fs = mk ? 1.f / (1.f - drop_p) : 1.f;
     int rc;
-    {   // dZ[g][k] = sum_f d_hg[g][f] Wp[k][f]
+    if (dz_given) p.dZ = const_cast<float*>(d_hg);
+    if (!dz_given) {   // dZ[g][k] = sum_f d_hg[g][f] Wp[k][f]
         VMat A = vmat_plain(d_hg, ld_dhg, G, Fo);
         VMat B = vmat_plain(Wp, Fop, round_up(Kp, 128), Fop);
         Epi E = epi_plain(p.dZ, Kp, Kp);
@@ -2689,7 +2750,7 @@ int txe_gcn_collapse_bwd(const int* rowptr_in, const int* col_src, const int* gr
         rc = gemm_nt(A, B, E, G, Kp, Fo, 1, s, p.tail, p.tail_bytes);
         if (rc) return rc;
     }
-    {   // dW[k][f] = sum_g Z[g][k] d_hg[g][f]
+    if (!dz_given) {   // dW[k][f] = sum_g Z[g][k] d_hg[g][f]
         VMat A = vmat_plain(Z, Kp, G, Kp);
         VMat B = vmat_plain(d_hg, ld_dhg, G, Fo);
         Epi E = epi_plain(p.part, Fop, Fo);
@@ -2702,7 +2763,7 @@ int txe_gcn_collapse_bwd(const int* rowptr_in, const int* col_src, const int* gr
                            (const float*)p.part, G > 0 ? p.splits : 0, E.split_stride, Kt, Fo, Fop, dW);
         TXE_CHECK_LAUNCH();
     }
-    if (d_b) {
+    if (d_b && !dz_given) {
         rc = colsum_launch(d_hg, ld_dhg, G, Fo, p.cpart, d_b, s);
         if (rc) return rc;
     }

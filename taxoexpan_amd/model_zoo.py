@@ -185,6 +185,8 @@ class DeferredNodeOutput:
     def _can_fold(self):
         """may the stack stop at Z (the graph vector folded into the bilinear matcher)?"""
         csr, cfg = self._args[:2]
+        if self._fn is ops.GCNStackFunction:
+            return ops.gcn_folded_graph_vector_ok(csr, cfg, self._args[4])
         return self._fn is ops.GATStackFunction and ops.folded_graph_vector_ok(csr, cfg)
 
     def tensor(self):
@@ -290,8 +292,8 @@ class DeferredGraphVector:
             return self._tensor.detach()
         if self._z is None and not self.can_fold():
             return self.tensor().detach()
-        Z, Wp, _link = self._run_z()
-        return ops.folded_graph_linear(Z.detach(), Wp, self._d)
+        Z, Wp, link = self._run_z()
+        return ops.folded_graph_linear(Z.detach(), Wp, self._d, link)
 
     def __getattr__(self, name):
         if name.startswith("_"):

@@ -536,10 +536,13 @@ class FoldLink:
     """What the producer of Z (GATStackFunction, cfg.final == 'collapse_z') shares with whoever consumes Z as the folded graph vector
     hg = Z W^T: the consumer's backward leaves the main part of the output layer's weight gradient here (S slices [D, Kp], summed in
     order) and hands dZ back through autograd; the producer's backward adds the attention rows' part and returns the whole dW."""
-    __slots__ = ("part", "S", "fwd", "e_part", "m")
+    __slots__ = ("part", "S", "fwd", "e_part", "m", "by_k", "one_col")
 
     def __init__(self):
         self.part, self.S = None, 0
+        # the producer's weight packing: a GAT layer's Wp [Fp][Kp] (rows < D the weight) or -- by_k -- a GCN layer's Wp [Kp128][Fop] (row k, D
+        # columns; row one_col holds the bias and column one_col of Z counts as 1).  by_k: `part` comes back as [Kp][D], row one_col = d_bias
+        self.by_k, self.one_col = False, -1
         # with a matcher job (folded_match_job) the producer forms T before its Z sweep, the sweep leaves <T[run(g)], keep X[u]> per node
         # (e_part) and backward's <dZ, X> sweep becomes a scaling by the matcher's score gradient (m = (ds, s, apply_exp)):
         self.fwd, self.e_part, self.m = None, None, None
@@ -820,7 +823,8 @@ class GCNStackFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, csr, cfg, h, pos, rpos, pw, *params):
-        collapse = (getattr(cfg, "final", None) == "collapse")
+        z_only = (getattr(cfg, "final", None) == "collapse_z")   # 'collapse' that stops at Z: returns (Z [G, Kp], the output layer's packed weights)
+        collapse = (getattr(cfg, "final", None) == "collapse") or z_only
         L = cfg.n_layers
         need = getattr(cfg, "grad_enabled", True) and any(ctx.needs_input_grad)     # (see apply_stack)
         table = _use_table(h, need, cfg.drop_ps[0]) and not (collapse and L == 1)
@@ -864,20 +868,29 @@ class GCNStackFunction(torch.autograd.Function):
                                if cfg.drop_ps[l] > 0.0 else None)
                     # (a first layer on raw features that is not the folded one: only its GEMMs read X -> stored with the dropout applied)
                     st.x_dropped = bool(l == 0 and not (last and collapse) and cfg.drop_ps[l] > 0.0)
+                    # (folded into the matcher: the bias rides as one more weight row, behind a column of Z that counts as 1)
+                    bias_row = st.b if (last and z_only and st.b is not None) else None
                     call("txe_gcn_layer_prepare", ptr(h if l == 0 else None), ld_h if l == 0 else 0, N, st.Kh,
                          ptr(pos if st.P is not None else None), ptr(st.P), st.Pd, ptr(st.X), ptr(st.W), st.Fo, ptr(st.Wp),
-                         cfg.drop_ps[l], st.seed, ptr(st.mask), int(st.x_dropped), st_)
+                         cfg.drop_ps[l], st.seed, ptr(st.mask), int(st.x_dropped), ptr(bias_row), st_)
                 if last and collapse:
                     G = csr.n_graphs
                     coef, wsum = _empty((max(N, 1),), h), _empty((max(G, 1),), h)
                     gid = torch.empty(max(N, 1), dtype=torch.int32, device=h.device)
-                    Z, out = _empty((max(G, 1), st.Kp), h), _empty((G, st.Fo), h)
+                    Z, out = _empty((max(G, 1), st.Kp), h), (None if z_only else _empty((G, st.Fo), h))
                     wsb = call("txe_gcn_collapse_ws_bytes", N, G, st.Kh, st.Pd, st.Fo, 8)
                     ws = _ws(wsb, h)
                     call("txe_gcn_collapse_fwd", ptr(csr.rowptr_out), ptr(csr.col_dst), ptr(csr.graph_off), N, G, ptr(st.X), st.Kh, st.Pd,
                          ptr(st.Wp), st.Fo, ptr(st.b), cfg.drop_ps[l], ptr(st.mask), ptr(norm), ptr(rpos), ptr(pwf), ptr(coef), ptr(wsum),
                          ptr(gid), ptr(Z), ptr(out), st.Fo, ptr(ws), wsb, st_)
                     st.cl = (coef, wsum, gid, Z)
+                    if z_only:
+                        link = getattr(cfg, "link", None)
+                        if link is not None:
+                            link.by_k, link.one_col = True, (st.Kh + st.Pd if st.b is not None else -1)
+                        out = (Z, st.Wp)
+                        ctx.mark_non_differentiable(st.Wp)
+                        ctx.set_materialize_grads(False)
                     if not need:
                         st.cl = st.mask = st.Wp = st.X = None
                     break
@@ -905,24 +918,29 @@ class GCNStackFunction(torch.autograd.Function):
                     if l > 0:
                         st.X = None
         ctx.csr, ctx.cfg, ctx.pos, ctx.norm = csr, cfg, pos, norm
-        note_route("stack", "collapse" if collapse else "layers")
+        ctx.link = getattr(cfg, "link", None) if z_only else None
+        note_route("stack", "collapse_z" if z_only else ("collapse" if collapse else "layers"))
         if _CAPTURE is not None:
             _CAPTURE.append((csr, cfg, states))
         ctx.states = states if need else None
         ctx.h_req = ctx.needs_input_grad[2]
-        ctx.out = out if need else None
+        ctx.out = out if (need and not z_only) else None
         ctx.rpos, ctx.pwf, ctx.pw_shape = rpos, pwf, (pw.shape if pwf is not None else None)
         return out
 
     @staticmethod
-    def backward(ctx, d_out):
+    def backward(ctx, d_out, *_unused):
         csr, cfg, pos, norm, states = ctx.csr, ctx.cfg, ctx.pos, ctx.norm, ctx.states
         if states is None:
             raise RuntimeError(_BACKWARD_TWICE)
         L = cfg.n_layers
+        z_only = (getattr(cfg, "final", None) == "collapse_z")
+        if d_out is None:                          # (collapse_z does not materialise absent gradients: Z took no part in the loss)
+            ctx.states = None
+            return (None,) * (6 + 3 * L)
         d_out = _f32(d_out)
         grads = [None] * (3 * L)
-        collapse = (getattr(cfg, "final", None) == "collapse")
+        collapse = (getattr(cfg, "final", None) == "collapse") or z_only
         d_pw = None
         with _lib.on_device(d_out.device):
             st_ = _lib.stream_ptr()
@@ -944,8 +962,15 @@ class GCNStackFunction(torch.autograd.Function):
                     dh, ld = _rows(d_out)
                     act_on = l > 0 and cfg.act_slopes[l - 1] is not None
                     d_X = _empty((N, st.Kp), d_out)
-                    dW = torch.empty_like(st.W)
-                    d_b = torch.empty_like(st.b) if st.b is not None else None
+                    if z_only:                     # d_out IS dZ; the consumer of Z left dW (and d_b as row Kt) in the FoldLink, [Kp][Fo]
+                        part = ctx.link.part if ctx.link is not None else None
+                        if part is None or ctx.link.S != 1 or tuple(part.shape) != (st.Kp, st.Fo):
+                            raise RuntimeError("folded GCN output layer: the consumer of Z left no weight gradient in the FoldLink")
+                        Kt = st.Kh + st.Pd
+                        dW, d_b = part[:Kt], (part[Kt] if st.b is not None else None)
+                    else:
+                        dW = torch.empty_like(st.W)
+                        d_b = torch.empty_like(st.b) if st.b is not None else None
                     dP = torch.empty_like(st.P) if st.P is not None else None
                     d_pw = torch.empty_like(ctx.pwf) if ctx.pwf is not None else None
                     v = max(cfg.vocab, ctx.pwf.numel() if ctx.pwf is not None else 0)
@@ -954,7 +979,8 @@ class GCNStackFunction(torch.autograd.Function):
                     call("txe_gcn_collapse_bwd", ptr(csr.rowptr_in), ptr(csr.col_src), ptr(csr.graph_off), N, G, ptr(st.X), st.Kh, st.Pd,
                          ptr(pos if st.P is not None else ctx.rpos), v, ptr(st.Wp), st.Fo, cfg.drop_ps[l], ptr(st.mask), ptr(norm),
                          ptr(ctx.pwf), ptr(coef), ptr(wsum), ptr(gid), ptr(Z), ptr(dh), ld, int(act_on),
-                         (cfg.act_slopes[l - 1] if act_on else 1.0), ptr(d_X), ptr(dW), ptr(d_b), ptr(dP), ptr(d_pw), ptr(ws), wsb, st_)
+                         (cfg.act_slopes[l - 1] if act_on else 1.0), ptr(d_X), None if z_only else ptr(dW), None if z_only else ptr(d_b),
+                         ptr(dP), ptr(d_pw), int(z_only), ptr(ws), wsb, st_)
                     grads[3 * l:3 * l + 3] = [dW, d_b, dP]
                     if l > 0:
                         d_pre, ld_dpre = d_X, st.Kp
@@ -1328,6 +1354,15 @@ class BilinearStackedRunsFunction(torch.autograd.Function):
         return d_e1, None, dW.reshape(wshape), None
 
 
+def gcn_folded_graph_vector_ok(csr, cfg, params):
+    """may a GCN stack hand out Z instead of hg (cfg.final = 'collapse_z')?  The output layer's bias then rides as one more weight row
+    behind a column of Z that counts as 1: its input width must leave a padding column ((Kin) % 32 != 0)."""
+    if _NO_MATCH_FOLD or csr.n_edges <= 0 or csr.n_graphs <= 0 or csr.n_nodes <= 0:
+        return False
+    W, b = params[-3], params[-2]
+    return b is None or (W.shape[0] % 32) != 0
+
+
 def folded_graph_vector_ok(csr, cfg):
     """may a GAT stack hand out Z instead of hg (cfg.final = 'collapse_z')?  Needs the fused backward of the folded layer (the only one
     that takes dZ): at least two layers, the shapes txe_gat_fused_bwd_supported covers, edges, and the default routes."""
@@ -1337,14 +1372,19 @@ def folded_graph_vector_ok(csr, cfg):
     return call("txe_gat_fused_bwd_supported", kh, cfg.pos_dims[-1], cfg.heads[-2], cfg.out_dims[-2]) == 1
 
 
-def folded_graph_linear(Z, Wp, D):
-    """hg [G, D] = Z [G, Kp] Wp[:D]^T, outside autograd (DeferredGraphVector.detach)"""
+def folded_graph_linear(Z, Wp, D, link=None):
+    """hg [G, D] = Z [G, Kp] Wp[:D]^T (link.by_k: Z Wp[:, :D] + bias), outside autograd (DeferredGraphVector.detach)"""
     _need_cuda(Z, Wp)
     G, Kp = Z.shape
     hg = _empty((G, D), Z)
     with _lib.on_device(Z.device):
         tws = _tail_ws(Z)
-        call("txe_gemm_plain", 0, ptr(Z), Kp, ptr(Wp), Kp, ptr(hg), D, G, D, Kp, 1, 0, ptr(tws), tws.numel(), _lib.stream_ptr())
+        if link is not None and link.by_k:          # a GCN layer's packing: hg = Z Wp[:Kp, :D] + bias (row one_col; Z's column there is 0)
+            call("txe_gemm_plain", 1, ptr(Z), Kp, ptr(Wp), Wp.stride(0), ptr(hg), D, G, D, Kp, 1, 0, ptr(tws), tws.numel(), _lib.stream_ptr())
+            if link.one_col >= 0:
+                hg += Wp[link.one_col, :D]
+        else:
+            call("txe_gemm_plain", 0, ptr(Z), Kp, ptr(Wp), Kp, ptr(hg), D, G, D, Kp, 1, 0, ptr(tws), tws.numel(), _lib.stream_ptr())
     return hg
 
 
@@ -1357,7 +1397,7 @@ class FoldedGraphLinearFunction(torch.autograd.Function):
     def forward(ctx, Z, Wp, link, D):
         _need_cuda(Z, Wp)
         G, Kp = Z.shape
-        hg = folded_graph_linear(Z, Wp, D)
+        hg = folded_graph_linear(Z, Wp, D, link)
         note_route("fold", "materialised")
         ctx.misc = (Z, Wp, link, D)
         return hg
@@ -1368,6 +1408,16 @@ class FoldedGraphLinearFunction(torch.autograd.Function):
         G, Kp = Z.shape
         d_hg, ld = _rows(_f32(d_hg))
         dZ = _empty((G, Kp), Z)
+        if link.by_k:                               # dZ = d_hg Wp[:, :D]^T;  part [Kp][D] = Z^T d_hg, row one_col = d_bias = column sums of d_hg
+            part = _empty((Kp, D), Z)
+            with _lib.on_device(Z.device):
+                tws = _tail_ws(Z)
+                call("txe_gemm_plain", 0, ptr(d_hg), ld, ptr(Wp), Wp.stride(0), ptr(dZ), Kp, G, Kp, D, 1, 0, ptr(tws), tws.numel(), _lib.stream_ptr())
+                call("txe_gemm_plain", 2, ptr(Z), Kp, ptr(d_hg), ld, ptr(part), D, Kp, D, G, 1, 0, None, 0, _lib.stream_ptr())
+            if link.one_col >= 0:
+                part[link.one_col] = d_hg.sum(0)
+            link.part, link.S = part, 1
+            return dZ, None, None, None
         S = max(1, min(8, G // 512))
         part = _empty((S * D, Kp), Z)
         with _lib.on_device(Z.device):
@@ -1400,7 +1450,7 @@ def folded_match_job(e2, rows, run_off, Wm):
                 G = None
             V, T = _empty((max(U, 1), l), Wp), _empty((max(U, 1), Kp), Wp)
             call("txe_bilinear_folded_fwd", None, Kp, G if G is not None else 1, Kp, ptr(Wp), Kp, l, ptr(Q), ldq, r, ptr(roff), ptr(n_runs), U, first_row,
-                 ptr(Wmf), 0, ptr(V), ptr(T), None, 1, _lib.stream_ptr())
+                 ptr(Wmf), 0, ptr(V), ptr(T), None, 1, 0, -1, _lib.stream_ptr())
         fw = dict(e2=e2, rows=rows, run_off_in=run_off, Wm=Wm, Wm_version=Wm._version, Wp=Wp, Q=Q, ldq=ldq, roff=roff, n_runs=n_runs, U=U,
                   first_row=first_row, V=V, T=T, run_id=(run_id if rows is None else None))
         return fw
@@ -1454,8 +1504,8 @@ class BilinearFoldedRunsFunction(torch.autograd.Function):
                 call("txe_gat_collapse_fold_scores", ptr(goff), n_, g_, kh_, pd_, ptr(coef_), ptr(wsum_), ptr(link.e_part), fp_, masked_, int(apply_exp),
                      ptr(s), _lib.stream_ptr())
             else:
-                call("txe_bilinear_folded_fwd", ptr(Z), Kp, G, Kp, ptr(Wp), Kp, l, ptr(Q), ldq, r, ptr(run_off), ptr(n_runs), U, first_row, ptr(Wmf),
-                     int(apply_exp), ptr(V), ptr(T), ptr(s), 2 if ready else 3, _lib.stream_ptr())
+                call("txe_bilinear_folded_fwd", ptr(Z), Kp, G, Kp, ptr(Wp), Wp.stride(0), l, ptr(Q), ldq, r, ptr(run_off), ptr(n_runs), U, first_row,
+                     ptr(Wmf), int(apply_exp), ptr(V), ptr(T), ptr(s), 2 if ready else 3, int(link.by_k), int(link.one_col), _lib.stream_ptr())
         ctx.misc = (Z, Wp, link, Wmf, Q, ldq, run_off, n_runs, U, first_row, V, T, s, int(apply_exp), Wm.shape)
         return s.unsqueeze(1)
 
@@ -1468,10 +1518,11 @@ class BilinearFoldedRunsFunction(torch.autograd.Function):
         edot = link.e_part is not None              # the stack reads "dZ[g]" as dsl_g T[run(g)] (FoldLink): no dZ tensor exists
         dZ = None if edot else _empty((G, Kp), Z)
         dT, dV = _empty((max(U, 1), Kp), Z), _empty((max(U, 1), l), Z)
-        dWm, dWf = _empty((l, r), Z), _empty((l, Kp), Z)
+        dWm, dWf = _empty((l, r), Z), (_empty((Kp, l), Z) if link.by_k else _empty((l, Kp), Z))
         with _lib.on_device(Z.device):
-            call("txe_bilinear_folded_bwd", ptr(Z), Kp, G, Kp, ptr(Wp), Kp, l, ptr(Q), ldq, r, ptr(run_off), ptr(n_runs), U, first_row, apply_exp,
-                 ptr(V), ptr(T), ptr(s), ptr(ds), ptr(dZ), Kp, ptr(dT), ptr(dV), ptr(dWm), ptr(dWf), _lib.stream_ptr())
+            call("txe_bilinear_folded_bwd", ptr(Z), Kp, G, Kp, ptr(Wp), Wp.stride(0), l, ptr(Q), ldq, r, ptr(run_off), ptr(n_runs), U, first_row, apply_exp,
+                 ptr(V), ptr(T), ptr(s), ptr(ds), ptr(dZ), Kp, ptr(dT), ptr(dV), ptr(dWm), ptr(dWf), int(link.by_k), int(link.one_col),
+                 _lib.stream_ptr())
         link.part, link.S = dWf, 1
         link.m = (ds, s, apply_exp) if link.e_part is not None else None
         return dZ, None, None, None, dWm.reshape(wshape), None, None, None, None

@@ -106,14 +106,14 @@ def _expected_routes(prop, form):
     'fused+edot' -- and a test that silently ran anything else is a test of something else"""
     from taxoexpan_amd import model_zoo as mz, ops
     runs_ok = form == "rows" or not ops._NO_QUERY_RUNS
-    fold = prop == "PGAT" and runs_ok and not (ops._NO_MATCH_FOLD or ops._NO_FUSED_BWD or mz._NO_FOLD)
-    edot = fold and not ops._NO_FOLD_EDOT and form != "hook"
+    fold = runs_ok and not (ops._NO_MATCH_FOLD or mz._NO_FOLD) and (prop != "PGAT" or not ops._NO_FUSED_BWD)
+    edot = fold and prop == "PGAT" and not ops._NO_FOLD_EDOT and form != "hook"
     match = "folded" if fold else (("runs" if form == "rows" else "stacked") if runs_ok else "pair")
     if mz._NO_FOLD:
         stack = "mean" if prop == "PGAT" else "layers"
     else:
         stack = ("collapse_z" + ("+edot" if edot else "")) if fold else "collapse"
-    fold_kind = ("edot" if edot else ("inline" if form == "hook" else "job")) if fold else None
+    fold_kind = ("edot" if edot else ("inline" if (form == "hook" or prop != "PGAT") else "job")) if fold else None
     bwd = "fused+edot" if edot else (("collapse" if not mz._NO_FOLD else "layers") if prop == "PGAT" else None)
     return dict(match=match, stack=stack, fold=fold_kind, stack_bwd=bwd)
 
@@ -133,7 +133,7 @@ def _graph_vectors_from_capture(prop, states, model, D):
 
 
 @pytest.mark.parametrize("workload,form", [("pgat", "stacked"), ("pgat", "rows"), ("pgat", "hook"), ("pgcn", "stacked"), ("pgat2", "stacked"),
-                                           ("semeval", "stacked"), ("semeval", "rows")])
+                                           ("semeval", "stacked"), ("semeval", "rows"), ("pgcn", "rows"), ("pgcn", "hook")])
 def test_full_size_training_step_matches_oracle(workload, form, monkeypatch):
     """form: how the queries arrive / who else looks at the graph vector --
       'stacked': the reference collate's [G, r] matrix (data_loaders.py:9-28), nothing else touches the step: THE ROUTE bench.py TIMES;

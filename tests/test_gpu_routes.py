@@ -66,21 +66,24 @@ def _expected(c, n_nodes):
         runs = "stacked"
     else:
         runs = None
-    foldable = (lazy and gat and c["hook"] != "touch" and not (ops._NO_MATCH_FOLD or ops._NO_FUSED_BWD) and
-                _lib.call("txe_gat_fused_bwd_supported", H[-2] * c["hidden"], pd, H[-2], c["hidden"]) == 1)
+    if gat:
+        foldable = (lazy and c["hook"] != "touch" and not (ops._NO_MATCH_FOLD or ops._NO_FUSED_BWD) and
+                    _lib.call("txe_gat_fused_bwd_supported", H[-2] * c["hidden"], pd, H[-2], c["hidden"]) == 1)
+    else:       # a GCN stack folds when its output layer's input width leaves a padding column for the bias row (hidden + pd never a multiple of 32 here)
+        foldable = lazy and c["hook"] != "touch" and not ops._NO_MATCH_FOLD and (c["hidden"] + pd) % 32 != 0
     folded = bool(runs and c["grad"] and foldable)
     match = "folded" if folded else (runs or "pair")
-    edot = (folded and c["hook"] != "detach" and not ops._NO_FOLD_EDOT and
+    edot = (folded and gat and c["hook"] != "detach" and not ops._NO_FOLD_EDOT and
             _lib.call("txe_gat_collapse_e_tiles", n_nodes, c["G"], H[-2] * c["hidden"], pd) > 0)
-    if folded:
-        stack, fold = "collapse_z" + ("+edot" if edot else ""), ("edot" if edot else ("inline" if c["hook"] == "detach" else "job"))
+    if folded:          # (a GCN stack has no sweep for the matcher's job to ride in: always the in-line kernels)
+        stack, fold = "collapse_z" + ("+edot" if edot else ""), ("edot" if edot else ("inline" if (c["hook"] == "detach" or not gat) else "job"))
     elif deferred_nodes:
         stack, fold = "collapse", None
     else:
         stack, fold = ("mean" if gat else "layers"), None
     # (a detach() on a foldable vector runs the stack as 'collapse_z' even when the matcher then takes another form: hg = Z W^T is
     #  materialised as an autograd node afterwards)
-    if not folded and lazy and gat and c["hook"] == "detach" and foldable:
+    if not folded and lazy and c["hook"] == "detach" and foldable:
         stack, fold = "collapse_z", "materialised"
     if not c["grad"]:
         bwd = None

@@ -7,7 +7,9 @@ import csv
 import glob
 import sys
 
-f = (sys.argv[1:] or sorted(glob.glob("gpurun_out/tl/**/*kernel_trace.csv", recursive=True)))[-1]
+import os
+f = sorted(glob.glob("gpurun_out/tl/**/*kernel_trace.csv", recursive=True))[-1]
+FIRST = tuple((os.environ.get("TXE_TL_FIRST") or "gat_prepare_multi,gat_prepare_kernel").split(","))   # the step's first launch (pgcn: gcn_norm)
 rows = [dict(name=r["Kernel_Name"].replace("void ", "").replace("txe::", "").split("(")[0][:60], q=r["Queue_Id"], s=int(r["Start_Timestamp"]),
              e=int(r["End_Timestamp"])) for r in csv.DictReader(open(f))]
 rows.sort(key=lambda r: r["s"])
@@ -16,7 +18,7 @@ for r in rows:
     busy[r["q"]] += r["e"] - r["s"]
 main = max(busy, key=busy.get)
 # the last full step: from the last `gat_prepare_multi_kernel` (first launch of a step) but one to the last one
-starts = [i for i, r in enumerate(rows) if r["name"].startswith("gat_prepare_multi") or r["name"].startswith("gat_prepare_kernel")]
+starts = [i for i, r in enumerate(rows) if r["name"].startswith(FIRST)]
 a, b = starts[-2], starts[-1]
 step = rows[a:b]
 t0 = step[0]["s"]

@@ -9,7 +9,8 @@
  *     elements); nothing is allocated, freed or synchronised inside; all work is enqueued on `stream`
  *     (a hipStream_t passed as void*);  workspaces are supplied by the caller (size from the *_ws_bytes functions)
  *   - return value: 0 = TXE_OK, <0 = error (TXE_ERR_ARG -1, TXE_ERR_LAUNCH -2, TXE_ERR_WORKSPACE -3); never throws
- *   - re-entrant, no global state
+ *   - re-entrant; no state between calls except the optional per-launch profiler (txe_profile_*, off by default: a process-global
+ *     switch and a per-device ring of events) and the cached CU count of the current device
  *   - graph structure: destination-sorted CSR  (rowptr_in[N+1], col_src[E])  and source-sorted CSR
  *     (rowptr_out[N+1], col_dst[E], pos_out[E] = index of that edge in the destination-sorted order); per-edge
  *     arrays (alpha, dz) live in destination-sorted order

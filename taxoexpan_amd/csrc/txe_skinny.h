@@ -172,7 +172,7 @@ constexpr int SK_MAXJOBS = 2;
 struct SkinnyMulti { int n; SkinnyArgs j[SK_MAXJOBS]; };
 
 // independent products in one launch, each on its own range of workgroups (all with the same number of waves)
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void skinny_gemm_kernel(const SkinnyMulti m) {
+__global__ __launch_bounds__(1024) void skinny_gemm_kernel(const SkinnyMulti m) {
     extern __shared__ float sk_red[];
     int b = blockIdx.x, i = 0;
     while (i + 1 < m.n && b >= m.j[i].nb) { b -= m.j[i].nb; ++i; }
@@ -204,7 +204,7 @@ static inline void skinny_setup(SkinnyArgs& a, bool akm, bool bkm, int m_hint, i
     // k-slices per tile: enough waves to put ~4 on every SIMD of the chip, at least two 16-k steps per wave
     const long long tiles = (long long)a.nb_n * a.nb_m;
     int ks = 1;
-    while (ks < 8 && tiles * ks < 2048 && k_hint / (2 * ks) >= 32) ks *= 2;
+    while (ks < 16 && tiles * ks < 2048 && k_hint / (2 * ks) >= 32) ks *= 2;
     a.ks = ks;
 }
 // launch of up to SK_MAXJOBS set-up products: the workgroups hold max ks waves, a job with fewer slices puts several tiles in a workgroup

@@ -1496,6 +1496,7 @@ class BilinearFoldedRunsFunction(torch.autograd.Function):
                 n_runs, U, first_row = None, Q.shape[0], 0
             V, T = _empty((max(U, 1), l), Z), _empty((max(U, 1), Kp), Z)
         s = _empty((G,), Z)
+        # 'edot': the stack ran the matcher's job and its Z sweep carried T; 'job': it ran the job only; 'inline': V / T formed here
         note_route("fold", "edot" if (ready and link.e_part is not None and "score" in fw) else ("job" if ready else "inline"))
         with _lib.on_device(Z.device):
             if ready and link.e_part is not None and "score" in fw:

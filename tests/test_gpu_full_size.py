@@ -106,14 +106,17 @@ def _expected_routes(prop, form):
     'fused+edot' -- and a test that silently ran anything else is a test of something else"""
     from taxoexpan_amd import model_zoo as mz, ops
     runs_ok = form == "rows" or not ops._NO_QUERY_RUNS
-    fold = runs_ok and not (ops._NO_MATCH_FOLD or mz._NO_FOLD) and (prop != "PGAT" or not ops._NO_FUSED_BWD)
+    can_fold = not (ops._NO_MATCH_FOLD or mz._NO_FOLD) and (prop != "PGAT" or not ops._NO_FUSED_BWD)
+    fold = runs_ok and can_fold
     edot = fold and prop == "PGAT" and not ops._NO_FOLD_EDOT and form != "hook"
     match = "folded" if fold else (("runs" if form == "rows" else "stacked") if runs_ok else "pair")
     if mz._NO_FOLD:
         stack = "mean" if prop == "PGAT" else "layers"
     else:
         stack = ("collapse_z" + ("+edot" if edot else "")) if fold else "collapse"
-    fold_kind = ("edot" if edot else ("inline" if (form == "hook" or prop != "PGAT") else "job")) if fold else None
+    fold_kind = ("edot" if edot else "inline") if fold else None      # (the matcher's job is only handed to the stack for the sweep to carry T)
+    if not fold and form == "hook" and can_fold:                        # the hook's .detach() ran the stack up to Z; hg = Z W^T materialised afterwards
+        stack, fold_kind = "collapse_z", "materialised"
     bwd = "fused+edot" if edot else (("collapse" if not mz._NO_FOLD else "layers") if prop == "PGAT" else None)
     return dict(match=match, stack=stack, fold=fold_kind, stack_bwd=bwd)
 

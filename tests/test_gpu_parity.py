@@ -67,7 +67,7 @@ def test_model_matches_reference_goldens(name):
     if spec.get("repeat_queries") and not (ops._NO_MATCH_FOLD or ops._NO_FUSED_BWD or ops._NO_QUERY_RUNS or mz._NO_FOLD):
         edot = not ops._NO_FOLD_EDOT
         taken = dict(runs.routes)
-        assert (taken["match"], taken["stack"], taken["fold"]) == ("folded", "collapse_z" + ("+edot" if edot else ""), "edot" if edot else "job"), taken
+        assert (taken["match"], taken["stack"], taken["fold"]) == ("folded", "collapse_z" + ("+edot" if edot else ""), "edot" if edot else "inline"), taken
         assert ops.ROUTES["stack_bwd"] == ("fused+edot" if edot else "collapse")
     step = gc.row_steps(spec)[0]
     np.testing.assert_allclose(g.ndata["h"].detach().cpu().numpy()[::step], z["hn"], rtol=RT, atol=AT)
@@ -1497,7 +1497,7 @@ def test_graph_vector_folded_into_the_matcher_equals_the_materialised_one(matche
     # ... against the same step with nothing touched in between (the job rides in the sweep)
     model.zero_grad()
     s2 = model.match(fresh(), q_arg)
-    assert ops.ROUTES["fold"] == ("edot" if edot else "job")
+    assert ops.ROUTES["fold"] == ("edot" if edot else "inline")
     info_nce_loss(s2.reshape(nq, -1), target).backward()
     np.testing.assert_allclose(s1.detach().cpu().numpy(), s2.detach().cpu().numpy(), rtol=1e-4, atol=1e-6)
     for n, p in model.named_parameters():

@@ -76,7 +76,7 @@ def _expected(c, n_nodes):
     edot = (folded and gat and c["hook"] != "detach" and not ops._NO_FOLD_EDOT and
             _lib.call("txe_gat_collapse_e_tiles", n_nodes, c["G"], H[-2] * c["hidden"], pd) > 0)
     if folded:          # (a GCN stack has no sweep for the matcher's job to ride in: always the in-line kernels)
-        stack, fold = "collapse_z" + ("+edot" if edot else ""), ("edot" if edot else ("inline" if (c["hook"] == "detach" or not gat) else "job"))
+        stack, fold = "collapse_z" + ("+edot" if edot else ""), ("edot" if edot else "inline")
     elif deferred_nodes:
         stack, fold = "collapse", None
     else:

@@ -81,17 +81,17 @@ __device__ __forceinline__ void unfold_job(const int f, const UnfoldArgs& a) {
     const float al = a.attn_l[f], ar = a.attn_r[f];
     float dl = 0.f, dr = 0.f;
     for (int k = threadIdx.x; k < a.Kt; k += blockDim.x) {
-        // the split-K partials are summed in slice order, four (unconditional, clamped) loads in flight at a time
+        // the split-K partials are summed in slice order, eight (unconditional, clamped) loads in flight at a time
         const float* pp = a.part + (long long)f * a.ldp + k;
         const float gl = a.dwa[(long long)h * a.ldp + k], gr = a.dwa[(long long)(a.H + h) * a.ldp + k];
         const float wv = a.W[(long long)f * a.ldw + k];
         float acc = 0.f;
-        for (int s0 = 0; s0 < a.S; s0 += 4) {
-            float v[4];
+        for (int s0 = 0; s0 < a.S; s0 += 8) {
+            float v[8];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = pp[(long long)min(s0 + j, a.S - 1) * a.split_stride];
+            for (int j = 0; j < 8; ++j) v[j] = pp[(long long)min(s0 + j, a.S - 1) * a.split_stride];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc += (s0 + j < a.S) ? v[j] : 0.f;
+            for (int j = 0; j < 8; ++j) acc += (s0 + j < a.S) ? v[j] : 0.f;
         }
         a.dW[(long long)f * a.ld_dw + k] = acc + al * gl + ar * gr;
         dl = fmaf(gl, wv, dl);

@@ -269,3 +269,73 @@ def test_data_loader_uses_the_cache_after_the_first_raw_load(tmp_path, monkeypat
     b = data_loaders._open_dataset(str(tmp_path))
     assert b.vocab == a.vocab and b.train_node_ids == a.train_node_ids and b.test_node_ids == a.test_node_ids
     assert torch.equal(b.g_full.ndata["x"], a.g_full.ndata["x"]) and np.array_equal(b.edges, a.edges)
+
+
+def test_matcher_route_decision_and_deferred_vector_protocol_on_the_host():
+    """model_zoo._Bilinear._route (ONE route per call, from the inputs alone) and the DeferredGraphVector protocol, without a GPU: the
+    decisions that need no kernel -- RepeatedRows with / without repetition, the eval loop's expanded query, host tensors (never a run
+    form), grad mode; can_fold / started / the refusal of a second differentiable use after the fold."""
+    import numpy as np
+    from taxoexpan_amd import model_zoo as mz, ops
+    m = mz.LBM(6, 4)
+    e1 = torch.randn(8, 6)
+    table = torch.randn(3, 4)
+    rep = ops.RepeatedRows.from_ids(table, np.repeat([0, 2], 4))                 # 2 distinct rows behind 8 pairs: repetition
+    few = ops.RepeatedRows.from_ids(table, np.array([0, 1, 2, 0, 1, 2, 0, 1]))  # 8 runs of 1: none
+    assert m._route(e1, rep)[0] == "runs"
+    route, dense = m._route(e1, few)
+    assert route == "pair" and torch.is_tensor(dense) and dense.shape == (8, 4)
+    assert m._route(e1[:6], rep)[0] == "pair"                                    # row counts differ: densified
+    q = torch.randn(4)
+    with torch.no_grad():
+        assert m._route(e1, q.expand(8, -1))[0] == "expand"                      # test_fast.py:122-123
+    assert m._route(e1, q.expand(8, -1))[0] == "pair"                            # ... with gradients: the plain form
+    assert m._route(e1, torch.randn(8, 4))[0] == "pair"                          # a host tensor never takes a device run form
+
+    class _Node:                                                                 # stands in for a DeferredNodeOutput
+        def __init__(self, ok):
+            self._args = (type("C", (), dict(n_graphs=8, n_nodes=20, n_edges=30))(), None, torch.zeros(1), None, [])
+            self._ok, self.calls = ok, []
+
+        def _out_dim(self):
+            return 6
+
+        def _can_fold(self):
+            return self._ok
+
+        def _collapse(self, final, rpos, pw, fold_job=None):
+            self.calls.append(final)
+            c = type("Cfg", (), dict(link=ops.FoldLink()))()
+            return ((torch.zeros(8, 32), torch.zeros(128, 32)) if final == "collapse_z" else torch.ones(8, 6)), c
+    hv = mz.DeferredGraphVector(_Node(True), None, None)
+    assert tuple(hv.shape) == (8, 6) and len(hv) == 8 and not hv.started() and hv.can_fold() and "pending" in repr(hv)
+    assert m._route(hv, rep)[0] == "folded"
+    with torch.no_grad():
+        assert m._route(hv, rep)[0] == "runs"                                    # the fold is a training-time route
+    t = hv.tensor()                                                              # any tensor consumer: the plain stack, once
+    assert torch.is_tensor(t) and hv._src[0].calls == ["collapse"] and hv.started() and not hv.can_fold()
+    assert hv.tensor() is t and m._route(hv, rep)[0] == "runs"
+    assert not mz.DeferredGraphVector(_Node(False), None, None).can_fold()
+    hv2 = mz.DeferredGraphVector(_Node(True), None, None)
+    hv2._folded = True                                                           # (what match_folded leaves behind)
+    with pytest.raises(RuntimeError, match="consumed FOLDED"):
+        hv2.tensor()
+    prev, ops._NO_MATCH_FOLD = ops._NO_MATCH_FOLD, True
+    try:
+        assert not mz.DeferredGraphVector(_Node(True), None, None).can_fold()
+    finally:
+        ops._NO_MATCH_FOLD = prev
+
+
+def test_loss_tensor_backward_starts_from_a_unit_gradient_only_when_asked_plainly():
+    """loss.LossTensor: `loss.backward()` hands autograd a cached constant 1 (on the device); anything else -- an explicit gradient,
+    arithmetic on the loss, a host tensor -- is the ordinary torch path.  Here: the host-side mechanics (no GPU: the plain path)."""
+    from taxoexpan_amd import loss as L
+    x = torch.ones(3, requires_grad=True)
+    l = (2 * x).sum().as_subclass(L.LossTensor)
+    assert isinstance(l, L.LossTensor) and float(l.detach()) == 6.0
+    l.backward()
+    assert torch.equal(x.grad, torch.full((3,), 2.0))
+    x.grad = None
+    ((3 * x).sum().as_subclass(L.LossTensor) / 2).backward(torch.tensor(4.0))
+    assert torch.equal(x.grad, torch.full((3,), 6.0))

@@ -209,6 +209,12 @@ static inline void skinny_setup(SkinnyArgs& a, bool akm, bool bkm, int m_hint, i
 }
 // launch of up to SK_MAXJOBS set-up products: the workgroups hold max ks waves, a job with fewer slices puts several tiles in a workgroup
 static inline int skinny_launch(SkinnyMulti& m, hipStream_t st) {
+    for (int i = 0; i < m.n; ++i) {                                 // the kernel addresses its operands with 32-bit element offsets
+        const SkinnyArgs& j = m.j[i];
+        const long long rows = (long long)(j.M > j.K ? j.M : j.K) > j.N ? (long long)(j.M > j.K ? j.M : j.K) : (long long)j.N;
+        const long long ld = j.lda > j.ldb ? j.lda : j.ldb;
+        if ((rows + 1) * ld >= (1LL << 31)) return TXE_ERR_ARG;
+    }
     int wg = 1;
     for (int i = 0; i < m.n; ++i) wg = m.j[i].ks > wg ? m.j[i].ks : wg;
     int total = 0;

@@ -519,12 +519,15 @@ def make_model(workload, device):
         return TaxoExpan("PGAT", "WMR", "LBM", **MAG).to(device).train()
     if workload == "pgat2":
         return TaxoExpan("PGAT", "WMR", "LBM", **dict(MAG, num_layers=2, heads=[4, 4, 1])).to(device).train()
+    if workload == "semeval":      # BASELINE configs[0]: config.wordnet.json's dimensions (in 300, hidden 600, out 300)
+        return TaxoExpan("PGAT", "WMR", "LBM", **dict(MAG, in_dim=300, hidden_dim=600, out_dim=300)).to(device).train()
     return TaxoExpan("PGCN", "MR", "BIM", **MAG).to(device).train()
 
 
 WORKLOAD_TEXT = {"pgat": "MAG-CS synthetic taxonomy (29,654 nodes, d=250), PGAT+WMR+LBM fp32 dims 250/50/500/500 heads [4,1], ",
                  "pgat2": "MAG-Full synthetic taxonomy (431,416 nodes, d=250), PGAT num_layers=2 +WMR+LBM fp32 dims 250/50/500/500 heads [4,4,1], ",
-                 "pgcn": "MAG-CS synthetic taxonomy (29,654 nodes, d=250), PGCN+MR+BIM fp32 dims 250/50/500/500, "}
+                 "pgcn": "MAG-CS synthetic taxonomy (29,654 nodes, d=250), PGCN+MR+BIM fp32 dims 250/50/500/500, ",
+                 "semeval": "SemEval-Noun synthetic taxonomy (83,073 nodes, d=300), PGAT+WMR+LBM fp32 dims 300/50/600/300 heads [4,1], "}
 STEP_TEXT = "128 queries x 32 = 4096 egonets per GPU per step, fwd + InfoNCE + bwd + Adam(amsgrad), dropout 0.1"
 
 
@@ -562,6 +565,22 @@ def large_batch_step(tax, device, factor=8):
         r = variant_step("pgat", tax, device, steps=5, reps=5)
         r["workload"] = WORKLOAD_TEXT["pgat"] + f"{N_QUERIES} queries x 32 = {N_QUERIES * 32} egonets per step, fwd + InfoNCE + bwd + Adam(amsgrad), dropout 0.1"
         r["ms_per_4096_egonets"] = r["ms_per_step"] / factor
+        return r
+    finally:
+        N_QUERIES = base
+
+
+def semeval_step(device):
+    """BASELINE configs[0] on the GPU: the SemEval-Noun shape (config.wordnet.json's dimensions), 64 queries x 32 = 2,048 egonets per step
+     -- the reference's CPU-runnable case; its parity at this size is tests/test_gpu_full_size.py [semeval-*]"""
+    global N_QUERIES
+    from taxoexpan_amd import synthetic as syn
+    base = N_QUERIES
+    try:
+        N_QUERIES = 64
+        tax = syn.make_named_taxonomy("semeval_noun", seed=47)
+        r = variant_step("semeval", tax, device, steps=10, reps=5)
+        r["workload"] = WORKLOAD_TEXT["semeval"] + "64 queries x 32 = 2048 egonets per step, fwd + InfoNCE + bwd + Adam(amsgrad), dropout 0.1"
         return r
     finally:
         N_QUERIES = base
@@ -846,7 +865,8 @@ def main():
             for name, fn in (("mag_full", lambda: extra_metrics_mag_full(model, device, tax_full)),
                              ("step_32768_egonets", lambda: large_batch_step(tax, device, 8)),
                              ("step_pgcn", lambda: variant_step("pgcn", tax, device)),
-                             ("step_pgat2", lambda: variant_step("pgat2", tax_full, device))):
+                             ("step_pgat2", lambda: variant_step("pgat2", tax_full, device)),
+                             ("step_semeval", lambda: semeval_step(device))):
                 try:                                     # never let a secondary metric take the bench line down
                     extra[name] = fn()
                 except Exception as exc:                 # noqa: BLE001
@@ -940,6 +960,8 @@ def main():
                                 ("infer_top5_queries_per_s", ("mag_full", "infer_top5_queries_per_s")),
                                 ("infer_top5_fused_over_composite", ("mag_full", "infer_top5_fused_over_composite")),
                                 ("step_pgcn_ms", ("step_pgcn", "ms_per_step")), ("step_pgat2_ms", ("step_pgat2", "ms_per_step")),
+                                ("step_semeval_ms", ("step_semeval", "ms_per_step")),
+                                ("step_semeval_edges_per_s", ("step_semeval", "egonet_edges_per_s")),
                                 ("step_32768_egonets_ms", ("step_32768_egonets", "ms_per_step")),
                                 ("step_32768_egonets_edges_per_s", ("step_32768_egonets", "egonet_edges_per_s")),
                                 ("step_32768_egonets_roofline_frac", ("step_32768_egonets", "roofline", "frac"))):

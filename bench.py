@@ -810,6 +810,17 @@ def main():
         ab["step_reference_caller_ms"] = timed(torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=0, amsgrad=True),
                                                lambda out, tgt: F.cross_entropy(out, tgt, reduction="sum"))     # all three as train.py has them
         torch.autograd.set_multithreading_enabled(False)
+        # ... and with ONE key added to the reference's config JSON ("optimizer": {"args": {..., "fused": true}}, train.py builds the
+        # optimizer from it): torch's own single-launch Adam
+        try:
+            ab["step_torch_adam_fused_ms"] = timed(torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=0, amsgrad=True, fused=True))
+            torch.autograd.set_multithreading_enabled(True)
+            ab["step_reference_caller_fused_adam_ms"] = timed(torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=0, amsgrad=True, fused=True),
+                                                              lambda out, tgt: F.cross_entropy(out, tgt, reduction="sum"))
+        except (RuntimeError, TypeError, ValueError) as e:       # (a torch build without the fused implementation)
+            ab["step_torch_adam_fused_ms"] = None
+            ab["step_torch_adam_fused_error"] = str(e)[:200]
+        torch.autograd.set_multithreading_enabled(False)
 
     # the same step with a NEW batch built inside it (what an epoch of train.py pays per step): not `value` -- the contract times the
     # hot path on resident inputs -- but reported next to it

@@ -8,6 +8,8 @@ how the propagation stack ends -- over a seeded sample of the whole space:
 For every sample: the route that RAN (ops.ROUTES, noted by the code itself) must be the route `_expected` derives from the inputs alone,
 and scores, loss and every parameter gradient must agree with the CPU oracle (reference: model/model.py:70-87, model_zoo.py:301-328,
 trainer/trainer.py:52-56).  A route change that nobody asked for -- the kind a harmless-looking hook once caused -- fails here."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -45,7 +47,8 @@ def _samples(n=28, seed=20260929):
     return out
 
 
-SAMPLES = _samples()
+# (a wider sweep on demand: TXE_ROUTE_FUZZ_N=300 TXE_ROUTE_FUZZ_SEED=7 python -m pytest tests/test_gpu_routes.py -m gpu)
+SAMPLES = _samples(int(os.environ.get("TXE_ROUTE_FUZZ_N", "28")), int(os.environ.get("TXE_ROUTE_FUZZ_SEED", "20260929")))
 
 
 def _id(c):
@@ -157,6 +160,8 @@ def test_the_expected_route_runs_and_agrees_with_the_oracle(c):
         np.testing.assert_allclose(loss.item(), l_ref.item(), rtol=1e-4)
         for k, p in model.named_parameters():
             ref = P[k].grad.numpy()
-            # (+ 2e-6 absolute: the output layer's bias shifts every score of a query alike, its InfoNCE gradient is exactly 0 -- rounding
-            #  noise of ~1e-7 on both sides)
-            np.testing.assert_allclose(p.grad.cpu().numpy(), ref, rtol=2e-3, atol=3e-4 * float(np.abs(ref).max()) + 2e-6, err_msg=k)
+            # (+ an absolute term: the output layer's bias shifts every score of a query alike, its InfoNCE gradient is exactly 0 -- what
+            #  both sides hold there is the rounding noise of a sum over G graphs: 2e-6 at 256 graphs, growing like sqrt(G); a 260-sample
+            #  sweep found 2.7e-6 at 4,096)
+            np.testing.assert_allclose(p.grad.cpu().numpy(), ref, rtol=2e-3,
+                                       atol=3e-4 * float(np.abs(ref).max()) + 2e-6 * max(1.0, (c["G"] / 256.0) ** 0.5), err_msg=k)

@@ -3,6 +3,7 @@ how the propagation stack ends -- over a seeded sample of the whole space:
 
     grad mode on / off  x  queries stacked (the reference collate, data_loaders.py:9-28) / ops.RepeatedRows / rows that never repeat
     x  a readout hook that does nothing / logs `out.detach()` / touches the tensor (`out + 0`)  x  G in {200, 256, 4096} egonets
+    x  dropout off / 0.1 (the oracle gets the kernels' own counter-based masks)  x  num_layers 1 / 2
     x  PGAT / GAT / PGCN / GCN  x  MeanReadout / WeightedMeanReadout  x  BIM / LBM  x  head layouts with and without a foldable output layer
 
 For every sample: the route that RAN (ops.ROUTES, noted by the code itself) must be the route `_expected` derives from the inputs alone,
@@ -43,12 +44,18 @@ def _samples(n=28, seed=20260929):
                  heads=([[4, 1], [2, 1], [1, 1], [2, 2]][rs.randint(4)] if prop in ("PGAT", "GAT") else None),
                  hidden=int(rs.choice([16, 16, 10])), grad=bool(rs.rand() < 0.8), queries=str(rs.choice(["stacked", "rows", "unique"])),
                  hook=[None, "detach", "touch"][rs.randint(3)], G=int(rs.choice([200, 256, 256, 4096])))
+        if rs.rand() < 0.3:
+            c["drop"] = 0.1                                           # feature / attention dropout on, the oracle gets the kernels' own masks
         if WIDE:                                                     # realistic widths too: vector / tile remainders of every kernel
             c.update(in_dim=int(rs.choice([12, 50, 128, 250, 300])), out_dim=int(rs.choice([24, 100, 300, 500])),
                      pos_dim=int(rs.choice([4, 10, 50])), hidden=int(rs.choice([16, 10, 64, 100, 126, 250, 500, 600])),
                      G=int(rs.choice([200, 256, 256, 512])))
             if c["heads"] is not None and rs.rand() < 0.3:
                 c["heads"] = [3, 1]
+        if rs.rand() < 0.2:
+            c["layers"] = 2                                           # num_layers = 2: three GAT / GCN layers (heads [a, a, last])
+            if c["heads"] is not None:
+                c["heads"] = [c["heads"][0]] + list(c["heads"])
         key = repr(sorted(c.items(), key=lambda kv: kv[0]))
         if key not in seen:
             seen.add(key)
@@ -62,7 +69,7 @@ SAMPLES = _samples(int(os.environ.get("TXE_ROUTE_FUZZ_N", "28")), int(os.environ
 
 def _id(c):
     return "-".join(str(c[k]).replace(" ", "") for k in ("prop", "readout", "match", "heads", "hidden", "grad", "queries", "hook", "G") +
-                    (("in_dim", "out_dim", "pos_dim") if "in_dim" in c else ()))
+                    (("in_dim", "out_dim", "pos_dim") if "in_dim" in c else ())) + ("-drop" if c.get("drop") else "") + ("-L2" if c.get("layers") == 2 else "")
 
 
 def _expected(c, n_nodes):
@@ -108,7 +115,7 @@ def _expected(c, n_nodes):
 
 
 @pytest.mark.parametrize("c", SAMPLES, ids=[_id(c) for c in SAMPLES])
-def test_the_expected_route_runs_and_agrees_with_the_oracle(c):
+def test_the_expected_route_runs_and_agrees_with_the_oracle(c, monkeypatch):
     from taxoexpan_amd import TaxoExpan, ops, synthetic as syn
     dev = torch.device("cuda:0")
     per = 25 if c["G"] == 200 else 32
@@ -122,10 +129,13 @@ def test_the_expected_route_runs_and_agrees_with_the_oracle(c):
     x = g.ndata.pop("x")
     pos = g.ndata["pos"].clone()
     gat = c["prop"] in ("PGAT", "GAT")
-    L = 1
+    L = int(c.get("layers", 1))
     torch.manual_seed(11)
+    drop = float(c.get("drop", 0.0))
     model = TaxoExpan(c["prop"], c["readout"], c["match"], in_dim=in_dim, hidden_dim=c["hidden"], out_dim=out_dim, pos_dim=pos_dim, num_layers=L,
-                      heads=c["heads"], feat_drop=0.0, attn_drop=0.0, hidden_drop=0.0, out_drop=0.0).to(dev).train()
+                      heads=c["heads"], feat_drop=drop, attn_drop=drop, hidden_drop=drop, out_drop=drop).to(dev).train()
+    seed = 1234567 + c["G"]
+    monkeypatch.setattr(ops, "new_seed", lambda: seed)               # (the kernels' counter-based masks: taxoexpan_amd/rng.py restates them)
     with torch.no_grad():
         model.match.W.weight.mul_(3.0)                               # (spread the scores: InfoNCE rows that are not flat)
     q_dev = qf.to(dev)
@@ -169,9 +179,15 @@ def test_the_expected_route_runs_and_agrees_with_the_oracle(c):
     P = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in model.state_dict().items()}
     graph = dict(src=torch.from_numpy(np.asarray(g._src)).long(), dst=torch.from_numpy(np.asarray(g._dst)).long(), pos=pos.long(),
                  graph_off=csr.graph_off.long(), num_nodes=csr.n_nodes)
+    masks = branches
+    if drop > 0.0:
+        from test_gpu_full_size import _masks
+        masks = _masks("PGAT" if gat else "PGCN", P, c["heads"], L, csr.n_nodes, csr.n_edges, seed, csr.eid_in.numpy(), drop, drop)
+        for mk, br in zip(masks, branches or [{} for _ in masks]):
+            mk.update(br)
     orc.BRANCH_AUDIT = [] if branches is not None else None
     try:
-        s_ref, _hg, _hn = orc.taxoexpan_forward(P, graph, x, qf, c["prop"], c["readout"], c["match"], c["heads"], L, branches)
+        s_ref, _hg, _hn = orc.taxoexpan_forward(P, graph, x, qf, c["prop"], c["readout"], c["match"], c["heads"], L, masks)
         audit = list(orc.BRANCH_AUDIT or [])
     finally:
         orc.BRANCH_AUDIT = None

@@ -16,7 +16,6 @@ Graph argument: a taxoexpan_amd.graph.(Batched)DGLGraph -- the DGL-0.4 surface o
 Side effects the callers rely on are kept: PGAT/PGCN pop g.ndata['pos'] (model_zoo.py:163,212); WeightedMeanReadout
 writes g.ndata['a'] (:241).
 """
-import math
 
 import torch
 import torch.nn as nn

@@ -7,7 +7,6 @@ wide streaming reads by 2x -- MI355X_MICROARCH.md HBM section) followed by the h
 import os
 import sys
 
-import numpy as np
 import torch
 
 torch.autograd.set_multithreading_enabled(False)     # as bench.py: the backward runs on the calling thread

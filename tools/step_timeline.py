@@ -5,7 +5,6 @@ the idle gaps between consecutive kernels on the caller's stream, and the kernel
 import collections
 import csv
 import glob
-import sys
 
 import os
 f = sorted(glob.glob("gpurun_out/tl/**/*kernel_trace.csv", recursive=True))[-1]

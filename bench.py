@@ -451,6 +451,9 @@ def extra_metrics(model, tax, device, batches, full_batches):
                    candidates_scored_per_s_incl_encode_and_rank=pairs / (t_enc + t_sc + t_rk),
                    candidates_scored_per_s_fused_rank_incl_dedup_encode=pairs / (t_enc_l + t_fused),
                    score_gemm_tflops=2.0 * 250 * pairs / t_sc / 1e12, score_gemm_frac_of_mfma_peak=2.0 * 250 * pairs / t_sc / PEAK_MFMA_F32,
+                   # (SURVEY 8d's factored count of the SAME timed region: U = hg W once, 2 G l r, + 2 r per pair)
+                   score_factored_tflops=(2.0 * 250 * pairs + 2.0 * hg.shape[0] * 500 * 250) / t_sc / 1e12,
+                   score_factored_frac_of_mfma_peak=(2.0 * 250 * pairs + 2.0 * hg.shape[0] * 500 * 250) / t_sc / PEAK_MFMA_F32,
                    mean_rank=float(ranks.float().mean().item()) if ranks.numel() else None)
     model.train()
     return out, hg, queries[:256]
@@ -506,6 +509,9 @@ def extra_metrics_mag_full(model, device, tax, n_queries=8192, qblock=1024):
                    encode_30000_chunks_s=t_enc_c, encode_30000_chunks_edges_per_s=n_edges / t_enc_c, encode_chunks=n_chunks,
                    score_s=t_sc, candidates_scored_per_s=pairs / t_sc,
                    score_gemm_tflops=2.0 * 250 * pairs / t_sc / 1e12, score_gemm_frac_of_mfma_peak=2.0 * 250 * pairs / t_sc / PEAK_MFMA_F32,
+                   # (SURVEY 8d's factored count of the SAME timed region: U = hg W once, 2 G l r, + 2 r per pair)
+                   score_factored_tflops=(2.0 * 250 * pairs + 2.0 * hg.shape[0] * 500 * 250) / t_sc / 1e12,
+                   score_factored_frac_of_mfma_peak=(2.0 * 250 * pairs + 2.0 * hg.shape[0] * 500 * 250) / t_sc / PEAK_MFMA_F32,
                    fused_score_rank_s=t_fr, candidates_scored_per_s_fused_rank=pairs / t_fr,
                    candidates_scored_per_s_fused_rank_incl_encode=pairs / (t_fr + t_enc),
                    mean_rank=float(ranks.float().mean().item()) if ranks.numel() else None)

@@ -2008,7 +2008,9 @@ __device__ __forceinline__ void fb_body(const FusedBwdArgs& a, const int b, cons
 }
 
 template <bool MASK, int NI, int NWH /* waves per head = 4 / H */>
-__global__ __launch_bounds__(256, TXE_FB_OCC) void gat_fused_bwd_kernel(const FusedBwdArgs a) {
+// (three workgroups per CU = 168 VGPRs hold the sweep up to NI = 2 -- rows of up to 2,048 columns, the MAG shape; wider rows (SemEval:
+//  2,400) spilled 77 registers per lane there: two workgroups per CU, 256 VGPRs)
+__global__ __launch_bounds__(256, (NI >= 3) ? 2 : TXE_FB_OCC) void gat_fused_bwd_kernel(const FusedBwdArgs a) {
     __shared__ int s_v[FB_MAXE], s_p[FB_MAXE], s_ni[4 * FB_NODES];
     __shared__ float s_cn[FB_MAXE], s_g1[FB_MAXE], s_g2[FB_MAXE], s_nf[4 * FB_NODES];
     __shared__ float s_dot[4][4];

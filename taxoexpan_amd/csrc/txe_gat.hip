@@ -824,7 +824,10 @@ int txe_gat_aggregate_fwd(const int* rowptr_in, const int* col_src, int n_nodes,
     nx.scale = 1.f / (1.f - ((nx_a12 || out_drop) ? nx_feat_drop_p : 0.f)); nx.kp = nx_kp; nx.mask_ld = nx_kp / 32;
     // algorithmic (compulsory) bytes, SURVEY 8d: read ft + write out + a_src/a_dst + CSR (+ alpha when kept for backward);
     // the edge count is not known here (device rowptr), the E-proportional terms are added by the caller-side model
-    const int ni = pick_ni(H * D / vec);
+    // (16-byte rows of 257-320 or 513-640 vectors -- SemEval's 4 x 600 columns are 600 -- take 5 per lane: two passes over 320 lane slots
+    //  instead of two over 512 whose clamped loads still issue)
+    const int nvec = H * D / vec;
+    const int ni = (vec == 4 && ((nvec > 256 && nvec <= 320) || (nvec > 512 && nvec <= 640))) ? 5 : pick_ni(nvec);
     const int npw = fwd_nodes_per_wave(n_nodes, npw_req);
     const int nb = (n_nodes + GAT_WAVES * npw - 1) / (GAT_WAVES * npw);
     const KName kn("gat_aggregate_fwd_kernel", vec, ni, nx_a12 ? (nx.mask ? 2 : 1) : (out_drop ? 3 : 0), false, npw);
@@ -838,8 +841,9 @@ int txe_gat_aggregate_fwd(const int* rowptr_in, const int* col_src, int n_nodes,
 #define TXE_LXM(I, M) TXE_LP(4, I, M, (size_t)2 * nx_kp * sizeof(float))
 #define TXE_LX(I) do { if (nx.mask) TXE_LXM(I, 2); else TXE_LXM(I, 1); } while (0)
 #define TXE_LD(I) TXE_LP(4, I, 3, 0)
-    if (nx_a12) { if (ni == 8) TXE_LX(8); else if (ni == 4) TXE_LX(4); else TXE_LX(2); }
-    else if (out_drop) { if (ni == 8) TXE_LD(8); else if (ni == 4) TXE_LD(4); else TXE_LD(2); }
+    if (nx_a12) { if (ni == 8) TXE_LX(8); else if (ni == 5) TXE_LX(5); else if (ni == 4) TXE_LX(4); else TXE_LX(2); }
+    else if (out_drop) { if (ni == 8) TXE_LD(8); else if (ni == 5) TXE_LD(5); else if (ni == 4) TXE_LD(4); else TXE_LD(2); }
+    else if (ni == 5) TXE_L(4, 5);
     else TXE_DISPATCH_VEC_NI(vec, ni, TXE_L);
 #undef TXE_LD
 #undef TXE_LX

@@ -1160,7 +1160,7 @@ constexpr int ZS_GPW = 4;
 // the backward's <dZ[g], keep X[u]> sweep is this sweep's <Tf[zrow[g]], keep X[u]> times a scalar: the wave adds its tile's share of that
 // dot product per node to e_part[u][tile] (summed over the tiles, in tile order, by cl_fold_dc_kernel).
 template <bool MASK, bool EDOT = false>
-__global__ __launch_bounds__(256) void cl_zsum_chunk_kernel(const int* __restrict__ goff, int G, int ntile, const float* __restrict__ X, int Kp,
+__global__ __launch_bounds__(256) void cl_zsum_chunk_kernel(const int* __restrict__ goff, int G, int ntile, int nmap, const float* __restrict__ X, int Kp,
                                                             const unsigned* __restrict__ mask, int mask_ld, float scale,
                                                             const float* __restrict__ coef, const float* __restrict__ wsum,
                                                             float* __restrict__ Z, const float* __restrict__ Tf = nullptr,
@@ -1168,9 +1168,12 @@ __global__ __launch_bounds__(256) void cl_zsum_chunk_kernel(const int* __restric
     constexpr int NU = 8;
     const int l = threadIdx.x & 63;
     const long long wid = ((long long)blockIdx.x * 256 + threadIdx.x) >> 6;
-    const int ch = (int)(wid / ntile), t = (int)(wid % ntile);
+    // waves are numbered over (chunk, nmap slots): nmap = ntile, or ntile + 1 with an idle slot when ntile is a multiple of 4 -- the four
+    // waves of a workgroup (and the two workgroups of an 8-tile row) would otherwise always sit on the SAME chunk's rows, which costs a
+    // quarter of the sweep's rate (8 tiles: 67 against 51 us; 4: 35 / 25; 16: 118 / 90 -- with or without the e_part stores)
+    const int ch = (int)(wid / nmap), t = (int)(wid % nmap);
     const int g0 = ch * ZS_GPW;
-    if (g0 >= G) return;
+    if (g0 >= G || t >= ntile) return;
     const int ng = min(ZS_GPW, G - g0);
     const int my_off = goff[g0 + min(l, ng)];                       // lanes 0..ng: the chunk's graph offsets
     const float my_ws = wsum[g0 + min(l, ng - 1)];                  // lanes 0..ng-1: their weight sums
@@ -1253,25 +1256,26 @@ static int cl_zsum_launch(const int* graph_off, int G, int n_nodes, const float*
                           int mask_ld, float fs, const float* coef, const float* wsum, float* Z, hipStream_t s, const float* Tf = nullptr,
                           const int* zrow = nullptr, float* e_part = nullptr) {
     const int ntile = (Kp / 4 + 63) / 64;
+    const int nmap = (ntile % 4 == 0) ? ntile + 1 : ntile;          // (slots per chunk in the chunked kernel's wave numbering: see there)
     const bool chunked = cl_zsum_chunked(n_nodes, G);
     if (e_part) {                                   // (only the chunked kernel forms the dot products: the entry point checks cl_zsum_chunked)
         if (!chunked || !Tf || !zrow) return TXE_ERR_ARG;
-        const long long nw = (long long)((G + ZS_GPW - 1) / ZS_GPW) * ntile;
+        const long long nw = (long long)((G + ZS_GPW - 1) / ZS_GPW) * nmap;
         ProfScope prof(mk ? "cl_zsum_chunk_kernel<true, true>" : "cl_zsum_chunk_kernel<false, true>", s, 4.0 * (n_nodes + (double)G) * Kp, 1);
         const dim3 grid((unsigned)((nw + 3) / 4));
-        if (mk) hipLaunchKernelGGL((cl_zsum_chunk_kernel<true, true>), grid, dim3(256), 0, s, graph_off, G, ntile, X, Kp, mk, mask_ld, fs, coef, wsum, Z, Tf, zrow, e_part);
-        else hipLaunchKernelGGL((cl_zsum_chunk_kernel<false, true>), grid, dim3(256), 0, s, graph_off, G, ntile, X, Kp, dummy_mask, mask_ld, fs, coef, wsum, Z, Tf,
+        if (mk) hipLaunchKernelGGL((cl_zsum_chunk_kernel<true, true>), grid, dim3(256), 0, s, graph_off, G, ntile, nmap, X, Kp, mk, mask_ld, fs, coef, wsum, Z, Tf, zrow, e_part);
+        else hipLaunchKernelGGL((cl_zsum_chunk_kernel<false, true>), grid, dim3(256), 0, s, graph_off, G, ntile, nmap, X, Kp, dummy_mask, mask_ld, fs, coef, wsum, Z, Tf,
                                 zrow, e_part);
         TXE_CHECK_LAUNCH();
         return TXE_OK;
     }
-    const long long nwaves = (chunked ? (long long)((G + ZS_GPW - 1) / ZS_GPW) : (long long)G) * ntile;
+    const long long nwaves = chunked ? (long long)((G + ZS_GPW - 1) / ZS_GPW) * nmap : (long long)G * ntile;
     ProfScope prof(chunked ? (mk ? "cl_zsum_chunk_kernel<true, false>" : "cl_zsum_chunk_kernel<false, false>") : (mk ? "cl_zsum_kernel<true>" : "cl_zsum_kernel<false>"), s,
                    4.0 * (n_nodes + (double)G) * Kp, 1);
     const dim3 grid((unsigned)((nwaves + 3) / 4));
-    if (chunked && mk) hipLaunchKernelGGL((cl_zsum_chunk_kernel<true, false>), grid, dim3(256), 0, s, graph_off, G, ntile, X, Kp, mk, mask_ld, fs, coef, wsum, Z,
+    if (chunked && mk) hipLaunchKernelGGL((cl_zsum_chunk_kernel<true, false>), grid, dim3(256), 0, s, graph_off, G, ntile, nmap, X, Kp, mk, mask_ld, fs, coef, wsum, Z,
                                           (const float*)nullptr, (const int*)nullptr, (float*)nullptr);
-    else if (chunked) hipLaunchKernelGGL((cl_zsum_chunk_kernel<false, false>), grid, dim3(256), 0, s, graph_off, G, ntile, X, Kp, dummy_mask, mask_ld, fs, coef, wsum,
+    else if (chunked) hipLaunchKernelGGL((cl_zsum_chunk_kernel<false, false>), grid, dim3(256), 0, s, graph_off, G, ntile, nmap, X, Kp, dummy_mask, mask_ld, fs, coef, wsum,
                                          Z, (const float*)nullptr, (const int*)nullptr, (float*)nullptr);
     else if (mk) hipLaunchKernelGGL(cl_zsum_kernel<true>, grid, dim3(256), 0, s, graph_off, G, ntile, X, Kp, mk, mask_ld, fs, coef, wsum, Z);
     else hipLaunchKernelGGL(cl_zsum_kernel<false>, grid, dim3(256), 0, s, graph_off, G, ntile, X, Kp, dummy_mask, mask_ld, fs, coef, wsum, Z);

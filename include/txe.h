@@ -164,7 +164,7 @@ int txe_gcn_aggregate_fwd(const int* rowptr_in, const int* col_src, int n_nodes,
 size_t txe_gcn_aggregate_bwd_ws_bytes(int n_nodes, int F);
 int txe_gcn_aggregate_bwd(const int* rowptr_out, const int* col_dst, int n_nodes, const float* d_pre, long long ld_dpre,
                           const float* norm, int F, float* d_hw, long long ld_dhw, float* d_bias, void* ws, size_t ws_bytes,
-                          void* stream);
+                          void* stream);   /* also zeroes d_hw's columns [F, min(ld_dhw, roundup(F, 32))): txe_gcn_dense_bwd's zero padding */
 
 /* ---- readouts: MeanReadout model_zoo.py:231-232 (pw = NULL), WeightedMeanReadout :240-242 ------------------------- */
 int txe_readout_fwd(const int* graph_off, int G, const float* h, long long ld_h, const int* pos, const float* pw, int D,

@@ -21,7 +21,7 @@ __global__ __launch_bounds__(GAT_WAVES * 64) void gcn_aggregate_kernel(const int
                                                                        const long long ld_x, const float* __restrict__ norm,
                                                                        const float* __restrict__ bias, const int has_act,
                                                                        const float act_slope, const int F, float* __restrict__ out,
-                                                                       const long long ld_out) {
+                                                                       const long long ld_out, const int pad_to) {
     __shared__ float s_w[GAT_WAVES][64];
     __shared__ int s_idx[GAT_WAVES][64];
     const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
@@ -65,6 +65,7 @@ __global__ __launch_bounds__(GAT_WAVES * 64) void gcn_aggregate_kernel(const int
             }
         }
     }
+    for (int c = F + l; c < pad_to; c += 64) out[(long long)v * ld_out + c] = 0.f;      // (the row's padding columns, when asked for)
 }
 
 static inline int gcn_pick_vec(int F, long long ld1, long long ld2, const void* p1, const void* p2) {
@@ -75,7 +76,7 @@ static inline int gcn_pick_vec(int F, long long ld1, long long ld2, const void* 
 }
 
 static int gcn_launch(const int* rowptr, const int* col, int n, const float* x, long long ld_x, const float* norm,
-                      const float* bias, int has_act, float slope, int F, float* out, long long ld_out, hipStream_t s) {
+                      const float* bias, int has_act, float slope, int F, float* out, long long ld_out, hipStream_t s, int pad_to = 0) {
     const int nb = (n + GAT_WAVES - 1) / GAT_WAVES;
     int vec = gcn_pick_vec(F, ld_x, ld_out, x, out);
     const int ni = pick_ni(F / vec);
@@ -84,7 +85,7 @@ static int gcn_launch(const int* rowptr, const int* col, int n, const float* x, 
     ProfScope prof(kn, s, 4.0 * (2.0 * n * (double)F + 2.0 * n + 1), 1);
 #define TXE_L(V, I)                                                                                                           \
     hipLaunchKernelGGL((gcn_aggregate_kernel<V, I>), dim3(nb), dim3(GAT_WAVES * 64), 0, s, rowptr, col, n, x, ld_x, norm, bias, \
-                       has_act, slope, F, out, ld_out)
+                       has_act, slope, F, out, ld_out, pad_to)
     if (vec == 4) { if (ni == 8) TXE_L(4, 8); else if (ni == 4) TXE_L(4, 4); else TXE_L(4, 2); }
     else if (vec == 2) { if (ni == 8) TXE_L(2, 8); else if (ni == 4) TXE_L(2, 4); else TXE_L(2, 2); }
     else { if (ni == 8) TXE_L(1, 8); else if (ni == 4) TXE_L(1, 4); else TXE_L(1, 2); }
@@ -119,14 +120,18 @@ int txe_gcn_aggregate_fwd(const int* rowptr_in, const int* col_src, int n_nodes,
 size_t txe_gcn_aggregate_bwd_ws_bytes(int n_nodes, int F) { return colsum_ws_bytes(n_nodes, F); }
 
 // d_pre: gradient w.r.t. the pre-activation output (caller applies leaky' first, e.g. txe_leaky_relu_bwd).
-// d_hw[u] = norm[u] * sum_{u->v} norm[v] d_pre[v];  d_bias = column sum of d_pre (may be NULL).
+// d_hw[u] = norm[u] * sum_{u->v} norm[v] d_pre[v];  d_bias = column sum of d_pre (may be NULL).  The columns [F, min(ld_dhw, roundup(F, 32)))
+// of d_hw are set to 0 (txe_gcn_dense_bwd wants zero padding columns).
 int txe_gcn_aggregate_bwd(const int* rowptr_out, const int* col_dst, int n_nodes, const float* d_pre, long long ld_dpre,
                           const float* norm, int F, float* d_hw, long long ld_dhw, float* d_bias, void* ws, size_t ws_bytes,
                           void* stream) {
     if (n_nodes < 0 || F < 1 || !rowptr_out || !d_pre || !norm || !d_hw) return TXE_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
     if (n_nodes > 0) {
-        int rc = gcn_launch(rowptr_out, col_dst, n_nodes, d_pre, ld_dpre, norm, nullptr, 0, 1.f, F, d_hw, ld_dhw, s);
+        // (d_hw's padding columns up to the next multiple of 32 -- what the dense backward's GEMMs read as zeros -- are written here too)
+        const long long pad = ((F + 31) / 32) * 32;
+        int rc = gcn_launch(rowptr_out, col_dst, n_nodes, d_pre, ld_dpre, norm, nullptr, 0, 1.f, F, d_hw, ld_dhw, s,
+                            (int)(pad < ld_dhw ? pad : ld_dhw));
         if (rc) return rc;
     }
     if (d_bias) {

@@ -986,7 +986,6 @@ class GCNStackFunction(torch.autograd.Function):
                         d_pre, ld_dpre = d_X, st.Kp
                     continue
                 d_hw = _empty((N, st.Fop), d_out)
-                call("txe_zero_cols", ptr(d_hw), st.Fop, N, st.Fo, st.Fop, st_)
                 d_b = torch.empty_like(st.b) if st.b is not None else None
                 wsb = call("txe_gcn_aggregate_bwd_ws_bytes", N, st.Fo)
                 ws = _ws(wsb, d_out)

@@ -77,6 +77,13 @@ int txe_gcn_layer_prepare(const float* h, long long ld_h, int n_nodes, int Kh, c
                           const float* W, int Fo, float* Wp, float drop_p, unsigned long long seed, unsigned* mask, int x_dropped,
                           const float* bias_row /* NULL, or the layer's bias packed as row Kh + Pd of Wp (a padding row must exist) */,
                           void* stream);   /* x_dropped: as in txe_gat_prepare_desc (txe_gcn_dense_fwd then without mask) */
+/* ... for every GCNLayer of a stack in ONE launch (descs[i]: the arguments of txe_gcn_layer_prepare for layer i; h == NULL for every layer
+ * but the first), together with the stack's norm = in_degree^-1/2 (txe_gcn_norm, model_zoo.py:157-161; rowptr_in == NULL: without it) */
+struct txe_gcn_prepare_desc {
+    const float* h; long long ld_h; int n_nodes, Kh; const int* pos; const float* P; int Pd; float* X;
+    const float* W; int Fo; float* Wp; float drop_p; unsigned long long seed; unsigned* mask; int x_dropped; const float* bias_row;
+};
+int txe_gcn_layers_prepare(const struct txe_gcn_prepare_desc* descs, int n_layers, const int* rowptr_in, int n_nodes, float* norm, void* stream);
 
 /* Eval-mode layer-0 projection of a batch whose node features are rows of a taxonomy feature table (SURVEY 8f-2 "dedup by _id"):
  * the projection T = table W^T is formed once per DISTINCT taxonomy node (txe_gemm_plain), T2 = the position rows' projections, and

@@ -19,6 +19,7 @@ SIGNATURES = {
     "txe_gat_build_x": (I, [P, L, I, I, P, P, I, P, P]),
     "txe_gat_layer_prepare": (I, [P, L, I, I, P, P, I, P, P, P, P, I, I, P, F, U64, P, P]),
     "txe_gcn_layer_prepare": (I, [P, L, I, I, P, P, I, P, P, I, P, F, U64, P, I, P, P]),
+    "txe_gcn_layers_prepare": (I, [P, I, P, I, P, P]),
     "txe_gather_add_rows": (I, [P, L, P, P, L, P, L, I, P, L, P]),
     "txe_gat_dense_ws_bytes": (SZ, [I, I, I, I, I, I]),
     "txe_gat_dense_fwd": (I, [P, I, I, I, P, I, I, F, P, P, P, SZ, P]),
@@ -114,6 +115,12 @@ class GatPrepareDesc(C.Structure):
     """struct txe_gat_prepare_desc (include/txe.h)"""
     _fields_ = [("h", P), ("ld_h", L), ("n_nodes", I), ("Kh", I), ("pos", P), ("P", P), ("Pd", I), ("X", P), ("W", P), ("attn_l", P),
                 ("attn_r", P), ("H", I), ("D", I), ("Wp", P), ("feat_drop_p", F), ("seed", U64), ("mask", P), ("x_dropped", I)]
+
+
+class GcnPrepareDesc(C.Structure):
+    """struct txe_gcn_prepare_desc (include/txe.h)"""
+    _fields_ = [("h", P), ("ld_h", L), ("n_nodes", I), ("Kh", I), ("pos", P), ("P", P), ("Pd", I), ("X", P), ("W", P), ("Fo", I), ("Wp", P),
+                ("drop_p", F), ("seed", U64), ("mask", P), ("x_dropped", I), ("bias_row", P)]
 
 
 _ERR = {-1: "TXE_ERR_ARG", -2: "TXE_ERR_LAUNCH", -3: "TXE_ERR_WORKSPACE"}

@@ -659,9 +659,18 @@ struct txe_gat_prepare_desc {
 }  // extern "C"
 namespace txe {
 constexpr int PREP_MAXL = 4;
-struct PrepMulti { int n; int nb_end[PREP_MAXL]; PrepArgs a[PREP_MAXL]; };
+struct PrepMulti {
+    int n; int nb_end[PREP_MAXL]; PrepArgs a[PREP_MAXL];
+    int nb_norm; const int* norm_rowptr; int norm_n; float* norm;   // GCN stacks: norm = in_degree^-1/2 (model_zoo.py:157-161) by leading workgroups
+};
 __global__ __launch_bounds__(64 * FOLD_DG) void gat_prepare_multi_kernel(const PrepMulti m) {
     int b = blockIdx.x, i = 0;
+    if (b < m.nb_norm) {
+        const int v = b * (64 * FOLD_DG) + threadIdx.x;
+        if (v < m.norm_n) { const int deg = m.norm_rowptr[v + 1] - m.norm_rowptr[v]; m.norm[v] = deg > 0 ? 1.0f / sqrtf((float)deg) : 0.f; }
+        return;
+    }
+    b -= m.nb_norm;
     while (i + 1 < m.n && b >= m.nb_end[i]) ++i;                    // (block-uniform)
     prepare_jobs(m.a[i], b - ((i > 0) ? m.nb_end[i - 1] : 0));
 }
@@ -717,34 +726,73 @@ int txe_gat_layers_prepare(const struct txe_gat_prepare_desc* descs, int n_layer
 
 // The same for a GCNLayer (model_zoo.py:35-37): txe_gat_build_x + txe_gcn_pack_weights + txe_dropout_mask in one launch.
 // W [Kh+Pd][Fo] -> Wp [roundup(roundup(Kh+Pd,32),128)][roundup(Fo,32)]; mask may be NULL when drop_p == 0.
+struct txe_gcn_prepare_desc {
+    const float* h; long long ld_h; int n_nodes, Kh; const int* pos; const float* P; int Pd; float* X;
+    const float* W; int Fo; float* Wp; float drop_p; unsigned long long seed; unsigned* mask; int x_dropped; const float* bias_row;
+};
+}  // extern "C"
+namespace txe {
+static int fill_prep_gcn(PrepArgs& a, const txe_gcn_prepare_desc& d) {
+    // bias_row (or NULL): packed as row Kh + Pd of Wp (needs a padding row: (Kh + Pd) % 32 != 0) -- the folded output layer then carries
+    // its bias as the weight row of a column of Z that counts as 1 (txe_bilinear_folded_*: one_col)
+    if (d.n_nodes < 0 || d.Kh < 1 || d.Pd < 0 || !d.X || (d.Pd > 0 && (!d.pos || !d.P)) || !d.W || !d.Wp || d.Fo < 1) return TXE_ERR_ARG;
+    if (d.bias_row && ((d.Kh + d.Pd) % 32) == 0) return TXE_ERR_ARG;
+    if (d.drop_p < 0.f || d.drop_p >= 1.f || (d.drop_p > 0.f && !d.mask)) return TXE_ERR_ARG;
+    const int T = 64 * FOLD_DG;
+    memset(&a, 0, sizeof(a));
+    a.Kt = d.Kh + d.Pd; a.Kp = round_up(a.Kt, 32);
+    auto blocks = [&](long long n, int cap) { const long long b = (n + T - 1) / T; return (int)(b < cap ? b : cap); };
+    const long long nx = (long long)d.n_nodes * (a.Kp - (d.h ? 0 : d.Kh));
+    a.seed = d.seed; a.thr16 = (unsigned)(d.drop_p * 65536.0f + 0.5f); a.mask = d.mask;
+    a.x_dropped = (d.x_dropped && d.drop_p > 0.f && a.thr16 != 0u) ? 1 : 0;      // (as txe_gat_prepare_desc.x_dropped)
+    a.x_mask = (a.x_dropped && d.h != nullptr && nx > 0) ? 1 : 0;
+    a.drop_scale = 1.f / (1.f - d.drop_p);
+    a.nb_x = nx > 0 ? build_x_blocks(T, d.n_nodes, d.Kh, d.Pd, a.Kp, d.h != nullptr, a.x_dropped != 0, 2048) : 0;
+    a.n_words = (d.drop_p > 0.f) ? (long long)d.n_nodes * ((a.Kt + 31) / 32) : 0;
+    a.nb_m = a.x_mask ? 0 : blocks(a.n_words, 1024);
+    a.pk_rows = a.Kt; a.pk_ext = a.Kt; a.pk_prows = round_up(a.Kp, 128); a.pk_cols = d.Fo; a.pk_pcols = round_up(d.Fo, 32);
+    a.nb_w = blocks(((long long)a.pk_prows * a.pk_pcols / 4 + PREP_U - 1) / PREP_U, 512);
+    a.nb_f = 0; a.fold_bx = 1;
+    a.h = d.h; a.ld_h = d.ld_h; a.pos = d.pos; a.P = d.P; a.n_rows = d.n_nodes; a.Kh = d.Kh; a.Pd = d.Pd; a.X = d.X;
+    a.W = d.W; a.Wp = d.Wp; a.pk_extra = d.bias_row;
+    return TXE_OK;
+}
+}  // namespace txe
+extern "C" {
 int txe_gcn_layer_prepare(const float* h, long long ld_h, int n_nodes, int Kh, const int* pos, const float* P, int Pd, float* X,
                           const float* W, int Fo, float* Wp, float drop_p, unsigned long long seed, unsigned* mask, int x_dropped,
                           const float* bias_row, void* stream) {
-    // bias_row (or NULL): packed as row Kh + Pd of Wp (needs a padding row: (Kh + Pd) % 32 != 0) -- the folded output layer then carries
-    // its bias as the weight row of a column of Z that counts as 1 (txe_bilinear_folded_*: one_col)
-    if (n_nodes < 0 || Kh < 1 || Pd < 0 || !X || (Pd > 0 && (!pos || !P)) || !W || !Wp || Fo < 1) return TXE_ERR_ARG;
-    if (bias_row && ((Kh + Pd) % 32) == 0) return TXE_ERR_ARG;
-    if (drop_p < 0.f || drop_p >= 1.f || (drop_p > 0.f && !mask)) return TXE_ERR_ARG;
-    const int T = 64 * FOLD_DG;
+    const txe_gcn_prepare_desc d{h, ld_h, n_nodes, Kh, pos, P, Pd, X, W, Fo, Wp, drop_p, seed, mask, x_dropped, bias_row};
     PrepArgs a;
-    memset(&a, 0, sizeof(a));
-    a.Kt = Kh + Pd; a.Kp = round_up(a.Kt, 32);
-    auto blocks = [&](long long n, int cap) { const long long b = (n + T - 1) / T; return (int)(b < cap ? b : cap); };
-    const long long nx = (long long)n_nodes * (a.Kp - (h ? 0 : Kh));
-    a.seed = seed; a.thr16 = (unsigned)(drop_p * 65536.0f + 0.5f); a.mask = mask;
-    a.x_dropped = (x_dropped && drop_p > 0.f && a.thr16 != 0u) ? 1 : 0;      // (as txe_gat_prepare_desc.x_dropped)
-    a.x_mask = (a.x_dropped && h != nullptr && nx > 0) ? 1 : 0;
-    a.drop_scale = 1.f / (1.f - drop_p);
-    a.nb_x = nx > 0 ? build_x_blocks(T, n_nodes, Kh, Pd, a.Kp, h != nullptr, a.x_dropped != 0, 2048) : 0;
-    a.n_words = (drop_p > 0.f) ? (long long)n_nodes * ((a.Kt + 31) / 32) : 0;
-    a.nb_m = a.x_mask ? 0 : blocks(a.n_words, 1024);
-    a.pk_rows = a.Kt; a.pk_ext = a.Kt; a.pk_prows = round_up(a.Kp, 128); a.pk_cols = Fo; a.pk_pcols = round_up(Fo, 32);
-    a.nb_w = blocks(((long long)a.pk_prows * a.pk_pcols / 4 + PREP_U - 1) / PREP_U, 512);
-    a.nb_f = 0; a.fold_bx = 1;
-    a.h = h; a.ld_h = ld_h; a.pos = pos; a.P = P; a.n_rows = n_nodes; a.Kh = Kh; a.Pd = Pd; a.X = X;
-    a.W = W; a.Wp = Wp; a.pk_extra = bias_row;
-    hipLaunchKernelGGL(gat_prepare_kernel, dim3(a.nb_x + a.nb_m + a.nb_w), dim3(T), 0, (hipStream_t)stream, a);
+    const int rc = fill_prep_gcn(a, d);
+    if (rc) return rc;
+    hipLaunchKernelGGL(gat_prepare_kernel, dim3(a.nb_x + a.nb_m + a.nb_w), dim3(64 * FOLD_DG), 0, (hipStream_t)stream, a);
     TXE_CHECK_LAUNCH();
+    return TXE_OK;
+}
+
+// ... for every GCNLayer of a stack in ONE launch (a layer's preparation never depends on the layer below's output), together with the
+// stack's degree normalisation norm[v] = in_degree(v)^-1/2 (txe_gcn_norm; rowptr_in == NULL: without it)
+int txe_gcn_layers_prepare(const struct txe_gcn_prepare_desc* descs, int n_layers, const int* rowptr_in, int n_nodes, float* norm, void* stream) {
+    if (!descs || n_layers < 1 || (rowptr_in && (n_nodes < 0 || !norm))) return TXE_ERR_ARG;
+    for (int i0 = 0; i0 < n_layers; i0 += PREP_MAXL) {
+        PrepMulti m;
+        memset(&m, 0, sizeof(m));
+        m.n = n_layers - i0 < PREP_MAXL ? n_layers - i0 : PREP_MAXL;
+        if (i0 == 0 && rowptr_in && n_nodes > 0) {
+            m.nb_norm = (n_nodes + 64 * FOLD_DG - 1) / (64 * FOLD_DG); m.norm_rowptr = rowptr_in; m.norm_n = n_nodes; m.norm = norm;
+        }
+        int total = 0;
+        for (int i = 0; i < m.n; ++i) {
+            const int rc = fill_prep_gcn(m.a[i], descs[i0 + i]);
+            if (rc) return rc;
+            total += m.a[i].nb_x + m.a[i].nb_m + m.a[i].nb_w;
+            m.nb_end[i] = total;
+        }
+        if (total + m.nb_norm == 0) continue;
+        hipLaunchKernelGGL(gat_prepare_multi_kernel, dim3(total + m.nb_norm), dim3(64 * FOLD_DG), 0, (hipStream_t)stream, m);
+        TXE_CHECK_LAUNCH();
+    }
     return TXE_OK;
 }
 

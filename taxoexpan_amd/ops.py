@@ -804,12 +804,6 @@ class GCNConfig:
         self.n_layers = len(self.out_dims)
 
 
-def gcn_norm(csr, ref):
-    norm = _empty((csr.n_nodes,), ref)
-    call("txe_gcn_norm", ptr(csr.rowptr_in), csr.n_nodes, ptr(norm), _lib.stream_ptr())
-    return norm
-
-
 class _GcnLayerState:
     __slots__ = ("X", "Wp", "mask", "W", "b", "P", "Kh", "Pd", "Kp", "Fo", "Fop", "seed", "cl", "x_dropped")
 
@@ -844,7 +838,6 @@ class GCNStackFunction(torch.autograd.Function):
         states = []
         with _lib.on_device(h.device):
             st_ = _lib.stream_ptr()
-            norm = gcn_norm(csr, h)
             kh = kh0
             for l in range(L):
                 st = _GcnLayerState()
@@ -857,22 +850,37 @@ class GCNStackFunction(torch.autograd.Function):
                 st.X = None
                 states.append(st)
                 kh = st.Fo
-            states[0].X = None if table else _empty((N, states[0].Kp), h)
+            # every layer's input buffer now; ONE launch prepares the whole stack (layer inputs' position / padding columns, packed weights,
+            # keep masks -- none of it depends on a layer below's output) and forms the degree normalisation
+            norm = _empty((max(N, 1),), h)
+            for l, st in enumerate(states):
+                st.X = None if (table and l == 0) else _empty((N, st.Kp), h)
+            todo = [(l, st) for l, st in enumerate(states) if not (table and l == 0)]
+            import ctypes
+            descs = (_lib.GcnPrepareDesc * max(len(todo), 1))()
+            keep = []
+            for d, (l, st) in zip(descs, todo):
+                last = (l == L - 1)
+                kp128 = (st.Kp + 127) // 128 * 128
+                st.Wp = _empty((kp128, st.Fop), h)
+                st.mask = (torch.empty((N, (st.Kh + st.Pd + 31) // 32), dtype=torch.int32, device=h.device)
+                           if cfg.drop_ps[l] > 0.0 else None)
+                # (a first layer on raw features that is not the folded one: only its GEMMs read X -> stored with the dropout applied)
+                st.x_dropped = bool(l == 0 and not (last and collapse) and cfg.drop_ps[l] > 0.0)
+                # (folded into the matcher: the bias rides as one more weight row, behind a column of Z that counts as 1)
+                bias_row = st.b if (last and z_only and st.b is not None) else None
+                keep.append(bias_row)
+                d.h, d.ld_h, d.n_nodes, d.Kh = ptr(h if l == 0 else None), (ld_h if l == 0 else 0), N, st.Kh
+                d.pos, d.P, d.Pd, d.X = ptr(pos if st.P is not None else None), ptr(st.P), st.Pd, ptr(st.X)
+                d.W, d.Fo, d.Wp, d.drop_p, d.seed, d.mask = ptr(st.W), st.Fo, ptr(st.Wp), cfg.drop_ps[l], st.seed, ptr(st.mask)
+                d.x_dropped, d.bias_row = int(st.x_dropped), ptr(bias_row)
+            if todo:
+                call("txe_gcn_layers_prepare", ctypes.cast(descs, ctypes.c_void_p), len(todo), ptr(csr.rowptr_in), csr.n_nodes, ptr(norm), st_)
+            else:
+                call("txe_gcn_norm", ptr(csr.rowptr_in), csr.n_nodes, ptr(norm), st_)
             tws = _tail_ws(h)
             for l, st in enumerate(states):
                 last = (l == L - 1)
-                if not (table and l == 0):          # layer input, packed weights and keep mask: one launch
-                    kp128 = (st.Kp + 127) // 128 * 128
-                    st.Wp = _empty((kp128, st.Fop), h)
-                    st.mask = (torch.empty((N, (st.Kh + st.Pd + 31) // 32), dtype=torch.int32, device=h.device)
-                               if cfg.drop_ps[l] > 0.0 else None)
-                    # (a first layer on raw features that is not the folded one: only its GEMMs read X -> stored with the dropout applied)
-                    st.x_dropped = bool(l == 0 and not (last and collapse) and cfg.drop_ps[l] > 0.0)
-                    # (folded into the matcher: the bias rides as one more weight row, behind a column of Z that counts as 1)
-                    bias_row = st.b if (last and z_only and st.b is not None) else None
-                    call("txe_gcn_layer_prepare", ptr(h if l == 0 else None), ld_h if l == 0 else 0, N, st.Kh,
-                         ptr(pos if st.P is not None else None), ptr(st.P), st.Pd, ptr(st.X), ptr(st.W), st.Fo, ptr(st.Wp),
-                         cfg.drop_ps[l], st.seed, ptr(st.mask), int(st.x_dropped), ptr(bias_row), st_)
                 if last and collapse:
                     G = csr.n_graphs
                     coef, wsum = _empty((max(N, 1),), h), _empty((max(G, 1),), h)
@@ -908,7 +916,6 @@ class GCNStackFunction(torch.autograd.Function):
                 if last:
                     out, ld_out = _empty((N, st.Fo), h), st.Fo
                 else:
-                    states[l + 1].X = _empty((N, states[l + 1].Kp), h)
                     out, ld_out = states[l + 1].X, states[l + 1].Kp
                 slope = cfg.act_slopes[l]
                 call("txe_gcn_aggregate_fwd", ptr(csr.rowptr_in), ptr(csr.col_src), N, ptr(hw), st.Fop, ptr(norm), ptr(st.b),

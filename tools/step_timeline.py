@@ -8,7 +8,7 @@ import glob
 
 import os
 f = sorted(glob.glob("gpurun_out/tl/**/*kernel_trace.csv", recursive=True))[-1]
-FIRST = tuple((os.environ.get("TXE_TL_FIRST") or "gat_prepare_multi,gat_prepare_kernel").split(","))   # the step's first launch (pgcn: gcn_norm)
+FIRST = tuple((os.environ.get("TXE_TL_FIRST") or "gat_prepare_multi,gat_prepare_kernel").split(","))   # the step's first launch
 rows = [dict(name=r["Kernel_Name"].replace("void ", "").replace("txe::", "").split("(")[0][:60], q=r["Queue_Id"], s=int(r["Start_Timestamp"]),
              e=int(r["End_Timestamp"])) for r in csv.DictReader(open(f))]
 rows.sort(key=lambda r: r["s"])

@@ -8,7 +8,7 @@ import weakref
 import torch
 
 from . import _lib
-from ._lib import call, ptr
+from ._lib import call, ptr, pure
 
 LEAKY_SLOPE = 0.01  # F.leaky_relu default, the only activation model.py:25-41 passes
 
@@ -242,7 +242,7 @@ def _gat_table_projection(st, src):
     tab = src.table
     n_tab, Kh, Kp, Fp = tab.shape[0], st.Kh, st.Kp, st.Fp
     s = _lib.stream_ptr()
-    Kt = call("txe_gat_padded_k", Kh, 0)
+    Kt = pure("txe_gat_padded_k", Kh, 0)
     Xt = _empty((n_tab, Kt), tab)
     call("txe_gat_build_x", ptr(tab), tab.stride(0), n_tab, Kh, None, None, 0, ptr(Xt), s)
     Wp = _empty((Fp, Kp), tab)
@@ -269,7 +269,7 @@ def _gcn_table_projection(st, src):
     tab = src.table
     n_tab, Kh, Fop = tab.shape[0], st.Kh, st.Fop
     s = _lib.stream_ptr()
-    Kt = call("txe_gat_padded_k", Kh, 0)
+    Kt = pure("txe_gat_padded_k", Kh, 0)
     Xt = _empty((n_tab, Kt), tab)
     call("txe_gat_build_x", ptr(tab), tab.stride(0), n_tab, Kh, None, None, 0, ptr(Xt), s)
     kp128 = (st.Kp + 127) // 128 * 128
@@ -321,7 +321,7 @@ def _tail_ws(ref):
     key = (ref.device.index, torch.cuda.current_stream(ref.device).cuda_stream)
     t = _tail_ws_cache.get(key)
     if t is None:
-        t = torch.empty(call("txe_gemm_tail_ws_bytes"), dtype=torch.uint8, device=ref.device)
+        t = torch.empty(pure("txe_gemm_tail_ws_bytes"), dtype=torch.uint8, device=ref.device)
         _tail_ws_cache[key] = t
     return t
 
@@ -385,11 +385,11 @@ def _gat_collapse_fwd(csr, st, h, ld_h, pos, rpos, pw, feat_p, attn_p, attn_slop
     alpha, coef = _empty((max(E, 1),), st.X), _empty((max(N, 1),), st.X)
     wsum, Z, hg = _empty((max(G, 1),), st.X), _empty((max(G, 1), st.Kp), st.X), (None if z_only else _empty((G, st.D), st.X))
     gid = torch.empty(max(N, 1), dtype=torch.int32, device=st.X.device)
-    wsb = call("txe_gat_collapse_ws_bytes", N, E, G, st.Kh, st.Pd, st.D, 8)
+    wsb = pure("txe_gat_collapse_ws_bytes", N, E, G, st.Kh, st.Pd, st.D, 8)
     ws = _ws(wsb, st.X)
     Tf = zrow = e_part = None
     if z_only and fold_job is not None and link is not None and N > 0 and G > 0 and not _NO_FOLD_EDOT:
-        nt = call("txe_gat_collapse_e_tiles", N, G, st.Kh, st.Pd)
+        nt = pure("txe_gat_collapse_e_tiles", N, G, st.Kh, st.Pd)
         fw = fold_job(st.Wp, st.D) if nt > 0 else None       # the matcher's runs, V and T, formed now: T rides in the Z sweep
         if fw is not None:
             Tf, zrow, e_part = fw["T"], _fold_job_run_ids(fw, G, st.X), _empty((N, nt), st.X)
@@ -413,7 +413,7 @@ def _gat_collapse_bwd(csr, st, pos, rpos, pw, vocab, feat_p, attn_p, attn_slope,
     d_pw = torch.empty_like(pw) if pw is not None else None
     d_X = _empty((N, st.Kp), st.X)
     v = max(vocab, pw.numel() if pw is not None else 0)
-    wsb = call("txe_gat_collapse_ws_bytes", N, E, G, st.Kh, st.Pd, st.D, max(v, 8))
+    wsb = pure("txe_gat_collapse_ws_bytes", N, E, G, st.Kh, st.Pd, st.D, max(v, 8))
     ws = _ws(wsb, st.X)
     call("txe_gat_collapse_bwd", ptr(csr.rowptr_in), ptr(csr.col_src), ptr(csr.rowptr_out), ptr(csr.col_dst), ptr(csr.pos_out),
          ptr(csr.graph_off), N, E, G, ptr(st.X), st.Kh, st.Pd, ptr(pos if pos is not None else rpos), v, ptr(st.Wp), ptr(st.W),
@@ -434,7 +434,7 @@ def _gat_layer_fwd(csr, st, h, ld_h, pos, out, ld_out, feat_p, attn_p, attn_slop
         T, T2 = _gat_table_projection(st, h)[:2]
         nx_kp = nxt[0].Kp if nxt is not None else 0
         if (T2 is not None and pos is not None and not save and not _NO_TABLE_SWEEP and attn_p == 0.0
-                and call("txe_gat_aggregate_table_supported", H, D, Fp, T2.shape[0], nx_kp) == 1):
+                and pure("txe_gat_aggregate_table_supported", H, D, Fp, T2.shape[0], nx_kp) == 1):
             # the projected rows T[id] + T2[pos] are formed inside the sweep: no [N, Fp] round trip through HBM
             st.Y = st.alpha = None
             call("txe_gat_aggregate_table_fwd", ptr(csr.rowptr_in), ptr(csr.col_src), N, ptr(T), Fp, ptr(_i32(h.index, T.device)), ptr(T2),
@@ -492,7 +492,7 @@ def _gat_dense_bwd(st, pos, vocab, feat_p, d_Y, need_dh, act_on, act_slope, chai
     dW, dal, dar = torch.empty_like(st.W), torch.empty_like(st.al), torch.empty_like(st.ar)
     dP = torch.empty_like(st.P) if st.P is not None else None
     d_X = _empty((N, st.Kp), st.X) if (need_dh or st.Pd > 0) else None
-    wsb = call("txe_gat_dense_ws_bytes", N, st.Kh, st.Pd, st.H, st.D, vocab)
+    wsb = pure("txe_gat_dense_ws_bytes", N, st.Kh, st.Pd, st.H, st.D, vocab)
     ws = _ws(wsb, st.X)
     def run(phases):
         call("txe_gat_dense_bwd", ptr(st.X), N, st.Kh, st.Pd, ptr(pos), vocab, ptr(st.Wp), ptr(st.W), ptr(st.al), ptr(st.ar), st.H, st.D, feat_p,
@@ -529,7 +529,7 @@ def _side_stream(device):
 def _fused_bwd_ok(csr, st, sp):
     """can the folded layer `st`'s backward run fused with the message/reduce backward of the layer below `sp`?"""
     return (not _NO_FUSED_BWD and sp.alpha is not None and sp.H * sp.D == st.Kh and st.cl is not None and csr.n_edges > 0
-            and call("txe_gat_fused_bwd_supported", st.Kh, st.Pd, sp.H, sp.D) == 1)
+            and pure("txe_gat_fused_bwd_supported", st.Kh, st.Pd, sp.H, sp.D) == 1)
 
 
 class FoldLink:
@@ -567,7 +567,7 @@ def _gat_collapse_bwd_fused(csr, st, sp, pos, rpos, pw, vocab, feat_p, attn_p, a
     d_Yp = _empty((N, sp.Fp), st.X)
     dz = _empty((max(E, 1) * sp.H,), st.X)
     v = max(vocab, pw.numel() if pw is not None else 0)
-    wsb = call("txe_gat_collapse_bwd_fused_ws_bytes", N, E, G, st.Kh, st.Pd, st.D, max(v, 8), sp.H)
+    wsb = pure("txe_gat_collapse_bwd_fused_ws_bytes", N, E, G, st.Kh, st.Pd, st.D, max(v, 8), sp.H)
     ws = _ws(wsb, st.X)
     def run(phases):
         call("txe_gat_collapse_bwd_fused", ptr(csr.rowptr_in), ptr(csr.col_src), ptr(csr.rowptr_out), ptr(csr.col_dst), ptr(csr.pos_out),
@@ -640,8 +640,8 @@ class GATStackFunction(torch.autograd.Function):
                 st.W, st.al, st.ar, st.P = (_f32(p) for p in params[4 * l:4 * l + 4])
                 st.H, st.D, st.Kh = cfg.heads[l], cfg.out_dims[l], kh
                 st.Pd = 0 if st.P is None else st.P.shape[1]
-                st.Kp = call("txe_gat_padded_k", st.Kh, st.Pd)
-                st.Fp = call("txe_gat_padded_f", st.H, st.D)
+                st.Kp = pure("txe_gat_padded_k", st.Kh, st.Pd)
+                st.Fp = pure("txe_gat_padded_f", st.H, st.D)
                 st.seed = cfg.seed + 16 * l
                 st.X = None
                 states.append(st)
@@ -844,8 +844,8 @@ class GCNStackFunction(torch.autograd.Function):
                 st.W, st.b, st.P = (_f32(p) for p in params[3 * l:3 * l + 3])
                 st.Kh, st.Fo = kh, cfg.out_dims[l]
                 st.Pd = 0 if st.P is None else st.P.shape[1]
-                st.Kp = call("txe_gat_padded_k", st.Kh, st.Pd)
-                st.Fop = call("txe_gcn_padded_f", st.Fo)
+                st.Kp = pure("txe_gat_padded_k", st.Kh, st.Pd)
+                st.Fop = pure("txe_gcn_padded_f", st.Fo)
                 st.seed = cfg.seed + 16 * l
                 st.X = None
                 states.append(st)
@@ -886,7 +886,7 @@ class GCNStackFunction(torch.autograd.Function):
                     coef, wsum = _empty((max(N, 1),), h), _empty((max(G, 1),), h)
                     gid = torch.empty(max(N, 1), dtype=torch.int32, device=h.device)
                     Z, out = _empty((max(G, 1), st.Kp), h), (None if z_only else _empty((G, st.Fo), h))
-                    wsb = call("txe_gcn_collapse_ws_bytes", N, G, st.Kh, st.Pd, st.Fo, 8)
+                    wsb = pure("txe_gcn_collapse_ws_bytes", N, G, st.Kh, st.Pd, st.Fo, 8)
                     ws = _ws(wsb, h)
                     call("txe_gcn_collapse_fwd", ptr(csr.rowptr_out), ptr(csr.col_dst), ptr(csr.graph_off), N, G, ptr(st.X), st.Kh, st.Pd,
                          ptr(st.Wp), st.Fo, ptr(st.b), cfg.drop_ps[l], ptr(st.mask), ptr(norm), ptr(rpos), ptr(pwf), ptr(coef), ptr(wsum),
@@ -981,7 +981,7 @@ class GCNStackFunction(torch.autograd.Function):
                     dP = torch.empty_like(st.P) if st.P is not None else None
                     d_pw = torch.empty_like(ctx.pwf) if ctx.pwf is not None else None
                     v = max(cfg.vocab, ctx.pwf.numel() if ctx.pwf is not None else 0)
-                    wsb = call("txe_gcn_collapse_ws_bytes", N, G, st.Kh, st.Pd, st.Fo, max(v, 8))
+                    wsb = pure("txe_gcn_collapse_ws_bytes", N, G, st.Kh, st.Pd, st.Fo, max(v, 8))
                     ws = _ws(wsb, d_out)
                     call("txe_gcn_collapse_bwd", ptr(csr.rowptr_in), ptr(csr.col_src), ptr(csr.graph_off), N, G, ptr(st.X), st.Kh, st.Pd,
                          ptr(pos if st.P is not None else ctx.rpos), v, ptr(st.Wp), st.Fo, cfg.drop_ps[l], ptr(st.mask), ptr(norm),
@@ -994,7 +994,7 @@ class GCNStackFunction(torch.autograd.Function):
                     continue
                 d_hw = _empty((N, st.Fop), d_out)
                 d_b = torch.empty_like(st.b) if st.b is not None else None
-                wsb = call("txe_gcn_aggregate_bwd_ws_bytes", N, st.Fo)
+                wsb = pure("txe_gcn_aggregate_bwd_ws_bytes", N, st.Fo)
                 ws = _ws(wsb, d_out)
                 call("txe_gcn_aggregate_bwd", ptr(csr.rowptr_out), ptr(csr.col_dst), N, ptr(d_pre), ld_dpre, ptr(norm), st.Fo, ptr(d_hw),
                      st.Fop, ptr(d_b), ptr(ws), wsb, st_)
@@ -1003,7 +1003,7 @@ class GCNStackFunction(torch.autograd.Function):
                 d_X = _empty((N, st.Kp), d_out) if (need_dh or st.Pd > 0) else None
                 dW = torch.empty_like(st.W)
                 dP = torch.empty_like(st.P) if st.P is not None else None
-                wsb2 = call("txe_gcn_dense_ws_bytes", N, st.Kh, st.Pd, st.Fo, cfg.vocab)
+                wsb2 = pure("txe_gcn_dense_ws_bytes", N, st.Kh, st.Pd, st.Fo, cfg.vocab)
                 ws2 = _ws(wsb2, d_out)
                 call("txe_gcn_dense_bwd", ptr(st.X), N, st.Kh, st.Pd, ptr(pos if st.P is not None else None), cfg.vocab, ptr(st.Wp), st.Fo,
                      cfg.drop_ps[l], ptr(st.mask), ptr(d_hw), int(need_dh), int(act_on), (cfg.act_slopes[l - 1] if act_on else 1.0),
@@ -1113,7 +1113,7 @@ class LinearFunction(torch.autograd.Function):
         dW = torch.empty_like(Wf)
         db = _empty((O,), y) if has_b else None
         with _lib.on_device(y.device):
-            wsb = call("txe_linear_bwd_ws_bytes", G, l, r, O)
+            wsb = pure("txe_linear_bwd_ws_bytes", G, l, r, O)
             ws = _ws(wsb, y)
             call("txe_linear_bwd", ptr(x1), ld1, l, ptr(x2), ld2, r, G, ptr(Wf), O, act, ptr(y), ptr(dy), ptr(dx1), l, ptr(dx2), r, ptr(dW),
                  ptr(db), ptr(ws), wsb, _lib.stream_ptr())
@@ -1215,13 +1215,13 @@ class BilinearPairFunction(torch.autograd.Function):
         dW = torch.empty_like(Wf)
         with _lib.on_device(e1.device):
             if query_side:
-                wsb = call("txe_bilinear_query_bwd_ws_bytes", G, l, r)
+                wsb = pure("txe_bilinear_query_bwd_ws_bytes", G, l, r)
                 ws = _ws(wsb, e1)
                 call("txe_bilinear_query_bwd", ptr(e1), ld1, ptr(e2), ld2, G, l, r, apply_exp, ptr(U), ptr(s), ptr(ds), ptr(d_e1), l, ptr(dW),
                      ptr(ws), wsb, _lib.stream_ptr())
                 return d_e1, None, dW.reshape(wshape), None, None
             d_e2 = _empty((G, r), e1)
-            wsb = call("txe_bilinear_pair_bwd_ws_bytes", G, l, r)
+            wsb = pure("txe_bilinear_pair_bwd_ws_bytes", G, l, r)
             ws = _ws(wsb, e1)
             call("txe_bilinear_pair_bwd", ptr(e1), ld1, ptr(e2), ld2, G, l, r, ptr(Wf), apply_exp, ptr(U), ptr(s), ptr(ds), ptr(d_e1),
                  l, ptr(d_e2), r, ptr(dW), ptr(ws), wsb, _lib.stream_ptr())
@@ -1300,7 +1300,7 @@ class BilinearRunsFunction(torch.autograd.Function):
         d_e1 = _empty((G, l), e1)
         dW = _empty((l, r), e1)
         with _lib.on_device(e1.device):
-            wsb = call("txe_bilinear_runs_bwd_ws_bytes", U, l, r)
+            wsb = pure("txe_bilinear_runs_bwd_ws_bytes", U, l, r)
             ws = _ws(wsb, e1)
             call("txe_bilinear_runs_bwd", ptr(e1), ld1, ptr(rows), ldq, ptr(run_off), G, U, l, r, apply_exp, ptr(V), ptr(s), ptr(ds), ptr(d_e1), l,
                  ptr(dW), ptr(ws), wsb, _lib.stream_ptr())
@@ -1353,7 +1353,7 @@ class BilinearStackedRunsFunction(torch.autograd.Function):
         d_e1 = _empty((G, l), e1)
         dW = _empty((l, r), e1)
         with _lib.on_device(e1.device):
-            wsb = call("txe_bilinear_stacked_bwd_ws_bytes", G, l, r)
+            wsb = pure("txe_bilinear_stacked_bwd_ws_bytes", G, l, r)
             ws = _ws(wsb, e1)
             call("txe_bilinear_stacked_bwd", ptr(e1), ld1, ptr(e2), ld2, ptr(run_off), ptr(n_runs), G, l, r, apply_exp, ptr(V), ptr(s), ptr(ds),
                  ptr(d_e1), l, ptr(dW), ptr(ws), wsb, _lib.stream_ptr())
@@ -1375,7 +1375,7 @@ def folded_graph_vector_ok(csr, cfg):
     if _NO_MATCH_FOLD or _NO_FUSED_BWD or cfg.n_layers < 2 or cfg.heads[-1] != 1 or csr.n_edges <= 0 or csr.n_graphs <= 0 or csr.n_nodes <= 0:
         return False
     kh = cfg.heads[-2] * cfg.out_dims[-2]
-    return call("txe_gat_fused_bwd_supported", kh, cfg.pos_dims[-1], cfg.heads[-2], cfg.out_dims[-2]) == 1
+    return pure("txe_gat_fused_bwd_supported", kh, cfg.pos_dims[-1], cfg.heads[-2], cfg.out_dims[-2]) == 1
 
 
 def folded_graph_linear(Z, Wp, D, link=None):
@@ -1736,7 +1736,7 @@ def score_topk_block(Q, U, apply_exp, k, larger_is_better=True, idx_base=0, q_pa
     if nq == 0:
         return idx, key
     with _lib.on_device(Q.device):
-        nt = call("txe_score_topk_tiles", G)
+        nt = pure("txe_score_topk_tiles", G)
         need = nq * nt * k
         sc = scratch if scratch is not None else {}
         if sc.get("n", 0) < need or sc.get("nq", 0) < nq or sc["key"].device != Q.device:

@@ -93,6 +93,12 @@ int txe_gather_add_rows(const float* T, long long ld_t, const int* row, const fl
 size_t txe_gat_dense_ws_bytes(int n_nodes, int Kh, int Pd, int H, int D, int vocab);
 int txe_gat_dense_fwd(const float* X, int n_nodes, int Kh, int Pd, const float* Wp, int H, int D, float feat_drop_p,
                       const unsigned* mask, float* Y, void* ws, size_t ws_bytes, void* stream);
+/* txe_gat_dense_fwd on the bf16 matrix pipe in fp32 accuracy (txe_gemm_nt_split below): X must be a PLAIN operand (dropout already
+ * applied -- txe_gat_prepare_desc.x_dropped -- or none).  Xs / Ws = packed planes of X (side 0) / Wp (side 1), or NULL: they are then
+ * packed into ws (txe_gat_dense_split_ws_bytes). */
+size_t txe_gat_dense_split_ws_bytes(int n_nodes, int Kh, int Pd, int H, int D);
+int txe_gat_dense_fwd_split(const float* X, int n_nodes, int Kh, int Pd, const float* Wp, int H, int D, const void* Xs, const void* Ws,
+                            float* Y, void* ws, size_t ws_bytes, void* stream);
 int txe_gat_dense_bwd(const float* X, int n_nodes, int Kh, int Pd, const int* pos, int vocab, const float* Wp, const float* W,
                       const float* attn_l, const float* attn_r, int H, int D, float feat_drop_p, const unsigned* mask, const float* d_Y,
                       int need_dh, int act_on, float act_slope, float* d_X, float* dW, float* d_attn_l, float* d_attn_r, float* dP,
@@ -427,6 +433,16 @@ int txe_info_nce(const float* x, long long ld_x, int B, int Cc, const long long*
 int txe_adam_step(int n_tensors, float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
                   float* const* max_exp_avg_sq, const long long* numel, double lr, double beta1, double beta2, double eps,
                   double weight_decay, long long step, void* stream);
+
+/* ---- fp32 products on the bf16 matrix pipe (replaces the fp32-MFMA route of model_zoo.py:83 `self.fc(...)` for the first
+ * layer's projection).  A packed operand holds every fp32 element as the EXACT sum of three bf16 numbers (three planes, stored as 1-KB
+ * MFMA fragments: csrc/txe_gemm_split.h); txe_gemm_nt_split forms C [M][N] = A [M][K] B[N][K]^T from six of the nine plane products with
+ * fp32 accumulation -- the dropped terms are below the rounding of one fp32 multiply.
+ * side 0 = the operand whose rows are C's rows, side 1 = the operand whose rows are C's columns. */
+size_t txe_split_packed_bytes(int rows, int cols);
+int txe_split_pack(const float* src, long long ld, int rows, int cols, int side, void* packed, void* stream);
+int txe_gemm_split_variant(int v);   /* tuning: tile / stage variant of the next products */
+int txe_gemm_nt_split(const void* A_packed, const void* B_packed, int M, int N, int K, float* C, long long ldc, void* stream);
 
 /* host-side evaluation of the counter-based dropout hash the kernels inline (uniform in [0,1)); keep = u >= p */
 float txe_dropout_uniform_host(unsigned long long seed, unsigned long long idx);

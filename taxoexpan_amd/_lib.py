@@ -23,6 +23,8 @@ SIGNATURES = {
     "txe_gather_add_rows": (I, [P, L, P, P, L, P, L, I, P, L, P]),
     "txe_gat_dense_ws_bytes": (SZ, [I, I, I, I, I, I]),
     "txe_gat_dense_fwd": (I, [P, I, I, I, P, I, I, F, P, P, P, SZ, P]),
+    "txe_gat_dense_split_ws_bytes": (SZ, [I, I, I, I, I]),
+    "txe_gat_dense_fwd_split": (I, [P, I, I, I, P, I, I, P, P, P, P, SZ, P]),
     "txe_gat_dense_bwd": (I, [P, I, I, I, P, I, P, P, P, P, I, I, F, P, P, I, I, F, P, P, P, P, P, I, I, P, P, SZ, P]),
     "txe_gat_tail_flush": (I, [P, P]),
     "txe_zero_cols": (I, [P, L, I, I, I, P]),
@@ -109,6 +111,10 @@ SIGNATURES = {
     "txe_profile_stream": (I, [I, P]),
     "txe_stream_order": (I, [P, P]),
     "txe_copy_stream": (I, [P, P, L, P]),
+    "txe_split_packed_bytes": (SZ, [I, I]),
+    "txe_split_pack": (I, [P, L, I, I, I, P, P]),
+    "txe_gemm_split_variant": (I, [I]),
+    "txe_gemm_nt_split": (I, [P, P, I, I, I, P, L, P]),
 }
 
 class GatPrepareDesc(C.Structure):

@@ -10,9 +10,9 @@ import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SOURCES = ["txe_gemm_nt.hip", "txe_gemm_nn.hip", "txe_gemm_tn.hip", "txe_gat.hip", "txe_gcn.hip", "txe_project.hip", "txe_dxpos.hip", "txe_readout.hip", "txe_match.hip",
+SOURCES = ["txe_gemm_nt.hip", "txe_gemm_nn.hip", "txe_gemm_tn.hip", "txe_gemm_split.hip", "txe_gat.hip", "txe_gcn.hip", "txe_project.hip", "txe_dxpos.hip", "txe_readout.hip", "txe_match.hip",
            "txe_graph.hip", "txe_rank.hip", "txe_profile.hip", "txe_egonet.hip", "txe_optim.hip", "txe_loss.hip"]
-HEADERS = ["txe_common.h", "txe_gemm.h", "txe_gather.h", "txe_colsum.h", "txe_dxpos.h", "txe_gemm_tnlds.h", "txe_skinny.h"]
+HEADERS = ["txe_common.h", "txe_gemm.h", "txe_gather.h", "txe_colsum.h", "txe_dxpos.h", "txe_gemm_tnlds.h", "txe_skinny.h", "txe_gemm_split.h"]
 LIB = os.path.join(HERE, "libtxe.so")
 OBJ_DIR = os.path.join(HERE, "build")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

@@ -1,0 +1,231 @@
+// C = A B^T in fp32 accuracy on the bf16 matrix pipe (three-plane operands, six plane products: txe_gemm_split.h)
+#include "txe_common.h"
+#include "txe_gemm_split.h"
+
+namespace txe {
+
+typedef __attribute__((ext_vector_type(8))) short bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16s;
+
+// ---- packing: fp32 [rows][ld] -> three bf16 planes in fragment order --------------------------------------------------------------
+// one thread per (fragment block rb, k-tile kt, lane): reads 8 consecutive floats of its slot's row, writes 16 bytes per plane
+__global__ __launch_bounds__(256) void split_pack_kernel(const float* __restrict__ src, long long ld, int rows, int cols, int side, int nrb,
+                                                         int nkt, uint4* __restrict__ dst) {
+    const long long total = (long long)nrb * nkt * 64;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int l = (int)(i & 63);
+        const long long f = i >> 6;                       // fragment pair index rb * nkt + kt
+        const int kt = (int)(f % nkt), rb = (int)(f / nkt);
+        const int row = split_slot_row(side, rb, l & 31), k0 = kt * SPL_KT + 8 * (l >> 5);
+        float x[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) x[q] = 0.f;
+        if (row < rows) {
+            const float* p = src + (long long)row * ld + k0;
+            if (k0 + 7 < cols && ((reinterpret_cast<uintptr_t>(p) & 15) == 0)) {
+                const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+                x[0] = a.x; x[1] = a.y; x[2] = a.z; x[3] = a.w; x[4] = b.x; x[5] = b.y; x[6] = b.z; x[7] = b.w;
+            } else {
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+                    if (k0 + q < cols) x[q] = p[q];
+            }
+        }
+        uint4 w1, w2, w3;
+        split3x8(x, w1, w2, w3);
+        uint4* o = dst + f * 3 * 64 + l;
+        o[0] = w1; o[64] = w2; o[128] = w3;
+    }
+}
+
+// ---- the product -----------------------------------------------------------------------------------------------------------------
+// A (64 MI) x 128 tile per workgroup of four waves (2 x 2; a wave owns MI x 2 MFMA blocks of 32 x 32: 16 MI x 2 accumulator registers);
+// k-tiles of 16 columns: (2 MI + 4) x 3 fragments per stage, NST stages in a ring, every wave copies a quarter of a stage's fragments
+// global -> LDS directly per k-tile, reads 3 (MI + 2) with ds_read_b128 and issues 12 MI MFMAs.
+struct SplitGemm {
+    const char* A; const char* B;     // packed operands
+    int nkt;                          // k-tiles of 16
+    float* C; long long ldc; int M, N;
+    int nbm, nbn;
+};
+
+template <int MI, int NST, int MINB>
+__global__ __launch_bounds__(256, MINB) void gemm_nt_split_kernel(const SplitGemm p) {
+    constexpr int NA = 2 * MI, NB = 4;                      // A / B fragment blocks per tile
+    constexpr int NF = 3 * (NA + NB), CP = NF / 4;          // fragments per stage, copies per wave and k-tile
+    static_assert(NF % 4 == 0, "fragments per wave");
+    constexpr int STAGE_U4 = NF * 64;
+    // one LDS object per stage
+    __shared__ __attribute__((aligned(16))) uint4 st0[STAGE_U4];
+    __shared__ __attribute__((aligned(16))) uint4 st1[STAGE_U4];
+    __shared__ __attribute__((aligned(16))) uint4 st2[NST == 3 ? STAGE_U4 : 1];
+    typedef __attribute__((address_space(3))) uint4 lds_u4;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), l = threadIdx.x & 63;
+    const int lb = xcd_remap(blockIdx.x, gridDim.x);
+    const int tm = lb / p.nbn, tn = lb % p.nbn;
+    const int wm = w >> 1, wn = w & 1;
+    const int nkt = p.nkt;
+    // this wave's copies: fragments f = CP w + q of the stage; f < 3 NA: A block f / 3, plane f % 3, else B block (f - 3 NA) / 3.
+    // Source of k-tile kt: fragment (block, kt, plane) of the packed operand (wave-uniform base + lane * 16)
+    const char* gsrc[CP];
+#pragma unroll
+    for (int q = 0; q < CP; ++q) {
+        const int f = CP * w + q;
+        const bool isa = f < 3 * NA;
+        const int blk = isa ? f / 3 : (f - 3 * NA) / 3, pl = isa ? f % 3 : (f - 3 * NA) % 3;
+        const char* base = isa ? p.A : p.B;
+        const long long b0 = isa ? (long long)NA * tm + blk : (long long)NB * tn + blk;
+        gsrc[q] = base + (b0 * nkt) * (3 * SPL_FRAG_BYTES) + pl * SPL_FRAG_BYTES;
+    }
+    const unsigned lane_off = l * 16;
+
+    f32x16s acc[MI][2];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+// (inline asm: hipcc's wait-count pass treats every pending LDS-direct copy as a hazard for every later ds_read and turns the ring into
+//  vmcnt(0) -- copy, wait, compute -- however the stages are declared; issued from asm the copies are invisible to it and the waits
+//  below are the only ones; nothing else in this kernel uses M0 -- gfx9 DS instructions do not)
+#define TXE_SP_COPY(g_, d_)                                                                                           \
+    asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(lane_off), "s"(g_), "s"((unsigned)(uintptr_t)(d_)) : "memory");
+#define TXE_SP_ISSUE(st_, kt_)                                                                                        \
+    {                                                                                                                \
+        const long long ko = (long long)min((kt_), nkt - 1) * (3 * SPL_FRAG_BYTES);                                  \
+        lds_u4* d0 = (lds_u4*)(st_) + (CP * w) * 64;                                                                 \
+        _Pragma("unroll") for (int q = 0; q < CP; ++q) TXE_SP_COPY(gsrc[q] + ko, d0 + q * 64)                        \
+    }
+#define TXE_SP_MFMA(pa_, pb_)                                                                                         \
+    _Pragma("unroll") for (int i = 0; i < MI; ++i)                                                                   \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                                \
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][pa_], fb[j][pb_], acc[i][j], 0, 0, 0);
+#define TXE_SP_COMPUTE(st_)                                                                                           \
+    {                                                                                                                \
+        bf16x8 fa[MI][3], fb[2][3];                                                                                  \
+        _Pragma("unroll") for (int i = 0; i < MI; ++i)                                                               \
+            _Pragma("unroll") for (int q = 0; q < 3; ++q) {                                                          \
+                const uint4 t = (st_)[((MI * wm + i) * 3 + q) * 64 + l];                                             \
+                fa[i][q] = __builtin_bit_cast(bf16x8, t);                                                            \
+            }                                                                                                        \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                                \
+            _Pragma("unroll") for (int q = 0; q < 3; ++q) {                                                          \
+                const uint4 t = (st_)[(3 * NA + (2 * wn + j) * 3 + q) * 64 + l];                                     \
+                fb[j][q] = __builtin_bit_cast(bf16x8, t);                                                            \
+            }                                                                                                        \
+        TXE_SP_MFMA(2, 0) TXE_SP_MFMA(0, 2) TXE_SP_MFMA(1, 1) TXE_SP_MFMA(1, 0) TXE_SP_MFMA(0, 1) TXE_SP_MFMA(0, 0)  \
+    }
+    // this wave's copies of the stage about to be read have landed (three stages: the CP of the stage after it may still be in flight);
+    // the barrier then says the same of every wave's, and that every wave is done reading the stage the next copies overwrite
+#define TXE_SP_SYNC()                                                                                                 \
+    {                                                                                                                \
+        if constexpr (NST == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CP) : "memory");                            \
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                        \
+        __syncthreads();                                                                                             \
+    }
+#define TXE_SP_STEP(cur_, nxt_, kt_)                                                                                  \
+    TXE_SP_SYNC()                                                                                                    \
+    TXE_SP_ISSUE(nxt_, kt_)                                                                                          \
+    __builtin_amdgcn_sched_barrier(0);                                                                               \
+    TXE_SP_COMPUTE(cur_)                                                                                             \
+    __builtin_amdgcn_sched_barrier(0);
+
+    TXE_SP_ISSUE(st0, 0)
+    if constexpr (NST == 3) {
+        TXE_SP_ISSUE(st1, 1)
+        for (int t = 0; t < nkt; t += 3) {
+            TXE_SP_STEP(st0, st2, t + 2)
+            if (t + 1 >= nkt) break;
+            TXE_SP_STEP(st1, st0, t + 3)
+            if (t + 2 >= nkt) break;
+            TXE_SP_STEP(st2, st1, t + 4)
+        }
+    } else {
+        for (int t = 0; t < nkt; t += 2) {
+            TXE_SP_STEP(st0, st1, t + 1)
+            if (t + 1 >= nkt) break;
+            TXE_SP_STEP(st1, st0, t + 2)
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the clamped copies past the last k-tile have landed too
+#undef TXE_SP_STEP
+#undef TXE_SP_SYNC
+#undef TXE_SP_COMPUTE
+#undef TXE_SP_MFMA
+#undef TXE_SP_ISSUE
+#undef TXE_SP_COPY
+
+    // accumulator register e of block (i, j): row 32 i + (e & 3) + 8 (e >> 2) + 4 (lane >> 5), slot lane & 31 of B fragment 2 wn + j =
+    // column 64 wn + 2 (lane & 31) + j of the tile
+    const int c0 = tn * SPL_BN + 64 * wn + 2 * (l & 31);
+    const int r0 = tm * (64 * MI) + 32 * MI * wm + 4 * (l >> 5);
+    const bool vec = ((p.ldc & 1) == 0) && ((reinterpret_cast<uintptr_t>(p.C) & 7) == 0);
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int m = r0 + 32 * i + (e & 3) + 8 * (e >> 2);
+            if (m < p.M) {
+                float* dst = p.C + (long long)m * p.ldc + c0;
+                if (vec && c0 + 1 < p.N) *reinterpret_cast<float2*>(dst) = make_float2(acc[i][0][e], acc[i][1][e]);
+                else {
+                    if (c0 < p.N) dst[0] = acc[i][0][e];
+                    if (c0 + 1 < p.N) dst[1] = acc[i][1][e];
+                }
+            }
+        }
+}
+
+int g_split_variant = 0;
+
+int split_pack_launch(const float* src, long long ld, int rows, int cols, int side, void* packed, hipStream_t stream) {
+    if (!src || !packed || rows < 1 || cols < 1 || ld < cols || side < 0 || side > 1) return TXE_ERR_ARG;
+    const int nrb = ((rows + 255) / 256) * 8, nkt = (cols + SPL_KT - 1) / SPL_KT;
+    const long long total = (long long)nrb * nkt * 64;
+    const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    ProfScope prof("split_pack_kernel", stream, 10.0 * rows * (double)cols, 1);
+    hipLaunchKernelGGL(split_pack_kernel, dim3(blocks), dim3(256), 0, stream, src, ld, rows, cols, side, nrb, nkt, (uint4*)packed);
+    TXE_CHECK_LAUNCH();
+    return TXE_OK;
+}
+
+int gemm_nt_split_launch(const void* Ap, const void* Bp, int M, int N, int K, float* C, long long ldc, double alg_flops, hipStream_t stream) {
+    if (!Ap || !Bp || !C || M < 1 || N < 1 || K < 1 || ldc < N) return TXE_ERR_ARG;
+    SplitGemm p;
+    p.A = (const char*)Ap; p.B = (const char*)Bp; p.nkt = (K + SPL_KT - 1) / SPL_KT;
+    p.C = C; p.ldc = ldc; p.M = M; p.N = N;
+    const int v = g_split_variant & 15;
+    const int bm = (v == 2 || v == 3) ? 256 : 128;
+    p.nbm = (M + bm - 1) / bm; p.nbn = (N + SPL_BN - 1) / SPL_BN;
+    ProfScope prof("gemm_nt_split_kernel", stream, alg_flops > 0.0 ? alg_flops : 2.0 * M * (double)N * K, 0);
+    const dim3 grid(p.nbm * p.nbn), blk(256);
+    if (g_split_variant & 16) p.M = 0;                  // (timing experiment: no C stores)
+    if (v == 0) hipLaunchKernelGGL((gemm_nt_split_kernel<2, 3, 2>), grid, blk, 0, stream, p);
+    else if (v == 1) hipLaunchKernelGGL((gemm_nt_split_kernel<2, 2, 3>), grid, blk, 0, stream, p);
+    else if (v == 2) hipLaunchKernelGGL((gemm_nt_split_kernel<4, 2, 2>), grid, blk, 0, stream, p);
+    else if (v == 3) hipLaunchKernelGGL((gemm_nt_split_kernel<4, 3, 1>), grid, blk, 0, stream, p);
+    else if (v == 4) hipLaunchKernelGGL((gemm_nt_split_kernel<2, 2, 2>), grid, blk, 0, stream, p);
+    else return TXE_ERR_ARG;
+    TXE_CHECK_LAUNCH();
+    return TXE_OK;
+}
+
+}  // namespace txe
+using namespace txe;
+extern "C" {
+
+size_t txe_split_packed_bytes(int rows, int cols) { return (rows < 1 || cols < 1) ? 0 : split_packed_bytes(rows, cols); }
+
+int txe_split_pack(const float* src, long long ld, int rows, int cols, int side, void* packed, void* stream) {
+    return split_pack_launch(src, ld, rows, cols, side, packed, (hipStream_t)stream);
+}
+
+int txe_gemm_split_variant(int v) { g_split_variant = v; return TXE_OK; }
+
+int txe_gemm_nt_split(const void* Ap, const void* Bp, int M, int N, int K, float* C, long long ldc, void* stream) {
+    return gemm_nt_split_launch(Ap, Bp, M, N, K, C, ldc, 0.0, (hipStream_t)stream);
+}
+
+}  // extern "C"

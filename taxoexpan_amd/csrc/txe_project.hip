@@ -17,6 +17,7 @@
 #include "txe_gather.h"
 #include "txe_colsum.h"
 #include "txe_dxpos.h"
+#include "txe_gemm_split.h"
 
 namespace txe {
 
@@ -840,6 +841,41 @@ int txe_gat_dense_fwd(const float* X, int n_nodes, int Kh, int Pd, const float* 
     E.k_valid = Kh + Pd;                                             // (X and Wp carry zeros behind it: txe_gat_layers_prepare / pack_w)
     const bool tail_ok = ws && ws_bytes >= gemm_tail_ws_bytes();
     return gemm_nt(A, B, E, n_nodes, Fe, Kp, 1, (hipStream_t)stream, tail_ok ? ws : nullptr, tail_ok ? ws_bytes : 0);
+}
+
+// The same product on the bf16 matrix pipe (txe_gemm_split.h: three bf16 planes per fp32 operand, six plane products, fp32
+// accumulation -- fp32 accuracy at 6/16 of the fp32 MFMA's time).  X is a PLAIN operand here: dropout(X) already applied
+// (txe_gat_prepare_desc.x_dropped) or no dropout.  Xs / Ws: the packed planes of X (side 0) / Wp (side 1) when the preparation launch
+// wrote them (txe_gat_prepare_desc.Xs / .Ws), else NULL -- they are then packed here, into ws.
+size_t txe_gat_dense_split_ws_bytes(int n_nodes, int Kh, int Pd, int H, int D) {
+    if (n_nodes < 1 || Kh < 1 || Pd < 0 || H < 1 || D < 1) return 0;
+    const int Fp = round_up(H * D + 2 * H, 128), Kp = round_up(Kh + Pd, 32);
+    return align_up(split_packed_bytes(n_nodes, Kp), 256) + align_up(split_packed_bytes(Fp, Kp), 256);
+}
+int txe_gat_dense_fwd_split(const float* X, int n_nodes, int Kh, int Pd, const float* Wp, int H, int D, const void* Xs, const void* Ws,
+                            float* Y, void* ws, size_t ws_bytes, void* stream) {
+    if (n_nodes < 0 || Kh < 1 || Pd < 0 || H < 1 || D < 1 || !Y || (!Xs && !X) || (!Ws && !Wp)) return TXE_ERR_ARG;
+    if (n_nodes == 0) return TXE_OK;
+    const int Fe = H * D + 2 * H, Fp = round_up(Fe, 128), Kp = round_up(Kh + Pd, 32);
+    hipStream_t s = (hipStream_t)stream;
+    char* w = (char*)ws;
+    size_t off = 0;
+    int rc;
+    if (!Xs) {
+        const size_t b = align_up(split_packed_bytes(n_nodes, Kp), 256);
+        if (!ws || ws_bytes < off + b) return TXE_ERR_WORKSPACE;
+        rc = split_pack_launch(X, Kp, n_nodes, Kp, 0, w + off, s);
+        if (rc) return rc;
+        Xs = w + off; off += b;
+    }
+    if (!Ws) {
+        const size_t b = align_up(split_packed_bytes(Fp, Kp), 256);
+        if (!ws || ws_bytes < off + b) return TXE_ERR_WORKSPACE;
+        rc = split_pack_launch(Wp, Kp, Fp, Kp, 1, w + off, s);
+        if (rc) return rc;
+        Ws = w + off; off += b;
+    }
+    return gemm_nt_split_launch(Xs, Ws, n_nodes, Fe, Kp, Y, Fp, 2.0 * n_nodes * (double)Fe * (Kh + Pd), s);
 }
 
 // Backward of txe_gat_dense_fwd.  d_Y [N][Fp] must have ZERO padding columns [F+2H, Fp).

@@ -48,6 +48,7 @@ _NO_MATCH_FOLD = False      # the graph vector hg = Z W^T is always formed (neve
 _NO_FOLD_EDOT = False       # the folded matcher's T does not ride in the Z sweep: backward runs its <dZ, X> sweep
 _NO_FUSED_BWD = False       # the folded layer's backward as the unfused chain (d_X' materialised)
 _NO_QUERY_RUNS = False      # stacked query rows always take the GEMM form of the bilinear match
+_NO_SPLIT_GEMM = False      # the first layer's projection on the fp32 MFMA instead of the bf16 pipe's six plane products
 _NO_TAIL_CHAIN = False      # every layer's last reduction launch in place instead of chained into the bottom layer's
 _I32_MEMO = {}       # id(source tensor) -> (weakref, version, device, int32 copy): `pos` is converted once per batch, not once per module
 
@@ -450,8 +451,15 @@ def _gat_layer_fwd(csr, st, h, ld_h, pos, out, ld_out, feat_p, attn_p, attn_slop
         st.Y = _empty((N, Fp), st.X)
         tws = _tail_ws(st.X)
         dropped = getattr(st, "x_dropped", False)
-        call("txe_gat_dense_fwd", ptr(st.X), N, Kh, Pd, ptr(st.Wp), H, D, 0.0 if dropped else feat_p, None if dropped else ptr(st.mask), ptr(st.Y),
-             ptr(tws), tws.numel(), s)
+        if (dropped or feat_p == 0.0) and not _NO_SPLIT_GEMM:      # X is a plain operand: fp32-accurate product on the bf16 pipe
+            wsb = pure("txe_gat_dense_split_ws_bytes", N, Kh, Pd, H, D)
+            sws = _ws(wsb, st.X)
+            call("txe_gat_dense_fwd_split", ptr(st.X), N, Kh, Pd, ptr(st.Wp), H, D, None, None, ptr(st.Y), ptr(sws), wsb, s)
+            note_route("proj", "bf16x6")
+        else:
+            call("txe_gat_dense_fwd", ptr(st.X), N, Kh, Pd, ptr(st.Wp), H, D, 0.0 if dropped else feat_p, None if dropped else ptr(st.mask), ptr(st.Y),
+                 ptr(tws), tws.numel(), s)
+            note_route("proj", "fp32")
         _launch_pending_prefetch()
     st.alpha = _empty((max(csr.n_edges, 1), H), st.Y) if save else None
     call("txe_gat_aggregate_fwd", ptr(csr.rowptr_in), ptr(csr.col_src), N, ptr(st.Y), Fp, ptr(st.Y) + 4 * F, ptr(st.Y) + 4 * (F + H), Fp,

@@ -41,6 +41,14 @@ MAG = dict(in_dim=250, hidden_dim=500, out_dim=500, pos_dim=50, num_layers=1, he
            hidden_drop=0.1, out_drop=0.1)
 N_QUERIES, NEG = 128, 31
 PEAK_MFMA_F32 = 157.3e12      # MI355X_MICROARCH.md: fp32 MFMA = fp32 vector peak, no TF32 on gfx950
+PEAK_MFMA_BF16 = 2.5e15       # ... dense bf16 MFMA
+SPLIT_PRODUCTS = 6            # csrc/txe_gemm_split.h: an fp32 product = six bf16 plane products (fp32-accurate) -> roof 2.5 PF / 6 per fp32 flop
+
+
+def mfma_peak(kernel_name):
+    """the matrix-pipe roof a kernel's ALGORITHMIC fp32 flops are priced against: the fp32 MFMA's, or -- for the products that run as six
+    bf16 plane products per fp32 product (gemm_*_split_kernel) -- a sixth of the bf16 pipe's"""
+    return PEAK_MFMA_BF16 / SPLIT_PRODUCTS if "_split_kernel" in kernel_name else PEAK_MFMA_F32
 PEAK_HBM = 8.0e12             # spec; ~6.3e12 achievable
 
 
@@ -258,7 +266,7 @@ def summarize_profile(all_recs, n_edges_by_launch, n_nodes_by_launch=None, workl
             a["work"] += work
     out = []
     for name, a in agg.items():
-        peak = PEAK_HBM if a["kind"] == 1 else PEAK_MFMA_F32
+        peak = PEAK_HBM if a["kind"] == 1 else mfma_peak(name)
         ach = a["work"] / a["sec"] if a["sec"] > 0 else 0.0
         second = name.endswith(SECOND_STREAM_TAG)
         name = name[:-len(SECOND_STREAM_TAG)] if second else name
@@ -268,6 +276,9 @@ def summarize_profile(all_recs, n_edges_by_launch, n_nodes_by_launch=None, workl
                         achieved=(ach / 1e9 if a["kind"] == 1 else ach / 1e12), peak=(peak / 1e9 if a["kind"] == 1 else peak / 1e12),
                         unit="GB/s" if a["kind"] == 1 else "TFLOP/s", frac=ach / peak, work_per_launch=a["work"] / a["launches"],
                         traffic=traffic.get(name), traffic_source=traffic_src if name in traffic else None))
+        if a["kind"] != 1 and "_split_kernel" in name:
+            out[-1]["pipe"] = "bf16 MFMA, %d plane products per fp32 product (fp32-accurate: DESIGN 4.10); peak = 2.5 PF/s / %d" % (SPLIT_PRODUCTS, SPLIT_PRODUCTS)
+            out[-1]["frac_of_f32_mfma_peak"] = ach / PEAK_MFMA_F32
     out.sort(key=lambda r: -r["total_us"])
     return out
 
@@ -919,6 +930,7 @@ def main():
         roofline = {"bound": dom["bound"], "achieved": dom["achieved"], "peak": dom["peak"], "unit": dom["unit"],
                     "frac": dom["frac"], "traffic": dom["traffic"], "traffic_source": dom["traffic_source"],
                     "kernel": dom["kernel"], "avg_us": dom["avg_us"], "flops": "algorithmic (unpadded operands)",
+                    **({"pipe": dom["pipe"], "frac_of_f32_mfma_peak": dom["frac_of_f32_mfma_peak"]} if "pipe" in dom else {}),
                     "stream": dom["stream"], "launches_profiled": dom["launches"], "work_per_launch": dom["work_per_launch"],
                     # the HBM side as flat scalars (the north star's target is an HBM-utilisation one): the longest HBM-bound kernel of
                     # the step, algorithmic bytes / live launch duration against the 8 TB/s spec and against this box's copy rate
@@ -936,7 +948,8 @@ def main():
                 roofline[f"hbm_{short}_avg_us"] = r["avg_us"]
         mf = [r for r in roof_all if r["bound"] == "mfma" and r["stream"] == "main"]
         if mf:        # all main-stream MFMA launches of a step together: algorithmic flops / their summed durations
-            roofline["mfma_main_stream_frac"] = sum(r["work_per_launch"] * r["launches"] for r in mf) / sum(r["total_us"] * 1e-6 for r in mf) / PEAK_MFMA_F32
+            # (each kernel's flops against ITS pipe's roof: time at the roof / time spent)
+            roofline["mfma_main_stream_frac"] = sum(r["work_per_launch"] * r["launches"] / (r["peak"] * 1e12) for r in mf) / sum(r["total_us"] * 1e-6 for r in mf)
         if cpu is not None:                              # (flat copies: nested objects do not survive every consumer of this line)
             for leg in ("fwd", "scoring"):
                 if leg in cpu:

@@ -95,14 +95,16 @@ int txe_gat_dense_fwd(const float* X, int n_nodes, int Kh, int Pd, const float* 
                       const unsigned* mask, float* Y, void* ws, size_t ws_bytes, void* stream);
 /* txe_gat_dense_fwd on the bf16 matrix pipe in fp32 accuracy (txe_gemm_nt_split below): X must be a PLAIN operand (dropout already
  * applied -- txe_gat_prepare_desc.x_dropped -- or none).  Xs / Ws = packed planes of X (side 0) / Wp (side 1), or NULL: they are then
- * packed into ws (txe_gat_dense_split_ws_bytes). */
+ * packed into ws (txe_gat_dense_split_ws_bytes).  Xt_out (or NULL): txe_gat_dense_split_xt_bytes (0 = shape not eligible) for X packed
+ * contraction-major (txe_split_pack_t) -- txe_gat_dense_bwd's `Xt`: its weight-gradient product then runs on the same pipe. */
 size_t txe_gat_dense_split_ws_bytes(int n_nodes, int Kh, int Pd, int H, int D);
+size_t txe_gat_dense_split_xt_bytes(int n_nodes, int Kh, int Pd, int H, int D);
 int txe_gat_dense_fwd_split(const float* X, int n_nodes, int Kh, int Pd, const float* Wp, int H, int D, const void* Xs, const void* Ws,
-                            float* Y, void* ws, size_t ws_bytes, void* stream);
+                            void* Xt_out, float* Y, void* ws, size_t ws_bytes, void* stream);
 int txe_gat_dense_bwd(const float* X, int n_nodes, int Kh, int Pd, const int* pos, int vocab, const float* Wp, const float* W,
                       const float* attn_l, const float* attn_r, int H, int D, float feat_drop_p, const unsigned* mask, const float* d_Y,
                       int need_dh, int act_on, float act_slope, float* d_X, float* dW, float* d_attn_l, float* d_attn_r, float* dP,
-                      int x_dropped, int phases, void* chain, void* ws, size_t ws_bytes, void* stream);
+                      int x_dropped, const void* Xt, int phases, void* chain, void* ws, size_t ws_bytes, void* stream);
 /* phases: 7 = all of it; 1 | 2 | 4 = d_X | the weight-gradient product (split-K partial slices) | the reductions that finish dW,
  * d_attn, dP -- 1 and 2 are independent, 4 needs both.
  * chain (may be NULL): TXE_TAIL_CHAIN_BYTES of HOST memory, zero-filled = empty, owned by the caller for one backward pass.  The last
@@ -443,6 +445,14 @@ size_t txe_split_packed_bytes(int rows, int cols);
 int txe_split_pack(const float* src, long long ld, int rows, int cols, int side, void* packed, void* stream);
 int txe_gemm_split_variant(int v);   /* tuning: tile / stage variant of the next products */
 int txe_gemm_nt_split(const void* A_packed, const void* B_packed, int M, int N, int K, float* C, long long ldc, void* stream);
+
+/* The TN form (weight gradients, model_zoo.py:83 backward: dW = d_Y^T X over the nodes): part[z][M][ldc] = A[rows of slice z]^T B[same rows],
+ * z < S, slices of ksplit rows (a multiple of 16).  A [n_rows][lda] is fp32 (split in the product's loader), B comes packed
+ * contraction-major by txe_split_pack_t (cols % 160 == 0; 16-byte aligned rows).  M % 128 == 0, N % 160 == 0. */
+size_t txe_split_packed_t_bytes(int rows, int cols);
+int txe_split_pack_t(const float* src, long long ld, int rows, int cols, void* packed, void* stream);
+int txe_gemm_tn_split(const float* A, long long lda, int M, const void* B_packed_t, int N, int n_rows, int S, int ksplit, float* part,
+                      long long ldc, long long split_stride, void* stream);
 
 /* host-side evaluation of the counter-based dropout hash the kernels inline (uniform in [0,1)); keep = u >= p */
 float txe_dropout_uniform_host(unsigned long long seed, unsigned long long idx);

@@ -24,8 +24,9 @@ SIGNATURES = {
     "txe_gat_dense_ws_bytes": (SZ, [I, I, I, I, I, I]),
     "txe_gat_dense_fwd": (I, [P, I, I, I, P, I, I, F, P, P, P, SZ, P]),
     "txe_gat_dense_split_ws_bytes": (SZ, [I, I, I, I, I]),
-    "txe_gat_dense_fwd_split": (I, [P, I, I, I, P, I, I, P, P, P, P, SZ, P]),
-    "txe_gat_dense_bwd": (I, [P, I, I, I, P, I, P, P, P, P, I, I, F, P, P, I, I, F, P, P, P, P, P, I, I, P, P, SZ, P]),
+    "txe_gat_dense_split_xt_bytes": (SZ, [I, I, I, I, I]),
+    "txe_gat_dense_fwd_split": (I, [P, I, I, I, P, I, I, P, P, P, P, P, SZ, P]),
+    "txe_gat_dense_bwd": (I, [P, I, I, I, P, I, P, P, P, P, I, I, F, P, P, I, I, F, P, P, P, P, P, I, P, I, P, P, SZ, P]),
     "txe_gat_tail_flush": (I, [P, P]),
     "txe_zero_cols": (I, [P, L, I, I, I, P]),
     "txe_gat_dx_streams": (I, [I, I, I]),
@@ -114,6 +115,9 @@ SIGNATURES = {
     "txe_split_packed_bytes": (SZ, [I, I]),
     "txe_split_pack": (I, [P, L, I, I, I, P, P]),
     "txe_gemm_split_variant": (I, [I]),
+    "txe_split_packed_t_bytes": (SZ, [I, I]),
+    "txe_split_pack_t": (I, [P, L, I, I, P, P]),
+    "txe_gemm_tn_split": (I, [P, L, I, P, I, I, I, I, P, L, L, P]),
     "txe_gemm_nt_split": (I, [P, P, I, I, I, P, L, P]),
 }
 

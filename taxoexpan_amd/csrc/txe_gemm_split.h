@@ -27,34 +27,54 @@ static inline size_t split_packed_bytes(int rows, int cols) {
     return rb * nkt * 3 * SPL_FRAG_BYTES;
 }
 
-// x -> (x1, x2, x3) as bf16 bit patterns, round-to-nearest-even at each level (x - x1 and (x - x1) - x2 are exact in fp32)
-__device__ __forceinline__ unsigned bf16_rne(float x) {
-    const unsigned u = __float_as_uint(x);
-    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+// x -> (x1, x2, x3) as bf16 bit patterns, round-to-nearest-even at each level (v_cvt_pk_bf16_f32; x - x1 and (x - x1) - x2 are exact in
+// fp32 whatever the rounding, so x1 + x2 + x3 == x exactly)
+typedef float split_f2 __attribute__((ext_vector_type(2)));
+typedef __bf16 split_b2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pk_bf16(float lo, float hi) {
+    const split_f2 v = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, split_b2));
 }
-__device__ __forceinline__ void split3(float x, unsigned& p1, unsigned& p2, unsigned& p3) {
-    p1 = bf16_rne(x);
-    const float r1 = x - __uint_as_float(p1 << 16);
-    p2 = bf16_rne(r1);
-    const float r2 = r1 - __uint_as_float(p2 << 16);
-    p3 = bf16_rne(r2);
+__device__ __forceinline__ void split3x2(float x0, float x1, unsigned& w1, unsigned& w2, unsigned& w3) {
+    w1 = pk_bf16(x0, x1);
+    const float r0 = x0 - __uint_as_float(w1 << 16), r1 = x1 - __uint_as_float(w1 & 0xffff0000u);
+    w2 = pk_bf16(r0, r1);
+    const float q0 = r0 - __uint_as_float(w2 << 16), q1 = r1 - __uint_as_float(w2 & 0xffff0000u);
+    w3 = pk_bf16(q0, q1);
 }
-// eight consecutive columns of one row -> the three planes' 16-byte lane words
+// eight consecutive contraction elements of one row / column -> the three planes' 16-byte lane words
 __device__ __forceinline__ void split3x8(const float (&x)[8], uint4& w1, uint4& w2, uint4& w3) {
-    unsigned a[8], b[8], c[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) split3(x[i], a[i], b[i], c[i]);
-    w1 = make_uint4(a[0] | (a[1] << 16), a[2] | (a[3] << 16), a[4] | (a[5] << 16), a[6] | (a[7] << 16));
-    w2 = make_uint4(b[0] | (b[1] << 16), b[2] | (b[3] << 16), b[4] | (b[5] << 16), b[6] | (b[7] << 16));
-    w3 = make_uint4(c[0] | (c[1] << 16), c[2] | (c[3] << 16), c[4] | (c[5] << 16), c[6] | (c[7] << 16));
+    split3x2(x[0], x[1], w1.x, w2.x, w3.x);
+    split3x2(x[2], x[3], w1.y, w2.y, w3.y);
+    split3x2(x[4], x[5], w1.z, w2.z, w3.z);
+    split3x2(x[6], x[7], w1.w, w2.w, w3.w);
+}
+__device__ __forceinline__ void split3x4(const float (&x)[4], uint2& w1, uint2& w2, uint2& w3) {
+    split3x2(x[0], x[1], w1.x, w2.x, w3.x);
+    split3x2(x[2], x[3], w1.y, w2.y, w3.y);
 }
 // row of slot s of fragment block rb
 __device__ __host__ __forceinline__ int split_slot_row(int side, int rb, int s) {
     return side == 0 ? 32 * rb + s : 128 * (rb >> 2) + 64 * ((rb & 3) >> 1) + 2 * s + (rb & 1);
 }
 
+// ---- the TN product C = A^T B over the ROWS of A [n][M] and B [n][N] (weight gradients: A = d_Y, B = X, n = nodes) ------------------
+// B comes packed CONTRACTION-major ("side 2", written once per step by split_pack_t_launch): fragment (nt, kb, p) = rows
+// [16 nt, 16 nt + 16) x the 32 column slots of block kb, at byte ((nt * nkb + kb) * 3 + p) * 1024; lane (nh = l >> 5, s = l & 31) owns rows
+// 16 nt + 8 nh .. + 7 of slot s.  Slot -> column inside a 160-column tile h (blocks kb = 5 h + j): j < 4: column 160 h + 4 s + j,
+// j == 4: column 160 h + 128 + s -- a lane's five accumulator blocks are then four ADJACENT columns of C (one 16-byte store) and one more.
+// Rows past the end are zeros.  A is read as fp32 and split in the product's loader (each element once per column tile).
+static inline size_t split_packed_t_bytes(int rows, int cols) {
+    return (size_t)((rows + 15) / 16) * (size_t)(cols / 32) * 3 * SPL_FRAG_BYTES;
+}
+static inline bool split_tn_eligible(int M, int N) { return M % 128 == 0 && N % 160 == 0 && M > 0 && N > 0; }
+
 // launches (txe_gemm_split.hip)
 int split_pack_launch(const float* src, long long ld, int rows, int cols, int side, void* packed, hipStream_t stream);
 int gemm_nt_split_launch(const void* Ap, const void* Bp, int M, int N, int K, float* C, long long ldc, double alg_flops, hipStream_t stream);
+int split_pack_t_launch(const float* src, long long ld, int rows, int cols, void* packed, hipStream_t stream);
+// part[z][M][ldc] = A[rows of slice z]^T B[rows of slice z], z < S, slices of ksplit rows (a multiple of 16)
+int gemm_tn_split_launch(const float* A, long long lda, int M, const void* Bt, int N, int n_rows, int S, int ksplit, float* part, long long ldc,
+                         long long split_stride, double alg_flops, hipStream_t stream);
 
 }  // namespace txe

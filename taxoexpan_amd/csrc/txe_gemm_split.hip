@@ -178,6 +178,165 @@ __global__ __launch_bounds__(256, MINB) void gemm_nt_split_kernel(const SplitGem
         }
 }
 
+// ---- side 2 packing: fp32 [rows][ld] -> contraction-major planes (txe_gemm_split.h) ------------------------------------------------
+// one thread per (row tile nt, column tile h, lane): 8 rows x (4 + 1) columns -> five fragments' lane words per plane
+__global__ __launch_bounds__(256) void split_pack_t_kernel(const float* __restrict__ src, long long ld, int rows, int nht, int nnt,
+                                                           uint4* __restrict__ dst) {
+    const long long total = (long long)nnt * nht * 64;
+    const int nkb = nht * 5;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int l = (int)(i & 63), s = l & 31, nh = l >> 5;
+        const long long g = i >> 6;
+        const int h = (int)(g % nht), nt = (int)(g / nht);
+        const int n0 = nt * 16 + nh * 8;
+        float4 q[8];
+        float o[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const int row = min(n0 + r, rows - 1);
+            const float* p = src + (long long)row * ld + 160 * h;
+            q[r] = *reinterpret_cast<const float4*>(p + 4 * s);
+            o[r] = p[128 + s];
+        }
+#pragma unroll
+        for (int r = 0; r < 8; ++r)
+            if (n0 + r >= rows) { q[r] = make_float4(0.f, 0.f, 0.f, 0.f); o[r] = 0.f; }
+        uint4* base = dst + ((long long)nt * nkb + 5 * h) * 3 * 64 + l;
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            float x[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) x[r] = j == 0 ? q[r].x : (j == 1 ? q[r].y : (j == 2 ? q[r].z : (j == 3 ? q[r].w : o[r])));
+            uint4 w1, w2, w3;
+            split3x8(x, w1, w2, w3);
+            base[(j * 3 + 0) * 64] = w1; base[(j * 3 + 1) * 64] = w2; base[(j * 3 + 2) * 64] = w3;
+        }
+    }
+}
+
+// ---- the TN product ------------------------------------------------------------------------------------------------------------
+// 128 (M) x 160 (N) tile per workgroup of four waves; wave w owns the 32 row slots of A block w x all five B blocks (80 accumulator
+// registers).  k-tiles of 16 contraction rows, two stages: B's 15 fragments arrive by LDS-direct copies (15 KB contiguous), A's
+// [16][128] fp32 patch goes through registers -- thread (pair q = t & 63, row quad t >> 6) loads 4 rows x 2 adjacent columns, splits
+// them and writes six 8-byte half lane words -- while the MFMA block of the tile before runs.
+// A's slot permutation: slot s of block fb is column 64 (fb >> 1) + 2 s + (fb & 1) of the tile (a thread's two columns land in slot
+// s of two neighbouring blocks: consecutive lanes write consecutive LDS words).
+struct SplitTn {
+    const float* A; long long lda; const char* Bt; int nkb;
+    float* C; long long ldc, split_stride;
+    int n_rows, ksplit, ntm, ntn;
+};
+constexpr int SPT_A_U4 = 4 * 3 * 64, SPT_B_U4 = 5 * 3 * 64, SPT_STAGE_U4 = SPT_A_U4 + SPT_B_U4;   // 12 KB + 15 KB
+
+__global__ __launch_bounds__(256, 2) void gemm_tn_split_kernel(const SplitTn p) {
+    __shared__ __attribute__((aligned(16))) uint4 st0[SPT_STAGE_U4];
+    __shared__ __attribute__((aligned(16))) uint4 st1[SPT_STAGE_U4];
+    typedef __attribute__((address_space(3))) uint4 lds_u4;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), l = threadIdx.x & 63;
+    const int ntiles = p.ntm * p.ntn;
+    const int vb = xcd_remap(blockIdx.x, gridDim.x);
+    const int z = vb / ntiles, lb = vb % ntiles;
+    const int tm = lb / p.ntn, h = lb % p.ntn;
+    const int kbeg = z * p.ksplit, kend = min(p.n_rows, kbeg + p.ksplit);
+    const int nk = kend > kbeg ? (kend - kbeg + 15) / 16 : 0;
+    // B: fragments 4 w .. 4 w + 3 (< 15) of the k-tile's 15
+    const char* gb = p.Bt + (((long long)(kbeg / 16) * p.nkb + 5 * h) * 3 + 4 * w) * SPL_FRAG_BYTES;
+    const long long adv_b = (long long)p.nkb * 3 * SPL_FRAG_BYTES;
+    const unsigned lane_off = l * 16;
+    // A: this thread's 4 rows x 2 columns
+    const int q = l, g = q >> 5, s = q & 31;
+    const float* ga = p.A + (long long)tm * 128 + 64 * g + 2 * s;
+    const int last_row = p.n_rows - 1;
+
+    f32x16s acc[5];
+#pragma unroll
+    for (int j = 0; j < 5; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+    float2 ra[4];
+
+#define TXE_ST_COPY(g_, d_)                                                                                           \
+    asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(lane_off), "s"(g_), "s"((unsigned)(uintptr_t)(d_)) : "memory");
+#define TXE_ST_ISSUE_B(st_, t_)                                                                                       \
+    {                                                                                                                \
+        const char* sb = gb + (long long)(t_) * adv_b;                                                               \
+        lds_u4* d0 = (lds_u4*)(st_) + SPT_A_U4 + (4 * w) * 64;                                                       \
+        TXE_ST_COPY(sb, d0)                                                                                          \
+        TXE_ST_COPY(sb + SPL_FRAG_BYTES, d0 + 64)                                                                    \
+        TXE_ST_COPY(sb + 2 * SPL_FRAG_BYTES, d0 + 128)                                                               \
+        if (w < 3) TXE_ST_COPY(sb + 3 * SPL_FRAG_BYTES, d0 + 192)                                                    \
+    }
+#define TXE_ST_LOAD_A(t_)                                                                                             \
+    _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                                                  \
+        const int row = min(kbeg + (t_) * 16 + 4 * w + r, last_row);                                                 \
+        ra[r] = *reinterpret_cast<const float2*>(ga + (long long)row * p.lda);                                       \
+    }
+    // rows 4 w .. 4 w + 3 of the k-tile = half (w & 1) of lane word (nh = w >> 1, slot s) of blocks 2 g and 2 g + 1
+#define TXE_ST_STORE_A(st_)                                                                                           \
+    {                                                                                                                \
+        const float x0[4] = {ra[0].x, ra[1].x, ra[2].x, ra[3].x}, x1[4] = {ra[0].y, ra[1].y, ra[2].y, ra[3].y};      \
+        uint2 u1, u2, u3, v1, v2, v3;                                                                                \
+        split3x4(x0, u1, u2, u3);                                                                                    \
+        split3x4(x1, v1, v2, v3);                                                                                    \
+        uint2* d = reinterpret_cast<uint2*>((st_) + (2 * g) * 3 * 64 + (w >> 1) * 32 + s) + (w & 1);                 \
+        d[0] = u1; d[2 * 64] = u2; d[4 * 64] = u3;                                                                   \
+        d[6 * 64] = v1; d[8 * 64] = v2; d[10 * 64] = v3;                                                             \
+    }
+#define TXE_ST_MFMA(pa_, pb_)                                                                                         \
+    _Pragma("unroll") for (int j = 0; j < 5; ++j)                                                                    \
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[pa_], fb[j][pb_], acc[j], 0, 0, 0);
+#define TXE_ST_COMPUTE(st_)                                                                                           \
+    {                                                                                                                \
+        bf16x8 fa[3], fb[5][3];                                                                                      \
+        _Pragma("unroll") for (int c = 0; c < 3; ++c) fa[c] = __builtin_bit_cast(bf16x8, (st_)[(w * 3 + c) * 64 + l]); \
+        _Pragma("unroll") for (int j = 0; j < 5; ++j)                                                                \
+            _Pragma("unroll") for (int c = 0; c < 3; ++c)                                                            \
+                fb[j][c] = __builtin_bit_cast(bf16x8, (st_)[SPT_A_U4 + (j * 3 + c) * 64 + l]);                       \
+        TXE_ST_MFMA(2, 0) TXE_ST_MFMA(0, 2) TXE_ST_MFMA(1, 1) TXE_ST_MFMA(1, 0) TXE_ST_MFMA(0, 1) TXE_ST_MFMA(0, 0)  \
+    }
+#define TXE_ST_STEP(cur_, nxt_, t_)                                                                                   \
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     /* B of this tile has landed (A of it was stored a step ago) */ \
+    __syncthreads();                                                                                                 \
+    if ((t_) + 1 < nk) {                                                                                             \
+        TXE_ST_ISSUE_B(nxt_, (t_) + 1)                                                                               \
+        TXE_ST_LOAD_A((t_) + 1)                                                                                      \
+    }                                                                                                                \
+    __builtin_amdgcn_sched_barrier(0);                                                                               \
+    TXE_ST_COMPUTE(cur_)                                                                                             \
+    __builtin_amdgcn_sched_barrier(0);                                                                               \
+    if ((t_) + 1 < nk) TXE_ST_STORE_A(nxt_)
+
+    if (nk > 0) {
+        TXE_ST_ISSUE_B(st0, 0)
+        TXE_ST_LOAD_A(0)
+        TXE_ST_STORE_A(st0)
+        for (int t = 0; t < nk; t += 2) {
+            TXE_ST_STEP(st0, st1, t)
+            if (t + 1 >= nk) break;
+            TXE_ST_STEP(st1, st0, t + 1)
+        }
+    }
+#undef TXE_ST_STEP
+#undef TXE_ST_COMPUTE
+#undef TXE_ST_MFMA
+#undef TXE_ST_STORE_A
+#undef TXE_ST_LOAD_A
+#undef TXE_ST_ISSUE_B
+#undef TXE_ST_COPY
+
+    // accumulator register e: row slot (e & 3) + 8 (e >> 2) + 4 (lane >> 5) of A block w = C row 64 (w >> 1) + 2 slot + (w & 1) of the
+    // tile; blocks 0-3: columns 4 (lane & 31) + j, block 4: column 128 + (lane & 31)
+    float* cb = p.C + (long long)z * p.split_stride + (long long)(tm * 128 + 64 * (w >> 1) + (w & 1)) * p.ldc + 160 * h;
+    const int sl = l & 31;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int slot = (e & 3) + 8 * (e >> 2) + 4 * (l >> 5);
+        float* dst = cb + (long long)(2 * slot) * p.ldc;
+        *reinterpret_cast<float4*>(dst + 4 * sl) = make_float4(acc[0][e], acc[1][e], acc[2][e], acc[3][e]);
+        dst[128 + sl] = acc[4][e];
+    }
+}
+
 int g_split_variant = 0;
 
 int split_pack_launch(const float* src, long long ld, int rows, int cols, int side, void* packed, hipStream_t stream) {
@@ -212,6 +371,32 @@ int gemm_nt_split_launch(const void* Ap, const void* Bp, int M, int N, int K, fl
     return TXE_OK;
 }
 
+int split_pack_t_launch(const float* src, long long ld, int rows, int cols, void* packed, hipStream_t stream) {
+    if (!src || !packed || rows < 1 || cols < 160 || cols % 160 != 0 || ld < cols || (ld & 3) != 0 || (reinterpret_cast<uintptr_t>(src) & 15) != 0)
+        return TXE_ERR_ARG;
+    const int nht = cols / 160, nnt = (rows + 15) / 16;
+    const long long total = (long long)nnt * nht * 64;
+    ProfScope prof("split_pack_t_kernel", stream, 10.0 * rows * (double)cols, 1);
+    hipLaunchKernelGGL(split_pack_t_kernel, dim3((int)((total + 255) / 256)), dim3(256), 0, stream, src, ld, rows, nht, nnt, (uint4*)packed);
+    TXE_CHECK_LAUNCH();
+    return TXE_OK;
+}
+
+int gemm_tn_split_launch(const float* A, long long lda, int M, const void* Bt, int N, int n_rows, int S, int ksplit, float* part, long long ldc,
+                         long long split_stride, double alg_flops, hipStream_t stream) {
+    if (!A || !Bt || !part || !split_tn_eligible(M, N) || n_rows < 1 || S < 1 || ksplit < 16 || ksplit % 16 != 0 || ldc < N || (ldc & 3) != 0 ||
+        (lda & 1) != 0 || (reinterpret_cast<uintptr_t>(A) & 7) != 0 || (reinterpret_cast<uintptr_t>(part) & 15) != 0 || (split_stride & 3) != 0)
+        return TXE_ERR_ARG;
+    SplitTn p;
+    p.A = A; p.lda = lda; p.Bt = (const char*)Bt; p.nkb = N / 32;
+    p.C = part; p.ldc = ldc; p.split_stride = split_stride;
+    p.n_rows = n_rows; p.ksplit = ksplit; p.ntm = M / 128; p.ntn = N / 160;
+    ProfScope prof("gemm_tn_split_kernel", stream, alg_flops > 0.0 ? alg_flops : 2.0 * M * (double)N * n_rows, 0);
+    hipLaunchKernelGGL(gemm_tn_split_kernel, dim3(p.ntm * p.ntn * S), dim3(256), 0, stream, p);
+    TXE_CHECK_LAUNCH();
+    return TXE_OK;
+}
+
 }  // namespace txe
 using namespace txe;
 extern "C" {
@@ -226,6 +411,17 @@ int txe_gemm_split_variant(int v) { g_split_variant = v; return TXE_OK; }
 
 int txe_gemm_nt_split(const void* Ap, const void* Bp, int M, int N, int K, float* C, long long ldc, void* stream) {
     return gemm_nt_split_launch(Ap, Bp, M, N, K, C, ldc, 0.0, (hipStream_t)stream);
+}
+
+size_t txe_split_packed_t_bytes(int rows, int cols) { return (rows < 1 || cols < 32) ? 0 : split_packed_t_bytes(rows, cols); }
+
+int txe_split_pack_t(const float* src, long long ld, int rows, int cols, void* packed, void* stream) {
+    return split_pack_t_launch(src, ld, rows, cols, packed, (hipStream_t)stream);
+}
+
+int txe_gemm_tn_split(const float* A, long long lda, int M, const void* Bt, int N, int n_rows, int S, int ksplit, float* part, long long ldc,
+                      long long split_stride, void* stream) {
+    return gemm_tn_split_launch(A, lda, M, Bt, N, n_rows, S, ksplit, part, ldc, split_stride, 0.0, (hipStream_t)stream);
 }
 
 }  // extern "C"

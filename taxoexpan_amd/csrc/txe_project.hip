@@ -846,14 +846,20 @@ int txe_gat_dense_fwd(const float* X, int n_nodes, int Kh, int Pd, const float* 
 // The same product on the bf16 matrix pipe (txe_gemm_split.h: three bf16 planes per fp32 operand, six plane products, fp32
 // accumulation -- fp32 accuracy at 6/16 of the fp32 MFMA's time).  X is a PLAIN operand here: dropout(X) already applied
 // (txe_gat_prepare_desc.x_dropped) or no dropout.  Xs / Ws: the packed planes of X (side 0) / Wp (side 1) when the preparation launch
-// wrote them (txe_gat_prepare_desc.Xs / .Ws), else NULL -- they are then packed here, into ws.
+// wrote them, else NULL -- they are then packed here, into ws.  Xt_out (or NULL): txe_gat_dense_split_xt_bytes for X packed
+// contraction-major, what txe_gat_dense_bwd's weight gradient takes on the same pipe.
 size_t txe_gat_dense_split_ws_bytes(int n_nodes, int Kh, int Pd, int H, int D) {
     if (n_nodes < 1 || Kh < 1 || Pd < 0 || H < 1 || D < 1) return 0;
     const int Fp = round_up(H * D + 2 * H, 128), Kp = round_up(Kh + Pd, 32);
     return align_up(split_packed_bytes(n_nodes, Kp), 256) + align_up(split_packed_bytes(Fp, Kp), 256);
 }
+size_t txe_gat_dense_split_xt_bytes(int n_nodes, int Kh, int Pd, int H, int D) {       // 0: this layer's weight gradient keeps the fp32 route
+    if (n_nodes < 1 || Kh < 1 || Pd < 0 || H < 1 || D < 1) return 0;
+    const int Fp = round_up(H * D + 2 * H, 128), Kp = round_up(Kh + Pd, 32);
+    return split_tn_eligible(Fp, Kp) ? split_packed_t_bytes(n_nodes, Kp) : 0;
+}
 int txe_gat_dense_fwd_split(const float* X, int n_nodes, int Kh, int Pd, const float* Wp, int H, int D, const void* Xs, const void* Ws,
-                            float* Y, void* ws, size_t ws_bytes, void* stream) {
+                            void* Xt_out, float* Y, void* ws, size_t ws_bytes, void* stream) {
     if (n_nodes < 0 || Kh < 1 || Pd < 0 || H < 1 || D < 1 || !Y || (!Xs && !X) || (!Ws && !Wp)) return TXE_ERR_ARG;
     if (n_nodes == 0) return TXE_OK;
     const int Fe = H * D + 2 * H, Fp = round_up(Fe, 128), Kp = round_up(Kh + Pd, 32);
@@ -875,7 +881,14 @@ int txe_gat_dense_fwd_split(const float* X, int n_nodes, int Kh, int Pd, const f
         if (rc) return rc;
         Ws = w + off; off += b;
     }
-    return gemm_nt_split_launch(Xs, Ws, n_nodes, Fe, Kp, Y, Fp, 2.0 * n_nodes * (double)Fe * (Kh + Pd), s);
+    rc = gemm_nt_split_launch(Xs, Ws, n_nodes, Fe, Kp, Y, Fp, 2.0 * n_nodes * (double)Fe * (Kh + Pd), s);
+    if (rc) return rc;
+    // X packed contraction-major for the backward pass's weight gradient (txe_gat_dense_bwd: Xt), behind the product: off its input's path
+    if (Xt_out) {
+        if (!X || !split_tn_eligible(Fp, Kp)) return TXE_ERR_ARG;
+        return split_pack_t_launch(X, Kp, n_nodes, Kp, Xt_out, s);
+    }
+    return TXE_OK;
 }
 
 // Backward of txe_gat_dense_fwd.  d_Y [N][Fp] must have ZERO padding columns [F+2H, Fp).
@@ -888,7 +901,7 @@ int txe_gat_dense_fwd_split(const float* X, int n_nodes, int Kh, int Pd, const f
 int txe_gat_dense_bwd(const float* X, int n_nodes, int Kh, int Pd, const int* pos, int vocab, const float* Wp, const float* W,
                       const float* attn_l, const float* attn_r, int H, int D, float feat_drop_p, const unsigned* mask, const float* d_Y,
                       int need_dh, int act_on, float act_slope, float* d_X, float* dW, float* d_attn_l, float* d_attn_r, float* dP,
-                      int x_dropped, int phases, void* chain, void* ws, size_t ws_bytes, void* stream) {
+                      int x_dropped, const void* Xt, int phases, void* chain, void* ws, size_t ws_bytes, void* stream) {
     if (n_nodes < 0 || Kh < 1 || Pd < 0 || H < 1 || D < 1 || !X || !Wp || !W || !attn_l || !attn_r || !d_Y || !dW || !d_attn_l || !d_attn_r || !ws)
         return TXE_ERR_ARG;
     static_assert(sizeof(TailChain) <= TXE_TAIL_CHAIN_BYTES, "txe.h: TXE_TAIL_CHAIN_BYTES");
@@ -938,7 +951,12 @@ int txe_gat_dense_bwd(const float* X, int n_nodes, int Kh, int Pd, const int* po
     E.split_stride = (long long)Fp * Kp;
     E.alg_flops = 2.0 * Fe * (double)Kt * n_nodes;
     const int splits = p.splits;
-    if (phases & 2) {
+    if ((phases & 2) && Xt && x_dropped + (feat_drop_p == 0.f) > 0 && split_tn_eligible(Fp, Kp) && n_nodes > 0) {
+        // the same slices on the bf16 pipe (txe_gemm_split.h): X packed contraction-major by the forward pass, d_Y split in the loader
+        const int ks = round_up((n_nodes + splits - 1) / splits, 16);
+        rc = gemm_tn_split_launch(d_Y, Fp, Fp, Xt, Kp, n_nodes, splits, ks, p.part, Kp, E.split_stride, E.alg_flops, s);
+        if (rc) return rc;
+    } else if (phases & 2) {
         rc = gemm_tn(A, B, E, Fp, Kp, n_nodes, splits, s);
         if (rc) return rc;
     }

@@ -328,7 +328,7 @@ def _tail_ws(ref):
 
 
 class _GatLayerState:
-    __slots__ = ("X", "Wp", "mask", "Y", "alpha", "W", "al", "ar", "P", "Kh", "Pd", "Kp", "Fp", "H", "D", "seed", "cl", "prepared", "x_dropped")
+    __slots__ = ("X", "Wp", "mask", "Y", "alpha", "W", "al", "ar", "P", "Kh", "Pd", "Kp", "Fp", "H", "D", "seed", "cl", "prepared", "x_dropped", "Xt")
 
 
 def _x_dropped_ok(cfg, states, l, collapse):
@@ -454,7 +454,9 @@ def _gat_layer_fwd(csr, st, h, ld_h, pos, out, ld_out, feat_p, attn_p, attn_slop
         if (dropped or feat_p == 0.0) and not _NO_SPLIT_GEMM:      # X is a plain operand: fp32-accurate product on the bf16 pipe
             wsb = pure("txe_gat_dense_split_ws_bytes", N, Kh, Pd, H, D)
             sws = _ws(wsb, st.X)
-            call("txe_gat_dense_fwd_split", ptr(st.X), N, Kh, Pd, ptr(st.Wp), H, D, None, None, ptr(st.Y), ptr(sws), wsb, s)
+            xtb = pure("txe_gat_dense_split_xt_bytes", N, Kh, Pd, H, D) if save else 0
+            st.Xt = _ws(xtb, st.X) if xtb else None        # X packed contraction-major: the backward pass's weight gradient reads it
+            call("txe_gat_dense_fwd_split", ptr(st.X), N, Kh, Pd, ptr(st.Wp), H, D, None, None, ptr(st.Xt), ptr(st.Y), ptr(sws), wsb, s)
             note_route("proj", "bf16x6")
         else:
             call("txe_gat_dense_fwd", ptr(st.X), N, Kh, Pd, ptr(st.Wp), H, D, 0.0 if dropped else feat_p, None if dropped else ptr(st.mask), ptr(st.Y),
@@ -505,7 +507,7 @@ def _gat_dense_bwd(st, pos, vocab, feat_p, d_Y, need_dh, act_on, act_slope, chai
     def run(phases):
         call("txe_gat_dense_bwd", ptr(st.X), N, st.Kh, st.Pd, ptr(pos), vocab, ptr(st.Wp), ptr(st.W), ptr(st.al), ptr(st.ar), st.H, st.D, feat_p,
              ptr(st.mask), ptr(d_Y), int(need_dh), int(act_on), act_slope if act_slope else 1.0, ptr(d_X), ptr(dW), ptr(dal), ptr(dar),
-             ptr(dP), int(getattr(st, "x_dropped", False)), phases, chain.ptr if chain is not None else None, ptr(ws), wsb, _lib.stream_ptr())
+             ptr(dP), int(getattr(st, "x_dropped", False)), ptr(getattr(st, "Xt", None)), phases, chain.ptr if chain is not None else None, ptr(ws), wsb, _lib.stream_ptr())
     # (a first PGAT layer's d_X -- position columns only -- is one HBM stream over d_Y, txe_dxpos.hip; every other d_X is a GEMM)
     run(7 | (64 if (defer and chain is not None) else 0))
     if chain is not None:

@@ -261,7 +261,7 @@ def test_first_layer_position_dx_streaming_kernel(N, Kh, Pd, H, D, vocab, p):
         cp = ctypes.cast(chain, ctypes.c_void_p)
         _lib.call("txe_gat_dense_bwd", X.data_ptr(), N, Kh, Pd, pos.data_ptr(), vocab, Wp.data_ptr(), W.data_ptr(), al.data_ptr(), ar.data_ptr(),
                   H, D, p, mask.data_ptr() if mask is not None else None, dY.data_ptr(), 0, 0, 1.0, dX.data_ptr(), dW.data_ptr(), dal.data_ptr(),
-                  dar.data_ptr(), dP.data_ptr(), 0, 7 | (64 if deferred else 0), cp if deferred else None, ws.data_ptr(), wsb, _lib.stream_ptr())
+                  dar.data_ptr(), dP.data_ptr(), 0, None, 7 | (64 if deferred else 0), cp if deferred else None, ws.data_ptr(), wsb, _lib.stream_ptr())
         if deferred:
             _lib.call("txe_gat_tail_flush", cp, _lib.stream_ptr())
         torch.cuda.synchronize()

@@ -1,0 +1,131 @@
+"""fp32 products on the bf16 matrix pipe (csrc/txe_gemm_split.*): the packed three-plane operands are EXACT
+(x1 + x2 + x3 == x bit for bit), the NT and TN products agree with float64 at least as well as an fp32 product does, on ragged shapes,
+and the model's first-layer projection / weight gradient take the route."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev():
+    return torch.device("cuda:0")
+
+
+def _bf16_bits_to_f64(u16):
+    return (u16.astype(np.uint32) << 16).view(np.float32).astype(np.float64)
+
+
+def _slot_row(side, rb, s):
+    """csrc/txe_gemm_split.h split_slot_row"""
+    return 32 * rb + s if side == 0 else 128 * (rb >> 2) + 64 * ((rb & 3) >> 1) + 2 * s + (rb & 1)
+
+
+@pytest.mark.parametrize("rows,cols,side", [(300, 50, 0), (129, 33, 1), (1, 1, 0), (257, 320, 1)])
+def test_packed_planes_sum_to_the_operand_exactly(rows, cols, side):
+    from taxoexpan_amd import _lib
+    g = torch.Generator().manual_seed(rows * 7 + cols)
+    x = torch.randn(rows, cols, generator=g) * torch.exp(4 * torch.randn(rows, cols, generator=g))
+    x[0, 0] = 0.0
+    xd = x.to(_dev())
+    nb = _lib.call("txe_split_packed_bytes", rows, cols)
+    buf = torch.zeros(nb, dtype=torch.uint8, device=_dev())
+    _lib.call("txe_split_pack", xd.data_ptr(), cols, rows, cols, side, buf.data_ptr(), _lib.stream_ptr())
+    torch.cuda.synchronize()
+    raw = buf.cpu().numpy().view(np.uint16)
+    nkt = (cols + 15) // 16
+    nrb = ((rows + 255) // 256) * 8
+    frag = raw.reshape(nrb, nkt, 3, 2, 32, 8)          # [rb][kt][plane][kh][slot][8 k]
+    total = np.zeros((rows, nkt * 16))
+    seen = np.zeros((rows, nkt * 16), dtype=bool)
+    for rb in range(nrb):
+        for s in range(32):
+            r = _slot_row(side, rb, s)
+            if r >= rows:
+                assert not frag[rb, :, :, :, s, :].any()          # padding rows are zeros
+                continue
+            for kt in range(nkt):
+                for kh in range(2):
+                    k0 = kt * 16 + kh * 8
+                    total[r, k0:k0 + 8] = sum(_bf16_bits_to_f64(frag[rb, kt, p, kh, s, :]) for p in range(3))
+                    seen[r, k0:k0 + 8] = True
+    assert seen.all()
+    np.testing.assert_array_equal(total[:, :cols], x.numpy().astype(np.float64))     # exact: three bf16 numbers carry the 24 bits
+    assert not total[:, cols:].any()
+
+
+def _err(c, ref, scale):
+    return ((c.double() - ref).abs() / scale).max().item()
+
+
+@pytest.mark.parametrize("M,N,K", [(1000, 2008, 300), (17, 5, 3), (128, 128, 16), (391, 130, 100), (2500, 250, 512)])
+def test_nt_product_against_float64(M, N, K):
+    from taxoexpan_amd import _lib
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn(M, K, generator=g).to(_dev())
+    B = (torch.randn(N, K, generator=g) * 0.1).to(_dev())
+    A[0, :] *= 1e15
+    s = _lib.stream_ptr()
+    Ap = torch.empty(_lib.call("txe_split_packed_bytes", M, K), dtype=torch.uint8, device=_dev())
+    Bp = torch.empty(_lib.call("txe_split_packed_bytes", N, K), dtype=torch.uint8, device=_dev())
+    ldc = N + 3
+    C = torch.full((M, ldc), float("nan"), device=_dev())
+    _lib.call("txe_split_pack", A.data_ptr(), K, M, K, 0, Ap.data_ptr(), s)
+    _lib.call("txe_split_pack", B.data_ptr(), K, N, K, 1, Bp.data_ptr(), s)
+    _lib.call("txe_gemm_nt_split", Ap.data_ptr(), Bp.data_ptr(), M, N, K, C.data_ptr(), ldc, s)
+    torch.cuda.synchronize()
+    assert torch.isnan(C[:, N:]).all()                       # nothing stored past N
+    ref = A.double() @ B.double().t()
+    scale = (A.double().abs() @ B.double().abs().t()).clamp_min(1e-300)
+    e_split, e_f32 = _err(C[:, :N], ref, scale), _err(A @ B.t(), ref, scale)
+    assert e_split <= max(1.5 * e_f32, 2e-7), (e_split, e_f32)      # as close to the exact product as an fp32 one
+
+
+@pytest.mark.parametrize("n,M,N,S", [(1000, 128, 160, 3), (4097, 256, 320, 16), (15, 128, 160, 2)])
+def test_tn_product_against_float64(n, M, N, S):
+    from taxoexpan_amd import _lib
+    g = torch.Generator().manual_seed(n + M)
+    A = (torch.randn(n, M, generator=g) * 0.01).to(_dev())
+    B = torch.randn(n, N, generator=g).to(_dev())
+    s = _lib.stream_ptr()
+    Bt = torch.empty(_lib.call("txe_split_packed_t_bytes", n, N), dtype=torch.uint8, device=_dev())
+    ks = (((n + S - 1) // S) + 15) // 16 * 16
+    part = torch.full((S, M, N), float("nan"), device=_dev())
+    _lib.call("txe_split_pack_t", B.data_ptr(), N, n, N, Bt.data_ptr(), s)
+    _lib.call("txe_gemm_tn_split", A.data_ptr(), M, M, Bt.data_ptr(), N, n, S, ks, part.data_ptr(), N, M * N, s)
+    torch.cuda.synchronize()
+    assert torch.isfinite(part).all()                        # slices past the last row hold zeros
+    for z in range(S):
+        lo, hi = min(n, z * ks), min(n, (z + 1) * ks)
+        ref = A[lo:hi].double().t() @ B[lo:hi].double()
+        scale = (A[lo:hi].double().abs().t() @ B[lo:hi].double().abs()).clamp_min(1e-30)
+        e_split = _err(part[z], ref, scale)
+        e_f32 = _err(A[lo:hi].t() @ B[lo:hi], ref, scale) if hi > lo else 0.0
+        assert e_split <= max(1.5 * e_f32, 2e-7), (z, e_split, e_f32)
+
+
+def test_first_layer_takes_the_split_route_and_matches_the_fp32_route(monkeypatch):
+    """one training-layout batch through the stack on both routes: outputs and every gradient agree to fp32 rounding, and the
+    route notes say which product ran where"""
+    import golden_cases as gc
+    from taxoexpan_amd import TaxoExpan, ops
+    from taxoexpan_amd.graph import BatchedDGLGraph
+    spec = gc.CASES["mag_pgat_wmr_lbm_q8x32"]
+    shapes, x, q = gc.make_inputs(spec)
+    params = gc.make_params(spec)
+    res = {}
+    for route in ("bf16x6", "fp32"):
+        monkeypatch.setattr(ops, "_NO_SPLIT_GEMM", route == "fp32")
+        model = TaxoExpan("PGAT", "WMR", "LBM", in_dim=250, hidden_dim=500, out_dim=500, pos_dim=50, num_layers=1, heads=[4, 1],
+                          feat_drop=0.0, attn_drop=0.0, hidden_drop=0.0, out_drop=0.0)
+        model.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()}, strict=True)
+        model = model.to(_dev()).train()
+        g = BatchedDGLGraph.from_egonet_shapes([s[0] for s in shapes], [s[1] for s in shapes])
+        scores = model(g, torch.from_numpy(x).to(_dev()), torch.from_numpy(q).to(_dev()))
+        assert ops.ROUTES.get("proj") == route
+        scores.reshape(spec["n_queries"], -1).logsumexp(1).sum().backward()
+        torch.cuda.synchronize()
+        res[route] = (scores.detach().cpu().numpy(), {k: p.grad.cpu().numpy() for k, p in model.named_parameters() if p.grad is not None})
+    np.testing.assert_allclose(res["bf16x6"][0], res["fp32"][0], rtol=1e-4, atol=2e-5)
+    for k, gref in res["fp32"][1].items():
+        np.testing.assert_allclose(res["bf16x6"][1][k], gref, rtol=2e-3, atol=2e-4 * float(np.abs(gref).max()) + 1e-12, err_msg=k)

@@ -67,5 +67,42 @@ def main():
           f"({6 * fl / t_g * 1e-6 / 2500:.2f} of the bf16 pipe's 2.5 PF/s on six plane products); torch.mm fp32 {t_mm:.1f} us")
 
 
+def main_tn():
+    """weight-gradient form: part[z] = dY[slice z]^T X[slice z]  (the step's first-layer shapes: 17877 nodes, 2048 x 320)"""
+    n, M, N, S = 17877, 2048, 320, 16
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device="cpu").manual_seed(2)
+    A = (torch.randn(n, M, generator=g) * 0.01).to(dev)
+    B = torch.randn(n, N, generator=g).to(dev)
+    B[:, 300:] = 0
+    s = stream_ptr()
+    Bt = torch.empty(call("txe_split_packed_t_bytes", n, N), dtype=torch.uint8, device=dev)
+    ksplit = ((n + S - 1) // S + 31) // 32 * 32
+    part = torch.full((S, M, N), float("nan"), device=dev)
+    call("txe_split_pack_t", ptr(B), N, n, N, ptr(Bt), s)
+    call("txe_gemm_tn_split", ptr(A), M, M, ptr(Bt), N, n, S, ksplit, ptr(part), N, M * N, s)
+    torch.cuda.synchronize()
+    assert torch.isfinite(part).all()
+    C = part.double().sum(0)
+    ref = A.double().t() @ B.double()
+    c32 = (A.t() @ B).double()
+    scale = (A.double().abs().t() @ B.double().abs()).clamp_min(1e-300)
+    print(f"TN {M} x {N} over {n} rows, {S} slices of {ksplit}: max |err| / (|a|.|b|): split {((C - ref).abs() / scale).max().item():.3e}  "
+          f"torch fp32 {((c32 - ref).abs() / scale).max().item():.3e}")
+    for z in (0, S - 1):
+        lo, hi = z * ksplit, min(n, (z + 1) * ksplit)
+        rz = A[lo:hi].double().t() @ B[lo:hi].double()
+        sz = (A[lo:hi].double().abs().t() @ B[lo:hi].double().abs()).clamp_min(1e-300)
+        print(f"  slice {z}: max rel err {((part[z].double() - rz).abs() / sz).max().item():.3e}")
+    t_p = timed(lambda: call("txe_split_pack_t", ptr(B), N, n, N, ptr(Bt), s))
+    t_g = timed(lambda: call("txe_gemm_tn_split", ptr(A), M, M, ptr(Bt), N, n, S, ksplit, ptr(part), N, M * N, s))
+    out = torch.empty(M, N, device=dev)
+    t_mm = timed(lambda: torch.mm(A.t(), B, out=out))
+    print(f"pack {t_p:.1f} us, product {t_g:.1f} us = {2.0 * M * N * n / t_g * 1e-6:.1f} TF/s algorithmic (padded shapes); torch.mm fp32 {t_mm:.1f} us")
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "tn":
+        main_tn()
+    else:
+        main()

@@ -816,6 +816,9 @@ def main():
         _ops_ab._NO_MATCH_FOLD = True                    # the graph vector hg = Z W^T formed, the matcher on 4,096 rows of it (DESIGN 4.9 off)
         ab["step_no_match_fold_ms"] = timed(opt)
         _ops_ab._NO_MATCH_FOLD = False
+        _ops_ab._NO_SPLIT_GEMM = True                    # the first layer's projection and weight gradient on the fp32 MFMA (what rounds 1-5
+        ab["step_fp32_mfma_ms"] = timed(opt)             # timed) instead of the bf16 pipe's six plane products
+        _ops_ab._NO_SPLIT_GEMM = False
         ab["step_reference_model_py_ms"] = timed(opt, mdl=ReferenceCaller(model))
         ab["step_reference_model_py_routes"] = {k: _ops_ab.ROUTES.get(k) for k in ("match", "stack", "fold", "stack_bwd")}
         torch.autograd.set_multithreading_enabled(True)

@@ -216,9 +216,12 @@ __global__ __launch_bounds__(256) void split_pack_t_kernel(const float* __restri
 
 // ---- the TN product ------------------------------------------------------------------------------------------------------------
 // 128 (M) x 160 (N) tile per workgroup of four waves; wave w owns the 32 row slots of A block w x all five B blocks (80 accumulator
-// registers).  k-tiles of 16 contraction rows, two stages: B's 15 fragments arrive by LDS-direct copies (15 KB contiguous), A's
-// [16][128] fp32 patch goes through registers -- thread (pair q = t & 63, row quad t >> 6) loads 4 rows x 2 adjacent columns, splits
-// them and writes six 8-byte half lane words -- while the MFMA block of the tile before runs.
+// registers).  k-tiles of 16 contraction rows, two fragment stages.  B's 15 fragments arrive by LDS-direct copies (15 KB contiguous,
+// one k-tile ahead).  A's [16][128] fp32 patch arrives by LDS-direct copies too, TWO k-tiles ahead, into a raw ring: wave w copies rows
+// 4 w .. 4 w + 3 (2 KB) and is the only reader of them -- thread (column pair q = lane, row quad w) reads its 4 rows x 2 adjacent
+// columns back, splits them and writes six 8-byte half lane words into the next fragment stage while the other waves still multiply.
+// (The first version loaded the patch into registers one k-tile ahead: the wait for those loads cost 25 of its 131 us.)
+// Every copy is issued from inline asm and every wave issues exactly 6 per k-tile (4 B + 2 A), so the waits are exact counts.
 // A's slot permutation: slot s of block fb is column 64 (fb >> 1) + 2 s + (fb & 1) of the tile (a thread's two columns land in slot
 // s of two neighbouring blocks: consecutive lanes write consecutive LDS words).
 struct SplitTn {
@@ -227,11 +230,15 @@ struct SplitTn {
     int n_rows, ksplit, ntm, ntn;
 };
 constexpr int SPT_A_U4 = 4 * 3 * 64, SPT_B_U4 = 5 * 3 * 64, SPT_STAGE_U4 = SPT_A_U4 + SPT_B_U4;   // 12 KB + 15 KB
+constexpr int SPT_RAW_F = 16 * 128;                                                              // 8 KB
 
 __global__ __launch_bounds__(256, 2) void gemm_tn_split_kernel(const SplitTn p) {
     __shared__ __attribute__((aligned(16))) uint4 st0[SPT_STAGE_U4];
     __shared__ __attribute__((aligned(16))) uint4 st1[SPT_STAGE_U4];
+    __shared__ __attribute__((aligned(16))) float raw0[SPT_RAW_F];
+    __shared__ __attribute__((aligned(16))) float raw1[SPT_RAW_F];
     typedef __attribute__((address_space(3))) uint4 lds_u4;
+    typedef __attribute__((address_space(3))) float lds_f;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), l = threadIdx.x & 63;
     const int ntiles = p.ntm * p.ntn;
     const int vb = xcd_remap(blockIdx.x, gridDim.x);
@@ -239,41 +246,45 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_split_kernel(const SplitTn p) 
     const int tm = lb / p.ntn, h = lb % p.ntn;
     const int kbeg = z * p.ksplit, kend = min(p.n_rows, kbeg + p.ksplit);
     const int nk = kend > kbeg ? (kend - kbeg + 15) / 16 : 0;
-    // B: fragments 4 w .. 4 w + 3 (< 15) of the k-tile's 15
+    // B: fragments 4 w .. 4 w + 3 of the k-tile's 15 (wave 3: 12, 13, 14 and 14 again -- every wave issues the same number of copies)
     const char* gb = p.Bt + (((long long)(kbeg / 16) * p.nkb + 5 * h) * 3 + 4 * w) * SPL_FRAG_BYTES;
     const long long adv_b = (long long)p.nkb * 3 * SPL_FRAG_BYTES;
     const unsigned lane_off = l * 16;
-    // A: this thread's 4 rows x 2 columns
-    const int q = l, g = q >> 5, s = q & 31;
-    const float* ga = p.A + (long long)tm * 128 + 64 * g + 2 * s;
+    // A: rows 4 w + 2 i + (lane >> 5), i = 0, 1, 16 bytes per lane (32-bit byte offsets from the tile's first column: the launcher checks)
+    const float* ga = p.A + (long long)tm * 128;
+    const unsigned a_col = (l & 31) * 16;
     const int last_row = p.n_rows - 1;
+    const int g = l >> 5, s = l & 31;
 
     f32x16s acc[5];
 #pragma unroll
     for (int j = 0; j < 5; ++j)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
-    float2 ra[4];
 
-#define TXE_ST_COPY(g_, d_)                                                                                           \
-    asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(lane_off), "s"(g_), "s"((unsigned)(uintptr_t)(d_)) : "memory");
+#define TXE_ST_COPY(v_, g_, d_)                                                                                       \
+    asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(v_), "s"(g_), "s"((unsigned)(uintptr_t)(d_)) : "memory");
 #define TXE_ST_ISSUE_B(st_, t_)                                                                                       \
     {                                                                                                                \
-        const char* sb = gb + (long long)(t_) * adv_b;                                                               \
+        const char* sb = gb + (long long)min((t_), nk - 1) * adv_b;                                                  \
         lds_u4* d0 = (lds_u4*)(st_) + SPT_A_U4 + (4 * w) * 64;                                                       \
-        TXE_ST_COPY(sb, d0)                                                                                          \
-        TXE_ST_COPY(sb + SPL_FRAG_BYTES, d0 + 64)                                                                    \
-        TXE_ST_COPY(sb + 2 * SPL_FRAG_BYTES, d0 + 128)                                                               \
-        if (w < 3) TXE_ST_COPY(sb + 3 * SPL_FRAG_BYTES, d0 + 192)                                                    \
+        const int q3 = w < 3 ? 3 : 2;                                                                                \
+        TXE_ST_COPY(lane_off, sb, d0)                                                                                \
+        TXE_ST_COPY(lane_off, sb + SPL_FRAG_BYTES, d0 + 64)                                                          \
+        TXE_ST_COPY(lane_off, sb + 2 * SPL_FRAG_BYTES, d0 + 128)                                                     \
+        TXE_ST_COPY(lane_off, sb + q3 * SPL_FRAG_BYTES, d0 + q3 * 64)                                                \
     }
-#define TXE_ST_LOAD_A(t_)                                                                                             \
-    _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                                                  \
-        const int row = min(kbeg + (t_) * 16 + 4 * w + r, last_row);                                                 \
-        ra[r] = *reinterpret_cast<const float2*>(ga + (long long)row * p.lda);                                       \
+#define TXE_ST_ISSUE_A(raw_, t_)                                                                                      \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                                  \
+        const int row = min(kbeg + min((t_), nk - 1) * 16 + 4 * w + 2 * i + (l >> 5), last_row);                     \
+        const unsigned off = (unsigned)row * (unsigned)(p.lda * 4) + a_col;                                          \
+        TXE_ST_COPY(off, ga, (lds_f*)(raw_) + (4 * w + 2 * i) * 128)                                                 \
     }
-    // rows 4 w .. 4 w + 3 of the k-tile = half (w & 1) of lane word (nh = w >> 1, slot s) of blocks 2 g and 2 g + 1
-#define TXE_ST_STORE_A(st_)                                                                                           \
+    // raw rows 4 w .. 4 w + 3, columns 2 lane, 2 lane + 1 = half (w & 1) of lane word (nh = w >> 1, slot s) of blocks 2 g and 2 g + 1
+#define TXE_ST_CONVERT(raw_, st_)                                                                                     \
     {                                                                                                                \
+        float2 ra[4];                                                                                                \
+        _Pragma("unroll") for (int r = 0; r < 4; ++r) ra[r] = *reinterpret_cast<const float2*>((raw_) + (4 * w + r) * 128 + 2 * l); \
         const float x0[4] = {ra[0].x, ra[1].x, ra[2].x, ra[3].x}, x1[4] = {ra[0].y, ra[1].y, ra[2].y, ra[3].y};      \
         uint2 u1, u2, u3, v1, v2, v3;                                                                                \
         split3x4(x0, u1, u2, u3);                                                                                    \
@@ -294,33 +305,36 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_split_kernel(const SplitTn p) 
                 fb[j][c] = __builtin_bit_cast(bf16x8, (st_)[SPT_A_U4 + (j * 3 + c) * 64 + l]);                       \
         TXE_ST_MFMA(2, 0) TXE_ST_MFMA(0, 2) TXE_ST_MFMA(1, 1) TXE_ST_MFMA(1, 0) TXE_ST_MFMA(0, 1) TXE_ST_MFMA(0, 0)  \
     }
-#define TXE_ST_STEP(cur_, nxt_, t_)                                                                                   \
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     /* B of this tile has landed (A of it was stored a step ago) */ \
-    __syncthreads();                                                                                                 \
-    if ((t_) + 1 < nk) {                                                                                             \
-        TXE_ST_ISSUE_B(nxt_, (t_) + 1)                                                                               \
-        TXE_ST_LOAD_A((t_) + 1)                                                                                      \
-    }                                                                                                                \
+    // step t: in flight at its start are B(t) (4 copies) and, younger, A(t+1) (2 copies)
+#define TXE_ST_STEP(cur_, nxt_, rcur_, rnxt_, t_)                                                                     \
+    asm volatile("s_waitcnt vmcnt(2)" ::: "memory");     /* B(t) has landed */                                       \
+    __syncthreads();                                     /* ... every wave's, and every wave's converted A(t) */     \
+    TXE_ST_ISSUE_B(nxt_, (t_) + 1)                                                                                   \
+    TXE_ST_ISSUE_A(rcur_, (t_) + 2)                      /* (this wave converted raw(t) a step ago) */               \
     __builtin_amdgcn_sched_barrier(0);                                                                               \
     TXE_ST_COMPUTE(cur_)                                                                                             \
     __builtin_amdgcn_sched_barrier(0);                                                                               \
-    if ((t_) + 1 < nk) TXE_ST_STORE_A(nxt_)
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");     /* A(t+1) has landed (this wave's own rows) */              \
+    if ((t_) + 1 < nk) TXE_ST_CONVERT(rnxt_, nxt_)
 
     if (nk > 0) {
         TXE_ST_ISSUE_B(st0, 0)
-        TXE_ST_LOAD_A(0)
-        TXE_ST_STORE_A(st0)
+        TXE_ST_ISSUE_A(raw0, 0)
+        TXE_ST_ISSUE_A(raw1, 1)
+        asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        TXE_ST_CONVERT(raw0, st0)
         for (int t = 0; t < nk; t += 2) {
-            TXE_ST_STEP(st0, st1, t)
+            TXE_ST_STEP(st0, st1, raw0, raw1, t)
             if (t + 1 >= nk) break;
-            TXE_ST_STEP(st1, st0, t + 1)
+            TXE_ST_STEP(st1, st0, raw1, raw0, t + 1)
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the clamped copies past the last k-tile
     }
 #undef TXE_ST_STEP
 #undef TXE_ST_COMPUTE
 #undef TXE_ST_MFMA
-#undef TXE_ST_STORE_A
-#undef TXE_ST_LOAD_A
+#undef TXE_ST_CONVERT
+#undef TXE_ST_ISSUE_A
 #undef TXE_ST_ISSUE_B
 #undef TXE_ST_COPY
 
@@ -385,7 +399,7 @@ int split_pack_t_launch(const float* src, long long ld, int rows, int cols, void
 int gemm_tn_split_launch(const float* A, long long lda, int M, const void* Bt, int N, int n_rows, int S, int ksplit, float* part, long long ldc,
                          long long split_stride, double alg_flops, hipStream_t stream) {
     if (!A || !Bt || !part || !split_tn_eligible(M, N) || n_rows < 1 || S < 1 || ksplit < 16 || ksplit % 16 != 0 || ldc < N || (ldc & 3) != 0 ||
-        (lda & 1) != 0 || (reinterpret_cast<uintptr_t>(A) & 7) != 0 || (reinterpret_cast<uintptr_t>(part) & 15) != 0 || (split_stride & 3) != 0)
+        (lda & 3) != 0 || (reinterpret_cast<uintptr_t>(A) & 15) != 0 || (double)n_rows * (double)lda * 4.0 >= 4294967296.0 || (reinterpret_cast<uintptr_t>(part) & 15) != 0 || (split_stride & 3) != 0)
         return TXE_ERR_ARG;
     SplitTn p;
     p.A = A; p.lda = lda; p.Bt = (const char*)Bt; p.nkb = N / 32;

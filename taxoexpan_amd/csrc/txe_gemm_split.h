@@ -12,7 +12,7 @@
 // Slot -> row: side 0 (the A operand, C's rows): row = 32 rb + s.  Side 1 (the B operand, C's columns): a 128-column tile is four
 // fragments j = rb & 3 and slot s of fragment j is column 128 (rb >> 2) + 64 (j >> 1) + 2 s + (j & 1), so that a lane's two
 // accumulator blocks hold two ADJACENT columns of C (8-byte stores, 256 contiguous bytes per half wave).
-// Rows are padded to 256 and columns to 16 with zeros.
+// Rows are padded to 768 (whole tiles of 128, 192 or 256 rows) and columns to 16 with zeros.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -23,7 +23,7 @@ constexpr int SPL_BM = 128, SPL_BN = 128, SPL_KT = 16;
 constexpr int SPL_FRAG_BYTES = 1024;
 
 static inline size_t split_packed_bytes(int rows, int cols) {
-    const size_t rb = (size_t)((rows + 255) / 256) * 8, nkt = (size_t)(cols + SPL_KT - 1) / SPL_KT;
+    const size_t rb = (size_t)((rows + 767) / 768) * 24, nkt = (size_t)(cols + SPL_KT - 1) / SPL_KT;
     return rb * nkt * 3 * SPL_FRAG_BYTES;
 }
 

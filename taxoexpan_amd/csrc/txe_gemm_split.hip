@@ -52,8 +52,8 @@ struct SplitGemm {
 template <int MI, int NST, int MINB>
 __global__ __launch_bounds__(256, MINB) void gemm_nt_split_kernel(const SplitGemm p) {
     constexpr int NA = 2 * MI, NB = 4;                      // A / B fragment blocks per tile
-    constexpr int NF = 3 * (NA + NB), CP = NF / 4;          // fragments per stage, copies per wave and k-tile
-    static_assert(NF % 4 == 0, "fragments per wave");
+    constexpr int NF = 3 * (NA + NB), CP = (NF + 3) / 4;    // fragments per stage, copies per wave and k-tile (the last wave: the rest)
+    static_assert(NST == 2 || NF % 4 == 0, "the three-stage ring waits on an exact copy count");
     constexpr int STAGE_U4 = NF * 64;
     // one LDS object per stage
     __shared__ __attribute__((aligned(16))) uint4 st0[STAGE_U4];
@@ -70,7 +70,7 @@ __global__ __launch_bounds__(256, MINB) void gemm_nt_split_kernel(const SplitGem
     const char* gsrc[CP];
 #pragma unroll
     for (int q = 0; q < CP; ++q) {
-        const int f = CP * w + q;
+        const int f = min(CP * w + q, NF - 1);
         const bool isa = f < 3 * NA;
         const int blk = isa ? f / 3 : (f - 3 * NA) / 3, pl = isa ? f % 3 : (f - 3 * NA) % 3;
         const char* base = isa ? p.A : p.B;
@@ -96,7 +96,8 @@ __global__ __launch_bounds__(256, MINB) void gemm_nt_split_kernel(const SplitGem
     {                                                                                                                \
         const long long ko = (long long)min((kt_), nkt - 1) * (3 * SPL_FRAG_BYTES);                                  \
         lds_u4* d0 = (lds_u4*)(st_) + (CP * w) * 64;                                                                 \
-        _Pragma("unroll") for (int q = 0; q < CP; ++q) TXE_SP_COPY(gsrc[q] + ko, d0 + q * 64)                        \
+        _Pragma("unroll") for (int q = 0; q < CP; ++q)                                                               \
+            if (NF % 4 == 0 || CP * w + q < NF) TXE_SP_COPY(gsrc[q] + ko, d0 + q * 64)                               \
     }
 #define TXE_SP_MFMA(pa_, pb_)                                                                                         \
     _Pragma("unroll") for (int i = 0; i < MI; ++i)                                                                   \
@@ -355,7 +356,7 @@ int g_split_variant = 0;
 
 int split_pack_launch(const float* src, long long ld, int rows, int cols, int side, void* packed, hipStream_t stream) {
     if (!src || !packed || rows < 1 || cols < 1 || ld < cols || side < 0 || side > 1) return TXE_ERR_ARG;
-    const int nrb = ((rows + 255) / 256) * 8, nkt = (cols + SPL_KT - 1) / SPL_KT;
+    const int nrb = ((rows + 767) / 768) * 24, nkt = (cols + SPL_KT - 1) / SPL_KT;
     const long long total = (long long)nrb * nkt * 64;
     const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
     ProfScope prof("split_pack_kernel", stream, 10.0 * rows * (double)cols, 1);
@@ -370,7 +371,7 @@ int gemm_nt_split_launch(const void* Ap, const void* Bp, int M, int N, int K, fl
     p.A = (const char*)Ap; p.B = (const char*)Bp; p.nkt = (K + SPL_KT - 1) / SPL_KT;
     p.C = C; p.ldc = ldc; p.M = M; p.N = N;
     const int v = g_split_variant & 15;
-    const int bm = (v == 2 || v == 3) ? 256 : 128;
+    const int bm = (v == 2 || v == 3) ? 256 : (v == 5 ? 192 : 128);
     p.nbm = (M + bm - 1) / bm; p.nbn = (N + SPL_BN - 1) / SPL_BN;
     ProfScope prof("gemm_nt_split_kernel", stream, alg_flops > 0.0 ? alg_flops : 2.0 * M * (double)N * K, 0);
     const dim3 grid(p.nbm * p.nbn), blk(256);
@@ -380,6 +381,7 @@ int gemm_nt_split_launch(const void* Ap, const void* Bp, int M, int N, int K, fl
     else if (v == 2) hipLaunchKernelGGL((gemm_nt_split_kernel<4, 2, 2>), grid, blk, 0, stream, p);
     else if (v == 3) hipLaunchKernelGGL((gemm_nt_split_kernel<4, 3, 1>), grid, blk, 0, stream, p);
     else if (v == 4) hipLaunchKernelGGL((gemm_nt_split_kernel<2, 2, 2>), grid, blk, 0, stream, p);
+    else if (v == 5) hipLaunchKernelGGL((gemm_nt_split_kernel<3, 2, 2>), grid, blk, 0, stream, p);
     else return TXE_ERR_ARG;
     TXE_CHECK_LAUNCH();
     return TXE_OK;

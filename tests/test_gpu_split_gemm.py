@@ -34,7 +34,7 @@ def test_packed_planes_sum_to_the_operand_exactly(rows, cols, side):
     torch.cuda.synchronize()
     raw = buf.cpu().numpy().view(np.uint16)
     nkt = (cols + 15) // 16
-    nrb = ((rows + 255) // 256) * 8
+    nrb = ((rows + 767) // 768) * 24
     frag = raw.reshape(nrb, nkt, 3, 2, 32, 8)          # [rb][kt][plane][kh][slot][8 k]
     total = np.zeros((rows, nkt * 16))
     seen = np.zeros((rows, nkt * 16), dtype=bool)

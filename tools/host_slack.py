@@ -44,10 +44,18 @@ for i in range(300):
 import gc; gc.collect(); gc.freeze()
 base = measure()
 print(f"base {base:.4f} ms")
-for name in ("txe_gat_layers_prepare", "txe_gat_dense_fwd", "txe_gat_aggregate_fwd", "txe_rows_find_runs", "txe_bilinear_folded_fwd", "txe_gat_collapse_fwd", "txe_gat_collapse_fold_scores",
+for name in ("txe_gat_layers_prepare", "txe_gat_dense_fwd_split", "txe_gat_aggregate_fwd", "txe_rows_find_runs", "txe_bilinear_folded_fwd", "txe_gat_collapse_fwd", "txe_gat_collapse_fold_scores",
              "txe_info_nce", "txe_bilinear_folded_bwd", "txe_gat_collapse_bwd_fused", "txe_gat_dense_bwd", "txe_adam_step"):
     DELAY.update(name=name, us=30.0)
     t = measure()
     print(f"+30 us of host time before {name:34s}: {t:.4f} ms  ({1e3 * (t - base):+.1f} us)")
 DELAY.update(name=None)
 print(f"base again {measure():.4f} ms")
+# host enqueue time of one step (no device wait): the queue is drained first, then 20 steps are enqueued back to back
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for i in range(20):
+    bench.train_step(model, opt, batches[i % 4], target, 1)
+t_host = (time.perf_counter() - t0) / 20
+torch.cuda.synchronize()
+print(f"host enqueue time per step (20 steps enqueued without waiting): {1e3 * t_host:.4f} ms")

@@ -10,7 +10,8 @@
  *     (a hipStream_t passed as void*);  workspaces are supplied by the caller (size from the *_ws_bytes functions)
  *   - return value: 0 = TXE_OK, <0 = error (TXE_ERR_ARG -1, TXE_ERR_LAUNCH -2, TXE_ERR_WORKSPACE -3); never throws
  *   - re-entrant; no state between calls except the optional per-launch profiler (txe_profile_*, off by default: a process-global
- *     switch and a per-device ring of events) and the cached CU count of the current device
+ *     switch and a per-device ring of events), the cached CU count of the current device and the tuning hook txe_gemm_split_variant
+ *     (a process-global int the library itself never sets)
  *   - graph structure: destination-sorted CSR  (rowptr_in[N+1], col_src[E])  and source-sorted CSR
  *     (rowptr_out[N+1], col_dst[E], pos_out[E] = index of that edge in the destination-sorted order); per-edge
  *     arrays (alpha, dz) live in destination-sorted order
@@ -405,7 +406,7 @@ int txe_egonet_fill(const int* par_ptr, const int* par_idx, const int* chd_ptr, 
                     int* rowptr_in, int* col_src, int* eid_in, int* rowptr_out, int* col_dst, int* pos_out, void* stream);
 
 /* ---- optional per-kernel timing (debug / bench): HIP events on the launch stream around every kernel launch, with the
- * algorithmic work (flops or compulsory bytes) its launcher attributes to it.  The library's only global state; off by
+ * algorithmic work (flops or compulsory bytes) its launcher attributes to it.  Global state (see the conventions at the top); off by
  * default.  txe_profile_get synchronises on record i's events. */
 int txe_profile_enable(int on);
 int txe_profile_reset(void);
@@ -443,7 +444,8 @@ int txe_adam_step(int n_tensors, float* const* params, const float* const* grads
  * side 0 = the operand whose rows are C's rows, side 1 = the operand whose rows are C's columns. */
 size_t txe_split_packed_bytes(int rows, int cols);
 int txe_split_pack(const float* src, long long ld, int rows, int cols, int side, void* packed, void* stream);
-int txe_gemm_split_variant(int v);   /* tuning: tile / stage variant of the next products */
+int txe_gemm_split_variant(int v);   /* tuning hook (tools/split_gemm_probe.py): tile / stage variant of the products launched after it;
+                                       * PROCESS-GLOBAL state, not thread-safe, default 0 -- the library itself never calls it */
 int txe_gemm_nt_split(const void* A_packed, const void* B_packed, int M, int N, int K, float* C, long long ldc, void* stream);
 
 /* The TN form (weight gradients, model_zoo.py:83 backward: dW = d_Y^T X over the nodes): part[z][M][ldc] = A[rows of slice z]^T B[same rows],

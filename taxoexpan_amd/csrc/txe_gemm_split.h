@@ -68,11 +68,15 @@ static inline size_t split_packed_t_bytes(int rows, int cols) {
     return (size_t)((rows + 15) / 16) * (size_t)(cols / 32) * 3 * SPL_FRAG_BYTES;
 }
 static inline bool split_tn_eligible(int M, int N) { return M % 128 == 0 && N % 160 == 0 && M > 0 && N > 0; }
+// ... and A [n_rows][lda] is addressed with 32-bit byte offsets
+static inline bool split_tn_fits(int n_rows, long long lda) { return (double)n_rows * (double)lda * 4.0 < 4294967296.0; }
 
 // launches (txe_gemm_split.hip)
 int split_pack_launch(const float* src, long long ld, int rows, int cols, int side, void* packed, hipStream_t stream);
 int gemm_nt_split_launch(const void* Ap, const void* Bp, int M, int N, int K, float* C, long long ldc, double alg_flops, hipStream_t stream);
 int split_pack_t_launch(const float* src, long long ld, int rows, int cols, void* packed, hipStream_t stream);
+int split_pack_layer_launch(const float* X, long long ldx, int n, const float* W, long long ldw, int f, int K, void* Xs, void* Ws, void* Xt,
+                            hipStream_t stream);
 // part[z][M][ldc] = A[rows of slice z]^T B[rows of slice z], z < S, slices of ksplit rows (a multiple of 16)
 int gemm_tn_split_launch(const float* A, long long lda, int M, const void* Bt, int N, int n_rows, int S, int ksplit, float* part, long long ldc,
                          long long split_stride, double alg_flops, hipStream_t stream);

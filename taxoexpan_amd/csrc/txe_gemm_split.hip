@@ -1,4 +1,5 @@
 // C = A B^T in fp32 accuracy on the bf16 matrix pipe (three-plane operands, six plane products: txe_gemm_split.h)
+#include <string.h>
 #include "txe_common.h"
 #include "txe_gemm_split.h"
 
@@ -9,22 +10,26 @@ typedef __attribute__((ext_vector_type(16))) float f32x16s;
 
 // ---- packing: fp32 [rows][ld] -> three bf16 planes in fragment order --------------------------------------------------------------
 // one thread per (fragment block rb, k-tile kt, lane): reads 8 consecutive floats of its slot's row, writes 16 bytes per plane
-__global__ __launch_bounds__(256) void split_pack_kernel(const float* __restrict__ src, long long ld, int rows, int cols, int side, int nrb,
-                                                         int nkt, uint4* __restrict__ dst) {
-    const long long total = (long long)nrb * nkt * 64;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+struct SplitPackArgs { const float* src; long long ld; int rows, cols, side, nrb, nkt; uint4* dst; };
+__device__ __forceinline__ void split_pack_job(const SplitPackArgs& a, const int bid, const int nb) {
+    const float* __restrict__ src = a.src;
+    uint4* __restrict__ dst = a.dst;
+    const int nkt = a.nkt, rows = a.rows, cols = a.cols;
+    const long long ld = a.ld;
+    const long long total = (long long)a.nrb * nkt * 64;
+    for (long long i = (long long)bid * blockDim.x + threadIdx.x; i < total; i += (long long)nb * blockDim.x) {
         const int l = (int)(i & 63);
         const long long f = i >> 6;                       // fragment pair index rb * nkt + kt
         const int kt = (int)(f % nkt), rb = (int)(f / nkt);
-        const int row = split_slot_row(side, rb, l & 31), k0 = kt * SPL_KT + 8 * (l >> 5);
+        const int row = split_slot_row(a.side, rb, l & 31), k0 = kt * SPL_KT + 8 * (l >> 5);
         float x[8];
 #pragma unroll
         for (int q = 0; q < 8; ++q) x[q] = 0.f;
         if (row < rows) {
             const float* p = src + (long long)row * ld + k0;
             if (k0 + 7 < cols && ((reinterpret_cast<uintptr_t>(p) & 15) == 0)) {
-                const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
-                x[0] = a.x; x[1] = a.y; x[2] = a.z; x[3] = a.w; x[4] = b.x; x[5] = b.y; x[6] = b.z; x[7] = b.w;
+                const float4 u = *reinterpret_cast<const float4*>(p), v = *reinterpret_cast<const float4*>(p + 4);
+                x[0] = u.x; x[1] = u.y; x[2] = u.z; x[3] = u.w; x[4] = v.x; x[5] = v.y; x[6] = v.z; x[7] = v.w;
             } else {
 #pragma unroll
                 for (int q = 0; q < 8; ++q)
@@ -37,6 +42,7 @@ __global__ __launch_bounds__(256) void split_pack_kernel(const float* __restrict
         o[0] = w1; o[64] = w2; o[128] = w3;
     }
 }
+__global__ __launch_bounds__(256) void split_pack_kernel(const SplitPackArgs a) { split_pack_job(a, blockIdx.x, gridDim.x); }
 
 // ---- the product -----------------------------------------------------------------------------------------------------------------
 // A (64 MI) x 128 tile per workgroup of four waves (2 x 2; a wave owns MI x 2 MFMA blocks of 32 x 32: 16 MI x 2 accumulator registers);
@@ -181,11 +187,15 @@ __global__ __launch_bounds__(256, MINB) void gemm_nt_split_kernel(const SplitGem
 
 // ---- side 2 packing: fp32 [rows][ld] -> contraction-major planes (txe_gemm_split.h) ------------------------------------------------
 // one thread per (row tile nt, column tile h, lane): 8 rows x (4 + 1) columns -> five fragments' lane words per plane
-__global__ __launch_bounds__(256) void split_pack_t_kernel(const float* __restrict__ src, long long ld, int rows, int nht, int nnt,
-                                                           uint4* __restrict__ dst) {
-    const long long total = (long long)nnt * nht * 64;
+struct SplitPackTArgs { const float* src; long long ld; int rows, nht, nnt; uint4* dst; };
+__device__ __forceinline__ void split_pack_t_job(const SplitPackTArgs& a, const int bid, const int nb) {
+    const float* __restrict__ src = a.src;
+    uint4* __restrict__ dst = a.dst;
+    const int rows = a.rows, nht = a.nht;
+    const long long ld = a.ld;
+    const long long total = (long long)a.nnt * nht * 64;
     const int nkb = nht * 5;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    for (long long i = (long long)bid * blockDim.x + threadIdx.x; i < total; i += (long long)nb * blockDim.x) {
         const int l = (int)(i & 63), s = l & 31, nh = l >> 5;
         const long long g = i >> 6;
         const int h = (int)(g % nht), nt = (int)(g / nht);
@@ -213,6 +223,18 @@ __global__ __launch_bounds__(256) void split_pack_t_kernel(const float* __restri
             base[(j * 3 + 0) * 64] = w1; base[(j * 3 + 1) * 64] = w2; base[(j * 3 + 2) * 64] = w3;
         }
     }
+}
+__global__ __launch_bounds__(256) void split_pack_t_kernel(const SplitPackTArgs a) { split_pack_t_job(a, blockIdx.x, gridDim.x); }
+
+// the packs a layer's two products need, in ONE launch: side 0 of X, side 1 of Wp, side 2 of X (three launches of 4-13 us cost their
+// dispatch gaps on top)
+struct SplitPackMulti { SplitPackArgs a[2]; SplitPackTArgs t; int nb[3]; };
+__global__ __launch_bounds__(256) void split_pack_multi_kernel(const SplitPackMulti m) {
+    int b = blockIdx.x;
+    if (b < m.nb[0]) { split_pack_job(m.a[0], b, m.nb[0]); return; }
+    b -= m.nb[0];
+    if (b < m.nb[1]) { split_pack_job(m.a[1], b, m.nb[1]); return; }
+    split_pack_t_job(m.t, b - m.nb[1], m.nb[2]);
 }
 
 // ---- the TN product ------------------------------------------------------------------------------------------------------------
@@ -354,13 +376,40 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_split_kernel(const SplitTn p) 
 
 int g_split_variant = 0;
 
+static bool fill_pack(SplitPackArgs& a, int& nb, const float* src, long long ld, int rows, int cols, int side, void* packed) {
+    if (!src || !packed || rows < 1 || cols < 1 || ld < cols || side < 0 || side > 1) return false;
+    a.src = src; a.ld = ld; a.rows = rows; a.cols = cols; a.side = side; a.dst = (uint4*)packed;
+    a.nrb = ((rows + 767) / 768) * 24; a.nkt = (cols + SPL_KT - 1) / SPL_KT;
+    const long long total = (long long)a.nrb * a.nkt * 64;
+    nb = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    return true;
+}
+static bool fill_pack_t(SplitPackTArgs& a, int& nb, const float* src, long long ld, int rows, int cols, void* packed) {
+    if (!src || !packed || rows < 1 || cols < 160 || cols % 160 != 0 || ld < cols || (ld & 3) != 0 || (reinterpret_cast<uintptr_t>(src) & 15) != 0)
+        return false;
+    a.src = src; a.ld = ld; a.rows = rows; a.nht = cols / 160; a.nnt = (rows + 15) / 16; a.dst = (uint4*)packed;
+    const long long total = (long long)a.nnt * a.nht * 64;
+    nb = (int)((total + 255) / 256);
+    return true;
+}
 int split_pack_launch(const float* src, long long ld, int rows, int cols, int side, void* packed, hipStream_t stream) {
-    if (!src || !packed || rows < 1 || cols < 1 || ld < cols || side < 0 || side > 1) return TXE_ERR_ARG;
-    const int nrb = ((rows + 767) / 768) * 24, nkt = (cols + SPL_KT - 1) / SPL_KT;
-    const long long total = (long long)nrb * nkt * 64;
-    const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    SplitPackArgs a;
+    int nb;
+    if (!fill_pack(a, nb, src, ld, rows, cols, side, packed)) return TXE_ERR_ARG;
     ProfScope prof("split_pack_kernel", stream, 10.0 * rows * (double)cols, 1);
-    hipLaunchKernelGGL(split_pack_kernel, dim3(blocks), dim3(256), 0, stream, src, ld, rows, cols, side, nrb, nkt, (uint4*)packed);
+    hipLaunchKernelGGL(split_pack_kernel, dim3(nb), dim3(256), 0, stream, a);
+    TXE_CHECK_LAUNCH();
+    return TXE_OK;
+}
+// X [n][ldx] -> Xs (side 0) and, Xt != NULL, Xt (side 2); W [f][ldw] -> Ws (side 1): one launch
+int split_pack_layer_launch(const float* X, long long ldx, int n, const float* W, long long ldw, int f, int K, void* Xs, void* Ws, void* Xt,
+                            hipStream_t stream) {
+    SplitPackMulti m;
+    memset(&m, 0, sizeof(m));
+    if (!fill_pack(m.a[0], m.nb[0], X, ldx, n, K, 0, Xs) || !fill_pack(m.a[1], m.nb[1], W, ldw, f, K, 1, Ws)) return TXE_ERR_ARG;
+    if (Xt && !fill_pack_t(m.t, m.nb[2], X, ldx, n, K, Xt)) return TXE_ERR_ARG;
+    ProfScope prof("split_pack_multi_kernel", stream, 10.0 * K * ((Xt ? 2.0 : 1.0) * n + f), 1);
+    hipLaunchKernelGGL(split_pack_multi_kernel, dim3(m.nb[0] + m.nb[1] + m.nb[2]), dim3(256), 0, stream, m);
     TXE_CHECK_LAUNCH();
     return TXE_OK;
 }
@@ -388,12 +437,11 @@ int gemm_nt_split_launch(const void* Ap, const void* Bp, int M, int N, int K, fl
 }
 
 int split_pack_t_launch(const float* src, long long ld, int rows, int cols, void* packed, hipStream_t stream) {
-    if (!src || !packed || rows < 1 || cols < 160 || cols % 160 != 0 || ld < cols || (ld & 3) != 0 || (reinterpret_cast<uintptr_t>(src) & 15) != 0)
-        return TXE_ERR_ARG;
-    const int nht = cols / 160, nnt = (rows + 15) / 16;
-    const long long total = (long long)nnt * nht * 64;
+    SplitPackTArgs a;
+    int nb;
+    if (!fill_pack_t(a, nb, src, ld, rows, cols, packed)) return TXE_ERR_ARG;
     ProfScope prof("split_pack_t_kernel", stream, 10.0 * rows * (double)cols, 1);
-    hipLaunchKernelGGL(split_pack_t_kernel, dim3((int)((total + 255) / 256)), dim3(256), 0, stream, src, ld, rows, nht, nnt, (uint4*)packed);
+    hipLaunchKernelGGL(split_pack_t_kernel, dim3(nb), dim3(256), 0, stream, a);
     TXE_CHECK_LAUNCH();
     return TXE_OK;
 }

@@ -856,7 +856,7 @@ size_t txe_gat_dense_split_ws_bytes(int n_nodes, int Kh, int Pd, int H, int D) {
 size_t txe_gat_dense_split_xt_bytes(int n_nodes, int Kh, int Pd, int H, int D) {       // 0: this layer's weight gradient keeps the fp32 route
     if (n_nodes < 1 || Kh < 1 || Pd < 0 || H < 1 || D < 1) return 0;
     const int Fp = round_up(H * D + 2 * H, 128), Kp = round_up(Kh + Pd, 32);
-    return split_tn_eligible(Fp, Kp) ? split_packed_t_bytes(n_nodes, Kp) : 0;
+    return (split_tn_eligible(Fp, Kp) && split_tn_fits(n_nodes, Fp)) ? split_packed_t_bytes(n_nodes, Kp) : 0;
 }
 int txe_gat_dense_fwd_split(const float* X, int n_nodes, int Kh, int Pd, const float* Wp, int H, int D, const void* Xs, const void* Ws,
                             void* Xt_out, float* Y, void* ws, size_t ws_bytes, void* stream) {
@@ -867,6 +867,15 @@ int txe_gat_dense_fwd_split(const float* X, int n_nodes, int Kh, int Pd, const f
     char* w = (char*)ws;
     size_t off = 0;
     int rc;
+    if (Xt_out && (!X || !split_tn_eligible(Fp, Kp))) return TXE_ERR_ARG;
+    bool xt_done = false;
+    if (!Xs && !Ws) {                                   // the usual case: all three packs in one launch
+        const size_t ba = align_up(split_packed_bytes(n_nodes, Kp), 256), bb = align_up(split_packed_bytes(Fp, Kp), 256);
+        if (!ws || ws_bytes < ba + bb) return TXE_ERR_WORKSPACE;
+        rc = split_pack_layer_launch(X, Kp, n_nodes, Wp, Kp, Fp, Kp, w, w + ba, Xt_out, s);
+        if (rc) return rc;
+        Xs = w; Ws = w + ba; xt_done = true;
+    }
     if (!Xs) {
         const size_t b = align_up(split_packed_bytes(n_nodes, Kp), 256);
         if (!ws || ws_bytes < off + b) return TXE_ERR_WORKSPACE;
@@ -883,11 +892,8 @@ int txe_gat_dense_fwd_split(const float* X, int n_nodes, int Kh, int Pd, const f
     }
     rc = gemm_nt_split_launch(Xs, Ws, n_nodes, Fe, Kp, Y, Fp, 2.0 * n_nodes * (double)Fe * (Kh + Pd), s);
     if (rc) return rc;
-    // X packed contraction-major for the backward pass's weight gradient (txe_gat_dense_bwd: Xt), behind the product: off its input's path
-    if (Xt_out) {
-        if (!X || !split_tn_eligible(Fp, Kp)) return TXE_ERR_ARG;
-        return split_pack_t_launch(X, Kp, n_nodes, Kp, Xt_out, s);
-    }
+    // (X packed contraction-major for the backward pass's weight gradient, txe_gat_dense_bwd: Xt)
+    if (Xt_out && !xt_done) return split_pack_t_launch(X, Kp, n_nodes, Kp, Xt_out, s);
     return TXE_OK;
 }
 
@@ -951,7 +957,7 @@ int txe_gat_dense_bwd(const float* X, int n_nodes, int Kh, int Pd, const int* po
     E.split_stride = (long long)Fp * Kp;
     E.alg_flops = 2.0 * Fe * (double)Kt * n_nodes;
     const int splits = p.splits;
-    if ((phases & 2) && Xt && x_dropped + (feat_drop_p == 0.f) > 0 && split_tn_eligible(Fp, Kp) && n_nodes > 0) {
+    if ((phases & 2) && Xt && x_dropped + (feat_drop_p == 0.f) > 0 && split_tn_eligible(Fp, Kp) && split_tn_fits(n_nodes, Fp) && n_nodes > 0) {
         // the same slices on the bf16 pipe (txe_gemm_split.h): X packed contraction-major by the forward pass, d_Y split in the loader
         const int ks = round_up((n_nodes + splits - 1) / splits, 16);
         rc = gemm_tn_split_launch(d_Y, Fp, Fp, Xt, Kp, n_nodes, splits, ks, p.part, Kp, E.split_stride, E.alg_flops, s);

@@ -106,6 +106,9 @@ int txe_gat_dense_bwd(const float* X, int n_nodes, int Kh, int Pd, const int* po
                       const float* attn_l, const float* attn_r, int H, int D, float feat_drop_p, const unsigned* mask, const float* d_Y,
                       int need_dh, int act_on, float act_slope, float* d_X, float* dW, float* d_attn_l, float* d_attn_r, float* dP,
                       int x_dropped, const void* Xt, int phases, void* chain, void* ws, size_t ws_bytes, void* stream);
+/* ws_bytes >= txe_gat_dense_ws_bytes + txe_gat_dense_bwd_split_ws_bytes and need_dh: d_X = d_Y Wp (the whole input gradient of a layer
+ * above the first) runs on the bf16 matrix pipe in fp32 accuracy, dropout mask and leaky' factor applied in its store loop. */
+size_t txe_gat_dense_bwd_split_ws_bytes(int n_nodes, int Kh, int Pd, int H, int D);
 /* phases: 7 = all of it; 1 | 2 | 4 = d_X | the weight-gradient product (split-K partial slices) | the reductions that finish dW,
  * d_attn, dP -- 1 and 2 are independent, 4 needs both.
  * chain (may be NULL): TXE_TAIL_CHAIN_BYTES of HOST memory, zero-filled = empty, owned by the caller for one backward pass.  The last
@@ -443,7 +446,8 @@ int txe_adam_step(int n_tensors, float* const* params, const float* const* grads
  * fp32 accumulation -- the dropped terms are below the rounding of one fp32 multiply.
  * side 0 = the operand whose rows are C's rows, side 1 = the operand whose rows are C's columns. */
 size_t txe_split_packed_bytes(int rows, int cols);
-int txe_split_pack(const float* src, long long ld, int rows, int cols, int side, void* packed, void* stream);
+int txe_split_pack(const float* src, long long ld, int rows, int cols, int side, void* packed, void* stream);   /* side 2 / 3: side 0 / 1 of
+    a matrix given as its transpose, src [cols][ld >= rows] */
 int txe_gemm_split_variant(int v);   /* tuning hook (tools/split_gemm_probe.py): tile / stage variant of the products launched after it;
                                        * PROCESS-GLOBAL state, not thread-safe, default 0 -- the library itself never calls it */
 int txe_gemm_nt_split(const void* A_packed, const void* B_packed, int M, int N, int K, float* C, long long ldc, void* stream);

@@ -25,6 +25,7 @@ SIGNATURES = {
     "txe_gat_dense_fwd": (I, [P, I, I, I, P, I, I, F, P, P, P, SZ, P]),
     "txe_gat_dense_split_ws_bytes": (SZ, [I, I, I, I, I]),
     "txe_gat_dense_split_xt_bytes": (SZ, [I, I, I, I, I]),
+    "txe_gat_dense_bwd_split_ws_bytes": (SZ, [I, I, I, I, I]),
     "txe_gat_dense_fwd_split": (I, [P, I, I, I, P, I, I, P, P, P, P, P, SZ, P]),
     "txe_gat_dense_bwd": (I, [P, I, I, I, P, I, P, P, P, P, I, I, F, P, P, I, I, F, P, P, P, P, P, I, P, I, P, P, SZ, P]),
     "txe_gat_tail_flush": (I, [P, P]),

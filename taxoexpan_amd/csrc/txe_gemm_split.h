@@ -9,6 +9,7 @@
 //     fragment (rb, kt, p) = rows-slots [32 rb, 32 rb + 32) x columns [16 kt, 16 kt + 16) of plane p, at byte ((rb * nkt + kt) * 3 + p) * 1024,
 //     inside it lane l = (column half kh = l >> 5, slot s = l & 31) owns the 16 bytes at l * 16: columns 16 kt + 8 kh .. + 7 of slot s
 // -- exactly what ONE global_load_lds_dwordx4 of a wave copies into LDS and what ONE ds_read_b128 hands the MFMA as its A / B operand.
+// (txe_split_pack sides 2 / 3: sides 0 / 1 of a matrix given as its transpose [K][ld >= R].)
 // Slot -> row: side 0 (the A operand, C's rows): row = 32 rb + s.  Side 1 (the B operand, C's columns): a 128-column tile is four
 // fragments j = rb & 3 and slot s of fragment j is column 128 (rb >> 2) + 64 (j >> 1) + 2 s + (j & 1), so that a lane's two
 // accumulator blocks hold two ADJACENT columns of C (8-byte stores, 256 contiguous bytes per half wave).
@@ -73,7 +74,14 @@ static inline bool split_tn_fits(int n_rows, long long lda) { return (double)n_r
 
 // launches (txe_gemm_split.hip)
 int split_pack_launch(const float* src, long long ld, int rows, int cols, int side, void* packed, hipStream_t stream);
-int gemm_nt_split_launch(const void* Ap, const void* Bp, int M, int N, int K, float* C, long long ldc, double alg_flops, hipStream_t stream);
+// epilogue extras of the NT product (NULL = plain): C = acc * (mask bit of column + mask_col0 ? drop_scale : 0) * (act_src[m][c] > 0 or c >= cols_act
+// ? 1 : act_slope) -- what txe_gemm.h's epi_store_one applies (mask == NULL / act_src == NULL: that factor is 1)
+struct SplitEpi {
+    const unsigned* mask; int mask_ld, mask_col0; float drop_scale;
+    const float* act_src; long long ld_act; float act_slope; int cols_act;
+};
+int gemm_nt_split_launch(const void* Ap, const void* Bp, int M, int N, int K, float* C, long long ldc, double alg_flops, hipStream_t stream,
+                         const SplitEpi* epi = nullptr);
 int split_pack_t_launch(const float* src, long long ld, int rows, int cols, void* packed, hipStream_t stream);
 int split_pack_layer_launch(const float* X, long long ldx, int n, const float* W, long long ldw, int f, int K, void* Xs, void* Ws, void* Xt,
                             hipStream_t stream);

@@ -10,7 +10,7 @@ typedef __attribute__((ext_vector_type(16))) float f32x16s;
 
 // ---- packing: fp32 [rows][ld] -> three bf16 planes in fragment order --------------------------------------------------------------
 // one thread per (fragment block rb, k-tile kt, lane): reads 8 consecutive floats of its slot's row, writes 16 bytes per plane
-struct SplitPackArgs { const float* src; long long ld; int rows, cols, side, nrb, nkt; uint4* dst; };
+struct SplitPackArgs { const float* src; long long ld; int rows, cols, side, nrb, nkt; uint4* dst; int transposed; };
 __device__ __forceinline__ void split_pack_job(const SplitPackArgs& a, const int bid, const int nb) {
     const float* __restrict__ src = a.src;
     uint4* __restrict__ dst = a.dst;
@@ -25,7 +25,13 @@ __device__ __forceinline__ void split_pack_job(const SplitPackArgs& a, const int
         float x[8];
 #pragma unroll
         for (int q = 0; q < 8; ++q) x[q] = 0.f;
-        if (row < rows) {
+        if (a.transposed) {                                // element (row, k) = src[k][row]: an operand given as its transpose
+            if (row < rows) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+                    if (k0 + q < cols) x[q] = src[(long long)(k0 + q) * ld + row];
+            }
+        } else if (row < rows) {
             const float* p = src + (long long)row * ld + k0;
             if (k0 + 7 < cols && ((reinterpret_cast<uintptr_t>(p) & 15) == 0)) {
                 const float4 u = *reinterpret_cast<const float4*>(p), v = *reinterpret_cast<const float4*>(p + 4);
@@ -53,9 +59,12 @@ struct SplitGemm {
     int nkt;                          // k-tiles of 16
     float* C; long long ldc; int M, N;
     int nbm, nbn;
+    // epilogue extras (EPI kernels; txe_gemm.h epi_store_one): C = acc * (keep bit ? drop_scale : 0) * (act_src > 0 || column >= cols_act ? 1 : slope)
+    const unsigned* mask; int mask_ld, mask_col0, mask_on; float drop_scale;
+    const float* act_src; long long ld_act; float act_slope; int act_on, cols_act;
 };
 
-template <int MI, int NST, int MINB>
+template <int MI, int NST, int MINB, bool EPI = false>
 __global__ __launch_bounds__(256, MINB) void gemm_nt_split_kernel(const SplitGemm p) {
     constexpr int NA = 2 * MI, NB = 4;                      // A / B fragment blocks per tile
     constexpr int NF = 3 * (NA + NB), CP = (NF + 3) / 4;    // fragments per stage, copies per wave and k-tile (the last wave: the rest)
@@ -176,10 +185,25 @@ __global__ __launch_bounds__(256, MINB) void gemm_nt_split_kernel(const SplitGem
             const int m = r0 + 32 * i + (e & 3) + 8 * (e >> 2);
             if (m < p.M) {
                 float* dst = p.C + (long long)m * p.ldc + c0;
-                if (vec && c0 + 1 < p.N) *reinterpret_cast<float2*>(dst) = make_float2(acc[i][0][e], acc[i][1][e]);
+                float v0 = acc[i][0][e], v1 = acc[i][1][e];
+                if constexpr (EPI) {
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        const int c = c0 + q;
+                        if (c >= p.N) continue;
+                        float g = 1.f;
+                        if (p.mask_on) {
+                            const int cm = c + p.mask_col0;
+                            g = ((p.mask[(long long)m * p.mask_ld + (cm >> 5)] >> (cm & 31)) & 1u) ? p.drop_scale : 0.f;
+                        }
+                        if (p.act_on && c < p.cols_act && !(p.act_src[(long long)m * p.ld_act + c] > 0.f)) g *= p.act_slope;
+                        if (q == 0) v0 *= g; else v1 *= g;
+                    }
+                }
+                if (vec && c0 + 1 < p.N) *reinterpret_cast<float2*>(dst) = make_float2(v0, v1);
                 else {
-                    if (c0 < p.N) dst[0] = acc[i][0][e];
-                    if (c0 + 1 < p.N) dst[1] = acc[i][1][e];
+                    if (c0 < p.N) dst[0] = v0;
+                    if (c0 + 1 < p.N) dst[1] = v1;
                 }
             }
         }
@@ -377,8 +401,9 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_split_kernel(const SplitTn p) 
 int g_split_variant = 0;
 
 static bool fill_pack(SplitPackArgs& a, int& nb, const float* src, long long ld, int rows, int cols, int side, void* packed) {
-    if (!src || !packed || rows < 1 || cols < 1 || ld < cols || side < 0 || side > 1) return false;
-    a.src = src; a.ld = ld; a.rows = rows; a.cols = cols; a.side = side; a.dst = (uint4*)packed;
+    const int tr = side >> 1;                             // sides 2, 3 = sides 0, 1 of a matrix given as its transpose [cols][ld >= rows]
+    if (!src || !packed || rows < 1 || cols < 1 || ld < (tr ? rows : cols) || side < 0 || side > 3) return false;
+    a.src = src; a.ld = ld; a.rows = rows; a.cols = cols; a.side = side & 1; a.dst = (uint4*)packed; a.transposed = tr;
     a.nrb = ((rows + 767) / 768) * 24; a.nkt = (cols + SPL_KT - 1) / SPL_KT;
     const long long total = (long long)a.nrb * a.nkt * 64;
     nb = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
@@ -414,17 +439,28 @@ int split_pack_layer_launch(const float* X, long long ldx, int n, const float* W
     return TXE_OK;
 }
 
-int gemm_nt_split_launch(const void* Ap, const void* Bp, int M, int N, int K, float* C, long long ldc, double alg_flops, hipStream_t stream) {
+int gemm_nt_split_launch(const void* Ap, const void* Bp, int M, int N, int K, float* C, long long ldc, double alg_flops, hipStream_t stream,
+                         const SplitEpi* epi) {
     if (!Ap || !Bp || !C || M < 1 || N < 1 || K < 1 || ldc < N) return TXE_ERR_ARG;
     SplitGemm p;
+    memset(&p, 0, sizeof(p));
     p.A = (const char*)Ap; p.B = (const char*)Bp; p.nkt = (K + SPL_KT - 1) / SPL_KT;
     p.C = C; p.ldc = ldc; p.M = M; p.N = N;
     const int v = g_split_variant & 15;
     const int bm = (v == 2 || v == 3) ? 256 : (v == 5 ? 192 : 128);
     p.nbm = (M + bm - 1) / bm; p.nbn = (N + SPL_BN - 1) / SPL_BN;
-    ProfScope prof("gemm_nt_split_kernel", stream, alg_flops > 0.0 ? alg_flops : 2.0 * M * (double)N * K, 0);
+    ProfScope prof(epi ? "gemm_nt_split_kernel[epi]" : "gemm_nt_split_kernel", stream, alg_flops > 0.0 ? alg_flops : 2.0 * M * (double)N * K, 0);
     const dim3 grid(p.nbm * p.nbn), blk(256);
     if (g_split_variant & 16) p.M = 0;                  // (timing experiment: no C stores)
+    if (epi) {
+        p.mask = epi->mask; p.mask_ld = epi->mask_ld; p.mask_col0 = epi->mask_col0; p.mask_on = epi->mask ? 1 : 0;
+        p.drop_scale = epi->drop_scale;
+        p.act_src = epi->act_src; p.ld_act = epi->ld_act; p.act_slope = epi->act_slope; p.act_on = epi->act_src ? 1 : 0; p.cols_act = epi->cols_act;
+        p.nbm = (M + 127) / 128;
+        hipLaunchKernelGGL((gemm_nt_split_kernel<2, 3, 2, true>), dim3(p.nbm * p.nbn), blk, 0, stream, p);
+        TXE_CHECK_LAUNCH();
+        return TXE_OK;
+    }
     if (v == 0) hipLaunchKernelGGL((gemm_nt_split_kernel<2, 3, 2>), grid, blk, 0, stream, p);
     else if (v == 1) hipLaunchKernelGGL((gemm_nt_split_kernel<2, 2, 3>), grid, blk, 0, stream, p);
     else if (v == 2) hipLaunchKernelGGL((gemm_nt_split_kernel<4, 2, 2>), grid, blk, 0, stream, p);
@@ -474,7 +510,7 @@ int txe_split_pack(const float* src, long long ld, int rows, int cols, int side,
 int txe_gemm_split_variant(int v) { g_split_variant = v; return TXE_OK; }
 
 int txe_gemm_nt_split(const void* Ap, const void* Bp, int M, int N, int K, float* C, long long ldc, void* stream) {
-    return gemm_nt_split_launch(Ap, Bp, M, N, K, C, ldc, 0.0, (hipStream_t)stream);
+    return gemm_nt_split_launch(Ap, Bp, M, N, K, C, ldc, 0.0, (hipStream_t)stream, nullptr);
 }
 
 size_t txe_split_packed_t_bytes(int rows, int cols) { return (rows < 1 || cols < 32) ? 0 : split_packed_t_bytes(rows, cols); }

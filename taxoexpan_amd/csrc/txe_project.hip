@@ -822,6 +822,14 @@ int txe_gat_dx_streams(int Kh, int Pd, int need_dh) {
     return (Kh + Pd - c0 <= DXPOS_MAXC && Kh - c0 + Pd <= DXPOS_MAXC) ? 1 : 0;
 }
 
+// extra workspace (behind txe_gat_dense_ws_bytes) with which txe_gat_dense_bwd forms a need_dh layer's d_X on the bf16 pipe
+static inline size_t dense_bwd_split_bytes(int n_nodes, int Fp, int Kt) {
+    return align_up(split_packed_bytes(n_nodes, Fp), 256) + align_up(split_packed_bytes(Kt, Fp), 256);
+}
+size_t txe_gat_dense_bwd_split_ws_bytes(int n_nodes, int Kh, int Pd, int H, int D) {
+    if (n_nodes < 1 || Kh < 1 || Pd < 0 || H < 1 || D < 1) return 0;
+    return dense_bwd_split_bytes(n_nodes, round_up(H * D + 2 * H, 128), Kh + Pd);
+}
 size_t txe_gat_dense_ws_bytes(int n_nodes, int Kh, int Pd, int H, int D, int vocab) {
     return plan_dense_ws(nullptr, n_nodes, round_up(H * D + 2 * H, 128), 2 * H, round_up(Kh + Pd, 32), Pd, vocab).total;
 }
@@ -937,6 +945,22 @@ int txe_gat_dense_bwd(const float* X, int n_nodes, int Kh, int Pd, const int* po
     }
     if ((phases & 1) && stream_dx) {
         rc = dxpos_launch(da, s);
+        if (rc) return rc;
+    } else if ((phases & 1) && need_dh && n_nodes > 0 && ws_bytes >= p.total + dense_bwd_split_bytes(n_nodes, Fp, Kt)) {
+        // the whole d_X = d_Y Wp on the bf16 pipe (txe_gemm_split.h): d_Y packed as the row operand, Wp -- given as the transpose of
+        // the column operand -- packed from its columns; dropout mask and leaky' factor in the store loop (epi_store_one's arithmetic)
+        char* sw = (char*)ws + p.total;
+        const size_t ba = align_up(split_packed_bytes(n_nodes, Fp), 256);
+        rc = split_pack_launch(d_Y, Fp, n_nodes, Fp, 0, sw, s);
+        if (rc) return rc;
+        rc = split_pack_launch(Wp, Kp, Kt, Fp, 3, sw + ba, s);
+        if (rc) return rc;
+        SplitEpi e;
+        memset(&e, 0, sizeof(e));
+        e.drop_scale = 1.f;
+        if (mask && feat_drop_p > 0.f) { e.mask = mask; e.mask_ld = (Kt + 31) / 32; e.mask_col0 = 0; e.drop_scale = 1.f / (1.f - feat_drop_p); }
+        if (act_on) { e.act_src = X; e.ld_act = Kp; e.act_slope = act_slope; e.cols_act = Kh; }
+        rc = gemm_nt_split_launch(sw, sw + ba, n_nodes, Kt, Fp, d_X, Kp, 2.0 * n_nodes * (double)Kt * Fe, s, &e);
         if (rc) return rc;
     } else if ((phases & 1) && Kt - c0 > 0 && n_nodes > 0 && (need_dh || Pd > 0)) {
         VMat A = vmat_plain(d_Y, Fp, n_nodes, Fp);

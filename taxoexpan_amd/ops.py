@@ -503,6 +503,8 @@ def _gat_dense_bwd(st, pos, vocab, feat_p, d_Y, need_dh, act_on, act_slope, chai
     dP = torch.empty_like(st.P) if st.P is not None else None
     d_X = _empty((N, st.Kp), st.X) if (need_dh or st.Pd > 0) else None
     wsb = pure("txe_gat_dense_ws_bytes", N, st.Kh, st.Pd, st.H, st.D, vocab)
+    if need_dh and not _NO_SPLIT_GEMM:                 # room for d_Y and Wp as packed planes: d_X = d_Y Wp on the bf16 pipe
+        wsb += pure("txe_gat_dense_bwd_split_ws_bytes", N, st.Kh, st.Pd, st.H, st.D)
     ws = _ws(wsb, st.X)
     def run(phases):
         call("txe_gat_dense_bwd", ptr(st.X), N, st.Kh, st.Pd, ptr(pos), vocab, ptr(st.Wp), ptr(st.W), ptr(st.al), ptr(st.ar), st.H, st.D, feat_p,

@@ -129,3 +129,60 @@ def test_first_layer_takes_the_split_route_and_matches_the_fp32_route(monkeypatc
     np.testing.assert_allclose(res["bf16x6"][0], res["fp32"][0], rtol=1e-4, atol=2e-5)
     for k, gref in res["fp32"][1].items():
         np.testing.assert_allclose(res["bf16x6"][1][k], gref, rtol=2e-3, atol=2e-4 * float(np.abs(gref).max()) + 1e-12, err_msg=k)
+
+
+@pytest.mark.parametrize("N,Kh,Pd,H,D,p", [(1000, 2000, 50, 4, 500, 0.1), (300, 64, 16, 2, 63, 0.25), (129, 250, 50, 1, 126, 0.0)])
+def test_input_gradient_of_a_deeper_layer_on_the_split_route(N, Kh, Pd, H, D, p):
+    """txe_gat_dense_bwd with need_dh = 1 (a layer above the first: d_X = d_Y Wp over ALL columns, dropout mask and leaky' factor in
+    the epilogue): with the extra workspace the product runs on the bf16 pipe (d_Y packed as rows, Wp packed from its transpose) --
+    against float64 and against the fp32-MFMA route of the same call"""
+    import ctypes
+    from taxoexpan_amd import _lib
+    dev = _dev()
+    rs = np.random.RandomState(5 + N)
+    vocab = 3
+    Kt, F = Kh + Pd, H * D
+    Kp, Fp = _lib.call("txe_gat_padded_k", Kh, Pd), _lib.call("txe_gat_padded_f", H, D)
+    f32 = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev)
+    W, al, ar = f32(rs.standard_normal((F, Kt)) * 0.1), f32(rs.standard_normal(F)), f32(rs.standard_normal(F))
+    Wp = torch.zeros((Fp, Kp), device=dev)
+    _lib.call("txe_gat_pack_weights", W.data_ptr(), al.data_ptr(), ar.data_ptr(), H, D, Kt, Wp.data_ptr(), _lib.stream_ptr())
+    X = torch.zeros((N, Kp), device=dev)
+    X[:, :Kt] = f32(rs.standard_normal((N, Kt)))
+    pos = torch.from_numpy(rs.randint(0, vocab, N).astype(np.int32)).to(dev)
+    dY = torch.zeros((N, Fp), device=dev)
+    dY[:, :F + 2 * H] = f32(rs.standard_normal((N, F + 2 * H)))
+    mask = None
+    if p > 0:
+        mask = torch.empty((N, (Kt + 31) // 32), dtype=torch.int32, device=dev)
+        _lib.call("txe_dropout_mask", N, Kt, p, 99, mask.data_ptr(), _lib.stream_ptr())
+    base = _lib.call("txe_gat_dense_ws_bytes", N, Kh, Pd, H, D, vocab)
+    extra = _lib.call("txe_gat_dense_bwd_split_ws_bytes", N, Kh, Pd, H, D)
+    assert extra > 0
+    slope = 0.2
+    outs = []
+    for wsb in (base + extra, base):
+        ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+        dX = torch.full((N, Kp), float("nan"), device=dev)
+        dW, dal, dar, dP = torch.empty_like(W), torch.empty_like(al), torch.empty_like(ar), torch.empty((vocab, Pd), device=dev)
+        _lib.call("txe_gat_dense_bwd", X.data_ptr(), N, Kh, Pd, pos.data_ptr(), vocab, Wp.data_ptr(), W.data_ptr(), al.data_ptr(), ar.data_ptr(),
+                  H, D, p, mask.data_ptr() if mask is not None else None, dY.data_ptr(), 1, 1, slope, dX.data_ptr(), dW.data_ptr(), dal.data_ptr(),
+                  dar.data_ptr(), dP.data_ptr(), 0, None, 7, None, ws.data_ptr(), wsb, _lib.stream_ptr())
+        torch.cuda.synchronize()
+        assert torch.isnan(dX[:, Kt:]).all() or Kt == Kp                # padding columns are not this call's to write
+        outs.append((dX[:, :Kt].cpu().double().numpy(), dW.cpu().double().numpy(), dP.cpu().double().numpy()))
+    keep = np.ones((N, Kt))
+    if mask is not None:
+        bits = ((mask.cpu().numpy().astype(np.int64)[:, :, None] >> np.arange(32)) & 1).reshape(N, -1)[:, :Kt]
+        keep = bits / (1.0 - p)
+    Wd, dYd, Xd = W.cpu().double().numpy(), dY.cpu().double().numpy(), X.cpu().double().numpy()[:, :Kt]
+    ald, ard = al.cpu().double().numpy(), ar.cpu().double().numpy()
+    wa = np.stack([(ald.reshape(H, D)[h][:, None] * Wd[h * D:(h + 1) * D]).sum(0) for h in range(H)] +
+                  [(ard.reshape(H, D)[h][:, None] * Wd[h * D:(h + 1) * D]).sum(0) for h in range(H)])
+    ref = (dYd[:, :F + 2 * H] @ np.concatenate([Wd, wa], axis=0)) * keep
+    ref[:, :Kh] *= np.where(Xd[:, :Kh] > 0, 1.0, slope)
+    scale = np.abs(ref).max()
+    for dX, _, _ in outs:
+        assert np.abs(dX - ref).max() <= 2e-5 * scale
+    assert np.abs(outs[0][0] - outs[1][0]).max() <= 4e-6 * scale            # the two routes: fp32 rounding apart
+    np.testing.assert_array_equal(outs[0][1], outs[1][1])                    # (dW does not depend on the d_X route)

@@ -58,7 +58,7 @@ struct SplitGemm {
     const char* A; const char* B;     // packed operands
     int nkt;                          // k-tiles of 16
     float* C; long long ldc; int M, N;
-    int nbm, nbn;
+    int nbm, nbn, row_major;
     // epilogue extras (EPI kernels; txe_gemm.h epi_store_one): C = acc * (keep bit ? drop_scale : 0) * (act_src > 0 || column >= cols_act ? 1 : slope)
     const unsigned* mask; int mask_ld, mask_col0, mask_on; float drop_scale;
     const float* act_src; long long ld_act; float act_slope; int act_on, cols_act;
@@ -77,7 +77,18 @@ __global__ __launch_bounds__(256, MINB) void gemm_nt_split_kernel(const SplitGem
     typedef __attribute__((address_space(3))) uint4 lds_u4;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), l = threadIdx.x & 63;
     const int lb = xcd_remap(blockIdx.x, gridDim.x);
-    const int tm = lb / p.nbn, tn = lb % p.nbn;
+    // tile order: blocks of 16 row panels x 8 column tiles, column-tile fast -- the 64 tiles an XCD runs at a time share HALF of a
+    // 16-tile-wide B (2 MB of planes at K = 320) and 8 A panels (2 MB): its 4 MB L2 holds them, where 4 panels x all 16 column tiles
+    // (row-major order) cycled 4.9 MB through it (FETCH_SIZE 304 MB per launch for 38 MB of operands)
+    int tm, tn;
+    if (p.row_major) { tm = lb / p.nbn; tn = lb % p.nbn; }
+    else {
+        constexpr int GM = 16, GN = 8;
+        const int srt = GM * p.nbn, sr = lb / srt, rem = lb - sr * srt;
+        const int hgt = min(GM, p.nbm - sr * GM);
+        const int cg = rem / (hgt * GN), r = rem - cg * hgt * GN, wg = min(GN, p.nbn - cg * GN);
+        tm = sr * GM + r / wg; tn = cg * GN + r % wg;
+    }
     const int wm = w >> 1, wn = w & 1;
     const int nkt = p.nkt;
     // this wave's copies: fragments f = CP w + q of the stage; f < 3 NA: A block f / 3, plane f % 3, else B block (f - 3 NA) / 3.
@@ -427,12 +438,13 @@ int split_pack_launch(const float* src, long long ld, int rows, int cols, int si
     return TXE_OK;
 }
 // X [n][ldx] -> Xs (side 0) and, Xt != NULL, Xt (side 2); W [f][ldw] -> Ws (side 1): one launch
-int split_pack_layer_launch(const float* X, long long ldx, int n, const float* W, long long ldw, int f, int K, void* Xs, void* Ws, void* Xt,
-                            hipStream_t stream) {
+// (K columns for the NT operands, Kt_cols -- a multiple of 160 -- for the contraction-major one)
+int split_pack_layer_launch(const float* X, long long ldx, int n, const float* W, long long ldw, int f, int K, int Kt_cols, void* Xs, void* Ws,
+                            void* Xt, hipStream_t stream) {
     SplitPackMulti m;
     memset(&m, 0, sizeof(m));
     if (!fill_pack(m.a[0], m.nb[0], X, ldx, n, K, 0, Xs) || !fill_pack(m.a[1], m.nb[1], W, ldw, f, K, 1, Ws)) return TXE_ERR_ARG;
-    if (Xt && !fill_pack_t(m.t, m.nb[2], X, ldx, n, K, Xt)) return TXE_ERR_ARG;
+    if (Xt && !fill_pack_t(m.t, m.nb[2], X, ldx, n, Kt_cols, Xt)) return TXE_ERR_ARG;
     ProfScope prof("split_pack_multi_kernel", stream, 10.0 * K * ((Xt ? 2.0 : 1.0) * n + f), 1);
     hipLaunchKernelGGL(split_pack_multi_kernel, dim3(m.nb[0] + m.nb[1] + m.nb[2]), dim3(256), 0, stream, m);
     TXE_CHECK_LAUNCH();
@@ -452,6 +464,7 @@ int gemm_nt_split_launch(const void* Ap, const void* Bp, int M, int N, int K, fl
     ProfScope prof(epi ? "gemm_nt_split_kernel[epi]" : "gemm_nt_split_kernel", stream, alg_flops > 0.0 ? alg_flops : 2.0 * M * (double)N * K, 0);
     const dim3 grid(p.nbm * p.nbn), blk(256);
     if (g_split_variant & 16) p.M = 0;                  // (timing experiment: no C stores)
+    p.row_major = (g_split_variant & 32) ? 1 : 0;       // (... the first tile order)
     if (epi) {
         p.mask = epi->mask; p.mask_ld = epi->mask_ld; p.mask_col0 = epi->mask_col0; p.mask_on = epi->mask ? 1 : 0;
         p.drop_scale = epi->drop_scale;

@@ -877,28 +877,30 @@ int txe_gat_dense_fwd_split(const float* X, int n_nodes, int Kh, int Pd, const f
     int rc;
     if (Xt_out && (!X || !split_tn_eligible(Fp, Kp))) return TXE_ERR_ARG;
     bool xt_done = false;
+    // the contraction runs over whole k-tiles of 16: Kc columns (X and Wp hold zeros in [Kh + Pd, Kp))
+    const int Kc = round_up(Kh + Pd, 16);
     if (!Xs && !Ws) {                                   // the usual case: all three packs in one launch
         const size_t ba = align_up(split_packed_bytes(n_nodes, Kp), 256), bb = align_up(split_packed_bytes(Fp, Kp), 256);
         if (!ws || ws_bytes < ba + bb) return TXE_ERR_WORKSPACE;
-        rc = split_pack_layer_launch(X, Kp, n_nodes, Wp, Kp, Fp, Kp, w, w + ba, Xt_out, s);
+        rc = split_pack_layer_launch(X, Kp, n_nodes, Wp, Kp, Fp, Kc, Kp, w, w + ba, Xt_out, s);
         if (rc) return rc;
         Xs = w; Ws = w + ba; xt_done = true;
     }
     if (!Xs) {
         const size_t b = align_up(split_packed_bytes(n_nodes, Kp), 256);
         if (!ws || ws_bytes < off + b) return TXE_ERR_WORKSPACE;
-        rc = split_pack_launch(X, Kp, n_nodes, Kp, 0, w + off, s);
+        rc = split_pack_launch(X, Kp, n_nodes, Kc, 0, w + off, s);
         if (rc) return rc;
         Xs = w + off; off += b;
     }
     if (!Ws) {
         const size_t b = align_up(split_packed_bytes(Fp, Kp), 256);
         if (!ws || ws_bytes < off + b) return TXE_ERR_WORKSPACE;
-        rc = split_pack_launch(Wp, Kp, Fp, Kp, 1, w + off, s);
+        rc = split_pack_launch(Wp, Kp, Fp, Kc, 1, w + off, s);
         if (rc) return rc;
         Ws = w + off; off += b;
     }
-    rc = gemm_nt_split_launch(Xs, Ws, n_nodes, Fe, Kp, Y, Fp, 2.0 * n_nodes * (double)Fe * (Kh + Pd), s);
+    rc = gemm_nt_split_launch(Xs, Ws, n_nodes, Fe, Kc, Y, Fp, 2.0 * n_nodes * (double)Fe * (Kh + Pd), s);
     if (rc) return rc;
     // (X packed contraction-major for the backward pass's weight gradient, txe_gat_dense_bwd: Xt)
     if (Xt_out && !xt_done) return split_pack_t_launch(X, Kp, n_nodes, Kp, Xt_out, s);
@@ -951,16 +953,17 @@ int txe_gat_dense_bwd(const float* X, int n_nodes, int Kh, int Pd, const int* po
         // the column operand -- packed from its columns; dropout mask and leaky' factor in the store loop (epi_store_one's arithmetic)
         char* sw = (char*)ws + p.total;
         const size_t ba = align_up(split_packed_bytes(n_nodes, Fp), 256);
-        rc = split_pack_launch(d_Y, Fp, n_nodes, Fp, 0, sw, s);
+        const int Fc = round_up(Fe, 16);                 // whole k-tiles of 16 over the contraction (d_Y's columns past Fe are zeros)
+        rc = split_pack_launch(d_Y, Fp, n_nodes, Fc, 0, sw, s);
         if (rc) return rc;
-        rc = split_pack_launch(Wp, Kp, Kt, Fp, 3, sw + ba, s);
+        rc = split_pack_launch(Wp, Kp, Kt, Fc, 3, sw + ba, s);
         if (rc) return rc;
         SplitEpi e;
         memset(&e, 0, sizeof(e));
         e.drop_scale = 1.f;
         if (mask && feat_drop_p > 0.f) { e.mask = mask; e.mask_ld = (Kt + 31) / 32; e.mask_col0 = 0; e.drop_scale = 1.f / (1.f - feat_drop_p); }
         if (act_on) { e.act_src = X; e.ld_act = Kp; e.act_slope = act_slope; e.cols_act = Kh; }
-        rc = gemm_nt_split_launch(sw, sw + ba, n_nodes, Kt, Fp, d_X, Kp, 2.0 * n_nodes * (double)Kt * Fe, s, &e);
+        rc = gemm_nt_split_launch(sw, sw + ba, n_nodes, Kt, Fc, d_X, Kp, 2.0 * n_nodes * (double)Kt * Fe, s, &e);
         if (rc) return rc;
     } else if ((phases & 1) && Kt - c0 > 0 && n_nodes > 0 && (need_dh || Pd > 0)) {
         VMat A = vmat_plain(d_Y, Fp, n_nodes, Fp);

@@ -458,6 +458,214 @@ __global__ __launch_bounds__(256) void gemm_tail_fixup_kernel(const Epi E, const
     }
 }
 
+// The epilogue of a 128 x BN tile staged in LDS (Cs = smem, row pitch BN + 4; SMEM floats in all: what lies behind the tile is scratch
+// for the count mode) -- plain / exp / mask / activation stores, the pick, count and best-k modes.  Shared by gemm_kernel and the
+// bf16-pipe product of txe_gemm_split.hip (the scoring loop's four entry points must produce bit-identical scores: ONE epilogue).
+// cnt_pb / cnt_np / cnt_th: the count mode's per-row positive range and first thresholds, fetched by the caller before its k-loop.
+template <int BN, int SMEM>
+__device__ __forceinline__ void gemm_tile_epilogue(const Epi& E, float* smem, const int m0, const int n0, const int M, const int N, const int tn,
+                                                   const int nbn, const int zslice, const int cnt_pb, const int cnt_np, const float (&cnt_th)[8]) {
+    constexpr int CLD = BN + 4;
+    constexpr int C4 = BN / 4;                       // 16-byte chunks per tile row
+    float* Cs = smem;
+    if (E.cnt_mode == 3) {                           // pick mode: store the rows' own columns only
+        for (int idx = threadIdx.x; idx < GEMM_BM * C4; idx += GEMM_THREADS) {
+            const int row = idx / C4, c4 = idx % C4;
+            const int m = m0 + row, mc = min(m, M - 1);
+            const int lo = E.cnt_off[mc], hi = E.cnt_off[mc + 1];
+            const float4 t4 = *reinterpret_cast<const float4*>(Cs + row * CLD + c4 * 4);
+            const float v4[4] = {t4.x, t4.y, t4.z, t4.w};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int n = n0 + c4 * 4 + q;
+                if (m < M && n >= lo && n < hi && n < N) E.c[n] = E.apply_exp ? __expf(v4[q]) : v4[q];
+            }
+        }
+        return;
+    }
+    if (E.cnt_mode == 4 || E.cnt_mode == 5) {
+        // best-k columns of every row of this tile: two threads per row, each scans its half row (ascending columns) into a best-k list,
+        // the pair merges, the even thread writes the row's topk_k entries of this column tile
+        static_assert(GEMM_THREADS == 2 * GEMM_BM, "two threads per tile row");
+        constexpr int HW = BN / 2;
+        const int row = threadIdx.x >> 1, half = threadIdx.x & 1;
+        const int m = m0 + row, nb = n0 + half * HW;
+        const bool larger = E.cnt_mode == 4;
+        float bk[TOPK_MAX];
+        int bi[TOPK_MAX];
+        topk_init(bk, bi);
+        // the row's floor: the largest k-th best key any tile of this row has published so far -- a lower bound of the row's FINAL k-th
+        // best key, so a value strictly below it can never be selected and is skipped.  After the first round of tiles almost nothing
+        // passes, and the (divergent) insert branch is rarely taken by any lane of a wave.  A stale read (another XCD's L2) is only a
+        // lower floor: the selection is exact and deterministic whatever the timing; only the work saved varies.
+        const int mf = (m < M) ? m : 0;
+        const float floor_key = topk_unord(__hip_atomic_load(E.topk_floor + mf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        const int kk = E.topk_k;
+        float wk = -INFINITY;                            // the list's current k-th best: what a candidate has to beat
+        int wi = 0x7fffffff;
+#pragma unroll 4
+        for (int j = 0; j < HW / 4; ++j) {
+            const float4 t4 = *reinterpret_cast<const float4*>(Cs + row * CLD + half * HW + 4 * j);
+            const float v4[4] = {t4.x, t4.y, t4.z, t4.w};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int n = nb + 4 * j + q;
+                const float key = topk_key_of(E.apply_exp ? __expf(v4[q]) : v4[q], larger);
+                if (n < N && !(key < floor_key) && topk_better(key, n, wk, wi)) {
+                    topk_insert(bk, bi, key, n);
+                    topk_kth(bk, bi, kk, wk, wi);
+                }
+            }
+        }
+        // the odd thread's list goes to the even one (all lanes shuffle; only the even thread's merge is kept)
+#pragma unroll
+        for (int t = 0; t < TOPK_MAX; ++t) {
+            const float ok = __shfl_xor(bk[t], 1, 64);
+            const int oi = __shfl_xor(bi[t], 1, 64);
+            // (the partner's list is sorted: once an entry fails, the rest would too -- the insert is predicated, not skipped, to keep
+            //  the shuffles of the next round uniform)
+            if (half == 0 && t < kk && topk_better(ok, oi, wk, wi)) {
+                topk_insert(bk, bi, ok, oi);
+                topk_kth(bk, bi, kk, wk, wi);
+            }
+        }
+        if (half == 0 && m < M) {
+            const long long o = ((long long)m * nbn + tn) * E.topk_k;
+            float kth = -INFINITY;
+            int kth_i = 0x7fffffff;
+#pragma unroll
+            for (int t = 0; t < TOPK_MAX; ++t)
+                if (t < E.topk_k) { E.topk_key[o + t] = bk[t]; E.topk_idx[o + t] = bi[t]; kth = bk[t]; kth_i = bi[t]; }
+            // this tile holds k real entries at or above kth: the row's final k-th best key cannot be lower
+            if (kth_i != 0x7fffffff && kth > floor_key) atomicMax(E.topk_floor + m, topk_ord(kth));
+        }
+        return;
+    }
+    if (E.cnt_mode != 0) {
+        // fused ranking: every thread owns 4 consecutive columns of a row; the C4 lanes of a row reduce their counts by butterfly.
+        // The rows' positive ranges and (up to PS) thresholds are staged once per tile in the LDS left over behind the C tile.
+        constexpr int FREE = SMEM - GEMM_BM * CLD;
+        constexpr int PS = (FREE - 2 * GEMM_BM) / GEMM_BM >= 8 ? 8 : ((FREE - 2 * GEMM_BM) / GEMM_BM > 0 ? (FREE - 2 * GEMM_BM) / GEMM_BM : 0);
+        float* s_thr = smem + GEMM_BM * CLD;
+        int* s_pb = reinterpret_cast<int*>(s_thr + GEMM_BM * PS);
+        int* s_np = s_pb + GEMM_BM;
+        if constexpr (PS > 0) {
+            if (threadIdx.x < GEMM_BM) {
+                s_pb[threadIdx.x] = cnt_pb;
+                s_np[threadIdx.x] = cnt_np;
+#pragma unroll
+                for (int k = 0; k < PS; ++k) s_thr[threadIdx.x * PS + k] = cnt_th[k];
+            }
+            __syncthreads();
+        }
+        // two threads per row: each keeps its half row (BN/2 values) in registers and sweeps it once per positive of the row
+        {
+            static_assert(GEMM_THREADS == 2 * GEMM_BM, "two threads per tile row");
+            constexpr int HW = BN / 2;
+            const int row = threadIdx.x >> 1, half = threadIdx.x & 1;
+            const int m = m0 + row, nb = n0 + half * HW;
+            float v[HW];
+#pragma unroll
+            for (int j = 0; j < HW / 4; ++j) {
+                const float4 t4 = *reinterpret_cast<const float4*>(Cs + row * CLD + half * HW + 4 * j);
+                v[4 * j] = t4.x; v[4 * j + 1] = t4.y; v[4 * j + 2] = t4.z; v[4 * j + 3] = t4.w;
+            }
+            // columns past N never count: push them to the losing side of every comparison
+            const float lose = (E.cnt_mode == 1) ? -INFINITY : INFINITY;
+#pragma unroll
+            for (int i = 0; i < HW; ++i) {
+                const float x = E.apply_exp ? __expf(v[i]) : v[i];
+                v[i] = (nb + i < N) ? x : lose;
+            }
+            int pb, np;
+            if constexpr (PS > 0) { pb = s_pb[row]; np = s_np[row]; }
+            else { pb = (m < M) ? E.cnt_off[m] : 0; np = (m < M) ? E.cnt_off[m + 1] - pb : 0; }
+            for (int k = 0; k < np; ++k) {                       // the two threads of a row share the trip count
+                const float th = (k < PS) ? s_thr[row * PS + k] : E.cnt_thr[pb + k];
+                int c = 0;
+                if (E.cnt_mode == 1) {
+#pragma unroll
+                    for (int i = 0; i < HW; ++i) c += (v[i] > th) ? 1 : 0;
+                } else {
+#pragma unroll
+                    for (int i = 0; i < HW; ++i) c += (v[i] < th) ? 1 : 0;
+                }
+                c += __shfl_xor(c, 1, 64);
+                if (half == 0 && c != 0) atomicAdd(E.cnt_out + pb + k, c);
+            }
+        }
+        return;
+    }
+    float* cbase = E.c + (long long)zslice * E.split_stride;
+    const bool vec_main = ((E.ldc & 3) == 0) && ((reinterpret_cast<uintptr_t>(cbase) & 15) == 0);
+    const bool vec_c2 = ((E.ldc2 & 3) == 0) && ((reinterpret_cast<uintptr_t>(E.c2) & 15) == 0) && ((E.cols_main & 3) == 0);
+    const bool vec_act = (E.act_on == 0) || (((E.ld_act & 3) == 0) && ((reinterpret_cast<uintptr_t>(E.act_src) & 15) == 0));
+    constexpr int NCH = GEMM_BM * C4 / GEMM_THREADS;  // chunks per thread (16 / 8)
+    constexpr int UB = (NCH % 8 == 0) ? 8 : 5;        // chunks whose extras are fetched together (independent loads in flight)
+    static_assert(NCH % UB == 0, "chunk batches");
+    const int w1max = E.mask_on ? E.mask_ld - 1 : 0;
+    for (int cb = 0; cb < NCH; cb += UB) {
+        float v[UB][4], av[UB][4];
+        unsigned mw0[UB], mw1[UB];
+        bool fast[UB];
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+            const int idx = threadIdx.x + (cb + u) * GEMM_THREADS;
+            const int row = idx / C4, c4 = idx % C4;
+            const int m = m0 + row, n = n0 + c4 * 4;
+            const bool all_main = n + 3 < E.cols_main, all_c2 = n >= E.cols_main;
+            fast[u] = (m < M) && (n + 3 < N) && ((all_main && vec_main && vec_act) || (all_c2 && vec_c2));
+            const float4 t = *reinterpret_cast<const float4*>(Cs + row * CLD + c4 * 4);
+            v[u][0] = t.x; v[u][1] = t.y; v[u][2] = t.z; v[u][3] = t.w;
+            const int mm = fast[u] ? m : 0, nn = fast[u] ? n : 0;          // clamped: the extras' loads stay unconditional
+            if (E.mask_on) {                                               // kernel-uniform
+                const int cm = nn + E.mask_col0;
+                mw0[u] = E.mask[(long long)mm * E.mask_ld + (cm >> 5)];
+                mw1[u] = E.mask[(long long)mm * E.mask_ld + min((cm + 3) >> 5, w1max)];
+            }
+            if (E.act_on != 0 && vec_act) {
+                const float4 a4 = *reinterpret_cast<const float4*>(E.act_src + (long long)mm * E.ld_act + (all_main ? nn : 0));
+                av[u][0] = a4.x; av[u][1] = a4.y; av[u][2] = a4.z; av[u][3] = a4.w;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+            const int idx = threadIdx.x + (cb + u) * GEMM_THREADS;
+            const int row = idx / C4, c4 = idx % C4;
+            const int m = m0 + row, n = n0 + c4 * 4;
+            if (fast[u]) {
+                const bool all_main = n + 3 < E.cols_main;
+                float g[4] = {E.drop_scale, E.drop_scale, E.drop_scale, E.drop_scale};
+                if (E.mask_on) {
+                    const int cm = n + E.mask_col0;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int c = cm + q;
+                        const unsigned wd = ((c >> 5) == (cm >> 5)) ? mw0[u] : mw1[u];
+                        g[q] = ((wd >> (c & 31)) & 1u) ? E.drop_scale : 0.f;
+                    }
+                }
+                if (E.act_on != 0 && all_main) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) g[q] *= (av[u][q] > 0.f) ? 1.f : E.act_slope;
+                }
+                float o[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float x = v[u][q] * g[q];
+                    o[q] = E.apply_exp ? __expf(x) : x;
+                }
+                float* dst = all_main ? (cbase + (long long)m * E.ldc + n) : (E.c2 + (long long)m * E.ldc2 + (n - E.cols_main));
+                *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+            } else if (m < M) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (n + q < N) epi_store_one(E, m, n + q, v[u][q], cbase);
+            }
+        }
+    }
+}
+
 template <bool AK, bool BKC, int VA, int VB, int BN>
 __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_kernel(VMat A, VMat B, const Epi E, const int M, const int N,
                                                                 const int K, const int ksplit, const Tail T) {
@@ -656,202 +864,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_kernel(VMat A, VMat B, c
         }
         return;
     }
-    if (E.cnt_mode == 3) {                           // pick mode: store the rows' own columns only
-        for (int idx = threadIdx.x; idx < GEMM_BM * C4; idx += GEMM_THREADS) {
-            const int row = idx / C4, c4 = idx % C4;
-            const int m = m0 + row, mc = min(m, M - 1);
-            const int lo = E.cnt_off[mc], hi = E.cnt_off[mc + 1];
-            const float4 t4 = *reinterpret_cast<const float4*>(Cs + row * CLD + c4 * 4);
-            const float v4[4] = {t4.x, t4.y, t4.z, t4.w};
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int n = n0 + c4 * 4 + q;
-                if (m < M && n >= lo && n < hi && n < N) E.c[n] = E.apply_exp ? __expf(v4[q]) : v4[q];
-            }
-        }
-        return;
-    }
-    if (E.cnt_mode == 4 || E.cnt_mode == 5) {
-        // best-k columns of every row of this tile: two threads per row, each scans its half row (ascending columns) into a best-k list,
-        // the pair merges, the even thread writes the row's topk_k entries of this column tile
-        static_assert(GEMM_THREADS == 2 * GEMM_BM, "two threads per tile row");
-        constexpr int HW = BN / 2;
-        const int row = threadIdx.x >> 1, half = threadIdx.x & 1;
-        const int m = m0 + row, nb = n0 + half * HW;
-        const bool larger = E.cnt_mode == 4;
-        float bk[TOPK_MAX];
-        int bi[TOPK_MAX];
-        topk_init(bk, bi);
-        // the row's floor: the largest k-th best key any tile of this row has published so far -- a lower bound of the row's FINAL k-th
-        // best key, so a value strictly below it can never be selected and is skipped.  After the first round of tiles almost nothing
-        // passes, and the (divergent) insert branch is rarely taken by any lane of a wave.  A stale read (another XCD's L2) is only a
-        // lower floor: the selection is exact and deterministic whatever the timing; only the work saved varies.
-        const int mf = (m < M) ? m : 0;
-        const float floor_key = topk_unord(__hip_atomic_load(E.topk_floor + mf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-        const int kk = E.topk_k;
-        float wk = -INFINITY;                            // the list's current k-th best: what a candidate has to beat
-        int wi = 0x7fffffff;
-#pragma unroll 4
-        for (int j = 0; j < HW / 4; ++j) {
-            const float4 t4 = *reinterpret_cast<const float4*>(Cs + row * CLD + half * HW + 4 * j);
-            const float v4[4] = {t4.x, t4.y, t4.z, t4.w};
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int n = nb + 4 * j + q;
-                const float key = topk_key_of(E.apply_exp ? __expf(v4[q]) : v4[q], larger);
-                if (n < N && !(key < floor_key) && topk_better(key, n, wk, wi)) {
-                    topk_insert(bk, bi, key, n);
-                    topk_kth(bk, bi, kk, wk, wi);
-                }
-            }
-        }
-        // the odd thread's list goes to the even one (all lanes shuffle; only the even thread's merge is kept)
-#pragma unroll
-        for (int t = 0; t < TOPK_MAX; ++t) {
-            const float ok = __shfl_xor(bk[t], 1, 64);
-            const int oi = __shfl_xor(bi[t], 1, 64);
-            // (the partner's list is sorted: once an entry fails, the rest would too -- the insert is predicated, not skipped, to keep
-            //  the shuffles of the next round uniform)
-            if (half == 0 && t < kk && topk_better(ok, oi, wk, wi)) {
-                topk_insert(bk, bi, ok, oi);
-                topk_kth(bk, bi, kk, wk, wi);
-            }
-        }
-        if (half == 0 && m < M) {
-            const long long o = ((long long)m * nbn + tn) * E.topk_k;
-            float kth = -INFINITY;
-            int kth_i = 0x7fffffff;
-#pragma unroll
-            for (int t = 0; t < TOPK_MAX; ++t)
-                if (t < E.topk_k) { E.topk_key[o + t] = bk[t]; E.topk_idx[o + t] = bi[t]; kth = bk[t]; kth_i = bi[t]; }
-            // this tile holds k real entries at or above kth: the row's final k-th best key cannot be lower
-            if (kth_i != 0x7fffffff && kth > floor_key) atomicMax(E.topk_floor + m, topk_ord(kth));
-        }
-        return;
-    }
-    if (E.cnt_mode != 0) {
-        // fused ranking: every thread owns 4 consecutive columns of a row; the C4 lanes of a row reduce their counts by butterfly.
-        // The rows' positive ranges and (up to PS) thresholds are staged once per tile in the LDS left over behind the C tile.
-        constexpr int FREE = SMEM - GEMM_BM * CLD;
-        constexpr int PS = (FREE - 2 * GEMM_BM) / GEMM_BM >= 8 ? 8 : ((FREE - 2 * GEMM_BM) / GEMM_BM > 0 ? (FREE - 2 * GEMM_BM) / GEMM_BM : 0);
-        float* s_thr = smem + GEMM_BM * CLD;
-        int* s_pb = reinterpret_cast<int*>(s_thr + GEMM_BM * PS);
-        int* s_np = s_pb + GEMM_BM;
-        if constexpr (PS > 0) {
-            if (threadIdx.x < GEMM_BM) {
-                s_pb[threadIdx.x] = cnt_pb;
-                s_np[threadIdx.x] = cnt_np;
-#pragma unroll
-                for (int k = 0; k < PS; ++k) s_thr[threadIdx.x * PS + k] = cnt_th[k];
-            }
-            __syncthreads();
-        }
-        // two threads per row: each keeps its half row (BN/2 values) in registers and sweeps it once per positive of the row
-        {
-            static_assert(GEMM_THREADS == 2 * GEMM_BM, "two threads per tile row");
-            constexpr int HW = BN / 2;
-            const int row = threadIdx.x >> 1, half = threadIdx.x & 1;
-            const int m = m0 + row, nb = n0 + half * HW;
-            float v[HW];
-#pragma unroll
-            for (int j = 0; j < HW / 4; ++j) {
-                const float4 t4 = *reinterpret_cast<const float4*>(Cs + row * CLD + half * HW + 4 * j);
-                v[4 * j] = t4.x; v[4 * j + 1] = t4.y; v[4 * j + 2] = t4.z; v[4 * j + 3] = t4.w;
-            }
-            // columns past N never count: push them to the losing side of every comparison
-            const float lose = (E.cnt_mode == 1) ? -INFINITY : INFINITY;
-#pragma unroll
-            for (int i = 0; i < HW; ++i) {
-                const float x = E.apply_exp ? __expf(v[i]) : v[i];
-                v[i] = (nb + i < N) ? x : lose;
-            }
-            int pb, np;
-            if constexpr (PS > 0) { pb = s_pb[row]; np = s_np[row]; }
-            else { pb = (m < M) ? E.cnt_off[m] : 0; np = (m < M) ? E.cnt_off[m + 1] - pb : 0; }
-            for (int k = 0; k < np; ++k) {                       // the two threads of a row share the trip count
-                const float th = (k < PS) ? s_thr[row * PS + k] : E.cnt_thr[pb + k];
-                int c = 0;
-                if (E.cnt_mode == 1) {
-#pragma unroll
-                    for (int i = 0; i < HW; ++i) c += (v[i] > th) ? 1 : 0;
-                } else {
-#pragma unroll
-                    for (int i = 0; i < HW; ++i) c += (v[i] < th) ? 1 : 0;
-                }
-                c += __shfl_xor(c, 1, 64);
-                if (half == 0 && c != 0) atomicAdd(E.cnt_out + pb + k, c);
-            }
-        }
-        return;
-    }
-    float* cbase = E.c + (long long)zslice * E.split_stride;
-    const bool vec_main = ((E.ldc & 3) == 0) && ((reinterpret_cast<uintptr_t>(cbase) & 15) == 0);
-    const bool vec_c2 = ((E.ldc2 & 3) == 0) && ((reinterpret_cast<uintptr_t>(E.c2) & 15) == 0) && ((E.cols_main & 3) == 0);
-    const bool vec_act = (E.act_on == 0) || (((E.ld_act & 3) == 0) && ((reinterpret_cast<uintptr_t>(E.act_src) & 15) == 0));
-    constexpr int NCH = GEMM_BM * C4 / GEMM_THREADS;  // chunks per thread (16 / 8)
-    constexpr int UB = (NCH % 8 == 0) ? 8 : 5;        // chunks whose extras are fetched together (independent loads in flight)
-    static_assert(NCH % UB == 0, "chunk batches");
-    const int w1max = E.mask_on ? E.mask_ld - 1 : 0;
-    for (int cb = 0; cb < NCH; cb += UB) {
-        float v[UB][4], av[UB][4];
-        unsigned mw0[UB], mw1[UB];
-        bool fast[UB];
-#pragma unroll
-        for (int u = 0; u < UB; ++u) {
-            const int idx = threadIdx.x + (cb + u) * GEMM_THREADS;
-            const int row = idx / C4, c4 = idx % C4;
-            const int m = m0 + row, n = n0 + c4 * 4;
-            const bool all_main = n + 3 < E.cols_main, all_c2 = n >= E.cols_main;
-            fast[u] = (m < M) && (n + 3 < N) && ((all_main && vec_main && vec_act) || (all_c2 && vec_c2));
-            const float4 t = *reinterpret_cast<const float4*>(Cs + row * CLD + c4 * 4);
-            v[u][0] = t.x; v[u][1] = t.y; v[u][2] = t.z; v[u][3] = t.w;
-            const int mm = fast[u] ? m : 0, nn = fast[u] ? n : 0;          // clamped: the extras' loads stay unconditional
-            if (E.mask_on) {                                               // kernel-uniform
-                const int cm = nn + E.mask_col0;
-                mw0[u] = E.mask[(long long)mm * E.mask_ld + (cm >> 5)];
-                mw1[u] = E.mask[(long long)mm * E.mask_ld + min((cm + 3) >> 5, w1max)];
-            }
-            if (E.act_on != 0 && vec_act) {
-                const float4 a4 = *reinterpret_cast<const float4*>(E.act_src + (long long)mm * E.ld_act + (all_main ? nn : 0));
-                av[u][0] = a4.x; av[u][1] = a4.y; av[u][2] = a4.z; av[u][3] = a4.w;
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < UB; ++u) {
-            const int idx = threadIdx.x + (cb + u) * GEMM_THREADS;
-            const int row = idx / C4, c4 = idx % C4;
-            const int m = m0 + row, n = n0 + c4 * 4;
-            if (fast[u]) {
-                const bool all_main = n + 3 < E.cols_main;
-                float g[4] = {E.drop_scale, E.drop_scale, E.drop_scale, E.drop_scale};
-                if (E.mask_on) {
-                    const int cm = n + E.mask_col0;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const int c = cm + q;
-                        const unsigned wd = ((c >> 5) == (cm >> 5)) ? mw0[u] : mw1[u];
-                        g[q] = ((wd >> (c & 31)) & 1u) ? E.drop_scale : 0.f;
-                    }
-                }
-                if (E.act_on != 0 && all_main) {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) g[q] *= (av[u][q] > 0.f) ? 1.f : E.act_slope;
-                }
-                float o[4];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const float x = v[u][q] * g[q];
-                    o[q] = E.apply_exp ? __expf(x) : x;
-                }
-                float* dst = all_main ? (cbase + (long long)m * E.ldc + n) : (E.c2 + (long long)m * E.ldc2 + (n - E.cols_main));
-                *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
-            } else if (m < M) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    if (n + q < N) epi_store_one(E, m, n + q, v[u][q], cbase);
-            }
-        }
-    }
+    gemm_tile_epilogue<BN, SMEM>(E, smem, m0, n0, M, N, tn, nbn, zslice, cnt_pb, cnt_np, cnt_th);
 }
 
 // ---- whole rounds of a plain product: persistent workgroups, the C tile drained under the NEXT tile's k-loop ---------------------

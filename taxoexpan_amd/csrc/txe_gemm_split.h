@@ -83,6 +83,8 @@ struct SplitEpi {
 int gemm_nt_split_launch(const void* Ap, const void* Bp, int M, int N, int K, float* C, long long ldc, double alg_flops, hipStream_t stream,
                          const SplitEpi* epi = nullptr);
 int split_pack_t_launch(const float* src, long long ld, int rows, int cols, void* packed, hipStream_t stream);
+struct Epi;
+int gemm_nt_split_epi_launch(const void* Ap, const void* Bp, const Epi& E, int M, int N, int K, hipStream_t stream);
 int split_pack_layer_launch(const float* X, long long ldx, int n, const float* W, long long ldw, int f, int K, int Kt_cols, void* Xs, void* Ws,
                             void* Xt, hipStream_t stream);
 // part[z][M][ldc] = A[rows of slice z]^T B[rows of slice z], z < S, slices of ksplit rows (a multiple of 16)

@@ -1,6 +1,7 @@
 // C = A B^T in fp32 accuracy on the bf16 matrix pipe (three-plane operands, six plane products: txe_gemm_split.h)
 #include <string.h>
 #include "txe_common.h"
+#include "txe_gemm.h"
 #include "txe_gemm_split.h"
 
 namespace txe {
@@ -64,16 +65,19 @@ struct SplitGemm {
     const float* act_src; long long ld_act; float act_slope; int act_on, cols_act;
 };
 
-template <int MI, int NST, int MINB, bool EPI = false>
-__global__ __launch_bounds__(256, MINB) void gemm_nt_split_kernel(const SplitGemm p) {
+// EPI: 0 = plain stores from the accumulators; 1 = the same with the dropout-mask / activation factors; 2 = the tile goes through LDS into
+// gemm_kernel's own epilogue (txe_gemm.h gemm_tile_epilogue: exp, pick, count and best-k modes -- the scoring loop), E = its arguments
+template <int MI, int NST, int MINB, int EPI = 0>
+__global__ __launch_bounds__(256, MINB) void gemm_nt_split_kernel(const SplitGemm p, const Epi E) {
     constexpr int NA = 2 * MI, NB = 4;                      // A / B fragment blocks per tile
     constexpr int NF = 3 * (NA + NB), CP = (NF + 3) / 4;    // fragments per stage, copies per wave and k-tile (the last wave: the rest)
     static_assert(NST == 2 || NF % 4 == 0, "the three-stage ring waits on an exact copy count");
     constexpr int STAGE_U4 = NF * 64;
-    // one LDS object per stage
-    __shared__ __attribute__((aligned(16))) uint4 st0[STAGE_U4];
-    __shared__ __attribute__((aligned(16))) uint4 st1[STAGE_U4];
-    __shared__ __attribute__((aligned(16))) uint4 st2[NST == 3 ? STAGE_U4 : 1];
+    __shared__ __attribute__((aligned(16))) uint4 smem_u4[NST * STAGE_U4];
+    uint4* const st0 = smem_u4;
+    uint4* const st1 = smem_u4 + STAGE_U4;
+    uint4* const st2 = smem_u4 + (NST == 3 ? 2 : 0) * STAGE_U4;
+    static_assert(EPI != 2 || (MI == 2 && NST * STAGE_U4 * 4 >= 128 * 132 + 128 * 10), "the epilogue's C tile + count scratch live in the stages");
     typedef __attribute__((address_space(3))) uint4 lds_u4;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), l = threadIdx.x & 63;
     const int lb = xcd_remap(blockIdx.x, gridDim.x);
@@ -91,6 +95,23 @@ __global__ __launch_bounds__(256, MINB) void gemm_nt_split_kernel(const SplitGem
     }
     const int wm = w >> 1, wn = w & 1;
     const int nkt = p.nkt;
+    // (EPI 2) count / pick modes: as gemm_kernel -- a pick-mode tile without a (row, own column) pair has nothing to do; the rows'
+    // positive ranges and first thresholds are fetched now, under the k-loop
+    int cnt_pb = 0, cnt_np = 0;
+    float cnt_th[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if constexpr (EPI == 2) {
+        const int m0 = tm * 128, n0 = tn * SPL_BN;
+        if (E.cnt_mode == 3) {
+            const int lo = E.cnt_off[m0], hi = E.cnt_off[min(m0 + 128, p.M)];
+            if (n0 >= hi || n0 + SPL_BN <= lo) return;
+        }
+        if ((E.cnt_mode == 1 || E.cnt_mode == 2) && threadIdx.x < 128 && m0 + (int)threadIdx.x < p.M) {
+            cnt_pb = E.cnt_off[m0 + threadIdx.x];
+            cnt_np = E.cnt_off[m0 + threadIdx.x + 1] - cnt_pb;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) cnt_th[k] = E.cnt_thr[(k < cnt_np) ? cnt_pb + k : 0];
+        }
+    }
     // this wave's copies: fragments f = CP w + q of the stage; f < 3 NA: A block f / 3, plane f % 3, else B block (f - 3 NA) / 3.
     // Source of k-tile kt: fragment (block, kt, plane) of the packed operand (wave-uniform base + lane * 16)
     const char* gsrc[CP];
@@ -184,6 +205,22 @@ __global__ __launch_bounds__(256, MINB) void gemm_nt_split_kernel(const SplitGem
 #undef TXE_SP_ISSUE
 #undef TXE_SP_COPY
 
+    if constexpr (EPI == 2) {
+        float* Cs = reinterpret_cast<float*>(smem_u4);
+        __syncthreads();                                 // every wave is done reading the stages
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int row = 32 * MI * wm + 32 * i + 4 * (l >> 5) + (e & 3) + 8 * (e >> 2);
+                    Cs[row * 132 + 64 * wn + 2 * (l & 31) + j] = acc[i][j][e];
+                }
+        __syncthreads();
+        gemm_tile_epilogue<128, NST * STAGE_U4 * 4>(E, Cs, tm * 128, tn * SPL_BN, p.M, p.N, tn, p.nbn, 0, cnt_pb, cnt_np, cnt_th);
+        return;
+    }
     // accumulator register e of block (i, j): row 32 i + (e & 3) + 8 (e >> 2) + 4 (lane >> 5), slot lane & 31 of B fragment 2 wn + j =
     // column 64 wn + 2 (lane & 31) + j of the tile
     const int c0 = tn * SPL_BN + 64 * wn + 2 * (l & 31);
@@ -197,7 +234,7 @@ __global__ __launch_bounds__(256, MINB) void gemm_nt_split_kernel(const SplitGem
             if (m < p.M) {
                 float* dst = p.C + (long long)m * p.ldc + c0;
                 float v0 = acc[i][0][e], v1 = acc[i][1][e];
-                if constexpr (EPI) {
+                if constexpr (EPI == 1) {
 #pragma unroll
                     for (int q = 0; q < 2; ++q) {
                         const int c = c0 + q;
@@ -461,6 +498,7 @@ int gemm_nt_split_launch(const void* Ap, const void* Bp, int M, int N, int K, fl
     const int v = g_split_variant & 15;
     const int bm = (v == 2 || v == 3) ? 256 : (v == 5 ? 192 : 128);
     p.nbm = (M + bm - 1) / bm; p.nbn = (N + SPL_BN - 1) / SPL_BN;
+    const Epi E0 = epi_plain(C, ldc, N);                // (unused by these variants)
     ProfScope prof(epi ? "gemm_nt_split_kernel[epi]" : "gemm_nt_split_kernel", stream, alg_flops > 0.0 ? alg_flops : 2.0 * M * (double)N * K, 0);
     const dim3 grid(p.nbm * p.nbn), blk(256);
     if (g_split_variant & 16) p.M = 0;                  // (timing experiment: no C stores)
@@ -470,17 +508,37 @@ int gemm_nt_split_launch(const void* Ap, const void* Bp, int M, int N, int K, fl
         p.drop_scale = epi->drop_scale;
         p.act_src = epi->act_src; p.ld_act = epi->ld_act; p.act_slope = epi->act_slope; p.act_on = epi->act_src ? 1 : 0; p.cols_act = epi->cols_act;
         p.nbm = (M + 127) / 128;
-        hipLaunchKernelGGL((gemm_nt_split_kernel<2, 3, 2, true>), dim3(p.nbm * p.nbn), blk, 0, stream, p);
+        hipLaunchKernelGGL((gemm_nt_split_kernel<2, 3, 2, 1>), dim3(p.nbm * p.nbn), blk, 0, stream, p, E0);
         TXE_CHECK_LAUNCH();
         return TXE_OK;
     }
-    if (v == 0) hipLaunchKernelGGL((gemm_nt_split_kernel<2, 3, 2>), grid, blk, 0, stream, p);
-    else if (v == 1) hipLaunchKernelGGL((gemm_nt_split_kernel<2, 2, 3>), grid, blk, 0, stream, p);
-    else if (v == 2) hipLaunchKernelGGL((gemm_nt_split_kernel<4, 2, 2>), grid, blk, 0, stream, p);
-    else if (v == 3) hipLaunchKernelGGL((gemm_nt_split_kernel<4, 3, 1>), grid, blk, 0, stream, p);
-    else if (v == 4) hipLaunchKernelGGL((gemm_nt_split_kernel<2, 2, 2>), grid, blk, 0, stream, p);
-    else if (v == 5) hipLaunchKernelGGL((gemm_nt_split_kernel<3, 2, 2>), grid, blk, 0, stream, p);
+    if (v == 0) hipLaunchKernelGGL((gemm_nt_split_kernel<2, 3, 2>), grid, blk, 0, stream, p, E0);
+    else if (v == 1) hipLaunchKernelGGL((gemm_nt_split_kernel<2, 2, 3>), grid, blk, 0, stream, p, E0);
+    else if (v == 2) hipLaunchKernelGGL((gemm_nt_split_kernel<4, 2, 2>), grid, blk, 0, stream, p, E0);
+    else if (v == 3) hipLaunchKernelGGL((gemm_nt_split_kernel<4, 3, 1>), grid, blk, 0, stream, p, E0);
+    else if (v == 4) hipLaunchKernelGGL((gemm_nt_split_kernel<2, 2, 2>), grid, blk, 0, stream, p, E0);
+    else if (v == 5) hipLaunchKernelGGL((gemm_nt_split_kernel<3, 2, 2>), grid, blk, 0, stream, p, E0);
     else return TXE_ERR_ARG;
+    TXE_CHECK_LAUNCH();
+    return TXE_OK;
+}
+
+// C = A B^T through gemm_kernel's epilogue E (E.c / E.ldc, exp, pick / count / best-k modes: the scoring loop's four entry points)
+int gemm_nt_split_epi_launch(const void* Ap, const void* Bp, const Epi& E, int M, int N, int K, hipStream_t stream) {
+    if (!Ap || !Bp || M < 1 || N < 1 || K < 1 || E.mask_on || E.act_on || E.c2) return TXE_ERR_ARG;
+    SplitGemm p;
+    memset(&p, 0, sizeof(p));
+    p.A = (const char*)Ap; p.B = (const char*)Bp; p.nkt = (K + SPL_KT - 1) / SPL_KT;
+    p.C = E.c; p.ldc = E.ldc; p.M = M; p.N = N;
+    p.nbm = (M + 127) / 128; p.nbn = (N + SPL_BN - 1) / SPL_BN;
+    Epi E2 = E;
+    {   // the epilogue loads its extras unconditionally: give the unused ones a readable dummy address (gemm_launch_layout does the same)
+        const void* valid = E2.c ? (const void*)E2.c : (const void*)Ap;
+        E2.act_src = (const float*)valid;
+        E2.mask = (const unsigned*)valid;
+    }
+    ProfScope prof("gemm_nt_split_kernel[score]", stream, E.alg_flops > 0.0 ? E.alg_flops : 2.0 * M * (double)N * K, 0);
+    hipLaunchKernelGGL((gemm_nt_split_kernel<2, 3, 2, 2>), dim3(p.nbm * p.nbn), dim3(256), 0, stream, p, E2);
     TXE_CHECK_LAUNCH();
     return TXE_OK;
 }

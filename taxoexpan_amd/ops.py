@@ -1613,6 +1613,15 @@ def _pad_queries(Q, r, rp):
     return Qp
 
 
+def _score_sws(nq, G, r, ref):
+    """scratch with which a scoring entry point runs on the bf16 matrix pipe: (tensor, bytes), or (None, 0) on the fp32-MFMA
+    route.  The four entry points compare scores bit for bit among themselves: the switch is one module attribute for all of them."""
+    if _NO_SPLIT_GEMM or nq < 1 or G < 1:
+        return None, 0
+    n = pure("txe_score_split_ws_bytes", int(nq), int(G), int(r))
+    return _ws(n, ref), n
+
+
 def score_block(Q, U, apply_exp, out=None):
     """S[q][g] = match(hg[g], Q[q]) for a block of queries against every candidate (test_fast.py:116-123)."""
     _need_cuda(Q, U)
@@ -1631,7 +1640,9 @@ def score_block(Q, U, apply_exp, out=None):
     S = out if out is not None else _empty((nq, (G + 3) // 4 * 4), Q)[:, :G]     # 16-byte row pitch: vector stores / rank sweeps
     with _lib.on_device(Q.device):
         tws = _tail_ws(Q)
-        call("txe_score_block", ptr(Q), ldq, nq, ptr(U), ldu, G, r, int(apply_exp), ptr(S), S.stride(0), ptr(tws), tws.numel(), _lib.stream_ptr())
+        sws, swb = _score_sws(nq, G, r, Q)
+        call("txe_score_block", ptr(Q), ldq, nq, ptr(U), ldu, G, r, int(apply_exp), ptr(S), S.stride(0), ptr(tws), tws.numel(), ptr(sws), swb,
+             _lib.stream_ptr())
     return S
 
 
@@ -1676,8 +1687,9 @@ def positive_scores_staircase(Q, Up, apply_exp, pos_off, out):
     if rp != r and ldq == rp:            # both operands carry zeros up to the same k-tile pitch (pad_queries_like / gather_padded_rows): the
         r = rp                           # whole reduction on the plain loader -- and the very k-tiles txe_score_count_block runs
     with _lib.on_device(Q.device):
+        sws, swb = _score_sws(Q.shape[0], Up.shape[0], r, Q)
         call("txe_score_positives", ptr(Q), ldq, Q.shape[0], ptr(Up), ldu, Up.shape[0], r, int(apply_exp), ptr(pos_off), ptr(out),
-             _lib.stream_ptr())
+             ptr(sws), swb, _lib.stream_ptr())
     return out
 
 
@@ -1712,8 +1724,9 @@ def score_count_block(Q, U, apply_exp, pos_off, thr, larger_is_better=True, coun
         return counts
     assert counts.dtype == torch.int32 and counts.is_contiguous() and counts.numel() >= thr.numel()
     with _lib.on_device(Q.device):
+        sws, swb = _score_sws(nq, U.shape[0], r, Q)
         call("txe_score_count_block", ptr(Q), ldq, nq, ptr(U), ldu, U.shape[0], r, int(apply_exp), ptr(pos_off), ptr(thr),
-             int(larger_is_better), ptr(counts), _lib.stream_ptr())
+             int(larger_is_better), ptr(counts), ptr(sws), swb, _lib.stream_ptr())
     return counts
 
 
@@ -1749,13 +1762,14 @@ def score_topk_block(Q, U, apply_exp, k, larger_is_better=True, idx_base=0, q_pa
         return idx, key
     with _lib.on_device(Q.device):
         nt = pure("txe_score_topk_tiles", G)
+        sws, swb = _score_sws(nq, G, r, Q)
         need = nq * nt * k
         sc = scratch if scratch is not None else {}
         if sc.get("n", 0) < need or sc.get("nq", 0) < nq or sc["key"].device != Q.device:
             sc["key"], sc["idx"], sc["n"] = _empty((need,), Q), torch.empty(need, dtype=torch.int32, device=Q.device), need
             sc["floor"], sc["nq"] = torch.empty(nq, dtype=torch.int32, device=Q.device), nq
         call("txe_score_topk_block", ptr(Q), ldq, nq, ptr(U), ldu, G, r, int(apply_exp), int(larger_is_better), int(k), int(idx_base),
-             ptr(sc["key"]), ptr(sc["idx"]), ptr(sc["floor"]), ptr(idx), ptr(key), _lib.stream_ptr())
+             ptr(sc["key"]), ptr(sc["idx"]), ptr(sc["floor"]), ptr(idx), ptr(key), ptr(sws), swb, _lib.stream_ptr())
     return idx, key
 
 

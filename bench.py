@@ -45,6 +45,12 @@ PEAK_MFMA_BF16 = 2.5e15       # ... dense bf16 MFMA
 SPLIT_PRODUCTS = 6            # csrc/txe_gemm_split.h: an fp32 product = six bf16 plane products (fp32-accurate) -> roof 2.5 PF / 6 per fp32 flop
 
 
+def score_peak():
+    """the roof of the scoring product: on the bf16 pipe (six plane products per fp32 product) unless the route is switched off"""
+    from taxoexpan_amd import ops
+    return PEAK_MFMA_F32 if ops._NO_SPLIT_GEMM else PEAK_MFMA_BF16 / SPLIT_PRODUCTS
+
+
 def mfma_peak(kernel_name):
     """the matrix-pipe roof a kernel's ALGORITHMIC fp32 flops are priced against: the fp32 MFMA's, or -- for the products that run as six
     bf16 plane products per fp32 product (gemm_*_split_kernel) -- a sixth of the bf16 pipe's"""
@@ -461,10 +467,10 @@ def extra_metrics(model, tax, device, batches, full_batches):
                    infer_fused_score_rank_s=t_fused, candidates_scored_per_s=pairs / t_sc,
                    candidates_scored_per_s_incl_encode_and_rank=pairs / (t_enc + t_sc + t_rk),
                    candidates_scored_per_s_fused_rank_incl_dedup_encode=pairs / (t_enc_l + t_fused),
-                   score_gemm_tflops=2.0 * 250 * pairs / t_sc / 1e12, score_gemm_frac_of_mfma_peak=2.0 * 250 * pairs / t_sc / PEAK_MFMA_F32,
+                   score_gemm_tflops=2.0 * 250 * pairs / t_sc / 1e12, score_gemm_frac_of_mfma_peak=2.0 * 250 * pairs / t_sc / score_peak(), score_gemm_frac_of_f32_mfma_peak=2.0 * 250 * pairs / t_sc / PEAK_MFMA_F32,
                    # (SURVEY 8d's factored count of the SAME timed region: U = hg W once, 2 G l r, + 2 r per pair)
                    score_factored_tflops=(2.0 * 250 * pairs + 2.0 * hg.shape[0] * 500 * 250) / t_sc / 1e12,
-                   score_factored_frac_of_mfma_peak=(2.0 * 250 * pairs + 2.0 * hg.shape[0] * 500 * 250) / t_sc / PEAK_MFMA_F32,
+                   score_factored_frac_of_mfma_peak=(2.0 * 250 * pairs + 2.0 * hg.shape[0] * 500 * 250) / t_sc / score_peak(),
                    mean_rank=float(ranks.float().mean().item()) if ranks.numel() else None)
     model.train()
     return out, hg, queries[:256]
@@ -519,10 +525,10 @@ def extra_metrics_mag_full(model, device, tax, n_queries=8192, qblock=1024):
                    device_egonet_build_s=t_build, encode_s=t_enc, encode_edges_per_s=n_edges / t_enc,
                    encode_30000_chunks_s=t_enc_c, encode_30000_chunks_edges_per_s=n_edges / t_enc_c, encode_chunks=n_chunks,
                    score_s=t_sc, candidates_scored_per_s=pairs / t_sc,
-                   score_gemm_tflops=2.0 * 250 * pairs / t_sc / 1e12, score_gemm_frac_of_mfma_peak=2.0 * 250 * pairs / t_sc / PEAK_MFMA_F32,
+                   score_gemm_tflops=2.0 * 250 * pairs / t_sc / 1e12, score_gemm_frac_of_mfma_peak=2.0 * 250 * pairs / t_sc / score_peak(), score_gemm_frac_of_f32_mfma_peak=2.0 * 250 * pairs / t_sc / PEAK_MFMA_F32,
                    # (SURVEY 8d's factored count of the SAME timed region: U = hg W once, 2 G l r, + 2 r per pair)
                    score_factored_tflops=(2.0 * 250 * pairs + 2.0 * hg.shape[0] * 500 * 250) / t_sc / 1e12,
-                   score_factored_frac_of_mfma_peak=(2.0 * 250 * pairs + 2.0 * hg.shape[0] * 500 * 250) / t_sc / PEAK_MFMA_F32,
+                   score_factored_frac_of_mfma_peak=(2.0 * 250 * pairs + 2.0 * hg.shape[0] * 500 * 250) / t_sc / score_peak(),
                    fused_score_rank_s=t_fr, candidates_scored_per_s_fused_rank=pairs / t_fr,
                    candidates_scored_per_s_fused_rank_incl_encode=pairs / (t_fr + t_enc),
                    mean_rank=float(ranks.float().mean().item()) if ranks.numel() else None)

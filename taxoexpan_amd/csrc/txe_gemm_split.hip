@@ -59,7 +59,7 @@ struct SplitGemm {
     const char* A; const char* B;     // packed operands
     int nkt;                          // k-tiles of 16
     float* C; long long ldc; int M, N;
-    int nbm, nbn, row_major;
+    int nbm, nbn, row_major, apply_exp;
     // epilogue extras (EPI kernels; txe_gemm.h epi_store_one): C = acc * (keep bit ? drop_scale : 0) * (act_src > 0 || column >= cols_act ? 1 : slope)
     const unsigned* mask; int mask_ld, mask_col0, mask_on; float drop_scale;
     const float* act_src; long long ld_act; float act_slope; int act_on, cols_act;
@@ -248,6 +248,7 @@ __global__ __launch_bounds__(256, MINB) void gemm_nt_split_kernel(const SplitGem
                         if (q == 0) v0 *= g; else v1 *= g;
                     }
                 }
+                if (p.apply_exp) { v0 = __expf(v0); v1 = __expf(v1); }       // (the scoring loop's exp: the very call gemm_tile_epilogue makes)
                 if (vec && c0 + 1 < p.N) *reinterpret_cast<float2*>(dst) = make_float2(v0, v1);
                 else {
                     if (c0 < p.N) dst[0] = v0;
@@ -512,6 +513,13 @@ int gemm_nt_split_launch(const void* Ap, const void* Bp, int M, int N, int K, fl
         TXE_CHECK_LAUNCH();
         return TXE_OK;
     }
+    if (g_split_variant & 64) {                          // (experiment: C through the LDS-staged 16-byte row stores of gemm_tile_epilogue)
+        Epi E1 = E0;
+        E1.act_src = C; E1.mask = (const unsigned*)C;
+        hipLaunchKernelGGL((gemm_nt_split_kernel<2, 3, 2, 2>), dim3(((M + 127) / 128) * p.nbn), blk, 0, stream, p, E1);
+        TXE_CHECK_LAUNCH();
+        return TXE_OK;
+    }
     if (v == 0) hipLaunchKernelGGL((gemm_nt_split_kernel<2, 3, 2>), grid, blk, 0, stream, p, E0);
     else if (v == 1) hipLaunchKernelGGL((gemm_nt_split_kernel<2, 2, 3>), grid, blk, 0, stream, p, E0);
     else if (v == 2) hipLaunchKernelGGL((gemm_nt_split_kernel<4, 2, 2>), grid, blk, 0, stream, p, E0);
@@ -538,6 +546,8 @@ int gemm_nt_split_epi_launch(const void* Ap, const void* Bp, const Epi& E, int M
         E2.mask = (const unsigned*)valid;
     }
     ProfScope prof("gemm_nt_split_kernel[score]", stream, E.alg_flops > 0.0 ? E.alg_flops : 2.0 * M * (double)N * K, 0);
+    // (plain / exp stores straight from the accumulators -- EPI 0 with the exp -- measured SLOWER than the LDS-staged 16-byte row stores:
+    //  MAG-CS 200 against 215 G pairs/s)
     hipLaunchKernelGGL((gemm_nt_split_kernel<2, 3, 2, 2>), dim3(p.nbm * p.nbn), dim3(256), 0, stream, p, E2);
     TXE_CHECK_LAUNCH();
     return TXE_OK;

@@ -459,7 +459,7 @@ int txe_gemm_nt_split(const void* A_packed, const void* B_packed, int M, int N, 
 
 /* The TN form (weight gradients, model_zoo.py:83 backward: dW = d_Y^T X over the nodes): part[z][M][ldc] = A[rows of slice z]^T B[same rows],
  * z < S, slices of ksplit rows (a multiple of 16).  A [n_rows][lda] is fp32 (split in the product's loader), B comes packed
- * contraction-major by txe_split_pack_t (cols % 160 == 0; 16-byte aligned rows).  M % 128 == 0, N % 160 == 0. */
+ * contraction-major by txe_split_pack_t (cols % 4 == 0, 16-byte aligned rows; the last 160-column tile is zero-filled).  M % 128 == 0. */
 size_t txe_split_packed_t_bytes(int rows, int cols);
 int txe_split_pack_t(const float* src, long long ld, int rows, int cols, void* packed, void* stream);
 int txe_gemm_tn_split(const float* A, long long lda, int M, const void* B_packed_t, int N, int n_rows, int S, int ksplit, float* part,

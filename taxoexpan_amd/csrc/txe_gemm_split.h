@@ -64,11 +64,11 @@ __device__ __host__ __forceinline__ int split_slot_row(int side, int rb, int s) 
 // [16 nt, 16 nt + 16) x the 32 column slots of block kb, at byte ((nt * nkb + kb) * 3 + p) * 1024; lane (nh = l >> 5, s = l & 31) owns rows
 // 16 nt + 8 nh .. + 7 of slot s.  Slot -> column inside a 160-column tile h (blocks kb = 5 h + j): j < 4: column 160 h + 4 s + j,
 // j == 4: column 160 h + 128 + s -- a lane's five accumulator blocks are then four ADJACENT columns of C (one 16-byte store) and one more.
-// Rows past the end are zeros.  A is read as fp32 and split in the product's loader (each element once per column tile).
-static inline size_t split_packed_t_bytes(int rows, int cols) {
-    return (size_t)((rows + 15) / 16) * (size_t)(cols / 32) * 3 * SPL_FRAG_BYTES;
+// Rows past the end and the columns that fill the last 160-column tile are zeros.  A is read as fp32 and split in the product's loader (each element once per column tile).
+static inline size_t split_packed_t_bytes(int rows, int cols) {            // (whole 160-column tiles: the last one zero-filled)
+    return (size_t)((rows + 15) / 16) * (size_t)(((cols + 159) / 160) * 5) * 3 * SPL_FRAG_BYTES;
 }
-static inline bool split_tn_eligible(int M, int N) { return M % 128 == 0 && N % 160 == 0 && M > 0 && N > 0; }
+static inline bool split_tn_eligible(int M, int N) { return M % 128 == 0 && N % 4 == 0 && M > 0 && N > 0; }
 // ... and A [n_rows][lda] is addressed with 32-bit byte offsets
 static inline bool split_tn_fits(int n_rows, long long lda) { return (double)n_rows * (double)lda * 4.0 < 4294967296.0; }
 

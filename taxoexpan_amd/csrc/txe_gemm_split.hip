@@ -260,7 +260,7 @@ __global__ __launch_bounds__(256, MINB) void gemm_nt_split_kernel(const SplitGem
 
 // ---- side 2 packing: fp32 [rows][ld] -> contraction-major planes (txe_gemm_split.h) ------------------------------------------------
 // one thread per (row tile nt, column tile h, lane): 8 rows x (4 + 1) columns -> five fragments' lane words per plane
-struct SplitPackTArgs { const float* src; long long ld; int rows, nht, nnt; uint4* dst; };
+struct SplitPackTArgs { const float* src; long long ld; int rows, cols, nht, nnt; uint4* dst; };
 __device__ __forceinline__ void split_pack_t_job(const SplitPackTArgs& a, const int bid, const int nb) {
     const float* __restrict__ src = a.src;
     uint4* __restrict__ dst = a.dst;
@@ -275,16 +275,20 @@ __device__ __forceinline__ void split_pack_t_job(const SplitPackTArgs& a, const 
         const int n0 = nt * 16 + nh * 8;
         float4 q[8];
         float o[8];
+        const int c4 = min(160 * h + 4 * s, a.cols - 4), c1 = min(160 * h + 128 + s, a.cols - 1);   // (clamped; zeroed below)
+        const bool ok4 = 160 * h + 4 * s + 3 < a.cols, ok1 = 160 * h + 128 + s < a.cols;
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
             const int row = min(n0 + r, rows - 1);
-            const float* p = src + (long long)row * ld + 160 * h;
-            q[r] = *reinterpret_cast<const float4*>(p + 4 * s);
-            o[r] = p[128 + s];
+            const float* p = src + (long long)row * ld;
+            q[r] = *reinterpret_cast<const float4*>(p + c4);
+            o[r] = p[c1];
         }
 #pragma unroll
-        for (int r = 0; r < 8; ++r)
-            if (n0 + r >= rows) { q[r] = make_float4(0.f, 0.f, 0.f, 0.f); o[r] = 0.f; }
+        for (int r = 0; r < 8; ++r) {
+            if (n0 + r >= rows || !ok4) q[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (n0 + r >= rows || !ok1) o[r] = 0.f;
+        }
         uint4* base = dst + ((long long)nt * nkb + 5 * h) * 3 * 64 + l;
 #pragma unroll
         for (int j = 0; j < 5; ++j) {
@@ -323,7 +327,7 @@ __global__ __launch_bounds__(256) void split_pack_multi_kernel(const SplitPackMu
 struct SplitTn {
     const float* A; long long lda; const char* Bt; int nkb;
     float* C; long long ldc, split_stride;
-    int n_rows, ksplit, ntm, ntn;
+    int n_rows, ksplit, ntm, ntn, N;
 };
 constexpr int SPT_A_U4 = 4 * 3 * 64, SPT_B_U4 = 5 * 3 * 64, SPT_STAGE_U4 = SPT_A_U4 + SPT_B_U4;   // 12 KB + 15 KB
 constexpr int SPT_RAW_F = 16 * 128;                                                              // 8 KB
@@ -442,8 +446,8 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_split_kernel(const SplitTn p) 
     for (int e = 0; e < 16; ++e) {
         const int slot = (e & 3) + 8 * (e >> 2) + 4 * (l >> 5);
         float* dst = cb + (long long)(2 * slot) * p.ldc;
-        *reinterpret_cast<float4*>(dst + 4 * sl) = make_float4(acc[0][e], acc[1][e], acc[2][e], acc[3][e]);
-        dst[128 + sl] = acc[4][e];
+        if (160 * h + 4 * sl + 3 < p.N) *reinterpret_cast<float4*>(dst + 4 * sl) = make_float4(acc[0][e], acc[1][e], acc[2][e], acc[3][e]);
+        if (160 * h + 128 + sl < p.N) dst[128 + sl] = acc[4][e];
     }
 }
 
@@ -459,9 +463,9 @@ static bool fill_pack(SplitPackArgs& a, int& nb, const float* src, long long ld,
     return true;
 }
 static bool fill_pack_t(SplitPackTArgs& a, int& nb, const float* src, long long ld, int rows, int cols, void* packed) {
-    if (!src || !packed || rows < 1 || cols < 160 || cols % 160 != 0 || ld < cols || (ld & 3) != 0 || (reinterpret_cast<uintptr_t>(src) & 15) != 0)
+    if (!src || !packed || rows < 1 || cols < 4 || cols % 4 != 0 || ld < cols || (ld & 3) != 0 || (reinterpret_cast<uintptr_t>(src) & 15) != 0)
         return false;
-    a.src = src; a.ld = ld; a.rows = rows; a.nht = cols / 160; a.nnt = (rows + 15) / 16; a.dst = (uint4*)packed;
+    a.src = src; a.ld = ld; a.rows = rows; a.cols = cols; a.nht = (cols + 159) / 160; a.nnt = (rows + 15) / 16; a.dst = (uint4*)packed;
     const long long total = (long long)a.nnt * a.nht * 64;
     nb = (int)((total + 255) / 256);
     return true;
@@ -569,9 +573,9 @@ int gemm_tn_split_launch(const float* A, long long lda, int M, const void* Bt, i
         (lda & 3) != 0 || (reinterpret_cast<uintptr_t>(A) & 15) != 0 || (double)n_rows * (double)lda * 4.0 >= 4294967296.0 || (reinterpret_cast<uintptr_t>(part) & 15) != 0 || (split_stride & 3) != 0)
         return TXE_ERR_ARG;
     SplitTn p;
-    p.A = A; p.lda = lda; p.Bt = (const char*)Bt; p.nkb = N / 32;
+    p.A = A; p.lda = lda; p.Bt = (const char*)Bt; p.nkb = ((N + 159) / 160) * 5; p.N = N;
     p.C = part; p.ldc = ldc; p.split_stride = split_stride;
-    p.n_rows = n_rows; p.ksplit = ksplit; p.ntm = M / 128; p.ntn = N / 160;
+    p.n_rows = n_rows; p.ksplit = ksplit; p.ntm = M / 128; p.ntn = (N + 159) / 160;
     ProfScope prof("gemm_tn_split_kernel", stream, alg_flops > 0.0 ? alg_flops : 2.0 * M * (double)N * n_rows, 0);
     hipLaunchKernelGGL(gemm_tn_split_kernel, dim3(p.ntm * p.ntn * S), dim3(256), 0, stream, p);
     TXE_CHECK_LAUNCH();
@@ -594,7 +598,7 @@ int txe_gemm_nt_split(const void* Ap, const void* Bp, int M, int N, int K, float
     return gemm_nt_split_launch(Ap, Bp, M, N, K, C, ldc, 0.0, (hipStream_t)stream, nullptr);
 }
 
-size_t txe_split_packed_t_bytes(int rows, int cols) { return (rows < 1 || cols < 32) ? 0 : split_packed_t_bytes(rows, cols); }
+size_t txe_split_packed_t_bytes(int rows, int cols) { return (rows < 1 || cols < 4) ? 0 : split_packed_t_bytes(rows, cols); }
 
 int txe_split_pack_t(const float* src, long long ld, int rows, int cols, void* packed, void* stream) {
     return split_pack_t_launch(src, ld, rows, cols, packed, (hipStream_t)stream);

@@ -81,7 +81,7 @@ def test_nt_product_against_float64(M, N, K):
     assert e_split <= max(1.5 * e_f32, 2e-7), (e_split, e_f32)      # as close to the exact product as an fp32 one
 
 
-@pytest.mark.parametrize("n,M,N,S", [(1000, 128, 160, 3), (4097, 256, 320, 16), (15, 128, 160, 2)])
+@pytest.mark.parametrize("n,M,N,S", [(1000, 128, 160, 3), (4097, 256, 320, 16), (15, 128, 160, 2), (2000, 256, 352, 4), (333, 128, 36, 2)])
 def test_tn_product_against_float64(n, M, N, S):
     from taxoexpan_amd import _lib
     g = torch.Generator().manual_seed(n + M)

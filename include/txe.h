@@ -448,7 +448,7 @@ int txe_adam_step(int n_tensors, float* const* params, const float* const* grads
 /* ---- fp32 products on the bf16 matrix pipe (replaces the fp32-MFMA route of model_zoo.py:83 `self.fc(...)` for the first
  * layer's projection).  A packed operand holds every fp32 element as the EXACT sum of three bf16 numbers (three planes, stored as 1-KB
  * MFMA fragments: csrc/txe_gemm_split.h); txe_gemm_nt_split forms C [M][N] = A [M][K] B[N][K]^T from six of the nine plane products with
- * fp32 accumulation -- the dropped terms are below the rounding of one fp32 multiply.
+ * fp32 accumulation -- the dropped terms are a quarter of an fp32 multiply's own rounding error in the root mean square (at most twice it).
  * side 0 = the operand whose rows are C's rows, side 1 = the operand whose rows are C's columns. */
 size_t txe_split_packed_bytes(int rows, int cols);
 int txe_split_pack(const float* src, long long ld, int rows, int cols, int side, void* packed, void* stream);   /* side 2 / 3: side 0 / 1 of

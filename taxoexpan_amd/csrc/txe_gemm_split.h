@@ -1,8 +1,9 @@
 // fp32 products on the bf16 matrix pipe: C = A B^T with every fp32 operand element carried as the EXACT sum of three bf16 numbers
 // (x = x1 + x2 + x3: 8 + 8 + 8 significand bits) and six of the nine plane products formed by v_mfma_f32_32x32x16_bf16 with fp32
 // accumulation -- a1b1, a1b2, a2b1, a1b3, a2b2, a3b1.  Each plane product is exact in fp32 (8 x 8 bits); the three dropped terms are
-// below 2^-26 |a b|, i.e. below the rounding of ONE fp32 multiply, and an element sees 6 K/16 accumulator roundings instead of the
-// fp32 MFMA's K/2 -- the result is as close to the exact product as the fp32 path's (tests: both against float64).  The bf16 pipe
+// 2^-27.4 |a b| in the root mean square and at most 2^-23 |a b| (an fp32 multiply's own rounding: 2^-25.2 rms, at most 2^-24;
+// tests/test_split_arithmetic.py), and an element sees 6 K/16 accumulator roundings instead of the fp32 MFMA's K/2 -- the result is as
+// close to the exact product as the fp32 path's (tests/test_gpu_split_gemm.py: both against float64).  The bf16 pipe
 // runs 16x the fp32 MFMA rate (MI355X: 2.5 PFLOP/s dense against 157.3 TFLOP/s), so six products per k cost 6/16 of the fp32 time.
 //
 // Packed operand ("planes"): a matrix of R rows x K columns is stored as 1-KB MFMA fragments,

@@ -311,8 +311,11 @@ int txe_topk_merge(const float* keys, const int* idx, int nq, long long cnt, int
  * 2: C = A[K][M]^T B[K][N].  splits > 1: `splits` partial products at C + z*M*ldc.  ws/ws_bytes (optional, txe_gemm_tail_ws_bytes):
  * scratch that lets the last, partial round of workgroups be split along k ("tail splitting").
  * route: 0 = the route the model paths take; test bits selecting a bit-equal alternative kernel: 1 = whole rounds on gemm_kernel instead
- * of the persistent kernel, 2 = split-K TN products without the LDS-direct copies, 4 = every eligible split-K product on 128 x 160 tiles. */
+ * of the persistent kernel, 2 = split-K TN products without the LDS-direct copies, 4 = every eligible split-K product on 128 x 160 tiles.
+ * route bit 8 (layout 0, splits 1): the product runs on the bf16 matrix pipe in fp32 accuracy (txe_gemm_nt_split below); ws then holds the
+ * packed operands -- txe_gemm_plain_split_ws_bytes(M, N, K) bytes. */
 size_t txe_gemm_tail_ws_bytes(void);
+size_t txe_gemm_plain_split_ws_bytes(int M, int N, int K);
 int txe_gemm_plain(int layout, const float* A, long long lda, const float* B, long long ldb, float* C, long long ldc, int M, int N,
                    int K, int splits, int route, void* ws, size_t ws_bytes, void* stream);
 
@@ -333,6 +336,9 @@ int txe_build_csr(const int* src, const int* dst, int n_nodes, int n_edges, int*
  * instead of N node rows.  X [N][Kp] / Wp [Fp][Kp] / mask as for txe_gat_dense_*; pw == NULL: MeanReadout.  Forward keeps
  * a12 [N][2], alpha [E], coef [N], wsum [G], gid [N], Z [G][Kp] for backward; d_X has the layout txe_gat_dense_bwd produces. */
 size_t txe_gat_collapse_ws_bytes(int n_nodes, int n_edges, int G, int Kh, int Pd, int D, int vocab);
+/* ws_bytes >= txe_gat_collapse_ws_bytes + txe_gat_collapse_split_ws_bytes: txe_gat_collapse_fwd forms hg = Z W^T on the bf16 matrix pipe in
+ * fp32 accuracy (txe_gemm_nt_split below) */
+size_t txe_gat_collapse_split_ws_bytes(int G, int Kh, int Pd, int D);
 int txe_gat_collapse_fwd(const int* rowptr_in, const int* col_src, const int* rowptr_out, const int* col_dst, const int* pos_out,
                          const int* graph_off, int n_nodes, int n_edges, int G, const float* X, int Kh, int Pd, const float* Wp, int D,
                          float feat_drop_p, const unsigned* mask, float attn_slope, float attn_drop_p, unsigned long long seed,

@@ -82,6 +82,8 @@ SIGNATURES = {
     "txe_score_positives": (I, [P, L, I, P, L, I, I, I, P, P, P, SZ, P]),
     "txe_rank_finalize": (I, [P, I, P, P, I, P, P]),
     "txe_gemm_tail_ws_bytes": (SZ, []),
+    "txe_gemm_plain_split_ws_bytes": (SZ, [I, I, I]),
+    "txe_gat_collapse_split_ws_bytes": (SZ, [I, I, I, I]),
     "txe_gemm_plain": (I, [I, P, L, P, L, P, L, I, I, I, I, I, P, SZ, P]),
     "txe_build_csr_ws_bytes": (SZ, [I, I]),
     "txe_build_csr": (I, [P, P, I, I, P, P, P, P, P, P, P, SZ, P]),

@@ -29,6 +29,11 @@ static inline size_t split_packed_bytes(int rows, int cols) {
     return rb * nkt * 3 * SPL_FRAG_BYTES;
 }
 
+// both operands of an M x N x K product, each on a 256-byte boundary
+static inline size_t split_pair_bytes(int M, int N, int K) {
+    return (split_packed_bytes(M, K) + 255) / 256 * 256 + (split_packed_bytes(N, K) + 255) / 256 * 256;
+}
+
 // x -> (x1, x2, x3) as bf16 bit patterns, round-to-nearest-even at each level (v_cvt_pk_bf16_f32; x - x1 and (x - x1) - x2 are exact in
 // fp32 whatever the rounding, so x1 + x2 + x3 == x exactly)
 typedef float split_f2 __attribute__((ext_vector_type(2)));

@@ -637,9 +637,25 @@ int txe_topk_merge(const float* keys, const int* idx, int nq, long long cnt, int
 // instead of the persistent kernel, 2 split-K TN products without the LDS-direct copies, 4 every eligible split-K product on 128 x 160 tiles.
 size_t txe_gemm_tail_ws_bytes(void) { return gemm_tail_ws_bytes(); }
 
+// route bit 8 (layout 0, splits 1): the product on the bf16 matrix pipe in fp32 accuracy (txe_gemm_split.h); ws then holds the packed
+// operands: txe_gemm_plain_split_ws_bytes(M, N, K)
+size_t txe_gemm_plain_split_ws_bytes(int M, int N, int K) { return (M < 1 || N < 1 || K < 1) ? 0 : split_pair_bytes(M, N, K); }
+
 int txe_gemm_plain(int layout, const float* A, long long lda, const float* B, long long ldb, float* C, long long ldc, int M, int N,
                    int K, int splits, int route, void* ws, size_t ws_bytes, void* stream) {
-    if (layout < 0 || layout > 2 || M < 0 || N < 0 || K < 0 || !A || !B || !C || route < 0 || route > 7) return TXE_ERR_ARG;
+    if (layout < 0 || layout > 2 || M < 0 || N < 0 || K < 0 || !A || !B || !C || route < 0 || route > 15) return TXE_ERR_ARG;
+    if (route & 8) {
+        if (layout != 0 || splits > 1) return TXE_ERR_ARG;
+        if (M == 0 || N == 0 || K == 0) return TXE_OK;
+        if (!ws || ws_bytes < split_pair_bytes(M, N, K)) return TXE_ERR_WORKSPACE;
+        char* w = (char*)ws;
+        const size_t a = (split_packed_bytes(M, K) + 255) / 256 * 256;
+        int rc = split_pack_launch(A, lda, M, K, 0, w, (hipStream_t)stream);
+        if (rc) return rc;
+        rc = split_pack_launch(B, ldb, N, K, 1, w + a, (hipStream_t)stream);
+        if (rc) return rc;
+        return gemm_nt_split_launch(w, w + a, M, N, K, C, ldc, 0.0, (hipStream_t)stream);
+    }
     Epi E = epi_plain(C, ldc, N);
     E.route = route;
     if (splits > 1) E.split_stride = (long long)M * ldc;

@@ -2374,6 +2374,14 @@ static CollapseWs plan_collapse_ws(void* ws, int n, int e, int G, int Kp, int D,
 using namespace txe;
 extern "C" {
 
+// extra workspace (behind txe_gat_collapse_ws_bytes) with which txe_gat_collapse_fwd forms hg = Z W^T on the bf16 pipe
+static inline size_t collapse_split_bytes(int G, int D, int Kt) {
+    const int Kc = round_up(Kt, 16);
+    return align_up(split_packed_bytes(G, Kc), 256) + align_up(split_packed_bytes(D, Kc), 256);
+}
+size_t txe_gat_collapse_split_ws_bytes(int G, int Kh, int Pd, int D) {
+    return (G < 1 || Kh < 1 || Pd < 0 || D < 1) ? 0 : collapse_split_bytes(G, D, Kh + Pd);
+}
 size_t txe_gat_collapse_ws_bytes(int n_nodes, int n_edges, int G, int Kh, int Pd, int D, int vocab) {
     return plan_collapse_ws(nullptr, n_nodes, n_edges, G, round_up(Kh + Pd, 32), D, Pd, vocab).total;
 }
@@ -2439,6 +2447,17 @@ int txe_gat_collapse_fwd(const int* rowptr_in, const int* col_src, const int* ro
                                     e_part);
     if (rc_z) return rc_z;
     if (!hg) return TXE_OK;          // (the caller folds hg = Z W^T into what consumes it: txe_bilinear_folded_*)
+    if (G > 0 && ws_bytes >= p.total + collapse_split_bytes(G, D, Kt)) {
+        // hg = Z W^T on the bf16 matrix pipe (txe_gemm_split.h): Z and the weight rows packed behind the workspace's own regions
+        char* sw = (char*)ws + p.total;
+        const int Kc = round_up(Kt, 16);
+        const size_t ba = align_up(split_packed_bytes(G, Kc), 256);
+        int rc = split_pack_launch(Z, Kp, G, Kc, 0, sw, s);
+        if (rc) return rc;
+        rc = split_pack_launch(Wp, Kp, D, Kc, 1, sw + ba, s);
+        if (rc) return rc;
+        return gemm_nt_split_launch(sw, sw + ba, G, D, Kc, hg, ld_hg, 2.0 * G * (double)D * Kt, s);
+    }
     VMat A = vmat_plain(Z, Kp, G, Kp);
     VMat B = vmat_plain(Wp, Kp, round_up(D + 2, 128), Kp);       // all Fp packed rows are readable: every tile stays on the plain loader
     Epi E = epi_plain(hg, ld_hg, D);

@@ -251,7 +251,12 @@ def _gat_table_projection(st, src):
     tws = _tail_ws(tab)
     T = _empty((n_tab, Fp), tab)
     # the padding columns [Kh, Kt) of Xt are zero, so whatever Wp holds there (position columns) does not contribute
-    call("txe_gemm_plain", 0, ptr(Xt), Kt, ptr(Wp), Kp, ptr(T), Fp, n_tab, Fp, min(Kt, Kp), 1, 0, ptr(tws), tws.numel(), s)
+    if _NO_SPLIT_GEMM:
+        call("txe_gemm_plain", 0, ptr(Xt), Kt, ptr(Wp), Kp, ptr(T), Fp, n_tab, Fp, min(Kt, Kp), 1, 0, ptr(tws), tws.numel(), s)
+    else:                                               # the table's projection on the bf16 pipe (route bit 8)
+        wsb = pure("txe_gemm_plain_split_ws_bytes", n_tab, Fp, min(Kt, Kp))
+        sws = _ws(wsb, tab)
+        call("txe_gemm_plain", 0, ptr(Xt), Kt, ptr(Wp), Kp, ptr(T), Fp, n_tab, Fp, min(Kt, Kp), 1, 8, ptr(sws), wsb, s)
     T2 = None
     if st.Pd > 0:
         T2 = _empty((st.P.shape[0], Fp), tab)
@@ -387,6 +392,8 @@ def _gat_collapse_fwd(csr, st, h, ld_h, pos, rpos, pw, feat_p, attn_p, attn_slop
     wsum, Z, hg = _empty((max(G, 1),), st.X), _empty((max(G, 1), st.Kp), st.X), (None if z_only else _empty((G, st.D), st.X))
     gid = torch.empty(max(N, 1), dtype=torch.int32, device=st.X.device)
     wsb = pure("txe_gat_collapse_ws_bytes", N, E, G, st.Kh, st.Pd, st.D, 8)
+    if not z_only and G > 0 and not _NO_SPLIT_GEMM:      # room for Z and the weight rows as packed planes: hg = Z W^T on the bf16 pipe
+        wsb += pure("txe_gat_collapse_split_ws_bytes", G, st.Kh, st.Pd, st.D)
     ws = _ws(wsb, st.X)
     Tf = zrow = e_part = None
     if z_only and fold_job is not None and link is not None and N > 0 and G > 0 and not _NO_FOLD_EDOT:

@@ -75,8 +75,8 @@ static inline size_t split_packed_t_bytes(int rows, int cols) {            // (w
     return (size_t)((rows + 15) / 16) * (size_t)(((cols + 159) / 160) * 5) * 3 * SPL_FRAG_BYTES;
 }
 static inline bool split_tn_eligible(int M, int N) { return M % 128 == 0 && N % 4 == 0 && M > 0 && N > 0; }
-// ... and A [n_rows][lda] is addressed with 32-bit byte offsets
-static inline bool split_tn_fits(int n_rows, long long lda) { return (double)n_rows * (double)lda * 4.0 < 4294967296.0; }
+// ... and A [n_rows][lda] is addressed with 32-bit byte offsets (kept below 2^31: no reliance on how the instruction extends them)
+static inline bool split_tn_fits(int n_rows, long long lda) { return (double)n_rows * (double)lda * 4.0 < 2147483648.0; }
 
 // launches (txe_gemm_split.hip)
 int split_pack_launch(const float* src, long long ld, int rows, int cols, int side, void* packed, hipStream_t stream);

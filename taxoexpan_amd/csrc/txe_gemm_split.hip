@@ -570,7 +570,7 @@ int split_pack_t_launch(const float* src, long long ld, int rows, int cols, void
 int gemm_tn_split_launch(const float* A, long long lda, int M, const void* Bt, int N, int n_rows, int S, int ksplit, float* part, long long ldc,
                          long long split_stride, double alg_flops, hipStream_t stream) {
     if (!A || !Bt || !part || !split_tn_eligible(M, N) || n_rows < 1 || S < 1 || ksplit < 16 || ksplit % 16 != 0 || ldc < N || (ldc & 3) != 0 ||
-        (lda & 3) != 0 || (reinterpret_cast<uintptr_t>(A) & 15) != 0 || (double)n_rows * (double)lda * 4.0 >= 4294967296.0 || (reinterpret_cast<uintptr_t>(part) & 15) != 0 || (split_stride & 3) != 0)
+        (lda & 3) != 0 || (reinterpret_cast<uintptr_t>(A) & 15) != 0 || !split_tn_fits(n_rows, lda) || (reinterpret_cast<uintptr_t>(part) & 15) != 0 || (split_stride & 3) != 0)
         return TXE_ERR_ARG;
     SplitTn p;
     p.A = A; p.lda = lda; p.Bt = (const char*)Bt; p.nkb = ((N + 159) / 160) * 5; p.N = N;

@@ -200,7 +200,8 @@ int txe_readout_multi_bwd(const int* graph_off, int G, const int* pos, int D, in
 
 /* ---- matchers: BIM model_zoo.py:313, LBM :328 (apply_exp) ------------------------------------------------------- */
 int txe_bilinear_project(const float* e1, long long ld_e1, int G, int l, const float* W, int r, float* U, long long ld_u,
-                         void* stream);
+                         void* sws, size_t sws_bytes, void* stream);   /* sws: NULL, or txe_gemm_plain_split_ws_bytes(G, r, l) of scratch:
+                         the product then runs on the bf16 matrix pipe in fp32 accuracy */
 int txe_bilinear_pair_fwd(const float* e1, long long ld_e1, const float* e2, long long ld_e2, int G, int l, int r,
                           const float* W, int apply_exp, float* U, float* s, void* stream);
 size_t txe_bilinear_pair_bwd_ws_bytes(int G, int l, int r);

@@ -54,7 +54,7 @@ SIGNATURES = {
     "txe_linear_fwd": (I, [P, L, I, P, L, I, I, P, P, I, I, P, P]),
     "txe_linear_bwd_ws_bytes": (SZ, [I, I, I, I]),
     "txe_linear_bwd": (I, [P, L, I, P, L, I, I, P, I, I, P, P, P, L, P, L, P, P, P, SZ, P]),
-    "txe_bilinear_project": (I, [P, L, I, I, P, I, P, L, P]),
+    "txe_bilinear_project": (I, [P, L, I, I, P, I, P, L, P, SZ, P]),
     "txe_bilinear_pair_fwd": (I, [P, L, P, L, I, I, I, P, I, P, P, P]),
     "txe_bilinear_query_fwd": (I, [P, L, P, L, I, I, I, P, I, P, P, P]),
     "txe_bilinear_query_project": (I, [P, L, I, I, I, P, P, P]),

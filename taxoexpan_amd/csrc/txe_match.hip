@@ -291,9 +291,21 @@ using namespace txe;
 extern "C" {
 
 // U[G][r] = E1[G][l] * W[l][r]   (row stride ld_u >= r: a multiple of 4 lets the scoring GEMM read U with 16-byte loads)
+// sws (or NULL: the fp32 MFMA): txe_gemm_plain_split_ws_bytes(G, r, l) of scratch -- the product on the bf16 matrix pipe in fp32 accuracy
+// (txe_gemm_split.h; W packed from its transpose)
 int txe_bilinear_project(const float* e1, long long ld_e1, int G, int l, const float* W, int r, float* U, long long ld_u,
-                         void* stream) {
+                         void* sws, size_t sws_bytes, void* stream) {
     if (G < 0 || l < 1 || r < 1 || ld_u < r || !e1 || !W || !U) return TXE_ERR_ARG;
+    if (sws && G > 0) {
+        if (sws_bytes < split_pair_bytes(G, r, l)) return TXE_ERR_WORKSPACE;
+        char* w = (char*)sws;
+        const size_t a = (split_packed_bytes(G, l) + 255) / 256 * 256;
+        int rc = split_pack_launch(e1, ld_e1, G, l, 0, w, (hipStream_t)stream);
+        if (rc) return rc;
+        rc = split_pack_launch(W, r, r, l, 3, w + a, (hipStream_t)stream);      // W [l][r] = the transpose of the column operand [r][l]
+        if (rc) return rc;
+        return gemm_nt_split_launch(w, w + a, G, r, l, U, ld_u, 0.0, (hipStream_t)stream);
+    }
     VMat A = vmat_plain(e1, ld_e1, G, l);
     VMat B = vmat_plain(W, r, l, r);
     Epi E = epi_plain(U, ld_u, r);
@@ -305,7 +317,7 @@ int txe_bilinear_project(const float* e1, long long ld_e1, int G, int l, const f
 int txe_bilinear_pair_fwd(const float* e1, long long ld_e1, const float* e2, long long ld_e2, int G, int l, int r,
                           const float* W, int apply_exp, float* U, float* s, void* stream) {
     if (G < 0 || !e2 || !s) return TXE_ERR_ARG;
-    int rc = txe_bilinear_project(e1, ld_e1, G, l, W, r, U, r, stream);
+    int rc = txe_bilinear_project(e1, ld_e1, G, l, W, r, U, r, nullptr, 0, stream);
     if (rc) return rc;
     if (G == 0) return TXE_OK;
     hipLaunchKernelGGL(rowdot_kernel, dim3((G + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const float*)U, e2, ld_e2, G, r,

@@ -1577,7 +1577,9 @@ def bilinear_project(hg, W):
         Wp[:, :r].copy_(Wf)
         Wf = Wp
     with _lib.on_device(hg.device):
-        call("txe_bilinear_project", ptr(hg), ld, G, l, ptr(Wf), rp, ptr(Ufull), rp, _lib.stream_ptr())
+        swb = 0 if (_NO_SPLIT_GEMM or G < 1) else pure("txe_gemm_plain_split_ws_bytes", G, rp, l)
+        sws = _ws(swb, hg) if swb else None
+        call("txe_bilinear_project", ptr(hg), ld, G, l, ptr(Wf), rp, ptr(Ufull), rp, ptr(sws), swb, _lib.stream_ptr())
     _ZERO_PADDED[U.data_ptr()] = (rp, weakref.ref(Ufull))
     return U
 

@@ -186,3 +186,60 @@ def test_input_gradient_of_a_deeper_layer_on_the_split_route(N, Kh, Pd, H, D, p)
         assert np.abs(dX - ref).max() <= 2e-5 * scale
     assert np.abs(outs[0][0] - outs[1][0]).max() <= 4e-6 * scale            # the two routes: fp32 rounding apart
     np.testing.assert_array_equal(outs[0][1], outs[1][1])                    # (dW does not depend on the d_X route)
+
+
+def test_seeded_shape_fuzz_of_the_three_products():
+    """60 random shapes each of the NT product (ragged M / N / K, odd leading dimensions), the TN product (any 4-aligned width, slices that
+    end past the last row) and the plain-GEMM route bit: against float64, error no worse than 1.5 x an fp32 product's"""
+    from taxoexpan_amd import _lib
+    rs = np.random.RandomState(2024)
+    s = _lib.stream_ptr()
+    dev = _dev()
+    for it in range(60):
+        M, N, K = int(rs.randint(1, 700)), int(rs.randint(1, 500)), int(rs.randint(1, 400))
+        lda, ldb, ldc = K + int(rs.randint(0, 5)), K + int(rs.randint(0, 5)), N + int(rs.randint(0, 7))
+        A = torch.randn(M, lda, device=dev)[:, :K]
+        B = torch.randn(N, ldb, device=dev)[:, :K]
+        C = torch.full((M, ldc), float("nan"), device=dev)
+        wsb = _lib.call("txe_gemm_plain_split_ws_bytes", M, N, K)
+        ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+        _lib.call("txe_gemm_plain", 0, A.data_ptr(), lda, B.data_ptr(), ldb, C.data_ptr(), ldc, M, N, K, 1, 8, ws.data_ptr(), wsb, s)
+        ref = A.double() @ B.double().t()
+        scale = (A.double().abs() @ B.double().abs().t()).clamp_min(1e-300)
+        e_split, e_f32 = _err(C[:, :N], ref, scale), _err(A @ B.t(), ref, scale)
+        assert torch.isnan(C[:, N:]).all() and e_split <= max(1.5 * e_f32, 2e-7), (it, M, N, K, e_split, e_f32)
+    for it in range(60):
+        n, M, N, S = int(rs.randint(1, 3000)), 128 * int(rs.randint(1, 4)), 4 * int(rs.randint(1, 120)), int(rs.randint(1, 9))
+        A = (torch.randn(n, M, device=dev) * 0.1)
+        B = torch.randn(n, N, device=dev)
+        Bt = torch.empty(_lib.call("txe_split_packed_t_bytes", n, N), dtype=torch.uint8, device=dev)
+        ks = (((n + S - 1) // S) + 15) // 16 * 16
+        part = torch.full((S, M, N), float("nan"), device=dev)
+        _lib.call("txe_split_pack_t", B.data_ptr(), N, n, N, Bt.data_ptr(), s)
+        _lib.call("txe_gemm_tn_split", A.data_ptr(), M, M, Bt.data_ptr(), N, n, S, ks, part.data_ptr(), N, M * N, s)
+        assert torch.isfinite(part).all(), (it, n, M, N, S)
+        ref = A.double().t() @ B.double()
+        scale = (A.double().abs().t() @ B.double().abs()).clamp_min(1e-300)
+        e_split, e_f32 = _err(part.double().sum(0), ref, scale), _err(A.t() @ B, ref, scale)
+        assert e_split <= max(1.5 * e_f32, 2e-7), (it, n, M, N, S, e_split, e_f32)
+
+
+def test_bilinear_projection_on_the_split_route():
+    """U = hg W (the scoring loop's factored half) with the scratch: against float64 and the fp32-MFMA route"""
+    from taxoexpan_amd import _lib
+    dev = _dev()
+    g = torch.Generator().manual_seed(3)
+    G, l, r = 3001, 500, 256
+    hg, W = torch.randn(G, l, generator=g).to(dev), (torch.randn(l, r, generator=g) * 0.05).to(dev)
+    outs = []
+    for split in (True, False):
+        U = torch.full((G, r), float("nan"), device=dev)
+        wsb = _lib.call("txe_gemm_plain_split_ws_bytes", G, r, l) if split else 0
+        ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=dev)
+        _lib.call("txe_bilinear_project", hg.data_ptr(), l, G, l, W.data_ptr(), r, U.data_ptr(), r, ws.data_ptr() if split else None, wsb, _lib.stream_ptr())
+        torch.cuda.synchronize()
+        outs.append(U)
+    ref = hg.double() @ W.double()
+    scale = (hg.double().abs() @ W.double().abs()).clamp_min(1e-300)
+    e_split, e_f32 = _err(outs[0], ref, scale), _err(outs[1], ref, scale)
+    assert e_split <= max(1.5 * e_f32, 2e-7), (e_split, e_f32)

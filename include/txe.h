@@ -456,7 +456,8 @@ int txe_adam_step(int n_tensors, float* const* params, const float* const* grads
  * layer's projection).  A packed operand holds every fp32 element as the EXACT sum of three bf16 numbers (three planes, stored as 1-KB
  * MFMA fragments: csrc/txe_gemm_split.h); txe_gemm_nt_split forms C [M][N] = A [M][K] B[N][K]^T from six of the nine plane products with
  * fp32 accumulation -- the dropped terms are a quarter of an fp32 multiply's own rounding error in the root mean square (at most twice it).
- * side 0 = the operand whose rows are C's rows, side 1 = the operand whose rows are C's columns. */
+ * side 0 = the operand whose rows are C's rows, side 1 = the operand whose rows are C's columns.  An operand element that is +-Inf gives
+ * NaN where an fp32 product gives +-Inf (Inf - Inf in the split); NaN stays NaN. */
 size_t txe_split_packed_bytes(int rows, int cols);
 int txe_split_pack(const float* src, long long ld, int rows, int cols, int side, void* packed, void* stream);   /* side 2 / 3: side 0 / 1 of
     a matrix given as its transpose, src [cols][ld >= rows] */
@@ -466,7 +467,8 @@ int txe_gemm_nt_split(const void* A_packed, const void* B_packed, int M, int N, 
 
 /* The TN form (weight gradients, model_zoo.py:83 backward: dW = d_Y^T X over the nodes): part[z][M][ldc] = A[rows of slice z]^T B[same rows],
  * z < S, slices of ksplit rows (a multiple of 16).  A [n_rows][lda] is fp32 (split in the product's loader), B comes packed
- * contraction-major by txe_split_pack_t (cols % 4 == 0, 16-byte aligned rows; the last 160-column tile is zero-filled).  M % 128 == 0. */
+ * contraction-major by txe_split_pack_t (cols % 4 == 0, 16-byte aligned rows; the last 160-column tile is zero-filled).  M % 128 == 0; lda % 4 == 0, A 16-byte aligned and
+ * n_rows * lda * 4 < 2^31 (32-bit byte offsets), else TXE_ERR_ARG -- txe_gat_dense_bwd falls back to the fp32 MFMA by itself. */
 size_t txe_split_packed_t_bytes(int rows, int cols);
 int txe_split_pack_t(const float* src, long long ld, int rows, int cols, void* packed, void* stream);
 int txe_gemm_tn_split(const float* A, long long lda, int M, const void* B_packed_t, int N, int n_rows, int S, int ksplit, float* part,

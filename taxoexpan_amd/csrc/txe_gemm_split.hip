@@ -150,6 +150,26 @@ __global__ __launch_bounds__(256, MINB) void gemm_nt_split_kernel(const SplitGem
     _Pragma("unroll") for (int i = 0; i < MI; ++i)                                                                   \
         _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                                \
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][pa_], fb[j][pb_], acc[i][j], 0, 0, 0);
+#ifdef TXE_SPLIT_TMP
+    /* the five small plane products of a k-tile are summed in a fresh accumulator (C = 0) and added to the running sum ONCE: the running
+       sum then sees two roundings per k-tile instead of six */
+#define TXE_SP_MFMAT(pa_, pb_)                                                                                        \
+    _Pragma("unroll") for (int i = 0; i < MI; ++i)                                                                   \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                                \
+            tmp[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][pa_], fb[j][pb_], tmp[i][j], 0, 0, 0);
+#define TXE_SP_PRODUCTS()                                                                                             \
+    f32x16s tmp[MI][2];                                                                                              \
+    _Pragma("unroll") for (int i = 0; i < MI; ++i)                                                                   \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                                \
+            _Pragma("unroll") for (int e = 0; e < 16; ++e) tmp[i][j][e] = 0.f;                                       \
+    TXE_SP_MFMAT(2, 0) TXE_SP_MFMAT(0, 2) TXE_SP_MFMAT(1, 1) TXE_SP_MFMAT(1, 0) TXE_SP_MFMAT(0, 1) TXE_SP_MFMA(0, 0)  \
+    _Pragma("unroll") for (int i = 0; i < MI; ++i)                                                                   \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                                \
+            _Pragma("unroll") for (int e = 0; e < 16; ++e) acc[i][j][e] += tmp[i][j][e];
+#else
+#define TXE_SP_PRODUCTS()                                                                                             \
+    TXE_SP_MFMA(2, 0) TXE_SP_MFMA(0, 2) TXE_SP_MFMA(1, 1) TXE_SP_MFMA(1, 0) TXE_SP_MFMA(0, 1) TXE_SP_MFMA(0, 0)
+#endif
 #define TXE_SP_COMPUTE(st_)                                                                                           \
     {                                                                                                                \
         bf16x8 fa[MI][3], fb[2][3];                                                                                  \
@@ -163,7 +183,7 @@ __global__ __launch_bounds__(256, MINB) void gemm_nt_split_kernel(const SplitGem
                 const uint4 t = (st_)[(3 * NA + (2 * wn + j) * 3 + q) * 64 + l];                                     \
                 fb[j][q] = __builtin_bit_cast(bf16x8, t);                                                            \
             }                                                                                                        \
-        TXE_SP_MFMA(2, 0) TXE_SP_MFMA(0, 2) TXE_SP_MFMA(1, 1) TXE_SP_MFMA(1, 0) TXE_SP_MFMA(0, 1) TXE_SP_MFMA(0, 0)  \
+        TXE_SP_PRODUCTS()                                                                                            \
     }
     // this wave's copies of the stage about to be read have landed (three stages: the CP of the stage after it may still be in flight);
     // the barrier then says the same of every wave's, and that every wave is done reading the stage the next copies overwrite
@@ -202,6 +222,7 @@ __global__ __launch_bounds__(256, MINB) void gemm_nt_split_kernel(const SplitGem
 #undef TXE_SP_SYNC
 #undef TXE_SP_COMPUTE
 #undef TXE_SP_MFMA
+#undef TXE_SP_PRODUCTS
 #undef TXE_SP_ISSUE
 #undef TXE_SP_COPY
 

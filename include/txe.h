@@ -461,7 +461,8 @@ int txe_adam_step(int n_tensors, float* const* params, const float* const* grads
 size_t txe_split_packed_bytes(int rows, int cols);
 int txe_split_pack(const float* src, long long ld, int rows, int cols, int side, void* packed, void* stream);   /* side 2 / 3: side 0 / 1 of
     a matrix given as its transpose, src [cols][ld >= rows] */
-int txe_gemm_split_variant(int v);   /* tuning hook (tools/split_gemm_probe.py): tile / stage variant of the products launched after it;
+int txe_gemm_split_variant(int v);   /* tuning hook (tools/split_gemm_probe.py): tile / stage variant of the products launched after it
+                                       * (bit 128: the plain NT product sums a k-tile's small plane products apart -- more accurate, +13 % time);
                                        * PROCESS-GLOBAL state, not thread-safe, default 0 -- the library itself never calls it */
 int txe_gemm_nt_split(const void* A_packed, const void* B_packed, int M, int N, int K, float* C, long long ldc, void* stream);
 

@@ -67,7 +67,9 @@ struct SplitGemm {
 
 // EPI: 0 = plain stores from the accumulators; 1 = the same with the dropout-mask / activation factors; 2 = the tile goes through LDS into
 // gemm_kernel's own epilogue (txe_gemm.h gemm_tile_epilogue: exp, pick, count and best-k modes -- the scoring loop), E = its arguments
-template <int MI, int NST, int MINB, int EPI = 0>
+// TMP: a k-tile's five small plane products are summed in a fresh accumulator (C = 0) and added to the running sum once -- two roundings per
+// k-tile instead of six (DESIGN 4.10 "One accumulator or two": error below torch.mm's fp32 on every probe shape, +13 % time)
+template <int MI, int NST, int MINB, int EPI = 0, bool TMP = false>
 __global__ __launch_bounds__(256, MINB) void gemm_nt_split_kernel(const SplitGemm p, const Epi E) {
     constexpr int NA = 2 * MI, NB = 4;                      // A / B fragment blocks per tile
     constexpr int NF = 3 * (NA + NB), CP = (NF + 3) / 4;    // fragments per stage, copies per wave and k-tile (the last wave: the rest)
@@ -150,26 +152,23 @@ __global__ __launch_bounds__(256, MINB) void gemm_nt_split_kernel(const SplitGem
     _Pragma("unroll") for (int i = 0; i < MI; ++i)                                                                   \
         _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                                \
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][pa_], fb[j][pb_], acc[i][j], 0, 0, 0);
-#ifdef TXE_SPLIT_TMP
-    /* the five small plane products of a k-tile are summed in a fresh accumulator (C = 0) and added to the running sum ONCE: the running
-       sum then sees two roundings per k-tile instead of six */
 #define TXE_SP_MFMAT(pa_, pb_)                                                                                        \
     _Pragma("unroll") for (int i = 0; i < MI; ++i)                                                                   \
         _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                                \
             tmp[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][pa_], fb[j][pb_], tmp[i][j], 0, 0, 0);
 #define TXE_SP_PRODUCTS()                                                                                             \
-    f32x16s tmp[MI][2];                                                                                              \
-    _Pragma("unroll") for (int i = 0; i < MI; ++i)                                                                   \
-        _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                                \
-            _Pragma("unroll") for (int e = 0; e < 16; ++e) tmp[i][j][e] = 0.f;                                       \
-    TXE_SP_MFMAT(2, 0) TXE_SP_MFMAT(0, 2) TXE_SP_MFMAT(1, 1) TXE_SP_MFMAT(1, 0) TXE_SP_MFMAT(0, 1) TXE_SP_MFMA(0, 0)  \
-    _Pragma("unroll") for (int i = 0; i < MI; ++i)                                                                   \
-        _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                                \
-            _Pragma("unroll") for (int e = 0; e < 16; ++e) acc[i][j][e] += tmp[i][j][e];
-#else
-#define TXE_SP_PRODUCTS()                                                                                             \
-    TXE_SP_MFMA(2, 0) TXE_SP_MFMA(0, 2) TXE_SP_MFMA(1, 1) TXE_SP_MFMA(1, 0) TXE_SP_MFMA(0, 1) TXE_SP_MFMA(0, 0)
-#endif
+    if constexpr (TMP) {                                                                                             \
+        f32x16s tmp[MI][2];                                                                                          \
+        _Pragma("unroll") for (int i = 0; i < MI; ++i)                                                               \
+            _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                            \
+                _Pragma("unroll") for (int e = 0; e < 16; ++e) tmp[i][j][e] = 0.f;                                   \
+        TXE_SP_MFMAT(2, 0) TXE_SP_MFMAT(0, 2) TXE_SP_MFMAT(1, 1) TXE_SP_MFMAT(1, 0) TXE_SP_MFMAT(0, 1) TXE_SP_MFMA(0, 0) \
+        _Pragma("unroll") for (int i = 0; i < MI; ++i)                                                               \
+            _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                            \
+                _Pragma("unroll") for (int e = 0; e < 16; ++e) acc[i][j][e] += tmp[i][j][e];                         \
+    } else {                                                                                                         \
+        TXE_SP_MFMA(2, 0) TXE_SP_MFMA(0, 2) TXE_SP_MFMA(1, 1) TXE_SP_MFMA(1, 0) TXE_SP_MFMA(0, 1) TXE_SP_MFMA(0, 0)  \
+    }
 #define TXE_SP_COMPUTE(st_)                                                                                           \
     {                                                                                                                \
         bf16x8 fa[MI][3], fb[2][3];                                                                                  \
@@ -223,6 +222,7 @@ __global__ __launch_bounds__(256, MINB) void gemm_nt_split_kernel(const SplitGem
 #undef TXE_SP_COMPUTE
 #undef TXE_SP_MFMA
 #undef TXE_SP_PRODUCTS
+#undef TXE_SP_MFMAT
 #undef TXE_SP_ISSUE
 #undef TXE_SP_COPY
 
@@ -545,7 +545,8 @@ int gemm_nt_split_launch(const void* Ap, const void* Bp, int M, int N, int K, fl
         TXE_CHECK_LAUNCH();
         return TXE_OK;
     }
-    if (v == 0) hipLaunchKernelGGL((gemm_nt_split_kernel<2, 3, 2>), grid, blk, 0, stream, p, E0);
+    if (v == 0 && (g_split_variant & 128)) hipLaunchKernelGGL((gemm_nt_split_kernel<2, 3, 2, 0, true>), grid, blk, 0, stream, p, E0);
+    else if (v == 0) hipLaunchKernelGGL((gemm_nt_split_kernel<2, 3, 2>), grid, blk, 0, stream, p, E0);
     else if (v == 1) hipLaunchKernelGGL((gemm_nt_split_kernel<2, 2, 3>), grid, blk, 0, stream, p, E0);
     else if (v == 2) hipLaunchKernelGGL((gemm_nt_split_kernel<4, 2, 2>), grid, blk, 0, stream, p, E0);
     else if (v == 3) hipLaunchKernelGGL((gemm_nt_split_kernel<4, 3, 1>), grid, blk, 0, stream, p, E0);

@@ -525,7 +525,8 @@ int gemm_nt_split_launch(const void* Ap, const void* Bp, int M, int N, int K, fl
     const int bm = (v == 2 || v == 3) ? 256 : (v == 5 ? 192 : 128);
     p.nbm = (M + bm - 1) / bm; p.nbn = (N + SPL_BN - 1) / SPL_BN;
     const Epi E0 = epi_plain(C, ldc, N);                // (unused by these variants)
-    ProfScope prof(epi ? "gemm_nt_split_kernel[epi]" : "gemm_nt_split_kernel", stream, alg_flops > 0.0 ? alg_flops : 2.0 * M * (double)N * K, 0);
+    // (named as rocprofv3 prints the default instantiations: bench.py joins its HIP-event timings with the committed profiles by name)
+    ProfScope prof(epi ? "gemm_nt_split_kernel<2, 3, 2, 1, false>" : "gemm_nt_split_kernel<2, 3, 2, 0, false>", stream, alg_flops > 0.0 ? alg_flops : 2.0 * M * (double)N * K, 0);
     const dim3 grid(p.nbm * p.nbn), blk(256);
     if (g_split_variant & 16) p.M = 0;                  // (timing experiment: no C stores)
     p.row_major = (g_split_variant & 32) ? 1 : 0;       // (... the first tile order)
@@ -571,7 +572,7 @@ int gemm_nt_split_epi_launch(const void* Ap, const void* Bp, const Epi& E, int M
         E2.act_src = (const float*)valid;
         E2.mask = (const unsigned*)valid;
     }
-    ProfScope prof("gemm_nt_split_kernel[score]", stream, E.alg_flops > 0.0 ? E.alg_flops : 2.0 * M * (double)N * K, 0);
+    ProfScope prof("gemm_nt_split_kernel<2, 3, 2, 2, false>", stream, E.alg_flops > 0.0 ? E.alg_flops : 2.0 * M * (double)N * K, 0);
     // (plain / exp stores straight from the accumulators -- EPI 0 with the exp -- measured SLOWER than the LDS-staged 16-byte row stores:
     //  MAG-CS 200 against 215 G pairs/s)
     hipLaunchKernelGGL((gemm_nt_split_kernel<2, 3, 2, 2>), dim3(p.nbm * p.nbn), dim3(256), 0, stream, p, E2);

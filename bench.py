@@ -976,6 +976,11 @@ def main():
                                           "bilinear matcher (DESIGN 4.9): its three G x D x Kp products run on the 128 query runs -- every output and "
                                           "gradient still produced, all work inside the timed region"),
                        "egonets_per_step_per_gpu": N_QUERIES * (1 + NEG), "avg_edges_per_step_per_gpu": edges / args.steps / world,
+                       "matrix_pipe": "the first layer's projection and weight gradient (and, in the eval extras, the scoring loop and the encoder's two large "
+                                      "products) run on the bf16 MFMA as SIX exact plane products per fp32 product with fp32 accumulation -- every fp32 "
+                                      "operand is the exact sum of three bf16 numbers; results are as close to float64 as an fp32 GEMM's "
+                                      "(DESIGN 4.10, tests/test_gpu_split_gemm.py, tests/test_split_arithmetic.py); step_fp32_mfma_ms = the same "
+                                      "step with those products on the fp32 MFMA; roofline_all prices them against 2.5 PF/s / 6",
                        "settle_steps": SETTLE_STEPS, "sanity": sanity, "routes": routes_timed,
                        "parallelism": f"dp{world}"},
             "roofline_all": roof_all,

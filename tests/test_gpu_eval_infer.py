@@ -238,9 +238,21 @@ def test_bench_two_ranks_sharded_inference_on_one_gpu():
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, out.stdout[-2000:]
+    assert len(lines[0]) < 4096, len(lines[0])
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["parallelism"] == "dp2" and d["value"] > 0
-    ex = d["extra"]
+    # the compact line says which collective transport ran on how many ranks, and carries BASELINE's multi-GPU configs flat:
+    # configs[3] (2-layer MAG-Full step, data-parallel) and configs[2]'s sharded scoring with its all-gather / all-reduce rates
+    assert d["rccl_world"] == 2 and d["collective_backend"] == "gloo"
+    for k in ("step_pgat2_dp_ms", "step_pgat2_dp_edges_per_s", "candidates_scored_per_s_allgather", "candidates_scored_per_s_fused_allreduce",
+              "allgather_gbs_per_rank", "allreduce_counts_queries_per_s"):
+        assert d[k] > 0, k
+    with open(os.path.join(repo, "bench_extra.json")) as f:          # (the full record of the same run; stderr of two ranks may interleave)
+        full = json.load(f)
+    assert full["value"] == d["value"] and full["n_gpus"] == 2
+    ex = full["extra"]
+    assert "error" not in ex and "error" not in ex["step_pgat2_dp"], ex
+    assert "dp2" in ex["step_pgat2_dp"]["workload"] and ex["step_pgat2_dp"]["gradient_bytes_per_rank_per_step"] > 0
     assert "error" not in ex, ex
     assert ex["infer_queries"] == 2048 and ex["candidates_per_rank"] * 2 >= ex["infer_candidates"]
     for k in ("candidates_scored_per_s_local", "candidates_scored_per_s_allgather", "candidates_scored_per_s_fused_allreduce",

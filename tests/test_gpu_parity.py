@@ -939,10 +939,24 @@ def test_bench_contract_line():
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1
-    d = json.loads(lines[0])
+    assert len(lines[0]) < 4096, len(lines[0])          # the driver keeps an 8 KB stdout tail: the whole line must fit well inside it
+    compact = json.loads(lines[0])
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
-              "data", "config", "roofline", "cpu_baseline"):
-        assert k in d, k
+              "data", "config", "roofline", "cpu_baseline", "matrix_pipe", "value_fp32_mfma"):
+        assert k in compact, k
+    assert all(not isinstance(v, (dict, list)) for k in ("roofline", "cpu_baseline") for v in compact[k].values())      # flat objects
+    assert "workload" in compact["config"] and "routes" in compact["config"] and compact["config"]["parallelism"] == "dp1"
+    assert compact["matrix_pipe"].startswith("bf16x3-split") and 0.5 * compact["value"] < compact["value_fp32_mfma"] < 1.2 * compact["value"]
+    # everything else (roofline_all, extras, A/B legs, prose) is in bench_extra.json and on stderr -- the same run's full record
+    full_lines = [ln for ln in out.stderr.splitlines() if ln.startswith("BENCH_FULL ")]
+    assert len(full_lines) == 1
+    d = json.loads(full_lines[0][len("BENCH_FULL "):])
+    with open(os.path.join(repo, "bench_extra.json")) as f:
+        assert json.load(f) == d
+    for k in ("value", "ms_per_step", "steps", "warmup", "n_gpus", "dtype"):
+        assert compact[k] == d[k], k
+    assert abs(compact["roofline"]["frac"] - d["roofline"]["frac"]) < 1e-5 and compact["roofline"]["kernel"] == d["roofline"]["kernel"]
+    assert compact["cpu_baseline"]["cores"] == d["cpu_baseline"]["cores"] and "sample" in compact["cpu_baseline"]
     assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["higher_is_better"] is True and d["scaling"] == "weak"
     assert d["dtype"] == "f32" and d["data"] == "synthetic" and d["vs_baseline"] is None and "workload" in d["config"]
     assert abs(d["value"] - d["config"]["avg_edges_per_step_per_gpu"] / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6

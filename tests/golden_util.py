@@ -58,3 +58,45 @@ def check_grad(z, key, got, rtol, atol):
         flat = got.reshape(-1)
         np.testing.assert_allclose(flat[::int(stride)], z["gradsample:" + key], rtol=rtol, atol=atol, err_msg=key)
         np.testing.assert_allclose(np.abs(flat.astype(np.float64)).sum(), a, rtol=1e-4, err_msg=key)
+
+
+def oracle_gradients_f64(spec, params, graph, x, q, masks=None, with_x=False):
+    """the oracle run in FLOAT64 on a golden case's inputs: {parameter name: gradient} (+ the gradient to the node features) -- the
+    reference every gradient gate is measured against; the fp32 yardstick beside it is the unmodified reference's own golden gradient
+    (or the same oracle in fp32)"""
+    P = {k: torch.from_numpy(v).double().requires_grad_(True) for k, v in params.items()}
+    xc = torch.from_numpy(x).double().requires_grad_(with_x)
+    s, _hg, _hn = orc.taxoexpan_forward(P, graph, xc, torch.from_numpy(q).double(), spec["prop"], spec["readout"], spec["match"],
+                                        spec["heads"], spec["num_layers"], masks)
+    orc.info_nce_loss(s, spec["n_queries"]).backward()
+    return {k: p.grad.numpy() for k, p in P.items()}, (xc.grad.numpy() if with_x else None)
+
+
+def gradient_scale_floor(g64):
+    """1e-3 of the largest gradient entry of the whole model: a tensor whose exact gradient is (nearly) zero -- attn_r of a one-head
+    output layer: a constant added to every in-edge of a destination leaves its softmax unchanged -- is judged on that scale, not its own"""
+    return 1e-3 * max(float(np.abs(np.asarray(v)).max()) for v in g64.values())
+
+
+def gate_against_f64(got, ref64, yard, what, errors, report=None, factor=1.5, floor=1e-5, cap=1e-4, scale_floor=0.0):
+    """the north star's "within 1e-4 fp32" for a gradient tensor: max |got - f64| <= factor x max |yardstick - f64| (the device is no
+    further from the exact gradient than fp32 arithmetic in another summation order -- `yard` is the reference's own fp32 result or the
+    fp32 oracle's), floored at `floor` x max |f64| (a tensor the yardstick happens to get to 1e-7 must not fail the device at 2e-7), and
+    never more than `cap` x max |f64|"""
+    got, ref64, yard = (np.asarray(a, dtype=np.float64) for a in (got, ref64, yard))
+    assert got.shape == ref64.shape == yard.shape, (what, got.shape, ref64.shape, yard.shape)
+    scale = max(float(np.abs(ref64).max()), scale_floor) or 1.0
+    e_got, e_yard = float(np.abs(got - ref64).max()), float(np.abs(yard - ref64).max())
+    if report is not None:
+        report.append((what, e_got / scale, e_yard / scale))
+    if not (e_got <= max(factor * e_yard, floor * scale) and e_got <= cap * scale):
+        errors.append(f"{what}: max |HIP - f64| = {e_got / scale:.3e} of max |ref|; the fp32 yardstick's is {e_yard / scale:.3e}")
+
+
+def golden_grad_entries(z, key, *arrays):
+    """the entries of a parameter gradient a golden file holds (all of them, or every stride-th): (golden values, the same entries of
+    each of `arrays`)"""
+    if "grad:" + key in z:
+        return z["grad:" + key], [np.asarray(a) for a in arrays]
+    stride = int(z["gradstats:" + key][2])
+    return z["gradsample:" + key], [np.asarray(a).reshape(-1)[::stride] for a in arrays]

@@ -10,8 +10,7 @@
  *     (a hipStream_t passed as void*);  workspaces are supplied by the caller (size from the *_ws_bytes functions)
  *   - return value: 0 = TXE_OK, <0 = error (TXE_ERR_ARG -1, TXE_ERR_LAUNCH -2, TXE_ERR_WORKSPACE -3); never throws
  *   - re-entrant; no state between calls except the optional per-launch profiler (txe_profile_*, off by default: a process-global
- *     switch and a per-device ring of events), the cached CU count of the current device and the tuning hook txe_gemm_split_variant
- *     (a process-global int the library itself never sets)
+ *     switch and a per-device ring of events) and the cached CU count of the current device
  *   - graph structure: destination-sorted CSR  (rowptr_in[N+1], col_src[E])  and source-sorted CSR
  *     (rowptr_out[N+1], col_dst[E], pos_out[E] = index of that edge in the destination-sorted order); per-edge
  *     arrays (alpha, dz) live in destination-sorted order
@@ -461,9 +460,6 @@ int txe_adam_step(int n_tensors, float* const* params, const float* const* grads
 size_t txe_split_packed_bytes(int rows, int cols);
 int txe_split_pack(const float* src, long long ld, int rows, int cols, int side, void* packed, void* stream);   /* side 2 / 3: side 0 / 1 of
     a matrix given as its transpose, src [cols][ld >= rows] */
-int txe_gemm_split_variant(int v);   /* tuning hook (tools/split_gemm_probe.py): tile / stage variant of the products launched after it
-                                       * (bit 128: the plain NT product sums a k-tile's small plane products apart -- more accurate, +13 % time);
-                                       * PROCESS-GLOBAL state, not thread-safe, default 0 -- the library itself never calls it */
 int txe_gemm_nt_split(const void* A_packed, const void* B_packed, int M, int N, int K, float* C, long long ldc, void* stream);
 
 /* The TN form (weight gradients, model_zoo.py:83 backward: dW = d_Y^T X over the nodes): part[z][M][ldc] = A[rows of slice z]^T B[same rows],

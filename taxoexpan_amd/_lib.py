@@ -118,7 +118,6 @@ SIGNATURES = {
     "txe_copy_stream": (I, [P, P, L, P]),
     "txe_split_packed_bytes": (SZ, [I, I]),
     "txe_split_pack": (I, [P, L, I, I, I, P, P]),
-    "txe_gemm_split_variant": (I, [I]),
     "txe_split_packed_t_bytes": (SZ, [I, I]),
     "txe_split_pack_t": (I, [P, L, I, I, P, P]),
     "txe_gemm_tn_split": (I, [P, L, I, P, I, I, I, I, P, L, L, P]),

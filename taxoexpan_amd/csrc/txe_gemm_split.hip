@@ -59,7 +59,7 @@ struct SplitGemm {
     const char* A; const char* B;     // packed operands
     int nkt;                          // k-tiles of 16
     float* C; long long ldc; int M, N;
-    int nbm, nbn, row_major, apply_exp;
+    int nbm, nbn, apply_exp;
     // epilogue extras (EPI kernels; txe_gemm.h epi_store_one): C = acc * (keep bit ? drop_scale : 0) * (act_src > 0 || column >= cols_act ? 1 : slope)
     const unsigned* mask; int mask_ld, mask_col0, mask_on; float drop_scale;
     const float* act_src; long long ld_act; float act_slope; int act_on, cols_act;
@@ -67,9 +67,7 @@ struct SplitGemm {
 
 // EPI: 0 = plain stores from the accumulators; 1 = the same with the dropout-mask / activation factors; 2 = the tile goes through LDS into
 // gemm_kernel's own epilogue (txe_gemm.h gemm_tile_epilogue: exp, pick, count and best-k modes -- the scoring loop), E = its arguments
-// TMP: a k-tile's five small plane products are summed in a fresh accumulator (C = 0) and added to the running sum once -- two roundings per
-// k-tile instead of six (DESIGN 4.10 "One accumulator or two": error below torch.mm's fp32 on every probe shape, +13 % time)
-template <int MI, int NST, int MINB, int EPI = 0, bool TMP = false>
+template <int MI, int NST, int MINB, int EPI = 0>
 __global__ __launch_bounds__(256, MINB) void gemm_nt_split_kernel(const SplitGemm p, const Epi E) {
     constexpr int NA = 2 * MI, NB = 4;                      // A / B fragment blocks per tile
     constexpr int NF = 3 * (NA + NB), CP = (NF + 3) / 4;    // fragments per stage, copies per wave and k-tile (the last wave: the rest)
@@ -87,8 +85,7 @@ __global__ __launch_bounds__(256, MINB) void gemm_nt_split_kernel(const SplitGem
     // 16-tile-wide B (2 MB of planes at K = 320) and 8 A panels (2 MB): its 4 MB L2 holds them, where 4 panels x all 16 column tiles
     // (row-major order) cycled 4.9 MB through it (FETCH_SIZE 304 MB per launch for 38 MB of operands)
     int tm, tn;
-    if (p.row_major) { tm = lb / p.nbn; tn = lb % p.nbn; }
-    else {
+    {
         constexpr int GM = 16, GN = 8;
         const int srt = GM * p.nbn, sr = lb / srt, rem = lb - sr * srt;
         const int hgt = min(GM, p.nbm - sr * GM);
@@ -152,23 +149,8 @@ __global__ __launch_bounds__(256, MINB) void gemm_nt_split_kernel(const SplitGem
     _Pragma("unroll") for (int i = 0; i < MI; ++i)                                                                   \
         _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                                \
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][pa_], fb[j][pb_], acc[i][j], 0, 0, 0);
-#define TXE_SP_MFMAT(pa_, pb_)                                                                                        \
-    _Pragma("unroll") for (int i = 0; i < MI; ++i)                                                                   \
-        _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                                \
-            tmp[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][pa_], fb[j][pb_], tmp[i][j], 0, 0, 0);
 #define TXE_SP_PRODUCTS()                                                                                             \
-    if constexpr (TMP) {                                                                                             \
-        f32x16s tmp[MI][2];                                                                                          \
-        _Pragma("unroll") for (int i = 0; i < MI; ++i)                                                               \
-            _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                            \
-                _Pragma("unroll") for (int e = 0; e < 16; ++e) tmp[i][j][e] = 0.f;                                   \
-        TXE_SP_MFMAT(2, 0) TXE_SP_MFMAT(0, 2) TXE_SP_MFMAT(1, 1) TXE_SP_MFMAT(1, 0) TXE_SP_MFMAT(0, 1) TXE_SP_MFMA(0, 0) \
-        _Pragma("unroll") for (int i = 0; i < MI; ++i)                                                               \
-            _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                            \
-                _Pragma("unroll") for (int e = 0; e < 16; ++e) acc[i][j][e] += tmp[i][j][e];                         \
-    } else {                                                                                                         \
-        TXE_SP_MFMA(2, 0) TXE_SP_MFMA(0, 2) TXE_SP_MFMA(1, 1) TXE_SP_MFMA(1, 0) TXE_SP_MFMA(0, 1) TXE_SP_MFMA(0, 0)  \
-    }
+    TXE_SP_MFMA(2, 0) TXE_SP_MFMA(0, 2) TXE_SP_MFMA(1, 1) TXE_SP_MFMA(1, 0) TXE_SP_MFMA(0, 1) TXE_SP_MFMA(0, 0)
 #define TXE_SP_COMPUTE(st_)                                                                                           \
     {                                                                                                                \
         bf16x8 fa[MI][3], fb[2][3];                                                                                  \
@@ -222,7 +204,6 @@ __global__ __launch_bounds__(256, MINB) void gemm_nt_split_kernel(const SplitGem
 #undef TXE_SP_COMPUTE
 #undef TXE_SP_MFMA
 #undef TXE_SP_PRODUCTS
-#undef TXE_SP_MFMAT
 #undef TXE_SP_ISSUE
 #undef TXE_SP_COPY
 
@@ -472,8 +453,6 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_split_kernel(const SplitTn p) 
     }
 }
 
-int g_split_variant = 0;
-
 static bool fill_pack(SplitPackArgs& a, int& nb, const float* src, long long ld, int rows, int cols, int side, void* packed) {
     const int tr = side >> 1;                             // sides 2, 3 = sides 0, 1 of a matrix given as its transpose [cols][ld >= rows]
     if (!src || !packed || rows < 1 || cols < 1 || ld < (tr ? rows : cols) || side < 0 || side > 3) return false;
@@ -521,39 +500,20 @@ int gemm_nt_split_launch(const void* Ap, const void* Bp, int M, int N, int K, fl
     memset(&p, 0, sizeof(p));
     p.A = (const char*)Ap; p.B = (const char*)Bp; p.nkt = (K + SPL_KT - 1) / SPL_KT;
     p.C = C; p.ldc = ldc; p.M = M; p.N = N;
-    const int v = g_split_variant & 15;
-    const int bm = (v == 2 || v == 3) ? 256 : (v == 5 ? 192 : 128);
-    p.nbm = (M + bm - 1) / bm; p.nbn = (N + SPL_BN - 1) / SPL_BN;
-    const Epi E0 = epi_plain(C, ldc, N);                // (unused by these variants)
+    p.nbm = (M + 127) / 128; p.nbn = (N + SPL_BN - 1) / SPL_BN;
+    const Epi E0 = epi_plain(C, ldc, N);                // (unused by the EPI 0 / 1 instantiations)
     // (named as rocprofv3 prints the default instantiations: bench.py joins its HIP-event timings with the committed profiles by name)
-    ProfScope prof(epi ? "gemm_nt_split_kernel<2, 3, 2, 1, false>" : "gemm_nt_split_kernel<2, 3, 2, 0, false>", stream, alg_flops > 0.0 ? alg_flops : 2.0 * M * (double)N * K, 0);
+    ProfScope prof(epi ? "gemm_nt_split_kernel<2, 3, 2, 1>" : "gemm_nt_split_kernel<2, 3, 2, 0>", stream, alg_flops > 0.0 ? alg_flops : 2.0 * M * (double)N * K, 0);
     const dim3 grid(p.nbm * p.nbn), blk(256);
-    if (g_split_variant & 16) p.M = 0;                  // (timing experiment: no C stores)
-    p.row_major = (g_split_variant & 32) ? 1 : 0;       // (... the first tile order)
     if (epi) {
         p.mask = epi->mask; p.mask_ld = epi->mask_ld; p.mask_col0 = epi->mask_col0; p.mask_on = epi->mask ? 1 : 0;
         p.drop_scale = epi->drop_scale;
         p.act_src = epi->act_src; p.ld_act = epi->ld_act; p.act_slope = epi->act_slope; p.act_on = epi->act_src ? 1 : 0; p.cols_act = epi->cols_act;
-        p.nbm = (M + 127) / 128;
-        hipLaunchKernelGGL((gemm_nt_split_kernel<2, 3, 2, 1>), dim3(p.nbm * p.nbn), blk, 0, stream, p, E0);
+        hipLaunchKernelGGL((gemm_nt_split_kernel<2, 3, 2, 1>), grid, blk, 0, stream, p, E0);
         TXE_CHECK_LAUNCH();
         return TXE_OK;
     }
-    if (g_split_variant & 64) {                          // (experiment: C through the LDS-staged 16-byte row stores of gemm_tile_epilogue)
-        Epi E1 = E0;
-        E1.act_src = C; E1.mask = (const unsigned*)C;
-        hipLaunchKernelGGL((gemm_nt_split_kernel<2, 3, 2, 2>), dim3(((M + 127) / 128) * p.nbn), blk, 0, stream, p, E1);
-        TXE_CHECK_LAUNCH();
-        return TXE_OK;
-    }
-    if (v == 0 && (g_split_variant & 128)) hipLaunchKernelGGL((gemm_nt_split_kernel<2, 3, 2, 0, true>), grid, blk, 0, stream, p, E0);
-    else if (v == 0) hipLaunchKernelGGL((gemm_nt_split_kernel<2, 3, 2>), grid, blk, 0, stream, p, E0);
-    else if (v == 1) hipLaunchKernelGGL((gemm_nt_split_kernel<2, 2, 3>), grid, blk, 0, stream, p, E0);
-    else if (v == 2) hipLaunchKernelGGL((gemm_nt_split_kernel<4, 2, 2>), grid, blk, 0, stream, p, E0);
-    else if (v == 3) hipLaunchKernelGGL((gemm_nt_split_kernel<4, 3, 1>), grid, blk, 0, stream, p, E0);
-    else if (v == 4) hipLaunchKernelGGL((gemm_nt_split_kernel<2, 2, 2>), grid, blk, 0, stream, p, E0);
-    else if (v == 5) hipLaunchKernelGGL((gemm_nt_split_kernel<3, 2, 2>), grid, blk, 0, stream, p, E0);
-    else return TXE_ERR_ARG;
+    hipLaunchKernelGGL((gemm_nt_split_kernel<2, 3, 2>), grid, blk, 0, stream, p, E0);
     TXE_CHECK_LAUNCH();
     return TXE_OK;
 }
@@ -572,7 +532,7 @@ int gemm_nt_split_epi_launch(const void* Ap, const void* Bp, const Epi& E, int M
         E2.act_src = (const float*)valid;
         E2.mask = (const unsigned*)valid;
     }
-    ProfScope prof("gemm_nt_split_kernel<2, 3, 2, 2, false>", stream, E.alg_flops > 0.0 ? E.alg_flops : 2.0 * M * (double)N * K, 0);
+    ProfScope prof("gemm_nt_split_kernel<2, 3, 2, 2>", stream, E.alg_flops > 0.0 ? E.alg_flops : 2.0 * M * (double)N * K, 0);
     // (plain / exp stores straight from the accumulators -- EPI 0 with the exp -- measured SLOWER than the LDS-staged 16-byte row stores:
     //  MAG-CS 200 against 215 G pairs/s)
     hipLaunchKernelGGL((gemm_nt_split_kernel<2, 3, 2, 2>), dim3(p.nbm * p.nbn), dim3(256), 0, stream, p, E2);
@@ -614,8 +574,6 @@ size_t txe_split_packed_bytes(int rows, int cols) { return (rows < 1 || cols < 1
 int txe_split_pack(const float* src, long long ld, int rows, int cols, int side, void* packed, void* stream) {
     return split_pack_launch(src, ld, rows, cols, side, packed, (hipStream_t)stream);
 }
-
-int txe_gemm_split_variant(int v) { g_split_variant = v; return TXE_OK; }
 
 int txe_gemm_nt_split(const void* Ap, const void* Bp, int M, int N, int K, float* C, long long ldc, void* stream) {
     return gemm_nt_split_launch(Ap, Bp, M, N, K, C, ldc, 0.0, (hipStream_t)stream, nullptr);

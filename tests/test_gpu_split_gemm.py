@@ -248,30 +248,3 @@ def test_bilinear_projection_on_the_split_route():
     scale = (hg.double().abs() @ W.double().abs()).clamp_min(1e-300)
     e_split, e_f32 = _err(outs[0], ref, scale), _err(outs[1], ref, scale)
     assert e_split <= max(1.5 * e_f32, ABS_FLOOR), (e_split, e_f32)
-
-
-def test_small_products_in_their_own_accumulator_variant():
-    """txe_gemm_split_variant(128): a k-tile's five small plane products summed apart -- at least as accurate as the default on the
-    same operands, and inside the fp32 band"""
-    from taxoexpan_amd import _lib
-    dev = _dev()
-    g = torch.Generator().manual_seed(9)
-    M, N, K = 700, 260, 300
-    A, B = torch.randn(M, K, generator=g).to(dev), (torch.randn(N, K, generator=g) * 0.1).to(dev)
-    s = _lib.stream_ptr()
-    Ap = torch.empty(_lib.call("txe_split_packed_bytes", M, K), dtype=torch.uint8, device=dev)
-    Bp = torch.empty(_lib.call("txe_split_packed_bytes", N, K), dtype=torch.uint8, device=dev)
-    _lib.call("txe_split_pack", A.data_ptr(), K, M, K, 0, Ap.data_ptr(), s)
-    _lib.call("txe_split_pack", B.data_ptr(), K, N, K, 1, Bp.data_ptr(), s)
-    ref = A.double() @ B.double().t()
-    errs = {}
-    try:
-        for v in (0, 128):
-            _lib.call("txe_gemm_split_variant", v)
-            C = torch.full((M, N), float("nan"), device=dev)
-            _lib.call("txe_gemm_nt_split", Ap.data_ptr(), Bp.data_ptr(), M, N, K, C.data_ptr(), N, s)
-            torch.cuda.synchronize()
-            errs[v] = ((C.double() - ref).norm() / ref.norm()).item()
-    finally:
-        _lib.call("txe_gemm_split_variant", 0)
-    assert errs[128] <= errs[0] * 1.05 and errs[128] < 3e-7, errs

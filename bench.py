@@ -40,6 +40,11 @@ sys.path.insert(0, REPO)
 MAG = dict(in_dim=250, hidden_dim=500, out_dim=500, pos_dim=50, num_layers=1, heads=[4, 1], feat_drop=0.1, attn_drop=0.1,
            hidden_drop=0.1, out_drop=0.1)
 N_QUERIES, NEG = 128, 31
+# config.mag.json:66-73 trains with lr 1e-3 -- on real embeddings.  On the synthetic random-embedding taxonomy that rate drives the LBM's
+# exp scores to overflow: loss 1e13 by step ~200 and NaN parameters by step ~240-300 (tools/ measurement, rounds 1-5 timed such steps
+# unknowingly: the step's work does not depend on the values).  1e-4 trains the same model stably (loss 455 -> 79 over 4,000 steps); every
+# timed model is checked finite at the end (assert_finite) so that a diverged run can never be reported as a number.
+LR = 1e-4
 PEAK_MFMA_F32 = 157.3e12      # MI355X_MICROARCH.md: fp32 MFMA = fp32 vector peak, no TF32 on gfx950
 PEAK_MFMA_BF16 = 2.5e15       # ... dense bf16 MFMA
 SPLIT_PRODUCTS = 6            # csrc/txe_gemm_split.h: an fp32 product = six bf16 plane products (fp32-accurate) -> roof 2.5 PF / 6 per fp32 flop
@@ -162,6 +167,14 @@ def train_step(model, opt, batch, target, world, loss_fn=None):
         loss.backward()                                                  # trainer.py:60
     opt.step()                                                       # trainer.py:61
     return loss
+
+
+def assert_finite(model, loss, what):
+    """the timed steps trained a model whose loss and parameters are still finite (a diverged run times something else -- and, with
+    non-finite operands, the bf16-pipe products recompute their tiles in fp32: csrc/txe_gemm_split.h)"""
+    ok = bool(torch.isfinite(loss.detach()).all()) and all(bool(torch.isfinite(p).all()) for p in model.parameters())
+    assert ok, f"{what}: the model diverged (non-finite loss or parameters) -- the timing is void"
+    return float(loss.detach())
 
 
 SETTLE_STEPS = 256        # untimed steps before the contract's --warmup (reported as config.settle_steps)
@@ -560,7 +573,7 @@ def variant_step(workload, tax, device, steps=10, reps=5):
     from taxoexpan_amd.optim import Adam
     torch.manual_seed(47)
     model = make_model(workload, device)
-    opt = Adam(model.parameters(), lr=1e-3, weight_decay=0, amsgrad=True)
+    opt = Adam(model.parameters(), lr=LR, weight_decay=0, amsgrad=True)
     batches = build_batches(tax, 2, seed0=1000, device=device)
     target = torch.zeros(N_QUERIES, dtype=torch.long, device=device)
     it = iter(range(10 ** 9))
@@ -568,6 +581,7 @@ def variant_step(workload, tax, device, steps=10, reps=5):
     def one():
         train_step(model, opt, batches[next(it) % 2], target, 1)
     dt = median_time(one, reps=reps, inner=steps, warm=5)
+    assert_finite(model, train_step(model, opt, batches[0], target, 1), workload)
     edges = float(np.mean([b["n_edges"] for b in batches]))
     recs = [profile_step(model, opt, b, target) for b in batches]
     roof = summarize_profile(recs, [b["n_edges"] for b in batches], [b["n_nodes"] for b in batches], workload=workload)
@@ -619,7 +633,7 @@ def dp_step_pgat2(device, world, rank, tax_full, steps=10, reps=3):
     model = make_model("pgat2", device)
     for p in model.parameters():
         dist.broadcast(p.data, src=0)
-    opt = Adam(model.parameters(), lr=1e-3, weight_decay=0, amsgrad=True)
+    opt = Adam(model.parameters(), lr=LR, weight_decay=0, amsgrad=True)
     batches = build_batches(tax_full, 2, seed0=7000 + 1000 * rank, device=device)
     target = torch.zeros(N_QUERIES, dtype=torch.long, device=device)
     for i in range(5):
@@ -632,6 +646,7 @@ def dp_step_pgat2(device, world, rank, tax_full, steps=10, reps=3):
             train_step(model, opt, batches[i % 2], target, world)
         torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
         ts.append((time.perf_counter() - t0) / steps)
+    assert_finite(model, train_step(model, opt, batches[0], target, world), "pgat2 dp")
     t = torch.tensor(ts, dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.median().item())
@@ -756,7 +771,7 @@ def compact_line(full):
     if full.get("step_fp32_mfma_ms"):
         line["value_fp32_mfma"] = full["value"] * full["ms_per_step"] / full["step_fp32_mfma_ms"]
     line["config"] = {k: c[k] for k in ("workload", "egonets_per_step_per_gpu", "avg_edges_per_step_per_gpu", "parallelism", "routes",
-                                        "settle_steps") if k in c}
+                                        "settle_steps", "lr", "final_loss") if k in c}
     line["roofline"] = {k: r[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "avg_us", "work_per_launch",
                                           "hbm_kernel", "hbm_frac", "hbm_avg_us", "hbm_achieved_gbs", "hbm_traffic_ratio",
                                           "hbm_frac_of_copy_ceiling", "copy_ceiling_gbs", "hbm_aggregate_fwd_frac", "hbm_fused_bwd_frac",
@@ -844,7 +859,7 @@ def main():
         for p in model.parameters():
             dist.broadcast(p.data, src=0)
     from taxoexpan_amd.optim import Adam          # torch.optim.Adam's update (config.mag.json:66-73) as one HIP launch
-    opt = Adam(model.parameters(), lr=1e-3, weight_decay=0, amsgrad=True)
+    opt = Adam(model.parameters(), lr=LR, weight_decay=0, amsgrad=True)
     batches = build_batches(tax, 4, seed0=1000 * (rank + 1), device=device)
     target = torch.zeros(N_QUERIES, dtype=torch.long, device=device)
     sanity = route_sanity(model, batches[0], target)       # before anything is timed: the step's loss is finite and route-independent
@@ -871,13 +886,14 @@ def main():
     edges = 0
     for i in range(args.steps):
         b = batches[i % len(batches)]
-        train_step(model, opt, b, target, world)
+        last_loss = train_step(model, opt, b, target, world)
         edges += b["n_edges"]
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    final_loss = assert_finite(model, last_loss, "timed steps")
     from taxoexpan_amd import ops as _ops_r
     routes_timed = {k: _ops_r.ROUTES.get(k) for k in ("match", "stack", "fold", "stack_bwd")}     # the routes the timed steps took
     if world > 1:
@@ -939,18 +955,18 @@ def main():
         torch.autograd.set_multithreading_enabled(True)
         ab["step_default_autograd_ms"] = timed(opt)
         torch.autograd.set_multithreading_enabled(False)
-        ab["step_torch_adam_ms"] = timed(torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=0, amsgrad=True))
+        ab["step_torch_adam_ms"] = timed(torch.optim.Adam(model.parameters(), lr=LR, weight_decay=0, amsgrad=True))
         ab["step_torch_loss_ms"] = timed(opt, lambda out, tgt: F.cross_entropy(out, tgt, reduction="sum"))
         torch.autograd.set_multithreading_enabled(True)
-        ab["step_reference_caller_ms"] = timed(torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=0, amsgrad=True),
+        ab["step_reference_caller_ms"] = timed(torch.optim.Adam(model.parameters(), lr=LR, weight_decay=0, amsgrad=True),
                                                lambda out, tgt: F.cross_entropy(out, tgt, reduction="sum"))     # all three as train.py has them
         torch.autograd.set_multithreading_enabled(False)
         # ... and with ONE key added to the reference's config JSON ("optimizer": {"args": {..., "fused": true}}, train.py builds the
         # optimizer from it): torch's own single-launch Adam
         try:
-            ab["step_torch_adam_fused_ms"] = timed(torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=0, amsgrad=True, fused=True))
+            ab["step_torch_adam_fused_ms"] = timed(torch.optim.Adam(model.parameters(), lr=LR, weight_decay=0, amsgrad=True, fused=True))
             torch.autograd.set_multithreading_enabled(True)
-            ab["step_reference_caller_fused_adam_ms"] = timed(torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=0, amsgrad=True, fused=True),
+            ab["step_reference_caller_fused_adam_ms"] = timed(torch.optim.Adam(model.parameters(), lr=LR, weight_decay=0, amsgrad=True, fused=True),
                                                               lambda out, tgt: F.cross_entropy(out, tgt, reduction="sum"))
         except (RuntimeError, TypeError, ValueError) as e:       # (a torch build without the fused implementation)
             ab["step_torch_adam_fused_ms"] = None
@@ -992,6 +1008,7 @@ def main():
     torch.cuda.synchronize()
     build_ms = 1e3 * (time.perf_counter() - tb0) / max(n_fresh, 1)
 
+    assert_finite(model, train_step(model, opt, batches[0], target, world), "after the A/B and fresh-batch legs")
     roof_all, cpu, extra = None, None, None
     if rank == 0:
         # instrumented steps (HIP events around every launch, on the launch stream) at the clocks of the timed region: a few plain
@@ -1097,7 +1114,7 @@ def main():
                                       "operand is the exact sum of three bf16 numbers; results are as close to float64 as an fp32 GEMM's "
                                       "(DESIGN 4.10, tests/test_gpu_split_gemm.py, tests/test_split_arithmetic.py); step_fp32_mfma_ms = the same "
                                       "step with those products on the fp32 MFMA; roofline_all prices them against 2.5 PF/s / 6",
-                       "settle_steps": SETTLE_STEPS, "sanity": sanity, "routes": routes_timed,
+                       "settle_steps": SETTLE_STEPS, "sanity": sanity, "routes": routes_timed, "lr": LR, "final_loss": final_loss,
                        "parallelism": f"dp{world}"},
             "roofline_all": roof_all,
             "extra": extra,

@@ -455,8 +455,12 @@ int txe_adam_step(int n_tensors, float* const* params, const float* const* grads
  * layer's projection).  A packed operand holds every fp32 element as the EXACT sum of three bf16 numbers (three planes, stored as 1-KB
  * MFMA fragments: csrc/txe_gemm_split.h); txe_gemm_nt_split forms C [M][N] = A [M][K] B[N][K]^T from six of the nine plane products with
  * fp32 accumulation -- the dropped terms are a quarter of an fp32 multiply's own rounding error in the root mean square (at most twice it).
- * side 0 = the operand whose rows are C's rows, side 1 = the operand whose rows are C's columns.  An operand element that is +-Inf gives
- * NaN where an fp32 product gives +-Inf (Inf - Inf in the split); NaN stays NaN. */
+ * side 0 = the operand whose rows are C's rows, side 1 = the operand whose rows are C's columns.
+ * The whole fp32 domain is covered (csrc/txe_gemm_split.h): a packed fragment that holds +-Inf, NaN or |x| >= 2^120 is stored raw with a
+ * NaN marker plane, the product kernels check their accumulators after the k-loop and a tile that is not finite recomputes itself with fp32
+ * FMAs over the exactly decoded operands -- the same entries are NaN / +Inf / -Inf as in an IEEE fp32 product (tests/test_gpu_split_gemm.py
+ * *_on_the_whole_fp32_domain), at scalar speed for those tiles only.  Nonzero |x| < 2^-100 is carried to 2^-126 ABSOLUTE (flush-to-zero
+ * semantics, as GPU fp32 units treat subnormals: such elements are routine in gradients and stay on the fast path). */
 size_t txe_split_packed_bytes(int rows, int cols);
 int txe_split_pack(const float* src, long long ld, int rows, int cols, int side, void* packed, void* stream);   /* side 2 / 3: side 0 / 1 of
     a matrix given as its transpose, src [cols][ld >= rows] */

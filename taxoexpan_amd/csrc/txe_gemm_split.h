@@ -49,12 +49,66 @@ __device__ __forceinline__ void split3x2(float x0, float x1, unsigned& w1, unsig
     const float q0 = r0 - __uint_as_float(w2 << 16), q1 = r1 - __uint_as_float(w2 & 0xffff0000u);
     w3 = pk_bf16(q0, q1);
 }
+// ---- the whole fp32 domain ---------------------------------------------------------------------------------------------------------
+// The three-plane form is exact for |x| < 2^120 down to 2^-100 (every plane a normal bf16 number or zero).  Above that -- +-Inf, NaN,
+// |x| >= 2^120 (x1 may round to Inf, and Inf - Inf poisons the residuals) -- an element is EXCEPTIONAL, and a packed fragment (32 slots x
+// 16 contraction columns) that holds one is stored RAW instead: plane 1 = the high halves of the fp32 words, plane 2 = the low halves,
+// plane 3 = 0x7FC0 (a bf16 NaN) in every element.  The NaN plane poisons every accumulator the fragment touches, the product kernels look
+// at their accumulators once after the k-loop (anything not finite), and a tile that finds one recomputes itself with fp32 FMAs over
+// operands decoded back to their exact fp32 values (split_decode8): IEEE results -- Inf stays Inf, Inf * 0 and Inf - Inf are NaN, a NaN
+// stays in its row / column -- at scalar speed, for such tiles only.  (A tile whose exact result overflows recomputes itself too and
+// arrives at the same Inf.)  The TN product's fp32 operand is split in its loader: Inf / NaN / beyond-bf16 elements poison its accumulators
+// by themselves (Inf - Inf in the residual).
+// Below 2^-100 the lower planes sink towards bf16's smallest numbers: a nonzero |x| < 2^-100 is carried with an ABSOLUTE error of at most
+// 2^-126 (FLT_MIN) instead of fp32's relative 2^-24 -- what a flush-to-zero fp32 unit does to subnormals, extended to 2^-100.  Such
+// elements are ordinary in gradients (softmax tails: alpha ~ e^-90), so they must not leave the fast path; their products are below
+// 2^-100 |b| and matter to a result only when every other term of the dot product is that small too.
+constexpr unsigned SPL_RAW_MARK = 0x7FC07FC0u;
+__device__ __forceinline__ bool split_exceptional(float x) {
+    return (__float_as_uint(x) & 0x7fffffffu) >= (247u << 23);      // |x| >= 2^120 (exponent field 247), Inf, NaN
+}
+__device__ __forceinline__ void split_raw2(float x0, float x1, unsigned& w1, unsigned& w2, unsigned& w3) {
+    const unsigned b0 = __float_as_uint(x0), b1 = __float_as_uint(x1);
+    w1 = (b0 >> 16) | (b1 & 0xffff0000u);
+    w2 = (b0 & 0xffffu) | (b1 << 16);
+    w3 = SPL_RAW_MARK;
+}
+// a lane word of each plane -> the eight fp32 values it stands for (exact: the planes' sum, or the raw halves of a marked fragment)
+__device__ __forceinline__ void split_decode8(const uint4& w1, const uint4& w2, const uint4& w3, float (&x)[8]) {
+    const unsigned a[4] = {w1.x, w1.y, w1.z, w1.w}, b[4] = {w2.x, w2.y, w2.z, w2.w}, c[4] = {w3.x, w3.y, w3.z, w3.w};
+    const bool raw = c[0] == SPL_RAW_MARK;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if (raw) {
+            x[2 * i] = __uint_as_float((a[i] << 16) | (b[i] & 0xffffu));
+            x[2 * i + 1] = __uint_as_float((a[i] & 0xffff0000u) | (b[i] >> 16));
+        } else {
+            x[2 * i] = (__uint_as_float(a[i] << 16) + __uint_as_float(b[i] << 16)) + __uint_as_float(c[i] << 16);
+            x[2 * i + 1] = (__uint_as_float(a[i] & 0xffff0000u) + __uint_as_float(b[i] & 0xffff0000u)) + __uint_as_float(c[i] & 0xffff0000u);
+        }
+    }
+}
+__device__ __forceinline__ bool not_finite(float v) { return (__float_as_uint(v) & 0x7f800000u) == 0x7f800000u; }
+
 // eight consecutive contraction elements of one row / column -> the three planes' 16-byte lane words
 __device__ __forceinline__ void split3x8(const float (&x)[8], uint4& w1, uint4& w2, uint4& w3) {
     split3x2(x[0], x[1], w1.x, w2.x, w3.x);
     split3x2(x[2], x[3], w1.y, w2.y, w3.y);
     split3x2(x[4], x[5], w1.z, w2.z, w3.z);
     split3x2(x[6], x[7], w1.w, w2.w, w3.w);
+}
+// ... of a fragment that holds an exceptional element: raw halves + the NaN plane
+__device__ __forceinline__ void split_raw8(const float (&x)[8], uint4& w1, uint4& w2, uint4& w3) {
+    split_raw2(x[0], x[1], w1.x, w2.x, w3.x);
+    split_raw2(x[2], x[3], w1.y, w2.y, w3.y);
+    split_raw2(x[4], x[5], w1.z, w2.z, w3.z);
+    split_raw2(x[6], x[7], w1.w, w2.w, w3.w);
+}
+__device__ __forceinline__ bool split_exceptional8(const float (&x)[8]) {
+    bool bad = false;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) bad |= split_exceptional(x[q]);
+    return bad;
 }
 __device__ __forceinline__ void split3x4(const float (&x)[4], uint2& w1, uint2& w2, uint2& w3) {
     split3x2(x[0], x[1], w1.x, w2.x, w3.x);

@@ -44,7 +44,8 @@ __device__ __forceinline__ void split_pack_job(const SplitPackArgs& a, const int
             }
         }
         uint4 w1, w2, w3;
-        split3x8(x, w1, w2, w3);
+        if (__ballot(split_exceptional8(x)) != 0ull) split_raw8(x, w1, w2, w3);      // (a wave = one fragment: txe_gemm_split.h "the whole fp32 domain")
+        else split3x8(x, w1, w2, w3);
         uint4* o = dst + f * 3 * 64 + l;
         o[0] = w1; o[64] = w2; o[128] = w3;
     }
@@ -64,6 +65,34 @@ struct SplitGemm {
     const unsigned* mask; int mask_ld, mask_col0, mask_on; float drop_scale;
     const float* act_src; long long ld_act; float act_slope; int act_on, cols_act;
 };
+
+// A tile that saw an exceptional fragment (or whose result is not finite) recomputes itself: C tile [64 MI][128] into LDS (the stage ring
+// is free after the k-loop), every output an fp32 FMA chain in ascending k over operands decoded from the packed form -- exact fp32
+// values, IEEE arithmetic (txe_gemm_split.h "the whole fp32 domain").  Scalar speed and deliberately small code: thread t owns column
+// t & 127 and every second row; it re-reads both operands' lane words from global memory (L2) for every output and half k-tile.
+template <int MI>
+__device__ __forceinline__ void gemm_nt_split_slow_tile(const char* __restrict__ A, const char* __restrict__ B, const int nkt, const int tm,
+                                                        const int tn, float* __restrict__ Cs) {
+    constexpr int NA = 2 * MI, NB = 4;
+    const int c = threadIdx.x & 127;
+    const uint4* fb0 = reinterpret_cast<const uint4*>(B + ((long long)(NB * tn + 2 * (c >> 6) + (c & 1)) * nkt * 3) * SPL_FRAG_BYTES) + ((c & 63) >> 1);
+#pragma unroll 1
+    for (int r = threadIdx.x >> 7; r < 64 * MI; r += 2) {
+        const uint4* fa0 = reinterpret_cast<const uint4*>(A + ((long long)(NA * tm + (r >> 5)) * nkt * 3) * SPL_FRAG_BYTES) + (r & 31);
+        float sum = 0.f;
+#pragma unroll 1
+        for (int h = 0; h < 2 * nkt; ++h) {              // half k-tiles: fragment triple h >> 1, lanes 32 (h & 1) + slot
+            const uint4* fa = fa0 + (h >> 1) * 192 + (h & 1) * 32;
+            const uint4* fb = fb0 + (h >> 1) * 192 + (h & 1) * 32;
+            float a[8], b[8];
+            split_decode8(fa[0], fa[64], fa[128], a);
+            split_decode8(fb[0], fb[64], fb[128], b);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) sum = __builtin_fmaf(a[q], b[q], sum);
+        }
+        Cs[r * 129 + c] = sum;
+    }
+}
 
 // EPI: 0 = plain stores from the accumulators; 1 = the same with the dropout-mask / activation factors; 2 = the tile goes through LDS into
 // gemm_kernel's own epilogue (txe_gemm.h gemm_tile_epilogue: exp, pick, count and best-k modes -- the scoring loop), E = its arguments
@@ -207,6 +236,30 @@ __global__ __launch_bounds__(256, MINB) void gemm_nt_split_kernel(const SplitGem
 #undef TXE_SP_ISSUE
 #undef TXE_SP_COPY
 
+    {   // an accumulator that is not finite: a raw fragment's NaN plane, or an overflowing result -- the tile recomputes itself in fp32
+        bool odd = false;
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) odd |= not_finite(acc[i][j][e]);
+        static_assert(NST * STAGE_U4 * 4 >= 64 * MI * 129, "the recomputed tile lives in the stage ring");
+        if (__syncthreads_or(odd)) {                     // (the barrier: every wave is done reading the stages)
+            float* Cs = reinterpret_cast<float*>(smem_u4);
+            gemm_nt_split_slow_tile<MI>(p.A, p.B, nkt, tm, tn, Cs);
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e)
+                        acc[i][j][e] = Cs[(32 * MI * wm + 32 * i + 4 * (l >> 5) + (e & 3) + 8 * (e >> 2)) * 129 + 64 * wn + 2 * (l & 31) + j];
+            __syncthreads();
+        }
+    }
+
     if constexpr (EPI == 2) {
         float* Cs = reinterpret_cast<float*>(smem_u4);
         __syncthreads();                                 // every wave is done reading the stages
@@ -298,7 +351,8 @@ __device__ __forceinline__ void split_pack_t_job(const SplitPackTArgs& a, const 
 #pragma unroll
             for (int r = 0; r < 8; ++r) x[r] = j == 0 ? q[r].x : (j == 1 ? q[r].y : (j == 2 ? q[r].z : (j == 3 ? q[r].w : o[r])));
             uint4 w1, w2, w3;
-            split3x8(x, w1, w2, w3);
+            if (__ballot(split_exceptional8(x)) != 0ull) split_raw8(x, w1, w2, w3);  // (a wave = the five fragments of one (nt, h): each judged alone)
+            else split3x8(x, w1, w2, w3);
             base[(j * 3 + 0) * 64] = w1; base[(j * 3 + 1) * 64] = w2; base[(j * 3 + 2) * 64] = w3;
         }
     }
@@ -333,6 +387,29 @@ struct SplitTn {
 };
 constexpr int SPT_A_U4 = 4 * 3 * 64, SPT_B_U4 = 5 * 3 * 64, SPT_STAGE_U4 = SPT_A_U4 + SPT_B_U4;   // 12 KB + 15 KB
 constexpr int SPT_RAW_F = 16 * 128;                                                              // 8 KB
+
+// The TN tile's recomputation (txe_gemm_split.h "the whole fp32 domain"): the 32 C rows of A block `blk` x 160 columns into LDS, every
+// output an fp32 FMA chain over the slice's contraction rows in ascending order -- A read as the fp32 it is, B decoded from its packed form
+__device__ __forceinline__ void gemm_tn_split_slow_block(const SplitTn& p, const int tm, const int h, const int kbeg, const int kend,
+                                                         const int blk, float* __restrict__ Cs) {
+#pragma unroll 1
+    for (int o = threadIdx.x; o < 32 * 160; o += 256) {
+        const int sa = o / 160, cc = o - sa * 160;
+        const int j = cc < 128 ? (cc & 3) : 4, sb = cc < 128 ? (cc >> 2) : cc - 128;
+        const float* a = p.A + (long long)tm * 128 + 64 * (blk >> 1) + 2 * sa + (blk & 1);
+        float sum = 0.f;
+#pragma unroll 1
+        for (int n0 = kbeg; n0 < kend; n0 += 8) {        // (kbeg is a multiple of 16: eight rows = one half of a fragment's lanes)
+            const uint4* f = reinterpret_cast<const uint4*>(p.Bt + ((((long long)(n0 >> 4) * p.nkb + 5 * h + j) * 3) * SPL_FRAG_BYTES)) + ((n0 >> 3) & 1) * 32 + sb;
+            float b[8];
+            split_decode8(f[0], f[64], f[128], b);
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                if (n0 + q < kend) sum = __builtin_fmaf(a[(long long)(n0 + q) * p.lda], b[q], sum);
+        }
+        Cs[sa * 161 + cc] = sum;
+    }
+}
 
 __global__ __launch_bounds__(256, 2) void gemm_tn_split_kernel(const SplitTn p) {
     __shared__ __attribute__((aligned(16))) uint4 st0[SPT_STAGE_U4];
@@ -439,6 +516,34 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_split_kernel(const SplitTn p) 
 #undef TXE_ST_ISSUE_A
 #undef TXE_ST_ISSUE_B
 #undef TXE_ST_COPY
+
+    {   // exceptional operands (txe_gemm_split.h "the whole fp32 domain"): an accumulator that is not finite -- a raw B fragment's NaN plane;
+        // Inf / NaN / beyond-bf16 elements of A; an overflowing result -- and the tile recomputes itself in fp32
+        bool odd = false;
+#pragma unroll
+        for (int j = 0; j < 5; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) odd |= not_finite(acc[j][e]);
+        static_assert(SPT_STAGE_U4 * 4 >= 32 * 161, "a block's recomputed rows live in one fragment stage");
+        if (__syncthreads_or(odd)) {
+            float* Cs = reinterpret_cast<float*>(st0);
+#pragma unroll 1
+            for (int blk = 0; blk < 4; ++blk) {
+                gemm_tn_split_slow_block(p, tm, h, kbeg, kend, blk, Cs);
+                __syncthreads();
+                if (blk == w) {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const float* row = Cs + ((e & 3) + 8 * (e >> 2) + 4 * (l >> 5)) * 161;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) acc[j][e] = row[4 * (l & 31) + j];
+                        acc[4][e] = row[128 + (l & 31)];
+                    }
+                }
+                __syncthreads();
+            }
+        }
+    }
 
     // accumulator register e: row slot (e & 3) + 8 (e >> 2) + 4 (lane >> 5) of A block w = C row 64 (w >> 1) + 2 slot + (w & 1) of the
     // tile; blocks 0-3: columns 4 (lane & 31) + j, block 4: column 128 + (lane & 31)

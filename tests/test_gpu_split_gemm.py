@@ -59,6 +59,172 @@ def test_packed_planes_sum_to_the_operand_exactly(rows, cols, side):
     assert not total[:, cols:].any()
 
 
+RAW_MARK = 0x7FC0         # csrc/txe_gemm_split.h SPL_RAW_MARK: plane 3 of a fragment stored raw (it holds an exceptional element)
+
+
+def _decode_fragment(frag_rb_kt):
+    """[plane][kh][slot][8] uint16 -> float64 values [kh][slot][8] and whether the fragment is stored raw"""
+    p1, p2, p3 = frag_rb_kt[0], frag_rb_kt[1], frag_rb_kt[2]
+    if (p3 == RAW_MARK).all():
+        bits = (p1.astype(np.uint32) << 16) | p2.astype(np.uint32)
+        return bits.view(np.float32).astype(np.float64), True
+    assert not (p3 == RAW_MARK).any()
+    return _bf16_bits_to_f64(p1) + _bf16_bits_to_f64(p2) + _bf16_bits_to_f64(p3), False
+
+
+def _exceptional(x):
+    return ~np.isfinite(x) | (np.abs(x.astype(np.float64)) >= 2.0 ** 120)
+
+
+@pytest.mark.parametrize("side", [0, 1])
+def test_packed_form_carries_the_whole_fp32_domain(side):
+    """+-Inf, NaN, 3.4e38, 2^120 and values inside the ordinary range in one operand: a fragment (32 slots x 16 columns) that holds an
+    exceptional element (not finite, or |x| >= 2^120) is stored RAW (high halves, low halves, NaN plane) and decodes to the operand bit
+    for bit; every other fragment is three planes whose sum is the operand exactly down to 2^-100, and within 2^-126 below that"""
+    from taxoexpan_amd import _lib
+    rows, cols = 200, 70
+    g = torch.Generator().manual_seed(11 + side)
+    x = torch.randn(rows, cols, generator=g)
+    specials = [float("inf"), float("-inf"), float("nan"), 1e-45, -3e-39, 1.1754944e-38, 1e-38, 2.0 ** -101, 3.4028234e38, -3.39e38, 2.0 ** 120, 1e37, 2.0 ** -100]
+    for i, v in enumerate(specials):
+        x[(7 * i) % rows, (5 * i) % cols] = v
+    x[150:160, 40:50] = torch.randn(10, 10, generator=g) * 1e-41            # a block of subnormals
+    xd = x.to(_dev())
+    buf = torch.zeros(_lib.call("txe_split_packed_bytes", rows, cols), dtype=torch.uint8, device=_dev())
+    _lib.call("txe_split_pack", xd.data_ptr(), cols, rows, cols, side, buf.data_ptr(), _lib.stream_ptr())
+    torch.cuda.synchronize()
+    nkt, nrb = (cols + 15) // 16, ((rows + 767) // 768) * 24
+    frag = buf.cpu().numpy().view(np.uint16).reshape(nrb, nkt, 3, 2, 32, 8)
+    xn = x.numpy()
+    pad = np.zeros((nrb * 32 + 768, nkt * 16), dtype=np.float32)
+    pad[:rows, :cols] = xn
+    n_raw = 0
+    for rb in range(nrb):
+        rws = np.array([_slot_row(side, rb, s) for s in range(32)])
+        for kt in range(nkt):
+            vals, raw = _decode_fragment(frag[rb, kt])
+            want = np.stack([pad[rws][:, kt * 16 + 8 * kh:kt * 16 + 8 * kh + 8] for kh in range(2)])     # [kh][slot][8]
+            assert raw == bool(_exceptional(want).any()), (rb, kt)
+            n_raw += raw
+            if raw:
+                np.testing.assert_array_equal(vals.astype(np.float32).view(np.uint32), want.view(np.uint32))
+            else:
+                w64 = want.astype(np.float64)
+                big = np.abs(w64) >= 2.0 ** -100
+                np.testing.assert_array_equal(vals[big | (w64 == 0)], w64[big | (w64 == 0)])
+                assert (np.abs(vals - w64) <= 2.0 ** -126).all()
+    assert n_raw >= 3
+
+
+def _ieee_compare(got, A, B, ref32, e_bound):
+    """got (device, fp32) against the fp32 product ref32 = torch.mm on the CPU (IEEE arithmetic): the same entries are NaN, the same are
+    +Inf / -Inf, and the finite ones are as close to float64 as an fp32 product (the bound of the ordinary tests, plus a few FLT_MIN:
+    results in the subnormal range may be flushed by the matrix pipe as by any GPU GEMM)"""
+    got, ref32 = got.cpu(), ref32.cpu()
+    A64, B64 = torch.nan_to_num(A.double().cpu(), nan=0.0, posinf=0.0, neginf=0.0), torch.nan_to_num(B.double().cpu(), nan=0.0, posinf=0.0, neginf=0.0)
+    # an operand element below 2^-133 may act as zero (flush-to-zero semantics below 2^-100: csrc/txe_gemm_split.h): where one meets an
+    # infinity of the other operand IEEE gives +-Inf, a flushed zero gives NaN -- there only "not finite" is asked
+    tiniest = lambda X64: ((X64 != 0) & (X64.abs() < 2.0 ** -132)).double()
+    isinf64 = lambda X: torch.isinf(X.cpu()).double()
+    loose = (tiniest(A64) @ isinf64(B) + isinf64(A) @ tiniest(B64)) > 0
+    strict = ~loose
+    assert not torch.isfinite(got[loose]).any()
+    assert torch.equal(torch.isnan(got)[strict], torch.isnan(ref32)[strict]), (torch.isnan(got).sum().item(), torch.isnan(ref32).sum().item())
+    inf = torch.isinf(ref32) & strict
+    assert torch.equal(torch.isinf(got)[strict], torch.isinf(ref32)[strict]) and torch.equal(got[inf], ref32[inf])
+    fin = torch.isfinite(ref32)
+    ref = A64 @ B64
+    scale = A64.abs() @ B64.abs()
+    err = (got.double() - ref).abs()[fin]
+    e32 = (ref32.double() - ref).abs()[fin]
+    sc = scale[fin]
+    rel32 = (e32 / sc.clamp_min(1e-300)).max().item()
+    # operand elements below 2^-100 are carried to 2^-126 absolute (csrc/txe_gemm_split.h): their share of the bound
+    tinyA, tinyB = ((A64 != 0) & (A64.abs() < 2.0 ** -100)).double(), ((B64 != 0) & (B64.abs() < 2.0 ** -100)).double()
+    tiny = 2.0 ** -126 * (tinyA @ B64.abs() + A64.abs() @ tinyB)[fin]
+    tol = max(1.5 * rel32, e_bound) * sc + tiny + 4 * 1.1754944e-38
+    assert (err <= tol).all(), ((err / sc.clamp_min(1e-300)).max().item(), rel32)
+
+
+def _special_operands(M, N, K, seed):
+    g = torch.Generator().manual_seed(seed)
+    A = torch.randn(M, K, generator=g)
+    B = torch.randn(N, K, generator=g) * 0.1
+    A[3, 5] = float("inf")                      # Inf x finite = +-Inf along the row ...
+    B[4, 5] = 0.0                               # ... Inf x 0 = NaN in this column
+    A[10, :] = float("nan")
+    A[20, 7] = float("-inf"); A[20, 9] = float("inf")      # Inf - Inf = NaN wherever both columns of B are nonzero of one sign ...
+    A[40, :] = torch.randn(K, generator=g) * 1e-40          # a subnormal row ...
+    B[6, :] = torch.randn(K, generator=g) * 1e10            # ... against a large column: products ~1e-30, every bit of the subnormals counts
+    A[50, :] = torch.randn(K, generator=g).abs() * 1e-38   # just under / over FLT_MIN
+    A[60, 0] = 3.0e38                                       # beyond bf16's largest number
+    B[8, 0], B[9, 0], B[11, 0] = 0.5, 2.0, -2.0             # 1.5e38 (finite), +Inf, -Inf
+    # ordinary-range operands whose product overflows: every term positive, +Inf in any summation order (and no OTHER pairing of the
+    # scaled rows / columns overflows: whether Inf - Inf appears inside a sum depends on the order and on FMA contraction, not on IEEE)
+    A[70, :] = A[70, :].abs() * 1e25; B[12, :] = B[12, :].abs() * 1e15
+    B[13, 2] = float("inf"); B[14, :] = float("nan"); B[15, :] = torch.randn(K, generator=g) * 1e-42
+    A[M - 1, K - 1] = float("inf")                          # the last element of a ragged tile
+    return A, B
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 200, 100), (129, 17, 33), (1000, 260, 320)])
+def test_nt_product_on_the_whole_fp32_domain(M, N, K):
+    """Inf, NaN, near-FLT_MAX and overflowing operands: the bf16-pipe product gives what an IEEE fp32 product gives -- the same entries NaN,
+    the same +-Inf, the finite ones inside the fp32 band; subnormal / tiny operand elements are carried to 2^-126 absolute"""
+    from taxoexpan_amd import _lib
+    A, B = _special_operands(M, N, K, M + K)
+    Ad, Bd = A.to(_dev()), B.to(_dev())
+    s = _lib.stream_ptr()
+    Ap = torch.empty(_lib.call("txe_split_packed_bytes", M, K), dtype=torch.uint8, device=_dev())
+    Bp = torch.empty(_lib.call("txe_split_packed_bytes", N, K), dtype=torch.uint8, device=_dev())
+    C = torch.full((M, N), 123.0, device=_dev())
+    _lib.call("txe_split_pack", Ad.data_ptr(), K, M, K, 0, Ap.data_ptr(), s)
+    _lib.call("txe_split_pack", Bd.data_ptr(), K, N, K, 1, Bp.data_ptr(), s)
+    _lib.call("txe_gemm_nt_split", Ap.data_ptr(), Bp.data_ptr(), M, N, K, C.data_ptr(), N, s)
+    torch.cuda.synchronize()
+    _ieee_compare(C, A, B.t(), A @ B.t(), ABS_FLOOR)
+
+
+@pytest.mark.parametrize("n,M,N,S", [(500, 128, 160, 2), (333, 256, 36, 3)])
+def test_tn_product_on_the_whole_fp32_domain(n, M, N, S):
+    """the weight-gradient form: exceptional elements in the fp32 operand (split in the product's loader) and in the packed one"""
+    from taxoexpan_amd import _lib
+    At, Bt_ = _special_operands(M, N, n, n + M)          # [M][n], [N][n]: contraction over n
+    A, B = At.t().contiguous(), Bt_.t().contiguous()     # A [n][M], B [n][N]
+    Ad, Bd = A.to(_dev()), B.to(_dev())
+    s = _lib.stream_ptr()
+    Bp = torch.empty(_lib.call("txe_split_packed_t_bytes", n, N), dtype=torch.uint8, device=_dev())
+    ks = (((n + S - 1) // S) + 15) // 16 * 16
+    part = torch.full((S, M, N), 123.0, device=_dev())
+    _lib.call("txe_split_pack_t", Bd.data_ptr(), N, n, N, Bp.data_ptr(), s)
+    _lib.call("txe_gemm_tn_split", Ad.data_ptr(), M, M, Bp.data_ptr(), N, n, S, ks, part.data_ptr(), N, M * N, s)
+    torch.cuda.synchronize()
+    for z in range(S):
+        lo, hi = min(n, z * ks), min(n, (z + 1) * ks)
+        _ieee_compare(part[z], A[lo:hi].t(), B[lo:hi], A[lo:hi].t() @ B[lo:hi], ABS_FLOOR)
+
+
+def test_scoring_entry_points_propagate_infinities():
+    """test_fast.py:121-123 with an overflowing graph vector and an overflowing query (LBM scores reach inf legitimately:
+    tests/golden/newterms.npz holds 124): the bf16-pipe scoring product gives the fp32 route's Inf / NaN / 0 pattern"""
+    from taxoexpan_amd import ops
+    g = torch.Generator().manual_seed(5)
+    G, nq, r = 700, 130, 500
+    U = (torch.randn(G, r, generator=g) * 0.05)
+    Q = torch.randn(nq, r, generator=g)
+    U[5, 3] = float("inf"); U[6, :] = float("nan"); U[7, 4] = float("-inf"); Q[2, 8] = float("inf"); Q[9, 3] = 0.0
+    ref = Q @ U.t()
+    for apply_exp in (False, True):
+        S = ops.score_block(Q.to(_dev()), U.to(_dev()), apply_exp)
+        torch.cuda.synchronize()
+        want = ref.exp() if apply_exp else ref
+        got = S.cpu()
+        assert torch.equal(torch.isnan(got), torch.isnan(want))
+        assert torch.equal(torch.isinf(got), torch.isinf(want)) and torch.equal(got[torch.isinf(want)], want[torch.isinf(want)])
+        fin = torch.isfinite(want)
+        np.testing.assert_allclose(got[fin].numpy(), want[fin].numpy(), rtol=2e-5, atol=1e-5)
+
+
 def _err(c, ref, scale):
     return ((c.double() - ref).abs() / scale).max().item()
 

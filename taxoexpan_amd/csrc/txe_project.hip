@@ -1950,6 +1950,9 @@ struct FusedBwdArgs {
     const float* Y; long long ld_y; int H, D; const float* alpha; float drop_p, drop_scale; unsigned long long seed;
     float* d_Y; long long ld_dy; float* dal; float* dwa_part; float* ppart;
     int npw;                            // source nodes per workgroup
+    // (the egonet-walking variant) the graphs themselves: destination CSR, graph offsets, node -> graph
+    const int *rowptr_in, *col_src, *goff, *ggid; int G;
+    float* hpart;                       // [workgroups][H*D]: a workgroup's share of d_ft[hub] for a graph whose hub lives in an earlier window
 };
 
 // Source nodes per workgroup of the fused sweep.  The kernel holds 3 workgroups per CU; its workgroups cost about (nodes + 6) each (LDS
@@ -2189,6 +2192,348 @@ __global__ __launch_bounds__(256, (NI >= 3) ? 2 : TXE_FB_OCC) void gat_fused_bwd
     for (int i = threadIdx.x; i < a.vocab * a.Pd; i += 256) a.ppart[(long long)b * a.vocab * a.Pd + i] = s_dp[i];
 }
 
+// ---- the same sweep, WALKING EGONETS (dataset.py:404-437: parents -> anchor, anchor -> siblings, self loops) -----------------------
+// The sweep above fetches X'[v] once per out-edge (u -> v): an anchor's row once per parent, a sibling's row once for the anchor and
+// once as its own -- 64 MB of re-fetched rows on the training batch (FETCH_SIZE 374 MB against 326 MB algorithmic).  In an egonet every
+// edge that is not a self loop touches ONE node, the hub h (the anchor): parents u have out-edges {u, h}, siblings s have {s} and the
+// in-edge h -> s.  With the hub's three row slices in registers -- ft[h], d_pre[h] and the accumulating d_ft[h] -- every other node's rows
+// are read exactly once:
+//     hub h        : d_pre[h], self edge
+//     parent u     : d_pre[u], self edge;  edge u -> h: d alpha = <d_pre[h], ft[u]>, d_ft[u] += alpha' d_pre[h]
+//     sibling s    : d_pre[s], self edge;  edge h -> s: d alpha = <d_pre[s], ft[h]>, d_ft[h] += alpha' d_pre[s]
+// X', Y are streamed once, d_Y written once: the algorithmic bytes.
+// Work list: the nodes of a hub-shaped graph in the order hub, parents, siblings (list position = node index except inside a graph);
+// a workgroup walks npw consecutive LIST POSITIONS, two per round trip -- every workgroup the same amount of work, whatever the graph
+// sizes (a 54-node egonet beside 2-node ones).  A graph cut by a workgroup boundary: the later workgroup first loads the hub's rows
+// again (d_pre[h], ft[h]; nothing written), and leaves ITS share of d_ft[h] in hpart[workgroup]; gat_attn_bwd_reduce_a_kernel -- the next
+// launch -- adds those rows to d_Y[h] in workgroup order (fused_hub_fixup_job: deterministic, no atomics).
+// The shape is CHECKED per graph from the CSR arrays (out-degrees, out-lists of the small nodes, in-lists of the siblings -- never the
+// position labels), by every workgroup that touches the graph: a graph that is not hub-shaped -- or has more than EGO_MAXN nodes -- is
+// walked by the generic body above (fb_body, edge scalars from global memory) for the source nodes in the workgroup's window.
+// One head per wave (H = 4: the per-head dot products are wave-local); other head counts keep the kernel above.
+constexpr int EGO_MAXN = 64;                             // largest hub-shaped graph walked from registers
+constexpr int EGO_TAB = FB_NODES + 2 * EGO_MAXN;         // nodes of the graphs that intersect a window of <= FB_NODES positions
+enum { EGO_SKIP = 0, EGO_HUB = 1, EGO_PRE = 2, EGO_POST = 3, EGO_FOREIGN = 4 };
+
+// list position (local index t inside a hub-shaped graph with hub h) -> local node index
+__device__ __forceinline__ int ego_node_of(int t, int h) { return t == 0 ? h : (t <= h ? t - 1 : t); }
+
+template <bool MASK, int NI>
+__global__ __launch_bounds__(256, (NI >= 3) ? 2 : 3) void gat_fused_bwd_ego_kernel(const FusedBwdArgs a) {
+    __shared__ int s_v[4], s_p[4], s_ni[4 * FB_NODES];                         // (the generic body's per-node table; its edge tables are not used)
+    __shared__ float s_cn[4], s_g1[4], s_g2[4], s_nf[4 * FB_NODES];
+    __shared__ float s_dot[4][4];
+    // per list position of the window (+ one entry for a foreign hub, + one skip entry that pads an odd count)
+    __shared__ int t_node[FB_NODES + 2], t_role[FB_NODES + 2], t_self[FB_NODES + 2], t_hub[FB_NODES + 2], t_dz[FB_NODES + 2], t_pos[FB_NODES + 2];
+    __shared__ float t_cn[FB_NODES + 2], t_g1[FB_NODES + 2], t_g2[FB_NODES + 2];
+    // per node of the intersecting graphs (staging)
+    __shared__ int n_deg[EGO_TAB], n_tgt[EGO_TAB], n_role[EGO_TAB], n_self[EGO_TAB], n_hubp[EGO_TAB];
+    __shared__ int g_hub[FB_NODES], g_ok[FB_NODES];
+    extern __shared__ __attribute__((aligned(16))) float s_dyn[];
+    const int b = xcd_remap(blockIdx.x, gridDim.x);
+    const int Kp = a.Kp;
+    float* s_wa = s_dyn;
+    float* s_acc = s_dyn + 2 * Kp;
+    float* s_dp = s_dyn + 4 * Kp;
+    const int tid = threadIdx.x;
+    // ---- the window of list positions and the graphs that intersect it ----
+    const int u0 = b * a.npw, u1 = min(a.n_nodes, u0 + a.npw), nw = u1 - u0;   // (nw >= 1: the grid has ceil(n / npw) workgroups)
+    const int gF = a.ggid[u0], gL = a.ggid[u1 - 1], ng = gL - gF + 1;          // <= npw <= FB_NODES graphs
+    const int offF = a.goff[gF], endL = a.goff[gL + 1];
+    const int tb = (a.goff[gF + 1] - offF <= EGO_MAXN) ? offF : u0;           // first / one-past-last node with a staging entry
+    const int te = (endL - a.goff[gL] <= EGO_MAXN) ? endL : u1;                // (only the first and the last graph reach outside the window)
+    for (int i = tid; i < FB_NODES + 2; i += 256) { t_node[i] = u0; t_role[i] = EGO_SKIP; t_self[i] = 0; t_hub[i] = 0; t_dz[i] = 0; t_pos[i] = 0; t_cn[i] = 0.f; t_g1[i] = 0.f; t_g2[i] = 0.f; }
+    for (int i = tid; i < a.vocab * a.Pd; i += 256) s_dp[i] = 0.f;
+    for (int i = tid * 4; i < 2 * Kp; i += 1024) {
+        *reinterpret_cast<float4*>(s_wa + i) = *reinterpret_cast<const float4*>(a.wa + i);
+        *reinterpret_cast<float4*>(s_acc + i) = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    if (tid < ng) { g_ok[tid] = (a.goff[gF + tid + 1] - a.goff[gF + tid] <= EGO_MAXN) ? 1 : 0; g_hub[tid] = 0; }
+    __syncthreads();
+    // (1) out-degree, and the non-self target of a node of out-degree 2 -- one thread per node of the graphs that fit
+    int my_g = -1, my_i = 0, my_n = 0, my_v = 0, my_base = 0;
+    if (tid < te - tb) {
+        const int v = tb + tid, g = a.ggid[v];
+        if (g_ok[g - gF]) { my_g = g - gF; my_base = a.goff[g] - tb; my_i = v - a.goff[g]; my_n = a.goff[g + 1] - a.goff[g]; my_v = v; }
+    }
+    if (my_g >= 0) {
+        const int e0 = a.rowptr_out[my_v], d = a.rowptr_out[my_v + 1] - e0;
+        n_deg[tid] = d;
+        int tgt = -1;
+        if (d == 2) { const int d0 = a.col_dst[e0], d1 = a.col_dst[e0 + 1]; tgt = (d0 == my_v) ? d1 : d0; }
+        n_tgt[tid] = tgt - (tb + my_base);                                 // local index inside the graph (or out of range)
+    }
+    __syncthreads();
+    // (2) the hub of every graph: THE node of out-degree >= 3, else the target of the first node of out-degree 2, else node 0 of a
+    //     single-node graph
+    if (tid < ng && g_ok[tid]) {
+        const int base = a.goff[gF + tid] - tb, n = a.goff[gF + tid + 1] - a.goff[gF + tid];
+        int h = -1, big = 0;
+        for (int i = 0; i < n; ++i) if (n_deg[base + i] >= 3) { h = i; ++big; }
+        if (big == 0) {
+            for (int i = 0; i < n && h < 0; ++i) if (n_deg[base + i] == 2) h = n_tgt[base + i];
+            if (h < 0) h = (n == 1) ? 0 : -1;
+        }
+        if (big > 1 || h < 0 || h >= n) g_ok[tid] = 0; else g_hub[tid] = h;
+    }
+    __syncthreads();
+    // (3) every node against the hub shape; its role and the destination-CSR positions of its self loop and of its edge with the hub
+    if (my_g >= 0 && g_ok[my_g]) {
+        const int h = g_hub[my_g], vh = tb + my_base + h, d = n_deg[tid];
+        const int pi0 = a.rowptr_in[my_v], din = a.rowptr_in[my_v + 1] - pi0;
+        int role = EGO_SKIP, pself = -1, phub = -1;
+        bool ok = true;
+        if (my_i == h) {                       // hub: itself in its in-list; out-degree = 1 + #siblings (the siblings check their side)
+            role = EGO_HUB;
+            for (int q = 0; q < din; ++q) if (a.col_src[pi0 + q] == my_v) pself = pi0 + q;
+            int n_post = 0;
+            for (int i = 0; i < my_n; ++i) n_post += (i != h && n_deg[my_base + i] == 1) ? 1 : 0;
+            ok = pself >= 0 && d == 1 + n_post;
+            phub = pself;
+        } else if (d == 2) {                   // parent: out-list {self, hub}
+            role = EGO_PRE;
+            const int e0 = a.rowptr_out[my_v];
+            const int d0 = a.col_dst[e0], d1 = a.col_dst[e0 + 1];
+            if (d0 == my_v && d1 == vh) { pself = a.pos_out[e0]; phub = a.pos_out[e0 + 1]; }
+            else if (d1 == my_v && d0 == vh) { pself = a.pos_out[e0 + 1]; phub = a.pos_out[e0]; }
+            else ok = false;
+        } else if (d == 1) {                   // sibling: in-list {hub, self}; its one out-edge is then the self loop
+            role = EGO_POST;
+            if (din == 2) {
+                const int s0 = a.col_src[pi0], s1 = a.col_src[pi0 + 1];
+                if (s0 == my_v && s1 == vh) { pself = pi0; phub = pi0 + 1; }
+                else if (s1 == my_v && s0 == vh) { pself = pi0 + 1; phub = pi0; }
+                else ok = false;
+            } else ok = false;
+        } else ok = false;
+        if (!ok) g_ok[my_g] = 0;                 // (benign race: every writer stores 0)
+        n_role[tid] = role; n_self[tid] = max(pself, 0); n_hubp[tid] = max(phub, 0);
+    }
+    __syncthreads();
+    // (4) the window's list positions -> table entries; entry nw: the hub of a graph whose list the window enters in the middle
+    if (tid <= nw) {
+        int v = -1, role = EGO_SKIP, idx = 0;
+        if (tid < nw) {
+            const int p = u0 + tid, g = a.ggid[p];
+            if (g_ok[g - gF]) { v = a.goff[g] + ego_node_of(p - a.goff[g], g_hub[g - gF]); idx = v - tb; role = n_role[idx]; }
+        } else if (g_ok[0] && u0 > offF) { v = offF + g_hub[0]; idx = v - tb; role = EGO_FOREIGN; }
+        if (v >= 0) {
+            t_node[tid] = v; t_role[tid] = role; t_self[tid] = n_self[idx]; t_hub[tid] = n_hubp[idx];
+            t_dz[tid] = a.gid[v]; t_pos[tid] = a.pos[v];
+            t_cn[tid] = a.cn[v]; t_g1[tid] = a.da1[v]; t_g2[tid] = a.da2[v];
+        }
+    }
+    __syncthreads();
+
+    const int w = uni((int)(tid >> 6)), l = tid & 63;
+    const int F = a.H * a.D, SL = F >> 2, nvec = SL >> 2;
+    const int c0 = w * SL, hw = c0 / a.D;
+    int off[NI];
+    float live[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int j = l + 64 * i;
+        off[i] = c0 + 4 * ((j < nvec) ? j : 0);
+        live[i] = (j < nvec) ? 1.f : 0.f;
+    }
+    const int tvec = (Kp - F) >> 2;
+    const bool tail = (w == 0) && (l < tvec);
+    const int tc = min(F + 4 * (tail ? l : 0), Kp - 4);
+    float fth[NI][4], pph[NI][4], acch[NI][4];
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { fth[i][k] = 0.f; pph[i][k] = 0.f; acch[i][k] = 0.f; }
+    int hub_node = -1;                           // the hub whose slices are in registers; hub_home: its d_ft goes to d_Y (else to hpart[b])
+    bool hub_home = true;
+    // a window that starts inside a graph of <= EGO_MAXN nodes owes the fix-up pass a row hpart[b]: its share of the hub's d_ft, or
+    // zeros if the graph turned out not to be hub-shaped (fused_hub_fixup_job repeats only the cheap half of the shape check)
+    const bool owes_hpart = u0 > offF && (a.goff[gF + 1] - offF <= EGO_MAXN);
+    bool paid_hpart = false;
+    auto flush_hub = [&]() {
+        if (hub_node >= 0) {
+            if (!hub_home) paid_hpart = true;
+            float* dst = hub_home ? a.d_Y + (long long)hub_node * a.ld_dy : a.hpart + (long long)b * F;
+#pragma unroll
+            for (int i = 0; i < NI; ++i)
+                if (l + 64 * i < nvec) vstore<4>(dst + off[i], acch[i]);
+        }
+    };
+
+    // the walk: entry nw (a foreign hub, or a skip) first, paired with position 0; then two positions per round trip
+    for (int t0 = -1; t0 < nw; t0 += 2) {
+        // ---- every load of the two entries first (rows, masks, edge scalars), nothing in between ----
+        int vv[2], role[2], ps[2], ph[2], pv[2];
+        float cnv[2], g1v[2], g2v[2], als[2], alh[2];
+        float ft[2][NI][4], xv[2][NI][4], dz[2][NI][4], xt[2][4], dzt[2][4];
+        unsigned mv[2][NI], mt[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int t = (t0 + q < 0) ? nw : ((t0 + q < nw) ? t0 + q : FB_NODES + 1);     // (FB_NODES + 1: an entry that stays EGO_SKIP)
+            vv[q] = uni(t_node[t]); role[q] = uni(t_role[t]); ps[q] = uni(t_self[t]); ph[q] = uni(t_hub[t]); pv[q] = t_pos[t];
+            cnv[q] = uni(t_cn[t]); g1v[q] = uni(t_g1[t]); g2v[q] = uni(t_g2[t]);
+            const int dzr = uni(t_dz[t]);
+            als[q] = a.alpha[(long long)ps[q] * a.H + hw];
+            alh[q] = a.alpha[(long long)ph[q] * a.H + hw];
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                vload<4>(a.Y + (long long)vv[q] * a.ld_y + off[i], ft[q][i]);
+                vload<4>(a.X + (long long)vv[q] * Kp + off[i], xv[q][i]);
+                vload<4>(a.dZ + (long long)dzr * Kp + off[i], dz[q][i]);
+                mv[q][i] = fb_keep<MASK>(a.mask, a.mask_ld, vv[q], off[i]);
+            }
+            vload<4>(a.X + (long long)vv[q] * Kp + tc, xt[q]);
+            vload<4>(a.dZ + (long long)dzr * Kp + tc, dzt[q]);
+            mt[q] = fb_keep<MASK>(a.mask, a.mask_ld, vv[q], tc);
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            if (role[q] == EGO_SKIP) continue;                        // (wave-uniform)
+            const int v = vv[q];
+            const bool own = role[q] != EGO_FOREIGN;                  // a foreign hub: d_pre and ft only -- its own-row work belongs to its home
+            const float sc = cnv[q] * a.fscale, s1 = g1v[q] * a.fscale, s2 = g2v[q] * a.fscale;
+            float dp[NI][4], acc[NI][4];
+            const float fd = (a.drop_p > 0.f) ? drop_factor(a.seed, (unsigned long long)ps[q] * a.H + hw, a.drop_p, a.drop_scale) : 1.f;
+            const float coef = als[q] * fd;
+            const float go1 = own ? g1v[q] : 0.f, go2 = own ? g2v[q] : 0.f;
+            float part = 0.f;
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                float w1[4], w2[4], a1[4], a2[4];
+                vload<4>(s_wa + off[i], w1);
+                vload<4>(s_wa + Kp + off[i], w2);
+                vload<4>(s_acc + off[i], a1);
+                vload<4>(s_acc + Kp + off[i], a2);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const bool keep = ((mv[q][i] >> k) & 1u) != 0u;
+                    const float tv = sc * dz[q][i][k] + s1 * w1[k] + s2 * w2[k];
+                    const float lk = (xv[q][i][k] > 0.f) ? live[i] : a.act_slope * live[i];
+                    dp[i][k] = keep ? tv * lk : 0.f;
+                    part = fmaf(dp[i][k], ft[q][i][k], part);
+                    acc[i][k] = coef * dp[i][k];
+                    const float xd = keep ? xv[q][i][k] * a.fscale * live[i] : 0.f;       // own-row leftovers of cl_bwd_dx: d_wa partials
+                    a1[k] = fmaf(go1, xd, a1[k]);
+                    a2[k] = fmaf(go2, xd, a2[k]);
+                }
+                if (l + 64 * i < nvec) { vstore<4>(s_acc + off[i], a1); vstore<4>(s_acc + Kp + off[i], a2); }
+            }
+            if (tail && own) {
+                float a1[4], a2[4], wt1[4], wt2[4];
+                vload<4>(s_acc + tc, a1);
+                vload<4>(s_acc + Kp + tc, a2);
+                vload<4>(s_wa + tc, wt1);
+                vload<4>(s_wa + Kp + tc, wt2);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const bool keep = ((mt[q] >> k) & 1u) != 0u;
+                    const float xd = keep ? xt[q][k] * a.fscale : 0.f;
+                    a1[k] = fmaf(g1v[q], xd, a1[k]);
+                    a2[k] = fmaf(g2v[q], xd, a2[k]);
+                    const int pc = tc + k - a.Kh;                      // position column (d_X' there has no activation factor)
+                    if (pc >= 0 && pc < a.Pd) s_dp[pv[q] * a.Pd + pc] += keep ? a.fscale * (cnv[q] * dzt[q][k] + g1v[q] * wt1[k] + g2v[q] * wt2[k]) : 0.f;
+                }
+                vstore<4>(s_acc + tc, a1);
+                vstore<4>(s_acc + Kp + tc, a2);
+            }
+            if (own) {
+                part = wave_sum(part);
+                if (l == 0) a.dal[(long long)ps[q] * a.H + hw] = part * fd;           // the self loop's raw d alpha
+            }
+            if (role[q] == EGO_HUB || role[q] == EGO_FOREIGN) {
+                flush_hub();
+                hub_node = v; hub_home = own;
+#pragma unroll
+                for (int i = 0; i < NI; ++i)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) { fth[i][k] = ft[q][i][k]; pph[i][k] = dp[i][k]; acch[i][k] = own ? acc[i][k] : 0.f; }
+            } else {
+                const float fdh = (a.drop_p > 0.f) ? drop_factor(a.seed, (unsigned long long)ph[q] * a.H + hw, a.drop_p, a.drop_scale) : 1.f;
+                const float coefh = alh[q] * fdh;
+                float part2 = 0.f;
+                if (role[q] == EGO_PRE) {          // edge v -> hub: d_pre[hub] against this node's ft, accumulated into this node's d_ft
+#pragma unroll
+                    for (int i = 0; i < NI; ++i)
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) { part2 = fmaf(pph[i][k], ft[q][i][k], part2); acc[i][k] = fmaf(coefh, pph[i][k], acc[i][k]); }
+                } else {                           // edge hub -> v: this node's d_pre against the hub's ft, accumulated into the hub's d_ft
+#pragma unroll
+                    for (int i = 0; i < NI; ++i)
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) { part2 = fmaf(dp[i][k], fth[i][k], part2); acch[i][k] = fmaf(coefh, dp[i][k], acch[i][k]); }
+                }
+                part2 = wave_sum(part2);
+                if (l == 0) a.dal[(long long)ph[q] * a.H + hw] = part2 * fdh;
+#pragma unroll
+                for (int i = 0; i < NI; ++i)
+                    if (l + 64 * i < nvec) vstore<4>(a.d_Y + (long long)v * a.ld_dy + off[i], acc[i]);
+            }
+        }
+    }
+    flush_hub();
+    if (owes_hpart && !paid_hpart) {
+        const float z[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+            if (l + 64 * i < nvec) vstore<4>(a.hpart + (long long)b * F + off[i], z);
+    }
+    // ---- graphs that are not hub-shaped (or too large): the generic body over their source nodes inside the window ----
+    for (int gi = 0; gi < ng; ++gi) {
+        if (g_ok[gi]) continue;                                      // (LDS value: the same for every thread)
+        const int c = max(u0, a.goff[gF + gi]), cu1 = min(u1, a.goff[gF + gi + 1]);
+        __syncthreads();
+        if (tid < cu1 - c) {
+            const int u = c + tid;
+            s_ni[4 * tid] = a.gid[u]; s_ni[4 * tid + 1] = a.rowptr_out[u]; s_ni[4 * tid + 2] = a.rowptr_out[u + 1];
+            s_ni[4 * tid + 3] = a.pos[u];
+            s_nf[4 * tid] = a.da1[u]; s_nf[4 * tid + 1] = a.da2[u]; s_nf[4 * tid + 2] = a.cn[u];
+        }
+        __syncthreads();
+        const int e0 = a.rowptr_out[c], ne = a.rowptr_out[cu1] - e0;
+        fb_body<MASK, NI, 1, false>(a, b, c, cu1, e0, ne, s_v, s_p, s_cn, s_g1, s_g2, s_ni, s_nf, s_dot, s_dp, s_wa, s_acc);
+    }
+    __syncthreads();
+    float* dw = a.dwa_part + (long long)b * 2 * Kp;
+    for (int i = tid * 4; i < 2 * Kp; i += 1024) *reinterpret_cast<float4*>(dw + i) = *reinterpret_cast<const float4*>(s_acc + i);
+    for (int i = tid; i < a.vocab * a.Pd; i += 256) a.ppart[(long long)b * a.vocab * a.Pd + i] = s_dp[i];
+}
+
+// A hub-shaped graph cut by workgroup boundaries of the walk above: d_Y[hub] (written by the hub's home workgroup) += the later
+// workgroups' shares, in workgroup order.  Block j stands for the boundary in front of window j; it acts only if that boundary cuts a
+// graph whose hub lives in window j - 1... or earlier but this is the FIRST boundary inside the graph -- every cut graph is fixed once.
+struct HubFixArgs { const int *goff, *ggid, *rowptr_out, *col_dst; int n_nodes, npw, nblocks, F; const float* hpart; float* d_Y; long long ld_dy; };
+__device__ __forceinline__ void fused_hub_fixup_job(const int j, const HubFixArgs& a) {
+    const int p = j * a.npw;                                         // first list position of window j (1 <= j < nblocks)
+    const int g = a.ggid[p], o = a.goff[g], n = a.goff[g + 1] - o;
+    if (o == p || n > EGO_MAXN) return;                              // no graph is cut here / never hub-walked
+    const int bh = o / a.npw;                                        // home window of the hub (list position o)
+    if (j != bh + 1) return;                                         // (the first boundary inside the graph does the whole job)
+    // the graph's hub and whether it was hub-walked at all: the same rule as the sweep (out-degrees; the full shape check is repeated
+    // cheaply: a graph that failed there wrote no hpart rows and must not be touched -- recompute the verdict)
+    __shared__ int s_h, s_ok;
+    if (threadIdx.x == 0) {
+        int h = -1, big = 0;
+        for (int i = 0; i < n; ++i) if (a.rowptr_out[o + i + 1] - a.rowptr_out[o + i] >= 3) { h = i; ++big; }
+        if (big == 0) {
+            for (int i = 0; i < n && h < 0; ++i) {
+                const int e0 = a.rowptr_out[o + i];
+                if (a.rowptr_out[o + i + 1] - e0 == 2) { const int d0 = a.col_dst[e0], d1 = a.col_dst[e0 + 1]; h = ((d0 == o + i) ? d1 : d0) - o; }
+            }
+            if (h < 0) h = (n == 1) ? 0 : -1;
+        }
+        s_h = h; s_ok = (big <= 1 && h >= 0 && h < n) ? 1 : 0;
+    }
+    __syncthreads();
+    if (!s_ok) return;
+    const int bl = (o + n - 1) / a.npw;
+    float* dst = a.d_Y + (long long)(o + s_h) * a.ld_dy;
+    for (int c = threadIdx.x; c < a.F; c += 256) {
+        float v = dst[c];
+        for (int bb = bh + 1; bb <= bl; ++bb) v += a.hpart[(long long)bb * a.F + c];
+        dst[c] = v;
+    }
+}
+
 // Softmax + leaky-relu backward of a GATLayer's attention from the raw d alpha of the fused sweep, edge level:
 //   dz_p = alpha_p (dal_p - sum_q alpha_q dal_q) leaky'(a_src[u_p] + a_dst[v]);  d a_dst[v] = sum_in dz;  d a_src[u] = sum_out dz
 // written into the a1 / a2 columns of d_Y (and zeros into its padding columns).  A workgroup owns FA_GRAPHS consecutive graphs:
@@ -2302,9 +2647,13 @@ __device__ __forceinline__ void gat_attn_bwd_job(const int bid, const AttnBwdArg
 }
 // The attention backward of the layer below and stage 1 of the folded layer's reductions depend on the fused sweep only, not on each
 // other: one launch, the first nb_attn workgroups do the former.
-__global__ __launch_bounds__(256) void gat_attn_bwd_reduce_a_kernel(const AttnBwdArgs aa, const int nb_attn, const TailA a) {
-    if ((int)blockIdx.x < nb_attn) { gat_attn_bwd_job(blockIdx.x, aa); return; }
-    reduce_a_job((int)blockIdx.x - nb_attn, a);
+// ... and (after the egonet-walking sweep) the hubs of graphs cut by its window boundaries: nb_fix = windows - 1 more workgroups.
+__global__ __launch_bounds__(256) void gat_attn_bwd_reduce_a_kernel(const AttnBwdArgs aa, const int nb_attn, const TailA a, const HubFixArgs hf,
+                                                                    const int nb_fix) {
+    if ((int)blockIdx.x < nb_fix) { fused_hub_fixup_job((int)blockIdx.x + 1, hf); return; }
+    const int bid = (int)blockIdx.x - nb_fix;
+    if (bid < nb_attn) { gat_attn_bwd_job(bid, aa); return; }
+    reduce_a_job(bid - nb_attn, a);
 }
 
 struct CollapseWs {
@@ -2561,7 +2910,7 @@ int txe_gat_collapse_bwd(const int* rowptr_in, const int* col_src, const int* ro
 namespace txe {
 struct FusedWs {
     CollapseWs c;
-    float *dal, *dwa_part, *ppart;
+    float *dal, *dwa_part, *ppart, *hpart;
     int nblocks, npw;
     size_t total;
 };
@@ -2577,6 +2926,7 @@ static FusedWs plan_fused_ws(void* ws, int n, int e, int G, int Kp, int D, int P
     f.dal = take((size_t)(e > 0 ? e : 1) * Hp * 4);
     f.dwa_part = take((size_t)nb1 * 2 * Kp * 4);
     f.ppart = take((size_t)nb1 * (vocab > 0 ? vocab : 1) * (Pd > 0 ? Pd : 1) * 4);
+    f.hpart = take(Hp == 4 ? (size_t)nb1 * Kp * 4 : 4);             // (the egonet walk: H*D = Kh <= Kp floats per window)
     f.total = off;
     return f;
 }
@@ -2602,6 +2952,7 @@ size_t txe_gat_collapse_bwd_fused_ws_bytes(int n_nodes, int n_edges, int G, int 
 // layers (1 = none).  dP / d_pw / dW / d_attn as txe_gat_collapse_bwd.  phases: 15 = everything; or, for a caller that overlaps the
 // independent weight-gradient GEMM with the sweeps on a second stream, separate calls with 1 (dZ GEMM), 2 (dW GEMM partials: needs
 // only d_hg and Z), 4 (sweeps + first reduction stage: needs 1), 8 (final reductions: needs 2 and 4) and the same workspace.
+// phases | 1024: the source-side sweep does not walk egonets from registers (gat_fused_bwd_kernel for every head count: the A/B switch).
 int txe_gat_collapse_bwd_fused(const int* rowptr_in, const int* col_src, const int* rowptr_out, const int* col_dst, const int* pos_out,
                                const int* graph_off, int n_nodes, int n_edges, int G, const float* X, int Kh, int Pd, const int* pos,
                                int vocab, const float* Wp, const float* W, const float* attn_l, const float* attn_r, int D,
@@ -2696,15 +3047,24 @@ int txe_gat_collapse_bwd_fused(const int* rowptr_in, const int* col_src, const i
             a.drop_scale = 1.f / (1.f - attn_drop_p_p); a.seed = seed_p;
             a.d_Y = d_Yp; a.ld_dy = ld_dyp; a.dal = fw.dal; a.dwa_part = fw.dwa_part; a.ppart = fw.ppart;
             a.npw = fw.npw;
+            a.rowptr_in = rowptr_in; a.col_src = col_src; a.goff = graph_off; a.ggid = gid; a.G = G; a.hpart = fw.hpart;
             const int nvec = F / 16, ni = (nvec + 63) / 64, nwh = 4 / Hp;
             // algorithmic bytes: read X' (own row + once per out-edge is an L2 matter), dZ, Y; write d_Y
             char name[64];
-            snprintf(name, sizeof(name), "gat_fused_bwd_kernel<%s, %d, %d>", mk ? "true" : "false", ni, nwh);
+            const bool ego = Hp == 4 && !(phases & 1024);            // one head per wave: the egonet-walking variant (generic graphs inside)
+            if (ego) snprintf(name, sizeof(name), "gat_fused_bwd_ego_kernel<%s, %d>", mk ? "true" : "false", ni);
+            else snprintf(name, sizeof(name), "gat_fused_bwd_kernel<%s, %d, %d>", mk ? "true" : "false", ni, nwh);
             ProfScope prof(name, s, 4.0 * (n_nodes * ((double)Kp + 2.0 * F) + (double)G * Kp), 1);
 #define TXE_FB(M_, NI_, NW_) hipLaunchKernelGGL((gat_fused_bwd_kernel<M_, NI_, NW_>), dim3(fw.nblocks), dim3(256), (size_t)(4 * Kp + a.vocab * (Pd > 0 ? Pd : 1)) * sizeof(float), s, a)
 #define TXE_FB_NI(M_, NW_) do { if (ni == 1) TXE_FB(M_, 1, NW_); else if (ni == 2) TXE_FB(M_, 2, NW_); else if (ni == 3) TXE_FB(M_, 3, NW_); else TXE_FB(M_, 4, NW_); } while (0)
 #define TXE_FB_NW(M_) do { if (nwh == 1) TXE_FB_NI(M_, 1); else if (nwh == 2) TXE_FB_NI(M_, 2); else TXE_FB_NI(M_, 4); } while (0)
-            if (mk) TXE_FB_NW(true); else TXE_FB_NW(false);
+            if (ego) {
+#define TXE_FBE(M_, NI_) hipLaunchKernelGGL((gat_fused_bwd_ego_kernel<M_, NI_>), dim3(fw.nblocks), dim3(256), (size_t)(4 * Kp + a.vocab * (Pd > 0 ? Pd : 1)) * sizeof(float), s, a)
+#define TXE_FBE_NI(M_) do { if (ni == 1) TXE_FBE(M_, 1); else if (ni == 2) TXE_FBE(M_, 2); else if (ni == 3) TXE_FBE(M_, 3); else TXE_FBE(M_, 4); } while (0)
+                if (mk) TXE_FBE_NI(true); else TXE_FBE_NI(false);
+#undef TXE_FBE_NI
+#undef TXE_FBE
+            } else if (mk) TXE_FB_NW(true); else TXE_FB_NW(false);
 #undef TXE_FB_NW
 #undef TXE_FB_NI
 #undef TXE_FB
@@ -2725,8 +3085,11 @@ int txe_gat_collapse_bwd_fused(const int* rowptr_in, const int* col_src, const i
     AttnBwdArgs aa{rowptr_in, col_src, rowptr_out, pos_out, graph_off, G, Yp, ld_yp, Hp, F, attn_slope_p, alpha_p, (const float*)fw.dal, dz_p, d_Yp,
                    ld_dyp, n_pad};
     const int nb_attn = attn ? (G + FA_GRAPHS - 1) / FA_GRAPHS : 0;
+    const bool ego = Hp == 4 && !(phases & 1024) && attn;
+    HubFixArgs hf{graph_off, gid, rowptr_out, col_dst, n_nodes, fw.npw, fw.nblocks, F, fw.hpart, d_Yp, ld_dyp};
+    const int nb_fix = ego ? fw.nblocks - 1 : 0;
     ProfScope prof("gat_attn_bwd_reduce_a_kernel", s, attn ? 4.0 * (n_edges * (4.0 * Hp + 2.0) + n_nodes * (4.0 * Hp + n_pad)) : 0.0, 1);
-    hipLaunchKernelGGL(gat_attn_bwd_reduce_a_kernel, dim3(nb_attn + ta.nb_s1b + ta.nb_r), dim3(256), 0, s, aa, nb_attn, ta);
+    hipLaunchKernelGGL(gat_attn_bwd_reduce_a_kernel, dim3(nb_fix + nb_attn + ta.nb_s1b + ta.nb_r), dim3(256), 0, s, aa, nb_attn, ta, hf, nb_fix);
     TXE_CHECK_LAUNCH();
     }
     if (!(phases & 8)) return TXE_OK;

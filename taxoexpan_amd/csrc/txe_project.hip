@@ -1958,11 +1958,11 @@ struct FusedBwdArgs {
 // Source nodes per workgroup of the fused sweep.  The kernel holds 3 workgroups per CU; its workgroups cost about (nodes + 6) each (LDS
 // staging of the folded rows, the partial rows written at the end), and a last partial round costs a whole one: on the 18 k-node
 // training batch 24 nodes make 745 workgroups = one round of 768 (141 us), 16 make 1.46 rounds (153 us), 32 three quarters of one (154 us).
-static inline int fb_nodes_per_wg(int n_nodes) {
-    const int slots = 3 * device_cu_count();
+static inline int fb_nodes_per_wg(int n_nodes, int occupancy = 3) {
+    const int slots = occupancy * device_cu_count();
     int best = 16;
     double best_cost = 1e30;
-    for (int npw = 12; npw <= FB_NODES; npw += 4) {
+    for (int npw = 12; npw <= FB_NODES; npw += 2) {
         const long long blocks = ((long long)n_nodes + npw - 1) / npw;
         const double cost = (double)((blocks + slots - 1) / slots) * (npw + 6.0);
         if (cost <= best_cost) { best_cost = cost; best = npw; }     // (ties: fewer, larger workgroups)
@@ -2218,14 +2218,22 @@ enum { EGO_SKIP = 0, EGO_HUB = 1, EGO_PRE = 2, EGO_POST = 3, EGO_FOREIGN = 4 };
 // list position (local index t inside a hub-shaped graph with hub h) -> local node index
 __device__ __forceinline__ int ego_node_of(int t, int h) { return t == 0 ? h : (t <= h ? t - 1 : t); }
 
+#ifndef TXE_EGO_OCC
+#define TXE_EGO_OCC 3
+#endif
+#ifndef TXE_EGO_SLOTS
+#define TXE_EGO_SLOTS 1
+#endif
 template <bool MASK, int NI>
-__global__ __launch_bounds__(256, (NI >= 3) ? 2 : 3) void gat_fused_bwd_ego_kernel(const FusedBwdArgs a) {
+__global__ __launch_bounds__(256, (NI >= 3) ? 2 : TXE_EGO_OCC) void gat_fused_bwd_ego_kernel(const FusedBwdArgs a) {
     __shared__ int s_v[4], s_p[4], s_ni[4 * FB_NODES];                         // (the generic body's per-node table; its edge tables are not used)
     __shared__ float s_cn[4], s_g1[4], s_g2[4], s_nf[4 * FB_NODES];
     __shared__ float s_dot[4][4];
     // per list position of the window (+ one entry for a foreign hub, + one skip entry that pads an odd count)
     __shared__ int t_node[FB_NODES + 2], t_role[FB_NODES + 2], t_self[FB_NODES + 2], t_hub[FB_NODES + 2], t_dz[FB_NODES + 2], t_pos[FB_NODES + 2];
     __shared__ float t_cn[FB_NODES + 2], t_g1[FB_NODES + 2], t_g2[FB_NODES + 2];
+    // per position and head: alpha' = alpha * dropout factor and the factor itself, of the self loop [0..3] and of the edge with the hub [4..7]
+    __shared__ float t_coef[FB_NODES + 2][8], t_fd[FB_NODES + 2][8];
     // per node of the intersecting graphs (staging)
     __shared__ int n_deg[EGO_TAB], n_tgt[EGO_TAB], n_role[EGO_TAB], n_self[EGO_TAB], n_hubp[EGO_TAB];
     __shared__ int g_hub[FB_NODES], g_ok[FB_NODES];
@@ -2243,6 +2251,7 @@ __global__ __launch_bounds__(256, (NI >= 3) ? 2 : 3) void gat_fused_bwd_ego_kern
     const int tb = (a.goff[gF + 1] - offF <= EGO_MAXN) ? offF : u0;           // first / one-past-last node with a staging entry
     const int te = (endL - a.goff[gL] <= EGO_MAXN) ? endL : u1;                // (only the first and the last graph reach outside the window)
     for (int i = tid; i < FB_NODES + 2; i += 256) { t_node[i] = u0; t_role[i] = EGO_SKIP; t_self[i] = 0; t_hub[i] = 0; t_dz[i] = 0; t_pos[i] = 0; t_cn[i] = 0.f; t_g1[i] = 0.f; t_g2[i] = 0.f; }
+    for (int i = tid; i < (FB_NODES + 2) * 8; i += 256) { t_coef[i >> 3][i & 7] = 0.f; t_fd[i >> 3][i & 7] = 0.f; }
     for (int i = tid; i < a.vocab * a.Pd; i += 256) s_dp[i] = 0.f;
     for (int i = tid * 4; i < 2 * Kp; i += 1024) {
         *reinterpret_cast<float4*>(s_wa + i) = *reinterpret_cast<const float4*>(a.wa + i);
@@ -2324,6 +2333,17 @@ __global__ __launch_bounds__(256, (NI >= 3) ? 2 : 3) void gat_fused_bwd_ego_kern
         }
     }
     __syncthreads();
+    // (5) the edge scalars of every (position, edge, head): one thread each -- the walk reads them from LDS
+    for (int i = tid; i < (nw + 1) * 8; i += 256) {
+        const int t = i >> 3, e = (i >> 2) & 1, hd = i & 3;
+        if (t_role[t] != EGO_SKIP) {
+            const long long idx = (long long)(e ? t_hub[t] : t_self[t]) * a.H + hd;
+            const float fd = (a.drop_p > 0.f) ? drop_factor(a.seed, (unsigned long long)idx, a.drop_p, a.drop_scale) : 1.f;
+            t_fd[t][i & 7] = fd;
+            t_coef[t][i & 7] = a.alpha[idx] * fd;
+        }
+    }
+    __syncthreads();
 
     const int w = uni((int)(tid >> 6)), l = tid & 63;
     const int F = a.H * a.D, SL = F >> 2, nvec = SL >> 2;
@@ -2360,21 +2380,21 @@ __global__ __launch_bounds__(256, (NI >= 3) ? 2 : 3) void gat_fused_bwd_ego_kern
         }
     };
 
-    // the walk: entry nw (a foreign hub, or a skip) first, paired with position 0; then two positions per round trip
-    for (int t0 = -1; t0 < nw; t0 += 2) {
+    // the walk, NS entries per round trip: entry nw first if it is a foreign hub, then the positions
+    constexpr int NS = TXE_EGO_SLOTS;
+    for (int t0 = (t_role[nw] == EGO_FOREIGN) ? -1 : 0; t0 < nw; t0 += NS) {
         // ---- every load of the two entries first (rows, masks, edge scalars), nothing in between ----
-        int vv[2], role[2], ps[2], ph[2], pv[2];
-        float cnv[2], g1v[2], g2v[2], als[2], alh[2];
-        float ft[2][NI][4], xv[2][NI][4], dz[2][NI][4], xt[2][4], dzt[2][4];
-        unsigned mv[2][NI], mt[2];
+        int vv[NS], role[NS], ps[NS], ph[NS], pv[NS];
+        float cnv[NS], g1v[NS], g2v[NS], cfs[NS], fds[NS], cfh[NS], fdh2[NS];
+        float ft[NS][NI][4], xv[NS][NI][4], dz[NS][NI][4], xt[NS][4], dzt[NS][4];
+        unsigned mv[NS][NI], mt[NS];
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
+        for (int q = 0; q < NS; ++q) {
             const int t = (t0 + q < 0) ? nw : ((t0 + q < nw) ? t0 + q : FB_NODES + 1);     // (FB_NODES + 1: an entry that stays EGO_SKIP)
             vv[q] = uni(t_node[t]); role[q] = uni(t_role[t]); ps[q] = uni(t_self[t]); ph[q] = uni(t_hub[t]); pv[q] = t_pos[t];
             cnv[q] = uni(t_cn[t]); g1v[q] = uni(t_g1[t]); g2v[q] = uni(t_g2[t]);
             const int dzr = uni(t_dz[t]);
-            als[q] = a.alpha[(long long)ps[q] * a.H + hw];
-            alh[q] = a.alpha[(long long)ph[q] * a.H + hw];
+            cfs[q] = uni(t_coef[t][hw]); fds[q] = uni(t_fd[t][hw]); cfh[q] = uni(t_coef[t][4 + hw]); fdh2[q] = uni(t_fd[t][4 + hw]);
 #pragma unroll
             for (int i = 0; i < NI; ++i) {
                 vload<4>(a.Y + (long long)vv[q] * a.ld_y + off[i], ft[q][i]);
@@ -2386,15 +2406,29 @@ __global__ __launch_bounds__(256, (NI >= 3) ? 2 : 3) void gat_fused_bwd_ego_kern
             vload<4>(a.dZ + (long long)dzr * Kp + tc, dzt[q]);
             mt[q] = fb_keep<MASK>(a.mask, a.mask_ld, vv[q], tc);
         }
+#if defined(TXE_EGO_X) && TXE_EGO_X == 1
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
+        for (int q = 0; q < NS; ++q) {
+            if (role[q] == EGO_SKIP || role[q] == EGO_FOREIGN) continue;
+            float acc[NI][4];
+#pragma unroll
+            for (int i = 0; i < NI; ++i)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) acc[i][k] = ft[q][i][k] + xv[q][i][k] + dz[q][i][k] + xt[q][k] + dzt[q][k] + cfs[q] + cfh[q] + (float)(mv[q][i] + mt[q]);
+#pragma unroll
+            for (int i = 0; i < NI; ++i)
+                if (l + 64 * i < nvec) vstore<4>(a.d_Y + (long long)vv[q] * a.ld_dy + off[i], acc[i]);
+        }
+        continue;
+#endif
+#pragma unroll
+        for (int q = 0; q < NS; ++q) {
             if (role[q] == EGO_SKIP) continue;                        // (wave-uniform)
             const int v = vv[q];
             const bool own = role[q] != EGO_FOREIGN;                  // a foreign hub: d_pre and ft only -- its own-row work belongs to its home
             const float sc = cnv[q] * a.fscale, s1 = g1v[q] * a.fscale, s2 = g2v[q] * a.fscale;
             float dp[NI][4], acc[NI][4];
-            const float fd = (a.drop_p > 0.f) ? drop_factor(a.seed, (unsigned long long)ps[q] * a.H + hw, a.drop_p, a.drop_scale) : 1.f;
-            const float coef = als[q] * fd;
+            const float fd = fds[q], coef = cfs[q];
             const float go1 = own ? g1v[q] : 0.f, go2 = own ? g2v[q] : 0.f;
             float part = 0.f;
 #pragma unroll
@@ -2448,8 +2482,7 @@ __global__ __launch_bounds__(256, (NI >= 3) ? 2 : 3) void gat_fused_bwd_ego_kern
 #pragma unroll
                     for (int k = 0; k < 4; ++k) { fth[i][k] = ft[q][i][k]; pph[i][k] = dp[i][k]; acch[i][k] = own ? acc[i][k] : 0.f; }
             } else {
-                const float fdh = (a.drop_p > 0.f) ? drop_factor(a.seed, (unsigned long long)ph[q] * a.H + hw, a.drop_p, a.drop_scale) : 1.f;
-                const float coefh = alh[q] * fdh;
+                const float fdh = fdh2[q], coefh = cfh[q];
                 float part2 = 0.f;
                 if (role[q] == EGO_PRE) {          // edge v -> hub: d_pre[hub] against this node's ft, accumulated into this node's d_ft
 #pragma unroll
@@ -2914,13 +2947,13 @@ struct FusedWs {
     int nblocks, npw;
     size_t total;
 };
-static FusedWs plan_fused_ws(void* ws, int n, int e, int G, int Kp, int D, int Pd, int vocab, int Hp, int max_splits = 0) {
+static FusedWs plan_fused_ws(void* ws, int n, int e, int G, int Kh, int Kp, int D, int Pd, int vocab, int Hp, int max_splits = 0) {
     FusedWs f;
     f.c = plan_collapse_ws(ws, n, e, G, Kp, D, Pd, vocab, max_splits);
     char* b = (char*)ws;
     size_t off = f.c.total;
     auto take = [&](size_t bytes) { float* r = (float*)(b + off); off += align_up(bytes > 0 ? bytes : 4, 256); return r; };
-    f.npw = fb_nodes_per_wg(n);
+    f.npw = fb_nodes_per_wg(n, (Kh > 2048) ? 2 : 3);                // (rows of more than 2,048 feature columns: NI >= 3, two workgroups per CU)
     f.nblocks = (n + f.npw - 1) / f.npw;
     const int nb1 = f.nblocks > 0 ? f.nblocks : 1;
     f.dal = take((size_t)(e > 0 ? e : 1) * Hp * 4);
@@ -2942,7 +2975,7 @@ int txe_gat_fused_bwd_supported(int Kh, int Pd, int Hp, int Dp) {
 }
 
 size_t txe_gat_collapse_bwd_fused_ws_bytes(int n_nodes, int n_edges, int G, int Kh, int Pd, int D, int vocab, int Hp) {
-    return plan_fused_ws(nullptr, n_nodes, n_edges, G, round_up(Kh + Pd, 32), D, Pd, vocab, Hp).total;
+    return plan_fused_ws(nullptr, n_nodes, n_edges, G, Kh, round_up(Kh + Pd, 32), D, Pd, vocab, Hp).total;
 }
 
 // txe_gat_collapse_bwd FUSED with txe_gat_aggregate_bwd of the layer below: same inputs as txe_gat_collapse_bwd plus
@@ -2979,7 +3012,7 @@ int txe_gat_collapse_bwd_fused(const int* rowptr_in, const int* col_src, const i
     if (feat_drop_p < 0.f || feat_drop_p >= 1.f || attn_drop_p < 0.f || attn_drop_p >= 1.f || attn_drop_p_p < 0.f || attn_drop_p_p >= 1.f)
         return TXE_ERR_ARG;
     const int Kt = Kh + Pd, Kp = round_up(Kt, 32), F = Hp * Dp;
-    FusedWs fw = plan_fused_ws(ws, n_nodes, n_edges, G, Kp, D, Pd, vocab, Hp, (phases & 128) ? DW_BESIDE_SPLITS : 0);
+    FusedWs fw = plan_fused_ws(ws, n_nodes, n_edges, G, Kh, Kp, D, Pd, vocab, Hp, (phases & 128) ? DW_BESIDE_SPLITS : 0);
     CollapseWs& p = fw.c;
     if (ws_bytes < fw.total) return TXE_ERR_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;

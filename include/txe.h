@@ -270,11 +270,14 @@ int txe_linear_bwd(const float* x1, long long ld1, int l, const float* x2, long 
 /* ---- all-candidate scoring loop: test_fast.py:116-123 / infer.py:95-99.  U = txe_bilinear_project(hg, W) once, then
  * per query block S[q][g] = match(hg[g], Q[q]) for every candidate g. */
 int txe_score_block(const float* Q, long long ld_q, int nq, const float* U, long long ld_u, int G, int r, int apply_exp, float* S,
-                    long long ld_s, void* ws, size_t ws_bytes, void* sws, size_t sws_bytes, void* stream);
+                    long long ld_s, void* ws, size_t ws_bytes, void* sws, size_t sws_bytes, const void* u_packed, void* stream);
 /* ws: optional, txe_gemm_tail_ws_bytes() of scratch.  sws (here and in the three entry points below; NULL = the fp32 MFMA): scratch of
  * txe_score_split_ws_bytes(nq, G or n_pos, r) bytes -- the product then runs on the bf16 matrix pipe in fp32 accuracy (txe_gemm_nt_split
  * below: Q and U are packed into sws per call) through the SAME epilogues.  The four entry points compare scores bit for bit among
- * themselves: give all of them a workspace or none. */
+ * themselves: give all of them a workspace or none.
+ * u_packed (NULL = pack here): the candidates' planes, txe_split_pack(U, ld_u, G, r, side 1, ...) into txe_split_packed_bytes(G, r) bytes,
+ * made ONCE per candidate set -- the loop over query blocks then packs only its queries, and sws needs txe_split_packed_bytes(nq, r)
+ * (rounded up to 256) bytes only.  Same planes, same kernel: bit-identical scores either way. */
 size_t txe_score_split_ws_bytes(int nq, int G, int r);
 
 /* fused scoring + ranking: the score tile is compared in the GEMM epilogue and never stored.  counts [pos_off[nq]] int32
@@ -282,7 +285,8 @@ size_t txe_score_split_ws_bytes(int nq, int G, int r);
  * true parent as computed by txe_score_block (bit-identical k-order).  txe_rank_finalize: ranks[j] = 1 + counts[j] - (the query's
  * other positives that beat j) -- metric.py:7-31. */
 int txe_score_count_block(const float* Q, long long ld_q, int nq, const float* U, long long ld_u, int G, int r, int apply_exp,
-                          const int* pos_off, const float* thr, int larger_is_better, int* counts, void* sws, size_t sws_bytes, void* stream);
+                          const int* pos_off, const float* thr, int larger_is_better, int* counts, void* sws, size_t sws_bytes,
+                          const void* u_packed, void* stream);
 int txe_rank_finalize(const int* pos_off, int nq, const float* thr, const int* counts, int larger_is_better, int* ranks, void* stream);
 /* the thresholds themselves: Up [n_pos][r] = the candidate rows of the queries' true parents, query by query (gathered by the caller);
  * thr[j] = match(Q[q], Up[j]) for j in [pos_off[q], pos_off[q+1]) -- the score kernel's own tiles (bit-identical values), but only the
@@ -303,7 +307,7 @@ int txe_score_positives(const float* Q, long long ld_q, int nq, const float* Up,
 int txe_score_topk_tiles(int G);
 int txe_score_topk_block(const float* Q, long long ld_q, int nq, const float* U, long long ld_u, int G, int r, int apply_exp,
                          int larger_is_better, int k, int idx_base, float* part_key, int* part_idx, int* floor_ws, int* out_idx,
-                         float* out_key, void* sws, size_t sws_bytes, void* stream);
+                         float* out_key, void* sws, size_t sws_bytes, const void* u_packed, void* stream);
 int txe_topk_merge(const float* keys, const int* idx, int nq, long long cnt, int k, int idx_base, int* out_idx, float* out_key,
                    void* stream);
 

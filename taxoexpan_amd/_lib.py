@@ -66,7 +66,7 @@ SIGNATURES = {
     "txe_bilinear_runs_bwd": (I, [P, L, P, L, P, I, I, I, I, I, P, P, P, P, L, P, P, SZ, P]),
     "txe_rows_find_runs": (I, [P, L, I, I, P, P, P, P]),
     "txe_score_topk_tiles": (I, [I]),
-    "txe_score_topk_block": (I, [P, L, I, P, L, I, I, I, I, I, I, P, P, P, P, P, P, SZ, P]),
+    "txe_score_topk_block": (I, [P, L, I, P, L, I, I, I, I, I, I, P, P, P, P, P, P, SZ, P, P]),
     "txe_topk_merge": (I, [P, P, I, L, I, I, P, P, P]),
     "txe_bilinear_stacked_fwd": (I, [P, L, P, L, P, P, I, I, I, P, I, P, P, P]),
     "txe_bilinear_stacked_bwd_ws_bytes": (SZ, [I, I, I]),
@@ -76,9 +76,9 @@ SIGNATURES = {
     "txe_bilinear_folded_bwd": (I, [P, L, I, I, P, L, I, P, L, I, P, P, I, I, I, P, P, P, P, P, L, P, P, P, P, I, I, P]),
     "txe_bilinear_pair_bwd_ws_bytes": (SZ, [I, I, I]),
     "txe_bilinear_pair_bwd": (I, [P, L, P, L, I, I, I, P, I, P, P, P, P, L, P, L, P, P, SZ, P]),
-    "txe_score_block": (I, [P, L, I, P, L, I, I, I, P, L, P, SZ, P, SZ, P]),
+    "txe_score_block": (I, [P, L, I, P, L, I, I, I, P, L, P, SZ, P, SZ, P, P]),
     "txe_score_split_ws_bytes": (SZ, [I, I, I]),
-    "txe_score_count_block": (I, [P, L, I, P, L, I, I, I, P, P, I, P, P, SZ, P]),
+    "txe_score_count_block": (I, [P, L, I, P, L, I, I, I, P, P, I, P, P, SZ, P, P]),
     "txe_score_positives": (I, [P, L, I, P, L, I, I, I, P, P, P, SZ, P]),
     "txe_rank_finalize": (I, [P, I, P, P, I, P, P]),
     "txe_gemm_tail_ws_bytes": (SZ, []),

@@ -757,17 +757,21 @@ static inline size_t score_split_bytes(int nq, int G, int r) {
     return a + b;
 }
 // 1 = done on the split route, 0 = not taken (no workspace), < 0 = error
+// u_packed: the candidates' planes (txe_split_pack(U, ld_u, G, r, side 1)) made ONCE per candidate set by the caller -- the loop over query
+// blocks then packs only its queries (a MAG-Full block packed 620 MB of U again for every 1,024 queries: 10.8 % of the inference profile)
 static int score_split(const float* Q, long long ld_q, int nq, const float* U, long long ld_u, int G, int r, const Epi& E, void* sws,
-                       size_t sws_bytes, hipStream_t s) {
+                       size_t sws_bytes, const void* u_packed, hipStream_t s) {
     if (!sws || nq < 1 || G < 1) return 0;
-    if (sws_bytes < score_split_bytes(nq, G, r)) return TXE_ERR_WORKSPACE;
-    char* w = (char*)sws;
     const size_t a = (split_packed_bytes(nq, r) + 255) / 256 * 256;
+    if (sws_bytes < (u_packed ? a : score_split_bytes(nq, G, r))) return TXE_ERR_WORKSPACE;
+    char* w = (char*)sws;
     int rc = split_pack_launch(Q, ld_q, nq, r, 0, w, s);
     if (rc) return rc;
-    rc = split_pack_launch(U, ld_u, G, r, 1, w + a, s);
-    if (rc) return rc;
-    rc = gemm_nt_split_epi_launch(w, w + a, E, nq, G, r, s);
+    if (!u_packed) {
+        rc = split_pack_launch(U, ld_u, G, r, 1, w + a, s);
+        if (rc) return rc;
+    }
+    rc = gemm_nt_split_epi_launch(w, u_packed ? u_packed : (const void*)(w + a), E, nq, G, r, s);
     return rc ? rc : 1;
 }
 }  // namespace txe
@@ -776,7 +780,7 @@ size_t txe_score_split_ws_bytes(int nq, int G, int r) { return (nq < 1 || G < 1 
 
 // One block of the scoring loop: S[q][g] = <Q[q], U[g]> (exp optionally), q < nq, g < G.  S row stride ld_s.
 int txe_score_block(const float* Q, long long ld_q, int nq, const float* U, long long ld_u, int G, int r, int apply_exp, float* S,
-                    long long ld_s, void* ws, size_t ws_bytes, void* sws, size_t sws_bytes, void* stream) {
+                    long long ld_s, void* ws, size_t ws_bytes, void* sws, size_t sws_bytes, const void* u_packed, void* stream) {
     if (nq < 0 || G < 0 || r < 1 || ld_u < r || !Q || !U || !S) return TXE_ERR_ARG;
     VMat A = vmat_plain(Q, ld_q, nq, r);
     VMat B = vmat_plain(U, ld_u, G, r);
@@ -787,7 +791,7 @@ int txe_score_block(const float* Q, long long ld_q, int nq, const float* U, long
     // scores of different launches (thresholds from here, the count epilogue's own tiles) bit for bit
     E.plain_k_order = 1;
     {
-        const int sr = score_split(Q, ld_q, nq, U, ld_u, G, r, E, sws, sws_bytes, (hipStream_t)stream);
+        const int sr = score_split(Q, ld_q, nq, U, ld_u, G, r, E, sws, sws_bytes, u_packed, (hipStream_t)stream);
         if (sr != 0) return sr < 0 ? sr : TXE_OK;
     }
     const bool ok = ws && ws_bytes >= gemm_tail_ws_bytes();
@@ -811,7 +815,7 @@ int txe_score_positives(const float* Q, long long ld_q, int nq, const float* Up,
     E.plain_k_order = 1;
     E.alg_flops = 2.0 * n_pos * (double)r;           // the pairs that are wanted
     {
-        const int sr = score_split(Q, ld_q, nq, Up, ld_u, n_pos, r, E, sws, sws_bytes, (hipStream_t)stream);
+        const int sr = score_split(Q, ld_q, nq, Up, ld_u, n_pos, r, E, sws, sws_bytes, nullptr, (hipStream_t)stream);
         if (sr != 0) return sr < 0 ? sr : TXE_OK;
     }
     return gemm_nt(A, B, E, nq, n_pos, r, 1, (hipStream_t)stream);
@@ -823,7 +827,8 @@ int txe_score_positives(const float* Q, long long ld_q, int nq, const float* Up,
 // rows: identical k-order, hence bit-identical values); counts are int32, zeroed by the caller, accumulated with atomics --
 // exact and order independent.  Candidates may be a shard: counts of shards add.  txe_rank_finalize turns them into ranks.
 int txe_score_count_block(const float* Q, long long ld_q, int nq, const float* U, long long ld_u, int G, int r, int apply_exp,
-                          const int* pos_off, const float* thr, int larger_is_better, int* counts, void* sws, size_t sws_bytes, void* stream) {
+                          const int* pos_off, const float* thr, int larger_is_better, int* counts, void* sws, size_t sws_bytes,
+                          const void* u_packed, void* stream) {
     if (nq < 0 || G < 0 || r < 1 || ld_u < r || !Q || !U || !pos_off || !thr || !counts) return TXE_ERR_ARG;
     if (nq == 0 || G == 0) return TXE_OK;
     VMat A = vmat_plain(Q, ld_q, nq, r);
@@ -833,7 +838,7 @@ int txe_score_count_block(const float* Q, long long ld_q, int nq, const float* U
     E.cnt_mode = larger_is_better ? 1 : 2;
     E.cnt_off = pos_off; E.cnt_thr = thr; E.cnt_out = counts;
     {
-        const int sr = score_split(Q, ld_q, nq, U, ld_u, G, r, E, sws, sws_bytes, (hipStream_t)stream);
+        const int sr = score_split(Q, ld_q, nq, U, ld_u, G, r, E, sws, sws_bytes, u_packed, (hipStream_t)stream);
         if (sr != 0) return sr < 0 ? sr : TXE_OK;
     }
     return gemm_nt(A, B, E, nq, G, r, 1, (hipStream_t)stream);
@@ -858,7 +863,7 @@ extern "C" {
 
 int txe_score_topk_block(const float* Q, long long ld_q, int nq, const float* U, long long ld_u, int G, int r, int apply_exp,
                          int larger_is_better, int k, int idx_base, float* part_key, int* part_idx, int* floor_ws, int* out_idx,
-                         float* out_key, void* sws, size_t sws_bytes, void* stream) {
+                         float* out_key, void* sws, size_t sws_bytes, const void* u_packed, void* stream) {
     if (nq < 0 || G < 1 || r < 1 || ld_u < r || k < 1 || k > TOPK_MAX || !Q || !U || !part_key || !part_idx || !floor_ws || !out_idx)
         return TXE_ERR_ARG;
     if (nq == 0) return TXE_OK;
@@ -871,7 +876,7 @@ int txe_score_topk_block(const float* Q, long long ld_q, int nq, const float* U,
     E.cnt_mode = larger_is_better ? 4 : 5;
     E.topk_k = k; E.topk_key = part_key; E.topk_idx = part_idx; E.topk_floor = floor_ws;
     E.force_bn128 = 1;                                              // (the scratch layout counts 128-wide column tiles)
-    int rc = score_split(Q, ld_q, nq, U, ld_u, G, r, E, sws, sws_bytes, (hipStream_t)stream);
+    int rc = score_split(Q, ld_q, nq, U, ld_u, G, r, E, sws, sws_bytes, u_packed, (hipStream_t)stream);
     if (rc < 0) return rc;
     if (rc == 0) rc = gemm_nt(A, B, E, nq, G, r, 1, (hipStream_t)stream);
     else rc = TXE_OK;

@@ -1581,10 +1581,31 @@ def bilinear_project(hg, W):
         sws = _ws(swb, hg) if swb else None
         call("txe_bilinear_project", ptr(hg), ld, G, l, ptr(Wf), rp, ptr(Ufull), rp, ptr(sws), swb, _lib.stream_ptr())
     _ZERO_PADDED[U.data_ptr()] = (rp, weakref.ref(Ufull))
+    if not _NO_SPLIT_GEMM and G >= 1:
+        # the candidates' bf16 planes for the scoring loop, once per candidate set (every score_* call on this U finds them: the loop
+        # over query blocks packs only its queries).  U is never written after this point -- the planes ARE this U.
+        with _lib.on_device(hg.device):
+            planes = torch.empty(pure("txe_split_packed_bytes", G, rp), dtype=torch.uint8, device=hg.device)
+            call("txe_split_pack", ptr(Ufull), rp, G, rp, 1, ptr(planes), _lib.stream_ptr())
+        key = U.data_ptr()
+        _PACKED_U[key] = (rp, G, weakref.ref(Ufull, lambda _ref, key=key: _PACKED_U.pop(key, None)), planes)    # (the planes die with their U)
     return U
 
 
 _ZERO_PADDED = {}      # data_ptr of a U made by bilinear_project -> (zero-padded row width, weak reference to its storage)
+_PACKED_U = {}         # ... -> (contraction width, rows, weak reference to its storage, the packed bf16 planes of side 1)
+
+
+def _u_planes(U, r):
+    """the planes bilinear_project packed for this very U (all its rows, contraction width r), or None"""
+    ent = _PACKED_U.get(U.data_ptr())
+    if ent is None or _NO_SPLIT_GEMM:
+        return None
+    rp, G, ref, planes = ent
+    if ref() is None:
+        del _PACKED_U[U.data_ptr()]
+        return None
+    return planes if (rp == r and U.shape[0] == G and U.stride(0) == rp) else None
 
 
 def _padded_width(U, r):
@@ -1622,12 +1643,13 @@ def _pad_queries(Q, r, rp):
     return Qp
 
 
-def _score_sws(nq, G, r, ref):
+def _score_sws(nq, G, r, ref, u_packed=False):
     """scratch with which a scoring entry point runs on the bf16 matrix pipe: (tensor, bytes), or (None, 0) on the fp32-MFMA
-    route.  The four entry points compare scores bit for bit among themselves: the switch is one module attribute for all of them."""
+    route.  The four entry points compare scores bit for bit among themselves: the switch is one module attribute for all of them.
+    u_packed: the candidates' planes exist already (_u_planes) -- room for the queries' only."""
     if _NO_SPLIT_GEMM or nq < 1 or G < 1:
         return None, 0
-    n = pure("txe_score_split_ws_bytes", int(nq), int(G), int(r))
+    n = (pure("txe_split_packed_bytes", int(nq), int(r)) + 255) // 256 * 256 if u_packed else pure("txe_score_split_ws_bytes", int(nq), int(G), int(r))
     return _ws(n, ref), n
 
 
@@ -1649,9 +1671,10 @@ def score_block(Q, U, apply_exp, out=None):
     S = out if out is not None else _empty((nq, (G + 3) // 4 * 4), Q)[:, :G]     # 16-byte row pitch: vector stores / rank sweeps
     with _lib.on_device(Q.device):
         tws = _tail_ws(Q)
-        sws, swb = _score_sws(nq, G, r, Q)
+        up = _u_planes(U, r)
+        sws, swb = _score_sws(nq, G, r, Q, up is not None)
         call("txe_score_block", ptr(Q), ldq, nq, ptr(U), ldu, G, r, int(apply_exp), ptr(S), S.stride(0), ptr(tws), tws.numel(), ptr(sws), swb,
-             _lib.stream_ptr())
+             ptr(up), _lib.stream_ptr())
     return S
 
 
@@ -1733,9 +1756,10 @@ def score_count_block(Q, U, apply_exp, pos_off, thr, larger_is_better=True, coun
         return counts
     assert counts.dtype == torch.int32 and counts.is_contiguous() and counts.numel() >= thr.numel()
     with _lib.on_device(Q.device):
-        sws, swb = _score_sws(nq, U.shape[0], r, Q)
+        up = _u_planes(U, r)
+        sws, swb = _score_sws(nq, U.shape[0], r, Q, up is not None)
         call("txe_score_count_block", ptr(Q), ldq, nq, ptr(U), ldu, U.shape[0], r, int(apply_exp), ptr(pos_off), ptr(thr),
-             int(larger_is_better), ptr(counts), ptr(sws), swb, _lib.stream_ptr())
+             int(larger_is_better), ptr(counts), ptr(sws), swb, ptr(up), _lib.stream_ptr())
     return counts
 
 
@@ -1771,14 +1795,15 @@ def score_topk_block(Q, U, apply_exp, k, larger_is_better=True, idx_base=0, q_pa
         return idx, key
     with _lib.on_device(Q.device):
         nt = pure("txe_score_topk_tiles", G)
-        sws, swb = _score_sws(nq, G, r, Q)
+        up = _u_planes(U, r)
+        sws, swb = _score_sws(nq, G, r, Q, up is not None)
         need = nq * nt * k
         sc = scratch if scratch is not None else {}
         if sc.get("n", 0) < need or sc.get("nq", 0) < nq or sc["key"].device != Q.device:
             sc["key"], sc["idx"], sc["n"] = _empty((need,), Q), torch.empty(need, dtype=torch.int32, device=Q.device), need
             sc["floor"], sc["nq"] = torch.empty(nq, dtype=torch.int32, device=Q.device), nq
         call("txe_score_topk_block", ptr(Q), ldq, nq, ptr(U), ldu, G, r, int(apply_exp), int(larger_is_better), int(k), int(idx_base),
-             ptr(sc["key"]), ptr(sc["idx"]), ptr(sc["floor"]), ptr(idx), ptr(key), ptr(sws), swb, _lib.stream_ptr())
+             ptr(sc["key"]), ptr(sc["idx"]), ptr(sc["floor"]), ptr(idx), ptr(key), ptr(sws), swb, ptr(up), _lib.stream_ptr())
     return idx, key
 
 

@@ -13,7 +13,7 @@ torch.autograd.set_multithreading_enabled(False)
 tax = syn.make_named_taxonomy("mag_cs", seed=47)
 torch.manual_seed(47)
 model = bench.make_model("pgat", dev)
-opt = Adam(model.parameters(), lr=1e-3, weight_decay=0, amsgrad=True)
+opt = Adam(model.parameters(), lr=bench.LR, weight_decay=0, amsgrad=True)
 batches = bench.build_batches(tax, 4, seed0=1000, device=dev)
 target = torch.zeros(bench.N_QUERIES, dtype=torch.long, device=dev)
 DELAY = {"name": None, "us": 0.0}

@@ -105,8 +105,10 @@ int txe_gat_dense_bwd(const float* X, int n_nodes, int Kh, int Pd, const int* po
                       const float* attn_l, const float* attn_r, int H, int D, float feat_drop_p, const unsigned* mask, const float* d_Y,
                       int need_dh, int act_on, float act_slope, float* d_X, float* dW, float* d_attn_l, float* d_attn_r, float* dP,
                       int x_dropped, const void* Xt, int phases, void* chain, void* ws, size_t ws_bytes, void* stream);
-/* ws_bytes >= txe_gat_dense_ws_bytes + txe_gat_dense_bwd_split_ws_bytes and need_dh: d_X = d_Y Wp (the whole input gradient of a layer
- * above the first) runs on the bf16 matrix pipe in fp32 accuracy, dropout mask and leaky' factor applied in its store loop. */
+/* phases | 16 and need_dh: d_X = d_Y Wp (the whole input gradient of a layer above the first) runs on the bf16 matrix pipe in fp32
+ * accuracy, dropout mask and leaky' factor applied in its store loop; its packed operands live behind the workspace:
+ * ws_bytes >= txe_gat_dense_ws_bytes + txe_gat_dense_bwd_split_ws_bytes, else TXE_ERR_WORKSPACE.  Without the bit: the fp32 MFMA,
+ * whatever the size of the buffer -- the route is the caller's explicit choice. */
 size_t txe_gat_dense_bwd_split_ws_bytes(int n_nodes, int Kh, int Pd, int H, int D);
 /* phases: 7 = all of it; 1 | 2 | 4 = d_X | the weight-gradient product (split-K partial slices) | the reductions that finish dW,
  * d_attn, dP -- 1 and 2 are independent, 4 needs both.
@@ -346,7 +348,9 @@ size_t txe_gat_collapse_split_ws_bytes(int G, int Kh, int Pd, int D);
 int txe_gat_collapse_fwd(const int* rowptr_in, const int* col_src, const int* rowptr_out, const int* col_dst, const int* pos_out,
                          const int* graph_off, int n_nodes, int n_edges, int G, const float* X, int Kh, int Pd, const float* Wp, int D,
                          float feat_drop_p, const unsigned* mask, float attn_slope, float attn_drop_p, unsigned long long seed,
-                         const int* pos, const float* pw, float* a12, int a12_ready, float* alpha, float* coef, float* wsum, int* gid, float* Z,
+                         const int* pos, const float* pw, float* a12, int a12_ready /* bit 0: a12 holds the logits already; bit 1: hg = Z W^T on
+                         the bf16 matrix pipe -- ws_bytes >= txe_gat_collapse_ws_bytes + txe_gat_collapse_split_ws_bytes, else TXE_ERR_WORKSPACE */,
+                         float* alpha, float* coef, float* wsum, int* gid, float* Z,
                          float* hg, long long ld_hg /* hg NULL: stop at Z (the consumer folds hg = Z W^T: txe_bilinear_folded_*) */,
                          const float* Tf, const int* zrow, float* e_part /* all NULL, or (with hg NULL): see phases | 512 below */, void* ws,
                          size_t ws_bytes, void* stream);

@@ -178,12 +178,21 @@ def call(name, *args):
 
 
 _pure = {}
+_get_device = None
+
+
+def _current_device():
+    global _get_device
+    if _get_device is None:
+        import torch
+        _get_device = torch._C._cuda_getDevice if torch.cuda.is_available() else (lambda: -1)
+    return _get_device()
 
 
 def pure(name, *args):
     """call() for the entry points that are pure functions of their integer arguments (and of the device's CU count): padded widths,
     workspace sizes, `*_supported` predicates -- the answer is cached (a ctypes call costs the host 2-4 us; a step asks ~10 of them)"""
-    key = (name,) + args
+    key = (name, _current_device()) + args              # (the plans depend on the device's CU count)
     v = _pure.get(key)
     if v is None:
         if len(_pure) > 4096:

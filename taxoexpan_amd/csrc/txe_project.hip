@@ -913,7 +913,8 @@ int txe_gat_dense_fwd_split(const float* X, int n_nodes, int Kh, int Pd, const f
 //                previous layer), all by the dropout factor.
 //   dW [F][Kt], d_attn_l / d_attn_r [F], dP [vocab][Pd].
 // phases: 7 = everything; 1 = d_X, 2 = the dW GEMM (independent of each other), 4 = the reductions that need both -- separate calls
-// share the workspace.
+// share the workspace.  phases | 16: the full d_X product (need_dh) runs on the bf16 matrix pipe, its packed operands behind the workspace
+// (ws_bytes >= txe_gat_dense_ws_bytes + txe_gat_dense_bwd_split_ws_bytes, else TXE_ERR_WORKSPACE); without the bit: the fp32 MFMA.
 int txe_gat_dense_bwd(const float* X, int n_nodes, int Kh, int Pd, const int* pos, int vocab, const float* Wp, const float* W,
                       const float* attn_l, const float* attn_r, int H, int D, float feat_drop_p, const unsigned* mask, const float* d_Y,
                       int need_dh, int act_on, float act_slope, float* d_X, float* dW, float* d_attn_l, float* d_attn_r, float* dP,
@@ -948,7 +949,8 @@ int txe_gat_dense_bwd(const float* X, int n_nodes, int Kh, int Pd, const int* po
     if ((phases & 1) && stream_dx) {
         rc = dxpos_launch(da, s);
         if (rc) return rc;
-    } else if ((phases & 1) && need_dh && n_nodes > 0 && ws_bytes >= p.total + dense_bwd_split_bytes(n_nodes, Fp, Kt)) {
+    } else if ((phases & 1) && (phases & 16) && need_dh && n_nodes > 0) {
+        if (ws_bytes < p.total + dense_bwd_split_bytes(n_nodes, Fp, Kt)) return TXE_ERR_WORKSPACE;     // (the route is the caller's choice, not the buffer's size)
         // the whole d_X = d_Y Wp on the bf16 pipe (txe_gemm_split.h): d_Y packed as the row operand, Wp -- given as the transpose of
         // the column operand -- packed from its columns; dropout mask and leaky' factor in the store loop (epi_store_one's arithmetic)
         char* sw = (char*)ws + p.total;
@@ -2812,7 +2814,7 @@ int txe_gat_collapse_fwd(const int* rowptr_in, const int* col_src, const int* ro
     const unsigned* dummy_mask = reinterpret_cast<const unsigned*>(X);     // never dereferenced by the <false> instantiations
     if (n_nodes > 0) {
         const int nb = (n_nodes + 3) / 4;
-        if (!a12_ready) {          // (the producer of X may already have formed them: txe_gat_aggregate_fwd's fused epilogue)
+        if (!(a12_ready & 1)) {    // (the producer of X may already have formed them: txe_gat_aggregate_fwd's fused epilogue)
             ProfScope prof(mk ? "cl_logits_kernel<true>" : "cl_logits_kernel<false>", s, 4.0 * n_nodes * (double)Kp, 1);
             if (mk) hipLaunchKernelGGL(cl_logits_kernel<true>, dim3(nb < 2048 ? nb : 2048), dim3(256), 0, s, X, Kp, n_nodes, mk, mask_ld, fs, wa, a12);
             else hipLaunchKernelGGL(cl_logits_kernel<false>, dim3(nb < 2048 ? nb : 2048), dim3(256), 0, s, X, Kp, n_nodes, dummy_mask, mask_ld, fs, wa, a12);
@@ -2829,7 +2831,8 @@ int txe_gat_collapse_fwd(const int* rowptr_in, const int* col_src, const int* ro
                                     e_part);
     if (rc_z) return rc_z;
     if (!hg) return TXE_OK;          // (the caller folds hg = Z W^T into what consumes it: txe_bilinear_folded_*)
-    if (G > 0 && ws_bytes >= p.total + collapse_split_bytes(G, D, Kt)) {
+    if (G > 0 && (a12_ready & 2)) {
+        if (ws_bytes < p.total + collapse_split_bytes(G, D, Kt)) return TXE_ERR_WORKSPACE;            // (the route is the caller's choice, not the buffer's size)
         // hg = Z W^T on the bf16 matrix pipe (txe_gemm_split.h): Z and the weight rows packed behind the workspace's own regions
         char* sw = (char*)ws + p.total;
         const int Kc = round_up(Kt, 16);

@@ -392,7 +392,8 @@ def _gat_collapse_fwd(csr, st, h, ld_h, pos, rpos, pw, feat_p, attn_p, attn_slop
     wsum, Z, hg = _empty((max(G, 1),), st.X), _empty((max(G, 1), st.Kp), st.X), (None if z_only else _empty((G, st.D), st.X))
     gid = torch.empty(max(N, 1), dtype=torch.int32, device=st.X.device)
     wsb = pure("txe_gat_collapse_ws_bytes", N, E, G, st.Kh, st.Pd, st.D, 8)
-    if not z_only and G > 0 and not _NO_SPLIT_GEMM:      # room for Z and the weight rows as packed planes: hg = Z W^T on the bf16 pipe
+    split_hg = not z_only and G > 0 and not _NO_SPLIT_GEMM
+    if split_hg:                                         # room for Z and the weight rows as packed planes: hg = Z W^T on the bf16 pipe
         wsb += pure("txe_gat_collapse_split_ws_bytes", G, st.Kh, st.Pd, st.D)
     ws = _ws(wsb, st.X)
     Tf = zrow = e_part = None
@@ -406,7 +407,7 @@ def _gat_collapse_fwd(csr, st, h, ld_h, pos, rpos, pw, feat_p, attn_p, attn_slop
             fw["score"] = (csr.graph_off, N, G, st.Kh, st.Pd, coef, wsum, feat_p, int(st.mask is not None and feat_p > 0.0))
     call("txe_gat_collapse_fwd", ptr(csr.rowptr_in), ptr(csr.col_src), ptr(csr.rowptr_out), ptr(csr.col_dst), ptr(csr.pos_out),
          ptr(csr.graph_off), N, E, G, ptr(st.X), st.Kh, st.Pd, ptr(st.Wp), st.D, feat_p, ptr(st.mask), attn_slope, attn_p, st.seed + 1,
-         ptr(rpos), ptr(pw), ptr(a12), int(ready), ptr(alpha), ptr(coef), ptr(wsum), ptr(gid), ptr(Z), ptr(hg), st.D, ptr(Tf), ptr(zrow),
+         ptr(rpos), ptr(pw), ptr(a12), int(ready) | (2 if split_hg else 0), ptr(alpha), ptr(coef), ptr(wsum), ptr(gid), ptr(Z), ptr(hg), st.D, ptr(Tf), ptr(zrow),
          ptr(e_part), ptr(ws), wsb, _lib.stream_ptr())
     st.cl = (a12, alpha, coef, wsum, gid, Z, hg)
     return Z if z_only else hg
@@ -510,7 +511,8 @@ def _gat_dense_bwd(st, pos, vocab, feat_p, d_Y, need_dh, act_on, act_slope, chai
     dP = torch.empty_like(st.P) if st.P is not None else None
     d_X = _empty((N, st.Kp), st.X) if (need_dh or st.Pd > 0) else None
     wsb = pure("txe_gat_dense_ws_bytes", N, st.Kh, st.Pd, st.H, st.D, vocab)
-    if need_dh and not _NO_SPLIT_GEMM:                 # room for d_Y and Wp as packed planes: d_X = d_Y Wp on the bf16 pipe
+    split_dx = bool(need_dh) and not _NO_SPLIT_GEMM
+    if split_dx:                                       # room for d_Y and Wp as packed planes: d_X = d_Y Wp on the bf16 pipe
         wsb += pure("txe_gat_dense_bwd_split_ws_bytes", N, st.Kh, st.Pd, st.H, st.D)
     ws = _ws(wsb, st.X)
     def run(phases):
@@ -518,7 +520,7 @@ def _gat_dense_bwd(st, pos, vocab, feat_p, d_Y, need_dh, act_on, act_slope, chai
              ptr(st.mask), ptr(d_Y), int(need_dh), int(act_on), act_slope if act_slope else 1.0, ptr(d_X), ptr(dW), ptr(dal), ptr(dar),
              ptr(dP), int(getattr(st, "x_dropped", False)), ptr(getattr(st, "Xt", None)), phases, chain.ptr if chain is not None else None, ptr(ws), wsb, _lib.stream_ptr())
     # (a first PGAT layer's d_X -- position columns only -- is one HBM stream over d_Y, txe_dxpos.hip; every other d_X is a GEMM)
-    run(7 | (64 if (defer and chain is not None) else 0))
+    run(7 | (16 if split_dx else 0) | (64 if (defer and chain is not None) else 0))
     if chain is not None:
         chain.keep += [ws, d_Y, st]
     return d_X, dW, dal, dar, dP

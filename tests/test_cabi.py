@@ -113,3 +113,27 @@ def test_ops_refuse_host_tensors():
     from taxoexpan_amd import ops
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         ops.bilinear_project(torch.zeros(4, 3), torch.zeros(1, 3, 2))
+
+
+def test_lds_direct_copies_are_the_only_users_of_m0():
+    """csrc/txe_gemm_split.hip issues its global -> LDS copies from inline asm (`s_mov_b32 m0, <lds address>` + `global_load_lds_dwordx4`):
+    M0 is a reserved register that cannot be named in a clobber list, so the source cannot tell the compiler about it.  What CAN be
+    checked is the generated gfx950 ISA: in that file every mention of m0 is such a move, immediately followed by the copy that reads
+    it -- no compiler-generated M0 user (readlane/movrel, s_sendmsg, GWS, LDS-direct ds_* with M0) exists for the asm to corrupt."""
+    import re
+    import shutil
+    import subprocess
+    import tempfile
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    src = os.path.join(REPO, "taxoexpan_amd", "csrc", "txe_gemm_split.hip")
+    with tempfile.TemporaryDirectory() as d:
+        out = os.path.join(d, "split.s")
+        r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "--cuda-device-only", "-S", src, "-o", out],
+                           capture_output=True, text=True, cwd=os.path.dirname(src))
+        assert r.returncode == 0, r.stderr[-2000:]
+        lines = [ln.strip() for ln in open(out) if ln.strip() and not ln.strip().startswith((";", ".", "//"))]
+    uses = [i for i, ln in enumerate(lines) if re.search(r"\bm0\b", ln.split(";")[0])]
+    assert len(uses) >= 20                                   # the copies are there
+    for i in uses:
+        assert re.match(r"s_mov_b32 m0, s\d+", lines[i]), lines[i]
+        assert lines[i + 1].startswith("global_load_lds_dwordx4"), (lines[i], lines[i + 1])

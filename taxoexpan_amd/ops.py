@@ -50,6 +50,7 @@ _NO_FUSED_BWD = False       # the folded layer's backward as the unfused chain (
 _NO_QUERY_RUNS = False      # stacked query rows always take the GEMM form of the bilinear match
 _NO_SPLIT_GEMM = False      # the first layer's projection on the fp32 MFMA instead of the bf16 pipe's six plane products
 _NO_TAIL_CHAIN = False      # every layer's last reduction launch in place instead of chained into the bottom layer's
+_NO_EGO_WALK = False        # the fused backward sweep fetches X'[v] per out-edge (gat_fused_bwd_kernel) instead of walking egonets from registers
 _I32_MEMO = {}       # id(source tensor) -> (weakref, version, device, int32 copy): `pos` is converted once per batch, not once per module
 
 
@@ -596,7 +597,7 @@ def _gat_collapse_bwd_fused(csr, st, sp, pos, rpos, pw, vocab, feat_p, attn_p, a
              ptr(st.al), ptr(st.ar), st.D, feat_p, ptr(st.mask), attn_slope, attn_p, st.seed + 1, ptr(pw), ptr(a12), ptr(alpha), ptr(coef),
              ptr(wsum), ptr(gid), ptr(Z), ptr(hg), st.D, ptr(d_hg), ld, act_slope if act_slope else 1.0, ptr(sp.Y), sp.Fp, sp.H, sp.D,
              attn_slope, attn_p, sp.seed + 1, ptr(sp.alpha), ptr(d_Yp), sp.Fp, sp.Fp - Fe, ptr(dz), ptr(dW), ptr(dal), ptr(dar), ptr(dP),
-             ptr(d_pw), phases | (512 if edot else 0), ptr(link.part) if (link is not None and link.S > 0) else None,
+             ptr(d_pw), phases | (512 if edot else 0) | (1024 if _NO_EGO_WALK else 0), ptr(link.part) if (link is not None and link.S > 0) else None,
              link.S if link is not None else 0, *((ptr(link.e_part), ptr(link.m[0]), ptr(link.m[1]), int(link.m[2]), ptr(link.fwd["T"]),
                                                   ptr(link.fwd["run_id"]), ptr(zgid)) if edot else (None, None, None, 0, None, None, None)),
              chain.ptr if chain is not None else None, ptr(ws), wsb, _lib.stream_ptr())

@@ -152,13 +152,17 @@ def test_training_mode_dropout_matches_oracle(name, drop, monkeypatch):
     assert not errors, "\n".join(errors)
 
 
-@pytest.mark.parametrize("switch", ["_NO_SIDE_STREAM", "_NO_FUSED_BWD", "_NO_FUSED_LOGITS", "_NO_TAIL_CHAIN"])
-def test_ab_switch_routes_give_the_same_training_step(switch, monkeypatch):
-    """every route attribute of ops.py selects another ROUTE to the same numbers: a training step (dropout on, fixed seed) of the 2-layer
-    PGAT case with the switch set against the default -- scores and every gradient (the per-layer preparation entry once left the
-    stored-dropped flag of its argument block uninitialised: the default route never noticed)"""
+@pytest.mark.parametrize("switch,case", [("_NO_SIDE_STREAM", "small_pgat_2layer"), ("_NO_FUSED_BWD", "small_pgat_2layer"),
+                                         ("_NO_FUSED_LOGITS", "small_pgat_2layer"), ("_NO_TAIL_CHAIN", "small_pgat_2layer"),
+                                         # four heads under the folded layer: the egonet-walking sweep (windows cut the larger egonets:
+                                         # foreign hubs, hpart rows, the fix-up pass) against the per-out-edge sweep
+                                         ("_NO_EGO_WALK", "mag_pgat_wmr_lbm_q8x32"), ("_NO_EGO_WALK", "semeval_pgat_wmr_bim_q8x32")])
+def test_ab_switch_routes_give_the_same_training_step(switch, case, monkeypatch):
+    """every route attribute of ops.py selects another ROUTE to the same numbers: a training step (dropout on, fixed seed) with the switch
+    set against the default -- scores and every gradient (the per-layer preparation entry once left the stored-dropped flag of its
+    argument block uninitialised: the default route never noticed)"""
     from taxoexpan_amd import ops
-    spec, z, shapes, x, q, params, graph = load_case("small_pgat_2layer")
+    spec, z, shapes, x, q, params, graph = load_case(case)
     spec = dict(spec, dropout=(0.3, 0.25))
     monkeypatch.setattr(ops, "new_seed", lambda: 424242)
     outs = []

@@ -6,7 +6,8 @@ namespace txe {
 
 constexpr int DXPOS_ROWS = 16;       // rows of d_Y per row block (= one 16x16x4 MFMA row block)
 constexpr int DXPOS_MAXC = 64;       // widest column range [c0, c0 + NC) the kernel covers
-constexpr int DXPOS_KSL = 512;       // k-slice of the weight slab a workgroup keeps in LDS (512 x 64 floats = 128 KB)
+constexpr int DXPOS_KSL = 416;       // k-slice of the weight slab a workgroup keeps in LDS as bf16 planes: 13 steps of 32 k
+constexpr int DXPOS_STEP_BYTES = 3 * 4 * 64 * 16;   // 3 planes x 4 column blocks x 64 lanes x 16 bytes = 12 KB per step (156 KB per slice)
 
 struct DxPosArgs {
     const float* dY; long long ld_dy; int n_rows; int K;     // d_Y [n_rows][K], K a multiple of 128

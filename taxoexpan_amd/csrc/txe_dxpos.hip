@@ -20,30 +20,47 @@
 //     (txe_dxpos.h) inside the layer's reduction launch: slices in fixed order, dropout keep bits, the d_X store and the per-class
 //     partial sums of dP -- the `pos_segsum_stage1` pass over d_X disappears and no launch is added.
 #include "txe_dxpos.h"
+#include "txe_gemm_split.h"
 
 #include <stdlib.h>
 
 namespace txe {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((ext_vector_type(8))) short dx_bf16x8;
 
 int device_cu_count();     // txe_profile.hip
 
+// The product runs on the bf16 matrix pipe in fp32 accuracy (txe_gemm_split.h: every fp32 operand the exact sum of three bf16 planes, six
+// plane products by v_mfma_f32_16x16x32_bf16, fp32 accumulation): 28 GF of plane products at the bf16 rate cost a third of what the
+// 4.7 GF cost on the fp32 MFMA (v_mfma_f32_16x16x4_f32: 30 us at its peak, 48 us measured -- the kernel was compute-bound on the slow
+// pipe), which leaves the 146 MB stream over d_Y as the bound.
+//   * the weight slab W[k-slice][c0:c0+64] is split ONCE per workgroup into planes laid out as MFMA B operands in LDS: entry
+//     ((step * 3 + plane) * 4 + e) * 64 + lane = the 8 weights k = 32 step + 8 (lane >> 4) .. + 7 of output column 4 (lane & 15) + e
+//     (12 KB per 32-k step; a 416-row slice = 156 KB);
+//   * a lane's 8 consecutive floats of d_Y (row lane & 15, k = 8 (lane >> 4) .. + 7 of the step: the 32-byte load of the fp32 version)
+//     ARE its A operand of the 16x16x32 MFMA once split (txe_gemm_split.h split3x8, in registers);
+//   * a wave owns TWO 16-row blocks per pass: the 12 B fragments of a step are read from LDS once for 48 MFMAs;
+//   * the whole fp32 domain (txe_gemm_split.h): a weight group that holds +-Inf / NaN / |w| >= 2^120 gets the NaN marker plane, such
+//     elements of d_Y poison the accumulators by themselves (Inf - Inf in the residual); a wave whose accumulators are not finite after
+//     its k-slice recomputes its two row blocks with fp32 FMAs from global memory (wave-local: no LDS, no barrier).
 __global__ __launch_bounds__(512) void gat_dx_pos_kernel(const DxPosArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float Bs[];    // [slice_len][64]
+    extern __shared__ __attribute__((aligned(16))) uint4 Bp[];    // [steps][3 planes][4 column blocks][64 lanes]
     const int ks = blockIdx.x % a.KS, rg = blockIdx.x / a.KS;
-    const int k0 = ks * DXPOS_KSL, slice_len = min(DXPOS_KSL, a.K - k0);          // (a multiple of 128)
-    {   // the weight slice: every load first, then the LDS stores (column vectors past the matrix re-read its last one: their
-        // products land in output columns that are never stored)
-        const int i = threadIdx.x & 15, r = threadIdx.x >> 4;
-        const float* src = a.Wp + (long long)(k0 + r) * a.ld_w + min(a.c0 + 4 * i, a.Kp - 4);
-        for (int n0 = 0; n0 < slice_len / 32; n0 += 4) {           // (slice_len is a multiple of 128: whole batches, no branch)
-            float4 t[4];
+    const int k0 = ks * DXPOS_KSL, slice_len = min(DXPOS_KSL, a.K - k0);          // (a multiple of 32)
+    const int nsteps = slice_len / 32;
+    for (int idx = threadIdx.x; idx < nsteps * 256; idx += 512) {
+        const int lane = idx & 63, e = (idx >> 6) & 3, st = idx >> 8;
+        // (column vectors past the matrix re-read its last one: their products land in output columns that are never stored)
+        const float* src = a.Wp + (long long)(k0 + 32 * st + 8 * (lane >> 4)) * a.ld_w + min(a.c0 + 4 * (lane & 15), a.Kp - 4) + e;
+        float x[8];
 #pragma unroll
-            for (int n = 0; n < 4; ++n) t[n] = *reinterpret_cast<const float4*>(src + (long long)(n0 + n) * 32 * a.ld_w);
-#pragma unroll
-            for (int n = 0; n < 4; ++n) *reinterpret_cast<float4*>(Bs + ((n0 + n) * 32 + r) * 64 + 4 * i) = t[n];
-        }
+        for (int t = 0; t < 8; ++t) x[t] = src[(long long)t * a.ld_w];
+        uint4 w1, w2, w3;
+        if (split_exceptional8(x)) { split3x8(x, w1, w2, w3); w3 = make_uint4(SPL_RAW_MARK, SPL_RAW_MARK, SPL_RAW_MARK, SPL_RAW_MARK); }
+        else split3x8(x, w1, w2, w3);
+        uint4* d = Bp + ((st * 3) * 4 + e) * 64 + lane;
+        d[0] = w1; d[256] = w2; d[512] = w3;
     }
     __syncthreads();
 
@@ -52,68 +69,99 @@ __global__ __launch_bounds__(512) void gat_dx_pos_kernel(const DxPosArgs a) {
     const int nrb = dxpos_blocks(a.n_rows);
     const int base = nrb / a.RG, rem = nrb % a.RG;
     const int rb_begin = rg * base + min(rg, rem), rb_end = rb_begin + base + (rg < rem ? 1 : 0);
-    const int NG = slice_len / 128;
-    const float* bl = Bs + (8 * kq) * 64 + 4 * i;                  // this lane's part of the B addresses
+    const int NG = (nsteps + 1) / 2;                               // groups of two steps (64 k): the unit of the d_Y prefetch
     float* const slab = a.part + (long long)ks * nrb * DXPOS_ROWS * DXPOS_MAXC;
 
     auto row_ptr = [&](int rb) {                                   // rows past the end re-read the last one (their partial rows are never used)
         const int row = min(rb * DXPOS_ROWS + i, a.n_rows - 1);
         return a.dY + (long long)row * a.ld_dy + k0 + 8 * kq;
     };
-    int rb = rb_begin + w;
+    // the second step of a slice's last group may not exist: its loads re-read the step before (never multiplied)
+    auto load_group = [&](const float* ap, int g, float4 (&d)[4]) {
+        const int o0 = 64 * g, o1 = min(64 * g + 32, 32 * (nsteps - 1));
+        d[0] = *reinterpret_cast<const float4*>(ap + o0); d[1] = *reinterpret_cast<const float4*>(ap + o0 + 4);
+        d[2] = *reinterpret_cast<const float4*>(ap + o1); d[3] = *reinterpret_cast<const float4*>(ap + o1 + 4);
+    };
+    int rb = rb_begin + 2 * w;
     if (rb >= rb_end) return;
-    const float* ap = row_ptr(rb);
-    float4 ac[8], an[8];
+    const float *apA = row_ptr(rb), *apB = row_ptr(min(rb + 1, rb_end - 1));
+    float4 cA[4], cB[4], nA[4], nB[4];
+    load_group(apA, 0, cA);
+    load_group(apB, 0, cB);
+    for (; rb < rb_end; rb += 16) {
+        f32x4 acc[2][4];
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        ac[2 * p] = *reinterpret_cast<const float4*>(ap + 32 * p);
-        ac[2 * p + 1] = *reinterpret_cast<const float4*>(ap + 32 * p + 4);
-    }
-    for (; rb < rb_end; rb += 8) {
-        f32x4 acc[4];
+        for (int x = 0; x < 2; ++x)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int q = 0; q < 4; ++q) acc[x][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int rbn = rb + 16 < rb_end ? rb + 16 : rb;            // this wave's next pair of row blocks (none left: this one again)
+        const float *apAn = row_ptr(rbn), *apBn = row_ptr(min(rbn + 1, rb_end - 1));
         for (int g = 0; g < NG; ++g) {
-            // the next group: further along this row block, else the head of this wave's next row block (none left: this one again)
             const bool more = g + 1 < NG;
-            const int rbn = rb + 8 < rb_end ? rb + 8 : rb;
-            const float* apn = more ? ap + 128 : row_ptr(rbn);
-#pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                an[2 * p] = *reinterpret_cast<const float4*>(apn + 32 * p);
-                an[2 * p + 1] = *reinterpret_cast<const float4*>(apn + 32 * p + 4);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            const float* bg = bl + g * 128 * 64;
-            // B fragments two steps ahead of the MFMAs that use them (ds_read latency under the previous steps' MFMAs)
-#define TXE_DX_ROW(j_) (32 * ((j_) >> 3) + ((j_) & 7))              /* step j = 8 p + 4 h + t  ->  weight row 32 p + 4 h + t (+ 8 kq) */
-            float4 bq[3];
-            bq[0] = *reinterpret_cast<const float4*>(bg + TXE_DX_ROW(0) * 64);
-            bq[1] = *reinterpret_cast<const float4*>(bg + TXE_DX_ROW(1) * 64);
-#pragma unroll
-            for (int j = 0; j < 32; ++j) {
-                if (j + 2 < 32) bq[(j + 2) % 3] = *reinterpret_cast<const float4*>(bg + TXE_DX_ROW(j + 2) * 64);
-                __builtin_amdgcn_sched_barrier(0);                 // (left alone the scheduler sinks every read to just before its use)
-                const float4 v = ac[j >> 2];
-                const float av = (j & 3) == 0 ? v.x : ((j & 3) == 1 ? v.y : ((j & 3) == 2 ? v.z : v.w));
-                const float4 b = bq[j % 3];
-                acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b.x, acc[0], 0, 0, 0);
-                acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b.y, acc[1], 0, 0, 0);
-                acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b.z, acc[2], 0, 0, 0);
-                acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b.w, acc[3], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-#undef TXE_DX_ROW
+            load_group(more ? apA : apAn, more ? g + 1 : 0, nA);
+            load_group(more ? apB : apBn, more ? g + 1 : 0, nB);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int q = 0; q < 8; ++q) ac[q] = an[q];
-            ap = apn;
+            for (int h = 0; h < 2; ++h) {
+                const int st = 2 * g + h;
+                if (st < nsteps) {                                 // (wave-uniform)
+                    const float xa[8] = {cA[2 * h].x, cA[2 * h].y, cA[2 * h].z, cA[2 * h].w, cA[2 * h + 1].x, cA[2 * h + 1].y, cA[2 * h + 1].z, cA[2 * h + 1].w};
+                    const float xb[8] = {cB[2 * h].x, cB[2 * h].y, cB[2 * h].z, cB[2 * h].w, cB[2 * h + 1].x, cB[2 * h + 1].y, cB[2 * h + 1].z, cB[2 * h + 1].w};
+                    uint4 pa[3], pb[3];
+                    split3x8(xa, pa[0], pa[1], pa[2]);
+                    split3x8(xb, pb[0], pb[1], pb[2]);
+                    const uint4* bs = Bp + (st * 12) * 64 + l;
+#define TXE_DX_PROD(pl_a_, pl_b_)                                                                                          \
+    _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                                       \
+        const dx_bf16x8 bw = __builtin_bit_cast(dx_bf16x8, bs[((pl_b_) * 4 + e) * 64]);                                    \
+        acc[0][e] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(dx_bf16x8, pa[pl_a_]), bw, acc[0][e], 0, 0, 0); \
+        acc[1][e] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(dx_bf16x8, pb[pl_a_]), bw, acc[1][e], 0, 0, 0); \
+    }
+                    TXE_DX_PROD(2, 0) TXE_DX_PROD(0, 2) TXE_DX_PROD(1, 1) TXE_DX_PROD(1, 0) TXE_DX_PROD(0, 1) TXE_DX_PROD(0, 0)
+#undef TXE_DX_PROD
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { cA[q] = nA[q]; cB[q] = nB[q]; }
         }
         // accumulator register r of column block e: row 4*(lane >> 4) + r, output column 4*(lane & 15) + e
-        float* dst = slab + ((long long)rb * DXPOS_ROWS + 4 * kq) * DXPOS_MAXC + 4 * i;
+        bool odd = false;
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-            *reinterpret_cast<float4*>(dst + r * DXPOS_MAXC) = make_float4(acc[0][r], acc[1][r], acc[2][r], acc[3][r]);
+        for (int x = 0; x < 2; ++x)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) odd |= not_finite(acc[x][e][r]);
+        if (__ballot(odd) != 0ull) {                               // (rare) fp32 FMAs over the slice, straight from global memory
+#pragma unroll
+            for (int x = 0; x < 2; ++x) {                          // (x, r unrolled: they index accumulator registers)
+                const int rbx = min(rb + x, rb_end - 1);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float* dy = a.dY + (long long)min(rbx * DXPOS_ROWS + 4 * kq + r, a.n_rows - 1) * a.ld_dy + k0;
+                    const float* wc = a.Wp + (long long)k0 * a.ld_w + min(a.c0 + 4 * i, a.Kp - 4);
+                    float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 1
+                    for (int k = 0; k < slice_len; ++k) {
+                        const float av = dy[k];
+                        const float4 wv = *reinterpret_cast<const float4*>(wc + (long long)k * a.ld_w);
+                        sum.x = __builtin_fmaf(av, wv.x, sum.x); sum.y = __builtin_fmaf(av, wv.y, sum.y);
+                        sum.z = __builtin_fmaf(av, wv.z, sum.z); sum.w = __builtin_fmaf(av, wv.w, sum.w);
+                    }
+                    acc[x][0][r] = sum.x; acc[x][1][r] = sum.y; acc[x][2][r] = sum.z; acc[x][3][r] = sum.w;
+                }
+            }
+        }
+#pragma unroll
+        for (int x = 0; x < 2; ++x) {
+            if (rb + x >= rb_end) break;
+            float* dst = slab + ((long long)(rb + x) * DXPOS_ROWS + 4 * kq) * DXPOS_MAXC + 4 * i;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                *reinterpret_cast<float4*>(dst + r * DXPOS_MAXC) = make_float4(acc[x][0][r], acc[x][1][r], acc[x][2][r], acc[x][3][r]);
+        }
+        apA = apAn; apB = apBn;
     }
 }
 
@@ -123,7 +171,7 @@ int dxpos_prepare(DxPosArgs& a) {
         return TXE_ERR_ARG;
     if (!a.mask_on) { a.mask = reinterpret_cast<const unsigned*>(a.Wp); a.mask_ld = 1; a.drop_scale = 1.f; }
     a.KS = dxpos_kslices(a.K);
-    int rg = device_cu_count() / a.KS;                            // one workgroup (128 KB of LDS) per CU
+    int rg = device_cu_count() / a.KS;                            // one workgroup (up to 156 KB of LDS) per CU
     const int nrb = dxpos_blocks(a.n_rows);
     if (rg > nrb) rg = nrb;
     a.RG = rg < 1 ? 1 : rg;
@@ -135,12 +183,12 @@ int dxpos_launch(const DxPosArgs& a, hipStream_t stream) {
     // the kernel needs more than the default 64 KB of LDS.  Function attributes are per DEVICE and this library keeps no state: set
     // before every launch (a host-side table write, idempotent, thread-safe)
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(gat_dx_pos_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            DXPOS_KSL * DXPOS_MAXC * (int)sizeof(float)) != hipSuccess)
+                            (DXPOS_KSL / 32) * DXPOS_STEP_BYTES) != hipSuccess)
         return TXE_ERR_LAUNCH;
     // algorithmic bytes: d_Y once, the weight slab once, the outputs once
     ProfScope prof("gat_dx_pos_kernel", stream, 4.0 * ((double)a.n_rows * a.K + (double)a.K * a.NC + (double)a.n_rows * a.NC), 1);
     const int slice = a.K < DXPOS_KSL ? a.K : DXPOS_KSL;
-    hipLaunchKernelGGL(gat_dx_pos_kernel, dim3(a.KS * a.RG), dim3(512), (size_t)slice * DXPOS_MAXC * sizeof(float), stream, a);
+    hipLaunchKernelGGL(gat_dx_pos_kernel, dim3(a.KS * a.RG), dim3(512), (size_t)(slice / 32) * DXPOS_STEP_BYTES, stream, a);
     TXE_CHECK_LAUNCH();
     return TXE_OK;
 }

@@ -1,8 +1,8 @@
 """GPU parity tests proper: the HIP path (through the C ABI, include/txe.h) against (a) the golden vectors captured from
 the unmodified reference and (b) the CPU oracle on the same seeded inputs.  Tolerance: BASELINE.json's north star asks
 logits / ranking within 1e-4 fp32.  Model-level gradients are gated against the oracle run in FLOAT64 with the unmodified reference's
-own fp32 gradient (the golden) as the yardstick: max |HIP - f64| <= max(1.5 x max |reference fp32 - f64|, 1e-5 max |f64|) and
-<= 1e-4 max |f64| per tensor (golden_util.gate_against_f64) -- and, entry by entry, 2e-3 relative against the golden itself."""
+own fp32 gradient (the golden) as the yardstick: max |HIP - f64| <= max(2 x max |reference fp32 - f64|, 2e-5 max |f64|) and
+<= 1e-4 max |f64| per tensor unless fp32 itself cannot (golden_util.gate_against_f64) -- and, entry by entry, 2e-3 relative against the golden itself."""
 import os
 
 import numpy as np

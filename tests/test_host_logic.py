@@ -339,3 +339,37 @@ def test_loss_tensor_backward_starts_from_a_unit_gradient_only_when_asked_plainl
     x.grad = None
     ((3 * x).sum().as_subclass(L.LossTensor) / 2).backward(torch.tensor(4.0))
     assert torch.equal(x.grad, torch.full((3,), 6.0))
+
+
+def test_bench_compact_line_fits_the_drivers_tail_and_keeps_the_contract():
+    """bench.compact_line on a real full record (profiles/r06_bench_full.json: what bench.py writes to bench_extra.json): the ONE stdout
+    line stays far below the driver's 8 KB tail (round 5's 21 KB line parsed to null), carries the contract's keys with flat `roofline`
+    and `cpu_baseline` objects, and -- with the N > 1 scalars present -- the multi-GPU keys of BASELINE configs[2] / [3]"""
+    import importlib.util
+    import json
+    import os
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_for_test", os.path.join(repo, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    full = json.load(open(os.path.join(repo, "profiles", "r06_bench_full.json")))
+    line = bench.compact_line(full)
+    text = json.dumps(line, separators=(",", ":"))
+    assert len(text) < 3000 < bench.COMPACT_LIMIT == 4096
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+              "config", "roofline", "cpu_baseline", "matrix_pipe", "value_fp32_mfma"):
+        assert k in line, k
+    assert line["value"] == full["value"] and line["ms_per_step"] == full["ms_per_step"] and line["vs_baseline"] is None
+    assert set(line["config"]) >= {"workload", "egonets_per_step_per_gpu", "parallelism", "routes", "lr", "final_loss"}
+    assert all(not isinstance(v, (dict, list)) for k in ("roofline", "cpu_baseline") for v in line[k].values())
+    assert abs(line["roofline"]["frac"] - line["roofline"]["achieved"] / line["roofline"]["peak"]) < 1e-4
+    assert line["cpu_baseline"]["kind"] == "port" and line["cpu_baseline"]["cores"] >= 1 and len(line["cpu_baseline"]["sample"]) <= 240
+    # N > 1: the flat keys ride along and the line still fits
+    multi = dict(full, n_gpus=8, rccl_world=8, collective_backend="nccl", step_pgat2_dp_ms=3.4, step_pgat2_dp_edges_per_s=7.4e7,
+                 candidates_scored_per_s_allgather=1.1e12, candidates_scored_per_s_fused_allreduce=2.2e12, allgather_gbs_per_rank=44.0,
+                 allreduce_counts_queries_per_s=9.9e5)
+    line8 = bench.compact_line(multi)
+    for k in ("rccl_world", "collective_backend", "step_pgat2_dp_ms", "step_pgat2_dp_edges_per_s", "candidates_scored_per_s_allgather",
+              "candidates_scored_per_s_fused_allreduce", "allgather_gbs_per_rank", "allreduce_counts_queries_per_s"):
+        assert k in line8, k
+    assert len(json.dumps(line8, separators=(",", ":"))) < 3500

@@ -2259,6 +2259,27 @@ __global__ __launch_bounds__(256, (NI >= 3) ? 2 : TXE_EGO_OCC) void gat_fused_bw
         *reinterpret_cast<float4*>(s_wa + i) = *reinterpret_cast<const float4*>(a.wa + i);
         *reinterpret_cast<float4*>(s_acc + i) = make_float4(0.f, 0.f, 0.f, 0.f);
     }
+    if (ng > FB_NODES) {
+        // more graphs than positions in the window: it holds EMPTY graphs (an egonet has at least its anchor) -- not a batch of egonets;
+        // every source node of the window through the generic body, and the row a fix-up pass may read cleared
+        __syncthreads();
+        if (tid < nw) {
+            const int u = u0 + tid;
+            s_ni[4 * tid] = a.gid[u]; s_ni[4 * tid + 1] = a.rowptr_out[u]; s_ni[4 * tid + 2] = a.rowptr_out[u + 1];
+            s_ni[4 * tid + 3] = a.pos[u];
+            s_nf[4 * tid] = a.da1[u]; s_nf[4 * tid + 1] = a.da2[u]; s_nf[4 * tid + 2] = a.cn[u];
+        }
+        __syncthreads();
+        const int e0 = a.rowptr_out[u0], ne = a.rowptr_out[u1] - e0;
+        fb_body<MASK, NI, 1, false>(a, b, u0, u1, e0, ne, s_v, s_p, s_cn, s_g1, s_g2, s_ni, s_nf, s_dot, s_dp, s_wa, s_acc);
+        if (u0 > offF && a.goff[gF + 1] - offF <= EGO_MAXN)
+            for (int c = tid; c < a.H * a.D; c += 256) a.hpart[(long long)b * a.H * a.D + c] = 0.f;
+        __syncthreads();
+        float* dwg = a.dwa_part + (long long)b * 2 * Kp;
+        for (int i = tid * 4; i < 2 * Kp; i += 1024) *reinterpret_cast<float4*>(dwg + i) = *reinterpret_cast<const float4*>(s_acc + i);
+        for (int i = tid; i < a.vocab * a.Pd; i += 256) a.ppart[(long long)b * a.vocab * a.Pd + i] = s_dp[i];
+        return;
+    }
     if (tid < ng) { g_ok[tid] = (a.goff[gF + tid + 1] - a.goff[gF + tid] <= EGO_MAXN) ? 1 : 0; g_hub[tid] = 0; }
     __syncthreads();
     // (1) out-degree, and the non-self target of a node of out-degree 2 -- one thread per node of the graphs that fit

@@ -287,9 +287,12 @@ def test_fused_stack_intermediates_match_reference_goldens(name):
     np.testing.assert_allclose(scores.detach().cpu().numpy(), z["scores"], rtol=1e-4, atol=2e-5)
 
 
-@pytest.mark.parametrize("heads,hidden,drop,layers", [([4, 1], 500, 0.1, 1), ([4, 1], 8, 0.0, 1), ([2, 1], 24, 0.2, 1), ([1, 1], 32, 0.2, 1),
-                                                      ([4, 1], 600, 0.1, 1), ([3, 4, 1], 12, 0.1, 2), ([4, 1], 100, 0.0, 1)])
-def test_fused_backward_sweep_equals_unfused_chain(heads, hidden, drop, layers, monkeypatch):
+@pytest.mark.parametrize("heads,hidden,drop,layers,empties", [([4, 1], 500, 0.1, 1, 0), ([4, 1], 8, 0.0, 1, 0), ([2, 1], 24, 0.2, 1, 0), ([1, 1], 32, 0.2, 1, 0),
+                                                              ([4, 1], 600, 0.1, 1, 0), ([3, 4, 1], 12, 0.1, 2, 0), ([4, 1], 100, 0.0, 1, 0),
+                                                              # 45 EMPTY graphs in the batch: a window of the egonet walk then holds more
+                                                              # graphs than positions and takes the generic body as a whole
+                                                              ([4, 1], 500, 0.1, 1, 45), ([4, 1], 8, 0.0, 1, 45)])
+def test_fused_backward_sweep_equals_unfused_chain(heads, hidden, drop, layers, empties, monkeypatch):
     """txe_gat_collapse_bwd_fused (d_X' formed on the fly inside the layer below's source-side sweep) against the unfused chain
     txe_gat_collapse_bwd -> txe_gat_aggregate_bwd of the SAME forward pass (same saved state, same dropout seeds): every gradient,
     on generic batched multigraphs (a hub with in-degree > 64 and a node with ~400 out-edges, nodes without in-edges, graphs of
@@ -311,6 +314,8 @@ def test_fused_backward_sweep_equals_unfused_chain(heads, hidden, drop, layers, 
         if n != 33:
             g.add_edges(g.nodes(), g.nodes())                                 # (the 33-node graph has nodes without any in-edge)
         graphs.append(g)
+        if n == 7:
+            graphs.extend(DGLGraph() for _ in range(empties))                 # (graphs without nodes, in the middle of the batch)
     bg = batch(graphs)
     N = bg.number_of_nodes()
     pos = torch.from_numpy(rs.randint(0, 3, N)).to(dev)

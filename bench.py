@@ -1081,7 +1081,7 @@ def main():
                     "hbm_traffic_ratio": (hb["traffic"] / hb["work_per_launch"] if hb and hb.get("traffic") else None),
                     "copy_ceiling_gbs": copy_bw / 1e9, "copy_ceiling_torch_gbs": copy_bw_torch / 1e9,
                     "pair_frac": pair["pair_frac"] if pair else None, "pair_kernel": pair["kernel"] if pair else None}
-        for short, prefix in (("aggregate_fwd", "gat_aggregate_fwd_kernel"), ("fused_bwd", "gat_fused_bwd"),
+        for short, prefix in (("aggregate_fwd", "gat_aggregate_"), ("fused_bwd", "gat_fused_bwd"),
                               ("dx_pos", "gat_dx_pos_kernel"), ("bwd_dot", "cl_bwd_dot"), ("zsum", "cl_zsum")):
             r = by_kernel(prefix)
             if r is not None:

@@ -151,7 +151,11 @@ int txe_gat_aggregate_fwd(const int* rowptr_in, const int* col_src, int n_nodes,
                           const float* a_src, const float* a_dst, int ld_a, int H, int D, float attn_slope, float attn_drop_p,
                           unsigned long long seed, int out_mode, float act_slope, float* out, long long ld_out, float* alpha,
                           const float* nx_wa, int nx_kp, const unsigned* nx_mask, float nx_feat_drop_p, float* nx_a12, int npw, void* stream);
-/* npw: destination nodes per wave, 0 = chosen from the batch size, 1 | 2 = forced (bit-equal results; a parity test compares them).
+/* npw: 0 = the sweep is chosen from the batch (batches of 4,096 nodes and more with four heads and 16-byte rows walk egonets:
+ * gat_aggregate_ego_kernel, a workgroup per window of consecutive nodes, every row read once); 1 | 2 = one wave per node with that many
+ * nodes per wave; 4 = one wave per node, nodes per wave from the batch size; 3 | 8..32 = the egonet walk, forced (with that many nodes per
+ * window; TXE_ERR_ARG if the shape does not fit).  `out` and `alpha` are bit-equal across all of them, nx_a12 within rounding (a
+ * parity test compares them).
  * d_pre = gradient w.r.t. the PRE-activation aggregated output.  Writes d_ft [N][H*D], d_a_src/d_a_dst [N][H]
  * (row stride ld_da).  dz_ws: E*H floats of scratch.  n_pad: floats following d_a_dst[v][H-1] in every row that are cleared as
  * well (the zero padding columns of txe_gat_dense_bwd's d_Y operand when d_ft | d_a_src | d_a_dst share one padded row); 0 = none. */

@@ -351,6 +351,339 @@ __global__ __launch_bounds__(GAT_WAVES * 64, TAB ? 3 : 1) void gat_aggregate_fwd
     }
 }
 
+// ---- the same sweep, WALKING EGONETS (dataset.py:404-437: parents -> anchor, anchor -> siblings, self loops) ----------------------
+// The kernel above fetches ft[u] once per in-edge (u -> v): an anchor's row once for itself and once per sibling, a parent's row twice
+// (FETCH_SIZE 181 MB against 143 MB of rows on the training batch), and a wave asks for ONE 8-KB row per round trip.  Here a workgroup
+// walks a window of npw CONSECUTIVE destination nodes, its four waves a quarter of the row each (H = 4: one head per wave), and every
+// row is read once, in node order, with the next node's slice already in flight:
+//   * a node whose in-list is a RUN of its predecessors and itself, [v-k .. v-1, v] (k = 0: a parent or a lone anchor; k >= 1: an anchor
+//     behind its parents; k = 1 also: the first sibling behind its anchor): the predecessors' rows were accumulated into `acc` -- with
+//     the coefficients of THIS node's edges, which the staging phase wrote into the predecessors' table entries -- while they were
+//     walked as destinations themselves;
+//   * a node whose in-list is [h, v] with h further back (the second and later siblings): the anchor's slice is kept in registers
+//     (`hub`) from the moment it was walked (a window that starts behind the anchor loads it once more: the only re-read);
+//   * anything else (not an egonet: other in-lists, more than 64 in-edges, none; runs that overlap) is left to gat_fwd_node, one wave
+//     per node, after the walk.
+// The shape is read off the destination CSR by the staging phase -- one wave per node, lane = in-edge, the softmax exactly as
+// gat_fwd_node forms it -- so every edge coefficient and, per element, the order of the multiply-adds are those of the kernel above:
+// `out` and `alpha` are bit-identical; the next layer's logits (nx_a12) are summed in a different order (a quarter row per wave).
+// The walk itself has no branch: kinds and flags are selects, stores are unconditional (a lane past the slice repeats lane 0's vector
+// and writes the same value), so the loads of node t + 1 stay in flight across the arithmetic of node t.
+constexpr int EF_NODES = 32;                       // most destination nodes a workgroup walks
+constexpr int EF_BACK = 64;                        // run members in front of a window's first node (in-degree <= 64)
+constexpr int EF_TAB = EF_BACK + EF_NODES;
+#ifndef TXE_EF_RING
+#define TXE_EF_RING 4
+#endif
+#ifndef TXE_EF_OCC
+#define TXE_EF_OCC 4
+#endif
+constexpr int EF_RING = TXE_EF_RING;               // row slices in flight per wave + 1
+constexpr int EF_MAXE = 256;                       // in-edges of a window staged in LDS (an egonet batch has < 2 per node)
+// a workgroup barrier that waits for the LDS traffic only: global loads issued before it stay in flight, global stores are not drained
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+enum { EF_RUN = 0, EF_HUBREF = 1, EF_GENERIC = 2 };
+
+struct EgoFwdArgs {
+    const int *rowptr, *col; int n_nodes;
+    const float* ft; long long ld_ft; const float *a_src, *a_dst; int ld_a, D;
+    float slope, drop_p, drop_scale; unsigned long long seed; int out_mode; float act_slope;
+    float* out; long long ld_out; float* alpha; NextLogits nx; int npw;
+};
+
+template <int NI, int NX>
+__global__ __launch_bounds__(256, (NI >= 3) ? 3 : TXE_EF_OCC) void gat_aggregate_ego_kernel(const EgoFwdArgs a) {
+    __shared__ int t_kind[EF_NODES], t_hub[EF_NODES], t_ishub[EF_NODES], t_hasrun[EF_NODES];
+    __shared__ float t_self[EF_NODES][4], t_hubc[EF_NODES][4];
+    __shared__ float t_run[EF_TAB][4];
+    __shared__ int t_flag[EF_TAB], t_cnt[EF_TAB];
+    __shared__ float s_nx[EF_NODES][4][2];
+    __shared__ int s_nf, s_fhub, s_bad;
+    __shared__ float g_w[GAT_WAVES][4 * 64];                       // gat_fwd_node's per-wave slots (nodes the walk leaves out)
+    __shared__ int g_idx[GAT_WAVES][64];
+    __shared__ float g_stat[GAT_WAVES][8];
+    extern __shared__ __attribute__((aligned(16))) float s_wa[];   // NX 1 | 2: the next layer's two folded rows [2][kp]
+    __shared__ int s_rp[EF_NODES + 1], s_col[EF_MAXE];
+    __shared__ float s_as[EF_TAB][4], s_ad[EF_NODES][4];          // a_src of the nodes [u0 - EF_BACK, u0 + EF_NODES), a_dst of the window's
+    constexpr int H = 4;
+    const int tid = threadIdx.x, l = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b = xcd_remap(blockIdx.x, gridDim.x);
+    const int u0 = b * a.npw, u1 = min(a.n_nodes, u0 + a.npw), nw = u1 - u0;     // (nw >= 1)
+    const int D = a.D, F = H * D, nvec = D >> 2, c0 = w * D;
+    int off[NI];
+    bool live[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int j = l + 64 * i;
+        live[i] = j < nvec;
+        off[i] = c0 + 4 * (live[i] ? j : 0);
+    }
+    // (NX 1 | 2) the columns behind the feature part -- position embedding and zero padding, at most 128: waves 0 and 1, one per lane
+    const int ct = F + w * 64 + l;
+    const bool tlive = (NX == 1 || NX == 2) && w < 2 && ct < a.nx.kp;
+    const int cc = tlive ? ct : 0;
+    float ring[EF_RING][NI][4], txr[EF_RING];                      // position q's slice lives in slot q % EF_RING
+    unsigned kbr[EF_RING][NI], tkr[EF_RING];
+    auto load_row = [&](const int v, float (&y)[NI][4], unsigned (&kb)[NI], float& tx, unsigned& tk) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            vload<4>(a.ft + (long long)v * a.ld_ft + off[i], y[i]);
+            kb[i] = 0xFu;
+            if constexpr (NX >= 2) kb[i] = a.nx.mask[(long long)v * a.nx.mask_ld + (off[i] >> 5)] >> (off[i] & 31);
+        }
+        tx = 0.f; tk = 1u;
+        if constexpr (NX == 1 || NX == 2) {
+            tx = a.out[(long long)v * a.ld_out + cc];
+            if constexpr (NX == 2) tk = (a.nx.mask[(long long)v * a.nx.mask_ld + (cc >> 5)] >> (cc & 31)) & 1u;
+        }
+    };
+    // ---- staging, trip 1: the window's row pointers and attention terms; behind them (in flight across the whole staging phase: its
+    //      barriers wait for LDS only) the first row slices of the walk ----
+    {
+        const int rp = a.rowptr[u0 + min(tid, nw)];
+        float sa[(EF_TAB * 4 + 255) / 256];
+#pragma unroll
+        for (int q = 0; q < (EF_TAB * 4 + 255) / 256; ++q) {
+            const int i = min(tid + 256 * q, EF_TAB * 4 - 1);
+            const int node = min(max(u0 - EF_BACK + (i >> 2), 0), a.n_nodes - 1);
+            sa[q] = a.a_src[(long long)node * a.ld_a + (i & 3)];
+        }
+        const int dn = min(tid >> 2, nw - 1) ;
+        const float sd = a.a_dst[(long long)(u0 + dn) * a.ld_a + (tid & 3)];
+#pragma unroll
+        for (int r = 0; r < EF_RING - 1; ++r) load_row(u0 + min(r, nw - 1), ring[r], kbr[r], txr[r], tkr[r]);
+        if (tid <= nw) s_rp[tid] = rp;
+#pragma unroll
+        for (int q = 0; q < (EF_TAB * 4 + 255) / 256; ++q) {
+            const int i = tid + 256 * q;
+            if (i < EF_TAB * 4) s_as[i >> 2][i & 3] = sa[q];
+        }
+        if (tid < EF_NODES * 4) s_ad[tid >> 2][tid & 3] = sd;
+    }
+    for (int i = tid; i < EF_TAB; i += 256) { t_flag[i] = 0; t_cnt[i] = 0; }
+    for (int i = tid; i < EF_TAB * 4; i += 256) t_run[i >> 2][i & 3] = 0.f;
+    if (tid < EF_NODES) { t_kind[tid] = EF_GENERIC; t_hub[tid] = -1; t_ishub[tid] = 0; t_hasrun[tid] = 0; }
+    if (tid < EF_NODES * 4) { t_self[tid >> 2][tid & 3] = 0.f; t_hubc[tid >> 2][tid & 3] = 0.f; }
+    if (tid == 0) { s_nf = 0; s_fhub = -1; s_bad = 0; }
+    lds_barrier();
+    // ---- trip 2: the window's in-lists (consecutive in the destination CSR) ----
+    const int e0 = s_rp[0], ne = s_rp[nw] - e0;
+    bool bad = ne > EF_MAXE;                                       // (not a batch of egonets: every node through gat_fwd_node)
+    const int colv = (!bad && tid < ne) ? a.col[e0 + tid] : 0;
+    if constexpr (NX == 1 || NX == 2) {                            // (the vector memory counter is in order: waiting for these also waits for
+        // the row slices issued in trip 1 -- which have had a whole trip's time by now)
+        for (int i = tid * 4; i < 2 * a.nx.kp; i += 1024) *reinterpret_cast<float4*>(s_wa + i) = *reinterpret_cast<const float4*>(a.nx.wa + i);
+    }
+    if (!bad) {
+        if (tid < ne) s_col[tid] = colv;
+        lds_barrier();
+        // nodes with one or two in-edges (parents, siblings, lone anchors): a thread per (node, head) -- max / sum of two numbers are what
+        // the wave reductions of gat_fwd_node give, bit for bit
+        if (tid < nw * 4) {
+            const int t = tid >> 2, h = tid & 3, v = u0 + t;
+            const int beg = s_rp[t] - e0, din = s_rp[t + 1] - s_rp[t];
+            if (din == 1 || din == 2) {
+                const int uo = s_col[beg], us = s_col[beg + din - 1];
+                int kind = EF_GENERIC;
+                if (us == v) {
+                    if (din == 1 || uo == v - 1) kind = EF_RUN;
+                    else if (uo < v - 1 && uo >= u0 - EF_BACK) kind = EF_HUBREF;
+                }
+                if (kind != EF_GENERIC) {
+                    const float adv = s_ad[t][h];
+                    const float es = leaky(s_as[v - u0 + EF_BACK][h] + adv, a.slope);
+                    const float eo = (din == 2) ? leaky(s_as[uo - u0 + EF_BACK][h] + adv, a.slope) : -INFINITY;
+                    const float m = fmaxf(eo, es);
+                    const float xs = __expf(es - m), xo = (din == 2) ? __expf(eo - m) : 0.f;
+                    const float sm = xo + xs;
+                    const int ps = e0 + beg + din - 1;
+                    {
+                        const float al = xs / sm;
+                        if (a.alpha != nullptr) a.alpha[(long long)ps * H + h] = al;
+                        float f = 1.f;
+                        if (a.drop_p > 0.f) f = drop_factor(a.seed, (unsigned long long)ps * H + h, a.drop_p, a.drop_scale);
+                        t_self[t][h] = al * f;
+                    }
+                    if (din == 2) {
+                        const int po = e0 + beg;
+                        const float al = xo / sm;
+                        if (a.alpha != nullptr) a.alpha[(long long)po * H + h] = al;
+                        float f = 1.f;
+                        if (a.drop_p > 0.f) f = drop_factor(a.seed, (unsigned long long)po * H + h, a.drop_p, a.drop_scale);
+                        if (kind == EF_RUN) {
+                            t_run[EF_BACK + t - 1][h] = al * f;
+                            if (h == 0) { t_flag[EF_BACK + t - 1] = 2; atomicAdd(&t_cnt[EF_BACK + t - 1], 1); }
+                        } else t_hubc[t][h] = al * f;
+                    }
+                }
+                if (h == 0) {
+                    t_kind[t] = kind;
+                    t_hub[t] = (kind == EF_HUBREF) ? uo : -1;
+                    t_hasrun[t] = (kind == EF_RUN && din == 2) ? 1 : 0;
+                    if (kind == EF_RUN && din == 2 && t == 0) atomicMax(&s_nf, 1);
+                }
+            }
+        }
+        // nodes with 3..64 in-edges (anchors behind their parents): a wave per node, lane = in-edge, as gat_fwd_node does it
+        for (int t = w; t < nw; t += GAT_WAVES) {
+            const int beg = s_rp[t] - e0, din = s_rp[t + 1] - s_rp[t];
+            if (din < 3 || din > 64) continue;                                // (wave-uniform; 0 or more than 64: EF_GENERIC)
+            const int v = u0 + t, first = v - (din - 1);
+            const bool valid = l < din;
+            const int u = s_col[beg + (valid ? l : 0)];
+            if (__ballot(valid && u != first + l) != 0ull) continue;          // not a run: EF_GENERIC
+            float e[4], ex[4], m[4], sm[4];
+#pragma unroll
+            for (int h = 0; h < 4; ++h) e[h] = valid ? leaky(s_as[(valid ? u : v) - u0 + EF_BACK][h] + s_ad[t][h], a.slope) : -INFINITY;
+#pragma unroll
+            for (int h = 0; h < 4; ++h) m[h] = wave_max(e[h]);
+#pragma unroll
+            for (int h = 0; h < 4; ++h) ex[h] = valid ? __expf(e[h] - m[h]) : 0.f;
+#pragma unroll
+            for (int h = 0; h < 4; ++h) sm[h] = wave_sum(ex[h]);
+            if (valid) {
+                const int p = e0 + beg + l;
+                const int idx = first + l - u0 + EF_BACK;                     // (run member: 1 <= idx < EF_BACK + nw)
+                const bool self = l == din - 1;
+#pragma unroll
+                for (int h = 0; h < 4; ++h) {
+                    const float al = ex[h] / sm[h];
+                    if (a.alpha != nullptr) a.alpha[(long long)p * H + h] = al;
+                    float f = 1.f;
+                    if (a.drop_p > 0.f) f = drop_factor(a.seed, (unsigned long long)p * H + h, a.drop_p, a.drop_scale);
+                    if (self) t_self[t][h] = al * f; else t_run[idx][h] = al * f;
+                }
+                if (!self) { t_flag[idx] = (l == 0) ? 2 : 1; atomicAdd(&t_cnt[idx], 1); }
+            }
+            if (l == 0) {
+                t_kind[t] = EF_RUN; t_hasrun[t] = 1;
+                if (first < u0) atomicMax(&s_nf, u0 - first);
+            }
+        }
+        lds_barrier();
+        if (tid < EF_TAB && t_cnt[tid] > 1) s_bad = 1;                        // a row wanted by two runs: one accumulator cannot serve both
+        if (tid < nw && t_kind[tid] == EF_HUBREF) {
+            const int hb = t_hub[tid];
+            if (hb >= u0) t_ishub[hb - u0] = 1; else atomicMax(&s_fhub, hb);
+        }
+        lds_barrier();
+        if (tid < nw && t_kind[tid] == EF_HUBREF) {                           // the slice in `hub` when this node is walked must be its hub's
+            int latest = s_fhub;
+            for (int j = tid - 1; j >= 0; --j) if (t_ishub[j]) { latest = u0 + j; break; }
+            if (latest != t_hub[tid]) t_kind[tid] = EF_GENERIC;
+        }
+        lds_barrier();
+        bad = s_bad != 0;
+    }
+
+#if defined(TXE_EF_X) && TXE_EF_X == 1
+    if (false) {
+#else
+    if (!bad) {
+#endif
+        float acc[NI][4], hub[NI][4];
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) acc[i][k] = 0.f;
+        {   // the hub a window that starts behind its anchor needs
+            const int fh = s_fhub;
+            const int hv = (fh >= 0) ? fh : u0;
+#pragma unroll
+            for (int i = 0; i < NI; ++i) vload<4>(a.ft + (long long)hv * a.ld_ft + off[i], hub[i]);
+        }
+        // run members in front of the window (an anchor whose parents sit in the previous window): their rows once more
+        const int nf = s_nf;
+        for (int f = 0; f < nf; ++f) {
+            const int idx = EF_BACK - nf + f, fl = t_flag[idx];
+            const float cr = t_run[idx][w];
+            float y[NI][4];
+#pragma unroll
+            for (int i = 0; i < NI; ++i) vload<4>(a.ft + (long long)(u0 - nf + f) * a.ld_ft + off[i], y[i]);
+#pragma unroll
+            for (int i = 0; i < NI; ++i)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float tmp = fmaf(cr, y[i][k], (fl == 2) ? 0.f : acc[i][k]);
+                    acc[i][k] = fl ? tmp : acc[i][k];
+                }
+        }
+        auto step = [&](const int t, const float (&cur)[NI][4], const unsigned (&kbc)[NI], const float txc, const unsigned tkc) {
+            const int v = u0 + t;
+            const int kind = t_kind[t], fl = t_flag[EF_BACK + t], ish = t_ishub[t], hasrun = t_hasrun[t];
+            const float cs = t_self[t][w], ch = t_hubc[t][w], cr = t_run[EF_BACK + t][w];
+            float nx1 = 0.f, nx2 = 0.f;
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                float res[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float y = cur[i][k];
+                    const float base = (kind == EF_HUBREF) ? fmaf(ch, hub[i][k], 0.f) : (hasrun ? acc[i][k] : 0.f);
+                    float r = fmaf(cs, y, base);
+                    const float tmp = fmaf(cr, y, (fl == 2) ? 0.f : acc[i][k]);
+                    acc[i][k] = fl ? tmp : acc[i][k];
+                    hub[i][k] = ish ? y : hub[i][k];
+                    if (a.out_mode == 1) r = leaky(r, a.act_slope);
+                    if constexpr (NX == 3) r = ((kbc[i] >> k) & 1u) ? r * a.nx.scale : 0.f;
+                    res[k] = r;
+                }
+                vstore<4>(a.out + (long long)v * a.ld_out + off[i], res);
+                if constexpr (NX == 1 || NX == 2) {
+                    float w1[4], w2[4];
+                    vload<4>(s_wa + off[i], w1);
+                    vload<4>(s_wa + a.nx.kp + off[i], w2);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const float xd = (live[i] && ((kbc[i] >> k) & 1u)) ? res[k] : 0.f;
+                        nx1 = fmaf(xd, w1[k], nx1);
+                        nx2 = fmaf(xd, w2[k], nx2);
+                    }
+                }
+            }
+            if constexpr (NX == 1 || NX == 2) {
+                const float xd = (tlive && tkc) ? txc : 0.f;
+                nx1 = fmaf(xd, s_wa[cc], nx1);
+                nx2 = fmaf(xd, s_wa[a.nx.kp + cc], nx2);
+                nx1 = wave_sum(nx1);
+                nx2 = wave_sum(nx2);
+                if (l == 0) { s_nx[t][w][0] = nx1; s_nx[t][w][1] = nx2; }
+            }
+        };
+        int t = 0;
+        for (; t + EF_RING <= nw; t += EF_RING) {
+#pragma unroll
+            for (int r = 0; r < EF_RING; ++r) {
+                constexpr int RN = EF_RING - 1;
+                const int rn = (r + RN) % EF_RING;
+                load_row(u0 + min(t + r + RN, nw - 1), ring[rn], kbr[rn], txr[rn], tkr[rn]);
+                step(t + r, ring[r], kbr[r], txr[r], tkr[r]);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < EF_RING - 1; ++r)
+            if (t + r < nw) step(t + r, ring[r], kbr[r], txr[r], tkr[r]);
+    }
+    __syncthreads();                                                          // (the walk's stores are out: a generic node's row is rewritten below)
+    if constexpr (NX == 1 || NX == 2) {
+        if (!bad && tid < nw && t_kind[tid] != EF_GENERIC) {
+            const float p1 = (s_nx[tid][0][0] + s_nx[tid][1][0]) + (s_nx[tid][2][0] + s_nx[tid][3][0]);
+            const float p2 = (s_nx[tid][0][1] + s_nx[tid][1][1]) + (s_nx[tid][2][1] + s_nx[tid][3][1]);
+            a.nx.a12[2 * (long long)(u0 + tid)] = p1 * a.nx.scale;
+            a.nx.a12[2 * (long long)(u0 + tid) + 1] = p2 * a.nx.scale;
+        }
+    }
+    for (int t = w; t < nw; t += GAT_WAVES) {
+        if (bad || t_kind[t] == EF_GENERIC) {
+            gat_fwd_node<4, 4, NX, false>(u0 + t, l, g_w[w], g_idx[w], g_stat[w], s_wa, a.rowptr, a.col, a.ft, a.ld_ft, a.a_src, a.a_dst, a.ld_a, H,
+                                          a.D, a.slope, a.drop_p, a.drop_scale, a.seed, a.out_mode, a.act_slope, a.out, a.ld_out, a.alpha,
+                                          a.nx, TabSrc{nullptr, nullptr, nullptr, 0}, g_idx[w], s_wa);
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // backward, destination side: d alpha (dot products), softmax + leaky-relu backward -> dz[E,H],
 // d a_dst[N,H].  d_pre = gradient w.r.t. the aggregated (pre-activation) output.
@@ -787,6 +1120,21 @@ static inline int fwd_nodes_per_wave(int n_nodes, int forced) {
     return n_nodes >= 4096 ? 2 : 1;       // (4 per wave was measured too: 173 VGPRs = two waves per SIMD, 119 us against 93 us)
 }
 
+// destination nodes per workgroup of the egonet walk: one round of workgroups where the batch allows it (four per CU), a workgroup
+// costing about (nodes + 4)
+int device_cu_count();     // txe_profile.hip
+static inline int ef_nodes_per_wg(int n_nodes, int occupancy) {
+    const int slots = occupancy * device_cu_count();
+    int best = 16;
+    double best_cost = 1e30;
+    for (int npw = 12; npw <= EF_NODES; npw += 2) {
+        const long long blocks = ((long long)n_nodes + npw - 1) / npw;
+        const double cost = (double)((blocks + slots - 1) / slots) * (npw + 4.0);
+        if (cost < best_cost) { best_cost = cost; best = npw; }
+    }
+    return best;
+}
+
 static inline int pick_vec(int D, long long ld1, long long ld2, const void* p1, const void* p2) {
     auto al = [](const void* p, int bytes) { return ((uintptr_t)p % bytes) == 0; };
     if (D % 4 == 0 && ld1 % 4 == 0 && ld2 % 4 == 0 && al(p1, 16) && al(p2, 16)) return 4;
@@ -804,7 +1152,9 @@ int txe_gat_aggregate_fwd(const int* rowptr_in, const int* col_src, int n_nodes,
                           const float* a_src, const float* a_dst, int ld_a, int H, int D, float attn_slope, float attn_drop_p,
                           unsigned long long seed, int out_mode, float act_slope, float* out, long long ld_out, float* alpha,
                           const float* nx_wa, int nx_kp, const unsigned* nx_mask, float nx_feat_drop_p, float* nx_a12, int npw_req, void* stream) {
-    if (n_nodes < 0 || H < 1 || H > GAT_MAXH || D < 1 || !rowptr_in || !ft || !a_src || !a_dst || !out || npw_req < 0 || npw_req > 2) return TXE_ERR_ARG;
+    if (n_nodes < 0 || H < 1 || H > GAT_MAXH || D < 1 || !rowptr_in || !ft || !a_src || !a_dst || !out || npw_req < 0 ||
+        (npw_req > 4 && npw_req < 8) || npw_req > EF_NODES)
+        return TXE_ERR_ARG;
     if (out_mode != 0 && out_mode != 1) return TXE_ERR_ARG;
     if (attn_drop_p < 0.f || attn_drop_p >= 1.f) return TXE_ERR_ARG;
     if (nx_a12 && (!nx_wa || nx_kp < H * D || nx_kp - H * D > 128 || (nx_kp & 31) || ld_out != nx_kp || nx_feat_drop_p < 0.f || nx_feat_drop_p >= 1.f ||
@@ -827,6 +1177,30 @@ int txe_gat_aggregate_fwd(const int* rowptr_in, const int* col_src, int n_nodes,
     // (16-byte rows of 257-320 or 513-640 vectors -- SemEval's 4 x 600 columns are 600 -- take 5 per lane: two passes over 320 lane slots
     //  instead of two over 512 whose clamped loads still issue)
     const int nvec = H * D / vec;
+    // the egonet walk (gat_aggregate_ego_kernel): four heads, 16-byte rows of at most 192 vectors per head; npw_req 0 = when the batch
+    // fills the chip, 3 | 8..32 = forced (with that many nodes per workgroup), 1 | 2 | 4 = never
+    const bool ego_fits = H == 4 && vec == 4 && (D & 3) == 0 && D / 4 <= 192 && (!nx_wa || nx_kp <= 4096);
+    if ((npw_req == 3 || npw_req >= 8) && !ego_fits) return TXE_ERR_ARG;
+    if (ego_fits && (npw_req == 3 || npw_req >= 8 || (npw_req == 0 && n_nodes >= 4096))) {
+        EgoFwdArgs ea;
+        ea.rowptr = rowptr_in; ea.col = col_src; ea.n_nodes = n_nodes; ea.ft = ft; ea.ld_ft = ld_ft; ea.a_src = a_src; ea.a_dst = a_dst;
+        ea.ld_a = ld_a; ea.D = D; ea.slope = attn_slope; ea.drop_p = attn_drop_p; ea.drop_scale = scale; ea.seed = seed;
+        ea.out_mode = out_mode; ea.act_slope = act_slope; ea.out = out; ea.ld_out = ld_out; ea.alpha = alpha; ea.nx = nx;
+        ea.npw = (npw_req >= 8) ? npw_req : ef_nodes_per_wg(n_nodes, (D / 4 <= 128) ? TXE_EF_OCC : 3);
+        const int nbe = (n_nodes + ea.npw - 1) / ea.npw;
+        const int nie = (D / 4 <= 128) ? 2 : 3;
+        const int mode = nx_a12 ? (nx.mask ? 2 : 1) : (out_drop ? 3 : 0);
+        const size_t lds = nx_a12 ? (size_t)2 * nx_kp * sizeof(float) : 0;
+        const KName kn("gat_aggregate_ego_kernel", nie, mode);
+        ProfScope prof(kn.s, s, 4.0 * (2.0 * n_nodes * (double)H * D + 2.0 * n_nodes * H + n_nodes + 1), 1);
+#define TXE_LE(I, M) hipLaunchKernelGGL((gat_aggregate_ego_kernel<I, M>), dim3(nbe), dim3(256), lds, s, ea)
+#define TXE_LEM(I) do { if (mode == 0) TXE_LE(I, 0); else if (mode == 1) TXE_LE(I, 1); else if (mode == 2) TXE_LE(I, 2); else TXE_LE(I, 3); } while (0)
+        if (nie == 2) TXE_LEM(2); else TXE_LEM(3);
+#undef TXE_LEM
+#undef TXE_LE
+        TXE_CHECK_LAUNCH();
+        return TXE_OK;
+    }
     const int ni = (vec == 4 && ((nvec > 256 && nvec <= 320) || (nvec > 512 && nvec <= 640))) ? 5 : pick_ni(nvec);
     const int npw = fwd_nodes_per_wave(n_nodes, npw_req);
     const int nb = (n_nodes + GAT_WAVES * npw - 1) / (GAT_WAVES * npw);

@@ -50,7 +50,8 @@ _NO_FUSED_BWD = False       # the folded layer's backward as the unfused chain (
 _NO_QUERY_RUNS = False      # stacked query rows always take the GEMM form of the bilinear match
 _NO_SPLIT_GEMM = False      # the first layer's projection on the fp32 MFMA instead of the bf16 pipe's six plane products
 _NO_TAIL_CHAIN = False      # every layer's last reduction launch in place instead of chained into the bottom layer's
-_NO_EGO_WALK = False        # the fused backward sweep fetches X'[v] per out-edge (gat_fused_bwd_kernel) instead of walking egonets from registers
+_FWD_SWEEP = 0              # txe_gat_aggregate_fwd's npw argument (0 = chosen from the batch; tools/kt_quick.py sets others)
+_NO_EGO_WALK = False        # the forward sweep runs one wave per node and the fused backward sweep fetches X'[v] per out-edge, instead of walking egonets
 _I32_MEMO = {}       # id(source tensor) -> (weakref, version, device, int32 copy): `pos` is converted once per batch, not once per module
 
 
@@ -476,7 +477,8 @@ def _gat_layer_fwd(csr, st, h, ld_h, pos, out, ld_out, feat_p, attn_p, attn_slop
     call("txe_gat_aggregate_fwd", ptr(csr.rowptr_in), ptr(csr.col_src), N, ptr(st.Y), Fp, ptr(st.Y) + 4 * F, ptr(st.Y) + 4 * (F + H), Fp,
          H, D, attn_slope, attn_p, st.seed + 1, out_mode, act_slope, ptr(out), ld_out, ptr(st.alpha),
          *((ptr(nxt[0].Wp) + 4 * nxt[0].D * nxt[0].Kp, nxt[0].Kp, ptr(nxt[0].mask), feat_p, ptr(nxt[1])) if nxt is not None
-           else ((None, out_drop.Kp, ptr(out_drop.mask), feat_p, None) if out_drop is not None else (None, 0, None, 0.0, None))), 0, s)
+           else ((None, out_drop.Kp, ptr(out_drop.mask), feat_p, None) if out_drop is not None else (None, 0, None, 0.0, None))),
+         4 if _NO_EGO_WALK else (_FWD_SWEEP if H == 4 and D % 4 == 0 else 0), s)
 
 
 def _gat_aggregate_bwd(csr, st, attn_p, attn_slope, d_pre, ld_dpre):

@@ -152,6 +152,31 @@ def test_training_mode_dropout_matches_oracle(name, drop, monkeypatch):
     assert not errors, "\n".join(errors)
 
 
+@pytest.mark.parametrize("name", ["mag_pgat_wmr_lbm_q8x32", "semeval_pgat_wmr_bim_q8x32"])
+def test_forward_egonet_walk_matches_reference_goldens(name, monkeypatch):
+    """the four-head goldens of the unmodified reference with the forward message/reduce sweep FORCED onto the egonet walk
+    (gat_aggregate_ego_kernel; by itself it takes batches of 4,096 nodes and more -- the full-size tests): node states, graph vectors,
+    scores, loss, every gradient entry"""
+    from taxoexpan_amd import ops
+    monkeypatch.setattr(ops, "_FWD_SWEEP", 3)
+    spec, z, shapes, x, q, params, graph = load_case(name)
+    model = _build_model(spec, params).eval()
+    g = _graph(shapes)
+    caps = {}
+    model.readout.register_forward_hook(lambda m, i, o: caps.__setitem__("hg", o))
+    scores = model(g, torch.from_numpy(x).to(_dev()), torch.from_numpy(q).to(_dev()))
+    nq = spec["n_queries"]
+    loss = torch.nn.functional.cross_entropy(scores.reshape(nq, -1), torch.zeros(nq, dtype=torch.long, device=_dev()), reduction="sum")
+    loss.backward()
+    step = gc.row_steps(spec)[0]
+    np.testing.assert_allclose(g.ndata["h"].detach().cpu().numpy()[::step], z["hn"], rtol=RT, atol=AT)
+    np.testing.assert_allclose(_values(caps["hg"]), z["hg"], rtol=RT, atol=AT)
+    np.testing.assert_allclose(scores.detach().cpu().numpy(), z["scores"], rtol=RT, atol=AT)
+    np.testing.assert_allclose(loss.item(), float(z["loss"]), rtol=1e-4)
+    for k, p in model.named_parameters():
+        check_grad(z, k, p.grad.cpu().numpy(), rtol=2e-3, atol=2e-5)
+
+
 @pytest.mark.parametrize("switch,case", [("_NO_SIDE_STREAM", "small_pgat_2layer"), ("_NO_FUSED_BWD", "small_pgat_2layer"),
                                          ("_NO_FUSED_LOGITS", "small_pgat_2layer"), ("_NO_TAIL_CHAIN", "small_pgat_2layer"),
                                          # four heads under the folded layer: the egonet-walking sweep (windows cut the larger egonets:
@@ -166,6 +191,8 @@ def test_ab_switch_routes_give_the_same_training_step(switch, case, monkeypatch)
     spec = dict(spec, dropout=(0.3, 0.25))
     monkeypatch.setattr(ops, "new_seed", lambda: 424242)
     outs = []
+    if switch == "_NO_EGO_WALK":       # (these batches are below the size at which the forward sweep walks egonets by itself)
+        monkeypatch.setattr(ops, "_FWD_SWEEP", 3)
     for on in (False, True):
         monkeypatch.setattr(ops, switch, on)
         model = _build_model(spec, params).train()
@@ -609,6 +636,73 @@ def test_forward_sweep_two_nodes_per_wave_is_bit_equal_to_one():
         assert np.isfinite(outs[1][k]).all(), k
         assert np.array_equal(outs[1][k], outs[2][k]), k
     assert not np.array_equal(outs[1]["plain_eval_out"][:, :208], np.full((4099, 208), 0.25, dtype=np.float32))
+
+
+def _egonet_csr_for_walk(rs, shapes, dev):
+    from taxoexpan_amd.graph import BatchedDGLGraph
+    g = BatchedDGLGraph.from_egonet_shapes([s[0] for s in shapes], [s[1] for s in shapes])
+    csr = g.csr(dev)
+    return csr.rowptr_in, csr.col_src, csr.n_nodes, csr.n_edges
+
+
+@pytest.mark.parametrize("D,kp", [(52, 224), (500, 2080), (600, 2464)])
+def test_forward_sweep_walking_egonets_is_bit_equal_to_node_per_wave(D, kp):
+    """gat_aggregate_ego_kernel (txe_gat.hip: a workgroup walks a window of consecutive destination nodes, every row read once) against
+    gat_aggregate_fwd_kernel (one wave per node) -- `out` and `alpha` bit for bit, the next layer's logits within rounding (another
+    summation order) -- on a batch of egonets (anchors without parents, with 40 parents, with 51 siblings, single nodes) for several
+    window sizes (so that windows start behind anchors and between parents), and on a generic multigraph (no egonet in it: hubs above 64
+    in-edges, nodes without in-edges, chains whose runs overlap), where every node takes the kernel's generic path."""
+    from taxoexpan_amd import _lib
+    from taxoexpan_amd._lib import call, ptr
+    rs = np.random.RandomState(11)
+    dev = _dev()
+    H = 4
+    shapes = [(int(rs.randint(0, 4)), int(rs.randint(0, 9))) for _ in range(900)]
+    shapes[3], shapes[4], shapes[5], shapes[6], shapes[7] = (40, 2), (0, 0), (1, 51), (63, 0), (0, 51)
+    shapes[200:210] = [(0, 0)] * 10
+    graphs = {}
+    rp, cl, N, E = _egonet_csr_for_walk(rs, shapes, dev)
+    graphs["egonets"] = (rp, cl, N, E)
+    Ng = 4099
+    deg = rs.randint(0, 6, size=Ng); deg[[5, 77, Ng - 1]] = [70, 200, 130]; deg[[6, 7, 4000]] = 0
+    deg[1000:1040] = 3; deg[1100:1110] = 2; deg[1200:1230] = 2; deg[1300:1320] = 2; deg[1400:1410] = 1
+    rowptr = np.concatenate([[0], np.cumsum(deg)]).astype(np.int32)
+    col = rs.randint(0, Ng, size=int(rowptr[-1])).astype(np.int32)
+    for v in range(1000, 1040): col[rowptr[v]:rowptr[v + 1]] = [v - 2, v - 1, v]          # runs that overlap
+    for v in range(1100, 1110): col[rowptr[v]:rowptr[v + 1]] = [v, v - 1]                 # the self loop first
+    for v in range(1200, 1230): col[rowptr[v]:rowptr[v + 1]] = [v - 5, v]                 # every node another hub
+    for v in range(1300, 1320): col[rowptr[v]:rowptr[v + 1]] = [1290 + (v & 1), v]        # two hubs, alternating
+    for v in range(1400, 1410): col[rowptr[v]:rowptr[v + 1]] = [v + 1]                    # one in-edge, not the self loop
+    graphs["multigraph"] = (torch.from_numpy(rowptr).to(dev), torch.from_numpy(col).to(dev), Ng, int(rowptr[-1]))
+    for gname, (rp, cl, N, E) in graphs.items():
+        ft = torch.from_numpy(rs.standard_normal((N, H * D)).astype(np.float32)).to(dev)
+        a12 = torch.from_numpy(rs.standard_normal((N, 2 * H)).astype(np.float32)).to(dev)
+        wa = torch.from_numpy(rs.standard_normal((2, kp)).astype(np.float32)).to(dev)
+        mask = torch.from_numpy(rs.randint(0, 2 ** 31, size=(N, kp // 32)).astype(np.int32)).to(dev)
+        outs = {}
+        for npw in (1, 3, 8, 13, 32):
+            res = {}
+            for mode, (nx, nx_p, use_mask) in dict(plain=(False, 0.0, False), logits=(True, 0.0, False), logits_mask=(True, 0.5, True),
+                                                   rows_dropped=(False, 0.5, True)).items():
+                for attn_p, keep in ((0.0, False), (0.3, True)):
+                    out = torch.full((N, kp), 0.25, device=dev)
+                    alpha = torch.full((E * H + 1,), -1.0, device=dev)
+                    nxa = torch.full((N, 2), -1.0, device=dev)
+                    call('txe_gat_aggregate_fwd', ptr(rp), ptr(cl), N, ptr(ft), H * D, ptr(a12), ptr(a12[:, H:]), 2 * H, H, D, 0.2, attn_p, 99, 1, 0.01,
+                         ptr(out), kp, ptr(alpha) if keep else None, ptr(wa) if nx else None, kp, ptr(mask) if use_mask else None, nx_p,
+                         ptr(nxa) if nx else None, npw, _lib.stream_ptr())
+                    torch.cuda.synchronize()
+                    k = mode + ('_train' if keep else '_eval')
+                    res[k + '_out'], res[k + '_alpha'], res[k + '_nx'] = out.cpu().numpy(), alpha.cpu().numpy(), nxa.cpu().numpy()
+            outs[npw] = res
+        for npw in (3, 8, 13, 32):
+            for k in outs[1]:
+                assert np.isfinite(outs[npw][k]).all(), (gname, npw, k)
+                if k.endswith('_nx'):
+                    scale = np.abs(outs[1][k]).max() + 1e-6
+                    assert np.abs(outs[npw][k] - outs[1][k]).max() <= 2e-6 * scale * np.sqrt(kp), (gname, npw, k)
+                else:
+                    assert np.array_equal(outs[1][k], outs[npw][k]), (gname, npw, k, int((outs[1][k] != outs[npw][k]).sum()))
 
 
 def test_readout_and_match_ops_against_oracle():

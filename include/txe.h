@@ -135,7 +135,8 @@ int txe_gat_aggregate_table_supported(int H, int D, long long ld_t, int vocab, i
 int txe_gat_aggregate_table_fwd(const int* rowptr_in, const int* col_src, int n_nodes, const float* T, long long ld_t, const int* rid,
                                 const float* T2, const int* pos, int vocab, int H, int D, float attn_slope, int out_mode,
                                 float act_slope, float* out, long long ld_out, const float* nx_wa, int nx_kp, float* nx_a12,
-                                void* stream);
+                                int npw, void* stream);
+/* npw: as txe_gat_aggregate_fwd's (0 = chosen from the batch, 1 | 4 = one wave per node, 3 | 8..32 = the egonet walk, forced). */
 
 /* ---- GATLayer message/reduce: model_zoo.py:90-95,106-114 (edge_attention, edge_softmax, attn_drop, update_all) -----
  * out_mode 0: out = aggregated features; 1: out = leaky_relu(aggregated, act_slope) (model_zoo.py:216 fused).

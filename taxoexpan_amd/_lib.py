@@ -33,7 +33,7 @@ SIGNATURES = {
     "txe_gat_dx_streams": (I, [I, I, I]),
     "txe_gat_aggregate_fwd": (I, [P, P, I, P, L, P, P, I, I, I, F, F, U64, I, F, P, L, P, P, I, P, F, P, I, P]),
     "txe_gat_aggregate_table_supported": (I, [I, I, L, I, I]),
-    "txe_gat_aggregate_table_fwd": (I, [P, P, I, P, L, P, P, P, I, I, I, F, I, F, P, L, P, I, P, P]),
+    "txe_gat_aggregate_table_fwd": (I, [P, P, I, P, L, P, P, P, I, I, I, F, I, F, P, L, P, I, P, I, P]),
     "txe_gat_aggregate_bwd": (I, [P, P, P, P, P, I, P, L, P, P, I, I, I, F, F, U64, P, P, L, P, L, P, P, I, P, I, P]),
     "txe_leaky_relu_bwd": (I, [P, P, F, L, P, P]),
     "txe_head_mean_fwd": (I, [P, I, I, L, P, P]),

@@ -389,22 +389,29 @@ struct EgoFwdArgs {
     const float* ft; long long ld_ft; const float *a_src, *a_dst; int ld_a, D;
     float slope, drop_p, drop_scale; unsigned long long seed; int out_mode; float act_slope;
     float* out; long long ld_out; float* alpha; NextLogits nx; int npw;
+    TabSrc tab;                          // TAB: ft = T, rows ft[u] = T[rid[u]] + T2[pos[u]] (a_src / a_dst: columns F.., F + H.. of the same)
 };
 
-template <int NI, int NX>
+template <int NI, int NX, bool TAB = false>
 __global__ __launch_bounds__(256, (NI >= 3) ? 3 : TXE_EF_OCC) void gat_aggregate_ego_kernel(const EgoFwdArgs a) {
     __shared__ int t_kind[EF_NODES], t_hub[EF_NODES], t_ishub[EF_NODES], t_hasrun[EF_NODES];
     __shared__ float t_self[EF_NODES][4], t_hubc[EF_NODES][4];
-    __shared__ float t_run[EF_TAB][4];
     __shared__ int t_flag[EF_TAB], t_cnt[EF_TAB];
     __shared__ float s_nx[EF_NODES][4][2];
     __shared__ int s_nf, s_fhub, s_bad;
-    __shared__ float g_w[GAT_WAVES][4 * 64];                       // gat_fwd_node's per-wave slots (nodes the walk leaves out)
-    __shared__ int g_idx[GAT_WAVES][64];
+    __shared__ int g_idx[GAT_WAVES][64], g_pos[TAB ? GAT_WAVES : 1][64];      // gat_fwd_node's per-wave slots (nodes the walk leaves out)
     __shared__ float g_stat[GAT_WAVES][8];
-    extern __shared__ __attribute__((aligned(16))) float s_wa[];   // NX 1 | 2: the next layer's two folded rows [2][kp]
-    __shared__ int s_rp[EF_NODES + 1], s_col[EF_MAXE];
-    __shared__ float s_as[EF_TAB][4], s_ad[EF_NODES][4];          // a_src of the nodes [u0 - EF_BACK, u0 + EF_NODES), a_dst of the window's
+    __shared__ int s_rp[EF_NODES + 1];
+    __shared__ int t_rid[TAB ? EF_TAB : 1], t_posn[TAB ? EF_TAB : 1];          // TAB: table row / T2 row of the nodes [u0 - EF_BACK, u0 + EF_NODES)
+    // staging tables that the generic phase no longer needs; gat_fwd_node's weight slots (4 x 256 floats) lie on top of them then
+    __shared__ __attribute__((aligned(16))) float s_pool[EF_MAXE + EF_TAB * 4 + EF_NODES * 4 + EF_TAB * 4];
+    static_assert(EF_MAXE + EF_TAB * 4 + EF_NODES * 4 + EF_TAB * 4 >= GAT_WAVES * 4 * 64, "gat_fwd_node's slots fit the pool");
+    int* const s_col = reinterpret_cast<int*>(s_pool);                                            // [EF_MAXE]
+    float (*const s_as)[4] = reinterpret_cast<float (*)[4]>(s_pool + EF_MAXE);                    // [EF_TAB]: a_src of [u0 - EF_BACK, u0 + EF_NODES)
+    float (*const s_ad)[4] = reinterpret_cast<float (*)[4]>(s_pool + EF_MAXE + EF_TAB * 4);       // [EF_NODES]: a_dst of the window's nodes
+    float (*const t_run)[4] = reinterpret_cast<float (*)[4]>(s_pool + EF_MAXE + EF_TAB * 4 + EF_NODES * 4);   // [EF_TAB]
+    extern __shared__ __attribute__((aligned(16))) float s_wa[];   // NX 1 | 2: the next layer's two folded rows [2][kp]; TAB: T2 behind them
+    float* const s_t2 = s_wa + ((NX == 1 || NX == 2) ? 2 * a.nx.kp : 0);
     constexpr int H = 4;
     const int tid = threadIdx.x, l = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -425,10 +432,17 @@ __global__ __launch_bounds__(256, (NI >= 3) ? 3 : TXE_EF_OCC) void gat_aggregate
     const int cc = tlive ? ct : 0;
     float ring[EF_RING][NI][4], txr[EF_RING];                      // position q's slice lives in slot q % EF_RING
     unsigned kbr[EF_RING][NI], tkr[EF_RING];
-    auto load_row = [&](const int v, float (&y)[NI][4], unsigned (&kb)[NI], float& tx, unsigned& tk) {
+    // the slice of the node at window position q (q < 0: in front of the window) -- TAB: of its table row, T2's share is added at its use
+    auto row_of = [&](const int q) -> const float* {
+        if constexpr (TAB) return a.ft + (long long)t_rid[q + EF_BACK] * a.ld_ft;
+        else return a.ft + (long long)(u0 + q) * a.ld_ft;
+    };
+    auto load_row = [&](const int q, float (&y)[NI][4], unsigned (&kb)[NI], float& tx, unsigned& tk) {
+        const int v = u0 + q;
+        const float* row = row_of(q);
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
-            vload<4>(a.ft + (long long)v * a.ld_ft + off[i], y[i]);
+            vload<4>(row + off[i], y[i]);
             kb[i] = 0xFu;
             if constexpr (NX >= 2) kb[i] = a.nx.mask[(long long)v * a.nx.mask_ld + (off[i] >> 5)] >> (off[i] & 31);
         }
@@ -440,7 +454,19 @@ __global__ __launch_bounds__(256, (NI >= 3) ? 3 : TXE_EF_OCC) void gat_aggregate
     };
     // ---- staging, trip 1: the window's row pointers and attention terms; behind them (in flight across the whole staging phase: its
     //      barriers wait for LDS only) the first row slices of the walk ----
-    {
+    if constexpr (TAB) {
+        // (the table route needs one trip more before a row can be asked for: node -> table row)
+        const int rp = a.rowptr[u0 + min(tid, nw)];
+        const int node = min(max(u0 - EF_BACK + min(tid, EF_TAB - 1), 0), a.n_nodes - 1);
+        const int rr = a.tab.rid[node], pp = a.tab.pos[node];
+        for (long long i = tid * 4; i < (long long)a.tab.vocab * a.ld_ft; i += 1024)
+            *reinterpret_cast<float4*>(s_t2 + i) = *reinterpret_cast<const float4*>(a.tab.t2 + i);
+        if constexpr (NX == 1 || NX == 2) {
+            for (int i = tid * 4; i < 2 * a.nx.kp; i += 1024) *reinterpret_cast<float4*>(s_wa + i) = *reinterpret_cast<const float4*>(a.nx.wa + i);
+        }
+        if (tid <= nw) s_rp[tid] = rp;
+        if (tid < EF_TAB) { t_rid[tid] = rr; t_posn[tid] = pp; }
+    } else {
         const int rp = a.rowptr[u0 + min(tid, nw)];
         float sa[(EF_TAB * 4 + 255) / 256];
 #pragma unroll
@@ -452,7 +478,7 @@ __global__ __launch_bounds__(256, (NI >= 3) ? 3 : TXE_EF_OCC) void gat_aggregate
         const int dn = min(tid >> 2, nw - 1) ;
         const float sd = a.a_dst[(long long)(u0 + dn) * a.ld_a + (tid & 3)];
 #pragma unroll
-        for (int r = 0; r < EF_RING - 1; ++r) load_row(u0 + min(r, nw - 1), ring[r], kbr[r], txr[r], tkr[r]);
+        for (int r = 0; r < EF_RING - 1; ++r) load_row(min(r, nw - 1), ring[r], kbr[r], txr[r], tkr[r]);
         if (tid <= nw) s_rp[tid] = rp;
 #pragma unroll
         for (int q = 0; q < (EF_TAB * 4 + 255) / 256; ++q) {
@@ -471,7 +497,25 @@ __global__ __launch_bounds__(256, (NI >= 3) ? 3 : TXE_EF_OCC) void gat_aggregate
     const int e0 = s_rp[0], ne = s_rp[nw] - e0;
     bool bad = ne > EF_MAXE;                                       // (not a batch of egonets: every node through gat_fwd_node)
     const int colv = (!bad && tid < ne) ? a.col[e0 + tid] : 0;
-    if constexpr (NX == 1 || NX == 2) {                            // (the vector memory counter is in order: waiting for these also waits for
+    if constexpr (TAB) {
+        // attention terms from the table rows, exactly as the materialised row would hold them; behind them the first row slices
+        float sa[(EF_TAB * 4 + 255) / 256];
+#pragma unroll
+        for (int q = 0; q < (EF_TAB * 4 + 255) / 256; ++q) {
+            const int i = min(tid + 256 * q, EF_TAB * 4 - 1);
+            sa[q] = a.ft[(long long)t_rid[i >> 2] * a.ld_ft + F + (i & 3)];
+        }
+        const int dn = EF_BACK + min(tid >> 2, nw - 1);
+        const float sd = a.ft[(long long)t_rid[dn] * a.ld_ft + F + H + (tid & 3)];
+#pragma unroll
+        for (int r = 0; r < EF_RING - 1; ++r) load_row(min(r, nw - 1), ring[r], kbr[r], txr[r], tkr[r]);
+#pragma unroll
+        for (int q = 0; q < (EF_TAB * 4 + 255) / 256; ++q) {
+            const int i = tid + 256 * q;
+            if (i < EF_TAB * 4) s_as[i >> 2][i & 3] = sa[q] + s_t2[(long long)t_posn[i >> 2] * a.ld_ft + F + (i & 3)];
+        }
+        if (tid < EF_NODES * 4) s_ad[tid >> 2][tid & 3] = sd + s_t2[(long long)t_posn[dn] * a.ld_ft + F + H + (tid & 3)];
+    } else if constexpr (NX == 1 || NX == 2) {                     // (the vector memory counter is in order: waiting for these also waits for
         // the row slices issued in trip 1 -- which have had a whole trip's time by now)
         for (int i = tid * 4; i < 2 * a.nx.kp; i += 1024) *reinterpret_cast<float4*>(s_wa + i) = *reinterpret_cast<const float4*>(a.nx.wa + i);
     }
@@ -589,9 +633,20 @@ __global__ __launch_bounds__(256, (NI >= 3) ? 3 : TXE_EF_OCC) void gat_aggregate
             for (int k = 0; k < 4; ++k) acc[i][k] = 0.f;
         {   // the hub a window that starts behind its anchor needs
             const int fh = s_fhub;
-            const int hv = (fh >= 0) ? fh : u0;
+            const int hq = (fh >= 0) ? fh - u0 : 0;
+            const float* hrow = row_of(hq);
 #pragma unroll
-            for (int i = 0; i < NI; ++i) vload<4>(a.ft + (long long)hv * a.ld_ft + off[i], hub[i]);
+            for (int i = 0; i < NI; ++i) vload<4>(hrow + off[i], hub[i]);
+            if constexpr (TAB) {
+                const float* trow = s_t2 + (long long)t_posn[hq + EF_BACK] * a.ld_ft;
+#pragma unroll
+                for (int i = 0; i < NI; ++i) {
+                    float tv[4];
+                    vload<4>(trow + off[i], tv);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) hub[i][k] += tv[k];
+                }
+            }
         }
         // run members in front of the window (an anchor whose parents sit in the previous window): their rows once more
         const int nf = s_nf;
@@ -599,8 +654,19 @@ __global__ __launch_bounds__(256, (NI >= 3) ? 3 : TXE_EF_OCC) void gat_aggregate
             const int idx = EF_BACK - nf + f, fl = t_flag[idx];
             const float cr = t_run[idx][w];
             float y[NI][4];
+            const float* frow = row_of(f - nf);
 #pragma unroll
-            for (int i = 0; i < NI; ++i) vload<4>(a.ft + (long long)(u0 - nf + f) * a.ld_ft + off[i], y[i]);
+            for (int i = 0; i < NI; ++i) vload<4>(frow + off[i], y[i]);
+            if constexpr (TAB) {
+                const float* trow = s_t2 + (long long)t_posn[idx] * a.ld_ft;
+#pragma unroll
+                for (int i = 0; i < NI; ++i) {
+                    float tv[4];
+                    vload<4>(trow + off[i], tv);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) y[i][k] += tv[k];
+                }
+            }
 #pragma unroll
             for (int i = 0; i < NI; ++i)
 #pragma unroll
@@ -614,12 +680,14 @@ __global__ __launch_bounds__(256, (NI >= 3) ? 3 : TXE_EF_OCC) void gat_aggregate
             const int kind = t_kind[t], fl = t_flag[EF_BACK + t], ish = t_ishub[t], hasrun = t_hasrun[t];
             const float cs = t_self[t][w], ch = t_hubc[t][w], cr = t_run[EF_BACK + t][w];
             float nx1 = 0.f, nx2 = 0.f;
+            const float* trow = s_t2 + (TAB ? (long long)t_posn[EF_BACK + t] * a.ld_ft : 0);
 #pragma unroll
             for (int i = 0; i < NI; ++i) {
-                float res[4];
+                float res[4], tv[4] = {0.f, 0.f, 0.f, 0.f};
+                if constexpr (TAB) vload<4>(trow + off[i], tv);
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    const float y = cur[i][k];
+                    const float y = TAB ? cur[i][k] + tv[k] : cur[i][k];
                     const float base = (kind == EF_HUBREF) ? fmaf(ch, hub[i][k], 0.f) : (hasrun ? acc[i][k] : 0.f);
                     float r = fmaf(cs, y, base);
                     const float tmp = fmaf(cr, y, (fl == 2) ? 0.f : acc[i][k]);
@@ -657,7 +725,7 @@ __global__ __launch_bounds__(256, (NI >= 3) ? 3 : TXE_EF_OCC) void gat_aggregate
             for (int r = 0; r < EF_RING; ++r) {
                 constexpr int RN = EF_RING - 1;
                 const int rn = (r + RN) % EF_RING;
-                load_row(u0 + min(t + r + RN, nw - 1), ring[rn], kbr[rn], txr[rn], tkr[rn]);
+                load_row(min(t + r + RN, nw - 1), ring[rn], kbr[rn], txr[rn], tkr[rn]);
                 step(t + r, ring[r], kbr[r], txr[r], tkr[r]);
             }
         }
@@ -676,9 +744,9 @@ __global__ __launch_bounds__(256, (NI >= 3) ? 3 : TXE_EF_OCC) void gat_aggregate
     }
     for (int t = w; t < nw; t += GAT_WAVES) {
         if (bad || t_kind[t] == EF_GENERIC) {
-            gat_fwd_node<4, 4, NX, false>(u0 + t, l, g_w[w], g_idx[w], g_stat[w], s_wa, a.rowptr, a.col, a.ft, a.ld_ft, a.a_src, a.a_dst, a.ld_a, H,
-                                          a.D, a.slope, a.drop_p, a.drop_scale, a.seed, a.out_mode, a.act_slope, a.out, a.ld_out, a.alpha,
-                                          a.nx, TabSrc{nullptr, nullptr, nullptr, 0}, g_idx[w], s_wa);
+            gat_fwd_node<4, 4, NX, TAB>(u0 + t, l, s_pool + w * 4 * 64, g_idx[w], g_stat[w], s_wa, a.rowptr, a.col, a.ft, a.ld_ft, a.a_src, a.a_dst,
+                                        a.ld_a, H, a.D, a.slope, a.drop_p, a.drop_scale, a.seed, a.out_mode, a.act_slope, a.out, a.ld_out,
+                                        a.alpha, a.nx, a.tab, g_pos[TAB ? w : 0], s_t2);
             __builtin_amdgcn_wave_barrier();
         }
     }
@@ -1102,6 +1170,7 @@ struct KName {
     KName(const char* base, int a, int b) { snprintf(s, sizeof(s), "%s<%d, %d>", base, a, b); }
     KName(const char* base, int a) { snprintf(s, sizeof(s), "%s<%d>", base, a); }
     KName(const char* base, int a, int b, int c) { snprintf(s, sizeof(s), "%s<%d, %d, %d>", base, a, b, c); }
+    KName(const char* base, int a, int b, bool c) { snprintf(s, sizeof(s), "%s<%d, %d, %s>", base, a, b, c ? "true" : "false"); }
     KName(const char* base, int a, int b, int c, bool d) { snprintf(s, sizeof(s), "%s<%d, %d, %d, %s>", base, a, b, c, d ? "true" : "false"); }
     KName(const char* base, int a, int b, int c, bool d, int e) { snprintf(s, sizeof(s), "%s<%d, %d, %d, %s, %d>", base, a, b, c, d ? "true" : "false", e); }
 };
@@ -1186,6 +1255,7 @@ int txe_gat_aggregate_fwd(const int* rowptr_in, const int* col_src, int n_nodes,
         ea.rowptr = rowptr_in; ea.col = col_src; ea.n_nodes = n_nodes; ea.ft = ft; ea.ld_ft = ld_ft; ea.a_src = a_src; ea.a_dst = a_dst;
         ea.ld_a = ld_a; ea.D = D; ea.slope = attn_slope; ea.drop_p = attn_drop_p; ea.drop_scale = scale; ea.seed = seed;
         ea.out_mode = out_mode; ea.act_slope = act_slope; ea.out = out; ea.ld_out = ld_out; ea.alpha = alpha; ea.nx = nx;
+        ea.tab = TabSrc{nullptr, nullptr, nullptr, 0};
         ea.npw = (npw_req >= 8) ? npw_req : ef_nodes_per_wg(n_nodes, (D / 4 <= 128) ? TXE_EF_OCC : 3);
         const int nbe = (n_nodes + ea.npw - 1) / ea.npw;
         const int nie = (D / 4 <= 128) ? 2 : 3;
@@ -1241,8 +1311,9 @@ int txe_gat_aggregate_table_supported(int H, int D, long long ld_t, int vocab, i
 int txe_gat_aggregate_table_fwd(const int* rowptr_in, const int* col_src, int n_nodes, const float* T, long long ld_t, const int* rid,
                                 const float* T2, const int* pos, int vocab, int H, int D, float attn_slope, int out_mode,
                                 float act_slope, float* out, long long ld_out, const float* nx_wa, int nx_kp, float* nx_a12,
-                                void* stream) {
+                                int npw_req, void* stream) {
     if (n_nodes < 0 || !rowptr_in || !T || !rid || !T2 || !pos || !out || (out_mode != 0 && out_mode != 1)) return TXE_ERR_ARG;
+    if (npw_req < 0 || (npw_req > 4 && npw_req < 8) || npw_req > EF_NODES || npw_req == 2) return TXE_ERR_ARG;
     if (!txe_gat_aggregate_table_supported(H, D, ld_t, vocab, nx_a12 ? nx_kp : 0)) return TXE_ERR_ARG;
     if ((ld_out & 3) || (((uintptr_t)T | (uintptr_t)T2 | (uintptr_t)out) & 15)) return TXE_ERR_ARG;
     if (nx_a12 && (!nx_wa || nx_kp < H * D || nx_kp - H * D > 128 || (nx_kp & 31) || ld_out != nx_kp || ((uintptr_t)nx_wa & 15))) return TXE_ERR_ARG;
@@ -1253,8 +1324,30 @@ int txe_gat_aggregate_table_fwd(const int* rowptr_in, const int* col_src, int n_
     nx.wa = nx_wa; nx.mask = nullptr; nx.a12 = nx_a12; nx.scale = 1.f; nx.kp = nx_a12 ? nx_kp : 0; nx.mask_ld = nx.kp / 32;
     TabSrc tab;
     tab.rid = rid; tab.pos = pos; tab.t2 = T2; tab.vocab = vocab;
-    const int ni = pick_ni(H * D / 4);
     const size_t lds = table_lds_bytes(ld_t, vocab, nx.kp);
+    // the egonet walk (gat_aggregate_ego_kernel<.., TAB>), as in txe_gat_aggregate_fwd: npw_req 0 = for batches that fill the chip,
+    // 3 | 8..32 = forced, 1 | 4 = one wave per node
+    const bool ego_fits = H == 4 && D / 4 <= 192 && lds + 12 * 1024 <= 64 * 1024;
+    if ((npw_req == 3 || npw_req >= 8) && !ego_fits) return TXE_ERR_ARG;
+    if (ego_fits && (npw_req == 3 || npw_req >= 8 || (npw_req == 0 && n_nodes >= 4096))) {
+        EgoFwdArgs ea;
+        ea.rowptr = rowptr_in; ea.col = col_src; ea.n_nodes = n_nodes; ea.ft = T; ea.ld_ft = ld_t; ea.a_src = T; ea.a_dst = T;
+        ea.ld_a = 0; ea.D = D; ea.slope = attn_slope; ea.drop_p = 0.f; ea.drop_scale = 1.f; ea.seed = 0ull;
+        ea.out_mode = out_mode; ea.act_slope = act_slope; ea.out = out; ea.ld_out = ld_out; ea.alpha = nullptr; ea.nx = nx; ea.tab = tab;
+        const int nie = (D / 4 <= 128) ? 2 : 3;
+        const int occ_lds = (int)((160 * 1024) / (lds + 12 * 1024)), occ = ((nie == 2) ? TXE_EF_OCC : 3) < occ_lds ? ((nie == 2) ? TXE_EF_OCC : 3) : occ_lds;
+        ea.npw = (npw_req >= 8) ? npw_req : ef_nodes_per_wg(n_nodes, occ);
+        const int nbe = (n_nodes + ea.npw - 1) / ea.npw;
+        const KName kn("gat_aggregate_ego_kernel", nie, nx_a12 ? 1 : 0, true);
+        ProfScope prof(kn.s, s, 4.0 * (2.0 * n_nodes * (double)H * D + 2.0 * n_nodes * H + 3.0 * n_nodes + 1), 1);
+#define TXE_LET(I, X) hipLaunchKernelGGL((gat_aggregate_ego_kernel<I, X, true>), dim3(nbe), dim3(256), lds, s, ea)
+        if (nx_a12) { if (nie == 2) TXE_LET(2, 1); else TXE_LET(3, 1); }
+        else { if (nie == 2) TXE_LET(2, 0); else TXE_LET(3, 0); }
+#undef TXE_LET
+        TXE_CHECK_LAUNCH();
+        return TXE_OK;
+    }
+    const int ni = pick_ni(H * D / 4);
     const KName kn("gat_aggregate_fwd_kernel", 4, ni, nx_a12 ? 1 : 0, true, 1);
     ProfScope prof(kn.s, s, 4.0 * (2.0 * n_nodes * (double)H * D + 2.0 * n_nodes * H + 3.0 * n_nodes + 1), 1);
 #define TXE_LT(I, X)                                                                                                              \

@@ -450,7 +450,8 @@ def _gat_layer_fwd(csr, st, h, ld_h, pos, out, ld_out, feat_p, attn_p, attn_slop
             st.Y = st.alpha = None
             call("txe_gat_aggregate_table_fwd", ptr(csr.rowptr_in), ptr(csr.col_src), N, ptr(T), Fp, ptr(_i32(h.index, T.device)), ptr(T2),
                  ptr(pos), T2.shape[0], H, D, attn_slope, out_mode, act_slope, ptr(out), ld_out,
-                 *((ptr(nxt[0].Wp) + 4 * nxt[0].D * nxt[0].Kp, nx_kp, ptr(nxt[1])) if nxt is not None else (None, 0, None)), s)
+                 *((ptr(nxt[0].Wp) + 4 * nxt[0].D * nxt[0].Kp, nx_kp, ptr(nxt[1])) if nxt is not None else (None, 0, None)),
+                 4 if _NO_EGO_WALK else (_FWD_SWEEP if H == 4 and D % 4 == 0 else 0), s)
             return
         st.Y = _empty((N, Fp), T)
         call("txe_gather_add_rows", ptr(T), Fp, ptr(_i32(h.index, T.device)), ptr(T2), Fp, ptr(pos) if T2 is not None else None, N, Fp,

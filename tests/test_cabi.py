@@ -67,7 +67,7 @@ def test_argument_validation_needs_no_gpu():
     assert lib.txe_gat_dense_ws_bytes(100, 250, 50, 4, 500, 3) > 0
     assert lib.txe_gat_padded_k(250, 50) == 320 and lib.txe_gat_padded_f(4, 500) == 2048
     assert lib.txe_gat_aggregate_table_supported(4, 500, 2048, 3, 2080) == 1 and lib.txe_gat_aggregate_table_supported(5, 500, 2560, 3, 0) == 0
-    assert lib.txe_gat_aggregate_table_fwd(None, None, 5, None, 2048, None, None, None, 3, 4, 500, 0.2, 0, 1.0, None, 0, None, 0, None, None) == -1
+    assert lib.txe_gat_aggregate_table_fwd(None, None, 5, None, 2048, None, None, None, 3, 4, 500, 0.2, 0, 1.0, None, 0, None, 0, None, 0, None) == -1
 
 
 def test_host_rng_restatement_matches_library():

@@ -705,6 +705,51 @@ def test_forward_sweep_walking_egonets_is_bit_equal_to_node_per_wave(D, kp):
                     assert np.array_equal(outs[1][k], outs[npw][k]), (gname, npw, k, int((outs[1][k] != outs[npw][k]).sum()))
 
 
+@pytest.mark.parametrize("D,with_nx", [(500, True), (52, False), (600, True)])
+def test_table_sweep_walking_egonets_is_bit_equal_to_node_per_wave(D, with_nx):
+    """txe_gat_aggregate_table_fwd on the egonet walk (gat_aggregate_ego_kernel<.., TAB>: rows T[rid[u]] + T2[pos[u]] formed from the
+    table inside the walk) against its wave-per-node kernel: `out` bit for bit, the next layer's logits within rounding -- a batch of
+    egonets for several window sizes, and a generic multigraph (every node on the kernel's generic path)"""
+    from taxoexpan_amd import _lib, graph as G
+    rs = np.random.RandomState(23)
+    dev = _dev()
+    H, vocab, n_tab = 4, 3, 300
+    F, Fe = H * D, H * D + 2 * H
+    Fp = -(-Fe // 32) * 32
+    kp = -(-(F + 50) // 32) * 32
+    shapes = [(int(rs.randint(0, 4)), int(rs.randint(0, 9))) for _ in range(700)]
+    shapes[3], shapes[4], shapes[5], shapes[6] = (40, 2), (0, 0), (1, 51), (63, 0)
+    graphs = {"egonets": _egonet_csr_for_walk(rs, shapes, dev)[:3]}
+    Ng = 1500
+    src, dst = rs.randint(0, Ng, 5000), rs.randint(5, Ng, 5000)
+    src[:150], dst[:150] = rs.randint(0, Ng, 150), 17
+    rin, col = G.build_csr_device(torch.from_numpy(src.astype(np.int32)).to(dev), torch.from_numpy(dst.astype(np.int32)).to(dev), Ng)[:2]
+    graphs["multigraph"] = (rin, col, Ng)
+    if _lib.call("txe_gat_aggregate_table_supported", H, D, Fp, vocab, kp if with_nx else 0) != 1:
+        pytest.skip("the T2 rows of this width do not fit the LDS")
+    T = torch.from_numpy(rs.standard_normal((n_tab, Fp)).astype(np.float32)).to(dev)
+    T2 = torch.from_numpy(rs.standard_normal((vocab, Fp)).astype(np.float32)).to(dev)
+    wa = torch.from_numpy(rs.standard_normal((2, kp)).astype(np.float32)).to(dev)
+    for gname, (rp, cl, N) in graphs.items():
+        rid = torch.from_numpy(rs.randint(0, n_tab, N).astype(np.int32)).to(dev)
+        pos = torch.from_numpy(rs.randint(0, vocab, N).astype(np.int32)).to(dev)
+        ld_out = kp if with_nx else F
+        outs = {}
+        for npw in (1, 3, 8, 13, 32):
+            out = torch.full((N, ld_out), 0.25, device=dev)
+            a12 = torch.zeros(N, 2, device=dev)
+            _lib.call("txe_gat_aggregate_table_fwd", rp.data_ptr(), cl.data_ptr(), N, T.data_ptr(), Fp, rid.data_ptr(), T2.data_ptr(),
+                      pos.data_ptr(), vocab, H, D, 0.2, 1, 0.1, out.data_ptr(), ld_out, wa.data_ptr() if with_nx else None, kp if with_nx else 0,
+                      a12.data_ptr() if with_nx else None, npw, _lib.stream_ptr())
+            torch.cuda.synchronize()
+            outs[npw] = (out.cpu().numpy(), a12.cpu().numpy())
+        assert np.isfinite(outs[1][0]).all() and np.abs(outs[1][0][:, :F]).max() > 0
+        for npw in (3, 8, 13, 32):
+            assert np.array_equal(outs[1][0], outs[npw][0]), (gname, npw, int((outs[1][0] != outs[npw][0]).sum()))
+            scale = np.abs(outs[1][1]).max() + 1e-6
+            assert np.abs(outs[npw][1] - outs[1][1]).max() <= 2e-6 * scale * np.sqrt(kp), (gname, npw)
+
+
 def test_readout_and_match_ops_against_oracle():
     from taxoexpan_amd import ops
     from taxoexpan_amd.graph import BatchedDGLGraph
@@ -1902,7 +1947,7 @@ def test_table_rows_formed_inside_the_sweep_equal_materialised_rows(H, D, with_n
         if table:
             _lib.call("txe_gat_aggregate_table_fwd", rin.data_ptr(), col.data_ptr(), N, T.data_ptr(), Fp, rid.data_ptr(), T2.data_ptr(),
                       pos.data_ptr(), vocab, H, D, 0.2, 1, 0.1, out.data_ptr(), ld_out, nx[0], nx[1], a12.data_ptr() if with_nx else None,
-                      _lib.stream_ptr())
+                      1, _lib.stream_ptr())
         else:
             Y = torch.empty(N, Fp, device=dev)
             _lib.call("txe_gather_add_rows", T.data_ptr(), Fp, rid.data_ptr(), T2.data_ptr(), Fp, pos.data_ptr(), N, Fp, Y.data_ptr(), Fp,

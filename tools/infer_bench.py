@@ -25,6 +25,8 @@ ap.add_argument("--profile", action="store_true", help="per-kernel HIP-event tim
 args = ap.parse_args()
 
 dev = torch.device("cuda:0")
+if os.environ.get("TXE_FWD_SWEEP"):                     # txe_gat_aggregate_*_fwd's npw argument (4 = one wave per node, 3 = the egonet walk)
+    ops._FWD_SWEEP = int(os.environ["TXE_FWD_SWEEP"])
 t0 = time.perf_counter()
 tax = syn.make_named_taxonomy(args.shape, seed=47)
 cand, val, test = syn.split_candidates(tax)

@@ -1292,7 +1292,10 @@ __global__ __launch_bounds__(256) void cl_zsum_kernel(const int* __restrict__ go
 // contiguous range: the wave streams it eight nodes (8 KB) per step and writes a graph's row of Z whenever the range crosses into
 // the next graph (offsets and weight sums of the chunk sit in lanes, read back as scalars: uniform control flow).  Per graph the same
 // nodes in the same order: bit-identical to cl_zsum_kernel.
-constexpr int ZS_GPW = 4;
+#ifndef TXE_ZS_GPW
+#define TXE_ZS_GPW 4
+#endif
+constexpr int ZS_GPW = TXE_ZS_GPW;
 // EDOT (the graph vector folded into a bilinear matcher): the gradient of Z will be dZ[g] = dsl_g Tf[zrow[g]] with Tf known NOW, so
 // the backward's <dZ[g], keep X[u]> sweep is this sweep's <Tf[zrow[g]], keep X[u]> times a scalar: the wave adds its tile's share of that
 // dot product per node to e_part[u][tile] (summed over the tiles, in tile order, by cl_fold_dc_kernel).
@@ -1370,16 +1373,29 @@ __global__ __launch_bounds__(256) void cl_zsum_chunk_kernel(const int* __restric
             // eight sums over the wave in 10 exchanges instead of 8 x 6: halve the set of values a lane carries with every exchange
             // (lane bit 5 picks nodes 0-3 / 4-7, bit 4 pairs, bit 3 one), then three plain butterflies; lane 8 n holds node n's sum
             static_assert(NU == 8, "the reduction below is written for eight nodes per step");
+            // (all on the VALU: v_permlane32_swap / v_permlane16_swap hand the half a lane does not keep to its partner 32 / 16 lanes away,
+            //  DPP row rotations and quad permutes do the rest -- __shfl_xor is ds_bpermute, a trip through the LDS pipeline per exchange;
+            //  same pairs added in the same order)
             float a4[4], b2[2];
             const bool h5 = (l & 32) != 0, h4 = (l & 16) != 0, h3 = (l & 8) != 0;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) a4[k] = (h5 ? pe[k + 4] : pe[k]) + __shfl_xor(h5 ? pe[k] : pe[k + 4], 32, 64);
+            for (int k = 0; k < 4; ++k) {
+                const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(pe[k]), __float_as_uint(pe[k + 4]), false, false);
+                a4[k] = h5 ? __uint_as_float(r[1]) + __uint_as_float(r[0]) : __uint_as_float(r[0]) + __uint_as_float(r[1]);
+            }
 #pragma unroll
-            for (int k = 0; k < 2; ++k) b2[k] = (h4 ? a4[k + 2] : a4[k]) + __shfl_xor(h4 ? a4[k] : a4[k + 2], 16, 64);
-            float c1 = (h3 ? b2[1] : b2[0]) + __shfl_xor(h3 ? b2[0] : b2[1], 8, 64);
-            c1 += __shfl_xor(c1, 4, 64);
-            c1 += __shfl_xor(c1, 2, 64);
-            c1 += __shfl_xor(c1, 1, 64);
+            for (int k = 0; k < 2; ++k) {
+                const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a4[k]), __float_as_uint(a4[k + 2]), false, false);
+                b2[k] = h4 ? __uint_as_float(r[1]) + __uint_as_float(r[0]) : __uint_as_float(r[0]) + __uint_as_float(r[1]);
+            }
+            float c1 = (h3 ? b2[1] : b2[0]) + dpp_f<0x128>(h3 ? b2[0] : b2[1]);          // row_ror:8 = lane ^ 8
+            {   // lane ^ 4: row_shl:4 for the lanes with bit 2 clear (banks 0, 2), row_shr:4 for the others
+                int o = __builtin_amdgcn_update_dpp(0, __float_as_int(c1), 0x104, 0xF, 0x5, false);
+                o = __builtin_amdgcn_update_dpp(o, __float_as_int(c1), 0x114, 0xF, 0xA, false);
+                c1 += __int_as_float(o);
+            }
+            c1 += dpp_f<0x4E>(c1);                                                       // quad_perm [2,3,0,1] = lane ^ 2
+            c1 += dpp_f<0xB1>(c1);                                                       // quad_perm [1,0,3,2] = lane ^ 1
             const int en = (h5 ? 4 : 0) + (h4 ? 2 : 0) + (h3 ? 1 : 0);
             if ((l & 7) == 0 && u0 + en < end) e_part[(long long)(u0 + en) * ntile + t] = c1;
         }
@@ -1388,7 +1404,7 @@ __global__ __launch_bounds__(256) void cl_zsum_chunk_kernel(const int* __restric
 }
 
 // launch of the Z sweep: small graphs (egonets: ~4 nodes) on the chunked kernel, large ones one wave per graph and tile
-static bool cl_zsum_chunked(int n_nodes, int G) { return (long long)n_nodes <= 16LL * G && G >= 4 * ZS_GPW; }
+static bool cl_zsum_chunked(int n_nodes, int G) { return (long long)n_nodes <= 16LL * G && G >= 16; }
 static int cl_zsum_launch(const int* graph_off, int G, int n_nodes, const float* X, int Kp, const unsigned* mk, const unsigned* dummy_mask,
                           int mask_ld, float fs, const float* coef, const float* wsum, float* Z, hipStream_t s, const float* Tf = nullptr,
                           const int* zrow = nullptr, float* e_part = nullptr) {

@@ -401,8 +401,15 @@ int txe_gat_collapse_bwd_fused(const int* rowptr_in, const int* col_src, const i
                                float attn_drop_p_p, unsigned long long seed_p, const float* alpha_p, float* d_Yp, long long ld_dyp,
                                int n_pad, float* dz_p, float* dW, float* d_attn_l, float* d_attn_r, float* dP, float* d_pw, int phases,
                                const float* dw_main, int dw_slices, const float* e_part, const float* m_ds, const float* m_s, int m_exp,
-                               const float* Tf, const int* zrow, int* zgid /* [N] scratch */, void* chain, void* ws, size_t ws_bytes,
-                               void* stream);
+                               const float* Tf, const int* zrow, int* zgid /* [N] scratch */, const int* walk_plan, void* chain, void* ws,
+                               size_t ws_bytes, void* stream);
+/* walk_plan (optional, NULL = none): the batch's plan from txe_egonet_walk_plan -- what the egonet-walking sweep otherwise works out from
+ * the CSR arrays in every workgroup of every step (hub, roles, CSR positions, list order of each graph) done once per batch of graphs:
+ * the sweep's staging is then two dependent trips instead of eight.  Same results bit for bit.  plan: txe_egonet_walk_plan_bytes(n_nodes)
+ * bytes, 16-byte aligned; depends on the graphs only (both CSR orders, graph offsets), valid as long as they are. */
+size_t txe_egonet_walk_plan_bytes(int n_nodes);
+int txe_egonet_walk_plan(const int* rowptr_in, const int* col_src, const int* rowptr_out, const int* col_dst, const int* pos_out,
+                         const int* graph_off, int n_nodes, int G, int* plan, void* stream);
 
 /* ---- output GCNLayer folded behind MeanReadout / WeightedMeanReadout: model_zoo.py:35-47,139-167,227-242.
  * hg[g] = (sum_{u in g} c_u Xd[u]) W + b with c_u = norm_u sum_{v: u->v} w_v norm_v / S_g (graph constants).  X / Wp / mask as for

@@ -1971,6 +1971,7 @@ struct FusedBwdArgs {
     // (the egonet-walking variant) the graphs themselves: destination CSR, graph offsets, node -> graph
     const int *rowptr_in, *col_src, *goff, *ggid; int G;
     float* hpart;                       // [workgroups][H*D]: a workgroup's share of d_ft[hub] for a graph whose hub lives in an earlier window
+    const int* plan;                    // [n_nodes][8] or NULL: the batch's walk plan (egonet_walk_plan_kernel): the shape checks done once
 };
 
 // Source nodes per workgroup of the fused sweep.  The kernel holds 3 workgroups per CU; its workgroups cost about (nodes + 6) each (LDS
@@ -2236,6 +2237,76 @@ enum { EGO_SKIP = 0, EGO_HUB = 1, EGO_PRE = 2, EGO_POST = 3, EGO_FOREIGN = 4 };
 // list position (local index t inside a hub-shaped graph with hub h) -> local node index
 __device__ __forceinline__ int ego_node_of(int t, int h) { return t == 0 ? h : (t <= h ? t - 1 : t); }
 
+// The walk plan of a batch: what the staging phases (1)-(3) of the kernel below work out per workgroup and step -- hub, roles, CSR
+// positions, the list order -- depends on the graphs alone, so it can be done ONCE per batch (it is a view of the graph like the two CSR
+// orders).  8 ints per LIST POSITION p: the node walked there, flags (role | walkable << 4 | at most EGO_MAXN nodes << 5), the destination
+// CSR positions of its self loop and of its edge with the hub, the graph's hub (node id), the graph's first position.  With a plan the
+// sweep's staging is two trips (plan; then the per-node scalars and the edge coefficients) instead of eight.  One wave per graph.
+constexpr int EGO_PLAN_W = 8;
+__global__ __launch_bounds__(256) void egonet_walk_plan_kernel(const int* __restrict__ rowptr_in, const int* __restrict__ col_src,
+                                                               const int* __restrict__ rowptr_out, const int* __restrict__ col_dst,
+                                                               const int* __restrict__ pos_out, const int* __restrict__ goff, const int G,
+                                                               int* __restrict__ plan) {
+    const int g = (int)(((long long)blockIdx.x * 256 + threadIdx.x) >> 6), l = threadIdx.x & 63;
+    if (g >= G) return;
+    const int o = goff[g], n = goff[g + 1] - o;
+    auto put = [&](int p, int node, int flags, int ps, int ph, int hub) {
+        int4* q = reinterpret_cast<int4*>(plan + (long long)p * EGO_PLAN_W);
+        q[0] = make_int4(node, flags, ps, ph);
+        q[1] = make_int4(hub, o, 0, 0);
+    };
+    if (n > EGO_MAXN) {                                             // never walked from registers: list position = node
+        for (int i = l; i < n; i += 64) put(o + i, o + i, EGO_SKIP, 0, 0, -1);
+        return;
+    }
+    if (n == 0) return;
+    const bool act = l < n;
+    const int v = o + (act ? l : 0);
+    const int e0 = rowptr_out[v], d = act ? rowptr_out[v + 1] - e0 : 0;
+    int tgt = -1;
+    if (d == 2) { const int d0 = col_dst[e0], d1 = col_dst[e0 + 1]; tgt = ((d0 == v) ? d1 : d0) - o; }
+    // the hub: THE node of out-degree >= 3, else the target of the first node of out-degree 2, else node 0 of a single-node graph
+    const unsigned long long mbig = __ballot(d >= 3), m2 = __ballot(d == 2);
+    int h = -1;
+    if (mbig != 0ull) h = __ffsll((long long)mbig) - 1;
+    else if (m2 != 0ull) h = __shfl(tgt, __ffsll((long long)m2) - 1, 64);
+    else if (n == 1) h = 0;
+    bool gok = __popcll(mbig) <= 1 && h >= 0 && h < n;
+    int role = EGO_SKIP, pself = -1, phub = -1;
+    if (gok) {
+        const int vh = o + h;
+        const int n_post = __popcll(__ballot(act && l != h && d == 1));
+        bool ok = true;
+        if (act) {
+            const int pi0 = rowptr_in[v], din = rowptr_in[v + 1] - pi0;
+            if (l == h) {                          // hub: itself in its in-list; out-degree = 1 + #siblings (the siblings check their side)
+                role = EGO_HUB;
+                for (int q = 0; q < din; ++q) if (col_src[pi0 + q] == v) pself = pi0 + q;
+                ok = pself >= 0 && d == 1 + n_post;
+                phub = pself;
+            } else if (d == 2) {                   // parent: out-list {self, hub}
+                role = EGO_PRE;
+                const int d0 = col_dst[e0], d1 = col_dst[e0 + 1];
+                if (d0 == v && d1 == vh) { pself = pos_out[e0]; phub = pos_out[e0 + 1]; }
+                else if (d1 == v && d0 == vh) { pself = pos_out[e0 + 1]; phub = pos_out[e0]; }
+                else ok = false;
+            } else if (d == 1) {                   // sibling: in-list {hub, self}; its one out-edge is then the self loop
+                role = EGO_POST;
+                if (din == 2) {
+                    const int s0 = col_src[pi0], s1 = col_src[pi0 + 1];
+                    if (s0 == v && s1 == vh) { pself = pi0; phub = pi0 + 1; }
+                    else if (s1 == v && s0 == vh) { pself = pi0 + 1; phub = pi0; }
+                    else ok = false;
+                } else ok = false;
+            } else ok = false;
+        }
+        gok = __ballot(act && !ok) == 0ull;
+    }
+    if (!act) return;
+    if (gok) put(o + ((l == h) ? 0 : (l < h ? l + 1 : l)), v, role | 16 | 32, max(pself, 0), max(phub, 0), o + h);
+    else put(o + l, v, EGO_SKIP | 32, 0, 0, -1);
+}
+
 #ifndef TXE_EGO_OCC
 #define TXE_EGO_OCC 3
 #endif
@@ -2264,17 +2335,58 @@ __global__ __launch_bounds__(256, (NI >= 3) ? 2 : TXE_EGO_OCC) void gat_fused_bw
     const int tid = threadIdx.x;
     // ---- the window of list positions and the graphs that intersect it ----
     const int u0 = b * a.npw, u1 = min(a.n_nodes, u0 + a.npw), nw = u1 - u0;   // (nw >= 1: the grid has ceil(n / npw) workgroups)
-    const int gF = a.ggid[u0], gL = a.ggid[u1 - 1], ng = gL - gF + 1;          // <= npw <= FB_NODES graphs
-    const int offF = a.goff[gF], endL = a.goff[gL + 1];
-    const int tb = (a.goff[gF + 1] - offF <= EGO_MAXN) ? offF : u0;           // first / one-past-last node with a staging entry
-    const int te = (endL - a.goff[gL] <= EGO_MAXN) ? endL : u1;                // (only the first and the last graph reach outside the window)
-    for (int i = tid; i < FB_NODES + 2; i += 256) { t_node[i] = u0; t_role[i] = EGO_SKIP; t_self[i] = 0; t_hub[i] = 0; t_dz[i] = 0; t_pos[i] = 0; t_cn[i] = 0.f; t_g1[i] = 0.f; t_g2[i] = 0.f; }
-    for (int i = tid; i < (FB_NODES + 2) * 8; i += 256) { t_coef[i >> 3][i & 7] = 0.f; t_fd[i >> 3][i & 7] = 0.f; }
+    __shared__ int t_ok[FB_NODES + 2], t_gs[FB_NODES + 2];                     // (with a plan) the position's graph is walked; its first position
+    const bool planned = a.plan != nullptr;
+    int gF = 0, gL = 0, ng = 0, offF = 0, endL = 0, tb = 0, te = 0;
+    if (!planned) {
+        gF = a.ggid[u0]; gL = a.ggid[u1 - 1]; ng = gL - gF + 1;                // <= npw <= FB_NODES graphs
+        offF = a.goff[gF]; endL = a.goff[gL + 1];
+        tb = (a.goff[gF + 1] - offF <= EGO_MAXN) ? offF : u0;                 // first / one-past-last node with a staging entry
+        te = (endL - a.goff[gL] <= EGO_MAXN) ? endL : u1;                      // (only the first and the last graph reach outside the window)
+    }
+    // (with a plan the entries 0..nw are written whole by the staging loop below: no barrier between defaults and values)
+    for (int i = tid; i < FB_NODES + 2; i += 256)
+        if (!planned || i > nw) { t_node[i] = u0; t_role[i] = EGO_SKIP; t_self[i] = 0; t_hub[i] = 0; t_dz[i] = 0; t_pos[i] = 0; t_cn[i] = 0.f; t_g1[i] = 0.f; t_g2[i] = 0.f; }
+    for (int i = tid; i < (FB_NODES + 2) * 8; i += 256)
+        if (!planned || (i >> 3) > nw) { t_coef[i >> 3][i & 7] = 0.f; t_fd[i >> 3][i & 7] = 0.f; }
     for (int i = tid; i < a.vocab * a.Pd; i += 256) s_dp[i] = 0.f;
     for (int i = tid * 4; i < 2 * Kp; i += 1024) {
         *reinterpret_cast<float4*>(s_wa + i) = *reinterpret_cast<const float4*>(a.wa + i);
         *reinterpret_cast<float4*>(s_acc + i) = make_float4(0.f, 0.f, 0.f, 0.f);
     }
+    bool owes_hpart = false;
+    if (planned) {
+        // ---- staging from the batch's walk plan: trip 1 = the plan entries (the window's first one with them: does the window start
+        //      inside a graph?), trip 2 = the nodes' scalars and the edge coefficients; one barrier ----
+        const int4 p0 = *reinterpret_cast<const int4*>(a.plan + (long long)u0 * EGO_PLAN_W);
+        const int4 p0b = *reinterpret_cast<const int4*>(a.plan + (long long)u0 * EGO_PLAN_W + 4);
+        for (int i = tid; i < (nw + 1) * 8; i += 256) {
+            const int t = i >> 3, e = (i >> 2) & 1, hd = i & 3;
+            const long long pp = (long long)(u0 + (t < nw ? t : 0)) * EGO_PLAN_W;
+            const int4 q = *reinterpret_cast<const int4*>(a.plan + pp);
+            const int4 qb = *reinterpret_cast<const int4*>(a.plan + pp + 4);
+            const bool foreign = p0b.y < u0 && (p0.y & 16) != 0;               // the window starts inside a graph that is walked
+            const int role = (t < nw) ? (q.y & 15) : (foreign ? EGO_FOREIGN : EGO_SKIP);
+            const int v = (role == EGO_SKIP) ? u0 : ((t < nw) ? q.x : qb.x);
+            float fd = 0.f, cf = 0.f;
+            if (role != EGO_SKIP) {
+                const long long idx = (long long)(e ? q.w : q.z) * a.H + hd;   // (a foreign hub's coefficients are never used)
+                fd = (a.drop_p > 0.f) ? drop_factor(a.seed, (unsigned long long)idx, a.drop_p, a.drop_scale) : 1.f;
+                cf = (t < nw) ? a.alpha[idx] * fd : 0.f;
+            }
+            t_fd[t][i & 7] = fd;
+            t_coef[t][i & 7] = cf;
+            if ((i & 7) == 0) {
+                const bool live = role != EGO_SKIP;
+                t_ok[t] = (q.y >> 4) & 1; t_gs[t] = qb.y;
+                t_node[t] = v; t_role[t] = role; t_self[t] = live ? q.z : 0; t_hub[t] = live ? q.w : 0;
+                t_dz[t] = live ? a.gid[v] : 0; t_pos[t] = live ? a.pos[v] : 0;
+                t_cn[t] = live ? a.cn[v] : 0.f; t_g1[t] = live ? a.da1[v] : 0.f; t_g2[t] = live ? a.da2[v] : 0.f;
+            }
+        }
+        owes_hpart = p0b.y < u0 && (p0.y & 32) != 0;                           // (a graph of at most EGO_MAXN nodes, walked or not)
+        __syncthreads();
+    } else {
     if (ng > FB_NODES) {
         // more graphs than positions in the window: it holds EMPTY graphs (an egonet has at least its anchor) -- not a batch of egonets;
         // every source node of the window through the generic body, and the row a fix-up pass may read cleared
@@ -2384,6 +2496,8 @@ __global__ __launch_bounds__(256, (NI >= 3) ? 2 : TXE_EGO_OCC) void gat_fused_bw
     }
     __syncthreads();
 
+    }   // (!planned)
+
     const int w = uni((int)(tid >> 6)), l = tid & 63;
     const int F = a.H * a.D, SL = F >> 2, nvec = SL >> 2;
     const int c0 = w * SL, hw = c0 / a.D;
@@ -2407,7 +2521,7 @@ __global__ __launch_bounds__(256, (NI >= 3) ? 2 : TXE_EGO_OCC) void gat_fused_bw
     bool hub_home = true;
     // a window that starts inside a graph of <= EGO_MAXN nodes owes the fix-up pass a row hpart[b]: its share of the hub's d_ft, or
     // zeros if the graph turned out not to be hub-shaped (fused_hub_fixup_job repeats only the cheap half of the shape check)
-    const bool owes_hpart = u0 > offF && (a.goff[gF + 1] - offF <= EGO_MAXN);
+    if (!planned) owes_hpart = u0 > offF && (a.goff[gF + 1] - offF <= EGO_MAXN);
     bool paid_hpart = false;
     auto flush_hub = [&]() {
         if (hub_node >= 0) {
@@ -2550,9 +2664,18 @@ __global__ __launch_bounds__(256, (NI >= 3) ? 2 : TXE_EGO_OCC) void gat_fused_bw
             if (l + 64 * i < nvec) vstore<4>(a.hpart + (long long)b * F + off[i], z);
     }
     // ---- graphs that are not hub-shaped (or too large): the generic body over their source nodes inside the window ----
-    for (int gi = 0; gi < ng; ++gi) {
+    for (int gi = 0, tp = 0; planned ? tp < nw : gi < ng; ++gi) {
+        int c, cu1;
+        if (planned) {                                               // the next stretch of positions of ONE graph that is not walked
+            if (t_ok[tp]) { ++tp; continue; }                        // (LDS values: the same for every thread)
+            const int gs = t_gs[tp];
+            c = u0 + tp;
+            while (tp < nw && !t_ok[tp] && t_gs[tp] == gs) ++tp;
+            cu1 = u0 + tp;
+        } else {
         if (g_ok[gi]) continue;                                      // (LDS value: the same for every thread)
-        const int c = max(u0, a.goff[gF + gi]), cu1 = min(u1, a.goff[gF + gi + 1]);
+        c = max(u0, a.goff[gF + gi]); cu1 = min(u1, a.goff[gF + gi + 1]);
+        }
         __syncthreads();
         if (tid < cu1 - c) {
             const int u = c + tid;
@@ -3009,6 +3132,20 @@ static FusedWs plan_fused_ws(void* ws, int n, int e, int G, int Kh, int Kp, int 
 
 extern "C" {
 
+// The walk plan of a batch of graphs for the egonet-walking sweeps (egonet_walk_plan_kernel): 8 ints per node.
+size_t txe_egonet_walk_plan_bytes(int n_nodes) { return (size_t)(n_nodes > 0 ? n_nodes : 1) * EGO_PLAN_W * sizeof(int); }
+int txe_egonet_walk_plan(const int* rowptr_in, const int* col_src, const int* rowptr_out, const int* col_dst, const int* pos_out,
+                         const int* graph_off, int n_nodes, int G, int* plan, void* stream) {
+    if (n_nodes < 0 || G < 0 || !plan || (n_nodes > 0 && (!rowptr_in || !col_src || !rowptr_out || !col_dst || !pos_out || !graph_off))) return TXE_ERR_ARG;
+    if (((uintptr_t)plan & 15) != 0) return TXE_ERR_ARG;
+    if (n_nodes == 0 || G == 0) return TXE_OK;
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof("egonet_walk_plan_kernel", s, 4.0 * (6.0 * n_nodes + EGO_PLAN_W * (double)n_nodes), 1);
+    hipLaunchKernelGGL(egonet_walk_plan_kernel, dim3((G + 3) / 4), dim3(256), 0, s, rowptr_in, col_src, rowptr_out, col_dst, pos_out, graph_off, G, plan);
+    TXE_CHECK_LAUNCH();
+    return TXE_OK;
+}
+
 // 1 when txe_gat_collapse_bwd_fused supports the shape: the previous layer has 1, 2 or 4 heads, its H*D columns are a multiple of 16
 // and at most 4096, and the folded layer's input has at most 128 columns behind them.
 int txe_gat_fused_bwd_supported(int Kh, int Pd, int Hp, int Dp) {
@@ -3038,7 +3175,8 @@ int txe_gat_collapse_bwd_fused(const int* rowptr_in, const int* col_src, const i
                                float attn_drop_p_p, unsigned long long seed_p, const float* alpha_p, float* d_Yp, long long ld_dyp,
                                int n_pad, float* dz_p, float* dW, float* d_attn_l, float* d_attn_r, float* dP, float* d_pw, int phases,
                                const float* dw_main, int dw_slices, const float* e_part, const float* m_ds, const float* m_s, int m_exp,
-                               const float* Tf, const int* zrow, int* zgid, void* chain, void* ws, size_t ws_bytes, void* stream) {
+                               const float* Tf, const int* zrow, int* zgid, const int* walk_plan, void* chain, void* ws, size_t ws_bytes,
+                               void* stream) {
     // phases | 512 (with | 256): the <dZ, X> sweep was done in forward (txe_gat_collapse_fwd's e_part); m_ds / m_s [G]: the folded matcher's
     // score gradient and scores, m_exp: it exponentiates -- see cl_fold_dc_kernel
     // phases | 256: `d_hg` IS dZ [G][Kp] (ld_dhg its row pitch) -- whoever consumed Z folded hg = Z W^T into its own product
@@ -3123,6 +3261,7 @@ int txe_gat_collapse_bwd_fused(const int* rowptr_in, const int* col_src, const i
             a.d_Y = d_Yp; a.ld_dy = ld_dyp; a.dal = fw.dal; a.dwa_part = fw.dwa_part; a.ppart = fw.ppart;
             a.npw = fw.npw;
             a.rowptr_in = rowptr_in; a.col_src = col_src; a.goff = graph_off; a.ggid = gid; a.G = G; a.hpart = fw.hpart;
+            a.plan = walk_plan;
             const int nvec = F / 16, ni = (nvec + 63) / 64, nwh = 4 / Hp;
             // algorithmic bytes: read X' (own row + once per out-edge is an L2 matter), dZ, Y; write d_Y
             char name[64];

@@ -51,6 +51,7 @@ _NO_QUERY_RUNS = False      # stacked query rows always take the GEMM form of th
 _NO_SPLIT_GEMM = False      # the first layer's projection on the fp32 MFMA instead of the bf16 pipe's six plane products
 _NO_TAIL_CHAIN = False      # every layer's last reduction launch in place instead of chained into the bottom layer's
 _FWD_SWEEP = 0              # txe_gat_aggregate_fwd's npw argument (0 = chosen from the batch; tools/kt_quick.py sets others)
+_NO_WALK_PLAN = False       # the egonet-walking backward sweep works the graphs' shapes out of the CSR arrays in every workgroup (no per-batch plan)
 _NO_EGO_WALK = False        # the forward sweep runs one wave per node and the fused backward sweep fetches X'[v] per out-edge, instead of walking egonets
 _I32_MEMO = {}       # id(source tensor) -> (weakref, version, device, int32 copy): `pos` is converted once per batch, not once per module
 
@@ -573,6 +574,24 @@ class FoldLink:
         self.fwd, self.e_part, self.m = None, None, None
 
 
+def walk_plan(csr):
+    """the batch's plan for the egonet-walking sweeps (txe_egonet_walk_plan): a view of the graphs like the two CSR orders, built once per
+    batch -- by the first backward pass that wants it, or by the loader that built the batch -- and kept on the CSR object"""
+    key = id(csr.rowptr_in)                               # (the CSR views are cached on their graph: one tensor object per batch)
+    ent = _WALK_PLANS.get(key)
+    if ent is not None and ent[0]() is csr.rowptr_in:
+        return ent[1]
+    N = csr.n_nodes
+    plan = torch.empty(pure("txe_egonet_walk_plan_bytes", N) // 4, dtype=torch.int32, device=csr.rowptr_in.device)
+    call("txe_egonet_walk_plan", ptr(csr.rowptr_in), ptr(csr.col_src), ptr(csr.rowptr_out), ptr(csr.col_dst), ptr(csr.pos_out),
+         ptr(csr.graph_off), N, csr.n_graphs, ptr(plan), _lib.stream_ptr())
+    _WALK_PLANS[key] = (weakref.ref(csr.rowptr_in, lambda _ref, key=key: _WALK_PLANS.pop(key, None)), plan)   # (the plan dies with its graph)
+    return plan
+
+
+_WALK_PLANS = {}       # id of a CSR's rowptr_in tensor -> (weak reference to it, the plan)
+
+
 def _gat_collapse_bwd_fused(csr, st, sp, pos, rpos, pw, vocab, feat_p, attn_p, attn_slope, d_hg, act_slope, chain=None, link=None):
     """txe_gat_collapse_bwd_fused: the folded layer's parameter gradients AND the layer below's d_Y in one sweep (no d_X).
     link given: d_hg IS dZ [G, Kp] (the consumer of Z folded hg = Z W^T into its own products, FoldLink)."""
@@ -603,8 +622,9 @@ def _gat_collapse_bwd_fused(csr, st, sp, pos, rpos, pw, vocab, feat_p, attn_p, a
              ptr(d_pw), phases | (512 if edot else 0) | (1024 if _NO_EGO_WALK else 0), ptr(link.part) if (link is not None and link.S > 0) else None,
              link.S if link is not None else 0, *((ptr(link.e_part), ptr(link.m[0]), ptr(link.m[1]), int(link.m[2]), ptr(link.fwd["T"]),
                                                   ptr(link.fwd["run_id"]), ptr(zgid)) if edot else (None, None, None, 0, None, None, None)),
-             chain.ptr if chain is not None else None, ptr(ws), wsb, _lib.stream_ptr())
+             ptr(plan), chain.ptr if chain is not None else None, ptr(ws), wsb, _lib.stream_ptr())
     zgid = torch.empty(max(N, 1), dtype=torch.int32, device=st.X.device) if edot else None
+    plan = walk_plan(csr) if (sp.H == 4 and not _NO_EGO_WALK and not _NO_WALK_PLAN) else None
     last = 8 | (64 if chain is not None else 0)     # (with a chain the final reductions are left to the bottom layer's launch)
     if chain is not None:
         chain.keep += [ws, d_hg, st, sp, zgid] + ([link.part, link.fwd, link.m] if link is not None else [])

@@ -181,7 +181,9 @@ def test_forward_egonet_walk_matches_reference_goldens(name, monkeypatch):
                                          ("_NO_FUSED_LOGITS", "small_pgat_2layer"), ("_NO_TAIL_CHAIN", "small_pgat_2layer"),
                                          # four heads under the folded layer: the egonet-walking sweep (windows cut the larger egonets:
                                          # foreign hubs, hpart rows, the fix-up pass) against the per-out-edge sweep
-                                         ("_NO_EGO_WALK", "mag_pgat_wmr_lbm_q8x32"), ("_NO_EGO_WALK", "semeval_pgat_wmr_bim_q8x32")])
+                                         ("_NO_EGO_WALK", "mag_pgat_wmr_lbm_q8x32"), ("_NO_EGO_WALK", "semeval_pgat_wmr_bim_q8x32"),
+                                         # the backward walk staged from the batch's plan against staging from the CSR arrays
+                                         ("_NO_WALK_PLAN", "mag_pgat_wmr_lbm_q8x32"), ("_NO_WALK_PLAN", "semeval_pgat_wmr_bim_q8x32")])
 def test_ab_switch_routes_give_the_same_training_step(switch, case, monkeypatch):
     """every route attribute of ops.py selects another ROUTE to the same numbers: a training step (dropout on, fixed seed) with the switch
     set against the default -- scores and every gradient (the per-layer preparation entry once left the stored-dropped flag of its

@@ -10,6 +10,9 @@ from taxoexpan_amd.optim import Adam
 wl = sys.argv[1] if len(sys.argv) > 1 else "pgat"
 top = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 dev = torch.device("cuda:0")
+if os.environ.get("TXE_NO_WALK_PLAN", "0") == "1":
+    from taxoexpan_amd import ops as _o
+    _o._NO_WALK_PLAN = True
 if os.environ.get("TXE_FWD_SWEEP"):
     from taxoexpan_amd import ops
     ops._FWD_SWEEP = int(os.environ["TXE_FWD_SWEEP"])

@@ -168,12 +168,15 @@ def finish_device_batch(pending, features):
             from .ops import RepeatedRows
             qt = features.index_select(0, packed[2 * B:2 * B + U])
             qf = RepeatedRows(qt, packed[3 * B:3 * B + U + 1], B)
+        from . import ops
+        # the batch's walk plan (a view of its graphs like the CSR orders; the backward sweep of a four-head stack stages from it)
+        plan = ops.walk_plan(g.csr(dev)) if not (ops._NO_EGO_WALK or ops._NO_WALK_PLAN) else None
     if side is not main:
         main.wait_stream(side)
         csr = g.csr(dev)
         packed.record_stream(main)
         for t in (x, qt, g.ndata["_id"], g.ndata["pos"], csr.rowptr_in, csr.col_src, csr.eid_in, csr.rowptr_out, csr.col_dst, csr.pos_out,
-                  csr.graph_off):
+                  csr.graph_off) + ((plan,) if plan is not None else ()):
             t.record_stream(main)
     return dict(g=g, x=x, pos=g.ndata["pos"], qf=qf, n_nodes=g.number_of_nodes(), n_edges=g.number_of_edges())
 

@@ -752,6 +752,57 @@ def test_table_sweep_walking_egonets_is_bit_equal_to_node_per_wave(D, with_nx):
             assert np.abs(outs[npw][1] - outs[1][1]).max() <= 2e-6 * scale * np.sqrt(kp), (gname, npw)
 
 
+def test_walk_plan_of_a_batch_names_hub_roles_and_csr_positions():
+    """txe_egonet_walk_plan (what the egonet-walking sweeps otherwise work out per workgroup and step) on a batch of egonets -- list order
+    anchor, parents, siblings; roles; the destination-CSR positions of every node's self loop and of its edge with the anchor -- and on
+    graphs that are no egonets (not walked: list position = node)"""
+    from taxoexpan_amd import _lib
+    from taxoexpan_amd.graph import BatchedDGLGraph, DGLGraph, batch
+    rs = np.random.RandomState(5)
+    dev = _dev()
+    shapes = [(int(rs.randint(0, 4)), int(rs.randint(0, 9))) for _ in range(300)]
+    shapes[3], shapes[4], shapes[5], shapes[6] = (40, 2), (0, 0), (1, 51), (62, 1)
+    g = BatchedDGLGraph.from_egonet_shapes([s_[0] for s_ in shapes], [s_[1] for s_ in shapes])
+    others = []
+    for n in (5, 70, 9):                                        # a ring, a graph of more than 64 nodes, two hubs
+        h = DGLGraph(); h.add_nodes(n)
+        h.add_edges(np.arange(n), (np.arange(n) + 1) % n)
+        if n == 9: h.add_edges(np.array([0, 0, 0, 1, 1, 1]), np.array([2, 3, 4, 5, 6, 7]))
+        h.add_edges(h.nodes(), h.nodes())
+        others.append(h)
+    for graph, egonets in ((g, True), (batch(others), False)):
+        csr = graph.csr(dev)
+        N, G = csr.n_nodes, csr.n_graphs
+        plan = torch.full((_lib.call("txe_egonet_walk_plan_bytes", N) // 4,), -7, dtype=torch.int32, device=dev)
+        _lib.call("txe_egonet_walk_plan", csr.rowptr_in.data_ptr(), csr.col_src.data_ptr(), csr.rowptr_out.data_ptr(), csr.col_dst.data_ptr(),
+                  csr.pos_out.data_ptr(), csr.graph_off.data_ptr(), N, G, plan.data_ptr(), _lib.stream_ptr())
+        torch.cuda.synchronize()
+        P = plan.cpu().numpy().reshape(N, 8)
+        goff = csr.graph_off.cpu().numpy()
+        src = csr.col_src.cpu().numpy()
+        dst = np.repeat(np.arange(N), np.diff(csr.rowptr_in.cpu().numpy()))
+        for gi in range(G):
+            o, n = int(goff[gi]), int(goff[gi + 1] - goff[gi])
+            rows = P[o:o + n]
+            assert (rows[:, 5] == o).all()
+            if not egonets:
+                assert (rows[:, 0] == np.arange(o, o + n)).all() and ((rows[:, 1] & 31) == 0).all()      # not walked, no role
+                assert ((rows[:, 1] & 32) != 0).all() == (n <= 64)
+                continue
+            k, m = shapes[gi]
+            if (k, m) == (0, 1): k, m = 1, 0                    # (anchor -> one sibling IS parent -> anchor: the walk takes the second reading)
+            anchor = o + k
+            assert list(rows[:, 0]) == [anchor] + list(range(o, anchor)) + list(range(anchor + 1, o + n)), gi
+            assert (rows[:, 1] >> 4 == 3).all() and (rows[:, 4] == anchor).all()
+            assert list(rows[:, 1] & 15) == [1] + [2] * k + [3] * m
+            for node, fl, ps, ph in rows[:, :4]:
+                assert src[ps] == node and dst[ps] == node
+                role = fl & 15
+                if role == 1: assert ph == ps
+                elif role == 2: assert src[ph] == node and dst[ph] == anchor
+                else: assert src[ph] == anchor and dst[ph] == node
+
+
 def test_readout_and_match_ops_against_oracle():
     from taxoexpan_amd import ops
     from taxoexpan_amd.graph import BatchedDGLGraph

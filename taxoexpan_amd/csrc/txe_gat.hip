@@ -621,11 +621,7 @@ __global__ __launch_bounds__(256, (NI >= 3) ? 3 : TXE_EF_OCC) void gat_aggregate
         bad = s_bad != 0;
     }
 
-#if defined(TXE_EF_X) && TXE_EF_X == 1
-    if (false) {
-#else
     if (!bad) {
-#endif
         float acc[NI][4], hub[NI][4];
 #pragma unroll
         for (int i = 0; i < NI; ++i)

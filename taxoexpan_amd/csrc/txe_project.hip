@@ -2559,21 +2559,6 @@ __global__ __launch_bounds__(256, (NI >= 3) ? 2 : TXE_EGO_OCC) void gat_fused_bw
             vload<4>(a.dZ + (long long)dzr * Kp + tc, dzt[q]);
             mt[q] = fb_keep<MASK>(a.mask, a.mask_ld, vv[q], tc);
         }
-#if defined(TXE_EGO_X) && TXE_EGO_X == 1
-#pragma unroll
-        for (int q = 0; q < NS; ++q) {
-            if (role[q] == EGO_SKIP || role[q] == EGO_FOREIGN) continue;
-            float acc[NI][4];
-#pragma unroll
-            for (int i = 0; i < NI; ++i)
-#pragma unroll
-                for (int k = 0; k < 4; ++k) acc[i][k] = ft[q][i][k] + xv[q][i][k] + dz[q][i][k] + xt[q][k] + dzt[q][k] + cfs[q] + cfh[q] + (float)(mv[q][i] + mt[q]);
-#pragma unroll
-            for (int i = 0; i < NI; ++i)
-                if (l + 64 * i < nvec) vstore<4>(a.d_Y + (long long)vv[q] * a.ld_dy + off[i], acc[i]);
-        }
-        continue;
-#endif
 #pragma unroll
         for (int q = 0; q < NS; ++q) {
             if (role[q] == EGO_SKIP) continue;                        // (wave-uniform)

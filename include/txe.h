@@ -101,6 +101,13 @@ size_t txe_gat_dense_split_ws_bytes(int n_nodes, int Kh, int Pd, int H, int D);
 size_t txe_gat_dense_split_xt_bytes(int n_nodes, int Kh, int Pd, int H, int D);
 int txe_gat_dense_fwd_split(const float* X, int n_nodes, int Kh, int Pd, const float* Wp, int H, int D, const void* Xs, const void* Ws,
                             void* Xt_out, float* Y, void* ws, size_t ws_bytes, void* stream);
+/* ... for a FIRST layer whose input X = dropout([h | Emb[pos]]) (model_zoo.py:82,213-214) is never stored: the packs form its elements
+ * from h [N][ld_h], the position table P [vocab][Pd] / pos [N] and the keep mask (NULL or feat_drop_p == 0: no dropout) -- the same
+ * planes as packing the stored X, bit for bit.  txe_gat_layers_prepare with desc.X == NULL then writes mask and weights only, and
+ * txe_gat_dense_bwd takes X == NULL with Xt (no act_on).  ws: txe_gat_dense_split_ws_bytes. */
+int txe_gat_dense_fwd_split_src(const float* h, long long ld_h, const int* pos, const float* P, const unsigned* mask, float feat_drop_p,
+                                int n_nodes, int Kh, int Pd, const float* Wp, int H, int D, void* Xt_out, float* Y, void* ws, size_t ws_bytes,
+                                void* stream);
 int txe_gat_dense_bwd(const float* X, int n_nodes, int Kh, int Pd, const int* pos, int vocab, const float* Wp, const float* W,
                       const float* attn_l, const float* attn_r, int H, int D, float feat_drop_p, const unsigned* mask, const float* d_Y,
                       int need_dh, int act_on, float act_slope, float* d_X, float* dW, float* d_attn_l, float* d_attn_r, float* dP,

@@ -99,6 +99,7 @@ SIGNATURES = {
     "txe_gat_collapse_bwd_fused_ws_bytes": (SZ, [I, I, I, I, I, I, I, I]),
     "txe_gat_collapse_bwd_fused": (I, [P, P, P, P, P, P, I, I, I, P, I, I, P, I, P, P, P, P, I, F, P, F, F, U64, P, P, P, P, P, P, P, P, L, P, L,
                                        F, P, L, I, I, F, F, U64, P, P, L, I, P, P, P, P, P, P, I, P, I, P, P, P, I, P, P, P, P, P, P, SZ, P]),
+    "txe_gat_dense_fwd_split_src": (I, [P, L, P, P, P, F, I, I, I, P, I, I, P, P, P, SZ, P]),
     "txe_egonet_walk_plan_bytes": (SZ, [I]),
     "txe_egonet_walk_plan": (I, [P, P, P, P, P, P, I, I, P, P]),
     "txe_gcn_collapse_ws_bytes": (SZ, [I, I, I, I, I, I]),

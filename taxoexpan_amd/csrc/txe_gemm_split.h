@@ -145,8 +145,10 @@ int gemm_nt_split_launch(const void* Ap, const void* Bp, int M, int N, int K, fl
 int split_pack_t_launch(const float* src, long long ld, int rows, int cols, void* packed, hipStream_t stream);
 struct Epi;
 int gemm_nt_split_epi_launch(const void* Ap, const void* Bp, const Epi& E, int M, int N, int K, hipStream_t stream);
+// X given by its sources instead of stored (split_pack_job): [h | Emb[pos]] with the feature dropout of mask (NULL: none) applied
+struct SplitVSrc { const float* h; long long ld_h; const int* pos; const float* P; int Kh, Pd; const unsigned* mask; int wpr; float scale; };
 int split_pack_layer_launch(const float* X, long long ldx, int n, const float* W, long long ldw, int f, int K, int Kt_cols, void* Xs, void* Ws,
-                            void* Xt, hipStream_t stream);
+                            void* Xt, hipStream_t stream, const SplitVSrc* vs = nullptr);
 // part[z][M][ldc] = A[rows of slice z]^T B[rows of slice z], z < S, slices of ksplit rows (a multiple of 16)
 int gemm_tn_split_launch(const float* A, long long lda, int M, const void* Bt, int N, int n_rows, int S, int ksplit, float* part, long long ldc,
                          long long split_stride, double alg_flops, hipStream_t stream);

@@ -11,7 +11,62 @@ typedef __attribute__((ext_vector_type(16))) float f32x16s;
 
 // ---- packing: fp32 [rows][ld] -> three bf16 planes in fragment order --------------------------------------------------------------
 // one thread per (fragment block rb, k-tile kt, lane): reads 8 consecutive floats of its slot's row, writes 16 bytes per plane
-struct SplitPackArgs { const float* src; long long ld; int rows, cols, side, nrb, nkt; uint4* dst; int transposed; };
+// A first GATLayer's input NEVER WRITTEN: element (row, c) of X = dropout([h | Emb[pos]]) formed where it is packed --
+//   c < Kh: h[row][c];  Kh <= c < Kh + Pd: P[pos[row]][c - Kh];  beyond: 0;  times keep(mask word (row, c / 32), bit c % 32) * scale
+// -- the arithmetic of build_x_job (txe_project.hip), so the planes are those of the stored X bit for bit.  h == NULL: the matrix at src.
+// (struct SplitVSrc: txe_gemm_split.h)
+// NC consecutive columns c0 .. c0 + NC - 1 (c0 a multiple of NC, NC | 32: one mask word per row) of R rows.  The kind of column range
+// is decided ONCE, outside the row loops, and every load of a kind is issued before the first use (a branch between a load and its
+// use costs a full round trip per row: csrc/txe_gather.h).
+template <int NC, int R>
+__device__ __forceinline__ void vsrc_load_rows(const SplitVSrc& v, const int (&row)[R], const int c0, float (&x)[R][NC]) {
+    unsigned word[R];
+    const bool masked = v.mask != nullptr && c0 < v.wpr * 32;
+#pragma unroll
+    for (int r = 0; r < R; ++r) word[r] = masked ? v.mask[(long long)row[r] * v.wpr + (c0 >> 5)] : 0xFFFFFFFFu;
+    if (c0 + NC <= v.Kh) {                                           // feature columns
+        const bool two = (NC & 1) == 0 && ((reinterpret_cast<uintptr_t>(v.h + c0) & 7) == 0) && (v.ld_h & 1) == 0;
+        if (two) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const float* hr = v.h + (long long)row[r] * v.ld_h + c0;
+#pragma unroll
+                for (int q = 0; q + 1 < NC; q += 2) { const float2 t = *reinterpret_cast<const float2*>(hr + q); x[r][q] = t.x; x[r][q + 1] = t.y; }
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+#pragma unroll
+                for (int q = 0; q < NC; ++q) x[r][q] = v.h[(long long)row[r] * v.ld_h + c0 + q];
+        }
+    } else if (c0 >= v.Kh + v.Pd) {                                  // zero padding columns
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int q = 0; q < NC; ++q) x[r][q] = 0.f;
+        return;
+    } else {                                                         // position columns, or the range that straddles Kh
+        int pr[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) pr[r] = (v.Pd > 0) ? v.pos[row[r]] : 0;
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int q = 0; q < NC; ++q) {
+                const int c = c0 + q;
+                const float hv = v.h[(long long)row[r] * v.ld_h + min(c, v.Kh - 1)];
+                const float pv = (v.Pd > 0) ? v.P[(long long)pr[r] * v.Pd + min(max(c - v.Kh, 0), v.Pd - 1)] : 0.f;
+                x[r][q] = (c < v.Kh) ? hv : ((c < v.Kh + v.Pd) ? pv : 0.f);
+            }
+    }
+    if (masked) {
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int q = 0; q < NC; ++q) x[r][q] = ((word[r] >> ((c0 & 31) + q)) & 1u) ? x[r][q] * v.scale : 0.f;
+    }
+}
+struct SplitPackArgs { const float* src; long long ld; int rows, cols, side, nrb, nkt; uint4* dst; int transposed; SplitVSrc v; };
 __device__ __forceinline__ void split_pack_job(const SplitPackArgs& a, const int bid, const int nb) {
     const float* __restrict__ src = a.src;
     uint4* __restrict__ dst = a.dst;
@@ -26,7 +81,15 @@ __device__ __forceinline__ void split_pack_job(const SplitPackArgs& a, const int
         float x[8];
 #pragma unroll
         for (int q = 0; q < 8; ++q) x[q] = 0.f;
-        if (a.transposed) {                                // element (row, k) = src[k][row]: an operand given as its transpose
+        if (a.v.h != nullptr) {
+            if (row < rows) {
+                const int r1[1] = {row};
+                float x1[1][8];
+                vsrc_load_rows<8, 1>(a.v, r1, k0, x1);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) x[q] = x1[0][q];
+            }
+        } else if (a.transposed) {                         // element (row, k) = src[k][row]: an operand given as its transpose
             if (row < rows) {
 #pragma unroll
                 for (int q = 0; q < 8; ++q)
@@ -315,7 +378,7 @@ __global__ __launch_bounds__(256, MINB) void gemm_nt_split_kernel(const SplitGem
 
 // ---- side 2 packing: fp32 [rows][ld] -> contraction-major planes (txe_gemm_split.h) ------------------------------------------------
 // one thread per (row tile nt, column tile h, lane): 8 rows x (4 + 1) columns -> five fragments' lane words per plane
-struct SplitPackTArgs { const float* src; long long ld; int rows, cols, nht, nnt; uint4* dst; };
+struct SplitPackTArgs { const float* src; long long ld; int rows, cols, nht, nnt; uint4* dst; SplitVSrc v; };
 __device__ __forceinline__ void split_pack_t_job(const SplitPackTArgs& a, const int bid, const int nb) {
     const float* __restrict__ src = a.src;
     uint4* __restrict__ dst = a.dst;
@@ -332,12 +395,23 @@ __device__ __forceinline__ void split_pack_t_job(const SplitPackTArgs& a, const 
         float o[8];
         const int c4 = min(160 * h + 4 * s, a.cols - 4), c1 = min(160 * h + 128 + s, a.cols - 1);   // (clamped; zeroed below)
         const bool ok4 = 160 * h + 4 * s + 3 < a.cols, ok1 = 160 * h + 128 + s < a.cols;
+        if (a.v.h != nullptr) {
+            int rr[8];
+            float t4[8][4], t1[8][1];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) rr[r] = min(n0 + r, rows - 1);
+            vsrc_load_rows<4, 8>(a.v, rr, c4, t4);
+            vsrc_load_rows<1, 8>(a.v, rr, c1, t1);
+#pragma unroll
+            for (int r = 0; r < 8; ++r) { q[r] = make_float4(t4[r][0], t4[r][1], t4[r][2], t4[r][3]); o[r] = t1[r][0]; }
+        } else {
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
             const int row = min(n0 + r, rows - 1);
             const float* p = src + (long long)row * ld;
             q[r] = *reinterpret_cast<const float4*>(p + c4);
             o[r] = p[c1];
+        }
         }
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
@@ -562,6 +636,7 @@ static bool fill_pack(SplitPackArgs& a, int& nb, const float* src, long long ld,
     const int tr = side >> 1;                             // sides 2, 3 = sides 0, 1 of a matrix given as its transpose [cols][ld >= rows]
     if (!src || !packed || rows < 1 || cols < 1 || ld < (tr ? rows : cols) || side < 0 || side > 3) return false;
     a.src = src; a.ld = ld; a.rows = rows; a.cols = cols; a.side = side & 1; a.dst = (uint4*)packed; a.transposed = tr;
+    memset(&a.v, 0, sizeof(a.v));                         // (a stored matrix; split_pack_layer_launch sets the sources of an unstored X)
     a.nrb = ((rows + 767) / 768) * 24; a.nkt = (cols + SPL_KT - 1) / SPL_KT;
     const long long total = (long long)a.nrb * a.nkt * 64;
     nb = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
@@ -571,6 +646,7 @@ static bool fill_pack_t(SplitPackTArgs& a, int& nb, const float* src, long long 
     if (!src || !packed || rows < 1 || cols < 4 || cols % 4 != 0 || ld < cols || (ld & 3) != 0 || (reinterpret_cast<uintptr_t>(src) & 15) != 0)
         return false;
     a.src = src; a.ld = ld; a.rows = rows; a.cols = cols; a.nht = (cols + 159) / 160; a.nnt = (rows + 15) / 16; a.dst = (uint4*)packed;
+    memset(&a.v, 0, sizeof(a.v));
     const long long total = (long long)a.nnt * a.nht * 64;
     nb = (int)((total + 255) / 256);
     return true;
@@ -587,11 +663,15 @@ int split_pack_launch(const float* src, long long ld, int rows, int cols, int si
 // X [n][ldx] -> Xs (side 0) and, Xt != NULL, Xt (side 2); W [f][ldw] -> Ws (side 1): one launch
 // (K columns for the NT operands, Kt_cols -- a multiple of 160 -- for the contraction-major one)
 int split_pack_layer_launch(const float* X, long long ldx, int n, const float* W, long long ldw, int f, int K, int Kt_cols, void* Xs, void* Ws,
-                            void* Xt, hipStream_t stream) {
+                            void* Xt, hipStream_t stream, const SplitVSrc* vs) {
     SplitPackMulti m;
     memset(&m, 0, sizeof(m));
+    // (vs: X is not stored -- its elements are formed from vs; the fill functions still want a readable 16-byte aligned address)
+    if (vs && (!vs->h || vs->Kh < 1 || vs->Pd < 0 || vs->ld_h < vs->Kh || (vs->Pd > 0 && (!vs->pos || !vs->P)) || (vs->mask && vs->wpr < 1))) return TXE_ERR_ARG;
+    if (vs) X = reinterpret_cast<const float*>(W);
     if (!fill_pack(m.a[0], m.nb[0], X, ldx, n, K, 0, Xs) || !fill_pack(m.a[1], m.nb[1], W, ldw, f, K, 1, Ws)) return TXE_ERR_ARG;
     if (Xt && !fill_pack_t(m.t, m.nb[2], X, ldx, n, Kt_cols, Xt)) return TXE_ERR_ARG;
+    if (vs) { m.a[0].v = *vs; m.t.v = *vs; }
     ProfScope prof("split_pack_multi_kernel", stream, 10.0 * K * ((Xt ? 2.0 : 1.0) * n + f), 1);
     hipLaunchKernelGGL(split_pack_multi_kernel, dim3(m.nb[0] + m.nb[1] + m.nb[2]), dim3(256), 0, stream, m);
     TXE_CHECK_LAUNCH();

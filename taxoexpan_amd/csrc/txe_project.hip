@@ -680,14 +680,15 @@ __global__ __launch_bounds__(64 * FOLD_DG) void gat_prepare_multi_kernel(const P
 //  against 138 us on the 1.1 M-node inference batch; the deeper layers' preparation on the second stream under the first
 //  projection GEMM: the step unchanged -- its workgroups crawl beside the persistent GEMM's and that GEMM loses what was gained)
 static int fill_prep(PrepArgs& a, const txe_gat_prepare_desc& d) {
-    if (d.n_nodes < 0 || d.Kh < 1 || d.Pd < 0 || !d.X || (d.Pd > 0 && (!d.pos || !d.P)) || !d.W || !d.attn_l || !d.attn_r || !d.Wp || d.H < 1 ||
+    // (X == NULL: the layer's input is not stored -- txe_gat_dense_fwd_split_src forms it from h; mask and weights are still written)
+    if (d.n_nodes < 0 || d.Kh < 1 || d.Pd < 0 || (!d.X && !d.h) || (d.Pd > 0 && (!d.pos || !d.P)) || !d.W || !d.attn_l || !d.attn_r || !d.Wp || d.H < 1 ||
         d.D < 1 || d.feat_drop_p < 0.f || d.feat_drop_p >= 1.f || (d.feat_drop_p > 0.f && !d.mask))
         return TXE_ERR_ARG;
     const int T = 64 * FOLD_DG;
     a.Kt = d.Kh + d.Pd; a.Kp = round_up(a.Kt, 32);
     a.F = d.H * d.D; a.Fe = a.F + 2 * d.H; a.Fp = round_up(a.Fe, 128);
     auto blocks = [&](long long n, int cap) { const long long b = (n + T - 1) / T; return (int)(b < cap ? b : cap); };
-    const long long nx = (long long)d.n_nodes * (a.Kp - (d.h ? 0 : d.Kh));
+    const long long nx = d.X ? (long long)d.n_nodes * (a.Kp - (d.h ? 0 : d.Kh)) : 0;
     a.seed = d.seed; a.thr16 = (unsigned)(d.feat_drop_p * 65536.0f + 0.5f); a.mask = d.mask;
     a.x_dropped = (d.x_dropped && d.feat_drop_p > 0.f && a.thr16 != 0u) ? 1 : 0;
     a.x_mask = (a.x_dropped && d.h != nullptr && nx > 0) ? 1 : 0;     // build_x hashes every word of its rows anyway: it writes the mask
@@ -907,6 +908,29 @@ int txe_gat_dense_fwd_split(const float* X, int n_nodes, int Kh, int Pd, const f
     return TXE_OK;
 }
 
+// The same product for a FIRST layer whose input X = dropout([h | Emb[pos]]) is never stored: the packs form its elements from h, the
+// position table and the keep mask (txe_gat_layers_prepare with X == NULL writes mask and weights only) -- one 23-MB write and two reads
+// of it less per step on the training batch.  mask == NULL or feat_drop_p == 0: no dropout.
+int txe_gat_dense_fwd_split_src(const float* h, long long ld_h, const int* pos, const float* P, const unsigned* mask, float feat_drop_p,
+                                int n_nodes, int Kh, int Pd, const float* Wp, int H, int D, void* Xt_out, float* Y, void* ws, size_t ws_bytes,
+                                void* stream) {
+    if (n_nodes < 0 || Kh < 1 || Pd < 0 || H < 1 || D < 1 || !Y || !h || !Wp || ld_h < Kh || (Pd > 0 && (!pos || !P)) || feat_drop_p < 0.f ||
+        feat_drop_p >= 1.f || (feat_drop_p > 0.f && !mask))
+        return TXE_ERR_ARG;
+    if (n_nodes == 0) return TXE_OK;
+    const int Fe = H * D + 2 * H, Fp = round_up(Fe, 128), Kp = round_up(Kh + Pd, 32);
+    hipStream_t s = (hipStream_t)stream;
+    char* w = (char*)ws;
+    if (Xt_out && !split_tn_eligible(Fp, Kp)) return TXE_ERR_ARG;
+    const int Kc = round_up(Kh + Pd, 16);
+    const size_t ba = align_up(split_packed_bytes(n_nodes, Kp), 256), bb = align_up(split_packed_bytes(Fp, Kp), 256);
+    if (!ws || ws_bytes < ba + bb) return TXE_ERR_WORKSPACE;
+    SplitVSrc vs{h, ld_h, pos, P, Kh, Pd, feat_drop_p > 0.f ? mask : nullptr, (Kh + Pd + 31) / 32, 1.f / (1.f - feat_drop_p)};
+    int rc = split_pack_layer_launch(nullptr, Kp, n_nodes, Wp, Kp, Fp, Kc, Kp, w, w + ba, Xt_out, s, &vs);
+    if (rc) return rc;
+    return gemm_nt_split_launch(w, w + ba, n_nodes, Fe, Kc, Y, Fp, 2.0 * n_nodes * (double)Fe * (Kh + Pd), s);
+}
+
 // Backward of txe_gat_dense_fwd.  d_Y [N][Fp] must have ZERO padding columns [F+2H, Fp).
 //   d_X [N][Kp]: columns [c0, Kt) are written, c0 = 0 if need_dh else the 32-aligned start of the position columns;
 //                columns < Kh are multiplied by leaky'(X) when act_slope_on (X[:, :Kh] is then the activated output of the
@@ -919,7 +943,8 @@ int txe_gat_dense_bwd(const float* X, int n_nodes, int Kh, int Pd, const int* po
                       const float* attn_l, const float* attn_r, int H, int D, float feat_drop_p, const unsigned* mask, const float* d_Y,
                       int need_dh, int act_on, float act_slope, float* d_X, float* dW, float* d_attn_l, float* d_attn_r, float* dP,
                       int x_dropped, const void* Xt, int phases, void* chain, void* ws, size_t ws_bytes, void* stream) {
-    if (n_nodes < 0 || Kh < 1 || Pd < 0 || H < 1 || D < 1 || !X || !Wp || !W || !attn_l || !attn_r || !d_Y || !dW || !d_attn_l || !d_attn_r || !ws)
+    // (X == NULL: a first layer whose input was never stored, txe_gat_dense_fwd_split_src -- its weight gradient needs Xt then)
+    if (n_nodes < 0 || Kh < 1 || Pd < 0 || H < 1 || D < 1 || (!X && (!Xt || act_on)) || !Wp || !W || !attn_l || !attn_r || !d_Y || !dW || !d_attn_l || !d_attn_r || !ws)
         return TXE_ERR_ARG;
     static_assert(sizeof(TailChain) <= TXE_TAIL_CHAIN_BYTES, "txe.h: TXE_TAIL_CHAIN_BYTES");
     if ((need_dh || Pd > 0) && !d_X) return TXE_ERR_ARG;
@@ -992,6 +1017,7 @@ int txe_gat_dense_bwd(const float* X, int n_nodes, int Kh, int Pd, const int* po
         rc = gemm_tn_split_launch(d_Y, Fp, Fp, Xt, Kp, n_nodes, splits, ks, p.part, Kp, E.split_stride, E.alg_flops, s);
         if (rc) return rc;
     } else if (phases & 2) {
+        if (!X) return TXE_ERR_ARG;
         rc = gemm_tn(A, B, E, Fp, Kp, n_nodes, splits, s);
         if (rc) return rc;
     }

@@ -51,6 +51,7 @@ _NO_QUERY_RUNS = False      # stacked query rows always take the GEMM form of th
 _NO_SPLIT_GEMM = False      # the first layer's projection on the fp32 MFMA instead of the bf16 pipe's six plane products
 _NO_TAIL_CHAIN = False      # every layer's last reduction launch in place instead of chained into the bottom layer's
 _FWD_SWEEP = 0              # txe_gat_aggregate_fwd's npw argument (0 = chosen from the batch; tools/kt_quick.py sets others)
+_NO_VIRTUAL_X = False       # a first layer's input X = dropout([h | Emb[pos]]) is written by the preparation launch and read back by the packs
 _NO_WALK_PLAN = False       # the egonet-walking backward sweep works the graphs' shapes out of the CSR arrays in every workgroup (no per-batch plan)
 _NO_EGO_WALK = False        # the forward sweep runs one wave per node and the fused backward sweep fetches X'[v] per out-edge, instead of walking egonets
 _I32_MEMO = {}       # id(source tensor) -> (weakref, version, device, int32 copy): `pos` is converted once per batch, not once per module
@@ -336,7 +337,18 @@ def _tail_ws(ref):
 
 
 class _GatLayerState:
-    __slots__ = ("X", "Wp", "mask", "Y", "alpha", "W", "al", "ar", "P", "Kh", "Pd", "Kp", "Fp", "H", "D", "seed", "cl", "prepared", "x_dropped", "Xt")
+    __slots__ = ("X", "Wp", "mask", "Y", "alpha", "W", "al", "ar", "P", "Kh", "Pd", "Kp", "Fp", "H", "D", "seed", "cl", "prepared", "x_dropped", "Xt",
+                 "vx")      # vx: X is NOT stored (a first layer on the bf16 pipe: the packs form dropout([h | Emb[pos]]) themselves)
+
+
+def _virtual_x_ok(st, h, ld_h, N, need, first_is_folded):
+    """may a FIRST layer's input stay unwritten?  Its only readers must be the two packs of the bf16-pipe products: the projection
+    (txe_gat_dense_fwd_split_src) and, with a backward pass to come, the weight gradient's contraction-major form (Xt)."""
+    if _NO_SPLIT_GEMM or _NO_VIRTUAL_X or first_is_folded or N == 0 or not torch.is_tensor(h) or h.dtype != torch.float32:
+        return False
+    if pure("txe_gat_dense_split_ws_bytes", N, st.Kh, st.Pd, st.H, st.D) == 0:
+        return False
+    return (not need) or pure("txe_gat_dense_split_xt_bytes", N, st.Kh, st.Pd, st.H, st.D) > 0
 
 
 def _x_dropped_ok(cfg, states, l, collapse):
@@ -359,9 +371,10 @@ def _gat_layers_prepare(items, feat_p):
     descs = (_lib.GatPrepareDesc * len(items))()
     for d, (st, h, ld_h, pos, dropped) in zip(descs, items):
         N = st.X.shape[0]
+        st.vx = getattr(st, "vx", False)
         st.Wp = _empty((st.Fp, st.Kp), st.X)
         st.mask = torch.empty((N, (st.Kh + st.Pd + 31) // 32), dtype=torch.int32, device=st.X.device) if feat_p > 0.0 else None
-        d.h, d.ld_h, d.n_nodes, d.Kh, d.pos, d.P, d.Pd, d.X = ptr(h), ld_h, N, st.Kh, ptr(pos), ptr(st.P), st.Pd, ptr(st.X)
+        d.h, d.ld_h, d.n_nodes, d.Kh, d.pos, d.P, d.Pd, d.X = ptr(h), ld_h, N, st.Kh, ptr(pos), ptr(st.P), st.Pd, (None if st.vx else ptr(st.X))
         d.W, d.attn_l, d.attn_r, d.H, d.D, d.Wp = ptr(st.W), ptr(st.al), ptr(st.ar), st.H, st.D, ptr(st.Wp)
         d.feat_drop_p, d.seed, d.mask = feat_p, st.seed, ptr(st.mask)
         st.x_dropped = bool(dropped and feat_p > 0.0)
@@ -468,7 +481,11 @@ def _gat_layer_fwd(csr, st, h, ld_h, pos, out, ld_out, feat_p, attn_p, attn_slop
             sws = _ws(wsb, st.X)
             xtb = pure("txe_gat_dense_split_xt_bytes", N, Kh, Pd, H, D) if save else 0
             st.Xt = _ws(xtb, st.X) if xtb else None        # X packed contraction-major: the backward pass's weight gradient reads it
-            call("txe_gat_dense_fwd_split", ptr(st.X), N, Kh, Pd, ptr(st.Wp), H, D, None, None, ptr(st.Xt), ptr(st.Y), ptr(sws), wsb, s)
+            if getattr(st, "vx", False):                   # X was never written: the packs read h, the position table and the mask
+                call("txe_gat_dense_fwd_split_src", ptr(h), ld_h, ptr(pos), ptr(st.P), ptr(st.mask), feat_p if st.mask is not None else 0.0,
+                     N, Kh, Pd, ptr(st.Wp), H, D, ptr(st.Xt), ptr(st.Y), ptr(sws), wsb, s)
+            else:
+                call("txe_gat_dense_fwd_split", ptr(st.X), N, Kh, Pd, ptr(st.Wp), H, D, None, None, ptr(st.Xt), ptr(st.Y), ptr(sws), wsb, s)
             note_route("proj", "bf16x6")
         else:
             call("txe_gat_dense_fwd", ptr(st.X), N, Kh, Pd, ptr(st.Wp), H, D, 0.0 if dropped else feat_p, None if dropped else ptr(st.mask), ptr(st.Y),
@@ -521,7 +538,7 @@ def _gat_dense_bwd(st, pos, vocab, feat_p, d_Y, need_dh, act_on, act_slope, chai
         wsb += pure("txe_gat_dense_bwd_split_ws_bytes", N, st.Kh, st.Pd, st.H, st.D)
     ws = _ws(wsb, st.X)
     def run(phases):
-        call("txe_gat_dense_bwd", ptr(st.X), N, st.Kh, st.Pd, ptr(pos), vocab, ptr(st.Wp), ptr(st.W), ptr(st.al), ptr(st.ar), st.H, st.D, feat_p,
+        call("txe_gat_dense_bwd", None if getattr(st, "vx", False) else ptr(st.X), N, st.Kh, st.Pd, ptr(pos), vocab, ptr(st.Wp), ptr(st.W), ptr(st.al), ptr(st.ar), st.H, st.D, feat_p,
              ptr(st.mask), ptr(d_Y), int(need_dh), int(act_on), act_slope if act_slope else 1.0, ptr(d_X), ptr(dW), ptr(dal), ptr(dar),
              ptr(dP), int(getattr(st, "x_dropped", False)), ptr(getattr(st, "Xt", None)), phases, chain.ptr if chain is not None else None, ptr(ws), wsb, _lib.stream_ptr())
     # (a first PGAT layer's d_X -- position columns only -- is one HBM stream over d_Y, txe_dxpos.hip; every other d_X is a GEMM)
@@ -698,6 +715,7 @@ class GATStackFunction(torch.autograd.Function):
                     states[l].X = _empty((N, states[l].Kp), h)
                 # (a layer that is not the folded one: only its GEMMs read X, so X is stored with the dropout applied -- by the
                 #  preparation (raw features, position columns) and by the aggregation of the layer below (_drops_output))
+                states[0].vx = (not table) and _virtual_x_ok(states[0], src, ld_h, N, need, collapse and L == 1)
                 _gat_layers_prepare([(st, (src if l == 0 else None), (ld_h if l == 0 else 0), pos if st.P is not None else None,
                                       _x_dropped_ok(cfg, states, l, collapse))
                                      for l, st in enumerate(states) if not (table and l == 0)], cfg.feat_p)

@@ -26,7 +26,8 @@ def _has_gpu():
 _ROUTES = {"no_fold": ("model_zoo", "_NO_FOLD"), "no_fused_bwd": ("ops", "_NO_FUSED_BWD"), "no_fused_logits": ("ops", "_NO_FUSED_LOGITS"),
            "no_side_stream": ("ops", "_NO_SIDE_STREAM"), "no_table_sweep": ("ops", "_NO_TABLE_SWEEP"), "no_query_runs": ("ops", "_NO_QUERY_RUNS"), "no_tail_chain": ("ops", "_NO_TAIL_CHAIN"), "no_match_fold": ("ops", "_NO_MATCH_FOLD"), "no_fold_edot": ("ops", "_NO_FOLD_EDOT"),
            "no_split_gemm": ("ops", "_NO_SPLIT_GEMM"), "no_ego_walk": ("ops", "_NO_EGO_WALK"),
-           "no_walk_plan": ("ops", "_NO_WALK_PLAN")}
+           "no_walk_plan": ("ops", "_NO_WALK_PLAN"),
+           "no_virtual_x": ("ops", "_NO_VIRTUAL_X")}
 # tests OF a route that the setting removes (they look into the folded output layer's buffers)
 _ROUTE_TESTS = {
     "no_fold": ("test_fused_backward_sweep_equals_unfused_chain", "test_collapsed_output_layer_equals_unfused_path",

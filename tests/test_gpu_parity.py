@@ -183,7 +183,10 @@ def test_forward_egonet_walk_matches_reference_goldens(name, monkeypatch):
                                          # foreign hubs, hpart rows, the fix-up pass) against the per-out-edge sweep
                                          ("_NO_EGO_WALK", "mag_pgat_wmr_lbm_q8x32"), ("_NO_EGO_WALK", "semeval_pgat_wmr_bim_q8x32"),
                                          # the backward walk staged from the batch's plan against staging from the CSR arrays
-                                         ("_NO_WALK_PLAN", "mag_pgat_wmr_lbm_q8x32"), ("_NO_WALK_PLAN", "semeval_pgat_wmr_bim_q8x32")])
+                                         ("_NO_WALK_PLAN", "mag_pgat_wmr_lbm_q8x32"), ("_NO_WALK_PLAN", "semeval_pgat_wmr_bim_q8x32"),
+                                         # the first layer's input never stored (the packs form it) against the stored one
+                                         ("_NO_VIRTUAL_X", "mag_pgat_wmr_lbm_q8x32"), ("_NO_VIRTUAL_X", "small_pgat_2layer"),
+                                         ("_NO_VIRTUAL_X", "semeval_pgat_wmr_bim_q8x32")])
 def test_ab_switch_routes_give_the_same_training_step(switch, case, monkeypatch):
     """every route attribute of ops.py selects another ROUTE to the same numbers: a training step (dropout on, fixed seed) with the switch
     set against the default -- scores and every gradient (the per-layer preparation entry once left the stored-dropped flag of its
@@ -205,6 +208,9 @@ def test_ab_switch_routes_give_the_same_training_step(switch, case, monkeypatch)
         torch.cuda.synchronize()
         outs.append((s.detach().cpu().numpy(), xg.grad.cpu().numpy(), {k: p.grad.cpu().numpy() for k, p in model.named_parameters()}))
     assert np.isfinite(outs[1][0]).all()
+    if switch == "_NO_VIRTUAL_X":      # the same planes reach the same products: bit for bit
+        assert np.array_equal(outs[1][0], outs[0][0]) and np.array_equal(outs[1][1], outs[0][1])
+        assert all(np.array_equal(outs[1][2][k], outs[0][2][k]) for k in outs[0][2])
     np.testing.assert_allclose(outs[1][0], outs[0][0], rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(outs[1][1], outs[0][1], rtol=1e-4, atol=1e-6)
     for k in outs[0][2]:
@@ -801,6 +807,57 @@ def test_walk_plan_of_a_batch_names_hub_roles_and_csr_positions():
                 if role == 1: assert ph == ps
                 elif role == 2: assert src[ph] == node and dst[ph] == anchor
                 else: assert src[ph] == anchor and dst[ph] == node
+
+
+@pytest.mark.parametrize("N,Kh,ld_h,Pd,p,H,D", [(517, 250, 250, 50, 0.3, 4, 500), (33, 10, 10, 4, 0.3, 2, 6), (301, 251, 253, 50, 0.1, 4, 24),
+                                                   (64, 96, 96, 0, 0.5, 2, 60), (129, 300, 300, 50, 0.0, 4, 600), (1, 250, 250, 50, 0.5, 4, 500)])
+def test_first_layer_input_formed_inside_the_packs_equals_the_stored_one(N, Kh, ld_h, Pd, p, H, D):
+    """txe_gat_dense_fwd_split_src (X = dropout([h | Emb[pos]]) never stored: the packs form it from h, the position table and the keep
+    mask that txe_gat_layers_prepare writes with X == NULL) against txe_gat_layers_prepare + txe_gat_dense_fwd_split on the stored X:
+    the same mask and weights, Y and the contraction-major planes (the backward pass's Xt) bit for bit -- 8-byte and 4-byte feature
+    rows, a width whose last quad straddles Kh, no position columns, no dropout, a single row"""
+    import ctypes
+    from taxoexpan_amd import _lib
+    dev = _dev()
+    rs = np.random.RandomState(7 + Kh + N)
+    seed = 9876543210
+    Kt = Kh + Pd
+    Kp, Fp = _lib.call("txe_gat_padded_k", Kh, Pd), _lib.call("txe_gat_padded_f", H, D)
+    wsb = _lib.call("txe_gat_dense_split_ws_bytes", N, Kh, Pd, H, D)
+    xtb = _lib.call("txe_gat_dense_split_xt_bytes", N, Kh, Pd, H, D)
+    assert wsb > 0 and xtb > 0
+    h = torch.from_numpy(rs.standard_normal((N, ld_h)).astype(np.float32)).to(dev)
+    pos = torch.from_numpy(rs.randint(0, 3, N).astype(np.int32)).to(dev)
+    P = torch.from_numpy(rs.standard_normal((3, max(Pd, 1))).astype(np.float32)).to(dev)[:, :Pd].contiguous() if Pd else None
+    W = torch.from_numpy(rs.standard_normal((H * D, Kt)).astype(np.float32)).to(dev)
+    al, ar = (torch.from_numpy(rs.standard_normal((1, H, D)).astype(np.float32)).to(dev) for _ in range(2))
+    ptr = lambda t: t.data_ptr() if t is not None else None
+    outs = []
+    for stored in (True, False):
+        X = torch.full((N, Kp), 7.0, device=dev)
+        Wp = torch.full((Fp, Kp), 7.0, device=dev)
+        mask = torch.zeros((N, (Kt + 31) // 32), dtype=torch.int32, device=dev) if p > 0 else None
+        d = (_lib.GatPrepareDesc * 1)()
+        d[0].h, d[0].ld_h, d[0].n_nodes, d[0].Kh, d[0].pos, d[0].P, d[0].Pd = h.data_ptr(), ld_h, N, Kh, ptr(pos) if Pd else None, ptr(P), Pd
+        d[0].X, d[0].W, d[0].attn_l, d[0].attn_r, d[0].H, d[0].D, d[0].Wp = (X.data_ptr() if stored else None), W.data_ptr(), al.data_ptr(), ar.data_ptr(), H, D, Wp.data_ptr()
+        d[0].feat_drop_p, d[0].seed, d[0].mask, d[0].x_dropped = p, seed, ptr(mask), 1
+        _lib.call("txe_gat_layers_prepare", ctypes.cast(d, ctypes.c_void_p), 1, _lib.stream_ptr())
+        Y = torch.full((N, Fp), -3.0, device=dev)
+        ws = torch.zeros(wsb, dtype=torch.uint8, device=dev)
+        Xt = torch.zeros(xtb, dtype=torch.uint8, device=dev)
+        if stored:
+            _lib.call("txe_gat_dense_fwd_split", X.data_ptr(), N, Kh, Pd, Wp.data_ptr(), H, D, None, None, Xt.data_ptr(), Y.data_ptr(), ws.data_ptr(), wsb,
+                      _lib.stream_ptr())
+        else:
+            _lib.call("txe_gat_dense_fwd_split_src", h.data_ptr(), ld_h, ptr(pos) if Pd else None, ptr(P), ptr(mask), p, N, Kh, Pd, Wp.data_ptr(), H, D,
+                      Xt.data_ptr(), Y.data_ptr(), ws.data_ptr(), wsb, _lib.stream_ptr())
+            assert float((X - 7.0).abs().max()) == 0.0                     # never written
+        torch.cuda.synchronize()
+        outs.append((Y.cpu(), Xt.cpu(), Wp.cpu(), mask.cpu() if mask is not None else None))
+    (Ya, Xta, Wpa, ma), (Yb, Xtb_, Wpb, mb) = outs
+    assert torch.equal(Wpa, Wpb) and (ma is None or torch.equal(ma, mb))
+    assert torch.equal(Ya[:, :H * D + 2 * H], Yb[:, :H * D + 2 * H]) and bool(torch.isfinite(Ya[:, :H * D + 2 * H]).all())
+    assert torch.equal(Xta, Xtb_)
 
 
 def test_readout_and_match_ops_against_oracle():

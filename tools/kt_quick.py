@@ -13,6 +13,9 @@ dev = torch.device("cuda:0")
 if os.environ.get("TXE_NO_WALK_PLAN", "0") == "1":
     from taxoexpan_amd import ops as _o
     _o._NO_WALK_PLAN = True
+if os.environ.get("TXE_NO_VIRTUAL_X", "0") == "1":
+    from taxoexpan_amd import ops as _o2
+    _o2._NO_VIRTUAL_X = True
 if os.environ.get("TXE_FWD_SWEEP"):
     from taxoexpan_amd import ops
     ops._FWD_SWEEP = int(os.environ["TXE_FWD_SWEEP"])
